@@ -1,0 +1,389 @@
+"""oracle/ast_ref.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+CPU restatement (NumPy, float64 or float32) of the reference's encoder-decoder
+training hot path, executed the way Chainer-on-NumPy executes it: one Python
+iteration per time step and per layer, one GEMM per Linear, the per-step
+concat growth kept, conv via im2col + GEMM, a define-by-run reverse pass, and a
+per-parameter decay -> clip -> AMSGrad update.
+
+Follows (file:line under /root/reference):
+  seq2seq.py:35-156   parameter set / initialisers        -> init_params
+  seq2seq.py:158-180  forward_cnn                         -> RefModel.forward_cnn
+  seq2seq.py:182-242  reset / feed_rnn / forward_rnn_encode (quirk Q1 kept) -> feed_rnn, forward_rnn_encode
+  seq2seq.py:293-314  encode (+ multiplicative speech noise)
+  seq2seq.py:318-333  init_decoder_state
+  seq2seq.py:336-357  compute_context_vector (unmasked softmax over time, Q2)
+  seq2seq.py:361-396  decode_step (input feeding)
+  seq2seq.py:399-473  forward_loss (teacher forcing Q4, CE denominator Q6)
+  seq2seq.py:475-527  predict (greedy)
+  nn.py:81-119        optimizer + hook order              -> RefOptimizer
+  nn.py:168-194       train step and reported loss (Q5)   -> train_step
+
+PARITY UNPINNED (see oracle/minichainer.py header and DESIGN.md): no reference
+test vectors exist and Chainer is not runnable here.
+"""
+import random as _pyrandom
+import numpy as np
+
+from . import minichainer as F
+from .minichainer import Variable, Parameter
+
+PAD_ID, GO_ID, EOS_ID, UNK_ID = 0, 1, 2, 3      # dataloader.py:26-36
+
+
+# --------------------------------------------------------------------------- shapes
+def conv_out(n, k, s, p):
+    return (n + 2 * p - k) // s + 1                # A3, cover_all=False
+
+
+def cnn_out_dims(cnn_layers, T, D):
+    """(T'', F', C_last) after the conv stack."""
+    c = 1
+    for l in cnn_layers:
+        kh, kw = l["ksize"]
+        sy, sx = l["stride"]
+        ph, pw = l["pad"]
+        T, D, c = conv_out(T, kh, sy, ph), conv_out(D, kw, sx, pw), l["out_channels"]
+    return T, D, c
+
+
+# --------------------------------------------------------------------------- parameters
+def init_params(cfg, in_dim, vocab_size=None, seed=0, dtype=np.float32):
+    """Reference initialisers (A9): conv HeNormal, Linear/LSTM LeCunNormal, forget bias 1,
+    EmbedID N(0,1), BN gamma=1 beta=0.  Names follow Chainer's save_npz keys (A10)."""
+    rng = np.random.default_rng(seed)
+    rc, cc = cfg["rnn_config"], cfg["cnn_config"]
+    V = vocab_size if vocab_size is not None else rc["dec_vocab_size"]
+    P = {}
+
+    def normal(shape, std):
+        return (rng.standard_normal(shape) * std).astype(dtype)
+
+    cin, fdim = 1, in_dim
+    for i, l in enumerate(cc["cnn_layers"]):
+        kh, kw = l["ksize"]
+        co = l["out_channels"]
+        P[f"CNN_{i}/W"] = normal((co, cin, kh, kw), np.sqrt(2.0 / (cin * kh * kw)))
+        if cc["bn"]:
+            P[f"CNN_{i}_bn/gamma"] = np.ones(co, dtype)
+            P[f"CNN_{i}_bn/beta"] = np.zeros(co, dtype)
+            P[f"CNN_{i}_bn/avg_mean"] = np.zeros(co, dtype)
+            P[f"CNN_{i}_bn/avg_var"] = np.ones(co, dtype)
+        else:
+            P[f"CNN_{i}/b"] = np.zeros(co, dtype)
+        fdim = conv_out(fdim, kw, l["stride"][1], l["pad"][1])
+        cin = co
+    rnn_in = cin * fdim
+
+    def lstm_params(name, n_in, n_out):
+        P[f"{name}/upward/W"] = normal((4 * n_out, n_in), np.sqrt(1.0 / n_in))
+        b = np.zeros(4 * n_out, dtype)
+        b[2::4] = 1                                 # forget gate entries b[4j+2] (A9)
+        P[f"{name}/upward/b"] = b
+        P[f"{name}/lateral/W"] = normal((4 * n_out, n_out), np.sqrt(1.0 / n_out))
+
+    Hh = rc["hidden_units"] // 2 if rc["bi_rnn"] else rc["hidden_units"]
+    stacks = ["L{}_enc"] + (["L{}_rev_enc"] if rc["bi_rnn"] else [])
+    for pat in stacks:
+        n_in = rnn_in
+        for i in range(rc["enc_layers"]):
+            lstm_params(pat.format(i), n_in, Hh)
+            n_in = Hh
+    H, E, A = rc["hidden_units"], rc["embedding_units"], rc["attn_units"]
+    n_attn = rc.get("n_attn", 1)
+    P["attn_Wa/W"] = normal((H, H), np.sqrt(1.0 / H))
+    P["attn_Wa/b"] = np.zeros(H, dtype)
+    P["context/W"] = normal((A, (n_attn + 1) * H), np.sqrt(1.0 / ((n_attn + 1) * H)))
+    P["context/b"] = np.zeros(A, dtype)
+    P["embed_dec/W"] = normal((V, E), 1.0)
+    feed = rc.get("feed_attn", True)
+    n_in = E + A if feed else E
+    for i in range(rc["dec_layers"]):
+        lstm_params(f"L{i}_dec", n_in, H)
+        n_in = H
+    P["out/W"] = normal((V, A), np.sqrt(1.0 / A))
+    P["out/b"] = np.zeros(V, dtype)
+    return P
+
+
+PERSISTENT = ("avg_mean", "avg_var")               # not optimised, saved by save_npz (A10)
+
+
+def is_trainable(name):
+    return not name.endswith(PERSISTENT)
+
+
+# --------------------------------------------------------------------------- mask sources
+class NoMasks:
+    def __call__(self, shape, ratio, tag):
+        raise RuntimeError("dropout requested but no mask source given")
+
+
+class RecordingMasks:
+    """Draws dropout masks from a seeded generator and records them by tag so the identical
+    masks can be injected into the HIP path (Q7: the reference's masks are unseeded)."""
+
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+        self.masks = {}
+
+    def __call__(self, shape, ratio, tag):
+        keep = self.rng.random(shape) >= ratio      # A5: mask = rand >= ratio
+        m = keep.astype(np.float32) / np.float32(1.0 - ratio)
+        self.masks[tag] = m
+        return m
+
+
+# --------------------------------------------------------------------------- the model
+class RefModel:
+    def __init__(self, cfg, params, vocab_size=None):
+        self.cfg = cfg
+        rc = cfg["rnn_config"]
+        self.V = vocab_size if vocab_size is not None else rc["dec_vocab_size"]
+        self.p = {k: (Parameter(v, name=k) if is_trainable(k) else v) for k, v in params.items()}
+        self.dtype = params["out/W"].dtype
+        self.bi = rc["bi_rnn"]
+        self.n_enc, self.n_dec = rc["enc_layers"], rc["dec_layers"]
+        self.n_attn = rc.get("n_attn", 1)
+        self.feed_attn = rc.get("feed_attn", True)
+        assert not rc.get("ln", False) and not rc.get("linear_proj", False), "outside the hot-path scope"
+        assert self.n_attn == 1
+        self.cnn_layers = cfg["cnn_config"]["cnn_layers"]
+        self.cnn_bn = cfg["cnn_config"]["bn"]
+        self.bn = {}
+        if self.cnn_bn:
+            for i in range(len(self.cnn_layers)):
+                n = f"CNN_{i}_bn"
+                self.bn[n] = F.BatchNormState(self.p[n + "/gamma"], self.p[n + "/beta"],
+                                              self.p[n + "/avg_mean"], self.p[n + "/avg_var"])
+        mk = lambda n: F.LSTMLink(self.p[n + "/upward/W"], self.p[n + "/upward/b"], self.p[n + "/lateral/W"])
+        self.enc = [mk(f"L{i}_enc") for i in range(self.n_enc)]
+        self.rev = [mk(f"L{i}_rev_enc") for i in range(self.n_enc)] if self.bi else []
+        self.dec = [mk(f"L{i}_dec") for i in range(self.n_dec)]
+        w = np.ones(self.V, dtype=self.dtype)       # seq2seq.py:152-156
+        w[PAD_ID] = 0
+        self.mask_pad_id = w
+        self.train = True
+        self.masks = NoMasks()
+        self.enc_states = None
+
+    # ---- chainer.Chain-like helpers
+    def params(self):
+        return [(k, v) for k, v in self.p.items() if isinstance(v, Parameter)]
+
+    def cleargrads(self):
+        for _, v in self.params():
+            v.grad = None
+
+    # ---- seq2seq.py:158-180
+    def forward_cnn(self, X):
+        h = F.swapaxes(F.expand_dims(X, 2), 1, 2)               # (B,T,D) -> (B,1,T,D)
+        for i, l in enumerate(self.cnn_layers):
+            h = F.convolution_2d(h, self.p[f"CNN_{i}/W"], tuple(l["stride"]), tuple(l["pad"]))
+            if self.cnn_bn:
+                h = self.bn[f"CNN_{i}_bn"](h, train=self.train)
+            h = F.relu(h)
+        h = F.swapaxes(h, 1, 2)                                 # (B,T'',C,F')
+        h = F.reshape(h, h.shape[:2] + (-1,))                   # feature index c*F'+f  (Q9)
+        return F.rollaxis(h, 1)                                 # (T'',B,C*F')
+
+    # ---- seq2seq.py:182-203
+    def reset_rnn_state(self):
+        for l in self.enc + self.rev + self.dec:
+            l.reset_state()
+
+    def feed_rnn(self, x, links, stack, step):
+        hs = x
+        ratio = self.cfg["dropout"]["rnn"]
+        for k, link in enumerate(links):
+            hs = F.dropout(link(hs), ratio, self.masks, (stack, k, step), self.train)
+        return hs
+
+    # ---- seq2seq.py:205-242  (Q1: reverse stack reads X[-i]: 0, T''-1, ..., 1)
+    def forward_rnn_encode(self, X):
+        self.reset_rnn_state()
+        n = X.shape[0]
+        h_fwd = h_rev = None
+        for i in range(n):
+            f = F.expand_dims(self.feed_rnn(X[i], self.enc, "enc", i), 0)
+            h_fwd = f if h_fwd is None else F.concat((h_fwd, f), axis=0)    # quadratic growth kept
+            if self.bi:
+                r = F.expand_dims(self.feed_rnn(X[-i], self.rev, "rev", i), 0)
+                h_rev = r if h_rev is None else F.concat((h_rev, r), axis=0)
+        states = F.concat((h_fwd, F.flipud(h_rev)), axis=2) if self.bi else h_fwd
+        self.enc_states = F.swapaxes(states, 0, 1)              # (B,T'',H)
+
+    # ---- seq2seq.py:293-314
+    def encode(self, X, add_noise=0, noise=None):
+        X = F.as_variable(X)
+        if add_noise > 0 and self.train:
+            assert noise is not None, "inject the N(1,sigma) tensor (Q7: the reference's draw is unseeded)"
+            X = F.mul(X, Variable(noise.astype(self.dtype)))
+        self.forward_rnn_encode(self.forward_cnn(X))
+
+    # ---- seq2seq.py:318-333
+    def init_decoder_state(self):
+        if self.bi:
+            for e, r, d in zip(self.enc, self.rev, self.dec):
+                d.set_state(F.concat((e.c, r.c)), F.concat((e.h, r.h)))
+        else:
+            for e, d in zip(self.enc, self.dec):
+                d.set_state(e.c, e.h)
+
+    # ---- seq2seq.py:336-357
+    def compute_context_vector(self, dec_h):
+        q = F.linear(dec_h, self.p["attn_Wa/W"], self.p["attn_Wa/b"])
+        scores = F.batch_matmul(self.enc_states, q)              # (B,T'',1)
+        alphas = F.softmax(scores)                               # over time, no padding mask (Q2)
+        cv = F.squeeze(F.batch_matmul(F.swapaxes(self.enc_states, 2, 1), alphas), 2)
+        return cv, alphas
+
+    # ---- seq2seq.py:361-396
+    def decode_step(self, word, ht, step=0):
+        dr = self.cfg["dropout"]
+        emb = F.dropout(F.embed_id(word, self.p["embed_dec/W"]), dr["embed"], self.masks, ("emb", 0, step), self.train)
+        rnn_in = F.concat((emb, ht), axis=1) if self.feed_attn else emb
+        h = self.feed_rnn(rnn_in, self.dec, "dec", step)
+        cv, alphas = self.compute_context_vector(h)
+        ht = F.tanh(F.linear(F.concat((cv, h), axis=1), self.p["context/W"], self.p["context/b"]))
+        logits = F.dropout(F.linear(ht, self.p["out/W"], self.p["out/b"]), dr["out"], self.masks, ("out", 0, step), self.train)
+        return logits, ht, alphas
+
+    # ---- seq2seq.py:399-473
+    def forward_loss(self, X, y, teach_ratio, random_out=0, add_noise=0, noise=None, pyrandom=_pyrandom):
+        assert random_out == 0, "random_out>0 (Q8) is outside the restated path"
+        y = np.asarray(y.data if isinstance(y, Variable) else y)
+        B = X.shape[0]
+        self.encode(X, add_noise, noise)
+        self.init_decoder_state()
+        yT = y.T                                                 # (L,B)
+        L = len(yT)
+        A = self.cfg["rnn_config"]["attn_units"]
+        ht = Variable(np.zeros((B, A), dtype=self.dtype))
+        loss = 0
+        self.use_truth = []
+        dec_in = None
+        for i in range(L - 1):
+            cur, nxt = yT[i], yT[i + 1]
+            if 0 < i < L - 2:                                    # Q4: one coin per step, whole batch
+                truth = pyrandom.random() < teach_ratio
+            else:
+                truth = True
+            self.use_truth.append(bool(truth))
+            if truth:
+                dec_in = cur
+            logits, ht, _ = self.decode_step(dec_in, ht, step=i)
+            dec_in = F.argmax(logits, axis=1)
+            loss = loss + F.softmax_cross_entropy(logits, nxt.copy(), class_weight=self.mask_pad_id)
+        return loss
+
+    # ---- seq2seq.py:475-527
+    def predict(self, X, start_token=GO_ID, end_token=EOS_ID, stop_limit=10):
+        was = self.train
+        self.train = False
+        try:
+            B = X.shape[0]
+            self.encode(X)
+            self.init_decoder_state()
+            A = self.cfg["rnn_config"]["attn_units"]
+            ht = Variable(np.zeros((B, A), dtype=self.dtype))
+            word = np.full((B,), start_token, dtype=np.int32)
+            done = np.zeros(B, dtype=bool)
+            rows, npred = [], 0
+            while npred < stop_limit:
+                logits, ht, _ = self.decode_step(word, ht, step=npred)
+                word = F.argmax(logits, axis=1)
+                rows.append(word)
+                done[word == end_token] = True
+                if done.all():
+                    break
+                npred += 1
+            return np.stack(rows, 0).T
+        finally:
+            self.train = was
+
+
+# --------------------------------------------------------------------------- optimizer (nn.py:81-119)
+class RefOptimizer:
+    """Adam(alpha, .9, .999, 1e-8, amsgrad=True) or SGD, with hooks in insertion order:
+    WeightDecay(l2) -> GradientClipping(grad_clip)  (A7, A8)."""
+
+    def __init__(self, model, opt_cfg):
+        self.model, self.cfg = model, opt_cfg
+        self.t = 0
+        self.state = {}
+        self.last_grad_norm = None
+        self.frozen = set()
+        for l in opt_cfg.get("freeze", []):
+            self.frozen |= {k for k, _ in model.params() if k.split("/")[0] == l}
+
+    def update(self):
+        c = self.cfg
+        plist = [(k, p) for k, p in self.model.params() if k not in self.frozen]
+        for _, p in plist:                         # reallocate_cleared_grads
+            if p.grad is None:
+                p.grad = np.zeros_like(p.data)
+        if c["l2"] > 0:
+            for _, p in plist:
+                p.grad = p.grad + p.dtype.type(c["l2"]) * p.data
+        sq = 0.0
+        for _, p in plist:
+            g = p.grad.ravel()
+            sq += float(g.dot(g))
+        norm = np.sqrt(sq)
+        self.last_grad_norm = norm                 # the "grad norm" parity observable (K29)
+        rate = c["grad_clip"] / norm if norm > 0 else np.inf
+        if rate < 1:
+            for _, p in plist:
+                p.grad = p.grad * p.dtype.type(rate)
+        assert c.get("grad_noise_eta", 0) == 0
+        self.t += 1
+        if c["type"] == 0:
+            b1, b2, eps, alpha = 0.9, 0.999, 1e-8, c["lr"]
+            lr_t = alpha * np.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
+            for k, p in plist:
+                st = self.state.setdefault(k, {n: np.zeros_like(p.data) for n in ("m", "v", "vhat")})
+                dt = p.dtype.type
+                g = p.grad
+                st["m"] += dt(1 - b1) * (g - st["m"])
+                st["v"] += dt(1 - b2) * (g * g - st["v"])
+                np.maximum(st["vhat"], st["v"], out=st["vhat"])
+                p.data -= dt(lr_t) * st["m"] / (np.sqrt(st["vhat"]) + dt(eps))
+        else:
+            for _, p in plist:
+                p.data -= p.dtype.type(c["lr"]) * p.grad
+
+
+def train_step(model, opt, X, y, teach_ratio, add_noise=0, noise=None, pyrandom=_pyrandom):
+    """nn.py:174-189: forward_loss -> cleargrads -> backward -> update; reports loss/B (Q5)."""
+    model.train = True
+    loss = model.forward_loss(X, y, teach_ratio, 0, add_noise, noise, pyrandom)
+    model.cleargrads()
+    loss.backward()
+    opt.update()
+    return float(loss.data), float(loss.data) / len(y)
+
+
+# --------------------------------------------------------------------------- synthetic batches
+def synth_batch(B, T, D, L, V, seed=20, dtype=np.float32):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((B, T, D)).astype(dtype)
+    y = np.zeros((B, L), dtype=np.int32)
+    for b in range(B):
+        # row 0 has the full padded length so that L really is the batch maximum
+        n = L if b == 0 else int(rng.integers(max(L // 2, 3), L + 1))
+        y[b, 0] = GO_ID
+        y[b, 1:n - 1] = rng.integers(4, V, size=n - 2)
+        y[b, n - 1] = EOS_ID
+    return X, y
+
+
+def teacher_flags(L, teach_ratio, pyrandom):
+    """Q4 flag sequence for one forward_loss call with targets of padded length L."""
+    flags = []
+    for i in range(L - 1):
+        if 0 < i < L - 2:
+            flags.append(pyrandom.random() < teach_ratio)
+        else:
+            flags.append(True)
+    return flags
