@@ -1,0 +1,134 @@
+"""ctypes binding of libastk.so (include/astk.h).  The product path has no fallback: if the HIP library is
+missing or fails to load, importing the compute path raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libastk.so")
+
+MAX_CNN = 4
+MAX_RNN = 8
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int32)
+c_double_p = C.POINTER(C.c_double)
+
+
+class CnnDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("D", C.c_int), ("n_layers", C.c_int),
+                ("C", C.c_int * MAX_CNN), ("kt", C.c_int * MAX_CNN), ("kf", C.c_int * MAX_CNN),
+                ("st", C.c_int * MAX_CNN), ("sf", C.c_int * MAX_CNN), ("pt", C.c_int * MAX_CNN),
+                ("bn_eps", C.c_float), ("bn_decay", C.c_float)]
+
+
+class CnnLayerParams(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("avg_mean", C.c_void_p), ("avg_var", C.c_void_p)]
+
+
+class CnnLayerGrads(C.Structure):
+    _fields_ = [("dW", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+
+
+class LstmStackDesc(C.Structure):
+    _fields_ = [("T", C.c_int), ("B", C.c_int), ("in_dim", C.c_int), ("h", C.c_int),
+                ("n_layers", C.c_int), ("n_dirs", C.c_int)]
+
+
+class LstmParams(C.Structure):
+    _fields_ = [("Wu", C.c_void_p), ("b", C.c_void_p), ("Wl", C.c_void_p)]
+
+
+class LstmGrads(C.Structure):
+    _fields_ = [("dWu", C.c_void_p), ("db", C.c_void_p), ("dWl", C.c_void_p)]
+
+
+class DecoderDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("L", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int),
+                ("A", C.c_int), ("V", C.c_int), ("n_layers", C.c_int)]
+
+
+class DecoderParams(C.Structure):
+    _fields_ = [("embed", C.c_void_p), ("lstm", LstmParams * MAX_RNN),
+                ("Wa", C.c_void_p), ("ba", C.c_void_p), ("Wc", C.c_void_p), ("bc", C.c_void_p),
+                ("Wo", C.c_void_p), ("bo", C.c_void_p), ("class_weight", C.c_void_p)]
+
+
+class DecoderGrads(C.Structure):
+    _fields_ = [("d_embed", C.c_void_p), ("lstm", LstmGrads * MAX_RNN),
+                ("dWa", C.c_void_p), ("dba", C.c_void_p), ("dWc", C.c_void_p), ("dbc", C.c_void_p),
+                ("dWo", C.c_void_p), ("dbo", C.c_void_p)]
+
+
+# every symbol include/astk.h declares: name -> (restype, argtypes)
+_VP, _I, _L, _SZ, _F, _U64 = C.c_void_p, C.c_int, C.c_long, C.c_size_t, C.c_float, C.c_uint64
+SIGNATURES = {
+    "astk_version": (C.c_int, []),
+    "astk_last_error": (C.c_char_p, []),
+    "astk_gemm_f32": (C.c_int, [_I, _I, _I, _I, _VP, _L, _VP, _L, _VP, _L, _VP, _I, _I, _I, _L, _L, _L, _VP]),
+    "astk_conv_bn_relu_out_dims": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "astk_conv_bn_relu_workspace_bytes": (_SZ, [C.POINTER(CnnDesc)]),
+    "astk_conv_bn_relu_fwd": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(CnnLayerParams), _VP, _VP, _VP, _VP, _SZ, _I, _VP]),
+    "astk_conv_bn_relu_bwd": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(CnnLayerParams), C.POINTER(CnnLayerGrads), _VP, _VP, _SZ, _VP]),
+    "astk_lstm_stack_workspace_bytes": (_SZ, [C.POINTER(LstmStackDesc)]),
+    "astk_lstm_stack_fwd": (C.c_int, [C.POINTER(LstmStackDesc), C.POINTER(LstmParams), _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "astk_lstm_stack_bwd": (C.c_int, [C.POINTER(LstmStackDesc), C.POINTER(LstmParams), C.POINTER(LstmGrads), _VP, _VP, _VP, _VP,
+                                      _VP, _VP, _VP, _SZ, _VP]),
+    "astk_attn_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "astk_attn_step_fwd": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "astk_attn_step_bwd": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "astk_decoder_workspace_bytes": (_SZ, [C.POINTER(DecoderDesc)]),
+    "astk_decoder_fwd": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderParams), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
+                                   _VP, _SZ, _VP]),
+    "astk_decoder_bwd": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderParams), C.POINTER(DecoderGrads), _VP, _VP, _VP, _VP,
+                                   _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "astk_decoder_step_infer": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderParams), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
+                                          _VP, _SZ, _VP]),
+    "astk_softmax_ce_fwd": (C.c_int, [_I, _I, _L, _VP, _VP, _L, _VP, _F, _VP, _VP, _VP]),
+    "astk_grad_sqnorm": (C.c_int, [_VP, _VP, _F, _SZ, _VP, _VP]),
+    "astk_decay_clip_amsgrad_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _SZ, _F, _F, _VP, _F, _F, _F, _F, _I, _VP]),
+    "astk_decay_clip_sgd_step": (C.c_int, [_VP, _VP, _SZ, _F, _F, _VP, _F, _VP]),
+    "astk_fill_dropout_mask": (C.c_int, [_VP, _SZ, _F, _U64, _U64, _VP]),
+    "astk_fill_normal": (C.c_int, [_VP, _SZ, _F, _F, _U64, _U64, _VP]),
+    "astk_scale_f32": (C.c_int, [_VP, _SZ, _F, _VP]),
+    "astk_graph_begin": (C.c_int, [_VP]),
+    "astk_graph_end": (C.c_int, [_VP, C.POINTER(C.c_void_p)]),
+    "astk_graph_launch": (C.c_int, [_VP, _VP]),
+    "astk_graph_destroy": (C.c_int, [_VP]),
+}
+
+_lib = None
+
+
+class AstkError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libastk.so and bind every declared symbol; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AstkError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(there is no CPU or PyTorch fallback for the compute path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise AstkError(f"libastk error {rc}: {load().astk_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "libastk expects contiguous tensors"
+    return C.c_void_p(t.data_ptr())

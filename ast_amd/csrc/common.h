@@ -1,0 +1,193 @@
+// Internal helpers shared by the libastk translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/astk.h"
+
+namespace astk {
+
+void set_error(const char* fmt, ...);
+
+#define ASTK_CHECK(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      astk::set_error(__VA_ARGS__);      \
+      return -1;                         \
+    }                                    \
+  } while (0)
+
+#define ASTK_HIP(expr)                                                               \
+  do {                                                                               \
+    hipError_t e_ = (expr);                                                          \
+    if (e_ != hipSuccess) {                                                          \
+      astk::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return -2;                                                                     \
+    }                                                                                \
+  } while (0)
+
+#define ASTK_LAUNCH_CHECK()                                                          \
+  do {                                                                               \
+    hipError_t e_ = hipGetLastError();                                               \
+    if (e_ != hipSuccess) {                                                          \
+      astk::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return -3;                                                                     \
+    }                                                                                \
+  } while (0)
+
+#define ASTK_TRY(expr)        \
+  do {                        \
+    int r_ = (expr);          \
+    if (r_ != 0) return r_;   \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// Bump allocator over a caller-provided workspace (256-byte aligned slices).
+struct Carver {
+  char* base;
+  size_t off;
+  explicit Carver(void* p) : base((char*)p), off(0) {}
+  template <typename T>
+  T* take(size_t n) {
+    off = align_up(off, 256);
+    T* r = base ? (T*)(base + off) : nullptr;
+    off += n * sizeof(T);
+    return r;
+  }
+  size_t total() const { return align_up(off, 256); }
+};
+
+// Row-major matrix view with generalised row addressing:
+//   rowoff(r) = rowidx ? rowidx[r]*ld : (tn > 0 ? (r / tn) * sg + (r % tn) * st : r * ld)
+// (two-level rows express zero-copy im2col windows of the padded channels-last conv activations).
+struct MatView {
+  const float* p;
+  long ld;
+  int tn;
+  long sg, st;
+  const int* rowidx;
+};
+static inline MatView mat(const float* p, long ld) { return MatView{p, ld, 0, 0, 0, nullptr}; }
+static inline MatView mat2(const float* p, int tn, long sg, long st) { return MatView{p, st, tn, sg, st, nullptr}; }
+static inline MatView mat_idx(const float* p, long ld, const int* idx) { return MatView{p, ld, 0, 0, 0, idx}; }
+
+enum GemmLayout { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
+enum GemmMode { GEMM_STORE = 0, GEMM_ACCUM = 1, GEMM_ATOMIC = 2 };
+
+struct GemmArgs {
+  MatView A, B;
+  float* C;
+  long ldc;
+  int c_tn;
+  long c_sg, c_st;  // two-level C rows when c_tn > 0
+  const float* bias;
+  int M, N, K;
+  int mode;
+  int ksplit;
+  int batch;
+  long sA, sB, sC;
+};
+static inline GemmArgs gemm_args(int M, int N, int K, MatView A, MatView B, float* C, long ldc,
+                                 const float* bias = nullptr, int mode = GEMM_STORE, int ksplit = 1) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.B = B; g.C = C; g.ldc = ldc; g.bias = bias; g.M = M; g.N = N; g.K = K;
+  g.mode = mode; g.ksplit = ksplit; g.batch = 1;
+  return g;
+}
+int gemm_launch(int layout, const GemmArgs& g, hipStream_t s);
+
+// ---- small utility kernels (util.hip)
+int fill_zero(void* p, size_t bytes, hipStream_t s);
+int copy_f32(float* dst, const float* src, size_t n, hipStream_t s);
+int copy2d_f32(float* dst, long ldd, const float* src, long lds, int rows, int cols, int cols_dst, hipStream_t s);
+int add2d_f32(float* dst, long ldd, const float* src, long lds, int rows, int cols, hipStream_t s);
+int transpose_f32(float* dst, long ldd, const float* src, long lds, int rows, int cols, hipStream_t s);  // dst[c][r] = src[r][c]
+int colsum_add_f32(float* dst, const float* src, long lds, int rows, int cols, hipStream_t s);           // dst[c] += sum_r src[r][c]
+int axpy_rows(float* dst, const float* src, size_t n, hipStream_t s);                                    // dst += src
+
+// ---- row-panel ("skinny", M <= a few dozen) MFMA products used by every recurrent step (rowgemm.hip)
+struct RowPair {
+  const float* A;  // [M][K], row stride lda
+  long lda;
+  const float* W;  // [N][K] K-contiguous (Linear layout), row stride ldw
+  long ldw;
+  int K;
+};
+enum RowAct { ACT_NONE = 0, ACT_TANH = 1, ACT_DTANH = 2 };
+struct RowGemmArgs {
+  RowPair p[2];
+  int npairs;
+  int M, N;
+  const float* bias;    // [N] or null
+  const float* addend;  // [M][N] (ld_add) or null
+  long ld_add;
+  const float* aux;     // ACT_DTANH: y = tanh output, out = (acc+addend)*(1-y*y)
+  long ld_aux;
+  float* out;
+  long ld_out;
+  float* out2;          // optional second copy of the result (e.g. into the input-feeding concat buffer)
+  long ld_out2;
+  int act;
+};
+int rowgemm_launch(const RowGemmArgs& a, hipStream_t s);
+
+struct LstmCellFwdArgs {
+  RowPair p[2];          // p[0]: (h_prev, Wl) lateral (K may be 0 at the first encoder step); p[1]: (x, Wu) optional
+  int npairs;
+  int B, h;
+  const float* zx;       // [B][4h] precomputed upward projection incl. bias (row stride ld_zx) or null
+  long ld_zx;
+  const float* bias;     // [4h] or null (used when zx is null or in addition)
+  const float* c_prev;   // [B][h] or null (zeros)
+  float* gates;          // [B][4h] activated a,i,f,o interleaved (may alias zx)
+  long ld_g;
+  float* c_out;          // [B][h]
+  float* h_out;          // [B][h] raw
+  const float* mask;     // [B][h] scaled keep-mask or null
+  float* hd_out;         // [B][h'] dropped output, row stride ld_hd (null: skip)
+  long ld_hd;
+  float* hd_out2;        // optional second destination (enc_states slice), row stride ld_hd2
+  long ld_hd2;
+};
+int lstm_cell_fwd_launch(const LstmCellFwdArgs* cells, int ncells, hipStream_t s);
+
+struct LstmCellBwdArgs {
+  RowPair p[2];          // p[0]: (dz_next [B][4h], WlT [h][4h]) -> dh_rec ; p[1]: (dz_above, WuT_above) -> dx (masked)
+  int npairs;
+  int B, h;
+  const float* dh_add;   // [B][h] un-masked addend (d_hT at the last step) or null
+  const float* dy;       // [B][h'] gradient wrt the dropped output (row stride ld_dy) or null
+  long ld_dy;
+  const float* dy2;      // second gradient wrt the dropped output (e.g. d_enc slice) or null
+  long ld_dy2;
+  const float* mask;     // [B][h] or null
+  const float* dc_next;  // [B][h] or null
+  const float* c_prev;   // [B][h] or null (zeros)
+  const float* c_cur;    // [B][h]
+  float* gates_dz;       // [B][4h]: in: activated gates, out: dz  (row stride ld_g)
+  long ld_g;
+  float* dc_prev;        // [B][h]
+};
+int lstm_cell_bwd_launch(const LstmCellBwdArgs* cells, int ncells, hipStream_t s);
+
+// ---- attention (attn.hip)
+int attn_fwd_launch(int B, int T, int H, const float* enc, const float* q, long ldq, float* alpha, float* cv, long ldcv,
+                    float* cv2, long ldcv2, void* ws, hipStream_t s);
+int attn_bwd_launch(int B, int T, int H, const float* enc, const float* alpha, const float* cv, long ldcv,
+                    const float* d_cv, long ld_dcv, float* ds, float* dq, void* ws, hipStream_t s);
+size_t attn_ws_bytes(int B, int T, int H);
+
+// ---- decoder helpers (decoder.hip)
+int softmax_ce_launch(int B, int V, long ld, float* logits, const int32_t* targets, long t_stride, const float* cw,
+                      float inv_count, float* loss_rows, int32_t* argmax, hipStream_t s);
+
+}  // namespace astk

@@ -1,0 +1,471 @@
+// CNN front-end of the speech encoder (seq2seq.py:158-180):
+//   [Conv2D(nobias) -> BatchNorm(batch statistics) -> ReLU] x n, then the (T'',B,C*F') re-layout (Q9).
+//
+// Data layout in HBM (all f32):
+//   layer 0 : X (B,T,D) [* noise] --im2col--> P0 [(b,f,t1)][kt*kf padded to 4]  (coalesced reads of the padded
+//             (T,D) frame matrix: one workgroup streams whole frame rows) -> Y0 = P0 W0^T  (MFMA GEMM)
+//   layer i : activations are kept channels-last and time-padded, HP[(b,f)][pt + T_i + pt][C_i]; because the
+//             frequency kernel/stride of layers >= 1 is 1, the im2col row of output (b,f,t) is the CONTIGUOUS
+//             window HP[(b,f)][t*st .. t*st+kt)[:] -- the conv runs as a zero-copy "window" GEMM (two-level row
+//             addressing in gemm.hip), K = kt*C_{i-1}, against the weight re-packed to [co][kt][ci].
+//   backward: wgrad = TN window GEMM with split-K atomics; dgrad = one window GEMM per stride phase over the
+//             time-padded dY (transposed convolution without col2im scatter).
+//   BatchNorm: column statistics of the raw conv output [rows][C] in float64 atomics, then one fused
+//             scale/shift/ReLU pass that writes the next layer's padded layout (or the LSTM layout).
+#include "common.h"
+
+namespace astk {
+
+namespace {
+
+struct CnnPlan {
+  int n;
+  int B, T, D, F;
+  int Tn[ASTK_MAX_CNN_LAYERS];      // output time length of layer i
+  int Cn[ASTK_MAX_CNN_LAYERS];
+  int rows[ASTK_MAX_CNN_LAYERS];    // B*F*Tn[i]
+  int K0, K0p;                      // layer-0 patch size and its padded width
+  int padA[ASTK_MAX_CNN_LAYERS];    // time padding of HP_i (= pt of layer i+1), front == back
+  int dF[ASTK_MAX_CNN_LAYERS], dB[ASTK_MAX_CNN_LAYERS];  // front/back padding of DYP_i for the dgrad windows (i>=1)
+  // workspace slices
+  float* P0;
+  float* Y[ASTK_MAX_CNN_LAYERS];
+  float* HP[ASTK_MAX_CNN_LAYERS];   // i < n-1
+  float* Wr[ASTK_MAX_CNN_LAYERS];   // repacked weights (i=0: padded (C0,K0p); i>=1: (C_i, kt*C_{i-1}))
+  double* stat;                     // [2][Cmax] column sums
+  float* bn[ASTK_MAX_CNN_LAYERS];   // [4][C]: mean, inv_std, scale, shift
+  float* G;                         // [rows_max][Cmax] gradient wrt post-ReLU output (row layout)
+  float* DY[ASTK_MAX_CNN_LAYERS];   // padded dY (i>=1) / plain dY (i=0)
+  float* dWr;                       // scratch for re-packed weight gradients
+  float* Wd;                        // phase weights for dgrad
+  size_t bytes;
+};
+
+int conv_out(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
+
+int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
+  ASTK_CHECK(d && d->n_layers >= 1 && d->n_layers <= ASTK_MAX_CNN_LAYERS, "cnn: 1..%d layers", ASTK_MAX_CNN_LAYERS);
+  ASTK_CHECK(d->B > 0 && d->T > 0 && d->D > 0, "cnn: bad input dims");
+  P.n = d->n_layers; P.B = d->B; P.T = d->T; P.D = d->D;
+  ASTK_CHECK(d->kf[0] >= 1 && d->kf[0] <= d->D && d->sf[0] >= 1, "cnn: bad layer-0 frequency kernel");
+  P.F = conv_out(d->D, d->kf[0], d->sf[0], 0);
+  int t = d->T;
+  size_t cmax = 0, rowsmax_c = 0;
+  for (int i = 0; i < P.n; ++i) {
+    ASTK_CHECK(d->kt[i] >= 1 && d->st[i] >= 1 && d->pt[i] >= 0 && d->C[i] >= 1, "cnn: bad layer %d", i);
+    ASTK_CHECK(i == 0 || (d->kf[i] == 1 && d->sf[i] == 1), "cnn: layers >= 1 must have a (kt,1) kernel and frequency stride 1");
+    ASTK_CHECK(d->kt[i] >= d->st[i], "cnn: time kernel must be >= time stride (layer %d)", i);
+    ASTK_CHECK((d->C[i] % 4) == 0, "cnn: channel counts must be multiples of 4 (layer %d: %d)", i, d->C[i]);
+    t = conv_out(t, d->kt[i], d->st[i], d->pt[i]);
+    ASTK_CHECK(t >= 1 && P.F >= 1, "cnn: input too short for layer %d", i);
+    P.Tn[i] = t;
+    P.Cn[i] = d->C[i];
+    P.rows[i] = d->B * P.F * t;
+    cmax = cmax > (size_t)d->C[i] ? cmax : (size_t)d->C[i];
+    size_t rc = (size_t)P.rows[i] * d->C[i];
+    rowsmax_c = rowsmax_c > rc ? rowsmax_c : rc;
+  }
+  P.K0 = d->kt[0] * d->kf[0];
+  P.K0p = (P.K0 + 3) / 4 * 4;
+  Carver c(ws);
+  P.P0 = c.take<float>((size_t)P.rows[0] * P.K0p);
+  size_t wd_max = 0, dwr_max = (size_t)d->C[0] * P.K0p;
+  for (int i = 0; i < P.n; ++i) {
+    P.Y[i] = c.take<float>((size_t)P.rows[i] * P.Cn[i]);
+    P.bn[i] = c.take<float>(4 * (size_t)P.Cn[i]);
+    if (i < P.n - 1) {
+      P.padA[i] = d->pt[i + 1];
+      P.HP[i] = c.take<float>((size_t)d->B * P.F * (P.Tn[i] + 2 * P.padA[i]) * P.Cn[i]);
+    } else {
+      P.padA[i] = 0;
+      P.HP[i] = nullptr;
+    }
+    if (i == 0) {
+      P.Wr[0] = c.take<float>((size_t)d->C[0] * P.K0p);
+      P.dF[0] = P.dB[0] = 0;
+      P.DY[0] = c.take<float>((size_t)P.rows[0] * P.Cn[0]);
+    } else {
+      const int KT = d->kt[i], st = d->st[i], pt = d->pt[i];
+      P.Wr[i] = c.take<float>((size_t)P.Cn[i] * KT * P.Cn[i - 1]);
+      const int na_max = (KT + st - 1) / st;
+      int f = na_max - 1 - pt / st;
+      P.dF[i] = f > 0 ? f : 0;
+      const int qmax = (P.Tn[i - 1] - 1 + pt) / st;
+      int bk = qmax - (P.Tn[i] - 1);
+      P.dB[i] = bk > 0 ? bk : 0;
+      P.DY[i] = c.take<float>((size_t)d->B * P.F * (P.Tn[i] + P.dF[i] + P.dB[i]) * P.Cn[i]);
+      size_t wd = (size_t)P.Cn[i - 1] * na_max * P.Cn[i];
+      wd_max = wd_max > wd ? wd : wd_max;
+      size_t dw = (size_t)P.Cn[i] * KT * P.Cn[i - 1];
+      dwr_max = dwr_max > dw ? dw : dwr_max;
+    }
+  }
+  P.stat = c.take<double>(2 * cmax);
+  P.G = c.take<float>(rowsmax_c);
+  P.dWr = c.take<float>(dwr_max);
+  P.Wd = c.take<float>(wd_max ? wd_max : 4);
+  P.bytes = c.total();
+  return 0;
+}
+
+// ------------------------------------------------------------------ kernels
+// P0[(b,f,t1)][k = a*kf + j] = X[b][t1*st - pt + a][f*sf + j] * noise ; one block per (b, t1): the kt frame rows it
+// needs are read as whole rows (coalesced), every f patch is written as a contiguous K0p-float row.
+__global__ __launch_bounds__(256) void k_im2col0(const float* __restrict__ X, const float* __restrict__ noise, float* __restrict__ P0,
+                                                 int B, int T, int D, int F, int T1, int kt, int kf, int st, int sf, int pt, int K0p) {
+  const int t1 = blockIdx.x, b = blockIdx.y;
+  const int K0 = kt * kf;
+  const int total = F * K0p;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int f = i / K0p, k = i % K0p;
+    float v = 0.f;
+    if (k < K0) {
+      const int a = k / kf, j = k % kf;
+      const int t = t1 * st - pt + a;
+      if (t >= 0 && t < T) {
+        const long idx = ((long)b * T + t) * D + f * sf + j;
+        v = X[idx];
+        if (noise) v *= noise[idx];
+      }
+    }
+    P0[(((long)b * F + f) * T1 + t1) * K0p + k] = v;
+  }
+}
+
+// Wr[co][kt*Ci + ci] = W[co][ci][kt]   (W is (Co,Ci,KT,1))
+__global__ void k_repack_w(const float* __restrict__ W, float* __restrict__ Wr, int Co, int Ci, int KT) {
+  const long n = (long)Co * Ci * KT;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Ci);
+    const int k = (int)((i / Ci) % KT);
+    const int co = (int)(i / ((long)Ci * KT));
+    Wr[i] = W[((long)co * Ci + ci) * KT + k];
+  }
+}
+// dW[co][ci][kt] += dWr[co][kt*Ci + ci]
+__global__ void k_unpack_dw(const float* __restrict__ dWr, float* __restrict__ dW, int Co, int Ci, int KT) {
+  const long n = (long)Co * Ci * KT;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % KT);
+    const int ci = (int)((i / KT) % Ci);
+    const int co = (int)(i / ((long)Ci * KT));
+    dW[i] += dWr[((long)co * KT + k) * Ci + ci];
+  }
+}
+// dgrad phase weight: Wd[ci][a*Co + co] = W[co][ci][kt = r + st*(na-1-a)]
+__global__ void k_phase_w(const float* __restrict__ W, float* __restrict__ Wd, int Co, int Ci, int KT, int r, int st, int na) {
+  const long n = (long)Ci * na * Co;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Co);
+    const int a = (int)((i / Co) % na);
+    const int ci = (int)(i / ((long)Co * na));
+    const int k = r + st * (na - 1 - a);
+    Wd[i] = W[((long)co * Ci + ci) * KT + k];
+  }
+}
+
+// column sums of Y and Y^2 ( -> double atomics ). Thread layout: Cw = min(C,256) columns x 256/Cw row lanes.
+__global__ __launch_bounds__(256) void k_colstats(const float* __restrict__ Y, int rows, int C, double* __restrict__ stat,
+                                                  int rows_per_block) {
+  const int Cw = C < 256 ? C : 256;
+  const int nsub = 256 / Cw;
+  const int c0 = threadIdx.x % Cw, rs = threadIdx.x / Cw;
+  if (rs >= nsub) return;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (int c = c0; c < C; c += Cw) {
+    float s = 0.f, s2 = 0.f;
+    for (int r = r0 + rs; r < r1; r += nsub) {
+      const float v = Y[(long)r * C + c];
+      s += v;
+      s2 += v * v;
+    }
+    atomicAdd(&stat[c], (double)s);
+    atomicAdd(&stat[C + c], (double)s2);
+  }
+}
+
+// bn[0]=mean, bn[1]=inv_std, bn[2]=scale, bn[3]=shift ; running statistics per Chainer-sem A4
+__global__ void k_bn_finalize(const double* __restrict__ stat, int C, double m, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, float* __restrict__ avg_mean, float* __restrict__ avg_var,
+                              float* __restrict__ bn, float eps, float decay, int train) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, inv_std;
+  if (train) {
+    const double mu = stat[c] / m;
+    double var = stat[C + c] / m - mu * mu;
+    if (var < 0) var = 0;
+    mean = (float)mu;
+    inv_std = (float)(1.0 / sqrt(var + (double)eps));
+    const double adjust = m / (m - 1.0 > 1.0 ? m - 1.0 : 1.0);
+    avg_mean[c] = decay * avg_mean[c] + (1.f - decay) * mean;
+    avg_var[c] = decay * avg_var[c] + (float)((1.0 - (double)decay) * adjust * var);
+  } else {
+    mean = avg_mean[c];
+    inv_std = 1.f / sqrtf(avg_var[c] + eps);
+  }
+  const float sc = gamma[c] * inv_std;
+  bn[c] = mean;
+  bn[C + c] = inv_std;
+  bn[2 * C + c] = sc;
+  bn[3 * C + c] = beta[c] - mean * sc;
+}
+
+// dst[prow(m)][c] = relu(Y[m][c]*scale + shift), prow(m) = (m/Tn)*(Tn+2*pad) + pad + m%Tn  (float4 over channels)
+__global__ void k_bn_relu_rows(const float* __restrict__ Y, const float* __restrict__ bn, float* __restrict__ dst, int rows, int C,
+                               int Tn, int pad) {
+  const long n4 = (long)rows * C / 4;
+  const int C4 = C / 4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / C4), c = (int)(i % C4) * 4;
+    const float4 y = *reinterpret_cast<const float4*>(Y + (long)m * C + c);
+    const float4 sc = *reinterpret_cast<const float4*>(bn + 2 * C + c);
+    const float4 sh = *reinterpret_cast<const float4*>(bn + 3 * C + c);
+    float4 o;
+    o.x = fmaxf(y.x * sc.x + sh.x, 0.f); o.y = fmaxf(y.y * sc.y + sh.y, 0.f);
+    o.z = fmaxf(y.z * sc.z + sh.z, 0.f); o.w = fmaxf(y.w * sc.w + sh.w, 0.f);
+    const long pr = (long)(m / Tn) * (Tn + 2 * pad) + pad + (m % Tn);
+    *reinterpret_cast<float4*>(dst + pr * C + c) = o;
+  }
+}
+
+// out[t][b][c*F+f] = relu(bn(Y[(b,f,t)][c]))  -- one block per (t, b); LDS re-orders (f,c) -> (c,f)
+__global__ __launch_bounds__(256) void k_bn_relu_to_seq(const float* __restrict__ Y, const float* __restrict__ bn, float* __restrict__ out,
+                                                        int B, int F, int Tn, int C) {
+  extern __shared__ float tile[];   // [C*F]
+  const int t = blockIdx.x, b = blockIdx.y;
+  const int n = C * F;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int f = i / C, c = i % C;
+    const float y = Y[(((long)b * F + f) * Tn + t) * C + c];
+    tile[c * F + f] = fmaxf(y * bn[2 * C + c] + bn[3 * C + c], 0.f);
+  }
+  __syncthreads();
+  float* o = out + ((long)t * B + b) * n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) o[i] = tile[i];
+}
+// G[(b,f,t)][c] = d_out[t][b][c*F+f]
+__global__ __launch_bounds__(256) void k_seq_to_rows(const float* __restrict__ d_out, float* __restrict__ G, int B, int F, int Tn, int C) {
+  extern __shared__ float tile[];
+  const int t = blockIdx.x, b = blockIdx.y;
+  const int n = C * F;
+  const float* src = d_out + ((long)t * B + b) * n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) tile[i] = src[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int f = i / C, c = i % C;
+    G[(((long)b * F + f) * Tn + t) * C + c] = tile[c * F + f];
+  }
+}
+
+// backward statistics: stat[c] = sum g, stat[C+c] = sum g*xhat, g = G*(bn(Y)>0)
+__global__ __launch_bounds__(256) void k_bn_bwd_stats(const float* __restrict__ Y, const float* __restrict__ G, const float* __restrict__ bn,
+                                                      int rows, int C, double* __restrict__ stat, int rows_per_block) {
+  const int Cw = C < 256 ? C : 256;
+  const int nsub = 256 / Cw;
+  const int c0 = threadIdx.x % Cw, rs = threadIdx.x / Cw;
+  if (rs >= nsub) return;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (int c = c0; c < C; c += Cw) {
+    const float mean = bn[c], inv = bn[C + c], sc = bn[2 * C + c], sh = bn[3 * C + c];
+    float s = 0.f, s2 = 0.f;
+    for (int r = r0 + rs; r < r1; r += nsub) {
+      const float y = Y[(long)r * C + c];
+      const float g = (y * sc + sh > 0.f) ? G[(long)r * C + c] : 0.f;
+      s += g;
+      s2 += g * (y - mean) * inv;
+    }
+    atomicAdd(&stat[c], (double)s);
+    atomicAdd(&stat[C + c], (double)s2);
+  }
+}
+// dY[prow(m)][c] = scale*(g - (xhat*dgamma + dbeta)/rows) ; also accumulates dgamma/dbeta (block 0)
+__global__ void k_bn_bwd_apply(const float* __restrict__ Y, const float* __restrict__ G, const float* __restrict__ bn,
+                               const double* __restrict__ stat, float* __restrict__ dY, int rows, int C, int Tn, int padF, int padB,
+                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const long n = (long)rows * C;
+  const float invm = 1.f / (float)rows;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / C), c = (int)(i % C);
+    const float mean = bn[c], inv = bn[C + c], sc = bn[2 * C + c], sh = bn[3 * C + c];
+    const float y = Y[i];
+    const float g = (y * sc + sh > 0.f) ? G[i] : 0.f;
+    const float xh = (y - mean) * inv;
+    const float v = sc * (g - (xh * (float)stat[C + c] + (float)stat[c]) * invm);
+    const long pr = (long)(m / Tn) * (Tn + padF + padB) + padF + (m % Tn);
+    dY[pr * C + c] = v;
+  }
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      dgamma[c] += (float)stat[C + c];
+      dbeta[c] += (float)stat[c];
+    }
+}
+
+inline unsigned gridn(size_t n) {
+  size_t b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 4096) b = 4096;
+  return (unsigned)b;
+}
+
+int ksplit_for(long tiles, long K) {
+  // aim for ~512 workgroups, at least 256 of K per split
+  long s = 512 / (tiles > 0 ? tiles : 1);
+  if (s < 1) s = 1;
+  long smax = K / 256;
+  if (smax < 1) smax = 1;
+  if (s > smax) s = smax;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+
+}  // namespace
+
+int cnn_out_dims(const astk_cnn_desc* d, int* T_out, int* F_out, int* feat) {
+  CnnPlan P;
+  ASTK_TRY(make_plan(d, nullptr, P));
+  if (T_out) *T_out = P.Tn[P.n - 1];
+  if (F_out) *F_out = P.F;
+  if (feat) *feat = P.Cn[P.n - 1] * P.F;
+  return 0;
+}
+
+}  // namespace astk
+
+using namespace astk;
+
+extern "C" {
+
+int astk_conv_bn_relu_out_dims(const astk_cnn_desc* d, int* T_out, int* F_out, int* feat_dim) {
+  return cnn_out_dims(d, T_out, F_out, feat_dim);
+}
+
+size_t astk_conv_bn_relu_workspace_bytes(const astk_cnn_desc* d) {
+  CnnPlan P;
+  if (make_plan(d, nullptr, P) != 0) return 0;
+  return P.bytes;
+}
+
+int astk_conv_bn_relu_fwd(const astk_cnn_desc* d, const astk_cnn_layer_params* L, const float* X, const float* noise, float* out,
+                          void* ws, size_t ws_bytes, int train, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CnnPlan P;
+  ASTK_TRY(make_plan(d, ws, P));
+  ASTK_CHECK(ws && ws_bytes >= P.bytes, "conv_bn_relu_fwd: workspace too small (%zu < %zu)", ws_bytes, P.bytes);
+  ASTK_CHECK(X && out && L, "conv_bn_relu_fwd: null pointer");
+  const int B = P.B, F = P.F;
+  // ---- layer 0: im2col + GEMM
+  hipLaunchKernelGGL(k_im2col0, dim3(P.Tn[0], B), dim3(256), 0, s, X, noise, P.P0, B, P.T, P.D, F, P.Tn[0], d->kt[0], d->kf[0],
+                     d->st[0], d->sf[0], d->pt[0], P.K0p);
+  ASTK_LAUNCH_CHECK();
+  ASTK_TRY(copy2d_f32(P.Wr[0], P.K0p, L[0].W, P.K0, P.Cn[0], P.K0, P.K0p, s));
+  ASTK_TRY(gemm_launch(GEMM_NT, gemm_args(P.rows[0], P.Cn[0], P.K0p, mat(P.P0, P.K0p), mat(P.Wr[0], P.K0p), P.Y[0], P.Cn[0]), s));
+  for (int i = 0; i < P.n; ++i) {
+    const int C = P.Cn[i], rows = P.rows[i];
+    if (i > 0) {
+      const int Ci = P.Cn[i - 1], KT = d->kt[i];
+      hipLaunchKernelGGL(k_repack_w, dim3(gridn((size_t)C * Ci * KT)), dim3(256), 0, s, L[i].W, P.Wr[i], C, Ci, KT);
+      ASTK_LAUNCH_CHECK();
+      const long prow = (long)(P.Tn[i - 1] + 2 * P.padA[i - 1]) * Ci;
+      GemmArgs g = gemm_args(rows, C, KT * Ci, mat2(P.HP[i - 1], P.Tn[i], prow, (long)d->st[i] * Ci), mat(P.Wr[i], (long)KT * Ci),
+                             P.Y[i], C);
+      ASTK_TRY(gemm_launch(GEMM_NT, g, s));
+    }
+    // ---- batch statistics -> scale/shift
+    if (train) {
+      ASTK_TRY(fill_zero(P.stat, 2 * (size_t)C * sizeof(double), s));
+      const int rpb = 128;
+      hipLaunchKernelGGL(k_colstats, dim3(cdiv(rows, rpb)), dim3(256), 0, s, P.Y[i], rows, C, P.stat, rpb);
+      ASTK_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, s, P.stat, C, (double)rows, L[i].gamma, L[i].beta,
+                       L[i].avg_mean, L[i].avg_var, P.bn[i], d->bn_eps, d->bn_decay, train);
+    ASTK_LAUNCH_CHECK();
+    if (i < P.n - 1) {
+      ASTK_TRY(fill_zero(P.HP[i], (size_t)B * F * (P.Tn[i] + 2 * P.padA[i]) * C * sizeof(float), s));
+      hipLaunchKernelGGL(k_bn_relu_rows, dim3(gridn((size_t)rows * C / 4)), dim3(256), 0, s, P.Y[i], P.bn[i], P.HP[i], rows, C,
+                         P.Tn[i], P.padA[i]);
+      ASTK_LAUNCH_CHECK();
+    } else {
+      const size_t shm = (size_t)C * F * sizeof(float);
+      ASTK_CHECK(shm <= 64 * 1024, "cnn: C*F' too large for the re-layout tile (%zu bytes)", shm);
+      hipLaunchKernelGGL(k_bn_relu_to_seq, dim3(P.Tn[i], B), dim3(256), shm, s, P.Y[i], P.bn[i], out, B, F, P.Tn[i], C);
+      ASTK_LAUNCH_CHECK();
+    }
+  }
+  return 0;
+}
+
+int astk_conv_bn_relu_bwd(const astk_cnn_desc* d, const astk_cnn_layer_params* L, const astk_cnn_layer_grads* Gr, float* d_out,
+                          void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CnnPlan P;
+  ASTK_TRY(make_plan(d, ws, P));
+  ASTK_CHECK(ws && ws_bytes >= P.bytes, "conv_bn_relu_bwd: workspace too small");
+  ASTK_CHECK(d_out && L && Gr, "conv_bn_relu_bwd: null pointer");
+  const int B = P.B, F = P.F;
+  {
+    const int i = P.n - 1;
+    const size_t shm = (size_t)P.Cn[i] * F * sizeof(float);
+    hipLaunchKernelGGL(k_seq_to_rows, dim3(P.Tn[i], B), dim3(256), shm, s, d_out, P.G, B, F, P.Tn[i], P.Cn[i]);
+    ASTK_LAUNCH_CHECK();
+  }
+  for (int i = P.n - 1; i >= 0; --i) {
+    const int C = P.Cn[i], rows = P.rows[i];
+    // ---- ReLU + BatchNorm backward: G (grad wrt post-ReLU) -> DY[i] (grad wrt raw conv output)
+    ASTK_TRY(fill_zero(P.stat, 2 * (size_t)C * sizeof(double), s));
+    const int rpb = 128;
+    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(cdiv(rows, rpb)), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], rows, C, P.stat, rpb);
+    ASTK_LAUNCH_CHECK();
+    const int Tp = P.Tn[i] + P.dF[i] + P.dB[i];
+    if (P.dF[i] + P.dB[i] > 0) ASTK_TRY(fill_zero(P.DY[i], (size_t)B * F * Tp * C * sizeof(float), s));
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(gridn((size_t)rows * C)), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], P.stat, P.DY[i], rows, C,
+                       P.Tn[i], P.dF[i], P.dB[i], Gr[i].dgamma, Gr[i].dbeta);
+    ASTK_LAUNCH_CHECK();
+    if (i == 0) {
+      // ---- wgrad layer 0: dW0p[C0][K0p] = DY0^T P0
+      ASTK_TRY(fill_zero(P.dWr, (size_t)C * P.K0p * sizeof(float), s));
+      const int ks = ksplit_for(1, rows);
+      ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(C, P.K0p, rows, mat(P.DY[0], C), mat(P.P0, P.K0p), P.dWr, P.K0p, nullptr, GEMM_ATOMIC, ks), s));
+      ASTK_TRY(add2d_f32(Gr[0].dW, P.K0, P.dWr, P.K0p, C, P.K0, s));
+    } else {
+      const int Ci = P.Cn[i - 1], KT = d->kt[i], st = d->st[i], pt = d->pt[i];
+      const long dyrow = (long)Tp * C;                                  // per (b,f) group of the padded dY
+      const long hprow = (long)(P.Tn[i - 1] + 2 * P.padA[i - 1]) * Ci;  // per (b,f) group of HP[i-1]
+      // ---- wgrad: dWr[co][kt*Ci+ci] = sum_rows DY[row][co] * window(row)[k]
+      ASTK_TRY(fill_zero(P.dWr, (size_t)C * KT * Ci * sizeof(float), s));
+      {
+        MatView A = mat2(P.DY[i] + (long)P.dF[i] * C, P.Tn[i], dyrow, C);
+        MatView Bm = mat2(P.HP[i - 1], P.Tn[i], hprow, (long)st * Ci);
+        const long tiles = (long)cdiv(C, 128) * cdiv(KT * Ci, 128);
+        ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(C, KT * Ci, rows, A, Bm, P.dWr, (long)KT * Ci, nullptr, GEMM_ATOMIC, ksplit_for(tiles, rows)), s));
+      }
+      hipLaunchKernelGGL(k_unpack_dw, dim3(gridn((size_t)C * Ci * KT)), dim3(256), 0, s, P.dWr, Gr[i].dW, C, Ci, KT);
+      ASTK_LAUNCH_CHECK();
+      // ---- dgrad: one window GEMM per stride phase rho of the input position t_in = rho + st*j
+      for (int rho = 0; rho < st && rho < P.Tn[i - 1]; ++rho) {
+        const int r = (rho + pt) % st;
+        const int na = (KT - r + st - 1) / st;
+        if (na <= 0) {   // no tap reaches this phase: gradient is zero
+          continue;
+        }
+        const int nj = (P.Tn[i - 1] - rho + st - 1) / st;
+        const int q0 = (rho + pt) / st;
+        hipLaunchKernelGGL(k_phase_w, dim3(gridn((size_t)Ci * na * C)), dim3(256), 0, s, L[i].W, P.Wd, C, Ci, KT, r, st, na);
+        ASTK_LAUNCH_CHECK();
+        const long start = (long)(q0 - na + 1 + P.dF[i]);
+        ASTK_CHECK(start >= 0, "cnn dgrad: negative window start");
+        GemmArgs g = gemm_args(B * F * nj, Ci, na * C, mat2(P.DY[i] + start * C, nj, dyrow, C), mat(P.Wd, (long)na * C),
+                               P.G + (long)rho * Ci, Ci);
+        g.c_tn = nj;
+        g.c_sg = (long)P.Tn[i - 1] * Ci;
+        g.c_st = (long)st * Ci;
+        ASTK_TRY(gemm_launch(GEMM_NT, g, s));
+      }
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"

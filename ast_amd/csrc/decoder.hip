@@ -1,0 +1,499 @@
+// Attention decoder loop (seq2seq.py:318-333, 361-473) and its hand-written backward.
+//
+// Per step s (all on one stream, graph-capturable; the teacher-forcing coin of quirk Q4 is a device flag so
+// the launch sequence is static):
+//   embed(+dropout) into the [emb ; ht_{s-1}] input-feeding buffer -> fused LSTM cells (row-panel MFMA +
+//   gate epilogue) -> q = Wa h + ba -> attention scan (attn.hip) -> ht = tanh(Wc[cv;h] + bc) (written to HT and
+//   into the next step's concat buffer) -> logits = Wo ht + bo -> fused softmax-CE / argmax / dlogits.
+// Everything the backward needs is saved step-major in the workspace; weight gradients are NOT computed per
+// step: the per-step data-path gradients (dz, d_pre, dq, ...) are saved and every dW is one batched TN GEMM
+// over S*B rows after the loop; d_enc_states is one batched GEMM over the saved (alpha, ds).
+#include "common.h"
+
+namespace astk {
+
+namespace {
+
+struct DecPlan {
+  int B, L, S, T, Tp, H, E, A, V, Vp, XI, nl;
+  int* TOK;      // [S][B] token fed at step s
+  int* PRED;     // [S][B] argmax of step s
+  float* X0;     // [S][B][XI]  concat(emb, ht_prev)
+  float* G[ASTK_MAX_RNN_LAYERS];    // [S][B][4H] gates -> dz
+  float* C[ASTK_MAX_RNN_LAYERS];    // [(S+1)][B][H], C[0] = c0
+  float* HR[ASTK_MAX_RNN_LAYERS];   // [(S+1)][B][H], HR[0] = h0
+  float* HD[ASTK_MAX_RNN_LAYERS];   // [S][B][H] dropped outputs of layers < top (with masks)
+  float* Q;      // [S][B][H]
+  float* ALPHA;  // [S][B][Tp]
+  float* CVH;    // [S][B][2H]  concat(cv, h_top_dropped)
+  float* HT;     // [(S+1)][B][A], HT[0] = 0
+  float* LOGITS; // [S][B][Vp] -> dlogits
+  float* LOSSROWS;  // [S][B]
+  // backward
+  float* DPRE;   // [S][B][A]
+  float* DCVH;   // [S][B][2H]
+  float* DS;     // [S][B][Tp]
+  float* DQ;     // [S][B][H]
+  float* DX0;    // [S][B][XI]
+  float* DHTOP;  // [B][H]
+  float* DC[ASTK_MAX_RNN_LAYERS][2];
+  float* WoT;    // [A][Vp]
+  float* WcT;    // [2H][A]
+  float* WaT;    // [H][H]
+  float* WuT[ASTK_MAX_RNN_LAYERS];  // [in][4H]
+  float* WlT[ASTK_MAX_RNN_LAYERS];  // [H][4H]
+  float* ZERO;   // [B][max(A,H)] zeros
+  void* attn_ws;
+  size_t bytes;
+};
+
+int make_plan(const astk_decoder_desc* d, void* ws, DecPlan& P) {
+  ASTK_CHECK(d && d->B > 0 && d->L >= 2 && d->T > 0 && d->V > 1, "decoder: bad dims");
+  ASTK_CHECK(d->n_layers >= 1 && d->n_layers <= ASTK_MAX_RNN_LAYERS, "decoder: layers");
+  ASTK_CHECK((d->H % 4) == 0 && (d->E % 4) == 0 && (d->A % 4) == 0, "decoder: H, E, A must be multiples of 4");
+  P.B = d->B; P.L = d->L; P.S = d->L - 1; P.T = d->T; P.Tp = (d->T + 3) / 4 * 4;
+  P.H = d->H; P.E = d->E; P.A = d->A; P.V = d->V; P.Vp = (d->V + 3) / 4 * 4; P.XI = d->E + d->A; P.nl = d->n_layers;
+  Carver c(ws);
+  const size_t S = P.S, B = P.B, H = P.H;
+  P.TOK = c.take<int>(S * B);
+  P.PRED = c.take<int>(S * B);
+  P.X0 = c.take<float>(S * B * P.XI);
+  for (int l = 0; l < P.nl; ++l) {
+    P.G[l] = c.take<float>(S * B * 4 * H);
+    P.C[l] = c.take<float>((S + 1) * B * H);
+    P.HR[l] = c.take<float>((S + 1) * B * H);
+    P.HD[l] = c.take<float>(S * B * H);
+    P.DC[l][0] = c.take<float>(B * H);
+    P.DC[l][1] = c.take<float>(B * H);
+    const size_t in = l == 0 ? P.XI : H;
+    P.WuT[l] = c.take<float>(in * 4 * H);
+    P.WlT[l] = c.take<float>(H * 4 * H);
+  }
+  P.Q = c.take<float>(S * B * H);
+  P.ALPHA = c.take<float>(S * B * P.Tp);
+  P.CVH = c.take<float>(S * B * 2 * H);
+  P.HT = c.take<float>((S + 1) * B * P.A);
+  P.LOGITS = c.take<float>(S * B * P.Vp);
+  P.LOSSROWS = c.take<float>(S * B);
+  P.DPRE = c.take<float>(S * B * P.A);
+  P.DCVH = c.take<float>(S * B * 2 * H);
+  P.DS = c.take<float>(S * B * P.Tp);
+  P.DQ = c.take<float>(S * B * H);
+  P.DX0 = c.take<float>(S * B * P.XI);
+  P.DHTOP = c.take<float>(B * H);
+  P.WoT = c.take<float>((size_t)P.A * P.Vp);
+  P.WcT = c.take<float>(2 * H * P.A);
+  P.WaT = c.take<float>(H * H);
+  P.ZERO = c.take<float>(B * (size_t)(P.A > P.H ? P.A : P.H));
+  P.attn_ws = c.take<char>(attn_ws_bytes(P.B, P.T, P.H));
+  P.bytes = c.total();
+  return 0;
+}
+
+// tok = use_truth[s] ? y[b][s] : pred_prev[b] ; x0[b][0:E] = embed[tok] * mask   (seq2seq.py:365, 431-436)
+__global__ void k_embed(const float* __restrict__ embed, const int32_t* __restrict__ y, int L, int s, const int32_t* __restrict__ use_truth,
+                        const int32_t* __restrict__ pred_prev, const int32_t* __restrict__ tokens_direct, int32_t* __restrict__ tok_out,
+                        const float* __restrict__ mask, float* __restrict__ x0, int B, int E, int XI, int V) {
+  const int b = blockIdx.x;
+  int tok;
+  if (tokens_direct) tok = tokens_direct[b];
+  else tok = (use_truth[s] || !pred_prev) ? y[(long)b * L + s] : pred_prev[b];
+  tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+  if (threadIdx.x == 0 && tok_out) tok_out[b] = tok;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float v = embed[(long)tok * E + e];
+    if (mask) v *= mask[(long)b * E + e];
+    x0[(long)b * XI + e] = v;
+  }
+}
+
+// d_embed[tok][e] += dx0[s][b][e] * mask  for all (s,b)
+__global__ void k_embed_bwd(float* __restrict__ d_embed, const int32_t* __restrict__ tok, const float* __restrict__ dx0,
+                            const float* __restrict__ mask, int SB, int E, int XI) {
+  const int r = blockIdx.x;
+  if (r >= SB) return;
+  const int t = tok[r];
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float v = dx0[(long)r * XI + e];
+    if (mask) v *= mask[(long)r * E + e];
+    atomicAdd(&d_embed[(long)t * E + e], v);
+  }
+}
+
+// One block per row: log-softmax, weighted NLL / count, first-max argmax, dlogits in place (Chainer-sem A6).
+__global__ __launch_bounds__(256) void k_softmax_ce(int V, long ld, float* __restrict__ logits, const int32_t* __restrict__ targets,
+                                                    long t_stride, const float* __restrict__ cw, float inv_count,
+                                                    float* __restrict__ loss_rows, int32_t* __restrict__ argmax) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int b = blockIdx.x;
+  float* x = logits + (long)b * ld;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float mx = -INFINITY;
+  int mi = 0x7fffffff;
+  for (int v = threadIdx.x; v < V; v += 256) {
+    const float a = x[v];
+    if (a > mx) { mx = a; mi = v; }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(mx, o);
+    const int oi = __shfl_xor(mi, o);
+    if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+  }
+  if (lane == 0) { sv[wave] = mx; si[wave] = mi; }
+  __syncthreads();
+  mx = sv[0]; mi = si[0];
+  for (int w = 1; w < 4; ++w)
+    if (sv[w] > mx || (sv[w] == mx && si[w] < mi)) { mx = sv[w]; mi = si[w]; }
+  __syncthreads();
+  float sum = 0.f;
+  for (int v = threadIdx.x; v < V; v += 256) sum += expf(x[v] - mx);
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if (lane == 0) sv[wave] = sum;
+  __syncthreads();
+  sum = sv[0] + sv[1] + sv[2] + sv[3];
+  const float lse = mx + logf(sum);
+  int t = targets[(long)b * t_stride];
+  const bool ignore = t < 0;                      // ignore_label = -1 never occurs on this path (PAD is 0)
+  t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+  const float w = ignore ? 0.f : (cw ? cw[t] : 1.f);
+  const float xt = x[t];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (loss_rows) loss_rows[b] = -(xt - lse) * w * inv_count;
+    if (argmax) argmax[b] = mi;
+  }
+  const float scale = w * inv_count;
+  for (int v = threadIdx.x; v < ld; v += 256) {
+    float g = 0.f;
+    if (v < V) {
+      g = expf(x[v] - lse) * scale;
+      if (v == t) g -= scale;
+    }
+    x[v] = g;
+  }
+}
+
+__global__ void k_sum_to(const float* __restrict__ src, int n, float* __restrict__ dst) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)src[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *dst = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void k_copy_i32(int32_t* dst, const int32_t* src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+RowGemmArgs rg(int M, int N, const float* A, long lda, const float* W, long ldw, int K, float* out, long ld_out) {
+  RowGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.npairs = 1;
+  a.p[0].A = A; a.p[0].lda = lda; a.p[0].W = W; a.p[0].ldw = ldw; a.p[0].K = K;
+  a.M = M; a.N = N; a.out = out; a.ld_out = ld_out;
+  return a;
+}
+
+int ksplit_rows(long tiles, int rows) {
+  long s = 256 / (tiles > 0 ? tiles : 1);
+  if (s < 1) s = 1;
+  long smax = rows / 128;
+  if (smax < 1) smax = 1;
+  return (int)(s > smax ? smax : s);
+}
+
+// dW (M x N) += A^T B over `rows` rows (A: rows x M, B: rows x N)
+int wgrad(float* dW, long ldw, int M, int N, const float* A, long lda, const float* Bm, long ldb, int rows, hipStream_t s) {
+  const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
+  return gemm_launch(GEMM_TN, gemm_args(M, N, rows, mat(A, lda), mat(Bm, ldb), dW, ldw, nullptr, GEMM_ATOMIC, ksplit_rows(tiles, rows)), s);
+}
+
+int cell_fwd(const DecPlan& P, const astk_decoder_params* prm, int l, const float* x_in, long ld_x, int in, const float* h_prev,
+             const float* c_prev, float* gates, float* c_out, float* h_out, const float* mask, float* hd_out, long ld_hd,
+             hipStream_t s) {
+  LstmCellFwdArgs c;
+  memset(&c, 0, sizeof(c));
+  c.npairs = 2;
+  c.p[0].A = h_prev; c.p[0].lda = P.H; c.p[0].W = prm->lstm[l].Wl; c.p[0].ldw = P.H; c.p[0].K = P.H;
+  c.p[1].A = x_in; c.p[1].lda = ld_x; c.p[1].W = prm->lstm[l].Wu; c.p[1].ldw = in; c.p[1].K = in;
+  c.B = P.B; c.h = P.H;
+  c.bias = prm->lstm[l].b;
+  c.c_prev = c_prev;
+  c.gates = gates; c.ld_g = 4 * P.H;
+  c.c_out = c_out; c.h_out = h_out;
+  c.mask = mask;
+  c.hd_out = hd_out; c.ld_hd = ld_hd;
+  return lstm_cell_fwd_launch(&c, 1, s);
+}
+
+}  // namespace
+
+int softmax_ce_launch(int B, int V, long ld, float* logits, const int32_t* targets, long t_stride, const float* cw, float inv_count,
+                      float* loss_rows, int32_t* argmax, hipStream_t s) {
+  ASTK_CHECK(B > 0 && V > 0 && ld >= V && logits && targets, "softmax_ce: bad arguments");
+  hipLaunchKernelGGL(k_softmax_ce, dim3(B), dim3(256), 0, s, V, ld, logits, targets, t_stride, cw, inv_count, loss_rows, argmax);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace astk
+
+using namespace astk;
+
+extern "C" {
+
+size_t astk_decoder_workspace_bytes(const astk_decoder_desc* d) {
+  DecPlan P;
+  if (make_plan(d, nullptr, P) != 0) return 0;
+  return P.bytes;
+}
+
+int astk_softmax_ce_fwd(int B, int V, long ld, float* logits_inout, const int32_t* targets, long t_stride, const float* class_weight,
+                        float inv_count, float* loss_rows, int32_t* argmax, void* stream) {
+  return softmax_ce_launch(B, V, ld, logits_inout, targets, t_stride, class_weight, inv_count, loss_rows, argmax, (hipStream_t)stream);
+}
+
+int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* prm, const float* enc, const float* c0, const float* h0,
+                     const int32_t* y, const int32_t* use_truth, const float* emb_mask, const float* rnn_masks, float* loss,
+                     int32_t* pred, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DecPlan P;
+  ASTK_TRY(make_plan(d, ws, P));
+  ASTK_CHECK(ws && ws_bytes >= P.bytes, "decoder_fwd: workspace too small (%zu < %zu)", ws_bytes, P.bytes);
+  ASTK_CHECK(prm && enc && c0 && h0 && y && use_truth && loss, "decoder_fwd: null pointer");
+  const int B = P.B, S = P.S, H = P.H, E = P.E, A = P.A, V = P.V, XI = P.XI, nl = P.nl;
+  const size_t bh = (size_t)B * H;
+  // initial states and zero attention vector (seq2seq.py:318-333, :420)
+  for (int l = 0; l < nl; ++l) {
+    ASTK_TRY(copy_f32(P.C[l], c0 + l * bh, bh, s));
+    ASTK_TRY(copy_f32(P.HR[l], h0 + l * bh, bh, s));
+  }
+  ASTK_TRY(fill_zero(P.HT, (size_t)B * A * sizeof(float), s));
+  ASTK_TRY(fill_zero(P.X0, (size_t)B * XI * sizeof(float), s));   // ht_{-1} half of the first concat buffer
+  const int top = nl - 1;
+  for (int st = 0; st < S; ++st) {
+    float* x0 = P.X0 + (size_t)st * B * XI;
+    hipLaunchKernelGGL(k_embed, dim3(B), dim3(128), 0, s, prm->embed, y, P.L, st, use_truth, st > 0 ? P.PRED + (size_t)(st - 1) * B : nullptr,
+                       (const int32_t*)nullptr, P.TOK + (size_t)st * B, emb_mask ? emb_mask + (size_t)st * B * E : nullptr, x0, B, E, XI, V);
+    ASTK_LAUNCH_CHECK();
+    float* cvh = P.CVH + (size_t)st * B * 2 * H;
+    const float* x_in = x0;
+    long ld_x = XI;
+    int in = XI;
+    for (int l = 0; l < nl; ++l) {
+      const float* mask = rnn_masks ? rnn_masks + ((size_t)l * S + st) * bh : nullptr;
+      float* hd;
+      long ld_hd;
+      if (l == top) { hd = cvh + H; ld_hd = 2 * H; }
+      else { hd = P.HD[l] + (size_t)st * bh; ld_hd = H; }
+      ASTK_TRY(cell_fwd(P, prm, l, x_in, ld_x, in, P.HR[l] + (size_t)st * bh, P.C[l] + (size_t)st * bh, P.G[l] + (size_t)st * B * 4 * H,
+                        P.C[l] + (size_t)(st + 1) * bh, P.HR[l] + (size_t)(st + 1) * bh, mask, hd, ld_hd, s));
+      x_in = hd; ld_x = ld_hd; in = H;
+    }
+    // q = Wa h + ba
+    float* q = P.Q + (size_t)st * bh;
+    {
+      RowGemmArgs a = rg(B, H, cvh + H, 2 * H, prm->Wa, H, H, q, H);
+      a.bias = prm->ba;
+      ASTK_TRY(rowgemm_launch(a, s));
+    }
+    ASTK_TRY(attn_fwd_launch(B, P.T, H, enc, q, H, P.ALPHA + (size_t)st * B * P.Tp, cvh, 2 * H, nullptr, 0, P.attn_ws, s));
+    // ht = tanh(Wc [cv;h] + bc) -> HT[st+1] and the next step's concat buffer
+    float* ht = P.HT + (size_t)(st + 1) * B * A;
+    {
+      RowGemmArgs a = rg(B, A, cvh, 2 * H, prm->Wc, 2 * H, 2 * H, ht, A);
+      a.bias = prm->bc;
+      a.act = ACT_TANH;
+      if (st + 1 < S) { a.out2 = P.X0 + (size_t)(st + 1) * B * XI + E; a.ld_out2 = XI; }
+      ASTK_TRY(rowgemm_launch(a, s));
+    }
+    float* lg = P.LOGITS + (size_t)st * B * P.Vp;
+    {
+      RowGemmArgs a = rg(B, V, ht, A, prm->Wo, A, A, lg, P.Vp);
+      a.bias = prm->bo;
+      ASTK_TRY(rowgemm_launch(a, s));
+    }
+    ASTK_TRY(softmax_ce_launch(B, V, P.Vp, lg, y + st + 1, P.L, prm->class_weight, 1.f / (float)B, P.LOSSROWS + (size_t)st * B,
+                               P.PRED + (size_t)st * B, s));
+  }
+  hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, s, P.LOSSROWS, S * B, loss);
+  ASTK_LAUNCH_CHECK();
+  if (pred) {
+    hipLaunchKernelGGL(k_copy_i32, dim3(cdiv(S * B, 256)), dim3(256), 0, s, pred, P.PRED, S * B);
+    ASTK_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* prm, const astk_decoder_grads* g, const float* enc,
+                     const float* c0, const float* h0, const int32_t* y, const float* emb_mask, const float* rnn_masks, float* d_enc,
+                     float* d_c0, float* d_h0, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  (void)c0; (void)h0; (void)y;
+  DecPlan P;
+  ASTK_TRY(make_plan(d, ws, P));
+  ASTK_CHECK(ws && ws_bytes >= P.bytes, "decoder_bwd: workspace too small");
+  ASTK_CHECK(prm && g && enc && d_enc && d_c0 && d_h0, "decoder_bwd: null pointer");
+  const int B = P.B, S = P.S, H = P.H, E = P.E, A = P.A, V = P.V, Vp = P.Vp, XI = P.XI, nl = P.nl, T = P.T, Tp = P.Tp;
+  const size_t bh = (size_t)B * H;
+  const int top = nl - 1;
+  // transposed weights for the data-path products (dY W as row-panel NT products)
+  ASTK_TRY(transpose_f32(P.WoT, Vp, prm->Wo, A, V, A, s));        // (V,A) -> (A,Vp)
+  ASTK_TRY(transpose_f32(P.WcT, A, prm->Wc, 2 * H, A, 2 * H, s)); // (A,2H) -> (2H,A)
+  ASTK_TRY(transpose_f32(P.WaT, H, prm->Wa, H, H, H, s));
+  for (int l = 0; l < nl; ++l) {
+    const int in = l == 0 ? XI : H;
+    ASTK_TRY(transpose_f32(P.WuT[l], 4 * H, prm->lstm[l].Wu, in, 4 * H, in, s));   // (4H,in) -> (in,4H)
+    ASTK_TRY(transpose_f32(P.WlT[l], 4 * H, prm->lstm[l].Wl, H, 4 * H, H, s));     // (4H,H)  -> (H,4H)
+  }
+  ASTK_TRY(fill_zero(P.ZERO, (size_t)B * (A > H ? A : H) * sizeof(float), s));
+  for (int st = S - 1; st >= 0; --st) {
+    const bool last = st == S - 1;
+    float* dl = P.LOGITS + (size_t)st * B * Vp;
+    float* dpre = P.DPRE + (size_t)st * B * A;
+    // d_pre = (dlogits Wo + d_ht carried from step st+1 through input feeding) * (1 - ht^2)
+    {
+      RowGemmArgs a = rg(B, A, dl, Vp, P.WoT, Vp, Vp, dpre, A);
+      if (!last) { a.addend = P.DX0 + (size_t)(st + 1) * B * XI + E; a.ld_add = XI; }
+      a.act = ACT_DTANH;
+      a.aux = P.HT + (size_t)(st + 1) * B * A;
+      a.ld_aux = A;
+      ASTK_TRY(rowgemm_launch(a, s));
+    }
+    float* dcvh = P.DCVH + (size_t)st * B * 2 * H;
+    ASTK_TRY(rowgemm_launch(rg(B, 2 * H, dpre, A, P.WcT, A, A, dcvh, 2 * H), s));
+    float* cvh = P.CVH + (size_t)st * B * 2 * H;
+    float* dq = P.DQ + (size_t)st * bh;
+    ASTK_TRY(attn_bwd_launch(B, T, H, enc, P.ALPHA + (size_t)st * B * Tp, cvh, 2 * H, dcvh, 2 * H, P.DS + (size_t)st * B * Tp, dq,
+                             P.attn_ws, s));
+    // gradient wrt the dropped top-layer output: dh_top = dcvh[:, H:] + dq Wa
+    {
+      RowGemmArgs a = rg(B, H, dq, H, P.WaT, H, H, P.DHTOP, H);
+      a.addend = dcvh + H;
+      a.ld_add = 2 * H;
+      ASTK_TRY(rowgemm_launch(a, s));
+    }
+    for (int l = top; l >= 0; --l) {
+      LstmCellBwdArgs c;
+      memset(&c, 0, sizeof(c));
+      c.npairs = 1;
+      c.p[0].A = last ? nullptr : P.G[l] + (size_t)(st + 1) * B * 4 * H;
+      c.p[0].lda = 4 * H; c.p[0].W = P.WlT[l]; c.p[0].ldw = 4 * H; c.p[0].K = last ? 0 : 4 * H;
+      if (l < top) {   // gradient from the layer above at the same step: dz_{l+1,st} Wu_{l+1}
+        c.npairs = 2;
+        c.p[1].A = P.G[l + 1] + (size_t)st * B * 4 * H;
+        c.p[1].lda = 4 * H; c.p[1].W = P.WuT[l + 1]; c.p[1].ldw = 4 * H; c.p[1].K = 4 * H;
+      } else {
+        c.dy = P.DHTOP;
+        c.ld_dy = H;
+      }
+      c.B = B; c.h = H;
+      c.mask = rnn_masks ? rnn_masks + ((size_t)l * S + st) * bh : nullptr;
+      c.dc_next = last ? nullptr : P.DC[l][(st + 1) & 1];
+      c.c_prev = P.C[l] + (size_t)st * bh;
+      c.c_cur = P.C[l] + (size_t)(st + 1) * bh;
+      c.gates_dz = P.G[l] + (size_t)st * B * 4 * H;
+      c.ld_g = 4 * H;
+      c.dc_prev = P.DC[l][st & 1];
+      ASTK_TRY(lstm_cell_bwd_launch(&c, 1, s));
+    }
+    // gradient wrt the concat input [emb ; ht_{st-1}]
+    ASTK_TRY(rowgemm_launch(rg(B, XI, P.G[0] + (size_t)st * B * 4 * H, 4 * H, P.WuT[0], 4 * H, 4 * H, P.DX0 + (size_t)st * B * XI, XI), s));
+  }
+  // ---- gradients wrt the initial states (flow into the encoder's final states, seq2seq.py:326-329)
+  for (int l = 0; l < nl; ++l) {
+    ASTK_TRY(rowgemm_launch(rg(B, H, P.G[l], 4 * H, P.WlT[l], 4 * H, 4 * H, d_h0 + l * bh, H), s));
+    ASTK_TRY(copy_f32(d_c0 + l * bh, P.DC[l][0], bh, s));
+  }
+  // ---- weight gradients: one batched TN GEMM each over the S*B saved rows
+  const int SB = S * B;
+  ASTK_TRY(wgrad(g->dWo, A, V, A, P.LOGITS, Vp, P.HT + (size_t)B * A, A, SB, s));
+  ASTK_TRY(colsum_add_f32(g->dbo, P.LOGITS, Vp, SB, V, s));
+  ASTK_TRY(wgrad(g->dWc, 2 * H, A, 2 * H, P.DPRE, A, P.CVH, 2 * H, SB, s));
+  ASTK_TRY(colsum_add_f32(g->dbc, P.DPRE, A, SB, A, s));
+  ASTK_TRY(wgrad(g->dWa, H, H, H, P.DQ, H, P.CVH + H, 2 * H, SB, s));
+  ASTK_TRY(colsum_add_f32(g->dba, P.DQ, H, SB, H, s));
+  for (int l = 0; l < nl; ++l) {
+    const int in = l == 0 ? XI : H;
+    const float* xin;
+    long ldx;
+    if (l == 0) { xin = P.X0; ldx = XI; }
+    else if (rnn_masks) { xin = P.HD[l - 1]; ldx = H; }
+    else { xin = P.HR[l - 1] + bh; ldx = H; }
+    ASTK_TRY(wgrad(g->lstm[l].dWu, in, 4 * H, in, P.G[l], 4 * H, xin, ldx, SB, s));
+    ASTK_TRY(wgrad(g->lstm[l].dWl, H, 4 * H, H, P.G[l], 4 * H, P.HR[l], H, SB, s));
+    ASTK_TRY(colsum_add_f32(g->lstm[l].db, P.G[l], 4 * H, SB, 4 * H, s));
+  }
+  hipLaunchKernelGGL(k_embed_bwd, dim3(SB), dim3(128), 0, s, g->d_embed, P.TOK, P.DX0, emb_mask, SB, E, XI);
+  ASTK_LAUNCH_CHECK();
+  // ---- d_enc[b] = alpha_b^T d_cv_b + ds_b^T q_b   (batched over b, K = S)
+  {
+    GemmArgs ga = gemm_args(T, H, S, mat(P.ALPHA, (long)B * Tp), mat(P.DCVH, (long)B * 2 * H), d_enc, H);
+    ga.batch = B; ga.sA = Tp; ga.sB = 2 * H; ga.sC = (long)T * H;
+    ASTK_TRY(gemm_launch(GEMM_TN, ga, s));
+    GemmArgs gb = gemm_args(T, H, S, mat(P.DS, (long)B * Tp), mat(P.Q, (long)B * H), d_enc, H, nullptr, GEMM_ACCUM);
+    gb.batch = B; gb.sA = Tp; gb.sB = H; gb.sC = (long)T * H;
+    ASTK_TRY(gemm_launch(GEMM_TN, gb, s));
+  }
+  return 0;
+}
+
+int astk_decoder_step_infer(const astk_decoder_desc* d, const astk_decoder_params* prm, const float* enc, float* c, float* h, float* ht,
+                            const int32_t* tokens, float* logits, float* alpha, int32_t* argmax, void* ws, size_t ws_bytes,
+                            void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DecPlan P;
+  ASTK_TRY(make_plan(d, ws, P));
+  ASTK_CHECK(ws && ws_bytes >= P.bytes, "decoder_step_infer: workspace too small");
+  ASTK_CHECK(prm && enc && c && h && ht && tokens && logits, "decoder_step_infer: null pointer");
+  const int B = P.B, H = P.H, E = P.E, A = P.A, V = P.V, XI = P.XI, nl = P.nl;
+  const size_t bh = (size_t)B * H;
+  float* x0 = P.X0;
+  hipLaunchKernelGGL(k_embed, dim3(B), dim3(128), 0, s, prm->embed, (const int32_t*)nullptr, 0, 0, (const int32_t*)nullptr,
+                     (const int32_t*)nullptr, tokens, (int32_t*)nullptr, (const float*)nullptr, x0, B, E, XI, V);
+  ASTK_LAUNCH_CHECK();
+  ASTK_TRY(copy2d_f32(x0 + E, XI, ht, A, B, A, A, s));
+  float* cvh = P.CVH;
+  const float* x_in = x0;
+  long ld_x = XI;
+  int in = XI;
+  for (int l = 0; l < nl; ++l) {
+    float* hd = l == nl - 1 ? cvh + H : P.HD[l];
+    const long ld_hd = l == nl - 1 ? 2 * H : H;
+    // new states go to scratch first (the cell reads h_prev while other workgroups write h_out)
+    ASTK_TRY(cell_fwd(P, prm, l, x_in, ld_x, in, h + l * bh, c + l * bh, P.G[l], P.C[l], P.HR[l], nullptr, hd, ld_hd, s));
+    ASTK_TRY(copy_f32(c + l * bh, P.C[l], bh, s));
+    ASTK_TRY(copy_f32(h + l * bh, P.HR[l], bh, s));
+    x_in = hd; ld_x = ld_hd; in = H;
+  }
+  {
+    RowGemmArgs a = rg(B, H, cvh + H, 2 * H, prm->Wa, H, H, P.Q, H);
+    a.bias = prm->ba;
+    ASTK_TRY(rowgemm_launch(a, s));
+  }
+  ASTK_TRY(attn_fwd_launch(B, P.T, H, enc, P.Q, H, P.ALPHA, cvh, 2 * H, nullptr, 0, P.attn_ws, s));
+  if (alpha) ASTK_TRY(copy2d_f32(alpha, P.T, P.ALPHA, P.Tp, B, P.T, P.T, s));
+  {
+    RowGemmArgs a = rg(B, A, cvh, 2 * H, prm->Wc, 2 * H, 2 * H, ht, A);
+    a.bias = prm->bc;
+    a.act = ACT_TANH;
+    ASTK_TRY(rowgemm_launch(a, s));
+  }
+  {
+    RowGemmArgs a = rg(B, V, ht, A, prm->Wo, A, A, logits, V);
+    a.bias = prm->bo;
+    ASTK_TRY(rowgemm_launch(a, s));
+  }
+  if (argmax) {
+    // argmax only: run the CE kernel on a scratch copy so that `logits` stays intact
+    ASTK_TRY(copy2d_f32(P.LOGITS, P.Vp, logits, V, B, V, P.Vp, s));
+    ASTK_TRY(softmax_ce_launch(B, V, P.Vp, P.LOGITS, tokens, 1, nullptr, 1.f, nullptr, argmax, s));
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,247 @@
+// Encoder LSTM stacks (seq2seq.py:182-242): n_dirs independent stacks of L.LSTM links.
+//
+// Schedule (one HIP stream, graph-capturable, no host sync):
+//   per layer: ONE batched-over-time MFMA GEMM for the upward projection of each direction
+//              (ZG[d][l] = X W_u^T + b, rows in loop-step order; the reverse direction reads frames through the
+//              Q1 permutation table 0,T-1,...,1 instead of a permuted copy), then T launches of the fused cell
+//              kernel (both directions in one launch: lateral product on f32 MFMA + interleaved-gate epilogue,
+//              activated gates overwrite ZG in place, dropped output written straight into the (B,T,H)
+//              enc_states slice for the top layer -- no concat growth, no flipud copy).
+//   backward : per layer, top down: T launches of the fused backward cell (dh_rec = dz_{t+1} Wl via the
+//              transposed weight, gate derivatives, dz overwrites the gates in place), then batched GEMMs for
+//              dWl, dWu, db and the gradient wrt the layer input.
+// HBM layout (per direction d, layer l, all f32, step-major):
+//   ZG (T,B,4h) gates -> dz | HR (T,B,h) raw h | CC (T,B,h) cell | HD (T,B,h) dropped output (only with masks)
+#include "common.h"
+
+namespace astk {
+
+namespace {
+
+struct LstmPlan {
+  int T, B, in, h, nl, nd;
+  int* perm;      // [T] frame consumed at loop step i by direction 1: (T-i)%T
+  int* inv;       // [T] loop step of direction 1 that consumed frame f
+  float* ZG[2][ASTK_MAX_RNN_LAYERS];
+  float* HR[2][ASTK_MAX_RNN_LAYERS];
+  float* CC[2][ASTK_MAX_RNN_LAYERS];
+  float* HD[2][ASTK_MAX_RNN_LAYERS];
+  float* WlT[2][ASTK_MAX_RNN_LAYERS];  // (h, 4h)
+  float* DX[2];                        // (T,B,h) gradient wrt a layer's input (layers >= 1)
+  float* DC[2][2];                     // dc ping-pong (B,h)
+  size_t bytes;
+};
+
+int make_plan(const astk_lstm_stack_desc* d, void* ws, bool with_masks, LstmPlan& P) {
+  ASTK_CHECK(d && d->T > 0 && d->B > 0 && d->in_dim > 0 && d->h > 0, "lstm_stack: bad dims");
+  ASTK_CHECK(d->n_layers >= 1 && d->n_layers <= ASTK_MAX_RNN_LAYERS && (d->n_dirs == 1 || d->n_dirs == 2), "lstm_stack: layers/dirs");
+  ASTK_CHECK((d->in_dim % 4) == 0 && (d->h % 4) == 0, "lstm_stack: in_dim and h must be multiples of 4");
+  P.T = d->T; P.B = d->B; P.in = d->in_dim; P.h = d->h; P.nl = d->n_layers; P.nd = d->n_dirs;
+  Carver c(ws);
+  const size_t tb = (size_t)P.T * P.B;
+  P.perm = c.take<int>(P.T);
+  P.inv = c.take<int>(P.T);
+  for (int dd = 0; dd < P.nd; ++dd) {
+    for (int l = 0; l < P.nl; ++l) {
+      P.ZG[dd][l] = c.take<float>(tb * 4 * P.h);
+      P.HR[dd][l] = c.take<float>(tb * P.h);
+      P.CC[dd][l] = c.take<float>(tb * P.h);
+      // the workspace size must not depend on whether masks are passed: always reserve HD
+      P.HD[dd][l] = c.take<float>(tb * P.h);
+      P.WlT[dd][l] = c.take<float>((size_t)P.h * 4 * P.h);
+    }
+    P.DX[dd] = c.take<float>(tb * P.h);
+    P.DC[dd][0] = c.take<float>((size_t)P.B * P.h);
+    P.DC[dd][1] = c.take<float>((size_t)P.B * P.h);
+  }
+  (void)with_masks;
+  P.bytes = c.total();
+  return 0;
+}
+
+__global__ void k_perm(int* perm, int* inv, int T) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < T) {
+    const int f = (T - i) % T;   // quirk Q1: X[-i]
+    perm[i] = f;
+    inv[f] = i;
+  }
+}
+// expands a frame permutation to (T*B) row indices: rows[i*B+b] = perm[i]*B + b
+__global__ void k_rowidx(const int* perm, int* rows, int T, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < T * B) rows[i] = perm[i / B] * B + (i % B);
+}
+
+}  // namespace
+}  // namespace astk
+
+using namespace astk;
+
+extern "C" {
+
+size_t astk_lstm_stack_workspace_bytes(const astk_lstm_stack_desc* d) {
+  LstmPlan P;
+  if (make_plan(d, nullptr, true, P) != 0) return 0;
+  // + two (T*B) row-index tables
+  return P.bytes + 2 * align_up((size_t)d->T * d->B * sizeof(int), 256);
+}
+
+int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* prm, const float* x, const float* masks,
+                        float* enc_states, float* cT, float* hT, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  LstmPlan P;
+  ASTK_TRY(make_plan(d, ws, masks != nullptr, P));
+  const size_t need = astk_lstm_stack_workspace_bytes(d);
+  ASTK_CHECK(ws && ws_bytes >= need, "lstm_stack_fwd: workspace too small (%zu < %zu)", ws_bytes, need);
+  ASTK_CHECK(prm && x && enc_states, "lstm_stack_fwd: null pointer");
+  const int T = P.T, B = P.B, h = P.h, H = P.nd * P.h;
+  int* rows_perm = (int*)((char*)ws + P.bytes);
+  int* rows_inv = (int*)((char*)rows_perm + align_up((size_t)T * B * sizeof(int), 256));
+  hipLaunchKernelGGL(k_perm, dim3(cdiv(T, 256)), dim3(256), 0, s, P.perm, P.inv, T);
+  ASTK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_rowidx, dim3(cdiv(T * B, 256)), dim3(256), 0, s, P.perm, rows_perm, T, B);
+  ASTK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_rowidx, dim3(cdiv(T * B, 256)), dim3(256), 0, s, P.inv, rows_inv, T, B);
+  ASTK_LAUNCH_CHECK();
+  const size_t bh = (size_t)B * h;
+  for (int l = 0; l < P.nl; ++l) {
+    const int in = l == 0 ? P.in : h;
+    for (int dd = 0; dd < P.nd; ++dd) {
+      const astk_lstm_params& p = prm[dd * P.nl + l];
+      ASTK_CHECK(p.Wu && p.b && p.Wl, "lstm_stack_fwd: null parameter (dir %d layer %d)", dd, l);
+      MatView A;
+      if (l == 0) A = dd == 0 ? mat(x, in) : mat_idx(x, in, rows_perm);
+      else A = mat(masks ? P.HD[dd][l - 1] : P.HR[dd][l - 1], h);
+      ASTK_TRY(gemm_launch(GEMM_NT, gemm_args(T * B, 4 * h, in, A, mat(p.Wu, in), P.ZG[dd][l], 4 * h, p.b), s));
+    }
+    const bool top = l == P.nl - 1;
+    for (int i = 0; i < T; ++i) {
+      LstmCellFwdArgs cells[2];
+      for (int dd = 0; dd < P.nd; ++dd) {
+        const astk_lstm_params& p = prm[dd * P.nl + l];
+        LstmCellFwdArgs& c = cells[dd];
+        memset(&c, 0, sizeof(c));
+        c.npairs = 1;
+        c.p[0].A = i > 0 ? P.HR[dd][l] + (size_t)(i - 1) * bh : nullptr;
+        c.p[0].lda = h;
+        c.p[0].W = p.Wl;
+        c.p[0].ldw = h;
+        c.p[0].K = i > 0 ? h : 0;     // h is None at the first step: lateral skipped (Chainer-sem A1)
+        c.B = B; c.h = h;
+        c.zx = P.ZG[dd][l] + (size_t)i * B * 4 * h;
+        c.ld_zx = 4 * h;
+        c.c_prev = i > 0 ? P.CC[dd][l] + (size_t)(i - 1) * bh : nullptr;
+        c.gates = P.ZG[dd][l] + (size_t)i * B * 4 * h;
+        c.ld_g = 4 * h;
+        c.c_out = P.CC[dd][l] + (size_t)i * bh;
+        c.h_out = P.HR[dd][l] + (size_t)i * bh;
+        c.mask = masks ? masks + (((size_t)dd * P.nl + l) * T + i) * bh : nullptr;
+        if (!top && masks) { c.hd_out = P.HD[dd][l] + (size_t)i * bh; c.ld_hd = h; }
+        if (top) {
+          const int pos = dd == 0 ? i : T - 1 - i;   // flipud of the reverse stack's output list
+          c.hd_out2 = enc_states + (size_t)pos * H + (size_t)dd * h;
+          c.ld_hd2 = (long)T * H;
+        }
+      }
+      ASTK_TRY(lstm_cell_fwd_launch(cells, P.nd, s));
+    }
+    for (int dd = 0; dd < P.nd; ++dd) {
+      if (cT) ASTK_TRY(copy_f32(cT + ((size_t)dd * P.nl + l) * bh, P.CC[dd][l] + (size_t)(T - 1) * bh, bh, s));
+      if (hT) ASTK_TRY(copy_f32(hT + ((size_t)dd * P.nl + l) * bh, P.HR[dd][l] + (size_t)(T - 1) * bh, bh, s));
+    }
+  }
+  return 0;
+}
+
+int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* prm, const astk_lstm_grads* gr, const float* x,
+                        const float* masks, const float* d_enc, const float* d_cT, const float* d_hT, float* dx, void* ws,
+                        size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  LstmPlan P;
+  ASTK_TRY(make_plan(d, ws, masks != nullptr, P));
+  const size_t need = astk_lstm_stack_workspace_bytes(d);
+  ASTK_CHECK(ws && ws_bytes >= need, "lstm_stack_bwd: workspace too small");
+  ASTK_CHECK(prm && gr && x && d_enc, "lstm_stack_bwd: null pointer");
+  const int T = P.T, B = P.B, h = P.h, H = P.nd * P.h;
+  int* rows_perm = (int*)((char*)ws + P.bytes);
+  int* rows_inv = (int*)((char*)rows_perm + align_up((size_t)T * B * sizeof(int), 256));
+  const size_t bh = (size_t)B * h;
+  for (int l = P.nl - 1; l >= 0; --l) {
+    const bool top = l == P.nl - 1;
+    const int in = l == 0 ? P.in : h;
+    for (int dd = 0; dd < P.nd; ++dd)
+      ASTK_TRY(transpose_f32(P.WlT[dd][l], 4 * h, prm[dd * P.nl + l].Wl, h, 4 * h, h, s));
+    for (int i = T - 1; i >= 0; --i) {
+      LstmCellBwdArgs cells[2];
+      for (int dd = 0; dd < P.nd; ++dd) {
+        LstmCellBwdArgs& c = cells[dd];
+        memset(&c, 0, sizeof(c));
+        c.npairs = 1;
+        const bool last = i == T - 1;
+        c.p[0].A = last ? nullptr : P.ZG[dd][l] + (size_t)(i + 1) * B * 4 * h;   // dz of step i+1
+        c.p[0].lda = 4 * h;
+        c.p[0].W = P.WlT[dd][l];
+        c.p[0].ldw = 4 * h;
+        c.p[0].K = last ? 0 : 4 * h;
+        c.B = B; c.h = h;
+        c.dh_add = (last && d_hT) ? d_hT + ((size_t)dd * P.nl + l) * bh : nullptr;
+        if (top) {
+          const int pos = dd == 0 ? i : T - 1 - i;
+          c.dy2 = d_enc + (size_t)pos * H + (size_t)dd * h;
+          c.ld_dy2 = (long)T * H;
+        } else {
+          c.dy = P.DX[dd] + (size_t)i * bh;
+          c.ld_dy = h;
+        }
+        c.mask = masks ? masks + (((size_t)dd * P.nl + l) * T + i) * bh : nullptr;
+        c.dc_next = last ? (d_cT ? d_cT + ((size_t)dd * P.nl + l) * bh : nullptr) : P.DC[dd][(i + 1) & 1];
+        c.c_prev = i > 0 ? P.CC[dd][l] + (size_t)(i - 1) * bh : nullptr;
+        c.c_cur = P.CC[dd][l] + (size_t)i * bh;
+        c.gates_dz = P.ZG[dd][l] + (size_t)i * B * 4 * h;
+        c.ld_g = 4 * h;
+        c.dc_prev = P.DC[dd][i & 1];
+      }
+      ASTK_TRY(lstm_cell_bwd_launch(cells, P.nd, s));
+    }
+    // ---- batched products over all time steps
+    for (int dd = 0; dd < P.nd; ++dd) {
+      const astk_lstm_params& p = prm[dd * P.nl + l];
+      const astk_lstm_grads& g = gr[dd * P.nl + l];
+      const float* dz = P.ZG[dd][l];
+      const int rows = T * B;
+      // dWl (4h,h) += sum_{i>=1} dz_i^T h_{i-1}
+      if (T > 1) {
+        const long tiles = (long)cdiv(4 * h, 128) * cdiv(h, 128);
+        int ks = (int)(512 / tiles);
+        if (ks < 1) ks = 1;
+        if (ks > (rows - B) / 128) ks = (rows - B) / 128 > 0 ? (rows - B) / 128 : 1;
+        ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(4 * h, h, rows - B, mat(dz + (size_t)B * 4 * h, 4 * h), mat(P.HR[dd][l], h), g.dWl, h,
+                                                nullptr, GEMM_ATOMIC, ks), s));
+      }
+      // dWu (4h,in) += dz^T X
+      {
+        MatView Xv;
+        if (l == 0) Xv = dd == 0 ? mat(x, in) : mat_idx(x, in, rows_perm);
+        else Xv = mat(masks ? P.HD[dd][l - 1] : P.HR[dd][l - 1], h);
+        const long tiles = (long)cdiv(4 * h, 128) * cdiv(in, 128);
+        int ks = (int)(512 / tiles);
+        if (ks < 1) ks = 1;
+        if (ks > rows / 128) ks = rows / 128 > 0 ? rows / 128 : 1;
+        ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(4 * h, in, rows, mat(dz, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, ks), s));
+      }
+      ASTK_TRY(colsum_add_f32(g.db, dz, 4 * h, rows, 4 * h, s));
+      // gradient wrt the layer input
+      if (l > 0) {
+        ASTK_TRY(gemm_launch(GEMM_NN, gemm_args(rows, h, 4 * h, mat(dz, 4 * h), mat(p.Wu, h), P.DX[dd], h), s));
+      } else if (dx) {
+        // dx (T,B,in) in frame order: direction 0 stores, direction 1 accumulates through the inverse permutation
+        MatView A = dd == 0 ? mat(dz, 4 * h) : mat_idx(dz, 4 * h, rows_inv);
+        ASTK_TRY(gemm_launch(GEMM_NN, gemm_args(rows, in, 4 * h, A, mat(p.Wu, in), dx, in, nullptr, dd == 0 ? GEMM_STORE : GEMM_ACCUM), s));
+      }
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"

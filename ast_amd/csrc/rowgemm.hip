@@ -1,0 +1,278 @@
+// Row-panel MFMA products for the recurrent steps (SURVEY.md K10/K11/K18/K19/K23/K24 and their
+// backward counterparts): out[M<=~64, N] = sum_p A_p[M,K_p] W_p[N,K_p]^T with a fused epilogue.
+//
+// These products have M = batch (16-64 rows), so they are weight-streaming / latency bound, not
+// MFMA bound.  Design: one workgroup owns a 16-row x (16*NT)-column output tile and splits K over
+// its 4 waves; operands go straight from global memory (L2 / MALL resident) into the
+// v_mfma_f32_16x16x4_f32 operand registers with 16-byte loads -- lane (r = l&15, q = l>>4) loads
+// floats [16s+4q, 16s+4q+4) of row r for k-block s and feeds them to 4 consecutive MFMAs, so that the
+// MFMA's k index is (q, c) <-> k = 16s+4q+c for both operands.  No LDS staging (nothing is reused
+// inside a workgroup); LDS is used once, for the 4-way K reduction before the epilogue.
+//
+// The LSTM cell kernels use NT = 4 tiles that are the four gates of 16 hidden units (Chainer's
+// interleaved layout, row 4j+k), so each thread of the epilogue holds a,i,f,o of one (batch row, unit).
+#include "common.h"
+
+namespace astk {
+
+namespace {
+
+struct WRows {   // W row for (tile t, column j) = base + j*sj + t*st ; valid columns: j < jmax
+  int base, sj, st;
+};
+
+template <int NT>
+__device__ __forceinline__ void tile_dot(const RowPair& pr, int m0, int M, WRows wr, int jvalid, int lane, int wave,
+                                         f32x4 (&acc)[NT]) {
+  const int K = pr.K;
+  if (K <= 0) return;
+  const int r = lane & 15, q = lane >> 4;
+  const int arow = min(m0 + r, M - 1);
+  const float* ap = pr.A + (long)arow * pr.lda + 4 * q;
+  const int j = min(r, jvalid - 1);
+  const float* wp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wp[t] = pr.W + (long)(wr.base + j * wr.sj + t * wr.st) * pr.ldw + 4 * q;
+  const int nblk = (K + 15) >> 4;
+  for (int s0 = wave; s0 < nblk; s0 += 8) {   // two k-blocks per trip: loads of both are issued before the MFMAs
+    const int s1 = s0 + 4;
+    const int k0 = 16 * s0 + 4 * q, k1 = 16 * s1 + 4 * q;
+    const bool v0 = k0 < K, v1 = (s1 < nblk) && (k1 < K);
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    float4 w0[NT], w1[NT];
+    if (v0) a0 = *reinterpret_cast<const float4*>(ap + 16 * s0);
+    if (v1) a1 = *reinterpret_cast<const float4*>(ap + 16 * s1);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      w0[t] = v0 ? *reinterpret_cast<const float4*>(wp[t] + 16 * s0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      w1[t] = v1 ? *reinterpret_cast<const float4*>(wp[t] + 16 * s1) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w0[t].x, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w0[t].y, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w0[t].z, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w0[t].w, acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, w1[t].x, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, w1[t].y, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, w1[t].z, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, w1[t].w, acc[t], 0, 0, 0);
+    }
+  }
+}
+
+// 4-wave K reduction.  D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
+// After the call thread tid holds, for each tile t, the full sum of element (row = tid>>4, col = tid&15).
+template <int NT>
+__device__ __forceinline__ void reduce_waves(f32x4 (&acc)[NT], float (&vals)[NT], float* red /* [4][NT][256] */) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    *reinterpret_cast<f32x4*>(&red[((wave * NT + t) * 64 + lane) * 4]) = acc[t];
+  __syncthreads();
+  const int row = tid >> 4, col = tid & 15;
+  const int src = ((row >> 2) * 16 + col) * 4 + (row & 3);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    vals[t] = red[(0 * NT + t) * 256 + src] + red[(1 * NT + t) * 256 + src] + red[(2 * NT + t) * 256 + src] +
+              red[(3 * NT + t) * 256 + src];
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// ------------------------------------------------------------------ generic row-panel GEMM
+__global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
+  constexpr int NT = 4;
+  __shared__ __attribute__((aligned(16))) float red[4 * NT * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 16 * NT, m0 = blockIdx.y * 16;
+  f32x4 acc[NT];
+  zero_acc<NT>(acc);
+  // tile t covers columns n0+16t .. n0+16t+15 (W rows n0+16t+j)
+  for (int p = 0; p < a.npairs; ++p) {
+    const RowPair pr = a.p[p];
+    if (n0 + 16 * NT <= a.N) {
+      tile_dot<NT>(pr, m0, a.M, WRows{n0, 1, 16}, 16, lane, wave, acc);
+    } else {
+      // last column block: tile by tile with the W row index clamped inside [0, N)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int nb = n0 + 16 * t;
+        if (nb < a.N) {
+          f32x4 one[1];
+          one[0] = acc[t];
+          tile_dot<1>(pr, m0, a.M, WRows{nb, 1, 0}, min(16, a.N - nb), lane, wave, one);
+          acc[t] = one[0];
+        }
+      }
+    }
+  }
+  float vals[NT];
+  reduce_waves<NT>(acc, vals, red);
+  const int row = m0 + (threadIdx.x >> 4), col = threadIdx.x & 15;
+  if (row >= a.M) return;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = n0 + 16 * t + col;
+    if (n >= a.N) continue;
+    float v = vals[t];
+    if (a.bias) v += a.bias[n];
+    if (a.addend) v += a.addend[(long)row * a.ld_add + n];
+    if (a.act == ACT_TANH) v = tanhf(v);
+    else if (a.act == ACT_DTANH) {
+      const float y = a.aux[(long)row * a.ld_aux + n];
+      v *= (1.f - y * y);
+    }
+    a.out[(long)row * a.ld_out + n] = v;
+    if (a.out2) a.out2[(long)row * a.ld_out2 + n] = v;
+  }
+}
+
+// ------------------------------------------------------------------ LSTM cell forward (Chainer-sem A1)
+struct CellFwdBatch {
+  LstmCellFwdArgs c[8];
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(CellFwdBatch batch) {
+  constexpr int NT = 4;
+  __shared__ __attribute__((aligned(16))) float red[4 * NT * 256];
+  const LstmCellFwdArgs& a = batch.c[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  f32x4 acc[NT];
+  zero_acc<NT>(acc);
+  const int jv = min(16, a.h - j0);
+  for (int p = 0; p < a.npairs; ++p) tile_dot<NT>(a.p[p], m0, a.B, WRows{4 * j0, 4, 1}, jv, lane, wave, acc);
+  float z[NT];
+  reduce_waves<NT>(acc, z, red);
+  const int b = m0 + (threadIdx.x >> 4), u = j0 + (threadIdx.x & 15);
+  if (b >= a.B || u >= a.h) return;
+  if (a.zx) {
+    const float4 zx = *reinterpret_cast<const float4*>(a.zx + (long)b * a.ld_zx + 4 * u);
+    z[0] += zx.x; z[1] += zx.y; z[2] += zx.z; z[3] += zx.w;
+  }
+  if (a.bias) {
+    const float4 bb = *reinterpret_cast<const float4*>(a.bias + 4 * u);
+    z[0] += bb.x; z[1] += bb.y; z[2] += bb.z; z[3] += bb.w;
+  }
+  const float ga = tanhf(z[0]), gi = sigmoidf_(z[1]), gf = sigmoidf_(z[2]), go = sigmoidf_(z[3]);
+  const float cp = a.c_prev ? a.c_prev[(long)b * a.h + u] : 0.f;
+  const float c = ga * gi + gf * cp;
+  const float hh = go * tanhf(c);
+  *reinterpret_cast<float4*>(a.gates + (long)b * a.ld_g + 4 * u) = make_float4(ga, gi, gf, go);
+  a.c_out[(long)b * a.h + u] = c;
+  a.h_out[(long)b * a.h + u] = hh;
+  const float hd = a.mask ? hh * a.mask[(long)b * a.h + u] : hh;
+  if (a.hd_out) a.hd_out[(long)b * a.ld_hd + u] = hd;
+  if (a.hd_out2) a.hd_out2[(long)b * a.ld_hd2 + u] = hd;
+}
+
+// ------------------------------------------------------------------ LSTM cell backward
+struct CellBwdBatch {
+  LstmCellBwdArgs c[8];
+};
+
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(CellBwdBatch batch) {
+  constexpr int NT = 2;   // tile 0: dh_rec = dz_next WlT ; tile 1: dx = dz_above WuT_above
+  __shared__ __attribute__((aligned(16))) float red[4 * NT * 256];
+  const LstmCellBwdArgs& a = batch.c[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const int jv = min(16, a.h - j0);
+  f32x4 acc[NT];
+  zero_acc<NT>(acc);
+  {
+    f32x4 one[1];
+    one[0] = acc[0];
+    tile_dot<1>(a.p[0], m0, a.B, WRows{j0, 1, 0}, jv, lane, wave, one);
+    acc[0] = one[0];
+    if (a.npairs > 1) {
+      one[0] = acc[1];
+      tile_dot<1>(a.p[1], m0, a.B, WRows{j0, 1, 0}, jv, lane, wave, one);
+      acc[1] = one[0];
+    }
+  }
+  float v[NT];
+  reduce_waves<NT>(acc, v, red);
+  const int b = m0 + (threadIdx.x >> 4), u = j0 + (threadIdx.x & 15);
+  if (b >= a.B || u >= a.h) return;
+  const long bu = (long)b * a.h + u;
+  float dy = v[1];
+  if (a.dy) dy += a.dy[(long)b * a.ld_dy + u];
+  if (a.dy2) dy += a.dy2[(long)b * a.ld_dy2 + u];
+  if (a.mask) dy *= a.mask[bu];
+  float dh = v[0] + dy;
+  if (a.dh_add) dh += a.dh_add[bu];
+  float* gp = a.gates_dz + (long)b * a.ld_g + 4 * u;
+  const float4 g = *reinterpret_cast<const float4*>(gp);
+  const float ga = g.x, gi = g.y, gf = g.z, go = g.w;
+  const float tc = tanhf(a.c_cur[bu]);
+  const float cp = a.c_prev ? a.c_prev[bu] : 0.f;
+  float dc = dh * go * (1.f - tc * tc);
+  if (a.dc_next) dc += a.dc_next[bu];
+  const float4 dz = make_float4(dc * gi * (1.f - ga * ga), dc * ga * gi * (1.f - gi), dc * cp * gf * (1.f - gf),
+                                dh * tc * go * (1.f - go));
+  *reinterpret_cast<float4*>(gp) = dz;
+  a.dc_prev[bu] = dc * gf;
+}
+
+int check_pair(const RowPair& p, const char* who) {
+  if (p.K <= 0) return 0;
+  ASTK_CHECK(p.A && p.W, "%s: null operand", who);
+  ASTK_CHECK((p.K % 4) == 0 && (p.lda % 4) == 0 && (p.ldw % 4) == 0 && aligned16(p.A) && aligned16(p.W),
+             "%s: K, lda, ldw must be multiples of 4 and pointers 16-byte aligned (K=%d lda=%ld ldw=%ld)", who, p.K, p.lda, p.ldw);
+  return 0;
+}
+
+}  // namespace
+
+int rowgemm_launch(const RowGemmArgs& a, hipStream_t s) {
+  ASTK_CHECK(a.M > 0 && a.N > 0 && a.out && a.npairs >= 1 && a.npairs <= 2, "rowgemm: bad arguments");
+  for (int p = 0; p < a.npairs; ++p) ASTK_TRY(check_pair(a.p[p], "rowgemm"));
+  hipLaunchKernelGGL(rowgemm_kernel, dim3(cdiv(a.N, 64), cdiv(a.M, 16)), dim3(256), 0, s, a);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int lstm_cell_fwd_launch(const LstmCellFwdArgs* cells, int ncells, hipStream_t s) {
+  ASTK_CHECK(ncells >= 1 && ncells <= 8, "lstm_cell_fwd: 1..8 cells per launch");
+  CellFwdBatch batch;
+  for (int i = 0; i < ncells; ++i) {
+    const LstmCellFwdArgs& c = cells[i];
+    ASTK_CHECK(c.B == cells[0].B && c.h == cells[0].h, "lstm_cell_fwd: cells of one launch must share B and h");
+    ASTK_CHECK(c.gates && c.c_out && c.h_out && (c.ld_g % 4) == 0 && aligned16(c.gates), "lstm_cell_fwd: bad outputs");
+    ASTK_CHECK(!c.zx || ((c.ld_zx % 4) == 0 && aligned16(c.zx)), "lstm_cell_fwd: zx alignment");
+    ASTK_CHECK(!c.bias || aligned16(c.bias), "lstm_cell_fwd: bias alignment");
+    for (int p = 0; p < c.npairs; ++p) ASTK_TRY(check_pair(c.p[p], "lstm_cell_fwd"));
+    batch.c[i] = c;
+  }
+  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv(cells[0].h, 16), cdiv(cells[0].B, 16), ncells), dim3(256), 0, s, batch);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int lstm_cell_bwd_launch(const LstmCellBwdArgs* cells, int ncells, hipStream_t s) {
+  ASTK_CHECK(ncells >= 1 && ncells <= 8, "lstm_cell_bwd: 1..8 cells per launch");
+  CellBwdBatch batch;
+  for (int i = 0; i < ncells; ++i) {
+    const LstmCellBwdArgs& c = cells[i];
+    ASTK_CHECK(c.B == cells[0].B && c.h == cells[0].h, "lstm_cell_bwd: cells of one launch must share B and h");
+    ASTK_CHECK(c.gates_dz && c.c_cur && c.dc_prev && (c.ld_g % 4) == 0 && aligned16(c.gates_dz), "lstm_cell_bwd: bad buffers");
+    for (int p = 0; p < c.npairs; ++p) ASTK_TRY(check_pair(c.p[p], "lstm_cell_bwd"));
+    batch.c[i] = c;
+  }
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv(cells[0].h, 16), cdiv(cells[0].B, 16), ncells), dim3(256), 0, s, batch);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace astk

@@ -1,0 +1,305 @@
+// Small memory-bound helpers: copies with re-pitch, transposes (weight re-layouts for the backward
+// products), column sums (bias gradients), counter-based RNG fills, and the fused optimizer
+// (nn.py:81-119: WeightDecay -> GradientClipping -> Adam(amsgrad) on one flat buffer).
+#include "common.h"
+#include <stdarg.h>
+
+namespace astk {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+namespace {
+
+__global__ void k_copy2d(float* dst, long ldd, const float* src, long lds, int rows, int cols, int cols_dst) {
+  const long n = (long)rows * cols_dst;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols_dst), c = (int)(i % cols_dst);
+    dst[r * ldd + c] = c < cols ? src[r * lds + c] : 0.f;
+  }
+}
+
+__global__ void k_add2d(float* dst, long ldd, const float* src, long lds, int rows, int cols) {
+  const long n = (long)rows * cols;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    dst[r * ldd + c] += src[r * lds + c];
+  }
+}
+
+__global__ void k_axpy(float* dst, const float* src, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+
+// dst[c][r] = src[r][c] through a 32x33 LDS tile; dst columns in [rows, ldd) are zero-filled.
+__global__ void k_transpose(float* dst, long ldd, const float* src, long lds, int rows, int cols) {
+  __shared__ float t[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx: src col block, by: src row block
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 256 threads: ty 0..7
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    t[j][tx] = (r < rows && c < cols) ? src[(long)r * lds + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;   // dst row = src col
+    if (c < cols && r < ldd) dst[(long)c * ldd + r] = t[tx][j];
+  }
+}
+
+// dst[c] += sum_r src[r][c]: one block per 64 columns x row slab, float partials then one atomic per column.
+__global__ void k_colsum(float* dst, const float* src, long lds, int rows, int cols, int rows_per_block) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < cols)
+    for (int r = r0 + w; r < r1; r += 4) s += src[(long)r * lds + c];
+  red[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < cols) atomicAdd(&dst[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void k_scale(float* x, size_t n, float s) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= s;
+}
+
+// ---- counter-based RNG (splitmix64 finaliser over (seed, counter)); quality is ample for dropout / noise
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ float u01(uint64_t bits) { return (float)((bits >> 40) + 1) * (1.0f / 16777217.0f); }  // (0,1)
+
+__global__ void k_dropout_mask(float* out, size_t n, float ratio, float scale, uint64_t seed, uint64_t offset) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float u = u01(mix64(seed ^ mix64(offset + i)));
+    out[i] = u >= ratio ? scale : 0.f;
+  }
+}
+
+__global__ void k_normal(float* out, size_t n, float mean, float sigma, uint64_t seed, uint64_t offset) {
+  const size_t pairs = (n + 1) / 2;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t b = mix64(seed ^ mix64(offset + i));
+    const float u1 = u01(b), u2 = u01(mix64(b));
+    const float r = sqrtf(-2.f * logf(u1));
+    float sn, cs;
+    sincosf(6.2831853071795864f * u2, &sn, &cs);
+    out[2 * i] = mean + sigma * r * cs;
+    if (2 * i + 1 < n) out[2 * i + 1] = mean + sigma * r * sn;
+  }
+}
+
+// ---- optimizer
+__global__ void k_sqnorm(const float* g, const float* p, float l2, size_t n, double* out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  const size_t n4 = n / 4;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  const float4* p4 = reinterpret_cast<const float4*>(p);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 a = g4[i], b = p4[i];
+    float x = a.x + l2 * b.x, y = a.y + l2 * b.y, z = a.z + l2 * b.z, w = a.w + l2 * b.w;
+    s += (double)(x * x + y * y) + (double)(z * z + w * w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (size_t i = n4 * 4; i < n; ++i) { float x = g[i] + l2 * p[i]; s += (double)x * x; }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void k_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, size_t n, float l2, float clip,
+                          const double* sqnorm, float lr_t, float b1, float b2, float eps, int amsgrad) {
+  const float norm = (float)sqrt(*sqnorm);
+  const float rate = clip / norm;                    // A7: r = c / n, applied only when r < 1
+  const float gs = rate < 1.f ? rate : 1.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float pi = p[i];
+    const float gi = (g[i] + l2 * pi) * gs;
+    float mi = m[i], vi = v[i];
+    mi += (1.f - b1) * (gi - mi);
+    vi += (1.f - b2) * (gi * gi - vi);
+    m[i] = mi;
+    v[i] = vi;
+    float vh = vi;
+    if (amsgrad) {
+      vh = fmaxf(vhat[i], vi);
+      vhat[i] = vh;
+    }
+    p[i] = pi - lr_t * mi / (sqrtf(vh) + eps);
+  }
+}
+
+__global__ void k_sgd(float* p, const float* g, size_t n, float l2, float clip, const double* sqnorm, float lr) {
+  const float norm = (float)sqrt(*sqnorm);
+  const float rate = clip / norm;
+  const float gs = rate < 1.f ? rate : 1.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] -= lr * (g[i] + l2 * p[i]) * gs;
+}
+
+inline unsigned grid_for(size_t n, int per = 256) {
+  size_t b = (n + per - 1) / per;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+int fill_zero(void* p, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return 0;
+  ASTK_HIP(hipMemsetAsync(p, 0, bytes, s));
+  return 0;
+}
+int copy_f32(float* dst, const float* src, size_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  ASTK_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+int copy2d_f32(float* dst, long ldd, const float* src, long lds, int rows, int cols, int cols_dst, hipStream_t s) {
+  if (rows <= 0 || cols_dst <= 0) return 0;
+  hipLaunchKernelGGL(k_copy2d, dim3(grid_for((size_t)rows * cols_dst)), dim3(256), 0, s, dst, ldd, src, lds, rows, cols, cols_dst);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+int add2d_f32(float* dst, long ldd, const float* src, long lds, int rows, int cols, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return 0;
+  hipLaunchKernelGGL(k_add2d, dim3(grid_for((size_t)rows * cols)), dim3(256), 0, s, dst, ldd, src, lds, rows, cols);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+int axpy_rows(float* dst, const float* src, size_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_axpy, dim3(grid_for(n)), dim3(256), 0, s, dst, src, n);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+int transpose_f32(float* dst, long ldd, const float* src, long lds, int rows, int cols, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return 0;
+  // y blocks cover ldd so that the pad columns [rows, ldd) of every dst row are written as zeros
+  hipLaunchKernelGGL(k_transpose, dim3(cdiv(cols, 32), cdiv(ldd, 32)), dim3(256), 0, s, dst, ldd, src, lds, rows, cols);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+int colsum_add_f32(float* dst, const float* src, long lds, int rows, int cols, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return 0;
+  int rpb = 256;
+  hipLaunchKernelGGL(k_colsum, dim3(cdiv(cols, 64), cdiv(rows, rpb)), dim3(256), 0, s, dst, src, lds, rows, cols, rpb);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace astk
+
+using namespace astk;
+
+extern "C" {
+
+int astk_version(void) { return ASTK_VERSION; }
+const char* astk_last_error(void) { return astk::last_error(); }
+
+int astk_grad_sqnorm(const float* g, const float* p, float l2, size_t n, double* sqnorm, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  ASTK_CHECK(g && p && sqnorm, "grad_sqnorm: null pointer");
+  ASTK_CHECK(aligned16(g) && aligned16(p), "grad_sqnorm: buffers must be 16-byte aligned");
+  ASTK_HIP(hipMemsetAsync(sqnorm, 0, sizeof(double), s));
+  hipLaunchKernelGGL(k_sqnorm, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, g, p, l2, n, sqnorm);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int astk_decay_clip_amsgrad_step(float* p, const float* g, float* m, float* v, float* vhat, size_t n, float l2, float clip,
+                                 const double* sqnorm, float lr_t, float beta1, float beta2, float eps, int amsgrad,
+                                 void* stream) {
+  ASTK_CHECK(p && g && m && v && sqnorm && (vhat || !amsgrad), "amsgrad_step: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_amsgrad, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vhat, n, l2, clip, sqnorm,
+                     lr_t, beta1, beta2, eps, amsgrad);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int astk_decay_clip_sgd_step(float* p, const float* g, size_t n, float l2, float clip, const double* sqnorm, float lr,
+                             void* stream) {
+  ASTK_CHECK(p && g && sqnorm, "sgd_step: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_sgd, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, n, l2, clip, sqnorm, lr);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int astk_fill_dropout_mask(float* out, size_t n, float ratio, uint64_t seed, uint64_t offset, void* stream) {
+  ASTK_CHECK(out && ratio >= 0.f && ratio < 1.f, "fill_dropout_mask: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_dropout_mask, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, n, ratio, 1.f / (1.f - ratio),
+                     seed, offset);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int astk_fill_normal(float* out, size_t n, float mean, float sigma, uint64_t seed, uint64_t offset, void* stream) {
+  ASTK_CHECK(out, "fill_normal: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_normal, dim3(grid_for((n + 1) / 2)), dim3(256), 0, (hipStream_t)stream, out, n, mean, sigma, seed, offset);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int astk_scale_f32(float* x, size_t n, float s, void* stream) {
+  ASTK_CHECK(x, "scale: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_scale, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, s);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int astk_gemm_f32(int layout, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                  const float* bias, int mode, int ksplit, int batch, long sA, long sB, long sC, void* stream) {
+  GemmArgs g = gemm_args(M, N, K, mat(A, lda), mat(B, ldb), C, ldc, bias, mode, ksplit);
+  g.batch = batch < 1 ? 1 : batch;
+  g.sA = sA; g.sB = sB; g.sC = sC;
+  return gemm_launch(layout, g, (hipStream_t)stream);
+}
+
+int astk_graph_begin(void* stream) {
+  ASTK_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  return 0;
+}
+int astk_graph_end(void* stream, void** graph_exec) {
+  hipGraph_t graph = nullptr;
+  ASTK_HIP(hipStreamEndCapture((hipStream_t)stream, &graph));
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    astk::set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    return -2;
+  }
+  *graph_exec = (void*)exec;
+  return 0;
+}
+int astk_graph_launch(void* graph_exec, void* stream) {
+  ASTK_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+  return 0;
+}
+int astk_graph_destroy(void* graph_exec) {
+  if (graph_exec) ASTK_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return 0;
+}
+
+}  // extern "C"

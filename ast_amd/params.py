@@ -1,0 +1,129 @@
+"""Flat parameter / gradient arenas in HBM.
+
+All trainable parameters live in ONE contiguous float32 buffer (and their gradients in another), each
+parameter 16-byte aligned, in Chainer's layouts and under Chainer's save_npz names.  One
+flat buffer makes `cleargrads` a single memset, the WeightDecay -> GradientClipping -> Adam hooks of
+nn.py:81-119 two kernel launches, and the data-parallel gradient exchange a single RCCL all-reduce.
+"""
+import numpy as np
+import torch
+
+
+def conv_out(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+def param_shapes(cfg, in_dim, vocab_size=None):
+    """Ordered {name: shape} for trainables and persistents, following seq2seq.py:35-156.
+    `in_dim` resolves the reference's lazily-shaped links (in_channels=None / L.LSTM(None, ...))."""
+    rc, cc = cfg["rnn_config"], cfg["cnn_config"]
+    V = vocab_size if vocab_size is not None else rc["dec_vocab_size"]
+    train, persist = {}, {}
+    cin, fdim = 1, in_dim
+    for i, l in enumerate(cc["cnn_layers"]):
+        kh, kw = l["ksize"]
+        co = l["out_channels"]
+        train[f"CNN_{i}/W"] = (co, cin, kh, kw)
+        if cc["bn"]:
+            train[f"CNN_{i}_bn/gamma"] = (co,)
+            train[f"CNN_{i}_bn/beta"] = (co,)
+            persist[f"CNN_{i}_bn/avg_mean"] = (co,)
+            persist[f"CNN_{i}_bn/avg_var"] = (co,)
+        fdim = conv_out(fdim, kw, l["stride"][1], l["pad"][1])
+        cin = co
+    rnn_in = cin * fdim
+    Hh = rc["hidden_units"] // 2 if rc["bi_rnn"] else rc["hidden_units"]
+    for pat in ["L{}_enc"] + (["L{}_rev_enc"] if rc["bi_rnn"] else []):
+        n_in = rnn_in
+        for i in range(rc["enc_layers"]):
+            n = pat.format(i)
+            train[f"{n}/upward/W"] = (4 * Hh, n_in)
+            train[f"{n}/upward/b"] = (4 * Hh,)
+            train[f"{n}/lateral/W"] = (4 * Hh, Hh)
+            n_in = Hh
+    H, E, A = rc["hidden_units"], rc["embedding_units"], rc["attn_units"]
+    n_attn = rc.get("n_attn", 1)
+    train["attn_Wa/W"] = (H, H)
+    train["attn_Wa/b"] = (H,)
+    train["context/W"] = (A, (n_attn + 1) * H)
+    train["context/b"] = (A,)
+    train["embed_dec/W"] = (V, E)
+    n_in = E + A if rc.get("feed_attn", True) else E
+    for i in range(rc["dec_layers"]):
+        train[f"L{i}_dec/upward/W"] = (4 * H, n_in)
+        train[f"L{i}_dec/upward/b"] = (4 * H,)
+        train[f"L{i}_dec/lateral/W"] = (4 * H, H)
+        n_in = H
+    train["out/W"] = (V, A)
+    train["out/b"] = (V,)
+    return train, persist
+
+
+def init_values(cfg, in_dim, vocab_size=None, seed=0):
+    """Reference initialisers: conv HeNormal, Linear/LSTM LeCunNormal, forget-gate bias 1,
+    EmbedID N(0,1), BN gamma 1 / beta 0, running mean 0 / var 1."""
+    train, persist = param_shapes(cfg, in_dim, vocab_size)
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shp in train.items():
+        leaf = name.split("/")[-1]
+        if name.startswith("CNN_") and leaf == "W":
+            fan_in = shp[1] * shp[2] * shp[3]
+            v = rng.standard_normal(shp) * np.sqrt(2.0 / fan_in)
+        elif leaf == "gamma":
+            v = np.ones(shp)
+        elif leaf in ("beta",):
+            v = np.zeros(shp)
+        elif name == "embed_dec/W":
+            v = rng.standard_normal(shp)
+        elif leaf == "W":
+            v = rng.standard_normal(shp) * np.sqrt(1.0 / shp[1])
+        elif leaf == "b":
+            v = np.zeros(shp)
+            if "/upward/" in name:
+                v[2::4] = 1.0
+        else:
+            raise KeyError(name)
+        out[name] = v.astype(np.float32)
+    for name, shp in persist.items():
+        out[name] = (np.ones(shp) if name.endswith("avg_var") else np.zeros(shp)).astype(np.float32)
+    return out
+
+
+class ParamArena:
+    def __init__(self, shapes, device):
+        self.shapes = dict(shapes)
+        self.offsets = {}
+        off = 0
+        for name, shp in self.shapes.items():
+            self.offsets[name] = off
+            n = int(np.prod(shp))
+            off += (n + 3) // 4 * 4                 # 16-byte aligned slices; pad elements stay zero forever
+        self.size = off
+        self.device = device
+        self.data = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        self.views, self.gviews = {}, {}
+        for name, shp in self.shapes.items():
+            o, n = self.offsets[name], int(np.prod(shp))
+            self.views[name] = self.data[o:o + n].view(shp)
+            self.gviews[name] = self.grad[o:o + n].view(shp)
+
+    def range_of(self, name):
+        o = self.offsets[name]
+        n = int(np.prod(self.shapes[name]))
+        return o, (n + 3) // 4 * 4
+
+    def p(self, name):
+        return self.views[name].data_ptr()
+
+    def g(self, name):
+        return self.gviews[name].data_ptr()
+
+    def load(self, values):
+        for name in self.shapes:
+            self.views[name].copy_(torch.as_tensor(values[name], dtype=torch.float32).reshape(self.shapes[name]))
+
+    def to_numpy(self, grads=False):
+        src = self.gviews if grads else self.views
+        return {k: v.detach().cpu().numpy().copy() for k, v in src.items()}

@@ -1,0 +1,450 @@
+"""Drop-in for the reference's model class (seq2seq.py:22-568): SpeechEncoderDecoder(gpuid, cfg) with the same
+method names, argument meaning and state protocol, running on libastk.so (hand-written HIP for gfx950).
+
+PyTorch is used only as the owner of device memory and streams; every arithmetic step of the hot path is a
+C-ABI call (include/astk.h).  There is no CPU / eager-PyTorch fallback: without the HIP library and a GPU
+the compute methods raise.
+"""
+import ctypes as C
+import random
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (CnnDesc, CnnLayerGrads, CnnLayerParams, DecoderDesc, DecoderGrads, DecoderParams, LstmGrads,
+                   LstmParams, LstmStackDesc, check)
+from .params import ParamArena, init_values, param_shapes
+
+
+class _Config:
+    """Stand-in for chainer.config / chainer.using_config('train', flag) (nn.py:174, 216, 248)."""
+    train = True
+
+
+config = _Config()
+
+
+class using_config:
+    def __init__(self, name, value):
+        assert name == "train"
+        self.value = value
+
+    def __enter__(self):
+        self.old = config.train
+        config.train = self.value
+
+    def __exit__(self, *a):
+        config.train = self.old
+
+
+class Link:
+    """What `model[name]` returns (nn.py:113-116 calls .disable_update(); copy_params.py reads child params)."""
+
+    def __init__(self, model, name):
+        self._model, self.name = model, name
+
+    def disable_update(self):
+        self._model._frozen.add(self.name)
+
+    def enable_update(self):
+        self._model._frozen.discard(self.name)
+
+    def namedparams(self):
+        a = self._model.arena
+        return [(k, v) for k, v in a.views.items() if k.split("/")[0] == self.name]
+
+
+class Loss:
+    """What forward_loss returns: `.data` (0-d tensor), float(), `.backward()` (nn.py:175-189)."""
+
+    def __init__(self, model, value):
+        self._model = model
+        self.data = value
+
+    def backward(self):
+        self._model._backward()
+
+    def __float__(self):
+        return float(self.data)
+
+
+def _vp(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class SpeechEncoderDecoder:
+    def __init__(self, gpuid, cfg):
+        self.gpuid = gpuid
+        self.cfg = cfg
+        rc, cc = cfg["rnn_config"], cfg["cnn_config"]
+        if rc.get("ln", False) or rc.get("linear_proj", False) or rc.get("n_attn", 1) != 1 or not rc.get("feed_attn", True):
+            raise NotImplementedError("ln / linear_proj / n_attn>1 / feed_attn=False are outside the MI355X hot path "
+                                      "(SURVEY.md 8f rank 4); the shipped experiments do not use them")
+        if not cc["bn"]:
+            raise NotImplementedError("cnn_config.bn=false is not part of the shipped configs")
+        if not rc["bi_rnn"]:
+            self.n_dirs = 1
+        else:
+            self.n_dirs = 2
+        self.cnns = [f"CNN_{i}" for i in range(len(cc["cnn_layers"]))]
+        self.cnn_bn = cc["bn"]
+        self.rnn_enc = [f"L{i}_enc" for i in range(rc["enc_layers"])]
+        self.rnn_rev_enc = [f"L{i}_rev_enc" for i in range(rc["enc_layers"])] if rc["bi_rnn"] else []
+        self.rnn_dec = [f"L{i}_dec" for i in range(rc["dec_layers"])]
+        self.bi_rnn = rc["bi_rnn"]
+        self.n_attn = 1
+        self.h = rc["hidden_units"] // 2 if rc["bi_rnn"] else rc["hidden_units"]
+        self.H, self.E, self.A = rc["hidden_units"], rc["embedding_units"], rc["attn_units"]
+        self.V = rc.get("dec_vocab_size")
+        self.device = torch.device(f"cuda:{gpuid}") if gpuid is not None and gpuid >= 0 else torch.device("cpu")
+        self.arena = None
+        self.persist = {}
+        self.in_dim = None
+        self._frozen = set()
+        self._ws = {}
+        self._shape_cache = {}
+        self.inject = {}          # test hooks: enc_masks / emb_mask / rnn_masks / noise / use_truth
+        self.rng_seed = 0x5EED
+        self._rng_offset = 0
+        self.enc_states = None
+        self.loss = 0
+        self._cur = None
+        self._dec_c = self._dec_h = None
+        self.mask_pad_id = None
+
+    # ------------------------------------------------------------------ parameters
+    def materialize(self, in_dim, values=None, seed=0):
+        """Allocates the (lazily shaped, seq2seq.py:52,83) parameters once the feature dim is known."""
+        if self.V is None:
+            raise ValueError("cfg['rnn_config']['dec_vocab_size'] must be set (config.py:24 injects it)")
+        train, persist = param_shapes(self.cfg, in_dim, self.V)
+        self.in_dim = in_dim
+        self.arena = ParamArena(train, self.device)
+        vals = values if values is not None else init_values(self.cfg, in_dim, self.V, seed)
+        self.arena.load(vals)
+        self.persist = {k: torch.as_tensor(np.asarray(vals[k], dtype=np.float32)).to(self.device).contiguous() for k in persist}
+        w = torch.ones(self.V, dtype=torch.float32)
+        w[0] = 0                                             # seq2seq.py:152-156
+        self.mask_pad_id = w.to(self.device)
+        self._shape_cache.clear()
+        return self
+
+    def to_gpu(self, gpuid=None):
+        if gpuid is not None and gpuid != self.gpuid:
+            assert self.arena is None, "move before materialize()"
+            self.gpuid = gpuid
+            self.device = torch.device(f"cuda:{gpuid}")
+        return self
+
+    def __getitem__(self, name):
+        return Link(self, name)
+
+    def namedparams(self):
+        return list(self.arena.views.items())
+
+    def params(self):
+        return list(self.arena.views.values())
+
+    def cleargrads(self):
+        if self.arena is not None:
+            self.arena.grad.zero_()
+
+    def enabled_ranges(self):
+        """Contiguous [offset, n) slices of the arena whose links have updates enabled (nn.py:113-116)."""
+        out = []
+        for name in self.arena.shapes:
+            if name.split("/")[0] in self._frozen:
+                continue
+            o, n = self.arena.range_of(name)
+            if out and out[-1][0] + out[-1][1] == o:
+                out[-1] = (out[-1][0], out[-1][1] + n)
+            else:
+                out.append((o, n))
+        return out
+
+    # ------------------------------------------------------------------ plumbing
+    def _require_gpu(self):
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("ast_amd compute path needs an MI355X GPU and libastk.so (no CPU fallback)")
+        return _lib.load()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, key, nbytes):
+        t = self._ws.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(int(nbytes * 1.0) + 256, dtype=torch.uint8, device=self.device)
+            self._ws[key] = t
+            for st in self._shape_cache.values():
+                st["graphs"] = {}
+        return t
+
+    def _shape_state(self, B, T, D, L):
+        key = (B, T, D, L)
+        st = self._shape_cache.get(key)
+        if st is not None:
+            return st
+        lib = self._require_gpu()
+        if self.arena is None:
+            self.materialize(D)
+        assert D == self.in_dim, f"feature dim {D} != materialized {self.in_dim}"
+        dev = self.device
+        cc = self.cfg["cnn_config"]["cnn_layers"]
+        cd = CnnDesc()
+        cd.B, cd.T, cd.D, cd.n_layers = B, T, D, len(cc)
+        for i, l in enumerate(cc):
+            cd.C[i] = l["out_channels"]
+            cd.kt[i], cd.kf[i] = l["ksize"]
+            cd.st[i], cd.sf[i] = l["stride"]
+            cd.pt[i] = l["pad"][0]
+            if l["pad"][1] != 0 or l.get("dilate", 1) != 1:
+                raise NotImplementedError("frequency padding / dilation are not used by the shipped configs")
+        cd.bn_eps, cd.bn_decay = 2e-5, 0.9
+        t2, f2, feat = C.c_int(), C.c_int(), C.c_int()
+        check(lib.astk_conv_bn_relu_out_dims(C.byref(cd), C.byref(t2), C.byref(f2), C.byref(feat)))
+        T2, feat = t2.value, feat.value
+        a = self.arena
+        cp = (CnnLayerParams * len(cc))()
+        cg = (CnnLayerGrads * len(cc))()
+        for i in range(len(cc)):
+            n = f"CNN_{i}"
+            cp[i].W, cp[i].gamma, cp[i].beta = a.p(n + "/W"), a.p(n + "_bn/gamma"), a.p(n + "_bn/beta")
+            cp[i].avg_mean = self.persist[n + "_bn/avg_mean"].data_ptr()
+            cp[i].avg_var = self.persist[n + "_bn/avg_var"].data_ptr()
+            cg[i].dW, cg[i].dgamma, cg[i].dbeta = a.g(n + "/W"), a.g(n + "_bn/gamma"), a.g(n + "_bn/beta")
+        nl, nd, h, H = len(self.rnn_enc), self.n_dirs, self.h, self.H
+        ld = LstmStackDesc(T2, B, feat, h, nl, nd)
+        lp = (LstmParams * (nl * nd))()
+        lg = (LstmGrads * (nl * nd))()
+        for d_, names in enumerate([self.rnn_enc, self.rnn_rev_enc][:nd]):
+            for l, n in enumerate(names):
+                k = d_ * nl + l
+                lp[k].Wu, lp[k].b, lp[k].Wl = a.p(n + "/upward/W"), a.p(n + "/upward/b"), a.p(n + "/lateral/W")
+                lg[k].dWu, lg[k].db, lg[k].dWl = a.g(n + "/upward/W"), a.g(n + "/upward/b"), a.g(n + "/lateral/W")
+        nld = len(self.rnn_dec)
+        dd = DecoderDesc(B, max(L, 2), T2, H, self.E, self.A, self.V, nld)
+        dp, dg = DecoderParams(), DecoderGrads()
+        dp.embed, dg.d_embed = a.p("embed_dec/W"), a.g("embed_dec/W")
+        for l, n in enumerate(self.rnn_dec):
+            dp.lstm[l].Wu, dp.lstm[l].b, dp.lstm[l].Wl = a.p(n + "/upward/W"), a.p(n + "/upward/b"), a.p(n + "/lateral/W")
+            dg.lstm[l].dWu, dg.lstm[l].db, dg.lstm[l].dWl = a.g(n + "/upward/W"), a.g(n + "/upward/b"), a.g(n + "/lateral/W")
+        dp.Wa, dp.ba, dp.Wc, dp.bc = a.p("attn_Wa/W"), a.p("attn_Wa/b"), a.p("context/W"), a.p("context/b")
+        dp.Wo, dp.bo, dp.class_weight = a.p("out/W"), a.p("out/b"), self.mask_pad_id.data_ptr()
+        dg.dWa, dg.dba, dg.dWc, dg.dbc = a.g("attn_Wa/W"), a.g("attn_Wa/b"), a.g("context/W"), a.g("context/b")
+        dg.dWo, dg.dbo = a.g("out/W"), a.g("out/b")
+        S = max(L, 2) - 1
+        f32 = dict(dtype=torch.float32, device=dev)
+        st = dict(key=key, B=B, T=T, D=D, L=L, T2=T2, feat=feat, S=S, cd=cd, cp=cp, cg=cg, ld=ld, lp=lp, lg=lg, dd=dd, dp=dp, dg=dg,
+                  xlstm=torch.empty(T2, B, feat, **f32), d_xlstm=torch.empty(T2, B, feat, **f32),
+                  enc_states=torch.empty(B, T2, H, **f32), d_enc=torch.empty(B, T2, H, **f32),
+                  cT=torch.zeros(nd, nl, B, h, **f32), hT=torch.zeros(nd, nl, B, h, **f32),
+                  d_cT=torch.zeros(nd, nl, B, h, **f32), d_hT=torch.zeros(nd, nl, B, h, **f32),
+                  c0=torch.zeros(nld, B, H, **f32), h0=torch.zeros(nld, B, H, **f32),
+                  d_c0=torch.zeros(nld, B, H, **f32), d_h0=torch.zeros(nld, B, H, **f32),
+                  loss=torch.zeros(1, **f32), pred=torch.zeros(S, B, dtype=torch.int32, device=dev),
+                  flags=torch.ones(S, dtype=torch.int32, device=dev), graphs={},
+                  ws_cnn=int(lib.astk_conv_bn_relu_workspace_bytes(C.byref(cd))),
+                  ws_lstm=int(lib.astk_lstm_stack_workspace_bytes(C.byref(ld))),
+                  ws_dec=int(lib.astk_decoder_workspace_bytes(C.byref(dd))))
+        assert st["ws_cnn"] and st["ws_lstm"] and st["ws_dec"], lib.astk_last_error().decode()
+        self._shape_cache[key] = st
+        return st
+
+    def _rng(self, n):
+        off = self._rng_offset
+        self._rng_offset += n
+        return off
+
+    def _masks(self, name, shape, ratio):
+        """Scaled keep-masks: injected (parity tests) or drawn on device; None when dropout is inactive."""
+        if name in self.inject:
+            m = self.inject[name]
+            return None if m is None else m.to(self.device, torch.float32).contiguous()
+        if not config.train or ratio <= 0:
+            return None
+        key = ("mask", name, shape)
+        t = self._ws.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=torch.float32, device=self.device)
+            self._ws[key] = t
+        lib = _lib.load()
+        check(lib.astk_fill_dropout_mask(_vp(t), t.numel(), float(ratio), self.rng_seed, self._rng(t.numel()), self._stream()))
+        return t
+
+    # ------------------------------------------------------------------ encoder (seq2seq.py:293-314)
+    def _as_input(self, X):
+        if isinstance(X, np.ndarray):
+            X = torch.from_numpy(X)
+        if hasattr(X, "data") and not isinstance(X, torch.Tensor):
+            X = X.data
+        return X.to(self.device, torch.float32).contiguous()
+
+    def encode(self, X, add_noise=0):
+        lib = self._require_gpu()
+        X = self._as_input(X)
+        B, T, D = X.shape
+        L = self._cur["L"] if (self._cur and self._cur.get("pending_L")) else 2
+        st = self._shape_state(B, T, D, L)
+        self._cur = st
+        st["X"] = X
+        noise = None
+        if add_noise > 0 and config.train:
+            if "noise" in self.inject:
+                noise = self.inject["noise"].to(self.device, torch.float32).contiguous()
+            else:
+                noise = self._ws.get(("noise", X.shape))
+                if noise is None:
+                    noise = torch.empty_like(X)
+                    self._ws[("noise", X.shape)] = noise
+                check(lib.astk_fill_normal(_vp(noise), noise.numel(), 1.0, float(add_noise), self.rng_seed ^ 0xABCDEF,
+                                           self._rng(noise.numel()), self._stream()))
+        st["noise"] = noise
+        nl, nd = len(self.rnn_enc), self.n_dirs
+        st["enc_masks"] = self._masks("enc_masks", (nd, nl, st["T2"], B, self.h), self.cfg["dropout"]["rnn"])
+        st["train_mode"] = bool(config.train)
+        s = self._stream()
+        wc = self._workspace("cnn", st["ws_cnn"])
+        check(lib.astk_conv_bn_relu_fwd(C.byref(st["cd"]), st["cp"], _vp(X), _vp(noise), _vp(st["xlstm"]), _vp(wc), wc.numel(),
+                                        1 if config.train else 0, s))
+        wl = self._workspace("lstm", st["ws_lstm"])
+        check(lib.astk_lstm_stack_fwd(C.byref(st["ld"]), st["lp"], _vp(st["xlstm"]), _vp(st["enc_masks"]), _vp(st["enc_states"]),
+                                      _vp(st["cT"]), _vp(st["hT"]), _vp(wl), wl.numel(), s))
+        self.enc_states = st["enc_states"]
+        self.loss = 0
+
+    # ------------------------------------------------------------------ seq2seq.py:318-333
+    def init_decoder_state(self):
+        st = self._cur
+        h = self.h
+        st["c0"].zero_()
+        st["h0"].zero_()
+        for k in range(min(len(self.rnn_enc), len(self.rnn_dec))):
+            for d_ in range(self.n_dirs):
+                st["c0"][k, :, d_ * h:(d_ + 1) * h] = st["cT"][d_, k]
+                st["h0"][k, :, d_ * h:(d_ + 1) * h] = st["hT"][d_, k]
+        self._dec_c, self._dec_h = st["c0"].clone(), st["h0"].clone()
+
+    # ------------------------------------------------------------------ seq2seq.py:399-473
+    def forward_loss(self, X, y, teach_ratio, random_out=0, add_noise=0):
+        if random_out:
+            raise NotImplementedError("random_out > 0 (quirk Q8) is not part of the shipped configs")
+        lib = self._require_gpu()
+        X = self._as_input(X)
+        if isinstance(y, np.ndarray):
+            y = torch.from_numpy(y)
+        if hasattr(y, "data") and not isinstance(y, torch.Tensor):
+            y = y.data
+        y = y.to(self.device, torch.int32).contiguous()
+        B, L = y.shape
+        assert L >= 2, "targets need at least GO and EOS"
+        self._cur = {"L": L, "pending_L": True}
+        self.encode(X, add_noise=add_noise)
+        st = self._cur
+        self.init_decoder_state()
+        S = L - 1
+        # quirk Q4: one Python-`random` coin per step for 0 < i < L-2, truth otherwise (seq2seq.py:431-436)
+        if "use_truth" in self.inject:
+            flags = [int(bool(v)) for v in self.inject["use_truth"]]
+        else:
+            flags = [int(random.random() < teach_ratio) if 0 < i < L - 2 else 1 for i in range(S)]
+        self.use_truth = flags
+        st["flags"].copy_(torch.tensor(flags, dtype=torch.int32), non_blocking=False)
+        st["y"] = y
+        dr = self.cfg["dropout"]
+        if dr.get("out", 0):
+            raise NotImplementedError("dropout.out > 0 is not used by the shipped configs")
+        st["emb_mask"] = self._masks("emb_mask", (S, B, self.E), dr["embed"])
+        st["rnn_masks"] = self._masks("rnn_masks", (len(self.rnn_dec), S, B, self.H), dr["rnn"])
+        wd = self._workspace("dec", st["ws_dec"])
+        check(lib.astk_decoder_fwd(C.byref(st["dd"]), C.byref(st["dp"]), _vp(st["enc_states"]), _vp(st["c0"]), _vp(st["h0"]),
+                                   _vp(y), _vp(st["flags"]), _vp(st["emb_mask"]), _vp(st["rnn_masks"]), _vp(st["loss"]),
+                                   _vp(st["pred"]), _vp(wd), wd.numel(), self._stream()))
+        self.loss = Loss(self, st["loss"][0])
+        return self.loss
+
+    def _backward(self):
+        lib = _lib.load()
+        st = self._cur
+        s = self._stream()
+        wd = self._workspace("dec", st["ws_dec"])
+        check(lib.astk_decoder_bwd(C.byref(st["dd"]), C.byref(st["dp"]), C.byref(st["dg"]), _vp(st["enc_states"]), _vp(st["c0"]),
+                                   _vp(st["h0"]), _vp(st["y"]), _vp(st["emb_mask"]), _vp(st["rnn_masks"]), _vp(st["d_enc"]),
+                                   _vp(st["d_c0"]), _vp(st["d_h0"]), _vp(wd), wd.numel(), s))
+        h = self.h
+        st["d_cT"].zero_()
+        st["d_hT"].zero_()
+        for k in range(min(len(self.rnn_enc), len(self.rnn_dec))):
+            for d_ in range(self.n_dirs):
+                st["d_cT"][d_, k] = st["d_c0"][k, :, d_ * h:(d_ + 1) * h]
+                st["d_hT"][d_, k] = st["d_h0"][k, :, d_ * h:(d_ + 1) * h]
+        wl = self._workspace("lstm", st["ws_lstm"])
+        check(lib.astk_lstm_stack_bwd(C.byref(st["ld"]), st["lp"], st["lg"], _vp(st["xlstm"]), _vp(st["enc_masks"]), _vp(st["d_enc"]),
+                                      _vp(st["d_cT"]), _vp(st["d_hT"]), _vp(st["d_xlstm"]), _vp(wl), wl.numel(), s))
+        wc = self._workspace("cnn", st["ws_cnn"])
+        check(lib.astk_conv_bn_relu_bwd(C.byref(st["cd"]), st["cp"], st["cg"], _vp(st["d_xlstm"]), _vp(wc), wc.numel(), s))
+
+    # ------------------------------------------------------------------ inference (seq2seq.py:361-396, 475-568)
+    def decode_step(self, word, ht):
+        """Eval-mode step for predict()/beam: returns (logits (B,V), ht (B,A), alphas (B,T'',1))."""
+        lib = self._require_gpu()
+        if config.train:
+            raise NotImplementedError("decode_step outside forward_loss is provided for eval mode (predict / beam)")
+        st = self._cur
+        if isinstance(word, np.ndarray):
+            word = torch.from_numpy(word)
+        word = word.to(self.device, torch.int32).contiguous()
+        B = word.shape[0]
+        ht = ht.to(self.device, torch.float32).contiguous().clone()
+        logits = torch.empty(B, self.V, dtype=torch.float32, device=self.device)
+        alpha = torch.empty(B, st["T2"], dtype=torch.float32, device=self.device)
+        wd = self._workspace("dec", st["ws_dec"])
+        check(lib.astk_decoder_step_infer(C.byref(st["dd"]), C.byref(st["dp"]), _vp(st["enc_states"]), _vp(self._dec_c),
+                                          _vp(self._dec_h), _vp(ht), _vp(word), _vp(logits), _vp(alpha), None, _vp(wd), wd.numel(),
+                                          self._stream()))
+        return logits, ht, alpha.unsqueeze(2)
+
+    def predict(self, X, start_token, end_token, stop_limit):
+        with using_config("train", False):
+            X = self._as_input(X)
+            B = X.shape[0]
+            self._cur = None
+            self.encode(X)
+            self.init_decoder_state()
+            ht = torch.zeros(B, self.A, dtype=torch.float32, device=self.device)
+            word = torch.full((B,), start_token, dtype=torch.int32, device=self.device)
+            done = torch.zeros(B, dtype=torch.bool, device=self.device)
+            rows, npred = [], 0
+            while npred < stop_limit:
+                logits, ht, _ = self.decode_step(word, ht)
+                word = logits.argmax(dim=1).to(torch.int32)
+                rows.append(word)
+                done |= word == end_token
+                if bool(done.all()):
+                    break
+                npred += 1
+            return torch.stack(rows, 0).T.cpu().numpy()
+
+    def get_encoder_states(self):
+        st = self._cur
+        h = self.h
+        out = {"c": [], "h": []}
+        for k in range(len(self.rnn_enc)):
+            out["c"].append(torch.cat([st["cT"][d_, k] for d_ in range(self.n_dirs)], 1))
+            out["h"].append(torch.cat([st["hT"][d_, k] for d_ in range(self.n_dirs)], 1))
+        return out
+
+    def get_decoder_states(self):
+        return {"c": [self._dec_c[l].clone() for l in range(len(self.rnn_dec))],
+                "h": [self._dec_h[l].clone() for l in range(len(self.rnn_dec))]}
+
+    def set_decoder_states(self, rnn_states):
+        n = len(self.rnn_dec)
+        B = rnn_states["c"][0].shape[0]
+        c = torch.zeros(n, B, self.H, dtype=torch.float32, device=self.device)
+        hh = torch.zeros(n, B, self.H, dtype=torch.float32, device=self.device)
+        for l in range(min(n, len(rnn_states["c"]))):
+            c[l] = rnn_states["c"][l]
+            hh[l] = rnn_states["h"][l]
+        self._dec_c, self._dec_h = c, hh

@@ -1,0 +1,206 @@
+/* astk.h -- C ABI of libastk.so: the MI355X (gfx950) encoder-decoder train-step kernels.
+ *
+ * The reference (0xSameer/ast) has no FFI: its hot path is Python calling Chainer links/functions.
+ * Each entry point below replaces the Chainer call sequence of one reference function, cited as
+ * /root/reference/<file>:<lines>.  Conventions:
+ *   - every pointer is a caller-owned DEVICE pointer (16-byte aligned), sizes are explicit;
+ *   - no allocation, no ownership transfer, no implicit synchronisation: functions only enqueue
+ *     work on `stream` (a hipStream_t passed as void*), so a caller may capture them in a hipGraph;
+ *   - the caller supplies one workspace per op (size from the matching *_workspace_bytes query);
+ *     the forward call leaves saved activations in it and the backward call reads them, so it must
+ *     stay untouched between the two;
+ *   - return 0 on success, <0 on error; astk_last_error() gives the thread-local message;
+ *   - weight layouts are Chainer's (A1/A2/A3/A10 of SURVEY.md): Linear W (out,in), LSTM gates
+ *     interleaved (unit j, gate k -> row 4j+k, k = a,i,f,o), Conv W (out,in,kh,kw).
+ * All arithmetic is float32 (f32-input MFMA for the GEMMs), matching the reference's dtype.
+ */
+#ifndef ASTK_H
+#define ASTK_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASTK_VERSION 100
+#define ASTK_MAX_CNN_LAYERS 4
+#define ASTK_MAX_RNN_LAYERS 8
+
+int astk_version(void);
+const char* astk_last_error(void);
+
+/* ---------------------------------------------------------------- generic f32 MFMA GEMM
+ * C[M,N] (+)= op(A) op(B) (+ bias[n]).  layout: 0 = "NT"  A[M,K] K-contiguous, B[N,K] K-contiguous (Linear forward)
+ *                                               1 = "NN"  A[M,K], B[K,N]                             (dgrad)
+ *                                               2 = "TN"  A[K,M], B[K,N]                             (wgrad)
+ * mode: 0 store, 1 C += result (single pass), 2 atomic add with split-K over `ksplit` slices.
+ * batch > 1 repeats with element strides sA/sB/sC.  Leading dimensions must be multiples of 4.
+ * Replaces the cuBLAS sgemm behind chainer.functions.linear / its backward (Chainer-sem A2). */
+int astk_gemm_f32(int layout, int M, int N, int K,
+                  const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                  const float* bias, int mode, int ksplit, int batch, long sA, long sB, long sC, void* stream);
+
+/* ---------------------------------------------------------------- CNN front-end  (seq2seq.py:158-180)
+ * [Conv2D(no bias) -> BatchNorm(train: batch stats) -> ReLU] x n_layers, then the (T'',B,C*F') time-major
+ * re-layout with feature index c*F'+f (quirk Q9).  Layer 0: in_channels 1, kernel (kt,kf), stride (st,sf),
+ * pad (pt,0).  Layers >= 1: kernel (kt,1), stride (st,1), pad (pt,0) -- the shipped cnn_config. */
+typedef struct {
+  int B, T, D;
+  int n_layers;
+  int C[ASTK_MAX_CNN_LAYERS];
+  int kt[ASTK_MAX_CNN_LAYERS], kf[ASTK_MAX_CNN_LAYERS];
+  int st[ASTK_MAX_CNN_LAYERS], sf[ASTK_MAX_CNN_LAYERS];
+  int pt[ASTK_MAX_CNN_LAYERS];
+  float bn_eps;    /* 2e-5  (Chainer-sem A4) */
+  float bn_decay;  /* 0.9 */
+} astk_cnn_desc;
+
+typedef struct {
+  const float* W;      /* (C, Cin, kt, kf) */
+  const float* gamma;  /* (C) */
+  const float* beta;   /* (C) */
+  float* avg_mean;     /* (C) running stats, updated in train mode */
+  float* avg_var;      /* (C) */
+} astk_cnn_layer_params;
+
+typedef struct {
+  float* dW;
+  float* dgamma;
+  float* dbeta;
+} astk_cnn_layer_grads;
+
+/* output dims: T_out = T'', F_out = F', feature dim = C_last*F' */
+int astk_conv_bn_relu_out_dims(const astk_cnn_desc* d, int* T_out, int* F_out, int* feat_dim);
+size_t astk_conv_bn_relu_workspace_bytes(const astk_cnn_desc* d);
+/* X (B,T,D); noise (B,T,D) or NULL: X*noise is the speech-noise product of seq2seq.py:297-305;
+ * out (T'',B,C_last*F').  train=0 uses running statistics (chainer.config.train False). */
+int astk_conv_bn_relu_fwd(const astk_cnn_desc* d, const astk_cnn_layer_params* layers, const float* X,
+                          const float* noise, float* out, void* ws, size_t ws_bytes, int train, void* stream);
+/* d_out (T'',B,C_last*F') is overwritten.  Gradients are ACCUMULATED into grads (caller zeroes = cleargrads). */
+int astk_conv_bn_relu_bwd(const astk_cnn_desc* d, const astk_cnn_layer_params* layers,
+                          const astk_cnn_layer_grads* grads, float* d_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- encoder LSTM stacks  (seq2seq.py:182-242)
+ * n_dirs independent uni-directional stacks of n_layers L.LSTM links (Chainer-sem A1), dropout on each
+ * layer's *output* copy only.  Direction 1 consumes frames in the reference's order 0,T-1,...,1 (quirk Q1)
+ * and its outputs are flipped before the concat, so enc_states[b,p,h:2h] is what seq2seq.py:231-242 builds. */
+typedef struct {
+  int T, B, in_dim, h, n_layers, n_dirs;
+} astk_lstm_stack_desc;
+
+typedef struct {
+  const float* Wu; /* upward.W  (4h, in)  */
+  const float* b;  /* upward.b  (4h)      */
+  const float* Wl; /* lateral.W (4h, h)   */
+} astk_lstm_params;
+
+typedef struct {
+  float* dWu;
+  float* db;
+  float* dWl;
+} astk_lstm_grads;
+
+size_t astk_lstm_stack_workspace_bytes(const astk_lstm_stack_desc* d);
+/* x (T,B,in); params[dir*n_layers+layer]; masks: NULL or (n_dirs,n_layers,T,B,h) scaled keep-masks indexed by
+ * loop step; enc_states (B,T,n_dirs*h); cT,hT (n_dirs,n_layers,B,h) final UN-dropped states. */
+int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* params, const float* x,
+                        const float* masks, float* enc_states, float* cT, float* hT,
+                        void* ws, size_t ws_bytes, void* stream);
+/* d_enc_states (B,T,n_dirs*h); d_cT,d_hT (n_dirs,n_layers,B,h) or NULL; dx (T,B,in) written (may be NULL). */
+int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* params, const astk_lstm_grads* grads,
+                        const float* x, const float* masks, const float* d_enc_states, const float* d_cT,
+                        const float* d_hT, float* dx, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- attention step  (seq2seq.py:336-357)
+ * q = Wa h + ba is computed by the caller (GEMM); this is the scan over enc_states:
+ * s[b,t] = enc[b,t,:].q[b,:]; alpha = softmax_t(s) (no mask, quirk Q2); cv[b,:] = sum_t alpha[b,t] enc[b,t,:].
+ * One streaming read of enc_states (online softmax), split over nsplit time chunks per batch row. */
+size_t astk_attn_workspace_bytes(int B, int T, int H);
+int astk_attn_step_fwd(int B, int T, int H, const float* enc, const float* q, float* alpha, float* cv,
+                       void* ws, size_t ws_bytes, void* stream);
+/* given d_cv: ds[b,t] = alpha (enc.d_cv - cv.d_cv); dq[b,:] = sum_t ds enc[b,t,:].  One read of enc_states.
+ * d_enc is NOT touched here: it is produced once per train step by the deferred batched GEMM in
+ * astk_decoder_bwd (d_enc[b] = alpha_b^T d_cv_b + ds_b^T q_b over all steps). */
+int astk_attn_step_bwd(int B, int T, int H, const float* enc, const float* alpha, const float* cv,
+                       const float* d_cv, float* ds, float* dq, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- decoder loop  (seq2seq.py:318-333, 361-473)
+ * embed(+dropout) -> [emb; ht] (input feeding) -> n_layers LSTM(H) -> attention -> ht = tanh(Wc[cv;h]+bc)
+ * -> logits = Wo ht + bo -> argmax feedback when not teacher-forced (quirk Q4) -> class-weighted softmax-CE
+ * with denominator B (quirk Q6), summed over the L-1 steps. */
+typedef struct {
+  int B, L, T, H, E, A, V, n_layers;
+} astk_decoder_desc;
+
+typedef struct {
+  const float* embed;                         /* (V,E) */
+  astk_lstm_params lstm[ASTK_MAX_RNN_LAYERS]; /* layer 0 in = E+A, others in = H */
+  const float* Wa; const float* ba;           /* attn_Wa (H,H) */
+  const float* Wc; const float* bc;           /* context (A,2H) */
+  const float* Wo; const float* bo;           /* out     (V,A)  */
+  const float* class_weight;                  /* (V) : mask_pad_id, seq2seq.py:152-156 */
+} astk_decoder_params;
+
+typedef struct {
+  float* d_embed;
+  astk_lstm_grads lstm[ASTK_MAX_RNN_LAYERS];
+  float* dWa; float* dba;
+  float* dWc; float* dbc;
+  float* dWo; float* dbo;
+} astk_decoder_grads;
+
+size_t astk_decoder_workspace_bytes(const astk_decoder_desc* d);
+/* enc (B,T,H); c0,h0 (n_layers,B,H) initial states (zeros for layers the encoder does not seed);
+ * y (B,L) int32 targets; use_truth (L-1) int32 flags; emb_mask NULL or (L-1,B,E); rnn_masks NULL or
+ * (n_layers,L-1,B,H); outputs: loss (1) = sum over steps, pred (L-1,B) int32 argmax per step (may be NULL). */
+int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* p, const float* enc,
+                     const float* c0, const float* h0, const int32_t* y, const int32_t* use_truth,
+                     const float* emb_mask, const float* rnn_masks, float* loss, int32_t* pred,
+                     void* ws, size_t ws_bytes, void* stream);
+/* gradients of `loss` (upstream 1.0).  d_enc (B,T,H), d_c0, d_h0 (n_layers,B,H) are written;
+ * parameter gradients are ACCUMULATED into g. */
+int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* p, const astk_decoder_grads* g,
+                     const float* enc, const float* c0, const float* h0, const int32_t* y,
+                     const float* emb_mask, const float* rnn_masks,
+                     float* d_enc, float* d_c0, float* d_h0, void* ws, size_t ws_bytes, void* stream);
+/* eval-mode single step for predict()/beam (seq2seq.py:361-396 under train=False): states (n_layers,B,H)
+ * and ht (B,A) are updated in place; logits (B,V) and alpha (B,T) written. */
+int astk_decoder_step_infer(const astk_decoder_desc* d, const astk_decoder_params* p, const float* enc,
+                            float* c, float* h, float* ht, const int32_t* tokens, float* logits, float* alpha,
+                            int32_t* argmax, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- softmax cross-entropy  (seq2seq.py:468-470)
+ * rows = B: loss_rows[b] = -w[t_b] log_softmax(x_b)[t_b] / B ; dlogits = w[t_b](softmax - onehot)/B written in
+ * place of logits; argmax (first maximum) written when non-NULL.  (Chainer-sem A6) */
+int astk_softmax_ce_fwd(int B, int V, long ld, float* logits_inout, const int32_t* targets, long t_stride,
+                        const float* class_weight, float inv_count, float* loss_rows, int32_t* argmax, void* stream);
+
+/* ---------------------------------------------------------------- optimizer  (nn.py:81-119, Chainer-sem A7/A8)
+ * One flat parameter / gradient buffer.  sqnorm[0] = sum (g + l2*p)^2 in float64 (the clip norm of hook order
+ * WeightDecay -> GradientClipping); the step applies decay, the clip rate min(1, clip/sqrt(sqnorm)) and
+ * AMSGrad-Adam with lr_t = alpha*sqrt(1-b2^t)/(1-b1^t) computed by the caller. */
+int astk_grad_sqnorm(const float* g, const float* p, float l2, size_t n, double* sqnorm, void* stream);
+int astk_decay_clip_amsgrad_step(float* p, const float* g, float* m, float* v, float* vhat, size_t n,
+                                 float l2, float clip, const double* sqnorm, float lr_t, float beta1, float beta2,
+                                 float eps, int amsgrad, void* stream);
+int astk_decay_clip_sgd_step(float* p, const float* g, size_t n, float l2, float clip, const double* sqnorm,
+                             float lr, void* stream);
+
+/* ---------------------------------------------------------------- utilities
+ * Dropout keep-masks (Chainer-sem A5): out[i] = (u_i >= ratio) / (1-ratio), u from a counter-based hash RNG. */
+int astk_fill_dropout_mask(float* out, size_t n, float ratio, uint64_t seed, uint64_t offset, void* stream);
+/* out[i] = 1 + sigma*N(0,1): the multiplicative speech noise of seq2seq.py:300-302, generated on device. */
+int astk_fill_normal(float* out, size_t n, float mean, float sigma, uint64_t seed, uint64_t offset, void* stream);
+int astk_scale_f32(float* x, size_t n, float s, void* stream);
+
+/* hipGraph capture of a sequence of the calls above on `stream` (static shapes per bucket). */
+int astk_graph_begin(void* stream);
+int astk_graph_end(void* stream, void** graph_exec);
+int astk_graph_launch(void* graph_exec, void* stream);
+int astk_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASTK_H */

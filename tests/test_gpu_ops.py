@@ -1,0 +1,426 @@
+"""GPU parity tests, operator level: every C-ABI entry point of include/astk.h against a float64 CPU reference
+(torch autograd restatement in oracle/ast_ref_torch.py, itself cross-checked against oracle/ast_ref.py).
+Tolerances: float32 kernels vs float64 reference -> relative 2e-4 on tensors (north_star: 1e-4 on loss /
+grad-norm, asserted in test_gpu_model.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import tiny_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ast_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return _lib.load()
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(a)).to("cuda", dtype).contiguous()
+
+
+def vp(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ok(lib, rc):
+    assert rc == 0, lib.astk_last_error().decode()
+
+
+def close(got, ref, rtol=2e-4, atol=None, msg=""):
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref = ref.detach().cpu().double().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (msg, got.shape, ref.shape)
+    scale = np.abs(ref).max() if ref.size else 1.0
+    tol = (atol if atol is not None else rtol * max(scale, 1e-6))
+    err = np.abs(got - ref).max() if ref.size else 0.0
+    assert err <= tol, f"{msg}: max abs err {err:.3e} > {tol:.3e} (ref scale {scale:.3e})"
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 72, 120), (37, 1098, 512), (6, 8, 44), (300, 260, 1000), (1, 1, 4)])
+def test_gemm_layouts(lib, layout, M, N, K):
+    rng = np.random.default_rng(M * 7 + N * 3 + K + layout)
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((N, K))
+    bias = rng.standard_normal(N)
+    ref = A @ B.T + bias
+    pad = lambda n: (n + 3) // 4 * 4
+    if layout == 0:
+        Ad, lda, Bd, ldb = np.zeros((M, pad(K))), pad(K), np.zeros((N, pad(K))), pad(K)
+        Ad[:, :K], Bd[:, :K] = A, B
+    elif layout == 1:
+        Ad, lda, Bd, ldb = np.zeros((M, pad(K))), pad(K), np.zeros((K, pad(N))), pad(N)
+        Ad[:, :K], Bd[:, :N] = A, B.T
+    else:
+        Ad, lda, Bd, ldb = np.zeros((K, pad(M))), pad(M), np.zeros((K, pad(N))), pad(N)
+        Ad[:, :M], Bd[:, :N] = A.T, B.T
+    a, b, bi = dev(Ad), dev(Bd), dev(bias)
+    c = torch.full((M, pad(N) + 4), 7.0, device="cuda")
+    ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(a), lda, vp(b), ldb, vp(c), c.shape[1], vp(bi), 0, 1, 1, 0, 0, 0, stream()))
+    close(c[:, :N], ref, msg="store")
+    assert float(c[:, N:].min()) == 7.0 and float(c[:, N:].max()) == 7.0, "wrote outside N"
+    # accumulate
+    ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(a), lda, vp(b), ldb, vp(c), c.shape[1], None, 1, 1, 1, 0, 0, 0, stream()))
+    close(c[:, :N], 2 * ref - bias, msg="accum")
+    # split-K atomics into zeros
+    c.zero_()
+    ks = 3 if K >= 96 else 1
+    ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(a), lda, vp(b), ldb, vp(c), c.shape[1], vp(bi), 2, ks, 1, 0, 0, 0, stream()))
+    close(c[:, :N], ref, msg="atomic split-K")
+
+
+def test_gemm_batched_tn(lib):
+    rng = np.random.default_rng(3)
+    Bt, M, N, K = 5, 22, 40, 9
+    A = rng.standard_normal((K, Bt, 24))       # rows k, batch stride 24, M=22 valid cols
+    Bm = rng.standard_normal((K, Bt, 40))
+    ref = np.einsum("kbm,kbn->bmn", A[:, :, :M], Bm)
+    a, b = dev(A), dev(Bm)
+    c = torch.zeros(Bt, M, N, device="cuda")
+    ok(lib, lib.astk_gemm_f32(2, M, N, K, vp(a), Bt * 24, vp(b), Bt * 40, vp(c), N, None, 0, 1, Bt, 24, 40, M * N, stream()))
+    close(c, ref)
+
+
+# ------------------------------------------------------------------ CNN front-end
+def _cnn_desc(cfg, B, T, D):
+    from ast_amd._lib import CnnDesc
+    cd = CnnDesc()
+    cc = cfg["cnn_config"]["cnn_layers"]
+    cd.B, cd.T, cd.D, cd.n_layers = B, T, D, len(cc)
+    for i, l in enumerate(cc):
+        cd.C[i] = l["out_channels"]
+        cd.kt[i], cd.kf[i] = l["ksize"]
+        cd.st[i], cd.sf[i] = l["stride"]
+        cd.pt[i] = l["pad"][0]
+    cd.bn_eps, cd.bn_decay = 2e-5, 0.9
+    return cd
+
+
+@pytest.mark.parametrize("B,T,D,c0,c1", [(3, 21, 26, 4, 8), (2, 50, 80, 8, 12), (2, 16, 13, 4, 4)])
+@pytest.mark.parametrize("with_noise", [False, True])
+def test_cnn_fwd_bwd(lib, B, T, D, c0, c1, with_noise):
+    from ast_amd._lib import CnnLayerGrads, CnnLayerParams
+    from oracle.ast_ref import init_params
+    from oracle.ast_ref_torch import cnn_torch
+    cfg = tiny_cfg(c0=c0, c1=c1)
+    P = init_params(cfg, D, 11, seed=1, dtype=np.float64)
+    rng = np.random.default_rng(0)
+    for i in range(2):                       # non-trivial BN affine
+        P[f"CNN_{i}_bn/gamma"] = 1 + 0.3 * rng.standard_normal(P[f"CNN_{i}_bn/gamma"].shape)
+        P[f"CNN_{i}_bn/beta"] = 0.2 * rng.standard_normal(P[f"CNN_{i}_bn/beta"].shape)
+    X = rng.standard_normal((B, T, D))
+    noise = rng.normal(1.0, 0.25, X.shape) if with_noise else None
+    Pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=k.startswith("CNN") and "avg" not in k) for k, v in P.items()}
+    out_ref = cnn_torch(cfg, Pt, torch.tensor(X), torch.tensor(noise) if with_noise else None)
+    gout = rng.standard_normal(out_ref.shape)
+    out_ref.backward(torch.tensor(gout))
+    cd = _cnn_desc(cfg, B, T, D)
+    t2, f2, feat = C.c_int(), C.c_int(), C.c_int()
+    ok(lib, lib.astk_conv_bn_relu_out_dims(C.byref(cd), C.byref(t2), C.byref(f2), C.byref(feat)))
+    assert (t2.value, B, feat.value) == tuple(out_ref.shape)
+    names = ["CNN_0", "CNN_1"]
+    prm = {n + s: dev(P[n + s]) for n in names for s in ("/W", "_bn/gamma", "_bn/beta", "_bn/avg_mean", "_bn/avg_var")}
+    grd = {k: torch.zeros_like(v) for k, v in prm.items()}
+    cp, cg = (CnnLayerParams * 2)(), (CnnLayerGrads * 2)()
+    for i, n in enumerate(names):
+        cp[i].W, cp[i].gamma, cp[i].beta = prm[n + "/W"].data_ptr(), prm[n + "_bn/gamma"].data_ptr(), prm[n + "_bn/beta"].data_ptr()
+        cp[i].avg_mean, cp[i].avg_var = prm[n + "_bn/avg_mean"].data_ptr(), prm[n + "_bn/avg_var"].data_ptr()
+        cg[i].dW, cg[i].dgamma, cg[i].dbeta = grd[n + "/W"].data_ptr(), grd[n + "_bn/gamma"].data_ptr(), grd[n + "_bn/beta"].data_ptr()
+    nbytes = lib.astk_conv_bn_relu_workspace_bytes(C.byref(cd))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    out = torch.empty(t2.value, B, feat.value, device="cuda")
+    xd, nd = dev(X), (dev(noise) if with_noise else None)
+    ok(lib, lib.astk_conv_bn_relu_fwd(C.byref(cd), cp, vp(xd), vp(nd), vp(out), vp(ws), nbytes, 1, stream()))
+    close(out, out_ref, msg="cnn out")
+    # running statistics (A4): mean 0.1*mu, var 0.9 + 0.1*var*m/(m-1)
+    h = torch.tensor(X * (noise if with_noise else 1.0)).unsqueeze(1)
+    y0 = torch.nn.functional.conv2d(h, Pt["CNN_0/W"].detach(), stride=(2, 13), padding=(4, 0))
+    m = y0.numel() // y0.shape[1]
+    close(prm["CNN_0_bn/avg_mean"], 0.1 * y0.mean(dim=(0, 2, 3)), msg="avg_mean")
+    close(prm["CNN_0_bn/avg_var"], 0.9 + 0.1 * y0.var(dim=(0, 2, 3), unbiased=False) * m / (m - 1), msg="avg_var")
+    g = dev(gout)
+    ok(lib, lib.astk_conv_bn_relu_bwd(C.byref(cd), cp, cg, vp(g), vp(ws), nbytes, stream()))
+    for n in names:
+        for s in ("/W", "_bn/gamma", "_bn/beta"):
+            close(grd[n + s], Pt[n + s].grad, rtol=5e-4, msg="grad " + n + s)
+    # eval mode uses the running statistics
+    ok(lib, lib.astk_conv_bn_relu_fwd(C.byref(cd), cp, vp(xd), None, vp(out), vp(ws), nbytes, 0, stream()))
+    hh = torch.tensor(X).unsqueeze(1)
+    for i, l in enumerate(cfg["cnn_config"]["cnn_layers"]):
+        hh = torch.nn.functional.conv2d(hh, Pt[f"CNN_{i}/W"].detach(), stride=tuple(l["stride"]), padding=tuple(l["pad"]))
+        hh = torch.nn.functional.batch_norm(hh, prm[f"CNN_{i}_bn/avg_mean"].cpu().double(), prm[f"CNN_{i}_bn/avg_var"].cpu().double(),
+                                            Pt[f"CNN_{i}_bn/gamma"].detach(), Pt[f"CNN_{i}_bn/beta"].detach(), training=False, eps=2e-5)
+        hh = torch.relu(hh)
+    Bc, Cc, T2, F2 = hh.shape
+    close(out, hh.permute(2, 0, 1, 3).reshape(T2, B, Cc * F2), msg="eval-mode out")
+
+
+# ------------------------------------------------------------------ encoder LSTM stacks
+@pytest.mark.parametrize("T,B,in_dim,h,nl,masks", [(7, 3, 12, 4, 2, False), (9, 5, 24, 20, 3, True), (5, 33, 64, 36, 1, True), (1, 2, 8, 4, 2, False)])
+def test_lstm_stack(lib, T, B, in_dim, h, nl, masks):
+    from ast_amd._lib import LstmGrads, LstmParams, LstmStackDesc
+    from oracle.ast_ref_torch import encoder_torch
+    rng = np.random.default_rng(T + B)
+    cfg = {"rnn_config": {"enc_layers": nl}}
+    P, names = {}, []
+    for pat in ("L{}_enc", "L{}_rev_enc"):
+        n_in = in_dim
+        for k in range(nl):
+            n = pat.format(k)
+            names.append(n)
+            P[n + "/upward/W"] = rng.standard_normal((4 * h, n_in)) / np.sqrt(n_in)
+            P[n + "/upward/b"] = rng.standard_normal(4 * h) * 0.3
+            P[n + "/lateral/W"] = rng.standard_normal((4 * h, h)) / np.sqrt(h)
+            n_in = h
+    x = rng.standard_normal((T, B, in_dim))
+    mk = ((rng.random((2, nl, T, B, h)) >= 0.3) / 0.7) if masks else None
+    Pt = {k: torch.tensor(v, requires_grad=True) for k, v in P.items()}
+    xt = torch.tensor(x, requires_grad=True)
+    enc, cT, hT = encoder_torch(cfg, Pt, xt, torch.tensor(mk) if masks else None)
+    g_enc, g_c, g_h = rng.standard_normal(enc.shape), rng.standard_normal(cT.shape), rng.standard_normal(hT.shape)
+    (enc * torch.tensor(g_enc)).sum().add((cT * torch.tensor(g_c)).sum()).add((hT * torch.tensor(g_h)).sum()).backward()
+    d = LstmStackDesc(T, B, in_dim, h, nl, 2)
+    prm = {k: dev(v) for k, v in P.items()}
+    grd = {k: torch.zeros_like(v) for k, v in prm.items()}
+    lp, lg = (LstmParams * (2 * nl))(), (LstmGrads * (2 * nl))()
+    for i, n in enumerate(names):
+        lp[i].Wu, lp[i].b, lp[i].Wl = (prm[n + s].data_ptr() for s in ("/upward/W", "/upward/b", "/lateral/W"))
+        lg[i].dWu, lg[i].db, lg[i].dWl = (grd[n + s].data_ptr() for s in ("/upward/W", "/upward/b", "/lateral/W"))
+    nbytes = lib.astk_lstm_stack_workspace_bytes(C.byref(d))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    xd, md = dev(x), (dev(mk) if masks else None)
+    enc_d = torch.zeros(B, T, 2 * h, device="cuda")
+    cT_d, hT_d = torch.zeros(2, nl, B, h, device="cuda"), torch.zeros(2, nl, B, h, device="cuda")
+    ok(lib, lib.astk_lstm_stack_fwd(C.byref(d), lp, vp(xd), vp(md), vp(enc_d), vp(cT_d), vp(hT_d), vp(ws), nbytes, stream()))
+    close(enc_d, enc, msg="enc_states")
+    close(cT_d, cT, msg="cT")
+    close(hT_d, hT, msg="hT")
+    dx = torch.zeros(T, B, in_dim, device="cuda")
+    ok(lib, lib.astk_lstm_stack_bwd(C.byref(d), lp, lg, vp(xd), vp(md), vp(dev(g_enc)), vp(dev(g_c)), vp(dev(g_h)), vp(dx), vp(ws),
+                                    nbytes, stream()))
+    close(dx, xt.grad, rtol=5e-4, msg="dx")
+    for k in P:
+        close(grd[k], Pt[k].grad, rtol=5e-4, msg="grad " + k)
+
+
+# ------------------------------------------------------------------ attention scan
+@pytest.mark.parametrize("B,T,H", [(3, 6, 8), (32, 50, 512), (5, 201, 260), (2, 9, 1024)])
+def test_attention_step(lib, B, T, H):
+    rng = np.random.default_rng(B * T)
+    enc = rng.standard_normal((B, T, H)) * 0.5
+    q = rng.standard_normal((B, H)) * 0.5
+    et, qt = torch.tensor(enc, requires_grad=True), torch.tensor(q, requires_grad=True)
+    alpha = torch.softmax(torch.einsum("bth,bh->bt", et, qt), dim=1)
+    cv = torch.einsum("bth,bt->bh", et, alpha)
+    g = rng.standard_normal(cv.shape)
+    Tp = (T + 3) // 4 * 4
+    nbytes = lib.astk_attn_workspace_bytes(B, T, H)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    ed, qd = dev(enc), dev(q)
+    a_d, cv_d = torch.zeros(B, Tp, device="cuda"), torch.zeros(B, H, device="cuda")
+    ok(lib, lib.astk_attn_step_fwd(B, T, H, vp(ed), vp(qd), vp(a_d), vp(cv_d), vp(ws), nbytes, stream()))
+    close(a_d[:, :T], alpha, msg="alpha")
+    close(cv_d, cv, msg="cv")
+    # backward: ds = dL/dscore, dq; d_enc is the deferred product alpha^T d_cv + ds^T q (checked in the decoder test)
+    scores = torch.einsum("bth,bh->bt", et, qt)
+    scores.retain_grad()
+    al2 = torch.softmax(scores, dim=1)
+    cv2 = torch.einsum("bth,bt->bh", et.detach(), al2)
+    cv2.backward(torch.tensor(g))
+    ds_ref = scores.grad
+    dq_ref = torch.einsum("bt,bth->bh", ds_ref, et.detach())
+    ds_d, dq_d = torch.zeros(B, Tp, device="cuda"), torch.zeros(B, H, device="cuda")
+    ok(lib, lib.astk_attn_step_bwd(B, T, H, vp(ed), vp(a_d), vp(cv_d), vp(dev(g)), vp(ds_d), vp(dq_d), vp(ws), nbytes, stream()))
+    close(ds_d[:, :T], ds_ref, rtol=5e-4, msg="ds")
+    close(dq_d, dq_ref, rtol=5e-4, msg="dq")
+
+
+# ------------------------------------------------------------------ decoder loop
+def _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=0):
+    from ast_amd._lib import DecoderDesc, DecoderGrads, DecoderParams
+    rng = np.random.default_rng(seed)
+    P = {"embed_dec/W": rng.standard_normal((V, E)), "attn_Wa/W": rng.standard_normal((H, H)) / np.sqrt(H),
+         "attn_Wa/b": rng.standard_normal(H) * 0.1, "context/W": rng.standard_normal((A, 2 * H)) / np.sqrt(2 * H),
+         "context/b": rng.standard_normal(A) * 0.1, "out/W": rng.standard_normal((V, A)) / np.sqrt(A),
+         "out/b": rng.standard_normal(V) * 0.1}
+    n_in = E + A
+    for k in range(nl):
+        P[f"L{k}_dec/upward/W"] = rng.standard_normal((4 * H, n_in)) / np.sqrt(n_in)
+        P[f"L{k}_dec/upward/b"] = rng.standard_normal(4 * H) * 0.2
+        P[f"L{k}_dec/lateral/W"] = rng.standard_normal((4 * H, H)) / np.sqrt(H)
+        n_in = H
+    enc = rng.standard_normal((B, T, H)) * 0.5
+    c0, h0 = rng.standard_normal((nl, B, H)) * 0.5, np.tanh(rng.standard_normal((nl, B, H)))
+    y = np.zeros((B, L), np.int32)
+    for b in range(B):
+        n = L if b == 0 else int(rng.integers(max(L // 2, 3), L + 1))
+        y[b, 0], y[b, 1:n - 1], y[b, n - 1] = 1, rng.integers(4, V, size=n - 2), 2
+    S = L - 1
+    flags = [1] + [int(rng.random() < 0.5) for _ in range(S - 2)] + [1] if S >= 2 else [1] * S
+    em = ((rng.random((S, B, E)) >= 0.3) / 0.7) if masks else None
+    rm = ((rng.random((nl, S, B, H)) >= 0.3) / 0.7) if masks else None
+    d = DecoderDesc(B, L, T, H, E, A, V, nl)
+    prm = {k: dev(v) for k, v in P.items()}
+    grd = {k: torch.zeros_like(v) for k, v in prm.items()}
+    cw = torch.ones(V, device="cuda")
+    cw[0] = 0
+    dp, dg = DecoderParams(), DecoderGrads()
+    dp.embed, dg.d_embed = prm["embed_dec/W"].data_ptr(), grd["embed_dec/W"].data_ptr()
+    for k in range(nl):
+        dp.lstm[k].Wu, dp.lstm[k].b, dp.lstm[k].Wl = (prm[f"L{k}_dec/" + s].data_ptr() for s in ("upward/W", "upward/b", "lateral/W"))
+        dg.lstm[k].dWu, dg.lstm[k].db, dg.lstm[k].dWl = (grd[f"L{k}_dec/" + s].data_ptr() for s in ("upward/W", "upward/b", "lateral/W"))
+    dp.Wa, dp.ba, dp.Wc, dp.bc, dp.Wo, dp.bo = (prm[k].data_ptr() for k in ("attn_Wa/W", "attn_Wa/b", "context/W", "context/b", "out/W", "out/b"))
+    dg.dWa, dg.dba, dg.dWc, dg.dbc, dg.dWo, dg.dbo = (grd[k].data_ptr() for k in ("attn_Wa/W", "attn_Wa/b", "context/W", "context/b", "out/W", "out/b"))
+    dp.class_weight = cw.data_ptr()
+    return dict(P=P, enc=enc, c0=c0, h0=h0, y=y, flags=flags, em=em, rm=rm, d=d, dp=dp, dg=dg, prm=prm, grd=grd, cw=cw, S=S)
+
+
+@pytest.mark.parametrize("B,L,T,H,E,A,V,nl,masks", [(3, 6, 6, 8, 4, 8, 11, 2, False), (5, 9, 23, 32, 12, 24, 57, 3, True),
+                                                    (33, 4, 10, 64, 16, 64, 130, 1, True), (2, 2, 5, 8, 4, 8, 7, 1, False)])
+def test_decoder_fwd_bwd(lib, B, L, T, H, E, A, V, nl, masks):
+    from oracle.ast_ref_torch import decoder_torch
+    s = _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=B + L)
+    cfg = {"rnn_config": {"dec_layers": nl, "attn_units": A}}
+    Pt = {k: torch.tensor(v, requires_grad=True) for k, v in s["P"].items()}
+    enc_t = torch.tensor(s["enc"], requires_grad=True)
+    c0_t, h0_t = torch.tensor(s["c0"], requires_grad=True), torch.tensor(s["h0"], requires_grad=True)
+    tt = lambda a: None if a is None else torch.tensor(a)
+    loss_ref, pred_ref = decoder_torch(cfg, Pt, enc_t, c0_t, h0_t, s["y"], s["flags"], V, tt(s["em"]), tt(s["rm"]))
+    loss_ref.backward()
+    nbytes = lib.astk_decoder_workspace_bytes(C.byref(s["d"]))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    enc_d, c0_d, h0_d = dev(s["enc"]), dev(s["c0"]), dev(s["h0"])
+    y_d, fl_d = dev(s["y"], torch.int32), dev(np.asarray(s["flags"]), torch.int32)
+    em_d, rm_d = (dev(s["em"]) if masks else None), (dev(s["rm"]) if masks else None)
+    loss_d = torch.zeros(1, device="cuda")
+    pred_d = torch.zeros(s["S"], B, dtype=torch.int32, device="cuda")
+    ok(lib, lib.astk_decoder_fwd(C.byref(s["d"]), C.byref(s["dp"]), vp(enc_d), vp(c0_d), vp(h0_d), vp(y_d), vp(fl_d), vp(em_d), vp(rm_d),
+                                 vp(loss_d), vp(pred_d), vp(ws), nbytes, stream()))
+    assert abs(float(loss_d) - float(loss_ref)) <= 1e-4 * abs(float(loss_ref)), (float(loss_d), float(loss_ref))
+    assert (pred_d.cpu().numpy() == pred_ref.numpy()).all(), "argmax feedback tokens differ"
+    d_enc = torch.zeros(B, T, H, device="cuda")
+    d_c0, d_h0 = torch.zeros(nl, B, H, device="cuda"), torch.zeros(nl, B, H, device="cuda")
+    ok(lib, lib.astk_decoder_bwd(C.byref(s["d"]), C.byref(s["dp"]), C.byref(s["dg"]), vp(enc_d), vp(c0_d), vp(h0_d), vp(y_d), vp(em_d),
+                                 vp(rm_d), vp(d_enc), vp(d_c0), vp(d_h0), vp(ws), nbytes, stream()))
+    close(d_enc, enc_t.grad, rtol=5e-4, msg="d_enc")
+    close(d_c0, c0_t.grad, rtol=5e-4, msg="d_c0")
+    close(d_h0, h0_t.grad, rtol=5e-4, msg="d_h0")
+    for k in s["P"]:
+        close(s["grd"][k], Pt[k].grad, rtol=5e-4, msg="grad " + k)
+
+
+def test_decoder_step_infer_matches_teacher_forced_step(lib):
+    """One eval-mode step from the initial state equals step 0 of the training loop without dropout."""
+    B, L, T, H, E, A, V, nl = 4, 5, 12, 16, 8, 16, 23, 2
+    s = _dec_setup(lib, B, L, T, H, E, A, V, nl, False, seed=5)
+    nbytes = lib.astk_decoder_workspace_bytes(C.byref(s["d"]))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    enc_d = dev(s["enc"])
+    c, h = dev(s["c0"]), dev(s["h0"])
+    ht = torch.zeros(B, A, device="cuda")
+    tok = dev(s["y"][:, 0], torch.int32)
+    logits, alpha = torch.zeros(B, V, device="cuda"), torch.zeros(B, T, device="cuda")
+    am = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ok(lib, lib.astk_decoder_step_infer(C.byref(s["d"]), C.byref(s["dp"]), vp(enc_d), vp(c), vp(h), vp(ht), vp(tok), vp(logits), vp(alpha),
+                                        vp(am), vp(ws), nbytes, stream()))
+    P = {k: torch.tensor(v) for k, v in s["P"].items()}
+    x = torch.cat([P["embed_dec/W"][torch.tensor(s["y"][:, 0]).long()], torch.zeros(B, A, dtype=torch.float64)], 1)
+    cs, hs = torch.tensor(s["c0"]), torch.tensor(s["h0"])
+    for k in range(nl):
+        z = (x @ P[f"L{k}_dec/upward/W"].t() + P[f"L{k}_dec/upward/b"] + hs[k] @ P[f"L{k}_dec/lateral/W"].t()).view(B, -1, 4)
+        a_, i_, f_, o_ = torch.tanh(z[..., 0]), torch.sigmoid(z[..., 1]), torch.sigmoid(z[..., 2]), torch.sigmoid(z[..., 3])
+        cn = a_ * i_ + f_ * cs[k]
+        x = o_ * torch.tanh(cn)
+        close(c[k], cn, msg=f"c{k}")
+        close(h[k], x, msg=f"h{k}")
+    q = x @ P["attn_Wa/W"].t() + P["attn_Wa/b"]
+    al = torch.softmax(torch.einsum("bth,bh->bt", torch.tensor(s["enc"]), q), 1)
+    cv = torch.einsum("bth,bt->bh", torch.tensor(s["enc"]), al)
+    htr = torch.tanh(torch.cat([cv, x], 1) @ P["context/W"].t() + P["context/b"])
+    lg = htr @ P["out/W"].t() + P["out/b"]
+    close(alpha, al, msg="alpha")
+    close(ht, htr, msg="ht")
+    close(logits, lg, msg="logits")
+    assert (am.cpu().numpy() == lg.argmax(1).numpy()).all()
+
+
+# ------------------------------------------------------------------ softmax-CE, optimizer, RNG
+def test_softmax_ce(lib):
+    rng = np.random.default_rng(1)
+    B, V, ld = 7, 1098, 1100
+    x = rng.standard_normal((B, V)) * 3
+    t = rng.integers(0, V, B).astype(np.int32)
+    t[2] = 0
+    w = np.ones(V)
+    w[0] = 0
+    xt = torch.tensor(x, requires_grad=True)
+    loss = torch.nn.functional.cross_entropy(xt, torch.tensor(t).long(), weight=torch.tensor(w), reduction="sum") / B
+    loss.backward()
+    buf = torch.zeros(B, ld, device="cuda")
+    buf[:, :V] = dev(x)
+    rows, am = torch.zeros(B, device="cuda"), torch.zeros(B, dtype=torch.int32, device="cuda")
+    ok(lib, lib.astk_softmax_ce_fwd(B, V, ld, vp(buf), vp(dev(t, torch.int32)), 1, vp(dev(w)), 1.0 / B, vp(rows), vp(am), stream()))
+    assert abs(float(rows.sum()) - float(loss)) < 1e-5 * abs(float(loss))
+    assert float(rows[2]) == 0.0
+    close(buf[:, :V], xt.grad, msg="dlogits")
+    assert float(buf[:, V:].abs().max()) == 0.0
+    assert (am.cpu().numpy() == x.argmax(1)).all()
+
+
+def test_optimizer_step_matches_reference(lib):
+    from oracle.ast_ref import RefOptimizer
+    from oracle import minichainer as F
+    rng = np.random.default_rng(2)
+    n = 10007
+    p0, grads = rng.standard_normal(n), [rng.standard_normal(n) * s for s in (0.05, 0.001, 0.2)]
+
+    class M:
+        def __init__(self):
+            self.p = {"a/W": F.Parameter(p0.copy())}
+
+        def params(self):
+            return list(self.p.items())
+    m = M()
+    ref = RefOptimizer(m, {"type": 0, "lr": 1e-3, "l2": 1e-4, "grad_clip": 2, "grad_noise_eta": 0, "freeze": []})
+    npad = (n + 3) // 4 * 4
+    p = torch.zeros(npad, device="cuda")
+    p[:n] = dev(p0)
+    mm, vv, vh = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
+    sq = torch.zeros(1, dtype=torch.float64, device="cuda")
+    for t, g0 in enumerate(grads, 1):
+        m.p["a/W"].grad = g0.copy()
+        ref.update()
+        g = torch.zeros(npad, device="cuda")
+        g[:n] = dev(g0)
+        ok(lib, lib.astk_grad_sqnorm(vp(g), vp(p), 1e-4, npad, vp(sq), stream()))
+        assert abs(float(sq.sqrt()) - ref.last_grad_norm) < 1e-5 * ref.last_grad_norm
+        lr_t = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        ok(lib, lib.astk_decay_clip_amsgrad_step(vp(p), vp(g), vp(mm), vp(vv), vp(vh), npad, 1e-4, 2.0, vp(sq), lr_t, 0.9, 0.999, 1e-8, 1,
+                                                 stream()))
+        close(p[:n], m.p["a/W"].data, rtol=1e-5, msg=f"params after step {t}")
+    assert float(p[n:].abs().max()) == 0.0
+
+
+def test_rng_fills(lib):
+    n = 1 << 20
+    m = torch.zeros(n, device="cuda")
+    ok(lib, lib.astk_fill_dropout_mask(vp(m), n, 0.3, 1234, 0, stream()))
+    keep = float((m > 0).float().mean())
+    assert abs(keep - 0.7) < 5e-3 and abs(float(m.max()) - 1 / 0.7) < 1e-6
+    m2 = torch.zeros(n, device="cuda")
+    ok(lib, lib.astk_fill_dropout_mask(vp(m2), n, 0.3, 1234, n, stream()))
+    assert float((m != m2).float().mean()) > 0.3, "successive offsets must give fresh masks"
+    z = torch.zeros(n, device="cuda")
+    ok(lib, lib.astk_fill_normal(vp(z), n, 1.0, 0.25, 99, 0, stream()))
+    assert abs(float(z.mean()) - 1.0) < 2e-3 and abs(float(z.std()) - 0.25) < 2e-3
