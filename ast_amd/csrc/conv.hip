@@ -95,9 +95,9 @@ int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
       P.dB[i] = bk > 0 ? bk : 0;
       P.DY[i] = c.take<float>((size_t)d->B * P.F * (P.Tn[i] + P.dF[i] + P.dB[i]) * P.Cn[i]);
       size_t wd = (size_t)P.Cn[i - 1] * na_max * P.Cn[i];
-      wd_max = wd_max > wd ? wd : wd_max;
+      wd_max = wd_max > wd ? wd_max : wd;
       size_t dw = (size_t)P.Cn[i] * KT * P.Cn[i - 1];
-      dwr_max = dwr_max > dw ? dw : dwr_max;
+      dwr_max = dwr_max > dw ? dwr_max : dw;
     }
   }
   P.stat = c.take<double>(2 * cmax);

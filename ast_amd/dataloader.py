@@ -1,0 +1,197 @@
+"""Data loaders with the reference's batch contract (dataloader.py:111-164, 244-297):
+  * utterances are bucketed by frame count, shuffled inside each bucket, cut into batches of `batch_size`, and the
+    batch list is shuffled -- all with Python's `random` (the stream nn.py:54 seeds);
+  * speech is truncated to (buckets_num+1)*buckets_width frames; train sets get int(zero_input*T_u) randomly chosen
+    frames (with replacement) zeroed; targets are [GO] + ids[:max_pred-2] + [EOS];
+  * X (B,T_max,D) float32 and y (B,L_max) int32 are zero-padded (PAD_ID = 0) and live on the GPU.
+Batches are staged through pinned host memory (one H2D copy each).  The SyntheticDataLoader produces the
+SURVEY.md 8(d) batches used by bench.py and the tests (the reference's feature blobs are not distributable)."""
+import os
+import pickle
+import random
+
+import numpy as np
+import torch
+
+from . import prep_buckets
+
+
+class SYMBOLS:
+    PAD = b"_PAD"
+    GO = b"_GO"
+    EOS = b"_EOS"
+    UNK = b"_UNK"
+    START_VOCAB = [PAD, GO, EOS, UNK]
+    PAD_ID = 0
+    GO_ID = 1
+    EOS_ID = 2
+    UNK_ID = 3
+
+
+def pad_batch(arrays, dtype, device):
+    """F.pad_sequence(xs, padding=0) followed by to_gpu (dataloader.py:156-162)."""
+    n = max(len(a) for a in arrays)
+    shape = (len(arrays), n) + tuple(arrays[0].shape[1:])
+    host = torch.zeros(shape, dtype=dtype)
+    if device.type == "cuda":
+        host = host.pin_memory()
+    for i, a in enumerate(arrays):
+        host[i, :len(a)] = torch.as_tensor(np.asarray(a))
+    return host.to(device, non_blocking=True)
+
+
+class DataLoader:
+    def __init__(self, data_cfg, model_dir, gpuid):
+        self.gpuid = gpuid
+        self.data_cfg = data_cfg
+        self.model_dir = model_dir
+        self.device = torch.device(f"cuda:{gpuid}") if gpuid is not None and gpuid >= 0 and torch.cuda.is_available() else torch.device("cpu")
+        self.map, self.vocab, self.info = {}, {}, {}
+        self.buckets = {}
+        self.n_utts = {}
+        # data-parallel sharding of every batch (ast_amd.dist): rank r takes rows r::world of each bucketed batch
+        self.rank, self.world = 0, 1
+
+    def _count(self):
+        self.n_utts = {k: sum(len(b) for b in v["buckets"]) for k, v in self.buckets.items()}
+
+    def _drop_frames(self, x, rate):
+        n = int(rate * len(x))
+        if n <= 0:
+            return x
+        mask = np.ones(len(x), dtype=np.float32)
+        mask[np.random.choice(np.arange(len(x)), size=n)] = 0        # with replacement, unseeded (quirk Q7)
+        return x * mask[:, None]
+
+    def _speech(self, utt, set_key, max_sp):
+        raise NotImplementedError
+
+    def _targets(self, utt, set_key):
+        dec_key, max_pred = self.data_cfg["dec_key"], self.data_cfg["max_pred"]
+        w2i = self.vocab[dec_key]["w2i"]
+        ids = [w2i.get(w, SYMBOLS.UNK_ID) for w in self.map[set_key][utt][dec_key]]
+        return np.asarray([SYMBOLS.GO_ID] + ids[:max_pred - 2] + [SYMBOLS.EOS_ID], dtype=np.int32)
+
+    def batch_plan(self, batch_size, set_key):
+        """The shuffled list of (utterances, bucket width) -- consumes the seeded `random` stream exactly like the reference."""
+        bk = self.buckets[set_key]
+        plan = []
+        for b, bucket in enumerate(bk["buckets"]):
+            random.shuffle(bucket)
+            for i in range(0, len(bucket), batch_size):
+                plan.append((bucket[i:i + batch_size], (b + 1) * bk["width_b"]))
+        random.shuffle(plan)
+        return plan
+
+    def get_batch(self, batch_size, set_key, train, labels=False):
+        bk = self.buckets[set_key]
+        max_sp = (bk["num_b"] + 1) * bk["width_b"]
+        for utts, _ in self.batch_plan(batch_size, set_key):
+            utts = utts[self.rank::self.world] if self.world > 1 else utts
+            if not utts:
+                continue
+            xs = [self._speech(u, set_key, max_sp) for u in utts]
+            out = {"X": pad_batch(xs, torch.float32, self.device), "utts": list(utts)}
+            if labels:
+                out["y"] = pad_batch([self._targets(u, set_key) for u in utts], torch.int32, self.device)
+            yield out
+
+    def get_hyps(self, preds):
+        dec_key = self.data_cfg["dec_key"]
+        join = " " if dec_key.endswith("_w") else ""
+        i2w = self.vocab[dec_key]["i2w"]
+        hyps = {}
+        for utt, p in preds:
+            hyps[utt] = []
+            if isinstance(p, list):
+                s = join.join(i2w[i].decode() for i in p if i >= len(SYMBOLS.START_VOCAB))
+                if "bpe_w" in dec_key:
+                    s = s.replace("@@ ", "")
+                hyps[utt].extend(s.strip().split())
+        return hyps
+
+
+class _PickledLoader(DataLoader):
+    def __init__(self, data_cfg, model_dir, gpuid):
+        super().__init__(data_cfg, model_dir, gpuid)
+        print("Loading data dictionaries")
+        for attr, key in (("map", "map_path"), ("vocab", "vocab_path"), ("info", "info_path")):
+            with open(data_cfg[key], "rb") as f:
+                setattr(self, attr, pickle.load(f))
+        print("Organising data into buckets")
+        self.buckets = prep_buckets.buckets_main(self.model_dir, data_cfg["buckets_num"], data_cfg["buckets_width"], key="sp",
+                                                 scale=data_cfg["train_scale"], seed="haha", info_path=data_cfg["info_path"])
+        self._count()
+
+
+class FisherDataLoader(_PickledLoader):
+    """Per-utterance <speech_path>/<set>/[<prefix>/]<utt>.npy float32 (T,D) files (dataloader.py:95-108)."""
+
+    def _speech(self, utt, set_key, max_sp):
+        base = os.path.join(self.data_cfg["speech_path"], set_key)
+        path = os.path.join(base, "{0:s}.npy".format(utt))
+        if not os.path.exists(path):
+            path = os.path.join(base, utt.split("_", 1)[0], "{0:s}.npy".format(utt))
+        x = np.load(path)[:max_sp]
+        if "train" in set_key and self.data_cfg["zero_input"] > 0:
+            x = self._drop_frames(x, self.data_cfg["zero_input"])
+        return x
+
+
+class GlobalPhoneDataLoader(_PickledLoader):
+    """One pickled {set: {utt: ndarray}} blob (dataloader.py:185-297)."""
+
+    def __init__(self, data_cfg, model_dir, gpuid):
+        super().__init__(data_cfg, model_dir, gpuid)
+        print("loading speech data from: {0:s}".format(data_cfg["speech_path"]))
+        with open(data_cfg["speech_path"], "rb") as f:
+            self.speech_data = pickle.load(f)
+
+    def _speech(self, utt, set_key, max_sp):
+        x = np.asarray(self.speech_data[set_key][utt][:max_sp])
+        if "train" in set_key and self.data_cfg["zero_input"] > 0:
+            x = self._drop_frames(x, self.data_cfg["zero_input"])
+        return x
+
+
+def synth_utterances(n_utts, feat_dim, vocab_size, frames_lo, frames_hi, tgt_lo, tgt_hi, seed=20):
+    """Synthetic corpus with the reference's schemas: info {utt: {'sp': frames}}, speech {utt: (T,D) f32}, ids."""
+    rng = np.random.default_rng(seed)
+    info, speech, ids = {}, {}, {}
+    for i in range(n_utts):
+        u = "utt_{0:06d}".format(i)
+        t = int(rng.integers(frames_lo, frames_hi + 1))
+        info[u] = {"sp": t}
+        speech[u] = rng.standard_normal((t, feat_dim)).astype(np.float32)
+        ids[u] = rng.integers(4, vocab_size, size=int(rng.integers(tgt_lo, tgt_hi + 1))).astype(np.int32)
+    return info, speech, ids
+
+
+class SyntheticDataLoader(DataLoader):
+    """data: {"dataloader": "synthetic", "vocab_size", "feat_dim", "n_utts": {set: n}, "frames": [lo,hi],
+    "targets": [lo,hi], buckets_num, buckets_width, max_pred, zero_input, train_scale}."""
+
+    def __init__(self, data_cfg, model_dir, gpuid):
+        super().__init__(data_cfg, model_dir, gpuid)
+        self.speech, self.ids, info = {}, {}, {}
+        for k, (set_key, n) in enumerate(sorted(data_cfg["n_utts"].items())):
+            info[set_key], self.speech[set_key], self.ids[set_key] = synth_utterances(
+                n, data_cfg["feat_dim"], data_cfg["vocab_size"], data_cfg["frames"][0], data_cfg["frames"][1],
+                data_cfg["targets"][0], data_cfg["targets"][1], seed=20 + k)
+        self.info = info
+        self.buckets = prep_buckets.buckets_from_info(info, data_cfg["buckets_num"], data_cfg["buckets_width"], "sp",
+                                                      data_cfg.get("train_scale", 1), "haha")
+        self._count()
+
+    def _speech(self, utt, set_key, max_sp):
+        x = self.speech[set_key][utt][:max_sp]
+        if "train" in set_key and self.data_cfg.get("zero_input", 0) > 0:
+            x = self._drop_frames(x, self.data_cfg["zero_input"])
+        return x
+
+    def _targets(self, utt, set_key):
+        ids = list(self.ids[set_key][utt])
+        return np.asarray([SYMBOLS.GO_ID] + ids[:self.data_cfg["max_pred"] - 2] + [SYMBOLS.EOS_ID], dtype=np.int32)
+
+    def get_hyps(self, preds):
+        return {utt: [str(i) for i in p if i >= 4] for utt, p in preds}
