@@ -222,10 +222,13 @@ int attn_fwd_launch(int B, int T, int H, const float* enc, const float* q, long 
   const size_t shm = (size_t)(4 * H + 8) * sizeof(float);
   dim3 grid(B * nsplit), blk(256);
   const int nch = cdiv(H, 256);
+  {
+  ProfScope prof(PROF_ATTN_FWD, s);
   if (nch <= 1) hipLaunchKernelGGL((attn_fwd_partial<1>), grid, blk, shm, s, B, T, H, enc, q, ldq, alpha, Tp, part, nsplit, chunk);
   else if (nch <= 2) hipLaunchKernelGGL((attn_fwd_partial<2>), grid, blk, shm, s, B, T, H, enc, q, ldq, alpha, Tp, part, nsplit, chunk);
   else if (nch <= 4) hipLaunchKernelGGL((attn_fwd_partial<4>), grid, blk, shm, s, B, T, H, enc, q, ldq, alpha, Tp, part, nsplit, chunk);
   else hipLaunchKernelGGL((attn_fwd_partial<8>), grid, blk, shm, s, B, T, H, enc, q, ldq, alpha, Tp, part, nsplit, chunk);
+  }
   ASTK_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_fwd_combine, dim3(B), blk, 0, s, B, T, H, alpha, Tp, part, nsplit, cv, ldcv, cv2, ldcv2);
   ASTK_LAUNCH_CHECK();
@@ -244,10 +247,13 @@ int attn_bwd_launch(int B, int T, int H, const float* enc, const float* alpha, c
   const size_t shm = (size_t)(4 * H) * sizeof(float);
   dim3 grid(B * nsplit), blk(256);
   const int nch = cdiv(H, 256);
+  {
+  ProfScope prof(PROF_ATTN_BWD, s);
   if (nch <= 1) hipLaunchKernelGGL((attn_bwd_partial<1>), grid, blk, shm, s, B, T, H, enc, alpha, Tp, cv, ldcv, d_cv, ld_dcv, ds, part, nsplit, chunk);
   else if (nch <= 2) hipLaunchKernelGGL((attn_bwd_partial<2>), grid, blk, shm, s, B, T, H, enc, alpha, Tp, cv, ldcv, d_cv, ld_dcv, ds, part, nsplit, chunk);
   else if (nch <= 4) hipLaunchKernelGGL((attn_bwd_partial<4>), grid, blk, shm, s, B, T, H, enc, alpha, Tp, cv, ldcv, d_cv, ld_dcv, ds, part, nsplit, chunk);
   else hipLaunchKernelGGL((attn_bwd_partial<8>), grid, blk, shm, s, B, T, H, enc, alpha, Tp, cv, ldcv, d_cv, ld_dcv, ds, part, nsplit, chunk);
+  }
   ASTK_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_bwd_combine, dim3(B), blk, 0, s, B, H, part, nsplit, dq);
   ASTK_LAUNCH_CHECK();

@@ -11,6 +11,17 @@ namespace astk {
 
 void set_error(const char* fmt, ...);
 
+// Optional per-kernel HIP-event timing on the launch stream (bench.py's roofline legs).  Off by default.
+enum ProfCat { PROF_ATTN_FWD = 0, PROF_ATTN_BWD = 1, PROF_GEMM = 2, PROF_CELL = 3, PROF_NCAT = 4 };
+bool prof_enabled();
+void prof_start(int cat, hipStream_t s, double work);
+void prof_stop(int cat, hipStream_t s);
+struct ProfScope {
+  int cat; hipStream_t s; bool on;
+  ProfScope(int c, hipStream_t st, double work = 0.0) : cat(c), s(st), on(prof_enabled()) { if (on) prof_start(cat, s, work); }
+  ~ProfScope() { if (on) prof_stop(cat, s); }
+};
+
 #define ASTK_CHECK(cond, ...)            \
   do {                                   \
     if (!(cond)) {                       \

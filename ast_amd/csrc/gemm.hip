@@ -205,6 +205,7 @@ int gemm_launch(int layout, const GemmArgs& g, hipStream_t s) {
   GemmArgs a = g;
   const long tiles = (long)cdiv(g.M, BM) * cdiv(g.N, BN);
   dim3 grid((unsigned)tiles, 1, (unsigned)(g.batch * g.ksplit));
+  ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * (double)g.K * g.batch);
   switch (layout) {
     case GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, a); break;
     case GEMM_NN: hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, a); break;

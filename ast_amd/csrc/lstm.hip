@@ -16,6 +16,15 @@
 
 namespace astk {
 
+struct PersistCellHost {
+  const float *Wl, *Wu, *bias, *zx, *xin, *mask, *WlT, *WuT_up, *dz_up, *d_enc, *d_hT, *d_cT;
+  float *gates, *C, *HR, *HD, *enc;
+  int reverse_pos, layer;
+};
+bool lstm_persist_applicable(int T, int B, int h, int nl, int nd);
+int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters, hipStream_t s);
+int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters, hipStream_t s);
+
 namespace {
 
 struct LstmPlan {
@@ -27,6 +36,8 @@ struct LstmPlan {
   float* CC[2][ASTK_MAX_RNN_LAYERS];
   float* HD[2][ASTK_MAX_RNN_LAYERS];
   float* WlT[2][ASTK_MAX_RNN_LAYERS];  // (h, 4h)
+  float* WuT[2][ASTK_MAX_RNN_LAYERS];  // (h, 4h) transposed upward weights of layers >= 1 (persistent backward)
+  unsigned* counters;                  // arrival counters of the persistent kernels
   float* DX[2];                        // (T,B,h) gradient wrt a layer's input (layers >= 1)
   float* DC[2][2];                     // dc ping-pong (B,h)
   size_t bytes;
@@ -49,12 +60,14 @@ int make_plan(const astk_lstm_stack_desc* d, void* ws, bool with_masks, LstmPlan
       // the workspace size must not depend on whether masks are passed: always reserve HD
       P.HD[dd][l] = c.take<float>(tb * P.h);
       P.WlT[dd][l] = c.take<float>((size_t)P.h * 4 * P.h);
+      P.WuT[dd][l] = c.take<float>((size_t)P.h * 4 * P.h);
     }
     P.DX[dd] = c.take<float>(tb * P.h);
     P.DC[dd][0] = c.take<float>((size_t)P.B * P.h);
     P.DC[dd][1] = c.take<float>((size_t)P.B * P.h);
   }
   (void)with_masks;
+  P.counters = c.take<unsigned>(((size_t)P.nd * P.nl * ((P.B + 15) / 16) + 2) * 64);
   P.bytes = c.total();
   return 0;
 }
@@ -105,6 +118,43 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
   hipLaunchKernelGGL(k_rowidx, dim3(cdiv(T * B, 256)), dim3(256), 0, s, P.inv, rows_inv, T, B);
   ASTK_LAUNCH_CHECK();
   const size_t bh = (size_t)B * h;
+  if (lstm_persist_applicable(T, B, h, P.nl, P.nd)) {
+    // ---- persistent wavefront path: layer-0 upward projection batched over time, everything else in ONE launch
+    PersistCellHost cells[16];
+    memset(cells, 0, sizeof(cells));
+    for (int dd = 0; dd < P.nd; ++dd) {
+      const astk_lstm_params& p0 = prm[dd * P.nl];
+      ASTK_CHECK(p0.Wu && p0.b && p0.Wl, "lstm_stack_fwd: null parameter (dir %d layer 0)", dd);
+      MatView A = dd == 0 ? mat(x, P.in) : mat_idx(x, P.in, rows_perm);
+      ASTK_TRY(gemm_launch(GEMM_NT, gemm_args(T * B, 4 * h, P.in, A, mat(p0.Wu, P.in), P.ZG[dd][0], 4 * h, p0.b), s));
+      for (int l = 0; l < P.nl; ++l) {
+        const astk_lstm_params& p = prm[dd * P.nl + l];
+        ASTK_CHECK(p.Wu && p.b && p.Wl, "lstm_stack_fwd: null parameter (dir %d layer %d)", dd, l);
+        PersistCellHost& c = cells[dd * P.nl + l];
+        const bool top = l == P.nl - 1;
+        c.Wl = p.Wl;
+        c.Wu = l > 0 ? p.Wu : nullptr;
+        c.bias = l > 0 ? p.b : nullptr;
+        c.zx = l == 0 ? P.ZG[dd][0] : nullptr;
+        c.gates = P.ZG[dd][l];
+        c.C = P.CC[dd][l];
+        c.HR = P.HR[dd][l];
+        c.HD = (!top && masks) ? P.HD[dd][l] : nullptr;
+        c.xin = l > 0 ? (masks ? P.HD[dd][l - 1] : P.HR[dd][l - 1]) : nullptr;
+        c.mask = masks ? masks + ((size_t)dd * P.nl + l) * T * bh : nullptr;
+        c.enc = top ? enc_states + (size_t)dd * h : nullptr;
+        c.reverse_pos = dd == 1;
+        c.layer = l;
+      }
+    }
+    ASTK_TRY(lstm_persist_fwd_launch(cells, P.nd * P.nl, P.nl, T, B, h, H, P.counters, s));
+    for (int dd = 0; dd < P.nd; ++dd)
+      for (int l = 0; l < P.nl; ++l) {
+        if (cT) ASTK_TRY(copy_f32(cT + ((size_t)dd * P.nl + l) * bh, P.CC[dd][l] + (size_t)(T - 1) * bh, bh, s));
+        if (hT) ASTK_TRY(copy_f32(hT + ((size_t)dd * P.nl + l) * bh, P.HR[dd][l] + (size_t)(T - 1) * bh, bh, s));
+      }
+    return 0;
+  }
   for (int l = 0; l < P.nl; ++l) {
     const int in = l == 0 ? P.in : h;
     for (int dd = 0; dd < P.nd; ++dd) {
@@ -167,12 +217,40 @@ int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
   int* rows_perm = (int*)((char*)ws + P.bytes);
   int* rows_inv = (int*)((char*)rows_perm + align_up((size_t)T * B * sizeof(int), 256));
   const size_t bh = (size_t)B * h;
+  const bool persist = lstm_persist_applicable(T, B, h, P.nl, P.nd);
+  if (persist) {
+    PersistCellHost cells[16];
+    memset(cells, 0, sizeof(cells));
+    for (int dd = 0; dd < P.nd; ++dd)
+      for (int l = 0; l < P.nl; ++l) {
+        const astk_lstm_params& p = prm[dd * P.nl + l];
+        ASTK_TRY(transpose_f32(P.WlT[dd][l], 4 * h, p.Wl, h, 4 * h, h, s));
+        if (l > 0) ASTK_TRY(transpose_f32(P.WuT[dd][l], 4 * h, p.Wu, h, 4 * h, h, s));
+      }
+    for (int dd = 0; dd < P.nd; ++dd)
+      for (int l = 0; l < P.nl; ++l) {
+        PersistCellHost& c = cells[dd * P.nl + l];
+        const bool top = l == P.nl - 1;
+        c.WlT = P.WlT[dd][l];
+        c.WuT_up = top ? nullptr : P.WuT[dd][l + 1];
+        c.dz_up = top ? nullptr : P.ZG[dd][l + 1];
+        c.gates = P.ZG[dd][l];
+        c.C = P.CC[dd][l];
+        c.mask = masks ? masks + ((size_t)dd * P.nl + l) * T * bh : nullptr;
+        c.d_enc = top ? d_enc + (size_t)dd * h : nullptr;
+        c.d_hT = d_hT ? d_hT + ((size_t)dd * P.nl + l) * bh : nullptr;
+        c.d_cT = d_cT ? d_cT + ((size_t)dd * P.nl + l) * bh : nullptr;
+        c.reverse_pos = dd == 1;
+        c.layer = l;
+      }
+    ASTK_TRY(lstm_persist_bwd_launch(cells, P.nd * P.nl, P.nl, T, B, h, H, P.counters, s));
+  }
   for (int l = P.nl - 1; l >= 0; --l) {
     const bool top = l == P.nl - 1;
     const int in = l == 0 ? P.in : h;
-    for (int dd = 0; dd < P.nd; ++dd)
+    for (int dd = 0; dd < P.nd && !persist; ++dd)
       ASTK_TRY(transpose_f32(P.WlT[dd][l], 4 * h, prm[dd * P.nl + l].Wl, h, 4 * h, h, s));
-    for (int i = T - 1; i >= 0; --i) {
+    for (int i = T - 1; i >= 0 && !persist; --i) {
       LstmCellBwdArgs cells[2];
       for (int dd = 0; dd < P.nd; ++dd) {
         LstmCellBwdArgs& c = cells[dd];
@@ -233,7 +311,7 @@ int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
       ASTK_TRY(colsum_add_f32(g.db, dz, 4 * h, rows, 4 * h, s));
       // gradient wrt the layer input
       if (l > 0) {
-        ASTK_TRY(gemm_launch(GEMM_NN, gemm_args(rows, h, 4 * h, mat(dz, 4 * h), mat(p.Wu, h), P.DX[dd], h), s));
+        if (!persist) ASTK_TRY(gemm_launch(GEMM_NN, gemm_args(rows, h, 4 * h, mat(dz, 4 * h), mat(p.Wu, h), P.DX[dd], h), s));
       } else if (dx) {
         // dx (T,B,in) in frame order: direction 0 stores, direction 1 accumulates through the inverse permutation
         MatView A = dd == 0 ? mat(dz, 4 * h) : mat_idx(dz, 4 * h, rows_inv);

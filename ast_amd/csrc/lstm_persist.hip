@@ -1,0 +1,440 @@
+// Persistent, wavefront-scheduled encoder LSTM kernels ("hard part" of section 7).
+//
+// One launch runs ALL time steps of ALL (direction, layer) cells.  A workgroup owns 16 hidden units x 16 batch
+// rows of one cell for the whole sequence:
+//   * its slice of the recurrent weights (64 gate rows of W_l, and for layers >= 1 the 64 gate rows of W_u) is
+//     loaded ONCE into VGPRs as f32-MFMA B fragments (K split over the 4 waves) and stays there for all T steps;
+//   * the cell state c (forward) / dc (backward) lives in a register of the thread that owns (batch row, unit);
+//   * per step only the 16 x h activations of the previous step (and of the layer below) are fetched.
+// Layers run as a wavefront: cell (l, t) starts as soon as (l, t-1) and (l-1, t) have been published, so the
+// sequential depth is T + n_layers - 1 steps instead of n_layers * T launches.
+//
+// Inter-workgroup hand-off (cdna_hip_programming.md Guideline 16, form R1 with a counter): producers store the
+// handed-off activations write-through (agent-scope relaxed atomic stores -> sc1), every storing wave drains
+// vmcnt, the workgroup barriers, ONE lane adds to the (dir, layer, batch-tile) arrival counter; consumers poll
+// that counter with a relaxed agent-scope (sc1) load from ONE lane, barrier, then read the payload with sc1
+// loads only.  Counters are zeroed by a memset node before every launch.  Every spin is bounded: on time-out a
+// workgroup raises the abort word, every poll loop checks it, and the grid drains.
+// Residency: the launcher only uses this path when the whole grid fits one workgroup per CU (<= 256 workgroups).
+#include "common.h"
+
+namespace astk {
+
+namespace {
+
+typedef unsigned long long u64;
+constexpr int CTR_STRIDE = 64;   // arrival counters live 256 bytes apart: pollers of different cells never share a line
+
+struct PCellF {
+  const float* Wl;      // (4h, h)
+  const float* Wu;      // (4h, h) layers >= 1, else null
+  const float* bias;    // (4h) layers >= 1 (layer 0: already inside zx)
+  const float* zx;      // layer 0: (T,B,4h) upward projection incl. bias
+  float* gates;         // (T,B,4h)
+  float* C;             // (T,B,h)
+  float* HR;            // (T,B,h) raw h
+  float* HD;            // (T,B,h) dropped output (null: next layer reads HR)
+  const float* xin;     // layers >= 1: HD or HR of the layer below
+  const float* mask;    // (T,B,h) or null
+  float* enc;           // top layer: enc_states + dir*h ; row stride enc_ldb per batch row, enc_ldt per position
+  int reverse_pos;      // top layer of direction 1: position = T-1-t
+  int layer;
+};
+struct PFwdArgs {
+  PCellF c[16];
+  int ncells, nl, T, B, h, H;
+  int dbg;              // timing experiments only (ASTK_PERSIST_DBG): 1 = skip payload loads + MFMA, 2 = skip publish drain
+  unsigned* done;       // [ncells][nbt] arrival counters
+  unsigned* abort_word;
+};
+
+struct PCellB {
+  const float* WlT;     // (h, 4h)
+  const float* WuT_up;  // (h, 4h): transposed upward weight of the layer ABOVE (null for the top layer)
+  float* gates_dz;      // (T,B,4h): activated gates in, dz out
+  const float* dz_up;   // gates_dz of the layer above (null for the top layer)
+  const float* C;       // (T,B,h)
+  const float* mask;    // (T,B,h) or null
+  const float* d_enc;   // top layer: d_enc_states + dir*h
+  const float* d_hT;    // (B,h) or null
+  const float* d_cT;    // (B,h) or null
+  int reverse_pos;
+  int layer;
+};
+struct PBwdArgs {
+  PCellB c[16];
+  int ncells, nl, T, B, h, H;
+  unsigned* done;
+  unsigned* abort_word;
+};
+
+__device__ __forceinline__ unsigned ld_flag(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 16 bytes of handed-off data as two 8-byte sc1 loads (agent-scope relaxed atomics bypass the CU's L1)
+__device__ __forceinline__ float4 ld16_sc1(const float* p) {
+  const u64 a = __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const u64 b = __hip_atomic_load(reinterpret_cast<const u64*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float4 v;
+  v.x = __uint_as_float((unsigned)a); v.y = __uint_as_float((unsigned)(a >> 32));
+  v.z = __uint_as_float((unsigned)b); v.w = __uint_as_float((unsigned)(b >> 32));
+  return v;
+}
+__device__ __forceinline__ void st4_sc1(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st16_sc1(float* p, float4 v) {
+  const u64 a = (u64)__float_as_uint(v.x) | ((u64)__float_as_uint(v.y) << 32);
+  const u64 b = (u64)__float_as_uint(v.z) | ((u64)__float_as_uint(v.w) << 32);
+  __hip_atomic_store(reinterpret_cast<u64*>(p), a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(reinterpret_cast<u64*>(p) + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One lane waits until *ctr >= target (or the abort word is raised).  Returns false on abort / time-out.
+__device__ __forceinline__ bool wait_ge(const unsigned* ctr, unsigned target, unsigned* abort_word) {
+  unsigned spins = 0;
+  while (ld_flag(ctr) < target) {
+    if ((++spins & 63u) == 0) {
+      if (ld_flag(abort_word) != 0) return false;
+      if (spins > (1u << 22)) {   // ~seconds: something is wrong (grid not resident); drain instead of hanging
+        __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
+// publish: every storing wave drains its stores, the workgroup barriers, one lane bumps the arrival counter
+__device__ __forceinline__ void publish(unsigned* ctr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// raw buffer descriptor over a hand-off buffer: lets the compiler track 16-byte sc1 loads / stores itself
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 ldb128_sc1(__amdgpu_buffer_rsrc_t r, long float_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_off * 4), 0, 16);   // aux 16 = sc1
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void stb128_sc1(__amdgpu_buffer_rsrc_t r, long float_off, float4 v) {
+  u32x4 u;
+  u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)(float_off * 4), 0, 16);
+}
+
+#define MFMA4(ACC, A4, W4)                                                   \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).x, (W4).x, ACC, 0, 0, 0);  \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).y, (W4).y, ACC, 0, 0, 0);  \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).z, (W4).z, ACC, 0, 0, 0);  \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).w, (W4).w, ACC, 0, 0, 0);
+
+// four independent accumulators (the gates) interleaved so that no MFMA waits on the previous one's result
+#define MFMA4G(ACC, A4, W)                                                                    \
+  _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) ACC[g_] = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).x, (W)[g_].x, ACC[g_], 0, 0, 0); \
+  _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) ACC[g_] = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).y, (W)[g_].y, ACC[g_], 0, 0, 0); \
+  _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) ACC[g_] = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).z, (W)[g_].z, ACC[g_], 0, 0, 0); \
+  _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) ACC[g_] = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).w, (W)[g_].w, ACC[g_], 0, 0, 0);
+
+// ------------------------------------------------------------------ forward
+// KB = k-blocks (16 floats each) of K = h per wave: h = 64*KB
+template <int KB>
+__global__ __launch_bounds__(256, 1) void lstm_persist_fwd(PFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 4 * 256];
+  __shared__ int s_ok1, s_ok2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int cell = blockIdx.z, bt = blockIdx.y, j0 = blockIdx.x * 16;
+  const PCellF& c = a.c[cell];
+  const int T = a.T, B = a.B, h = a.h;
+  const int nbt = gridDim.y, nslice = gridDim.x;
+  const bool has_up = c.layer > 0;
+  unsigned* done_own = a.done + (cell * nbt + bt) * CTR_STRIDE;
+  const unsigned* done_below = has_up ? a.done + ((cell - 1) * nbt + bt) * CTR_STRIDE : nullptr;
+  const int m0 = bt * 16;
+
+  // resident weight fragments: lane (r = unit j, q) holds floats [16*s + 4q, +4) of gate rows 4*(j0+r)+g
+  float4 wl[KB][4], wu[KB][4];
+#pragma unroll
+  for (int i = 0; i < KB; ++i) {
+    const int s = wave + 4 * i;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const long row = 4 * (j0 + r) + g;
+      wl[i][g] = *reinterpret_cast<const float4*>(c.Wl + row * h + 16 * s + 4 * q);
+      wu[i][g] = has_up ? *reinterpret_cast<const float4*>(c.Wu + row * h + 16 * s + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const __amdgpu_buffer_rsrc_t r_hr = make_rsrc(c.HR);
+  const __amdgpu_buffer_rsrc_t r_x = make_rsrc(has_up ? c.xin : c.HR);
+  const int arow = min(m0 + r, B - 1);
+  const int eb = m0 + (tid >> 4), eu = j0 + (tid & 15);      // epilogue ownership: (batch row, unit)
+  const bool evalid = eb < B;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (has_up) bias4 = *reinterpret_cast<const float4*>(c.bias + 4 * eu);
+  float c_state = 0.f;
+  long long tk[6] = {0, 0, 0, 0, 0, 0};
+  const bool timing = (a.dbg & 8) != 0;
+#define TICK(i, t0) if (timing) { const long long now_ = wall_clock64(); tk[i] += now_ - t0; t0 = now_; }
+
+  for (int t = 0; t < T; ++t) {
+    long long t0 = timing ? wall_clock64() : 0;
+    const long tb = (long)t * B + (evalid ? eb : 0);
+    // inputs that do not depend on this launch: issue their loads before any wait
+    float4 zadd = bias4;
+    float mk = 1.f;
+    if (evalid) {
+      if (!has_up) zadd = *reinterpret_cast<const float4*>(c.zx + tb * 4 * h + 4 * eu);
+      if (c.mask) mk = c.mask[tb * h + eu];
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- upward product first: the layer below runs one step ahead, so this is off the recurrence's critical path
+    if (has_up) {
+      if (tid == 0) s_ok1 = wait_ge(done_below, (unsigned)(nslice * (t + 1)), a.abort_word) ? 1 : 0;
+      __syncthreads();
+      if (!s_ok1) break;
+      TICK(0, t0)
+      float4 ax[KB];
+      const long xo = ((long)t * B + arow) * h + 4 * q;
+      if (a.dbg & 1) {
+#pragma unroll
+        for (int i = 0; i < KB; ++i) ax[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else
+#pragma unroll
+      for (int i = 0; i < KB; ++i) ax[i] = ldb128_sc1(r_x, xo + 16 * (wave + 4 * i));
+#pragma unroll
+      for (int i = 0; i < KB; ++i) { MFMA4G(acc, ax[i], wu[i]) }
+    }
+    // ---- recurrent product: needs h_{t-1} of every workgroup of this cell
+    TICK(1, t0)
+    if (t > 0) {
+      if (tid == 0) s_ok2 = wait_ge(done_own, (unsigned)(nslice * t), a.abort_word) ? 1 : 0;
+      __syncthreads();
+      if (!s_ok2) break;
+      TICK(2, t0)
+      float4 ah[KB];
+      const long ho = ((long)(t - 1) * B + arow) * h + 4 * q;
+      if (a.dbg & 1) {
+#pragma unroll
+        for (int i = 0; i < KB; ++i) ah[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else
+#pragma unroll
+      for (int i = 0; i < KB; ++i) ah[i] = ldb128_sc1(r_hr, ho + 16 * (wave + 4 * i));
+#pragma unroll
+      for (int i = 0; i < KB; ++i) { MFMA4G(acc, ah[i], wl[i]) }
+    }
+    // ---- 4-wave K reduction through LDS
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(&red[((wave * 4 + g) * 64 + lane) * 4]) = acc[g];
+    __syncthreads();
+    TICK(3, t0)
+    float ga = 0.f, gi = 0.f, gf = 0.f, go = 0.f, hd = 0.f;
+    if (evalid) {
+      const int row = tid >> 4, col = tid & 15;
+      const int src = ((row >> 2) * 16 + col) * 4 + (row & 3);
+      float z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        z[g] = red[(0 * 4 + g) * 256 + src] + red[(1 * 4 + g) * 256 + src] + red[(2 * 4 + g) * 256 + src] + red[(3 * 4 + g) * 256 + src];
+      ga = tanhf(z[0] + zadd.x); gi = sigm(z[1] + zadd.y); gf = sigm(z[2] + zadd.z); go = sigm(z[3] + zadd.w);
+      c_state = ga * gi + gf * c_state;
+      const float hh = go * tanhf(c_state);
+      hd = hh * mk;
+      // hand-off stores first (write-through), so that the publish below waits for nothing else
+      st4_sc1(c.HR + tb * h + eu, hh);                       // read by this cell's workgroups at step t+1
+      if (c.HD) st4_sc1(c.HD + tb * h + eu, hd);             // read by the layer above at step t
+    }
+    if (a.dbg & 2) { __syncthreads(); if (tid == 0) __hip_atomic_fetch_add(done_own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    else if (a.dbg & 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (tid == 0) __hip_atomic_store(done_own, (unsigned)(nslice * (t + 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    else { TICK(4, t0) publish(done_own); TICK(5, t0) }
+    if (evalid) {                                            // saved for the backward launch / the decoder: plain stores
+      *reinterpret_cast<float4*>(c.gates + tb * 4 * h + 4 * eu) = make_float4(ga, gi, gf, go);
+      c.C[tb * h + eu] = c_state;
+      if (c.enc) {
+        const int pos = c.reverse_pos ? T - 1 - t : t;
+        c.enc[((long)eb * T + pos) * a.H + eu] = hd;
+      }
+    }
+  }
+  if (timing && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0)
+    printf("persist_fwd cell %d (layer %d): per-step 10ns ticks: poll_below %lld  xpart %lld  poll_own %lld  hpart+reduce %lld  epilogue %lld  publish %lld\n",
+           cell, c.layer, tk[0] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T, tk[5] / T);
+#undef TICK
+}
+
+// ------------------------------------------------------------------ backward
+template <int KB>
+__global__ __launch_bounds__(256, 1) void lstm_persist_bwd(PBwdArgs a) {
+  constexpr int NB = 4 * KB;   // k-blocks of K = 4h per wave
+  __shared__ __attribute__((aligned(16))) float red[4 * 2 * 256];
+  __shared__ int s_ok1, s_ok2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int cell = blockIdx.z, bt = blockIdx.y, j0 = blockIdx.x * 16;
+  const PCellB& c = a.c[cell];
+  const int T = a.T, B = a.B, h = a.h;
+  const int nbt = gridDim.y, nslice = gridDim.x;
+  const bool has_up = c.dz_up != nullptr;
+  unsigned* done_own = a.done + (cell * nbt + bt) * CTR_STRIDE;
+  const unsigned* done_up = has_up ? a.done + ((cell + 1) * nbt + bt) * CTR_STRIDE : nullptr;
+  const int m0 = bt * 16;
+  const int K = 4 * h;
+
+  float4 wl[NB], wu[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int s = wave + 4 * i;
+    wl[i] = *reinterpret_cast<const float4*>(c.WlT + (long)(j0 + r) * K + 16 * s + 4 * q);
+    wu[i] = has_up ? *reinterpret_cast<const float4*>(c.WuT_up + (long)(j0 + r) * K + 16 * s + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const __amdgpu_buffer_rsrc_t r_dz = make_rsrc(c.gates_dz);
+  const __amdgpu_buffer_rsrc_t r_up = make_rsrc(has_up ? c.dz_up : c.gates_dz);
+  const int arow = min(m0 + r, B - 1);
+  const int eb = m0 + (tid >> 4), eu = j0 + (tid & 15);
+  const bool evalid = eb < B;
+  float dc_state = 0.f;
+  if (evalid && c.d_cT) dc_state = c.d_cT[(long)eb * h + eu];
+
+  for (int t = T - 1; t >= 0; --t) {
+    const int stepno = T - 1 - t;           // number of steps already completed by this cell
+    const long tb = (long)t * B + (evalid ? eb : 0);
+    // inputs from earlier launches: issue before any wait
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ccur = 0.f, cp = 0.f, mk = 1.f, dye = 0.f, dhadd = 0.f;
+    if (evalid) {
+      g = *reinterpret_cast<const float4*>(c.gates_dz + tb * K + 4 * eu);
+      ccur = c.C[tb * h + eu];
+      if (t > 0) cp = c.C[(tb - B) * h + eu];
+      if (c.mask) mk = c.mask[tb * h + eu];
+      if (c.d_enc) {
+        const int pos = c.reverse_pos ? T - 1 - t : t;
+        dye = c.d_enc[((long)eb * T + pos) * a.H + eu];
+      }
+      if (stepno == 0 && c.d_hT) dhadd = c.d_hT[(long)eb * h + eu];
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (has_up) {                            // the layer above runs one step ahead: off the critical path
+      if (tid == 0) s_ok1 = wait_ge(done_up, (unsigned)(nslice * (stepno + 1)), a.abort_word) ? 1 : 0;
+      __syncthreads();
+      if (!s_ok1) break;
+      const long o = ((long)t * B + arow) * K + 4 * q;
+      float4 av[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) av[i] = ldb128_sc1(r_up, o + 16 * (wave + 4 * i));
+#pragma unroll
+      for (int i = 0; i < NB; ++i) { MFMA4(acc1, av[i], wu[i]) }
+    }
+    if (stepno > 0) {
+      if (tid == 0) s_ok2 = wait_ge(done_own, (unsigned)(nslice * stepno), a.abort_word) ? 1 : 0;
+      __syncthreads();
+      if (!s_ok2) break;
+      const long o = ((long)(t + 1) * B + arow) * K + 4 * q;
+      float4 av[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) av[i] = ldb128_sc1(r_dz, o + 16 * (wave + 4 * i));
+#pragma unroll
+      for (int i = 0; i < NB; ++i) { MFMA4(acc0, av[i], wl[i]) }
+    }
+    *reinterpret_cast<f32x4*>(&red[((wave * 2 + 0) * 64 + lane) * 4]) = acc0;
+    *reinterpret_cast<f32x4*>(&red[((wave * 2 + 1) * 64 + lane) * 4]) = acc1;
+    __syncthreads();
+    if (evalid) {
+      const int row = tid >> 4, col = tid & 15;
+      const int src = ((row >> 2) * 16 + col) * 4 + (row & 3);
+      const float v0 = red[0 * 256 + src] + red[2 * 256 + src] + red[4 * 256 + src] + red[6 * 256 + src];
+      const float v1 = red[1 * 256 + src] + red[3 * 256 + src] + red[5 * 256 + src] + red[7 * 256 + src];
+      const float dh = v0 + (v1 + dye) * mk + dhadd;
+      const float tc = tanhf(ccur);
+      const float dcv = dh * g.w * (1.f - tc * tc) + dc_state;
+      stb128_sc1(r_dz, tb * K + 4 * eu,
+                 make_float4(dcv * g.y * (1.f - g.x * g.x), dcv * g.x * g.y * (1.f - g.y), dcv * cp * g.z * (1.f - g.z),
+                             dh * tc * g.w * (1.f - g.w)));
+      dc_state = dcv * g.z;
+    }
+    publish(done_own);
+  }
+}
+
+}  // namespace
+
+// ---- launchers (called from lstm.hip).  Return 1 if the persistent path is not applicable (caller falls back).
+struct PersistCellHost {
+  const float *Wl, *Wu, *bias, *zx, *xin, *mask, *WlT, *WuT_up, *dz_up, *d_enc, *d_hT, *d_cT;
+  float *gates, *C, *HR, *HD, *enc;
+  int reverse_pos, layer;
+};
+
+bool lstm_persist_applicable(int T, int B, int h, int nl, int nd) {
+  if (!(h == 64 || h == 128 || h == 256 || h == 512)) return false;
+  if (B < 1 || T < 1) return false;
+  const long wgs = (long)(h / 16) * ((B + 15) / 16) * nl * nd;
+  if (wgs > 256 || nl * nd > 16) return false;        // one workgroup per CU must hold the whole grid
+  const char* e = getenv("ASTK_LSTM_PERSIST");
+  if (e && e[0] == '0') return false;
+  return true;
+}
+
+int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters,
+                            hipStream_t s) {
+  PFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  const int nbt = (B + 15) / 16;
+  for (int i = 0; i < ncells; ++i) {
+    const PersistCellHost& c = cells[i];
+    PCellF& d = a.c[i];
+    d.Wl = c.Wl; d.Wu = c.Wu; d.bias = c.bias; d.zx = c.zx; d.gates = c.gates; d.C = c.C; d.HR = c.HR; d.HD = c.HD;
+    d.xin = c.xin; d.mask = c.mask; d.enc = c.enc; d.reverse_pos = c.reverse_pos; d.layer = c.layer;
+  }
+  a.ncells = ncells; a.nl = nl; a.T = T; a.B = B; a.h = h; a.H = H;
+  { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
+  a.done = counters;
+  a.abort_word = counters + (size_t)ncells * nbt * 64;
+  ASTK_HIP(hipMemsetAsync(counters, 0, ((size_t)ncells * nbt + 1) * 64 * sizeof(unsigned), s));
+  dim3 grid(h / 16, nbt, ncells), blk(256);
+  ProfScope prof(PROF_CELL, s);
+  switch (h) {
+    case 64: hipLaunchKernelGGL((lstm_persist_fwd<1>), grid, blk, 0, s, a); break;
+    case 128: hipLaunchKernelGGL((lstm_persist_fwd<2>), grid, blk, 0, s, a); break;
+    case 256: hipLaunchKernelGGL((lstm_persist_fwd<4>), grid, blk, 0, s, a); break;
+    default: hipLaunchKernelGGL((lstm_persist_fwd<8>), grid, blk, 0, s, a); break;
+  }
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters,
+                            hipStream_t s) {
+  PBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  const int nbt = (B + 15) / 16;
+  for (int i = 0; i < ncells; ++i) {
+    const PersistCellHost& c = cells[i];
+    PCellB& d = a.c[i];
+    d.WlT = c.WlT; d.WuT_up = c.WuT_up; d.gates_dz = c.gates; d.dz_up = c.dz_up; d.C = c.C; d.mask = c.mask; d.d_enc = c.d_enc;
+    d.d_hT = c.d_hT; d.d_cT = c.d_cT; d.reverse_pos = c.reverse_pos; d.layer = c.layer;
+  }
+  a.ncells = ncells; a.nl = nl; a.T = T; a.B = B; a.h = h; a.H = H;
+  a.done = counters;
+  a.abort_word = counters + (size_t)ncells * nbt * 64;
+  ASTK_HIP(hipMemsetAsync(counters, 0, ((size_t)ncells * nbt + 1) * 64 * sizeof(unsigned), s));
+  dim3 grid(h / 16, nbt, ncells), blk(256);
+  ProfScope prof(PROF_CELL, s);
+  switch (h) {
+    case 64: hipLaunchKernelGGL((lstm_persist_bwd<1>), grid, blk, 0, s, a); break;
+    case 128: hipLaunchKernelGGL((lstm_persist_bwd<2>), grid, blk, 0, s, a); break;
+    case 256: hipLaunchKernelGGL((lstm_persist_bwd<4>), grid, blk, 0, s, a); break;
+    default: hipLaunchKernelGGL((lstm_persist_bwd<8>), grid, blk, 0, s, a); break;
+  }
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace astk

@@ -255,6 +255,7 @@ int lstm_cell_fwd_launch(const LstmCellFwdArgs* cells, int ncells, hipStream_t s
     for (int p = 0; p < c.npairs; ++p) ASTK_TRY(check_pair(c.p[p], "lstm_cell_fwd"));
     batch.c[i] = c;
   }
+  ProfScope prof(PROF_CELL, s);
   hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv(cells[0].h, 16), cdiv(cells[0].B, 16), ncells), dim3(256), 0, s, batch);
   ASTK_LAUNCH_CHECK();
   return 0;
@@ -270,6 +271,7 @@ int lstm_cell_bwd_launch(const LstmCellBwdArgs* cells, int ncells, hipStream_t s
     for (int p = 0; p < c.npairs; ++p) ASTK_TRY(check_pair(c.p[p], "lstm_cell_bwd"));
     batch.c[i] = c;
   }
+  ProfScope prof(PROF_CELL, s);
   hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv(cells[0].h, 16), cdiv(cells[0].B, 16), ncells), dim3(256), 0, s, batch);
   ASTK_LAUNCH_CHECK();
   return 0;

@@ -3,6 +3,7 @@
 // (nn.py:81-119: WeightDecay -> GradientClipping -> Adam(amsgrad) on one flat buffer).
 #include "common.h"
 #include <stdarg.h>
+#include <vector>
 
 namespace astk {
 
@@ -15,6 +16,29 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 const char* last_error() { return g_err; }
+
+// ---- profiler
+struct ProfState {
+  bool on = false;
+  std::vector<hipEvent_t> ev[PROF_NCAT];   // start/stop pairs
+  double work[PROF_NCAT] = {0, 0, 0, 0};
+};
+static ProfState g_prof;
+bool prof_enabled() { return g_prof.on; }
+void prof_start(int cat, hipStream_t s, double work) {
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, s);
+  g_prof.ev[cat].push_back(e);
+  g_prof.work[cat] += work;
+}
+void prof_stop(int cat, hipStream_t s) {
+  if (g_prof.ev[cat].size() % 2 == 0) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) { g_prof.ev[cat].pop_back(); return; }
+  (void)hipEventRecord(e, s);
+  g_prof.ev[cat].push_back(e);
+}
 
 namespace {
 
@@ -274,6 +298,34 @@ int astk_gemm_f32(int layout, int M, int N, int K, const float* A, long lda, con
   g.batch = batch < 1 ? 1 : batch;
   g.sA = sA; g.sB = sB; g.sC = sC;
   return gemm_launch(layout, g, (hipStream_t)stream);
+}
+
+int astk_prof_begin(void) {
+  for (int c = 0; c < PROF_NCAT; ++c) { g_prof.ev[c].clear(); g_prof.work[c] = 0; }
+  g_prof.on = true;
+  return 0;
+}
+// res[0..1] attention fwd (ms, launches); [2..3] attention bwd; [4..6] GEMM (ms, launches, flops); [7..8] LSTM cells (ms, launches)
+int astk_prof_end(double* res) {
+  g_prof.on = false;
+  ASTK_HIP(hipDeviceSynchronize());
+  double ms[PROF_NCAT];
+  double n[PROF_NCAT];
+  for (int c = 0; c < PROF_NCAT; ++c) {
+    ms[c] = 0; n[c] = 0;
+    std::vector<hipEvent_t>& v = g_prof.ev[c];
+    for (size_t i = 0; i + 1 < v.size(); i += 2) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, v[i], v[i + 1]) == hipSuccess) { ms[c] += t; n[c] += 1; }
+    }
+    for (hipEvent_t e : v) (void)hipEventDestroy(e);
+    v.clear();
+  }
+  res[0] = ms[PROF_ATTN_FWD]; res[1] = n[PROF_ATTN_FWD];
+  res[2] = ms[PROF_ATTN_BWD]; res[3] = n[PROF_ATTN_BWD];
+  res[4] = ms[PROF_GEMM]; res[5] = n[PROF_GEMM]; res[6] = g_prof.work[PROF_GEMM];
+  res[7] = ms[PROF_CELL]; res[8] = n[PROF_CELL];
+  return 0;
 }
 
 int astk_graph_begin(void* stream) {

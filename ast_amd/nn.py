@@ -1,0 +1,116 @@
+"""NN drop-in (nn.py:42-322 of the reference): builds the model + optimizer from <cfg_dir>, resumes from the newest
+seq2seq_<N>.model, and runs the train step of nn.py:168-194 -- forward_loss -> cleargrads -> backward -> update --
+on the HIP path.  Data-parallel runs (one process per GPU, torchrun) shard every bucketed batch over the ranks and
+all-reduce the flat gradient arena over RCCL before the hooks (ast_amd.dist)."""
+import os
+import random
+
+from tqdm import tqdm
+
+from . import dist as adist
+from . import optimizers, serializers
+from .config import Config
+from .dataloader import SYMBOLS, FisherDataLoader, GlobalPhoneDataLoader, SyntheticDataLoader
+from .seq2seq import SpeechEncoderDecoder, using_config
+
+_ADAM = 0
+_SGD = 1
+
+
+class NN:
+    def __init__(self, cfg_path, vocab_size=None):
+        self.cfg = Config(cfg_path, vocab_size=vocab_size)
+        self.model_dir = self.cfg.model["model_dir"]
+        self.gpuid = self.cfg.train["gpuid"]
+        if adist.is_distributed():
+            self.gpuid = adist.local_rank()           # one process per GPU: the rank picks the device
+        random.seed(self.cfg.train["seed"])            # nn.py:54 -- the teacher-forcing / shuffling stream (Q4)
+        data = self.cfg.train["data"]
+        kind = data.get("dataloader", "fisher")
+        loader = {"globalphone": GlobalPhoneDataLoader, "synthetic": SyntheticDataLoader}.get(kind, FisherDataLoader)
+        self.data_loader = loader(data, self.model_dir, self.gpuid)
+        if adist.is_distributed():
+            self.data_loader.rank, self.data_loader.world = adist.rank(), adist.world_size()
+        self.get_model()
+        self.init_optimizer(self.cfg.train["optimizer"])
+        self.train_log = os.path.join(self.model_dir, "train.log")
+        self.dev_log = os.path.join(self.model_dir, "dev.log")
+
+    def init_optimizer(self, opt_cfg):
+        print("Setting up optimizer")
+        if opt_cfg["type"] == _ADAM:
+            print("using ADAM")
+            self.optimizer = optimizers.Adam(alpha=opt_cfg["lr"], beta1=0.9, beta2=0.999, eps=1e-08, amsgrad=True)
+        else:
+            print("using SGD")
+            self.optimizer = optimizers.SGD(lr=opt_cfg["lr"])
+        print("learning rate: {0:f}".format(opt_cfg["lr"]))
+        self.optimizer.setup(self.model)
+        if opt_cfg["l2"] > 0:
+            print("Adding WeightDecay: {0:f}".format(opt_cfg["l2"]))
+            self.optimizer.add_hook(optimizers.WeightDecay(opt_cfg["l2"]))
+        print("Clipping gradients at: {0:d}".format(opt_cfg["grad_clip"]))
+        self.optimizer.add_hook(optimizers.GradientClipping(threshold=opt_cfg["grad_clip"]))
+        if opt_cfg["grad_noise_eta"] > 0:
+            self.optimizer.add_hook(optimizers.GradientNoise(eta=opt_cfg["grad_noise_eta"]))
+        links = {n.split("/")[0] for n in (self.model.arena.shapes if self.model.arena is not None else [])}
+        for l in opt_cfg["freeze"]:
+            if not links or l in links:
+                print("freezing: {0:s}".format(l))
+                self.model[l].disable_update()
+            else:
+                print("layer {0:s} not in model".format(l))
+        if adist.is_distributed():
+            self.optimizer.grad_sync = adist.allreduce_grads
+
+    def get_model(self):
+        self.model_fname = os.path.join(self.model_dir, "seq2seq.model")
+        self.model = SpeechEncoderDecoder(self.gpuid, self.cfg.model)
+        self.model.to_gpu(self.gpuid)
+        feat_dim = self.cfg.train["data"].get("feat_dim")
+        if feat_dim:
+            self.model.materialize(int(feat_dim), seed=0)     # same seed on every rank: replicas start identical
+        self.max_epoch = 0
+        print("Checking for model in: {0:s}".format(self.model_dir))
+        stem = os.path.basename(self.model_fname).replace(".model", "")
+        files = [f for f in os.listdir(os.path.dirname(self.model_fname)) if stem in f and f.endswith(".model")]
+        if files:
+            newest = max(files, key=lambda s: int(s.split("_")[-1].split(".")[0]))
+            path = os.path.join(os.path.dirname(self.model_fname), newest)
+            print("model found = \n{0:s}".format(path))
+            serializers.load_npz(path, self.model)
+            self.max_epoch = int(newest.split("_")[-1].split(".")[0])
+        else:
+            print("model not found")
+
+    def train_epoch(self, set_key):
+        total_loss, n_batches = 0.0, 0
+        n_utts = self.data_loader.n_utts[set_key]
+        ex = self.cfg.train["extras"]
+        avg_loss = 0.0
+        with tqdm(total=n_utts, ncols=80, disable=adist.rank() != 0) as pbar:
+            for batch in self.data_loader.get_batch(self.cfg.train["batch_size"], set_key, train=True, labels=True):
+                with using_config("train", True):
+                    loss = self.model.forward_loss(X=batch["X"], y=batch["y"], teach_ratio=ex["teach_ratio"],
+                                                   random_out=ex["random_out"], add_noise=ex["speech_noise"])
+                    self.model.cleargrads()
+                    loss.backward()
+                    self.optimizer.update()
+                loss_val = float(loss.data) / len(batch["y"])          # quirk Q5: divided by the batch size
+                n_batches += 1
+                total_loss += loss_val
+                avg_loss = total_loss / n_batches
+                pbar.set_description("loss={0:0.4f}".format(avg_loss))
+                pbar.update(len(batch["X"]) * self.data_loader.world)
+        return avg_loss
+
+    def predict(self, set_key):
+        preds = []
+        stop_limit = self.cfg.train["data"]["max_pred"]
+        with tqdm(total=self.data_loader.n_utts[set_key], ncols=80, disable=adist.rank() != 0) as pbar:
+            for batch in self.data_loader.get_batch(self.cfg.train["batch_size"], set_key, train=False, labels=False):
+                with using_config("train", False):
+                    p = self.model.predict(batch["X"], SYMBOLS.GO_ID, SYMBOLS.EOS_ID, stop_limit)
+                    preds.extend(zip(batch["utts"], p.tolist()))
+                pbar.update(len(batch["X"]))
+        return preds

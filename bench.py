@@ -1,0 +1,205 @@
+"""bench.py -- speech frames/s of one full train step (BASELINE.json metric).
+
+step = speech noise -> forward_loss -> cleargrads -> backward -> [RCCL all-reduce of the flat gradient] -> WeightDecay +
+GradientClipping + AMSGrad, data already resident in HBM.  Workload (N=1 and per GPU for N>1, weak scaling): BASELINE.json
+configs[1]: synthetic fbank (T=800, 80-d) batch 32, 2x[Conv+BN+ReLU] -> 3-layer 2x256 LSTM encoder -> attention ->
+1-layer LSTM-512 decoder, V=1098, L=40, shipped training knobs (dropout .3, speech noise .25, teacher forcing .8).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import copy
+import ctypes as C
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MODEL_CFG = {
+    "dropout": {"embed": 0.3, "rnn": 0.3, "out": 0},
+    "rnn_config": {"bi_rnn": True, "enc_layers": 3, "dec_layers": 1, "hidden_units": 512, "embedding_units": 128,
+                   "attn_units": 512, "n_attn": 1, "feed_attn": True, "ln": False, "dec_vocab_size": 1098},
+    "cnn_config": {"bn": True, "cnn_layers": [
+        {"in_channels": None, "out_channels": 128, "ksize": [9, 13], "stride": [2, 13], "pad": [4, 0]},
+        {"in_channels": None, "out_channels": 512, "ksize": [9, 1], "stride": [2, 1], "pad": [4, 0]}]},
+}
+TRAIN = {"teach_ratio": 0.8, "speech_noise": 0.25, "lr": 1e-3, "l2": 1e-4, "grad_clip": 2}
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA dense peak
+
+
+def synth_batch(B, T, D, L, V, seed):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((B, T, D)).astype(np.float32)
+    y = np.zeros((B, L), dtype=np.int32)
+    for b in range(B):
+        n = L if b == 0 else int(rng.integers(max(L // 2, 3), L + 1))
+        y[b, 0] = 1
+        y[b, 1:n - 1] = rng.integers(4, V, size=n - 2)
+        y[b, n - 1] = 2
+    return X, y
+
+
+def cpu_baseline(B, T, D, L, V, budget_s=25.0):
+    """Times the CPU oracle (the faithful float32 NumPy restatement of the Chainer path, oracle/ast_ref.py) on a bounded
+    sample of the same workload: same model, same T/D/L, reduced batch.  Reported, never the target."""
+    import numpy as np
+    from oracle import ast_ref as R
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    Bs = 2
+    P = R.init_params(MODEL_CFG, D, V, seed=0, dtype=np.float32)
+    m = R.RefModel(MODEL_CFG, P, V)
+    m.masks = R.RecordingMasks(1)
+    opt = R.RefOptimizer(m, {"type": 0, "lr": TRAIN["lr"], "l2": TRAIN["l2"], "grad_clip": TRAIN["grad_clip"],
+                             "grad_noise_eta": 0, "freeze": []})
+    X, y = synth_batch(Bs, T, D, L, V, 20)
+    rnd = random.Random("seed-ast-20h")
+    noise = np.random.default_rng(1).normal(1.0, TRAIN["speech_noise"], X.shape).astype(np.float32)
+    times = []
+    t_all = time.time()
+    while len(times) < 3 and (time.time() - t_all) < budget_s:
+        t0 = time.time()
+        R.train_step(m, opt, X, y, TRAIN["teach_ratio"], add_noise=TRAIN["speech_noise"], noise=noise, pyrandom=rnd)
+        times.append(time.time() - t0)
+    best = min(times)
+    return {"value": round(Bs * T / best, 1), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} full train steps of the same model at batch {Bs} (T={T}, D={D}, L={L}); best step {best:.2f} s; "
+                      "float32 NumPy restatement of the Chainer path (Chainer is not installable offline)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--frames", type=int, default=800)
+    ap.add_argument("--feat", type=int, default=80)
+    ap.add_argument("--tgt-len", type=int, default=40)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=3, help="extra steps with per-kernel HIP-event timing")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from ast_amd import _lib, dist as adist
+    from ast_amd import optimizers as O
+    from ast_amd.seq2seq import SpeechEncoderDecoder, using_config
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        adist.init("nccl")
+    lib = _lib.load()
+    B, T, D, L, V = args.batch, args.frames, args.feat, args.tgt_len, MODEL_CFG["rnn_config"]["dec_vocab_size"]
+    cfg = copy.deepcopy(MODEL_CFG)
+    model = SpeechEncoderDecoder(local, cfg).materialize(D, seed=0)       # identical replicas
+    model.use_graphs = not args.no_graph
+    opt = O.Adam(alpha=TRAIN["lr"], beta1=0.9, beta2=0.999, eps=1e-8, amsgrad=True).setup(model)
+    opt.add_hook(O.WeightDecay(TRAIN["l2"]))
+    opt.add_hook(O.GradientClipping(TRAIN["grad_clip"]))
+    if world > 1:
+        opt.grad_sync = adist.allreduce_grads
+    random.seed("seed-ast-20h")                                           # same teacher-forcing stream on every rank
+    Xh, yh = synth_batch(B, T, D, L, V, 20 + rank)                        # each rank owns its shard of the global batch
+    X, y = torch.from_numpy(Xh).cuda(), torch.from_numpy(yh).cuda()
+
+    def step():
+        with using_config("train", True):
+            loss = model.forward_loss(X=X, y=y, teach_ratio=TRAIN["teach_ratio"], random_out=0, add_noise=TRAIN["speech_noise"])
+            model.cleargrads()
+            loss.backward()
+            opt.update()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss_val = float(loss.data)
+    assert np.isfinite(loss_val), "loss is not finite"
+    ms = dt / args.steps * 1e3
+    value = world * B * T / (dt / args.steps)
+
+    # ---- per-kernel timing of the attention scan and the GEMMs with HIP events on the launch stream (in situ)
+    roof, extra = None, {}
+    if hasattr(lib, "astk_prof_begin") and args.profile_steps > 0:
+        model.use_graphs = False
+        lib.astk_prof_begin()
+        for _ in range(args.profile_steps):
+            step()
+        torch.cuda.synchronize()
+        res = (C.c_double * 16)()
+        lib.astk_prof_end(res)
+        T2 = model._cur["T2"]
+        H = cfg["rnn_config"]["hidden_units"]
+        bytes_launch = B * T2 * H * 4                                    # one streaming read of enc_states
+        n_attn, ms_attn = res[1] + res[3], res[0] + res[2]
+        if n_attn > 0:
+            avg_us = ms_attn / n_attn * 1e3
+            ach = bytes_launch / (avg_us * 1e-6) / 1e9
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "attn_traffic.json")
+            if os.path.exists(tf):
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            roof = {"bound": "hbm", "kernel": "attn_fwd_partial+attn_bwd_partial", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "bytes_per_launch": bytes_launch, "avg_launch_us": round(avg_us, 3), "launches_per_step": int(n_attn / args.profile_steps)}
+            extra["attn_fwd_us"] = round(res[0] / max(res[1], 1) * 1e3, 3)
+            extra["attn_bwd_us"] = round(res[2] / max(res[3], 1) * 1e3, 3)
+        if res[5] > 0:
+            tfl = res[6] / (res[4] * 1e-3) / 1e12
+            extra["gemm"] = {"bound": "mfma", "achieved": round(tfl, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4), "ms_per_step": round(res[4] / args.profile_steps, 3),
+                             "launches_per_step": int(res[5] / args.profile_steps)}
+        if res[8] > 0:
+            extra["lstm_cell_us"] = round(res[7] / res[8] * 1e3, 3)
+            extra["lstm_cell_ms_per_step"] = round(res[7] / args.profile_steps, 3)
+
+    out = {"metric": "speech frames/s (train step)", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"BASELINE configs[1]: synthetic fbank T={T} D={D} batch {B}/GPU, 2xConv+BN -> 3-layer 2x256 LSTM enc -> "
+                                  f"attention -> 1-layer LSTM-512 dec, V={V}, L={L}, dropout .3, noise .25, teach .8, Adam(amsgrad)+L2+clip",
+                      "global_batch": world * B, "frames": T, "feat_dim": D, "tgt_len": L, "parallelism": f"dp{world}",
+                      "graphs": bool(not args.no_graph and getattr(model, "graphs_supported", False))},
+           "loss": round(loss_val, 4), "roofline": roof}
+    out.update({"kernels": extra} if extra else {})
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B, T, D, L, V)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -194,6 +194,12 @@ int astk_fill_dropout_mask(float* out, size_t n, float ratio, uint64_t seed, uin
 int astk_fill_normal(float* out, size_t n, float mean, float sigma, uint64_t seed, uint64_t offset, void* stream);
 int astk_scale_f32(float* x, size_t n, float s, void* stream);
 
+/* Optional per-kernel HIP-event timing on the launch stream (bench.py's roofline legs; off by default).
+ * astk_prof_end: res[0..1] attention-scan fwd (ms, launches); [2..3] attention-scan bwd; [4..6] GEMMs (ms, launches, flops);
+ * [7..8] fused LSTM cells (ms, launches).  res must hold 16 doubles.  Synchronises the device. */
+int astk_prof_begin(void);
+int astk_prof_end(double* res);
+
 /* hipGraph capture of a sequence of the calls above on `stream` (static shapes per bucket). */
 int astk_graph_begin(void* stream);
 int astk_graph_end(void* stream, void** graph_exec);

@@ -46,6 +46,9 @@ def _rel(a, b):
     ("mid-80d", _mid_cfg, 4, 120, 80, 9, 57, 0.0, 0.8),
     ("mid-80d-drop", _mid_cfg, 4, 120, 80, 9, 57, 0.3, 0.8),
     ("mid-13d", _mid_cfg, 5, 90, 13, 7, 57, 0.0, 0.8),
+    # hidden_units 128 -> 64 per direction: the persistent wavefront encoder kernels
+    ("persist-h64", lambda d: tiny_cfg(enc_layers=3, dec_layers=3, H=128, E=16, A=64, c0=8, c1=16, V=57, drop=d), 18, 70, 80, 8, 57, 0.0, 0.8),
+    ("persist-h64-drop", lambda d: tiny_cfg(enc_layers=2, dec_layers=1, H=128, E=16, A=64, c0=8, c1=16, V=57, drop=d), 4, 70, 80, 8, 57, 0.3, 0.8),
 ])
 def test_train_step_parity(name, cfgf, B, T, D, L, V, drop, teach):
     from oracle import ast_ref as R

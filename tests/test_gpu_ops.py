@@ -189,7 +189,10 @@ def test_cnn_fwd_bwd(lib, B, T, D, c0, c1, with_noise):
 
 
 # ------------------------------------------------------------------ encoder LSTM stacks
-@pytest.mark.parametrize("T,B,in_dim,h,nl,masks", [(7, 3, 12, 4, 2, False), (9, 5, 24, 20, 3, True), (5, 33, 64, 36, 1, True), (1, 2, 8, 4, 2, False)])
+@pytest.mark.parametrize("T,B,in_dim,h,nl,masks", [(7, 3, 12, 4, 2, False), (9, 5, 24, 20, 3, True), (5, 33, 64, 36, 1, True), (1, 2, 8, 4, 2, False),
+                                                   # h in {64,128,256,512}: the persistent wavefront kernels
+                                                   (12, 5, 24, 64, 3, True), (7, 33, 16, 128, 2, False), (6, 16, 32, 256, 3, True),
+                                                   (3, 4, 16, 512, 1, False), (1, 3, 8, 64, 2, True)])
 def test_lstm_stack(lib, T, B, in_dim, h, nl, masks):
     from ast_amd._lib import LstmGrads, LstmParams, LstmStackDesc
     from oracle.ast_ref_torch import encoder_torch
