@@ -2,8 +2,8 @@
 //
 //   forward : s[b,t] = enc[b,t,:].q[b,:] ; alpha = softmax_t(s) (unmasked, quirk Q2) ; cv = sum_t alpha enc[b,t,:]
 //             ONE pass over enc_states with an online softmax; the time axis of every batch row is split
-//             over `nsplit` workgroups so that B*nsplit >= #CUs, partial (max, sum, cv) are merged by a
-//             tiny second kernel that also normalises alpha.
+//             over `nsplit` workgroups so that B*nsplit >= #CUs; the workgroup that finishes a batch row last
+//             merges the partial (max, sum, cv) and normalises alpha inside the same launch.
 //   backward: ds[b,t] = alpha (enc.d_cv - cv.d_cv) (the softmax Jacobian's sum_t alpha dalpha equals cv.d_cv)
 //             dq = sum_t ds enc[b,t,:]  -- again ONE pass; d_enc is produced once per train step by a deferred
 //             batched GEMM over the saved (alpha, ds) (decoder.hip), not here.
@@ -17,6 +17,26 @@ namespace astk {
 namespace {
 
 constexpr int PART_PAD = 4;   // part row: [m, l, -, -, acc[H]]
+constexpr int MAX_SPLIT = 128;
+
+// Cross-workgroup combine inside the launch ("last arriver reduces", cdna_hip_programming.md section 5 item 2, sc1 form):
+// partials are stored write-through (sc1), every storing wave drains, the workgroup barriers, one lane takes a ticket on the
+// batch row's counter; the workgroup that draws the last ticket re-reads all partials with sc1 loads and finishes the row.
+// The counter is reset by the last arriver, so it is zero again for the next launch on the stream.
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool last_arriver(unsigned* cnt, int nsplit, int* s_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned tk = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = tk == (unsigned)(nsplit - 1);
+    if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_flag = last;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -43,8 +63,11 @@ __device__ __forceinline__ float dot_row(const float4 (&a)[NCH], const float4 (&
 template <int NCH>
 __global__ __launch_bounds__(256) void attn_fwd_partial(int B, int T, int H, const float* __restrict__ enc,
                                                         const float* __restrict__ q, long ldq, float* __restrict__ scores,
-                                                        int Tp, float* __restrict__ part, int nsplit, int chunk) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][H] + 8
+                                                        int Tp, float* __restrict__ part, int nsplit, int chunk,
+                                                        unsigned* __restrict__ cnt, float* __restrict__ cv, long ldcv,
+                                                        float* __restrict__ cv2, long ldcv2) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][H] + 8 + 2*MAX_SPLIT
+  __shared__ int s_last;
   const int b = blockIdx.x % B, sp = blockIdx.x / B;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t0 = sp * chunk, t1 = min(T, t0 + chunk);
@@ -62,7 +85,7 @@ __global__ __launch_bounds__(256) void attn_fwd_partial(int B, int T, int H, con
     if (two) load_row<NCH>(base + (long)(t + 4) * H, H, lane, e1);
     {
       const float s = wave_sum(dot_row<NCH>(e0, qv));
-      if (lane == 0) scores[(long)b * Tp + t] = s;
+      if (lane == 0) st_sc1(&scores[(long)b * Tp + t], s);
       const float mn = fmaxf(m, s);
       const float sc = expf(m - mn), p = expf(s - mn);
       l = l * sc + p;
@@ -75,7 +98,7 @@ __global__ __launch_bounds__(256) void attn_fwd_partial(int B, int T, int H, con
     }
     if (two) {
       const float s = wave_sum(dot_row<NCH>(e1, qv));
-      if (lane == 0) scores[(long)b * Tp + t + 4] = s;
+      if (lane == 0) st_sc1(&scores[(long)b * Tp + t + 4], s);
       const float mn = fmaxf(m, s);
       const float sc = expf(m - mn), p = expf(s - mn);
       l = l * sc + p;
@@ -103,33 +126,40 @@ __global__ __launch_bounds__(256) void attn_fwd_partial(int B, int T, int H, con
   for (int k = 0; k < 4; ++k) w[k] = sml[k] == -INFINITY ? 0.f : expf(sml[k] - M);
   float* prow = part + ((long)b * nsplit + sp) * (H + PART_PAD);
   for (int i = threadIdx.x; i < H; i += 256)
-    prow[PART_PAD + i] = sacc[i] * w[0] + sacc[H + i] * w[1] + sacc[2 * H + i] * w[2] + sacc[3 * H + i] * w[3];
+    st_sc1(&prow[PART_PAD + i], sacc[i] * w[0] + sacc[H + i] * w[1] + sacc[2 * H + i] * w[2] + sacc[3 * H + i] * w[3]);
   if (threadIdx.x == 0) {
-    prow[0] = M;
-    prow[1] = sml[4] * w[0] + sml[5] * w[1] + sml[6] * w[2] + sml[7] * w[3];
+    st_sc1(&prow[0], M);
+    st_sc1(&prow[1], sml[4] * w[0] + sml[5] * w[1] + sml[6] * w[2] + sml[7] * w[3]);
   }
-}
-
-__global__ __launch_bounds__(256) void attn_fwd_combine(int B, int T, int H, float* __restrict__ alpha, int Tp,
-                                                        const float* __restrict__ part, int nsplit, float* __restrict__ cv,
-                                                        long ldcv, float* __restrict__ cv2, long ldcv2) {
-  const int b = blockIdx.x;
+  if (!last_arriver(cnt + b, nsplit, &s_last)) return;
+  // ---- this workgroup finishes batch row b: merge the nsplit partials, normalise alpha
+  float* wgt = sm + 4 * H + 8;            // [MAX_SPLIT] weights exp(m_s - M)
+  float* lsum = wgt + MAX_SPLIT;          // [MAX_SPLIT]
   const float* pb = part + (long)b * nsplit * (H + PART_PAD);
-  float M = -INFINITY;
-  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pb[(long)s * (H + PART_PAD)]);
+  if (threadIdx.x < nsplit) {
+    wgt[threadIdx.x] = ld_sc1(&pb[(long)threadIdx.x * (H + PART_PAD)]);
+    lsum[threadIdx.x] = ld_sc1(&pb[(long)threadIdx.x * (H + PART_PAD) + 1]);
+  }
+  __syncthreads();
+  float Mx = -INFINITY;
+  for (int s2 = 0; s2 < nsplit; ++s2) Mx = fmaxf(Mx, wgt[s2]);
+  __syncthreads();
+  if (threadIdx.x < nsplit) wgt[threadIdx.x] = expf(wgt[threadIdx.x] - Mx);
+  __syncthreads();
   float L = 0.f;
-  for (int s = 0; s < nsplit; ++s) L += pb[(long)s * (H + PART_PAD) + 1] * expf(pb[(long)s * (H + PART_PAD)] - M);
+  for (int s2 = 0; s2 < nsplit; ++s2) L += lsum[s2] * wgt[s2];
   const float inv = 1.f / L;
   for (int i = threadIdx.x; i < H; i += 256) {
     float v = 0.f;
-    for (int s = 0; s < nsplit; ++s) v += pb[(long)s * (H + PART_PAD) + PART_PAD + i] * expf(pb[(long)s * (H + PART_PAD)] - M);
+    for (int s2 = 0; s2 < nsplit; ++s2) v += ld_sc1(&pb[(long)s2 * (H + PART_PAD) + PART_PAD + i]) * wgt[s2];
     v *= inv;
     cv[(long)b * ldcv + i] = v;
     if (cv2) cv2[(long)b * ldcv2 + i] = v;
   }
   for (int t = threadIdx.x; t < Tp; t += 256) {
-    float* a = alpha + (long)b * Tp + t;
-    *a = t < T ? expf(*a - M) * inv : 0.f;
+    float* ap = scores + (long)b * Tp + t;
+    const float sc = t < T ? ld_sc1(ap) : 0.f;
+    *ap = t < T ? expf(sc - Mx) * inv : 0.f;
   }
 }
 
@@ -137,8 +167,10 @@ template <int NCH>
 __global__ __launch_bounds__(256) void attn_bwd_partial(int B, int T, int H, const float* __restrict__ enc,
                                                         const float* __restrict__ alpha, int Tp, const float* __restrict__ cv,
                                                         long ldcv, const float* __restrict__ dcv, long ld_dcv,
-                                                        float* __restrict__ ds, float* __restrict__ part, int nsplit, int chunk) {
+                                                        float* __restrict__ ds, float* __restrict__ part, int nsplit, int chunk,
+                                                        unsigned* __restrict__ cnt, float* __restrict__ dq) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][H]
+  __shared__ int s_last;
   const int b = blockIdx.x % B, sp = blockIdx.x / B;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t0 = sp * chunk, t1 = min(T, t0 + chunk);
@@ -181,15 +213,11 @@ __global__ __launch_bounds__(256) void attn_bwd_partial(int B, int T, int H, con
   }
   __syncthreads();
   float* prow = part + ((long)b * nsplit + sp) * H;
-  for (int i = threadIdx.x; i < H; i += 256) prow[i] = sm[i] + sm[H + i] + sm[2 * H + i] + sm[3 * H + i];
-}
-
-__global__ __launch_bounds__(256) void attn_bwd_combine(int B, int H, const float* __restrict__ part, int nsplit,
-                                                        float* __restrict__ dq) {
-  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < H; i += 256) st_sc1(&prow[i], sm[i] + sm[H + i] + sm[2 * H + i] + sm[3 * H + i]);
+  if (!last_arriver(cnt + b, nsplit, &s_last)) return;
   for (int i = threadIdx.x; i < H; i += 256) {
     float v = 0.f;
-    for (int s = 0; s < nsplit; ++s) v += part[((long)b * nsplit + s) * H + i];
+    for (int s2 = 0; s2 < nsplit; ++s2) v += ld_sc1(&part[((long)b * nsplit + s2) * H + i]);
     dq[(long)b * H + i] = v;
   }
 }
@@ -200,6 +228,7 @@ inline void split_for(int B, int T, int& nsplit, int& chunk) {
   chunk = cdiv(T, want);
   if (chunk < 8) chunk = 8;                // at least 2 rows per wave
   if (chunk > T) chunk = T;
+  if (cdiv(T, chunk) > MAX_SPLIT) chunk = cdiv(T, MAX_SPLIT);
   nsplit = cdiv(T, chunk);
 }
 
@@ -208,7 +237,17 @@ inline void split_for(int B, int T, int& nsplit, int& chunk) {
 size_t attn_ws_bytes(int B, int T, int H) {
   int nsplit, chunk;
   split_for(B, T, nsplit, chunk);
-  return align_up((size_t)B * nsplit * (H + PART_PAD) * sizeof(float), 256);
+  return align_up((size_t)B * nsplit * (H + PART_PAD) * sizeof(float), 256) + align_up((size_t)B * sizeof(unsigned), 256);
+}
+// the ticket counters live behind the partials; they must be zero before the first launch (attn_ws_init) and stay zero
+unsigned* attn_counters(void* ws, int B, int T, int H) {
+  int nsplit, chunk;
+  split_for(B, T, nsplit, chunk);
+  return (unsigned*)((char*)ws + align_up((size_t)B * nsplit * (H + PART_PAD) * sizeof(float), 256));
+}
+int attn_ws_init(void* ws, int B, int T, int H, hipStream_t s) {
+  ASTK_HIP(hipMemsetAsync(attn_counters(ws, B, T, H), 0, (size_t)B * sizeof(unsigned), s));
+  return 0;
 }
 
 int attn_fwd_launch(int B, int T, int H, const float* enc, const float* q, long ldq, float* alpha, float* cv, long ldcv,
@@ -219,18 +258,17 @@ int attn_fwd_launch(int B, int T, int H, const float* enc, const float* q, long 
   split_for(B, T, nsplit, chunk);
   const int Tp = (T + 3) / 4 * 4;
   float* part = (float*)ws;
-  const size_t shm = (size_t)(4 * H + 8) * sizeof(float);
+  const size_t shm = (size_t)(4 * H + 8 + 2 * MAX_SPLIT) * sizeof(float);
   dim3 grid(B * nsplit), blk(256);
+  unsigned* cnt = attn_counters(ws, B, T, H);
   const int nch = cdiv(H, 256);
   {
   ProfScope prof(PROF_ATTN_FWD, s);
-  if (nch <= 1) hipLaunchKernelGGL((attn_fwd_partial<1>), grid, blk, shm, s, B, T, H, enc, q, ldq, alpha, Tp, part, nsplit, chunk);
-  else if (nch <= 2) hipLaunchKernelGGL((attn_fwd_partial<2>), grid, blk, shm, s, B, T, H, enc, q, ldq, alpha, Tp, part, nsplit, chunk);
-  else if (nch <= 4) hipLaunchKernelGGL((attn_fwd_partial<4>), grid, blk, shm, s, B, T, H, enc, q, ldq, alpha, Tp, part, nsplit, chunk);
-  else hipLaunchKernelGGL((attn_fwd_partial<8>), grid, blk, shm, s, B, T, H, enc, q, ldq, alpha, Tp, part, nsplit, chunk);
+  if (nch <= 1) hipLaunchKernelGGL((attn_fwd_partial<1>), grid, blk, shm, s, B, T, H, enc, q, ldq, alpha, Tp, part, nsplit, chunk, cnt, cv, ldcv, cv2, ldcv2);
+  else if (nch <= 2) hipLaunchKernelGGL((attn_fwd_partial<2>), grid, blk, shm, s, B, T, H, enc, q, ldq, alpha, Tp, part, nsplit, chunk, cnt, cv, ldcv, cv2, ldcv2);
+  else if (nch <= 4) hipLaunchKernelGGL((attn_fwd_partial<4>), grid, blk, shm, s, B, T, H, enc, q, ldq, alpha, Tp, part, nsplit, chunk, cnt, cv, ldcv, cv2, ldcv2);
+  else hipLaunchKernelGGL((attn_fwd_partial<8>), grid, blk, shm, s, B, T, H, enc, q, ldq, alpha, Tp, part, nsplit, chunk, cnt, cv, ldcv, cv2, ldcv2);
   }
-  ASTK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_fwd_combine, dim3(B), blk, 0, s, B, T, H, alpha, Tp, part, nsplit, cv, ldcv, cv2, ldcv2);
   ASTK_LAUNCH_CHECK();
   return 0;
 }
@@ -246,16 +284,15 @@ int attn_bwd_launch(int B, int T, int H, const float* enc, const float* alpha, c
   float* part = (float*)ws;
   const size_t shm = (size_t)(4 * H) * sizeof(float);
   dim3 grid(B * nsplit), blk(256);
+  unsigned* cnt = attn_counters(ws, B, T, H);
   const int nch = cdiv(H, 256);
   {
   ProfScope prof(PROF_ATTN_BWD, s);
-  if (nch <= 1) hipLaunchKernelGGL((attn_bwd_partial<1>), grid, blk, shm, s, B, T, H, enc, alpha, Tp, cv, ldcv, d_cv, ld_dcv, ds, part, nsplit, chunk);
-  else if (nch <= 2) hipLaunchKernelGGL((attn_bwd_partial<2>), grid, blk, shm, s, B, T, H, enc, alpha, Tp, cv, ldcv, d_cv, ld_dcv, ds, part, nsplit, chunk);
-  else if (nch <= 4) hipLaunchKernelGGL((attn_bwd_partial<4>), grid, blk, shm, s, B, T, H, enc, alpha, Tp, cv, ldcv, d_cv, ld_dcv, ds, part, nsplit, chunk);
-  else hipLaunchKernelGGL((attn_bwd_partial<8>), grid, blk, shm, s, B, T, H, enc, alpha, Tp, cv, ldcv, d_cv, ld_dcv, ds, part, nsplit, chunk);
+  if (nch <= 1) hipLaunchKernelGGL((attn_bwd_partial<1>), grid, blk, shm, s, B, T, H, enc, alpha, Tp, cv, ldcv, d_cv, ld_dcv, ds, part, nsplit, chunk, cnt, dq);
+  else if (nch <= 2) hipLaunchKernelGGL((attn_bwd_partial<2>), grid, blk, shm, s, B, T, H, enc, alpha, Tp, cv, ldcv, d_cv, ld_dcv, ds, part, nsplit, chunk, cnt, dq);
+  else if (nch <= 4) hipLaunchKernelGGL((attn_bwd_partial<4>), grid, blk, shm, s, B, T, H, enc, alpha, Tp, cv, ldcv, d_cv, ld_dcv, ds, part, nsplit, chunk, cnt, dq);
+  else hipLaunchKernelGGL((attn_bwd_partial<8>), grid, blk, shm, s, B, T, H, enc, alpha, Tp, cv, ldcv, d_cv, ld_dcv, ds, part, nsplit, chunk, cnt, dq);
   }
-  ASTK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_combine, dim3(B), blk, 0, s, B, H, part, nsplit, dq);
   ASTK_LAUNCH_CHECK();
   return 0;
 }
@@ -272,12 +309,14 @@ size_t astk_attn_workspace_bytes(int B, int T, int H) { return attn_ws_bytes(B, 
 int astk_attn_step_fwd(int B, int T, int H, const float* enc, const float* q, float* alpha, float* cv, void* ws,
                        size_t ws_bytes, void* stream) {
   ASTK_CHECK(ws_bytes >= attn_ws_bytes(B, T, H), "attn_step_fwd: workspace too small");
+  ASTK_TRY(attn_ws_init(ws, B, T, H, (hipStream_t)stream));
   return attn_fwd_launch(B, T, H, enc, q, H, alpha, cv, H, nullptr, 0, ws, (hipStream_t)stream);
 }
 
 int astk_attn_step_bwd(int B, int T, int H, const float* enc, const float* alpha, const float* cv, const float* d_cv,
                        float* ds, float* dq, void* ws, size_t ws_bytes, void* stream) {
   ASTK_CHECK(ws_bytes >= attn_ws_bytes(B, T, H), "attn_step_bwd: workspace too small");
+  ASTK_TRY(attn_ws_init(ws, B, T, H, (hipStream_t)stream));
   return attn_bwd_launch(B, T, H, enc, alpha, cv, H, d_cv, H, ds, dq, ws, (hipStream_t)stream);
 }
 

@@ -196,6 +196,7 @@ int attn_fwd_launch(int B, int T, int H, const float* enc, const float* q, long 
 int attn_bwd_launch(int B, int T, int H, const float* enc, const float* alpha, const float* cv, long ldcv,
                     const float* d_cv, long ld_dcv, float* ds, float* dq, void* ws, hipStream_t s);
 size_t attn_ws_bytes(int B, int T, int H);
+int attn_ws_init(void* ws, int B, int T, int H, hipStream_t s);   // zero the ticket counters (once per workspace use)
 
 // ---- decoder helpers (decoder.hip)
 int softmax_ce_launch(int B, int V, long ld, float* logits, const int32_t* targets, long t_stride, const float* cw,

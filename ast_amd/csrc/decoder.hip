@@ -274,6 +274,7 @@ int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
   }
   ASTK_TRY(fill_zero(P.HT, (size_t)B * A * sizeof(float), s));
   ASTK_TRY(fill_zero(P.X0, (size_t)B * XI * sizeof(float), s));   // ht_{-1} half of the first concat buffer
+  ASTK_TRY(attn_ws_init(P.attn_ws, B, P.T, H, s));
   const int top = nl - 1;
   for (int st = 0; st < S; ++st) {
     float* x0 = P.X0 + (size_t)st * B * XI;
@@ -351,6 +352,7 @@ int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
     ASTK_TRY(transpose_f32(P.WlT[l], 4 * H, prm->lstm[l].Wl, H, 4 * H, H, s));     // (4H,H)  -> (H,4H)
   }
   ASTK_TRY(fill_zero(P.ZERO, (size_t)B * (A > H ? A : H) * sizeof(float), s));
+  ASTK_TRY(attn_ws_init(P.attn_ws, B, T, H, s));
   for (int st = S - 1; st >= 0; --st) {
     const bool last = st == S - 1;
     float* dl = P.LOGITS + (size_t)st * B * Vp;
@@ -453,6 +455,7 @@ int astk_decoder_step_infer(const astk_decoder_desc* d, const astk_decoder_param
   const int B = P.B, H = P.H, E = P.E, A = P.A, V = P.V, XI = P.XI, nl = P.nl;
   const size_t bh = (size_t)B * H;
   float* x0 = P.X0;
+  ASTK_TRY(attn_ws_init(P.attn_ws, B, P.T, H, s));
   hipLaunchKernelGGL(k_embed, dim3(B), dim3(128), 0, s, prm->embed, (const int32_t*)nullptr, 0, 0, (const int32_t*)nullptr,
                      (const int32_t*)nullptr, tokens, (int32_t*)nullptr, (const float*)nullptr, x0, B, E, XI, V);
   ASTK_LAUNCH_CHECK();

@@ -27,22 +27,24 @@ __device__ __forceinline__ long rowoff(const MatView& v, int r) {
   return (long)r * v.ld;
 }
 
-__device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (nvalid >= 4) {
-    v = *reinterpret_cast<const float4*>(p);
-  } else if (nvalid > 0) {
-    v.x = p[0];
-    if (nvalid > 1) v.y = p[1];
-    if (nvalid > 2) v.z = p[2];
-  }
+// Branch-free guarded load: the caller passes an address that is ALWAYS readable (clamped inside the matrix); elements
+// at index >= nvalid are zeroed with selects.  (A `cond ? load : 0` makes hipcc branch around every load and wait
+// vmcnt(0) per element -- the loads of a tile would serialise.)
+__device__ __forceinline__ float4 mask4(float4 v, int nvalid) {
+  v.x = nvalid > 0 ? v.x : 0.f;
+  v.y = nvalid > 1 ? v.y : 0.f;
+  v.z = nvalid > 2 ? v.z : 0.f;
+  v.w = nvalid > 3 ? v.w : 0.f;
   return v;
 }
 
-// Stages one operand tile.  RK: global rows are the tile's M (or N) index, K contiguous.
-template <bool RK>
+// Stages one operand tile.  RK: global rows are the tile's M (or N) index, K contiguous (row offsets are computed once,
+// any MatView addressing).  !RK: global rows are the k index; TWOLVL selects plain (k*ld) or two-level row offsets --
+// both branch-free, so the tile's loads are issued back to back (indexed rows are not supported on this path).
+template <bool RK, bool TWOLVL>
 struct Stager {
-  float4 reg[4];
+  float4 reg[4];  // raw staged data: masked only when it is written to LDS, so the global loads stay in flight over the MFMAs
+  int nv[4];      // valid elements of reg[p]
   long off[4];   // RK only: row offsets (fixed for the whole k loop)
   bool ok[4];    // RK only
   int a, b;      // RK: a = k-quad (0..7), b = row0 (0..31).  KR: a = col-quad (0..31), b = krow0 (0..7)
@@ -62,19 +64,28 @@ struct Stager {
       b = tid >> 5;
     }
   }
-  // kcur: first k of the tile, kend: exclusive end of this block's K range; col0/ncols: KR only
-  __device__ __forceinline__ void load(const MatView& v, int kcur, int kend, int col0, int ncols) {
+  // kcur: first k of the tile, kend: exclusive end of this block's K range, K: full K extent; col0/ncols: KR only.
+  // Leading dimensions are multiples of 4 and >= the extent, so a float4 at any multiple of 4 below round_up(extent,4)
+  // stays inside its row: addresses are clamped to that range and the surplus is masked.
+  __device__ __forceinline__ void load(const MatView& v, int kcur, int kend, int K, int col0, int ncols) {
     if (RK) {
-      int k = kcur + a * 4;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) reg[p] = ld4_guard(v.p + off[p] + k, ok[p] ? (kend - k) : 0);
-    } else {
-      int col = col0 + a * 4;
+      const int k = kcur + a * 4;
+      const int kc = min(k, ((K + 3) & ~3) - 4);
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        int kr = kcur + b + 8 * p;
-        if (kr < kend) reg[p] = ld4_guard(v.p + rowoff(v, kr) + col, ncols - col);
-        else reg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        reg[p] = *reinterpret_cast<const float4*>(v.p + off[p] + kc);
+        nv[p] = ok[p] ? (kend - k) : 0;
+      }
+    } else {
+      const int col = col0 + a * 4;
+      const int colc = min(col, ((ncols + 3) & ~3) - 4);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int kr = kcur + b + 8 * p;
+        const int krc = min(kr, kend - 1);
+        const long ro = TWOLVL ? (long)(krc / v.tn) * v.sg + (long)(krc % v.tn) * v.st : (long)krc * v.ld;
+        reg[p] = *reinterpret_cast<const float4*>(v.p + ro + colc);
+        nv[p] = kr < kend ? (ncols - col) : 0;
       }
     }
   }
@@ -82,20 +93,21 @@ struct Stager {
     if (RK) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        int r = b + 32 * p;
-        S[(a * 4 + 0) * LD_RK + r] = reg[p].x;
-        S[(a * 4 + 1) * LD_RK + r] = reg[p].y;
-        S[(a * 4 + 2) * LD_RK + r] = reg[p].z;
-        S[(a * 4 + 3) * LD_RK + r] = reg[p].w;
+        const int r = b + 32 * p;
+        const float4 m = mask4(reg[p], nv[p]);
+        S[(a * 4 + 0) * LD_RK + r] = m.x;
+        S[(a * 4 + 1) * LD_RK + r] = m.y;
+        S[(a * 4 + 2) * LD_RK + r] = m.z;
+        S[(a * 4 + 3) * LD_RK + r] = m.w;
       }
     } else {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(&S[(b + 8 * p) * LD_KR + a * 4]) = reg[p];
+      for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(&S[(b + 8 * p) * LD_KR + a * 4]) = mask4(reg[p], nv[p]);
     }
   }
 };
 
-template <bool A_RK, bool B_RK>
+template <bool A_RK, bool B_RK, bool TWOLVL>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   constexpr int LDA = A_RK ? LD_RK : LD_KR;
   constexpr int LDB = B_RK ? LD_RK : LD_KR;
@@ -120,8 +132,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   B.p += (long)zb * g.sB;
   float* C = g.C + (long)zb * g.sC;
 
-  Stager<A_RK> sa;
-  Stager<B_RK> sb;
+  Stager<A_RK, TWOLVL> sa;
+  Stager<B_RK, TWOLVL> sb;
   sa.init(A, m0, g.M, tid);
   sb.init(B, n0, g.N, tid);
 
@@ -137,8 +149,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int li = lane & 31, lk = lane >> 5;
   const int nk = (kend - kbeg + BK - 1) / BK;
 
-  sa.load(A, kbeg, kend, m0, g.M);
-  sb.load(B, kbeg, kend, n0, g.N);
+  sa.load(A, kbeg, kend, g.K, m0, g.M);
+  sb.load(B, kbeg, kend, g.K, n0, g.N);
   sa.store(As);
   sb.store(Bs);
   __syncthreads();
@@ -146,20 +158,35 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) {
-      sa.load(A, kbeg + (kt + 1) * BK, kend, m0, g.M);
-      sb.load(B, kbeg + (kt + 1) * BK, kend, n0, g.N);
+      sa.load(A, kbeg + (kt + 1) * BK, kend, g.K, m0, g.M);
+      sb.load(B, kbeg + (kt + 1) * BK, kend, g.K, n0, g.N);
     }
     const float* ap = As + lk * LDA + wm * 64 + li;
     const float* bp = Bs + lk * LDB + wn * 64 + li;
+    // software-pipelined operand fetch: the LDS reads of k-pair kk+2 are issued before the MFMAs of k-pair kk
+    float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      float a0 = ap[kk * LDA], a1 = ap[kk * LDA + 32];
-      float b0 = bp[kk * LDB], b1 = bp[kk * LDB + 32];
+      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+      if (kk + 2 < BK) {
+        na0 = ap[(kk + 2) * LDA]; na1 = ap[(kk + 2) * LDA + 32];
+        nb0 = bp[(kk + 2) * LDB]; nb1 = bp[(kk + 2) * LDB + 32];
+      }
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
+    // pin the interleave (hipcc otherwise sinks every LDS read directly in front of its MFMAs with lgkmcnt(0)):
+    // reads of k-pair i+1 (2 x ds_read2_b32) go in front of the 4 MFMAs of k-pair i
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+    for (int i = 0; i < BK / 2 - 1; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     __syncthreads();
     if (more) {
       sa.store(As);
@@ -203,13 +230,26 @@ int gemm_launch(int layout, const GemmArgs& g, hipStream_t s) {
              "gemm: leading dimensions / strides must be multiples of 4 floats (lda=%ld ldb=%ld)", g.A.ld, g.B.ld);
   ASTK_CHECK(g.ksplit >= 1 && (g.ksplit == 1 || g.mode == GEMM_ATOMIC), "gemm: split-K needs atomic mode");
   GemmArgs a = g;
+  const bool a_kr = layout == GEMM_TN, b_kr = layout != GEMM_NT;
+  ASTK_CHECK(!(a_kr && g.A.rowidx) && !(b_kr && g.B.rowidx), "gemm: indexed rows are only supported on K-contiguous operands");
+  const bool twolvl = (a_kr && g.A.tn > 0) || (b_kr && g.B.tn > 0);
+  if (twolvl) {   // a plain operand next to a two-level one: express it as one group of INT_MAX rows
+    if (a_kr && a.A.tn <= 0) { a.A.tn = 0x7fffffff; a.A.sg = 0; a.A.st = a.A.ld; }
+    if (b_kr && a.B.tn <= 0) { a.B.tn = 0x7fffffff; a.B.sg = 0; a.B.st = a.B.ld; }
+  }
   const long tiles = (long)cdiv(g.M, BM) * cdiv(g.N, BN);
   dim3 grid((unsigned)tiles, 1, (unsigned)(g.batch * g.ksplit));
   ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * (double)g.K * g.batch);
   switch (layout) {
-    case GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, a); break;
-    case GEMM_NN: hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, a); break;
-    case GEMM_TN: hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, a); break;
+    case GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<true, true, false>), grid, dim3(256), 0, s, a); break;
+    case GEMM_NN:
+      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<true, false, true>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gemm_f32_kernel<true, false, false>), grid, dim3(256), 0, s, a);
+      break;
+    case GEMM_TN:
+      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<false, false, true>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gemm_f32_kernel<false, false, false>), grid, dim3(256), 0, s, a);
+      break;
     default: ASTK_CHECK(false, "gemm: bad layout %d", layout);
   }
   ASTK_LAUNCH_CHECK();

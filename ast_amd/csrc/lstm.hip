@@ -38,6 +38,7 @@ struct LstmPlan {
   float* WlT[2][ASTK_MAX_RNN_LAYERS];  // (h, 4h)
   float* WuT[2][ASTK_MAX_RNN_LAYERS];  // (h, 4h) transposed upward weights of layers >= 1 (persistent backward)
   unsigned* counters;                  // arrival counters of the persistent kernels
+  float* GATH;                         // (T,B,4h) dz of the reverse stack's layer 0 re-ordered to frame order
   float* DX[2];                        // (T,B,h) gradient wrt a layer's input (layers >= 1)
   float* DC[2][2];                     // dc ping-pong (B,h)
   size_t bytes;
@@ -67,6 +68,7 @@ int make_plan(const astk_lstm_stack_desc* d, void* ws, bool with_masks, LstmPlan
     P.DC[dd][1] = c.take<float>((size_t)P.B * P.h);
   }
   (void)with_masks;
+  P.GATH = c.take<float>(P.nd > 1 ? tb * 4 * P.h : 4);
   P.counters = c.take<unsigned>(((size_t)P.nd * P.nl * ((P.B + 15) / 16) + 2) * 64);
   P.bytes = c.total();
   return 0;
@@ -78,6 +80,14 @@ __global__ void k_perm(int* perm, int* inv, int T) {
     const int f = (T - i) % T;   // quirk Q1: X[-i]
     perm[i] = f;
     inv[f] = i;
+  }
+}
+// dst[r][:] = src[idx[r]][:]  (float4 columns)
+__global__ void k_gather_rows(float* __restrict__ dst, const float* __restrict__ src, const int* __restrict__ idx, int rows, int cols4) {
+  const long n = (long)rows * cols4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols4), c = (int)(i % cols4);
+    reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[(long)idx[r] * cols4 + c];
   }
 }
 // expands a frame permutation to (T*B) row indices: rows[i*B+b] = perm[i]*B + b
@@ -297,16 +307,23 @@ int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
         ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(4 * h, h, rows - B, mat(dz + (size_t)B * 4 * h, 4 * h), mat(P.HR[dd][l], h), g.dWl, h,
                                                 nullptr, GEMM_ATOMIC, ks), s));
       }
-      // dWu (4h,in) += dz^T X
+      // dWu (4h,in) += dz^T X   (reverse stack, layer 0: dz is first re-ordered to frame order, sum_i dz_i^T x[perm i] = sum_f dz[inv f]^T x_f)
       {
         MatView Xv;
-        if (l == 0) Xv = dd == 0 ? mat(x, in) : mat_idx(x, in, rows_perm);
-        else Xv = mat(masks ? P.HD[dd][l - 1] : P.HR[dd][l - 1], h);
+        const float* dzu = dz;
+        if (l == 0) {
+          Xv = mat(x, in);
+          if (dd == 1) {
+            hipLaunchKernelGGL(k_gather_rows, dim3(2048), dim3(256), 0, s, P.GATH, dz, rows_inv, rows, h);
+            ASTK_LAUNCH_CHECK();
+            dzu = P.GATH;
+          }
+        } else Xv = mat(masks ? P.HD[dd][l - 1] : P.HR[dd][l - 1], h);
         const long tiles = (long)cdiv(4 * h, 128) * cdiv(in, 128);
         int ks = (int)(512 / tiles);
         if (ks < 1) ks = 1;
         if (ks > rows / 128) ks = rows / 128 > 0 ? rows / 128 : 1;
-        ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(4 * h, in, rows, mat(dz, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, ks), s));
+        ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(4 * h, in, rows, mat(dzu, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, ks), s));
       }
       ASTK_TRY(colsum_add_f32(g.db, dz, 4 * h, rows, 4 * h, s));
       // gradient wrt the layer input

@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd(PFwdArgs a) {
       } else
 #pragma unroll
       for (int i = 0; i < KB; ++i) ax[i] = ldb128_sc1(r_x, xo + 16 * (wave + 4 * i));
+      __builtin_amdgcn_sched_barrier(0);   // all loads of the step in flight before the first MFMA
 #pragma unroll
       for (int i = 0; i < KB; ++i) { MFMA4G(acc, ax[i], wu[i]) }
     }
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd(PFwdArgs a) {
       } else
 #pragma unroll
       for (int i = 0; i < KB; ++i) ah[i] = ldb128_sc1(r_hr, ho + 16 * (wave + 4 * i));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < KB; ++i) { MFMA4G(acc, ah[i], wl[i]) }
     }
@@ -329,6 +331,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd(PBwdArgs a) {
       float4 av[NB];
 #pragma unroll
       for (int i = 0; i < NB; ++i) av[i] = ldb128_sc1(r_up, o + 16 * (wave + 4 * i));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < NB; ++i) { MFMA4(acc1, av[i], wu[i]) }
     }
@@ -340,6 +343,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd(PBwdArgs a) {
       float4 av[NB];
 #pragma unroll
       for (int i = 0; i < NB; ++i) av[i] = ldb128_sc1(r_dz, o + 16 * (wave + 4 * i));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < NB; ++i) { MFMA4(acc0, av[i], wl[i]) }
     }

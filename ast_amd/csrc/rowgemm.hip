@@ -21,7 +21,8 @@ struct WRows {   // W row for (tile t, column j) = base + j*sj + t*st ; valid co
   int base, sj, st;
 };
 
-template <int NT>
+// CH k-blocks per wave are loaded back to back (one exposed memory round trip per trip) before their MFMAs issue.
+template <int NT, int CH>
 __device__ __forceinline__ void tile_dot(const RowPair& pr, int m0, int M, WRows wr, int jvalid, int lane, int wave,
                                          f32x4 (&acc)[NT]) {
   const int K = pr.K;
@@ -34,34 +35,41 @@ __device__ __forceinline__ void tile_dot(const RowPair& pr, int m0, int M, WRows
 #pragma unroll
   for (int t = 0; t < NT; ++t) wp[t] = pr.W + (long)(wr.base + j * wr.sj + t * wr.st) * pr.ldw + 4 * q;
   const int nblk = (K + 15) >> 4;
-  for (int s0 = wave; s0 < nblk; s0 += 8) {   // two k-blocks per trip: loads of both are issued before the MFMAs
-    const int s1 = s0 + 4;
-    const int k0 = 16 * s0 + 4 * q, k1 = 16 * s1 + 4 * q;
-    const bool v0 = k0 < K, v1 = (s1 < nblk) && (k1 < K);
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-    float4 w0[NT], w1[NT];
-    if (v0) a0 = *reinterpret_cast<const float4*>(ap + 16 * s0);
-    if (v1) a1 = *reinterpret_cast<const float4*>(ap + 16 * s1);
+  f32x4 acc2[NT];   // second accumulator chain: consecutive MFMAs never wait on each other's result
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      w0[t] = v0 ? *reinterpret_cast<const float4*>(wp[t] + 16 * s0) : make_float4(0.f, 0.f, 0.f, 0.f);
-      w1[t] = v1 ? *reinterpret_cast<const float4*>(wp[t] + 16 * s1) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = 0; t < NT; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int sb = wave; sb < nblk; sb += 4 * CH) {
+    float4 av[CH], wv[CH][NT];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      // branch-free: the address is clamped inside the row (K % 4 == 0), out-of-range k-blocks are zeroed by a select on the
+      // A operand only (0 * w = 0) -- a `cond ? load : 0` would serialise every load behind a vmcnt(0)
+      const int s = sb + 4 * i;
+      const int ko = min(16 * s + 4 * q, K - 4) - 4 * q;
+      const bool v = (16 * s + 4 * q) < K;
+      float4 x = *reinterpret_cast<const float4*>(ap + ko);
+      x.x = v ? x.x : 0.f; x.y = v ? x.y : 0.f; x.z = v ? x.z : 0.f; x.w = v ? x.w : 0.f;
+      av[i] = x;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wv[i][t] = *reinterpret_cast<const float4*>(wp[t] + ko);
     }
+    // keep every load of the trip in front of its MFMAs (hipcc otherwise sinks each load next to its use to save VGPRs,
+    // which turns the trip into CH dependent memory round trips)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w0[t].x, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w0[t].y, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w0[t].z, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w0[t].w, acc[t], 0, 0, 0);
-    }
+    for (int i = 0; i < CH; ++i) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, w1[t].x, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, w1[t].y, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, w1[t].z, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, w1[t].w, acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, wv[i][t].x, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, wv[i][t].y, acc2[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, wv[i][t].z, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, wv[i][t].w, acc2[t], 0, 0, 0);
     }
   }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] += acc2[t];
 }
 
 // 4-wave K reduction.  D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
@@ -88,51 +96,31 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NT]) {
 }
 
 // ------------------------------------------------------------------ generic row-panel GEMM
+// One workgroup = 16 rows x 16 columns (N/16 x M/16 workgroups: these products are latency bound, so they are
+// spread over as many CUs as possible and each wave's whole K share is fetched in at most a few round trips).
 __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
-  constexpr int NT = 4;
+  constexpr int NT = 1;
   __shared__ __attribute__((aligned(16))) float red[4 * NT * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n0 = blockIdx.x * 16 * NT, m0 = blockIdx.y * 16;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
   f32x4 acc[NT];
   zero_acc<NT>(acc);
-  // tile t covers columns n0+16t .. n0+16t+15 (W rows n0+16t+j)
-  for (int p = 0; p < a.npairs; ++p) {
-    const RowPair pr = a.p[p];
-    if (n0 + 16 * NT <= a.N) {
-      tile_dot<NT>(pr, m0, a.M, WRows{n0, 1, 16}, 16, lane, wave, acc);
-    } else {
-      // last column block: tile by tile with the W row index clamped inside [0, N)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int nb = n0 + 16 * t;
-        if (nb < a.N) {
-          f32x4 one[1];
-          one[0] = acc[t];
-          tile_dot<1>(pr, m0, a.M, WRows{nb, 1, 0}, min(16, a.N - nb), lane, wave, one);
-          acc[t] = one[0];
-        }
-      }
-    }
-  }
+  const int jv = min(16, a.N - n0);
+  for (int p = 0; p < a.npairs; ++p) tile_dot<NT, 8>(a.p[p], m0, a.M, WRows{n0, 1, 0}, jv, lane, wave, acc);
   float vals[NT];
   reduce_waves<NT>(acc, vals, red);
-  const int row = m0 + (threadIdx.x >> 4), col = threadIdx.x & 15;
-  if (row >= a.M) return;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int n = n0 + 16 * t + col;
-    if (n >= a.N) continue;
-    float v = vals[t];
-    if (a.bias) v += a.bias[n];
-    if (a.addend) v += a.addend[(long)row * a.ld_add + n];
-    if (a.act == ACT_TANH) v = tanhf(v);
-    else if (a.act == ACT_DTANH) {
-      const float y = a.aux[(long)row * a.ld_aux + n];
-      v *= (1.f - y * y);
-    }
-    a.out[(long)row * a.ld_out + n] = v;
-    if (a.out2) a.out2[(long)row * a.ld_out2 + n] = v;
+  const int row = m0 + (threadIdx.x >> 4), n = n0 + (threadIdx.x & 15);
+  if (row >= a.M || n >= a.N) return;
+  float v = vals[0];
+  if (a.bias) v += a.bias[n];
+  if (a.addend) v += a.addend[(long)row * a.ld_add + n];
+  if (a.act == ACT_TANH) v = tanhf(v);
+  else if (a.act == ACT_DTANH) {
+    const float y = a.aux[(long)row * a.ld_aux + n];
+    v *= (1.f - y * y);
   }
+  a.out[(long)row * a.ld_out + n] = v;
+  if (a.out2) a.out2[(long)row * a.ld_out2 + n] = v;
 }
 
 // ------------------------------------------------------------------ LSTM cell forward (Chainer-sem A1)
@@ -142,29 +130,35 @@ struct CellFwdBatch {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// One workgroup = 16 batch rows x 4 hidden units: the 16 MFMA columns are the 16 consecutive gate rows 4*j0 .. 4*j0+15 of
+// Chainer's interleaved layout, so a cell spreads over (h/4) x (B/16) workgroups and each streams only 16 weight rows.
 __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(CellFwdBatch batch) {
-  constexpr int NT = 4;
-  __shared__ __attribute__((aligned(16))) float red[4 * NT * 256];
+  __shared__ __attribute__((aligned(16))) float red[4 * 256];
+  __shared__ __attribute__((aligned(16))) float zt[256];
   const LstmCellFwdArgs& a = batch.c[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
-  f32x4 acc[NT];
-  zero_acc<NT>(acc);
-  const int jv = min(16, a.h - j0);
-  for (int p = 0; p < a.npairs; ++p) tile_dot<NT>(a.p[p], m0, a.B, WRows{4 * j0, 4, 1}, jv, lane, wave, acc);
-  float z[NT];
-  reduce_waves<NT>(acc, z, red);
-  const int b = m0 + (threadIdx.x >> 4), u = j0 + (threadIdx.x & 15);
+  const int u0 = blockIdx.x * 4, m0 = blockIdx.y * 16;
+  f32x4 acc[1];
+  zero_acc<1>(acc);
+  const int jv = min(16, 4 * (a.h - u0));
+  for (int p = 0; p < a.npairs; ++p) tile_dot<1, 8>(a.p[p], m0, a.B, WRows{4 * u0, 1, 0}, jv, lane, wave, acc);
+  float v[1];
+  reduce_waves<1>(acc, v, red);
+  zt[threadIdx.x] = v[0];                 // zt[row][col], col = 4*unit + gate
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  const int b = m0 + (threadIdx.x >> 2), u = u0 + (threadIdx.x & 3);
   if (b >= a.B || u >= a.h) return;
+  float4 z = *reinterpret_cast<const float4*>(&zt[(threadIdx.x >> 2) * 16 + (threadIdx.x & 3) * 4]);
   if (a.zx) {
     const float4 zx = *reinterpret_cast<const float4*>(a.zx + (long)b * a.ld_zx + 4 * u);
-    z[0] += zx.x; z[1] += zx.y; z[2] += zx.z; z[3] += zx.w;
+    z.x += zx.x; z.y += zx.y; z.z += zx.z; z.w += zx.w;
   }
   if (a.bias) {
     const float4 bb = *reinterpret_cast<const float4*>(a.bias + 4 * u);
-    z[0] += bb.x; z[1] += bb.y; z[2] += bb.z; z[3] += bb.w;
+    z.x += bb.x; z.y += bb.y; z.z += bb.z; z.w += bb.w;
   }
-  const float ga = tanhf(z[0]), gi = sigmoidf_(z[1]), gf = sigmoidf_(z[2]), go = sigmoidf_(z[3]);
+  const float ga = tanhf(z.x), gi = sigmoidf_(z.y), gf = sigmoidf_(z.z), go = sigmoidf_(z.w);
   const float cp = a.c_prev ? a.c_prev[(long)b * a.h + u] : 0.f;
   const float c = ga * gi + gf * cp;
   const float hh = go * tanhf(c);
@@ -193,11 +187,11 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(CellBwdBatch batch) 
   {
     f32x4 one[1];
     one[0] = acc[0];
-    tile_dot<1>(a.p[0], m0, a.B, WRows{j0, 1, 0}, jv, lane, wave, one);
+    tile_dot<1, 16>(a.p[0], m0, a.B, WRows{j0, 1, 0}, jv, lane, wave, one);
     acc[0] = one[0];
     if (a.npairs > 1) {
       one[0] = acc[1];
-      tile_dot<1>(a.p[1], m0, a.B, WRows{j0, 1, 0}, jv, lane, wave, one);
+      tile_dot<1, 16>(a.p[1], m0, a.B, WRows{j0, 1, 0}, jv, lane, wave, one);
       acc[1] = one[0];
     }
   }
@@ -238,7 +232,7 @@ int check_pair(const RowPair& p, const char* who) {
 int rowgemm_launch(const RowGemmArgs& a, hipStream_t s) {
   ASTK_CHECK(a.M > 0 && a.N > 0 && a.out && a.npairs >= 1 && a.npairs <= 2, "rowgemm: bad arguments");
   for (int p = 0; p < a.npairs; ++p) ASTK_TRY(check_pair(a.p[p], "rowgemm"));
-  hipLaunchKernelGGL(rowgemm_kernel, dim3(cdiv(a.N, 64), cdiv(a.M, 16)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(rowgemm_kernel, dim3(cdiv(a.N, 16), cdiv(a.M, 16)), dim3(256), 0, s, a);
   ASTK_LAUNCH_CHECK();
   return 0;
 }
@@ -256,7 +250,7 @@ int lstm_cell_fwd_launch(const LstmCellFwdArgs* cells, int ncells, hipStream_t s
     batch.c[i] = c;
   }
   ProfScope prof(PROF_CELL, s);
-  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv(cells[0].h, 16), cdiv(cells[0].B, 16), ncells), dim3(256), 0, s, batch);
+  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv(cells[0].h, 4), cdiv(cells[0].B, 16), ncells), dim3(256), 0, s, batch);
   ASTK_LAUNCH_CHECK();
   return 0;
 }
