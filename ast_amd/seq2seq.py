@@ -189,7 +189,6 @@ class SpeechEncoderDecoder:
         lib = self._require_gpu()
         if self.arena is None:
             self.materialize(D)
-        assert D == self.in_dim, f"feature dim {D} != materialized {self.in_dim}"
         dev = self.device
         cc = self.cfg["cnn_config"]["cnn_layers"]
         cd = CnnDesc()
@@ -205,6 +204,10 @@ class SpeechEncoderDecoder:
         t2, f2, feat = C.c_int(), C.c_int(), C.c_int()
         check(lib.astk_conv_bn_relu_out_dims(C.byref(cd), C.byref(t2), C.byref(f2), C.byref(feat)))
         T2, feat = t2.value, feat.value
+        rnn_in = self.arena.shapes["L0_enc/upward/W"][1]
+        if feat != rnn_in:
+            raise ValueError(f"feature dim {D} gives {feat} LSTM inputs but the model was built for {rnn_in} "
+                             f"(in_dim {self.in_dim}); the reference's lazily-shaped links fix this at the first batch")
         a = self.arena
         cp = (CnnLayerParams * len(cc))()
         cg = (CnnLayerGrads * len(cc))()

@@ -1,0 +1,172 @@
+"""CPU tests of the host-side mirror of the reference interface: config, bucketing, batch contract, parameter
+layout, checkpoints' shape inference, and that libastk.so loads and exports every symbol include/astk.h declares
+(no compute calls: there is no GPU here)."""
+import ctypes
+import json
+import os
+import pickle
+import random
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIPPED = {"dropout": {"embed": 0.3, "rnn": 0.3, "out": 0},
+           "rnn_config": {"bi_rnn": True, "enc_layers": 3, "dec_layers": 3, "hidden_units": 512, "embedding_units": 128,
+                          "attn_units": 512, "n_attn": 1, "feed_attn": True, "ln": False},
+           "cnn_config": {"bn": True, "cnn_layers": [
+               {"in_channels": None, "out_channels": 128, "ksize": [9, 13], "stride": [2, 13], "pad": [4, 0]},
+               {"in_channels": None, "out_channels": 512, "ksize": [9, 1], "stride": [2, 1], "pad": [4, 0]}]}}
+
+
+def test_library_exports_every_declared_symbol():
+    from ast_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "astk.h")).read()
+    declared = set(re.findall(r"\b(astk_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()                                   # raises if the .so or a symbol is missing
+    for name in declared:
+        assert isinstance(getattr(lib, name), ctypes._CFuncPtr)
+    assert lib.astk_version() >= 100
+
+
+def test_parameter_counts_match_the_reference_model():
+    from ast_amd.params import param_shapes
+    for D, n in ((13, 12333258), (80, 17576138)):       # SURVEY.md 8(a) row a3 / BASELINE.md
+        train, persist = param_shapes(SHIPPED, D, 1098)
+        assert sum(int(np.prod(s)) for s in train.values()) == n
+        assert set(persist) == {f"CNN_{i}_bn/{s}" for i in (0, 1) for s in ("avg_mean", "avg_var")}
+    train, _ = param_shapes(SHIPPED, 80, 1098)
+    assert train["L0_enc/upward/W"] == (1024, 3072) and train["L0_dec/upward/W"] == (2048, 640)
+    assert train["context/W"] == (512, 1024) and train["embed_dec/W"] == (1098, 128)
+
+
+def test_initialisers_follow_A9():
+    from ast_amd.params import init_values
+    cfg = json.loads(json.dumps(SHIPPED))
+    cfg["rnn_config"].update(hidden_units=64, attn_units=32, embedding_units=16)
+    v = init_values(cfg, 13, 50, seed=1)
+    b = v["L1_rev_enc/upward/b"]
+    assert (b[2::4] == 1).all() and b.sum() == b[2::4].sum()
+    assert abs(v["CNN_1/W"].std() - np.sqrt(2.0 / (128 * 9))) < 0.1 * np.sqrt(2.0 / (128 * 9))
+    assert abs(v["embed_dec/W"].std() - 1.0) < 0.1
+    assert (v["CNN_0_bn/gamma"] == 1).all() and (v["CNN_0_bn/avg_var"] == 1).all() and (v["CNN_0_bn/avg_mean"] == 0).all()
+
+
+def test_arena_layout_is_16_byte_aligned_and_flat():
+    import torch
+    from ast_amd.params import ParamArena
+    a = ParamArena({"a/W": (3, 5), "a/b": (7,), "c/W": (2, 2)}, torch.device("cpu"))
+    assert [a.offsets[k] for k in ("a/W", "a/b", "c/W")] == [0, 16, 24] and a.size == 28
+    a.views["a/b"].fill_(2.0)
+    assert float(a.data.sum()) == 14.0 and a.data[16:23].eq(2).all() and a.data[23] == 0
+    assert a.range_of("a/W") == (0, 16)
+
+
+def test_bucketing_matches_prep_buckets():
+    from ast_amd import prep_buckets
+    info = {"fisher_train": {f"u{i}": {"sp": t} for i, t in enumerate([27, 79, 80, 159, 160, 1599, 1600, 2566])},
+            "fisher_dev": {"d0": {"sp": 300}}}
+    out = prep_buckets.buckets_from_info(info, 20, 80)
+    b = out["fisher_train"]["buckets"]
+    assert b[0] == ["u0", "u1"] and b[1] == ["u2", "u3"] and b[2] == ["u4"] and b[19] == ["u5", "u6", "u7"]
+    assert out["fisher_dev"]["buckets"][3] == ["d0"] and out["fisher_train"]["width_b"] == 80
+    # train_scale > 1 subsamples train sets only, with the fixed seed
+    big = {"x_train": {f"u{i}": {"sp": 10} for i in range(10)}, "dev": {f"d{i}": {"sp": 10} for i in range(10)}}
+    o2 = prep_buckets.buckets_from_info(big, 2, 80, scale=2)
+    assert len(o2["x_train"]["buckets"][0]) == 5 and len(o2["dev"]["buckets"][0]) == 10
+    assert o2 == prep_buckets.buckets_from_info(big, 2, 80, scale=2)
+
+
+def _synth_cfg(tmp_path, n_train=37):
+    data = {"dataloader": "synthetic", "vocab_size": 31, "feat_dim": 13, "n_utts": {"syn_train": n_train, "syn_dev": 5},
+            "frames": [20, 400], "targets": [1, 30], "buckets_num": 4, "buckets_width": 80, "max_pred": 12,
+            "zero_input": 0.1, "train_scale": 1, "dec_key": "bpe_w"}
+    return data
+
+
+def test_batch_contract(tmp_path):
+    from ast_amd.dataloader import SYMBOLS, SyntheticDataLoader
+    data = _synth_cfg(tmp_path)
+    dl = SyntheticDataLoader(data, str(tmp_path), -1)
+    assert dl.n_utts == {"syn_train": 37, "syn_dev": 5}
+    random.seed("seed-ast-20h")
+    plan1 = dl.batch_plan(8, "syn_train")
+    random.seed("seed-ast-20h")
+    dl2 = SyntheticDataLoader(data, str(tmp_path), -1)
+    assert [u for u, _ in dl2.batch_plan(8, "syn_train")] == [u for u, _ in plan1]      # seeded stream => same plan
+    random.seed(1)
+    seen = []
+    for batch in dl.get_batch(8, "syn_train", train=True, labels=True):
+        X, y = batch["X"], batch["y"]
+        assert X.dtype.is_floating_point and X.shape[2] == 13 and y.dtype == __import__("torch").int32
+        assert X.shape[0] == y.shape[0] == len(batch["utts"]) <= 8
+        assert X.shape[1] <= (4 + 1) * 80                          # hard truncation (dataloader.py:118)
+        widths = {min(dl.info["syn_train"][u]["sp"] // 80, 3) for u in batch["utts"]}
+        assert len(widths) == 1                                    # one bucket per batch
+        yn = y.numpy()
+        assert (yn[:, 0] == SYMBOLS.GO_ID).all() and y.shape[1] <= 12
+        for row in yn:
+            n = int((row != 0).sum())
+            assert row[n - 1] == SYMBOLS.EOS_ID and (row[n:] == SYMBOLS.PAD_ID).all()
+        for i, u in enumerate(batch["utts"]):                      # zero padding beyond each utterance
+            t = min(dl.info["syn_train"][u]["sp"], 400)
+            assert float(X[i, t:].abs().sum()) == 0.0
+            zero_rows = int((X[i, :t].abs().sum(dim=1) == 0).sum())
+            assert zero_rows <= int(0.1 * t)                       # frame zeroing, with replacement
+        seen += batch["utts"]
+    assert sorted(seen) == sorted(dl.info["syn_train"])
+    dev = next(dl.get_batch(8, "syn_dev", train=False, labels=False))
+    assert "y" not in dev
+
+
+def test_data_parallel_sharding_of_batches(tmp_path):
+    from ast_amd.dataloader import SyntheticDataLoader
+    data = _synth_cfg(tmp_path, n_train=64)
+    shards = []
+    for r in range(2):
+        dl = SyntheticDataLoader(data, str(tmp_path), -1)
+        dl.rank, dl.world = r, 2
+        random.seed("seed-ast-20h")
+        shards.append([b["utts"] for b in dl.get_batch(8, "syn_train", train=True, labels=True)])
+    flat0, flat1 = sum(shards[0], []), sum(shards[1], [])
+    assert not set(flat0) & set(flat1) and len(flat0) + len(flat1) == 64
+
+
+def test_config_injects_vocab_size(tmp_path):
+    from ast_amd.config import Config
+    vocab = {"bpe_w": {"w2i": {bytes([i]): i for i in range(57)}, "i2w": {}, "freq": {}}}
+    vp = tmp_path / "v.vocab"
+    pickle.dump(vocab, open(vp, "wb"))
+    json.dump(SHIPPED, open(tmp_path / "model_cfg.json", "w"))
+    json.dump({"seed": "s", "gpuid": 0, "data": {"vocab_path": str(vp), "dec_key": "bpe_w"}}, open(tmp_path / "train_cfg.json", "w"))
+    c = Config(str(tmp_path))
+    assert c.model["rnn_config"]["dec_vocab_size"] == 57 and c.model["model_dir"] == str(tmp_path)
+
+
+def test_checkpoint_shape_inference():
+    from ast_amd.serializers import infer_in_dim
+    assert infer_in_dim(SHIPPED, 3072) == 80 - 2 and infer_in_dim(SHIPPED, 512) == 13
+    # (80-d input: F' = 6 bins cover 78 of the 80 dims -- the last 2 never reach the conv, seq2seq.py:52 / SURVEY 0)
+
+
+def test_model_rejects_configs_outside_the_hot_path():
+    from ast_amd.seq2seq import SpeechEncoderDecoder
+    bad = json.loads(json.dumps(SHIPPED))
+    bad["rnn_config"]["ln"] = True
+    with pytest.raises(NotImplementedError):
+        SpeechEncoderDecoder(-1, bad)
+
+
+def test_compute_path_fails_loudly_without_gpu():
+    import torch
+    from ast_amd.seq2seq import SpeechEncoderDecoder
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cfg = json.loads(json.dumps(SHIPPED))
+    cfg["rnn_config"]["dec_vocab_size"] = 20
+    m = SpeechEncoderDecoder(-1, cfg)
+    with pytest.raises(RuntimeError):
+        m.forward_loss(np.zeros((1, 20, 13), np.float32), np.array([[1, 2]], np.int32), 1.0)
