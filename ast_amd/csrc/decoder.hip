@@ -12,6 +12,26 @@
 
 namespace astk {
 
+// persistent decoder loop (decoder_persist.hip)
+struct DecPersistBuffers {
+  int32_t *TOK, *PRED;
+  float *X0, *G, *C, *HR, *Q, *ALPHA, *CVH, *HT, *LOGITS, *LOSSROWS;
+  float *LSE, *PART, *CESTAT, *ENCA;
+  unsigned* ctr;
+};
+bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int* chunk_out);
+int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_params* prm, const float* enc, const int32_t* y,
+                               const int32_t* use_truth, const float* emb_mask, const float* rnn_masks, const DecPersistBuffers& bf,
+                               hipStream_t s);
+
+struct DecPersistBwdBuffers {
+  const float *WoT, *WcT, *WlT, *WuT, *ENCA, *ALPHA, *CVH, *HT, *LOGITS, *C;
+  float *G, *DPRE, *DCVH, *DS, *DX0, *DHATT, *d_c0;
+  unsigned* ctr;
+};
+int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, const float* rnn_masks, const DecPersistBwdBuffers& bf,
+                               hipStream_t s);
+
 namespace {
 
 struct DecPlan {
@@ -43,6 +63,8 @@ struct DecPlan {
   float* WuT[ASTK_MAX_RNN_LAYERS];  // [in][4H]
   float* WlT[ASTK_MAX_RNN_LAYERS];  // [H][4H]
   float* ZERO;   // [B][max(A,H)] zeros
+  float *LSE, *PART, *CESTAT, *ENCA;       // persistent path only
+  unsigned* PCTR;
   void* attn_ws;
   size_t bytes;
 };
@@ -86,6 +108,15 @@ int make_plan(const astk_decoder_desc* d, void* ws, DecPlan& P) {
   P.WaT = c.take<float>(H * H);
   P.ZERO = c.take<float>(B * (size_t)(P.A > P.H ? P.A : P.H));
   P.attn_ws = c.take<char>(attn_ws_bytes(P.B, P.T, P.H));
+  {
+    int ns = 1, ch = 1;
+    const bool pp = decoder_persist_applicable(d, &ns, &ch);
+    P.LSE = c.take<float>(pp ? S * B : 4);
+    P.PART = c.take<float>(pp ? S * B * ns * (H + 4) : 4);
+    P.CESTAT = c.take<float>(pp ? S * B * (size_t)((P.V + 15) / 16) * 4 : 4);
+    P.ENCA = c.take<float>(pp ? B * (size_t)P.T * H : 4);
+    P.PCTR = c.take<unsigned>(pp ? (size_t)(8 * ((P.B + 15) / 16) + 2) * 64 : 4);
+  }
   P.bytes = c.total();
   return 0;
 }
@@ -276,6 +307,23 @@ int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
   ASTK_TRY(fill_zero(P.X0, (size_t)B * XI * sizeof(float), s));   // ht_{-1} half of the first concat buffer
   ASTK_TRY(attn_ws_init(P.attn_ws, B, P.T, H, s));
   const int top = nl - 1;
+  {
+    int ns = 1, ch = 1;
+    if (decoder_persist_applicable(d, &ns, &ch)) {
+      DecPersistBuffers bf;
+      bf.TOK = P.TOK; bf.PRED = P.PRED; bf.X0 = P.X0; bf.G = P.G[0]; bf.C = P.C[0]; bf.HR = P.HR[0]; bf.Q = P.Q; bf.ALPHA = P.ALPHA;
+      bf.CVH = P.CVH; bf.HT = P.HT; bf.LOGITS = P.LOGITS; bf.LOSSROWS = P.LOSSROWS; bf.LSE = P.LSE; bf.PART = P.PART;
+      bf.CESTAT = P.CESTAT; bf.ENCA = P.ENCA; bf.ctr = P.PCTR;
+      ASTK_TRY(decoder_persist_fwd_launch(d, prm, enc, y, use_truth, emb_mask, rnn_masks, bf, s));
+      hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, s, P.LOSSROWS, S * B, loss);
+      ASTK_LAUNCH_CHECK();
+      if (pred) {
+        hipLaunchKernelGGL(k_copy_i32, dim3(cdiv(S * B, 256)), dim3(256), 0, s, pred, P.PRED, S * B);
+        ASTK_LAUNCH_CHECK();
+      }
+      return 0;
+    }
+  }
   for (int st = 0; st < S; ++st) {
     float* x0 = P.X0 + (size_t)st * B * XI;
     hipLaunchKernelGGL(k_embed, dim3(B), dim3(128), 0, s, prm->embed, y, P.L, st, use_truth, st > 0 ? P.PRED + (size_t)(st - 1) * B : nullptr,
@@ -353,7 +401,20 @@ int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
   }
   ASTK_TRY(fill_zero(P.ZERO, (size_t)B * (A > H ? A : H) * sizeof(float), s));
   ASTK_TRY(attn_ws_init(P.attn_ws, B, T, H, s));
-  for (int st = S - 1; st >= 0; --st) {
+  int ns_ = 1, ch_ = 1;
+  const bool persist = decoder_persist_applicable(d, &ns_, &ch_);
+  if (persist) {
+    DecPersistBwdBuffers bf;
+    bf.WoT = P.WoT; bf.WcT = P.WcT; bf.WlT = P.WlT[0]; bf.WuT = P.WuT[0]; bf.ENCA = P.ENCA; bf.ALPHA = P.ALPHA; bf.CVH = P.CVH;
+    bf.HT = P.HT; bf.LOGITS = P.LOGITS; bf.C = P.C[0]; bf.G = P.G[0]; bf.DPRE = P.DPRE; bf.DCVH = P.DCVH; bf.DS = P.DS; bf.DX0 = P.DX0;
+    bf.DHATT = P.PART; bf.d_c0 = d_c0; bf.ctr = P.PCTR;
+    ASTK_TRY(decoder_persist_bwd_launch(d, enc, rnn_masks, bf, s));
+    // dq[s][b][:] = sum_t ds[s][b][t] enc[b][t][:]  (batched over b) -- only the weight gradients of attn_Wa need it
+    GemmArgs gq = gemm_args(S, H, T, mat(P.DS, (long)B * Tp), mat(enc, H), P.DQ, (long)B * H);
+    gq.batch = B; gq.sA = Tp; gq.sB = (long)T * H; gq.sC = H;
+    ASTK_TRY(gemm_launch(GEMM_NN, gq, s));
+  }
+  for (int st = S - 1; st >= 0 && !persist; --st) {
     const bool last = st == S - 1;
     float* dl = P.LOGITS + (size_t)st * B * Vp;
     float* dpre = P.DPRE + (size_t)st * B * A;
@@ -409,7 +470,7 @@ int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
   // ---- gradients wrt the initial states (flow into the encoder's final states, seq2seq.py:326-329)
   for (int l = 0; l < nl; ++l) {
     ASTK_TRY(rowgemm_launch(rg(B, H, P.G[l], 4 * H, P.WlT[l], 4 * H, 4 * H, d_h0 + l * bh, H), s));
-    ASTK_TRY(copy_f32(d_c0 + l * bh, P.DC[l][0], bh, s));
+    if (!persist) ASTK_TRY(copy_f32(d_c0 + l * bh, P.DC[l][0], bh, s));
   }
   // ---- weight gradients: one batched TN GEMM each over the S*B saved rows
   const int SB = S * B;

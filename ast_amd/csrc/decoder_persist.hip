@@ -1,0 +1,981 @@
+// Persistent decoder-loop kernels (seq2seq.py:361-473): ONE launch runs all S = L-1 decoder steps.
+//
+// Why: a decoder step is ~9 tiny dependent kernels (M = batch rows); at ~4.4 us per launch the loop is launch-floor
+// bound and the attention scan can never exceed ~3 TB/s.  Here every phase of a step is a set of fixed "items"
+// owned by fixed workgroups for the whole loop:
+//   * the weight slice of an item lives in VGPRs as f32-MFMA B fragments (all decoder weights = 14.6 MB = 57 KB per
+//     workgroup), loaded once;
+//   * each attention item keeps its (batch row, time chunk) slice of enc_states in LDS for all steps, so after the
+//     first step the attention scan moves no global memory at all;
+//   * phases hand activations over with the same protocol as lstm_persist.hip (write-through stores, drained, one
+//     arrival add per item on a per-(phase, batch-tile) counter that lives on its own 256-byte line; consumers poll
+//     with one lane, barrier, then sc1 loads).  The decoder has no cross-batch-row dependency, so a consumer only
+//     waits for the producers of ITS 16 batch rows.
+// Forward phases per step (critical chain P1 -> P2 -> P3 -> P3b -> P4 -> next P1; P5/P6 only gate the next step when
+// it is not teacher-forced):
+//   P1 embed + LSTM cell (16 rows x 8 units)      P2 q = Wa h + ba        P3 attention partial (b, chunk)
+//   P3b attention combine per b (cv, alpha)       P4 ht = tanh(Wc[cv;h]+bc)   P5 logits tile + per-tile CE stats
+//   P6 CE combine per batch tile: lse, loss row, argmax (feedback token)
+// The saved-state layout is exactly decoder.hip's DecPlan, so either backward works on it.
+// Applicability (else the per-launch path of decoder.hip runs): 1 decoder layer, H,A multiples of 16, sizes within the
+// register budgets below, grid of 256 workgroups fully resident.  All spins are bounded (abort word).
+#include "common.h"
+
+namespace astk {
+
+namespace {
+
+constexpr int CTRS = 64;          // counter stride in words (256 B)
+constexpr int G = 256;            // workgroups (one per CU)
+enum Phase { PH_CELL = 0, PH_Q, PH_ATT, PH_CMB, PH_CTX, PH_LOG, PH_CE, PH_N };
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct PDecArgs {
+  int B, S, L, T, Tp, H, E, A, V, Vp, XI, nbt, nsplit, chunk, ntile_v;
+  const float *embed, *Wu, *bias, *Wl, *Wa, *ba, *Wc, *bc, *Wo, *bo, *cw;
+  const float* enc;
+  const float* encA;       // enc . Wa  (B,T,H): score = encA.h + enc.ba
+  const int32_t* y;
+  const int32_t* use_truth;
+  const float* emb_mask;   // [S][B][E] or null
+  const float* rnn_mask;   // [S][B][H] or null
+  int32_t* TOK; int32_t* PRED;
+  float *X0, *Gt, *Cst, *HR, *Q, *ALPHA, *CVH, *HT, *LOGITS, *LOSSROWS, *LSE;
+  float* PART;             // [S][B][nsplit][H+4]
+  float* CESTAT;           // [S][B][ntile_v][4]
+  unsigned* ctr;           // [PH_N][nbt] * CTRS
+  unsigned* abort_word;
+  int dbg;
+};
+
+__device__ __forceinline__ unsigned ld_flag(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sti_sc1(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ldi_sc1(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 ldb128_sc1(__amdgpu_buffer_rsrc_t r, long float_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_off * 4), 0, 16);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ bool wait_ge(const unsigned* ctr, unsigned target, unsigned* abort_word) {
+  unsigned spins = 0;
+  while (ld_flag(ctr) < target) {
+    if ((++spins & 63u) == 0) {
+      if (ld_flag(abort_word) != 0) return false;
+      if (spins > (1u << 22)) {
+        __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+  return true;
+}
+// workgroup-wide wait: lane 0 polls, everyone learns the outcome
+__device__ __forceinline__ bool wg_wait(const unsigned* ctr, unsigned target, unsigned* abort_word, int* s_flag) {
+  if (threadIdx.x == 0) *s_flag = wait_ge(ctr, target, abort_word) ? 1 : 0;
+  __syncthreads();
+  const bool ok = *s_flag != 0;
+  __syncthreads();            // s_flag may be rewritten by the next wait
+  return ok;
+}
+__device__ __forceinline__ void publish(unsigned* ctr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Resident weight fragments (NB k-blocks of 16 floats per wave): MFMA column j = lane&15 -> W row `row`.
+template <int NB>
+__device__ __forceinline__ void wload(float4* w, const float* W, long ldw, int row, int K, int lane, int wave) {
+  const int q = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int k = 16 * (wave + 4 * i) + 4 * q;
+    w[i] = k < K ? *reinterpret_cast<const float4*>(W + (long)row * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+// acc += A[arow][0:K] . W^T : A read with sc1 loads through `ra` at float offset a_off (+k)
+template <int NB>
+__device__ __forceinline__ void wmac(f32x4& acc, const float4* w, __amdgpu_buffer_rsrc_t ra, long a_off, int K, int lane, int wave) {
+  const int q = lane >> 4;
+  float4 a[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int k = min(16 * (wave + 4 * i) + 4 * q, K - 4);       // clamped: the matching w[i] is zero beyond K
+    a[i] = ldb128_sc1(ra, a_off + k);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, w[i].x, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, w[i].y, acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, w[i].z, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, w[i].w, acc2, 0, 0, 0);
+  }
+  acc += acc2;
+}
+
+// 4-wave reduction of one 16x16 accumulator: returns element (row = tid>>4, col = tid&15)
+__device__ __forceinline__ float reduce16(f32x4 acc, float* red /* [4][256] */) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  *reinterpret_cast<f32x4*>(&red[(wave * 64 + lane) * 4]) = acc;
+  __syncthreads();
+  const int row = tid >> 4, col = tid & 15;
+  const int src = ((row >> 2) * 16 + col) * 4 + (row & 3);
+  const float v = red[src] + red[256 + src] + red[512 + src] + red[768 + src];
+  __syncthreads();
+  return v;
+}
+
+// Register budgets (k-blocks of 16 per wave): cell emb-part E <= 128, ht-part A <= 512, h-part H <= 512; ctx 2H <= 1024;
+// logits A <= 512.  A workgroup is either a cell owner or a ctx/logits owner, so both roles share one register array:
+// cell = 2 tiles x (we[2] + wa[8] + wh[8]) = 36 float4 ; other = wc[16] + wl[2][8] = 32 float4.
+constexpr int NB_E = 2, NB_A = 8, NB_H = 8, NB_C = 16, NB_L = 8;
+constexpr int CELLW = NB_E + NB_A + NB_H;            // per gate tile
+constexpr int OFF_WC = 0, OFF_WL = NB_C, NWREG = 2 * CELLW;
+static_assert(OFF_WL + 2 * NB_L <= NWREG, "register budget");
+
+template <int NB>
+__device__ __forceinline__ void mfma_blocks(f32x4& acc, const float4* a, const float4* w) {
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, w[i].x, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, w[i].y, acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, w[i].z, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, w[i].w, acc2, 0, 0, 0);
+  }
+  acc += acc2;
+}
+// A fragments of a handed-off row block: sc1 16-byte loads at float offset a_off + k, k clamped (matching w is zero beyond K)
+template <int NB>
+__device__ __forceinline__ void aload_sc1(float4* a, __amdgpu_buffer_rsrc_t ra, long a_off, int K, int lane, int wave) {
+  const int q = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) a[i] = ldb128_sc1(ra, a_off + min(16 * (wave + 4 * i) + 4 * q, K - 4));
+}
+
+__global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // enc slice [chunk][H], encA slice [chunk][H], scratch
+  __shared__ __attribute__((aligned(16))) float red[4 * 256];
+  __shared__ __attribute__((aligned(16))) float zt[2 * 256];
+  __shared__ int s_flag;
+  __shared__ int yS[16 * 192];         // targets of this workgroup's batch tile (L <= 192)
+  __shared__ int flagS[192];           // teacher-forcing flags
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wg = blockIdx.x;
+  const int B = a.B, S = a.S, H = a.H, E = a.E, A = a.A, V = a.V, XI = a.XI, T = a.T, Tp = a.Tp;
+  const int nbt = a.nbt;
+  unsigned* ctr = a.ctr;
+#define CTR(ph, bt) (ctr + ((ph) * nbt + (bt)) * CTRS)
+
+  // ---------------- static item ownership
+  const int n_cell = nbt * (H / 8);                       // cell items (bt, 8 units): workgroups [0, n_cell)
+  const bool has_cell = wg < n_cell;
+  const int cell_bt = has_cell ? wg / (H / 8) : 0, cell_u0 = has_cell ? (wg % (H / 8)) * 8 : 0;
+  const int n_c = nbt * (A / 16);                         // ctx items: first non-cell workgroups
+  const int rest = G - n_cell;
+  const int r_idx = wg - n_cell;
+  const bool has_c = r_idx >= 0 && r_idx < n_c;
+  const int c_bt = has_c ? r_idx / (A / 16) : 0, c_n0 = has_c ? (r_idx % (A / 16)) * 16 : 0;
+  const int n_l = nbt * a.ntile_v;                        // logits items: up to 2 per non-cell workgroup
+  int l_item[2] = {-1, -1};
+  if (r_idx >= 0) {
+    if (r_idx < n_l) l_item[0] = r_idx;
+    if (r_idx + rest < n_l) l_item[1] = r_idx + rest;
+  }
+  const int n_att = B * a.nsplit;                         // attention items (b, split): one per workgroup
+  const bool has_att = wg < n_att;
+  const int att_b = has_att ? wg % B : 0, att_sp = has_att ? wg / B : 0;
+  const int cmb_rank = wg - (G - B);                      // combine items (b): the last B workgroups
+  const bool has_cmb = cmb_rank >= 0 && cmb_rank < B;
+  const int cmb_b = has_cmb ? cmb_rank : 0;
+  const int ce_rank = wg - (G - B - nbt);                 // CE items (bt)
+  const bool has_ce = ce_rank >= 0 && ce_rank < nbt;
+
+  // ---------------- resident weights
+  float4 wreg[NWREG];
+#pragma unroll
+  for (int i = 0; i < NWREG; ++i) wreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int r16 = lane & 15;
+  if (has_cell) {   // two 16-row gate tiles (units u0..u0+3, u0+4..u0+7): [emb cols | ht cols] of Wu, then Wl
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = 4 * cell_u0 + 16 * t + r16;
+      wload<NB_E>(wreg + t * CELLW, a.Wu + (long)row * XI, 0, 0, E, lane, wave);
+      wload<NB_A>(wreg + t * CELLW + NB_E, a.Wu + (long)row * XI + E, 0, 0, A, lane, wave);
+      wload<NB_H>(wreg + t * CELLW + NB_E + NB_A, a.Wl + (long)row * H, 0, 0, H, lane, wave);
+    }
+  } else {
+    if (has_c) wload<NB_C>(wreg + OFF_WC, a.Wc, 2 * H, c_n0 + r16, 2 * H, lane, wave);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (l_item[t] >= 0) {
+        const int n0 = (l_item[t] % a.ntile_v) * 16;
+        wload<NB_L>(wreg + OFF_WL + t * NB_L, a.Wo, A, min(n0 + r16, V - 1), A, lane, wave);
+      }
+  }
+  if (has_cell) {
+    for (int i = tid; i < 16 * a.L; i += 256) yS[i] = a.y[(long)min(cell_bt * 16 + i / a.L, B - 1) * a.L + (i % a.L)];
+    for (int i = tid; i < S; i += 256) flagS[i] = a.use_truth[i];
+  }
+  // ---------------- resident slices of enc_states and encA = enc Wa in LDS: rows [t0, t1) of batch row att_b
+  const int t0 = att_sp * a.chunk, t1 = min(T, t0 + a.chunk);
+  const int nrow = has_att ? t1 - t0 : 0;
+  float* encS = lds;
+  float* encAS = lds + a.chunk * H;
+  float* ebS = lds + 2 * a.chunk * H;            // [chunk] enc.ba, computed once
+  float* scr = ebS + ((a.chunk + 3) & ~3);       // per-step scratch: hS[H] | score[chunk] | p[chunk]  -- or the combine's partial rows
+  if (has_att) {
+    const float* src = a.enc + ((long)att_b * T + t0) * H;
+    const float* srcA = a.encA + ((long)att_b * T + t0) * H;
+    const int n4 = nrow * H / 4;
+    for (int i = tid; i < n4; i += 256) {
+      reinterpret_cast<float4*>(encS)[i] = reinterpret_cast<const float4*>(src)[i];
+      reinterpret_cast<float4*>(encAS)[i] = reinterpret_cast<const float4*>(srcA)[i];
+    }
+    __syncthreads();
+    for (int t = tid; t < nrow; t += 256) {       // eb[t] = enc[t,:] . ba  (score = encA.h + eb)
+      float d = 0.f;
+      for (int k = 0; k < H; ++k) d += encS[t * H + k] * a.ba[k];
+      ebS[t] = d;
+    }
+  }
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t r_x0 = make_rsrc(a.X0), r_hr = make_rsrc(a.HR), r_cvh = make_rsrc(a.CVH), r_ht = make_rsrc(a.HT);
+  const __amdgpu_buffer_rsrc_t r_part = make_rsrc(a.PART), r_ces = make_rsrc(a.CESTAT);
+  // cell epilogue ownership: threads 0..127: tile = tid>>6, (row = (tid>>2)&15, unit = tid&3)
+  const int ce_tile = tid >> 6, ce_row = (tid >> 2) & 15, ce_u = tid & 3;
+  const int cell_b = cell_bt * 16 + ce_row, cell_u = cell_u0 + 4 * ce_tile + ce_u;
+  float c_state = 0.f;
+  if (has_cell && tid < 128 && cell_b < B) c_state = a.Cst[(long)cell_b * H + cell_u];   // C[0] = c0
+  float4 cbias = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (has_cell && tid < 128) cbias = *reinterpret_cast<const float4*>(a.bias + 4 * cell_u);
+
+  long long tk[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tk[i] = 0;
+  const bool timing = a.dbg != 0;
+  long long tlast = timing ? wall_clock64() : 0;
+#define TICK(i) if (timing) { const long long now_ = wall_clock64(); tk[i] += now_ - tlast; tlast = now_; }
+  for (int s = 0; s < S; ++s) {
+    // ================= P1: embed + LSTM cell =================
+    if (has_cell) {
+      const int bt = cell_bt, m0 = bt * 16;
+      const int brow = min(m0 + r16, B - 1);             // this lane's A-operand batch row
+      const bool truth = s == 0 || flagS[s] != 0;
+      if (!truth) { if (!wg_wait(CTR(PH_CE, bt), (unsigned)s, a.abort_word, &s_flag)) return; }
+      int tok = truth ? yS[r16 * a.L + s] : ldi_sc1(a.PRED + (long)(s - 1) * B + brow);
+      tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+      TICK(15)
+      if (s > 0) { if (!wg_wait(CTR(PH_CELL, bt), (unsigned)((H / 8) * s), a.abort_word, &s_flag)) return; }
+      TICK(13)
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      {
+        // (a) embedding part and (b) recurrent part: neither depends on this step's ht, so they run before the wait on P4
+        const int q = lane >> 4;
+        float4 ae[NB_E], ah[NB_H];
+#pragma unroll
+        for (int i = 0; i < NB_E; ++i) {
+          const int k = min(16 * (wave + 4 * i) + 4 * q, E - 4);
+          float4 v = *reinterpret_cast<const float4*>(a.embed + (long)tok * E + k);
+          if (a.emb_mask) {
+            const float4 mk = *reinterpret_cast<const float4*>(a.emb_mask + ((long)s * B + brow) * E + k);
+            v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
+          }
+          ae[i] = v;
+        }
+        aload_sc1<NB_H>(ah, r_hr, ((long)s * B + brow) * H, H, lane, wave);     // h_{s-1}: published a whole step ago (waited above)
+        __builtin_amdgcn_sched_barrier(0);
+        if (timing) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TICK(14) }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          mfma_blocks<NB_E>(acc[t], ae, wreg + t * CELLW);
+          mfma_blocks<NB_H>(acc[t], ah, wreg + t * CELLW + NB_E + NB_A);
+        }
+      }
+      TICK(0)
+      // (c) input-feeding part: ht_{s-1}, written into X0[s][:, E:] by P4 of step s-1
+      if (s > 0) {
+        if (!wg_wait(CTR(PH_CTX, bt), (unsigned)((A / 16) * s), a.abort_word, &s_flag)) return;
+        TICK(1)
+        float4 at[NB_A];
+        aload_sc1<NB_A>(at, r_x0, ((long)s * B + brow) * XI + E, A, lane, wave);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_blocks<NB_A>(acc[0], at, wreg + NB_E);
+        mfma_blocks<NB_A>(acc[1], at, wreg + CELLW + NB_E);
+      }
+      const float z0 = reduce16(acc[0], red);
+      const float z1 = reduce16(acc[1], red);
+      zt[tid] = z0;
+      zt[256 + tid] = z1;
+      __syncthreads();
+      float4 gsave = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ev = tid < 128 && cell_b < B;
+      if (ev) {
+        const float4 z = *reinterpret_cast<const float4*>(&zt[ce_tile * 256 + ce_row * 16 + ce_u * 4]);
+        const float ga = tanhf(z.x + cbias.x), gi = sigm(z.y + cbias.y), gf = sigm(z.z + cbias.z), go = sigm(z.w + cbias.w);
+        c_state = ga * gi + gf * c_state;
+        const float hh = go * tanhf(c_state);
+        const float hd = a.rnn_mask ? hh * a.rnn_mask[((long)s * B + cell_b) * H + cell_u] : hh;
+        gsave = make_float4(ga, gi, gf, go);
+        st_sc1(a.HR + ((long)(s + 1) * B + cell_b) * H + cell_u, hh);
+        st_sc1(a.CVH + ((long)s * B + cell_b) * 2 * H + H + cell_u, hd);
+      }
+      TICK(2)
+      publish(CTR(PH_CELL, bt));
+      TICK(3)
+      if (ev) {                                    // saved for the backward (plain stores, off the critical path)
+        *reinterpret_cast<float4*>(a.Gt + ((long)s * B + cell_b) * 4 * H + 4 * cell_u) = gsave;
+        a.Cst[((long)(s + 1) * B + cell_b) * H + cell_u] = c_state;
+      }
+    }
+    // ================= P3: attention over the LDS-resident slices: score = encA.h + eb, p = exp(score - max), cv partial =========
+    if (has_att) {
+      const int b = att_b, bt = b / 16;
+      TICK(15)
+      if (!wg_wait(CTR(PH_CELL, bt), (unsigned)((H / 8) * (s + 1)), a.abort_word, &s_flag)) return;
+      TICK(4)
+      float* hS = scr;                 // [H]
+      float* scS = scr + H;            // [chunk] raw scores
+      float* pS = scr + H + a.chunk;   // [chunk] exp(score - m)
+      if (tid < H / 4) *reinterpret_cast<float4*>(hS + 4 * tid) = ldb128_sc1(r_cvh, ((long)s * B + b) * 2 * H + H + 4 * tid);
+      __syncthreads();
+      TICK(13)
+      {
+        // pass 1: 16 lanes per row, two rows per trip; lane l covers floats 4l + 64c (conflict-free LDS reads)
+        const int grp = tid >> 4, l16 = tid & 15;
+        for (int t = grp; t < nrow; t += 32) {
+          const int t2 = t + 16;
+          const bool two = t2 < nrow;
+          const float* e1 = encAS + t * H + 4 * l16;
+          const float* e2 = encAS + (two ? t2 : t) * H + 4 * l16;
+          float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            if (64 * c < H) {                                     // wave-uniform: H is a multiple of 64, <= 1024
+              const float4 hv = *reinterpret_cast<const float4*>(hS + 64 * c + 4 * l16);
+              const float4 x1 = *reinterpret_cast<const float4*>(e1 + 64 * c);
+              const float4 x2 = *reinterpret_cast<const float4*>(e2 + 64 * c);
+              d1 += x1.x * hv.x + x1.y * hv.y + x1.z * hv.z + x1.w * hv.w;
+              d2 += x2.x * hv.x + x2.y * hv.y + x2.z * hv.z + x2.w * hv.w;
+            }
+          }
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
+          if (l16 == 0) {
+            scS[t] = d1 + ebS[t];
+            if (two) scS[t2] = d2 + ebS[t2];
+          }
+        }
+      }
+      __syncthreads();
+      // chunk max / exp / sum with register reductions: thread t owns row t (nrow <= 256)
+      float* wred = pS + a.chunk;          // [8] wave partials (inside the scratch's 16-float tail)
+      const float sv = tid < nrow ? scS[tid] : -INFINITY;
+      float wm = sv;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+      if (lane == 0) wred[wave] = wm;
+      __syncthreads();
+      const float m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+      const float pv = tid < nrow ? expf(sv - m) : 0.f;
+      if (tid < nrow) {
+        pS[tid] = pv;
+        st_sc1(a.ALPHA + ((long)s * B + b) * Tp + t0 + tid, sv);     // raw score; P3b normalises
+      }
+      float ws = wave_sum(pv);
+      if (lane == 0) wred[4 + wave] = ws;
+      __syncthreads();
+      const float l = wred[4] + wred[5] + wred[6] + wred[7];
+      TICK(14)
+      float* prow = a.PART + (((long)s * B + b) * a.nsplit + att_sp) * (H + 4);
+      {
+        // pass 2: context partial; thread owns columns tid + 256 j (consecutive threads -> consecutive LDS words)
+        float cvp[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < nrow; ++t) {
+          const float pt = pS[t];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (256 * j < H) cvp[j] += pt * encS[t * H + min(tid + 256 * j, H - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (tid + 256 * j < H) st_sc1(&prow[4 + tid + 256 * j], cvp[j]);
+      }
+      if (tid == 0) { st_sc1(&prow[0], m); st_sc1(&prow[1], l); }
+      publish(CTR(PH_ATT, bt));
+      TICK(5)
+    }
+    // ================= P3b: combine the nsplit partials of one batch row =================
+    if (has_cmb) {
+      const int b = cmb_b, bt = b / 16;
+      const int rows_bt = min(16, B - bt * 16);
+      TICK(15)
+      if (!wg_wait(CTR(PH_ATT, bt), (unsigned)(rows_bt * a.nsplit * (s + 1)), a.abort_word, &s_flag)) return;
+      TICK(6)
+      float* pl = scr;                               // [nsplit][H+4] staged with batched 16-byte sc1 loads
+      const long pbo = ((long)s * B + b) * a.nsplit * (H + 4);
+      const int n4 = a.nsplit * (H + 4) / 4;
+      for (int i = tid; i < n4; i += 256) *reinterpret_cast<float4*>(pl + 4 * i) = ldb128_sc1(r_part, pbo + 4 * i);
+      __syncthreads();
+      float Mx = -INFINITY;
+      for (int k = 0; k < a.nsplit; ++k) Mx = fmaxf(Mx, pl[k * (H + 4)]);
+      float Ls = 0.f;
+      for (int k = 0; k < a.nsplit; ++k) Ls += pl[k * (H + 4) + 1] * expf(pl[k * (H + 4)] - Mx);
+      const float inv = 1.f / Ls;
+      for (int i = tid; i < H; i += 256) {
+        float v = 0.f;
+        for (int k = 0; k < a.nsplit; ++k) v += pl[k * (H + 4) + 4 + i] * expf(pl[k * (H + 4)] - Mx);
+        st_sc1(a.CVH + ((long)s * B + b) * 2 * H + i, v * inv);
+      }
+      publish(CTR(PH_CMB, bt));
+      TICK(7)
+      for (int t = tid; t < Tp; t += 256) {       // normalised alpha for the backward (off the critical path)
+        float* ap = a.ALPHA + ((long)s * B + b) * Tp + t;
+        const float sc = t < T ? ld_sc1(ap) : 0.f;
+        *ap = t < T ? expf(sc - Mx) * inv : 0.f;
+      }
+      __syncthreads();
+    }
+    // ================= P4: ht = tanh(Wc [cv;h] + bc) =================
+    if (has_c) {
+      const int bt = c_bt, m0 = bt * 16;
+      const int rows_bt = min(16, B - bt * 16);
+      TICK(15)
+      if (!wg_wait(CTR(PH_CMB, bt), (unsigned)(rows_bt * (s + 1)), a.abort_word, &s_flag)) return;
+      TICK(8)
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      wmac<NB_C>(acc, wreg + OFF_WC, r_cvh, ((long)s * B + min(m0 + r16, B - 1)) * 2 * H, 2 * H, lane, wave);
+      const float v = reduce16(acc, red);
+      const int row = m0 + (tid >> 4), n = c_n0 + (tid & 15);
+      if (row < B) {
+        const float ht = tanhf(v + a.bc[n]);
+        st_sc1(a.HT + ((long)(s + 1) * B + row) * A + n, ht);
+        if (s + 1 < S) st_sc1(a.X0 + ((long)(s + 1) * B + row) * XI + E + n, ht);
+      }
+      publish(CTR(PH_CTX, bt));
+      TICK(9)
+    }
+    // ================= P5: logits tiles + per-tile softmax statistics =================
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (l_item[t] < 0) continue;
+      const int bt = l_item[t] / a.ntile_v, tile = l_item[t] % a.ntile_v, m0 = bt * 16, n0 = tile * 16;
+      TICK(15)
+      if (!wg_wait(CTR(PH_CTX, bt), (unsigned)((A / 16) * (s + 1)), a.abort_word, &s_flag)) return;
+      TICK(10)
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      wmac<NB_L>(acc, wreg + OFF_WL + t * NB_L, r_ht, ((long)(s + 1) * B + min(m0 + r16, B - 1)) * A, A, lane, wave);
+      const float v = reduce16(acc, red);
+      const int row = m0 + (tid >> 4), n = n0 + (tid & 15);
+      const bool ok = row < B && n < V;
+      const float x = ok ? v + a.bo[n] : -INFINITY;
+      if (ok) a.LOGITS[((long)s * B + row) * a.Vp + n] = x;
+      else if (row < B && n < a.Vp) a.LOGITS[((long)s * B + row) * a.Vp + n] = 0.f;
+      float mx = x;
+      int mi = n;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        const float om = __shfl_xor(mx, o);
+        const int oi = __shfl_xor(mi, o);
+        if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+      }
+      float se = ok ? expf(x - mx) : 0.f;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o);
+      const int tgt = row < B ? a.y[(long)row * a.L + s + 1] : 0;
+      float xt = (ok && n == tgt) ? x : 0.f;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) xt += __shfl_xor(xt, o);
+      if ((tid & 15) == 0 && row < B) {
+        float* cs = a.CESTAT + (((long)s * B + row) * a.ntile_v + tile) * 4;
+        st_sc1(cs, mx); st_sc1(cs + 1, se); st_sc1(cs + 2, __int_as_float(mi)); st_sc1(cs + 3, xt);
+      }
+      publish(CTR(PH_LOG, bt));
+      TICK(11)
+    }
+    // ================= P6: cross-entropy combine per batch tile =================
+    if (has_ce) {
+      const int bt = ce_rank, m0 = bt * 16;
+      if (!wg_wait(CTR(PH_LOG, bt), (unsigned)(a.ntile_v * (s + 1)), a.abort_word, &s_flag)) return;
+      const int row = m0 + (tid >> 4), sub = tid & 15;       // 16 threads per row sweep the tiles
+      float mx = -INFINITY, se = 0.f, xt = 0.f;
+      int mi = 0x7fffffff;
+      if (row < B)
+        for (int k = sub; k < a.ntile_v; k += 16) {
+          const float4 cs = ldb128_sc1(r_ces, (((long)s * B + row) * a.ntile_v + k) * 4);
+          const float tm = cs.x, ts = cs.y, tx = cs.w;
+          const int ti = __float_as_int(cs.z);
+          const float nm = fmaxf(mx, tm);
+          se = se * expf(mx - nm) + ts * expf(tm - nm);
+          if (tm > mx || (tm == mx && ti < mi)) mi = ti;
+          mx = nm;
+          xt += tx;
+        }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        const float om = __shfl_xor(mx, o), os = __shfl_xor(se, o), ox = __shfl_xor(xt, o);
+        const int oi = __shfl_xor(mi, o);
+        const float nm = fmaxf(mx, om);
+        se = (mx == -INFINITY ? 0.f : se * expf(mx - nm)) + (om == -INFINITY ? 0.f : os * expf(om - nm));
+        if (om > mx || (om == mx && oi < mi)) mi = oi;
+        mx = nm;
+        xt += ox;
+      }
+      if (sub == 0 && row < B) {
+        const float lse = mx + logf(se);
+        const int tgt = a.y[(long)row * a.L + s + 1];
+        const float w = a.cw ? a.cw[tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt)] : 1.f;
+        a.LSE[(long)s * B + row] = lse;
+        a.LOSSROWS[(long)s * B + row] = -(xt - lse) * w / (float)B;
+        sti_sc1(a.PRED + (long)s * B + row, mi);
+      }
+      publish(CTR(PH_CE, bt));
+      TICK(12)
+    }
+  }
+  if (timing && tid == 0 && (wg == 0 || wg == n_cell || wg == G - B || wg == G - 1))
+    printf("pdec wg %3d per-step 10ns: P1[pre %lld waitctx %lld ht+epi %lld publish %lld] P3[wait %lld work %lld] P3b[wait %lld work %lld] "
+           "P4[wait %lld work %lld] P5[wait %lld work %lld] P6 %lld other %lld | P3: hload %lld pass1+max %lld\n", wg, tk[0] / S, tk[1] / S, tk[2] / S, tk[3] / S,
+           tk[4] / S, tk[5] / S, tk[6] / S, tk[7] / S, tk[8] / S, tk[9] / S, tk[10] / S, tk[11] / S, tk[12] / S, tk[15] / S, tk[13] / S, tk[14] / S);
+#undef TICK
+#undef CTR
+}
+
+// =====================================================================================================================
+// Backward loop.  Phases per step (s descending; n = S-1-s steps already done):
+//   B1 d_pre = (dlogits Wo + d_ht carried from step s+1) (1 - ht^2)      items (bt, 16 cols of A)
+//   B2 d_cvh = d_pre Wc  -> d_cv | dh (direct part)                      items (bt, 32 cols of 2H)
+//   B3 attention backward over the LDS-resident slices:  ds = alpha (enc.d_cv - cv.d_cv) ; dh_att partial = sum_t ds encA
+//   B5 cell backward: dh = mask (dh_direct + sum_splits dh_att) + dz_{s+1} Wl ; dz ; dc carried in a register
+//   B6 d_x0 = dz Wu  (its [E:] half is the d_ht carry of step s-1)       items (bt, 16 cols of E+A)
+// Products that do not depend on the current step's chain (dlogits Wo in B1, dz_{s+1} Wl in B5) run before the wait.
+// Weight gradients, d_enc, dq and d_embed are batched products over all steps after the loop (decoder.hip).
+enum BPhase { PB1 = 0, PB2, PB3, PB5, PB6, PB_N };
+
+struct PDecBwdArgs {
+  int B, S, L, T, Tp, H, E, A, V, Vp, XI, nbt, nsplit, chunk;
+  const float *WoT, *WcT, *WlT, *WuT;      // (A,Vp) (2H,A) (H,4H) (XI,4H)
+  const float *enc, *encA;
+  const float *ALPHA, *CVH, *HT, *LOGITS, *Cst, *rnn_mask;
+  float *Gt;                               // gates -> dz
+  float *DPRE, *DCVH, *DS, *DX0, *DHATT;   // DHATT [S][B][nsplit][H]
+  float *d_c0;
+  unsigned* ctr;
+  unsigned* abort_word;
+  int dbg;
+};
+
+constexpr int NB_B1 = 18, NB_B2 = 8, NB_B5 = 32, NB_B6 = 32;     // k-blocks per wave: Vp <= 1152, A <= 512, 4H <= 2048
+constexpr int NWB = 36;
+
+// acc += A . W over NB blocks, A fetched in chunks of CH blocks (bounds the live A registers)
+template <int NB, int CH>
+__device__ __forceinline__ void wmac_chunked(f32x4& acc, const float4* w, __amdgpu_buffer_rsrc_t ra, long a_off, int K, int lane, int wave) {
+  const int q = lane >> 4;
+#pragma unroll
+  for (int c0 = 0; c0 < NB; c0 += CH) {
+    float4 a[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) a[i] = ldb128_sc1(ra, a_off + min(16 * (wave + 4 * (c0 + i)) + 4 * q, K - 4));
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_blocks<CH>(acc, a, w + c0);
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ __attribute__((aligned(16))) float red[4 * 256];
+  __shared__ int s_flag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wg = blockIdx.x;
+  const int B = a.B, S = a.S, H = a.H, E = a.E, A = a.A, XI = a.XI, T = a.T, Tp = a.Tp, Vp = a.Vp;
+  const int nbt = a.nbt, K4 = 4 * H;
+  unsigned* ctr = a.ctr;
+#define CTR(ph, bt) (ctr + ((ph) * nbt + (bt)) * CTRS)
+  // ---------------- roles: [0,n5) cell bwd, [n5, n5+n6) dx0, [n5+n6, n5+n6+n1) d_pre + d_cvh ; attention: all
+  const int n5 = nbt * (H / 16), n6 = nbt * (XI / 16), n1 = nbt * (A / 16), n2 = nbt * (2 * H / 32);
+  const bool has5 = wg < n5;
+  const int b5_bt = has5 ? wg / (H / 16) : 0, b5_u0 = has5 ? (wg % (H / 16)) * 16 : 0;
+  const int r6 = wg - n5;
+  const bool has6 = r6 >= 0 && r6 < n6;
+  const int b6_bt = has6 ? r6 / (XI / 16) : 0, b6_n0 = has6 ? (r6 % (XI / 16)) * 16 : 0;
+  const int r1 = wg - n5 - n6;
+  const bool has1 = r1 >= 0 && r1 < n1;
+  const int b1_bt = has1 ? r1 / (A / 16) : 0, b1_n0 = has1 ? (r1 % (A / 16)) * 16 : 0;
+  const bool has2 = r1 >= 0 && r1 < n2;
+  const int b2_bt = has2 ? r1 / (2 * H / 32) : 0, b2_n0 = has2 ? (r1 % (2 * H / 32)) * 32 : 0;
+  const int n_att = B * a.nsplit;
+  const bool has_att = wg < n_att;
+  const int att_b = has_att ? wg % B : 0, att_sp = has_att ? wg / B : 0;
+
+  float4 wreg[NWB];
+#pragma unroll
+  for (int i = 0; i < NWB; ++i) wreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int r16 = lane & 15;
+  if (has5) wload<NB_B5>(wreg, a.WlT, K4, b5_u0 + r16, K4, lane, wave);
+  else if (has6) wload<NB_B6>(wreg, a.WuT, K4, b6_n0 + r16, K4, lane, wave);
+  else {
+    if (has1) wload<NB_B1>(wreg, a.WoT, Vp, b1_n0 + r16, Vp, lane, wave);
+    if (has2) {
+      wload<NB_B2>(wreg + NB_B1, a.WcT, A, b2_n0 + r16, A, lane, wave);
+      wload<NB_B2>(wreg + NB_B1 + NB_B2, a.WcT, A, b2_n0 + 16 + r16, A, lane, wave);
+    }
+  }
+  const int t0 = att_sp * a.chunk, t1 = min(T, t0 + a.chunk);
+  const int nrow = has_att ? t1 - t0 : 0;
+  float* encS = lds;
+  float* encAS = lds + a.chunk * H;
+  float* scr = lds + 2 * a.chunk * H;        // dS[H] (d_cv) | cvS[H] | ds[chunk] | wred[8]
+  if (has_att) {
+    const float* src = a.enc + ((long)att_b * T + t0) * H;
+    const float* srcA = a.encA + ((long)att_b * T + t0) * H;
+    const int n4 = nrow * H / 4;
+    for (int i = tid; i < n4; i += 256) {
+      reinterpret_cast<float4*>(encS)[i] = reinterpret_cast<const float4*>(src)[i];
+      reinterpret_cast<float4*>(encAS)[i] = reinterpret_cast<const float4*>(srcA)[i];
+    }
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t r_dl = make_rsrc(a.LOGITS), r_dpre = make_rsrc(a.DPRE), r_dcvh = make_rsrc(a.DCVH),
+                               r_g = make_rsrc(a.Gt), r_dx0 = make_rsrc(a.DX0), r_dha = make_rsrc(a.DHATT);
+  const int e_row = tid >> 4, e_col = tid & 15;
+  float dc_state = 0.f;
+
+  for (int s = S - 1; s >= 0; --s) {
+    const int n = S - 1 - s;
+    // ================= B1 =================
+    if (has1) {
+      const int bt = b1_bt, m0 = bt * 16;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      wmac_chunked<NB_B1, 9>(acc, wreg, r_dl, ((long)s * B + min(m0 + r16, B - 1)) * Vp, Vp, lane, wave);   // no dependency on the chain
+      const float v = reduce16(acc, red);
+      const int row = m0 + e_row, col = b1_n0 + e_col;
+      float carry = 0.f;
+      if (n > 0) {
+        if (!wg_wait(CTR(PB6, bt), (unsigned)((XI / 16) * n), a.abort_word, &s_flag)) return;
+        if (row < B) carry = ld_sc1(a.DX0 + ((long)(s + 1) * B + row) * XI + E + col);
+      }
+      if (row < B) {
+        const float y = a.HT[((long)(s + 1) * B + row) * A + col];
+        st_sc1(a.DPRE + ((long)s * B + row) * A + col, (v + carry) * (1.f - y * y));
+      }
+      publish(CTR(PB1, bt));
+    }
+    // ================= B2 =================
+    if (has2) {
+      const int bt = b2_bt, m0 = bt * 16;
+      if (!wg_wait(CTR(PB1, bt), (unsigned)((A / 16) * (n + 1)), a.abort_word, &s_flag)) return;
+      float4 av[NB_B2];
+      aload_sc1<NB_B2>(av, r_dpre, ((long)s * B + min(m0 + r16, B - 1)) * A, A, lane, wave);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      mfma_blocks<NB_B2>(acc0, av, wreg + NB_B1);
+      mfma_blocks<NB_B2>(acc1, av, wreg + NB_B1 + NB_B2);
+      const float v0 = reduce16(acc0, red);
+      const float v1 = reduce16(acc1, red);
+      const int row = m0 + e_row;
+      if (row < B) {
+        st_sc1(a.DCVH + ((long)s * B + row) * 2 * H + b2_n0 + e_col, v0);
+        st_sc1(a.DCVH + ((long)s * B + row) * 2 * H + b2_n0 + 16 + e_col, v1);
+      }
+      publish(CTR(PB2, bt));
+    }
+    // ================= B3: attention backward =================
+    if (has_att) {
+      const int b = att_b, bt = b / 16;
+      if (!wg_wait(CTR(PB2, bt), (unsigned)((2 * H / 32) * (n + 1)), a.abort_word, &s_flag)) return;
+      float* dS = scr;                  // d_cv[b][:]
+      float* cvS = scr + H;             // cv[b][:]
+      float* dsS = scr + 2 * H;         // ds[chunk]
+      float* wred = dsS + a.chunk;      // [8]
+      if (tid < H / 4) {
+        *reinterpret_cast<float4*>(dS + 4 * tid) = ldb128_sc1(r_dcvh, ((long)s * B + b) * 2 * H + 4 * tid);
+        *reinterpret_cast<float4*>(cvS + 4 * tid) = *reinterpret_cast<const float4*>(a.CVH + ((long)s * B + b) * 2 * H + 4 * tid);
+      }
+      __syncthreads();
+      float cdp = 0.f;                  // cv . d_cv
+      for (int k = tid; k < H; k += 256) cdp += cvS[k] * dS[k];
+      cdp = wave_sum(cdp);
+      if (lane == 0) wred[wave] = cdp;
+      __syncthreads();
+      const float cd = wred[0] + wred[1] + wred[2] + wred[3];
+      {
+        const int grp = tid >> 4, l16 = tid & 15;
+        for (int t = grp; t < nrow; t += 32) {
+          const int t2 = t + 16;
+          const bool two = t2 < nrow;
+          const float* e1 = encS + t * H + 4 * l16;
+          const float* e2 = encS + (two ? t2 : t) * H + 4 * l16;
+          float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            if (64 * c < H) {
+              const float4 dv = *reinterpret_cast<const float4*>(dS + 64 * c + 4 * l16);
+              const float4 x1 = *reinterpret_cast<const float4*>(e1 + 64 * c);
+              const float4 x2 = *reinterpret_cast<const float4*>(e2 + 64 * c);
+              d1 += x1.x * dv.x + x1.y * dv.y + x1.z * dv.z + x1.w * dv.w;
+              d2 += x2.x * dv.x + x2.y * dv.y + x2.z * dv.z + x2.w * dv.w;
+            }
+          }
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
+          if (l16 == 0) {
+            const float* al = a.ALPHA + ((long)s * B + b) * Tp + t0;
+            const float g1 = al[t] * (d1 - cd);
+            dsS[t] = g1;
+            a.DS[((long)s * B + b) * Tp + t0 + t] = g1;
+            if (two) {
+              const float g2 = al[t2] * (d2 - cd);
+              dsS[t2] = g2;
+              a.DS[((long)s * B + b) * Tp + t0 + t2] = g2;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      {
+        float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < nrow; ++t) {
+          const float g = dsS[t];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (256 * j < H) acc4[j] += g * encAS[t * H + min(tid + 256 * j, H - 1)];
+        }
+        float* out = a.DHATT + (((long)s * B + b) * a.nsplit + att_sp) * H;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (tid + 256 * j < H) st_sc1(&out[tid + 256 * j], acc4[j]);
+      }
+      publish(CTR(PB3, bt));
+    }
+    // ================= B5: cell backward =================
+    if (has5) {
+      const int bt = b5_bt, m0 = bt * 16;
+      const int rows_bt = min(16, B - bt * 16);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (n > 0) {       // dh_rec = dz_{s+1} Wl: independent of this step's chain
+        if (!wg_wait(CTR(PB5, bt), (unsigned)((H / 16) * n), a.abort_word, &s_flag)) return;
+        wmac_chunked<NB_B5, 16>(acc, wreg, r_g, ((long)(s + 1) * B + min(m0 + r16, B - 1)) * K4, K4, lane, wave);
+      }
+      const float v = reduce16(acc, red);
+      const int row = m0 + e_row, u = b5_u0 + e_col;
+      const bool ev = row < B;
+      // saved forward state of this (row, unit): plain loads issued before the wait
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+      float ccur = 0.f, cp = 0.f, mk = 1.f;
+      if (ev) {
+        g = *reinterpret_cast<const float4*>(a.Gt + ((long)s * B + row) * K4 + 4 * u);
+        ccur = a.Cst[((long)(s + 1) * B + row) * H + u];
+        cp = a.Cst[((long)s * B + row) * H + u];
+        if (a.rnn_mask) mk = a.rnn_mask[((long)s * B + row) * H + u];
+      }
+      if (!wg_wait(CTR(PB3, bt), (unsigned)(rows_bt * a.nsplit * (n + 1)), a.abort_word, &s_flag)) return;
+      if (ev) {
+        float dy = ld_sc1(a.DCVH + ((long)s * B + row) * 2 * H + H + u);
+        float hs = 0.f;
+        for (int k = 0; k < a.nsplit; ++k) hs += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+            r_dha, (int)(((((long)s * B + row) * a.nsplit + k) * H + u) * 4), 0, 16));
+        dy += hs;
+        const float dh = v + dy * mk;
+        const float tc = tanhf(ccur);
+        const float dcv = dh * g.w * (1.f - tc * tc) + dc_state;
+        u32x4 o;
+        o.x = __float_as_uint(dcv * g.y * (1.f - g.x * g.x)); o.y = __float_as_uint(dcv * g.x * g.y * (1.f - g.y));
+        o.z = __float_as_uint(dcv * cp * g.z * (1.f - g.z)); o.w = __float_as_uint(dh * tc * g.w * (1.f - g.w));
+        __builtin_amdgcn_raw_buffer_store_b128(o, r_g, (int)((((long)s * B + row) * K4 + 4 * u) * 4), 0, 16);
+        dc_state = dcv * g.z;
+      }
+      publish(CTR(PB5, bt));
+    }
+    // ================= B6: d_x0 = dz Wu =================
+    if (has6) {
+      const int bt = b6_bt, m0 = bt * 16;
+      if (!wg_wait(CTR(PB5, bt), (unsigned)((H / 16) * (n + 1)), a.abort_word, &s_flag)) return;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      wmac_chunked<NB_B6, 16>(acc, wreg, r_g, ((long)s * B + min(m0 + r16, B - 1)) * K4, K4, lane, wave);
+      const float v = reduce16(acc, red);
+      const int row = m0 + e_row;
+      if (row < B) st_sc1(a.DX0 + ((long)s * B + row) * XI + b6_n0 + e_col, v);
+      publish(CTR(PB6, bt));
+    }
+  }
+  if (has5) {
+    const int row = b5_bt * 16 + e_row, u = b5_u0 + e_col;
+    if (row < B) a.d_c0[(long)row * H + u] = dc_state;
+  }
+#undef CTR
+}
+
+// After the loop: TOK[s][b] (the token that was fed) and X0[s][b][:E] = embed[TOK] * mask for the backward's wgrad / scatter
+__global__ void k_record_inputs(const float* __restrict__ embed, const int32_t* __restrict__ y, const int32_t* __restrict__ use_truth,
+                                const int32_t* __restrict__ pred, const float* __restrict__ emb_mask, int32_t* __restrict__ tok_out,
+                                float* __restrict__ x0, int S, int B, int L, int E, int XI, int V) {
+  const int r = blockIdx.x, s = r / B, b = r % B;
+  int tok = (s == 0 || use_truth[s]) ? y[(long)b * L + s] : pred[(long)(s - 1) * B + b];
+  tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+  if (threadIdx.x == 0) tok_out[r] = tok;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float v = embed[(long)tok * E + e];
+    if (emb_mask) v *= emb_mask[(long)r * E + e];
+    x0[(long)r * XI + e] = v;
+  }
+}
+
+// dlogits = w[t] (softmax - onehot) / B in place of the saved logits, all steps at once (one block per (s,b) row)
+__global__ __launch_bounds__(256) void k_dlogits_all(float* __restrict__ logits, const float* __restrict__ lse, const int32_t* __restrict__ y,
+                                                     const float* __restrict__ cw, int S, int B, int L, int V, int Vp) {
+  const int r = blockIdx.x, s = r / B, b = r % B;
+  int t = y[(long)b * L + s + 1];
+  t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+  const float scale = (cw ? cw[t] : 1.f) / (float)B;
+  const float ls = lse[r];
+  float* x = logits + (long)r * Vp;
+  for (int v = threadIdx.x; v < Vp; v += 256) {
+    float g = 0.f;
+    if (v < V) {
+      g = expf(x[v] - ls) * scale;
+      if (v == t) g -= scale;
+    }
+    x[v] = g;
+  }
+}
+
+}  // namespace
+
+struct DecPersistBuffers {
+  int32_t *TOK, *PRED;
+  float *X0, *G, *C, *HR, *Q, *ALPHA, *CVH, *HT, *LOGITS, *LOSSROWS;
+  float *LSE, *PART, *CESTAT, *ENCA;
+  unsigned* ctr;
+};
+
+static size_t pdec_lds_floats(int chunk, int H, int nsplit) {
+  size_t scratch = (size_t)H + 2 * (size_t)chunk + 16;
+  if (scratch < (size_t)nsplit * (H + 4)) scratch = (size_t)nsplit * (H + 4);
+  return 2 * (size_t)chunk * H + (size_t)((chunk + 3) & ~3) + scratch;
+}
+
+bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int* chunk_out) {
+  const char* e = getenv("ASTK_DEC_PERSIST");
+  if (e && e[0] == '0') return false;
+  if (d->n_layers != 1) return false;
+  if ((d->H % 64) || (d->A % 16) || (d->E % 16) || d->A < 16 || d->E < 16) return false;
+  const int nbt = (d->B + 15) / 16, ntv = (d->V + 15) / 16;
+  if (d->E > 64 * NB_E || d->A > 64 * NB_A || d->H > 64 * NB_H || 2 * d->H > 64 * NB_C || d->A > 64 * NB_L || d->H > 1024) return false;
+  const int n_cell = nbt * (d->H / 8);
+  const int rest = G - n_cell;
+  if (n_cell >= G || rest < nbt * (d->A / 16) || 2 * rest < nbt * ntv) return false;
+  if (rest < d->B + nbt || d->B > G) return false;
+  int nsplit = G / d->B;
+  if (nsplit > 64) nsplit = 64;
+  if (nsplit > d->T) nsplit = d->T;
+  if (nsplit < 1) return false;
+  int chunk = (d->T + nsplit - 1) / nsplit;
+  nsplit = (d->T + chunk - 1) / chunk;
+  if (chunk > 256 || d->L > 192) return false;
+  {   // backward roles and register budgets
+    const int XI = d->E + d->A, Vp = (d->V + 3) / 4 * 4;
+    if (Vp > 64 * NB_B1 || d->A > 64 * NB_B2 || 4 * d->H > 64 * NB_B5 || (XI % 16) || ((2 * d->H) % 32)) return false;
+    if (nbt * (d->H / 16) + nbt * (XI / 16) + nbt * (d->A / 16) > G || nbt * (2 * d->H / 32) > nbt * (d->A / 16) + (G - nbt * (d->H / 16) - nbt * (XI / 16) - nbt * (d->A / 16))) return false;
+    if ((2 * (size_t)chunk * d->H + 2 * (size_t)d->H + chunk + 16) * sizeof(float) > 148 * 1024) return false;
+  }                       // pass-1 bookkeeping uses one thread per row
+  if (pdec_lds_floats(chunk, d->H, nsplit) * sizeof(float) > 136 * 1024) return false;
+  *nsplit_out = nsplit;
+  *chunk_out = chunk;
+  return true;
+}
+
+size_t decoder_persist_extra_floats(const astk_decoder_desc* d) {
+  int ns = 1, ch = 1;
+  if (!decoder_persist_applicable(d, &ns, &ch)) return 0;
+  const size_t S = d->L - 1, B = d->B;
+  return S * B /*LSE*/ + S * B * ns * (d->H + 4) + S * B * ((d->V + 15) / 16) * 4 + (size_t)(PH_N * ((d->B + 15) / 16) + 2) * CTRS + 1024;
+}
+
+struct DecPersistBwdBuffers {
+  const float *WoT, *WcT, *WlT, *WuT, *ENCA, *ALPHA, *CVH, *HT, *LOGITS, *C;
+  float *G, *DPRE, *DCVH, *DS, *DX0, *DHATT, *d_c0;
+  unsigned* ctr;
+};
+
+int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, const float* rnn_masks, const DecPersistBwdBuffers& bf,
+                               hipStream_t s) {
+  int nsplit = 1, chunk = 1;
+  ASTK_CHECK(decoder_persist_applicable(d, &nsplit, &chunk), "decoder_persist_bwd: not applicable");
+  PDecBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = d->B; a.S = d->L - 1; a.L = d->L; a.T = d->T; a.Tp = (d->T + 3) / 4 * 4; a.H = d->H; a.E = d->E; a.A = d->A; a.V = d->V;
+  a.Vp = (d->V + 3) / 4 * 4; a.XI = d->E + d->A; a.nbt = (d->B + 15) / 16; a.nsplit = nsplit; a.chunk = chunk;
+  a.WoT = bf.WoT; a.WcT = bf.WcT; a.WlT = bf.WlT; a.WuT = bf.WuT; a.enc = enc; a.encA = bf.ENCA; a.ALPHA = bf.ALPHA; a.CVH = bf.CVH;
+  a.HT = bf.HT; a.LOGITS = bf.LOGITS; a.Cst = bf.C; a.rnn_mask = rnn_masks; a.Gt = bf.G; a.DPRE = bf.DPRE; a.DCVH = bf.DCVH; a.DS = bf.DS;
+  a.DX0 = bf.DX0; a.DHATT = bf.DHATT; a.d_c0 = bf.d_c0;
+  a.ctr = bf.ctr;
+  a.abort_word = bf.ctr + (size_t)PB_N * a.nbt * CTRS;
+  ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)PB_N * a.nbt + 1) * CTRS * sizeof(unsigned), s));
+  size_t scratch = 2 * (size_t)a.H + (size_t)chunk + 16;
+  const size_t shm = (2 * (size_t)chunk * a.H + scratch) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    ASTK_HIP(hipFuncSetAttribute((const void*)decoder_persist_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(decoder_persist_bwd, dim3(G), dim3(256), shm, s, a);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_params* prm, const float* enc, const int32_t* y,
+                               const int32_t* use_truth, const float* emb_mask, const float* rnn_masks, const DecPersistBuffers& bf,
+                               hipStream_t s) {
+  int nsplit = 1, chunk = 1;
+  // encA = enc . Wa (one batched GEMM): the score of decoder step s is encA[b,t,:].h_s + enc[b,t,:].ba, so the per-step
+  // q = Wa h phase drops out of the sequential chain; Q itself is rebuilt after the loop for the backward.
+  ASTK_TRY(gemm_launch(GEMM_NN, gemm_args(d->B * d->T, d->H, d->H, mat(enc, d->H), mat(prm->Wa, d->H), bf.ENCA, d->H), s));
+  ASTK_CHECK(decoder_persist_applicable(d, &nsplit, &chunk), "decoder_persist: not applicable");
+  PDecArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = d->B; a.S = d->L - 1; a.L = d->L; a.T = d->T; a.Tp = (d->T + 3) / 4 * 4; a.H = d->H; a.E = d->E; a.A = d->A; a.V = d->V;
+  a.Vp = (d->V + 3) / 4 * 4; a.XI = d->E + d->A; a.nbt = (d->B + 15) / 16; a.nsplit = nsplit; a.chunk = chunk;
+  a.ntile_v = (d->V + 15) / 16;
+  a.embed = prm->embed; a.Wu = prm->lstm[0].Wu; a.bias = prm->lstm[0].b; a.Wl = prm->lstm[0].Wl;
+  a.Wa = prm->Wa; a.ba = prm->ba; a.Wc = prm->Wc; a.bc = prm->bc; a.Wo = prm->Wo; a.bo = prm->bo; a.cw = prm->class_weight;
+  a.enc = enc; a.encA = bf.ENCA; a.y = y; a.use_truth = use_truth; a.emb_mask = emb_mask; a.rnn_mask = rnn_masks;
+  a.TOK = bf.TOK; a.PRED = bf.PRED; a.X0 = bf.X0; a.Gt = bf.G; a.Cst = bf.C; a.HR = bf.HR; a.Q = bf.Q; a.ALPHA = bf.ALPHA;
+  a.CVH = bf.CVH; a.HT = bf.HT; a.LOGITS = bf.LOGITS; a.LOSSROWS = bf.LOSSROWS; a.LSE = bf.LSE; a.PART = bf.PART; a.CESTAT = bf.CESTAT;
+  a.ctr = bf.ctr;
+  a.abort_word = bf.ctr + (size_t)PH_N * a.nbt * CTRS;
+  { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
+  ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)PH_N * a.nbt + 1) * CTRS * sizeof(unsigned), s));
+  const size_t shm = pdec_lds_floats(chunk, a.H, nsplit) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    ASTK_HIP(hipFuncSetAttribute((const void*)decoder_persist_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(decoder_persist_fwd, dim3(G), dim3(256), shm, s, a);
+  ASTK_LAUNCH_CHECK();
+  // Q[s][b][:] = Wa h_top + ba for all steps (needed by the backward's deferred d_enc product)
+  ASTK_TRY(gemm_launch(GEMM_NT, gemm_args(a.S * a.B, a.H, a.H, mat(bf.CVH + a.H, 2 * a.H), mat(prm->Wa, a.H), bf.Q, a.H, prm->ba), s));
+  hipLaunchKernelGGL(k_record_inputs, dim3(a.S * a.B), dim3(128), 0, s, prm->embed, y, use_truth, bf.PRED, emb_mask, bf.TOK, bf.X0, a.S, a.B,
+                     a.L, a.E, a.XI, a.V);
+  ASTK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_dlogits_all, dim3(a.S * a.B), dim3(256), 0, s, bf.LOGITS, bf.LSE, y, prm->class_weight, a.S, a.B, a.L, a.V, a.Vp);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace astk

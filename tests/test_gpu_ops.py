@@ -318,7 +318,10 @@ def _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=0):
 
 
 @pytest.mark.parametrize("B,L,T,H,E,A,V,nl,masks", [(3, 6, 6, 8, 4, 8, 11, 2, False), (5, 9, 23, 32, 12, 24, 57, 3, True),
-                                                    (33, 4, 10, 64, 16, 64, 130, 1, True), (2, 2, 5, 8, 4, 8, 7, 1, False)])
+                                                    (33, 4, 10, 64, 16, 64, 130, 1, True), (2, 2, 5, 8, 4, 8, 7, 1, False),
+                                                    # 1 layer, H/A multiples of 16: the persistent decoder-loop kernel
+                                                    (5, 9, 23, 64, 16, 32, 57, 1, False), (32, 7, 50, 512, 128, 512, 1098, 1, True),
+                                                    (17, 5, 200, 256, 64, 128, 300, 1, True)])
 def test_decoder_fwd_bwd(lib, B, L, T, H, E, A, V, nl, masks):
     from oracle.ast_ref_torch import decoder_torch
     s = _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=B + L)
