@@ -12,8 +12,9 @@ namespace astk {
 void set_error(const char* fmt, ...);
 
 // Optional per-kernel HIP-event timing on the launch stream (bench.py's roofline legs).  Off by default.
-enum ProfCat { PROF_ATTN_FWD = 0, PROF_ATTN_BWD = 1, PROF_GEMM = 2, PROF_CELL = 3, PROF_NCAT = 4 };
+enum ProfCat { PROF_ATTN_FWD = 0, PROF_ATTN_BWD = 1, PROF_GEMM = 2, PROF_CELL = 3, PROF_DEC_FWD = 4, PROF_DEC_BWD = 5, PROF_NCAT = 6 };
 bool prof_enabled();
+float* prof_tick_buffer(int which);   // device buffer [257] for in-kernel phase timing (0: decoder fwd, 1: decoder bwd) or null
 void prof_start(int cat, hipStream_t s, double work);
 void prof_stop(int cat, hipStream_t s);
 struct ProfScope {

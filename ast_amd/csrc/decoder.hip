@@ -16,7 +16,7 @@ namespace astk {
 struct DecPersistBuffers {
   int32_t *TOK, *PRED;
   float *X0, *G, *C, *HR, *Q, *ALPHA, *CVH, *HT, *LOGITS, *LOSSROWS;
-  float *LSE, *PART, *CESTAT, *ENCA;
+  float *LSE, *PART, *CESTAT, *ENCA, *ML;
   unsigned* ctr;
 };
 bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int* chunk_out);
@@ -25,8 +25,8 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
                                hipStream_t s);
 
 struct DecPersistBwdBuffers {
-  const float *WoT, *WcT, *WlT, *WuT, *ENCA, *ALPHA, *CVH, *HT, *LOGITS, *C;
-  float *G, *DPRE, *DCVH, *DS, *DX0, *DHATT, *d_c0;
+  const float *WoT, *WcT, *WlT, *WuT, *ENCA, *CVH, *HT, *LOGITS, *C, *ML;
+  float *ALPHA, *G, *DPRE, *DCVH, *DS, *DX0, *DHATT, *d_c0;
   unsigned* ctr;
 };
 int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, const float* rnn_masks, const DecPersistBwdBuffers& bf,
@@ -63,7 +63,7 @@ struct DecPlan {
   float* WuT[ASTK_MAX_RNN_LAYERS];  // [in][4H]
   float* WlT[ASTK_MAX_RNN_LAYERS];  // [H][4H]
   float* ZERO;   // [B][max(A,H)] zeros
-  float *LSE, *PART, *CESTAT, *ENCA;       // persistent path only
+  float *LSE, *PART, *CESTAT, *ENCA, *MLB;       // persistent path only
   unsigned* PCTR;
   void* attn_ws;
   size_t bytes;
@@ -115,6 +115,7 @@ int make_plan(const astk_decoder_desc* d, void* ws, DecPlan& P) {
     P.PART = c.take<float>(pp ? S * B * ns * (H + 4) : 4);
     P.CESTAT = c.take<float>(pp ? S * B * (size_t)((P.V + 15) / 16) * 4 : 4);
     P.ENCA = c.take<float>(pp ? B * (size_t)P.T * H : 4);
+    P.MLB = c.take<float>(pp ? S * B * 2 : 4);
     P.PCTR = c.take<unsigned>(pp ? (size_t)(8 * ((P.B + 15) / 16) + 2) * 64 : 4);
   }
   P.bytes = c.total();
@@ -313,7 +314,7 @@ int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
       DecPersistBuffers bf;
       bf.TOK = P.TOK; bf.PRED = P.PRED; bf.X0 = P.X0; bf.G = P.G[0]; bf.C = P.C[0]; bf.HR = P.HR[0]; bf.Q = P.Q; bf.ALPHA = P.ALPHA;
       bf.CVH = P.CVH; bf.HT = P.HT; bf.LOGITS = P.LOGITS; bf.LOSSROWS = P.LOSSROWS; bf.LSE = P.LSE; bf.PART = P.PART;
-      bf.CESTAT = P.CESTAT; bf.ENCA = P.ENCA; bf.ctr = P.PCTR;
+      bf.CESTAT = P.CESTAT; bf.ENCA = P.ENCA; bf.ML = P.MLB; bf.ctr = P.PCTR;
       ASTK_TRY(decoder_persist_fwd_launch(d, prm, enc, y, use_truth, emb_mask, rnn_masks, bf, s));
       hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, s, P.LOSSROWS, S * B, loss);
       ASTK_LAUNCH_CHECK();
@@ -405,7 +406,7 @@ int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
   const bool persist = decoder_persist_applicable(d, &ns_, &ch_);
   if (persist) {
     DecPersistBwdBuffers bf;
-    bf.WoT = P.WoT; bf.WcT = P.WcT; bf.WlT = P.WlT[0]; bf.WuT = P.WuT[0]; bf.ENCA = P.ENCA; bf.ALPHA = P.ALPHA; bf.CVH = P.CVH;
+    bf.WoT = P.WoT; bf.WcT = P.WcT; bf.WlT = P.WlT[0]; bf.WuT = P.WuT[0]; bf.ENCA = P.ENCA; bf.ALPHA = P.ALPHA; bf.CVH = P.CVH; bf.ML = P.MLB;
     bf.HT = P.HT; bf.LOGITS = P.LOGITS; bf.C = P.C[0]; bf.G = P.G[0]; bf.DPRE = P.DPRE; bf.DCVH = P.DCVH; bf.DS = P.DS; bf.DX0 = P.DX0;
     bf.DHATT = P.PART; bf.d_c0 = d_c0; bf.ctr = P.PCTR;
     ASTK_TRY(decoder_persist_bwd_launch(d, enc, rnn_masks, bf, s));

@@ -43,10 +43,12 @@ struct PDecArgs {
   int32_t* TOK; int32_t* PRED;
   float *X0, *Gt, *Cst, *HR, *Q, *ALPHA, *CVH, *HT, *LOGITS, *LOSSROWS, *LSE;
   float* PART;             // [S][B][nsplit][H+4]
+  float* ML;               // [S][B][2] softmax max and 1/sum of every attention row
   float* CESTAT;           // [S][B][ntile_v][4]
   unsigned* ctr;           // [PH_N][nbt] * CTRS
   unsigned* abort_word;
   int dbg;
+  float* tick_out;         // profiler: [G] accumulated attention-phase microseconds per workgroup, [G+0] launches
 };
 
 __device__ __forceinline__ unsigned ld_flag(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
   for (int i = 0; i < 16; ++i) tk[i] = 0;
   const bool timing = a.dbg != 0;
   long long tlast = timing ? wall_clock64() : 0;
+  long long tk_att = 0;
 #define TICK(i) if (timing) { const long long now_ = wall_clock64(); tk[i] += now_ - tlast; tlast = now_; }
   for (int s = 0; s < S; ++s) {
     // ================= P1: embed + LSTM cell =================
@@ -279,9 +282,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       if (!truth) { if (!wg_wait(CTR(PH_CE, bt), (unsigned)s, a.abort_word, &s_flag)) return; }
       int tok = truth ? yS[r16 * a.L + s] : ldi_sc1(a.PRED + (long)(s - 1) * B + brow);
       tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
-      TICK(15)
       if (s > 0) { if (!wg_wait(CTR(PH_CELL, bt), (unsigned)((H / 8) * s), a.abort_word, &s_flag)) return; }
-      TICK(13)
       f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
       {
         // (a) embedding part and (b) recurrent part: neither depends on this step's ht, so they run before the wait on P4
@@ -299,7 +300,6 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
         }
         aload_sc1<NB_H>(ah, r_hr, ((long)s * B + brow) * H, H, lane, wave);     // h_{s-1}: published a whole step ago (waited above)
         __builtin_amdgcn_sched_barrier(0);
-        if (timing) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TICK(14) }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           mfma_blocks<NB_E>(acc[t], ae, wreg + t * CELLW);
@@ -348,10 +348,13 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       TICK(15)
       if (!wg_wait(CTR(PH_CELL, bt), (unsigned)((H / 8) * (s + 1)), a.abort_word, &s_flag)) return;
       TICK(4)
+      const long long ta0 = a.tick_out ? wall_clock64() : 0;
+      const int c4 = (a.chunk + 3) & ~3;
       float* hS = scr;                 // [H]
-      float* scS = scr + H;            // [chunk] raw scores
-      float* pS = scr + H + a.chunk;   // [chunk] exp(score - m)
+      float* scS = scr + H;            // [c4] raw scores (tail padded with -inf)
+      float* pS = scr + H + c4;        // [c4] exp(score - m) (tail 0)
       if (tid < H / 4) *reinterpret_cast<float4*>(hS + 4 * tid) = ldb128_sc1(r_cvh, ((long)s * B + b) * 2 * H + H + 4 * tid);
+      if (tid >= nrow && tid < c4) scS[tid] = -INFINITY;        // pad the score vector for the float4 sweeps below
       __syncthreads();
       TICK(13)
       {
@@ -382,34 +385,33 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
         }
       }
       __syncthreads();
-      // chunk max / exp / sum with register reductions: thread t owns row t (nrow <= 256)
-      float* wred = pS + a.chunk;          // [8] wave partials (inside the scratch's 16-float tail)
-      const float sv = tid < nrow ? scS[tid] : -INFINITY;
-      float wm = sv;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
-      if (lane == 0) wred[wave] = wm;
-      __syncthreads();
-      const float m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
-      const float pv = tid < nrow ? expf(sv - m) : 0.f;
-      if (tid < nrow) {
-        pS[tid] = pv;
-        st_sc1(a.ALPHA + ((long)s * B + b) * Tp + t0 + tid, sv);     // raw score; P3b normalises
+      // chunk max / exp / sum: every thread sweeps the (<= 256) scores with broadcast float4 LDS reads -- no shuffles
+      float m = -INFINITY;
+      for (int t = 0; t < nrow; t += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(scS + t);
+        m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
       }
-      float ws = wave_sum(pv);
-      if (lane == 0) wred[4 + wave] = ws;
+      if (tid < c4) pS[tid] = tid < nrow ? expf(scS[tid] - m) : 0.f;
+      const float my_score = tid < nrow ? scS[tid] : 0.f;
       __syncthreads();
-      const float l = wred[4] + wred[5] + wred[6] + wred[7];
+      float l = 0.f;
+      float cvp[4] = {0.f, 0.f, 0.f, 0.f};
       TICK(14)
       float* prow = a.PART + (((long)s * B + b) * a.nsplit + att_sp) * (H + 4);
       {
-        // pass 2: context partial; thread owns columns tid + 256 j (consecutive threads -> consecutive LDS words)
-        float cvp[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < nrow; ++t) {
-          const float pt = pS[t];
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (256 * j < H) cvp[j] += pt * encS[t * H + min(tid + 256 * j, H - 1)];
+        // pass 2: context partial; thread owns columns tid + 256 j (consecutive threads -> consecutive LDS words); 4 rows per trip
+        const int c0 = min(tid, H - 1), c1 = min(tid + 256, H - 1), c2 = min(tid + 512, H - 1), c3 = min(tid + 768, H - 1);
+        for (int t = 0; t < nrow; t += 4) {
+          const float4 pv = *reinterpret_cast<const float4*>(pS + t);      // rows beyond nrow have p = 0 and read the next slice rows
+          l += (pv.x + pv.y) + (pv.z + pv.w);
+          const float* e0 = encS + t * H;
+          const int r1 = min(t + 1, nrow - 1) - t, r2 = min(t + 2, nrow - 1) - t, r3 = min(t + 3, nrow - 1) - t;
+          cvp[0] += pv.x * e0[c0] + pv.y * e0[r1 * H + c0] + pv.z * e0[r2 * H + c0] + pv.w * e0[r3 * H + c0];
+          if (H > 256) cvp[1] += pv.x * e0[c1] + pv.y * e0[r1 * H + c1] + pv.z * e0[r2 * H + c1] + pv.w * e0[r3 * H + c1];
+          if (H > 512) {
+            cvp[2] += pv.x * e0[c2] + pv.y * e0[r1 * H + c2] + pv.z * e0[r2 * H + c2] + pv.w * e0[r3 * H + c2];
+            cvp[3] += pv.x * e0[c3] + pv.y * e0[r1 * H + c3] + pv.z * e0[r2 * H + c3] + pv.w * e0[r3 * H + c3];
+          }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -417,6 +419,8 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       }
       if (tid == 0) { st_sc1(&prow[0], m); st_sc1(&prow[1], l); }
       publish(CTR(PH_ATT, bt));
+      if (a.tick_out) tk_att += wall_clock64() - ta0;
+      if (tid < nrow) a.ALPHA[((long)s * B + b) * Tp + t0 + tid] = my_score;   // raw score, normalised by the backward (M, 1/L in ML)
       TICK(5)
     }
     // ================= P3b: combine the nsplit partials of one batch row =================
@@ -443,11 +447,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       }
       publish(CTR(PH_CMB, bt));
       TICK(7)
-      for (int t = tid; t < Tp; t += 256) {       // normalised alpha for the backward (off the critical path)
-        float* ap = a.ALPHA + ((long)s * B + b) * Tp + t;
-        const float sc = t < T ? ld_sc1(ap) : 0.f;
-        *ap = t < T ? expf(sc - Mx) * inv : 0.f;
-      }
+      if (tid == 0) { a.ML[((long)s * B + b) * 2] = Mx; a.ML[((long)s * B + b) * 2 + 1] = inv; }
       __syncthreads();
     }
     // ================= P4: ht = tanh(Wc [cv;h] + bc) =================
@@ -547,7 +547,11 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       TICK(12)
     }
   }
-  if (timing && tid == 0 && (wg == 0 || wg == n_cell || wg == G - B || wg == G - 1))
+  if (a.tick_out && tid == 0 && has_att) {     // attention phase = hand-off satisfied -> partial published (10 ns ticks -> us)
+    atomicAdd(&a.tick_out[wg], (float)tk_att * 0.01f / (float)S);
+    if (wg == 0) atomicAdd(&a.tick_out[G], 1.0f);
+  }
+  if (a.dbg != 0 && tid == 0 && (wg == 0 || wg == n_cell || wg == G - B || wg == G - 1))
     printf("pdec wg %3d per-step 10ns: P1[pre %lld waitctx %lld ht+epi %lld publish %lld] P3[wait %lld work %lld] P3b[wait %lld work %lld] "
            "P4[wait %lld work %lld] P5[wait %lld work %lld] P6 %lld other %lld | P3: hload %lld pass1+max %lld\n", wg, tk[0] / S, tk[1] / S, tk[2] / S, tk[3] / S,
            tk[4] / S, tk[5] / S, tk[6] / S, tk[7] / S, tk[8] / S, tk[9] / S, tk[10] / S, tk[11] / S, tk[12] / S, tk[15] / S, tk[13] / S, tk[14] / S);
@@ -570,13 +574,15 @@ struct PDecBwdArgs {
   int B, S, L, T, Tp, H, E, A, V, Vp, XI, nbt, nsplit, chunk;
   const float *WoT, *WcT, *WlT, *WuT;      // (A,Vp) (2H,A) (H,4H) (XI,4H)
   const float *enc, *encA;
-  const float *ALPHA, *CVH, *HT, *LOGITS, *Cst, *rnn_mask;
+  const float *CVH, *HT, *LOGITS, *Cst, *rnn_mask, *ML;
+  float *ALPHA;                            // raw scores in, normalised alpha out
   float *Gt;                               // gates -> dz
   float *DPRE, *DCVH, *DS, *DX0, *DHATT;   // DHATT [S][B][nsplit][H]
   float *d_c0;
   unsigned* ctr;
   unsigned* abort_word;
   int dbg;
+  float* tick_out;
 };
 
 constexpr int NB_B1 = 18, NB_B2 = 8, NB_B5 = 32, NB_B6 = 32;     // k-blocks per wave: Vp <= 1152, A <= 512, 4H <= 2048
@@ -654,6 +660,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
                                r_g = make_rsrc(a.Gt), r_dx0 = make_rsrc(a.DX0), r_dha = make_rsrc(a.DHATT);
   const int e_row = tid >> 4, e_col = tid & 15;
   float dc_state = 0.f;
+  long long tk_att = 0;
 
   for (int s = S - 1; s >= 0; --s) {
     const int n = S - 1 - s;
@@ -698,10 +705,13 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
     if (has_att) {
       const int b = att_b, bt = b / 16;
       if (!wg_wait(CTR(PB2, bt), (unsigned)((2 * H / 32) * (n + 1)), a.abort_word, &s_flag)) return;
+      const long long tb0 = a.tick_out ? wall_clock64() : 0;
       float* dS = scr;                  // d_cv[b][:]
       float* cvS = scr + H;             // cv[b][:]
-      float* dsS = scr + 2 * H;         // ds[chunk]
-      float* wred = dsS + a.chunk;      // [8]
+      float* dsS = scr + 2 * H;         // ds[c4] (tail 0)
+      const int c4 = (a.chunk + 3) & ~3;
+      float* wred = dsS + c4;           // [8]
+      if (tid >= nrow && tid < c4) dsS[tid] = 0.f;
       if (tid < H / 4) {
         *reinterpret_cast<float4*>(dS + 4 * tid) = ldb128_sc1(r_dcvh, ((long)s * B + b) * 2 * H + 4 * tid);
         *reinterpret_cast<float4*>(cvS + 4 * tid) = *reinterpret_cast<const float4*>(a.CVH + ((long)s * B + b) * 2 * H + 4 * tid);
@@ -713,6 +723,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
       if (lane == 0) wred[wave] = cdp;
       __syncthreads();
       const float cd = wred[0] + wred[1] + wred[2] + wred[3];
+      const float mlM = a.ML[((long)s * B + b) * 2], mlI = a.ML[((long)s * B + b) * 2 + 1];
       {
         const int grp = tid >> 4, l16 = tid & 15;
         for (int t = grp; t < nrow; t += 32) {
@@ -734,12 +745,16 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
 #pragma unroll
           for (int o = 8; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
           if (l16 == 0) {
-            const float* al = a.ALPHA + ((long)s * B + b) * Tp + t0;
-            const float g1 = al[t] * (d1 - cd);
+            float* al = a.ALPHA + ((long)s * B + b) * Tp + t0;
+            const float a1 = expf(al[t] - mlM) * mlI;
+            al[t] = a1;                                  // normalised alpha for the deferred d_enc product
+            const float g1 = a1 * (d1 - cd);
             dsS[t] = g1;
             a.DS[((long)s * B + b) * Tp + t0 + t] = g1;
             if (two) {
-              const float g2 = al[t2] * (d2 - cd);
+              const float a2 = expf(al[t2] - mlM) * mlI;
+              al[t2] = a2;
+              const float g2 = a2 * (d2 - cd);
               dsS[t2] = g2;
               a.DS[((long)s * B + b) * Tp + t0 + t2] = g2;
             }
@@ -749,11 +764,17 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
       __syncthreads();
       {
         float acc4[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < nrow; ++t) {
-          const float g = dsS[t];
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (256 * j < H) acc4[j] += g * encAS[t * H + min(tid + 256 * j, H - 1)];
+        const int c0 = min(tid, H - 1), c1 = min(tid + 256, H - 1), c2 = min(tid + 512, H - 1), c3 = min(tid + 768, H - 1);
+        for (int t = 0; t < nrow; t += 4) {
+          const float4 gv = *reinterpret_cast<const float4*>(dsS + t);
+          const float* e0 = encAS + t * H;
+          const int r1 = min(t + 1, nrow - 1) - t, r2 = min(t + 2, nrow - 1) - t, r3 = min(t + 3, nrow - 1) - t;
+          acc4[0] += gv.x * e0[c0] + gv.y * e0[r1 * H + c0] + gv.z * e0[r2 * H + c0] + gv.w * e0[r3 * H + c0];
+          if (H > 256) acc4[1] += gv.x * e0[c1] + gv.y * e0[r1 * H + c1] + gv.z * e0[r2 * H + c1] + gv.w * e0[r3 * H + c1];
+          if (H > 512) {
+            acc4[2] += gv.x * e0[c2] + gv.y * e0[r1 * H + c2] + gv.z * e0[r2 * H + c2] + gv.w * e0[r3 * H + c2];
+            acc4[3] += gv.x * e0[c3] + gv.y * e0[r1 * H + c3] + gv.z * e0[r2 * H + c3] + gv.w * e0[r3 * H + c3];
+          }
         }
         float* out = a.DHATT + (((long)s * B + b) * a.nsplit + att_sp) * H;
 #pragma unroll
@@ -761,6 +782,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
           if (tid + 256 * j < H) st_sc1(&out[tid + 256 * j], acc4[j]);
       }
       publish(CTR(PB3, bt));
+      if (a.tick_out) tk_att += wall_clock64() - tb0;
     }
     // ================= B5: cell backward =================
     if (has5) {
@@ -817,6 +839,10 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
     const int row = b5_bt * 16 + e_row, u = b5_u0 + e_col;
     if (row < B) a.d_c0[(long)row * H + u] = dc_state;
   }
+  if (a.tick_out && tid == 0 && has_att) {
+    atomicAdd(&a.tick_out[wg], (float)tk_att * 0.01f / (float)S);
+    if (wg == 0) atomicAdd(&a.tick_out[G], 1.0f);
+  }
 #undef CTR
 }
 
@@ -859,12 +885,12 @@ __global__ __launch_bounds__(256) void k_dlogits_all(float* __restrict__ logits,
 struct DecPersistBuffers {
   int32_t *TOK, *PRED;
   float *X0, *G, *C, *HR, *Q, *ALPHA, *CVH, *HT, *LOGITS, *LOSSROWS;
-  float *LSE, *PART, *CESTAT, *ENCA;
+  float *LSE, *PART, *CESTAT, *ENCA, *ML;
   unsigned* ctr;
 };
 
 static size_t pdec_lds_floats(int chunk, int H, int nsplit) {
-  size_t scratch = (size_t)H + 2 * (size_t)chunk + 16;
+  size_t scratch = (size_t)H + 2 * (size_t)((chunk + 3) & ~3) + 16;
   if (scratch < (size_t)nsplit * (H + 4)) scratch = (size_t)nsplit * (H + 4);
   return 2 * (size_t)chunk * H + (size_t)((chunk + 3) & ~3) + scratch;
 }
@@ -891,7 +917,7 @@ bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int
     const int XI = d->E + d->A, Vp = (d->V + 3) / 4 * 4;
     if (Vp > 64 * NB_B1 || d->A > 64 * NB_B2 || 4 * d->H > 64 * NB_B5 || (XI % 16) || ((2 * d->H) % 32)) return false;
     if (nbt * (d->H / 16) + nbt * (XI / 16) + nbt * (d->A / 16) > G || nbt * (2 * d->H / 32) > nbt * (d->A / 16) + (G - nbt * (d->H / 16) - nbt * (XI / 16) - nbt * (d->A / 16))) return false;
-    if ((2 * (size_t)chunk * d->H + 2 * (size_t)d->H + chunk + 16) * sizeof(float) > 148 * 1024) return false;
+    if ((2 * (size_t)chunk * d->H + 2 * (size_t)d->H + chunk + 20) * sizeof(float) > 148 * 1024) return false;
   }                       // pass-1 bookkeeping uses one thread per row
   if (pdec_lds_floats(chunk, d->H, nsplit) * sizeof(float) > 136 * 1024) return false;
   *nsplit_out = nsplit;
@@ -907,8 +933,8 @@ size_t decoder_persist_extra_floats(const astk_decoder_desc* d) {
 }
 
 struct DecPersistBwdBuffers {
-  const float *WoT, *WcT, *WlT, *WuT, *ENCA, *ALPHA, *CVH, *HT, *LOGITS, *C;
-  float *G, *DPRE, *DCVH, *DS, *DX0, *DHATT, *d_c0;
+  const float *WoT, *WcT, *WlT, *WuT, *ENCA, *CVH, *HT, *LOGITS, *C, *ML;
+  float *ALPHA, *G, *DPRE, *DCVH, *DS, *DX0, *DHATT, *d_c0;
   unsigned* ctr;
 };
 
@@ -920,20 +946,24 @@ int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, con
   memset(&a, 0, sizeof(a));
   a.B = d->B; a.S = d->L - 1; a.L = d->L; a.T = d->T; a.Tp = (d->T + 3) / 4 * 4; a.H = d->H; a.E = d->E; a.A = d->A; a.V = d->V;
   a.Vp = (d->V + 3) / 4 * 4; a.XI = d->E + d->A; a.nbt = (d->B + 15) / 16; a.nsplit = nsplit; a.chunk = chunk;
-  a.WoT = bf.WoT; a.WcT = bf.WcT; a.WlT = bf.WlT; a.WuT = bf.WuT; a.enc = enc; a.encA = bf.ENCA; a.ALPHA = bf.ALPHA; a.CVH = bf.CVH;
+  a.WoT = bf.WoT; a.WcT = bf.WcT; a.WlT = bf.WlT; a.WuT = bf.WuT; a.enc = enc; a.encA = bf.ENCA; a.ALPHA = bf.ALPHA; a.CVH = bf.CVH; a.ML = bf.ML;
   a.HT = bf.HT; a.LOGITS = bf.LOGITS; a.Cst = bf.C; a.rnn_mask = rnn_masks; a.Gt = bf.G; a.DPRE = bf.DPRE; a.DCVH = bf.DCVH; a.DS = bf.DS;
   a.DX0 = bf.DX0; a.DHATT = bf.DHATT; a.d_c0 = bf.d_c0;
   a.ctr = bf.ctr;
   a.abort_word = bf.ctr + (size_t)PB_N * a.nbt * CTRS;
+  a.tick_out = prof_tick_buffer(1);
   ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)PB_N * a.nbt + 1) * CTRS * sizeof(unsigned), s));
-  size_t scratch = 2 * (size_t)a.H + (size_t)chunk + 16;
+  size_t scratch = 2 * (size_t)a.H + (size_t)((chunk + 3) & ~3) + 16;
   const size_t shm = (2 * (size_t)chunk * a.H + scratch) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
     ASTK_HIP(hipFuncSetAttribute((const void*)decoder_persist_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL(decoder_persist_bwd, dim3(G), dim3(256), shm, s, a);
+  {
+    ProfScope prof(PROF_DEC_BWD, s);
+    hipLaunchKernelGGL(decoder_persist_bwd, dim3(G), dim3(256), shm, s, a);
+  }
   ASTK_LAUNCH_CHECK();
   return 0;
 }
@@ -955,10 +985,11 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
   a.Wa = prm->Wa; a.ba = prm->ba; a.Wc = prm->Wc; a.bc = prm->bc; a.Wo = prm->Wo; a.bo = prm->bo; a.cw = prm->class_weight;
   a.enc = enc; a.encA = bf.ENCA; a.y = y; a.use_truth = use_truth; a.emb_mask = emb_mask; a.rnn_mask = rnn_masks;
   a.TOK = bf.TOK; a.PRED = bf.PRED; a.X0 = bf.X0; a.Gt = bf.G; a.Cst = bf.C; a.HR = bf.HR; a.Q = bf.Q; a.ALPHA = bf.ALPHA;
-  a.CVH = bf.CVH; a.HT = bf.HT; a.LOGITS = bf.LOGITS; a.LOSSROWS = bf.LOSSROWS; a.LSE = bf.LSE; a.PART = bf.PART; a.CESTAT = bf.CESTAT;
+  a.CVH = bf.CVH; a.HT = bf.HT; a.LOGITS = bf.LOGITS; a.LOSSROWS = bf.LOSSROWS; a.LSE = bf.LSE; a.PART = bf.PART; a.CESTAT = bf.CESTAT; a.ML = bf.ML;
   a.ctr = bf.ctr;
   a.abort_word = bf.ctr + (size_t)PH_N * a.nbt * CTRS;
   { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
+  a.tick_out = prof_tick_buffer(0);
   ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)PH_N * a.nbt + 1) * CTRS * sizeof(unsigned), s));
   const size_t shm = pdec_lds_floats(chunk, a.H, nsplit) * sizeof(float);
   static bool attr_done = false;
@@ -966,7 +997,10 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
     ASTK_HIP(hipFuncSetAttribute((const void*)decoder_persist_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL(decoder_persist_fwd, dim3(G), dim3(256), shm, s, a);
+  {
+    ProfScope prof(PROF_DEC_FWD, s);
+    hipLaunchKernelGGL(decoder_persist_fwd, dim3(G), dim3(256), shm, s, a);
+  }
   ASTK_LAUNCH_CHECK();
   // Q[s][b][:] = Wa h_top + ba for all steps (needed by the backward's deferred d_enc product)
   ASTK_TRY(gemm_launch(GEMM_NT, gemm_args(a.S * a.B, a.H, a.H, mat(bf.CVH + a.H, 2 * a.H), mat(prm->Wa, a.H), bf.Q, a.H, prm->ba), s));

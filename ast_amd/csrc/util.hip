@@ -21,9 +21,11 @@ const char* last_error() { return g_err; }
 struct ProfState {
   bool on = false;
   std::vector<hipEvent_t> ev[PROF_NCAT];   // start/stop pairs
-  double work[PROF_NCAT] = {0, 0, 0, 0};
+  double work[PROF_NCAT] = {0, 0, 0, 0, 0, 0};
 };
 static ProfState g_prof;
+static float* g_tick = nullptr;     // [2][512] in-kernel phase timers of the persistent decoder kernels
+float* prof_tick_buffer(int which) { return (g_prof.on && g_tick) ? g_tick + 512 * which : nullptr; }
 bool prof_enabled() { return g_prof.on; }
 void prof_start(int cat, hipStream_t s, double work) {
   hipEvent_t e;
@@ -302,6 +304,8 @@ int astk_gemm_f32(int layout, int M, int N, int K, const float* A, long lda, con
 
 int astk_prof_begin(void) {
   for (int c = 0; c < PROF_NCAT; ++c) { g_prof.ev[c].clear(); g_prof.work[c] = 0; }
+  if (!g_tick) ASTK_HIP(hipMalloc((void**)&g_tick, 1024 * sizeof(float)));
+  ASTK_HIP(hipMemset(g_tick, 0, 1024 * sizeof(float)));
   g_prof.on = true;
   return 0;
 }
@@ -325,6 +329,25 @@ int astk_prof_end(double* res) {
   res[2] = ms[PROF_ATTN_BWD]; res[3] = n[PROF_ATTN_BWD];
   res[4] = ms[PROF_GEMM]; res[5] = n[PROF_GEMM]; res[6] = g_prof.work[PROF_GEMM];
   res[7] = ms[PROF_CELL]; res[8] = n[PROF_CELL];
+  // in-kernel attention-phase timing of the persistent decoder kernels: [9] fwd mean us, [10] fwd max-over-workgroups us,
+  // [11] launches ; [12] bwd mean, [13] bwd max, [14] launches
+  for (int k = 9; k < 24; ++k) res[k] = 0;
+  res[16] = ms[PROF_DEC_FWD]; res[17] = n[PROF_DEC_FWD]; res[18] = ms[PROF_DEC_BWD]; res[19] = n[PROF_DEC_BWD];
+  if (g_tick) {
+    float h[1024];
+    ASTK_HIP(hipMemcpy(h, g_tick, sizeof(h), hipMemcpyDeviceToHost));
+    for (int w = 0; w < 2; ++w) {
+      const float* t = h + 512 * w;
+      const double launches = t[256];
+      if (launches > 0) {
+        double sum = 0, mx = 0; int cnt = 0;
+        for (int i = 0; i < 256; ++i) if (t[i] > 0) { sum += t[i]; if (t[i] > mx) mx = t[i]; ++cnt; }
+        res[9 + 3 * w] = cnt ? sum / cnt / launches : 0;
+        res[10 + 3 * w] = mx / launches;
+        res[11 + 3 * w] = launches;
+      }
+    }
+  }
   return 0;
 }
 

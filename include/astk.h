@@ -196,7 +196,9 @@ int astk_scale_f32(float* x, size_t n, float s, void* stream);
 
 /* Optional per-kernel HIP-event timing on the launch stream (bench.py's roofline legs; off by default).
  * astk_prof_end: res[0..1] attention-scan fwd (ms, launches); [2..3] attention-scan bwd; [4..6] GEMMs (ms, launches, flops);
- * [7..8] fused LSTM cells (ms, launches).  res must hold 16 doubles.  Synchronises the device. */
+ * [7..8] fused LSTM cells (ms, launches); [9..11] attention-scan phase inside the persistent decoder forward measured with
+ * in-kernel timestamps (mean us per step over workgroups, slowest workgroup's mean us, launches); [12..14] same for the
+ * backward; [16..19] persistent decoder forward / backward kernels (ms, launches).  res must hold 24 doubles.  Synchronises the device. */
 int astk_prof_begin(void);
 int astk_prof_end(double* res);
 
