@@ -106,6 +106,10 @@ struct GemmArgs {
   int ksplit;
   int batch;
   long sA, sB, sC;
+  // filled by gemm_launch (work decomposition)
+  int kt;            // k-iterations per tile = ceil(K / 32)
+  int tiles_mn;      // tiles per batch matrix
+  long iters_total;  // batch * tiles_mn * kt
 };
 static inline GemmArgs gemm_args(int M, int N, int K, MatView A, MatView B, float* C, long ldc,
                                  const float* bias = nullptr, int mode = GEMM_STORE, int ksplit = 1) {

@@ -12,6 +12,9 @@
 // zero-copy "window" GEMMs over padded channels-last activations and the reverse LSTM direction reads
 // frames through its permutation table instead of a permuted copy.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
 
 namespace astk {
 
@@ -107,115 +110,156 @@ struct Stager {
   }
 };
 
+// Work decomposition ("stream-K"): the launch owns I = tiles * kt k-iterations (kt = ceil(K / BK)), tile-major, and
+// workgroup w of G runs the contiguous range [I*w/G, I*(w+1)/G).  A range covers a run of whole tiles plus at most one
+// partial tile at each end.  A whole tile is written the way `mode` says; a partial tile is accumulated with atomics
+// (for GEMM_STORE the launcher zeroes exactly those tiles first, k_zero_split_tiles).  With G = tiles (one tile each)
+// this degenerates to the classical data-parallel launch; with G = 256 or 512 every CU gets the same number of
+// k-iterations whatever the tile count -- a 400-tile product no longer runs as "2 waves, the second 56% full".
 template <bool A_RK, bool B_RK, bool TWOLVL>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   constexpr int LDA = A_RK ? LD_RK : LD_KR;
   constexpr int LDB = B_RK ? LD_RK : LD_KR;
-  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int tiles_n = (g.N + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int zb = blockIdx.z / g.ksplit, split = blockIdx.z % g.ksplit;
-
-  int kper = (g.K + g.ksplit - 1) / g.ksplit;
-  kper = (kper + BK - 1) / BK * BK;
-  const int kbeg = split * kper;
-  const int kend = min(g.K, kbeg + kper);
-  if (kbeg >= kend) return;
-
-  MatView A = g.A, B = g.B;
-  A.p += (long)zb * g.sA;
-  B.p += (long)zb * g.sB;
-  float* C = g.C + (long)zb * g.sC;
-
-  Stager<A_RK, TWOLVL> sa;
-  Stager<B_RK, TWOLVL> sb;
-  sa.init(A, m0, g.M, tid);
-  sb.init(B, n0, g.N, tid);
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lk = lane >> 5;
-  const int nk = (kend - kbeg + BK - 1) / BK;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int kt_tile = g.kt;
 
-  sa.load(A, kbeg, kend, g.K, m0, g.M);
-  sb.load(B, kbeg, kend, g.K, n0, g.N);
-  sa.store(As);
-  sb.store(Bs);
-  __syncthreads();
+  long it = g.iters_total * (long)blockIdx.x / (long)gridDim.x;
+  const long it_end = g.iters_total * (long)(blockIdx.x + 1) / (long)gridDim.x;
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) {
-      sa.load(A, kbeg + (kt + 1) * BK, kend, g.K, m0, g.M);
-      sb.load(B, kbeg + (kt + 1) * BK, kend, g.K, n0, g.N);
-    }
-    const float* ap = As + lk * LDA + wm * 64 + li;
-    const float* bp = Bs + lk * LDB + wn * 64 + li;
-    // software-pipelined operand fetch: the LDS reads of k-pair kk+2 are issued before the MFMAs of k-pair kk
-    float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
+  while (it < it_end) {
+    const long tile = it / kt_tile;
+    const int k0 = (int)(it - tile * kt_tile);
+    const int k1 = (int)min((long)kt_tile, (long)k0 + (it_end - it));
+    it += k1 - k0;
+    const int zb = (int)(tile / g.tiles_mn);
+    const int tmn = (int)(tile - (long)zb * g.tiles_mn);
+    const int m0 = (tmn / tiles_n) * BM, n0 = (tmn % tiles_n) * BN;
+    const int kbeg = k0 * BK;
+    const int kend = min(g.K, k1 * BK);
+    const bool whole = (k0 == 0) && (k1 == kt_tile);
+
+    MatView A = g.A, B = g.B;
+    A.p += (long)zb * g.sA;
+    B.p += (long)zb * g.sB;
+    float* C = g.C + (long)zb * g.sC;
+
+    Stager<A_RK, TWOLVL> sa;
+    Stager<B_RK, TWOLVL> sb;
+    sa.init(A, m0, g.M, tid);
+    sb.init(B, n0, g.N, tid);
+
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-      if (kk + 2 < BK) {
-        na0 = ap[(kk + 2) * LDA]; na1 = ap[(kk + 2) * LDA + 32];
-        nb0 = bp[(kk + 2) * LDB]; nb1 = bp[(kk + 2) * LDB + 32];
-      }
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-    }
-    // pin the interleave (hipcc otherwise sinks every LDS read directly in front of its MFMAs with lgkmcnt(0)):
-    // reads of k-pair i+1 (2 x ds_read2_b32) go in front of the 4 MFMAs of k-pair i
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int i = 0; i < BK / 2 - 1; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = k1 - k0;
+
+    // Pipeline: tile kt is multiplied out of LDS buffer kt&1 while tile kt+1 moves registers -> the other buffer and
+    // tile kt+2 is in flight global -> registers; one barrier per k-iteration.
+    sa.load(A, kbeg, kend, g.K, m0, g.M);
+    sb.load(B, kbeg, kend, g.K, n0, g.N);
+    sa.store(As[0]);
+    sb.store(Bs[0]);
+    if (nk > 1) {
+      sa.load(A, kbeg + BK, kend, g.K, m0, g.M);
+      sb.load(B, kbeg + BK, kend, g.K, n0, g.N);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     __syncthreads();
-    if (more) {
-      sa.store(As);
-      sb.store(Bs);
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) {
+        sa.store(As[cur ^ 1]);
+        sb.store(Bs[cur ^ 1]);
+      }
+      if (kt + 2 < nk) {
+        sa.load(A, kbeg + (kt + 2) * BK, kend, g.K, m0, g.M);
+        sb.load(B, kbeg + (kt + 2) * BK, kend, g.K, n0, g.N);
+      }
+      const float* ap = As[cur] + lk * LDA + wm * 64 + li;
+      const float* bp = Bs[cur] + lk * LDB + wn * 64 + li;
+      // software-pipelined operand fetch: the LDS reads of k-pair kk+2 are issued before the MFMAs of k-pair kk
+      float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+        if (kk + 2 < BK) {
+          na0 = ap[(kk + 2) * LDA]; na1 = ap[(kk + 2) * LDA + 32];
+          nb0 = bp[(kk + 2) * LDB]; nb1 = bp[(kk + 2) * LDB + 32];
+        }
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+      }
+      // pin the interleave (hipcc otherwise sinks every LDS read directly in front of its MFMAs with lgkmcnt(0)):
+      // reads of k-pair i+1 (2 x ds_read2_b32) go in front of the 4 MFMAs of k-pair i
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+      for (int i = 0; i < BK / 2 - 1; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       __syncthreads();
     }
-  }
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  const bool add_bias = g.bias != nullptr && split == 0;
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const bool add_bias = g.bias != nullptr && k0 == 0;
+    const int mode = whole ? g.mode : GEMM_ATOMIC;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      if (row >= g.M) continue;
-      const long coff = g.c_tn > 0 ? (long)(row / g.c_tn) * g.c_sg + (long)(row % g.c_tn) * g.c_st : (long)row * g.ldc;
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= g.M) continue;
+        const long coff = g.c_tn > 0 ? (long)(row / g.c_tn) * g.c_sg + (long)(row % g.c_tn) * g.c_st : (long)row * g.ldc;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + li;
-        if (col >= g.N) continue;
-        float v = acc[i][j][r];
-        if (add_bias) v += g.bias[col];
-        float* dst = C + coff + col;
-        if (g.mode == GEMM_STORE) *dst = v;
-        else if (g.mode == GEMM_ACCUM) *dst += v;
-        else atomicAdd(dst, v);
+        for (int j = 0; j < 2; ++j) {
+          const int col = n0 + wn * 64 + j * 32 + li;
+          if (col >= g.N) continue;
+          float v = acc[i][j][r];
+          if (add_bias) v += g.bias[col];
+          float* dst = C + coff + col;
+          if (mode == GEMM_STORE) *dst = v;
+          else if (mode == GEMM_ACCUM) *dst += v;
+          else atomicAdd(dst, v);
+        }
       }
     }
+  }
+}
+
+// GEMM_STORE + split tiles: zero the tiles that more than one workgroup will accumulate into.  Block b looks at the
+// boundary between workgroups b and b+1.
+__global__ __launch_bounds__(256) void k_zero_split_tiles(GemmArgs g, int G) {
+  const long it = g.iters_total * (long)(blockIdx.x + 1) / (long)G;
+  if (it % g.kt == 0) return;
+  const long tile = it / g.kt;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int zb = (int)(tile / g.tiles_mn);
+  const int tmn = (int)(tile - (long)zb * g.tiles_mn);
+  const int m0 = (tmn / tiles_n) * BM, n0 = (tmn % tiles_n) * BN;
+  float* C = g.C + (long)zb * g.sC;
+  const int col = n0 + (threadIdx.x & 127);
+  if (col >= g.N) return;
+  for (int r = threadIdx.x >> 7; r < BM; r += 2) {
+    const int row = m0 + r;
+    if (row >= g.M) break;
+    const long coff = g.c_tn > 0 ? (long)(row / g.c_tn) * g.c_sg + (long)(row % g.c_tn) * g.c_st : (long)row * g.ldc;
+    C[coff + col] = 0.f;
   }
 }
 
@@ -237,9 +281,29 @@ int gemm_launch(int layout, const GemmArgs& g, hipStream_t s) {
     if (a_kr && a.A.tn <= 0) { a.A.tn = 0x7fffffff; a.A.sg = 0; a.A.st = a.A.ld; }
     if (b_kr && a.B.tn <= 0) { a.B.tn = 0x7fffffff; a.B.sg = 0; a.B.st = a.B.ld; }
   }
-  const long tiles = (long)cdiv(g.M, BM) * cdiv(g.N, BN);
-  dim3 grid((unsigned)tiles, 1, (unsigned)(g.batch * g.ksplit));
+  a.tiles_mn = cdiv(g.M, BM) * cdiv(g.N, BN);
+  a.kt = cdiv(g.K, BK);
+  const long tiles = (long)a.tiles_mn * g.batch;
+  a.iters_total = tiles * a.kt;
+  // Grid (measured on MI355X, scratch/gemm_bench.py): two co-resident workgroups per CU is the sweet spot of this kernel
+  // (one hides the other's LDS-store/barrier phase), so a product with enough k-iterations is split evenly over 512
+  // workgroups -- 95-111 TFLOP/s on the train step's shapes against 60-93 for one-tile-per-workgroup launches.  Small
+  // products keep one tile per workgroup unless they have too few tiles to occupy the chip.
+  static const int force_g = getenv("ASTK_GEMM_G") ? atoi(getenv("ASTK_GEMM_G")) : -1;   // tuning hook: 0 = one tile per WG
+  long G = tiles;
+  if (a.iters_total >= 512L * 10) G = 512;
+  else if (tiles < 160) G = std::max(tiles, std::min(256L, a.iters_total / 4));
+  if (force_g == 0) G = tiles;
+  else if (force_g > 0) G = std::min<long>(force_g, a.iters_total);
+  const bool split_tiles = G != tiles;
+  static const bool log_shapes = getenv("ASTK_GEMM_LOG") != nullptr;
+  if (log_shapes)
+    fprintf(stderr, "astk_gemm layout=%d M=%d N=%d K=%d batch=%d mode=%d twolvl=%d tiles=%ld G=%ld kt=%d\n", layout, g.M, g.N, g.K,
+            g.batch, g.mode, (int)twolvl, tiles, G, a.kt);
   ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * (double)g.K * g.batch);
+  dim3 grid((unsigned)G, 1, 1);
+  if (split_tiles && g.mode == GEMM_STORE && G > 1)
+    hipLaunchKernelGGL(k_zero_split_tiles, dim3((unsigned)(G - 1)), dim3(256), 0, s, a, (int)G);
   switch (layout) {
     case GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<true, true, false>), grid, dim3(256), 0, s, a); break;
     case GEMM_NN:

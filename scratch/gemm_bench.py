@@ -17,7 +17,10 @@ def run(layout, M, N, K, iters=20, ks=1, mode=0):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     print(f"layout {layout} M{M} N{N} K{K} ks{ks}: {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TFLOP/s  tiles {((M+127)//128)*((N+127)//128)*ks}")
-for lay in (0, 1, 2):
-    run(lay, 4096, 4096, 4096)
-run(0, 6400, 1024, 3072); run(0, 38400, 512, 1152); run(1, 6400, 3072, 1024); run(2, 1024, 3072, 6400, ks=2, mode=2)
-run(0, 8192, 8192, 1024); run(0, 6400, 2048, 3072)
+import os
+print("ASTK_GEMM_G =", os.environ.get("ASTK_GEMM_G"))
+run(0, 4096, 4096, 4096)
+run(0, 76800, 128, 120); run(0, 38400, 512, 1152); run(0, 6400, 1024, 3072); run(1, 6400, 3072, 1024)
+run(2, 1024, 3072, 6400, mode=2, ks=2); run(0, 38400, 128, 2560); run(0, 38400, 128, 2048)
+run(2, 1024, 256, 6400, mode=2, ks=32); run(1, 6400, 512, 512); run(2, 2048, 640, 1248, mode=2, ks=3); run(2, 1098, 512, 1248, mode=2, ks=7)
+run(2, 128, 120, 76800, mode=2, ks=64); run(0, 1248, 512, 512)
