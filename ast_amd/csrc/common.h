@@ -120,6 +120,16 @@ static inline GemmArgs gemm_args(int M, int N, int K, MatView A, MatView B, floa
   return g;
 }
 int gemm_launch(int layout, const GemmArgs& g, hipStream_t s);
+// Several independent products of the same layout in ONE launch (their k-iterations are concatenated and split evenly
+// over the workgroups): used where a phase issues many small products that cannot fill the chip one at a time.
+constexpr int GEMM_GROUP_MAX = 12;
+struct GemmGroup {
+  int n;
+  long iters_total;
+  long iter_start[GEMM_GROUP_MAX + 1];
+  GemmArgs g[GEMM_GROUP_MAX];
+};
+int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s);
 
 // ---- small utility kernels (util.hip)
 int fill_zero(void* p, size_t bytes, hipStream_t s);

@@ -238,11 +238,22 @@ int ksplit_rows(long tiles, int rows) {
   return (int)(s > smax ? smax : s);
 }
 
-// dW (M x N) += A^T B over `rows` rows (A: rows x M, B: rows x N)
-int wgrad(float* dW, long ldw, int M, int N, const float* A, long lda, const float* Bm, long ldb, int rows, hipStream_t s) {
-  const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
-  return gemm_launch(GEMM_TN, gemm_args(M, N, rows, mat(A, lda), mat(Bm, ldb), dW, ldw, nullptr, GEMM_ATOMIC, ksplit_rows(tiles, rows)), s);
-}
+// dW (M x N) += A^T B over `rows` rows (A: rows x M, B: rows x N).  The weight gradients of one backward call are
+// independent products with few tiles each: they are collected and issued as ONE grouped launch.
+struct WgradBatch {
+  GemmArgs list[GEMM_GROUP_MAX];
+  int n = 0;
+  int add(float* dW, long ldw, int M, int N, const float* A, long lda, const float* Bm, long ldb, int rows, hipStream_t s) {
+    if (n == GEMM_GROUP_MAX) ASTK_TRY(flush(s));
+    list[n++] = gemm_args(M, N, rows, mat(A, lda), mat(Bm, ldb), dW, ldw, nullptr, GEMM_ATOMIC, 1);
+    return 0;
+  }
+  int flush(hipStream_t s) {
+    const int m = n;
+    n = 0;
+    return m > 0 ? gemm_launch_group(GEMM_TN, list, m, s) : 0;
+  }
+};
 
 int cell_fwd(const DecPlan& P, const astk_decoder_params* prm, int l, const float* x_in, long ld_x, int in, const float* h_prev,
              const float* c_prev, float* gates, float* c_out, float* h_out, const float* mask, float* hd_out, long ld_hd,
@@ -475,11 +486,12 @@ int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
   }
   // ---- weight gradients: one batched TN GEMM each over the S*B saved rows
   const int SB = S * B;
-  ASTK_TRY(wgrad(g->dWo, A, V, A, P.LOGITS, Vp, P.HT + (size_t)B * A, A, SB, s));
+  WgradBatch wb;
+  ASTK_TRY(wb.add(g->dWo, A, V, A, P.LOGITS, Vp, P.HT + (size_t)B * A, A, SB, s));
   ASTK_TRY(colsum_add_f32(g->dbo, P.LOGITS, Vp, SB, V, s));
-  ASTK_TRY(wgrad(g->dWc, 2 * H, A, 2 * H, P.DPRE, A, P.CVH, 2 * H, SB, s));
+  ASTK_TRY(wb.add(g->dWc, 2 * H, A, 2 * H, P.DPRE, A, P.CVH, 2 * H, SB, s));
   ASTK_TRY(colsum_add_f32(g->dbc, P.DPRE, A, SB, A, s));
-  ASTK_TRY(wgrad(g->dWa, H, H, H, P.DQ, H, P.CVH + H, 2 * H, SB, s));
+  ASTK_TRY(wb.add(g->dWa, H, H, H, P.DQ, H, P.CVH + H, 2 * H, SB, s));
   ASTK_TRY(colsum_add_f32(g->dba, P.DQ, H, SB, H, s));
   for (int l = 0; l < nl; ++l) {
     const int in = l == 0 ? XI : H;
@@ -488,10 +500,11 @@ int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
     if (l == 0) { xin = P.X0; ldx = XI; }
     else if (rnn_masks) { xin = P.HD[l - 1]; ldx = H; }
     else { xin = P.HR[l - 1] + bh; ldx = H; }
-    ASTK_TRY(wgrad(g->lstm[l].dWu, in, 4 * H, in, P.G[l], 4 * H, xin, ldx, SB, s));
-    ASTK_TRY(wgrad(g->lstm[l].dWl, H, 4 * H, H, P.G[l], 4 * H, P.HR[l], H, SB, s));
+    ASTK_TRY(wb.add(g->lstm[l].dWu, in, 4 * H, in, P.G[l], 4 * H, xin, ldx, SB, s));
+    ASTK_TRY(wb.add(g->lstm[l].dWl, H, 4 * H, H, P.G[l], 4 * H, P.HR[l], H, SB, s));
     ASTK_TRY(colsum_add_f32(g->lstm[l].db, P.G[l], 4 * H, SB, 4 * H, s));
   }
+  ASTK_TRY(wb.flush(s));
   hipLaunchKernelGGL(k_embed_bwd, dim3(SB), dim3(128), 0, s, g->d_embed, P.TOK, P.DX0, emb_mask, SB, E, XI);
   ASTK_LAUNCH_CHECK();
   // ---- d_enc[b] = alpha_b^T d_cv_b + ds_b^T q_b   (batched over b, K = S)

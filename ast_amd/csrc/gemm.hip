@@ -117,7 +117,7 @@ struct Stager {
 // this degenerates to the classical data-parallel launch; with G = 256 or 512 every CU gets the same number of
 // k-iterations whatever the tile count -- a 400-tile product no longer runs as "2 waves, the second 56% full".
 template <bool A_RK, bool B_RK, bool TWOLVL>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmGroup grp) {
   constexpr int LDA = A_RK ? LD_RK : LD_KR;
   constexpr int LDB = B_RK ? LD_RK : LD_KR;
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
@@ -127,16 +127,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lk = lane >> 5;
-  const int tiles_n = (g.N + BN - 1) / BN;
-  const int kt_tile = g.kt;
 
-  long it = g.iters_total * (long)blockIdx.x / (long)gridDim.x;
-  const long it_end = g.iters_total * (long)(blockIdx.x + 1) / (long)gridDim.x;
+  long it = grp.iters_total * (long)blockIdx.x / (long)gridDim.x;
+  const long it_end = grp.iters_total * (long)(blockIdx.x + 1) / (long)gridDim.x;
+  int prob = 0;
 
   while (it < it_end) {
-    const long tile = it / kt_tile;
-    const int k0 = (int)(it - tile * kt_tile);
-    const int k1 = (int)min((long)kt_tile, (long)k0 + (it_end - it));
+    while (it >= grp.iter_start[prob + 1]) ++prob;
+    const GemmArgs& g = grp.g[prob];
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int kt_tile = g.kt;
+    const long lit = it - grp.iter_start[prob];
+    const long lend = min(it_end, grp.iter_start[prob + 1]) - grp.iter_start[prob];
+    const long tile = lit / kt_tile;
+    const int k0 = (int)(lit - tile * kt_tile);
+    const int k1 = (int)min((long)kt_tile, (long)k0 + (lend - lit));
     it += k1 - k0;
     const int zb = (int)(tile / g.tiles_mn);
     const int tmn = (int)(tile - (long)zb * g.tiles_mn);
@@ -244,8 +249,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
 // GEMM_STORE + split tiles: zero the tiles that more than one workgroup will accumulate into.  Block b looks at the
 // boundary between workgroups b and b+1.
-__global__ __launch_bounds__(256) void k_zero_split_tiles(GemmArgs g, int G) {
-  const long it = g.iters_total * (long)(blockIdx.x + 1) / (long)G;
+__global__ __launch_bounds__(256) void k_zero_split_tiles(GemmGroup grp, int G) {
+  const long git = grp.iters_total * (long)(blockIdx.x + 1) / (long)G;
+  int prob = 0;
+  while (git >= grp.iter_start[prob + 1]) ++prob;
+  const GemmArgs& g = grp.g[prob];
+  if (g.mode != GEMM_STORE) return;
+  const long it = git - grp.iter_start[prob];
   if (it % g.kt == 0) return;
   const long tile = it / g.kt;
   const int tiles_n = (g.N + BN - 1) / BN;
@@ -265,59 +275,99 @@ __global__ __launch_bounds__(256) void k_zero_split_tiles(GemmArgs g, int G) {
 
 }  // namespace
 
-int gemm_launch(int layout, const GemmArgs& g, hipStream_t s) {
-  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0) return 0;
+static int gemm_prepare(int layout, const GemmArgs& g, GemmArgs& a, bool& twolvl) {
   ASTK_CHECK(g.A.p && g.B.p && g.C, "gemm: null operand");
   ASTK_CHECK(aligned16(g.A.p) && aligned16(g.B.p), "gemm: A/B must be 16-byte aligned");
   ASTK_CHECK((g.A.ld % 4) == 0 && (g.B.ld % 4) == 0 && (g.A.sg % 4) == 0 && (g.A.st % 4) == 0 &&
                  (g.B.sg % 4) == 0 && (g.B.st % 4) == 0 && (g.sA % 4) == 0 && (g.sB % 4) == 0,
              "gemm: leading dimensions / strides must be multiples of 4 floats (lda=%ld ldb=%ld)", g.A.ld, g.B.ld);
   ASTK_CHECK(g.ksplit >= 1 && (g.ksplit == 1 || g.mode == GEMM_ATOMIC), "gemm: split-K needs atomic mode");
-  GemmArgs a = g;
+  a = g;
   const bool a_kr = layout == GEMM_TN, b_kr = layout != GEMM_NT;
   ASTK_CHECK(!(a_kr && g.A.rowidx) && !(b_kr && g.B.rowidx), "gemm: indexed rows are only supported on K-contiguous operands");
-  const bool twolvl = (a_kr && g.A.tn > 0) || (b_kr && g.B.tn > 0);
-  if (twolvl) {   // a plain operand next to a two-level one: express it as one group of INT_MAX rows
-    if (a_kr && a.A.tn <= 0) { a.A.tn = 0x7fffffff; a.A.sg = 0; a.A.st = a.A.ld; }
-    if (b_kr && a.B.tn <= 0) { a.B.tn = 0x7fffffff; a.B.sg = 0; a.B.st = a.B.ld; }
-  }
+  twolvl = (a_kr && g.A.tn > 0) || (b_kr && g.B.tn > 0);
   a.tiles_mn = cdiv(g.M, BM) * cdiv(g.N, BN);
   a.kt = cdiv(g.K, BK);
-  const long tiles = (long)a.tiles_mn * g.batch;
-  a.iters_total = tiles * a.kt;
+  a.iters_total = (long)a.tiles_mn * g.batch * a.kt;
+  return 0;
+}
+
+int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
+  ASTK_CHECK(layout == GEMM_NT || layout == GEMM_NN || layout == GEMM_TN, "gemm: bad layout %d", layout);
+  ASTK_CHECK(n >= 0 && n <= GEMM_GROUP_MAX, "gemm: group of %d products (max %d)", n, GEMM_GROUP_MAX);
+  GemmGroup grp;
+  memset(&grp, 0, sizeof(grp));
+  bool twolvl = false, any_store = false;
+  long tiles = 0;
+  double flops = 0;
+  int min_kt = 0x7fffffff;
+  for (int i = 0; i < n; ++i) {
+    const GemmArgs& g = list[i];
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0) continue;
+    GemmArgs& a = grp.g[grp.n];
+    bool tl = false;
+    ASTK_TRY(gemm_prepare(layout, g, a, tl));
+    twolvl = twolvl || tl;
+    grp.iter_start[grp.n] = grp.iters_total;
+    grp.iters_total += a.iters_total;
+    tiles += (long)a.tiles_mn * g.batch;
+    flops += 2.0 * g.M * g.N * (double)g.K * g.batch;
+    any_store = any_store || g.mode == GEMM_STORE;
+    min_kt = std::min(min_kt, a.kt);
+    ++grp.n;
+  }
+  if (grp.n == 0) return 0;
+  for (int i = grp.n; i <= GEMM_GROUP_MAX; ++i) grp.iter_start[i] = grp.iters_total;
+  if (twolvl) {   // a plain operand next to a two-level one: express it as one group of INT_MAX rows
+    const bool a_kr = layout == GEMM_TN, b_kr = layout != GEMM_NT;
+    for (int i = 0; i < grp.n; ++i) {
+      GemmArgs& a = grp.g[i];
+      if (a_kr && a.A.tn <= 0) { a.A.tn = 0x7fffffff; a.A.sg = 0; a.A.st = a.A.ld; }
+      if (b_kr && a.B.tn <= 0) { a.B.tn = 0x7fffffff; a.B.sg = 0; a.B.st = a.B.ld; }
+    }
+  }
   // Grid (measured on MI355X, scratch/gemm_bench.py): two co-resident workgroups per CU is the sweet spot of this kernel
-  // (one hides the other's LDS-store/barrier phase), so a product with enough k-iterations is split evenly over 512
-  // workgroups -- 95-111 TFLOP/s on the train step's shapes against 60-93 for one-tile-per-workgroup launches.  Small
+  // (one hides the other's LDS-store/barrier phase), so a launch with enough k-iterations is split evenly over 512
+  // workgroups -- 100-111 TFLOP/s on the train step's shapes against 60-93 for one-tile-per-workgroup launches.  Small
   // products keep one tile per workgroup unless they have too few tiles to occupy the chip.
   static const int force_g = getenv("ASTK_GEMM_G") ? atoi(getenv("ASTK_GEMM_G")) : -1;   // tuning hook: 0 = one tile per WG
   long G = tiles;
-  if (a.iters_total >= 512L * 10) G = 512;
-  else if (tiles < 160) G = std::max(tiles, std::min(256L, a.iters_total / 4));
-  if (force_g == 0) G = tiles;
-  else if (force_g > 0) G = std::min<long>(force_g, a.iters_total);
-  const bool split_tiles = G != tiles;
+  bool aligned = true;   // workgroup boundaries fall on tile boundaries
+  if (grp.iters_total >= 512L * 10) { G = 512; aligned = false; }
+  else if (tiles < 160) {
+    const long g2 = std::min(256L, grp.iters_total / 4);
+    if (g2 > tiles) { G = g2; aligned = false; }
+  }
+  if (force_g > 0) { G = std::min<long>(force_g, grp.iters_total); aligned = false; }
+  if (aligned && grp.n > 1) {
+    // one tile per workgroup needs boundaries on tile boundaries: only true for uniform kt; otherwise fall back to an even split
+    bool uniform = true;
+    for (int i = 1; i < grp.n; ++i) uniform = uniform && grp.g[i].kt == grp.g[0].kt;
+    if (!uniform) { G = std::min(512L, std::max(1L, grp.iters_total / std::max(1, min_kt))); aligned = false; }
+  }
   static const bool log_shapes = getenv("ASTK_GEMM_LOG") != nullptr;
   if (log_shapes)
-    fprintf(stderr, "astk_gemm layout=%d M=%d N=%d K=%d batch=%d mode=%d twolvl=%d tiles=%ld G=%ld kt=%d\n", layout, g.M, g.N, g.K,
-            g.batch, g.mode, (int)twolvl, tiles, G, a.kt);
-  ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * (double)g.K * g.batch);
+    for (int i = 0; i < grp.n; ++i)
+      fprintf(stderr, "astk_gemm layout=%d M=%d N=%d K=%d batch=%d mode=%d twolvl=%d group=%d/%d G=%ld kt=%d\n", layout, grp.g[i].M,
+              grp.g[i].N, grp.g[i].K, grp.g[i].batch, grp.g[i].mode, (int)twolvl, i, grp.n, G, grp.g[i].kt);
+  ProfScope prof(PROF_GEMM, s, flops);
   dim3 grid((unsigned)G, 1, 1);
-  if (split_tiles && g.mode == GEMM_STORE && G > 1)
-    hipLaunchKernelGGL(k_zero_split_tiles, dim3((unsigned)(G - 1)), dim3(256), 0, s, a, (int)G);
+  if (!aligned && any_store && G > 1) hipLaunchKernelGGL(k_zero_split_tiles, dim3((unsigned)(G - 1)), dim3(256), 0, s, grp, (int)G);
   switch (layout) {
-    case GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<true, true, false>), grid, dim3(256), 0, s, a); break;
+    case GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<true, true, false>), grid, dim3(256), 0, s, grp); break;
     case GEMM_NN:
-      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<true, false, true>), grid, dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((gemm_f32_kernel<true, false, false>), grid, dim3(256), 0, s, a);
+      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<true, false, true>), grid, dim3(256), 0, s, grp);
+      else hipLaunchKernelGGL((gemm_f32_kernel<true, false, false>), grid, dim3(256), 0, s, grp);
       break;
-    case GEMM_TN:
-      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<false, false, true>), grid, dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((gemm_f32_kernel<false, false, false>), grid, dim3(256), 0, s, a);
+    default:
+      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<false, false, true>), grid, dim3(256), 0, s, grp);
+      else hipLaunchKernelGGL((gemm_f32_kernel<false, false, false>), grid, dim3(256), 0, s, grp);
       break;
-    default: ASTK_CHECK(false, "gemm: bad layout %d", layout);
   }
   ASTK_LAUNCH_CHECK();
   return 0;
 }
+
+int gemm_launch(int layout, const GemmArgs& g, hipStream_t s) { return gemm_launch_group(layout, &g, 1, s); }
 
 }  // namespace astk

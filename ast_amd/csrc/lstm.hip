@@ -255,6 +255,8 @@ int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
       }
     ASTK_TRY(lstm_persist_bwd_launch(cells, P.nd * P.nl, P.nl, T, B, h, H, P.counters, s));
   }
+  GemmArgs wg[GEMM_GROUP_MAX];   // weight-gradient products, issued as grouped launches
+  int nwg = 0;
   for (int l = P.nl - 1; l >= 0; --l) {
     const bool top = l == P.nl - 1;
     const int in = l == 0 ? P.in : h;
@@ -300,12 +302,8 @@ int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
       const int rows = T * B;
       // dWl (4h,h) += sum_{i>=1} dz_i^T h_{i-1}
       if (T > 1) {
-        const long tiles = (long)cdiv(4 * h, 128) * cdiv(h, 128);
-        int ks = (int)(512 / tiles);
-        if (ks < 1) ks = 1;
-        if (ks > (rows - B) / 128) ks = (rows - B) / 128 > 0 ? (rows - B) / 128 : 1;
-        ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(4 * h, h, rows - B, mat(dz + (size_t)B * 4 * h, 4 * h), mat(P.HR[dd][l], h), g.dWl, h,
-                                                nullptr, GEMM_ATOMIC, ks), s));
+        if (nwg == GEMM_GROUP_MAX) { ASTK_TRY(gemm_launch_group(GEMM_TN, wg, nwg, s)); nwg = 0; }
+        wg[nwg++] = gemm_args(4 * h, h, rows - B, mat(dz + (size_t)B * 4 * h, 4 * h), mat(P.HR[dd][l], h), g.dWl, h, nullptr, GEMM_ATOMIC, 1);
       }
       // dWu (4h,in) += dz^T X   (reverse stack, layer 0: dz is first re-ordered to frame order, sum_i dz_i^T x[perm i] = sum_f dz[inv f]^T x_f)
       {
@@ -319,11 +317,12 @@ int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
             dzu = P.GATH;
           }
         } else Xv = mat(masks ? P.HD[dd][l - 1] : P.HR[dd][l - 1], h);
-        const long tiles = (long)cdiv(4 * h, 128) * cdiv(in, 128);
-        int ks = (int)(512 / tiles);
-        if (ks < 1) ks = 1;
-        if (ks > rows / 128) ks = rows / 128 > 0 ? rows / 128 : 1;
-        ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(4 * h, in, rows, mat(dzu, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, ks), s));
+        if (l == 0 && dd == 1) {   // GATH is a single scratch buffer: issue this product right away
+          ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(4 * h, in, rows, mat(dzu, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, 1), s));
+        } else {
+          if (nwg == GEMM_GROUP_MAX) { ASTK_TRY(gemm_launch_group(GEMM_TN, wg, nwg, s)); nwg = 0; }
+          wg[nwg++] = gemm_args(4 * h, in, rows, mat(dzu, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, 1);
+        }
       }
       ASTK_TRY(colsum_add_f32(g.db, dz, 4 * h, rows, 4 * h, s));
       // gradient wrt the layer input
@@ -336,6 +335,7 @@ int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
       }
     }
   }
+  if (nwg > 0) ASTK_TRY(gemm_launch_group(GEMM_TN, wg, nwg, s));
   return 0;
 }
 
