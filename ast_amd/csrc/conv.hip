@@ -164,24 +164,16 @@ __global__ void k_phase_w(const float* __restrict__ W, float* __restrict__ Wd, i
   }
 }
 
-// column sums of Y and Y^2 ( -> double atomics ). Thread layout: Cw = min(C,256) columns x 256/Cw row lanes.
-__global__ __launch_bounds__(256) void k_colstats(const float* __restrict__ Y, int rows, int C, double* __restrict__ stat,
-                                                  int rows_per_block) {
-  const int Cw = C < 256 ? C : 256;
-  const int nsub = 256 / Cw;
-  const int c0 = threadIdx.x % Cw, rs = threadIdx.x / Cw;
-  if (rs >= nsub) return;
-  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  for (int c = c0; c < C; c += Cw) {
-    float s = 0.f, s2 = 0.f;
-    for (int r = r0 + rs; r < r1; r += nsub) {
-      const float v = Y[(long)r * C + c];
-      s += v;
-      s2 += v * v;
-    }
-    atomicAdd(&stat[c], (double)s);
-    atomicAdd(&stat[C + c], (double)s2);
-  }
+// column sums of Y and Y^2 ( -> double atomics ), colreduce_block skeleton
+__global__ __launch_bounds__(256) void k_colstats(const float* __restrict__ Y, int rows, int C, double* __restrict__ stat) {
+  colreduce_block<2>(
+      rows, C,
+      [&](int r, int c, float4* a) {
+        const float4 v = *reinterpret_cast<const float4*>(Y + (long)r * C + c);
+        a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
+        a[1].x += v.x * v.x; a[1].y += v.y * v.y; a[1].z += v.z * v.z; a[1].w += v.w * v.w;
+      },
+      [&](int col, int st, float v) { atomicAdd(&stat[st * C + col], (double)v); });
 }
 
 // bn[0]=mean, bn[1]=inv_std, bn[2]=scale, bn[3]=shift ; running statistics per Chainer-sem A4
@@ -258,26 +250,25 @@ __global__ __launch_bounds__(256) void k_seq_to_rows(const float* __restrict__ d
   }
 }
 
-// backward statistics: stat[c] = sum g, stat[C+c] = sum g*xhat, g = G*(bn(Y)>0)
+// backward statistics: stat[c] = sum g, stat[C+c] = sum g*xhat, g = G*(bn(Y)>0)   (colreduce_block skeleton)
 __global__ __launch_bounds__(256) void k_bn_bwd_stats(const float* __restrict__ Y, const float* __restrict__ G, const float* __restrict__ bn,
-                                                      int rows, int C, double* __restrict__ stat, int rows_per_block) {
-  const int Cw = C < 256 ? C : 256;
-  const int nsub = 256 / Cw;
-  const int c0 = threadIdx.x % Cw, rs = threadIdx.x / Cw;
-  if (rs >= nsub) return;
-  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  for (int c = c0; c < C; c += Cw) {
-    const float mean = bn[c], inv = bn[C + c], sc = bn[2 * C + c], sh = bn[3 * C + c];
-    float s = 0.f, s2 = 0.f;
-    for (int r = r0 + rs; r < r1; r += nsub) {
-      const float y = Y[(long)r * C + c];
-      const float g = (y * sc + sh > 0.f) ? G[(long)r * C + c] : 0.f;
-      s += g;
-      s2 += g * (y - mean) * inv;
-    }
-    atomicAdd(&stat[c], (double)s);
-    atomicAdd(&stat[C + c], (double)s2);
-  }
+                                                      int rows, int C, double* __restrict__ stat) {
+  const int q = blockIdx.x * min((C + 3) >> 2, COLREDUCE_CL) + threadIdx.x % min((C + 3) >> 2, COLREDUCE_CL);
+  const int cc = min(q * 4, C - 4);   // C % 4 == 0 (checked by the launcher)
+  const float4 mean = *reinterpret_cast<const float4*>(bn + cc), inv = *reinterpret_cast<const float4*>(bn + C + cc);
+  const float4 sc = *reinterpret_cast<const float4*>(bn + 2 * C + cc), sh = *reinterpret_cast<const float4*>(bn + 3 * C + cc);
+  colreduce_block<2>(
+      rows, C,
+      [&](int r, int c, float4* a) {
+        const float4 y = *reinterpret_cast<const float4*>(Y + (long)r * C + c);
+        const float4 gr = *reinterpret_cast<const float4*>(G + (long)r * C + c);
+        const float g0 = (y.x * sc.x + sh.x > 0.f) ? gr.x : 0.f, g1 = (y.y * sc.y + sh.y > 0.f) ? gr.y : 0.f;
+        const float g2 = (y.z * sc.z + sh.z > 0.f) ? gr.z : 0.f, g3 = (y.w * sc.w + sh.w > 0.f) ? gr.w : 0.f;
+        a[0].x += g0; a[0].y += g1; a[0].z += g2; a[0].w += g3;
+        a[1].x += g0 * (y.x - mean.x) * inv.x; a[1].y += g1 * (y.y - mean.y) * inv.y;
+        a[1].z += g2 * (y.z - mean.z) * inv.z; a[1].w += g3 * (y.w - mean.w) * inv.w;
+      },
+      [&](int col, int st, float v) { atomicAdd(&stat[st * C + col], (double)v); });
 }
 // dY[prow(m)][c] = scale*(g - (xhat*dgamma + dbeta)/rows) ; also accumulates dgamma/dbeta (block 0)
 __global__ void k_bn_bwd_apply(const float* __restrict__ Y, const float* __restrict__ G, const float* __restrict__ bn,
@@ -375,8 +366,7 @@ int astk_conv_bn_relu_fwd(const astk_cnn_desc* d, const astk_cnn_layer_params* L
     // ---- batch statistics -> scale/shift
     if (train) {
       ASTK_TRY(fill_zero(P.stat, 2 * (size_t)C * sizeof(double), s));
-      const int rpb = 128;
-      hipLaunchKernelGGL(k_colstats, dim3(cdiv(rows, rpb)), dim3(256), 0, s, P.Y[i], rows, C, P.stat, rpb);
+      hipLaunchKernelGGL(k_colstats, colreduce_grid(rows, C), dim3(256), 0, s, P.Y[i], rows, C, P.stat);
       ASTK_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, s, P.stat, C, (double)rows, L[i].gamma, L[i].beta,
@@ -415,8 +405,7 @@ int astk_conv_bn_relu_bwd(const astk_cnn_desc* d, const astk_cnn_layer_params* L
     const int C = P.Cn[i], rows = P.rows[i];
     // ---- ReLU + BatchNorm backward: G (grad wrt post-ReLU) -> DY[i] (grad wrt raw conv output)
     ASTK_TRY(fill_zero(P.stat, 2 * (size_t)C * sizeof(double), s));
-    const int rpb = 128;
-    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(cdiv(rows, rpb)), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], rows, C, P.stat, rpb);
+    hipLaunchKernelGGL(k_bn_bwd_stats, colreduce_grid(rows, C), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], rows, C, P.stat);
     ASTK_LAUNCH_CHECK();
     const int Tp = P.Tn[i] + P.dF[i] + P.dB[i];
     if (P.dF[i] + P.dB[i] > 0) ASTK_TRY(fill_zero(P.DY[i], (size_t)B * F * Tp * C * sizeof(float), s));

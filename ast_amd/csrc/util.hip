@@ -80,19 +80,16 @@ __global__ void k_transpose(float* dst, long ldd, const float* src, long lds, in
   }
 }
 
-// dst[c] += sum_r src[r][c]: one block per 64 columns x row slab, float partials then one atomic per column.
-__global__ void k_colsum(float* dst, const float* src, long lds, int rows, int cols, int rows_per_block) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int w = threadIdx.x >> 6;
-  const int r0 = blockIdx.y * rows_per_block;
-  const int r1 = min(rows, r0 + rows_per_block);
-  float s = 0.f;
-  if (c < cols)
-    for (int r = r0 + w; r < r1; r += 4) s += src[(long)r * lds + c];
-  red[w][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (w == 0 && c < cols) atomicAdd(&dst[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+// dst[c] += sum_r src[r][c]   (colreduce_block skeleton, one atomic per column and row slab)
+__global__ __launch_bounds__(256) void k_colsum(float* dst, const float* __restrict__ src, long lds, int rows, int cols) {
+  colreduce_block<1>(
+      rows, cols,
+      [&](int r, int c, float4* a) {
+        // columns past `cols` inside the last quad are readable (lds is a multiple of 4) and never emitted
+        const float4 v = *reinterpret_cast<const float4*>(src + (long)r * lds + c);
+        a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
+      },
+      [&](int col, int, float v) { atomicAdd(&dst[col], v); });
 }
 
 __global__ void k_scale(float* x, size_t n, float s) {
@@ -224,8 +221,8 @@ int transpose_f32(float* dst, long ldd, const float* src, long lds, int rows, in
 }
 int colsum_add_f32(float* dst, const float* src, long lds, int rows, int cols, hipStream_t s) {
   if (rows <= 0 || cols <= 0) return 0;
-  int rpb = 256;
-  hipLaunchKernelGGL(k_colsum, dim3(cdiv(cols, 64), cdiv(rows, rpb)), dim3(256), 0, s, dst, src, lds, rows, cols, rpb);
+  ASTK_CHECK((lds % 4) == 0 && aligned16(src), "colsum: source must be 16-byte aligned with a leading dimension multiple of 4");
+  hipLaunchKernelGGL(k_colsum, colreduce_grid(rows, cols), dim3(256), 0, s, dst, src, lds, rows, cols);
   ASTK_LAUNCH_CHECK();
   return 0;
 }
