@@ -19,6 +19,9 @@ namespace astk {
 struct PersistCellHost {
   const float *Wl, *Wu, *bias, *zx, *xin, *mask, *WlT, *WuT_up, *dz_up, *d_enc, *d_hT, *d_cT;
   float *gates, *C, *HR, *HD, *enc;
+  unsigned long long* gran;
+  const unsigned long long* gran_nb;
+  const float* nb_mask;
   int reverse_pos, layer;
 };
 bool lstm_persist_applicable(int T, int B, int h, int nl, int nd);
@@ -38,6 +41,7 @@ struct LstmPlan {
   float* WlT[2][ASTK_MAX_RNN_LAYERS];  // (h, 4h)
   float* WuT[2][ASTK_MAX_RNN_LAYERS];  // (h, 4h) transposed upward weights of layers >= 1 (persistent backward)
   unsigned* counters;                  // arrival counters of the persistent kernels
+  unsigned long long* GRAN[2][ASTK_MAX_RNN_LAYERS];  // granule hand-off buffers of the persistent kernels: (T,B,4h) x {value, tag}
   float* GATH;                         // (T,B,4h) dz of the reverse stack's layer 0 re-ordered to frame order
   float* DX[2];                        // (T,B,h) gradient wrt a layer's input (layers >= 1)
   float* DC[2][2];                     // dc ping-pong (B,h)
@@ -70,6 +74,8 @@ int make_plan(const astk_lstm_stack_desc* d, void* ws, bool with_masks, LstmPlan
   (void)with_masks;
   P.GATH = c.take<float>(P.nd > 1 ? tb * 4 * P.h : 4);
   P.counters = c.take<unsigned>(((size_t)P.nd * P.nl * ((P.B + 15) / 16) + 2) * 64);
+  for (int dd = 0; dd < P.nd; ++dd)
+    for (int l = 0; l < P.nl; ++l) P.GRAN[dd][l] = c.take<unsigned long long>(tb * 4 * P.h);
   P.bytes = c.total();
   return 0;
 }
@@ -155,6 +161,9 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
         c.enc = top ? enc_states + (size_t)dd * h : nullptr;
         c.reverse_pos = dd == 1;
         c.layer = l;
+        c.gran = P.GRAN[dd][l];
+        c.gran_nb = l > 0 ? P.GRAN[dd][l - 1] : nullptr;
+        c.nb_mask = (l > 0 && masks) ? masks + ((size_t)dd * P.nl + l - 1) * T * bh : nullptr;
       }
     }
     ASTK_TRY(lstm_persist_fwd_launch(cells, P.nd * P.nl, P.nl, T, B, h, H, P.counters, s));

@@ -17,6 +17,7 @@
 // workgroup raises the abort word, every poll loop checks it, and the grid drains.
 // Residency: the launcher only uses this path when the whole grid fits one workgroup per CU (<= 256 workgroups).
 #include "common.h"
+#include <type_traits>
 
 namespace astk {
 
@@ -272,6 +273,230 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd(PFwdArgs a) {
 #undef TICK
 }
 
+
+// ------------------------------------------------------------------ forward, granule hand-off (R2)
+// Same work split as lstm_persist_fwd, different transport: every h value is published as ONE 8-byte {value, tag}
+// granule (sc1 store, tag = t + 1, the buffer is zeroed before every launch), and every consuming WAVE sweeps exactly
+// the granules its own MFMA fragments need until all tags match -- the data is the flag.  Per step this removes the
+// producer's drain + barrier + counter add and the consumer's counter poll + barrier (three dependent fabric round
+// trips) from the recurrence's critical path, and waves no longer wait for producers they do not read.
+// A light poll of one 16-byte pair per lane precedes the full sweep so that waiting waves do not flood the fabric.
+// ---- tag-free hand-off: the data is the flag.
+// A hand-off buffer is filled with SENTINEL words (0xFFFFFFFF, a NaN pattern no finite activation and no arithmetic NaN
+// has) by a memset node before every launch; producers store each value ONCE, write-through (sc1), every value to its own
+// (step, row, column) slot; a consuming WAVE loads exactly the fragments its MFMAs need (sc1) and re-reads them until no
+// word is the sentinel.  4-byte stores are single-copy atomic, nothing is reused within a launch, so no tag, no flag, no
+// drain, no barrier is needed, and the buffers double as the saved activations the later launches read.
+constexpr unsigned SENTINEL = 0xffffffffu;
+template <int NB>
+__device__ __forceinline__ void frag_issue(__amdgpu_buffer_rsrc_t rs, int byte_off, int wave, u32x4 (&g)[NB]) {
+#pragma unroll
+  for (int i = 0; i < NB; ++i) g[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off + 64 * (wave + 4 * i), 0, 16);   // aux 16 = sc1
+}
+template <int NB>
+__device__ __forceinline__ bool frag_ok(const u32x4 (&g)[NB]) {
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) ok = ok && (g[i].x != SENTINEL) && (g[i].y != SENTINEL) && (g[i].z != SENTINEL) && (g[i].w != SENTINEL);
+  return __all(ok);
+}
+// Slow path: some fragment was not there yet.  Poll ONE fragment per lane until it is complete (waiting waves must not
+// flood the fabric with full sweeps), then re-read everything; repeat until complete.  Bounded; a time-out raises the
+// abort word, which every other spin checks, and the grid drains.
+template <int NB>
+__device__ __forceinline__ void frag_wait(__amdgpu_buffer_rsrc_t rs, int byte_off, int wave, u32x4 (&g)[NB], bool& dead, unsigned* abort_word) {
+  unsigned spins = 0;
+  while (!dead) {
+    const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off + 64 * wave, 0, 16);
+    if (__all((c.x != SENTINEL) & (c.y != SENTINEL) & (c.z != SENTINEL) & (c.w != SENTINEL))) {
+      frag_issue<NB>(rs, byte_off, wave, g);
+      if (frag_ok<NB>(g)) return;
+    }
+    if ((++spins & 63u) == 0) {
+      if (ld_flag(abort_word) != 0) dead = true;
+      else if (spins > (1u << 21)) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; }
+    }
+  }
+}
+__device__ __forceinline__ float4 frag_vals(const u32x4& g) {
+  return make_float4(__uint_as_float(g.x), __uint_as_float(g.y), __uint_as_float(g.z), __uint_as_float(g.w));
+}
+
+// Schedule of one step t (wave view).  vmcnt retires in issue order and the compiler cannot count memory operations
+// across branches, so every wait in the loop is in effect "everything issued so far"; the schedule is therefore built so
+// that at the step's ONE wait point W_t only the young operations of the recurrence's critical path are pending:
+//   top:   issue the h_{t-1} fragment loads (this step's hand-off stores of h_{t-1} went out just before)
+//          upward MFMAs of step t from REGISTERS (ax: fetched at W_{t-1})
+//   W_t:   h fragments complete? (slow path: poll)   x_{t+1} fragments complete? (issued a whole step ago) -> ax
+//   after: off-path traffic -- prefetch x_{t+2}, zx/mask of step t+1, the saved gates/cell state of step t-1
+//          recurrent MFMAs -> LDS reduction (one barrier) -> gates -> hand-off stores of h_t (HR, and HD for the layer above)
+// The layer above therefore trails the layer below by two steps.
+// Code shape: everything a wait depends on is UNCONDITIONAL inside the loop (HAS_UP is a template parameter, step 0 is
+// peeled, prefetch indices are clamped instead of guarded): a conditionally issued load becomes a phi of "old registers /
+// load result", and hipcc then copies the result right behind the load, i.e. waits for it at the point of issue.
+template <int KB, bool HAS_UP>
+__device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& c, float* red0, float* red1) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int bt = blockIdx.y, j0 = blockIdx.x * 16;
+  const int T = a.T, B = a.B, h = a.h;
+  const int m0 = bt * 16;
+  bool dead = false;
+
+  float4 wl[KB][4], wu[HAS_UP ? KB : 1][4];
+#pragma unroll
+  for (int i = 0; i < KB; ++i) {
+    const int s = wave + 4 * i;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const long row = 4 * (j0 + r) + g;
+      wl[i][g] = *reinterpret_cast<const float4*>(c.Wl + row * h + 16 * s + 4 * q);
+      if (HAS_UP) wu[i][g] = *reinterpret_cast<const float4*>(c.Wu + row * h + 16 * s + 4 * q);
+    }
+  }
+  const __amdgpu_buffer_rsrc_t r_own = make_rsrc(c.HR);
+  const __amdgpu_buffer_rsrc_t r_below = make_rsrc(HAS_UP ? c.xin : c.HR);
+  const int arow = min(m0 + r, B - 1);
+  const int eb = m0 + (tid >> 4), eu = j0 + (tid & 15);      // epilogue ownership: (batch row, unit)
+  const bool evalid = eb < B;
+  const long ebc = evalid ? eb : 0;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (HAS_UP) bias4 = *reinterpret_cast<const float4*>(c.bias + 4 * eu);
+  const bool use_mask = c.mask != nullptr;
+  const float* maskp = use_mask ? c.mask : c.C;   // always a readable (T,B,h) buffer: the mask load is unconditional
+  float c_state = 0.f;
+  const int step_bytes = B * h * 4;
+  const int frag0 = (arow * h + 4 * q) * 4;   // byte offset of this lane's fragment row at step 0
+  u32x4 gx[KB];
+  float4 ax[KB];
+  // what only later launches read, stored half a step late
+  float4 p_gates = make_float4(0.f, 0.f, 0.f, 0.f);
+  float p_hd = 0.f, p_c = 0.f;
+  auto store_saved = [&](int ts) {
+    if (!evalid) return;
+    const long tbs = (long)ts * B + eb;
+    *reinterpret_cast<float4*>(c.gates + tbs * 4 * h + 4 * eu) = p_gates;
+    c.C[tbs * h + eu] = p_c;
+    if (c.enc) {
+      const int pos = c.reverse_pos ? T - 1 - ts : ts;
+      c.enc[((long)eb * T + pos) * a.H + eu] = p_hd;
+    }
+  };
+  long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int slow_x = 0, slow_h = 0;
+  const bool timing = (a.dbg & 8) != 0;
+#define TICK(i, t0) if (timing) { __builtin_amdgcn_sched_barrier(0); const long long now_ = wall_clock64(); tk[i] += now_ - t0; t0 = now_; __builtin_amdgcn_sched_barrier(0); }
+
+  // ---- prologue: inputs of step 0; x_0 into registers, x_1 in flight
+  float4 zadd = bias4, zadd_n = bias4;
+  float mk_raw, mk_raw_n;
+  if (!HAS_UP) zadd = *reinterpret_cast<const float4*>(c.zx + ebc * 4 * h + 4 * eu);
+  mk_raw = maskp[ebc * h + eu];
+  if (HAS_UP) {
+    frag_issue<KB>(r_below, frag0, wave, gx);
+    if (!frag_ok<KB>(gx)) frag_wait<KB>(r_below, frag0, wave, gx, dead, a.abort_word);
+#pragma unroll
+    for (int i = 0; i < KB; ++i) ax[i] = frag_vals(gx[i]);
+    frag_issue<KB>(r_below, frag0 + min(1, T - 1) * step_bytes, wave, gx);
+  }
+
+  // One step.  FIRST: no recurrent part (h_{-1} = 0).
+  auto step = [&](auto first_tag, int t) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    long long t0 = timing ? wall_clock64() : 0;
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frag = frag0 + t * step_bytes;
+    u32x4 gh[KB];
+    if (!FIRST) frag_issue<KB>(r_own, frag - step_bytes, wave, gh);   // in flight behind the upward MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    if (HAS_UP) {
+#pragma unroll
+      for (int i = 0; i < KB; ++i) { MFMA4G(acc, ax[i], wu[i]) }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    TICK(0, t0)
+    // ---- W_t
+    if (!FIRST) {
+      if (!frag_ok<KB>(gh)) { ++slow_h; frag_wait<KB>(r_own, frag - step_bytes, wave, gh, dead, a.abort_word); }
+    }
+    TICK(1, t0)
+    const int t1 = min(t + 1, T - 1), t2 = min(t + 2, T - 1);
+    if (HAS_UP) {   // x_{t+1}: issued a whole step ago
+      if (!frag_ok<KB>(gx)) { ++slow_x; frag_wait<KB>(r_below, frag0 + t1 * step_bytes, wave, gx, dead, a.abort_word); }
+#pragma unroll
+      for (int i = 0; i < KB; ++i) ax[i] = frag_vals(gx[i]);
+    }
+    // Everything issued so far has landed (that is what W_t is); saying so explicitly lets the compiler drop its own
+    // conservative waits behind the slow path's merge, which would otherwise stall the recurrent MFMAs on the off-path
+    // loads issued next.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    TICK(2, t0)
+    // ---- off-path traffic
+    if (HAS_UP) frag_issue<KB>(r_below, frag0 + t2 * step_bytes, wave, gx);
+    {
+      const long tbs = (long)t1 * B + ebc;
+      if (!HAS_UP) zadd_n = *reinterpret_cast<const float4*>(c.zx + tbs * 4 * h + 4 * eu);
+      mk_raw_n = maskp[tbs * h + eu];
+    }
+    if (!FIRST) store_saved(t - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    TICK(3, t0)
+    if (!FIRST) {
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        const float4 ah = frag_vals(gh[i]);
+        MFMA4G(acc, ah, wl[i])
+      }
+    }
+    // ---- 4-wave K reduction through LDS (double-buffered: one barrier per step)
+    float* rd = (t & 1) ? red1 : red0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(&rd[((wave * 4 + g) * 64 + lane) * 4]) = acc[g];
+    TICK(4, t0)
+    __syncthreads();
+    TICK(5, t0)
+    {
+      const int row = tid >> 4, col = tid & 15;
+      const int src = ((row >> 2) * 16 + col) * 4 + (row & 3);
+      float z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        z[g] = rd[(0 * 4 + g) * 256 + src] + rd[(1 * 4 + g) * 256 + src] + rd[(2 * 4 + g) * 256 + src] + rd[(3 * 4 + g) * 256 + src];
+      const float ga = tanhf(z[0] + zadd.x), gi = sigm(z[1] + zadd.y), gf = sigm(z[2] + zadd.z), go = sigm(z[3] + zadd.w);
+      c_state = ga * gi + gf * c_state;
+      const float hh = go * tanhf(c_state);
+      const float hd = use_mask ? hh * mk_raw : hh;
+      // the hand-off: the values themselves, write-through; nothing to drain or signal
+      if (evalid) {
+        const long o = ((long)t * B + eb) * h + eu;
+        st4_sc1(c.HR + o, hh);
+        if (c.HD) st4_sc1(c.HD + o, hd);
+      }
+      p_gates = make_float4(ga, gi, gf, go);
+      p_hd = hd; p_c = c_state;
+    }
+    zadd = zadd_n; mk_raw = mk_raw_n;
+    TICK(6, t0)
+  };
+  step(std::true_type{}, 0);
+  for (int t = 1; t < T; ++t) step(std::false_type{}, t);
+  store_saved(T - 1);
+  if (timing && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0)
+    printf("persist_fwd_g cell %d (layer %d) wave %d: per-step 10ns ticks: issue+xmfma %lld  h_wait %lld  take_x %lld  traffic %lld  hmfma+lds %lld  barrier %lld  epilogue %lld  slow x %d h %d\n",
+           (int)blockIdx.z, c.layer, wave, tk[0] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T, tk[5] / T, tk[6] / T, slow_x, slow_h);
+#undef TICK
+}
+
+template <int KB>
+__global__ __launch_bounds__(256, 1) void lstm_persist_fwd_g(PFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[2][4 * 4 * 256];
+  const PCellF& c = a.c[blockIdx.z];
+  if (c.layer > 0) lstm_fwd_steps<KB, true>(a, c, red[0], red[1]);
+  else lstm_fwd_steps<KB, false>(a, c, red[0], red[1]);
+}
+
 // ------------------------------------------------------------------ backward
 template <int KB>
 __global__ __launch_bounds__(256, 1) void lstm_persist_bwd(PBwdArgs a) {
@@ -373,6 +598,9 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd(PBwdArgs a) {
 struct PersistCellHost {
   const float *Wl, *Wu, *bias, *zx, *xin, *mask, *WlT, *WuT_up, *dz_up, *d_enc, *d_hT, *d_cT;
   float *gates, *C, *HR, *HD, *enc;
+  unsigned long long* gran;       // this cell's granule buffer (T*B*4h granules: forward uses the first T*B*h)
+  const unsigned long long* gran_nb;  // forward: granules of the layer below; backward: of the layer above
+  const float* nb_mask;           // forward: dropout mask of the layer below
   int reverse_pos, layer;
 };
 
@@ -381,6 +609,7 @@ bool lstm_persist_applicable(int T, int B, int h, int nl, int nd) {
   if (B < 1 || T < 1) return false;
   const long wgs = (long)(h / 16) * ((B + 15) / 16) * nl * nd;
   if (wgs > 256 || nl * nd > 16) return false;        // one workgroup per CU must hold the whole grid
+  if ((long)T * B * h * 32 >= (1L << 31)) return false;  // granule buffers are addressed with 32-bit byte offsets
   const char* e = getenv("ASTK_LSTM_PERSIST");
   if (e && e[0] == '0') return false;
   return true;
@@ -403,12 +632,29 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   a.abort_word = counters + (size_t)ncells * nbt * 64;
   ASTK_HIP(hipMemsetAsync(counters, 0, ((size_t)ncells * nbt + 1) * 64 * sizeof(unsigned), s));
   dim3 grid(h / 16, nbt, ncells), blk(256);
+  static const bool use_granules = !(getenv("ASTK_LSTM_GRANULES") && getenv("ASTK_LSTM_GRANULES")[0] == '0');
+  if (use_granules) {
+    // hand-off buffers = the saved activations themselves: sentinel-filled before every launch
+    for (int i = 0; i < ncells; ++i) {
+      ASTK_HIP(hipMemsetAsync(cells[i].HR, 0xff, (size_t)T * B * h * sizeof(float), s));
+      if (cells[i].HD) ASTK_HIP(hipMemsetAsync(cells[i].HD, 0xff, (size_t)T * B * h * sizeof(float), s));
+    }
+  }
   ProfScope prof(PROF_CELL, s);
-  switch (h) {
-    case 64: hipLaunchKernelGGL((lstm_persist_fwd<1>), grid, blk, 0, s, a); break;
-    case 128: hipLaunchKernelGGL((lstm_persist_fwd<2>), grid, blk, 0, s, a); break;
-    case 256: hipLaunchKernelGGL((lstm_persist_fwd<4>), grid, blk, 0, s, a); break;
-    default: hipLaunchKernelGGL((lstm_persist_fwd<8>), grid, blk, 0, s, a); break;
+  if (use_granules) {
+    switch (h) {
+      case 64: hipLaunchKernelGGL((lstm_persist_fwd_g<1>), grid, blk, 0, s, a); break;
+      case 128: hipLaunchKernelGGL((lstm_persist_fwd_g<2>), grid, blk, 0, s, a); break;
+      case 256: hipLaunchKernelGGL((lstm_persist_fwd_g<4>), grid, blk, 0, s, a); break;
+      default: hipLaunchKernelGGL((lstm_persist_fwd_g<8>), grid, blk, 0, s, a); break;
+    }
+  } else {
+    switch (h) {
+      case 64: hipLaunchKernelGGL((lstm_persist_fwd<1>), grid, blk, 0, s, a); break;
+      case 128: hipLaunchKernelGGL((lstm_persist_fwd<2>), grid, blk, 0, s, a); break;
+      case 256: hipLaunchKernelGGL((lstm_persist_fwd<4>), grid, blk, 0, s, a); break;
+      default: hipLaunchKernelGGL((lstm_persist_fwd<8>), grid, blk, 0, s, a); break;
+    }
   }
   ASTK_LAUNCH_CHECK();
   return 0;
