@@ -133,6 +133,12 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s);
 
 // ---- small utility kernels (util.hip)
 int fill_zero(void* p, size_t bytes, hipStream_t s);
+// One launch that fills up to FILL_SEG_MAX separate 16-byte aligned regions with a 32-bit pattern (the sentinel fill of the
+// persistent kernels' hand-off buffers; a hipMemsetAsync per buffer costs ~5 us each).
+constexpr int FILL_SEG_MAX = 16;
+struct FillSegs { int n; void* p[FILL_SEG_MAX]; size_t bytes[FILL_SEG_MAX]; };
+static inline void fill_seg_add(FillSegs& f, void* p, size_t bytes) { if (bytes > 0 && f.n < FILL_SEG_MAX) { f.p[f.n] = p; f.bytes[f.n] = bytes; ++f.n; } }
+int fill_u32_segments(const FillSegs& f, unsigned value, hipStream_t s);
 int copy_f32(float* dst, const float* src, size_t n, hipStream_t s);
 int copy2d_f32(float* dst, long ldd, const float* src, long lds, int rows, int cols, int cols_dst, hipStream_t s);
 int add2d_f32(float* dst, long ldd, const float* src, long lds, int rows, int cols, hipStream_t s);

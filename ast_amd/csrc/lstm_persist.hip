@@ -635,10 +635,14 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   static const bool use_granules = !(getenv("ASTK_LSTM_GRANULES") && getenv("ASTK_LSTM_GRANULES")[0] == '0');
   if (use_granules) {
     // hand-off buffers = the saved activations themselves: sentinel-filled before every launch
+    FillSegs f;
+    f.n = 0;
     for (int i = 0; i < ncells; ++i) {
-      ASTK_HIP(hipMemsetAsync(cells[i].HR, 0xff, (size_t)T * B * h * sizeof(float), s));
-      if (cells[i].HD) ASTK_HIP(hipMemsetAsync(cells[i].HD, 0xff, (size_t)T * B * h * sizeof(float), s));
+      if (f.n + 2 > FILL_SEG_MAX) { ASTK_TRY(fill_u32_segments(f, 0xffffffffu, s)); f.n = 0; }
+      fill_seg_add(f, cells[i].HR, (size_t)T * B * h * sizeof(float));
+      if (cells[i].HD) fill_seg_add(f, cells[i].HD, (size_t)T * B * h * sizeof(float));
     }
+    ASTK_TRY(fill_u32_segments(f, 0xffffffffu, s));
   }
   ProfScope prof(PROF_CELL, s);
   if (use_granules) {

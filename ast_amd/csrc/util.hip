@@ -182,8 +182,33 @@ inline unsigned grid_for(size_t n, int per = 256) {
   return (unsigned)b;
 }
 
+__global__ __launch_bounds__(256) void k_fill_segments(FillSegs f, unsigned value) {
+  const int seg = blockIdx.y;
+  if (seg >= f.n) return;
+  const size_t n16 = f.bytes[seg] / 16;
+  uint4* p = reinterpret_cast<uint4*>(f.p[seg]);
+  const uint4 v = make_uint4(value, value, value, value);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+  if (blockIdx.x == 0) {   // tail words
+    unsigned* w = reinterpret_cast<unsigned*>(f.p[seg]);
+    for (size_t i = n16 * 4 + threadIdx.x; i < f.bytes[seg] / 4; i += blockDim.x) w[i] = value;
+  }
+}
+
 }  // namespace
 
+int fill_u32_segments(const FillSegs& f, unsigned value, hipStream_t s) {
+  if (f.n <= 0) return 0;
+  for (int i = 0; i < f.n; ++i) ASTK_CHECK(aligned16(f.p[i]) && (f.bytes[i] % 4) == 0, "fill_u32_segments: segment %d must be 16-byte aligned, size a multiple of 4", i);
+  size_t mx = 0;
+  for (int i = 0; i < f.n; ++i) mx = f.bytes[i] > mx ? f.bytes[i] : mx;
+  unsigned gx = (unsigned)((mx / 16 + 256 * 8 - 1) / (256 * 8));
+  if (gx < 1) gx = 1;
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(k_fill_segments, dim3(gx, (unsigned)f.n), dim3(256), 0, s, f, value);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
 int fill_zero(void* p, size_t bytes, hipStream_t s) {
   if (bytes == 0) return 0;
   ASTK_HIP(hipMemsetAsync(p, 0, bytes, s));
