@@ -168,6 +168,9 @@ __device__ __forceinline__ void aload_sc1(float4* a, __amdgpu_buffer_rsrc_t ra, 
   for (int i = 0; i < NB; ++i) a[i] = ldb128_sc1(ra, a_off + min(16 * (wave + 4 * i) + 4 * q, K - 4));
 }
 
+// NC > 0: H = 64 * NC and chunk <= 32 are compile-time facts for the attention phase (fully unrolled, batched LDS reads);
+// NC = 0: generic loops.
+template <int NC>
 __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // enc slice [chunk][H], encA slice [chunk][H], scratch
   __shared__ __attribute__((aligned(16))) float red[4 * 256];
@@ -272,6 +275,8 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
   const bool timing = a.dbg != 0;
   long long tlast = timing ? wall_clock64() : 0;
   long long tk_att = 0;
+  long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TQ(i) if (timing) { const long long now_ = wall_clock64(); tq[i] += now_ - tlast; tlast = now_; }
 #define TICK(i) if (timing) { const long long now_ = wall_clock64(); tk[i] += now_ - tlast; tlast = now_; }
   for (int s = 0; s < S; ++s) {
     // ================= P1: embed + LSTM cell =================
@@ -354,71 +359,174 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       float* scS = scr + H;            // [c4] raw scores (tail padded with -inf)
       float* pS = scr + H + c4;        // [c4] exp(score - m) (tail 0)
       if (tid < H / 4) *reinterpret_cast<float4*>(hS + 4 * tid) = ldb128_sc1(r_cvh, ((long)s * B + b) * 2 * H + H + 4 * tid);
-      if (tid >= nrow && tid < c4) scS[tid] = -INFINITY;        // pad the score vector for the float4 sweeps below
-      __syncthreads();
-      TICK(13)
-      {
-        // pass 1: 16 lanes per row, two rows per trip; lane l covers floats 4l + 64c (conflict-free LDS reads)
-        const int grp = tid >> 4, l16 = tid & 15;
-        for (int t = grp; t < nrow; t += 32) {
-          const int t2 = t + 16;
-          const bool two = t2 < nrow;
-          const float* e1 = encAS + t * H + 4 * l16;
-          const float* e2 = encAS + (two ? t2 : t) * H + 4 * l16;
+      float m, l = 0.f, my_score;
+      float* prow = a.PART + (((long)s * B + b) * a.nsplit + att_sp) * (H + 4);
+      if constexpr (NC > 0) {
+        // ---- specialised scan: H = 64 NC, nrow <= 32.  Every LDS read of a pass is issued before its first use.
+        constexpr int HH = 64 * NC;
+        float* const pS_ = scr + HH + 32;                // scratch: hS[H] | scores[32] | p[32] | fold
+        if (tid >= nrow && tid < 32) scS[tid] = -INFINITY;
+        __syncthreads();
+        TICK(13)
+        {
+          // pass 1: 16 lanes per row; group g owns rows g and g + 16; lane l covers floats 4l + 64c of the row
+          const int grp = tid >> 4, l16 = tid & 15;
+          const int ta = min(grp, nrow - 1), tb2 = min(grp + 16, nrow - 1);
+          const float* e1 = encAS + ta * HH + 4 * l16;
+          const float* e2 = encAS + tb2 * HH + 4 * l16;
+          float4 hv[NC], x1[NC], x2[NC];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            hv[c] = *reinterpret_cast<const float4*>(hS + 64 * c + 4 * l16);
+            x1[c] = *reinterpret_cast<const float4*>(e1 + 64 * c);
+            x2[c] = *reinterpret_cast<const float4*>(e2 + 64 * c);
+          }
           float d1 = 0.f, d2 = 0.f;
 #pragma unroll
-          for (int c = 0; c < 16; ++c) {
-            if (64 * c < H) {                                     // wave-uniform: H is a multiple of 64, <= 1024
-              const float4 hv = *reinterpret_cast<const float4*>(hS + 64 * c + 4 * l16);
-              const float4 x1 = *reinterpret_cast<const float4*>(e1 + 64 * c);
-              const float4 x2 = *reinterpret_cast<const float4*>(e2 + 64 * c);
-              d1 += x1.x * hv.x + x1.y * hv.y + x1.z * hv.z + x1.w * hv.w;
-              d2 += x2.x * hv.x + x2.y * hv.y + x2.z * hv.z + x2.w * hv.w;
-            }
+          for (int c = 0; c < NC; ++c) {
+            d1 += x1[c].x * hv[c].x + x1[c].y * hv[c].y + x1[c].z * hv[c].z + x1[c].w * hv[c].w;
+            d2 += x2[c].x * hv[c].x + x2[c].y * hv[c].y + x2[c].z * hv[c].z + x2[c].w * hv[c].w;
           }
 #pragma unroll
           for (int o = 8; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
           if (l16 == 0) {
-            scS[t] = d1 + ebS[t];
-            if (two) scS[t2] = d2 + ebS[t2];
+            if (grp < nrow) scS[grp] = d1 + ebS[grp];
+            if (grp + 16 < nrow) scS[grp + 16] = d2 + ebS[grp + 16];
           }
         }
-      }
-      __syncthreads();
-      // chunk max / exp / sum: every thread sweeps the (<= 256) scores with broadcast float4 LDS reads -- no shuffles
-      float m = -INFINITY;
-      for (int t = 0; t < nrow; t += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(scS + t);
-        m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
-      }
-      if (tid < c4) pS[tid] = tid < nrow ? expf(scS[tid] - m) : 0.f;
-      const float my_score = tid < nrow ? scS[tid] : 0.f;
-      __syncthreads();
-      float l = 0.f;
-      float cvp[4] = {0.f, 0.f, 0.f, 0.f};
-      TICK(14)
-      float* prow = a.PART + (((long)s * B + b) * a.nsplit + att_sp) * (H + 4);
-      {
-        // pass 2: context partial; thread owns columns tid + 256 j (consecutive threads -> consecutive LDS words); 4 rows per trip
-        const int c0 = min(tid, H - 1), c1 = min(tid + 256, H - 1), c2 = min(tid + 512, H - 1), c3 = min(tid + 768, H - 1);
-        for (int t = 0; t < nrow; t += 4) {
-          const float4 pv = *reinterpret_cast<const float4*>(pS + t);      // rows beyond nrow have p = 0 and read the next slice rows
-          l += (pv.x + pv.y) + (pv.z + pv.w);
-          const float* e0 = encS + t * H;
-          const int r1 = min(t + 1, nrow - 1) - t, r2 = min(t + 2, nrow - 1) - t, r3 = min(t + 3, nrow - 1) - t;
-          cvp[0] += pv.x * e0[c0] + pv.y * e0[r1 * H + c0] + pv.z * e0[r2 * H + c0] + pv.w * e0[r3 * H + c0];
-          if (H > 256) cvp[1] += pv.x * e0[c1] + pv.y * e0[r1 * H + c1] + pv.z * e0[r2 * H + c1] + pv.w * e0[r3 * H + c1];
-          if (H > 512) {
-            cvp[2] += pv.x * e0[c2] + pv.y * e0[r1 * H + c2] + pv.z * e0[r2 * H + c2] + pv.w * e0[r3 * H + c2];
-            cvp[3] += pv.x * e0[c3] + pv.y * e0[r1 * H + c3] + pv.z * e0[r2 * H + c3] + pv.w * e0[r3 * H + c3];
-          }
-        }
+        TQ(0)
+        __syncthreads();
+        TQ(1)
+        {
+          // chunk max / exp: every thread sweeps the 32 (padded) scores with 8 broadcast reads
+          float4 sv[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (tid + 256 * j < H) st_sc1(&prow[4 + tid + 256 * j], cvp[j]);
+          for (int i = 0; i < 8; ++i) sv[i] = *reinterpret_cast<const float4*>(scS + 4 * i);
+          m = -INFINITY;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) m = fmaxf(fmaxf(m, fmaxf(sv[i].x, sv[i].y)), fmaxf(sv[i].z, sv[i].w));
+          my_score = tid < nrow ? scS[tid] : 0.f;
+          if (tid < 32) pS_[tid] = tid < nrow ? expf(scS[tid] - m) : 0.f;
+        }
+        TQ(2)
+        __syncthreads();
+        TQ(3)
+        {
+          // pass 2: context partial.  Thread (cq, rh): columns 4cq..4cq+3, rows rh, rh+RH, ... (16-byte LDS reads), the RH row groups
+          // are folded through LDS and row group 0 publishes with 16-byte write-through stores.
+          constexpr int RH = 256 / (16 * NC);            // row groups (2 for H = 512)
+          constexpr int RPT = (32 + RH - 1) / RH;        // rows per thread (max)
+          const int cq = tid % (16 * NC), rh = tid / (16 * NC);
+          float4 ev[RPT];
+          float pv[RPT];
+#pragma unroll
+          for (int i = 0; i < RPT; ++i) {
+            const int t = rh + RH * i;
+            const int tc = min(t, nrow - 1);
+            ev[i] = *reinterpret_cast<const float4*>(encS + tc * HH + 4 * cq);
+            pv[i] = pS_[min(t, 31)];                      // rows beyond nrow have p = 0
+          }
+          float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int i = 0; i < RPT; ++i) {
+            acc4.x += pv[i] * ev[i].x; acc4.y += pv[i] * ev[i].y; acc4.z += pv[i] * ev[i].z; acc4.w += pv[i] * ev[i].w;
+          }
+          float4* fold = reinterpret_cast<float4*>(scr + HH + 64);   // [RH-1][16 NC] float4 (the launcher checks the scratch size)
+          if (RH > 1) {
+            if (rh > 0) fold[(rh - 1) * (16 * NC) + cq] = acc4;
+            __syncthreads();
+          }
+          if (rh == 0) {
+#pragma unroll
+            for (int k = 1; k < RH; ++k) {
+              const float4 o = fold[(k - 1) * (16 * NC) + cq];
+              acc4.x += o.x; acc4.y += o.y; acc4.z += o.z; acc4.w += o.w;
+            }
+            u32x4 u;
+            u.x = __float_as_uint(acc4.x); u.y = __float_as_uint(acc4.y); u.z = __float_as_uint(acc4.z); u.w = __float_as_uint(acc4.w);
+            __builtin_amdgcn_raw_buffer_store_b128(u, r_part, (int)((prow - a.PART + 4 + 4 * cq) * 4), 0, 16);
+          }
+          if (tid == 0) {
+            float4 pp[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pp[i] = *reinterpret_cast<const float4*>(pS_ + 4 * i);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) l += (pp[i].x + pp[i].y) + (pp[i].z + pp[i].w);
+          }
+          TQ(4)
+        }
+      } else {
+        float mg = -INFINITY;
+        if (tid >= nrow && tid < c4) scS[tid] = -INFINITY;        // pad the score vector for the float4 sweeps below
+        __syncthreads();
+        TICK(13)
+        {
+          // pass 1: 16 lanes per row, two rows per trip; lane l covers floats 4l + 64c (conflict-free LDS reads)
+          const int grp = tid >> 4, l16 = tid & 15;
+          for (int t = grp; t < nrow; t += 32) {
+            const int t2 = t + 16;
+            const bool two = t2 < nrow;
+            const float* e1 = encAS + t * H + 4 * l16;
+            const float* e2 = encAS + (two ? t2 : t) * H + 4 * l16;
+            float d1 = 0.f, d2 = 0.f;
+  #pragma unroll
+            for (int c = 0; c < 16; ++c) {
+              if (64 * c < H) {                                     // wave-uniform: H is a multiple of 64, <= 1024
+                const float4 hv = *reinterpret_cast<const float4*>(hS + 64 * c + 4 * l16);
+                const float4 x1 = *reinterpret_cast<const float4*>(e1 + 64 * c);
+                const float4 x2 = *reinterpret_cast<const float4*>(e2 + 64 * c);
+                d1 += x1.x * hv.x + x1.y * hv.y + x1.z * hv.z + x1.w * hv.w;
+                d2 += x2.x * hv.x + x2.y * hv.y + x2.z * hv.z + x2.w * hv.w;
+              }
+            }
+  #pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
+            if (l16 == 0) {
+              scS[t] = d1 + ebS[t];
+              if (two) scS[t2] = d2 + ebS[t2];
+            }
+          }
+        }
+        TQ(0)
+        __syncthreads();
+        TQ(1)
+        // chunk max / exp / sum: every thread sweeps the (<= 256) scores with broadcast float4 LDS reads -- no shuffles
+        for (int t = 0; t < nrow; t += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(scS + t);
+          mg = fmaxf(fmaxf(mg, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+        }
+        m = mg;
+        if (tid < c4) pS[tid] = tid < nrow ? expf(scS[tid] - m) : 0.f;
+        my_score = tid < nrow ? scS[tid] : 0.f;
+        TQ(2)
+        __syncthreads();
+        TQ(3)
+        float cvp[4] = {0.f, 0.f, 0.f, 0.f};
+        TICK(14)
+        {
+          // pass 2: context partial; thread owns columns tid + 256 j (consecutive threads -> consecutive LDS words); 4 rows per trip
+          const int c0 = min(tid, H - 1), c1 = min(tid + 256, H - 1), c2 = min(tid + 512, H - 1), c3 = min(tid + 768, H - 1);
+          for (int t = 0; t < nrow; t += 4) {
+            const float4 pv = *reinterpret_cast<const float4*>(pS + t);      // rows beyond nrow have p = 0 and read the next slice rows
+            l += (pv.x + pv.y) + (pv.z + pv.w);
+            const float* e0 = encS + t * H;
+            const int r1 = min(t + 1, nrow - 1) - t, r2 = min(t + 2, nrow - 1) - t, r3 = min(t + 3, nrow - 1) - t;
+            cvp[0] += pv.x * e0[c0] + pv.y * e0[r1 * H + c0] + pv.z * e0[r2 * H + c0] + pv.w * e0[r3 * H + c0];
+            if (H > 256) cvp[1] += pv.x * e0[c1] + pv.y * e0[r1 * H + c1] + pv.z * e0[r2 * H + c1] + pv.w * e0[r3 * H + c1];
+            if (H > 512) {
+              cvp[2] += pv.x * e0[c2] + pv.y * e0[r1 * H + c2] + pv.z * e0[r2 * H + c2] + pv.w * e0[r3 * H + c2];
+              cvp[3] += pv.x * e0[c3] + pv.y * e0[r1 * H + c3] + pv.z * e0[r2 * H + c3] + pv.w * e0[r3 * H + c3];
+            }
+          }
+  #pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (tid + 256 * j < H) st_sc1(&prow[4 + tid + 256 * j], cvp[j]);
+          TQ(4)
+        }
       }
       if (tid == 0) { st_sc1(&prow[0], m); st_sc1(&prow[1], l); }
       publish(CTR(PH_ATT, bt));
+      TQ(5)
       if (a.tick_out) tk_att += wall_clock64() - ta0;
       if (tid < nrow) a.ALPHA[((long)s * B + b) * Tp + t0 + tid] = my_score;   // raw score, normalised by the backward (M, 1/L in ML)
       TICK(5)
@@ -555,7 +663,11 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
     printf("pdec wg %3d per-step 10ns: P1[pre %lld waitctx %lld ht+epi %lld publish %lld] P3[wait %lld work %lld] P3b[wait %lld work %lld] "
            "P4[wait %lld work %lld] P5[wait %lld work %lld] P6 %lld other %lld | P3: hload %lld pass1+max %lld\n", wg, tk[0] / S, tk[1] / S, tk[2] / S, tk[3] / S,
            tk[4] / S, tk[5] / S, tk[6] / S, tk[7] / S, tk[8] / S, tk[9] / S, tk[10] / S, tk[11] / S, tk[12] / S, tk[15] / S, tk[13] / S, tk[14] / S);
+  if (a.dbg != 0 && tid == 0 && (wg == 0 || wg == G - 1))
+    printf("pdec-att wg %3d per-step 10ns: pass1 %lld barrier %lld max+exp %lld barrier %lld pass2+stores %lld publish %lld\n", wg, tq[0] / S, tq[1] / S,
+           tq[2] / S, tq[3] / S, tq[4] / S, tq[5] / S);
 #undef TICK
+#undef TQ
 #undef CTR
 }
 
@@ -994,12 +1106,14 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
   const size_t shm = pdec_lds_floats(chunk, a.H, nsplit) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    ASTK_HIP(hipFuncSetAttribute((const void*)decoder_persist_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024));
+    ASTK_HIP(hipFuncSetAttribute((const void*)decoder_persist_fwd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024));
+    ASTK_HIP(hipFuncSetAttribute((const void*)decoder_persist_fwd<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024));
     attr_done = true;
   }
   {
     ProfScope prof(PROF_DEC_FWD, s);
-    hipLaunchKernelGGL(decoder_persist_fwd, dim3(G), dim3(256), shm, s, a);
+    if (a.H == 512 && chunk <= 32 && (size_t)nsplit * (a.H + 4) >= (size_t)a.H + 64 + 512) hipLaunchKernelGGL(decoder_persist_fwd<8>, dim3(G), dim3(256), shm, s, a);
+    else hipLaunchKernelGGL(decoder_persist_fwd<0>, dim3(G), dim3(256), shm, s, a);
   }
   ASTK_LAUNCH_CHECK();
   // Q[s][b][:] = Wa h_top + ba for all steps (needed by the backward's deferred d_enc product)
