@@ -714,6 +714,7 @@ __device__ __forceinline__ void wmac_chunked(f32x4& acc, const float4* w, __amdg
   }
 }
 
+template <int NC>   // as in decoder_persist_fwd: NC > 0 means H = 64 NC and chunk <= 32 at compile time for the attention phase
 __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ __attribute__((aligned(16))) float red[4 * 256];
@@ -816,82 +817,184 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
     // ================= B3: attention backward =================
     if (has_att) {
       const int b = att_b, bt = b / 16;
-      if (!wg_wait(CTR(PB2, bt), (unsigned)((2 * H / 32) * (n + 1)), a.abort_word, &s_flag)) return;
-      const long long tb0 = a.tick_out ? wall_clock64() : 0;
-      float* dS = scr;                  // d_cv[b][:]
-      float* cvS = scr + H;             // cv[b][:]
-      float* dsS = scr + 2 * H;         // ds[c4] (tail 0)
-      const int c4 = (a.chunk + 3) & ~3;
-      float* wred = dsS + c4;           // [8]
-      if (tid >= nrow && tid < c4) dsS[tid] = 0.f;
-      if (tid < H / 4) {
-        *reinterpret_cast<float4*>(dS + 4 * tid) = ldb128_sc1(r_dcvh, ((long)s * B + b) * 2 * H + 4 * tid);
-        *reinterpret_cast<float4*>(cvS + 4 * tid) = *reinterpret_cast<const float4*>(a.CVH + ((long)s * B + b) * 2 * H + 4 * tid);
-      }
-      __syncthreads();
-      float cdp = 0.f;                  // cv . d_cv
-      for (int k = tid; k < H; k += 256) cdp += cvS[k] * dS[k];
-      cdp = wave_sum(cdp);
-      if (lane == 0) wred[wave] = cdp;
-      __syncthreads();
-      const float cd = wred[0] + wred[1] + wred[2] + wred[3];
-      const float mlM = a.ML[((long)s * B + b) * 2], mlI = a.ML[((long)s * B + b) * 2 + 1];
-      {
-        const int grp = tid >> 4, l16 = tid & 15;
-        for (int t = grp; t < nrow; t += 32) {
-          const int t2 = t + 16;
-          const bool two = t2 < nrow;
-          const float* e1 = encS + t * H + 4 * l16;
-          const float* e2 = encS + (two ? t2 : t) * H + 4 * l16;
+      long long tb0 = 0;
+      if constexpr (NC > 0) {
+        // ---- specialised scan (H = 64 NC, nrow <= 32): everything that does not depend on this step's chain (alpha from the saved raw
+        // scores, cv) is fetched BEFORE the wait; every LDS read of a pass is issued before its first use; 16-byte stores.
+        constexpr int HH = 64 * NC;
+        float* dS = scr;                       // d_cv[b][:]
+        float* dsS = scr + 2 * HH;             // ds[32] (tail 0)
+        float* aS = dsS + 32;                  // alpha[32] (tail 0)
+        float* wred = aS + 32;                 // [8]
+        float4* fold = reinterpret_cast<float4*>(scr + 2 * HH + 96);
+        float* al = a.ALPHA + ((long)s * B + b) * Tp + t0;
+        float a_t = 0.f;
+        float4 cv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        {
+          const float mlM = a.ML[((long)s * B + b) * 2], mlI = a.ML[((long)s * B + b) * 2 + 1];
+          const float raw = al[min(tid, nrow - 1)];
+          if (tid < HH / 4) cv4 = *reinterpret_cast<const float4*>(a.CVH + ((long)s * B + b) * 2 * HH + 4 * tid);
+          a_t = tid < nrow ? expf(raw - mlM) * mlI : 0.f;
+        }
+        if (!wg_wait(CTR(PB2, bt), (unsigned)((2 * H / 32) * (n + 1)), a.abort_word, &s_flag)) return;
+        tb0 = a.tick_out ? wall_clock64() : 0;
+        float cdp = 0.f;                       // cv . d_cv
+        if (tid < HH / 4) {
+          const float4 d4 = ldb128_sc1(r_dcvh, ((long)s * B + b) * 2 * HH + 4 * tid);
+          *reinterpret_cast<float4*>(dS + 4 * tid) = d4;
+          cdp = cv4.x * d4.x + cv4.y * d4.y + cv4.z * d4.z + cv4.w * d4.w;
+        }
+        cdp = wave_sum(cdp);
+        if (lane == 0) wred[wave] = cdp;
+        if (tid < 32) { aS[tid] = a_t; dsS[tid] = 0.f; }
+        if (tid < nrow) al[tid] = a_t;          // normalised alpha for the deferred d_enc product (off the chain)
+        __syncthreads();
+        const float cd = wred[0] + wred[1] + wred[2] + wred[3];
+        {
+          const int grp = tid >> 4, l16 = tid & 15;
+          const int ta = min(grp, nrow - 1), tb2 = min(grp + 16, nrow - 1);
+          const float* e1 = encS + ta * HH + 4 * l16;
+          const float* e2 = encS + tb2 * HH + 4 * l16;
+          float4 dv[NC], x1[NC], x2[NC];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            dv[c] = *reinterpret_cast<const float4*>(dS + 64 * c + 4 * l16);
+            x1[c] = *reinterpret_cast<const float4*>(e1 + 64 * c);
+            x2[c] = *reinterpret_cast<const float4*>(e2 + 64 * c);
+          }
+          const float a1 = aS[ta], a2 = aS[tb2];
           float d1 = 0.f, d2 = 0.f;
 #pragma unroll
-          for (int c = 0; c < 16; ++c) {
-            if (64 * c < H) {
-              const float4 dv = *reinterpret_cast<const float4*>(dS + 64 * c + 4 * l16);
-              const float4 x1 = *reinterpret_cast<const float4*>(e1 + 64 * c);
-              const float4 x2 = *reinterpret_cast<const float4*>(e2 + 64 * c);
-              d1 += x1.x * dv.x + x1.y * dv.y + x1.z * dv.z + x1.w * dv.w;
-              d2 += x2.x * dv.x + x2.y * dv.y + x2.z * dv.z + x2.w * dv.w;
-            }
+          for (int c = 0; c < NC; ++c) {
+            d1 += x1[c].x * dv[c].x + x1[c].y * dv[c].y + x1[c].z * dv[c].z + x1[c].w * dv[c].w;
+            d2 += x2[c].x * dv[c].x + x2[c].y * dv[c].y + x2[c].z * dv[c].z + x2[c].w * dv[c].w;
           }
 #pragma unroll
           for (int o = 8; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
           if (l16 == 0) {
-            float* al = a.ALPHA + ((long)s * B + b) * Tp + t0;
-            const float a1 = expf(al[t] - mlM) * mlI;
-            al[t] = a1;                                  // normalised alpha for the deferred d_enc product
-            const float g1 = a1 * (d1 - cd);
-            dsS[t] = g1;
-            a.DS[((long)s * B + b) * Tp + t0 + t] = g1;
-            if (two) {
-              const float a2 = expf(al[t2] - mlM) * mlI;
-              al[t2] = a2;
+            if (grp < nrow) {
+              const float g1 = a1 * (d1 - cd);
+              dsS[grp] = g1;
+              a.DS[((long)s * B + b) * Tp + t0 + grp] = g1;
+            }
+            if (grp + 16 < nrow) {
               const float g2 = a2 * (d2 - cd);
-              dsS[t2] = g2;
-              a.DS[((long)s * B + b) * Tp + t0 + t2] = g2;
+              dsS[grp + 16] = g2;
+              a.DS[((long)s * B + b) * Tp + t0 + grp + 16] = g2;
             }
           }
         }
-      }
-      __syncthreads();
-      {
-        float acc4[4] = {0.f, 0.f, 0.f, 0.f};
-        const int c0 = min(tid, H - 1), c1 = min(tid + 256, H - 1), c2 = min(tid + 512, H - 1), c3 = min(tid + 768, H - 1);
-        for (int t = 0; t < nrow; t += 4) {
-          const float4 gv = *reinterpret_cast<const float4*>(dsS + t);
-          const float* e0 = encAS + t * H;
-          const int r1 = min(t + 1, nrow - 1) - t, r2 = min(t + 2, nrow - 1) - t, r3 = min(t + 3, nrow - 1) - t;
-          acc4[0] += gv.x * e0[c0] + gv.y * e0[r1 * H + c0] + gv.z * e0[r2 * H + c0] + gv.w * e0[r3 * H + c0];
-          if (H > 256) acc4[1] += gv.x * e0[c1] + gv.y * e0[r1 * H + c1] + gv.z * e0[r2 * H + c1] + gv.w * e0[r3 * H + c1];
-          if (H > 512) {
-            acc4[2] += gv.x * e0[c2] + gv.y * e0[r1 * H + c2] + gv.z * e0[r2 * H + c2] + gv.w * e0[r3 * H + c2];
-            acc4[3] += gv.x * e0[c3] + gv.y * e0[r1 * H + c3] + gv.z * e0[r2 * H + c3] + gv.w * e0[r3 * H + c3];
+        __syncthreads();
+        {
+          constexpr int RH = 256 / (16 * NC);
+          constexpr int RPT = (32 + RH - 1) / RH;
+          const int cq = tid % (16 * NC), rh = tid / (16 * NC);
+          float4 ev[RPT];
+          float gv[RPT];
+#pragma unroll
+          for (int i = 0; i < RPT; ++i) {
+            const int t = rh + RH * i;
+            ev[i] = *reinterpret_cast<const float4*>(encAS + min(t, nrow - 1) * HH + 4 * cq);
+            gv[i] = dsS[min(t, 31)];             // rows beyond nrow carry 0
+          }
+          float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int i = 0; i < RPT; ++i) {
+            acc4.x += gv[i] * ev[i].x; acc4.y += gv[i] * ev[i].y; acc4.z += gv[i] * ev[i].z; acc4.w += gv[i] * ev[i].w;
+          }
+          if (RH > 1) {
+            if (rh > 0) fold[(rh - 1) * (16 * NC) + cq] = acc4;
+            __syncthreads();
+          }
+          if (rh == 0) {
+#pragma unroll
+            for (int k = 1; k < RH; ++k) {
+              const float4 o = fold[(k - 1) * (16 * NC) + cq];
+              acc4.x += o.x; acc4.y += o.y; acc4.z += o.z; acc4.w += o.w;
+            }
+            u32x4 u;
+            u.x = __float_as_uint(acc4.x); u.y = __float_as_uint(acc4.y); u.z = __float_as_uint(acc4.z); u.w = __float_as_uint(acc4.w);
+            __builtin_amdgcn_raw_buffer_store_b128(u, r_dha, (int)(((((long)s * B + b) * a.nsplit + att_sp) * HH + 4 * cq) * 4), 0, 16);
           }
         }
-        float* out = a.DHATT + (((long)s * B + b) * a.nsplit + att_sp) * H;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (tid + 256 * j < H) st_sc1(&out[tid + 256 * j], acc4[j]);
+      } else {
+        if (!wg_wait(CTR(PB2, bt), (unsigned)((2 * H / 32) * (n + 1)), a.abort_word, &s_flag)) return;
+        tb0 = a.tick_out ? wall_clock64() : 0;
+        float* dS = scr;                  // d_cv[b][:]
+        float* cvS = scr + H;             // cv[b][:]
+        float* dsS = scr + 2 * H;         // ds[c4] (tail 0)
+        const int c4 = (a.chunk + 3) & ~3;
+        float* wred = dsS + c4;           // [8]
+        if (tid >= nrow && tid < c4) dsS[tid] = 0.f;
+        if (tid < H / 4) {
+          *reinterpret_cast<float4*>(dS + 4 * tid) = ldb128_sc1(r_dcvh, ((long)s * B + b) * 2 * H + 4 * tid);
+          *reinterpret_cast<float4*>(cvS + 4 * tid) = *reinterpret_cast<const float4*>(a.CVH + ((long)s * B + b) * 2 * H + 4 * tid);
+        }
+        __syncthreads();
+        float cdp = 0.f;                  // cv . d_cv
+        for (int k = tid; k < H; k += 256) cdp += cvS[k] * dS[k];
+        cdp = wave_sum(cdp);
+        if (lane == 0) wred[wave] = cdp;
+        __syncthreads();
+        const float cd = wred[0] + wred[1] + wred[2] + wred[3];
+        const float mlM = a.ML[((long)s * B + b) * 2], mlI = a.ML[((long)s * B + b) * 2 + 1];
+        {
+          const int grp = tid >> 4, l16 = tid & 15;
+          for (int t = grp; t < nrow; t += 32) {
+            const int t2 = t + 16;
+            const bool two = t2 < nrow;
+            const float* e1 = encS + t * H + 4 * l16;
+            const float* e2 = encS + (two ? t2 : t) * H + 4 * l16;
+            float d1 = 0.f, d2 = 0.f;
+  #pragma unroll
+            for (int c = 0; c < 16; ++c) {
+              if (64 * c < H) {
+                const float4 dv = *reinterpret_cast<const float4*>(dS + 64 * c + 4 * l16);
+                const float4 x1 = *reinterpret_cast<const float4*>(e1 + 64 * c);
+                const float4 x2 = *reinterpret_cast<const float4*>(e2 + 64 * c);
+                d1 += x1.x * dv.x + x1.y * dv.y + x1.z * dv.z + x1.w * dv.w;
+                d2 += x2.x * dv.x + x2.y * dv.y + x2.z * dv.z + x2.w * dv.w;
+              }
+            }
+  #pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
+            if (l16 == 0) {
+              float* al = a.ALPHA + ((long)s * B + b) * Tp + t0;
+              const float a1 = expf(al[t] - mlM) * mlI;
+              al[t] = a1;                                  // normalised alpha for the deferred d_enc product
+              const float g1 = a1 * (d1 - cd);
+              dsS[t] = g1;
+              a.DS[((long)s * B + b) * Tp + t0 + t] = g1;
+              if (two) {
+                const float a2 = expf(al[t2] - mlM) * mlI;
+                al[t2] = a2;
+                const float g2 = a2 * (d2 - cd);
+                dsS[t2] = g2;
+                a.DS[((long)s * B + b) * Tp + t0 + t2] = g2;
+              }
+            }
+          }
+        }
+        __syncthreads();
+        {
+          float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+          const int c0 = min(tid, H - 1), c1 = min(tid + 256, H - 1), c2 = min(tid + 512, H - 1), c3 = min(tid + 768, H - 1);
+          for (int t = 0; t < nrow; t += 4) {
+            const float4 gv = *reinterpret_cast<const float4*>(dsS + t);
+            const float* e0 = encAS + t * H;
+            const int r1 = min(t + 1, nrow - 1) - t, r2 = min(t + 2, nrow - 1) - t, r3 = min(t + 3, nrow - 1) - t;
+            acc4[0] += gv.x * e0[c0] + gv.y * e0[r1 * H + c0] + gv.z * e0[r2 * H + c0] + gv.w * e0[r3 * H + c0];
+            if (H > 256) acc4[1] += gv.x * e0[c1] + gv.y * e0[r1 * H + c1] + gv.z * e0[r2 * H + c1] + gv.w * e0[r3 * H + c1];
+            if (H > 512) {
+              acc4[2] += gv.x * e0[c2] + gv.y * e0[r1 * H + c2] + gv.z * e0[r2 * H + c2] + gv.w * e0[r3 * H + c2];
+              acc4[3] += gv.x * e0[c3] + gv.y * e0[r1 * H + c3] + gv.z * e0[r2 * H + c3] + gv.w * e0[r3 * H + c3];
+            }
+          }
+          float* out = a.DHATT + (((long)s * B + b) * a.nsplit + att_sp) * H;
+  #pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (tid + 256 * j < H) st_sc1(&out[tid + 256 * j], acc4[j]);
+        }
       }
       publish(CTR(PB3, bt));
       if (a.tick_out) tk_att += wall_clock64() - tb0;
@@ -1029,7 +1132,7 @@ bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int
     const int XI = d->E + d->A, Vp = (d->V + 3) / 4 * 4;
     if (Vp > 64 * NB_B1 || d->A > 64 * NB_B2 || 4 * d->H > 64 * NB_B5 || (XI % 16) || ((2 * d->H) % 32)) return false;
     if (nbt * (d->H / 16) + nbt * (XI / 16) + nbt * (d->A / 16) > G || nbt * (2 * d->H / 32) > nbt * (d->A / 16) + (G - nbt * (d->H / 16) - nbt * (XI / 16) - nbt * (d->A / 16))) return false;
-    if ((2 * (size_t)chunk * d->H + 2 * (size_t)d->H + chunk + 20) * sizeof(float) > 148 * 1024) return false;
+    if ((2 * (size_t)chunk * d->H + 2 * (size_t)d->H + chunk + 20 + 640) * sizeof(float) > 148 * 1024) return false;
   }                       // pass-1 bookkeeping uses one thread per row
   if (pdec_lds_floats(chunk, d->H, nsplit) * sizeof(float) > 136 * 1024) return false;
   *nsplit_out = nsplit;
@@ -1065,16 +1168,18 @@ int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, con
   a.abort_word = bf.ctr + (size_t)PB_N * a.nbt * CTRS;
   a.tick_out = prof_tick_buffer(1);
   ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)PB_N * a.nbt + 1) * CTRS * sizeof(unsigned), s));
-  size_t scratch = 2 * (size_t)a.H + (size_t)((chunk + 3) & ~3) + 16;
+  size_t scratch = 2 * (size_t)a.H + (size_t)((chunk + 3) & ~3) + 16 + 640;   // + ds/alpha/fold of the specialised attention scan
   const size_t shm = (2 * (size_t)chunk * a.H + scratch) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    ASTK_HIP(hipFuncSetAttribute((const void*)decoder_persist_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    ASTK_HIP(hipFuncSetAttribute((const void*)decoder_persist_bwd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    ASTK_HIP(hipFuncSetAttribute((const void*)decoder_persist_bwd<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_done = true;
   }
   {
     ProfScope prof(PROF_DEC_BWD, s);
-    hipLaunchKernelGGL(decoder_persist_bwd, dim3(G), dim3(256), shm, s, a);
+    if (a.H == 512 && chunk <= 32) hipLaunchKernelGGL(decoder_persist_bwd<8>, dim3(G), dim3(256), shm, s, a);
+    else hipLaunchKernelGGL(decoder_persist_bwd<0>, dim3(G), dim3(256), shm, s, a);
   }
   ASTK_LAUNCH_CHECK();
   return 0;
