@@ -538,25 +538,42 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       TICK(15)
       if (!wg_wait(CTR(PH_ATT, bt), (unsigned)(rows_bt * a.nsplit * (s + 1)), a.abort_word, &s_flag)) return;
       TICK(6)
-      float* pl = scr;                               // [nsplit][H+4] staged with batched 16-byte sc1 loads
+      // No staging, no barrier: lane k of EVERY wave reads the header {max_k, sum_k} of partial k, the softmax weights of the
+      // nsplit partials are formed with wave shuffles (identically in every wave), and thread tid < H/4 folds its four columns of the
+      // nsplit partial context vectors straight from 16-byte sc1 loads (8 in flight) into one 16-byte write-through store.
       const long pbo = ((long)s * B + b) * a.nsplit * (H + 4);
-      const int n4 = a.nsplit * (H + 4) / 4;
-      for (int i = tid; i < n4; i += 256) *reinterpret_cast<float4*>(pl + 4 * i) = ldb128_sc1(r_part, pbo + 4 * i);
-      __syncthreads();
-      float Mx = -INFINITY;
-      for (int k = 0; k < a.nsplit; ++k) Mx = fmaxf(Mx, pl[k * (H + 4)]);
-      float Ls = 0.f;
-      for (int k = 0; k < a.nsplit; ++k) Ls += pl[k * (H + 4) + 1] * expf(pl[k * (H + 4)] - Mx);
+      float mk = -INFINITY, lk = 0.f;
+      if (lane < a.nsplit) {
+        const float4 hd = ldb128_sc1(r_part, pbo + (long)lane * (H + 4));
+        mk = hd.x; lk = hd.y;
+      }
+      const int cq = min(tid, H / 4 - 1);
+      float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      float Mx = mk;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) Mx = fmaxf(Mx, __shfl_xor(Mx, o));
+      const float wk_mine = lane < a.nsplit ? expf(mk - Mx) : 0.f;
+      const float Ls = wave_sum(lk * wk_mine);
       const float inv = 1.f / Ls;
-      for (int i = tid; i < H; i += 256) {
-        float v = 0.f;
-        for (int k = 0; k < a.nsplit; ++k) v += pl[k * (H + 4) + 4 + i] * expf(pl[k * (H + 4)] - Mx);
-        st_sc1(a.CVH + ((long)s * B + b) * 2 * H + i, v * inv);
+      for (int k0 = 0; k0 < a.nsplit; k0 += 8) {
+        float4 pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pv[j] = ldb128_sc1(r_part, pbo + (long)min(k0 + j, a.nsplit - 1) * (H + 4) + 4 + 4 * cq);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float wk = __shfl(wk_mine, min(k0 + j, 63));     // 0 for k >= nsplit
+          const float wv = k0 + j < a.nsplit ? wk : 0.f;
+          acc4.x += wv * pv[j].x; acc4.y += wv * pv[j].y; acc4.z += wv * pv[j].z; acc4.w += wv * pv[j].w;
+        }
+      }
+      if (tid < H / 4) {
+        u32x4 u;
+        u.x = __float_as_uint(acc4.x * inv); u.y = __float_as_uint(acc4.y * inv); u.z = __float_as_uint(acc4.z * inv); u.w = __float_as_uint(acc4.w * inv);
+        __builtin_amdgcn_raw_buffer_store_b128(u, r_cvh, (int)((((long)s * B + b) * 2 * H + 4 * tid) * 4), 0, 16);
       }
       publish(CTR(PH_CMB, bt));
       TICK(7)
       if (tid == 0) { a.ML[((long)s * B + b) * 2] = Mx; a.ML[((long)s * B + b) * 2 + 1] = inv; }
-      __syncthreads();
     }
     // ================= P4: ht = tanh(Wc [cv;h] + bc) =================
     if (has_c) {
