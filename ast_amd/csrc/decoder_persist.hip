@@ -580,10 +580,35 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       const int bt = c_bt, m0 = bt * 16;
       const int rows_bt = min(16, B - bt * 16);
       TICK(15)
-      if (!wg_wait(CTR(PH_CMB, bt), (unsigned)(rows_bt * (s + 1)), a.abort_word, &s_flag)) return;
-      TICK(8)
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      wmac<NB_C>(acc, wreg + OFF_WC, r_cvh, ((long)s * B + min(m0 + r16, B - 1)) * 2 * H, 2 * H, lane, wave);
+      const long crow = ((long)s * B + min(m0 + r16, B - 1)) * 2 * H;
+      if constexpr (NC > 0) {
+        // the h half of [cv ; h] was published by the cells long ago: its fragments (k-blocks NC..2NC-1 of each wave) and their MFMAs
+        // run BEFORE the wait on the combine; only the cv half is fetched and multiplied behind it
+        if (!wg_wait(CTR(PH_CELL, bt), (unsigned)((H / 8) * (s + 1)), a.abort_word, &s_flag)) return;
+        {
+          float4 ahd[NC];
+          const int q = lane >> 4;
+#pragma unroll
+          for (int i = 0; i < NC; ++i) ahd[i] = ldb128_sc1(r_cvh, crow + 16 * (wave + 4 * (NC + i)) + 4 * q);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_blocks<NC>(acc, ahd, wreg + OFF_WC + NC);
+        }
+        if (!wg_wait(CTR(PH_CMB, bt), (unsigned)(rows_bt * (s + 1)), a.abort_word, &s_flag)) return;
+        TICK(8)
+        {
+          float4 acv[NC];
+          const int q = lane >> 4;
+#pragma unroll
+          for (int i = 0; i < NC; ++i) acv[i] = ldb128_sc1(r_cvh, crow + 16 * (wave + 4 * i) + 4 * q);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_blocks<NC>(acc, acv, wreg + OFF_WC);
+        }
+      } else {
+        if (!wg_wait(CTR(PH_CMB, bt), (unsigned)(rows_bt * (s + 1)), a.abort_word, &s_flag)) return;
+        TICK(8)
+        wmac<NB_C>(acc, wreg + OFF_WC, r_cvh, crow, 2 * H, lane, wave);
+      }
       const float v = reduce16(acc, red);
       const int row = m0 + (tid >> 4), n = c_n0 + (tid & 15);
       if (row < B) {
