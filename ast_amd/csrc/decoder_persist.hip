@@ -816,6 +816,12 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   const int e_row = tid >> 4, e_col = tid & 15;
   float dc_state = 0.f;
   long long tk_att = 0;
+  long long tb[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tb[i] = 0;
+  const bool timing = a.dbg != 0;
+  long long tlast = timing ? wall_clock64() : 0;
+#define TB(i) if (timing) { const long long now_ = wall_clock64(); tb[i] += now_ - tlast; tlast = now_; }
 
   for (int s = S - 1; s >= 0; --s) {
     const int n = S - 1 - s;
@@ -827,8 +833,10 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
       const float v = reduce16(acc, red);
       const int row = m0 + e_row, col = b1_n0 + e_col;
       float carry = 0.f;
+      TB(0)
       if (n > 0) {
         if (!wg_wait(CTR(PB6, bt), (unsigned)((XI / 16) * n), a.abort_word, &s_flag)) return;
+        TB(1)
         if (row < B) carry = ld_sc1(a.DX0 + ((long)(s + 1) * B + row) * XI + E + col);
       }
       if (row < B) {
@@ -836,11 +844,14 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
         st_sc1(a.DPRE + ((long)s * B + row) * A + col, (v + carry) * (1.f - y * y));
       }
       publish(CTR(PB1, bt));
+      TB(2)
     }
     // ================= B2 =================
     if (has2) {
       const int bt = b2_bt, m0 = bt * 16;
+      TB(15)
       if (!wg_wait(CTR(PB1, bt), (unsigned)((A / 16) * (n + 1)), a.abort_word, &s_flag)) return;
+      TB(3)
       float4 av[NB_B2];
       aload_sc1<NB_B2>(av, r_dpre, ((long)s * B + min(m0 + r16, B - 1)) * A, A, lane, wave);
       __builtin_amdgcn_sched_barrier(0);
@@ -855,11 +866,13 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
         st_sc1(a.DCVH + ((long)s * B + row) * 2 * H + b2_n0 + 16 + e_col, v1);
       }
       publish(CTR(PB2, bt));
+      TB(4)
     }
     // ================= B3: attention backward =================
     if (has_att) {
       const int b = att_b, bt = b / 16;
       long long tb0 = 0;
+      TB(15)
       if constexpr (NC > 0) {
         // ---- specialised scan (H = 64 NC, nrow <= 32): everything that does not depend on this step's chain (alpha from the saved raw
         // scores, cv) is fetched BEFORE the wait; every LDS read of a pass is issued before its first use; 16-byte stores.
@@ -1040,6 +1053,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
       }
       publish(CTR(PB3, bt));
       if (a.tick_out) tk_att += wall_clock64() - tb0;
+      TB(5)
     }
     // ================= B5: cell backward =================
     if (has5) {
@@ -1062,12 +1076,21 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
         cp = a.Cst[((long)s * B + row) * H + u];
         if (a.rnn_mask) mk = a.rnn_mask[((long)s * B + row) * H + u];
       }
+      TB(6)
       if (!wg_wait(CTR(PB3, bt), (unsigned)(rows_bt * a.nsplit * (n + 1)), a.abort_word, &s_flag)) return;
+      TB(7)
       if (ev) {
         float dy = ld_sc1(a.DCVH + ((long)s * B + row) * 2 * H + H + u);
         float hs = 0.f;
-        for (int k = 0; k < a.nsplit; ++k) hs += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-            r_dha, (int)(((((long)s * B + row) * a.nsplit + k) * H + u) * 4), 0, 16));
+        for (int k0 = 0; k0 < a.nsplit; k0 += 8) {      // 8 partial loads in flight (a plain loop waits for each one)
+          float hv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            hv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                r_dha, (int)(((((long)s * B + row) * a.nsplit + min(k0 + j, a.nsplit - 1)) * H + u) * 4), 0, 16));
+#pragma unroll
+          for (int j = 0; j < 8; ++j) hs += k0 + j < a.nsplit ? hv[j] : 0.f;
+        }
         dy += hs;
         const float dh = v + dy * mk;
         const float tc = tanhf(ccur);
@@ -1079,19 +1102,27 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
         dc_state = dcv * g.z;
       }
       publish(CTR(PB5, bt));
+      TB(8)
     }
     // ================= B6: d_x0 = dz Wu =================
     if (has6) {
       const int bt = b6_bt, m0 = bt * 16;
+      TB(15)
       if (!wg_wait(CTR(PB5, bt), (unsigned)((H / 16) * (n + 1)), a.abort_word, &s_flag)) return;
+      TB(9)
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       wmac_chunked<NB_B6, 16>(acc, wreg, r_g, ((long)s * B + min(m0 + r16, B - 1)) * K4, K4, lane, wave);
       const float v = reduce16(acc, red);
       const int row = m0 + e_row;
       if (row < B) st_sc1(a.DX0 + ((long)s * B + row) * XI + b6_n0 + e_col, v);
       publish(CTR(PB6, bt));
+      TB(10)
     }
   }
+  if (timing && tid == 0 && (wg == 0 || wg == n5 || wg == n5 + 20 || wg == n5 + n6 || wg == n5 + n6 + n1 - 1 || wg == G - 1))
+    printf("pdecb wg %3d per-step 10ns: B1[pre %lld wait %lld tail %lld] B2[wait %lld work %lld] B3[wait+work %lld] B5[pre %lld wait %lld tail %lld] B6[wait %lld work %lld] other %lld\n",
+           wg, tb[0] / S, tb[1] / S, tb[2] / S, tb[3] / S, tb[4] / S, tb[5] / S, tb[6] / S, tb[7] / S, tb[8] / S, tb[9] / S, tb[10] / S, tb[15] / S);
+#undef TB
   if (has5) {
     const int row = b5_bt * 16 + e_row, u = b5_u0 + e_col;
     if (row < B) a.d_c0[(long)row * H + u] = dc_state;
@@ -1209,6 +1240,7 @@ int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, con
   a.ctr = bf.ctr;
   a.abort_word = bf.ctr + (size_t)PB_N * a.nbt * CTRS;
   a.tick_out = prof_tick_buffer(1);
+  { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
   ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)PB_N * a.nbt + 1) * CTRS * sizeof(unsigned), s));
   size_t scratch = 2 * (size_t)a.H + (size_t)((chunk + 3) & ~3) + 16 + 640;   // + ds/alpha/fold of the specialised attention scan
   const size_t shm = (2 * (size_t)chunk * a.H + scratch) * sizeof(float);
