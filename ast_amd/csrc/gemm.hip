@@ -2,7 +2,7 @@
 //
 // One kernel family covers every batched dense product of the train step (SURVEY.md K6, K9, K24 and
 // all dgrad / wgrad products): C[M,N] (+)= op(A) op(B) (+bias).
-//   128x128x32 block tile, 256 threads = 4 waves as 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles
+//   128x128x16 block tile (BK = 16, double-buffered in LDS), 256 threads = 4 waves as 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles
 //   (64 accumulator VGPRs).  Both operands are staged K-major in LDS (As[k][m], Bs[k][n]) so every MFMA
 //   operand read is one conflict-free ds_read_b32 across 32 consecutive floats; operands whose global
 //   rows are K-contiguous are transposed on the LDS write (row stride 129 -> conflict-free scalar
@@ -20,7 +20,12 @@ namespace astk {
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
+#ifndef ASTK_GEMM_BK
+#define ASTK_GEMM_BK 16
+#endif
+constexpr int BM = 128, BN = 128, BK = ASTK_GEMM_BK;
+constexpr int WGS_PER_CU = BK == 32 ? 2 : 3;   // co-resident workgroups the grid is sized for (BK = 16: 33 KB of LDS and 127 registers per
+                                               // workgroup; measured 768 ~ 1024 > 512 workgroups, and +5-7 % over BK = 32 at 512)
 constexpr int LD_RK = 129;  // LDS row stride (floats): operand staged from K-contiguous global rows
 constexpr int LD_KR = 132;  // LDS row stride: operand staged from M/N-contiguous global rows (16 B aligned)
 
@@ -46,19 +51,22 @@ __device__ __forceinline__ float4 mask4(float4 v, int nvalid) {
 // both branch-free, so the tile's loads are issued back to back (indexed rows are not supported on this path).
 template <bool RK, bool TWOLVL>
 struct Stager {
-  float4 reg[4];  // raw staged data: masked only when it is written to LDS, so the global loads stay in flight over the MFMAs
-  int nv[4];      // valid elements of reg[p]
-  long off[4];   // RK only: row offsets (fixed for the whole k loop)
-  bool ok[4];    // RK only
-  int a, b;      // RK: a = k-quad (0..7), b = row0 (0..31).  KR: a = col-quad (0..31), b = krow0 (0..7)
+  static constexpr int NP = BK / 8;        // passes: 256 threads x 16 B cover 1/NP of a 128 x BK tile
+  static constexpr int KQ = BK / 4;        // RK: k-quads per row
+  static constexpr int RPP = 256 / KQ;     // RK: rows per pass
+  float4 reg[NP];  // raw staged data: masked only when it is written to LDS, so the global loads stay in flight over the MFMAs
+  int nv[NP];      // valid elements of reg[p]
+  long off[NP];   // RK only: row offsets (fixed for the whole k loop)
+  bool ok[NP];    // RK only
+  int a, b;      // RK: a = k-quad (0..KQ-1), b = row0 (0..RPP-1).  KR: a = col-quad (0..31), b = krow0 (0..7)
 
   __device__ __forceinline__ void init(const MatView& v, int row0, int nrows, int tid) {
     if (RK) {
-      a = tid & 7;
-      b = tid >> 3;
+      a = tid % KQ;
+      b = tid / KQ;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        int r = row0 + b + 32 * p;
+      for (int p = 0; p < NP; ++p) {
+        int r = row0 + b + RPP * p;
         ok[p] = r < nrows;
         off[p] = rowoff(v, ok[p] ? r : (nrows - 1));
       }
@@ -75,7 +83,7 @@ struct Stager {
       const int k = kcur + a * 4;
       const int kc = min(k, ((K + 3) & ~3) - 4);
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      for (int p = 0; p < NP; ++p) {
         reg[p] = *reinterpret_cast<const float4*>(v.p + off[p] + kc);
         nv[p] = ok[p] ? (kend - k) : 0;
       }
@@ -83,7 +91,7 @@ struct Stager {
       const int col = col0 + a * 4;
       const int colc = min(col, ((ncols + 3) & ~3) - 4);
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      for (int p = 0; p < NP; ++p) {
         const int kr = kcur + b + 8 * p;
         const int krc = min(kr, kend - 1);
         const long ro = TWOLVL ? (long)(krc / v.tn) * v.sg + (long)(krc % v.tn) * v.st : (long)krc * v.ld;
@@ -95,8 +103,8 @@ struct Stager {
   __device__ __forceinline__ void store(float* S) const {
     if (RK) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int r = b + 32 * p;
+      for (int p = 0; p < NP; ++p) {
+        const int r = b + RPP * p;
         const float4 m = mask4(reg[p], nv[p]);
         S[(a * 4 + 0) * LD_RK + r] = m.x;
         S[(a * 4 + 1) * LD_RK + r] = m.y;
@@ -105,7 +113,7 @@ struct Stager {
       }
     } else {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(&S[(b + 8 * p) * LD_KR + a * 4]) = mask4(reg[p], nv[p]);
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<float4*>(&S[(b + 8 * p) * LD_KR + a * 4]) = mask4(reg[p], nv[p]);
     }
   }
 };
@@ -117,7 +125,7 @@ struct Stager {
 // this degenerates to the classical data-parallel launch; with G = 256 or 512 every CU gets the same number of
 // k-iterations whatever the tile count -- a 400-tile product no longer runs as "2 waves, the second 56% full".
 template <bool A_RK, bool B_RK, bool TWOLVL>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmGroup grp) {
+__global__ __launch_bounds__(256, WGS_PER_CU) void gemm_f32_kernel(GemmGroup grp) {
   constexpr int LDA = A_RK ? LD_RK : LD_KR;
   constexpr int LDB = B_RK ? LD_RK : LD_KR;
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
@@ -333,9 +341,9 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   static const int force_g = getenv("ASTK_GEMM_G") ? atoi(getenv("ASTK_GEMM_G")) : -1;   // tuning hook: 0 = one tile per WG
   long G = tiles;
   bool aligned = true;   // workgroup boundaries fall on tile boundaries
-  if (grp.iters_total >= 512L * 10) { G = 512; aligned = false; }
+  if (grp.iters_total >= 256L * WGS_PER_CU * 10 * (32 / BK)) { G = 256 * WGS_PER_CU; aligned = false; }
   else if (tiles < 160) {
-    const long g2 = std::min(256L, grp.iters_total / 4);
+    const long g2 = std::min(256L, grp.iters_total / (4 * (32 / BK)));
     if (g2 > tiles) { G = g2; aligned = false; }
   }
   if (force_g > 0) { G = std::min<long>(force_g, grp.iters_total); aligned = false; }
@@ -343,7 +351,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     // one tile per workgroup needs boundaries on tile boundaries: only true for uniform kt; otherwise fall back to an even split
     bool uniform = true;
     for (int i = 1; i < grp.n; ++i) uniform = uniform && grp.g[i].kt == grp.g[0].kt;
-    if (!uniform) { G = std::min(512L, std::max(1L, grp.iters_total / std::max(1, min_kt))); aligned = false; }
+    if (!uniform) { G = std::min(256L * WGS_PER_CU, std::max(1L, grp.iters_total / std::max(1, min_kt))); aligned = false; }
   }
   static const bool log_shapes = getenv("ASTK_GEMM_LOG") != nullptr;
   if (log_shapes)
