@@ -19,12 +19,14 @@ namespace astk {
 struct PersistCellHost {
   const float *Wl, *Wu, *bias, *zx, *xin, *mask, *WlT, *WuT_up, *dz_up, *d_enc, *d_hT, *d_cT;
   float *gates, *C, *HR, *HD, *enc;
-  unsigned long long* gran;
-  const unsigned long long* gran_nb;
-  const float* nb_mask;
+  const float* WuT;
+  float *PR, *PD;
+  const float* PD_up;
   int reverse_pos, layer;
 };
 bool lstm_persist_applicable(int T, int B, int h, int nl, int nd);
+size_t lstm_persist_pr_floats(int B, int h);
+size_t lstm_persist_pd_floats(int T, int B, int h);
 int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters, hipStream_t s);
 int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters, hipStream_t s);
 
@@ -41,7 +43,8 @@ struct LstmPlan {
   float* WlT[2][ASTK_MAX_RNN_LAYERS];  // (h, 4h)
   float* WuT[2][ASTK_MAX_RNN_LAYERS];  // (h, 4h) transposed upward weights of layers >= 1 (persistent backward)
   unsigned* counters;                  // arrival counters of the persistent kernels
-  unsigned long long* GRAN[2][ASTK_MAX_RNN_LAYERS];  // granule hand-off buffers of the persistent kernels: (T,B,4h) x {value, tag}
+  float* PR[2][ASTK_MAX_RNN_LAYERS];   // persistent backward (reduce-scatter): partial dh_rec ring of each cell
+  float* PD[2][ASTK_MAX_RNN_LAYERS];   // partial dx handed to the layer below (layers >= 1)
   float* GATH;                         // (T,B,4h) dz of the reverse stack's layer 0 re-ordered to frame order
   float* DX[2];                        // (T,B,h) gradient wrt a layer's input (layers >= 1)
   float* DC[2][2];                     // dc ping-pong (B,h)
@@ -73,9 +76,15 @@ int make_plan(const astk_lstm_stack_desc* d, void* ws, bool with_masks, LstmPlan
   }
   (void)with_masks;
   P.GATH = c.take<float>(P.nd > 1 ? tb * 4 * P.h : 4);
-  P.counters = c.take<unsigned>(((size_t)P.nd * P.nl * ((P.B + 15) / 16) + 2) * 64);
-  for (int dd = 0; dd < P.nd; ++dd)
-    for (int l = 0; l < P.nl; ++l) P.GRAN[dd][l] = c.take<unsigned long long>(tb * 4 * P.h);
+  P.counters = c.take<unsigned>(((size_t)2 * P.nd * P.nl * ((P.B + 15) / 16) + 2) * 64);
+  {
+    const bool pp = lstm_persist_applicable(P.T, P.B, P.h, P.nl, P.nd);
+    for (int dd = 0; dd < P.nd; ++dd)
+      for (int l = 0; l < P.nl; ++l) {
+        P.PR[dd][l] = c.take<float>(pp ? lstm_persist_pr_floats(P.B, P.h) : 4);
+        P.PD[dd][l] = c.take<float>(pp && l > 0 ? lstm_persist_pd_floats(P.T, P.B, P.h) : 4);
+      }
+  }
   P.bytes = c.total();
   return 0;
 }
@@ -161,9 +170,6 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
         c.enc = top ? enc_states + (size_t)dd * h : nullptr;
         c.reverse_pos = dd == 1;
         c.layer = l;
-        c.gran = P.GRAN[dd][l];
-        c.gran_nb = l > 0 ? P.GRAN[dd][l - 1] : nullptr;
-        c.nb_mask = (l > 0 && masks) ? masks + ((size_t)dd * P.nl + l - 1) * T * bh : nullptr;
       }
     }
     ASTK_TRY(lstm_persist_fwd_launch(cells, P.nd * P.nl, P.nl, T, B, h, H, P.counters, s));
@@ -237,6 +243,8 @@ int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
   int* rows_inv = (int*)((char*)rows_perm + align_up((size_t)T * B * sizeof(int), 256));
   const size_t bh = (size_t)B * h;
   const bool persist = lstm_persist_applicable(T, B, h, P.nl, P.nd);
+  static const bool rs_env = !(getenv("ASTK_LSTM_BWD_RS") && getenv("ASTK_LSTM_BWD_RS")[0] == '0');
+  const bool rs_path = persist && rs_env;
   if (persist) {
     PersistCellHost cells[16];
     memset(cells, 0, sizeof(cells));
@@ -253,6 +261,12 @@ int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
         c.WlT = P.WlT[dd][l];
         c.WuT_up = top ? nullptr : P.WuT[dd][l + 1];
         c.dz_up = top ? nullptr : P.ZG[dd][l + 1];
+        if (rs_path) {
+          c.WuT = l > 0 ? P.WuT[dd][l] : nullptr;
+          c.PR = P.PR[dd][l];
+          c.PD = l > 0 ? P.PD[dd][l] : nullptr;
+          c.PD_up = top ? nullptr : P.PD[dd][l + 1];
+        }
         c.gates = P.ZG[dd][l];
         c.C = P.CC[dd][l];
         c.mask = masks ? masks + ((size_t)dd * P.nl + l) * T * bh : nullptr;

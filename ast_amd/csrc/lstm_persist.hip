@@ -59,12 +59,18 @@ struct PCellB {
   const float* d_enc;   // top layer: d_enc_states + dir*h
   const float* d_hT;    // (B,h) or null
   const float* d_cT;    // (B,h) or null
+  // reduce-scatter path (lstm_persist_bwd_rs):
+  const float* WuT;     // (h, 4h): transposed upward weight of THIS cell (layers >= 1), for the partials handed DOWN
+  float* PR;            // ring [PR_RING][nbt][nslice consumer][nslice producer][16 col][16 row]: partial dh_rec of this cell
+  float* PD;            // [T][nbt][nslice consumer][nslice producer][16][16]: partial dx handed to the layer below (null: layer 0)
+  const float* PD_up;   // PD of the layer above (null: top layer)
   int reverse_pos;
   int layer;
 };
 struct PBwdArgs {
   PCellB c[16];
   int ncells, nl, T, B, h, H;
+  int dbg;
   unsigned* done;
   unsigned* abort_word;
 };
@@ -274,13 +280,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd(PFwdArgs a) {
 }
 
 
-// ------------------------------------------------------------------ forward, granule hand-off (R2)
-// Same work split as lstm_persist_fwd, different transport: every h value is published as ONE 8-byte {value, tag}
-// granule (sc1 store, tag = t + 1, the buffer is zeroed before every launch), and every consuming WAVE sweeps exactly
-// the granules its own MFMA fragments need until all tags match -- the data is the flag.  Per step this removes the
-// producer's drain + barrier + counter add and the consumer's counter poll + barrier (three dependent fabric round
-// trips) from the recurrence's critical path, and waves no longer wait for producers they do not read.
-// A light poll of one 16-byte pair per lane precedes the full sweep so that waiting waves do not flood the fabric.
+// ------------------------------------------------------------------ forward, sentinel hand-off
 // ---- tag-free hand-off: the data is the flag.
 // A hand-off buffer is filled with SENTINEL words (0xFFFFFFFF, a NaN pattern no finite activation and no arithmetic NaN
 // has) by a memset node before every launch; producers store each value ONCE, write-through (sc1), every value to its own
@@ -592,15 +592,187 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd(PBwdArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------ backward, reduce-scatter hand-off
+// lstm_persist_bwd gathers: every workgroup pulls the whole dz_{t+1} row block of its cell (16 x 4h) and of the layer above
+// -- 128 KB per workgroup and step, which is what bounds it (6.2 us/step).  Here the products are turned around: the
+// workgroup that OWNS 64 gate columns of dz multiplies them with the matching 64 rows of W_l (and of its own W_u for the layer
+// below) as soon as its gate epilogue has produced them, and hands out 16x16 PARTIAL sums, one tile per consuming slice; a
+// consumer adds the 16 partial tiles of its slice: 16 KB + 16 KB per workgroup and step instead of 128 KB, same MFMA count.
+// Thread ownership is (unit = tid >> 4, row = tid & 15) so that the partial tiles, stored by the MFMA lanes as [col][row] in
+// 16-byte pieces, are read back with fully coalesced 4-byte loads.  Counter protocol (R1): partials are written through (sc1),
+// drained, one arrival per workgroup and step on counter A (own cell) and, after the second product, counter B (layer below).
+constexpr int PR_RING = 4;
+template <int KB>
+__global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
+  constexpr int NS = 4 * KB;          // slices of a cell = 16x16 output tiles of a product = partial tiles per consumer
+  __shared__ __attribute__((aligned(16))) float dzS[16 * 64];
+  __shared__ int s_ok1, s_ok2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int cell = blockIdx.z, bt = blockIdx.y, j = blockIdx.x, j0 = j * 16;
+  const PCellB& c = a.c[cell];
+  const int T = a.T, B = a.B, h = a.h;
+  const int nbt = gridDim.y;
+  const int K = 4 * h;
+  const bool has_up = c.PD_up != nullptr, has_down = c.PD != nullptr;
+  unsigned* ctrA = a.done + (cell * nbt + bt) * CTR_STRIDE;
+  unsigned* ctrB = a.done + ((a.ncells + cell) * nbt + bt) * CTR_STRIDE;
+  const unsigned* upB = has_up ? a.done + ((a.ncells + cell + 1) * nbt + bt) * CTR_STRIDE : nullptr;
+  const int m0 = bt * 16;
+
+  // resident weight fragments: product tile tl = wave*KB + nt covers output units 16 tl .. 16 tl + 15; K = this slice's 64 gate columns
+  float4 wl[KB][4], wd[KB][4];
+#pragma unroll
+  for (int nt = 0; nt < KB; ++nt) {
+    const long n = 16 * (wave * KB + nt) + r16;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      wl[nt][s4] = *reinterpret_cast<const float4*>(c.WlT + n * K + 64 * j + 16 * s4 + 4 * q);
+      wd[nt][s4] = has_down ? *reinterpret_cast<const float4*>(c.WuT + n * K + 64 * j + 16 * s4 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const __amdgpu_buffer_rsrc_t r_pr = make_rsrc(c.PR);
+  const __amdgpu_buffer_rsrc_t r_pd = make_rsrc(has_down ? c.PD : c.PR);
+  const __amdgpu_buffer_rsrc_t r_pu = make_rsrc(has_up ? c.PD_up : c.PR);
+  const int u = tid >> 4, r = tid & 15;                   // epilogue ownership: (unit, row)
+  const int eu = j0 + u, eb = m0 + r;
+  const bool evalid = eb < B;
+  const long ebc = evalid ? eb : B - 1;
+  float dc_state = 0.f, dhadd = 0.f;
+  if (c.d_cT) dc_state = c.d_cT[ebc * h + eu];
+  if (c.d_hT) dhadd = c.d_hT[ebc * h + eu];
+  const int tile_bytes = 256 * 4;                          // one 16x16 partial tile
+  const long cons_stride = (long)NS * tile_bytes;          // bytes between consumers
+  bool pending_b = false;
+  f32x4 acc2[KB];
+#pragma unroll
+  for (int nt = 0; nt < KB; ++nt) acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto store_down = [&](int ts) {
+#pragma unroll
+    for (int nt = 0; nt < KB; ++nt) {
+      const int tl = wave * KB + nt;
+      u32x4 o;
+      o.x = __float_as_uint(acc2[nt][0]); o.y = __float_as_uint(acc2[nt][1]); o.z = __float_as_uint(acc2[nt][2]); o.w = __float_as_uint(acc2[nt][3]);
+      __builtin_amdgcn_raw_buffer_store_b128(o, r_pd, (int)((((long)ts * nbt + bt) * NS + tl) * cons_stride) + j * tile_bytes + (r16 * 16 + 4 * q) * 4, 0, 16);
+    }
+  };
+
+  long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool timing = a.dbg != 0;
+#define TICK(i, t0) if (timing) { const long long now_ = wall_clock64(); tk[i] += now_ - t0; t0 = now_; }
+  for (int t = T - 1; t >= 0; --t) {
+    long long t0 = timing ? wall_clock64() : 0;
+    const int stepno = T - 1 - t;
+    const long tb = (long)t * B + ebc;
+    // inputs from earlier launches: issue before any wait
+    const float4 g = *reinterpret_cast<const float4*>(c.gates_dz + tb * K + 4 * eu);
+    const float ccur = c.C[tb * h + eu];
+    const float cp = t > 0 ? c.C[(tb - B) * h + eu] : 0.f;
+    const float mk = c.mask ? c.mask[tb * h + eu] : 1.f;
+    float dye = 0.f;
+    if (c.d_enc) {
+      const int pos = c.reverse_pos ? T - 1 - t : t;
+      dye = c.d_enc[(ebc * T + pos) * a.H + eu];
+    }
+    float v1 = 0.f;
+    if (has_up) {                            // partials handed down by the layer above (it runs ahead)
+      if (tid == 0) s_ok1 = wait_ge(upB, (unsigned)(NS * (stepno + 1)), a.abort_word) ? 1 : 0;
+      __syncthreads();
+      if (!s_ok1) break;
+      const int base = (int)((((long)t * nbt + bt) * NS + j) * cons_stride) + tid * 4;
+      float pv[NS];
+#pragma unroll
+      for (int p = 0; p < NS; ++p) pv[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pu, base + p * tile_bytes, 0, 16));
+#pragma unroll
+      for (int p = 0; p < NS; ++p) v1 += pv[p];
+    }
+    TICK(0, t0)
+    float v0 = 0.f;
+    if (stepno > 0) {                        // partial dh_rec tiles of this cell's step t+1
+      if (tid == 0) s_ok2 = wait_ge(ctrA, (unsigned)(NS * stepno), a.abort_word) ? 1 : 0;
+      __syncthreads();
+      if (!s_ok2) break;
+      TICK(1, t0)
+      const int slot = (t + 1) % PR_RING;
+      const int base = (int)((((long)slot * nbt + bt) * NS + j) * cons_stride) + tid * 4;
+      float pv[NS];
+#pragma unroll
+      for (int p = 0; p < NS; ++p) pv[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pr, base + p * tile_bytes, 0, 16));
+#pragma unroll
+      for (int p = 0; p < NS; ++p) v0 += pv[p];
+    }
+    TICK(2, t0)
+    // every vector memory operation of this wave so far has completed (the partial loads were just consumed; the previous
+    // step's down-partials went out a whole step ago): this is the drain the deferred publish of counter B needs
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float4 dz;
+    {
+      const float dh = v0 + (v1 + dye) * mk + (stepno == 0 ? dhadd : 0.f);
+      const float tc = tanhf(ccur);
+      const float dcv = dh * g.w * (1.f - tc * tc) + dc_state;
+      dz = make_float4(dcv * g.y * (1.f - g.x * g.x), dcv * g.x * g.y * (1.f - g.y), dcv * cp * g.z * (1.f - g.z), dh * tc * g.w * (1.f - g.w));
+      dc_state = dcv * g.z;
+      *reinterpret_cast<float4*>(&dzS[r * 64 + 4 * u]) = dz;
+    }
+    TICK(3, t0)
+    __syncthreads();
+    if (pending_b && tid == 0) __hip_atomic_fetch_add(ctrB, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // down-partials of step t+1
+    float4 af[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) af[s4] = *reinterpret_cast<const float4*>(&dzS[r16 * 64 + 16 * s4 + 4 * q]);
+    // ---- product 1: partial dh_rec for every slice of this cell -> write-through stores
+    {
+      const int slot = t % PR_RING;
+#pragma unroll
+      for (int nt = 0; nt < KB; ++nt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc, af[s4], wl[nt][s4]) }
+        const int tl = wave * KB + nt;
+        u32x4 o;
+        o.x = __float_as_uint(acc[0]); o.y = __float_as_uint(acc[1]); o.z = __float_as_uint(acc[2]); o.w = __float_as_uint(acc[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(o, r_pr, (int)((((long)slot * nbt + bt) * NS + tl) * cons_stride) + j * tile_bytes + (r16 * 16 + 4 * q) * 4, 0, 16);
+      }
+    }
+    // ---- product 2 (partial dx for the layer below): its MFMAs run while the product-1 stores land; its own stores go out
+    // behind the publish of counter A and counter B is bumped at the next step's drain point.  (Measured alternatives: product 2
+    // behind the publish, with or without holding its stores back: 0.3-0.4 us per step slower -- the peers see counter A only
+    // ~2 us after the atomic either way, so hiding the 0.5 us drain is what pays.)
+    if (has_down) {
+#pragma unroll
+      for (int nt = 0; nt < KB; ++nt) {
+        acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc2[nt], af[s4], wd[nt][s4]) }
+      }
+    }
+    TICK(4, t0)
+    publish(ctrA);      // drain (product-1 stores only), barrier, one arrival
+    TICK(5, t0)
+    if (evalid) *reinterpret_cast<float4*>(c.gates_dz + tb * K + 4 * eu) = dz;   // for the batched products after the launch
+    if (has_down) {
+      store_down(t);
+      pending_b = true;
+    }
+    TICK(6, t0)
+  }
+  if (pending_b) publish(ctrB);
+  if (timing && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0)
+    printf("bwd_rs cell %d (layer %d): per-step 10ns: up wait+loads %lld  own wait %lld  own loads+sum %lld  epilogue %lld  barrier+mfma1+stores %lld  publishA %lld  product2+publishB %lld\n",
+           cell, c.layer, tk[0] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T, tk[5] / T, tk[6] / T);
+#undef TICK
+}
+
 }  // namespace
 
 // ---- launchers (called from lstm.hip).  Return 1 if the persistent path is not applicable (caller falls back).
 struct PersistCellHost {
   const float *Wl, *Wu, *bias, *zx, *xin, *mask, *WlT, *WuT_up, *dz_up, *d_enc, *d_hT, *d_cT;
   float *gates, *C, *HR, *HD, *enc;
-  unsigned long long* gran;       // this cell's granule buffer (T*B*4h granules: forward uses the first T*B*h)
-  const unsigned long long* gran_nb;  // forward: granules of the layer below; backward: of the layer above
-  const float* nb_mask;           // forward: dropout mask of the layer below
+  const float* WuT;               // backward: this cell's transposed upward weight (layers >= 1)
+  float *PR, *PD;                 // backward, reduce-scatter path: partial-sum buffers of this cell
+  const float* PD_up;
   int reverse_pos, layer;
 };
 
@@ -609,7 +781,8 @@ bool lstm_persist_applicable(int T, int B, int h, int nl, int nd) {
   if (B < 1 || T < 1) return false;
   const long wgs = (long)(h / 16) * ((B + 15) / 16) * nl * nd;
   if (wgs > 256 || nl * nd > 16) return false;        // one workgroup per CU must hold the whole grid
-  if ((long)T * B * h * 32 >= (1L << 31)) return false;  // granule buffers are addressed with 32-bit byte offsets
+  // hand-off buffers are addressed with 32-bit byte offsets
+  if ((long)T * B * h * 16 >= (1L << 31) || (long)T * ((B + 15) / 16) * (h / 16) * (h / 16) * 1024 >= (1L << 31)) return false;
   const char* e = getenv("ASTK_LSTM_PERSIST");
   if (e && e[0] == '0') return false;
   return true;
@@ -674,21 +847,42 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
     PCellB& d = a.c[i];
     d.WlT = c.WlT; d.WuT_up = c.WuT_up; d.gates_dz = c.gates; d.dz_up = c.dz_up; d.C = c.C; d.mask = c.mask; d.d_enc = c.d_enc;
     d.d_hT = c.d_hT; d.d_cT = c.d_cT; d.reverse_pos = c.reverse_pos; d.layer = c.layer;
+    d.WuT = c.WuT; d.PR = c.PR; d.PD = c.PD; d.PD_up = c.PD_up;
   }
   a.ncells = ncells; a.nl = nl; a.T = T; a.B = B; a.h = h; a.H = H;
   a.done = counters;
   a.abort_word = counters + (size_t)ncells * nbt * 64;
-  ASTK_HIP(hipMemsetAsync(counters, 0, ((size_t)ncells * nbt + 1) * 64 * sizeof(unsigned), s));
+  const bool rs = cells[0].PR != nullptr;
+  { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
+  if (rs) {   // counters A and B per (cell, batch tile), then the abort word
+    a.abort_word = counters + (size_t)2 * ncells * nbt * 64;
+    ASTK_HIP(hipMemsetAsync(counters, 0, ((size_t)2 * ncells * nbt + 1) * 64 * sizeof(unsigned), s));
+  } else {
+    ASTK_HIP(hipMemsetAsync(counters, 0, ((size_t)ncells * nbt + 1) * 64 * sizeof(unsigned), s));
+  }
   dim3 grid(h / 16, nbt, ncells), blk(256);
   ProfScope prof(PROF_CELL, s);
-  switch (h) {
-    case 64: hipLaunchKernelGGL((lstm_persist_bwd<1>), grid, blk, 0, s, a); break;
-    case 128: hipLaunchKernelGGL((lstm_persist_bwd<2>), grid, blk, 0, s, a); break;
-    case 256: hipLaunchKernelGGL((lstm_persist_bwd<4>), grid, blk, 0, s, a); break;
-    default: hipLaunchKernelGGL((lstm_persist_bwd<8>), grid, blk, 0, s, a); break;
+  if (rs) {
+    switch (h) {
+      case 64: hipLaunchKernelGGL((lstm_persist_bwd_rs<1>), grid, blk, 0, s, a); break;
+      case 128: hipLaunchKernelGGL((lstm_persist_bwd_rs<2>), grid, blk, 0, s, a); break;
+      case 256: hipLaunchKernelGGL((lstm_persist_bwd_rs<4>), grid, blk, 0, s, a); break;
+      default: hipLaunchKernelGGL((lstm_persist_bwd_rs<8>), grid, blk, 0, s, a); break;
+    }
+  } else {
+    switch (h) {
+      case 64: hipLaunchKernelGGL((lstm_persist_bwd<1>), grid, blk, 0, s, a); break;
+      case 128: hipLaunchKernelGGL((lstm_persist_bwd<2>), grid, blk, 0, s, a); break;
+      case 256: hipLaunchKernelGGL((lstm_persist_bwd<4>), grid, blk, 0, s, a); break;
+      default: hipLaunchKernelGGL((lstm_persist_bwd<8>), grid, blk, 0, s, a); break;
+    }
   }
   ASTK_LAUNCH_CHECK();
   return 0;
 }
+
+// bytes of the reduce-scatter partial buffers of one cell (lstm.hip sizes the workspace with these)
+size_t lstm_persist_pr_floats(int B, int h) { return (size_t)PR_RING * ((B + 15) / 16) * (h / 16) * (h / 16) * 256; }
+size_t lstm_persist_pd_floats(int T, int B, int h) { return (size_t)T * ((B + 15) / 16) * (h / 16) * (h / 16) * 256; }
 
 }  // namespace astk
