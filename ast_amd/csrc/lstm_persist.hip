@@ -739,9 +739,10 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
     // behind the publish of counter A and counter B is bumped at the next step's drain point.  (Measured alternatives: product 2
     // behind the publish, with or without holding its stores back: 0.3-0.4 us per step slower -- the peers see counter A only
     // ~2 us after the atomic either way, so hiding the 0.5 us drain is what pays.)
+    constexpr int KB1 = (KB + 1) / 2;     // first half of product 2 hides the drain, second half runs behind the publish
     if (has_down) {
 #pragma unroll
-      for (int nt = 0; nt < KB; ++nt) {
+      for (int nt = 0; nt < KB1; ++nt) {
         acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc2[nt], af[s4], wd[nt][s4]) }
@@ -752,6 +753,12 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
     TICK(5, t0)
     if (evalid) *reinterpret_cast<float4*>(c.gates_dz + tb * K + 4 * eu) = dz;   // for the batched products after the launch
     if (has_down) {
+#pragma unroll
+      for (int nt = KB1; nt < KB; ++nt) {
+        acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc2[nt], af[s4], wd[nt][s4]) }
+      }
       store_down(t);
       pending_b = true;
     }
