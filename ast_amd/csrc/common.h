@@ -139,6 +139,19 @@ constexpr int FILL_SEG_MAX = 16;
 struct FillSegs { int n; void* p[FILL_SEG_MAX]; size_t bytes[FILL_SEG_MAX]; };
 static inline void fill_seg_add(FillSegs& f, void* p, size_t bytes) { if (bytes > 0 && f.n < FILL_SEG_MAX) { f.p[f.n] = p; f.bytes[f.n] = bytes; ++f.n; } }
 int fill_u32_segments(const FillSegs& f, unsigned value, hipStream_t s);
+// One launch for up to FILL_SEG_MAX independent device-to-device copies (16-byte aligned, sizes multiples of 4 bytes) and one for
+// up to FILL_SEG_MAX independent transposes: the per-call state shuffling (final states, transposed weights) used to be ~35 tiny
+// launches of ~5 us each per train step.
+struct CopySegs { int n; void* dst[FILL_SEG_MAX]; const void* src[FILL_SEG_MAX]; size_t bytes[FILL_SEG_MAX]; };
+static inline void copy_seg_add(CopySegs& c, void* dst, const void* src, size_t bytes) {
+  if (bytes > 0 && c.n < FILL_SEG_MAX) { c.dst[c.n] = dst; c.src[c.n] = src; c.bytes[c.n] = bytes; ++c.n; }
+}
+int copy_segments(const CopySegs& c, hipStream_t s);
+struct TransposeJobs { int n; float* dst[FILL_SEG_MAX]; const float* src[FILL_SEG_MAX]; long ldd[FILL_SEG_MAX], lds[FILL_SEG_MAX]; int rows[FILL_SEG_MAX], cols[FILL_SEG_MAX]; };
+static inline void transpose_add(TransposeJobs& t, float* dst, long ldd, const float* src, long lds, int rows, int cols) {   // dst[c][r] = src[r][c]
+  if (rows > 0 && cols > 0 && t.n < FILL_SEG_MAX) { t.dst[t.n] = dst; t.ldd[t.n] = ldd; t.src[t.n] = src; t.lds[t.n] = lds; t.rows[t.n] = rows; t.cols[t.n] = cols; ++t.n; }
+}
+int transpose_batch(const TransposeJobs& t, hipStream_t s);
 int copy_f32(float* dst, const float* src, size_t n, hipStream_t s);
 int copy2d_f32(float* dst, long ldd, const float* src, long lds, int rows, int cols, int cols_dst, hipStream_t s);
 int add2d_f32(float* dst, long ldd, const float* src, long lds, int rows, int cols, hipStream_t s);

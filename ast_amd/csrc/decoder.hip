@@ -311,12 +311,21 @@ int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
   const int B = P.B, S = P.S, H = P.H, E = P.E, A = P.A, V = P.V, XI = P.XI, nl = P.nl;
   const size_t bh = (size_t)B * H;
   // initial states and zero attention vector (seq2seq.py:318-333, :420)
-  for (int l = 0; l < nl; ++l) {
-    ASTK_TRY(copy_f32(P.C[l], c0 + l * bh, bh, s));
-    ASTK_TRY(copy_f32(P.HR[l], h0 + l * bh, bh, s));
+  {
+    CopySegs cp;
+    cp.n = 0;
+    for (int l = 0; l < nl; ++l) {
+      if (cp.n + 2 > FILL_SEG_MAX) { ASTK_TRY(copy_segments(cp, s)); cp.n = 0; }
+      copy_seg_add(cp, P.C[l], c0 + l * bh, bh * sizeof(float));
+      copy_seg_add(cp, P.HR[l], h0 + l * bh, bh * sizeof(float));
+    }
+    ASTK_TRY(copy_segments(cp, s));
+    FillSegs fz;
+    fz.n = 0;
+    fill_seg_add(fz, P.HT, (size_t)B * A * sizeof(float));
+    fill_seg_add(fz, P.X0, (size_t)B * XI * sizeof(float));   // ht_{-1} half of the first concat buffer
+    ASTK_TRY(fill_u32_segments(fz, 0u, s));
   }
-  ASTK_TRY(fill_zero(P.HT, (size_t)B * A * sizeof(float), s));
-  ASTK_TRY(fill_zero(P.X0, (size_t)B * XI * sizeof(float), s));   // ht_{-1} half of the first concat buffer
   ASTK_TRY(attn_ws_init(P.attn_ws, B, P.T, H, s));
   const int top = nl - 1;
   {
@@ -403,13 +412,19 @@ int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
   const size_t bh = (size_t)B * H;
   const int top = nl - 1;
   // transposed weights for the data-path products (dY W as row-panel NT products)
-  ASTK_TRY(transpose_f32(P.WoT, Vp, prm->Wo, A, V, A, s));        // (V,A) -> (A,Vp)
-  ASTK_TRY(transpose_f32(P.WcT, A, prm->Wc, 2 * H, A, 2 * H, s)); // (A,2H) -> (2H,A)
-  ASTK_TRY(transpose_f32(P.WaT, H, prm->Wa, H, H, H, s));
-  for (int l = 0; l < nl; ++l) {
-    const int in = l == 0 ? XI : H;
-    ASTK_TRY(transpose_f32(P.WuT[l], 4 * H, prm->lstm[l].Wu, in, 4 * H, in, s));   // (4H,in) -> (in,4H)
-    ASTK_TRY(transpose_f32(P.WlT[l], 4 * H, prm->lstm[l].Wl, H, 4 * H, H, s));     // (4H,H)  -> (H,4H)
+  {
+    TransposeJobs tj;
+    tj.n = 0;
+    transpose_add(tj, P.WoT, Vp, prm->Wo, A, V, A);          // (V,A) -> (A,Vp)
+    transpose_add(tj, P.WcT, A, prm->Wc, 2 * H, A, 2 * H);   // (A,2H) -> (2H,A)
+    transpose_add(tj, P.WaT, H, prm->Wa, H, H, H);
+    for (int l = 0; l < nl; ++l) {
+      const int in = l == 0 ? XI : H;
+      if (tj.n + 2 > FILL_SEG_MAX) { ASTK_TRY(transpose_batch(tj, s)); tj.n = 0; }
+      transpose_add(tj, P.WuT[l], 4 * H, prm->lstm[l].Wu, in, 4 * H, in);   // (4H,in) -> (in,4H)
+      transpose_add(tj, P.WlT[l], 4 * H, prm->lstm[l].Wl, H, 4 * H, H);     // (4H,H)  -> (H,4H)
+    }
+    ASTK_TRY(transpose_batch(tj, s));
   }
   ASTK_TRY(fill_zero(P.ZERO, (size_t)B * (A > H ? A : H) * sizeof(float), s));
   ASTK_TRY(attn_ws_init(P.attn_ws, B, T, H, s));

@@ -173,11 +173,15 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
       }
     }
     ASTK_TRY(lstm_persist_fwd_launch(cells, P.nd * P.nl, P.nl, T, B, h, H, P.counters, s));
+    CopySegs cp;   // final states of every cell: one launch
+    cp.n = 0;
     for (int dd = 0; dd < P.nd; ++dd)
       for (int l = 0; l < P.nl; ++l) {
-        if (cT) ASTK_TRY(copy_f32(cT + ((size_t)dd * P.nl + l) * bh, P.CC[dd][l] + (size_t)(T - 1) * bh, bh, s));
-        if (hT) ASTK_TRY(copy_f32(hT + ((size_t)dd * P.nl + l) * bh, P.HR[dd][l] + (size_t)(T - 1) * bh, bh, s));
+        if (cp.n + 2 > FILL_SEG_MAX) { ASTK_TRY(copy_segments(cp, s)); cp.n = 0; }
+        if (cT) copy_seg_add(cp, cT + ((size_t)dd * P.nl + l) * bh, P.CC[dd][l] + (size_t)(T - 1) * bh, bh * sizeof(float));
+        if (hT) copy_seg_add(cp, hT + ((size_t)dd * P.nl + l) * bh, P.HR[dd][l] + (size_t)(T - 1) * bh, bh * sizeof(float));
       }
+    ASTK_TRY(copy_segments(cp, s));
     return 0;
   }
   for (int l = 0; l < P.nl; ++l) {
@@ -248,12 +252,16 @@ int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
   if (persist) {
     PersistCellHost cells[16];
     memset(cells, 0, sizeof(cells));
+    TransposeJobs tj;   // transposed recurrent / upward weights of every cell: one launch
+    tj.n = 0;
     for (int dd = 0; dd < P.nd; ++dd)
       for (int l = 0; l < P.nl; ++l) {
         const astk_lstm_params& p = prm[dd * P.nl + l];
-        ASTK_TRY(transpose_f32(P.WlT[dd][l], 4 * h, p.Wl, h, 4 * h, h, s));
-        if (l > 0) ASTK_TRY(transpose_f32(P.WuT[dd][l], 4 * h, p.Wu, h, 4 * h, h, s));
+        if (tj.n + 2 > FILL_SEG_MAX) { ASTK_TRY(transpose_batch(tj, s)); tj.n = 0; }
+        transpose_add(tj, P.WlT[dd][l], 4 * h, p.Wl, h, 4 * h, h);
+        if (l > 0) transpose_add(tj, P.WuT[dd][l], 4 * h, p.Wu, h, 4 * h, h);
       }
+    ASTK_TRY(transpose_batch(tj, s));
     for (int dd = 0; dd < P.nd; ++dd)
       for (int l = 0; l < P.nl; ++l) {
         PersistCellHost& c = cells[dd * P.nl + l];

@@ -2,6 +2,7 @@
 // products), column sums (bias gradients), counter-based RNG fills, and the fused optimizer
 // (nn.py:81-119: WeightDecay -> GradientClipping -> Adam(amsgrad) on one flat buffer).
 #include "common.h"
+#include <algorithm>
 #include <stdarg.h>
 #include <vector>
 
@@ -77,6 +78,40 @@ __global__ void k_transpose(float* dst, long ldd, const float* src, long lds, in
   for (int j = ty; j < 32; j += 8) {
     const int c = bx + j, r = by + tx;   // dst row = src col
     if (c < cols && r < ldd) dst[(long)c * ldd + r] = t[tx][j];
+  }
+}
+
+__global__ void k_transpose_batch(TransposeJobs tj) {
+  const int job = blockIdx.z;
+  const int rows = tj.rows[job], cols = tj.cols[job];
+  const long ldd = tj.ldd[job], lds = tj.lds[job];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  if (bx >= cols || by >= ldd) return;
+  __shared__ float t[32][33];
+  const float* src = tj.src[job];
+  float* dst = tj.dst[job];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    t[j][tx] = (r < rows && c < cols) ? src[(long)r * lds + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;
+    if (c < cols && r < ldd) dst[(long)c * ldd + r] = t[tx][j];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_copy_segments(CopySegs cs) {
+  const int seg = blockIdx.y;
+  const size_t n16 = cs.bytes[seg] / 16;
+  const uint4* src = reinterpret_cast<const uint4*>(cs.src[seg]);
+  uint4* dst = reinterpret_cast<uint4*>(cs.dst[seg]);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+  if (blockIdx.x == 0) {
+    const unsigned* sw = reinterpret_cast<const unsigned*>(cs.src[seg]);
+    unsigned* dw = reinterpret_cast<unsigned*>(cs.dst[seg]);
+    for (size_t i = n16 * 4 + threadIdx.x; i < cs.bytes[seg] / 4; i += blockDim.x) dw[i] = sw[i];
   }
 }
 
@@ -241,6 +276,27 @@ int transpose_f32(float* dst, long ldd, const float* src, long lds, int rows, in
   if (rows <= 0 || cols <= 0) return 0;
   // y blocks cover ldd so that the pad columns [rows, ldd) of every dst row are written as zeros
   hipLaunchKernelGGL(k_transpose, dim3(cdiv(cols, 32), cdiv(ldd, 32)), dim3(256), 0, s, dst, ldd, src, lds, rows, cols);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+int transpose_batch(const TransposeJobs& t, hipStream_t s) {
+  if (t.n <= 0) return 0;
+  int gx = 1, gy = 1;
+  for (int i = 0; i < t.n; ++i) { gx = std::max(gx, cdiv(t.cols[i], 32)); gy = std::max(gy, cdiv(t.ldd[i], 32)); }
+  hipLaunchKernelGGL(k_transpose_batch, dim3(gx, gy, t.n), dim3(256), 0, s, t);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+int copy_segments(const CopySegs& c, hipStream_t s) {
+  if (c.n <= 0) return 0;
+  size_t mx = 0;
+  for (int i = 0; i < c.n; ++i) {
+    ASTK_CHECK(aligned16(c.dst[i]) && aligned16(c.src[i]) && (c.bytes[i] % 4) == 0, "copy_segments: segment %d must be 16-byte aligned, size a multiple of 4", i);
+    mx = std::max(mx, c.bytes[i]);
+  }
+  unsigned gx = (unsigned)((mx / 16 + 256 * 4 - 1) / (256 * 4));
+  gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
+  hipLaunchKernelGGL(k_copy_segments, dim3(gx, (unsigned)c.n), dim3(256), 0, s, c);
   ASTK_LAUNCH_CHECK();
   return 0;
 }

@@ -320,14 +320,16 @@ class SpeechEncoderDecoder:
     # ------------------------------------------------------------------ seq2seq.py:318-333
     def init_decoder_state(self):
         st = self._cur
-        h = self.h
-        st["c0"].zero_()
-        st["h0"].zero_()
+        h, nd = self.h, self.n_dirs
+        # decoder layer k starts from [fwd_k ; rev_k] of the encoder; layers without an encoder counterpart keep the zeros they
+        # were allocated with (c0/h0 are only ever written here).  One strided copy per tensor and layer.
         for k in range(min(len(self.rnn_enc), len(self.rnn_dec))):
-            for d_ in range(self.n_dirs):
-                st["c0"][k, :, d_ * h:(d_ + 1) * h] = st["cT"][d_, k]
-                st["h0"][k, :, d_ * h:(d_ + 1) * h] = st["hT"][d_, k]
-        self._dec_c, self._dec_h = st["c0"].clone(), st["h0"].clone()
+            st["c0"][k].view(-1, nd, h).copy_(st["cT"][:, k].permute(1, 0, 2))
+            st["h0"][k].view(-1, nd, h).copy_(st["hT"][:, k].permute(1, 0, 2))
+        if config.train:
+            self._dec_c, self._dec_h = st["c0"], st["h0"]      # the step API (decode_step) clones before it advances them
+        else:
+            self._dec_c, self._dec_h = st["c0"].clone(), st["h0"].clone()
 
     # ------------------------------------------------------------------ seq2seq.py:399-473
     def forward_loss(self, X, y, teach_ratio, random_out=0, add_noise=0):
@@ -375,13 +377,11 @@ class SpeechEncoderDecoder:
         check(lib.astk_decoder_bwd(C.byref(st["dd"]), C.byref(st["dp"]), C.byref(st["dg"]), _vp(st["enc_states"]), _vp(st["c0"]),
                                    _vp(st["h0"]), _vp(st["y"]), _vp(st["emb_mask"]), _vp(st["rnn_masks"]), _vp(st["d_enc"]),
                                    _vp(st["d_c0"]), _vp(st["d_h0"]), _vp(wd), wd.numel(), s))
-        h = self.h
-        st["d_cT"].zero_()
-        st["d_hT"].zero_()
+        h, nd = self.h, self.n_dirs
+        # encoder layers without a decoder counterpart keep the zero gradient they were allocated with
         for k in range(min(len(self.rnn_enc), len(self.rnn_dec))):
-            for d_ in range(self.n_dirs):
-                st["d_cT"][d_, k] = st["d_c0"][k, :, d_ * h:(d_ + 1) * h]
-                st["d_hT"][d_, k] = st["d_h0"][k, :, d_ * h:(d_ + 1) * h]
+            st["d_cT"][:, k].copy_(st["d_c0"][k].view(-1, nd, h).permute(1, 0, 2))
+            st["d_hT"][:, k].copy_(st["d_h0"][k].view(-1, nd, h).permute(1, 0, 2))
         wl = self._workspace("lstm", st["ws_lstm"])
         check(lib.astk_lstm_stack_bwd(C.byref(st["ld"]), st["lp"], st["lg"], _vp(st["xlstm"]), _vp(st["enc_masks"]), _vp(st["d_enc"]),
                                       _vp(st["d_cT"]), _vp(st["d_hT"]), _vp(st["d_xlstm"]), _vp(wl), wl.numel(), s))
