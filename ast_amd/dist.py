@@ -50,6 +50,59 @@ def allreduce_grads(arena):
     return allreduce_flat(arena.grad)
 
 
+class GradBuckets:
+    """Overlapped gradient exchange: the flat gradient arena is cut into contiguous ranges that become final at different
+    points of the backward pass (arena order = [CNN | encoder LSTMs | attention + decoder], backward order = decoder ->
+    encoder -> CNN).  `launch(name)` starts an asynchronous all-reduce of one range on the communication stream as soon as
+    its producer has been enqueued; `finish(arena)` (installed as the optimizer's `grad_sync`) launches whatever is left,
+    waits for everything and applies the 1/world mean.  xGMI is point-to-point and a 53 MB all-reduce is ~1 ms of an ~9.5 ms
+    step: behind the encoder / CNN backward it costs nothing.  Numerically identical to `allreduce_grads` (same sums)."""
+
+    def __init__(self, arena, param_groups):
+        # param_groups: ordered {bucket name: [param names]}; every group must be one contiguous arena range
+        self.arena = arena
+        self.ranges = {}
+        covered = []
+        for gname, names in param_groups.items():
+            if not names:
+                continue
+            spans = sorted(arena.range_of(n) for n in names)
+            lo, hi = spans[0][0], spans[-1][0] + spans[-1][1]
+            assert sum(n for _, n in spans) == hi - lo, f"bucket {gname} is not contiguous in the arena"
+            self.ranges[gname] = (lo, hi)
+            covered.append((lo, hi))
+        covered.sort()
+        assert covered and covered[0][0] == 0 and covered[-1][1] == arena.size and all(
+            a[1] == b[0] for a, b in zip(covered, covered[1:])), "buckets must tile the arena"
+        self.pending = {}
+
+    def launch(self, name):
+        if not is_distributed() or name in self.pending or name not in self.ranges:
+            return
+        lo, hi = self.ranges[name]
+        self.pending[name] = td.all_reduce(self.arena.grad[lo:hi], op=td.ReduceOp.SUM, async_op=True)
+
+    def finish(self, arena=None):
+        if not is_distributed():
+            self.pending = {}
+            return
+        for name in self.ranges:
+            self.launch(name)
+        for work in self.pending.values():
+            work.wait()
+        self.pending = {}
+        self.arena.grad.mul_(1.0 / world_size())
+
+
+def make_grad_buckets(model):
+    """Buckets of a SpeechEncoderDecoder: CNN, encoder, decoder (+attention, embedding, output)."""
+    groups = {"cnn": [], "enc": [], "dec": []}
+    for name in model.arena.shapes:
+        link = name.split("/")[0]
+        groups["cnn" if link.startswith("CNN_") else "enc" if link.endswith("_enc") else "dec"].append(name)
+    return GradBuckets(model.arena, groups)
+
+
 def broadcast_params(arena, src=0):
     if is_distributed():
         td.broadcast(arena.data, src=src)

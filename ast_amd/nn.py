@@ -61,7 +61,11 @@ class NN:
             else:
                 print("layer {0:s} not in model".format(l))
         if adist.is_distributed():
-            self.optimizer.grad_sync = adist.allreduce_grads
+            if self.model.arena is not None:
+                self.model.grad_buckets = adist.make_grad_buckets(self.model)
+                self.optimizer.grad_sync = self.model.grad_buckets.finish
+            else:      # parameters materialise lazily on the first batch: fall back to one all-reduce of the whole arena
+                self.optimizer.grad_sync = adist.allreduce_grads
 
     def get_model(self):
         self.model_fname = os.path.join(self.model_dir, "seq2seq.model")

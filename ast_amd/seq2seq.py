@@ -111,6 +111,7 @@ class SpeechEncoderDecoder:
         self.loss = 0
         self._cur = None
         self._dec_c = self._dec_h = None
+        self.grad_buckets = None        # ast_amd.dist.GradBuckets under data parallelism: ranges are all-reduced as they become final
         self.mask_pad_id = None
 
     # ------------------------------------------------------------------ parameters
@@ -377,6 +378,8 @@ class SpeechEncoderDecoder:
         check(lib.astk_decoder_bwd(C.byref(st["dd"]), C.byref(st["dp"]), C.byref(st["dg"]), _vp(st["enc_states"]), _vp(st["c0"]),
                                    _vp(st["h0"]), _vp(st["y"]), _vp(st["emb_mask"]), _vp(st["rnn_masks"]), _vp(st["d_enc"]),
                                    _vp(st["d_c0"]), _vp(st["d_h0"]), _vp(wd), wd.numel(), s))
+        if self.grad_buckets is not None:
+            self.grad_buckets.launch("dec")
         h, nd = self.h, self.n_dirs
         # encoder layers without a decoder counterpart keep the zero gradient they were allocated with
         for k in range(min(len(self.rnn_enc), len(self.rnn_dec))):
@@ -385,8 +388,12 @@ class SpeechEncoderDecoder:
         wl = self._workspace("lstm", st["ws_lstm"])
         check(lib.astk_lstm_stack_bwd(C.byref(st["ld"]), st["lp"], st["lg"], _vp(st["xlstm"]), _vp(st["enc_masks"]), _vp(st["d_enc"]),
                                       _vp(st["d_cT"]), _vp(st["d_hT"]), _vp(st["d_xlstm"]), _vp(wl), wl.numel(), s))
+        if self.grad_buckets is not None:
+            self.grad_buckets.launch("enc")
         wc = self._workspace("cnn", st["ws_cnn"])
         check(lib.astk_conv_bn_relu_bwd(C.byref(st["cd"]), st["cp"], st["cg"], _vp(st["d_xlstm"]), _vp(wc), wc.numel(), s))
+        if self.grad_buckets is not None:
+            self.grad_buckets.launch("cnn")
 
     # ------------------------------------------------------------------ inference (seq2seq.py:361-396, 475-568)
     def decode_step(self, word, ht):

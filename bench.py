@@ -114,7 +114,9 @@ def main():
     opt.add_hook(O.WeightDecay(TRAIN["l2"]))
     opt.add_hook(O.GradientClipping(TRAIN["grad_clip"]))
     if world > 1:
-        opt.grad_sync = adist.allreduce_grads
+        # overlapped exchange: decoder / encoder / CNN gradient ranges are all-reduced as soon as their backward is enqueued
+        model.grad_buckets = adist.make_grad_buckets(model)
+        opt.grad_sync = model.grad_buckets.finish
     random.seed("seed-ast-20h")                                           # same teacher-forcing stream on every rank
     Xh, yh = synth_batch(B, T, D, L, V, 20 + rank)                        # each rank owns its shard of the global batch
     X, y = torch.from_numpy(Xh).cuda(), torch.from_numpy(yh).cuda()

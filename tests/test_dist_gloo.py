@@ -28,6 +28,19 @@ def _worker(rank, world, port, q):
     adist.allreduce_grads(arena)
     expect = torch.arange(arena.size, dtype=torch.float32) * (1 + world) / 2
     ok1 = bool(torch.allclose(arena.grad, expect))
+    # 1b) bucketed, overlapped exchange (GradBuckets) == the flat all-reduce, whatever the launch order
+    from ast_amd.dist import GradBuckets
+    shapes = {"CNN_0/W": (3, 1, 2, 2), "CNN_0_bn/gamma": (3,), "L0_enc/upward/W": (8, 5), "L0_rev_enc/lateral/W": (8, 2),
+              "attn_Wa/W": (4, 4), "out/b": (7,)}
+    ar2 = ParamArena(shapes, torch.device("cpu"))
+    base = torch.arange(ar2.size, dtype=torch.float32) + 1
+    ar2.grad.copy_(base * (rank + 2))
+    gb = GradBuckets(ar2, {"cnn": [n for n in shapes if n.startswith("CNN_")], "enc": [n for n in shapes if "_enc" in n],
+                           "dec": ["attn_Wa/W", "out/b"]})
+    gb.launch("dec")
+    gb.launch("enc")
+    gb.finish()                      # launches "cnn" itself, waits, scales
+    ok1 = ok1 and bool(torch.allclose(ar2.grad, base * sum(r + 2 for r in range(world)) / world))
     # 2) same seed string -> same teacher-forcing coins on every rank (quirk Q4 under DP)
     random.seed("seed-ast-20h")
     coins = torch.tensor([random.random() for _ in range(8)], dtype=torch.float64)
