@@ -27,8 +27,10 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
 struct DecPersistBwdBuffers {
   const float *WoT, *WcT, *WlT, *WuT, *ENCA, *CVH, *HT, *LOGITS, *C, *ML;
   float *ALPHA, *G, *DPRE, *DCVH, *DS, *DX0, *DHATT, *d_c0;
+  float* DXH;
   unsigned* ctr;
 };
+bool decoder_persist_b6_split(const astk_decoder_desc* d);
 int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, const float* rnn_masks, const DecPersistBwdBuffers& bf,
                                hipStream_t s);
 
@@ -63,7 +65,7 @@ struct DecPlan {
   float* WuT[ASTK_MAX_RNN_LAYERS];  // [in][4H]
   float* WlT[ASTK_MAX_RNN_LAYERS];  // [H][4H]
   float* ZERO;   // [B][max(A,H)] zeros
-  float *LSE, *PART, *CESTAT, *ENCA, *MLB;       // persistent path only
+  float *LSE, *PART, *CESTAT, *ENCA, *MLB, *DXH;       // persistent path only
   unsigned* PCTR;
   void* attn_ws;
   size_t bytes;
@@ -117,6 +119,7 @@ int make_plan(const astk_decoder_desc* d, void* ws, DecPlan& P) {
     P.ENCA = c.take<float>(pp ? B * (size_t)P.T * H : 4);
     P.MLB = c.take<float>(pp ? S * B * 2 : 4);
     P.PCTR = c.take<unsigned>(pp ? (size_t)(8 * ((P.B + 15) / 16) + 2) * 64 : 4);
+    P.DXH = c.take<float>(pp ? 2 * S * B * (size_t)P.A : 4);
   }
   P.bytes = c.total();
   return 0;
@@ -435,7 +438,11 @@ int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
     bf.WoT = P.WoT; bf.WcT = P.WcT; bf.WlT = P.WlT[0]; bf.WuT = P.WuT[0]; bf.ENCA = P.ENCA; bf.ALPHA = P.ALPHA; bf.CVH = P.CVH; bf.ML = P.MLB;
     bf.HT = P.HT; bf.LOGITS = P.LOGITS; bf.C = P.C[0]; bf.G = P.G[0]; bf.DPRE = P.DPRE; bf.DCVH = P.DCVH; bf.DS = P.DS; bf.DX0 = P.DX0;
     bf.DHATT = P.PART; bf.d_c0 = d_c0; bf.ctr = P.PCTR;
+    const bool b6s = decoder_persist_b6_split(d);
+    bf.DXH = b6s ? P.DXH : nullptr;
     ASTK_TRY(decoder_persist_bwd_launch(d, enc, rnn_masks, bf, s));
+    // split mode: the embedding columns of d_x0 (only the embedding scatter reads them) are one batched product over all steps
+    if (b6s) ASTK_TRY(gemm_launch(GEMM_NN, gemm_args(S * B, E, 4 * H, mat(P.G[0], 4 * H), mat(prm->lstm[0].Wu, XI), P.DX0, XI), s));
     // dq[s][b][:] = sum_t ds[s][b][t] enc[b][t][:]  (batched over b) -- only the weight gradients of attn_Wa need it
     GemmArgs gq = gemm_args(S, H, T, mat(P.DS, (long)B * Tp), mat(enc, H), P.DQ, (long)B * H);
     gq.batch = B; gq.sA = Tp; gq.sB = (long)T * H; gq.sC = H;

@@ -732,6 +732,9 @@ struct PDecBwdArgs {
   float *ALPHA;                            // raw scores in, normalised alpha out
   float *Gt;                               // gates -> dz
   float *DPRE, *DCVH, *DS, *DX0, *DHATT;   // DHATT [S][B][nsplit][H]
+  float* DXH;                              // b6_split: [2][S][B][A] K-halves of d_x0[:, E:] (the carry of the next step's B1)
+  int b6_split;                            // 1: B6 covers only the ht columns, every item split into two K halves (the embedding
+                                           //    columns are one batched GEMM after the launch)
   float *d_c0;
   unsigned* ctr;
   unsigned* abort_word;
@@ -768,12 +771,17 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   unsigned* ctr = a.ctr;
 #define CTR(ph, bt) (ctr + ((ph) * nbt + (bt)) * CTRS)
   // ---------------- roles: [0,n5) cell bwd, [n5, n5+n6) dx0, [n5+n6, n5+n6+n1) d_pre + d_cvh ; attention: all
-  const int n5 = nbt * (H / 16), n6 = nbt * (XI / 16), n1 = nbt * (A / 16), n2 = nbt * (2 * H / 32);
+  const int n5 = nbt * (H / 16), n6 = a.b6_split ? 2 * nbt * (A / 16) : nbt * (XI / 16), n1 = nbt * (A / 16), n2 = nbt * (2 * H / 32);
   const bool has5 = wg < n5;
   const int b5_bt = has5 ? wg / (H / 16) : 0, b5_u0 = has5 ? (wg % (H / 16)) * 16 : 0;
   const int r6 = wg - n5;
   const bool has6 = r6 >= 0 && r6 < n6;
-  const int b6_bt = has6 ? r6 / (XI / 16) : 0, b6_n0 = has6 ? (r6 % (XI / 16)) * 16 : 0;
+  // B6 item: 16 columns of d_x0 for one batch tile; split mode: ht columns only, item (r6 >> 1), K half (r6 & 1)
+  const int b6_half = a.b6_split ? (r6 & 1) : 0;
+  const int b6_item = a.b6_split ? (r6 >> 1) : r6;
+  const int b6_per_bt = a.b6_split ? A / 16 : XI / 16;
+  const int b6_bt = has6 ? b6_item / b6_per_bt : 0, b6_n0 = has6 ? (a.b6_split ? E : 0) + (b6_item % b6_per_bt) * 16 : 0;
+  const int b6_k0 = b6_half * (K4 / 2);
   const int r1 = wg - n5 - n6;
   const bool has1 = r1 >= 0 && r1 < n1;
   const int b1_bt = has1 ? r1 / (A / 16) : 0, b1_n0 = has1 ? (r1 % (A / 16)) * 16 : 0;
@@ -788,7 +796,10 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   for (int i = 0; i < NWB; ++i) wreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int r16 = lane & 15;
   if (has5) wload<NB_B5>(wreg, a.WlT, K4, b5_u0 + r16, K4, lane, wave);
-  else if (has6) wload<NB_B6>(wreg, a.WuT, K4, b6_n0 + r16, K4, lane, wave);
+  else if (has6) {
+    if (a.b6_split) wload<NB_B6 / 2>(wreg, a.WuT + b6_k0, K4, b6_n0 + r16, K4 / 2, lane, wave);
+    else wload<NB_B6>(wreg, a.WuT, K4, b6_n0 + r16, K4, lane, wave);
+  }
   else {
     if (has1) wload<NB_B1>(wreg, a.WoT, Vp, b1_n0 + r16, Vp, lane, wave);
     if (has2) {
@@ -835,9 +846,15 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
       float carry = 0.f;
       TB(0)
       if (n > 0) {
-        if (!wg_wait(CTR(PB6, bt), (unsigned)((XI / 16) * n), a.abort_word, &s_flag)) return;
+        if (!wg_wait(CTR(PB6, bt), (unsigned)((a.b6_split ? 2 * (A / 16) : XI / 16) * n), a.abort_word, &s_flag)) return;
         TB(1)
-        if (row < B) carry = ld_sc1(a.DX0 + ((long)(s + 1) * B + row) * XI + E + col);
+        if (row < B) {
+          if (a.b6_split) {
+            const float c0 = ld_sc1(a.DXH + ((long)(s + 1) * B + row) * A + col);
+            const float c1 = ld_sc1(a.DXH + ((long)(S + s + 1) * B + row) * A + col);
+            carry = c0 + c1;
+          } else carry = ld_sc1(a.DX0 + ((long)(s + 1) * B + row) * XI + E + col);
+        }
       }
       if (row < B) {
         const float y = a.HT[((long)(s + 1) * B + row) * A + col];
@@ -1111,10 +1128,14 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
       if (!wg_wait(CTR(PB5, bt), (unsigned)((H / 16) * (n + 1)), a.abort_word, &s_flag)) return;
       TB(9)
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      wmac_chunked<NB_B6, 16>(acc, wreg, r_g, ((long)s * B + min(m0 + r16, B - 1)) * K4, K4, lane, wave);
+      if (a.b6_split) wmac_chunked<NB_B6 / 2, 16>(acc, wreg, r_g, ((long)s * B + min(m0 + r16, B - 1)) * K4 + b6_k0, K4 / 2, lane, wave);
+      else wmac_chunked<NB_B6, 16>(acc, wreg, r_g, ((long)s * B + min(m0 + r16, B - 1)) * K4, K4, lane, wave);
       const float v = reduce16(acc, red);
       const int row = m0 + e_row;
-      if (row < B) st_sc1(a.DX0 + ((long)s * B + row) * XI + b6_n0 + e_col, v);
+      if (row < B) {
+        if (a.b6_split) st_sc1(a.DXH + ((long)(b6_half * S + s) * B + row) * A + (b6_n0 - E) + e_col, v);
+        else st_sc1(a.DX0 + ((long)s * B + row) * XI + b6_n0 + e_col, v);
+      }
       publish(CTR(PB6, bt));
       TB(10)
     }
@@ -1213,6 +1234,16 @@ bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int
   return true;
 }
 
+// d_x0 phase of the backward kernel as 2 K-halves per item over the ht columns only: fits when the roles still fit 256 workgroups
+bool decoder_persist_b6_split(const astk_decoder_desc* d) {
+  const int nbt = (d->B + 15) / 16;
+  const int n5 = nbt * (d->H / 16), n6 = 2 * nbt * (d->A / 16), n1 = nbt * (d->A / 16), n2 = nbt * (2 * d->H / 32);
+  if ((4 * d->H) % 128) return false;
+  const char* e = getenv("ASTK_DEC_B6_SPLIT");
+  if (e && e[0] == '0') return false;
+  return n5 + n6 + (n1 > n2 ? n1 : n2) <= G;
+}
+
 size_t decoder_persist_extra_floats(const astk_decoder_desc* d) {
   int ns = 1, ch = 1;
   if (!decoder_persist_applicable(d, &ns, &ch)) return 0;
@@ -1223,6 +1254,7 @@ size_t decoder_persist_extra_floats(const astk_decoder_desc* d) {
 struct DecPersistBwdBuffers {
   const float *WoT, *WcT, *WlT, *WuT, *ENCA, *CVH, *HT, *LOGITS, *C, *ML;
   float *ALPHA, *G, *DPRE, *DCVH, *DS, *DX0, *DHATT, *d_c0;
+  float* DXH;        // [2][S][B][A] or null (no K split of the d_x0 phase)
   unsigned* ctr;
 };
 
@@ -1237,6 +1269,8 @@ int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, con
   a.WoT = bf.WoT; a.WcT = bf.WcT; a.WlT = bf.WlT; a.WuT = bf.WuT; a.enc = enc; a.encA = bf.ENCA; a.ALPHA = bf.ALPHA; a.CVH = bf.CVH; a.ML = bf.ML;
   a.HT = bf.HT; a.LOGITS = bf.LOGITS; a.Cst = bf.C; a.rnn_mask = rnn_masks; a.Gt = bf.G; a.DPRE = bf.DPRE; a.DCVH = bf.DCVH; a.DS = bf.DS;
   a.DX0 = bf.DX0; a.DHATT = bf.DHATT; a.d_c0 = bf.d_c0;
+  a.DXH = bf.DXH;
+  a.b6_split = bf.DXH != nullptr && decoder_persist_b6_split(d) ? 1 : 0;
   a.ctr = bf.ctr;
   a.abort_word = bf.ctr + (size_t)PB_N * a.nbt * CTRS;
   a.tick_out = prof_tick_buffer(1);
