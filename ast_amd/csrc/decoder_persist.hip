@@ -90,6 +90,9 @@ __device__ __forceinline__ void publish(unsigned* ctr) {
   if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+// gate / tanh activations on the decoder chain: v_exp_f32 / v_rcp_f32 based (absolute error <= ~2e-7), as in lstm_persist.hip
+__device__ __forceinline__ float sigm_fast(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -331,9 +334,9 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       const bool ev = tid < 128 && cell_b < B;
       if (ev) {
         const float4 z = *reinterpret_cast<const float4*>(&zt[ce_tile * 256 + ce_row * 16 + ce_u * 4]);
-        const float ga = tanhf(z.x + cbias.x), gi = sigm(z.y + cbias.y), gf = sigm(z.z + cbias.z), go = sigm(z.w + cbias.w);
+        const float ga = tanh_fast(z.x + cbias.x), gi = sigm_fast(z.y + cbias.y), gf = sigm_fast(z.z + cbias.z), go = sigm_fast(z.w + cbias.w);
         c_state = ga * gi + gf * c_state;
-        const float hh = go * tanhf(c_state);
+        const float hh = go * tanh_fast(c_state);
         const float hd = a.rnn_mask ? hh * a.rnn_mask[((long)s * B + cell_b) * H + cell_u] : hh;
         gsave = make_float4(ga, gi, gf, go);
         st_sc1(a.HR + ((long)(s + 1) * B + cell_b) * H + cell_u, hh);
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       const float v = reduce16(acc, red);
       const int row = m0 + (tid >> 4), n = c_n0 + (tid & 15);
       if (row < B) {
-        const float ht = tanhf(v + a.bc[n]);
+        const float ht = tanh_fast(v + a.bc[n]);
         st_sc1(a.HT + ((long)(s + 1) * B + row) * A + n, ht);
         if (s + 1 < S) st_sc1(a.X0 + ((long)(s + 1) * B + row) * XI + E + n, ht);
       }
@@ -1110,7 +1113,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
         }
         dy += hs;
         const float dh = v + dy * mk;
-        const float tc = tanhf(ccur);
+        const float tc = tanh_fast(ccur);
         const float dcv = dh * g.w * (1.f - tc * tc) + dc_state;
         u32x4 o;
         o.x = __float_as_uint(dcv * g.y * (1.f - g.x * g.x)); o.y = __float_as_uint(dcv * g.x * g.y * (1.f - g.y));
