@@ -17,7 +17,7 @@
 namespace astk {
 
 struct PersistCellHost {
-  const float *Wl, *Wu, *bias, *zx, *xin, *mask, *WlT, *WuT_up, *dz_up, *d_enc, *d_hT, *d_cT;
+  const float *Wl, *Wu, *bias, *zx, *xin, *mask, *WlT, *d_enc, *d_hT, *d_cT;
   float *gates, *C, *HR, *HD, *enc;
   const float* WuT;
   float *PR, *PD;
@@ -247,8 +247,7 @@ int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
   int* rows_inv = (int*)((char*)rows_perm + align_up((size_t)T * B * sizeof(int), 256));
   const size_t bh = (size_t)B * h;
   const bool persist = lstm_persist_applicable(T, B, h, P.nl, P.nd);
-  static const bool rs_env = !(getenv("ASTK_LSTM_BWD_RS") && getenv("ASTK_LSTM_BWD_RS")[0] == '0');
-  const bool rs_path = persist && rs_env;
+  const bool rs_path = persist;
   if (persist) {
     PersistCellHost cells[16];
     memset(cells, 0, sizeof(cells));
@@ -267,8 +266,6 @@ int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
         PersistCellHost& c = cells[dd * P.nl + l];
         const bool top = l == P.nl - 1;
         c.WlT = P.WlT[dd][l];
-        c.WuT_up = top ? nullptr : P.WuT[dd][l + 1];
-        c.dz_up = top ? nullptr : P.ZG[dd][l + 1];
         if (rs_path) {
           c.WuT = l > 0 ? P.WuT[dd][l] : nullptr;
           c.PR = P.PR[dd][l];

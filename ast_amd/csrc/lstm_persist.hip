@@ -1,20 +1,22 @@
 // Persistent, wavefront-scheduled encoder LSTM kernels ("hard part" of section 7).
 //
 // One launch runs ALL time steps of ALL (direction, layer) cells.  A workgroup owns 16 hidden units x 16 batch
-// rows of one cell for the whole sequence:
-//   * its slice of the recurrent weights (64 gate rows of W_l, and for layers >= 1 the 64 gate rows of W_u) is
-//     loaded ONCE into VGPRs as f32-MFMA B fragments (K split over the 4 waves) and stays there for all T steps;
-//   * the cell state c (forward) / dc (backward) lives in a register of the thread that owns (batch row, unit);
-//   * per step only the 16 x h activations of the previous step (and of the layer below) are fetched.
-// Layers run as a wavefront: cell (l, t) starts as soon as (l, t-1) and (l-1, t) have been published, so the
-// sequential depth is T + n_layers - 1 steps instead of n_layers * T launches.
+// rows of one cell for the whole sequence; its weight slices are loaded ONCE into VGPRs as f32-MFMA B fragments and stay
+// there for all T steps; the cell state c (forward) / dc (backward) lives in a register of the thread that owns
+// (batch row, unit).  Layers run as a wavefront: cell (l, t) starts as soon as (l, t-1) and (l-1, t) are there, so the
+// sequential depth is T + O(n_layers) steps instead of n_layers * T launches.
 //
-// Inter-workgroup hand-off (cdna_hip_programming.md Guideline 16, form R1 with a counter): producers store the
-// handed-off activations write-through (agent-scope relaxed atomic stores -> sc1), every storing wave drains
-// vmcnt, the workgroup barriers, ONE lane adds to the (dir, layer, batch-tile) arrival counter; consumers poll
-// that counter with a relaxed agent-scope (sc1) load from ONE lane, barrier, then read the payload with sc1
-// loads only.  Counters are zeroed by a memset node before every launch.  Every spin is bounded: on time-out a
-// workgroup raises the abort word, every poll loop checks it, and the grid drains.
+// Two kernels, two hand-off protocols (DESIGN.md section 4 has the measurements behind the choice):
+//   lstm_persist_fwd_g   forward.  Gather: per step a workgroup needs the 16 x h activations of the previous step and of the
+//                        layer below (4 KB per wave).  Tag-free SENTINEL hand-off: the saved-activation buffers are filled
+//                        with 0xFFFFFFFF before the launch, producers store each value once (sc1), consumers re-read until no
+//                        word is the sentinel -- no counter, drain, atomic or barrier on the chain.
+//   lstm_persist_bwd_rs  backward.  Reduce-scatter: the owner of 64 gate columns of dz multiplies them with its rows of W_l
+//                        (and W_u for the layer below) and hands out 16x16 partial tiles; COUNTER hand-off (R1 of
+//                        cdna_hip_programming.md Guideline 16: write-through stores, every storing wave drains vmcnt,
+//                        barrier, ONE lane adds to the arrival counter on its own 256-byte line; consumers poll it with
+//                        ONE lane, barrier, sc1 loads).  Counters are zeroed by a memset before every launch.
+// Every spin is bounded: on time-out a workgroup raises the abort word, every poll loop checks it, and the grid drains.
 // Residency: the launcher only uses this path when the whole grid fits one workgroup per CU (<= 256 workgroups).
 #include "common.h"
 #include <type_traits>
@@ -51,9 +53,7 @@ struct PFwdArgs {
 
 struct PCellB {
   const float* WlT;     // (h, 4h)
-  const float* WuT_up;  // (h, 4h): transposed upward weight of the layer ABOVE (null for the top layer)
-  float* gates_dz;      // (T,B,4h): activated gates in, dz out
-  const float* dz_up;   // gates_dz of the layer above (null for the top layer)
+  float* gates_dz;      // (T,B,4h): activated gates in, dz out (in place; the batched products after the launch read it)
   const float* C;       // (T,B,h)
   const float* mask;    // (T,B,h) or null
   const float* d_enc;   // top layer: d_enc_states + dir*h
@@ -78,23 +78,8 @@ struct PBwdArgs {
 __device__ __forceinline__ unsigned ld_flag(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// 16 bytes of handed-off data as two 8-byte sc1 loads (agent-scope relaxed atomics bypass the CU's L1)
-__device__ __forceinline__ float4 ld16_sc1(const float* p) {
-  const u64 a = __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const u64 b = __hip_atomic_load(reinterpret_cast<const u64*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  float4 v;
-  v.x = __uint_as_float((unsigned)a); v.y = __uint_as_float((unsigned)(a >> 32));
-  v.z = __uint_as_float((unsigned)b); v.w = __uint_as_float((unsigned)(b >> 32));
-  return v;
-}
 __device__ __forceinline__ void st4_sc1(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st16_sc1(float* p, float4 v) {
-  const u64 a = (u64)__float_as_uint(v.x) | ((u64)__float_as_uint(v.y) << 32);
-  const u64 b = (u64)__float_as_uint(v.z) | ((u64)__float_as_uint(v.w) << 32);
-  __hip_atomic_store(reinterpret_cast<u64*>(p), a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(reinterpret_cast<u64*>(p) + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One lane waits until *ctr >= target (or the abort word is raised).  Returns false on abort / time-out.
@@ -119,7 +104,6 @@ __device__ __forceinline__ void publish(unsigned* ctr) {
   if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 // Gate activations of the persistent kernels' epilogues (on the recurrence's critical path): v_exp_f32 / v_rcp_f32 based,
 // absolute error <= ~2e-7 (libdevice's tanhf/expf with full-precision division cost ~0.25 us more per step).
 __device__ __forceinline__ float sigm_fast(float x) { return __frcp_rn(1.f + __expf(-x)); }
@@ -129,15 +113,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // raw buffer descriptor over a hand-off buffer: lets the compiler track 16-byte sc1 loads / stores itself
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ float4 ldb128_sc1(__amdgpu_buffer_rsrc_t r, long float_off) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_off * 4), 0, 16);   // aux 16 = sc1
-  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-__device__ __forceinline__ void stb128_sc1(__amdgpu_buffer_rsrc_t r, long float_off, float4 v) {
-  u32x4 u;
-  u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
-  __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)(float_off * 4), 0, 16);
 }
 
 #define MFMA4(ACC, A4, W4)                                                   \
@@ -152,137 +127,6 @@ __device__ __forceinline__ void stb128_sc1(__amdgpu_buffer_rsrc_t r, long float_
   _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) ACC[g_] = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).y, (W)[g_].y, ACC[g_], 0, 0, 0); \
   _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) ACC[g_] = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).z, (W)[g_].z, ACC[g_], 0, 0, 0); \
   _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) ACC[g_] = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).w, (W)[g_].w, ACC[g_], 0, 0, 0);
-
-// ------------------------------------------------------------------ forward
-// KB = k-blocks (16 floats each) of K = h per wave: h = 64*KB
-template <int KB>
-__global__ __launch_bounds__(256, 1) void lstm_persist_fwd(PFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 4 * 256];
-  __shared__ int s_ok1, s_ok2;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int cell = blockIdx.z, bt = blockIdx.y, j0 = blockIdx.x * 16;
-  const PCellF& c = a.c[cell];
-  const int T = a.T, B = a.B, h = a.h;
-  const int nbt = gridDim.y, nslice = gridDim.x;
-  const bool has_up = c.layer > 0;
-  unsigned* done_own = a.done + (cell * nbt + bt) * CTR_STRIDE;
-  const unsigned* done_below = has_up ? a.done + ((cell - 1) * nbt + bt) * CTR_STRIDE : nullptr;
-  const int m0 = bt * 16;
-
-  // resident weight fragments: lane (r = unit j, q) holds floats [16*s + 4q, +4) of gate rows 4*(j0+r)+g
-  float4 wl[KB][4], wu[KB][4];
-#pragma unroll
-  for (int i = 0; i < KB; ++i) {
-    const int s = wave + 4 * i;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const long row = 4 * (j0 + r) + g;
-      wl[i][g] = *reinterpret_cast<const float4*>(c.Wl + row * h + 16 * s + 4 * q);
-      wu[i][g] = has_up ? *reinterpret_cast<const float4*>(c.Wu + row * h + 16 * s + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  const __amdgpu_buffer_rsrc_t r_hr = make_rsrc(c.HR);
-  const __amdgpu_buffer_rsrc_t r_x = make_rsrc(has_up ? c.xin : c.HR);
-  const int arow = min(m0 + r, B - 1);
-  const int eb = m0 + (tid >> 4), eu = j0 + (tid & 15);      // epilogue ownership: (batch row, unit)
-  const bool evalid = eb < B;
-  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (has_up) bias4 = *reinterpret_cast<const float4*>(c.bias + 4 * eu);
-  float c_state = 0.f;
-  long long tk[6] = {0, 0, 0, 0, 0, 0};
-  const bool timing = (a.dbg & 8) != 0;
-#define TICK(i, t0) if (timing) { const long long now_ = wall_clock64(); tk[i] += now_ - t0; t0 = now_; }
-
-  for (int t = 0; t < T; ++t) {
-    long long t0 = timing ? wall_clock64() : 0;
-    const long tb = (long)t * B + (evalid ? eb : 0);
-    // inputs that do not depend on this launch: issue their loads before any wait
-    float4 zadd = bias4;
-    float mk = 1.f;
-    if (evalid) {
-      if (!has_up) zadd = *reinterpret_cast<const float4*>(c.zx + tb * 4 * h + 4 * eu);
-      if (c.mask) mk = c.mask[tb * h + eu];
-    }
-    f32x4 acc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // ---- upward product first: the layer below runs one step ahead, so this is off the recurrence's critical path
-    if (has_up) {
-      if (tid == 0) s_ok1 = wait_ge(done_below, (unsigned)(nslice * (t + 1)), a.abort_word) ? 1 : 0;
-      __syncthreads();
-      if (!s_ok1) break;
-      TICK(0, t0)
-      float4 ax[KB];
-      const long xo = ((long)t * B + arow) * h + 4 * q;
-      if (a.dbg & 1) {
-#pragma unroll
-        for (int i = 0; i < KB; ++i) ax[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      } else
-#pragma unroll
-      for (int i = 0; i < KB; ++i) ax[i] = ldb128_sc1(r_x, xo + 16 * (wave + 4 * i));
-      __builtin_amdgcn_sched_barrier(0);   // all loads of the step in flight before the first MFMA
-#pragma unroll
-      for (int i = 0; i < KB; ++i) { MFMA4G(acc, ax[i], wu[i]) }
-    }
-    // ---- recurrent product: needs h_{t-1} of every workgroup of this cell
-    TICK(1, t0)
-    if (t > 0) {
-      if (tid == 0) s_ok2 = wait_ge(done_own, (unsigned)(nslice * t), a.abort_word) ? 1 : 0;
-      __syncthreads();
-      if (!s_ok2) break;
-      TICK(2, t0)
-      float4 ah[KB];
-      const long ho = ((long)(t - 1) * B + arow) * h + 4 * q;
-      if (a.dbg & 1) {
-#pragma unroll
-        for (int i = 0; i < KB; ++i) ah[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      } else
-#pragma unroll
-      for (int i = 0; i < KB; ++i) ah[i] = ldb128_sc1(r_hr, ho + 16 * (wave + 4 * i));
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < KB; ++i) { MFMA4G(acc, ah[i], wl[i]) }
-    }
-    // ---- 4-wave K reduction through LDS
-#pragma unroll
-    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(&red[((wave * 4 + g) * 64 + lane) * 4]) = acc[g];
-    __syncthreads();
-    TICK(3, t0)
-    float ga = 0.f, gi = 0.f, gf = 0.f, go = 0.f, hd = 0.f;
-    if (evalid) {
-      const int row = tid >> 4, col = tid & 15;
-      const int src = ((row >> 2) * 16 + col) * 4 + (row & 3);
-      float z[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        z[g] = red[(0 * 4 + g) * 256 + src] + red[(1 * 4 + g) * 256 + src] + red[(2 * 4 + g) * 256 + src] + red[(3 * 4 + g) * 256 + src];
-      ga = tanhf(z[0] + zadd.x); gi = sigm(z[1] + zadd.y); gf = sigm(z[2] + zadd.z); go = sigm(z[3] + zadd.w);
-      c_state = ga * gi + gf * c_state;
-      const float hh = go * tanhf(c_state);
-      hd = hh * mk;
-      // hand-off stores first (write-through), so that the publish below waits for nothing else
-      st4_sc1(c.HR + tb * h + eu, hh);                       // read by this cell's workgroups at step t+1
-      if (c.HD) st4_sc1(c.HD + tb * h + eu, hd);             // read by the layer above at step t
-    }
-    if (a.dbg & 2) { __syncthreads(); if (tid == 0) __hip_atomic_fetch_add(done_own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    else if (a.dbg & 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (tid == 0) __hip_atomic_store(done_own, (unsigned)(nslice * (t + 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    else { TICK(4, t0) publish(done_own); TICK(5, t0) }
-    if (evalid) {                                            // saved for the backward launch / the decoder: plain stores
-      *reinterpret_cast<float4*>(c.gates + tb * 4 * h + 4 * eu) = make_float4(ga, gi, gf, go);
-      c.C[tb * h + eu] = c_state;
-      if (c.enc) {
-        const int pos = c.reverse_pos ? T - 1 - t : t;
-        c.enc[((long)eb * T + pos) * a.H + eu] = hd;
-      }
-    }
-  }
-  if (timing && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0)
-    printf("persist_fwd cell %d (layer %d): per-step 10ns ticks: poll_below %lld  xpart %lld  poll_own %lld  hpart+reduce %lld  epilogue %lld  publish %lld\n",
-           cell, c.layer, tk[0] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T, tk[5] / T);
-#undef TICK
-}
-
 
 // ------------------------------------------------------------------ forward, sentinel hand-off
 // ---- tag-free hand-off: the data is the flag.
@@ -501,101 +345,6 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_g(PFwdArgs a) {
   else lstm_fwd_steps<KB, false>(a, c, red[0], red[1]);
 }
 
-// ------------------------------------------------------------------ backward
-template <int KB>
-__global__ __launch_bounds__(256, 1) void lstm_persist_bwd(PBwdArgs a) {
-  constexpr int NB = 4 * KB;   // k-blocks of K = 4h per wave
-  __shared__ __attribute__((aligned(16))) float red[4 * 2 * 256];
-  __shared__ int s_ok1, s_ok2;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int cell = blockIdx.z, bt = blockIdx.y, j0 = blockIdx.x * 16;
-  const PCellB& c = a.c[cell];
-  const int T = a.T, B = a.B, h = a.h;
-  const int nbt = gridDim.y, nslice = gridDim.x;
-  const bool has_up = c.dz_up != nullptr;
-  unsigned* done_own = a.done + (cell * nbt + bt) * CTR_STRIDE;
-  const unsigned* done_up = has_up ? a.done + ((cell + 1) * nbt + bt) * CTR_STRIDE : nullptr;
-  const int m0 = bt * 16;
-  const int K = 4 * h;
-
-  float4 wl[NB], wu[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int s = wave + 4 * i;
-    wl[i] = *reinterpret_cast<const float4*>(c.WlT + (long)(j0 + r) * K + 16 * s + 4 * q);
-    wu[i] = has_up ? *reinterpret_cast<const float4*>(c.WuT_up + (long)(j0 + r) * K + 16 * s + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  const __amdgpu_buffer_rsrc_t r_dz = make_rsrc(c.gates_dz);
-  const __amdgpu_buffer_rsrc_t r_up = make_rsrc(has_up ? c.dz_up : c.gates_dz);
-  const int arow = min(m0 + r, B - 1);
-  const int eb = m0 + (tid >> 4), eu = j0 + (tid & 15);
-  const bool evalid = eb < B;
-  float dc_state = 0.f;
-  if (evalid && c.d_cT) dc_state = c.d_cT[(long)eb * h + eu];
-
-  for (int t = T - 1; t >= 0; --t) {
-    const int stepno = T - 1 - t;           // number of steps already completed by this cell
-    const long tb = (long)t * B + (evalid ? eb : 0);
-    // inputs from earlier launches: issue before any wait
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    float ccur = 0.f, cp = 0.f, mk = 1.f, dye = 0.f, dhadd = 0.f;
-    if (evalid) {
-      g = *reinterpret_cast<const float4*>(c.gates_dz + tb * K + 4 * eu);
-      ccur = c.C[tb * h + eu];
-      if (t > 0) cp = c.C[(tb - B) * h + eu];
-      if (c.mask) mk = c.mask[tb * h + eu];
-      if (c.d_enc) {
-        const int pos = c.reverse_pos ? T - 1 - t : t;
-        dye = c.d_enc[((long)eb * T + pos) * a.H + eu];
-      }
-      if (stepno == 0 && c.d_hT) dhadd = c.d_hT[(long)eb * h + eu];
-    }
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    if (has_up) {                            // the layer above runs one step ahead: off the critical path
-      if (tid == 0) s_ok1 = wait_ge(done_up, (unsigned)(nslice * (stepno + 1)), a.abort_word) ? 1 : 0;
-      __syncthreads();
-      if (!s_ok1) break;
-      const long o = ((long)t * B + arow) * K + 4 * q;
-      float4 av[NB];
-#pragma unroll
-      for (int i = 0; i < NB; ++i) av[i] = ldb128_sc1(r_up, o + 16 * (wave + 4 * i));
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < NB; ++i) { MFMA4(acc1, av[i], wu[i]) }
-    }
-    if (stepno > 0) {
-      if (tid == 0) s_ok2 = wait_ge(done_own, (unsigned)(nslice * stepno), a.abort_word) ? 1 : 0;
-      __syncthreads();
-      if (!s_ok2) break;
-      const long o = ((long)(t + 1) * B + arow) * K + 4 * q;
-      float4 av[NB];
-#pragma unroll
-      for (int i = 0; i < NB; ++i) av[i] = ldb128_sc1(r_dz, o + 16 * (wave + 4 * i));
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < NB; ++i) { MFMA4(acc0, av[i], wl[i]) }
-    }
-    *reinterpret_cast<f32x4*>(&red[((wave * 2 + 0) * 64 + lane) * 4]) = acc0;
-    *reinterpret_cast<f32x4*>(&red[((wave * 2 + 1) * 64 + lane) * 4]) = acc1;
-    __syncthreads();
-    if (evalid) {
-      const int row = tid >> 4, col = tid & 15;
-      const int src = ((row >> 2) * 16 + col) * 4 + (row & 3);
-      const float v0 = red[0 * 256 + src] + red[2 * 256 + src] + red[4 * 256 + src] + red[6 * 256 + src];
-      const float v1 = red[1 * 256 + src] + red[3 * 256 + src] + red[5 * 256 + src] + red[7 * 256 + src];
-      const float dh = v0 + (v1 + dye) * mk + dhadd;
-      const float tc = tanhf(ccur);
-      const float dcv = dh * g.w * (1.f - tc * tc) + dc_state;
-      stb128_sc1(r_dz, tb * K + 4 * eu,
-                 make_float4(dcv * g.y * (1.f - g.x * g.x), dcv * g.x * g.y * (1.f - g.y), dcv * cp * g.z * (1.f - g.z),
-                             dh * tc * g.w * (1.f - g.w)));
-      dc_state = dcv * g.z;
-    }
-    publish(done_own);
-  }
-}
-
 
 // ------------------------------------------------------------------ backward, reduce-scatter hand-off
 // lstm_persist_bwd gathers: every workgroup pulls the whole dz_{t+1} row block of its cell (16 x 4h) and of the layer above
@@ -779,7 +528,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
 
 // ---- launchers (called from lstm.hip).  Return 1 if the persistent path is not applicable (caller falls back).
 struct PersistCellHost {
-  const float *Wl, *Wu, *bias, *zx, *xin, *mask, *WlT, *WuT_up, *dz_up, *d_enc, *d_hT, *d_cT;
+  const float *Wl, *Wu, *bias, *zx, *xin, *mask, *WlT, *d_enc, *d_hT, *d_cT;
   float *gates, *C, *HR, *HD, *enc;
   const float* WuT;               // backward: this cell's transposed upward weight (layers >= 1)
   float *PR, *PD;                 // backward, reduce-scatter path: partial-sum buffers of this cell
@@ -816,8 +565,7 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   a.abort_word = counters + (size_t)ncells * nbt * 64;
   ASTK_HIP(hipMemsetAsync(counters, 0, ((size_t)ncells * nbt + 1) * 64 * sizeof(unsigned), s));
   dim3 grid(h / 16, nbt, ncells), blk(256);
-  static const bool use_granules = !(getenv("ASTK_LSTM_GRANULES") && getenv("ASTK_LSTM_GRANULES")[0] == '0');
-  if (use_granules) {
+  {
     // hand-off buffers = the saved activations themselves: sentinel-filled before every launch
     FillSegs f;
     f.n = 0;
@@ -829,20 +577,11 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
     ASTK_TRY(fill_u32_segments(f, 0xffffffffu, s));
   }
   ProfScope prof(PROF_CELL, s);
-  if (use_granules) {
-    switch (h) {
-      case 64: hipLaunchKernelGGL((lstm_persist_fwd_g<1>), grid, blk, 0, s, a); break;
-      case 128: hipLaunchKernelGGL((lstm_persist_fwd_g<2>), grid, blk, 0, s, a); break;
-      case 256: hipLaunchKernelGGL((lstm_persist_fwd_g<4>), grid, blk, 0, s, a); break;
-      default: hipLaunchKernelGGL((lstm_persist_fwd_g<8>), grid, blk, 0, s, a); break;
-    }
-  } else {
-    switch (h) {
-      case 64: hipLaunchKernelGGL((lstm_persist_fwd<1>), grid, blk, 0, s, a); break;
-      case 128: hipLaunchKernelGGL((lstm_persist_fwd<2>), grid, blk, 0, s, a); break;
-      case 256: hipLaunchKernelGGL((lstm_persist_fwd<4>), grid, blk, 0, s, a); break;
-      default: hipLaunchKernelGGL((lstm_persist_fwd<8>), grid, blk, 0, s, a); break;
-    }
+  switch (h) {
+    case 64: hipLaunchKernelGGL((lstm_persist_fwd_g<1>), grid, blk, 0, s, a); break;
+    case 128: hipLaunchKernelGGL((lstm_persist_fwd_g<2>), grid, blk, 0, s, a); break;
+    case 256: hipLaunchKernelGGL((lstm_persist_fwd_g<4>), grid, blk, 0, s, a); break;
+    default: hipLaunchKernelGGL((lstm_persist_fwd_g<8>), grid, blk, 0, s, a); break;
   }
   ASTK_LAUNCH_CHECK();
   return 0;
@@ -856,37 +595,24 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   for (int i = 0; i < ncells; ++i) {
     const PersistCellHost& c = cells[i];
     PCellB& d = a.c[i];
-    d.WlT = c.WlT; d.WuT_up = c.WuT_up; d.gates_dz = c.gates; d.dz_up = c.dz_up; d.C = c.C; d.mask = c.mask; d.d_enc = c.d_enc;
+    d.WlT = c.WlT; d.gates_dz = c.gates; d.C = c.C; d.mask = c.mask; d.d_enc = c.d_enc;
     d.d_hT = c.d_hT; d.d_cT = c.d_cT; d.reverse_pos = c.reverse_pos; d.layer = c.layer;
     d.WuT = c.WuT; d.PR = c.PR; d.PD = c.PD; d.PD_up = c.PD_up;
   }
   a.ncells = ncells; a.nl = nl; a.T = T; a.B = B; a.h = h; a.H = H;
   a.done = counters;
-  a.abort_word = counters + (size_t)ncells * nbt * 64;
-  const bool rs = cells[0].PR != nullptr;
   { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
-  if (rs) {   // counters A and B per (cell, batch tile), then the abort word
-    a.abort_word = counters + (size_t)2 * ncells * nbt * 64;
-    ASTK_HIP(hipMemsetAsync(counters, 0, ((size_t)2 * ncells * nbt + 1) * 64 * sizeof(unsigned), s));
-  } else {
-    ASTK_HIP(hipMemsetAsync(counters, 0, ((size_t)ncells * nbt + 1) * 64 * sizeof(unsigned), s));
-  }
+  ASTK_CHECK(cells[0].PR != nullptr, "lstm_persist_bwd: partial-sum buffers missing");
+  // counters A and B per (cell, batch tile), then the abort word
+  a.abort_word = counters + (size_t)2 * ncells * nbt * 64;
+  ASTK_HIP(hipMemsetAsync(counters, 0, ((size_t)2 * ncells * nbt + 1) * 64 * sizeof(unsigned), s));
   dim3 grid(h / 16, nbt, ncells), blk(256);
   ProfScope prof(PROF_CELL, s);
-  if (rs) {
-    switch (h) {
-      case 64: hipLaunchKernelGGL((lstm_persist_bwd_rs<1>), grid, blk, 0, s, a); break;
-      case 128: hipLaunchKernelGGL((lstm_persist_bwd_rs<2>), grid, blk, 0, s, a); break;
-      case 256: hipLaunchKernelGGL((lstm_persist_bwd_rs<4>), grid, blk, 0, s, a); break;
-      default: hipLaunchKernelGGL((lstm_persist_bwd_rs<8>), grid, blk, 0, s, a); break;
-    }
-  } else {
-    switch (h) {
-      case 64: hipLaunchKernelGGL((lstm_persist_bwd<1>), grid, blk, 0, s, a); break;
-      case 128: hipLaunchKernelGGL((lstm_persist_bwd<2>), grid, blk, 0, s, a); break;
-      case 256: hipLaunchKernelGGL((lstm_persist_bwd<4>), grid, blk, 0, s, a); break;
-      default: hipLaunchKernelGGL((lstm_persist_bwd<8>), grid, blk, 0, s, a); break;
-    }
+  switch (h) {
+    case 64: hipLaunchKernelGGL((lstm_persist_bwd_rs<1>), grid, blk, 0, s, a); break;
+    case 128: hipLaunchKernelGGL((lstm_persist_bwd_rs<2>), grid, blk, 0, s, a); break;
+    case 256: hipLaunchKernelGGL((lstm_persist_bwd_rs<4>), grid, blk, 0, s, a); break;
+    default: hipLaunchKernelGGL((lstm_persist_bwd_rs<8>), grid, blk, 0, s, a); break;
   }
   ASTK_LAUNCH_CHECK();
   return 0;
