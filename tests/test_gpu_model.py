@@ -178,3 +178,53 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libastk.so")
     with pytest.raises(_lib.AstkError):
         _lib.load()
+
+
+def test_full_size_directional_derivative_and_repeatability():
+    """BASELINE configs[1] at full size (B=32, T=800, D=80, h=256, H=512, V=1098, L=40): the oracle is too slow here, so
+    the check is a size-independent property.  With dropout / noise off and every step teacher-forced the loss is a smooth
+    function of the parameters: (L(p + e d) - L(p - e d)) / 2e must equal <grad L, d> -- the persistent encoder / decoder
+    kernels, the stream-K GEMMs and the CNN backward at exactly the benchmark's shapes, forward against backward.
+    Also: the same step twice gives the same loss up to the atomics' summation order."""
+    import copy
+    import bench
+    from ast_amd.seq2seq import SpeechEncoderDecoder, using_config
+    from oracle.ast_ref import synth_batch
+    cfg = copy.deepcopy(bench.MODEL_CFG)
+    cfg["dropout"] = {"embed": 0.0, "rnn": 0.0, "out": 0}
+    B, T, D, L, V = 32, 800, 80, 40, cfg["rnn_config"]["dec_vocab_size"]
+    X, y = synth_batch(B, T, D, L, V, 20, dtype=np.float32)
+    X, y = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    m = SpeechEncoderDecoder(0, cfg).materialize(D, seed=0)
+    m.inject = {"use_truth": [1] * (L - 1)}
+
+    def loss_only():
+        with using_config("train", True):
+            l = m.forward_loss(X=X, y=y, teach_ratio=1.0, random_out=0, add_noise=0)
+        return l
+
+    l0 = loss_only()
+    m.cleargrads()
+    l0.backward()
+    torch.cuda.synchronize()
+    base = float(l0.data)
+    g = m.arena.grad.clone()
+    assert np.isfinite(base) and bool(torch.isfinite(g).all())
+    l1 = float(loss_only().data)
+    assert abs(l1 - base) <= 1e-5 * abs(base), (base, l1)
+    p0 = m.arena.data.clone()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for trial in range(2):
+        # direction scaled like the parameters themselves; pad elements of the arena carry zero gradient and stay untouched
+        d = torch.randn(p0.shape, device="cuda", generator=gen) * p0.abs().clamp_min(1e-3)
+        d[g == 0] = 0
+        gd = float((g.double() * d.double()).sum())
+        eps = 0.05 / max(abs(gd), 1e-6)               # aim at |L+ - L-| ~ 0.1 on a loss of ~140
+        eps = min(eps, 1e-2)
+        m.arena.data.copy_(p0 + eps * d)
+        lp = float(loss_only().data)
+        m.arena.data.copy_(p0 - eps * d)
+        lm = float(loss_only().data)
+        m.arena.data.copy_(p0)
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - gd) <= 3e-2 * abs(gd) + 1e-3, (trial, fd, gd, eps, lp, lm)

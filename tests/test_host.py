@@ -170,3 +170,25 @@ def test_compute_path_fails_loudly_without_gpu():
     m = SpeechEncoderDecoder(-1, cfg)
     with pytest.raises(RuntimeError):
         m.forward_loss(np.zeros((1, 20, 13), np.float32), np.array([[1, 2]], np.int32), 1.0)
+
+
+def test_grad_buckets_tile_the_arena_of_every_config():
+    """The overlapped data-parallel exchange cuts the flat gradient arena into CNN / encoder / decoder ranges: they must be
+    contiguous and cover it for the benchmark model and for the shipped 3-layer-decoder variants."""
+    import copy
+    import types
+    import torch
+    import bench
+    from ast_amd import dist as adist
+    from ast_amd.params import ParamArena, param_shapes
+    for enc_layers, dec_layers, feat in [(3, 1, 80), (3, 3, 13), (1, 2, 40)]:
+        cfg = copy.deepcopy(bench.MODEL_CFG)
+        cfg["rnn_config"]["enc_layers"] = enc_layers
+        cfg["rnn_config"]["dec_layers"] = dec_layers
+        train, _ = param_shapes(cfg, feat)
+        arena = ParamArena(train, torch.device("cpu"))
+        gb = adist.make_grad_buckets(types.SimpleNamespace(arena=arena))
+        spans = sorted(gb.ranges.values())
+        assert spans[0][0] == 0 and spans[-1][1] == arena.size
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert set(gb.ranges) == {"cnn", "enc", "dec"}
