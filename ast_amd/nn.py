@@ -17,6 +17,44 @@ _ADAM = 0
 _SGD = 1
 
 
+# ---- beam search (nn.py:235-322 of the reference): one utterance, N best hypotheses kept, K expansions per live hypothesis.
+# Module-level so that it works on a bare SpeechEncoderDecoder too; NN.decode_beam / init_hyp / decode_beam_step delegate here.
+def init_hyp(model):
+    import torch
+    return {"hyp": [SYMBOLS.GO_ID], "score": 0, "dec_state": model.get_encoder_states(),
+            "attn_v": torch.zeros(1, model.cfg["rnn_config"]["attn_units"], dtype=torch.float32, device=model.device), "attn_history": []}
+
+
+def decode_beam_step(model, decode_entry, beam_width):
+    import torch
+    with using_config("train", False):
+        model.set_decoder_states(decode_entry["dec_state"])
+        word = torch.full((1,), int(decode_entry["hyp"][-1]), dtype=torch.int32)
+        logits, ht, alphas = model.decode_step(word, decode_entry["attn_v"])
+        logp = torch.log_softmax(logits[0].double(), dim=0).cpu().numpy()
+        top = logp.argsort()[-beam_width:]
+        state = model.get_decoder_states()
+        return [{"hyp": decode_entry["hyp"] + [int(pi)], "score": decode_entry["score"] + float(logp[pi]), "dec_state": state, "attn_v": ht,
+                 "attn_history": decode_entry["attn_history"] + [alphas.squeeze().cpu().numpy()]} for pi in top[::-1]]
+
+
+def decode_beam(model, X, stop_limit, N, K):
+    with using_config("train", False):
+        model.encode(X)
+        n_best = [init_hyp(model)]
+        for _ in range(stop_limit):
+            if all(e["hyp"][-1] == SYMBOLS.EOS_ID for e in n_best):
+                break
+            cur = []
+            for e in n_best:
+                if e["hyp"][-1] != SYMBOLS.EOS_ID:
+                    cur.extend(decode_beam_step(model, e, K))
+                else:
+                    cur.append(e)
+            n_best = sorted(cur, reverse=True, key=lambda t: t["score"])[:N]
+    return n_best
+
+
 class NN:
     def __init__(self, cfg_path, vocab_size=None):
         self.cfg = Config(cfg_path, vocab_size=vocab_size)
@@ -107,6 +145,16 @@ class NN:
                 pbar.set_description("loss={0:0.4f}".format(avg_loss))
                 pbar.update(len(batch["X"]) * self.data_loader.world)
         return avg_loss
+
+    # ---- nn.py:235-322
+    def init_hyp(self):
+        return init_hyp(self.model)
+
+    def decode_beam_step(self, decode_entry, beam_width):
+        return decode_beam_step(self.model, decode_entry, beam_width)
+
+    def decode_beam(self, X, stop_limit, N, K):
+        return decode_beam(self.model, X, stop_limit, N, K)
 
     def predict(self, set_key):
         preds = []

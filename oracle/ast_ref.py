@@ -304,6 +304,61 @@ class RefModel:
 
 
 # --------------------------------------------------------------------------- optimizer (nn.py:81-119)
+    # ---- seq2seq.py:529-568: the state API beam search uses
+    def get_encoder_states(self):
+        out = {"c": [], "h": []}
+        if self.bi:
+            for e, r in zip(self.enc, self.rev):
+                out["h"].append(F.concat((e.h, r.h)))
+                out["c"].append(F.concat((e.c, r.c)))
+        else:
+            for e, _ in zip(self.enc, self.dec):
+                out["h"].append(e.h)
+                out["c"].append(e.c)
+        return out
+
+    def get_decoder_states(self):
+        return {"c": [d.c for d in self.dec], "h": [d.h for d in self.dec]}
+
+    def set_decoder_states(self, rnn_states):
+        for i, d in enumerate(self.dec):
+            d.set_state(rnn_states["c"][i], rnn_states["h"][i])
+
+
+# ---- nn.py:235-322: beam search over one utterance (batch of 1), N best kept, K expansions per live hypothesis
+def decode_beam(model, X, stop_limit, N, K):
+    was = model.train
+    model.train = False
+    try:
+        model.encode(X)
+        A = model.cfg["rnn_config"]["attn_units"]
+        entry = {"hyp": [GO_ID], "score": 0, "dec_state": model.get_encoder_states(),
+                 "attn_v": Variable(np.zeros((1, A), dtype=model.dtype)), "attn_history": []}
+        n_best = [entry]
+        for _ in range(stop_limit):
+            if all(e["hyp"][-1] == EOS_ID for e in n_best):
+                break
+            cur = []
+            for e in n_best:
+                if e["hyp"][-1] == EOS_ID:
+                    cur.append(e)
+                    continue
+                model.set_decoder_states(e["dec_state"])
+                word = np.full((1,), e["hyp"][-1], dtype=np.int32)
+                logits, ht, alphas = model.decode_step(word, e["attn_v"])
+                x = np.asarray(logits.data[0], dtype=np.float64)
+                logp = x - (np.log(np.exp(x - x.max()).sum()) + x.max())
+                top = np.argsort(logp)[-K:]
+                state = model.get_decoder_states()
+                for pi in top[::-1]:
+                    cur.append({"hyp": e["hyp"] + [int(pi)], "score": e["score"] + float(logp[pi]), "dec_state": state, "attn_v": ht,
+                                "attn_history": e["attn_history"] + [np.squeeze(alphas.data)]})
+            n_best = sorted(cur, reverse=True, key=lambda t: t["score"])[:N]
+        return n_best
+    finally:
+        model.train = was
+
+
 class RefOptimizer:
     """Adam(alpha, .9, .999, 1e-8, amsgrad=True) or SGD, with hooks in insertion order:
     WeightDecay(l2) -> GradientClipping(grad_clip)  (A7, A8)."""

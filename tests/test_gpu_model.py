@@ -153,6 +153,26 @@ def test_predict_greedy_matches_oracle():
     assert got.shape == ref.shape and (got == ref).all(), (got, ref)
 
 
+def test_beam_search_matches_oracle():
+    """nn.py:235-322 (decode_beam / decode_beam_step / init_hyp) through the model's state API against the oracle's restatement:
+    same N-best hypotheses, scores within 1e-4."""
+    from oracle import ast_ref as R
+    from ast_amd import nn as gnn
+    cfg = tiny_cfg(enc_layers=3, dec_layers=3, H=64, E=16, A=64, c0=8, c1=16, V=57, drop=0.3)
+    B, T, D, L, V = 1, 90, 80, 8, 57
+    P, X, y = _make(cfg, B, T, D, L, V, seed=11)
+    m = R.RefModel(cfg, {k: v.astype(np.float64) for k, v in P.items()}, V)
+    ref = R.decode_beam(m, X.astype(np.float64), stop_limit=7, N=3, K=4)
+    g = _gpu_model(cfg, P, D, V)
+    got = gnn.decode_beam(g, torch.from_numpy(X), stop_limit=7, N=3, K=4)
+    assert len(got) == len(ref) == 3
+    for a, b in zip(got, ref):
+        assert a["hyp"] == b["hyp"], (a["hyp"], b["hyp"])
+        assert abs(a["score"] - b["score"]) <= 1e-4 * max(1.0, abs(b["score"])), (a["score"], b["score"])
+        assert len(a["attn_history"]) == len(b["attn_history"]) == len(a["hyp"]) - 1
+        np.testing.assert_allclose(a["attn_history"][-1], b["attn_history"][-1], rtol=0, atol=1e-5)
+
+
 def test_checkpoint_roundtrip(tmp_path):
     from ast_amd import serializers
     from ast_amd.seq2seq import SpeechEncoderDecoder
