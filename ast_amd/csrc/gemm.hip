@@ -26,7 +26,10 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = ASTK_GEMM_BK;
 constexpr int WGS_PER_CU = BK == 32 ? 2 : 3;   // co-resident workgroups the grid is sized for (BK = 16: 33 KB of LDS and 127 registers per
                                                // workgroup; measured 768 ~ 1024 > 512 workgroups, and +5-7 % over BK = 32 at 512)
-constexpr int LD_RK = 129;  // LDS row stride (floats): operand staged from K-contiguous global rows
+constexpr int LD_RK = BK + 4;  // LDS row stride (floats) of an operand staged from K-contiguous global rows: kept ROW-major [m][k'] with the
+                               // tile's k order permuted to [even k | odd k], so that a thread's global float4 (4 consecutive k) is two
+                               // 8-byte LDS writes and the 8 k values an MFMA lane consumes (k = lk, lk+2, ...) are two 16-byte LDS reads
+                               // (stride 20 floats: conflict-free for both); was K-major with 4 scalar transposing writes and 8 scalar reads
 constexpr int LD_KR = 132;  // LDS row stride: operand staged from M/N-contiguous global rows (16 B aligned)
 
 __device__ __forceinline__ long rowoff(const MatView& v, int r) {
@@ -106,10 +109,9 @@ struct Stager {
       for (int p = 0; p < NP; ++p) {
         const int r = b + RPP * p;
         const float4 m = mask4(reg[p], nv[p]);
-        S[(a * 4 + 0) * LD_RK + r] = m.x;
-        S[(a * 4 + 1) * LD_RK + r] = m.y;
-        S[(a * 4 + 2) * LD_RK + r] = m.z;
-        S[(a * 4 + 3) * LD_RK + r] = m.w;
+        // k = 4a .. 4a+3: the even pair goes to positions 2a, 2a+1, the odd pair to BK/2 + 2a, +1
+        *reinterpret_cast<float2*>(&S[r * LD_RK + 2 * a]) = make_float2(m.x, m.z);
+        *reinterpret_cast<float2*>(&S[r * LD_RK + BK / 2 + 2 * a]) = make_float2(m.y, m.w);
       }
     } else {
 #pragma unroll
@@ -128,8 +130,9 @@ template <bool A_RK, bool B_RK, bool TWOLVL>
 __global__ __launch_bounds__(256, WGS_PER_CU) void gemm_f32_kernel(GemmGroup grp) {
   constexpr int LDA = A_RK ? LD_RK : LD_KR;
   constexpr int LDB = B_RK ? LD_RK : LD_KR;
-  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+  __shared__ __attribute__((aligned(16))) float As[2][A_RK ? BM * LD_RK : BK * LD_KR];
+  __shared__ __attribute__((aligned(16))) float Bs[2][B_RK ? BN * LD_RK : BK * LD_KR];
+  static_assert(BK == 16, "the RK fragment reads below take BK / 2 = 8 floats per lane as two float4");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -200,32 +203,47 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gemm_f32_kernel(GemmGroup grp
         sa.load(A, kbeg + (kt + 2) * BK, kend, g.K, m0, g.M);
         sb.load(B, kbeg + (kt + 2) * BK, kend, g.K, n0, g.N);
       }
-      const float* ap = As[cur] + lk * LDA + wm * 64 + li;
-      const float* bp = Bs[cur] + lk * LDB + wn * 64 + li;
-      // software-pipelined operand fetch: the LDS reads of k-pair kk+2 are issued before the MFMAs of k-pair kk
-      float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
+      // MFMA 32x32x2 operands: lane (li, lk) supplies row/col li of the 32-wide tile at k = 2j + lk, j = 0..BK/2-1.
+      //   RK operand: those 8 values are 8 consecutive floats of its LDS row (two 16-byte reads for the whole k-iteration)
+      //   KR operand: one scalar read per k-pair (rolling prefetch, one k-pair ahead of the MFMAs)
+      float fa0[BK / 2], fa1[BK / 2], fb0[BK / 2], fb1[BK / 2];
+      const float* ap = As[cur] + (A_RK ? (wm * 64 + li) * LDA + (BK / 2) * lk : lk * LDA + wm * 64 + li);
+      const float* bp = Bs[cur] + (B_RK ? (wn * 64 + li) * LDB + (BK / 2) * lk : lk * LDB + wn * 64 + li);
+      if (A_RK) {
+        *reinterpret_cast<float4*>(&fa0[0]) = *reinterpret_cast<const float4*>(ap);
+        *reinterpret_cast<float4*>(&fa0[4]) = *reinterpret_cast<const float4*>(ap + 4);
+        *reinterpret_cast<float4*>(&fa1[0]) = *reinterpret_cast<const float4*>(ap + 32 * LDA);
+        *reinterpret_cast<float4*>(&fa1[4]) = *reinterpret_cast<const float4*>(ap + 32 * LDA + 4);
+      } else { fa0[0] = ap[0]; fa1[0] = ap[32]; }
+      if (B_RK) {
+        *reinterpret_cast<float4*>(&fb0[0]) = *reinterpret_cast<const float4*>(bp);
+        *reinterpret_cast<float4*>(&fb0[4]) = *reinterpret_cast<const float4*>(bp + 4);
+        *reinterpret_cast<float4*>(&fb1[0]) = *reinterpret_cast<const float4*>(bp + 32 * LDB);
+        *reinterpret_cast<float4*>(&fb1[4]) = *reinterpret_cast<const float4*>(bp + 32 * LDB + 4);
+      } else { fb0[0] = bp[0]; fb1[0] = bp[32]; }
 #pragma unroll
-      for (int kk = 0; kk < BK; kk += 2) {
-        float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-        if (kk + 2 < BK) {
-          na0 = ap[(kk + 2) * LDA]; na1 = ap[(kk + 2) * LDA + 32];
-          nb0 = bp[(kk + 2) * LDB]; nb1 = bp[(kk + 2) * LDB + 32];
+      for (int j = 0; j < BK / 2; ++j) {
+        if (j + 1 < BK / 2) {
+          if (!A_RK) { fa0[j + 1] = ap[2 * (j + 1) * LDA]; fa1[j + 1] = ap[2 * (j + 1) * LDA + 32]; }
+          if (!B_RK) { fb0[j + 1] = bp[2 * (j + 1) * LDB]; fb1[j + 1] = bp[2 * (j + 1) * LDB + 32]; }
         }
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[j], fb0[j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[j], fb1[j], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[j], fb0[j], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[j], fb1[j], acc[1][1], 0, 0, 0);
       }
-      // pin the interleave (hipcc otherwise sinks every LDS read directly in front of its MFMAs with lgkmcnt(0)):
-      // reads of k-pair i+1 (2 x ds_read2_b32) go in front of the 4 MFMAs of k-pair i
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      // pin the interleave of the scalar (KR) operand reads: hipcc otherwise sinks every LDS read directly in front of its MFMAs with
+      // lgkmcnt(0).  One ds_read2_b32 per KR operand and k-pair goes in front of the 4 MFMAs of the previous k-pair.
+      if (!A_RK || !B_RK) {
+        constexpr int NR = (A_RK ? 0 : 1) + (B_RK ? 0 : 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, NR + (A_RK ? 2 : 0) + (B_RK ? 2 : 0), 0);
 #pragma unroll
-      for (int i = 0; i < BK / 2 - 1; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        for (int i = 0; i < BK / 2 - 1; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       __syncthreads();
     }
 

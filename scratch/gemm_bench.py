@@ -1,5 +1,5 @@
 import sys, ctypes as C, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
 from ast_amd import _lib
 lib = _lib.load()
