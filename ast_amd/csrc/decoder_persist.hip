@@ -28,6 +28,7 @@ namespace {
 constexpr int CTRS = 64;          // counter stride in words (256 B)
 constexpr int G = 256;            // workgroups (one per CU)
 enum Phase { PH_CELL = 0, PH_Q, PH_ATT, PH_CMB, PH_CTX, PH_LOG, PH_CE, PH_N };
+constexpr int NPHASE_SLOTS = 8;   // counter lines reserved per batch tile ahead of the abort word and the per-row counters
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -82,6 +83,27 @@ __device__ __forceinline__ bool wg_wait(const unsigned* ctr, unsigned target, un
   __syncthreads();
   const bool ok = *s_flag != 0;
   __syncthreads();            // s_flag may be rewritten by the next wait
+  return ok;
+}
+// workgroup-wide wait on `count` (<= 64) counters `stride` words apart: lane i of wave 0 polls counter i
+__device__ __forceinline__ bool wg_wait_multi(const unsigned* base, int stride, int count, unsigned target, unsigned* abort_word, int* s_flag) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    bool ok = true;
+    unsigned spins = 0;
+    for (;;) {
+      const bool mine = lane < count ? ld_flag(base + (long)lane * stride) >= target : true;
+      if (__all(mine)) break;
+      if ((++spins & 63u) == 0) {
+        if (ld_flag(abort_word) != 0) { ok = false; break; }
+        if (spins > (1u << 22)) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
+      }
+    }
+    if (lane == 0) *s_flag = ok ? 1 : 0;
+  }
+  __syncthreads();
+  const bool ok = *s_flag != 0;
+  __syncthreads();
   return ok;
 }
 __device__ __forceinline__ void publish(unsigned* ctr) {
@@ -187,6 +209,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
   const int nbt = a.nbt;
   unsigned* ctr = a.ctr;
 #define CTR(ph, bt) (ctr + ((ph) * nbt + (bt)) * CTRS)
+#define ROWCTR(row) (ctr + ((long)NPHASE_SLOTS * nbt + 2 + (row)) * CTRS)
 
   // ---------------- static item ownership
   const int n_cell = nbt * (H / 8);                       // cell items (bt, 8 units): workgroups [0, n_cell)
@@ -528,7 +551,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
         }
       }
       if (tid == 0) { st_sc1(&prow[0], m); st_sc1(&prow[1], l); }
-      publish(CTR(PH_ATT, bt));
+      publish(ROWCTR(b));      // per-row counter: 8 arrivals instead of 128 on one word, and the combine waits for ITS row only
       TQ(5)
       if (a.tick_out) tk_att += wall_clock64() - ta0;
       if (tid < nrow) a.ALPHA[((long)s * B + b) * Tp + t0 + tid] = my_score;   // raw score, normalised by the backward (M, 1/L in ML)
@@ -539,7 +562,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       const int b = cmb_b, bt = b / 16;
       const int rows_bt = min(16, B - bt * 16);
       TICK(15)
-      if (!wg_wait(CTR(PH_ATT, bt), (unsigned)(rows_bt * a.nsplit * (s + 1)), a.abort_word, &s_flag)) return;
+      if (!wg_wait(ROWCTR(b), (unsigned)(a.nsplit * (s + 1)), a.abort_word, &s_flag)) return;
       TICK(6)
       // No staging, no barrier: lane k of EVERY wave reads the header {max_k, sum_k} of partial k, the softmax weights of the
       // nsplit partials are formed with wave shuffles (identically in every wave), and thread tid < H/4 folds its four columns of the
@@ -714,6 +737,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
 #undef TICK
 #undef TQ
 #undef CTR
+#undef ROWCTR
 }
 
 // =====================================================================================================================
@@ -773,6 +797,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   const int nbt = a.nbt, K4 = 4 * H;
   unsigned* ctr = a.ctr;
 #define CTR(ph, bt) (ctr + ((ph) * nbt + (bt)) * CTRS)
+#define ROWCTR(row) (ctr + ((long)NPHASE_SLOTS * nbt + 2 + (row)) * CTRS)
   // ---------------- roles: [0,n5) cell bwd, [n5, n5+n6) dx0, [n5+n6, n5+n6+n1) d_pre + d_cvh ; attention: all
   const int n5 = nbt * (H / 16), n6 = a.b6_split ? 2 * nbt * (A / 16) : nbt * (XI / 16), n1 = nbt * (A / 16), n2 = nbt * (2 * H / 32);
   const bool has5 = wg < n5;
@@ -1071,7 +1096,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
             if (tid + 256 * j < H) st_sc1(&out[tid + 256 * j], acc4[j]);
         }
       }
-      publish(CTR(PB3, bt));
+      publish(ROWCTR(b));
       if (a.tick_out) tk_att += wall_clock64() - tb0;
       TB(5)
     }
@@ -1097,7 +1122,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
         if (a.rnn_mask) mk = a.rnn_mask[((long)s * B + row) * H + u];
       }
       TB(6)
-      if (!wg_wait(CTR(PB3, bt), (unsigned)(rows_bt * a.nsplit * (n + 1)), a.abort_word, &s_flag)) return;
+      if (!wg_wait_multi(ROWCTR(m0), CTRS, rows_bt, (unsigned)(a.nsplit * (n + 1)), a.abort_word, &s_flag)) return;
       TB(7)
       if (ev) {
         float dy = ld_sc1(a.DCVH + ((long)s * B + row) * 2 * H + H + u);
@@ -1156,6 +1181,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
     if (wg == 0) atomicAdd(&a.tick_out[G], 1.0f);
   }
 #undef CTR
+#undef ROWCTR
 }
 
 // After the loop: TOK[s][b] (the token that was fed) and X0[s][b][:E] = embed[TOK] * mask for the backward's wgrad / scatter
@@ -1278,7 +1304,7 @@ int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, con
   a.abort_word = bf.ctr + (size_t)PB_N * a.nbt * CTRS;
   a.tick_out = prof_tick_buffer(1);
   { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
-  ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)PB_N * a.nbt + 1) * CTRS * sizeof(unsigned), s));
+  ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)NPHASE_SLOTS * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), s));
   size_t scratch = 2 * (size_t)a.H + (size_t)((chunk + 3) & ~3) + 16 + 640;   // + ds/alpha/fold of the specialised attention scan
   const size_t shm = (2 * (size_t)chunk * a.H + scratch) * sizeof(float);
   static bool attr_done = false;
@@ -1318,7 +1344,7 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
   a.abort_word = bf.ctr + (size_t)PH_N * a.nbt * CTRS;
   { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.tick_out = prof_tick_buffer(0);
-  ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)PH_N * a.nbt + 1) * CTRS * sizeof(unsigned), s));
+  ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)NPHASE_SLOTS * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), s));
   const size_t shm = pdec_lds_floats(chunk, a.H, nsplit) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
