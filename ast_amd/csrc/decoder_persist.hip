@@ -106,11 +106,37 @@ __device__ __forceinline__ bool wg_wait_multi(const unsigned* base, int stride, 
   __syncthreads();
   return ok;
 }
+// Sharded phase counters: the items of a (phase, batch tile) bump one of NSH words (item & 3), each on its own line, and a waiter
+// polls the NSH words with NSH lanes.  Same-address atomics retire at ~12 ns each, so 64 arrivals on one word cost ~0.8 us of
+// hand-off latency; four words take them in parallel.
+constexpr int NSH = 4;
+__device__ __forceinline__ bool wg_wait_sh(const unsigned* base, int n_items, int steps, unsigned* abort_word, int* s_flag) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const unsigned target = lane < NSH ? (unsigned)(((n_items - lane + NSH - 1) / NSH) * steps) : 0u;   // items with (idx & 3) == lane
+    bool ok = true;
+    unsigned spins = 0;
+    for (;;) {
+      const bool mine = (lane < NSH && target > 0) ? ld_flag(base + lane * CTRS) >= target : true;
+      if (__all(mine)) break;
+      if ((++spins & 63u) == 0) {
+        if (ld_flag(abort_word) != 0) { ok = false; break; }
+        if (spins > (1u << 22)) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
+      }
+    }
+    if (lane == 0) *s_flag = ok ? 1 : 0;
+  }
+  __syncthreads();
+  const bool ok = *s_flag != 0;
+  __syncthreads();
+  return ok;
+}
 __device__ __forceinline__ void publish(unsigned* ctr) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void publish_sh(unsigned* base, int item) { publish(base + (item & (NSH - 1)) * CTRS); }
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 // gate / tanh activations on the decoder chain: v_exp_f32 / v_rcp_f32 based (absolute error <= ~2e-7), as in lstm_persist.hip
 __device__ __forceinline__ float sigm_fast(float x) { return __frcp_rn(1.f + __expf(-x)); }
@@ -208,8 +234,8 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
   const int B = a.B, S = a.S, H = a.H, E = a.E, A = a.A, V = a.V, XI = a.XI, T = a.T, Tp = a.Tp;
   const int nbt = a.nbt;
   unsigned* ctr = a.ctr;
-#define CTR(ph, bt) (ctr + ((ph) * nbt + (bt)) * CTRS)
-#define ROWCTR(row) (ctr + ((long)NPHASE_SLOTS * nbt + 2 + (row)) * CTRS)
+#define CTR(ph, bt) (ctr + ((ph) * nbt + (bt)) * NSH * CTRS)
+#define ROWCTR(row) (ctr + ((long)NPHASE_SLOTS * NSH * nbt + 2 + (row)) * CTRS)
 
   // ---------------- static item ownership
   const int n_cell = nbt * (H / 8);                       // cell items (bt, 8 units): workgroups [0, n_cell)
@@ -310,10 +336,10 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       const int bt = cell_bt, m0 = bt * 16;
       const int brow = min(m0 + r16, B - 1);             // this lane's A-operand batch row
       const bool truth = s == 0 || flagS[s] != 0;
-      if (!truth) { if (!wg_wait(CTR(PH_CE, bt), (unsigned)s, a.abort_word, &s_flag)) return; }
+      if (!truth) { if (!wg_wait_sh(CTR(PH_CE, bt), 1, s, a.abort_word, &s_flag)) return; }
       int tok = truth ? yS[r16 * a.L + s] : ldi_sc1(a.PRED + (long)(s - 1) * B + brow);
       tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
-      if (s > 0) { if (!wg_wait(CTR(PH_CELL, bt), (unsigned)((H / 8) * s), a.abort_word, &s_flag)) return; }
+      if (s > 0) { if (!wg_wait_sh(CTR(PH_CELL, bt), H / 8, s, a.abort_word, &s_flag)) return; }
       f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
       {
         // (a) embedding part and (b) recurrent part: neither depends on this step's ht, so they run before the wait on P4
@@ -340,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       TICK(0)
       // (c) input-feeding part: ht_{s-1}, written into X0[s][:, E:] by P4 of step s-1
       if (s > 0) {
-        if (!wg_wait(CTR(PH_CTX, bt), (unsigned)((A / 16) * s), a.abort_word, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PH_CTX, bt), A / 16, s, a.abort_word, &s_flag)) return;
         TICK(1)
         float4 at[NB_A];
         aload_sc1<NB_A>(at, r_x0, ((long)s * B + brow) * XI + E, A, lane, wave);
@@ -366,7 +392,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
         st_sc1(a.CVH + ((long)s * B + cell_b) * 2 * H + H + cell_u, hd);
       }
       TICK(2)
-      publish(CTR(PH_CELL, bt));
+      publish_sh(CTR(PH_CELL, bt), cell_u0 / 8);
       TICK(3)
       if (ev) {                                    // saved for the backward (plain stores, off the critical path)
         *reinterpret_cast<float4*>(a.Gt + ((long)s * B + cell_b) * 4 * H + 4 * cell_u) = gsave;
@@ -377,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
     if (has_att) {
       const int b = att_b, bt = b / 16;
       TICK(15)
-      if (!wg_wait(CTR(PH_CELL, bt), (unsigned)((H / 8) * (s + 1)), a.abort_word, &s_flag)) return;
+      if (!wg_wait_sh(CTR(PH_CELL, bt), H / 8, s + 1, a.abort_word, &s_flag)) return;
       TICK(4)
       const long long ta0 = a.tick_out ? wall_clock64() : 0;
       const int c4 = (a.chunk + 3) & ~3;
@@ -597,7 +623,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
         u.x = __float_as_uint(acc4.x * inv); u.y = __float_as_uint(acc4.y * inv); u.z = __float_as_uint(acc4.z * inv); u.w = __float_as_uint(acc4.w * inv);
         __builtin_amdgcn_raw_buffer_store_b128(u, r_cvh, (int)((((long)s * B + b) * 2 * H + 4 * tid) * 4), 0, 16);
       }
-      publish(CTR(PH_CMB, bt));
+      publish_sh(CTR(PH_CMB, bt), b - bt * 16);
       TICK(7)
       if (tid == 0) { a.ML[((long)s * B + b) * 2] = Mx; a.ML[((long)s * B + b) * 2 + 1] = inv; }
     }
@@ -611,7 +637,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       if constexpr (NC > 0) {
         // the h half of [cv ; h] was published by the cells long ago: its fragments (k-blocks NC..2NC-1 of each wave) and their MFMAs
         // run BEFORE the wait on the combine; only the cv half is fetched and multiplied behind it
-        if (!wg_wait(CTR(PH_CELL, bt), (unsigned)((H / 8) * (s + 1)), a.abort_word, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PH_CELL, bt), H / 8, s + 1, a.abort_word, &s_flag)) return;
         {
           float4 ahd[NC];
           const int q = lane >> 4;
@@ -620,7 +646,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
           __builtin_amdgcn_sched_barrier(0);
           mfma_blocks<NC>(acc, ahd, wreg + OFF_WC + NC);
         }
-        if (!wg_wait(CTR(PH_CMB, bt), (unsigned)(rows_bt * (s + 1)), a.abort_word, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PH_CMB, bt), rows_bt, s + 1, a.abort_word, &s_flag)) return;
         TICK(8)
         {
           float4 acv[NC];
@@ -631,7 +657,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
           mfma_blocks<NC>(acc, acv, wreg + OFF_WC);
         }
       } else {
-        if (!wg_wait(CTR(PH_CMB, bt), (unsigned)(rows_bt * (s + 1)), a.abort_word, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PH_CMB, bt), rows_bt, s + 1, a.abort_word, &s_flag)) return;
         TICK(8)
         wmac<NB_C>(acc, wreg + OFF_WC, r_cvh, crow, 2 * H, lane, wave);
       }
@@ -642,7 +668,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
         st_sc1(a.HT + ((long)(s + 1) * B + row) * A + n, ht);
         if (s + 1 < S) st_sc1(a.X0 + ((long)(s + 1) * B + row) * XI + E + n, ht);
       }
-      publish(CTR(PH_CTX, bt));
+      publish_sh(CTR(PH_CTX, bt), c_n0 / 16);
       TICK(9)
     }
     // ================= P5: logits tiles + per-tile softmax statistics =================
@@ -651,7 +677,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       if (l_item[t] < 0) continue;
       const int bt = l_item[t] / a.ntile_v, tile = l_item[t] % a.ntile_v, m0 = bt * 16, n0 = tile * 16;
       TICK(15)
-      if (!wg_wait(CTR(PH_CTX, bt), (unsigned)((A / 16) * (s + 1)), a.abort_word, &s_flag)) return;
+      if (!wg_wait_sh(CTR(PH_CTX, bt), A / 16, s + 1, a.abort_word, &s_flag)) return;
       TICK(10)
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       wmac<NB_L>(acc, wreg + OFF_WL + t * NB_L, r_ht, ((long)(s + 1) * B + min(m0 + r16, B - 1)) * A, A, lane, wave);
@@ -680,13 +706,13 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
         float* cs = a.CESTAT + (((long)s * B + row) * a.ntile_v + tile) * 4;
         st_sc1(cs, mx); st_sc1(cs + 1, se); st_sc1(cs + 2, __int_as_float(mi)); st_sc1(cs + 3, xt);
       }
-      publish(CTR(PH_LOG, bt));
+      publish_sh(CTR(PH_LOG, bt), tile);
       TICK(11)
     }
     // ================= P6: cross-entropy combine per batch tile =================
     if (has_ce) {
       const int bt = ce_rank, m0 = bt * 16;
-      if (!wg_wait(CTR(PH_LOG, bt), (unsigned)(a.ntile_v * (s + 1)), a.abort_word, &s_flag)) return;
+      if (!wg_wait_sh(CTR(PH_LOG, bt), a.ntile_v, s + 1, a.abort_word, &s_flag)) return;
       const int row = m0 + (tid >> 4), sub = tid & 15;       // 16 threads per row sweep the tiles
       float mx = -INFINITY, se = 0.f, xt = 0.f;
       int mi = 0x7fffffff;
@@ -719,7 +745,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
         a.LOSSROWS[(long)s * B + row] = -(xt - lse) * w / (float)B;
         sti_sc1(a.PRED + (long)s * B + row, mi);
       }
-      publish(CTR(PH_CE, bt));
+      publish_sh(CTR(PH_CE, bt), 0);
       TICK(12)
     }
   }
@@ -796,8 +822,8 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   const int B = a.B, S = a.S, H = a.H, E = a.E, A = a.A, XI = a.XI, T = a.T, Tp = a.Tp, Vp = a.Vp;
   const int nbt = a.nbt, K4 = 4 * H;
   unsigned* ctr = a.ctr;
-#define CTR(ph, bt) (ctr + ((ph) * nbt + (bt)) * CTRS)
-#define ROWCTR(row) (ctr + ((long)NPHASE_SLOTS * nbt + 2 + (row)) * CTRS)
+#define CTR(ph, bt) (ctr + ((ph) * nbt + (bt)) * NSH * CTRS)
+#define ROWCTR(row) (ctr + ((long)NPHASE_SLOTS * NSH * nbt + 2 + (row)) * CTRS)
   // ---------------- roles: [0,n5) cell bwd, [n5, n5+n6) dx0, [n5+n6, n5+n6+n1) d_pre + d_cvh ; attention: all
   const int n5 = nbt * (H / 16), n6 = a.b6_split ? 2 * nbt * (A / 16) : nbt * (XI / 16), n1 = nbt * (A / 16), n2 = nbt * (2 * H / 32);
   const bool has5 = wg < n5;
@@ -874,7 +900,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
       float carry = 0.f;
       TB(0)
       if (n > 0) {
-        if (!wg_wait(CTR(PB6, bt), (unsigned)((a.b6_split ? 2 * (A / 16) : XI / 16) * n), a.abort_word, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PB6, bt), a.b6_split ? 2 * (A / 16) : XI / 16, n, a.abort_word, &s_flag)) return;
         TB(1)
         if (row < B) {
           if (a.b6_split) {
@@ -888,14 +914,14 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
         const float y = a.HT[((long)(s + 1) * B + row) * A + col];
         st_sc1(a.DPRE + ((long)s * B + row) * A + col, (v + carry) * (1.f - y * y));
       }
-      publish(CTR(PB1, bt));
+      publish_sh(CTR(PB1, bt), b1_n0 / 16);
       TB(2)
     }
     // ================= B2 =================
     if (has2) {
       const int bt = b2_bt, m0 = bt * 16;
       TB(15)
-      if (!wg_wait(CTR(PB1, bt), (unsigned)((A / 16) * (n + 1)), a.abort_word, &s_flag)) return;
+      if (!wg_wait_sh(CTR(PB1, bt), A / 16, n + 1, a.abort_word, &s_flag)) return;
       TB(3)
       float4 av[NB_B2];
       aload_sc1<NB_B2>(av, r_dpre, ((long)s * B + min(m0 + r16, B - 1)) * A, A, lane, wave);
@@ -910,7 +936,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
         st_sc1(a.DCVH + ((long)s * B + row) * 2 * H + b2_n0 + e_col, v0);
         st_sc1(a.DCVH + ((long)s * B + row) * 2 * H + b2_n0 + 16 + e_col, v1);
       }
-      publish(CTR(PB2, bt));
+      publish_sh(CTR(PB2, bt), b2_n0 / 32);
       TB(4)
     }
     // ================= B3: attention backward =================
@@ -936,7 +962,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
           if (tid < HH / 4) cv4 = *reinterpret_cast<const float4*>(a.CVH + ((long)s * B + b) * 2 * HH + 4 * tid);
           a_t = tid < nrow ? expf(raw - mlM) * mlI : 0.f;
         }
-        if (!wg_wait(CTR(PB2, bt), (unsigned)((2 * H / 32) * (n + 1)), a.abort_word, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PB2, bt), 2 * H / 32, n + 1, a.abort_word, &s_flag)) return;
         tb0 = a.tick_out ? wall_clock64() : 0;
         float cdp = 0.f;                       // cv . d_cv
         if (tid < HH / 4) {
@@ -1018,7 +1044,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
           }
         }
       } else {
-        if (!wg_wait(CTR(PB2, bt), (unsigned)((2 * H / 32) * (n + 1)), a.abort_word, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PB2, bt), 2 * H / 32, n + 1, a.abort_word, &s_flag)) return;
         tb0 = a.tick_out ? wall_clock64() : 0;
         float* dS = scr;                  // d_cv[b][:]
         float* cvS = scr + H;             // cv[b][:]
@@ -1106,7 +1132,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
       const int rows_bt = min(16, B - bt * 16);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       if (n > 0) {       // dh_rec = dz_{s+1} Wl: independent of this step's chain
-        if (!wg_wait(CTR(PB5, bt), (unsigned)((H / 16) * n), a.abort_word, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PB5, bt), H / 16, n, a.abort_word, &s_flag)) return;
         wmac_chunked<NB_B5, 16>(acc, wreg, r_g, ((long)(s + 1) * B + min(m0 + r16, B - 1)) * K4, K4, lane, wave);
       }
       const float v = reduce16(acc, red);
@@ -1146,14 +1172,14 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
         __builtin_amdgcn_raw_buffer_store_b128(o, r_g, (int)((((long)s * B + row) * K4 + 4 * u) * 4), 0, 16);
         dc_state = dcv * g.z;
       }
-      publish(CTR(PB5, bt));
+      publish_sh(CTR(PB5, bt), b5_u0 / 16);
       TB(8)
     }
     // ================= B6: d_x0 = dz Wu =================
     if (has6) {
       const int bt = b6_bt, m0 = bt * 16;
       TB(15)
-      if (!wg_wait(CTR(PB5, bt), (unsigned)((H / 16) * (n + 1)), a.abort_word, &s_flag)) return;
+      if (!wg_wait_sh(CTR(PB5, bt), H / 16, n + 1, a.abort_word, &s_flag)) return;
       TB(9)
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       if (a.b6_split) wmac_chunked<NB_B6 / 2, 16>(acc, wreg, r_g, ((long)s * B + min(m0 + r16, B - 1)) * K4 + b6_k0, K4 / 2, lane, wave);
@@ -1164,7 +1190,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
         if (a.b6_split) st_sc1(a.DXH + ((long)(b6_half * S + s) * B + row) * A + (b6_n0 - E) + e_col, v);
         else st_sc1(a.DX0 + ((long)s * B + row) * XI + b6_n0 + e_col, v);
       }
-      publish(CTR(PB6, bt));
+      publish_sh(CTR(PB6, bt), a.b6_split ? 2 * (b6_item % b6_per_bt) + b6_half : b6_item % b6_per_bt);
       TB(10)
     }
   }
@@ -1301,10 +1327,10 @@ int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, con
   a.DXH = bf.DXH;
   a.b6_split = bf.DXH != nullptr && decoder_persist_b6_split(d) ? 1 : 0;
   a.ctr = bf.ctr;
-  a.abort_word = bf.ctr + (size_t)PB_N * a.nbt * CTRS;
+  a.abort_word = bf.ctr + (size_t)NPHASE_SLOTS * NSH * a.nbt * CTRS;
   a.tick_out = prof_tick_buffer(1);
   { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
-  ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)NPHASE_SLOTS * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), s));
+  ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)NPHASE_SLOTS * NSH * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), s));
   size_t scratch = 2 * (size_t)a.H + (size_t)((chunk + 3) & ~3) + 16 + 640;   // + ds/alpha/fold of the specialised attention scan
   const size_t shm = (2 * (size_t)chunk * a.H + scratch) * sizeof(float);
   static bool attr_done = false;
@@ -1341,10 +1367,10 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
   a.TOK = bf.TOK; a.PRED = bf.PRED; a.X0 = bf.X0; a.Gt = bf.G; a.Cst = bf.C; a.HR = bf.HR; a.Q = bf.Q; a.ALPHA = bf.ALPHA;
   a.CVH = bf.CVH; a.HT = bf.HT; a.LOGITS = bf.LOGITS; a.LOSSROWS = bf.LOSSROWS; a.LSE = bf.LSE; a.PART = bf.PART; a.CESTAT = bf.CESTAT; a.ML = bf.ML;
   a.ctr = bf.ctr;
-  a.abort_word = bf.ctr + (size_t)PH_N * a.nbt * CTRS;
+  a.abort_word = bf.ctr + (size_t)NPHASE_SLOTS * NSH * a.nbt * CTRS;
   { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.tick_out = prof_tick_buffer(0);
-  ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)NPHASE_SLOTS * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), s));
+  ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)NPHASE_SLOTS * NSH * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), s));
   const size_t shm = pdec_lds_floats(chunk, a.H, nsplit) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
