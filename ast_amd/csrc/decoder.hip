@@ -118,7 +118,7 @@ int make_plan(const astk_decoder_desc* d, void* ws, DecPlan& P) {
     P.CESTAT = c.take<float>(pp ? S * B * (size_t)((P.V + 15) / 16) * 4 : 4);
     P.ENCA = c.take<float>(pp ? B * (size_t)P.T * H : 4);
     P.MLB = c.take<float>(pp ? S * B * 2 : 4);
-    P.PCTR = c.take<unsigned>(pp ? (size_t)(8 * 4 * ((P.B + 15) / 16) + 2 + P.B) * 64 : 4);   // sharded phase counters, abort word, per-row counters
+    P.PCTR = c.take<unsigned>(pp ? (size_t)(8 * 32 * ((P.B + 15) / 16) + 2 + P.B) * 64 : 4);   // sharded phase counters, abort word, per-row counters
     P.DXH = c.take<float>(pp ? 2 * S * B * (size_t)P.A : 4);
   }
   P.bytes = c.total();
