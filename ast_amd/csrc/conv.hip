@@ -176,6 +176,20 @@ __global__ __launch_bounds__(256) void k_colstats(const float* __restrict__ Y, i
       [&](int col, int st, float v) { atomicAdd(&stat[st * C + col], (double)v); });
 }
 
+// zero only the pad rows of a time-padded channels-last buffer [(group)][padF + Tn + padB][C]: the interior is rewritten every step
+__global__ __launch_bounds__(256) void k_zero_pads(float* __restrict__ buf, int groups, int Tn, int padF, int padB, int C) {
+  const int np = padF + padB;
+  const long n4 = (long)groups * np * (C / 4);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % (C / 4));
+    const long gp = i / (C / 4);
+    const int pr = (int)(gp % np);
+    const long grp = gp / np;
+    const int row = pr < padF ? pr : Tn + pr;     // rows [0, padF) and [padF + Tn, padF + Tn + padB)
+    reinterpret_cast<float4*>(buf + (grp * (padF + Tn + padB) + row) * C)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 // bn[0]=mean, bn[1]=inv_std, bn[2]=scale, bn[3]=shift ; running statistics per Chainer-sem A4
 __global__ void k_bn_finalize(const double* __restrict__ stat, int C, double m, const float* __restrict__ gamma,
                               const float* __restrict__ beta, float* __restrict__ avg_mean, float* __restrict__ avg_var,
@@ -373,7 +387,11 @@ int astk_conv_bn_relu_fwd(const astk_cnn_desc* d, const astk_cnn_layer_params* L
                        L[i].avg_mean, L[i].avg_var, P.bn[i], d->bn_eps, d->bn_decay, train);
     ASTK_LAUNCH_CHECK();
     if (i < P.n - 1) {
-      ASTK_TRY(fill_zero(P.HP[i], (size_t)B * F * (P.Tn[i] + 2 * P.padA[i]) * C * sizeof(float), s));
+      if (P.padA[i] > 0) {
+        hipLaunchKernelGGL(k_zero_pads, dim3(gridn((size_t)B * F * 2 * P.padA[i] * C / 4)), dim3(256), 0, s, P.HP[i], B * F, P.Tn[i], P.padA[i],
+                           P.padA[i], C);
+        ASTK_LAUNCH_CHECK();
+      }
       hipLaunchKernelGGL(k_bn_relu_rows, dim3(gridn((size_t)rows * C / 4)), dim3(256), 0, s, P.Y[i], P.bn[i], P.HP[i], rows, C,
                          P.Tn[i], P.padA[i]);
       ASTK_LAUNCH_CHECK();
@@ -408,7 +426,11 @@ int astk_conv_bn_relu_bwd(const astk_cnn_desc* d, const astk_cnn_layer_params* L
     hipLaunchKernelGGL(k_bn_bwd_stats, colreduce_grid(rows, C), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], rows, C, P.stat);
     ASTK_LAUNCH_CHECK();
     const int Tp = P.Tn[i] + P.dF[i] + P.dB[i];
-    if (P.dF[i] + P.dB[i] > 0) ASTK_TRY(fill_zero(P.DY[i], (size_t)B * F * Tp * C * sizeof(float), s));
+    if (P.dF[i] + P.dB[i] > 0) {
+      hipLaunchKernelGGL(k_zero_pads, dim3(gridn((size_t)B * F * (P.dF[i] + P.dB[i]) * C / 4)), dim3(256), 0, s, P.DY[i], B * F, P.Tn[i], P.dF[i],
+                         P.dB[i], C);
+      ASTK_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(gridn((size_t)rows * C)), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], P.stat, P.DY[i], rows, C,
                        P.Tn[i], P.dF[i], P.dB[i], Gr[i].dgamma, Gr[i].dbeta);
     ASTK_LAUNCH_CHECK();
