@@ -107,7 +107,8 @@ struct GemmArgs {
   int batch;
   long sA, sB, sC;
   // filled by gemm_launch (work decomposition)
-  int kt;            // k-iterations per tile = ceil(K / 32)
+  unsigned spanA, spanB;  // bytes from A.p / B.p to the end of one batch slice (buffer-load range)
+  int kt;            // k-iterations per tile = ceil(K / BK)
   int tiles_mn;      // tiles per batch matrix
   long iters_total;  // batch * tiles_mn * kt
 };

@@ -3,11 +3,11 @@
 // One kernel family covers every batched dense product of the train step (SURVEY.md K6, K9, K24 and
 // all dgrad / wgrad products): C[M,N] (+)= op(A) op(B) (+bias).
 //   128x128x16 block tile (BK = 16, double-buffered in LDS), 256 threads = 4 waves as 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles
-//   (64 accumulator VGPRs).  Both operands are staged K-major in LDS (As[k][m], Bs[k][n]) so every MFMA
-//   operand read is one conflict-free ds_read_b32 across 32 consecutive floats; operands whose global
-//   rows are K-contiguous are transposed on the LDS write (row stride 129 -> conflict-free scalar
-//   writes), operands whose rows are M/N-contiguous are written with ds_write_b128 (row stride 132).
-//   Global loads are 16 B per lane, register-staged one k-tile ahead of the MFMAs.
+//   (64 accumulator VGPRs), three workgroups per CU, k-iterations split evenly over the grid (stream-K).  An operand whose global
+//   rows are K-contiguous is kept row-major in LDS with the tile's k order permuted to [even | odd] (two 8-byte writes per
+//   staged float4, two 16-byte reads per lane and k-iteration); an operand whose rows are M/N-contiguous is kept K-major
+//   (16-byte writes, one ds_read2st64_b32 per k-pair).  Global loads are 16 B per lane, register-staged two k-tiles ahead of
+//   the MFMAs, and the k loop is free of vector-ALU work (see Stager).
 // Rows of A, B and C can use two-level or indexed addressing (MatView) so the conv layers run as
 // zero-copy "window" GEMMs over padded channels-last activations and the reverse LSTM direction reads
 // frames through its permutation table instead of a permuted copy.
@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <type_traits>
 
 namespace astk {
 
@@ -30,7 +31,10 @@ constexpr int LD_RK = BK + 4;  // LDS row stride (floats) of an operand staged f
                                // tile's k order permuted to [even k | odd k], so that a thread's global float4 (4 consecutive k) is two
                                // 8-byte LDS writes and the 8 k values an MFMA lane consumes (k = lk, lk+2, ...) are two 16-byte LDS reads
                                // (stride 20 floats: conflict-free for both); was K-major with 4 scalar transposing writes and 8 scalar reads
-constexpr int LD_KR = 132;  // LDS row stride: operand staged from M/N-contiguous global rows (16 B aligned)
+constexpr int LD_KR = 128;  // LDS row stride of an operand staged from M/N-contiguous global rows: K-major [k][m'], written with 16-byte stores;
+                            // the 128 columns are ordered [wave-row 0 tile 0 | wave-row 1 tile 0 | wave-row 0 tile 1 | wave-row 1 tile 1] so the
+                            // two values a lane needs per k (its column of both 32-wide MFMA tiles) are 64 floats apart and consecutive
+                            // k-pairs 256 floats: one ds_read2st64_b32 with immediate offsets per k-pair, no address arithmetic
 
 __device__ __forceinline__ long rowoff(const MatView& v, int r) {
   if (v.rowidx) return (long)v.rowidx[r] * v.ld;
@@ -38,84 +42,123 @@ __device__ __forceinline__ long rowoff(const MatView& v, int r) {
   return (long)r * v.ld;
 }
 
-// Branch-free guarded load: the caller passes an address that is ALWAYS readable (clamped inside the matrix); elements
-// at index >= nvalid are zeroed with selects.  (A `cond ? load : 0` makes hipcc branch around every load and wait
-// vmcnt(0) per element -- the loads of a tile would serialise.)
-__device__ __forceinline__ float4 mask4(float4 v, int nvalid) {
-  v.x = nvalid > 0 ? v.x : 0.f;
-  v.y = nvalid > 1 ? v.y : 0.f;
-  v.z = nvalid > 2 ? v.z : 0.f;
-  v.w = nvalid > 3 ? v.w : 0.f;
-  return v;
-}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// Stages one operand tile.  RK: global rows are the tile's M (or N) index, K contiguous (row offsets are computed once,
-// any MatView addressing).  !RK: global rows are the k index; TWOLVL selects plain (k*ld) or two-level row offsets --
-// both branch-free, so the tile's loads are issued back to back (indexed rows are not supported on this path).
+// Position j (0..BK/2-1) of the k values a lane of k-group lk (0/1) feeds to the MFMAs of one k-iteration is
+// k = KROW(j) + 2*lk: a staged float4 (4 consecutive k) then splits into the register pairs (x,y) -> lk 0 and (z,w) -> lk 1.
+#define KROW(j) (4 * ((j) >> 1) + ((j) & 1))
+
+// Stages one operand tile: global -> registers (load) -> LDS (store), one tile per call, tiles in k order.
+//   RK: global rows are the tile's M (or N) index, K contiguous (any MatView addressing; row offsets are computed once per tile).
+//   !RK: global rows are the k index; TWOLVL selects plain (k * ld) or two-level row offsets (indexed rows are not supported here).
+// The k loop must not spend vector-ALU instructions: on gfx950 a VALU instruction takes the issue slot of an MFMA pass
+// (scratch/mfma_mix_bench.hip: 3 VALU per MFMA cost 18 % of the MFMA rate), and the first version of this stager spent ~56 of
+// them per 32 MFMAs on 64-bit addresses, tail selects and register shuffles.  So:
+//   * loads are raw buffer loads: voffset = a 32-bit byte offset fixed for the tile, base = a uniform pointer that advances with
+//     k in SGPRs (operand slices are limited to 4 GiB, checked on the host);
+//   * rows / columns outside the matrix are CLAMPED, never masked: they only feed C elements the epilogue does not write;
+//   * the buffer's num_records is the exact extent of the operand slice, so reads past it return zeros: that IS the K tail of a
+//     plain K-major operand; a K-contiguous operand may pick up the neighbouring row's data in its last tile, which the
+//     owning thread then zeroes in LDS (zero_tail, taken once per tile at most and only when K is not a multiple of BK);
+//   * two-level K-major rows (the conv wgrad) are addressed like plain ones while a tile's BK rows lie inside one group (uniform
+//     test); only a tile that straddles groups computes per-row offsets.
 template <bool RK, bool TWOLVL>
 struct Stager {
   static constexpr int NP = BK / 8;        // passes: 256 threads x 16 B cover 1/NP of a 128 x BK tile
   static constexpr int KQ = BK / 4;        // RK: k-quads per row
-  static constexpr int RPP = 256 / KQ;     // RK: rows per pass
-  float4 reg[NP];  // raw staged data: masked only when it is written to LDS, so the global loads stay in flight over the MFMAs
-  int nv[NP];      // valid elements of reg[p]
-  long off[NP];   // RK only: row offsets (fixed for the whole k loop)
-  bool ok[NP];    // RK only
-  int a, b;      // RK: a = k-quad (0..KQ-1), b = row0 (0..RPP-1).  KR: a = col-quad (0..31), b = krow0 (0..7)
+  float4 reg[NP];     // staged data
+  unsigned voff[NP];  // RK and plain KR: byte offset of this thread's float4 from the tile's uniform base
+  int tgrp, trem;     // two-level KR: group and position inside the group of row kcur (uniform)
+  int tcol;           // two-level KR: this thread's (clamped) column
+  int a, b;           // RK: a = k-quad (0..KQ-1), b = row pair (0..63).  KR: a = column quad (0..31), b = krow0 (0..7)
+  int kcur;           // first k of the tile the next load() fetches
+  int lds;            // float offset of this thread's first LDS write
 
-  __device__ __forceinline__ void init(const MatView& v, int row0, int nrows, int tid) {
+  // row0 / nrows: the tile's first M (N) index and the operand's M (N) extent; [kbeg, kend): this workgroup's K range.
+  // Leading dimensions are multiples of 4 and >= the extent, so a float4 at any multiple of 4 below round_up(extent, 4)
+  // stays inside its row.
+  __device__ __forceinline__ void init(const MatView& v, int row0, int nrows, int kbeg, int kend, int tid) {
+    kcur = kbeg;
     if (RK) {
       a = tid % KQ;
       b = tid / KQ;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        int r = row0 + b + RPP * p;
-        ok[p] = r < nrows;
-        off[p] = rowoff(v, ok[p] ? r : (nrows - 1));
-      }
+      for (int p = 0; p < NP; ++p) voff[p] = (unsigned)((rowoff(v, min(row0 + NP * b + p, nrows - 1)) + a * 4) * 4);
+      lds = NP * b * LD_RK + 2 * a;   // a thread's NP rows are neighbours: one LDS address register serves all its writes
     } else {
       a = tid & 31;
       b = tid >> 5;
+      // LDS column order of a KR tile: [wm0 i0 | wm1 i0 | wm0 i1 | wm1 i1] x 32 (see LD_KR); lane a writes LDS columns 4a..4a+3,
+      // which hold the tile's columns wm*64 + i*32 + 4*(a&7) with i = a>>4, wm = (a>>3)&1
+      const int m = ((a >> 3) & 1) * 64 + (a >> 4) * 32 + (a & 7) * 4;
+      const int col = min(row0 + m, ((nrows + 3) & ~3) - 4);
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        voff[p] = (unsigned)(((long)(b + 8 * p) * (TWOLVL ? v.st : v.ld) + col) * 4);
+      if (TWOLVL) { tgrp = kbeg / v.tn; trem = kbeg % v.tn; tcol = col; }
+      lds = b * LD_KR + 4 * a;
     }
   }
-  // kcur: first k of the tile, kend: exclusive end of this block's K range, K: full K extent; col0/ncols: KR only.
-  // Leading dimensions are multiples of 4 and >= the extent, so a float4 at any multiple of 4 below round_up(extent,4)
-  // stays inside its row: addresses are clamped to that range and the surplus is masked.
-  __device__ __forceinline__ void load(const MatView& v, int kcur, int kend, int K, int col0, int ncols) {
-    if (RK) {
-      const int k = kcur + a * 4;
-      const int kc = min(k, ((K + 3) & ~3) - 4);
+  // span: bytes from v.p to the end of the operand slice (gemm_prepare)
+  __device__ __forceinline__ void load(const MatView& v, unsigned span, int kend) {
+    if (RK || !TWOLVL) {
+      const long adv = RK ? (long)kcur : (long)kcur * v.ld;
+      const __amdgpu_buffer_rsrc_t r =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(v.p + adv), 0, (int)(span - (unsigned)(adv * 4)), 0x00020000);
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        reg[p] = *reinterpret_cast<const float4*>(v.p + off[p] + kc);
-        nv[p] = ok[p] ? (kend - k) : 0;
+        const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff[p], 0, 0);
+        reg[p] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
       }
     } else {
-      const int col = col0 + a * 4;
-      const int colc = min(col, ((ncols + 3) & ~3) - 4);
+      if (trem + BK <= v.tn && kcur + BK <= kend) {   // the tile's BK rows exist and lie in one group (uniform): addressed like the plain case
+        const __amdgpu_buffer_rsrc_t r =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(v.p + (long)tgrp * v.sg + (long)trem * v.st), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int kr = kcur + b + 8 * p;
-        const int krc = min(kr, kend - 1);
-        const long ro = TWOLVL ? (long)(krc / v.tn) * v.sg + (long)(krc % v.tn) * v.st : (long)krc * v.ld;
-        reg[p] = *reinterpret_cast<const float4*>(v.p + ro + colc);
-        nv[p] = kr < kend ? (ncols - col) : 0;
+        for (int p = 0; p < NP; ++p) {
+          const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff[p], 0, 0);
+          reg[p] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+        }
+      } else {                   // the tile straddles groups (or runs past kend): per-row offsets, rows clamped to kend - 1
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int kr = min(kcur + b + 8 * p, kend - 1);
+          reg[p] = *reinterpret_cast<const float4*>(v.p + (long)(kr / v.tn) * v.sg + (long)(kr % v.tn) * v.st + tcol);
+        }
       }
+      trem += BK;
+      while (trem >= v.tn) { trem -= v.tn; ++tgrp; }
     }
+    kcur += BK;
   }
   __device__ __forceinline__ void store(float* S) const {
     if (RK) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        const int r = b + RPP * p;
-        const float4 m = mask4(reg[p], nv[p]);
-        // k = 4a .. 4a+3: the even pair goes to positions 2a, 2a+1, the odd pair to BK/2 + 2a, +1
-        *reinterpret_cast<float2*>(&S[r * LD_RK + 2 * a]) = make_float2(m.x, m.z);
-        *reinterpret_cast<float2*>(&S[r * LD_RK + BK / 2 + 2 * a]) = make_float2(m.y, m.w);
+        *reinterpret_cast<float2*>(&S[lds + p * LD_RK]) = make_float2(reg[p].x, reg[p].y);
+        *reinterpret_cast<float2*>(&S[lds + p * LD_RK + BK / 2]) = make_float2(reg[p].z, reg[p].w);
       }
     } else {
 #pragma unroll
-      for (int p = 0; p < NP; ++p) *reinterpret_cast<float4*>(&S[(b + 8 * p) * LD_KR + a * 4]) = mask4(reg[p], nv[p]);
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<float4*>(&S[lds + 8 * p * LD_KR]) = reg[p];
+    }
+  }
+  // Zeroes what this thread's store() wrote for k >= kend (ktile: first k of the tile in S).
+  __device__ __forceinline__ void zero_tail(float* S, int ktile, int kend) const {
+    if (RK) {
+      const int nv = kend - (ktile + a * 4);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        float* q = &S[lds + p * LD_RK];
+        if (nv < 1) q[0] = 0.f;
+        if (nv < 2) q[1] = 0.f;
+        if (nv < 3) q[BK / 2] = 0.f;
+        if (nv < 4) q[BK / 2 + 1] = 0.f;
+      }
+    } else if (TWOLVL) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        if (ktile + b + 8 * p >= kend) *reinterpret_cast<float4*>(&S[lds + 8 * p * LD_KR]) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 };
@@ -168,8 +211,8 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gemm_f32_kernel(GemmGroup grp
 
     Stager<A_RK, TWOLVL> sa;
     Stager<B_RK, TWOLVL> sb;
-    sa.init(A, m0, g.M, tid);
-    sb.init(B, n0, g.N, tid);
+    sa.init(A, m0, g.M, kbeg, kend, tid);
+    sb.init(B, n0, g.N, kbeg, kend, tid);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -183,49 +226,52 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gemm_f32_kernel(GemmGroup grp
 
     // Pipeline: tile kt is multiplied out of LDS buffer kt&1 while tile kt+1 moves registers -> the other buffer and
     // tile kt+2 is in flight global -> registers; one barrier per k-iteration.
-    sa.load(A, kbeg, kend, g.K, m0, g.M);
-    sb.load(B, kbeg, kend, g.K, n0, g.N);
+    sa.load(A, g.spanA, kend);
+    sb.load(B, g.spanB, kend);
     sa.store(As[0]);
     sb.store(Bs[0]);
+    if (kbeg + BK > kend) { sa.zero_tail(As[0], kbeg, kend); sb.zero_tail(Bs[0], kbeg, kend); }
     if (nk > 1) {
-      sa.load(A, kbeg + BK, kend, g.K, m0, g.M);
-      sb.load(B, kbeg + BK, kend, g.K, n0, g.N);
+      sa.load(A, g.spanA, kend);
+      sb.load(B, g.spanB, kend);
     }
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
+    // (two k-iterations per trip, so that the LDS buffer index is a compile-time constant and every LDS address an immediate offset)
+    auto step = [&](auto curc, const int kt) {
+      constexpr int cur = decltype(curc)::value;
       if (kt + 1 < nk) {
         sa.store(As[cur ^ 1]);
         sb.store(Bs[cur ^ 1]);
+        if (kbeg + (kt + 2) * BK > kend) { sa.zero_tail(As[cur ^ 1], kbeg + (kt + 1) * BK, kend); sb.zero_tail(Bs[cur ^ 1], kbeg + (kt + 1) * BK, kend); }
       }
       if (kt + 2 < nk) {
-        sa.load(A, kbeg + (kt + 2) * BK, kend, g.K, m0, g.M);
-        sb.load(B, kbeg + (kt + 2) * BK, kend, g.K, n0, g.N);
+        sa.load(A, g.spanA, kend);
+        sb.load(B, g.spanB, kend);
       }
-      // MFMA 32x32x2 operands: lane (li, lk) supplies row/col li of the 32-wide tile at k = 2j + lk, j = 0..BK/2-1.
+      // MFMA 32x32x2 operands: lane (li, lk) supplies row/col li of the 32-wide tile at k = KROW(j) + 2*lk, j = 0..BK/2-1.
       //   RK operand: those 8 values are 8 consecutive floats of its LDS row (two 16-byte reads for the whole k-iteration)
-      //   KR operand: one scalar read per k-pair (rolling prefetch, one k-pair ahead of the MFMAs)
+      //   KR operand: one ds_read2st64_b32 per k-pair (both 32-wide tiles), rolling one k-pair ahead of the MFMAs
       float fa0[BK / 2], fa1[BK / 2], fb0[BK / 2], fb1[BK / 2];
-      const float* ap = As[cur] + (A_RK ? (wm * 64 + li) * LDA + (BK / 2) * lk : lk * LDA + wm * 64 + li);
-      const float* bp = Bs[cur] + (B_RK ? (wn * 64 + li) * LDB + (BK / 2) * lk : lk * LDB + wn * 64 + li);
+      const float* ap = As[cur] + (A_RK ? (wm * 64 + li) * LDA + (BK / 2) * lk : 2 * lk * LDA + wm * 32 + li);
+      const float* bp = Bs[cur] + (B_RK ? (wn * 64 + li) * LDB + (BK / 2) * lk : 2 * lk * LDB + wn * 32 + li);
       if (A_RK) {
         *reinterpret_cast<float4*>(&fa0[0]) = *reinterpret_cast<const float4*>(ap);
         *reinterpret_cast<float4*>(&fa0[4]) = *reinterpret_cast<const float4*>(ap + 4);
         *reinterpret_cast<float4*>(&fa1[0]) = *reinterpret_cast<const float4*>(ap + 32 * LDA);
         *reinterpret_cast<float4*>(&fa1[4]) = *reinterpret_cast<const float4*>(ap + 32 * LDA + 4);
-      } else { fa0[0] = ap[0]; fa1[0] = ap[32]; }
+      } else { fa0[0] = ap[0]; fa1[0] = ap[64]; }
       if (B_RK) {
         *reinterpret_cast<float4*>(&fb0[0]) = *reinterpret_cast<const float4*>(bp);
         *reinterpret_cast<float4*>(&fb0[4]) = *reinterpret_cast<const float4*>(bp + 4);
         *reinterpret_cast<float4*>(&fb1[0]) = *reinterpret_cast<const float4*>(bp + 32 * LDB);
         *reinterpret_cast<float4*>(&fb1[4]) = *reinterpret_cast<const float4*>(bp + 32 * LDB + 4);
-      } else { fb0[0] = bp[0]; fb1[0] = bp[32]; }
+      } else { fb0[0] = bp[0]; fb1[0] = bp[64]; }
 #pragma unroll
       for (int j = 0; j < BK / 2; ++j) {
         if (j + 1 < BK / 2) {
-          if (!A_RK) { fa0[j + 1] = ap[2 * (j + 1) * LDA]; fa1[j + 1] = ap[2 * (j + 1) * LDA + 32]; }
-          if (!B_RK) { fb0[j + 1] = bp[2 * (j + 1) * LDB]; fb1[j + 1] = bp[2 * (j + 1) * LDB + 32]; }
+          if (!A_RK) { fa0[j + 1] = ap[KROW(j + 1) * LDA]; fa1[j + 1] = ap[KROW(j + 1) * LDA + 64]; }
+          if (!B_RK) { fb0[j + 1] = bp[KROW(j + 1) * LDB]; fb1[j + 1] = bp[KROW(j + 1) * LDB + 64]; }
         }
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[j], fb0[j], acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[j], fb1[j], acc[0][1], 0, 0, 0);
@@ -245,6 +291,10 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gemm_f32_kernel(GemmGroup grp
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       }
       __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      step(std::integral_constant<int, 0>{}, kt);
+      if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -310,6 +360,21 @@ static int gemm_prepare(int layout, const GemmArgs& g, GemmArgs& a, bool& twolvl
   ASTK_CHECK(g.ksplit >= 1 && (g.ksplit == 1 || g.mode == GEMM_ATOMIC), "gemm: split-K needs atomic mode");
   a = g;
   const bool a_kr = layout == GEMM_TN, b_kr = layout != GEMM_NT;
+  // the k loop addresses an operand as (uniform pointer) + (32-bit byte offset): each batch slice has to span less than 4 GiB
+  auto span = [&](const MatView& v, bool kr, int rows) -> long {   // floats from v.p to the end of the last element touched
+    const long k4 = (g.K + 3) & ~3L, r4 = (rows + 3) & ~3L;      // padded to the 16-byte granule (leading dimensions are multiples of 4)
+    if (kr) return v.tn > 0 ? 0 : (long)(g.K - 1) * v.ld + r4;   // two-level K-major rows use 64-bit offsets
+    if (v.rowidx) return (long)rows * v.ld;                      // indexed rows: a permutation of [0, rows)
+    if (v.tn > 0) return (long)((rows - 1) / v.tn) * v.sg + (long)(v.tn - 1) * v.st + k4;
+    return (long)(rows - 1) * v.ld + k4;
+  };
+  const long spa = span(g.A, a_kr, g.M), spb = span(g.B, b_kr, g.N);
+  ASTK_CHECK(spa < (1L << 30) && spb < (1L << 30), "gemm: an operand slice spans more than 4 GiB (M=%d N=%d K=%d lda=%ld ldb=%ld)",
+             g.M, g.N, g.K, g.A.ld, g.B.ld);
+  ASTK_CHECK(!(a_kr && g.A.tn > 0 && (long)BK * g.A.st + g.M >= (1L << 29)) && !(b_kr && g.B.tn > 0 && (long)BK * g.B.st + g.N >= (1L << 29)),
+             "gemm: two-level row stride too large");
+  a.spanA = (unsigned)(spa * 4);
+  a.spanB = (unsigned)(spb * 4);
   ASTK_CHECK(!(a_kr && g.A.rowidx) && !(b_kr && g.B.rowidx), "gemm: indexed rows are only supported on K-contiguous operands");
   twolvl = (a_kr && g.A.tn > 0) || (b_kr && g.B.tn > 0);
   a.tiles_mn = cdiv(g.M, BM) * cdiv(g.N, BN);

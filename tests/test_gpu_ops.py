@@ -99,6 +99,28 @@ def test_gemm_layouts(lib, layout, M, N, K):
     close(c[:, :N], ref, msg="atomic split-K")
 
 
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(70, 45, 37), (130, 129, 16), (5, 3, 1), (129, 70, 531)])
+def test_gemm_never_reads_padding_into_the_result(lib, layout, M, N, K):
+    """Row padding (ld > extent) and whatever follows a ragged K tail hold NaNs: none may reach C, nor the columns beyond N."""
+    rng = np.random.default_rng(M + N + K + layout)
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((N, K))
+    ref = A @ B.T
+    pad = lambda n: (n + 3) // 4 * 4 + 4
+    def padded(X):
+        P = np.full((X.shape[0], pad(X.shape[1])), np.nan)
+        P[:, :X.shape[1]] = X
+        return P
+    Ad = padded(A if layout != 2 else A.T)
+    Bd = padded(B if layout == 0 else B.T)
+    a, b = dev(Ad), dev(Bd)
+    c = torch.full((M, pad(N)), 7.0, device="cuda")
+    ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(a), Ad.shape[1], vp(b), Bd.shape[1], vp(c), c.shape[1], None, 0, 1, 1, 0, 0, 0, stream()))
+    close(c[:, :N], ref, msg="store")
+    assert float(c[:, N:].min()) == 7.0 and float(c[:, N:].max()) == 7.0, "wrote outside N"
+
+
 def test_gemm_batched_tn(lib):
     rng = np.random.default_rng(3)
     Bt, M, N, K = 5, 22, 40, 9
