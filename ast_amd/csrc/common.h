@@ -256,22 +256,25 @@ __device__ __forceinline__ void colreduce_block(int rows, int cols, Acc acc, Emi
   const int NR = 256 / CL;
   const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
   const int c4 = blockIdx.x * CL + cl;
-  const int rpb = (rows + gridDim.y - 1) / gridDim.y;
-  const int r0 = blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
   const bool act = rl < NR && c4 < q;
   const int c = c4 * 4, nvalid = cols - c;
   float4 a[NS];
 #pragma unroll
   for (int i = 0; i < NS; ++i) a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (act) {
-    int r = r0 + rl;
-    for (; r + 3 * NR < r1; r += 4 * NR) {
-      acc(r, c, a);
-      acc(r + NR, c, a);
-      acc(r + 2 * NR, c, a);
-      acc(r + 3 * NR, c, a);
+    // row chunks of 4*NR rows are dealt round-robin to the row slabs (blockIdx.y): at any moment the grid reads one contiguous
+    // window of the matrix instead of gridDim.y streams a fixed distance apart
+    const int rpc = 4 * NR;
+    for (int r = blockIdx.y * rpc + rl; r < rows; r += gridDim.y * rpc) {
+      if (r + 3 * NR < rows) {
+        acc(r, c, a);
+        acc(r + NR, c, a);
+        acc(r + 2 * NR, c, a);
+        acc(r + 3 * NR, c, a);
+      } else {
+        for (int rr = r; rr < rows && rr < r + rpc; rr += NR) acc(rr, c, a);
+      }
     }
-    for (; r < r1; r += NR) acc(r, c, a);
   }
   if (NR > 1) {
 #pragma unroll

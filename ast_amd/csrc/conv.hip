@@ -288,17 +288,23 @@ __global__ __launch_bounds__(256) void k_bn_bwd_stats(const float* __restrict__ 
 __global__ void k_bn_bwd_apply(const float* __restrict__ Y, const float* __restrict__ G, const float* __restrict__ bn,
                                const double* __restrict__ stat, float* __restrict__ dY, int rows, int C, int Tn, int padF, int padB,
                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const long n = (long)rows * C;
+  const int C4 = C / 4;   // C % 4 == 0 (checked by the launcher)
+  const long n4 = (long)rows * C4;
   const float invm = 1.f / (float)rows;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const int m = (int)(i / C), c = (int)(i % C);
-    const float mean = bn[c], inv = bn[C + c], sc = bn[2 * C + c], sh = bn[3 * C + c];
-    const float y = Y[i];
-    const float g = (y * sc + sh > 0.f) ? G[i] : 0.f;
-    const float xh = (y - mean) * inv;
-    const float v = sc * (g - (xh * (float)stat[C + c] + (float)stat[c]) * invm);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / C4), c = (int)(i % C4) * 4;
+    const float4 mean = *reinterpret_cast<const float4*>(bn + c), inv = *reinterpret_cast<const float4*>(bn + C + c);
+    const float4 sc = *reinterpret_cast<const float4*>(bn + 2 * C + c), sh = *reinterpret_cast<const float4*>(bn + 3 * C + c);
+    const float4 y = *reinterpret_cast<const float4*>(Y + i * 4), gr = *reinterpret_cast<const float4*>(G + i * 4);
+    const float dg0 = (float)stat[C + c], dg1 = (float)stat[C + c + 1], dg2 = (float)stat[C + c + 2], dg3 = (float)stat[C + c + 3];
+    const float db0 = (float)stat[c], db1 = (float)stat[c + 1], db2 = (float)stat[c + 2], db3 = (float)stat[c + 3];
+    float4 v;
+    v.x = sc.x * (((y.x * sc.x + sh.x > 0.f) ? gr.x : 0.f) - ((y.x - mean.x) * inv.x * dg0 + db0) * invm);
+    v.y = sc.y * (((y.y * sc.y + sh.y > 0.f) ? gr.y : 0.f) - ((y.y - mean.y) * inv.y * dg1 + db1) * invm);
+    v.z = sc.z * (((y.z * sc.z + sh.z > 0.f) ? gr.z : 0.f) - ((y.z - mean.z) * inv.z * dg2 + db2) * invm);
+    v.w = sc.w * (((y.w * sc.w + sh.w > 0.f) ? gr.w : 0.f) - ((y.w - mean.w) * inv.w * dg3 + db3) * invm);
     const long pr = (long)(m / Tn) * (Tn + padF + padB) + padF + (m % Tn);
-    dY[pr * C + c] = v;
+    *reinterpret_cast<float4*>(dY + pr * C + c) = v;
   }
   if (blockIdx.x == 0)
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -431,7 +437,7 @@ int astk_conv_bn_relu_bwd(const astk_cnn_desc* d, const astk_cnn_layer_params* L
                          P.dB[i], C);
       ASTK_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(gridn((size_t)rows * C)), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], P.stat, P.DY[i], rows, C,
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(gridn((size_t)rows * C / 4)), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], P.stat, P.DY[i], rows, C,
                        P.Tn[i], P.dF[i], P.dB[i], Gr[i].dgamma, Gr[i].dbeta);
     ASTK_LAUNCH_CHECK();
     if (i == 0) {

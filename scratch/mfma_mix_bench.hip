@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-template <int LDSR, int LDSW, int VALU, int GLD>
+template <int LDSR, int LDSW, int VALU, int GLD, int BAR = 0, int SALU = 0>
 __global__ __launch_bounds__(256, 3) void k(float* out, const float* in, int iters) {
   __shared__ __attribute__((aligned(16))) float S[2][128 * 20];
   f32x16 acc[4];
@@ -16,6 +16,7 @@ __global__ __launch_bounds__(256, 3) void k(float* out, const float* in, int ite
   float4 g[4];
   for (int i = 0; i < 4; ++i) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   int vsum = tid;
+  int ssum = iters;
   const float* ip = in + (size_t)blockIdx.x * 4096 + tid * 4;
   for (int it = 0; it < iters; ++it) {
     const int cur = it & 1;
@@ -54,19 +55,23 @@ __global__ __launch_bounds__(256, 3) void k(float* out, const float* in, int ite
         for (int v = 0; v < VALU; ++v) vsum = (vsum * 3 + j + v) ^ (vsum >> 3);
       }
     }
-    if (LDSW) __syncthreads();
+    if (LDSW || BAR) __syncthreads();
+    if (SALU) {
+#pragma unroll
+      for (int v = 0; v < SALU; ++v) asm volatile("s_mul_i32 %0, %0, 3" : "+s"(ssum) : : "scc");   // s_add would clobber the loop condition in SCC
+    }
   }
-  float s = (float)vsum + g[0].x + g[1].y + g[2].z + g[3].w;
+  float s = (float)vsum + (float)ssum + g[0].x + g[1].y + g[2].z + g[3].w;
   for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
   out[blockIdx.x * 256 + tid] = s;
 }
-template <int A, int B, int C, int D>
+template <int A, int B, int C, int D, int E = 0, int F = 0>
 void run(const char* name, float* out, float* in) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int grid = 768, iters = 4000;
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<A, B, C, D>), dim3(grid), dim3(256), 0, 0, out, in, iters);
+    hipLaunchKernelGGL((k<A, B, C, D, E, F>), dim3(grid), dim3(256), 0, 0, out, in, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (rep) printf("%-46s %.1f TFLOP/s\n", name, (double)grid * 4 * iters * 32 * 4096.0 / ms / 1e9);
@@ -83,5 +88,10 @@ int main() {
   run<0, 0, 0, 1>("+ 4 global_load_dwordx4 per 32 MFMA", out, in);
   run<2, 1, 0, 1>("+ ds_read + global + ds_write + barrier", out, in);
   run<2, 1, 2, 1>("+ everything", out, in);
+  run<0, 0, 0, 0, 1>("+ barrier per 32 MFMA only", out, in);
+  run<0, 1, 0, 0>("+ ds_write + barrier", out, in);
+  run<0, 1, 0, 1>("+ global + ds_write + barrier", out, in);
+  run<0, 0, 0, 0, 0, 32>("+ 32 SALU per 32 MFMA", out, in);
+  run<2, 1, 0, 1, 0, 32>("+ ds_read + global + ds_write + barrier + SALU", out, in);
   return 0;
 }
