@@ -70,6 +70,10 @@ SIGNATURES = {
     "astk_conv_bn_relu_workspace_bytes": (_SZ, [C.POINTER(CnnDesc)]),
     "astk_conv_bn_relu_fwd": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(CnnLayerParams), _VP, _VP, _VP, _VP, _SZ, _I, _VP]),
     "astk_conv_bn_relu_bwd": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(CnnLayerParams), C.POINTER(CnnLayerGrads), _VP, _VP, _SZ, _VP]),
+    # the exchange callback is passed as an opaque pointer (a ctypes CFUNCTYPE instance converts itself)
+    "astk_conv_bn_relu_fwd_sync": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(CnnLayerParams), _VP, _VP, _VP, _VP, _SZ, _I, _VP, _VP, _I, _VP]),
+    "astk_conv_bn_relu_bwd_sync": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(CnnLayerParams), C.POINTER(CnnLayerGrads), _VP, _VP, _SZ, _VP, _VP,
+                                             _I, _VP]),
     "astk_lstm_stack_workspace_bytes": (_SZ, [C.POINTER(LstmStackDesc)]),
     "astk_lstm_stack_fwd": (C.c_int, [C.POINTER(LstmStackDesc), C.POINTER(LstmParams), _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "astk_lstm_stack_bwd": (C.c_int, [C.POINTER(LstmStackDesc), C.POINTER(LstmParams), C.POINTER(LstmGrads), _VP, _VP, _VP, _VP,

@@ -287,10 +287,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_stats(const float* __restrict__ 
 // dY[prow(m)][c] = scale*(g - (xhat*dgamma + dbeta)/rows) ; also accumulates dgamma/dbeta (block 0)
 __global__ void k_bn_bwd_apply(const float* __restrict__ Y, const float* __restrict__ G, const float* __restrict__ bn,
                                const double* __restrict__ stat, float* __restrict__ dY, int rows, int C, int Tn, int padF, int padB,
-                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                               float* __restrict__ dgamma, float* __restrict__ dbeta, float invm) {
   const int C4 = C / 4;   // C % 4 == 0 (checked by the launcher)
   const long n4 = (long)rows * C4;
-  const float invm = 1.f / (float)rows;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const int m = (int)(i / C4), c = (int)(i % C4) * 4;
     const float4 mean = *reinterpret_cast<const float4*>(bn + c), inv = *reinterpret_cast<const float4*>(bn + C + c);
@@ -306,11 +305,18 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ Y, const float* __restr
     const long pr = (long)(m / Tn) * (Tn + padF + padB) + padF + (m % Tn);
     *reinterpret_cast<float4*>(dY + pr * C + c) = v;
   }
-  if (blockIdx.x == 0)
+  if (blockIdx.x == 0 && dgamma)
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       dgamma[c] += (float)stat[C + c];
       dbeta[c] += (float)stat[c];
     }
+}
+// dgamma / dbeta from the LOCAL sums (data-parallel BatchNorm: taken before the statistics are exchanged)
+__global__ void k_bn_param_grads(const double* __restrict__ stat, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dgamma[c] += (float)stat[C + c];
+  dbeta[c] += (float)stat[c];
 }
 
 inline unsigned gridn(size_t n) {
@@ -360,7 +366,15 @@ size_t astk_conv_bn_relu_workspace_bytes(const astk_cnn_desc* d) {
 
 int astk_conv_bn_relu_fwd(const astk_cnn_desc* d, const astk_cnn_layer_params* L, const float* X, const float* noise, float* out,
                           void* ws, size_t ws_bytes, int train, void* stream) {
+  return astk_conv_bn_relu_fwd_sync(d, L, X, noise, out, ws, ws_bytes, train, nullptr, nullptr, 1, stream);
+}
+
+int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_params* L, const float* X, const float* noise, float* out,
+                               void* ws, size_t ws_bytes, int train, astk_stat_exchange_fn exchange, void* user, int world,
+                               void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  ASTK_CHECK(world >= 1, "conv_bn_relu_fwd: world %d", world);
+  if (world == 1) exchange = nullptr;
   CnnPlan P;
   ASTK_TRY(make_plan(d, ws, P));
   ASTK_CHECK(ws && ws_bytes >= P.bytes, "conv_bn_relu_fwd: workspace too small (%zu < %zu)", ws_bytes, P.bytes);
@@ -388,8 +402,9 @@ int astk_conv_bn_relu_fwd(const astk_cnn_desc* d, const astk_cnn_layer_params* L
       ASTK_TRY(fill_zero(P.stat, 2 * (size_t)C * sizeof(double), s));
       hipLaunchKernelGGL(k_colstats, colreduce_grid(rows, C), dim3(256), 0, s, P.Y[i], rows, C, P.stat);
       ASTK_LAUNCH_CHECK();
+      if (exchange) ASTK_CHECK(exchange(user, P.stat, 2 * C, stream) == 0, "conv_bn_relu_fwd: statistics exchange failed (layer %d)", i);
     }
-    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, s, P.stat, C, (double)rows, L[i].gamma, L[i].beta,
+    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, s, P.stat, C, (double)rows * (exchange ? world : 1), L[i].gamma, L[i].beta,
                        L[i].avg_mean, L[i].avg_var, P.bn[i], d->bn_eps, d->bn_decay, train);
     ASTK_LAUNCH_CHECK();
     if (i < P.n - 1) {
@@ -413,7 +428,14 @@ int astk_conv_bn_relu_fwd(const astk_cnn_desc* d, const astk_cnn_layer_params* L
 
 int astk_conv_bn_relu_bwd(const astk_cnn_desc* d, const astk_cnn_layer_params* L, const astk_cnn_layer_grads* Gr, float* d_out,
                           void* ws, size_t ws_bytes, void* stream) {
+  return astk_conv_bn_relu_bwd_sync(d, L, Gr, d_out, ws, ws_bytes, nullptr, nullptr, 1, stream);
+}
+
+int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_params* L, const astk_cnn_layer_grads* Gr, float* d_out,
+                               void* ws, size_t ws_bytes, astk_stat_exchange_fn exchange, void* user, int world, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  ASTK_CHECK(world >= 1, "conv_bn_relu_bwd: world %d", world);
+  if (world == 1) exchange = nullptr;
   CnnPlan P;
   ASTK_TRY(make_plan(d, ws, P));
   ASTK_CHECK(ws && ws_bytes >= P.bytes, "conv_bn_relu_bwd: workspace too small");
@@ -431,6 +453,11 @@ int astk_conv_bn_relu_bwd(const astk_cnn_desc* d, const astk_cnn_layer_params* L
     ASTK_TRY(fill_zero(P.stat, 2 * (size_t)C * sizeof(double), s));
     hipLaunchKernelGGL(k_bn_bwd_stats, colreduce_grid(rows, C), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], rows, C, P.stat);
     ASTK_LAUNCH_CHECK();
+    if (exchange) {
+      hipLaunchKernelGGL(k_bn_param_grads, dim3(cdiv(C, 256)), dim3(256), 0, s, P.stat, C, Gr[i].dgamma, Gr[i].dbeta);
+      ASTK_LAUNCH_CHECK();
+      ASTK_CHECK(exchange(user, P.stat, 2 * C, stream) == 0, "conv_bn_relu_bwd: statistics exchange failed (layer %d)", i);
+    }
     const int Tp = P.Tn[i] + P.dF[i] + P.dB[i];
     if (P.dF[i] + P.dB[i] > 0) {
       hipLaunchKernelGGL(k_zero_pads, dim3(gridn((size_t)B * F * (P.dF[i] + P.dB[i]) * C / 4)), dim3(256), 0, s, P.DY[i], B * F, P.Tn[i], P.dF[i],
@@ -438,7 +465,8 @@ int astk_conv_bn_relu_bwd(const astk_cnn_desc* d, const astk_cnn_layer_params* L
       ASTK_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(gridn((size_t)rows * C / 4)), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], P.stat, P.DY[i], rows, C,
-                       P.Tn[i], P.dF[i], P.dB[i], Gr[i].dgamma, Gr[i].dbeta);
+                       P.Tn[i], P.dF[i], P.dB[i], exchange ? nullptr : Gr[i].dgamma, exchange ? nullptr : Gr[i].dbeta,
+                       1.f / ((float)rows * (exchange ? world : 1)));
     ASTK_LAUNCH_CHECK();
     if (i == 0) {
       // ---- wgrad layer 0: dW0p[C0][K0p] = DY0^T P0

@@ -1,7 +1,8 @@
 """Data parallelism: one process per GPU (torchrun), replicas of the bucketed minibatch, ONE all-reduce of the flat
 float32 gradient arena per step over RCCL/xGMI (backend "nccl" on ROCm), scaled by 1/world so that the per-replica
 1/B_local cross-entropy means compose to the global 1/B mean.  All ranks seed Python's `random`
-identically (nn.py:54), so the teacher-forcing flags agree; BatchNorm uses per-replica statistics.
+identically (nn.py:54), so the teacher-forcing flags agree.  BatchNorm uses per-replica statistics by default (what N independent
+Chainer processes would do); `StatExchange` gives the global-batch statistics of one process on the concatenated batch.
 CPU tests run the same code over gloo."""
 import os
 
@@ -112,3 +113,45 @@ def shard_rows(n_rows, rank_, world):
     """Contiguous row shard [lo, hi) of a bucketed batch for `rank_` (equal T => equal work)."""
     per = n_rows // world
     return rank_ * per, (rank_ + 1) * per
+
+
+class StatExchange:
+    """The exchange step of data-parallel BatchNorm with global-batch statistics (include/astk.h, astk_conv_bn_relu_*_sync):
+    the C library calls `self.callback(user, stat, n, stream)` between producing a layer's local per-channel sums (n float64
+    values inside the CNN workspace tensor) and consuming them; the callback sums them over the ranks in place.  The
+    all-reduce is enqueued behind the producing kernels (torch orders its communication stream after the current stream, which
+    is the stream the library launches on) and the consumers are enqueued after it returns.  `reduce` can be replaced for tests."""
+
+    def __init__(self, world=None, reduce=None):
+        import ctypes as C
+        self.world = world_size() if world is None else int(world)
+        self.workspace = None     # the uint8 tensor the library was given as `ws` for the current call
+        self.calls = 0
+        self.reduce = reduce if reduce is not None else (lambda view: td.all_reduce(view, op=td.ReduceOp.SUM))
+        self.error = None
+        self._ctype = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+        self.callback = self._ctype(self._call)
+
+    def view(self, ptr, n):
+        """float64 view of n statistics at device address `ptr` inside the bound workspace tensor"""
+        ws = self.workspace
+        if ws is None:
+            raise RuntimeError("StatExchange: no workspace bound")
+        off = int(ptr) - ws.data_ptr()
+        if off < 0 or off % 8 or off + 8 * n > ws.numel() * ws.element_size():
+            raise RuntimeError(f"statistics buffer {ptr:#x}+{8 * n} is outside the bound workspace")
+        return ws.view(torch.uint8)[off:off + 8 * n].view(torch.float64)
+
+    def _call(self, user, stat, n, stream):
+        try:                                   # exceptions cannot cross the C frame: report failure through the return code
+            self.reduce(self.view(stat, n))
+            self.calls += 1
+            return 0
+        except Exception as e:                 # noqa: BLE001
+            self.error = e
+            return -1
+
+    def bind(self, workspace):
+        self.workspace = workspace
+        self.error = None
+        return self

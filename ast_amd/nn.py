@@ -104,6 +104,8 @@ class NN:
                 self.optimizer.grad_sync = self.model.grad_buckets.finish
             else:      # parameters materialise lazily on the first batch: fall back to one all-reduce of the whole arena
                 self.optimizer.grad_sync = adist.allreduce_grads
+            if self.cfg.train.get("sync_bn", False):    # extension key: BatchNorm statistics over the global batch
+                self.model.stat_exchange = adist.StatExchange()
 
     def get_model(self):
         self.model_fname = os.path.join(self.model_dir, "seq2seq.model")

@@ -112,6 +112,7 @@ class SpeechEncoderDecoder:
         self._cur = None
         self._dec_c = self._dec_h = None
         self.grad_buckets = None        # ast_amd.dist.GradBuckets under data parallelism: ranges are all-reduced as they become final
+        self.stat_exchange = None       # ast_amd.dist.StatExchange: BatchNorm statistics over the global batch (train mode only)
         self.mask_pad_id = None
 
     # ------------------------------------------------------------------ parameters
@@ -310,8 +311,17 @@ class SpeechEncoderDecoder:
         st["train_mode"] = bool(config.train)
         s = self._stream()
         wc = self._workspace("cnn", st["ws_cnn"])
-        check(lib.astk_conv_bn_relu_fwd(C.byref(st["cd"]), st["cp"], _vp(X), _vp(noise), _vp(st["xlstm"]), _vp(wc), wc.numel(),
-                                        1 if config.train else 0, s))
+        sx = self.stat_exchange if config.train else None
+        if sx is None:
+            check(lib.astk_conv_bn_relu_fwd(C.byref(st["cd"]), st["cp"], _vp(X), _vp(noise), _vp(st["xlstm"]), _vp(wc), wc.numel(),
+                                            1 if config.train else 0, s))
+        else:
+            rc = lib.astk_conv_bn_relu_fwd_sync(C.byref(st["cd"]), st["cp"], _vp(X), _vp(noise), _vp(st["xlstm"]), _vp(wc), wc.numel(), 1,
+                                                C.cast(sx.bind(wc).callback, C.c_void_p), None, sx.world, s)
+            if sx.error is not None:
+                raise sx.error
+            check(rc)
+        st["bn_world"] = 1 if sx is None else sx.world
         wl = self._workspace("lstm", st["ws_lstm"])
         check(lib.astk_lstm_stack_fwd(C.byref(st["ld"]), st["lp"], _vp(st["xlstm"]), _vp(st["enc_masks"]), _vp(st["enc_states"]),
                                       _vp(st["cT"]), _vp(st["hT"]), _vp(wl), wl.numel(), s))
@@ -391,7 +401,15 @@ class SpeechEncoderDecoder:
         if self.grad_buckets is not None:
             self.grad_buckets.launch("enc")
         wc = self._workspace("cnn", st["ws_cnn"])
-        check(lib.astk_conv_bn_relu_bwd(C.byref(st["cd"]), st["cp"], st["cg"], _vp(st["d_xlstm"]), _vp(wc), wc.numel(), s))
+        sx = self.stat_exchange if st.get("bn_world", 1) > 1 else None   # backward of the statistics the forward pass used
+        if sx is None:
+            check(lib.astk_conv_bn_relu_bwd(C.byref(st["cd"]), st["cp"], st["cg"], _vp(st["d_xlstm"]), _vp(wc), wc.numel(), s))
+        else:
+            rc = lib.astk_conv_bn_relu_bwd_sync(C.byref(st["cd"]), st["cp"], st["cg"], _vp(st["d_xlstm"]), _vp(wc), wc.numel(),
+                                                C.cast(sx.bind(wc).callback, C.c_void_p), None, sx.world, s)
+            if sx.error is not None:
+                raise sx.error
+            check(rc)
         if self.grad_buckets is not None:
             self.grad_buckets.launch("cnn")
 

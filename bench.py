@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--tgt-len", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true", help="N>1: BatchNorm statistics over the global batch (4 extra 5-10 KB all-reduces)")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps with per-kernel HIP-event timing")
     args = ap.parse_args()
 
@@ -117,6 +118,8 @@ def main():
         # overlapped exchange: decoder / encoder / CNN gradient ranges are all-reduced as soon as their backward is enqueued
         model.grad_buckets = adist.make_grad_buckets(model)
         opt.grad_sync = model.grad_buckets.finish
+        if args.sync_bn:
+            model.stat_exchange = adist.StatExchange()
     random.seed("seed-ast-20h")                                           # same teacher-forcing stream on every rank
     Xh, yh = synth_batch(B, T, D, L, V, 20 + rank)                        # each rank owns its shard of the global batch
     X, y = torch.from_numpy(Xh).cuda(), torch.from_numpy(yh).cuda()
@@ -207,7 +210,7 @@ def main():
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"BASELINE configs[1]: synthetic fbank T={T} D={D} batch {B}/GPU, 2xConv+BN -> 3-layer 2x256 LSTM enc -> "
                                   f"attention -> 1-layer LSTM-512 dec, V={V}, L={L}, dropout .3, noise .25, teach .8, Adam(amsgrad)+L2+clip",
-                      "global_batch": world * B, "frames": T, "feat_dim": D, "tgt_len": L, "parallelism": f"dp{world}",
+                      "global_batch": world * B, "frames": T, "feat_dim": D, "tgt_len": L, "parallelism": f"dp{world}", "batchnorm": "global-batch statistics" if (world > 1 and args.sync_bn) else "per-replica statistics",
                       "graphs": bool(not args.no_graph and getattr(model, "graphs_supported", False))},
            "loss": round(loss_val, 4), "roofline": roof}
     out.update({"kernels": extra} if extra else {})

@@ -80,6 +80,20 @@ int astk_conv_bn_relu_fwd(const astk_cnn_desc* d, const astk_cnn_layer_params* l
 /* d_out (T'',B,C_last*F') is overwritten.  Gradients are ACCUMULATED into grads (caller zeroes = cleargrads). */
 int astk_conv_bn_relu_bwd(const astk_cnn_desc* d, const astk_cnn_layer_params* layers,
                           const astk_cnn_layer_grads* grads, float* d_out, void* ws, size_t ws_bytes, void* stream);
+/* Data-parallel BatchNorm with GLOBAL batch statistics (SURVEY.md 8e "SyncBN"): the same two calls with an exchange step.
+ * After a layer's local per-channel sums are on the device -- forward (sum y, sum y^2), backward (sum g, sum g*xhat), `n` = 2*C
+ * doubles at `stat`, inside the caller's workspace -- the library calls `exchange(user, stat, n, stream)` on the host; the callee
+ * enqueues, on `stream`, an in-place SUM of that buffer over the `world` replicas (RCCL all-reduce) and returns 0.  Statistics,
+ * running averages and the input gradient then use world * rows samples, which is what one process would compute on the
+ * concatenated batch; dgamma / dbeta accumulate the LOCAL sums, like every other parameter gradient (the caller's gradient
+ * all-reduce adds the replicas).  exchange == NULL (or world == 1) is astk_conv_bn_relu_fwd / _bwd. */
+typedef int (*astk_stat_exchange_fn)(void* user, double* stat, int n, void* stream);
+int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_params* layers, const float* X, const float* noise,
+                               float* out, void* ws, size_t ws_bytes, int train, astk_stat_exchange_fn exchange, void* user,
+                               int world, void* stream);
+int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_params* layers, const astk_cnn_layer_grads* grads,
+                               float* d_out, void* ws, size_t ws_bytes, astk_stat_exchange_fn exchange, void* user, int world,
+                               void* stream);
 
 /* ---------------------------------------------------------------- encoder LSTM stacks  (seq2seq.py:182-242)
  * n_dirs independent uni-directional stacks of n_layers L.LSTM links (Chainer-sem A1), dropout on each

@@ -1,7 +1,8 @@
 """world_size-2 gloo tests of the data-parallel plumbing (ast_amd.dist): the flat-gradient mean all-reduce, the
 identical teacher-forcing stream on every rank, and that averaging per-replica gradients of the reference's loss
 (mean over the LOCAL batch, quirk Q6) reproduces the single-process gradient of the global batch for everything
-that does not go through BatchNorm statistics."""
+that does not go through BatchNorm statistics, and the exchange step of the global-batch BatchNorm option
+(its numerics are checked on the GPU: tests/test_gpu_model.py::test_sync_batchnorm_...)."""
 import os
 import random
 import sys
@@ -69,7 +70,18 @@ def _worker(rank, world, port, q):
     local = grads(slice(lo, hi)).float()
     adist.allreduce_flat(local)
     ok3 = bool(torch.allclose(local.double(), grads(slice(0, B)), rtol=1e-5, atol=1e-7))
-    q.put((rank, ok1, ok2, ok3))
+    # 4) BatchNorm statistics exchange (StatExchange): called the way the C library calls it -- through the ctypes callback, with
+    #    the address of n float64 sums inside the workspace tensor -- it must leave the sum over ranks in place, and refuse
+    #    addresses outside the bound workspace
+    ws = torch.zeros(4096, dtype=torch.uint8)
+    stats = ws[1024:1024 + 8 * 6].view(torch.float64)
+    stats.copy_(torch.arange(6, dtype=torch.float64) + 10 * rank)
+    sx = adist.StatExchange().bind(ws)
+    rc = sx.callback(None, ws.data_ptr() + 1024, 6, None)
+    ok4 = rc == 0 and sx.world == world and bool(torch.equal(stats, world * torch.arange(6, dtype=torch.float64) + 10 * sum(range(world))))
+    ok4 = ok4 and bool((ws[:1024] == 0).all()) and bool((ws[1024 + 48:] == 0).all())
+    ok4 = ok4 and sx.callback(None, ws.data_ptr() + 4090, 6, None) == -1 and isinstance(sx.error, RuntimeError)
+    q.put((rank, ok1, ok2, ok3, ok4))
     td.destroy_process_group()
 
 
@@ -84,7 +96,8 @@ def test_two_rank_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, ok1, ok2, ok3 in res:
+    for rank, ok1, ok2, ok3, ok4 in res:
         assert ok1, f"rank {rank}: all-reduce mean wrong"
         assert ok2, f"rank {rank}: teacher-forcing streams differ"
         assert ok3, f"rank {rank}: averaged shard gradients != global-batch gradient"
+        assert ok4, f"rank {rank}: BatchNorm statistics exchange wrong"

@@ -248,3 +248,82 @@ def test_full_size_directional_derivative_and_repeatability():
         m.arena.data.copy_(p0)
         fd = (lp - lm) / (2 * eps)
         assert abs(fd - gd) <= 3e-2 * abs(gd) + 1e-3, (trial, fd, gd, eps, lp, lm)
+
+
+def test_sync_batchnorm_two_replicas_match_one_process_on_the_concatenated_batch():
+    """Global-batch BatchNorm under data parallelism (include/astk.h astk_conv_bn_relu_*_sync, ast_amd.dist.StatExchange).
+    Two replicas with the two halves of a batch are emulated in ONE process: the exchange callback is replaced by one that
+    plays back the sum of both replicas' statistics, which are collected exchange point by exchange point (4 per step: two
+    layers forward, two backward) over repeated passes.  Result: the replicas' mean loss, mean gradient, encoder states and
+    BatchNorm running statistics must be those of the oracle run once on the whole batch."""
+    from oracle import ast_ref as R
+    from ast_amd.dist import StatExchange
+    from ast_amd.seq2seq import using_config
+    cfg = tiny_cfg(enc_layers=2, dec_layers=1, H=16, E=8, A=16, c0=8, c1=8, V=23, drop=0.0)
+    B, T, D, L, V, world = 6, 37, 26, 6, 23, 2
+    P, X, y = _make(cfg, B, T, D, L, V)
+    ref = R.RefModel(cfg, {k: v.astype(np.float64) for k, v in P.items()}, V)
+    flags = [1] * (L - 1)
+
+    class _Truth:
+        def random(self): return 0.0
+    lref = ref.forward_loss(X.astype(np.float64), y, 1.0, pyrandom=_Truth())
+    ref.cleargrads()
+    lref.backward()
+    gref = {k: p.grad.copy() for k, p in ref.params()}
+
+    shards = [slice(r * B // world, (r + 1) * B // world) for r in range(world)]
+    models = [_gpu_model(cfg, P, D, V) for _ in range(world)]
+    known = []            # global statistics of exchange points 0..len-1
+
+    def run(m, rows, record):
+        state = {"k": 0}
+
+        def reduce(view):
+            k = state["k"]
+            state["k"] += 1
+            if k < len(known):
+                view.copy_(known[k])
+            elif k == len(known):
+                record.append(view.clone())
+        m.stat_exchange = StatExchange(world=world, reduce=reduce)
+        m.inject = {"use_truth": flags}
+        for name in ("avg_mean", "avg_var"):          # every pass starts from the initial running statistics
+            for i in range(2):
+                m.persist[f"CNN_{i}_bn/{name}"].copy_(torch.from_numpy(P[f"CNN_{i}_bn/{name}"]))
+        with using_config("train", True):
+            loss = m.forward_loss(X=torch.from_numpy(X[rows]), y=torch.from_numpy(y[rows]), teach_ratio=1.0)
+            m.cleargrads()
+            loss.backward()
+        torch.cuda.synchronize()
+        assert state["k"] == 4, state
+        return float(loss.data)
+
+    for _ in range(4):
+        rec = []
+        for m, rows in zip(models, shards):
+            run(m, rows, rec)
+        assert len(rec) == world
+        known.append(sum(rec))
+    losses = [run(m, rows, []) for m, rows in zip(models, shards)]
+    assert _rel(sum(losses) / world, float(lref.data)) < 1e-4, (losses, float(lref.data))
+    enc = np.concatenate([m.enc_states.cpu().numpy() for m in models])
+    np.testing.assert_allclose(enc, ref.enc_states.data, rtol=0, atol=2e-4 * np.abs(ref.enc_states.data).max())
+    grads = [m.arena.to_numpy(grads=True) for m in models]
+    gmax = max(np.abs(g).max() for g in gref.values())
+    for k, g in gref.items():
+        got = sum(gr[k] for gr in grads) / world
+        err = np.abs(got - g).max()
+        tol = 3e-4 * max(np.abs(g).max(), 1e-3 * gmax)
+        assert err <= tol, f"grad {k}: err {err:.3e} tol {tol:.3e}"
+    for i in range(2):
+        for s in ("avg_mean", "avg_var"):
+            for m in models:
+                np.testing.assert_allclose(m.persist[f"CNN_{i}_bn/{s}"].cpu().numpy(), ref.p[f"CNN_{i}_bn/{s}"], rtol=2e-3, atol=1e-5)
+    # and without the exchange the replicas differ from the one-process result (the test is sensitive to the statistics)
+    models[0].stat_exchange = None
+    models[0].inject = {"use_truth": flags}
+    with using_config("train", True):
+        models[0].forward_loss(X=torch.from_numpy(X[shards[0]]), y=torch.from_numpy(y[shards[0]]), teach_ratio=1.0)
+    torch.cuda.synchronize()
+    assert np.abs(models[0].enc_states.cpu().numpy() - ref.enc_states.data[shards[0]]).max() > 1e-3
