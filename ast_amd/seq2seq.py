@@ -343,6 +343,21 @@ class SpeechEncoderDecoder:
             self._dec_c, self._dec_h = st["c0"].clone(), st["h0"].clone()
 
     # ------------------------------------------------------------------ seq2seq.py:399-473
+    def _upload_flags(self, dst, flags):
+        """Host -> device copy of the teacher-forcing flags WITHOUT a host sync: a copy from pageable memory would make the host wait
+        for the encoder of this step, and the GPU then idles while the host catches up at the start of the next one.  The flags
+        go through a small ring of pinned buffers; a slot is reused only after the copy that read it has executed."""
+        ring = self._ws.get("flag_ring")
+        if ring is None or ring["bufs"][0][0].numel() < len(flags):
+            ring = {"i": 0, "bufs": [(torch.empty(max(64, len(flags)), dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(8)]}
+            self._ws["flag_ring"] = ring
+        buf, ev = ring["bufs"][ring["i"]]
+        ring["i"] = (ring["i"] + 1) % len(ring["bufs"])
+        ev.synchronize()                       # returns at once unless the host is 8 steps ahead
+        buf[:len(flags)] = torch.tensor(flags, dtype=torch.int32)
+        dst.copy_(buf[:len(flags)], non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.device))
+
     def forward_loss(self, X, y, teach_ratio, random_out=0, add_noise=0):
         if random_out:
             raise NotImplementedError("random_out > 0 (quirk Q8) is not part of the shipped configs")
@@ -366,7 +381,7 @@ class SpeechEncoderDecoder:
         else:
             flags = [int(random.random() < teach_ratio) if 0 < i < L - 2 else 1 for i in range(S)]
         self.use_truth = flags
-        st["flags"].copy_(torch.tensor(flags, dtype=torch.int32), non_blocking=False)
+        self._upload_flags(st["flags"], flags)
         st["y"] = y
         dr = self.cfg["dropout"]
         if dr.get("out", 0):
