@@ -158,6 +158,22 @@ int copy2d_f32(float* dst, long ldd, const float* src, long lds, int rows, int c
 int add2d_f32(float* dst, long ldd, const float* src, long lds, int rows, int cols, hipStream_t s);
 int transpose_f32(float* dst, long ldd, const float* src, long lds, int rows, int cols, hipStream_t s);  // dst[c][r] = src[r][c]
 int colsum_add_f32(float* dst, const float* src, long lds, int rows, int cols, hipStream_t s);           // dst[c] += sum_r src[r][c]
+// Several column sums (the bias gradients of one backward phase) in ONE launch: add() collects, flush() launches.
+constexpr int COLSUM_BATCH_MAX = 8;
+struct ColsumJobs {
+  int n;
+  float* dst[COLSUM_BATCH_MAX];
+  const float* src[COLSUM_BATCH_MAX];
+  long lds[COLSUM_BATCH_MAX];
+  int rows[COLSUM_BATCH_MAX], cols[COLSUM_BATCH_MAX];
+  int gx[COLSUM_BATCH_MAX], gy[COLSUM_BATCH_MAX];   // the job's own colreduce_grid()
+};
+struct ColsumBatch {
+  ColsumJobs j;
+  ColsumBatch() { j.n = 0; }
+  int add(float* dst, const float* src, long lds, int rows, int cols, hipStream_t s);
+  int flush(hipStream_t s);
+};
 int axpy_rows(float* dst, const float* src, size_t n, hipStream_t s);                                    // dst += src
 
 // ---- row-panel ("skinny", M <= a few dozen) MFMA products used by every recurrent step (rowgemm.hip)
@@ -248,14 +264,16 @@ int softmax_ce_launch(int B, int V, long ld, float* logits, const int32_t* targe
 //                             guarded load into a branch + vmcnt(0), which would serialise the stream)
 //   emit(col, stat, value)    publishes (normally an atomicAdd)
 constexpr int COLREDUCE_CL = 16;
+// (bx, by, ny): this block's column slab, row slab and the number of row slabs -- blockIdx.x, blockIdx.y, gridDim.y of a launch
+// made with colreduce_grid(), or a job's own grid inside a batched launch (k_colsum_batch)
 template <int NS, class Acc, class Emit>
-__device__ __forceinline__ void colreduce_block(int rows, int cols, Acc acc, Emit emit) {
+__device__ __forceinline__ void colreduce_block(int rows, int cols, Acc acc, Emit emit, int bx, int by, int ny) {
   __shared__ float4 red[NS][256];
   const int q = (cols + 3) >> 2;
   const int CL = q < COLREDUCE_CL ? q : COLREDUCE_CL;
   const int NR = 256 / CL;
   const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
-  const int c4 = blockIdx.x * CL + cl;
+  const int c4 = bx * CL + cl;
   const bool act = rl < NR && c4 < q;
   const int c = c4 * 4, nvalid = cols - c;
   float4 a[NS];
@@ -265,7 +283,7 @@ __device__ __forceinline__ void colreduce_block(int rows, int cols, Acc acc, Emi
     // row chunks of 4*NR rows are dealt round-robin to the row slabs (blockIdx.y): at any moment the grid reads one contiguous
     // window of the matrix instead of gridDim.y streams a fixed distance apart
     const int rpc = 4 * NR;
-    for (int r = blockIdx.y * rpc + rl; r < rows; r += gridDim.y * rpc) {
+    for (int r = by * rpc + rl; r < rows; r += ny * rpc) {
       if (r + 3 * NR < rows) {
         acc(r, c, a);
         acc(r + NR, c, a);
@@ -299,6 +317,10 @@ __device__ __forceinline__ void colreduce_block(int rows, int cols, Acc acc, Emi
       if (nvalid > 3) emit(c + 3, i, a[i].w);
     }
   }
+}
+template <int NS, class Acc, class Emit>
+__device__ __forceinline__ void colreduce_block(int rows, int cols, Acc acc, Emit emit) {
+  colreduce_block<NS>(rows, cols, acc, emit, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
 // grid for colreduce_block: enough row slabs for ~2 blocks per CU, at least 16 rows per lane
 static inline dim3 colreduce_grid(int rows, int cols) {

@@ -509,12 +509,13 @@ int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
   // ---- weight gradients: one batched TN GEMM each over the S*B saved rows
   const int SB = S * B;
   WgradBatch wb;
+  ColsumBatch cb;   // the bias gradients: one launch
   ASTK_TRY(wb.add(g->dWo, A, V, A, P.LOGITS, Vp, P.HT + (size_t)B * A, A, SB, s));
-  ASTK_TRY(colsum_add_f32(g->dbo, P.LOGITS, Vp, SB, V, s));
+  ASTK_TRY(cb.add(g->dbo, P.LOGITS, Vp, SB, V, s));
   ASTK_TRY(wb.add(g->dWc, 2 * H, A, 2 * H, P.DPRE, A, P.CVH, 2 * H, SB, s));
-  ASTK_TRY(colsum_add_f32(g->dbc, P.DPRE, A, SB, A, s));
+  ASTK_TRY(cb.add(g->dbc, P.DPRE, A, SB, A, s));
   ASTK_TRY(wb.add(g->dWa, H, H, H, P.DQ, H, P.CVH + H, 2 * H, SB, s));
-  ASTK_TRY(colsum_add_f32(g->dba, P.DQ, H, SB, H, s));
+  ASTK_TRY(cb.add(g->dba, P.DQ, H, SB, H, s));
   for (int l = 0; l < nl; ++l) {
     const int in = l == 0 ? XI : H;
     const float* xin;
@@ -524,8 +525,9 @@ int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
     else { xin = P.HR[l - 1] + bh; ldx = H; }
     ASTK_TRY(wb.add(g->lstm[l].dWu, in, 4 * H, in, P.G[l], 4 * H, xin, ldx, SB, s));
     ASTK_TRY(wb.add(g->lstm[l].dWl, H, 4 * H, H, P.G[l], 4 * H, P.HR[l], H, SB, s));
-    ASTK_TRY(colsum_add_f32(g->lstm[l].db, P.G[l], 4 * H, SB, 4 * H, s));
+    ASTK_TRY(cb.add(g->lstm[l].db, P.G[l], 4 * H, SB, 4 * H, s));
   }
+  ASTK_TRY(cb.flush(s));
   ASTK_TRY(wb.flush(s));
   hipLaunchKernelGGL(k_embed_bwd, dim3(SB), dim3(128), 0, s, g->d_embed, P.TOK, P.DX0, emb_mask, SB, E, XI);
   ASTK_LAUNCH_CHECK();

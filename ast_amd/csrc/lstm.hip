@@ -285,6 +285,7 @@ int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
   }
   GemmArgs wg[GEMM_GROUP_MAX];   // weight-gradient products, issued as grouped launches
   int nwg = 0;
+  ColsumBatch cb;                // bias gradients of all cells: one launch (dz of every cell is final when the recurrence kernel has run)
   for (int l = P.nl - 1; l >= 0; --l) {
     const bool top = l == P.nl - 1;
     const int in = l == 0 ? P.in : h;
@@ -352,7 +353,7 @@ int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
           wg[nwg++] = gemm_args(4 * h, in, rows, mat(dzu, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, 1);
         }
       }
-      ASTK_TRY(colsum_add_f32(g.db, dz, 4 * h, rows, 4 * h, s));
+      ASTK_TRY(cb.add(g.db, dz, 4 * h, rows, 4 * h, s));
       // gradient wrt the layer input
       if (l > 0) {
         if (!persist) ASTK_TRY(gemm_launch(GEMM_NN, gemm_args(rows, h, 4 * h, mat(dz, 4 * h), mat(p.Wu, h), P.DX[dd], h), s));
@@ -363,6 +364,7 @@ int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
       }
     }
   }
+  ASTK_TRY(cb.flush(s));
   if (nwg > 0) ASTK_TRY(gemm_launch_group(GEMM_TN, wg, nwg, s));
   return 0;
 }

@@ -127,6 +127,22 @@ __global__ __launch_bounds__(256) void k_colsum(float* dst, const float* __restr
       [&](int col, int, float v) { atomicAdd(&dst[col], v); });
 }
 
+// blockIdx.z = job; blocks outside the job's own grid leave at once
+__global__ __launch_bounds__(256) void k_colsum_batch(ColsumJobs j) {
+  const int q = blockIdx.z;
+  if ((int)blockIdx.x >= j.gx[q] || (int)blockIdx.y >= j.gy[q]) return;
+  const float* __restrict__ src = j.src[q];
+  float* dst = j.dst[q];
+  const long lds = j.lds[q];
+  colreduce_block<1>(
+      j.rows[q], j.cols[q],
+      [&](int r, int c, float4* a) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (long)r * lds + c);
+        a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
+      },
+      [&](int col, int, float v) { atomicAdd(&dst[col], v); }, (int)blockIdx.x, (int)blockIdx.y, j.gy[q]);
+}
+
 __global__ void k_scale(float* x, size_t n, float s) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= s;
 }
@@ -305,6 +321,25 @@ int colsum_add_f32(float* dst, const float* src, long lds, int rows, int cols, h
   ASTK_CHECK((lds % 4) == 0 && aligned16(src), "colsum: source must be 16-byte aligned with a leading dimension multiple of 4");
   hipLaunchKernelGGL(k_colsum, colreduce_grid(rows, cols), dim3(256), 0, s, dst, src, lds, rows, cols);
   ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int ColsumBatch::add(float* dst, const float* src, long lds, int rows, int cols, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return 0;
+  ASTK_CHECK((lds % 4) == 0 && aligned16(src), "colsum: source must be 16-byte aligned with a leading dimension multiple of 4");
+  if (j.n == COLSUM_BATCH_MAX) ASTK_TRY(flush(s));
+  const dim3 g = colreduce_grid(rows, cols);
+  const int i = j.n++;
+  j.dst[i] = dst; j.src[i] = src; j.lds[i] = lds; j.rows[i] = rows; j.cols[i] = cols; j.gx[i] = (int)g.x; j.gy[i] = (int)g.y;
+  return 0;
+}
+int ColsumBatch::flush(hipStream_t s) {
+  if (j.n == 0) return 0;
+  int gx = 0, gy = 0;
+  for (int i = 0; i < j.n; ++i) { gx = std::max(gx, j.gx[i]); gy = std::max(gy, j.gy[i]); }
+  hipLaunchKernelGGL(k_colsum_batch, dim3(gx, gy, j.n), dim3(256), 0, s, j);
+  ASTK_LAUNCH_CHECK();
+  j.n = 0;
   return 0;
 }
 

@@ -213,6 +213,13 @@ def main():
                       "global_batch": world * B, "frames": T, "feat_dim": D, "tgt_len": L, "parallelism": f"dp{world}", "batchnorm": "global-batch statistics" if (world > 1 and args.sync_bn) else "per-replica statistics",
                       "graphs": bool(not args.no_graph and getattr(model, "graphs_supported", False))},
            "loss": round(loss_val, 4), "roofline": roof}
+    if "gemm" in extra:   # the time-dominant kernel family (half of the step) against its own roofline, same shape as `roofline`
+        g = extra["gemm"]
+        out["roofline_mfma"] = {"bound": "mfma", "kernel": "gemm_f32_kernel<NT|NN|TN> + k_zero_split_tiles (all batched dense products of the step)",
+                                "achieved": g["achieved"], "peak": g["peak"], "unit": "TFLOP/s", "frac": g["frac"], "traffic": None,
+                                "flops_per_step": round(g["achieved"] * 1e12 * g["ms_per_step"] * 1e-3),
+                                "avg_launch_us": round(g["ms_per_step"] * 1e3 / max(1, g["launches_per_step"]), 1),
+                                "launches_per_step": g["launches_per_step"], "method": "HIP events around every launch on the launch stream"}
     out.update({"kernels": extra} if extra else {})
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
