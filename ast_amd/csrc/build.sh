@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libastk.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $ASTK_EXTRA_FLAGS"
 mkdir -p ../_obj
 pids=()
 for f in util gemm rowgemm attn conv lstm lstm_persist decoder decoder_persist; do

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gemm_f32_kernel(GemmGroup grp
   constexpr int LDB = B_RK ? LD_RK : LD_KR;
   __shared__ __attribute__((aligned(16))) float As[2][A_RK ? BM * LD_RK : BK * LD_KR];
   __shared__ __attribute__((aligned(16))) float Bs[2][B_RK ? BN * LD_RK : BK * LD_KR];
-  static_assert(BK == 16, "the RK fragment reads below take BK / 2 = 8 floats per lane as two float4");
+  static_assert(BK == 16 || BK == 32, "BK / 2 floats per lane and operand, read as BK / 8 float4");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -256,16 +256,18 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gemm_f32_kernel(GemmGroup grp
       const float* ap = As[cur] + (A_RK ? (wm * 64 + li) * LDA + (BK / 2) * lk : 2 * lk * LDA + wm * 32 + li);
       const float* bp = Bs[cur] + (B_RK ? (wn * 64 + li) * LDB + (BK / 2) * lk : 2 * lk * LDB + wn * 32 + li);
       if (A_RK) {
-        *reinterpret_cast<float4*>(&fa0[0]) = *reinterpret_cast<const float4*>(ap);
-        *reinterpret_cast<float4*>(&fa0[4]) = *reinterpret_cast<const float4*>(ap + 4);
-        *reinterpret_cast<float4*>(&fa1[0]) = *reinterpret_cast<const float4*>(ap + 32 * LDA);
-        *reinterpret_cast<float4*>(&fa1[4]) = *reinterpret_cast<const float4*>(ap + 32 * LDA + 4);
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+          *reinterpret_cast<float4*>(&fa0[4 * q]) = *reinterpret_cast<const float4*>(ap + 4 * q);
+          *reinterpret_cast<float4*>(&fa1[4 * q]) = *reinterpret_cast<const float4*>(ap + 32 * LDA + 4 * q);
+        }
       } else { fa0[0] = ap[0]; fa1[0] = ap[64]; }
       if (B_RK) {
-        *reinterpret_cast<float4*>(&fb0[0]) = *reinterpret_cast<const float4*>(bp);
-        *reinterpret_cast<float4*>(&fb0[4]) = *reinterpret_cast<const float4*>(bp + 4);
-        *reinterpret_cast<float4*>(&fb1[0]) = *reinterpret_cast<const float4*>(bp + 32 * LDB);
-        *reinterpret_cast<float4*>(&fb1[4]) = *reinterpret_cast<const float4*>(bp + 32 * LDB + 4);
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+          *reinterpret_cast<float4*>(&fb0[4 * q]) = *reinterpret_cast<const float4*>(bp + 4 * q);
+          *reinterpret_cast<float4*>(&fb1[4 * q]) = *reinterpret_cast<const float4*>(bp + 32 * LDB + 4 * q);
+        }
       } else { fb0[0] = bp[0]; fb1[0] = bp[64]; }
 #pragma unroll
       for (int j = 0; j < BK / 2; ++j) {

@@ -71,6 +71,10 @@ class NN:
             self.data_loader.rank, self.data_loader.world = adist.rank(), adist.world_size()
         self.get_model()
         self.init_optimizer(self.cfg.train["optimizer"])
+        if self.cfg.train.get("save_optimizer", False) and self.loaded_from and self.model.arena is not None:
+            # extension key: checkpoints also carry the Adam moments, so a resumed run continues instead of re-warming them
+            if serializers.load_optimizer(self.loaded_from, self.model, self.optimizer):
+                print("optimizer state restored (step {0:d})".format(self.optimizer.t))
         self.train_log = os.path.join(self.model_dir, "train.log")
         self.dev_log = os.path.join(self.model_dir, "dev.log")
 
@@ -115,6 +119,7 @@ class NN:
         if feat_dim:
             self.model.materialize(int(feat_dim), seed=0)     # same seed on every rank: replicas start identical
         self.max_epoch = 0
+        self.loaded_from = None
         print("Checking for model in: {0:s}".format(self.model_dir))
         stem = os.path.basename(self.model_fname).replace(".model", "")
         files = [f for f in os.listdir(os.path.dirname(self.model_fname)) if stem in f and f.endswith(".model")]
@@ -123,6 +128,7 @@ class NN:
             path = os.path.join(os.path.dirname(self.model_fname), newest)
             print("model found = \n{0:s}".format(path))
             serializers.load_npz(path, self.model)
+            self.loaded_from = path
             self.max_epoch = int(newest.split("_")[-1].split(".")[0])
         else:
             print("model not found")
@@ -132,6 +138,18 @@ class NN:
         n_utts = self.data_loader.n_utts[set_key]
         ex = self.cfg.train["extras"]
         avg_loss = 0.0
+        # nn.py:189 reads the loss back after every step (a device sync).  Here the read of step i happens after step i+1 has been
+        # enqueued, so the device never waits for the host; the reported numbers are the same, the progress bar lags by one batch.
+        pending = None
+
+        def settle(p):
+            nonlocal total_loss, n_batches, avg_loss
+            loss_val = float(p[0]) / p[1]                              # quirk Q5: divided by the batch size
+            n_batches += 1
+            total_loss += loss_val
+            avg_loss = total_loss / n_batches
+            pbar.set_description("loss={0:0.4f}".format(avg_loss))
+            pbar.update(p[2] * self.data_loader.world)
         with tqdm(total=n_utts, ncols=80, disable=adist.rank() != 0) as pbar:
             for batch in self.data_loader.get_batch(self.cfg.train["batch_size"], set_key, train=True, labels=True):
                 with using_config("train", True):
@@ -140,12 +158,12 @@ class NN:
                     self.model.cleargrads()
                     loss.backward()
                     self.optimizer.update()
-                loss_val = float(loss.data) / len(batch["y"])          # quirk Q5: divided by the batch size
-                n_batches += 1
-                total_loss += loss_val
-                avg_loss = total_loss / n_batches
-                pbar.set_description("loss={0:0.4f}".format(avg_loss))
-                pbar.update(len(batch["X"]) * self.data_loader.world)
+                cur = (loss.data.clone(), len(batch["y"]), len(batch["X"]))   # the loss buffer is reused by the next step
+                if pending is not None:
+                    settle(pending)
+                pending = cur
+            if pending is not None:
+                settle(pending)
         return avg_loss
 
     # ---- nn.py:235-322

@@ -42,9 +42,24 @@ def load_npz(path, model, optimizer=None):
         for k, v in model.persist.items():
             if k in keys:
                 v.copy_(torch.from_numpy(np.asarray(z[k], dtype=np.float32)))
-        if optimizer is not None and "__opt__/m" in keys:
-            optimizer.t = int(z["__opt__/t"])
-            dev = model.arena.device
-            optimizer.m = torch.from_numpy(z["__opt__/m"]).to(dev)
-            optimizer.v = torch.from_numpy(z["__opt__/v"]).to(dev)
-            optimizer.vhat = torch.from_numpy(z["__opt__/vhat"]).to(dev)
+        if optimizer is not None:
+            _restore_optimizer(z, keys, model, optimizer)
+
+
+def _restore_optimizer(z, keys, model, optimizer):
+    import torch
+    if "__opt__/m" not in keys:
+        return False
+    optimizer.t = int(z["__opt__/t"])
+    dev = model.arena.device
+    optimizer.m = torch.from_numpy(z["__opt__/m"]).to(dev)
+    optimizer.v = torch.from_numpy(z["__opt__/v"]).to(dev)
+    optimizer.vhat = torch.from_numpy(z["__opt__/vhat"]).to(dev)
+    return True
+
+
+def load_optimizer(path, model, optimizer):
+    """Restores the Adam/AMSGrad moments and step count saved by save_npz(..., optimizer=) -- an extension: the reference's
+    checkpoints hold the model only, so a resumed run restarts its moments (train.py:73-75).  Returns False if the file has none."""
+    with np.load(path) as z:
+        return _restore_optimizer(z, set(z.files), model, optimizer)

@@ -43,5 +43,6 @@ if __name__ == "__main__":
             print("BLEU = {0:.2f}".format(bleu))
         if (epoch % iters_save == 0 or epoch == max_epoch - 1) and adist.rank() == 0:
             print("Saving model")
-            serializers.save_npz(nn.model_fname.replace(".model", "_{0:d}.model".format(epoch)), nn.model)
+            serializers.save_npz(nn.model_fname.replace(".model", "_{0:d}.model".format(epoch)), nn.model,
+                                 optimizer=nn.optimizer if nn.cfg.train.get("save_optimizer", False) else None)
             print("Finished saving model")
