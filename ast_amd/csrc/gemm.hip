@@ -24,15 +24,19 @@ namespace {
 #ifndef ASTK_GEMM_BK
 #define ASTK_GEMM_BK 16
 #endif
-constexpr int BM = 128, BN = 128, BK = ASTK_GEMM_BK;
-constexpr int WGS_PER_CU = BK == 32 ? 2 : 3;   // co-resident workgroups the grid is sized for (BK = 16: 33 KB of LDS and 127 registers per
-                                               // workgroup; measured 768 ~ 1024 > 512 workgroups, and +5-7 % over BK = 32 at 512)
+constexpr int BK = ASTK_GEMM_BK;
+// Block tile edge TL: 128 (4 waves x 64x64, the throughput configuration) or 64 (4 waves x 32x32) for products too small to
+// give every CU a 128-tile's worth of k-iterations -- a k-iteration of a 128-tile is 32 MFMAs = 0.87 us per wave whatever the
+// problem size, so 40 such tiles with K = 512 cannot finish in less than 28 us; with 64-tiles the same product is 160 tiles of 7 us.
+constexpr int wgs_per_cu(int TL) { return TL == 64 ? 4 : (BK == 32 ? 2 : 3); }   // co-resident workgroups the grid is sized for (128-tiles,
+                                               // BK = 16: 40 KB of LDS and <= 168 registers per workgroup; 2, 3 and 4 per CU are within 2 %)
 constexpr int LD_RK = BK + 4;  // LDS row stride (floats) of an operand staged from K-contiguous global rows: kept ROW-major [m][k'] with the
                                // tile's k order permuted to [even k | odd k], so that a thread's global float4 (4 consecutive k) is two
                                // 8-byte LDS writes and the 8 k values an MFMA lane consumes (k = lk, lk+2, ...) are two 16-byte LDS reads
                                // (stride 20 floats: conflict-free for both); was K-major with 4 scalar transposing writes and 8 scalar reads
-constexpr int LD_KR = 128;  // LDS row stride of an operand staged from M/N-contiguous global rows: K-major [k][m'], written with 16-byte stores;
-                            // the 128 columns are ordered [wave-row 0 tile 0 | wave-row 1 tile 0 | wave-row 0 tile 1 | wave-row 1 tile 1] so the
+constexpr int ld_kr(int TL) { return TL; }
+                            // LDS row stride of an operand staged from M/N-contiguous global rows: K-major [k][m'], written with 16-byte stores;
+                            // the 128 columns of a 128-tile are ordered [wave-row 0 tile 0 | wave-row 1 tile 0 | wave-row 0 tile 1 | wave-row 1 tile 1] so the
                             // two values a lane needs per k (its column of both 32-wide MFMA tiles) are 64 floats apart and consecutive
                             // k-pairs 256 floats: one ds_read2st64_b32 with immediate offsets per k-pair, no address arithmetic
 
@@ -62,15 +66,19 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 //     owning thread then zeroes in LDS (zero_tail, taken once per tile at most and only when K is not a multiple of BK);
 //   * two-level K-major rows (the conv wgrad) are addressed like plain ones while a tile's BK rows lie inside one group (uniform
 //     test); only a tile that straddles groups computes per-row offsets.
-template <bool RK, bool TWOLVL>
+template <int TL, bool RK, bool TWOLVL>
 struct Stager {
-  static constexpr int NP = BK / 8;        // passes: 256 threads x 16 B cover 1/NP of a 128 x BK tile
-  static constexpr int KQ = BK / 4;        // RK: k-quads per row
+  static constexpr int LD_KR = ld_kr(TL);
+  static constexpr int KQ = BK / 4;                  // RK: k-quads per row
+  static constexpr int CQ = TL / 4;                  // KR: column quads per k row
+  static constexpr int RP = 256 / CQ;                // KR: k rows per pass (256 threads x 16 B)
+  static constexpr int NP = RK ? TL * KQ / 256 : BK / RP;   // passes over the TL x BK tile
+  static_assert(NP >= 1 && (RK || RP * NP == BK), "tile / thread-count mismatch");
   float4 reg[NP];     // staged data
   unsigned voff[NP];  // RK and plain KR: byte offset of this thread's float4 from the tile's uniform base
   int tgrp, trem;     // two-level KR: group and position inside the group of row kcur (uniform)
   int tcol;           // two-level KR: this thread's (clamped) column
-  int a, b;           // RK: a = k-quad (0..KQ-1), b = row pair (0..63).  KR: a = column quad (0..31), b = krow0 (0..7)
+  int a, b;           // RK: a = k-quad (0..KQ-1), b = row group (rows NP*b .. NP*b+NP-1).  KR: a = column quad, b = krow0 (0..RP-1)
   int kcur;           // first k of the tile the next load() fetches
   int lds;            // float offset of this thread's first LDS write
 
@@ -86,15 +94,15 @@ struct Stager {
       for (int p = 0; p < NP; ++p) voff[p] = (unsigned)((rowoff(v, min(row0 + NP * b + p, nrows - 1)) + a * 4) * 4);
       lds = NP * b * LD_RK + 2 * a;   // a thread's NP rows are neighbours: one LDS address register serves all its writes
     } else {
-      a = tid & 31;
-      b = tid >> 5;
-      // LDS column order of a KR tile: [wm0 i0 | wm1 i0 | wm0 i1 | wm1 i1] x 32 (see LD_KR); lane a writes LDS columns 4a..4a+3,
-      // which hold the tile's columns wm*64 + i*32 + 4*(a&7) with i = a>>4, wm = (a>>3)&1
-      const int m = ((a >> 3) & 1) * 64 + (a >> 4) * 32 + (a & 7) * 4;
+      a = tid % CQ;
+      b = tid / CQ;
+      // LDS column order of a 128-wide KR tile: [wm0 i0 | wm1 i0 | wm0 i1 | wm1 i1] x 32 (see ld_kr); lane a writes LDS columns 4a..4a+3,
+      // which hold the tile's columns wm*64 + i*32 + 4*(a&7) with i = a>>4, wm = (a>>3)&1.  A 64-wide tile is stored in order.
+      const int m = TL == 128 ? ((a >> 3) & 1) * 64 + (a >> 4) * 32 + (a & 7) * 4 : 4 * a;
       const int col = min(row0 + m, ((nrows + 3) & ~3) - 4);
 #pragma unroll
       for (int p = 0; p < NP; ++p)
-        voff[p] = (unsigned)(((long)(b + 8 * p) * (TWOLVL ? v.st : v.ld) + col) * 4);
+        voff[p] = (unsigned)(((long)(b + RP * p) * (TWOLVL ? v.st : v.ld) + col) * 4);
       if (TWOLVL) { tgrp = kbeg / v.tn; trem = kbeg % v.tn; tcol = col; }
       lds = b * LD_KR + 4 * a;
     }
@@ -122,7 +130,7 @@ struct Stager {
       } else {                   // the tile straddles groups (or runs past kend): per-row offsets, rows clamped to kend - 1
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          const int kr = min(kcur + b + 8 * p, kend - 1);
+          const int kr = min(kcur + b + RP * p, kend - 1);
           reg[p] = *reinterpret_cast<const float4*>(v.p + (long)(kr / v.tn) * v.sg + (long)(kr % v.tn) * v.st + tcol);
         }
       }
@@ -140,7 +148,7 @@ struct Stager {
       }
     } else {
 #pragma unroll
-      for (int p = 0; p < NP; ++p) *reinterpret_cast<float4*>(&S[lds + 8 * p * LD_KR]) = reg[p];
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<float4*>(&S[lds + RP * p * LD_KR]) = reg[p];
     }
   }
   // Zeroes what this thread's store() wrote for k >= kend (ktile: first k of the tile in S).
@@ -158,7 +166,7 @@ struct Stager {
     } else if (TWOLVL) {
 #pragma unroll
       for (int p = 0; p < NP; ++p)
-        if (ktile + b + 8 * p >= kend) *reinterpret_cast<float4*>(&S[lds + 8 * p * LD_KR]) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ktile + b + RP * p >= kend) *reinterpret_cast<float4*>(&S[lds + RP * p * LD_KR]) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 };
@@ -169,12 +177,15 @@ struct Stager {
 // (for GEMM_STORE the launcher zeroes exactly those tiles first, k_zero_split_tiles).  With G = tiles (one tile each)
 // this degenerates to the classical data-parallel launch; with G = 256 or 512 every CU gets the same number of
 // k-iterations whatever the tile count -- a 400-tile product no longer runs as "2 waves, the second 56% full".
-template <bool A_RK, bool B_RK, bool TWOLVL>
-__global__ __launch_bounds__(256, WGS_PER_CU) void gemm_f32_kernel(GemmGroup grp) {
+template <int TL, bool A_RK, bool B_RK, bool TWOLVL>
+__global__ __launch_bounds__(256, wgs_per_cu(TL)) void gemm_f32_kernel(GemmGroup grp) {
+  constexpr int LD_KR = ld_kr(TL);
   constexpr int LDA = A_RK ? LD_RK : LD_KR;
   constexpr int LDB = B_RK ? LD_RK : LD_KR;
-  __shared__ __attribute__((aligned(16))) float As[2][A_RK ? BM * LD_RK : BK * LD_KR];
-  __shared__ __attribute__((aligned(16))) float Bs[2][B_RK ? BN * LD_RK : BK * LD_KR];
+  constexpr int NA = TL / 64;      // 32x32 accumulator tiles per wave and dimension (the wave's sub-tile is TL/2 x TL/2)
+  constexpr int WT = TL / 2;
+  __shared__ __attribute__((aligned(16))) float As[2][A_RK ? TL * LD_RK : BK * LD_KR];
+  __shared__ __attribute__((aligned(16))) float Bs[2][B_RK ? TL * LD_RK : BK * LD_KR];
   static_assert(BK == 16 || BK == 32, "BK / 2 floats per lane and operand, read as BK / 8 float4");
 
   const int tid = threadIdx.x;
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gemm_f32_kernel(GemmGroup grp
   while (it < it_end) {
     while (it >= grp.iter_start[prob + 1]) ++prob;
     const GemmArgs& g = grp.g[prob];
-    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tiles_n = (g.N + TL - 1) / TL;
     const int kt_tile = g.kt;
     const long lit = it - grp.iter_start[prob];
     const long lend = min(it_end, grp.iter_start[prob + 1]) - grp.iter_start[prob];
@@ -199,7 +210,7 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gemm_f32_kernel(GemmGroup grp
     it += k1 - k0;
     const int zb = (int)(tile / g.tiles_mn);
     const int tmn = (int)(tile - (long)zb * g.tiles_mn);
-    const int m0 = (tmn / tiles_n) * BM, n0 = (tmn % tiles_n) * BN;
+    const int m0 = (tmn / tiles_n) * TL, n0 = (tmn % tiles_n) * TL;
     const int kbeg = k0 * BK;
     const int kend = min(g.K, k1 * BK);
     const bool whole = (k0 == 0) && (k1 == kt_tile);
@@ -209,16 +220,16 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gemm_f32_kernel(GemmGroup grp
     B.p += (long)zb * g.sB;
     float* C = g.C + (long)zb * g.sC;
 
-    Stager<A_RK, TWOLVL> sa;
-    Stager<B_RK, TWOLVL> sb;
+    Stager<TL, A_RK, TWOLVL> sa;
+    Stager<TL, B_RK, TWOLVL> sb;
     sa.init(A, m0, g.M, kbeg, kend, tid);
     sb.init(B, n0, g.N, kbeg, kend, tid);
 
-    f32x16 acc[2][2];
+    f32x16 acc[NA][NA];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NA; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -252,45 +263,46 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gemm_f32_kernel(GemmGroup grp
       // MFMA 32x32x2 operands: lane (li, lk) supplies row/col li of the 32-wide tile at k = KROW(j) + 2*lk, j = 0..BK/2-1.
       //   RK operand: those 8 values are 8 consecutive floats of its LDS row (two 16-byte reads for the whole k-iteration)
       //   KR operand: one ds_read2st64_b32 per k-pair (both 32-wide tiles), rolling one k-pair ahead of the MFMAs
-      float fa0[BK / 2], fa1[BK / 2], fb0[BK / 2], fb1[BK / 2];
-      const float* ap = As[cur] + (A_RK ? (wm * 64 + li) * LDA + (BK / 2) * lk : 2 * lk * LDA + wm * 32 + li);
-      const float* bp = Bs[cur] + (B_RK ? (wn * 64 + li) * LDB + (BK / 2) * lk : 2 * lk * LDB + wn * 32 + li);
-      if (A_RK) {
+      float fa[NA][BK / 2], fb[NA][BK / 2];
+      const float* ap = As[cur] + (A_RK ? (wm * WT + li) * LDA + (BK / 2) * lk : 2 * lk * LDA + wm * 32 + li);
+      const float* bp = Bs[cur] + (B_RK ? (wn * WT + li) * LDB + (BK / 2) * lk : 2 * lk * LDB + wn * 32 + li);
 #pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
-          *reinterpret_cast<float4*>(&fa0[4 * q]) = *reinterpret_cast<const float4*>(ap + 4 * q);
-          *reinterpret_cast<float4*>(&fa1[4 * q]) = *reinterpret_cast<const float4*>(ap + 32 * LDA + 4 * q);
-        }
-      } else { fa0[0] = ap[0]; fa1[0] = ap[64]; }
-      if (B_RK) {
+      for (int i = 0; i < NA; ++i) {
+        if (A_RK) {
 #pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
-          *reinterpret_cast<float4*>(&fb0[4 * q]) = *reinterpret_cast<const float4*>(bp + 4 * q);
-          *reinterpret_cast<float4*>(&fb1[4 * q]) = *reinterpret_cast<const float4*>(bp + 32 * LDB + 4 * q);
-        }
-      } else { fb0[0] = bp[0]; fb1[0] = bp[64]; }
+          for (int q = 0; q < BK / 8; ++q) *reinterpret_cast<float4*>(&fa[i][4 * q]) = *reinterpret_cast<const float4*>(ap + 32 * i * LDA + 4 * q);
+        } else fa[i][0] = ap[64 * i];
+        if (B_RK) {
+#pragma unroll
+          for (int q = 0; q < BK / 8; ++q) *reinterpret_cast<float4*>(&fb[i][4 * q]) = *reinterpret_cast<const float4*>(bp + 32 * i * LDB + 4 * q);
+        } else fb[i][0] = bp[64 * i];
+      }
 #pragma unroll
       for (int j = 0; j < BK / 2; ++j) {
         if (j + 1 < BK / 2) {
-          if (!A_RK) { fa0[j + 1] = ap[KROW(j + 1) * LDA]; fa1[j + 1] = ap[KROW(j + 1) * LDA + 64]; }
-          if (!B_RK) { fb0[j + 1] = bp[KROW(j + 1) * LDB]; fb1[j + 1] = bp[KROW(j + 1) * LDB + 64]; }
+#pragma unroll
+          for (int i = 0; i < NA; ++i) {
+            if (!A_RK) fa[i][j + 1] = ap[KROW(j + 1) * LDA + 64 * i];
+            if (!B_RK) fb[i][j + 1] = bp[KROW(j + 1) * LDB + 64 * i];
+          }
         }
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[j], fb0[j], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[j], fb1[j], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[j], fb0[j], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[j], fb1[j], acc[1][1], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+          for (int i2 = 0; i2 < NA; ++i2) acc[i][i2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[i2][j], acc[i][i2], 0, 0, 0);
       }
       // pin the interleave of the scalar (KR) operand reads: hipcc otherwise sinks every LDS read directly in front of its MFMAs with
-      // lgkmcnt(0).  One ds_read2_b32 per KR operand and k-pair goes in front of the 4 MFMAs of the previous k-pair.
+      // lgkmcnt(0).  One LDS read per KR operand and k-pair goes in front of the MFMAs of the previous k-pair.
       if (!A_RK || !B_RK) {
         constexpr int NR = (A_RK ? 0 : 1) + (B_RK ? 0 : 1);
-        __builtin_amdgcn_sched_group_barrier(0x100, NR + (A_RK ? 2 : 0) + (B_RK ? 2 : 0), 0);
+        constexpr int NRK = (A_RK ? NA * (BK / 8) : 0) + (B_RK ? NA * (BK / 8) : 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NR + NRK, 0);
 #pragma unroll
         for (int i = 0; i < BK / 2 - 1; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NA * NA, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NA * NA, 0);
       }
       __syncthreads();
     };
@@ -303,15 +315,15 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gemm_f32_kernel(GemmGroup grp
     const bool add_bias = g.bias != nullptr && k0 == 0;
     const int mode = whole ? g.mode : GEMM_ATOMIC;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NA; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int row = m0 + wm * WT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (row >= g.M) continue;
         const long coff = g.c_tn > 0 ? (long)(row / g.c_tn) * g.c_sg + (long)(row % g.c_tn) * g.c_st : (long)row * g.ldc;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int col = n0 + wn * 64 + j * 32 + li;
+        for (int j = 0; j < NA; ++j) {
+          const int col = n0 + wn * WT + j * 32 + li;
           if (col >= g.N) continue;
           float v = acc[i][j][r];
           if (add_bias) v += g.bias[col];
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void gemm_f32_kernel(GemmGroup grp
 
 // GEMM_STORE + split tiles: zero the tiles that more than one workgroup will accumulate into.  Block b looks at the
 // boundary between workgroups b and b+1.
-__global__ __launch_bounds__(256) void k_zero_split_tiles(GemmGroup grp, int G) {
+__global__ __launch_bounds__(256) void k_zero_split_tiles(GemmGroup grp, int G, int TL) {
   const long git = grp.iters_total * (long)(blockIdx.x + 1) / (long)G;
   int prob = 0;
   while (git >= grp.iter_start[prob + 1]) ++prob;
@@ -336,14 +348,14 @@ __global__ __launch_bounds__(256) void k_zero_split_tiles(GemmGroup grp, int G) 
   const long it = git - grp.iter_start[prob];
   if (it % g.kt == 0) return;
   const long tile = it / g.kt;
-  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tiles_n = (g.N + TL - 1) / TL;
   const int zb = (int)(tile / g.tiles_mn);
   const int tmn = (int)(tile - (long)zb * g.tiles_mn);
-  const int m0 = (tmn / tiles_n) * BM, n0 = (tmn % tiles_n) * BN;
+  const int m0 = (tmn / tiles_n) * TL, n0 = (tmn % tiles_n) * TL;
   float* C = g.C + (long)zb * g.sC;
-  const int col = n0 + (threadIdx.x & 127);
+  const int col = n0 + (threadIdx.x % TL);
   if (col >= g.N) return;
-  for (int r = threadIdx.x >> 7; r < BM; r += 2) {
+  for (int r = threadIdx.x / TL; r < TL; r += 256 / TL) {
     const int row = m0 + r;
     if (row >= g.M) break;
     const long coff = g.c_tn > 0 ? (long)(row / g.c_tn) * g.c_sg + (long)(row % g.c_tn) * g.c_st : (long)row * g.ldc;
@@ -353,7 +365,7 @@ __global__ __launch_bounds__(256) void k_zero_split_tiles(GemmGroup grp, int G) 
 
 }  // namespace
 
-static int gemm_prepare(int layout, const GemmArgs& g, GemmArgs& a, bool& twolvl) {
+static int gemm_prepare(int layout, const GemmArgs& g, GemmArgs& a, bool& twolvl, int TL) {
   ASTK_CHECK(g.A.p && g.B.p && g.C, "gemm: null operand");
   ASTK_CHECK(aligned16(g.A.p) && aligned16(g.B.p), "gemm: A/B must be 16-byte aligned");
   ASTK_CHECK((g.A.ld % 4) == 0 && (g.B.ld % 4) == 0 && (g.A.sg % 4) == 0 && (g.A.st % 4) == 0 &&
@@ -379,7 +391,7 @@ static int gemm_prepare(int layout, const GemmArgs& g, GemmArgs& a, bool& twolvl
   a.spanB = (unsigned)(spb * 4);
   ASTK_CHECK(!(a_kr && g.A.rowidx) && !(b_kr && g.B.rowidx), "gemm: indexed rows are only supported on K-contiguous operands");
   twolvl = (a_kr && g.A.tn > 0) || (b_kr && g.B.tn > 0);
-  a.tiles_mn = cdiv(g.M, BM) * cdiv(g.N, BN);
+  a.tiles_mn = cdiv(g.M, TL) * cdiv(g.N, TL);
   a.kt = cdiv(g.K, BK);
   a.iters_total = (long)a.tiles_mn * g.batch * a.kt;
   return 0;
@@ -389,26 +401,44 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   ASTK_CHECK(layout == GEMM_NT || layout == GEMM_NN || layout == GEMM_TN, "gemm: bad layout %d", layout);
   ASTK_CHECK(n >= 0 && n <= GEMM_GROUP_MAX, "gemm: group of %d products (max %d)", n, GEMM_GROUP_MAX);
   GemmGroup grp;
-  memset(&grp, 0, sizeof(grp));
   bool twolvl = false, any_store = false;
   long tiles = 0;
   double flops = 0;
   int min_kt = 0x7fffffff;
-  for (int i = 0; i < n; ++i) {
-    const GemmArgs& g = list[i];
-    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0) continue;
-    GemmArgs& a = grp.g[grp.n];
-    bool tl = false;
-    ASTK_TRY(gemm_prepare(layout, g, a, tl));
-    twolvl = twolvl || tl;
-    grp.iter_start[grp.n] = grp.iters_total;
-    grp.iters_total += a.iters_total;
-    tiles += (long)a.tiles_mn * g.batch;
-    flops += 2.0 * g.M * g.N * (double)g.K * g.batch;
-    any_store = any_store || g.mode == GEMM_STORE;
-    min_kt = std::min(min_kt, a.kt);
-    ++grp.n;
+  // Tile edge: 128 unless the whole launch is too small to keep the chip busy with 128-tiles (fewer k-iterations than the stream-K
+  // threshold below, and either too few tiles for the CUs or tiles so shallow that their ramp dominates): then 64-tiles give 4x the
+  // workgroups, each a quarter of the work.  ASTK_GEMM_TILE = 64 | 128 forces one.
+  static const int force_tl = getenv("ASTK_GEMM_TILE") ? atoi(getenv("ASTK_GEMM_TILE")) : 0;
+  int TL = 128;
+  for (int pass = 0; pass < 2; ++pass) {
+    memset(&grp, 0, sizeof(grp));
+    twolvl = any_store = false;
+    tiles = 0; flops = 0; min_kt = 0x7fffffff;
+    for (int i = 0; i < n; ++i) {
+      const GemmArgs& g = list[i];
+      if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0) continue;
+      GemmArgs& a = grp.g[grp.n];
+      bool tl = false;
+      ASTK_TRY(gemm_prepare(layout, g, a, tl, TL));
+      twolvl = twolvl || tl;
+      grp.iter_start[grp.n] = grp.iters_total;
+      grp.iters_total += a.iters_total;
+      tiles += (long)a.tiles_mn * g.batch;
+      flops += 2.0 * g.M * g.N * (double)g.K * g.batch;
+      any_store = any_store || g.mode == GEMM_STORE;
+      min_kt = std::min(min_kt, a.kt);
+      ++grp.n;
+    }
+    // (measured, scratch/gemm_bench.py: 40 tiles x 32 k-iterations 33 -> 18 us, 1 tile x 4800 57 -> 38 us, 600 tiles x 8 42 -> 38 us;
+    //  200 tiles x 32 is 5 % faster with 128-tiles)
+    int max_kt = 0;
+    for (int i = 0; i < grp.n; ++i) max_kt = std::max(max_kt, grp.g[i].kt);
+    const bool small = grp.iters_total < 256L * wgs_per_cu(128) * 10 * (32 / BK) && (tiles < 192 || max_kt <= 12 * (16 / BK > 0 ? 16 / BK : 1));
+    const int want = force_tl == 64 || force_tl == 128 ? force_tl : (small ? 64 : 128);
+    if (pass == 1 || want == TL) break;
+    TL = want;
   }
+  const int WGS_PER_CU = wgs_per_cu(TL);
   if (grp.n == 0) return 0;
   for (int i = grp.n; i <= GEMM_GROUP_MAX; ++i) grp.iter_start[i] = grp.iters_total;
   if (twolvl) {   // a plain operand next to a two-level one: express it as one group of INT_MAX rows
@@ -441,22 +471,25 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   static const bool log_shapes = getenv("ASTK_GEMM_LOG") != nullptr;
   if (log_shapes)
     for (int i = 0; i < grp.n; ++i)
-      fprintf(stderr, "astk_gemm layout=%d M=%d N=%d K=%d batch=%d mode=%d twolvl=%d group=%d/%d G=%ld kt=%d\n", layout, grp.g[i].M,
-              grp.g[i].N, grp.g[i].K, grp.g[i].batch, grp.g[i].mode, (int)twolvl, i, grp.n, G, grp.g[i].kt);
+      fprintf(stderr, "astk_gemm layout=%d M=%d N=%d K=%d batch=%d mode=%d twolvl=%d group=%d/%d G=%ld kt=%d tile=%d\n", layout, grp.g[i].M,
+              grp.g[i].N, grp.g[i].K, grp.g[i].batch, grp.g[i].mode, (int)twolvl, i, grp.n, G, grp.g[i].kt, TL);
   ProfScope prof(PROF_GEMM, s, flops);
   dim3 grid((unsigned)G, 1, 1);
-  if (!aligned && any_store && G > 1) hipLaunchKernelGGL(k_zero_split_tiles, dim3((unsigned)(G - 1)), dim3(256), 0, s, grp, (int)G);
-  switch (layout) {
-    case GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<true, true, false>), grid, dim3(256), 0, s, grp); break;
-    case GEMM_NN:
-      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<true, false, true>), grid, dim3(256), 0, s, grp);
-      else hipLaunchKernelGGL((gemm_f32_kernel<true, false, false>), grid, dim3(256), 0, s, grp);
-      break;
-    default:
-      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<false, false, true>), grid, dim3(256), 0, s, grp);
-      else hipLaunchKernelGGL((gemm_f32_kernel<false, false, false>), grid, dim3(256), 0, s, grp);
-      break;
+  if (!aligned && any_store && G > 1) hipLaunchKernelGGL(k_zero_split_tiles, dim3((unsigned)(G - 1)), dim3(256), 0, s, grp, (int)G, TL);
+#define ASTK_GEMM_LAUNCH(T_)                                                                                              \
+  switch (layout) {                                                                                                       \
+    case GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<T_, true, true, false>), grid, dim3(256), 0, s, grp); break;        \
+    case GEMM_NN:                                                                                                         \
+      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<T_, true, false, true>), grid, dim3(256), 0, s, grp);               \
+      else hipLaunchKernelGGL((gemm_f32_kernel<T_, true, false, false>), grid, dim3(256), 0, s, grp);                     \
+      break;                                                                                                              \
+    default:                                                                                                              \
+      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<T_, false, false, true>), grid, dim3(256), 0, s, grp);              \
+      else hipLaunchKernelGGL((gemm_f32_kernel<T_, false, false, false>), grid, dim3(256), 0, s, grp);                    \
+      break;                                                                                                              \
   }
+  if (TL == 64) { ASTK_GEMM_LAUNCH(64) } else { ASTK_GEMM_LAUNCH(128) }
+#undef ASTK_GEMM_LAUNCH
   ASTK_LAUNCH_CHECK();
   return 0;
 }
