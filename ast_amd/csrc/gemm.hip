@@ -3,7 +3,8 @@
 // One kernel family covers every batched dense product of the train step (SURVEY.md K6, K9, K24 and
 // all dgrad / wgrad products): C[M,N] (+)= op(A) op(B) (+bias).
 //   128x128x16 block tile (BK = 16, double-buffered in LDS), 256 threads = 4 waves as 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles
-//   (64 accumulator VGPRs), three workgroups per CU, k-iterations split evenly over the grid (stream-K).  An operand whose global
+//   (64 accumulator VGPRs), three workgroups per CU, k-iterations split evenly over the grid (stream-K); 64x64x16 tiles (each wave
+//   one 32x32 MFMA tile) for launches too small to occupy the chip with 128-tiles.  An operand whose global
 //   rows are K-contiguous is kept row-major in LDS with the tile's k order permuted to [even | odd] (two 8-byte writes per
 //   staged float4, two 16-byte reads per lane and k-iteration); an operand whose rows are M/N-contiguous is kept K-major
 //   (16-byte writes, one ds_read2st64_b32 per k-pair).  Global loads are 16 B per lane, register-staged two k-tiles ahead of
