@@ -340,7 +340,8 @@ __global__ __launch_bounds__(256, wgs_per_cu(TL)) void gemm_f32_kernel(GemmGroup
 
 // GEMM_STORE + split tiles: zero the tiles that more than one workgroup will accumulate into.  Block b looks at the
 // boundary between workgroups b and b+1.
-__global__ __launch_bounds__(256) void k_zero_split_tiles(GemmGroup grp, int G, int TL) {
+// (16-byte stores when every problem's C rows are 16-byte aligned -- `vec`, decided by the launcher -- else scalar)
+__global__ __launch_bounds__(256) void k_zero_split_tiles(GemmGroup grp, int G, int TL, int vec) {
   const long git = grp.iters_total * (long)(blockIdx.x + 1) / (long)G;
   int prob = 0;
   while (git >= grp.iter_start[prob + 1]) ++prob;
@@ -354,13 +355,17 @@ __global__ __launch_bounds__(256) void k_zero_split_tiles(GemmGroup grp, int G, 
   const int tmn = (int)(tile - (long)zb * g.tiles_mn);
   const int m0 = (tmn / tiles_n) * TL, n0 = (tmn % tiles_n) * TL;
   float* C = g.C + (long)zb * g.sC;
-  const int col = n0 + (threadIdx.x % TL);
+  const int w = vec ? 4 : 1;                    // floats per thread and row
+  const int tpr = TL / w;                        // threads per row
+  const int col = n0 + (threadIdx.x % tpr) * w;
   if (col >= g.N) return;
-  for (int r = threadIdx.x / TL; r < TL; r += 256 / TL) {
+  for (int r = threadIdx.x / tpr; r < TL; r += 256 / tpr) {
     const int row = m0 + r;
     if (row >= g.M) break;
     const long coff = g.c_tn > 0 ? (long)(row / g.c_tn) * g.c_sg + (long)(row % g.c_tn) * g.c_st : (long)row * g.ldc;
-    C[coff + col] = 0.f;
+    if (vec && col + 3 < g.N) *reinterpret_cast<float4*>(C + coff + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+    else
+      for (int c = col; c < min(col + w, g.N); ++c) C[coff + c] = 0.f;
   }
 }
 
@@ -476,7 +481,14 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
               grp.g[i].N, grp.g[i].K, grp.g[i].batch, grp.g[i].mode, (int)twolvl, i, grp.n, G, grp.g[i].kt, TL);
   ProfScope prof(PROF_GEMM, s, flops);
   dim3 grid((unsigned)G, 1, 1);
-  if (!aligned && any_store && G > 1) hipLaunchKernelGGL(k_zero_split_tiles, dim3((unsigned)(G - 1)), dim3(256), 0, s, grp, (int)G, TL);
+  if (!aligned && any_store && G > 1) {
+    bool vec = true;
+    for (int i = 0; i < grp.n; ++i) {
+      const GemmArgs& a = grp.g[i];
+      vec = vec && aligned16(a.C) && (a.sC % 4) == 0 && (a.c_tn > 0 ? (a.c_sg % 4) == 0 && (a.c_st % 4) == 0 : (a.ldc % 4) == 0);
+    }
+    hipLaunchKernelGGL(k_zero_split_tiles, dim3((unsigned)(G - 1)), dim3(256), 0, s, grp, (int)G, TL, vec ? 1 : 0);
+  }
 #define ASTK_GEMM_LAUNCH(T_)                                                                                              \
   switch (layout) {                                                                                                       \
     case GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<T_, true, true, false>), grid, dim3(256), 0, s, grp); break;        \
