@@ -371,3 +371,43 @@ def test_nn_trains_predicts_and_resumes_through_train_py(tmp_path):
     assert nn.max_epoch == 8
     preds = nn.predict("syn_dev")
     assert len(preds) == 6 and all(1 <= len(p) <= 12 and all(0 <= t < 31 for t in p) for _, p in preds)
+
+
+def test_full_size_batch_permutation_and_gradient_accumulation():
+    """Two more size-independent properties at BASELINE configs[1]'s full size (no dropout / noise, teacher-forced):
+    * nothing in the model couples batch rows except BatchNorm's statistics and the mean of the loss, and both are symmetric:
+      permuting the rows of (X, y) permutes enc_states the same way and leaves the loss and every gradient unchanged -- although
+      every row then runs in a different batch tile, workgroup and attention slice;
+    * gradients are ACCUMULATED (cleargrads is the caller's business, nn.py:177): backward twice without clearing doubles them."""
+    import copy
+    import bench
+    from ast_amd.seq2seq import SpeechEncoderDecoder, using_config
+    from oracle.ast_ref import synth_batch
+    cfg = copy.deepcopy(bench.MODEL_CFG)
+    cfg["dropout"] = {"embed": 0.0, "rnn": 0.0, "out": 0}
+    B, T, D, L, V = 32, 800, 80, 40, cfg["rnn_config"]["dec_vocab_size"]
+    X, y = synth_batch(B, T, D, L, V, 20, dtype=np.float32)
+    X, y = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    m = SpeechEncoderDecoder(0, cfg).materialize(D, seed=0)
+    m.inject = {"use_truth": [1] * (L - 1)}
+
+    def run(Xb, yb, clear=True):
+        with using_config("train", True):
+            l = m.forward_loss(X=Xb, y=yb, teach_ratio=1.0, random_out=0, add_noise=0)
+            if clear:
+                m.cleargrads()
+            l.backward()
+        torch.cuda.synchronize()
+        return float(l.data), m.arena.grad.clone(), m.enc_states.clone()
+
+    l0, g0, e0 = run(X, y)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).cuda()
+    assert not bool((perm == torch.arange(B, device="cuda")).all())
+    l1, g1, e1 = run(X[perm].contiguous(), y[perm].contiguous())
+    assert abs(l1 - l0) <= 2e-5 * abs(l0), (l0, l1)
+    assert float((e1 - e0[perm]).abs().max()) <= 2e-4 * float(e0.abs().max())
+    gscale = float(g0.abs().max())
+    assert float((g1 - g0).abs().max()) <= 2e-4 * gscale, float((g1 - g0).abs().max()) / gscale
+    # accumulate: same batch again without cleargrads
+    _, g2, _ = run(X[perm].contiguous(), y[perm].contiguous(), clear=False)
+    assert float((g2 - 2 * g1).abs().max()) <= 2e-4 * gscale
