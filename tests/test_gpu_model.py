@@ -371,6 +371,24 @@ def test_nn_trains_predicts_and_resumes_through_train_py(tmp_path):
     assert nn.max_epoch == 8
     preds = nn.predict("syn_dev")
     assert len(preds) == 6 and all(1 <= len(p) <= 12 and all(0 <= t < 31 for t in p) for _, p in preds)
+    # beam.py (beam.py:46-146): references in the reference's file layout, n-best pickle, BLEU line, hypothesis file, --resume
+    refs = tmp_path / "refs" / "syn_dev"
+    os.makedirs(refs)
+    utts = sorted(nn.data_loader.info["syn_dev"])
+    truth = nn.data_loader.get_hyps([(u, list(nn.data_loader.ids["syn_dev"][u])) for u in utts])
+    (refs / "eval.ids").write_text("".join(u + "\n" for u in utts))
+    (refs / "ref.en0").write_text("".join(" ".join(truth[u]) + "\n" for u in utts))
+    tcfg["data"].update(refs_path=str(tmp_path / "refs"), n_evals=1)
+    json.dump(tcfg, open(tmp_path / "train_cfg.json", "w"))
+    del nn
+    torch.cuda.empty_cache()
+    for extra in ([], ["--resume"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "beam.py"), "-m", str(tmp_path), "-n", "3", "-k", "4", "-s", "syn_dev", "-w", "0.6"] + extra,
+                           cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "BLEU = " in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert os.path.exists(tmp_path / "syn_dev_beam_N-3_K-4.p")
+    lines = open(tmp_path / "syn_dev_beam_N-3_K-4_W-0.60.en").read().split("\n")
+    assert len(lines) == 7 and lines[-1] == ""
 
 
 def test_full_size_batch_permutation_and_gradient_accumulation():

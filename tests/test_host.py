@@ -192,3 +192,30 @@ def test_grad_buckets_tile_the_arena_of_every_config():
         assert spans[0][0] == 0 and spans[-1][1] == arena.size
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         assert set(gb.ranges) == {"cnn", "enc", "dec"}
+
+
+def test_bleu_matches_hand_computation(tmp_path):
+    """ast_amd.eval restates nltk's corpus_bleu + SmoothingFunction.method2 (eval.py:30-38 of the reference)."""
+    import math
+    from ast_amd.eval import Eval, corpus_bleu
+    ref = "the cat is on the mat".split()
+    assert abs(corpus_bleu([[ref]], [ref]) - 1.0) < 1e-12                      # identical: every p_n = 1 (smoothed (k+1)/(k+1)), BP = 1
+    assert corpus_bleu([[ref]], ["dogs bark loudly".split()]) == 0.0            # no unigram match
+    # hypothesis "the the the cat" against two references: clipped unigrams: the<=2, cat<=1 -> 3/4; bigrams: "the cat" 1/3;
+    # trigrams 0/2, 4-grams 0/1; method2 -> 3/4, 2/4, 1/3, 1/2; closest reference length to 4 is 5 (|6-4| > |5-4|) -> BP = exp(1 - 5/4)
+    hyp = "the the the cat".split()
+    refs = [ref, "there is the cat here".split()]
+    want = math.exp(1 - 5 / 4) * math.exp(0.25 * (math.log(3 / 4) + math.log(2 / 4) + math.log(1 / 3) + math.log(1 / 2)))
+    assert abs(corpus_bleu([refs], [hyp]) - want) < 1e-12
+    # corpus level = micro-average over segments, not the mean of sentence scores
+    two = corpus_bleu([[ref], refs], [ref, hyp])
+    assert corpus_bleu([refs], [hyp]) < two < 1.0
+    # the Eval class reads the reference's file layout
+    (tmp_path / "eval.ids").write_text("u1\nu2\n")
+    (tmp_path / "ref.en0").write_text("the cat is on the mat\nthere is the cat here\n")
+    (tmp_path / "ref.en1").write_text("a cat sits on the mat\nthe cat is here\n")
+    ev = Eval(str(tmp_path), 2)
+    assert len(ev.refs) == 2 and ev.refs[0][1] == "a cat sits on the mat".split()
+    assert abs(ev.calc_bleu({"u1": ref, "u2": "the cat is here".split()}) - 1.0) < 1e-12
+    ev.write_to_file({"u1": ref, "u2": hyp}, str(tmp_path / "out.txt"))
+    assert (tmp_path / "out.txt").read_text() == "the cat is on the mat\nthe the the cat\n"
