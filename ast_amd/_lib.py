@@ -97,10 +97,6 @@ SIGNATURES = {
     "astk_scale_f32": (C.c_int, [_VP, _SZ, _F, _VP]),
     "astk_prof_begin": (C.c_int, []),
     "astk_prof_end": (C.c_int, [C.POINTER(C.c_double)]),
-    "astk_graph_begin": (C.c_int, [_VP]),
-    "astk_graph_end": (C.c_int, [_VP, C.POINTER(C.c_void_p)]),
-    "astk_graph_launch": (C.c_int, [_VP, _VP]),
-    "astk_graph_destroy": (C.c_int, [_VP]),
 }
 
 _lib = None

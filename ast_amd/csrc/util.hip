@@ -464,30 +464,4 @@ int astk_prof_end(double* res) {
   return 0;
 }
 
-int astk_graph_begin(void* stream) {
-  ASTK_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
-  return 0;
-}
-int astk_graph_end(void* stream, void** graph_exec) {
-  hipGraph_t graph = nullptr;
-  ASTK_HIP(hipStreamEndCapture((hipStream_t)stream, &graph));
-  hipGraphExec_t exec = nullptr;
-  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
-  if (e != hipSuccess) {
-    astk::set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
-    return -2;
-  }
-  *graph_exec = (void*)exec;
-  return 0;
-}
-int astk_graph_launch(void* graph_exec, void* stream) {
-  ASTK_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
-  return 0;
-}
-int astk_graph_destroy(void* graph_exec) {
-  if (graph_exec) ASTK_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
-  return 0;
-}
-
 }  // extern "C"

@@ -179,8 +179,6 @@ class SpeechEncoderDecoder:
         if t is None or t.numel() < nbytes:
             t = torch.empty(int(nbytes * 1.0) + 256, dtype=torch.uint8, device=self.device)
             self._ws[key] = t
-            for st in self._shape_cache.values():
-                st["graphs"] = {}
         return t
 
     def _shape_state(self, B, T, D, L):
@@ -249,7 +247,7 @@ class SpeechEncoderDecoder:
                   c0=torch.zeros(nld, B, H, **f32), h0=torch.zeros(nld, B, H, **f32),
                   d_c0=torch.zeros(nld, B, H, **f32), d_h0=torch.zeros(nld, B, H, **f32),
                   loss=torch.zeros(1, **f32), pred=torch.zeros(S, B, dtype=torch.int32, device=dev),
-                  flags=torch.ones(S, dtype=torch.int32, device=dev), graphs={},
+                  flags=torch.ones(S, dtype=torch.int32, device=dev),
                   ws_cnn=int(lib.astk_conv_bn_relu_workspace_bytes(C.byref(cd))),
                   ws_lstm=int(lib.astk_lstm_stack_workspace_bytes(C.byref(ld))),
                   ws_dec=int(lib.astk_decoder_workspace_bytes(C.byref(dd))))

@@ -216,12 +216,6 @@ int astk_scale_f32(float* x, size_t n, float s, void* stream);
 int astk_prof_begin(void);
 int astk_prof_end(double* res);
 
-/* hipGraph capture of a sequence of the calls above on `stream` (static shapes per bucket). */
-int astk_graph_begin(void* stream);
-int astk_graph_end(void* stream, void** graph_exec);
-int astk_graph_launch(void* graph_exec, void* stream);
-int astk_graph_destroy(void* graph_exec);
-
 #ifdef __cplusplus
 }
 #endif
