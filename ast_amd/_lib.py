@@ -78,6 +78,8 @@ SIGNATURES = {
     "astk_lstm_stack_fwd": (C.c_int, [C.POINTER(LstmStackDesc), C.POINTER(LstmParams), _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "astk_lstm_stack_bwd": (C.c_int, [C.POINTER(LstmStackDesc), C.POINTER(LstmParams), C.POINTER(LstmGrads), _VP, _VP, _VP, _VP,
                                       _VP, _VP, _VP, _SZ, _VP]),
+    "astk_lstm_stack_bwd_on": (C.c_int, [C.POINTER(LstmStackDesc), C.POINTER(LstmParams), C.POINTER(LstmGrads), _VP, _VP, _VP, _VP,
+                                      _VP, _VP, _VP, _SZ, _VP, _VP]),
     "astk_attn_workspace_bytes": (_SZ, [_I, _I, _I]),
     "astk_attn_step_fwd": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "astk_attn_step_bwd": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
@@ -86,6 +88,8 @@ SIGNATURES = {
                                    _VP, _SZ, _VP]),
     "astk_decoder_bwd": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderParams), C.POINTER(DecoderGrads), _VP, _VP, _VP, _VP,
                                    _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "astk_decoder_bwd_phase": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderParams), C.POINTER(DecoderGrads), _VP, _VP, _VP, _VP,
+                                         _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _I, _VP]),
     "astk_decoder_step_infer": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderParams), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                                           _VP, _SZ, _VP]),
     "astk_softmax_ce_fwd": (C.c_int, [_I, _I, _L, _VP, _VP, _L, _VP, _F, _VP, _VP, _VP]),

@@ -121,6 +121,14 @@ static inline GemmArgs gemm_args(int M, int N, int K, MatView A, MatView B, floa
   return g;
 }
 int gemm_launch(int layout, const GemmArgs& g, hipStream_t s);
+// Scoped cap on the co-resident GEMM workgroups per CU for launches made by this thread (0 = none): work that is meant to run
+// BESIDE a persistent recurrence kernel must leave registers free on every CU, or that kernel cannot become resident until the
+// stream-K workgroups (which live for the whole launch) have finished.
+struct GemmWgCap {
+  explicit GemmWgCap(int per_cu);
+  ~GemmWgCap();
+  int prev;
+};
 // Several independent products of the same layout in ONE launch (their k-iterations are concatenated and split evenly
 // over the workgroups): used where a phase issues many small products that cannot fill the chip one at a time.
 constexpr int GEMM_GROUP_MAX = 12;
@@ -157,6 +165,9 @@ int copy_f32(float* dst, const float* src, size_t n, hipStream_t s);
 int copy2d_f32(float* dst, long ldd, const float* src, long lds, int rows, int cols, int cols_dst, hipStream_t s);
 int add2d_f32(float* dst, long ldd, const float* src, long lds, int rows, int cols, hipStream_t s);
 int transpose_f32(float* dst, long ldd, const float* src, long lds, int rows, int cols, hipStream_t s);  // dst[c][r] = src[r][c]
+// Work enqueued on `to` after this call runs after everything enqueued on `from` before it (event record + stream wait; the
+// events come from a small per-thread pool and carry no timing).
+int stream_order(hipStream_t from, hipStream_t to);
 int colsum_add_f32(float* dst, const float* src, long lds, int rows, int cols, hipStream_t s);           // dst[c] += sum_r src[r][c]
 // Several column sums (the bias gradients of one backward phase) in ONE launch: add() collects, flush() launches.
 constexpr int COLSUM_BATCH_MAX = 8;

@@ -405,8 +405,16 @@ int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
 int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* prm, const astk_decoder_grads* g, const float* enc,
                      const float* c0, const float* h0, const int32_t* y, const float* emb_mask, const float* rnn_masks, float* d_enc,
                      float* d_c0, float* d_h0, void* ws, size_t ws_bytes, void* stream) {
+  return astk_decoder_bwd_phase(d, prm, g, enc, c0, h0, y, emb_mask, rnn_masks, d_enc, d_c0, d_h0, ws, ws_bytes, ASTK_DEC_BWD_ALL, stream);
+}
+
+int astk_decoder_bwd_phase(const astk_decoder_desc* d, const astk_decoder_params* prm, const astk_decoder_grads* g, const float* enc,
+                           const float* c0, const float* h0, const int32_t* y, const float* emb_mask, const float* rnn_masks,
+                           float* d_enc, float* d_c0, float* d_h0, void* ws, size_t ws_bytes, int phase, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   (void)c0; (void)h0; (void)y;
+  ASTK_CHECK(phase == ASTK_DEC_BWD_ALL || phase == ASTK_DEC_BWD_CHAIN || phase == ASTK_DEC_BWD_PARAMS, "decoder_bwd: bad phase %d", phase);
+  const bool do_chain = phase != ASTK_DEC_BWD_PARAMS, do_params = phase != ASTK_DEC_BWD_CHAIN;
   DecPlan P;
   ASTK_TRY(make_plan(d, ws, P));
   ASTK_CHECK(ws && ws_bytes >= P.bytes, "decoder_bwd: workspace too small");
@@ -414,6 +422,10 @@ int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
   const int B = P.B, S = P.S, H = P.H, E = P.E, A = P.A, V = P.V, Vp = P.Vp, XI = P.XI, nl = P.nl, T = P.T, Tp = P.Tp;
   const size_t bh = (size_t)B * H;
   const int top = nl - 1;
+  int ns_ = 1, ch_ = 1;
+  const bool persist = decoder_persist_applicable(d, &ns_, &ch_);
+  const bool b6s = persist && decoder_persist_b6_split(d);
+  if (do_chain) {
   // transposed weights for the data-path products (dY W as row-panel NT products)
   {
     TransposeJobs tj;
@@ -431,22 +443,13 @@ int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
   }
   ASTK_TRY(fill_zero(P.ZERO, (size_t)B * (A > H ? A : H) * sizeof(float), s));
   ASTK_TRY(attn_ws_init(P.attn_ws, B, T, H, s));
-  int ns_ = 1, ch_ = 1;
-  const bool persist = decoder_persist_applicable(d, &ns_, &ch_);
   if (persist) {
     DecPersistBwdBuffers bf;
     bf.WoT = P.WoT; bf.WcT = P.WcT; bf.WlT = P.WlT[0]; bf.WuT = P.WuT[0]; bf.ENCA = P.ENCA; bf.ALPHA = P.ALPHA; bf.CVH = P.CVH; bf.ML = P.MLB;
     bf.HT = P.HT; bf.LOGITS = P.LOGITS; bf.C = P.C[0]; bf.G = P.G[0]; bf.DPRE = P.DPRE; bf.DCVH = P.DCVH; bf.DS = P.DS; bf.DX0 = P.DX0;
     bf.DHATT = P.PART; bf.d_c0 = d_c0; bf.ctr = P.PCTR;
-    const bool b6s = decoder_persist_b6_split(d);
     bf.DXH = b6s ? P.DXH : nullptr;
     ASTK_TRY(decoder_persist_bwd_launch(d, enc, rnn_masks, bf, s));
-    // split mode: the embedding columns of d_x0 (only the embedding scatter reads them) are one batched product over all steps
-    if (b6s) ASTK_TRY(gemm_launch(GEMM_NN, gemm_args(S * B, E, 4 * H, mat(P.G[0], 4 * H), mat(prm->lstm[0].Wu, XI), P.DX0, XI), s));
-    // dq[s][b][:] = sum_t ds[s][b][t] enc[b][t][:]  (batched over b) -- only the weight gradients of attn_Wa need it
-    GemmArgs gq = gemm_args(S, H, T, mat(P.DS, (long)B * Tp), mat(enc, H), P.DQ, (long)B * H);
-    gq.batch = B; gq.sA = Tp; gq.sB = (long)T * H; gq.sC = H;
-    ASTK_TRY(gemm_launch(GEMM_NN, gq, s));
   }
   for (int st = S - 1; st >= 0 && !persist; --st) {
     const bool last = st == S - 1;
@@ -506,6 +509,28 @@ int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
     ASTK_TRY(rowgemm_launch(rg(B, H, P.G[l], 4 * H, P.WlT[l], 4 * H, 4 * H, d_h0 + l * bh, H), s));
     if (!persist) ASTK_TRY(copy_f32(d_c0 + l * bh, P.DC[l][0], bh, s));
   }
+  // ---- d_enc[b] = alpha_b^T d_cv_b + ds_b^T q_b   (batched over b, K = S)
+  {
+    GemmArgs ga = gemm_args(T, H, S, mat(P.ALPHA, (long)B * Tp), mat(P.DCVH, (long)B * 2 * H), d_enc, H);
+    ga.batch = B; ga.sA = Tp; ga.sB = 2 * H; ga.sC = (long)T * H;
+    ASTK_TRY(gemm_launch(GEMM_TN, ga, s));
+    GemmArgs gb = gemm_args(T, H, S, mat(P.DS, (long)B * Tp), mat(P.Q, (long)B * H), d_enc, H, nullptr, GEMM_ACCUM);
+    gb.batch = B; gb.sA = Tp; gb.sB = H; gb.sC = (long)T * H;
+    ASTK_TRY(gemm_launch(GEMM_TN, gb, s));
+  }
+  }   // do_chain
+  if (!do_params) return 0;
+  GemmWgCap cap(phase == ASTK_DEC_BWD_PARAMS ? 2 : 0);   // on its own stream this phase shares the CUs with the encoder's recurrence kernel
+  // ==== parameter gradients: read only what the chain phase left in the workspace; nothing downstream of the decoder needs them, so a
+  // caller may run this phase on a second stream beside the encoder's backward recurrence (ASTK_DEC_BWD_PARAMS)
+  if (persist) {
+    // split mode: the embedding columns of d_x0 (only the embedding scatter reads them) are one batched product over all steps
+    if (b6s) ASTK_TRY(gemm_launch(GEMM_NN, gemm_args(S * B, E, 4 * H, mat(P.G[0], 4 * H), mat(prm->lstm[0].Wu, XI), P.DX0, XI), s));
+    // dq[s][b][:] = sum_t ds[s][b][t] enc[b][t][:]  (batched over b) -- only the weight gradients of attn_Wa need it
+    GemmArgs gq = gemm_args(S, H, T, mat(P.DS, (long)B * Tp), mat(enc, H), P.DQ, (long)B * H);
+    gq.batch = B; gq.sA = Tp; gq.sB = (long)T * H; gq.sC = H;
+    ASTK_TRY(gemm_launch(GEMM_NN, gq, s));
+  }
   // ---- weight gradients: one batched TN GEMM each over the S*B saved rows
   const int SB = S * B;
   WgradBatch wb;
@@ -531,15 +556,6 @@ int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
   ASTK_TRY(wb.flush(s));
   hipLaunchKernelGGL(k_embed_bwd, dim3(SB), dim3(128), 0, s, g->d_embed, P.TOK, P.DX0, emb_mask, SB, E, XI);
   ASTK_LAUNCH_CHECK();
-  // ---- d_enc[b] = alpha_b^T d_cv_b + ds_b^T q_b   (batched over b, K = S)
-  {
-    GemmArgs ga = gemm_args(T, H, S, mat(P.ALPHA, (long)B * Tp), mat(P.DCVH, (long)B * 2 * H), d_enc, H);
-    ga.batch = B; ga.sA = Tp; ga.sB = 2 * H; ga.sC = (long)T * H;
-    ASTK_TRY(gemm_launch(GEMM_TN, ga, s));
-    GemmArgs gb = gemm_args(T, H, S, mat(P.DS, (long)B * Tp), mat(P.Q, (long)B * H), d_enc, H, nullptr, GEMM_ACCUM);
-    gb.batch = B; gb.sA = Tp; gb.sB = H; gb.sC = (long)T * H;
-    ASTK_TRY(gemm_launch(GEMM_TN, gb, s));
-  }
   return 0;
 }
 

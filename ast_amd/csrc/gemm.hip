@@ -403,6 +403,10 @@ static int gemm_prepare(int layout, const GemmArgs& g, GemmArgs& a, bool& twolvl
   return 0;
 }
 
+static thread_local int tl_wg_cap = 0;
+GemmWgCap::GemmWgCap(int per_cu) : prev(tl_wg_cap) { tl_wg_cap = per_cu; }
+GemmWgCap::~GemmWgCap() { tl_wg_cap = prev; }
+
 int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   ASTK_CHECK(layout == GEMM_NT || layout == GEMM_NN || layout == GEMM_TN, "gemm: bad layout %d", layout);
   ASTK_CHECK(n >= 0 && n <= GEMM_GROUP_MAX, "gemm: group of %d products (max %d)", n, GEMM_GROUP_MAX);
@@ -468,6 +472,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     if (g2 > tiles) { G = g2; aligned = false; }
   }
   if (force_g > 0) { G = std::min<long>(force_g, grp.iters_total); aligned = false; }
+  if (tl_wg_cap > 0 && G > 256L * tl_wg_cap) { G = 256L * tl_wg_cap; aligned = false; }
   if (aligned && grp.n > 1) {
     // one tile per workgroup needs boundaries on tile boundaries: only true for uniform kt; otherwise fall back to an even split
     bool uniform = true;

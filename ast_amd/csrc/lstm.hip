@@ -236,7 +236,14 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
 int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* prm, const astk_lstm_grads* gr, const float* x,
                         const float* masks, const float* d_enc, const float* d_cT, const float* d_hT, float* dx, void* ws,
                         size_t ws_bytes, void* stream) {
+  return astk_lstm_stack_bwd_on(d, prm, gr, x, masks, d_enc, d_cT, d_hT, dx, ws, ws_bytes, stream, nullptr);
+}
+
+int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params* prm, const astk_lstm_grads* gr, const float* x,
+                           const float* masks, const float* d_enc, const float* d_cT, const float* d_hT, float* dx, void* ws,
+                           size_t ws_bytes, void* stream, void* recurrence_stream) {
   hipStream_t s = (hipStream_t)stream;
+  hipStream_t sr = recurrence_stream ? (hipStream_t)recurrence_stream : s;
   LstmPlan P;
   ASTK_TRY(make_plan(d, ws, masks != nullptr, P));
   const size_t need = astk_lstm_stack_workspace_bytes(d);
@@ -281,7 +288,9 @@ int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
         c.reverse_pos = dd == 1;
         c.layer = l;
       }
-    ASTK_TRY(lstm_persist_bwd_launch(cells, P.nd * P.nl, P.nl, T, B, h, H, P.counters, s));
+    ASTK_TRY(stream_order(s, sr));     // the recurrence kernel may live on its own (CU-masked) stream, see astk.h
+    ASTK_TRY(lstm_persist_bwd_launch(cells, P.nd * P.nl, P.nl, T, B, h, H, P.counters, sr));
+    ASTK_TRY(stream_order(sr, s));
   }
   GemmArgs wg[GEMM_GROUP_MAX];   // weight-gradient products, issued as grouped launches
   int nwg = 0;

@@ -324,6 +324,19 @@ int colsum_add_f32(float* dst, const float* src, long lds, int rows, int cols, h
   return 0;
 }
 
+int stream_order(hipStream_t from, hipStream_t to) {
+  if (from == to) return 0;
+  constexpr int NEV = 16;
+  static thread_local hipEvent_t pool[NEV];
+  static thread_local int next = 0;
+  hipEvent_t& e = pool[next];
+  next = (next + 1) % NEV;
+  if (!e) ASTK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  ASTK_HIP(hipEventRecord(e, from));
+  ASTK_HIP(hipStreamWaitEvent(to, e, 0));   // the wait refers to this record even if the event is recorded again later
+  return 0;
+}
+
 int ColsumBatch::add(float* dst, const float* src, long lds, int rows, int cols, hipStream_t s) {
   if (rows <= 0 || cols <= 0) return 0;
   ASTK_CHECK((lds % 4) == 0 && aligned16(src), "colsum: source must be 16-byte aligned with a leading dimension multiple of 4");

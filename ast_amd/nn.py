@@ -5,6 +5,7 @@ all-reduce the flat gradient arena over RCCL before the hooks (ast_amd.dist)."""
 import os
 import random
 
+import torch
 from tqdm import tqdm
 
 from . import dist as adist
@@ -150,7 +151,11 @@ class NN:
             avg_loss = total_loss / n_batches
             pbar.set_description("loss={0:0.4f}".format(avg_loss))
             pbar.update(p[2] * self.data_loader.world)
-        with tqdm(total=n_utts, ncols=80, disable=adist.rank() != 0) as pbar:
+        # (a stream of its own: the model's CU-masked side streams synchronise implicitly with the legacy default stream)
+        if getattr(self, "_compute_stream", None) is None:
+            self._compute_stream = torch.cuda.Stream(device=self.model.device)
+        torch.cuda.synchronize(self.model.device)
+        with tqdm(total=n_utts, ncols=80, disable=adist.rank() != 0) as pbar, torch.cuda.stream(self._compute_stream):
             for batch in self.data_loader.get_batch(self.cfg.train["batch_size"], set_key, train=True, labels=True):
                 with using_config("train", True):
                     loss = self.model.forward_loss(X=batch["X"], y=batch["y"], teach_ratio=ex["teach_ratio"],
@@ -164,6 +169,7 @@ class NN:
                 pending = cur
             if pending is not None:
                 settle(pending)
+        torch.cuda.synchronize(self.model.device)      # later default-stream work (predict, checkpoint) sees the epoch's updates
         return avg_loss
 
     # ---- nn.py:235-322

@@ -6,6 +6,7 @@ C-ABI call (include/astk.h).  There is no CPU / eager-PyTorch fallback: without 
 the compute methods raise.
 """
 import ctypes as C
+import os
 import random
 
 import numpy as np
@@ -113,6 +114,8 @@ class SpeechEncoderDecoder:
         self._dec_c = self._dec_h = None
         self.grad_buckets = None        # ast_amd.dist.GradBuckets under data parallelism: ranges are all-reduced as they become final
         self.stat_exchange = None       # ast_amd.dist.StatExchange: BatchNorm statistics over the global batch (train mode only)
+        # decoder parameter gradients on a second stream beside the encoder's backward recurrence (ASTK_OVERLAP_PARAM_GRADS=0: in line)
+        self.overlap_param_grads = os.environ.get("ASTK_OVERLAP_PARAM_GRADS", "1") != "0"
         self.mask_pad_id = None
 
     # ------------------------------------------------------------------ parameters
@@ -341,6 +344,38 @@ class SpeechEncoderDecoder:
             self._dec_c, self._dec_h = st["c0"].clone(), st["h0"].clone()
 
     # ------------------------------------------------------------------ seq2seq.py:399-473
+    def _cu_streams(self, st):
+        """(recurrence stream masked to the CUs the encoder's persistent kernels occupy, side stream masked to the others), or None.
+        hipExtStreamCreateWithCUMask: bit i = CU i; contiguous ranges confine a launch as expected on MI355X (scratch/cumask_probe.hip)."""
+        if torch.cuda.current_stream(self.device).cuda_stream == 0:
+            # masked streams are created "blocking": they and the legacy default stream wait for each other's work, which serialises
+            # exactly what should overlap.  Callers that want the overlap run the step on a stream of their own (bench.py, NN.train_epoch).
+            return None
+        need = (self.h // 16) * ((st["B"] + 15) // 16) * self.n_dirs * len(self.rnn_enc)      # workgroups of lstm_persist_*: one per CU
+        n_lo = (need + 31) // 32 * 32
+        key = ("cu_streams", n_lo)
+        if key not in self._ws:
+            self._ws[key] = None
+            n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+            if self.h % 16 == 0 and n_cu == 256 and n_lo + 32 <= n_cu:
+                try:
+                    hip = C.CDLL("libamdhip64.so")
+
+                    def make(lo, hi):
+                        mask = (C.c_uint32 * (n_cu // 32))()
+                        for bit in range(lo, hi):
+                            mask[bit // 32] |= 1 << (bit % 32)
+                        handle = C.c_void_p()
+                        if hip.hipExtStreamCreateWithCUMask(C.byref(handle), len(mask), mask) != 0:
+                            raise RuntimeError("hipExtStreamCreateWithCUMask failed")
+                        return handle
+                    with torch.cuda.device(self.device):
+                        rec, side = make(0, n_lo), make(n_lo, n_cu)
+                    self._ws[key] = (rec, torch.cuda.ExternalStream(side.value, device=self.device))
+                except (OSError, RuntimeError, AttributeError):
+                    pass                                       # no masked streams on this stack: the phases run in line
+        return self._ws[key]
+
     def _upload_flags(self, dst, flags):
         """Host -> device copy of the teacher-forcing flags WITHOUT a host sync: a copy from pageable memory would make the host wait
         for the encoder of this step, and the GPU then idles while the host catches up at the start of the next one.  The flags
@@ -398,19 +433,47 @@ class SpeechEncoderDecoder:
         st = self._cur
         s = self._stream()
         wd = self._workspace("dec", st["ws_dec"])
-        check(lib.astk_decoder_bwd(C.byref(st["dd"]), C.byref(st["dp"]), C.byref(st["dg"]), _vp(st["enc_states"]), _vp(st["c0"]),
-                                   _vp(st["h0"]), _vp(st["y"]), _vp(st["emb_mask"]), _vp(st["rnn_masks"]), _vp(st["d_enc"]),
-                                   _vp(st["d_c0"]), _vp(st["d_h0"]), _vp(wd), wd.numel(), s))
-        if self.grad_buckets is not None:
-            self.grad_buckets.launch("dec")
+
+        def dec_bwd(phase, stream):
+            check(lib.astk_decoder_bwd_phase(C.byref(st["dd"]), C.byref(st["dp"]), C.byref(st["dg"]), _vp(st["enc_states"]), _vp(st["c0"]),
+                                             _vp(st["h0"]), _vp(st["y"]), _vp(st["emb_mask"]), _vp(st["rnn_masks"]), _vp(st["d_enc"]),
+                                             _vp(st["d_c0"]), _vp(st["d_h0"]), _vp(wd), wd.numel(), phase, stream))
+        joined, rec_stream = None, None
+        cu = self._cu_streams(st) if self.overlap_param_grads else None
+        if cu is not None:
+            # The encoder's backward recurrence (1 ms; one workgroup on each of 192 CUs, one wave per SIMD) leaves the device mostly
+            # idle and needs nothing from the decoder's parameter gradients (0.17 ms of GEMMs at full speed).  They run beside it:
+            # the recurrence kernel on a stream masked to the first CUs, the parameter phase on a stream masked to the remaining ones
+            # (on unmasked streams the two slow each other down by as much as the overlap saves: scratch/overlap_probe.py),
+            # ordered after the chain phase by an event and joined before anything reads the gradient arena or reuses the workspace.
+            rec_stream, side = cu
+            main = torch.cuda.current_stream(self.device)
+            dec_bwd(1, s)                                    # ASTK_DEC_BWD_CHAIN
+            fork = torch.cuda.Event()
+            fork.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(fork)
+                dec_bwd(2, C.c_void_p(side.cuda_stream))     # ASTK_DEC_BWD_PARAMS
+                joined = torch.cuda.Event()
+                joined.record(side)
+        else:
+            dec_bwd(0, s)
+            if self.grad_buckets is not None:
+                self.grad_buckets.launch("dec")
         h, nd = self.h, self.n_dirs
         # encoder layers without a decoder counterpart keep the zero gradient they were allocated with
         for k in range(min(len(self.rnn_enc), len(self.rnn_dec))):
             st["d_cT"][:, k].copy_(st["d_c0"][k].view(-1, nd, h).permute(1, 0, 2))
             st["d_hT"][:, k].copy_(st["d_h0"][k].view(-1, nd, h).permute(1, 0, 2))
         wl = self._workspace("lstm", st["ws_lstm"])
-        check(lib.astk_lstm_stack_bwd(C.byref(st["ld"]), st["lp"], st["lg"], _vp(st["xlstm"]), _vp(st["enc_masks"]), _vp(st["d_enc"]),
-                                      _vp(st["d_cT"]), _vp(st["d_hT"]), _vp(st["d_xlstm"]), _vp(wl), wl.numel(), s))
+        check(lib.astk_lstm_stack_bwd_on(C.byref(st["ld"]), st["lp"], st["lg"], _vp(st["xlstm"]), _vp(st["enc_masks"]), _vp(st["d_enc"]),
+                                         _vp(st["d_cT"]), _vp(st["d_hT"]), _vp(st["d_xlstm"]), _vp(wl), wl.numel(), s, rec_stream))
+        if joined is not None:
+            # the side stream finished long ago (0.5 ms of work beside a 1 ms kernel); from here on everything is on one stream again,
+            # and the gradient exchange is launched from it
+            torch.cuda.current_stream(self.device).wait_event(joined)
+            if self.grad_buckets is not None:
+                self.grad_buckets.launch("dec")
         if self.grad_buckets is not None:
             self.grad_buckets.launch("enc")
         wc = self._workspace("cnn", st["ws_cnn"])

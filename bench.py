@@ -123,8 +123,13 @@ def main():
     Xh, yh = synth_batch(B, T, D, L, V, 20 + rank)                        # each rank owns its shard of the global batch
     X, y = torch.from_numpy(Xh).cuda(), torch.from_numpy(yh).cuda()
 
+    # The step runs on a stream of its own, not on the legacy default stream: the model overlaps the decoder's parameter
+    # gradients with the encoder's backward recurrence on CU-masked streams, and those synchronise implicitly with stream 0.
+    compute = torch.cuda.Stream()
+    torch.cuda.synchronize()
+
     def step():
-        with using_config("train", True):
+        with torch.cuda.stream(compute), using_config("train", True):
             loss = model.forward_loss(X=X, y=y, teach_ratio=TRAIN["teach_ratio"], random_out=0, add_noise=TRAIN["speech_noise"])
             model.cleargrads()
             loss.backward()

@@ -125,6 +125,14 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
 int astk_lstm_stack_bwd(const astk_lstm_stack_desc* d, const astk_lstm_params* params, const astk_lstm_grads* grads,
                         const float* x, const float* masks, const float* d_enc_states, const float* d_cT,
                         const float* d_hT, float* dx, void* ws, size_t ws_bytes, void* stream);
+/* Same, with the persistent recurrence kernel (all T steps of all cells in one launch, one workgroup on each of 192 CUs at cfg 2,
+ * latency-bound) enqueued on `recurrence_stream` and ordered against `stream` with events on both sides; everything else stays on
+ * `stream`.  Meant for a stream created with hipExtStreamCreateWithCUMask: with the recurrence confined to one set of CUs and
+ * independent work (astk_decoder_bwd_phase PARAMS) on a stream masked to the others, the two overlap without slowing the chain
+ * (scratch/overlap_probe.py).  NULL = astk_lstm_stack_bwd. */
+int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params* params, const astk_lstm_grads* grads,
+                           const float* x, const float* masks, const float* d_enc_states, const float* d_cT,
+                           const float* d_hT, float* dx, void* ws, size_t ws_bytes, void* stream, void* recurrence_stream);
 
 /* ---------------------------------------------------------------- attention step  (seq2seq.py:336-357)
  * q = Wa h + ba is computed by the caller (GEMM); this is the scan over enc_states:
@@ -178,6 +186,16 @@ int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* p, c
                      const float* enc, const float* c0, const float* h0, const int32_t* y,
                      const float* emb_mask, const float* rnn_masks,
                      float* d_enc, float* d_c0, float* d_h0, void* ws, size_t ws_bytes, void* stream);
+/* The same backward in two phases, for callers that overlap them: ASTK_DEC_BWD_CHAIN runs the reversed loop and writes
+ * everything the encoder's backward needs (d_enc, d_c0, d_h0); ASTK_DEC_BWD_PARAMS accumulates the parameter gradients from
+ * what the chain phase left in `ws` -- it only has to be ordered after the chain phase (an event), so it can run on a second
+ * stream beside the encoder's latency-bound backward recurrence, which leaves most of the device idle.  The caller joins that
+ * stream before it reads g or reuses ws.  ASTK_DEC_BWD_ALL = astk_decoder_bwd. */
+enum { ASTK_DEC_BWD_ALL = 0, ASTK_DEC_BWD_CHAIN = 1, ASTK_DEC_BWD_PARAMS = 2 };
+int astk_decoder_bwd_phase(const astk_decoder_desc* d, const astk_decoder_params* p, const astk_decoder_grads* g,
+                           const float* enc, const float* c0, const float* h0, const int32_t* y,
+                           const float* emb_mask, const float* rnn_masks,
+                           float* d_enc, float* d_c0, float* d_h0, void* ws, size_t ws_bytes, int phase, void* stream);
 /* eval-mode single step for predict()/beam (seq2seq.py:361-396 under train=False): states (n_layers,B,H)
  * and ht (B,A) are updated in place; logits (B,V) and alpha (B,T) written. */
 int astk_decoder_step_infer(const astk_decoder_desc* d, const astk_decoder_params* p, const float* enc,

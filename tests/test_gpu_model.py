@@ -429,3 +429,31 @@ def test_full_size_batch_permutation_and_gradient_accumulation():
     # accumulate: same batch again without cleargrads
     _, g2, _ = run(X[perm].contiguous(), y[perm].contiguous(), clear=False)
     assert float((g2 - 2 * g1).abs().max()) <= 2e-4 * gscale
+
+
+def test_overlapped_backward_equals_inline_backward():
+    """On a stream of its own the model runs the decoder's parameter gradients on a CU-masked side stream beside the encoder's
+    backward recurrence (which moves to a stream masked to the other CUs): astk_decoder_bwd_phase + astk_lstm_stack_bwd_on.
+    Same batch, same weights: the gradients must equal those of the in-line backward on the default stream."""
+    from ast_amd.seq2seq import using_config
+    cfg = tiny_cfg(enc_layers=2, dec_layers=1, H=128, E=16, A=64, c0=8, c1=16, V=57, drop=0.0)
+    B, T, D, L, V = 4, 70, 80, 8, 57
+    P, X, y = _make(cfg, B, T, D, L, V)
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    res = []
+    for own_stream in (False, True):
+        m = _gpu_model(cfg, P, D, V)
+        m.inject = {"use_truth": [1] * (L - 1)}
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream() if own_stream else torch.cuda.current_stream()
+        with torch.cuda.stream(s), using_config("train", True):
+            loss = m.forward_loss(X=Xd, y=yd, teach_ratio=1.0)
+            m.cleargrads()
+            loss.backward()
+        torch.cuda.synchronize()
+        streams = [v for k, v in m._ws.items() if isinstance(k, tuple) and k[0] == "cu_streams"]
+        res.append((float(loss.data), m.arena.grad.clone(), streams))
+    assert res[0][2] == [] and len(res[1][2]) == 1 and res[1][2][0] is not None, "the masked streams were not used"
+    assert res[0][0] == res[1][0]
+    scale = float(res[0][1].abs().max())
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-5 * scale
