@@ -484,3 +484,37 @@ def test_rng_fills(lib):
     z = torch.zeros(n, device="cuda")
     ok(lib, lib.astk_fill_normal(vp(z), n, 1.0, 0.25, 99, 0, stream()))
     assert abs(float(z.mean()) - 1.0) < 2e-3 and abs(float(z.std()) - 0.25) < 2e-3
+
+
+def test_gemm_random_shapes_against_float64(lib):
+    """Seeded sweep over layouts, ragged extents, leading-dimension padding (poisoned with NaN), batches and output modes."""
+    rng = np.random.default_rng(2026)
+    pad4 = lambda n: (n + 3) // 4 * 4
+    for case in range(90):
+        layout = int(rng.integers(0, 3))
+        M, N = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        K = int(rng.choice([1, 3, 15, 16, 17, 31, 33, 64, 100, 257, 700]))
+        batch = int(rng.choice([1, 1, 3]))
+        mode = int(rng.integers(0, 3))
+        extra = 4 * int(rng.integers(0, 3))
+        A = rng.standard_normal((batch, M, K))
+        B = rng.standard_normal((batch, N, K))
+        ref = np.einsum("bmk,bnk->bmn", A, B)
+
+        def store(X, transpose):                      # (batch, rows, cols) -> padded device array, NaN in the padding
+            X = X.transpose(0, 2, 1) if transpose else X
+            P = np.full((batch, X.shape[1], pad4(X.shape[2]) + extra), np.nan)
+            P[:, :, :X.shape[2]] = X
+            return P
+        Ad, Bd = store(A, layout == 2), store(B, layout != 0)
+        a, b = dev(Ad), dev(Bd)
+        ldc = pad4(N) + extra
+        c0 = rng.standard_normal((batch, M, ldc))
+        c = dev(c0)
+        bias = dev(rng.standard_normal(N)) if (mode == 0 and case % 2 == 0) else None
+        ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(a), Ad.shape[2], vp(b), Bd.shape[2], vp(c), ldc, vp(bias) if bias is not None else None,
+                                  mode, 1, batch, Ad.shape[1] * Ad.shape[2], Bd.shape[1] * Bd.shape[2], M * ldc, stream()))
+        want = ref + (bias.cpu().double().numpy() if bias is not None else 0.0) + (c0[:, :, :N] if mode != 0 else 0.0)
+        msg = f"case {case}: layout {layout} M{M} N{N} K{K} batch {batch} mode {mode}"
+        close(c[:, :, :N], want, rtol=2e-5, msg=msg)
+        assert np.array_equal(c[:, :, N:].cpu().numpy(), c0[:, :, N:].astype(np.float32)), msg + ": wrote outside N"
