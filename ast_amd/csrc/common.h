@@ -145,8 +145,13 @@ int fill_zero(void* p, size_t bytes, hipStream_t s);
 // One launch that fills up to FILL_SEG_MAX separate 16-byte aligned regions with a 32-bit pattern (the sentinel fill of the
 // persistent kernels' hand-off buffers; a hipMemsetAsync per buffer costs ~5 us each).
 constexpr int FILL_SEG_MAX = 16;
-struct FillSegs { int n; void* p[FILL_SEG_MAX]; size_t bytes[FILL_SEG_MAX]; };
-static inline void fill_seg_add(FillSegs& f, void* p, size_t bytes) { if (bytes > 0 && f.n < FILL_SEG_MAX) { f.p[f.n] = p; f.bytes[f.n] = bytes; ++f.n; } }
+struct FillSegs { int n; void* p[FILL_SEG_MAX]; size_t bytes[FILL_SEG_MAX]; unsigned val[FILL_SEG_MAX]; unsigned own[FILL_SEG_MAX]; };
+static inline void fill_seg_add(FillSegs& f, void* p, size_t bytes) {          // filled with the launch's value
+  if (bytes > 0 && f.n < FILL_SEG_MAX) { f.p[f.n] = p; f.bytes[f.n] = bytes; f.own[f.n] = 0; f.val[f.n] = 0; ++f.n; }
+}
+static inline void fill_seg_add(FillSegs& f, void* p, size_t bytes, unsigned value) {   // filled with its own value
+  if (bytes > 0 && f.n < FILL_SEG_MAX) { f.p[f.n] = p; f.bytes[f.n] = bytes; f.own[f.n] = 1; f.val[f.n] = value; ++f.n; }
+}
 int fill_u32_segments(const FillSegs& f, unsigned value, hipStream_t s);
 // One launch for up to FILL_SEG_MAX independent device-to-device copies (16-byte aligned, sizes multiples of 4 bytes) and one for
 // up to FILL_SEG_MAX independent transposes: the per-call state shuffling (final states, transposed weights) used to be ~35 tiny

@@ -32,11 +32,12 @@ struct CnnPlan {
   float* Y[ASTK_MAX_CNN_LAYERS];
   float* HP[ASTK_MAX_CNN_LAYERS];   // i < n-1
   float* Wr[ASTK_MAX_CNN_LAYERS];   // repacked weights (i=0: padded (C0,K0p); i>=1: (C_i, kt*C_{i-1}))
-  double* stat;                     // [2][Cmax] column sums
+  double* stat[ASTK_MAX_CNN_LAYERS];  // per layer [2][C] column sums (double)
+  size_t zero_fwd_bytes, zero_bwd_bytes;  // one fill from stat[0] zeroes the statistics of all layers (forward) / and the dWr scratch (backward)
   float* bn[ASTK_MAX_CNN_LAYERS];   // [4][C]: mean, inv_std, scale, shift
   float* G;                         // [rows_max][Cmax] gradient wrt post-ReLU output (row layout)
   float* DY[ASTK_MAX_CNN_LAYERS];   // padded dY (i>=1) / plain dY (i=0)
-  float* dWr;                       // scratch for re-packed weight gradients
+  float* dWr[ASTK_MAX_CNN_LAYERS];    // per layer scratch for re-packed weight gradients
   float* Wd;                        // phase weights for dgrad
   size_t bytes;
 };
@@ -69,7 +70,7 @@ int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
   P.K0p = (P.K0 + 3) / 4 * 4;
   Carver c(ws);
   P.P0 = c.take<float>((size_t)P.rows[0] * P.K0p);
-  size_t wd_max = 0, dwr_max = (size_t)d->C[0] * P.K0p;
+  size_t wd_max = 0;
   for (int i = 0; i < P.n; ++i) {
     P.Y[i] = c.take<float>((size_t)P.rows[i] * P.Cn[i]);
     P.bn[i] = c.take<float>(4 * (size_t)P.Cn[i]);
@@ -96,13 +97,17 @@ int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
       P.DY[i] = c.take<float>((size_t)d->B * P.F * (P.Tn[i] + P.dF[i] + P.dB[i]) * P.Cn[i]);
       size_t wd = (size_t)P.Cn[i - 1] * na_max * P.Cn[i];
       wd_max = wd_max > wd ? wd_max : wd;
-      size_t dw = (size_t)P.Cn[i] * KT * P.Cn[i - 1];
-      dwr_max = dwr_max > dw ? dwr_max : dw;
     }
   }
-  P.stat = c.take<double>(2 * cmax);
+  // the buffers that have to be zero before use, back to back: ONE fill per pass instead of one per layer and buffer
+  const size_t off_stat = align_up(c.off, 256);
+  for (int i = 0; i < P.n; ++i) P.stat[i] = c.take<double>(2 * (size_t)P.Cn[i]);
+  const size_t off_dwr = align_up(c.off, 256);
+  for (int i = 0; i < P.n; ++i)
+    P.dWr[i] = c.take<float>(i == 0 ? (size_t)d->C[0] * P.K0p : (size_t)P.Cn[i] * d->kt[i] * P.Cn[i - 1]);
+  P.zero_fwd_bytes = off_dwr - off_stat;
+  P.zero_bwd_bytes = c.off - off_stat;
   P.G = c.take<float>(rowsmax_c);
-  P.dWr = c.take<float>(dwr_max);
   P.Wd = c.take<float>(wd_max ? wd_max : 4);
   P.bytes = c.total();
   return 0;
@@ -399,12 +404,12 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
     }
     // ---- batch statistics -> scale/shift
     if (train) {
-      ASTK_TRY(fill_zero(P.stat, 2 * (size_t)C * sizeof(double), s));
-      hipLaunchKernelGGL(k_colstats, colreduce_grid(rows, C), dim3(256), 0, s, P.Y[i], rows, C, P.stat);
+      if (i == 0) ASTK_TRY(fill_zero(P.stat[0], P.zero_fwd_bytes, s));   // the statistics of every layer
+      hipLaunchKernelGGL(k_colstats, colreduce_grid(rows, C), dim3(256), 0, s, P.Y[i], rows, C, P.stat[i]);
       ASTK_LAUNCH_CHECK();
-      if (exchange) ASTK_CHECK(exchange(user, P.stat, 2 * C, stream) == 0, "conv_bn_relu_fwd: statistics exchange failed (layer %d)", i);
+      if (exchange) ASTK_CHECK(exchange(user, P.stat[i], 2 * C, stream) == 0, "conv_bn_relu_fwd: statistics exchange failed (layer %d)", i);
     }
-    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, s, P.stat, C, (double)rows * (exchange ? world : 1), L[i].gamma, L[i].beta,
+    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, s, P.stat[i], C, (double)rows * (exchange ? world : 1), L[i].gamma, L[i].beta,
                        L[i].avg_mean, L[i].avg_var, P.bn[i], d->bn_eps, d->bn_decay, train);
     ASTK_LAUNCH_CHECK();
     if (i < P.n - 1) {
@@ -450,13 +455,13 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
   for (int i = P.n - 1; i >= 0; --i) {
     const int C = P.Cn[i], rows = P.rows[i];
     // ---- ReLU + BatchNorm backward: G (grad wrt post-ReLU) -> DY[i] (grad wrt raw conv output)
-    ASTK_TRY(fill_zero(P.stat, 2 * (size_t)C * sizeof(double), s));
-    hipLaunchKernelGGL(k_bn_bwd_stats, colreduce_grid(rows, C), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], rows, C, P.stat);
+    if (i == P.n - 1) ASTK_TRY(fill_zero(P.stat[0], P.zero_bwd_bytes, s));   // statistics and dWr scratch of every layer
+    hipLaunchKernelGGL(k_bn_bwd_stats, colreduce_grid(rows, C), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], rows, C, P.stat[i]);
     ASTK_LAUNCH_CHECK();
     if (exchange) {
-      hipLaunchKernelGGL(k_bn_param_grads, dim3(cdiv(C, 256)), dim3(256), 0, s, P.stat, C, Gr[i].dgamma, Gr[i].dbeta);
+      hipLaunchKernelGGL(k_bn_param_grads, dim3(cdiv(C, 256)), dim3(256), 0, s, P.stat[i], C, Gr[i].dgamma, Gr[i].dbeta);
       ASTK_LAUNCH_CHECK();
-      ASTK_CHECK(exchange(user, P.stat, 2 * C, stream) == 0, "conv_bn_relu_bwd: statistics exchange failed (layer %d)", i);
+      ASTK_CHECK(exchange(user, P.stat[i], 2 * C, stream) == 0, "conv_bn_relu_bwd: statistics exchange failed (layer %d)", i);
     }
     const int Tp = P.Tn[i] + P.dF[i] + P.dB[i];
     if (P.dF[i] + P.dB[i] > 0) {
@@ -464,29 +469,27 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
                          P.dB[i], C);
       ASTK_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(gridn((size_t)rows * C / 4)), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], P.stat, P.DY[i], rows, C,
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(gridn((size_t)rows * C / 4)), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], P.stat[i], P.DY[i], rows, C,
                        P.Tn[i], P.dF[i], P.dB[i], exchange ? nullptr : Gr[i].dgamma, exchange ? nullptr : Gr[i].dbeta,
                        1.f / ((float)rows * (exchange ? world : 1)));
     ASTK_LAUNCH_CHECK();
     if (i == 0) {
       // ---- wgrad layer 0: dW0p[C0][K0p] = DY0^T P0
-      ASTK_TRY(fill_zero(P.dWr, (size_t)C * P.K0p * sizeof(float), s));
       const int ks = ksplit_for(1, rows);
-      ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(C, P.K0p, rows, mat(P.DY[0], C), mat(P.P0, P.K0p), P.dWr, P.K0p, nullptr, GEMM_ATOMIC, ks), s));
-      ASTK_TRY(add2d_f32(Gr[0].dW, P.K0, P.dWr, P.K0p, C, P.K0, s));
+      ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(C, P.K0p, rows, mat(P.DY[0], C), mat(P.P0, P.K0p), P.dWr[0], P.K0p, nullptr, GEMM_ATOMIC, ks), s));
+      ASTK_TRY(add2d_f32(Gr[0].dW, P.K0, P.dWr[0], P.K0p, C, P.K0, s));
     } else {
       const int Ci = P.Cn[i - 1], KT = d->kt[i], st = d->st[i], pt = d->pt[i];
       const long dyrow = (long)Tp * C;                                  // per (b,f) group of the padded dY
       const long hprow = (long)(P.Tn[i - 1] + 2 * P.padA[i - 1]) * Ci;  // per (b,f) group of HP[i-1]
       // ---- wgrad: dWr[co][kt*Ci+ci] = sum_rows DY[row][co] * window(row)[k]
-      ASTK_TRY(fill_zero(P.dWr, (size_t)C * KT * Ci * sizeof(float), s));
       {
         MatView A = mat2(P.DY[i] + (long)P.dF[i] * C, P.Tn[i], dyrow, C);
         MatView Bm = mat2(P.HP[i - 1], P.Tn[i], hprow, (long)st * Ci);
         const long tiles = (long)cdiv(C, 128) * cdiv(KT * Ci, 128);
-        ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(C, KT * Ci, rows, A, Bm, P.dWr, (long)KT * Ci, nullptr, GEMM_ATOMIC, ksplit_for(tiles, rows)), s));
+        ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(C, KT * Ci, rows, A, Bm, P.dWr[i], (long)KT * Ci, nullptr, GEMM_ATOMIC, ksplit_for(tiles, rows)), s));
       }
-      hipLaunchKernelGGL(k_unpack_dw, dim3(gridn((size_t)C * Ci * KT)), dim3(256), 0, s, P.dWr, Gr[i].dW, C, Ci, KT);
+      hipLaunchKernelGGL(k_unpack_dw, dim3(gridn((size_t)C * Ci * KT)), dim3(256), 0, s, P.dWr[i], Gr[i].dW, C, Ci, KT);
       ASTK_LAUNCH_CHECK();
       // ---- dgrad: one window GEMM per stride phase rho of the input position t_in = rho + st*j
       for (int rho = 0; rho < st && rho < P.Tn[i - 1]; ++rho) {

@@ -64,7 +64,6 @@ struct DecPlan {
   float* WaT;    // [H][H]
   float* WuT[ASTK_MAX_RNN_LAYERS];  // [in][4H]
   float* WlT[ASTK_MAX_RNN_LAYERS];  // [H][4H]
-  float* ZERO;   // [B][max(A,H)] zeros
   float *LSE, *PART, *CESTAT, *ENCA, *MLB, *DXH;       // persistent path only
   unsigned* PCTR;
   void* attn_ws;
@@ -108,7 +107,6 @@ int make_plan(const astk_decoder_desc* d, void* ws, DecPlan& P) {
   P.WoT = c.take<float>((size_t)P.A * P.Vp);
   P.WcT = c.take<float>(2 * H * P.A);
   P.WaT = c.take<float>(H * H);
-  P.ZERO = c.take<float>(B * (size_t)(P.A > P.H ? P.A : P.H));
   P.attn_ws = c.take<char>(attn_ws_bytes(P.B, P.T, P.H));
   {
     int ns = 1, ch = 1;
@@ -329,11 +327,12 @@ int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
     fill_seg_add(fz, P.X0, (size_t)B * XI * sizeof(float));   // ht_{-1} half of the first concat buffer
     ASTK_TRY(fill_u32_segments(fz, 0u, s));
   }
-  ASTK_TRY(attn_ws_init(P.attn_ws, B, P.T, H, s));
   const int top = nl - 1;
   {
     int ns = 1, ch = 1;
-    if (decoder_persist_applicable(d, &ns, &ch)) {
+    const bool persist = decoder_persist_applicable(d, &ns, &ch);
+    if (!persist) ASTK_TRY(attn_ws_init(P.attn_ws, B, P.T, H, s));   // the persistent loop has its own counters
+    if (persist) {
       DecPersistBuffers bf;
       bf.TOK = P.TOK; bf.PRED = P.PRED; bf.X0 = P.X0; bf.G = P.G[0]; bf.C = P.C[0]; bf.HR = P.HR[0]; bf.Q = P.Q; bf.ALPHA = P.ALPHA;
       bf.CVH = P.CVH; bf.HT = P.HT; bf.LOGITS = P.LOGITS; bf.LOSSROWS = P.LOSSROWS; bf.LSE = P.LSE; bf.PART = P.PART;
@@ -441,8 +440,7 @@ int astk_decoder_bwd_phase(const astk_decoder_desc* d, const astk_decoder_params
     }
     ASTK_TRY(transpose_batch(tj, s));
   }
-  ASTK_TRY(fill_zero(P.ZERO, (size_t)B * (A > H ? A : H) * sizeof(float), s));
-  ASTK_TRY(attn_ws_init(P.attn_ws, B, T, H, s));
+  if (!persist) ASTK_TRY(attn_ws_init(P.attn_ws, B, T, H, s));   // the persistent loop has its own counters
   if (persist) {
     DecPersistBwdBuffers bf;
     bf.WoT = P.WoT; bf.WcT = P.WcT; bf.WlT = P.WlT[0]; bf.WuT = P.WuT[0]; bf.ENCA = P.ENCA; bf.ALPHA = P.ALPHA; bf.CVH = P.CVH; bf.ML = P.MLB;

@@ -563,12 +563,12 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.done = counters;
   a.abort_word = counters + (size_t)ncells * nbt * 64;
-  ASTK_HIP(hipMemsetAsync(counters, 0, ((size_t)ncells * nbt + 1) * 64 * sizeof(unsigned), s));
   dim3 grid(h / 16, nbt, ncells), blk(256);
   {
-    // hand-off buffers = the saved activations themselves: sentinel-filled before every launch
+    // hand-off buffers = the saved activations themselves: sentinel-filled before every launch (the counters / abort word ride along, zeroed)
     FillSegs f;
     f.n = 0;
+    fill_seg_add(f, counters, ((size_t)ncells * nbt + 1) * 64 * sizeof(unsigned), 0u);
     for (int i = 0; i < ncells; ++i) {
       if (f.n + 2 > FILL_SEG_MAX) { ASTK_TRY(fill_u32_segments(f, 0xffffffffu, s)); f.n = 0; }
       fill_seg_add(f, cells[i].HR, (size_t)T * B * h * sizeof(float));

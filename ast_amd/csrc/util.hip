@@ -236,6 +236,7 @@ inline unsigned grid_for(size_t n, int per = 256) {
 __global__ __launch_bounds__(256) void k_fill_segments(FillSegs f, unsigned value) {
   const int seg = blockIdx.y;
   if (seg >= f.n) return;
+  if (f.own[seg]) value = f.val[seg];
   const size_t n16 = f.bytes[seg] / 16;
   uint4* p = reinterpret_cast<uint4*>(f.p[seg]);
   const uint4 v = make_uint4(value, value, value, value);
