@@ -89,12 +89,19 @@ int make_plan(const astk_lstm_stack_desc* d, void* ws, bool with_masks, LstmPlan
   return 0;
 }
 
-__global__ void k_perm(int* perm, int* inv, int T) {
+// quirk Q1: the reverse stack reads frame X[-i] = (T - i) % T at step i -- an involution, so the frame permutation is its own inverse.
+// One launch writes it (perm = inv) and its expansions to (T*B) row indices: rows[i*B+b] = perm[i]*B + b.
+__global__ void k_perm_rows(int* perm, int* inv, int* rows_perm, int* rows_inv, int T, int B) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < T) {
-    const int f = (T - i) % T;   // quirk Q1: X[-i]
+    const int f = (T - i) % T;
     perm[i] = f;
     inv[f] = i;
+  }
+  if (i < T * B) {
+    const int r = ((T - i / B) % T) * B + (i % B);
+    rows_perm[i] = r;
+    rows_inv[i] = r;
   }
 }
 // dst[r][:] = src[idx[r]][:]  (float4 columns)
@@ -105,12 +112,6 @@ __global__ void k_gather_rows(float* __restrict__ dst, const float* __restrict__
     reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[(long)idx[r] * cols4 + c];
   }
 }
-// expands a frame permutation to (T*B) row indices: rows[i*B+b] = perm[i]*B + b
-__global__ void k_rowidx(const int* perm, int* rows, int T, int B) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < T * B) rows[i] = perm[i / B] * B + (i % B);
-}
-
 }  // namespace
 }  // namespace astk
 
@@ -136,11 +137,7 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
   const int T = P.T, B = P.B, h = P.h, H = P.nd * P.h;
   int* rows_perm = (int*)((char*)ws + P.bytes);
   int* rows_inv = (int*)((char*)rows_perm + align_up((size_t)T * B * sizeof(int), 256));
-  hipLaunchKernelGGL(k_perm, dim3(cdiv(T, 256)), dim3(256), 0, s, P.perm, P.inv, T);
-  ASTK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_rowidx, dim3(cdiv(T * B, 256)), dim3(256), 0, s, P.perm, rows_perm, T, B);
-  ASTK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_rowidx, dim3(cdiv(T * B, 256)), dim3(256), 0, s, P.inv, rows_inv, T, B);
+  hipLaunchKernelGGL(k_perm_rows, dim3(cdiv(T * B, 256)), dim3(256), 0, s, P.perm, P.inv, rows_perm, rows_inv, T, B);
   ASTK_LAUNCH_CHECK();
   const size_t bh = (size_t)B * h;
   if (lstm_persist_applicable(T, B, h, P.nl, P.nd)) {
