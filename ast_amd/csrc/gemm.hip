@@ -459,10 +459,11 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
       if (b_kr && a.B.tn <= 0) { a.B.tn = 0x7fffffff; a.B.sg = 0; a.B.st = a.B.ld; }
     }
   }
-  // Grid (measured on MI355X, scratch/gemm_bench.py): two co-resident workgroups per CU is the sweet spot of this kernel
-  // (one hides the other's LDS-store/barrier phase), so a launch with enough k-iterations is split evenly over 512
-  // workgroups -- 100-111 TFLOP/s on the train step's shapes against 60-93 for one-tile-per-workgroup launches.  Small
-  // products keep one tile per workgroup unless they have too few tiles to occupy the chip.
+  // Grid (measured on MI355X, scratch/gemm_bench.py): a launch with enough k-iterations is split evenly over 256 * wgs_per_cu
+  // workgroups (co-resident workgroups hide each other's LDS-store / barrier phases; the grid must be a multiple of 256 or the
+  // CUs are loaded unevenly: 600 workgroups for 1200 tiles ran 12 % slower than 768) -- 100-125 TFLOP/s on the train step's big
+  // shapes against 60-93 for one-tile-per-workgroup launches.  Smaller products keep one tile per workgroup unless they have too
+  // few tiles to occupy the chip; then their k range is split as well.
   static const int force_g = getenv("ASTK_GEMM_G") ? atoi(getenv("ASTK_GEMM_G")) : -1;   // tuning hook: 0 = one tile per WG
   long G = tiles;
   bool aligned = true;   // workgroup boundaries fall on tile boundaries
