@@ -431,12 +431,13 @@ def test_full_size_batch_permutation_and_gradient_accumulation():
     assert float((g2 - 2 * g1).abs().max()) <= 2e-4 * gscale
 
 
-def test_overlapped_backward_equals_inline_backward():
+@pytest.mark.parametrize("dec_layers", [1, 2])     # persistent decoder loop / per-launch decoder loop
+def test_overlapped_backward_equals_inline_backward(dec_layers):
     """On a stream of its own the model runs the decoder's parameter gradients on a CU-masked side stream beside the encoder's
     backward recurrence (which moves to a stream masked to the other CUs): astk_decoder_bwd_phase + astk_lstm_stack_bwd_on.
     Same batch, same weights: the gradients must equal those of the in-line backward on the default stream."""
     from ast_amd.seq2seq import using_config
-    cfg = tiny_cfg(enc_layers=2, dec_layers=1, H=128, E=16, A=64, c0=8, c1=16, V=57, drop=0.0)
+    cfg = tiny_cfg(enc_layers=2, dec_layers=dec_layers, H=128, E=16, A=64, c0=8, c1=16, V=57, drop=0.0)
     B, T, D, L, V = 4, 70, 80, 8, 57
     P, X, y = _make(cfg, B, T, D, L, V)
     Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
