@@ -1,0 +1,48 @@
+"""Exercises the data-parallel code path with the RCCL backend on ONE GPU (a process group of one rank): bucketed asynchronous
+all-reduces launched from the backward pass, the masked side streams, the non-default compute stream and the optional BatchNorm
+statistics exchange all run against the real backend; with one rank the result must equal the plain step."""
+import copy, os, random, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))   # run as a script from tests/
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+import torch, torch.distributed as td
+import bench
+from ast_amd import dist as adist, optimizers as O
+from ast_amd.seq2seq import SpeechEncoderDecoder, using_config
+from oracle.ast_ref import synth_batch
+torch.cuda.set_device(0)
+td.init_process_group("nccl", world_size=1, rank=0)
+adist.is_distributed = lambda: True                      # world of one: the collectives are identities but go through RCCL
+cfg = copy.deepcopy(bench.MODEL_CFG)
+B, T, D, L, V = 32, 800, 80, 40, cfg["rnn_config"]["dec_vocab_size"]
+X, y = synth_batch(B, T, D, L, V, 20)
+X, y = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+def run(dp):
+    m = SpeechEncoderDecoder(0, cfg).materialize(D, seed=0)
+    m.rng_seed = 1234
+    opt = O.Adam(alpha=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, amsgrad=True).setup(m)
+    opt.add_hook(O.WeightDecay(1e-4)); opt.add_hook(O.GradientClipping(2))
+    if dp:
+        m.grad_buckets = adist.make_grad_buckets(m)
+        opt.grad_sync = m.grad_buckets.finish
+        m.stat_exchange = adist.StatExchange(world=1)
+    random.seed("seed-ast-20h")
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    losses = []
+    with torch.cuda.stream(s):
+        for _ in range(4):
+            with using_config("train", True):
+                l = m.forward_loss(X=X, y=y, teach_ratio=0.8, random_out=0, add_noise=0.25)
+                m.cleargrads(); l.backward(); opt.update()
+            losses.append(l.data.clone())
+    torch.cuda.synchronize()
+    return [float(v) for v in losses], m.arena.data.clone()
+a, pa = run(False)
+b, pb = run(True)
+print("plain", a); print("dp   ", b)
+assert all(abs(x - z) <= 1e-4 * abs(x) for x, z in zip(a, b)), "losses differ"
+rel = float((pa - pb).abs().max() / pa.abs().max())
+print("max parameter difference after 4 steps (relative):", rel)
+assert rel < 1e-3
+td.destroy_process_group()
+print("ok")

@@ -458,3 +458,14 @@ def test_overlapped_backward_equals_inline_backward(dec_layers):
     assert res[0][0] == res[1][0]
     scale = float(res[0][1].abs().max())
     assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-5 * scale
+
+
+def test_data_parallel_path_against_rccl_with_one_rank():
+    """tests/dp_single_rank_rccl.py: a process group of ONE rank on the `nccl` (= RCCL) backend drives the real data-parallel code path
+    on this GPU -- bucketed asynchronous all-reduces launched from the backward pass, the BatchNorm statistics exchange through the
+    C callback, masked side streams, non-default compute stream -- and must reproduce the plain step (the collectives are
+    identities).  Multi-rank semantics are covered by tests/test_dist_gloo.py and the two-replica emulation above."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "dp_single_rank_rccl.py")], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-1500:] + r.stderr[-1500:]
