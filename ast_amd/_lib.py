@@ -92,6 +92,7 @@ SIGNATURES = {
                                          _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _I, _VP]),
     "astk_decoder_step_infer": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderParams), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                                           _VP, _SZ, _VP]),
+    "astk_spin": (C.c_int, [C.c_uint, _VP, _VP]),
     "astk_softmax_ce_fwd": (C.c_int, [_I, _I, _L, _VP, _VP, _L, _VP, _F, _VP, _VP, _VP]),
     "astk_grad_sqnorm": (C.c_int, [_VP, _VP, _F, _SZ, _VP, _VP]),
     "astk_decay_clip_amsgrad_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _SZ, _F, _F, _VP, _F, _F, _F, _F, _I, _VP]),

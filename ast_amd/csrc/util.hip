@@ -143,6 +143,13 @@ __global__ __launch_bounds__(256) void k_colsum_batch(ColsumJobs j) {
       [&](int col, int, float v) { atomicAdd(&dst[col], v); }, (int)blockIdx.x, (int)blockIdx.y, j.gy[q]);
 }
 
+// one wave that stays busy for `ticks` of the 100 MHz wall clock (bounded) and then bumps *flag
+__global__ void k_spin(unsigned long long ticks, unsigned* flag) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+  if (flag && threadIdx.x == 0) atomicAdd(flag, 1u);
+}
+
 __global__ void k_scale(float* x, size_t n, float s) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= s;
 }
@@ -409,6 +416,13 @@ int astk_fill_normal(float* out, size_t n, float mean, float sigma, uint64_t see
   ASTK_CHECK(out, "fill_normal: null pointer");
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_normal, dim3(grid_for((n + 1) / 2)), dim3(256), 0, (hipStream_t)stream, out, n, mean, sigma, seed, offset);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int astk_spin(unsigned usec, unsigned* flag, void* stream) {
+  ASTK_CHECK(usec <= 100000, "spin: at most 100 ms");
+  hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)usec * 100ull, flag);
   ASTK_LAUNCH_CHECK();
   return 0;
 }

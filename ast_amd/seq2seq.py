@@ -114,8 +114,11 @@ class SpeechEncoderDecoder:
         self._dec_c = self._dec_h = None
         self.grad_buckets = None        # ast_amd.dist.GradBuckets under data parallelism: ranges are all-reduced as they become final
         self.stat_exchange = None       # ast_amd.dist.StatExchange: BatchNorm statistics over the global batch (train mode only)
-        # decoder parameter gradients on a second stream beside the encoder's backward recurrence (ASTK_OVERLAP_PARAM_GRADS=0: in line)
-        self.overlap_param_grads = os.environ.get("ASTK_OVERLAP_PARAM_GRADS", "1") != "0"
+        # Opt-in (ASTK_OVERLAP_PARAM_GRADS=1): decoder parameter gradients on a CU-masked stream beside the encoder's backward
+        # recurrence.  Worth 0.03-0.08 ms per step when it works, but in processes that have created many streams (several models,
+        # other libraries) the masked queues fall into a state that costs 2-4 ms per step -- HIP multiplexes streams onto a few
+        # hardware queues -- and a pairwise concurrency probe does not see it coming.  Off by default for that reason.
+        self.overlap_param_grads = os.environ.get("ASTK_OVERLAP_PARAM_GRADS", "0") == "1"
         self.mask_pad_id = None
 
     # ------------------------------------------------------------------ parameters
@@ -371,10 +374,30 @@ class SpeechEncoderDecoder:
                         return handle
                     with torch.cuda.device(self.device):
                         rec, side = make(0, n_lo), make(n_lo, n_cu)
-                    self._ws[key] = (rec, torch.cuda.ExternalStream(side.value, device=self.device))
+                    rec_t = torch.cuda.ExternalStream(rec.value, device=self.device)
+                    side_t = torch.cuda.ExternalStream(side.value, device=self.device)
+                    main = torch.cuda.current_stream(self.device)
+                    # HIP multiplexes streams onto a few hardware queues; streams that share one are serialised whatever their events
+                    # say, and then the "overlap" costs a millisecond instead of saving a tenth.  Probe every pair once.
+                    if all(self._concurrent(a, b) for a, b in ((main, side_t), (main, rec_t), (rec_t, side_t))):
+                        self._ws[key] = (rec, side_t, rec_t)
                 except (OSError, RuntimeError, AttributeError):
                     pass                                       # no masked streams on this stack: the phases run in line
         return self._ws[key]
+
+    def _concurrent(self, a, b):
+        """True if a kernel on stream b runs while stream a is busy (one 300 us spin on a, a trivial kernel on b)."""
+        lib = _lib.load()
+        probe = self._ws.setdefault("probe", torch.zeros(4, device=self.device))
+        check(lib.astk_spin(300, None, C.c_void_p(a.cuda_stream)))
+        ea, eb = torch.cuda.Event(), torch.cuda.Event()
+        ea.record(a)
+        check(lib.astk_scale_f32(_vp(probe), 4, 1.0, C.c_void_p(b.cuda_stream)))
+        eb.record(b)
+        eb.synchronize()
+        overlapped = not ea.query()
+        ea.synchronize()
+        return overlapped
 
     def _upload_flags(self, dst, flags):
         """Host -> device copy of the teacher-forcing flags WITHOUT a host sync: a copy from pageable memory would make the host wait
@@ -446,7 +469,7 @@ class SpeechEncoderDecoder:
             # the recurrence kernel on a stream masked to the first CUs, the parameter phase on a stream masked to the remaining ones
             # (on unmasked streams the two slow each other down by as much as the overlap saves: scratch/overlap_probe.py),
             # ordered after the chain phase by an event and joined before anything reads the gradient arena or reuses the workspace.
-            rec_stream, side = cu
+            rec_stream, side = cu[0], cu[1]
             main = torch.cuda.current_stream(self.device)
             dec_bwd(1, s)                                    # ASTK_DEC_BWD_CHAIN
             fork = torch.cuda.Event()

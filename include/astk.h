@@ -225,6 +225,10 @@ int astk_fill_dropout_mask(float* out, size_t n, float ratio, uint64_t seed, uin
 /* out[i] = 1 + sigma*N(0,1): the multiplicative speech noise of seq2seq.py:300-302, generated on device. */
 int astk_fill_normal(float* out, size_t n, float mean, float sigma, uint64_t seed, uint64_t offset, void* stream);
 int astk_scale_f32(float* x, size_t n, float s, void* stream);
+/* One wavefront that keeps `stream` busy for `usec` microseconds (<= 100 000) and then increments *flag (may be NULL).  For probing
+ * whether two streams really execute concurrently: HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
+ * default), and two streams that share one are serialised whatever their events say (ast_amd/seq2seq.py:_cu_streams). */
+int astk_spin(unsigned usec, unsigned* flag, void* stream);
 
 /* Optional per-kernel HIP-event timing on the launch stream (bench.py's roofline legs; off by default).
  * astk_prof_end: res[0..1] attention-scan fwd (ms, launches); [2..3] attention-scan bwd; [4..6] GEMMs (ms, launches, flops);

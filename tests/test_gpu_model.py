@@ -433,7 +433,7 @@ def test_full_size_batch_permutation_and_gradient_accumulation():
 
 @pytest.mark.parametrize("dec_layers", [1, 2])     # persistent decoder loop / per-launch decoder loop
 def test_overlapped_backward_equals_inline_backward(dec_layers):
-    """On a stream of its own the model runs the decoder's parameter gradients on a CU-masked side stream beside the encoder's
+    """With overlap_param_grads (opt-in) and a stream of its own the model runs the decoder's parameter gradients on a CU-masked side stream beside the encoder's
     backward recurrence (which moves to a stream masked to the other CUs): astk_decoder_bwd_phase + astk_lstm_stack_bwd_on.
     Same batch, same weights: the gradients must equal those of the in-line backward on the default stream."""
     from ast_amd.seq2seq import using_config
@@ -444,6 +444,7 @@ def test_overlapped_backward_equals_inline_backward(dec_layers):
     res = []
     for own_stream in (False, True):
         m = _gpu_model(cfg, P, D, V)
+        m.overlap_param_grads = True                 # opt-in feature
         m.inject = {"use_truth": [1] * (L - 1)}
         torch.cuda.synchronize()
         s = torch.cuda.Stream() if own_stream else torch.cuda.current_stream()
