@@ -184,7 +184,7 @@ __global__ void k_normal(float* out, size_t n, float mean, float sigma, uint64_t
 }
 
 // ---- optimizer
-__global__ void k_sqnorm(const float* g, const float* p, float l2, size_t n, double* out) {
+__global__ void k_sqnorm(const float* g, const float* p, float gsc, float l2, size_t n, double* out) {
   __shared__ double red[4];
   double s = 0.0;
   const size_t n4 = n / 4;
@@ -192,25 +192,26 @@ __global__ void k_sqnorm(const float* g, const float* p, float l2, size_t n, dou
   const float4* p4 = reinterpret_cast<const float4*>(p);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float4 a = g4[i], b = p4[i];
-    float x = a.x + l2 * b.x, y = a.y + l2 * b.y, z = a.z + l2 * b.z, w = a.w + l2 * b.w;
+    // __fmul_rn: the scaled gradient is rounded before the decay term is added, exactly as if the buffer had been scaled first
+    float x = __fmul_rn(a.x, gsc) + l2 * b.x, y = __fmul_rn(a.y, gsc) + l2 * b.y, z = __fmul_rn(a.z, gsc) + l2 * b.z, w = __fmul_rn(a.w, gsc) + l2 * b.w;
     s += (double)(x * x + y * y) + (double)(z * z + w * w);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0)
-    for (size_t i = n4 * 4; i < n; ++i) { float x = g[i] + l2 * p[i]; s += (double)x * x; }
+    for (size_t i = n4 * 4; i < n; ++i) { float x = __fmul_rn(g[i], gsc) + l2 * p[i]; s += (double)x * x; }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
-__global__ void k_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, size_t n, float l2, float clip,
+__global__ void k_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, size_t n, float gsc, float l2, float clip,
                           const double* sqnorm, float lr_t, float b1, float b2, float eps, int amsgrad) {
   const float norm = (float)sqrt(*sqnorm);
   const float rate = clip / norm;                    // A7: r = c / n, applied only when r < 1
   const float gs = rate < 1.f ? rate : 1.f;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float pi = p[i];
-    const float gi = (g[i] + l2 * pi) * gs;
+    const float gi = (__fmul_rn(g[i], gsc) + l2 * pi) * gs;
     float mi = m[i], vi = v[i];
     mi += (1.f - b1) * (gi - mi);
     vi += (1.f - b2) * (gi * gi - vi);
@@ -225,12 +226,12 @@ __global__ void k_amsgrad(float* p, const float* g, float* m, float* v, float* v
   }
 }
 
-__global__ void k_sgd(float* p, const float* g, size_t n, float l2, float clip, const double* sqnorm, float lr) {
+__global__ void k_sgd(float* p, const float* g, size_t n, float gsc, float l2, float clip, const double* sqnorm, float lr) {
   const float norm = (float)sqrt(*sqnorm);
   const float rate = clip / norm;
   const float gs = rate < 1.f ? rate : 1.f;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    p[i] -= lr * (g[i] + l2 * p[i]) * gs;
+    p[i] -= lr * (__fmul_rn(g[i], gsc) + l2 * p[i]) * gs;
 }
 
 inline unsigned grid_for(size_t n, int per = 256) {
@@ -374,11 +375,14 @@ int astk_version(void) { return ASTK_VERSION; }
 const char* astk_last_error(void) { return astk::last_error(); }
 
 int astk_grad_sqnorm(const float* g, const float* p, float l2, size_t n, double* sqnorm, void* stream) {
+  return astk_grad_sqnorm_scaled(g, p, 1.f, l2, n, sqnorm, stream);
+}
+int astk_grad_sqnorm_scaled(const float* g, const float* p, float grad_scale, float l2, size_t n, double* sqnorm, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   ASTK_CHECK(g && p && sqnorm, "grad_sqnorm: null pointer");
   ASTK_CHECK(aligned16(g) && aligned16(p), "grad_sqnorm: buffers must be 16-byte aligned");
   ASTK_HIP(hipMemsetAsync(sqnorm, 0, sizeof(double), s));
-  hipLaunchKernelGGL(k_sqnorm, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, g, p, l2, n, sqnorm);
+  hipLaunchKernelGGL(k_sqnorm, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, g, p, grad_scale, l2, n, sqnorm);
   ASTK_LAUNCH_CHECK();
   return 0;
 }
@@ -386,9 +390,14 @@ int astk_grad_sqnorm(const float* g, const float* p, float l2, size_t n, double*
 int astk_decay_clip_amsgrad_step(float* p, const float* g, float* m, float* v, float* vhat, size_t n, float l2, float clip,
                                  const double* sqnorm, float lr_t, float beta1, float beta2, float eps, int amsgrad,
                                  void* stream) {
+  return astk_decay_clip_amsgrad_step_scaled(p, g, m, v, vhat, n, 1.f, l2, clip, sqnorm, lr_t, beta1, beta2, eps, amsgrad, stream);
+}
+int astk_decay_clip_amsgrad_step_scaled(float* p, const float* g, float* m, float* v, float* vhat, size_t n, float grad_scale, float l2,
+                                        float clip, const double* sqnorm, float lr_t, float beta1, float beta2, float eps, int amsgrad,
+                                        void* stream) {
   ASTK_CHECK(p && g && m && v && sqnorm && (vhat || !amsgrad), "amsgrad_step: null pointer");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_amsgrad, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vhat, n, l2, clip, sqnorm,
+  hipLaunchKernelGGL(k_amsgrad, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vhat, n, grad_scale, l2, clip, sqnorm,
                      lr_t, beta1, beta2, eps, amsgrad);
   ASTK_LAUNCH_CHECK();
   return 0;
@@ -396,9 +405,13 @@ int astk_decay_clip_amsgrad_step(float* p, const float* g, float* m, float* v, f
 
 int astk_decay_clip_sgd_step(float* p, const float* g, size_t n, float l2, float clip, const double* sqnorm, float lr,
                              void* stream) {
+  return astk_decay_clip_sgd_step_scaled(p, g, n, 1.f, l2, clip, sqnorm, lr, stream);
+}
+int astk_decay_clip_sgd_step_scaled(float* p, const float* g, size_t n, float grad_scale, float l2, float clip, const double* sqnorm,
+                                    float lr, void* stream) {
   ASTK_CHECK(p && g && sqnorm, "sgd_step: null pointer");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_sgd, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, n, l2, clip, sqnorm, lr);
+  hipLaunchKernelGGL(k_sgd, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, n, grad_scale, l2, clip, sqnorm, lr);
   ASTK_LAUNCH_CHECK();
   return 0;
 }

@@ -59,9 +59,11 @@ class GradBuckets:
     waits for everything and applies the 1/world mean.  xGMI is point-to-point and a 53 MB all-reduce is ~1 ms of an ~9.5 ms
     step: behind the encoder / CNN backward it costs nothing.  Numerically identical to `allreduce_grads` (same sums)."""
 
-    def __init__(self, arena, param_groups):
-        # param_groups: ordered {bucket name: [param names]}; every group must be one contiguous arena range
+    def __init__(self, arena, param_groups, defer_scale=False):
+        # param_groups: ordered {bucket name: [param names]}; every group must be one contiguous arena range.
+        # defer_scale: finish() leaves the SUM in the arena and returns 1/world for the optimizer kernels to apply on the fly.
         self.arena = arena
+        self.defer_scale = defer_scale
         self.ranges = {}
         covered = []
         for gname, names in param_groups.items():
@@ -92,6 +94,8 @@ class GradBuckets:
         for work in self.pending.values():
             work.wait()
         self.pending = {}
+        if self.defer_scale:
+            return 1.0 / world_size()
         self.arena.grad.mul_(1.0 / world_size())
 
 
@@ -101,7 +105,7 @@ def make_grad_buckets(model):
     for name in model.arena.shapes:
         link = name.split("/")[0]
         groups["cnn" if link.startswith("CNN_") else "enc" if link.endswith("_enc") else "dec"].append(name)
-    return GradBuckets(model.arena, groups)
+    return GradBuckets(model.arena, groups, defer_scale=True)
 
 
 def broadcast_params(arena, src=0):

@@ -32,6 +32,7 @@ class _Optimizer:
         self.t = 0
         self.sqnorm = None
         self.grad_sync = None      # set by ast_amd.dist for data-parallel runs: called before the hooks
+        self.grad_scale = 1.0
 
     def setup(self, model):
         self.target = model
@@ -54,13 +55,18 @@ class _Optimizer:
         a = m.arena
         if self.sqnorm is None:
             self.sqnorm = torch.zeros(1, dtype=torch.float64, device=a.device)
+        # grad_sync may leave the SUM over the replicas in the arena and return the factor that turns it into the mean:
+        # the kernels below apply it on the fly (one pass over 53 MB less per step than scaling in place)
+        self.grad_scale = 1.0
         if self.grad_sync is not None:
-            self.grad_sync(a)
+            r = self.grad_sync(a)
+            if isinstance(r, float):
+                self.grad_scale = r
         l2, clip = self._hook_values()
         s = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
         # the clip norm runs over every parameter (chainer's GradientClipping sums over target.params())
-        check(lib.astk_grad_sqnorm(C.c_void_p(a.grad.data_ptr()), C.c_void_p(a.data.data_ptr()), l2, a.size,
-                                   C.c_void_p(self.sqnorm.data_ptr()), s))
+        check(lib.astk_grad_sqnorm_scaled(C.c_void_p(a.grad.data_ptr()), C.c_void_p(a.data.data_ptr()), self.grad_scale, l2, a.size,
+                                          C.c_void_p(self.sqnorm.data_ptr()), s))
         if clip == float("inf"):
             clip = 3.0e38
         return lib, a, l2, clip, s
@@ -88,9 +94,9 @@ class Adam(_Optimizer):
         for off, n in self.target.enabled_ranges():
             def p(t):
                 return C.c_void_p(t.data_ptr() + 4 * off)
-            check(lib.astk_decay_clip_amsgrad_step(p(a.data), p(a.grad), p(self.m), p(self.v), p(self.vhat), n, l2, clip,
-                                                   C.c_void_p(self.sqnorm.data_ptr()), lr_t, self.beta1, self.beta2, self.eps,
-                                                   1 if self.amsgrad else 0, s))
+            check(lib.astk_decay_clip_amsgrad_step_scaled(p(a.data), p(a.grad), p(self.m), p(self.v), p(self.vhat), n, self.grad_scale, l2,
+                                                          clip, C.c_void_p(self.sqnorm.data_ptr()), lr_t, self.beta1, self.beta2,
+                                                          self.eps, 1 if self.amsgrad else 0, s))
 
 
 class SGD(_Optimizer):
@@ -102,5 +108,5 @@ class SGD(_Optimizer):
         lib, a, l2, clip, s = self._prepare()
         self.t += 1
         for off, n in self.target.enabled_ranges():
-            check(lib.astk_decay_clip_sgd_step(C.c_void_p(a.data.data_ptr() + 4 * off), C.c_void_p(a.grad.data_ptr() + 4 * off), n, l2,
-                                               clip, C.c_void_p(self.sqnorm.data_ptr()), self.lr, s))
+            check(lib.astk_decay_clip_sgd_step_scaled(C.c_void_p(a.data.data_ptr() + 4 * off), C.c_void_p(a.grad.data_ptr() + 4 * off), n,
+                                                      self.grad_scale, l2, clip, C.c_void_p(self.sqnorm.data_ptr()), self.lr, s))

@@ -218,6 +218,15 @@ int astk_decay_clip_amsgrad_step(float* p, const float* g, float* m, float* v, f
                                  float eps, int amsgrad, void* stream);
 int astk_decay_clip_sgd_step(float* p, const float* g, size_t n, float l2, float clip, const double* sqnorm,
                              float lr, void* stream);
+/* The same three with the gradient read as grad_scale * g: under data parallelism g holds the SUM over the replicas after the
+ * all-reduce and grad_scale = 1/world makes it the mean without a separate pass over the buffer (the product is rounded before
+ * the decay term is added, exactly as a separate scaling pass would round it). */
+int astk_grad_sqnorm_scaled(const float* g, const float* p, float grad_scale, float l2, size_t n, double* sqnorm, void* stream);
+int astk_decay_clip_amsgrad_step_scaled(float* p, const float* g, float* m, float* v, float* vhat, size_t n, float grad_scale,
+                                        float l2, float clip, const double* sqnorm, float lr_t, float beta1, float beta2,
+                                        float eps, int amsgrad, void* stream);
+int astk_decay_clip_sgd_step_scaled(float* p, const float* g, size_t n, float grad_scale, float l2, float clip,
+                                    const double* sqnorm, float lr, void* stream);
 
 /* ---------------------------------------------------------------- utilities
  * Dropout keep-masks (Chainer-sem A5): out[i] = (u_i >= ratio) / (1-ratio), u from a counter-based hash RNG. */

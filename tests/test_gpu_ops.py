@@ -518,3 +518,36 @@ def test_gemm_random_shapes_against_float64(lib):
         msg = f"case {case}: layout {layout} M{M} N{N} K{K} batch {batch} mode {mode}"
         close(c[:, :, :N], want, rtol=2e-5, msg=msg)
         assert np.array_equal(c[:, :, N:].cpu().numpy(), c0[:, :, N:].astype(np.float32)), msg + ": wrote outside N"
+
+
+def test_optimizer_grad_scale_equals_scaling_first(lib):
+    """astk_*_scaled read the gradient as grad_scale * g (the 1/world mean of data parallelism applied on the fly, rounded like a
+    separate scaling pass would round it): same result as scaling the buffer first and calling the unscaled entry points, up to the
+    summation order of the float64 norm (atomics), which can move the clip factor by an ulp."""
+    n, gs, l2, clip = 100003, float(np.float32(1.0 / 3.0)), 1e-4, 2.0     # not a power of two: the product rounds
+    g = torch.Generator(device="cuda").manual_seed(4)
+    p0 = torch.randn(n, device="cuda", generator=g)
+    grad = torch.randn(n, device="cuda", generator=g) * 3
+    res = []
+    for scaled in (False, True):
+        p, m, v, vh = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        gr = grad.clone() if scaled else grad * gs
+        sq = torch.zeros(1, dtype=torch.float64, device="cuda")
+        for t in range(1, 4):
+            lr_t = 1e-3 * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t)
+            if scaled:
+                ok(lib, lib.astk_grad_sqnorm_scaled(vp(gr), vp(p), gs, l2, n, vp(sq), stream()))
+                ok(lib, lib.astk_decay_clip_amsgrad_step_scaled(vp(p), vp(gr), vp(m), vp(v), vp(vh), n, gs, l2, clip, vp(sq), lr_t, 0.9, 0.999, 1e-8, 1, stream()))
+            else:
+                ok(lib, lib.astk_grad_sqnorm(vp(gr), vp(p), l2, n, vp(sq), stream()))
+                ok(lib, lib.astk_decay_clip_amsgrad_step(vp(p), vp(gr), vp(m), vp(v), vp(vh), n, l2, clip, vp(sq), lr_t, 0.9, 0.999, 1e-8, 1, stream()))
+        res.append((p.clone(), float(sq.item())))
+    assert abs(res[0][1] - res[1][1]) <= 1e-7 * res[0][1]
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-6 * float(res[0][0].abs().max())
+    ps = [p0.clone(), p0.clone()]
+    sq = torch.zeros(1, dtype=torch.float64, device="cuda")
+    gsc = grad * gs
+    ok(lib, lib.astk_grad_sqnorm(vp(gsc), vp(ps[0]), l2, n, vp(sq), stream()))
+    ok(lib, lib.astk_decay_clip_sgd_step(vp(ps[0]), vp(gsc), n, l2, clip, vp(sq), 0.05, stream()))
+    ok(lib, lib.astk_decay_clip_sgd_step_scaled(vp(ps[1]), vp(grad), n, gs, l2, clip, vp(sq), 0.05, stream()))
+    assert torch.equal(ps[0], ps[1])          # one norm, one clip factor: here the two paths are bit-identical
