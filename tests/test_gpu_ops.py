@@ -551,3 +551,16 @@ def test_optimizer_grad_scale_equals_scaling_first(lib):
     ok(lib, lib.astk_decay_clip_sgd_step(vp(ps[0]), vp(gsc), n, l2, clip, vp(sq), 0.05, stream()))
     ok(lib, lib.astk_decay_clip_sgd_step_scaled(vp(ps[1]), vp(grad), n, gs, l2, clip, vp(sq), 0.05, stream()))
     assert torch.equal(ps[0], ps[1])          # one norm, one clip factor: here the two paths are bit-identical
+
+
+def test_spin_keeps_the_stream_busy(lib):
+    """astk_spin: the concurrency probe's tool -- one wave busy for the requested time, then a flag increment."""
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    ok(lib, lib.astk_spin(500, vp(flag), stream()))
+    e1.record()
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1 and 0.4 <= e0.elapsed_time(e1) <= 5.0
+    assert lib.astk_spin(200000, None, stream()) != 0          # bounded: at most 100 ms
