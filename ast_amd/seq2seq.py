@@ -105,6 +105,8 @@ class SpeechEncoderDecoder:
         self._frozen = set()
         self._ws = {}
         self._shape_cache = {}
+        self._pools = {}                # grow-only device buffers shared by all batch shapes (_pool)
+        self._bstate = {}               # small zero-initialised state tensors, per batch size
         self.inject = {}          # test hooks: enc_masks / emb_mask / rnn_masks / noise / use_truth
         self.rng_seed = 0x5EED
         self._rng_offset = 0
@@ -187,6 +189,20 @@ class SpeechEncoderDecoder:
             self._ws[key] = t
         return t
 
+    def _pool(self, name, shape, dtype=torch.float32):
+        """A view of a persistent, grow-only device buffer: real batches come in hundreds of (T, L) combinations (bucket width 80
+        frames, 2..max_pred targets), and a fresh set of 80 MB activation tensors per combination costs 40 ms per step in
+        allocations and never gives the memory back.  Only data that is fully rewritten by every step lives here."""
+        n = 1
+        for d_ in shape:
+            n *= int(d_)
+        buf = self._pools.get(name)
+        if buf is None or buf.numel() < n or buf.dtype != dtype:
+            buf = torch.empty(int(n * 1.25) + 64, dtype=dtype, device=self.device)
+            self._pools[name] = buf
+            self._shape_cache.clear()          # cached views would keep the outgrown storage alive
+        return buf[:n].view(shape)
+
     def _shape_state(self, B, T, D, L):
         key = (B, T, D, L)
         st = self._shape_cache.get(key)
@@ -245,18 +261,24 @@ class SpeechEncoderDecoder:
         dg.dWo, dg.dbo = a.g("out/W"), a.g("out/b")
         S = max(L, 2) - 1
         f32 = dict(dtype=torch.float32, device=dev)
+        # pooled first (growing a pool clears the shape cache), then the per-batch-size state, then the views of this shape
+        big = dict(xlstm=self._pool("xlstm", (T2, B, feat)), d_xlstm=self._pool("d_xlstm", (T2, B, feat)),
+                   enc_states=self._pool("enc_states", (B, T2, H)), d_enc=self._pool("d_enc", (B, T2, H)),
+                   pred=self._pool("pred", (S, B), torch.int32), flags=self._pool("flags", (S,), torch.int32))
+        bs = self._bstate.get(B)
+        if bs is None:
+            # zero-initialised and only partly written (encoder layers without a decoder counterpart keep their zero gradient)
+            bs = dict(cT=torch.zeros(nd, nl, B, h, **f32), hT=torch.zeros(nd, nl, B, h, **f32),
+                      d_cT=torch.zeros(nd, nl, B, h, **f32), d_hT=torch.zeros(nd, nl, B, h, **f32),
+                      c0=torch.zeros(nld, B, H, **f32), h0=torch.zeros(nld, B, H, **f32),
+                      d_c0=torch.zeros(nld, B, H, **f32), d_h0=torch.zeros(nld, B, H, **f32), loss=torch.zeros(1, **f32))
+            self._bstate[B] = bs
         st = dict(key=key, B=B, T=T, D=D, L=L, T2=T2, feat=feat, S=S, cd=cd, cp=cp, cg=cg, ld=ld, lp=lp, lg=lg, dd=dd, dp=dp, dg=dg,
-                  xlstm=torch.empty(T2, B, feat, **f32), d_xlstm=torch.empty(T2, B, feat, **f32),
-                  enc_states=torch.empty(B, T2, H, **f32), d_enc=torch.empty(B, T2, H, **f32),
-                  cT=torch.zeros(nd, nl, B, h, **f32), hT=torch.zeros(nd, nl, B, h, **f32),
-                  d_cT=torch.zeros(nd, nl, B, h, **f32), d_hT=torch.zeros(nd, nl, B, h, **f32),
-                  c0=torch.zeros(nld, B, H, **f32), h0=torch.zeros(nld, B, H, **f32),
-                  d_c0=torch.zeros(nld, B, H, **f32), d_h0=torch.zeros(nld, B, H, **f32),
-                  loss=torch.zeros(1, **f32), pred=torch.zeros(S, B, dtype=torch.int32, device=dev),
-                  flags=torch.ones(S, dtype=torch.int32, device=dev),
                   ws_cnn=int(lib.astk_conv_bn_relu_workspace_bytes(C.byref(cd))),
                   ws_lstm=int(lib.astk_lstm_stack_workspace_bytes(C.byref(ld))),
                   ws_dec=int(lib.astk_decoder_workspace_bytes(C.byref(dd))))
+        st.update(big)
+        st.update(bs)
         assert st["ws_cnn"] and st["ws_lstm"] and st["ws_dec"], lib.astk_last_error().decode()
         self._shape_cache[key] = st
         return st
@@ -273,11 +295,7 @@ class SpeechEncoderDecoder:
             return None if m is None else m.to(self.device, torch.float32).contiguous()
         if not config.train or ratio <= 0:
             return None
-        key = ("mask", name, shape)
-        t = self._ws.get(key)
-        if t is None:
-            t = torch.empty(shape, dtype=torch.float32, device=self.device)
-            self._ws[key] = t
+        t = self._pool("mask_" + name, shape)
         lib = _lib.load()
         check(lib.astk_fill_dropout_mask(_vp(t), t.numel(), float(ratio), self.rng_seed, self._rng(t.numel()), self._stream()))
         return t
@@ -303,10 +321,7 @@ class SpeechEncoderDecoder:
             if "noise" in self.inject:
                 noise = self.inject["noise"].to(self.device, torch.float32).contiguous()
             else:
-                noise = self._ws.get(("noise", X.shape))
-                if noise is None:
-                    noise = torch.empty_like(X)
-                    self._ws[("noise", X.shape)] = noise
+                noise = self._pool("noise", tuple(X.shape))
                 check(lib.astk_fill_normal(_vp(noise), noise.numel(), 1.0, float(add_noise), self.rng_seed ^ 0xABCDEF,
                                            self._rng(noise.numel()), self._stream()))
         st["noise"] = noise
