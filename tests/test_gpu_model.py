@@ -470,3 +470,30 @@ def test_data_parallel_path_against_rccl_with_one_rank():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "dp_single_rank_rccl.py")], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_prefetching_loader_yields_the_same_batches_as_the_plain_one(tmp_path):
+    """On a GPU the loader stages batch k+1 on a helper thread into a ring of three reused pinned buffers while batch k is in use
+    (ast_amd/dataloader.py:_PinnedRing); the batches must be those of the plain host path -- also when the consumer is slow or
+    fast, and across more batches than the ring has slots."""
+    import time
+    from ast_amd.dataloader import SyntheticDataLoader
+    data = {"dataloader": "synthetic", "vocab_size": 31, "feat_dim": 13, "n_utts": {"syn_train": 61, "syn_dev": 5},
+            "frames": [20, 400], "targets": [1, 30], "buckets_num": 4, "buckets_width": 80, "max_pred": 12,
+            "zero_input": 0.0, "train_scale": 1, "dec_key": "bpe_w"}
+    for delay in (0.0, 0.01):
+        # fresh loaders per pass: batch_plan shuffles the buckets in place, like the reference
+        ref = SyntheticDataLoader(data, str(tmp_path), -1)
+        gpu = SyntheticDataLoader(data, str(tmp_path), 0)
+        random.seed("seed-ast-20h")
+        want = [(b["utts"], b["X"].clone(), b["y"].clone()) for b in ref.get_batch(4, "syn_train", train=True, labels=True)]
+        assert len(want) > 9
+        random.seed("seed-ast-20h")
+        got = []
+        for b in gpu.get_batch(4, "syn_train", train=True, labels=True):
+            assert b["X"].is_cuda and b["y"].is_cuda
+            time.sleep(delay)
+            got.append((b["utts"], b["X"].cpu(), b["y"].cpu()))
+        assert len(got) == len(want)
+        for (u0, x0, y0), (u1, x1, y1) in zip(want, got):
+            assert u0 == u1 and torch.equal(x0, x1) and torch.equal(y0, y1)
