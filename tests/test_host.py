@@ -219,3 +219,59 @@ def test_bleu_matches_hand_computation(tmp_path):
     assert abs(ev.calc_bleu({"u1": ref, "u2": "the cat is here".split()}) - 1.0) < 1e-12
     ev.write_to_file({"u1": ref, "u2": hyp}, str(tmp_path / "out.txt"))
     assert (tmp_path / "out.txt").read_text() == "the cat is on the mat\nthe the the cat\n"
+
+
+def _write_corpus(tmp_path, nested):
+    """A miniature corpus in the reference's on-disk schemas: info {set: {utt: {'sp': frames}}}, map {set: {utt: {dec_key: [bytes]}}},
+    vocab {dec_key: {'w2i', 'i2w', 'freq'}}, per-utterance .npy files (optionally under <speaker>/ sub-directories)."""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    words = [b"_PAD", b"_GO", b"_EOS", b"_UNK", b"hel@@", b"lo", b"wor@@", b"ld", b"a"]
+    vocab = {"bpe_w": {"w2i": {w: i for i, w in enumerate(words)}, "i2w": {i: w for i, w in enumerate(words)}, "freq": {}}}
+    info, mp, speech = {}, {}, {}
+    for set_key, n in (("fisher_train", 11), ("fisher_dev", 3)):
+        info[set_key], mp[set_key], speech[set_key] = {}, {}, {}
+        for i in range(n):
+            utt = "spk{0:d}_{1:03d}".format(i % 2, i)
+            t = int(rng.integers(30, 330))
+            x = rng.standard_normal((t, 5)).astype(np.float32)
+            info[set_key][utt] = {"sp": t}
+            mp[set_key][utt] = {"bpe_w": [words[int(j)] for j in rng.integers(4, 9, size=int(rng.integers(1, 9)))] + ([b"zzz"] if i == 0 else [])}
+            speech[set_key][utt] = x
+            d = tmp_path / "speech" / set_key / ("spk{0:d}".format(i % 2) if nested else "")
+            os.makedirs(d, exist_ok=True)
+            np.save(d / (utt + ".npy"), x)
+    for name, obj in (("info.dict", info), ("map.dict", mp), ("vocab.dict", vocab), ("speech.blob", speech)):
+        pickle.dump(obj, open(tmp_path / name, "wb"))
+    return info, mp, speech
+
+
+@pytest.mark.parametrize("kind", ["fisher-flat", "fisher-nested", "globalphone"])
+def test_file_loaders_follow_the_reference_schemas(tmp_path, kind):
+    """dataloader.py:95-164 / :185-297: per-utterance .npy files (flat or <prefix>/<utt>.npy) and the pickled blob; targets through
+    w2i with UNK, GO ... EOS, truncation to max_pred; zero padding; get_hyps joins BPE pieces."""
+    import numpy as np
+    from ast_amd.dataloader import SYMBOLS, FisherDataLoader, GlobalPhoneDataLoader
+    info, mp, speech = _write_corpus(tmp_path, nested=(kind == "fisher-nested"))
+    data = {"map_path": str(tmp_path / "map.dict"), "vocab_path": str(tmp_path / "vocab.dict"), "info_path": str(tmp_path / "info.dict"),
+            "speech_path": str(tmp_path / ("speech.blob" if kind == "globalphone" else "speech")), "buckets_num": 4, "buckets_width": 80,
+            "train_scale": 1, "dec_key": "bpe_w", "max_pred": 6, "zero_input": 0.0}
+    dl = (GlobalPhoneDataLoader if kind == "globalphone" else FisherDataLoader)(data, str(tmp_path), -1)
+    assert os.path.exists(tmp_path / "buckets_sp.dict") and dl.n_utts == {"fisher_train": 11, "fisher_dev": 3}
+    random.seed(3)
+    seen = []
+    for batch in dl.get_batch(4, "fisher_train", train=True, labels=True):
+        X, y = batch["X"].numpy(), batch["y"].numpy()
+        for i, u in enumerate(batch["utts"]):
+            x = speech["fisher_train"][u]
+            assert np.array_equal(X[i, :len(x)], x) and not X[i, len(x):].any()
+            ids = [dl.vocab["bpe_w"]["w2i"].get(w, SYMBOLS.UNK_ID) for w in mp["fisher_train"][u]["bpe_w"]]
+            want = [SYMBOLS.GO_ID] + ids[:4] + [SYMBOLS.EOS_ID]
+            assert list(y[i, :len(want)]) == want and not y[i, len(want):].any()
+        assert len({min(info["fisher_train"][u]["sp"] // 80, 3) for u in batch["utts"]}) == 1
+        seen += batch["utts"]
+    assert sorted(seen) == sorted(info["fisher_train"])
+    dl.data_cfg["max_pred"] = 64                                        # untruncated: the out-of-vocabulary word of utterance 0 maps to UNK
+    assert int(dl._targets("spk0_000", "fisher_train")[-2]) == SYMBOLS.UNK_ID
+    hyps = dl.get_hyps([("u", [4, 5, 6, 7, 8, 2]), ("v", [1, 8, 0])])
+    assert hyps == {"u": ["hello", "world", "a"], "v": ["a"]}
