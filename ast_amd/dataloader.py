@@ -39,9 +39,9 @@ def _pad_into(host, arrays):
     return host
 
 
-def pad_batch(arrays, dtype, device):
-    """F.pad_sequence(xs, padding=0) followed by to_gpu (dataloader.py:156-162)."""
-    n = max(len(a) for a in arrays)
+def pad_batch(arrays, dtype, device, n_min=0):
+    """F.pad_sequence(xs, padding=0) followed by to_gpu (dataloader.py:156-162); n_min: pad at least to this length."""
+    n = max(max(len(a) for a in arrays), n_min)
     shape = (len(arrays), n) + tuple(arrays[0].shape[1:])
     host = torch.zeros(shape, dtype=dtype)
     if device.type == "cuda":
@@ -124,16 +124,34 @@ class DataLoader:
         bk = self.buckets[set_key]
         max_sp = (bk["num_b"] + 1) * bk["width_b"]
         plan = []
+        world = self.world if train else 1      # evaluation batches are not sharded: rank 0 decodes the whole set (train.py:55-60)
         for utts, _ in self.batch_plan(batch_size, set_key):
-            utts = utts[self.rank::self.world] if self.world > 1 else utts
-            if utts:
-                plan.append(list(utts))
+            if world > 1:
+                # equal shards on every rank, and the same number of steps: a bucket's last batch is cut to a multiple of the world
+                # size (at most world-1 utterances per bucket sit out the epoch; a rank with an empty shard would skip a step
+                # the others take, and their all-reduce would wait for it forever)
+                utts = utts[:len(utts) // world * world]
+            mine = list(utts[self.rank::world]) if world > 1 else list(utts)
+            if not mine:
+                continue
+            pads = None
+            if world > 1:
+                # Every replica pads its shard to the extents of the WHOLE batch: equal (T, L) on all ranks means equal work, the
+                # row count global-batch BatchNorm assumes, and -- essential -- the same number of teacher-forcing coins drawn
+                # from the seeded `random` stream on every rank (one per decoder step), so that the ranks keep shuffling alike.
+                t_pad = max(min(int(self.info[set_key][u]["sp"]), max_sp) for u in utts)
+                l_pad = max(len(self._targets(u, set_key)) for u in utts) if labels else 0
+                pads = (t_pad, l_pad)
+            plan.append((mine, pads))
+
+        def padded(arrays, n_min):
+            return max(max(len(a) for a in arrays), n_min)
         if self.device.type != "cuda":
-            for utts in plan:
+            for utts, pads in plan:
                 xs = [self._speech(u, set_key, max_sp) for u in utts]
-                out = {"X": pad_batch(xs, torch.float32, self.device), "utts": utts}
+                out = {"X": pad_batch(xs, torch.float32, self.device, pads[0] if pads else 0), "utts": utts}
                 if labels:
-                    out["y"] = pad_batch([self._targets(u, set_key) for u in utts], torch.int32, self.device)
+                    out["y"] = pad_batch([self._targets(u, set_key) for u in utts], torch.int32, self.device, pads[1] if pads else 0)
                 yield out
             return
         # device batches: loading, frame zeroing and padding of batch k+1 run on a helper thread while batch k trains
@@ -141,18 +159,18 @@ class DataLoader:
         ring = self.__dict__.setdefault("_ring", _PinnedRing(self.device))
 
         def stage(k):
-            utts, slot = plan[k], k % ring.depth
+            (utts, pads), slot = plan[k], k % ring.depth
             ring.wait_free(slot)
             xs = [self._speech(u, set_key, max_sp) for u in utts]
-            n = max(len(a) for a in xs)
+            n = padded(xs, pads[0] if pads else 0)
             host = {"X": _pad_into(ring.host(slot, "X", (len(xs), n) + tuple(xs[0].shape[1:]), torch.float32), xs)}
             if labels:
                 ys = [self._targets(u, set_key) for u in utts]
-                host["y"] = _pad_into(ring.host(slot, "y", (len(ys), max(len(a) for a in ys)), torch.int32), ys)
+                host["y"] = _pad_into(ring.host(slot, "y", (len(ys), padded(ys, pads[1] if pads else 0)), torch.int32), ys)
             return host
         with ThreadPoolExecutor(max_workers=1) as pool:
             nxt = pool.submit(stage, 0) if plan else None
-            for k, utts in enumerate(plan):
+            for k, (utts, _) in enumerate(plan):
                 host = nxt.result()
                 nxt = pool.submit(stage, k + 1) if k + 1 < len(plan) else None
                 out = {name: h.to(self.device, non_blocking=True) for name, h in host.items()}

@@ -123,6 +123,9 @@ def test_batch_contract(tmp_path):
 
 
 def test_data_parallel_sharding_of_batches(tmp_path):
+    """Rank r takes rows r::world of every bucketed batch, padded to the extents of the WHOLE batch: the shards are disjoint, equally
+    large, and have the same (T, L) on every rank -- equal work and, because one teacher-forcing coin is drawn per decoder step, the same
+    consumption of the seeded `random` stream (otherwise the ranks' shuffles would drift apart after the first batch)."""
     from ast_amd.dataloader import SyntheticDataLoader
     data = _synth_cfg(tmp_path, n_train=64)
     shards = []
@@ -130,9 +133,15 @@ def test_data_parallel_sharding_of_batches(tmp_path):
         dl = SyntheticDataLoader(data, str(tmp_path), -1)
         dl.rank, dl.world = r, 2
         random.seed("seed-ast-20h")
-        shards.append([b["utts"] for b in dl.get_batch(8, "syn_train", train=True, labels=True)])
-    flat0, flat1 = sum(shards[0], []), sum(shards[1], [])
-    assert not set(flat0) & set(flat1) and len(flat0) + len(flat1) == 64
+        shards.append([(b["utts"], tuple(b["X"].shape[1:]), b["y"].shape[1]) for b in dl.get_batch(8, "syn_train", train=True, labels=True)])
+    flat0, flat1 = sum((u for u, _, _ in shards[0]), []), sum((u for u, _, _ in shards[1]), [])
+    # disjoint; a bucket's last batch is cut to a multiple of the world size, so at most one utterance per bucket sits out (4 buckets)
+    assert not set(flat0) & set(flat1) and 64 - 4 <= len(flat0) + len(flat1) <= 64
+    # the same number of steps, the same shard size and the same extents on every rank, step by step
+    assert len(shards[0]) == len(shards[1])
+    assert [(len(u), x, l) for u, x, l in shards[0]] == [(len(u), x, l) for u, x, l in shards[1]]
+    # evaluation is not sharded: the rank that scores the dev set sees all of it
+    assert sorted(sum((b["utts"] for b in dl.get_batch(8, "syn_dev", train=False, labels=False)), [])) == sorted(dl.info["syn_dev"])
 
 
 def test_config_injects_vocab_size(tmp_path):
