@@ -104,6 +104,8 @@ class NN:
             else:
                 print("layer {0:s} not in model".format(l))
         if adist.is_distributed():
+            # replicas draw different dropout masks / speech noise for their different rows (the teacher-forcing stream stays common)
+            self.model.rng_seed = (self.model.rng_seed + 0x9E3779B97F4A7C15 * adist.rank()) & 0xFFFFFFFFFFFFFFFF
             if self.model.arena is not None:
                 self.model.grad_buckets = adist.make_grad_buckets(self.model)
                 self.optimizer.grad_sync = self.model.grad_buckets.finish

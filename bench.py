@@ -117,6 +117,7 @@ def main():
         # overlapped exchange: decoder / encoder / CNN gradient ranges are all-reduced as soon as their backward is enqueued
         model.grad_buckets = adist.make_grad_buckets(model)
         opt.grad_sync = model.grad_buckets.finish
+        model.rng_seed = (model.rng_seed + 0x9E3779B97F4A7C15 * rank) & 0xFFFFFFFFFFFFFFFF   # per-replica dropout / noise streams
         if args.sync_bn:
             model.stat_exchange = adist.StatExchange()
     random.seed("seed-ast-20h")                                           # same teacher-forcing stream on every rank
