@@ -13,7 +13,7 @@ opt = O.Adam(alpha=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, amsgrad=True).setup(m
 opt.add_hook(O.WeightDecay(1e-4)); opt.add_hook(O.GradientClipping(2))
 random.seed("seed-ast-20h")
 s = torch.cuda.Stream()
-for B, T, L in ((32, 800, 40), (32, 799, 40), (32, 796, 40), (32, 777, 40), (32, 800, 33), (32, 763, 27), (31, 800, 40), (17, 800, 40)):
+for B, T, L in ((32, 160, 12), (32, 400, 25), (32, 800, 40), (32, 799, 40), (32, 763, 27), (31, 800, 40), (17, 800, 40), (32, 1040, 40), (32, 1120, 40), (32, 1200, 40), (32, 1680, 40), (16, 1680, 40)):
     X, y = synth_batch(B, T, D, L, V, 20)
     X, y = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
     def step():
@@ -24,8 +24,8 @@ for B, T, L in ((32, 800, 40), (32, 799, 40), (32, 796, 40), (32, 777, 40), (32,
     firsts = []
     for _ in range(3):
         t0 = time.perf_counter(); step(); t1 = time.perf_counter(); torch.cuda.synchronize(); firsts.append((t1 - t0, time.perf_counter() - t0))
-    print("   first three steps (host enqueue ms, total ms):", " ".join(f"({a*1e3:.1f}, {b*1e3:.1f})" for a, b in firsts))
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): step()
     torch.cuda.synchronize()
-    print(f"B={B} T={T} L={L}: {(time.perf_counter() - t0) * 100:.2f} ms/step", flush=True)
+    dt = (time.perf_counter() - t0) / 10
+    print(f"B={B} T={T} L={L}: {dt * 1e3:.2f} ms/step = {B * T / dt / 1e6:.2f} M frames/s", flush=True)
