@@ -391,7 +391,8 @@ def test_nn_trains_predicts_and_resumes_through_train_py(tmp_path):
     assert len(lines) == 7 and lines[-1] == ""
 
 
-def test_full_size_batch_permutation_and_gradient_accumulation():
+@pytest.mark.parametrize("T", [800, 1200])      # 1200 frames: T'' = 300 > 256, the decoder runs on its per-launch path at full width
+def test_full_size_batch_permutation_and_gradient_accumulation(T):
     """Two more size-independent properties at BASELINE configs[1]'s full size (no dropout / noise, teacher-forced):
     * nothing in the model couples batch rows except BatchNorm's statistics and the mean of the loss, and both are symmetric:
       permuting the rows of (X, y) permutes enc_states the same way and leaves the loss and every gradient unchanged -- although
@@ -403,7 +404,7 @@ def test_full_size_batch_permutation_and_gradient_accumulation():
     from oracle.ast_ref import synth_batch
     cfg = copy.deepcopy(bench.MODEL_CFG)
     cfg["dropout"] = {"embed": 0.0, "rnn": 0.0, "out": 0}
-    B, T, D, L, V = 32, 800, 80, 40, cfg["rnn_config"]["dec_vocab_size"]
+    B, D, L, V = 32, 80, 40, cfg["rnn_config"]["dec_vocab_size"]
     X, y = synth_batch(B, T, D, L, V, 20, dtype=np.float32)
     X, y = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
     m = SpeechEncoderDecoder(0, cfg).materialize(D, seed=0)
