@@ -103,6 +103,9 @@ SIGNATURES = {
     "astk_fill_dropout_mask": (C.c_int, [_VP, _SZ, _F, _U64, _U64, _VP]),
     "astk_fill_normal": (C.c_int, [_VP, _SZ, _F, _F, _U64, _U64, _VP]),
     "astk_scale_f32": (C.c_int, [_VP, _SZ, _F, _VP]),
+    "astk_persist_status_snapshot": (C.c_int, [_VP, _VP]),
+    "astk_persist_status": (C.c_int, [C.POINTER(C.c_uint), _I]),
+    "astk_device_cu_count": (C.c_int, []),
     "astk_prof_begin": (C.c_int, []),
     "astk_prof_end": (C.c_int, [C.POINTER(C.c_double)]),
 }

@@ -55,6 +55,27 @@ struct ProfScope {
     if (r_ != 0) return r_;   \
   } while (0)
 
+// ---- bounded spins of the persistent kernels (lstm_persist.hip, decoder_persist.hip)
+// A spin that times out raises the launch's own abort word (in the caller's workspace, zeroed before every launch: every other
+// spin of the grid checks it and the grid drains) AND sets this kernel's bit in the library's sticky status word, which the host
+// reads back next to the loss (astk_persist_status_snapshot) -- a step whose grid was not fully resident must not train on.
+enum PersistBit { PERSIST_ENC_FWD = 1, PERSIST_ENC_BWD = 2, PERSIST_DEC_FWD = 4, PERSIST_DEC_BWD = 8 };
+struct AbortCtl {
+  unsigned* word;     // per-launch abort word
+  unsigned* status;   // sticky status word of the library (device memory owned by util.hip)
+  unsigned limit;     // spin bound (polls); ASTK_PERSIST_SPIN_LIMIT overrides the default of 1 << 22 (seconds)
+  unsigned bit;       // PersistBit of the launching kernel
+};
+AbortCtl abort_ctl(unsigned* word, unsigned bit);     // host side: fills status / limit
+int device_cu_count();                                 // multiProcessorCount of the current device (cached per device)
+__device__ __forceinline__ bool abort_seen(const AbortCtl& ab) {
+  return __hip_atomic_load(ab.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+__device__ __forceinline__ void abort_raise(const AbortCtl& ab) {
+  __hip_atomic_store(ab.word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_or(ab.status, ab.bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

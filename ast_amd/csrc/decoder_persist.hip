@@ -47,7 +47,7 @@ struct PDecArgs {
   float* ML;               // [S][B][2] softmax max and 1/sum of every attention row
   float* CESTAT;           // [S][B][ntile_v][4]
   unsigned* ctr;           // [PH_N][nbt] * CTRS
-  unsigned* abort_word;
+  AbortCtl ab;
   int dbg;
   float* tick_out;         // profiler: [G] accumulated attention-phase microseconds per workgroup, [G+0] launches
 };
@@ -64,29 +64,27 @@ __device__ __forceinline__ float4 ldb128_sc1(__amdgpu_buffer_rsrc_t r, long floa
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_off * 4), 0, 16);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
-__device__ __forceinline__ bool wait_ge(const unsigned* ctr, unsigned target, unsigned* abort_word) {
+__device__ __forceinline__ bool wait_ge(const unsigned* ctr, unsigned target, const AbortCtl& ab) {
   unsigned spins = 0;
   while (ld_flag(ctr) < target) {
-    if ((++spins & 63u) == 0) {
-      if (ld_flag(abort_word) != 0) return false;
-      if (spins > (1u << 22)) {
-        __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return false;
-      }
+    if (++spins > ab.limit) {
+      abort_raise(ab);
+      return false;
     }
+    if ((spins & 63u) == 0 && abort_seen(ab)) return false;
   }
   return true;
 }
 // workgroup-wide wait: lane 0 polls, everyone learns the outcome
-__device__ __forceinline__ bool wg_wait(const unsigned* ctr, unsigned target, unsigned* abort_word, int* s_flag) {
-  if (threadIdx.x == 0) *s_flag = wait_ge(ctr, target, abort_word) ? 1 : 0;
+__device__ __forceinline__ bool wg_wait(const unsigned* ctr, unsigned target, const AbortCtl& ab, int* s_flag) {
+  if (threadIdx.x == 0) *s_flag = wait_ge(ctr, target, ab) ? 1 : 0;
   __syncthreads();
   const bool ok = *s_flag != 0;
   __syncthreads();            // s_flag may be rewritten by the next wait
   return ok;
 }
 // workgroup-wide wait on `count` (<= 64) counters `stride` words apart: lane i of wave 0 polls counter i
-__device__ __forceinline__ bool wg_wait_multi(const unsigned* base, int stride, int count, unsigned target, unsigned* abort_word, int* s_flag) {
+__device__ __forceinline__ bool wg_wait_multi(const unsigned* base, int stride, int count, unsigned target, const AbortCtl& ab, int* s_flag) {
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     bool ok = true;
@@ -94,10 +92,8 @@ __device__ __forceinline__ bool wg_wait_multi(const unsigned* base, int stride, 
     for (;;) {
       const bool mine = lane < count ? ld_flag(base + (long)lane * stride) >= target : true;
       if (__all(mine)) break;
-      if ((++spins & 63u) == 0) {
-        if (ld_flag(abort_word) != 0) { ok = false; break; }
-        if (spins > (1u << 22)) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
-      }
+      if (++spins > ab.limit) { abort_raise(ab); ok = false; break; }
+      if ((spins & 63u) == 0 && abort_seen(ab)) { ok = false; break; }
     }
     if (lane == 0) *s_flag = ok ? 1 : 0;
   }
@@ -111,7 +107,7 @@ __device__ __forceinline__ bool wg_wait_multi(const unsigned* base, int stride, 
 // far more under load): with 32-128 arrivals per hand-off on ONE word the decoder kernels ran 1.00 / 1.00 ms; 4 / 8 / 16 / 32 / 64 words:
 // 0.84/0.82, 0.80/0.78, 0.79/0.75, 0.78/0.73, 0.78/0.75 ms (forward / backward).
 constexpr int NSH = 32;
-__device__ __forceinline__ bool wg_wait_sh(const unsigned* base, int n_items, int steps, unsigned* abort_word, int* s_flag) {
+__device__ __forceinline__ bool wg_wait_sh(const unsigned* base, int n_items, int steps, const AbortCtl& ab, int* s_flag) {
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     const unsigned target = lane < NSH ? (unsigned)(((n_items - lane + NSH - 1) / NSH) * steps) : 0u;   // items with idx % NSH == lane
@@ -120,10 +116,8 @@ __device__ __forceinline__ bool wg_wait_sh(const unsigned* base, int n_items, in
     for (;;) {
       const bool mine = (lane < NSH && target > 0) ? ld_flag(base + lane * CTRS) >= target : true;
       if (__all(mine)) break;
-      if ((++spins & 63u) == 0) {
-        if (ld_flag(abort_word) != 0) { ok = false; break; }
-        if (spins > (1u << 22)) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
-      }
+      if (++spins > ab.limit) { abort_raise(ab); ok = false; break; }
+      if ((spins & 63u) == 0 && abort_seen(ab)) { ok = false; break; }
     }
     if (lane == 0) *s_flag = ok ? 1 : 0;
   }
@@ -337,10 +331,10 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       const int bt = cell_bt, m0 = bt * 16;
       const int brow = min(m0 + r16, B - 1);             // this lane's A-operand batch row
       const bool truth = s == 0 || flagS[s] != 0;
-      if (!truth) { if (!wg_wait_sh(CTR(PH_CE, bt), 1, s, a.abort_word, &s_flag)) return; }
+      if (!truth) { if (!wg_wait_sh(CTR(PH_CE, bt), 1, s, a.ab, &s_flag)) return; }
       int tok = truth ? yS[r16 * a.L + s] : ldi_sc1(a.PRED + (long)(s - 1) * B + brow);
       tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
-      if (s > 0) { if (!wg_wait_sh(CTR(PH_CELL, bt), H / 8, s, a.abort_word, &s_flag)) return; }
+      if (s > 0) { if (!wg_wait_sh(CTR(PH_CELL, bt), H / 8, s, a.ab, &s_flag)) return; }
       f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
       {
         // (a) embedding part and (b) recurrent part: neither depends on this step's ht, so they run before the wait on P4
@@ -367,7 +361,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       TICK(0)
       // (c) input-feeding part: ht_{s-1}, written into X0[s][:, E:] by P4 of step s-1
       if (s > 0) {
-        if (!wg_wait_sh(CTR(PH_CTX, bt), A / 16, s, a.abort_word, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PH_CTX, bt), A / 16, s, a.ab, &s_flag)) return;
         TICK(1)
         float4 at[NB_A];
         aload_sc1<NB_A>(at, r_x0, ((long)s * B + brow) * XI + E, A, lane, wave);
@@ -404,7 +398,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
     if (has_att) {
       const int b = att_b, bt = b / 16;
       TICK(15)
-      if (!wg_wait_sh(CTR(PH_CELL, bt), H / 8, s + 1, a.abort_word, &s_flag)) return;
+      if (!wg_wait_sh(CTR(PH_CELL, bt), H / 8, s + 1, a.ab, &s_flag)) return;
       TICK(4)
       const long long ta0 = a.tick_out ? wall_clock64() : 0;
       const int c4 = (a.chunk + 3) & ~3;
@@ -589,7 +583,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       const int b = cmb_b, bt = b / 16;
       const int rows_bt = min(16, B - bt * 16);
       TICK(15)
-      if (!wg_wait(ROWCTR(b), (unsigned)(a.nsplit * (s + 1)), a.abort_word, &s_flag)) return;
+      if (!wg_wait(ROWCTR(b), (unsigned)(a.nsplit * (s + 1)), a.ab, &s_flag)) return;
       TICK(6)
       // No staging, no barrier: lane k of EVERY wave reads the header {max_k, sum_k} of partial k, the softmax weights of the
       // nsplit partials are formed with wave shuffles (identically in every wave), and thread tid < H/4 folds its four columns of the
@@ -638,7 +632,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       if constexpr (NC > 0) {
         // the h half of [cv ; h] was published by the cells long ago: its fragments (k-blocks NC..2NC-1 of each wave) and their MFMAs
         // run BEFORE the wait on the combine; only the cv half is fetched and multiplied behind it
-        if (!wg_wait_sh(CTR(PH_CELL, bt), H / 8, s + 1, a.abort_word, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PH_CELL, bt), H / 8, s + 1, a.ab, &s_flag)) return;
         {
           float4 ahd[NC];
           const int q = lane >> 4;
@@ -647,7 +641,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
           __builtin_amdgcn_sched_barrier(0);
           mfma_blocks<NC>(acc, ahd, wreg + OFF_WC + NC);
         }
-        if (!wg_wait_sh(CTR(PH_CMB, bt), rows_bt, s + 1, a.abort_word, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PH_CMB, bt), rows_bt, s + 1, a.ab, &s_flag)) return;
         TICK(8)
         {
           float4 acv[NC];
@@ -658,7 +652,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
           mfma_blocks<NC>(acc, acv, wreg + OFF_WC);
         }
       } else {
-        if (!wg_wait_sh(CTR(PH_CMB, bt), rows_bt, s + 1, a.abort_word, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PH_CMB, bt), rows_bt, s + 1, a.ab, &s_flag)) return;
         TICK(8)
         wmac<NB_C>(acc, wreg + OFF_WC, r_cvh, crow, 2 * H, lane, wave);
       }
@@ -678,7 +672,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       if (l_item[t] < 0) continue;
       const int bt = l_item[t] / a.ntile_v, tile = l_item[t] % a.ntile_v, m0 = bt * 16, n0 = tile * 16;
       TICK(15)
-      if (!wg_wait_sh(CTR(PH_CTX, bt), A / 16, s + 1, a.abort_word, &s_flag)) return;
+      if (!wg_wait_sh(CTR(PH_CTX, bt), A / 16, s + 1, a.ab, &s_flag)) return;
       TICK(10)
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       wmac<NB_L>(acc, wreg + OFF_WL + t * NB_L, r_ht, ((long)(s + 1) * B + min(m0 + r16, B - 1)) * A, A, lane, wave);
@@ -713,7 +707,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
     // ================= P6: cross-entropy combine per batch tile =================
     if (has_ce) {
       const int bt = ce_rank, m0 = bt * 16;
-      if (!wg_wait_sh(CTR(PH_LOG, bt), a.ntile_v, s + 1, a.abort_word, &s_flag)) return;
+      if (!wg_wait_sh(CTR(PH_LOG, bt), a.ntile_v, s + 1, a.ab, &s_flag)) return;
       const int row = m0 + (tid >> 4), sub = tid & 15;       // 16 threads per row sweep the tiles
       float mx = -INFINITY, se = 0.f, xt = 0.f;
       int mi = 0x7fffffff;
@@ -791,7 +785,7 @@ struct PDecBwdArgs {
                                            //    columns are one batched GEMM after the launch)
   float *d_c0;
   unsigned* ctr;
-  unsigned* abort_word;
+  AbortCtl ab;
   int dbg;
   float* tick_out;
 };
@@ -901,7 +895,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
       float carry = 0.f;
       TB(0)
       if (n > 0) {
-        if (!wg_wait_sh(CTR(PB6, bt), a.b6_split ? 2 * (A / 16) : XI / 16, n, a.abort_word, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PB6, bt), a.b6_split ? 2 * (A / 16) : XI / 16, n, a.ab, &s_flag)) return;
         TB(1)
         if (row < B) {
           if (a.b6_split) {
@@ -922,7 +916,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
     if (has2) {
       const int bt = b2_bt, m0 = bt * 16;
       TB(15)
-      if (!wg_wait_sh(CTR(PB1, bt), A / 16, n + 1, a.abort_word, &s_flag)) return;
+      if (!wg_wait_sh(CTR(PB1, bt), A / 16, n + 1, a.ab, &s_flag)) return;
       TB(3)
       float4 av[NB_B2];
       aload_sc1<NB_B2>(av, r_dpre, ((long)s * B + min(m0 + r16, B - 1)) * A, A, lane, wave);
@@ -963,7 +957,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
           if (tid < HH / 4) cv4 = *reinterpret_cast<const float4*>(a.CVH + ((long)s * B + b) * 2 * HH + 4 * tid);
           a_t = tid < nrow ? expf(raw - mlM) * mlI : 0.f;
         }
-        if (!wg_wait_sh(CTR(PB2, bt), 2 * H / 32, n + 1, a.abort_word, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PB2, bt), 2 * H / 32, n + 1, a.ab, &s_flag)) return;
         tb0 = a.tick_out ? wall_clock64() : 0;
         float cdp = 0.f;                       // cv . d_cv
         if (tid < HH / 4) {
@@ -1045,7 +1039,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
           }
         }
       } else {
-        if (!wg_wait_sh(CTR(PB2, bt), 2 * H / 32, n + 1, a.abort_word, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PB2, bt), 2 * H / 32, n + 1, a.ab, &s_flag)) return;
         tb0 = a.tick_out ? wall_clock64() : 0;
         float* dS = scr;                  // d_cv[b][:]
         float* cvS = scr + H;             // cv[b][:]
@@ -1133,7 +1127,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
       const int rows_bt = min(16, B - bt * 16);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       if (n > 0) {       // dh_rec = dz_{s+1} Wl: independent of this step's chain
-        if (!wg_wait_sh(CTR(PB5, bt), H / 16, n, a.abort_word, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PB5, bt), H / 16, n, a.ab, &s_flag)) return;
         wmac_chunked<NB_B5, 16>(acc, wreg, r_g, ((long)(s + 1) * B + min(m0 + r16, B - 1)) * K4, K4, lane, wave);
       }
       const float v = reduce16(acc, red);
@@ -1149,7 +1143,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
         if (a.rnn_mask) mk = a.rnn_mask[((long)s * B + row) * H + u];
       }
       TB(6)
-      if (!wg_wait_multi(ROWCTR(m0), CTRS, rows_bt, (unsigned)(a.nsplit * (n + 1)), a.abort_word, &s_flag)) return;
+      if (!wg_wait_multi(ROWCTR(m0), CTRS, rows_bt, (unsigned)(a.nsplit * (n + 1)), a.ab, &s_flag)) return;
       TB(7)
       if (ev) {
         float dy = ld_sc1(a.DCVH + ((long)s * B + row) * 2 * H + H + u);
@@ -1180,7 +1174,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
     if (has6) {
       const int bt = b6_bt, m0 = bt * 16;
       TB(15)
-      if (!wg_wait_sh(CTR(PB5, bt), H / 16, n + 1, a.abort_word, &s_flag)) return;
+      if (!wg_wait_sh(CTR(PB5, bt), H / 16, n + 1, a.ab, &s_flag)) return;
       TB(9)
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       if (a.b6_split) wmac_chunked<NB_B6 / 2, 16>(acc, wreg, r_g, ((long)s * B + min(m0 + r16, B - 1)) * K4 + b6_k0, K4 / 2, lane, wave);
@@ -1264,6 +1258,7 @@ bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int
   const char* e = getenv("ASTK_DEC_PERSIST");
   if (e && e[0] == '0') return false;
   if (d->n_layers != 1) return false;
+  if (device_cu_count() < G) return false;        // fixed roles over G workgroups, all of them resident (one per CU)
   if ((d->H % 64) || (d->A % 16) || (d->E % 16) || d->A < 16 || d->E < 16) return false;
   const int nbt = (d->B + 15) / 16, ntv = (d->V + 15) / 16;
   if (d->E > 64 * NB_E || d->A > 64 * NB_A || d->H > 64 * NB_H || 2 * d->H > 64 * NB_C || d->A > 64 * NB_L || d->H > 1024) return false;
@@ -1321,7 +1316,7 @@ int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, con
   a.DXH = bf.DXH;
   a.b6_split = bf.DXH != nullptr && decoder_persist_b6_split(d) ? 1 : 0;
   a.ctr = bf.ctr;
-  a.abort_word = bf.ctr + (size_t)NPHASE_SLOTS * NSH * a.nbt * CTRS;
+  a.ab = abort_ctl(bf.ctr + (size_t)NPHASE_SLOTS * NSH * a.nbt * CTRS, PERSIST_DEC_BWD);
   a.tick_out = prof_tick_buffer(1);
   { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
   ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)NPHASE_SLOTS * NSH * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), s));
@@ -1361,7 +1356,7 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
   a.TOK = bf.TOK; a.PRED = bf.PRED; a.X0 = bf.X0; a.Gt = bf.G; a.Cst = bf.C; a.HR = bf.HR; a.Q = bf.Q; a.ALPHA = bf.ALPHA;
   a.CVH = bf.CVH; a.HT = bf.HT; a.LOGITS = bf.LOGITS; a.LOSSROWS = bf.LOSSROWS; a.LSE = bf.LSE; a.PART = bf.PART; a.CESTAT = bf.CESTAT; a.ML = bf.ML;
   a.ctr = bf.ctr;
-  a.abort_word = bf.ctr + (size_t)NPHASE_SLOTS * NSH * a.nbt * CTRS;
+  a.ab = abort_ctl(bf.ctr + (size_t)NPHASE_SLOTS * NSH * a.nbt * CTRS, PERSIST_DEC_FWD);
   { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.tick_out = prof_tick_buffer(0);
   ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)NPHASE_SLOTS * NSH * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), s));

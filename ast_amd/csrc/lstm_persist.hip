@@ -48,7 +48,7 @@ struct PFwdArgs {
   int ncells, nl, T, B, h, H;
   int dbg;              // timing experiments only (ASTK_PERSIST_DBG): 1 = skip payload loads + MFMA, 2 = skip publish drain
   unsigned* done;       // [ncells][nbt] arrival counters
-  unsigned* abort_word;
+  AbortCtl ab;
 };
 
 struct PCellB {
@@ -72,7 +72,7 @@ struct PBwdArgs {
   int ncells, nl, T, B, h, H;
   int dbg;
   unsigned* done;
-  unsigned* abort_word;
+  AbortCtl ab;
 };
 
 __device__ __forceinline__ unsigned ld_flag(const unsigned* p) {
@@ -83,16 +83,14 @@ __device__ __forceinline__ void st4_sc1(float* p, float v) {
 }
 
 // One lane waits until *ctr >= target (or the abort word is raised).  Returns false on abort / time-out.
-__device__ __forceinline__ bool wait_ge(const unsigned* ctr, unsigned target, unsigned* abort_word) {
+__device__ __forceinline__ bool wait_ge(const unsigned* ctr, unsigned target, const AbortCtl& ab) {
   unsigned spins = 0;
   while (ld_flag(ctr) < target) {
-    if ((++spins & 63u) == 0) {
-      if (ld_flag(abort_word) != 0) return false;
-      if (spins > (1u << 22)) {   // ~seconds: something is wrong (grid not resident); drain instead of hanging
-        __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return false;
-      }
+    if (++spins > ab.limit) {   // ~seconds: something is wrong (grid not resident); drain instead of hanging
+      abort_raise(ab);
+      return false;
     }
+    if ((spins & 63u) == 0 && abort_seen(ab)) return false;
   }
   return true;
 }
@@ -152,7 +150,7 @@ __device__ __forceinline__ bool frag_ok(const u32x4 (&g)[NB]) {
 // flood the fabric with full sweeps), then re-read everything; repeat until complete.  Bounded; a time-out raises the
 // abort word, which every other spin checks, and the grid drains.
 template <int NB>
-__device__ __forceinline__ void frag_wait(__amdgpu_buffer_rsrc_t rs, int byte_off, int wave, u32x4 (&g)[NB], bool& dead, unsigned* abort_word) {
+__device__ __forceinline__ void frag_wait(__amdgpu_buffer_rsrc_t rs, int byte_off, int wave, u32x4 (&g)[NB], bool& dead, const AbortCtl& ab) {
   unsigned spins = 0;
   while (!dead) {
     const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off + 64 * wave, 0, 16);
@@ -160,10 +158,8 @@ __device__ __forceinline__ void frag_wait(__amdgpu_buffer_rsrc_t rs, int byte_of
       frag_issue<NB>(rs, byte_off, wave, g);
       if (frag_ok<NB>(g)) return;
     }
-    if ((++spins & 63u) == 0) {
-      if (ld_flag(abort_word) != 0) dead = true;
-      else if (spins > (1u << 21)) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; }
-    }
+    if (++spins > (ab.limit >> 1)) { abort_raise(ab); dead = true; }
+    else if ((spins & 63u) == 0 && abort_seen(ab)) dead = true;
   }
 }
 __device__ __forceinline__ float4 frag_vals(const u32x4& g) {
@@ -242,7 +238,7 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
   mk_raw = maskp[ebc * h + eu];
   if (HAS_UP) {
     frag_issue<KB>(r_below, frag0, wave, gx);
-    if (!frag_ok<KB>(gx)) frag_wait<KB>(r_below, frag0, wave, gx, dead, a.abort_word);
+    if (!frag_ok<KB>(gx)) frag_wait<KB>(r_below, frag0, wave, gx, dead, a.ab);
 #pragma unroll
     for (int i = 0; i < KB; ++i) ax[i] = frag_vals(gx[i]);
     frag_issue<KB>(r_below, frag0 + min(1, T - 1) * step_bytes, wave, gx);
@@ -267,12 +263,12 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
     TICK(0, t0)
     // ---- W_t
     if (!FIRST) {
-      if (!frag_ok<KB>(gh)) { ++slow_h; frag_wait<KB>(r_own, frag - step_bytes, wave, gh, dead, a.abort_word); }
+      if (!frag_ok<KB>(gh)) { ++slow_h; frag_wait<KB>(r_own, frag - step_bytes, wave, gh, dead, a.ab); }
     }
     TICK(1, t0)
     const int t1 = min(t + 1, T - 1), t2 = min(t + 2, T - 1);
     if (HAS_UP) {   // x_{t+1}: issued a whole step ago
-      if (!frag_ok<KB>(gx)) { ++slow_x; frag_wait<KB>(r_below, frag0 + t1 * step_bytes, wave, gx, dead, a.abort_word); }
+      if (!frag_ok<KB>(gx)) { ++slow_x; frag_wait<KB>(r_below, frag0 + t1 * step_bytes, wave, gx, dead, a.ab); }
 #pragma unroll
       for (int i = 0; i < KB; ++i) ax[i] = frag_vals(gx[i]);
     }
@@ -430,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
     }
     float v1 = 0.f;
     if (has_up) {                            // partials handed down by the layer above (it runs ahead)
-      if (tid == 0) s_ok1 = wait_ge(upB, (unsigned)(NS * (stepno + 1)), a.abort_word) ? 1 : 0;
+      if (tid == 0) s_ok1 = wait_ge(upB, (unsigned)(NS * (stepno + 1)), a.ab) ? 1 : 0;
       __syncthreads();
       if (!s_ok1) break;
       const int base = (int)((((long)t * nbt + bt) * NS + j) * cons_stride) + tid * 4;
@@ -443,7 +439,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
     TICK(0, t0)
     float v0 = 0.f;
     if (stepno > 0) {                        // partial dh_rec tiles of this cell's step t+1
-      if (tid == 0) s_ok2 = wait_ge(ctrA, (unsigned)(NS * stepno), a.abort_word) ? 1 : 0;
+      if (tid == 0) s_ok2 = wait_ge(ctrA, (unsigned)(NS * stepno), a.ab) ? 1 : 0;
       __syncthreads();
       if (!s_ok2) break;
       TICK(1, t0)
@@ -540,7 +536,7 @@ bool lstm_persist_applicable(int T, int B, int h, int nl, int nd) {
   if (!(h == 64 || h == 128 || h == 256 || h == 512)) return false;
   if (B < 1 || T < 1) return false;
   const long wgs = (long)(h / 16) * ((B + 15) / 16) * nl * nd;
-  if (wgs > 256 || nl * nd > 16) return false;        // one workgroup per CU must hold the whole grid
+  if (wgs > device_cu_count() || nl * nd > 16) return false;        // one workgroup per CU must hold the whole grid
   // hand-off buffers are addressed with 32-bit byte offsets
   if ((long)T * B * h * 16 >= (1L << 31) || (long)T * ((B + 15) / 16) * (h / 16) * (h / 16) * 1024 >= (1L << 31)) return false;
   const char* e = getenv("ASTK_LSTM_PERSIST");
@@ -562,7 +558,7 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   a.ncells = ncells; a.nl = nl; a.T = T; a.B = B; a.h = h; a.H = H;
   { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.done = counters;
-  a.abort_word = counters + (size_t)ncells * nbt * 64;
+  a.ab = abort_ctl(counters + (size_t)ncells * nbt * 64, PERSIST_ENC_FWD);
   dim3 grid(h / 16, nbt, ncells), blk(256);
   {
     // hand-off buffers = the saved activations themselves: sentinel-filled before every launch (the counters / abort word ride along, zeroed)
@@ -604,7 +600,7 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
   ASTK_CHECK(cells[0].PR != nullptr, "lstm_persist_bwd: partial-sum buffers missing");
   // counters A and B per (cell, batch tile), then the abort word
-  a.abort_word = counters + (size_t)2 * ncells * nbt * 64;
+  a.ab = abort_ctl(counters + (size_t)2 * ncells * nbt * 64, PERSIST_ENC_BWD);
   ASTK_HIP(hipMemsetAsync(counters, 0, ((size_t)2 * ncells * nbt + 1) * 64 * sizeof(unsigned), s));
   dim3 grid(h / 16, nbt, ncells), blk(256);
   ProfScope prof(PROF_CELL, s);

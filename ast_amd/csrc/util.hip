@@ -43,7 +43,45 @@ void prof_stop(int cat, hipStream_t s) {
   g_prof.ev[cat].push_back(e);
 }
 
+// ---- sticky status word of the persistent kernels (common.h: AbortCtl)
+__device__ unsigned g_persist_status[16];     // word 0: PersistBit mask of the kernels whose bounded spins have timed out
+static unsigned* g_status_ptr[16] = {nullptr};
+static int g_cu_count[16] = {0};
+static unsigned* persist_status_ptr() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (!g_status_ptr[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_persist_status)) != hipSuccess) return nullptr;
+    g_status_ptr[dev] = (unsigned*)p;
+  }
+  return g_status_ptr[dev];
+}
+AbortCtl abort_ctl(unsigned* word, unsigned bit) {
+  AbortCtl ab;
+  ab.word = word;
+  ab.status = persist_status_ptr();
+  ab.limit = 1u << 22;
+  const char* e = getenv("ASTK_PERSIST_SPIN_LIMIT");      // test knob: a tiny bound forces the time-out path
+  if (e && e[0]) { const long v = atol(e); if (v > 0) ab.limit = (unsigned)v; }
+  ab.bit = bit;
+  return ab;
+}
+int device_cu_count() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  if (g_cu_count[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    g_cu_count[dev] = n;
+  }
+  return g_cu_count[dev];
+}
+
 namespace {
+
+__global__ void k_status_snapshot(const unsigned* status, float* dst) { *dst = (float)(*status); }
+__global__ void k_status_reset(unsigned* status) { *status = 0u; }
 
 __global__ void k_copy2d(float* dst, long ldd, const float* src, long lds, int rows, int cols, int cols_dst) {
   const long n = (long)rows * cols_dst;
@@ -455,6 +493,32 @@ int astk_gemm_f32(int layout, int M, int N, int K, const float* A, long lda, con
   g.sA = sA; g.sB = sB; g.sC = sC;
   return gemm_launch(layout, g, (hipStream_t)stream);
 }
+
+int astk_persist_status_snapshot(float* dst, void* stream) {
+  ASTK_CHECK(dst, "persist_status_snapshot: null pointer");
+  unsigned* st = persist_status_ptr();
+  ASTK_CHECK(st, "persist_status: no status word");
+  hipLaunchKernelGGL(k_status_snapshot, dim3(1), dim3(1), 0, (hipStream_t)stream, st, dst);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int astk_persist_status(unsigned* mask_out, int reset) {
+  unsigned* st = persist_status_ptr();
+  ASTK_CHECK(st, "persist_status: no status word");
+  ASTK_HIP(hipDeviceSynchronize());
+  unsigned v = 0;
+  ASTK_HIP(hipMemcpy(&v, st, sizeof(v), hipMemcpyDeviceToHost));
+  if (mask_out) *mask_out = v;
+  if (reset && v != 0) {
+    hipLaunchKernelGGL(k_status_reset, dim3(1), dim3(1), 0, (hipStream_t)0, st);
+    ASTK_LAUNCH_CHECK();
+    ASTK_HIP(hipDeviceSynchronize());
+  }
+  return 0;
+}
+
+int astk_device_cu_count(void) { return device_cu_count(); }
 
 int astk_prof_begin(void) {
   for (int c = 0; c < PROF_NCAT; ++c) { g_prof.ev[c].clear(); g_prof.work[c] = 0; }

@@ -125,7 +125,17 @@ class DataLoader:
         max_sp = (bk["num_b"] + 1) * bk["width_b"]
         plan = []
         world = self.world if train else 1      # evaluation batches are not sharded: rank 0 decodes the whole set (train.py:55-60)
-        for utts, _ in self.batch_plan(batch_size, set_key):
+        # Under data parallelism only rank 0 evaluates, and batch_plan() consumes the seeded `random` stream that every rank's training
+        # plan and teacher-forcing coins come from: an evaluation pass must leave that stream where it found it, or rank 0 would
+        # build different shards and flags from the next epoch on.  (One process: the stream is consumed exactly like the reference.)
+        rng_state = random.getstate() if (self.world > 1 and not train) else None
+        if rng_state is not None:
+            kept = [list(b) for b in bk["buckets"]]          # batch_plan shuffles the bucket lists in place
+        base_plan = self.batch_plan(batch_size, set_key)
+        if rng_state is not None:
+            random.setstate(rng_state)
+            bk["buckets"][:] = kept
+        for utts, _ in base_plan:
             if world > 1:
                 # equal shards on every rank, and the same number of steps: a bucket's last batch is cut to a multiple of the world
                 # size (at most world-1 utterances per bucket sit out the epoch; a rank with an empty shard would skip a step

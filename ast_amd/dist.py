@@ -35,7 +35,16 @@ def init(backend=None):
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
         torch.cuda.set_device(local_rank())
-    td.init_process_group(backend=backend)
+    # rank 0 alone runs the dev pass and writes checkpoints between epochs while the others wait at a barrier (train.py): the
+    # collective watchdog must outlast a dev decode
+    import datetime
+    minutes = float(os.environ.get("ASTK_DIST_TIMEOUT_MIN", "120"))
+    td.init_process_group(backend=backend, timeout=datetime.timedelta(minutes=minutes))
+
+
+def barrier():
+    if is_distributed():
+        td.barrier()
 
 
 def allreduce_flat(buf):
@@ -114,9 +123,12 @@ def broadcast_params(arena, src=0):
 
 
 def shard_rows(n_rows, rank_, world):
-    """Contiguous row shard [lo, hi) of a bucketed batch for `rank_` (equal T => equal work)."""
-    per = n_rows // world
-    return rank_ * per, (rank_ + 1) * per
+    """Row indices of `rank_`'s shard of a bucketed batch -- the ONE sharding scheme of the data-parallel path, the same the loader
+    applies to utterance lists (ast_amd/dataloader.py get_batch: `utts[rank::world]` after the batch has been cut to a multiple
+    of the world size): strided rows rank, rank+world, ...; at most world-1 trailing rows sit the step out, so every rank
+    gets the same number of rows (equal T => equal work, and the all-reduce never waits for an empty shard)."""
+    usable = n_rows // world * world
+    return list(range(rank_, usable, world))
 
 
 class StatExchange:

@@ -12,7 +12,7 @@ from . import dist as adist
 from . import optimizers, serializers
 from .config import Config
 from .dataloader import SYMBOLS, FisherDataLoader, GlobalPhoneDataLoader, SyntheticDataLoader
-from .seq2seq import SpeechEncoderDecoder, using_config
+from .seq2seq import SpeechEncoderDecoder, raise_if_aborted, using_config
 
 _ADAM = 0
 _SGD = 1
@@ -147,7 +147,9 @@ class NN:
 
         def settle(p):
             nonlocal total_loss, n_batches, avg_loss
-            loss_val = float(p[0]) / p[1]                              # quirk Q5: divided by the batch size
+            vals = p[0].tolist()                                       # [loss, status word of the persistent kernels]
+            raise_if_aborted(vals[1], "NN.train_epoch")
+            loss_val = vals[0] / p[1]                                  # quirk Q5: divided by the batch size
             n_batches += 1
             total_loss += loss_val
             avg_loss = total_loss / n_batches
@@ -165,7 +167,7 @@ class NN:
                     self.model.cleargrads()
                     loss.backward()
                     self.optimizer.update()
-                cur = (loss.data.clone(), len(batch["y"]), len(batch["X"]))   # the loss buffer is reused by the next step
+                cur = (loss.pair.clone(), len(batch["y"]), len(batch["X"]))   # the loss buffer is reused by the next step
                 if pending is not None:
                     settle(pending)
                 pending = cur

@@ -56,22 +56,67 @@ class Link:
         return [(k, v) for k, v in a.views.items() if k.split("/")[0] == self.name]
 
 
-class Loss:
-    """What forward_loss returns: `.data` (0-d tensor), float(), `.backward()` (nn.py:175-189)."""
+def raise_if_aborted(status, where="train step"):
+    """`status` = the persistent kernels' sticky status word as read back next to the loss (include/astk.h
+    astk_persist_status_snapshot).  Non-zero: a bounded spin timed out (the grid was not fully resident: another tenant on the GPU,
+    RCCL kernels holding CUs, a partitioned device), the kernels drained, and the step's loss and gradients are garbage."""
+    mask = int(status)
+    if mask:
+        names = [n for b, n in ((1, "encoder forward"), (2, "encoder backward"), (4, "decoder forward"), (8, "decoder backward")) if mask & b]
+        _lib.load().astk_persist_status(None, 1)          # clear the sticky word: the caller may retry (e.g. with ASTK_*_PERSIST=0)
+        raise _lib.AstkError(f"{where}: persistent kernel(s) timed out waiting for a peer workgroup ({', '.join(names)}); the results "
+                             "of this step are invalid.  The whole grid must be resident (one workgroup per CU); set "
+                             "ASTK_LSTM_PERSIST=0 / ASTK_DEC_PERSIST=0 to use the per-launch kernels on a shared device")
 
-    def __init__(self, model, value):
+
+class Loss:
+    """What forward_loss returns: `.data` (0-d tensor), float(), `.backward()` (nn.py:175-189).  `.pair` = [loss, status] on the
+    device: the status word of the persistent kernels rides next to the scalar, so one read-back serves both."""
+
+    def __init__(self, model, pair):
         self._model = model
-        self.data = value
+        self.pair = pair
+        self.data = pair[0]
 
     def backward(self):
         self._model._backward()
 
     def __float__(self):
-        return float(self.data)
+        v = self.pair.tolist()
+        raise_if_aborted(v[1])
+        return v[0]
 
 
 def _vp(t):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# Raw hipStream_t handles made with hipExtStreamCreateWithCUMask (opt-in overlap, _cu_streams).  torch only BORROWS them
+# (ExternalStream), so nothing ever destroyed them: they were still alive when the HIP runtime's static destructors ran, and five
+# rocprofv3 runs in a row ended with SIGSEGV inside __cxa_finalize after their results were written (round-1 logs ovl2/ovl3/sp/dpt/
+# dpt2).  They are now owned here: destroyed by SpeechEncoderDecoder.close() or, at the latest, by an atexit hook -- Python's
+# atexit runs before the interpreter and the runtime libraries are torn down.
+_MASKED_STREAMS = []
+
+
+def _destroy_masked_streams(handles=None):
+    todo = list(_MASKED_STREAMS) if handles is None else [h for h in handles if h in _MASKED_STREAMS]
+    if not todo:
+        return
+    try:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipStreamDestroy.argtypes = [C.c_void_p]
+        for h in todo:
+            hip.hipStreamDestroy(C.c_void_p(h))
+            _MASKED_STREAMS.remove(h)
+    except Exception:                                      # interpreter shutdown: nothing useful can be done with an error here
+        pass
+
+
+import atexit  # noqa: E402
+atexit.register(_destroy_masked_streams)
 
 
 class SpeechEncoderDecoder:
@@ -271,7 +316,7 @@ class SpeechEncoderDecoder:
             bs = dict(cT=torch.zeros(nd, nl, B, h, **f32), hT=torch.zeros(nd, nl, B, h, **f32),
                       d_cT=torch.zeros(nd, nl, B, h, **f32), d_hT=torch.zeros(nd, nl, B, h, **f32),
                       c0=torch.zeros(nld, B, H, **f32), h0=torch.zeros(nld, B, H, **f32),
-                      d_c0=torch.zeros(nld, B, H, **f32), d_h0=torch.zeros(nld, B, H, **f32), loss=torch.zeros(1, **f32))
+                      d_c0=torch.zeros(nld, B, H, **f32), d_h0=torch.zeros(nld, B, H, **f32), loss=torch.zeros(2, **f32))
             self._bstate[B] = bs
         st = dict(key=key, B=B, T=T, D=D, L=L, T2=T2, feat=feat, S=S, cd=cd, cp=cp, cg=cg, ld=ld, lp=lp, lg=lg, dd=dd, dp=dp, dg=dg,
                   ws_cnn=int(lib.astk_conv_bn_relu_workspace_bytes(C.byref(cd))),
@@ -394,11 +439,25 @@ class SpeechEncoderDecoder:
                     main = torch.cuda.current_stream(self.device)
                     # HIP multiplexes streams onto a few hardware queues; streams that share one are serialised whatever their events
                     # say, and then the "overlap" costs a millisecond instead of saving a tenth.  Probe every pair once.
+                    _MASKED_STREAMS.extend([rec.value, side.value])
                     if all(self._concurrent(a, b) for a, b in ((main, side_t), (main, rec_t), (rec_t, side_t))):
                         self._ws[key] = (rec, side_t, rec_t)
+                    else:
+                        del rec_t, side_t
+                        _destroy_masked_streams([rec.value, side.value])
                 except (OSError, RuntimeError, AttributeError):
                     pass                                       # no masked streams on this stack: the phases run in line
         return self._ws[key]
+
+    def close(self):
+        """Gives back what the model owns outside torch's allocator: the CU-masked streams of the opt-in overlap (the torch wrappers
+        are dropped first, then the handles are destroyed)."""
+        handles = []
+        for key in [k for k in self._ws if isinstance(k, tuple) and k[0] == "cu_streams"]:
+            v = self._ws.pop(key)
+            if v is not None:
+                handles += [v[0].value, v[1].cuda_stream]
+        _destroy_masked_streams(handles)
 
     def _concurrent(self, a, b):
         """True if a kernel on stream b runs while stream a is busy (one 300 us spin on a, a trivial kernel on b)."""
@@ -463,7 +522,8 @@ class SpeechEncoderDecoder:
         check(lib.astk_decoder_fwd(C.byref(st["dd"]), C.byref(st["dp"]), _vp(st["enc_states"]), _vp(st["c0"]), _vp(st["h0"]),
                                    _vp(y), _vp(st["flags"]), _vp(st["emb_mask"]), _vp(st["rnn_masks"]), _vp(st["loss"]),
                                    _vp(st["pred"]), _vp(wd), wd.numel(), self._stream()))
-        self.loss = Loss(self, st["loss"][0])
+        check(lib.astk_persist_status_snapshot(C.c_void_p(st["loss"].data_ptr() + 4), self._stream()))
+        self.loss = Loss(self, st["loss"])
         return self.loss
 
     def _backward(self):
@@ -496,8 +556,10 @@ class SpeechEncoderDecoder:
                 joined.record(side)
         else:
             dec_bwd(0, s)
-            if self.grad_buckets is not None:
-                self.grad_buckets.launch("dec")
+        # The decoder's gradient range is final here, but its all-reduce is NOT launched yet: an RCCL kernel holds its CUs until every
+        # peer has arrived, and the encoder's backward recurrence (next) needs up to 192 CUs to itself to become resident -- a peer
+        # that is late would turn into a time-out of the recurrence's bounded spins.  Both ranges go out behind the recurrence and
+        # hide behind the encoder's batched weight-gradient products and the CNN backward instead.
         h, nd = self.h, self.n_dirs
         # encoder layers without a decoder counterpart keep the zero gradient they were allocated with
         for k in range(min(len(self.rnn_enc), len(self.rnn_dec))):
@@ -510,9 +572,8 @@ class SpeechEncoderDecoder:
             # the side stream finished long ago (0.5 ms of work beside a 1 ms kernel); from here on everything is on one stream again,
             # and the gradient exchange is launched from it
             torch.cuda.current_stream(self.device).wait_event(joined)
-            if self.grad_buckets is not None:
-                self.grad_buckets.launch("dec")
         if self.grad_buckets is not None:
+            self.grad_buckets.launch("dec")
             self.grad_buckets.launch("enc")
         wc = self._workspace("cnn", st["ws_cnn"])
         sx = self.stat_exchange if st.get("bn_world", 1) > 1 else None   # backward of the statistics the forward pass used
@@ -526,6 +587,7 @@ class SpeechEncoderDecoder:
             check(rc)
         if self.grad_buckets is not None:
             self.grad_buckets.launch("cnn")
+        check(lib.astk_persist_status_snapshot(C.c_void_p(st["loss"].data_ptr() + 4), s))
 
     # ------------------------------------------------------------------ inference (seq2seq.py:361-396, 475-568)
     def decode_step(self, word, ht):

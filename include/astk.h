@@ -239,6 +239,19 @@ int astk_scale_f32(float* x, size_t n, float s, void* stream);
  * default), and two streams that share one are serialised whatever their events say (ast_amd/seq2seq.py:_cu_streams). */
 int astk_spin(unsigned usec, unsigned* flag, void* stream);
 
+/* Persistent-kernel health.  The encoder / decoder recurrences run as single launches whose workgroups hand activations to each
+ * other (lstm_persist.hip, decoder_persist.hip); that needs the whole grid resident (one workgroup per CU), which the launchers
+ * check against the device's CU count but cannot guarantee against other tenants of the GPU (RCCL kernels under data
+ * parallelism, another process).  Every spin is bounded: a time-out drains the grid and sets a bit in a STICKY status word
+ * (1 encoder fwd, 2 encoder bwd, 4 decoder fwd, 8 decoder bwd); the results of such a step are garbage.
+ *   astk_persist_status_snapshot  enqueues a copy of the word (as a float) to *dst on `stream`: the Python shim places it next to
+ *                                 the loss scalar, so the loss read-back of nn.py:189 sees it without an extra synchronisation;
+ *   astk_persist_status           synchronises the device, returns the word in *mask_out (may be NULL) and clears it if `reset`.
+ * ASTK_PERSIST_SPIN_LIMIT=<polls> (environment, read at every launch) shrinks the spin bound; tests use it to force a time-out. */
+int astk_persist_status_snapshot(float* dst, void* stream);
+int astk_persist_status(unsigned* mask_out, int reset);
+int astk_device_cu_count(void);
+
 /* Optional per-kernel HIP-event timing on the launch stream (bench.py's roofline legs; off by default).
  * astk_prof_end: res[0..1] attention-scan fwd (ms, launches); [2..3] attention-scan bwd; [4..6] GEMMs (ms, launches, flops);
  * [7..8] fused LSTM cells (ms, launches); [9..11] attention-scan phase inside the persistent decoder forward measured with

@@ -1,0 +1,125 @@
+"""Full-size golden scalars from the float64 CPU oracle (oracle/ast_ref.py), run ONCE in the build container.
+
+    python tests/golden/make_fullsize.py [case ...]        # minutes of CPU per case
+
+The small fixtures (make_fixtures.py) carry whole tensors; at BASELINE.json's real shapes that would be hundreds of MB,
+so here inputs and weights are REGENERATED FROM SEEDS on both sides (oracle.ast_ref.init_params / synth_batch with
+float32 values, which the oracle then widens to float64) and the committed file tests/golden/fullsize.json holds only
+what the GPU tests compare:
+  loss, clip norm sqrt(sum (g + l2 p)^2) (the "grad norm" observable, nn.py:104), the teacher-forcing flags (seeded
+  Python stream "seed-ast-20h", quirk Q4), per-tensor gradient L2 norms, 24 sampled gradient entries per tensor
+  (indices from default_rng(7)), the L2 norm and 64 sampled entries of enc_states, the smallest top-2 logit margin
+  over the argmax-fed steps (how close the float32 path is allowed to come to a different feedback token), and the
+  loss of the float32 oracle run on the same case (context for the tolerance).
+
+Cases (BASELINE.json configs):
+  cfg1      configs[1]: B=32 T=800 D=80 L=40, 3 enc layers (2x256), 1 dec layer 512, V=1098           (bench workload)
+  es_en_20h configs[0]: the shipped es_en_20h model (3 enc / 3 dec, /root/reference/experiments/es_en_20h/model_cfg.json
+            values restated in MODEL_ES_EN) at batch 2, T=800, D=80, L=40
+  asr_gpfr  configs[3]'s shape: same model JSON (experiments/asr_gpfr/model_cfg.json has no n_attn/feed_attn keys:
+            defaults equal), 13-d features, 3 dec layers, V=1004, L=60, batch 8, T=800
+Dropout / speech noise are 0 (quirk Q7: the reference's masks are unseeded; the masked variants are compared at small
+sizes with injected masks), teach_ratio 0.8 with the seeded flag stream.
+"""
+import copy
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import ast_ref as R  # noqa: E402
+from oracle import minichainer as F  # noqa: E402
+
+OUT = os.path.join(HERE, "fullsize.json")
+OPT = {"type": 0, "lr": 1e-3, "l2": 1e-4, "grad_clip": 2, "grad_noise_eta": 0, "freeze": []}
+N_SAMPLES = 24
+
+
+def model_cfg(dec_layers, V, explicit_attn_keys=True):
+    rc = {"bi_rnn": True, "enc_layers": 3, "dec_layers": dec_layers, "hidden_units": 512, "embedding_units": 128,
+          "attn_units": 512, "ln": False, "dec_vocab_size": V}
+    if explicit_attn_keys:
+        rc.update(n_attn=1, feed_attn=True)
+    return {"dropout": {"embed": 0.0, "rnn": 0.0, "out": 0}, "rnn_config": rc,
+            "cnn_config": {"bn": True, "cnn_layers": [
+                {"in_channels": None, "out_channels": 128, "ksize": [9, 13], "stride": [2, 13], "pad": [4, 0]},
+                {"in_channels": None, "out_channels": 512, "ksize": [9, 1], "stride": [2, 1], "pad": [4, 0]}]}}
+
+
+CASES = {
+    "cfg1": dict(cfg=model_cfg(1, 1098), B=32, T=800, D=80, L=40, V=1098, seed=0, data_seed=20),
+    "es_en_20h": dict(cfg=model_cfg(3, 1098), B=2, T=800, D=80, L=40, V=1098, seed=0, data_seed=20),
+    "asr_gpfr": dict(cfg=model_cfg(3, 1004, explicit_attn_keys=False), B=8, T=800, D=13, L=60, V=1004, seed=0, data_seed=20),
+}
+
+
+def sample_index(name, shape, n=N_SAMPLES):
+    """Flat indices into a tensor, reproducible from its name alone (no hash(): PYTHONHASHSEED varies)."""
+    size = int(np.prod(shape))
+    seed = int.from_bytes(name.encode()[:8].ljust(8, b"\0"), "little") ^ 7
+    return np.sort(np.random.default_rng(seed).integers(0, size, size=min(n, size)))
+
+
+def run_case(name, c):
+    cfg, B, T, D, L, V = c["cfg"], c["B"], c["T"], c["D"], c["L"], c["V"]
+    P32 = R.init_params(cfg, D, V, seed=c["seed"], dtype=np.float32)
+    X32, y = R.synth_batch(B, T, D, L, V, seed=c["data_seed"], dtype=np.float32)
+    out = {"B": B, "T": T, "D": D, "L": L, "V": V, "seed": c["seed"], "data_seed": c["data_seed"], "cfg": cfg, "teach_ratio": 0.8}
+    res = {}
+    for dt in (np.float64, np.float32):
+        t0 = time.time()
+        m = R.RefModel(copy.deepcopy(cfg), {k: v.astype(dt) for k, v in P32.items()}, V)
+        margins = []
+        orig_argmax = F.argmax
+
+        def spy(x, axis=1, _m=margins):
+            s = np.sort(np.asarray(x.data, dtype=np.float64), axis=1)
+            _m.append(float((s[:, -1] - s[:, -2]).min()))
+            return orig_argmax(x, axis)
+        R.F.argmax = spy
+        try:
+            loss = m.forward_loss(X32.astype(dt), y, 0.8, pyrandom=random.Random("seed-ast-20h"))
+        finally:
+            R.F.argmax = orig_argmax
+        m.cleargrads()
+        loss.backward()
+        grads = {k: p.grad.astype(np.float64).copy() for k, p in m.params()}
+        opt = R.RefOptimizer(m, OPT)
+        opt.update()
+        res[dt] = dict(loss=float(loss.data), gnorm=float(opt.last_grad_norm), grads=grads, flags=[int(f) for f in m.use_truth],
+                       enc=m.enc_states.data.astype(np.float64), margins=margins, secs=time.time() - t0)
+        print(f"[{name}] {dt.__name__}: loss {res[dt]['loss']:.10f} clip-norm {res[dt]['gnorm']:.10f} in {res[dt]['secs']:.0f} s", flush=True)
+    r = res[np.float64]
+    flags = r["flags"]
+    # margins of the steps whose argmax is actually fed back: step i+1 uses the argmax of step i iff flags[i+1] == 0
+    fed = [r["margins"][i] for i in range(len(flags) - 1) if not flags[i + 1]]
+    out.update(loss=r["loss"], grad_norm=r["gnorm"], flags=flags, loss_f32_oracle=res[np.float32]["loss"],
+               grad_norm_f32_oracle=res[np.float32]["gnorm"], min_fed_argmax_margin=min(fed) if fed else None,
+               enc_norm=float(np.sqrt((r["enc"] ** 2).sum())), enc_absmax=float(np.abs(r["enc"]).max()),
+               oracle_seconds_f64=round(r["secs"], 1), oracle_seconds_f32=round(res[np.float32]["secs"], 1))
+    idx = sample_index("enc_states", r["enc"].shape, 64)
+    out["enc_samples"] = {"index": idx.tolist(), "value": r["enc"].ravel()[idx].tolist()}
+    out["grads"] = {}
+    for k, g in r["grads"].items():
+        idx = sample_index(k, g.shape)
+        out["grads"][k] = {"norm": float(np.sqrt((g ** 2).sum())), "absmax": float(np.abs(g).max()),
+                           "index": idx.tolist(), "value": g.ravel()[idx].tolist()}
+    return out
+
+
+def main():
+    names = sys.argv[1:] or list(CASES)
+    data = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    for n in names:
+        data[n] = run_case(n, CASES[n])
+        json.dump(data, open(OUT, "w"), indent=1, sort_keys=True)
+        print("wrote", n, flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -66,8 +66,9 @@ def _worker(rank, world, port, q):
         loss, _ = decoder_torch(cfg, Pt, torch.tensor(enc[rows]), torch.tensor(c0[:, rows]), torch.tensor(h0[:, rows]), y[rows], flags, V)
         loss.backward()
         return torch.cat([Pt[k].grad.reshape(-1) for k in sorted(Pt)])
-    lo, hi = adist.shard_rows(B, rank, world)
-    local = grads(slice(lo, hi)).float()
+    rows = adist.shard_rows(B, rank, world)            # strided, like the loader's utts[rank::world]
+    assert rows == list(range(B))[rank::world] and adist.shard_rows(B + 1, rank, world) == rows
+    local = grads(rows).float()
     adist.allreduce_flat(local)
     ok3 = bool(torch.allclose(local.double(), grads(slice(0, B)), rtol=1e-5, atol=1e-7))
     # 4) BatchNorm statistics exchange (StatExchange): called the way the C library calls it -- through the ctypes callback, with

@@ -500,3 +500,44 @@ def test_prefetching_loader_yields_the_same_batches_as_the_plain_one(tmp_path):
         assert len(got) == len(want)
         for (u0, x0, y0), (u1, x1, y1) in zip(want, got):
             assert u0 == u1 and torch.equal(x0, x1) and torch.equal(y0, y1)
+
+
+def test_persistent_kernel_timeout_raises_instead_of_training_on(monkeypatch):
+    """Every spin of the persistent encoder / decoder kernels is bounded; a time-out (grid not fully resident) drains the grid and
+    sets a sticky status word that rides next to the loss scalar (include/astk.h astk_persist_status_snapshot).  Forced here with
+    ASTK_PERSIST_SPIN_LIMIT=1 (a wait that is not satisfied by its second poll gives up): reading the loss must raise, through
+    float(loss) and through NN.train_epoch's one-step-late read-back helper alike, the word must clear, and the next clean step
+    must give the oracle's loss again."""
+    from oracle import ast_ref as R
+    from ast_amd import _lib
+    from ast_amd.seq2seq import using_config, raise_if_aborted
+    cfg = tiny_cfg(enc_layers=2, dec_layers=1, H=128, E=16, A=64, c0=8, c1=16, V=57, drop=0.0)     # persistent encoder and decoder
+    B, T, D, L, V = 18, 70, 80, 8, 57
+    P, X, y = _make(cfg, B, T, D, L, V)
+    ref = R.RefModel(cfg, {k: v.astype(np.float64) for k, v in P.items()}, V)
+    rl = ref.forward_loss(X.astype(np.float64), y, 1.0, pyrandom=random.Random(0))
+    g = _gpu_model(cfg, P, D, V)
+    g.inject["use_truth"] = [1] * (L - 1)
+    lib = _lib.load()
+    import ctypes as C
+    mask = C.c_uint(0)
+    assert lib.astk_persist_status(C.byref(mask), 1) == 0
+
+    def step():
+        with using_config("train", True):
+            loss = g.forward_loss(X=torch.from_numpy(X), y=torch.from_numpy(y), teach_ratio=1.0)
+            g.cleargrads()
+            loss.backward()
+        return loss
+    monkeypatch.setenv("ASTK_PERSIST_SPIN_LIMIT", "1")
+    loss = step()
+    with pytest.raises(_lib.AstkError, match="timed out"):
+        float(loss)
+    assert lib.astk_persist_status(C.byref(mask), 0) == 0 and mask.value == 0          # cleared by the raise
+    loss = step()
+    pair = loss.pair.clone()                                                            # what NN.train_epoch keeps for its late read
+    with pytest.raises(_lib.AstkError, match="NN.train_epoch"):
+        raise_if_aborted(pair.tolist()[1], "NN.train_epoch")
+    monkeypatch.delenv("ASTK_PERSIST_SPIN_LIMIT")
+    loss = step()
+    assert _rel(float(loss), float(rl.data)) < 1e-4

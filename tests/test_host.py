@@ -144,6 +144,29 @@ def test_data_parallel_sharding_of_batches(tmp_path):
     assert sorted(sum((b["utts"] for b in dl.get_batch(8, "syn_dev", train=False, labels=False)), [])) == sorted(dl.info["syn_dev"])
 
 
+def test_evaluation_on_rank0_only_keeps_the_ranks_plans_in_step(tmp_path):
+    """train.py under data parallelism: only rank 0 runs the dev pass between two epochs.  Its batch plan consumes the seeded
+    `random` stream (and shuffles bucket lists in place); the pass must leave both as it found them, or rank 0's shards,
+    pads and teacher-forcing flags differ from the other ranks' from the second epoch on."""
+    from ast_amd.dataloader import SyntheticDataLoader
+    data = _synth_cfg(tmp_path, n_train=64)
+    plans = []
+    for r in range(2):
+        dl = SyntheticDataLoader(data, str(tmp_path), -1)
+        dl.rank, dl.world = r, 2
+        random.seed("seed-ast-20h")
+        epoch1 = [b["utts"] for b in dl.get_batch(8, "syn_train", train=True, labels=True)]
+        if r == 0:                                    # the dev pass, and an evaluation over the TRAIN set for good measure
+            list(dl.get_batch(8, "syn_dev", train=False, labels=False))
+            list(dl.get_batch(8, "syn_train", train=False, labels=False))
+        coin = random.random()                        # where the stream stands: the next teacher-forcing coin
+        epoch2 = [(b["utts"], tuple(b["X"].shape[1:]), b["y"].shape[1]) for b in dl.get_batch(8, "syn_train", train=True, labels=True)]
+        plans.append((epoch1, coin, epoch2))
+    assert plans[0][1] == plans[1][1]
+    assert [(len(u), x, l) for u, x, l in plans[0][2]] == [(len(u), x, l) for u, x, l in plans[1][2]]
+    assert not set(sum((u for u, _, _ in plans[0][2]), [])) & set(sum((u for u, _, _ in plans[1][2]), []))
+
+
 def test_config_injects_vocab_size(tmp_path):
     from ast_amd.config import Config
     vocab = {"bpe_w": {"w2i": {bytes([i]): i for i in range(57)}, "i2w": {}, "freq": {}}}

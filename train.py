@@ -46,3 +46,5 @@ if __name__ == "__main__":
             serializers.save_npz(nn.model_fname.replace(".model", "_{0:d}.model".format(epoch)), nn.model,
                                  optimizer=nn.optimizer if nn.cfg.train.get("save_optimizer", False) else None)
             print("Finished saving model")
+        # data parallel: the dev pass and the checkpoint are rank 0's alone; nobody enters the next epoch's all-reduces before it is back
+        adist.barrier()
