@@ -119,6 +119,11 @@ using namespace astk;
 
 extern "C" {
 
+int astk_lstm_stack_path(const astk_lstm_stack_desc* d) {
+  if (!d) return 0;
+  return lstm_persist_applicable(d->T, d->B, d->h, d->n_layers, d->n_dirs) ? 1 : 0;
+}
+
 size_t astk_lstm_stack_workspace_bytes(const astk_lstm_stack_desc* d) {
   LstmPlan P;
   if (make_plan(d, nullptr, true, P) != 0) return 0;

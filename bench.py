@@ -5,7 +5,8 @@ GradientClipping + AMSGrad, data already resident in HBM.  Workload (N=1 and per
 configs[1]: synthetic fbank (T=800, 80-d) batch 32, 2x[Conv+BN+ReLU] -> 3-layer 2x256 LSTM encoder -> attention ->
 1-layer LSTM-512 decoder, V=1098, L=40, shipped training knobs (dropout .3, speech noise .25, teacher forcing .8).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10            # BASELINE configs[1] (1-layer decoder): the metric's workload
+    python bench.py --model es_en_20h                          # the shipped model (3 decoder layers, experiments/es_en_20h)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -77,14 +78,16 @@ def cpu_baseline(B, T, D, L, V, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)        # >= 50 timed steps after >= 10 warm-ups
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--model", default="cfg1", choices=["cfg1", "es_en_20h"],
+                    help="cfg1 = BASELINE configs[1] (1-layer LSTM-512 decoder, the metric's workload); es_en_20h = the shipped "
+                         "experiments/es_en_20h model (3 decoder layers) on the same synthetic batch")
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--frames", type=int, default=800)
     ap.add_argument("--feat", type=int, default=80)
     ap.add_argument("--tgt-len", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="accepted for old command lines; there is no graph path")
     ap.add_argument("--sync-bn", action="store_true", help="N>1: BatchNorm statistics over the global batch (4 extra 5-10 KB all-reduces)")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps with per-kernel HIP-event timing")
     args = ap.parse_args()
@@ -109,6 +112,9 @@ def main():
     lib = _lib.load()
     B, T, D, L, V = args.batch, args.frames, args.feat, args.tgt_len, MODEL_CFG["rnn_config"]["dec_vocab_size"]
     cfg = copy.deepcopy(MODEL_CFG)
+    if args.model == "es_en_20h":
+        cfg["rnn_config"]["dec_layers"] = 3          # /root/reference/experiments/es_en_20h/model_cfg.json:12
+    n_dec = cfg["rnn_config"]["dec_layers"]
     model = SpeechEncoderDecoder(local, cfg).materialize(D, seed=0)       # identical replicas
     opt = O.Adam(alpha=TRAIN["lr"], beta1=0.9, beta2=0.999, eps=1e-8, amsgrad=True).setup(model)
     opt.add_hook(O.WeightDecay(TRAIN["l2"]))
@@ -154,13 +160,24 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-    loss_val = float(loss.data)
+    loss_val = float(loss)                      # raises AstkError if a persistent kernel timed out (status word next to the loss)
     assert np.isfinite(loss_val), "loss is not finite"
     ms = dt / args.steps * 1e3
     value = world * B * T / (dt / args.steps)
 
-    # ---- per-kernel timing of the attention scan and the GEMMs with HIP events on the launch stream (in situ)
-    roof, extra = None, {}
+    # ---- which kernels ran (a silent fall-back to the per-launch paths must show in the driver's line)
+    st = model._cur
+    paths = {"encoder": "persistent wavefront kernels (one launch for all steps of all cells)" if lib.astk_lstm_stack_path(C.byref(st["ld"]))
+             else "per-step fused-cell launches (fallback)"}
+    dpath = lib.astk_decoder_path(C.byref(st["dd"]))
+    paths["decoder"] = (f"persistent loop, {dpath >> 8} layer(s) fused" + (", attention phase specialised (H=512, chunk<=32)" if dpath & 2 else ", generic attention phase")) \
+        if dpath & 1 else "per-launch loop (fallback)"
+    paths["encoder_persistent"], paths["decoder_persistent"] = bool(lib.astk_lstm_stack_path(C.byref(st["ld"]))), bool(dpath & 1)
+    paths["cu_count"] = int(lib.astk_device_cu_count())
+    paths["overlap_param_grads"] = bool(model.overlap_param_grads)
+
+    # ---- per-kernel timing with HIP events on the launch stream (in situ), plus in-kernel phase stamps of the persistent decoder
+    roof, scan, extra = None, None, {}
     if args.profile_steps > 0:
         # per-kernel figures are taken with every kernel alone on the device: with the opt-in side-stream overlap
         # (decoder parameter gradients on 64 masked CUs beside the encoder recurrence) those GEMMs would be priced as slow ones
@@ -176,62 +193,75 @@ def main():
         H = cfg["rnn_config"]["hidden_units"]
         S = L - 1
         bytes_scan = B * T2 * H * 4                                    # one streaming read of enc_states
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "attn_traffic.json")
-        if os.path.exists(tf):
-            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
-        if res[11] > 0 and res[14] > 0:
-            # persistent decoder loop: the scan is a PHASE of one launch; its duration is measured in situ with in-kernel
-            # 100 MHz timestamps (hand-off satisfied -> partial published), taking the slowest workgroup's mean per step
-            us = 0.5 * (res[10] + res[13])
-            ach = bytes_scan / (us * 1e-6) / 1e9
-            k_fwd_us, k_bwd_us = res[16] / max(res[17], 1) * 1e3, res[18] / max(res[19], 1) * 1e3
-            roof = {"bound": "hbm", "kernel": "attention-scan phase of decoder_persist_fwd/_bwd (enc_states slices LDS-resident)",
-                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "bytes_per_launch": bytes_scan, "avg_launch_us": round(us, 3), "launches_per_step": 2 * S,
-                    "method": "in-kernel s_memrealtime stamps per phase (slowest workgroup's mean); the phase is not a separate launch",
-                    "phase_us": {"fwd_mean": round(res[9], 3), "fwd_slowest_wg": round(res[10], 3), "bwd_mean": round(res[12], 3),
-                                 "bwd_slowest_wg": round(res[13], 3)},
-                    "kernel_level": {"decoder_persist_fwd_us": round(k_fwd_us, 1), "decoder_persist_bwd_us": round(k_bwd_us, 1),
-                                     "scan_bytes_per_kernel": S * bytes_scan,
-                                     "scan_bytes_over_kernel_time_GBps": round(S * bytes_scan / ((k_fwd_us + k_bwd_us) / 2 * 1e-6) / 1e9, 1)}}
+
+        def profile_json(name):
+            f = os.path.join(ROOT, "profiles", name)
+            return json.load(open(f)) if os.path.exists(f) else {}
+        if res[5] > 0:
+            # THE dominant kernel family (half of the step): every batched dense product of the step on f32-input MFMA
+            tfl = res[6] / (res[4] * 1e-3) / 1e12
+            ms_gemm, n_gemm = res[4] / args.profile_steps, int(res[5] / args.profile_steps)
+            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<NT|NN|TN> + k_zero_split_tiles (all batched dense products of the step)",
+                    "achieved": round(tfl, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
+                    "traffic": profile_json("gemm_traffic.json").get("hbm_bytes_per_step"),
+                    "flops_per_step": round(res[6] / args.profile_steps), "ms_per_step": round(ms_gemm, 3),
+                    "avg_launch_us": round(ms_gemm * 1e3 / max(1, n_gemm), 1), "launches_per_step": n_gemm,
+                    "method": "2*M*N*K per launch / HIP events around every launch on the launch stream; traffic = FETCH_SIZE*2 + WRITE_SIZE "
+                              "of the same kernels from separate rocprofv3 --pmc passes (profiles/), per step"}
+        if res[17] > 0 and res[19] > 0:
+            # Attention scan (north_star's "HBM roofline on the attention scan").  The scan is a PHASE of the two persistent decoder
+            # launches, not a launch of its own, and its enc / encA slices are LDS-resident after step 0: the launches are LATENCY-bound
+            # (4-5 dependent hand-offs per decoder step), not HBM-bound.  Kernel-level: algorithmic bytes of all S scans of a launch
+            # over the launch's duration.  Phase-level (in-kernel stamps, hand-off satisfied -> partial published) is given for
+            # reference only: it is an HBM-EQUIVALENT rate of an on-chip pass, not HBM traffic.
+            k_fwd_us, k_bwd_us = res[16] / res[17] * 1e3, res[18] / res[19] * 1e3
+            ach = S * bytes_scan / ((k_fwd_us + k_bwd_us) / 2 * 1e-6) / 1e9
+            scan = {"bound": "latency (priced against the HBM roofline north_star names; slices are LDS-resident, measured HBM traffic < algorithmic bytes)",
+                    "kernel": "decoder_persist_fwd / decoder_persist_bwd (all S decoder steps per launch)",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": profile_json("attn_traffic.json").get("hbm_bytes_per_launch"),
+                    "bytes_per_launch": S * bytes_scan, "avg_launch_us": round((k_fwd_us + k_bwd_us) / 2, 1), "launches_per_step": 2,
+                    "us_per_decoder_step": {"fwd": round(k_fwd_us / S, 2), "bwd": round(k_bwd_us / S, 2)},
+                    "method": "algorithmic bytes (S scans x B*T''*H*4) / HIP-event duration of the launch",
+                    "phase": None}
+            if res[11] > 0 and res[14] > 0:
+                us = 0.5 * (res[10] + res[13])
+                scan["phase"] = {"what": "scan phase only, in-kernel s_memrealtime stamps (slowest workgroup's mean), HBM-equivalent rate of an LDS-resident pass",
+                                 "bytes": bytes_scan, "us": round(us, 3), "equiv_GBps": round(bytes_scan / (us * 1e-6) / 1e9, 1),
+                                 "equiv_frac_of_hbm_peak": round(bytes_scan / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "fwd_mean_us": round(res[9], 3), "fwd_slowest_wg_us": round(res[10], 3),
+                                 "bwd_mean_us": round(res[12], 3), "bwd_slowest_wg_us": round(res[13], 3)}
         else:
             n_attn, ms_attn = res[1] + res[3], res[0] + res[2]
             if n_attn > 0:
                 avg_us = ms_attn / n_attn * 1e3
                 ach = bytes_scan / (avg_us * 1e-6) / 1e9
-                roof = {"bound": "hbm", "kernel": "attn_fwd_partial+attn_bwd_partial", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "bytes_per_launch": bytes_scan,
+                scan = {"bound": "hbm", "kernel": "attn_fwd_partial+attn_bwd_partial (per-launch decoder loop)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": bytes_scan,
                         "avg_launch_us": round(avg_us, 3), "launches_per_step": int(n_attn / args.profile_steps)}
-        if res[5] > 0:
-            tfl = res[6] / (res[4] * 1e-3) / 1e12
-            extra["gemm"] = {"bound": "mfma", "achieved": round(tfl, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4), "ms_per_step": round(res[4] / args.profile_steps, 3),
-                             "launches_per_step": int(res[5] / args.profile_steps)}
         if res[8] > 0:
             extra["encoder_lstm_persistent_ms_per_step"] = round(res[7] / args.profile_steps, 3)
+            extra["encoder_us_per_time_step"] = round(res[7] / args.profile_steps * 1e3 / 2 / T2, 2)     # fwd + bwd launches
         if res[17] > 0:
             extra["decoder_persistent_ms_per_step"] = round((res[16] + res[18]) / args.profile_steps, 3)
 
+    dec_name = f"{n_dec}-layer LSTM-512 dec"
     out = {"metric": "speech frames/s (train step)", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"BASELINE configs[1]: synthetic fbank T={T} D={D} batch {B}/GPU, 2xConv+BN -> 3-layer 2x256 LSTM enc -> "
-                                  f"attention -> 1-layer LSTM-512 dec, V={V}, L={L}, dropout .3, noise .25, teach .8, Adam(amsgrad)+L2+clip",
+           "config": {"workload": (f"BASELINE configs[1]: " if args.model == "cfg1" else "shipped es_en_20h model (configs[0]'s model at configs[1]'s batch): ") +
+                                  f"synthetic fbank T={T} D={D} batch {B}/GPU, 2xConv+BN -> 3-layer 2x256 LSTM enc -> "
+                                  f"attention -> {dec_name}, V={V}, L={L}, dropout .3, noise .25, teach .8, Adam(amsgrad)+L2+clip",
                       "global_batch": world * B, "frames": T, "feat_dim": D, "tgt_len": L, "parallelism": f"dp{world}", "batchnorm": "global-batch statistics" if (world > 1 and args.sync_bn) else "per-replica statistics",
                       "launches": "plain stream launches (the step is GPU-bound: the host enqueues it in 0.6 ms)"},
-           "loss": round(loss_val, 4), "roofline": roof}
-    if "gemm" in extra:   # the time-dominant kernel family (half of the step) against its own roofline, same shape as `roofline`
-        g = extra["gemm"]
-        out["roofline_mfma"] = {"bound": "mfma", "kernel": "gemm_f32_kernel<NT|NN|TN> + k_zero_split_tiles (all batched dense products of the step)",
-                                "achieved": g["achieved"], "peak": g["peak"], "unit": "TFLOP/s", "frac": g["frac"], "traffic": None,
-                                "flops_per_step": round(g["achieved"] * 1e12 * g["ms_per_step"] * 1e-3),
-                                "avg_launch_us": round(g["ms_per_step"] * 1e3 / max(1, g["launches_per_step"]), 1),
-                                "launches_per_step": g["launches_per_step"], "method": "HIP events around every launch on the launch stream"}
+           "loss": round(loss_val, 4), "paths": paths, "roofline": roof, "roofline_scan": scan}
+    if world > 1:
+        out["dp"] = {"rccl_ranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
+                     "buckets": list(model.grad_buckets.ranges), "bucket_launch": "dec+enc behind the encoder recurrence, cnn behind the CNN backward"}
     out.update({"kernels": extra} if extra else {})
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(B, T, D, L, V)
+            out["cpu_baseline"] = cpu_baseline(cfg, B, T, D, L, V)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

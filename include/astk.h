@@ -249,6 +249,12 @@ int astk_spin(unsigned usec, unsigned* flag, void* stream);
  *   astk_persist_status           synchronises the device, returns the word in *mask_out (may be NULL) and clears it if `reset`.
  * ASTK_PERSIST_SPIN_LIMIT=<polls> (environment, read at every launch) shrinks the spin bound; tests use it to force a time-out. */
 int astk_persist_status_snapshot(float* dst, void* stream);
+/* Which path a shape takes on the current device (so that a silent fall-back shows up in logs / bench.py's JSON line):
+ *   astk_lstm_stack_path  1 = persistent wavefront kernels (all T steps of all cells in one launch), 0 = one fused-cell launch per step
+ *   astk_decoder_path     0 = per-launch decoder loop; otherwise bit 0 = persistent loop, bit 1 = attention phase specialised for
+ *                         H = 512 / chunk <= 32, bits 8.. = number of decoder layers fused into the persistent kernels */
+int astk_lstm_stack_path(const astk_lstm_stack_desc* d);
+int astk_decoder_path(const astk_decoder_desc* d);
 int astk_persist_status(unsigned* mask_out, int reset);
 int astk_device_cu_count(void);
 

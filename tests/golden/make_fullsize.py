@@ -107,8 +107,12 @@ def run_case(name, c):
     out["grads"] = {}
     for k, g in r["grads"].items():
         idx = sample_index(k, g.shape)
+        g32 = res[np.float32]["grads"][k]
         out["grads"][k] = {"norm": float(np.sqrt((g ** 2).sum())), "absmax": float(np.abs(g).max()),
-                           "index": idx.tolist(), "value": g.ravel()[idx].tolist()}
+                           "index": idx.tolist(), "value": g.ravel()[idx].tolist(),
+                           # how far the float32 ORACLE itself sits from the float64 one (context for the GPU tolerances)
+                           "f32_oracle_norm_relerr": float(abs(np.sqrt((g32 ** 2).sum()) - np.sqrt((g ** 2).sum())) / max(np.sqrt((g ** 2).sum()), 1e-300)),
+                           "f32_oracle_entry_err_over_absmax": float(np.abs(g32 - g).max() / max(np.abs(g).max(), 1e-300))}
     return out
 
 

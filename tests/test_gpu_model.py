@@ -200,7 +200,8 @@ def test_missing_library_fails_loudly(monkeypatch):
         _lib.load()
 
 
-def test_full_size_directional_derivative_and_repeatability():
+@pytest.mark.parametrize("dec_layers,D", [(1, 80), (3, 80), (3, 13)])   # configs[1]; shipped es_en_20h (3 decoder layers); asr_gpfr shape (13-d)
+def test_full_size_directional_derivative_and_repeatability(dec_layers, D):
     """BASELINE configs[1] at full size (B=32, T=800, D=80, h=256, H=512, V=1098, L=40): the oracle is too slow here, so
     the check is a size-independent property.  With dropout / noise off and every step teacher-forced the loss is a smooth
     function of the parameters: (L(p + e d) - L(p - e d)) / 2e must equal <grad L, d> -- the persistent encoder / decoder
@@ -212,7 +213,8 @@ def test_full_size_directional_derivative_and_repeatability():
     from oracle.ast_ref import synth_batch
     cfg = copy.deepcopy(bench.MODEL_CFG)
     cfg["dropout"] = {"embed": 0.0, "rnn": 0.0, "out": 0}
-    B, T, D, L, V = 32, 800, 80, 40, cfg["rnn_config"]["dec_vocab_size"]
+    cfg["rnn_config"]["dec_layers"] = dec_layers
+    B, T, L, V = 32, 800, 40, cfg["rnn_config"]["dec_vocab_size"]
     X, y = synth_batch(B, T, D, L, V, 20, dtype=np.float32)
     X, y = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
     m = SpeechEncoderDecoder(0, cfg).materialize(D, seed=0)
@@ -391,8 +393,9 @@ def test_nn_trains_predicts_and_resumes_through_train_py(tmp_path):
     assert len(lines) == 7 and lines[-1] == ""
 
 
-@pytest.mark.parametrize("T", [800, 1200])      # 1200 frames: T'' = 300 > 256, the decoder runs on its per-launch path at full width
-def test_full_size_batch_permutation_and_gradient_accumulation(T):
+# 1200 frames: T'' = 300 > 256 (long utterances); dec_layers 3 = the shipped es_en_20h / asr_gpfr decoders; D = 13: asr_gpfr features
+@pytest.mark.parametrize("T,dec_layers,D", [(800, 1, 80), (1200, 1, 80), (800, 3, 80), (1200, 3, 80), (800, 3, 13)])
+def test_full_size_batch_permutation_and_gradient_accumulation(T, dec_layers, D):
     """Two more size-independent properties at BASELINE configs[1]'s full size (no dropout / noise, teacher-forced):
     * nothing in the model couples batch rows except BatchNorm's statistics and the mean of the loss, and both are symmetric:
       permuting the rows of (X, y) permutes enc_states the same way and leaves the loss and every gradient unchanged -- although
@@ -404,7 +407,8 @@ def test_full_size_batch_permutation_and_gradient_accumulation(T):
     from oracle.ast_ref import synth_batch
     cfg = copy.deepcopy(bench.MODEL_CFG)
     cfg["dropout"] = {"embed": 0.0, "rnn": 0.0, "out": 0}
-    B, D, L, V = 32, 80, 40, cfg["rnn_config"]["dec_vocab_size"]
+    cfg["rnn_config"]["dec_layers"] = dec_layers
+    B, L, V = 32, 40, cfg["rnn_config"]["dec_vocab_size"]
     X, y = synth_batch(B, T, D, L, V, 20, dtype=np.float32)
     X, y = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
     m = SpeechEncoderDecoder(0, cfg).materialize(D, seed=0)
