@@ -13,9 +13,11 @@
 namespace astk {
 
 // persistent decoder loop (decoder_persist.hip)
+constexpr int PDEC_MAX_LAYERS = 3;
 struct DecPersistBuffers {
   int32_t *TOK, *PRED;
-  float *X0, *G, *C, *HR, *Q, *ALPHA, *CVH, *HT, *LOGITS, *LOSSROWS;
+  float *X0, *Q, *ALPHA, *CVH, *HT, *LOGITS, *LOSSROWS;
+  float *G[PDEC_MAX_LAYERS], *C[PDEC_MAX_LAYERS], *HR[PDEC_MAX_LAYERS], *HD[PDEC_MAX_LAYERS];
   float *LSE, *PART, *CESTAT, *ENCA, *ML;
   unsigned* ctr;
 };
@@ -25,8 +27,10 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
                                hipStream_t s);
 
 struct DecPersistBwdBuffers {
-  const float *WoT, *WcT, *WlT, *WuT, *ENCA, *CVH, *HT, *LOGITS, *C, *ML;
-  float *ALPHA, *G, *DPRE, *DCVH, *DS, *DX0, *DHATT, *d_c0;
+  const float *WoT, *WcT, *ENCA, *CVH, *HT, *LOGITS, *ML;
+  const float *WlT[PDEC_MAX_LAYERS], *WuT[PDEC_MAX_LAYERS], *C[PDEC_MAX_LAYERS];
+  float *G[PDEC_MAX_LAYERS];
+  float *ALPHA, *DPRE, *DCVH, *DS, *DX0, *DHATT, *d_c0;
   float* DXH;
   unsigned* ctr;
 };
@@ -340,7 +344,9 @@ int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
     if (!persist) ASTK_TRY(attn_ws_init(P.attn_ws, B, P.T, H, s));   // the persistent loop has its own counters
     if (persist) {
       DecPersistBuffers bf;
-      bf.TOK = P.TOK; bf.PRED = P.PRED; bf.X0 = P.X0; bf.G = P.G[0]; bf.C = P.C[0]; bf.HR = P.HR[0]; bf.Q = P.Q; bf.ALPHA = P.ALPHA;
+      memset(&bf, 0, sizeof(bf));
+      bf.TOK = P.TOK; bf.PRED = P.PRED; bf.X0 = P.X0; bf.Q = P.Q; bf.ALPHA = P.ALPHA;
+      for (int l = 0; l < nl; ++l) { bf.G[l] = P.G[l]; bf.C[l] = P.C[l]; bf.HR[l] = P.HR[l]; bf.HD[l] = P.HD[l]; }
       bf.CVH = P.CVH; bf.HT = P.HT; bf.LOGITS = P.LOGITS; bf.LOSSROWS = P.LOSSROWS; bf.LSE = P.LSE; bf.PART = P.PART;
       bf.CESTAT = P.CESTAT; bf.ENCA = P.ENCA; bf.ML = P.MLB; bf.ctr = P.PCTR;
       ASTK_TRY(decoder_persist_fwd_launch(d, prm, enc, y, use_truth, emb_mask, rnn_masks, bf, s));
@@ -449,8 +455,10 @@ int astk_decoder_bwd_phase(const astk_decoder_desc* d, const astk_decoder_params
   if (!persist) ASTK_TRY(attn_ws_init(P.attn_ws, B, T, H, s));   // the persistent loop has its own counters
   if (persist) {
     DecPersistBwdBuffers bf;
-    bf.WoT = P.WoT; bf.WcT = P.WcT; bf.WlT = P.WlT[0]; bf.WuT = P.WuT[0]; bf.ENCA = P.ENCA; bf.ALPHA = P.ALPHA; bf.CVH = P.CVH; bf.ML = P.MLB;
-    bf.HT = P.HT; bf.LOGITS = P.LOGITS; bf.C = P.C[0]; bf.G = P.G[0]; bf.DPRE = P.DPRE; bf.DCVH = P.DCVH; bf.DS = P.DS; bf.DX0 = P.DX0;
+    memset(&bf, 0, sizeof(bf));
+    bf.WoT = P.WoT; bf.WcT = P.WcT; bf.ENCA = P.ENCA; bf.ALPHA = P.ALPHA; bf.CVH = P.CVH; bf.ML = P.MLB;
+    for (int l = 0; l < nl; ++l) { bf.WlT[l] = P.WlT[l]; bf.WuT[l] = P.WuT[l]; bf.C[l] = P.C[l]; bf.G[l] = P.G[l]; }
+    bf.HT = P.HT; bf.LOGITS = P.LOGITS; bf.DPRE = P.DPRE; bf.DCVH = P.DCVH; bf.DS = P.DS; bf.DX0 = P.DX0;
     bf.DHATT = P.PART; bf.d_c0 = d_c0; bf.ctr = P.PCTR;
     bf.DXH = b6s ? P.DXH : nullptr;
     ASTK_TRY(decoder_persist_bwd_launch(d, enc, rnn_masks, bf, s));

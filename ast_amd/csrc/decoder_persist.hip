@@ -17,7 +17,12 @@
 //   P3b attention combine per b (cv, alpha)       P4 ht = tanh(Wc[cv;h]+bc)   P5 logits tile + per-tile CE stats
 //   P6 CE combine per batch tile: lse, loss row, argmax (feedback token)
 // The saved-state layout is exactly decoder.hip's DecPlan, so either backward works on it.
-// Applicability (else the per-launch path of decoder.hip runs): 1 decoder layer, H,A multiples of 16, sizes within the
+// Decoder layers 1..NL-1 (the shipped es_en_20h / asr_gpfr models have 3): layer l at step s needs layer l-1 at step s and its own
+// step s-1, and layer 0 needs ht_{s-1} (input feeding), so the layers of one step are strictly sequential: one more hand-off
+// per layer on the chain.  Every cell item (batch tile, 8 units) of every layer has a fixed owner: layers below the top live on
+// the workgroups that own the same item of layer 0, the top layer on the otherwise lightly loaded upper half of the grid
+// (ctx / logits owners), so that no workgroup holds more than 68 float4 (272 VGPRs) of weights.
+// Applicability (else the per-launch path of decoder.hip runs): 1-3 decoder layers, H,A multiples of 16, sizes within the
 // register budgets below, grid of 256 workgroups fully resident.  All spins are bounded (abort word).
 #include "common.h"
 
@@ -27,22 +32,26 @@ namespace {
 
 constexpr int CTRS = 64;          // counter stride in words (256 B)
 constexpr int G = 256;            // workgroups (one per CU)
-enum Phase { PH_CELL = 0, PH_Q, PH_ATT, PH_CMB, PH_CTX, PH_LOG, PH_CE, PH_N };
+enum Phase { PH_CELL = 0 /* + layer: 0..2 */, PH_CELL1, PH_CELL2, PH_CMB, PH_CTX, PH_LOG, PH_CE, PH_N };
+constexpr int PDEC_MAX_LAYERS = 3;
 constexpr int NPHASE_SLOTS = 8;   // counter lines reserved per batch tile ahead of the abort word and the per-row counters
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct PDecArgs {
   int B, S, L, T, Tp, H, E, A, V, Vp, XI, nbt, nsplit, chunk, ntile_v;
-  const float *embed, *Wu, *bias, *Wl, *Wa, *ba, *Wc, *bc, *Wo, *bo, *cw;
+  const float *embed, *Wa, *ba, *Wc, *bc, *Wo, *bo, *cw;
+  const float *Wu[PDEC_MAX_LAYERS], *bias[PDEC_MAX_LAYERS], *Wl[PDEC_MAX_LAYERS];     // per decoder layer
   const float* enc;
   const float* encA;       // enc . Wa  (B,T,H): score = encA.h + enc.ba
   const int32_t* y;
   const int32_t* use_truth;
   const float* emb_mask;   // [S][B][E] or null
-  const float* rnn_mask;   // [S][B][H] or null
+  const float* rnn_mask[PDEC_MAX_LAYERS];   // [S][B][H] per layer, or null
   int32_t* TOK; int32_t* PRED;
-  float *X0, *Gt, *Cst, *HR, *Q, *ALPHA, *CVH, *HT, *LOGITS, *LOSSROWS, *LSE;
+  float *Gt[PDEC_MAX_LAYERS], *Cst[PDEC_MAX_LAYERS], *HR[PDEC_MAX_LAYERS];
+  float* HD[PDEC_MAX_LAYERS];                // [S][B][H] dropped outputs of the layers below the top (the top's go to CVH[:, H:])
+  float *X0, *Q, *ALPHA, *CVH, *HT, *LOGITS, *LOSSROWS, *LSE;
   float* PART;             // [S][B][nsplit][H+4]
   float* ML;               // [S][B][2] softmax max and 1/sum of every attention row
   float* CESTAT;           // [S][B][ntile_v][4]
@@ -193,6 +202,11 @@ constexpr int NB_E = 2, NB_A = 8, NB_H = 8, NB_C = 16, NB_L = 8;
 constexpr int CELLW = NB_E + NB_A + NB_H;            // per gate tile
 constexpr int OFF_WC = 0, OFF_WL = NB_C, NWREG = 2 * CELLW;
 static_assert(OFF_WL + 2 * NB_L <= NWREG, "register budget");
+// NL > 1: two cell slots of 2 tiles x (8 + 8) k-blocks = 32 float4 each: [0, 32) layer 0 ([ht | lateral]; its embedding columns are
+// re-read every step, off the chain) or ctx / logits, [32, 64) a layer >= 1 ([upward | lateral]).  64 float4 = 256 registers = the
+// whole AGPR file: one float4 more and the compiler spills loop-invariant addresses to scratch inside the step loop.
+constexpr int CELLW2 = 2 * NB_H, OFF_C2 = 2 * CELLW2, NWREG_ML = 4 * CELLW2;
+static_assert(OFF_WL + 2 * NB_L <= OFF_C2, "register budget");
 
 template <int NB>
 __device__ __forceinline__ void mfma_blocks(f32x4& acc, const float4* a, const float4* w) {
@@ -216,7 +230,7 @@ __device__ __forceinline__ void aload_sc1(float4* a, __amdgpu_buffer_rsrc_t ra, 
 
 // NC > 0: H = 64 * NC and chunk <= 32 are compile-time facts for the attention phase (fully unrolled, batched LDS reads);
 // NC = 0: generic loops.
-template <int NC>
+template <int NC, int NL>
 __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // enc slice [chunk][H], encA slice [chunk][H], scratch
   __shared__ __attribute__((aligned(16))) float red[4 * 256];
@@ -256,18 +270,42 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
   const int ce_rank = wg - (G - B - nbt);                 // CE items (bt)
   const bool has_ce = ce_rank >= 0 && ce_rank < nbt;
 
+  // upper decoder layers (NL > 1): layers 1..NL-2 on the owner of the same layer-0 item, the top layer on the upper workgroups
+  constexpr int TOP = NL - 1;
+  const bool has_mid = NL > 2 && has_cell;
+  const int top_rank = wg - (G - n_cell);
+  const bool has_top = NL > 1 && top_rank >= 0;
+  const int top_bt = has_top ? top_rank / (H / 8) : 0, top_u0 = has_top ? (top_rank % (H / 8)) * 8 : 0;
+
   // ---------------- resident weights
-  float4 wreg[NWREG];
+  constexpr int NW = NL > 1 ? NWREG_ML : NWREG;
+  float4 wreg[NW];
 #pragma unroll
-  for (int i = 0; i < NWREG; ++i) wreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < NW; ++i) wreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int r16 = lane & 15;
+  if constexpr (NL > 1) {
+    // second cell slot: [tile][upward 8 | lateral 8] of layer 1 (mid, NL == 3) or of the top layer
+    const int l2 = has_mid ? 1 : TOP;
+    if (has_mid || has_top) {
+      const int u0 = has_mid ? cell_u0 : top_u0;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = 4 * u0 + 16 * t + r16;
+        wload<NB_H>(wreg + OFF_C2 + t * CELLW2, a.Wu[l2] + (long)row * H, 0, 0, H, lane, wave);
+        wload<NB_H>(wreg + OFF_C2 + t * CELLW2 + NB_H, a.Wl[l2] + (long)row * H, 0, 0, H, lane, wave);
+      }
+    }
+  }
+  // layer-0 slot: [emb | ht | lateral] per tile with one layer, [ht | lateral] with more (the embedding columns are streamed)
+  constexpr bool EMB_RES = NL == 1;
+  constexpr int CW0 = EMB_RES ? CELLW : CELLW2, W0_A = EMB_RES ? NB_E : 0, W0_H = W0_A + NB_A;
   if (has_cell) {   // two 16-row gate tiles (units u0..u0+3, u0+4..u0+7): [emb cols | ht cols] of Wu, then Wl
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int row = 4 * cell_u0 + 16 * t + r16;
-      wload<NB_E>(wreg + t * CELLW, a.Wu + (long)row * XI, 0, 0, E, lane, wave);
-      wload<NB_A>(wreg + t * CELLW + NB_E, a.Wu + (long)row * XI + E, 0, 0, A, lane, wave);
-      wload<NB_H>(wreg + t * CELLW + NB_E + NB_A, a.Wl + (long)row * H, 0, 0, H, lane, wave);
+      if constexpr (EMB_RES) wload<NB_E>(wreg + t * CW0, a.Wu[0] + (long)row * XI, 0, 0, E, lane, wave);
+      wload<NB_A>(wreg + t * CW0 + W0_A, a.Wu[0] + (long)row * XI + E, 0, 0, A, lane, wave);
+      wload<NB_H>(wreg + t * CW0 + W0_H, a.Wl[0] + (long)row * H, 0, 0, H, lane, wave);
     }
   } else {
     if (has_c) wload<NB_C>(wreg + OFF_WC, a.Wc, 2 * H, c_n0 + r16, 2 * H, lane, wave);
@@ -306,20 +344,32 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
   }
   __syncthreads();
 
-  const __amdgpu_buffer_rsrc_t r_x0 = make_rsrc(a.X0), r_hr = make_rsrc(a.HR), r_cvh = make_rsrc(a.CVH), r_ht = make_rsrc(a.HT);
+  const __amdgpu_buffer_rsrc_t r_x0 = make_rsrc(a.X0), r_hr = make_rsrc(a.HR[0]), r_cvh = make_rsrc(a.CVH), r_ht = make_rsrc(a.HT);
   const __amdgpu_buffer_rsrc_t r_part = make_rsrc(a.PART), r_ces = make_rsrc(a.CESTAT);
   // cell epilogue ownership: threads 0..127: tile = tid>>6, (row = (tid>>2)&15, unit = tid&3)
   const int ce_tile = tid >> 6, ce_row = (tid >> 2) & 15, ce_u = tid & 3;
   const int cell_b = cell_bt * 16 + ce_row, cell_u = cell_u0 + 4 * ce_tile + ce_u;
   float c_state = 0.f;
-  if (has_cell && tid < 128 && cell_b < B) c_state = a.Cst[(long)cell_b * H + cell_u];   // C[0] = c0
+  if (has_cell && tid < 128 && cell_b < B) c_state = a.Cst[0][(long)cell_b * H + cell_u];   // C[0] = c0
   float4 cbias = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (has_cell && tid < 128) cbias = *reinterpret_cast<const float4*>(a.bias + 4 * cell_u);
+  if (has_cell && tid < 128) cbias = *reinterpret_cast<const float4*>(a.bias[0] + 4 * cell_u);
+  // second cell slot: state and bias of this thread's (row, unit) of layer l2
+  const int l2 = has_mid ? 1 : TOP;
+  const int c2_bt = has_mid ? cell_bt : top_bt, c2_u0 = has_mid ? cell_u0 : top_u0;
+  const int c2_b = c2_bt * 16 + ce_row, c2_u = c2_u0 + 4 * ce_tile + ce_u;
+  const bool has_c2 = NL > 1 && (has_mid || has_top);
+  float c_state2 = 0.f;
+  float4 cbias2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (has_c2 && tid < 128) {
+    if (c2_b < B) c_state2 = a.Cst[l2][(long)c2_b * H + c2_u];
+    cbias2 = *reinterpret_cast<const float4*>(a.bias[l2] + 4 * c2_u);
+  }
 
   long long tk[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) tk[i] = 0;
-  const bool timing = a.dbg != 0;
+  // per-phase debug timers (ASTK_PERSIST_DBG): 50 registers when live -- compiled in only where they fit without spills (one layer)
+  const bool timing = NL == 1 && a.dbg != 0;
   long long tlast = timing ? wall_clock64() : 0;
   long long tk_att = 0;
   long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -354,8 +404,13 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          mfma_blocks<NB_E>(acc[t], ae, wreg + t * CELLW);
-          mfma_blocks<NB_H>(acc[t], ah, wreg + t * CELLW + NB_E + NB_A);
+          if constexpr (EMB_RES) mfma_blocks<NB_E>(acc[t], ae, wreg + t * CW0);
+          else {
+            float4 we[NB_E];
+            wload<NB_E>(we, a.Wu[0] + (long)(4 * cell_u0 + 16 * t + r16) * XI, 0, 0, E, lane, wave);
+            mfma_blocks<NB_E>(acc[t], ae, we);
+          }
+          mfma_blocks<NB_H>(acc[t], ah, wreg + t * CW0 + W0_H);
         }
       }
       TICK(0)
@@ -366,8 +421,8 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
         float4 at[NB_A];
         aload_sc1<NB_A>(at, r_x0, ((long)s * B + brow) * XI + E, A, lane, wave);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_blocks<NB_A>(acc[0], at, wreg + NB_E);
-        mfma_blocks<NB_A>(acc[1], at, wreg + CELLW + NB_E);
+        mfma_blocks<NB_A>(acc[0], at, wreg + W0_A);
+        mfma_blocks<NB_A>(acc[1], at, wreg + CW0 + W0_A);
       }
       const float z0 = reduce16(acc[0], red);
       const float z1 = reduce16(acc[1], red);
@@ -381,24 +436,78 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
         const float ga = tanh_fast(z.x + cbias.x), gi = sigm_fast(z.y + cbias.y), gf = sigm_fast(z.z + cbias.z), go = sigm_fast(z.w + cbias.w);
         c_state = ga * gi + gf * c_state;
         const float hh = go * tanh_fast(c_state);
-        const float hd = a.rnn_mask ? hh * a.rnn_mask[((long)s * B + cell_b) * H + cell_u] : hh;
+        const float hd = a.rnn_mask[0] ? hh * a.rnn_mask[0][((long)s * B + cell_b) * H + cell_u] : hh;
         gsave = make_float4(ga, gi, gf, go);
-        st_sc1(a.HR + ((long)(s + 1) * B + cell_b) * H + cell_u, hh);
-        st_sc1(a.CVH + ((long)s * B + cell_b) * 2 * H + H + cell_u, hd);
+        st_sc1(a.HR[0] + ((long)(s + 1) * B + cell_b) * H + cell_u, hh);
+        if constexpr (NL > 1) st_sc1(a.HD[0] + ((long)s * B + cell_b) * H + cell_u, hd);     // input of layer 1
+        else st_sc1(a.CVH + ((long)s * B + cell_b) * 2 * H + H + cell_u, hd);
       }
       TICK(2)
       publish_sh(CTR(PH_CELL, bt), cell_u0 / 8);
       TICK(3)
       if (ev) {                                    // saved for the backward (plain stores, off the critical path)
-        *reinterpret_cast<float4*>(a.Gt + ((long)s * B + cell_b) * 4 * H + 4 * cell_u) = gsave;
-        a.Cst[((long)(s + 1) * B + cell_b) * H + cell_u] = c_state;
+        *reinterpret_cast<float4*>(a.Gt[0] + ((long)s * B + cell_b) * 4 * H + 4 * cell_u) = gsave;
+        a.Cst[0][((long)(s + 1) * B + cell_b) * H + cell_u] = c_state;
+      }
+    }
+    // ================= P1b: decoder layers 1..NL-1 (one cell item per workgroup: layer 1 of a 3-layer stack on the lower
+    // workgroups, the top layer on the upper ones).  z = Wu hd_{l-1,s} + Wl h_{l,s-1} + b: the recurrent half runs before the wait.
+    if constexpr (NL > 1) {
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        // pass 0: layer 1 as a MID layer (NL == 3 only); pass 1: the TOP layer
+        const bool mine = pass == 0 ? has_mid : has_top;
+        if ((pass == 0 && NL < 3) || !mine) continue;
+        const int l = pass == 0 ? 1 : TOP;
+        const int bt = c2_bt, m0 = bt * 16;
+        const int brow = min(m0 + r16, B - 1);
+        if (s > 0) { if (!wg_wait_sh(CTR(PH_CELL + l, bt), H / 8, s, a.ab, &s_flag)) return; }
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        {
+          float4 ah[NB_H];
+          aload_sc1<NB_H>(ah, make_rsrc(a.HR[l]), ((long)s * B + brow) * H, H, lane, wave);     // h_{l,s-1} (h0 at s = 0)
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_blocks<NB_H>(acc[0], ah, wreg + OFF_C2 + NB_H);
+          mfma_blocks<NB_H>(acc[1], ah, wreg + OFF_C2 + CELLW2 + NB_H);
+        }
+        if (!wg_wait_sh(CTR(PH_CELL + l - 1, bt), H / 8, s + 1, a.ab, &s_flag)) return;
+        {
+          float4 ax[NB_H];
+          aload_sc1<NB_H>(ax, make_rsrc(a.HD[l - 1]), ((long)s * B + brow) * H, H, lane, wave);  // dropped output of the layer below
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_blocks<NB_H>(acc[0], ax, wreg + OFF_C2);
+          mfma_blocks<NB_H>(acc[1], ax, wreg + OFF_C2 + CELLW2);
+        }
+        const float z0 = reduce16(acc[0], red);
+        const float z1 = reduce16(acc[1], red);
+        zt[tid] = z0;
+        zt[256 + tid] = z1;
+        __syncthreads();
+        float4 gsave = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool ev = tid < 128 && c2_b < B;
+        if (ev) {
+          const float4 z = *reinterpret_cast<const float4*>(&zt[ce_tile * 256 + ce_row * 16 + ce_u * 4]);
+          const float ga = tanh_fast(z.x + cbias2.x), gi = sigm_fast(z.y + cbias2.y), gf = sigm_fast(z.z + cbias2.z), go = sigm_fast(z.w + cbias2.w);
+          c_state2 = ga * gi + gf * c_state2;
+          const float hh = go * tanh_fast(c_state2);
+          const float hd = a.rnn_mask[l] ? hh * a.rnn_mask[l][((long)s * B + c2_b) * H + c2_u] : hh;
+          gsave = make_float4(ga, gi, gf, go);
+          st_sc1(a.HR[l] + ((long)(s + 1) * B + c2_b) * H + c2_u, hh);
+          if (l == TOP) st_sc1(a.CVH + ((long)s * B + c2_b) * 2 * H + H + c2_u, hd);
+          else st_sc1(a.HD[l] + ((long)s * B + c2_b) * H + c2_u, hd);
+        }
+        publish_sh(CTR(PH_CELL + l, bt), c2_u0 / 8);
+        if (ev) {
+          *reinterpret_cast<float4*>(a.Gt[l] + ((long)s * B + c2_b) * 4 * H + 4 * c2_u) = gsave;
+          a.Cst[l][((long)(s + 1) * B + c2_b) * H + c2_u] = c_state2;
+        }
       }
     }
     // ================= P3: attention over the LDS-resident slices: score = encA.h + eb, p = exp(score - max), cv partial =========
     if (has_att) {
       const int b = att_b, bt = b / 16;
       TICK(15)
-      if (!wg_wait_sh(CTR(PH_CELL, bt), H / 8, s + 1, a.ab, &s_flag)) return;
+      if (!wg_wait_sh(CTR(PH_CELL + TOP, bt), H / 8, s + 1, a.ab, &s_flag)) return;
       TICK(4)
       const long long ta0 = a.tick_out ? wall_clock64() : 0;
       const int c4 = (a.chunk + 3) & ~3;
@@ -632,7 +741,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       if constexpr (NC > 0) {
         // the h half of [cv ; h] was published by the cells long ago: its fragments (k-blocks NC..2NC-1 of each wave) and their MFMAs
         // run BEFORE the wait on the combine; only the cv half is fetched and multiplied behind it
-        if (!wg_wait_sh(CTR(PH_CELL, bt), H / 8, s + 1, a.ab, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PH_CELL + TOP, bt), H / 8, s + 1, a.ab, &s_flag)) return;
         {
           float4 ahd[NC];
           const int q = lane >> 4;
@@ -748,11 +857,11 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
     atomicAdd(&a.tick_out[wg], (float)tk_att * 0.01f / (float)S);
     if (wg == 0) atomicAdd(&a.tick_out[G], 1.0f);
   }
-  if (a.dbg != 0 && tid == 0 && (wg == 0 || wg == n_cell || wg == G - B || wg == G - 1))
+  if (timing && tid == 0 && (wg == 0 || wg == n_cell || wg == G - B || wg == G - 1))
     printf("pdec wg %3d per-step 10ns: P1[pre %lld waitctx %lld ht+epi %lld publish %lld] P3[wait %lld work %lld] P3b[wait %lld work %lld] "
            "P4[wait %lld work %lld] P5[wait %lld work %lld] P6 %lld other %lld | P3: hload %lld pass1+max %lld\n", wg, tk[0] / S, tk[1] / S, tk[2] / S, tk[3] / S,
            tk[4] / S, tk[5] / S, tk[6] / S, tk[7] / S, tk[8] / S, tk[9] / S, tk[10] / S, tk[11] / S, tk[12] / S, tk[15] / S, tk[13] / S, tk[14] / S);
-  if (a.dbg != 0 && tid == 0 && (wg == 0 || wg == G - 1))
+  if (timing && tid == 0 && (wg == 0 || wg == G - 1))
     printf("pdec-att wg %3d per-step 10ns: pass1 %lld barrier %lld max+exp %lld barrier %lld pass2+stores %lld publish %lld\n", wg, tq[0] / S, tq[1] / S,
            tq[2] / S, tq[3] / S, tq[4] / S, tq[5] / S);
 #undef TICK
@@ -767,23 +876,29 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
 //   B2 d_cvh = d_pre Wc  -> d_cv | dh (direct part)                      items (bt, 32 cols of 2H)
 //   B3 attention backward over the LDS-resident slices:  ds = alpha (enc.d_cv - cv.d_cv) ; dh_att partial = sum_t ds encA
 //   B5 cell backward: dh = mask (dh_direct + sum_splits dh_att) + dz_{s+1} Wl ; dz ; dc carried in a register
-//   B6 d_x0 = dz Wu  (its [E:] half is the d_ht carry of step s-1)       items (bt, 16 cols of E+A)
+//      NL > 1: one B5 per layer, top first.  A layer below the top takes the gradient of its dropped output from the layer above by
+//      multiplying dz_{l+1,s} with its 16 columns of Wu_{l+1} ITSELF (no separate d_x phase, one hand-off per layer):
+//      dh_l = mask_l (dz_{l+1,s} Wu_{l+1}) + dz_{l,s+1} Wl_l
+//   B6 d_x0 = dz_0 Wu_0  (its [E:] half is the d_ht carry of step s-1)   items (bt, 16 cols of E+A)
 // Products that do not depend on the current step's chain (dlogits Wo in B1, dz_{s+1} Wl in B5) run before the wait.
 // Weight gradients, d_enc, dq and d_embed are batched products over all steps after the loop (decoder.hip).
-enum BPhase { PB1 = 0, PB2, PB3, PB5, PB6, PB_N };
+enum BPhase { PB1 = 0, PB2, PB5 /* + layer: 0..2 */, PB5_1, PB5_2, PB6, PB_N };
 
 struct PDecBwdArgs {
   int B, S, L, T, Tp, H, E, A, V, Vp, XI, nbt, nsplit, chunk;
-  const float *WoT, *WcT, *WlT, *WuT;      // (A,Vp) (2H,A) (H,4H) (XI,4H)
+  int NL;
+  const float *WoT, *WcT;                  // (A,Vp) (2H,A)
+  const float *WlT[PDEC_MAX_LAYERS], *WuT[PDEC_MAX_LAYERS];      // per layer: (H,4H), (in,4H) with in = XI for layer 0, H above
   const float *enc, *encA;
-  const float *CVH, *HT, *LOGITS, *Cst, *rnn_mask, *ML;
+  const float *CVH, *HT, *LOGITS, *ML;
+  const float *Cst[PDEC_MAX_LAYERS], *rnn_mask[PDEC_MAX_LAYERS];
   float *ALPHA;                            // raw scores in, normalised alpha out
-  float *Gt;                               // gates -> dz
+  float *Gt[PDEC_MAX_LAYERS];              // gates -> dz
   float *DPRE, *DCVH, *DS, *DX0, *DHATT;   // DHATT [S][B][nsplit][H]
   float* DXH;                              // b6_split: [2][S][B][A] K-halves of d_x0[:, E:] (the carry of the next step's B1)
   int b6_split;                            // 1: B6 covers only the ht columns, every item split into two K halves (the embedding
                                            //    columns are one batched GEMM after the launch)
-  float *d_c0;
+  float *d_c0;                             // [NL][B][H]
   unsigned* ctr;
   AbortCtl ab;
   int dbg;
@@ -792,6 +907,9 @@ struct PDecBwdArgs {
 
 constexpr int NB_B1 = 18, NB_B2 = 8, NB_B5 = 32, NB_B6 = 32;     // k-blocks per wave: Vp <= 1152, A <= 512, 4H <= 2048
 constexpr int NWB = 36;
+// NL > 1: B5 of layer l on workgroups [l n5, (l+1) n5) with Wl_l^T rows in [0, 32) and (below the top) Wu_{l+1}^T rows in [32, 64);
+// B1/B2 on the last max(n1, n2) workgroups in [0, 34); the split B6 items on the last n6 workgroups in [48, 64)
+constexpr int NWB_ML = 64, OFF_B5UP = NB_B5, OFF_B6_ML = 48;
 
 // acc += A . W over NB blocks, A fetched in chunks of CH blocks (bounds the live A registers)
 template <int NB, int CH>
@@ -807,7 +925,7 @@ __device__ __forceinline__ void wmac_chunked(f32x4& acc, const float4* w, __amdg
   }
 }
 
-template <int NC>   // as in decoder_persist_fwd: NC > 0 means H = 64 NC and chunk <= 32 at compile time for the attention phase
+template <int NC, int NL>   // as in decoder_persist_fwd: NC > 0 means H = 64 NC and chunk <= 32 at compile time for the attention phase
 __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ __attribute__((aligned(16))) float red[4 * 256];
@@ -819,11 +937,15 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   unsigned* ctr = a.ctr;
 #define CTR(ph, bt) (ctr + ((ph) * nbt + (bt)) * NSH * CTRS)
 #define ROWCTR(row) (ctr + ((long)NPHASE_SLOTS * NSH * nbt + 2 + (row)) * CTRS)
-  // ---------------- roles: [0,n5) cell bwd, [n5, n5+n6) dx0, [n5+n6, n5+n6+n1) d_pre + d_cvh ; attention: all
+  // ---------------- roles.  NL == 1: [0,n5) cell bwd, [n5, n5+n6) dx0, [n5+n6, n5+n6+n1) d_pre + d_cvh ; attention: all.
+  // NL > 1: [l n5, (l+1) n5) cell bwd of layer l ; d_pre + d_cvh on the last max(n1, n2) workgroups ; dx0 (split) on the last n6
+  constexpr int TOP = NL - 1;
   const int n5 = nbt * (H / 16), n6 = a.b6_split ? 2 * nbt * (A / 16) : nbt * (XI / 16), n1 = nbt * (A / 16), n2 = nbt * (2 * H / 32);
-  const bool has5 = wg < n5;
-  const int b5_bt = has5 ? wg / (H / 16) : 0, b5_u0 = has5 ? (wg % (H / 16)) * 16 : 0;
-  const int r6 = wg - n5;
+  const int n12 = n1 > n2 ? n1 : n2;
+  const bool has5 = wg < NL * n5;
+  const int b5_l = has5 ? wg / n5 : 0, b5_i = has5 ? wg % n5 : 0;
+  const int b5_bt = b5_i / (H / 16), b5_u0 = (b5_i % (H / 16)) * 16;
+  const int r6 = NL > 1 ? wg - (G - n6) : wg - n5;
   const bool has6 = r6 >= 0 && r6 < n6;
   // B6 item: 16 columns of d_x0 for one batch tile; split mode: ht columns only, item (r6 >> 1), K half (r6 & 1)
   const int b6_half = a.b6_split ? (r6 & 1) : 0;
@@ -831,7 +953,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   const int b6_per_bt = a.b6_split ? A / 16 : XI / 16;
   const int b6_bt = has6 ? b6_item / b6_per_bt : 0, b6_n0 = has6 ? (a.b6_split ? E : 0) + (b6_item % b6_per_bt) * 16 : 0;
   const int b6_k0 = b6_half * (K4 / 2);
-  const int r1 = wg - n5 - n6;
+  const int r1 = NL > 1 ? wg - (G - n12) : wg - n5 - n6;
   const bool has1 = r1 >= 0 && r1 < n1;
   const int b1_bt = has1 ? r1 / (A / 16) : 0, b1_n0 = has1 ? (r1 % (A / 16)) * 16 : 0;
   const bool has2 = r1 >= 0 && r1 < n2;
@@ -840,16 +962,23 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   const bool has_att = wg < n_att;
   const int att_b = has_att ? wg % B : 0, att_sp = has_att ? wg / B : 0;
 
-  float4 wreg[NWB];
+  constexpr int NW = NL > 1 ? NWB_ML : NWB;
+  constexpr int OFF_B6 = NL > 1 ? OFF_B6_ML : 0;
+  float4 wreg[NW];
 #pragma unroll
-  for (int i = 0; i < NWB; ++i) wreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < NW; ++i) wreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int r16 = lane & 15;
-  if (has5) wload<NB_B5>(wreg, a.WlT, K4, b5_u0 + r16, K4, lane, wave);
-  else if (has6) {
-    if (a.b6_split) wload<NB_B6 / 2>(wreg, a.WuT + b6_k0, K4, b6_n0 + r16, K4 / 2, lane, wave);
-    else wload<NB_B6>(wreg, a.WuT, K4, b6_n0 + r16, K4, lane, wave);
+  if (has5) {
+    wload<NB_B5>(wreg, a.WlT[b5_l], K4, b5_u0 + r16, K4, lane, wave);
+    if constexpr (NL > 1) {
+      if (b5_l < TOP) wload<NB_B5>(wreg + OFF_B5UP, a.WuT[b5_l + 1], K4, b5_u0 + r16, K4, lane, wave);
+    }
   }
-  else {
+  if (has6 && (NL > 1 || !has5)) {
+    if (a.b6_split) wload<NB_B6 / 2>(wreg + OFF_B6, a.WuT[0] + b6_k0, K4, b6_n0 + r16, K4 / 2, lane, wave);
+    else wload<NB_B6>(wreg + OFF_B6, a.WuT[0], K4, b6_n0 + r16, K4, lane, wave);
+  }
+  if (!has5 && (NL > 1 || !has6)) {
     if (has1) wload<NB_B1>(wreg, a.WoT, Vp, b1_n0 + r16, Vp, lane, wave);
     if (has2) {
       wload<NB_B2>(wreg + NB_B1, a.WcT, A, b2_n0 + r16, A, lane, wave);
@@ -872,14 +1001,14 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   }
   __syncthreads();
   const __amdgpu_buffer_rsrc_t r_dl = make_rsrc(a.LOGITS), r_dpre = make_rsrc(a.DPRE), r_dcvh = make_rsrc(a.DCVH),
-                               r_g = make_rsrc(a.Gt), r_dx0 = make_rsrc(a.DX0), r_dha = make_rsrc(a.DHATT);
+                               r_g = make_rsrc(a.Gt[b5_l]), r_g0 = make_rsrc(a.Gt[0]), r_dx0 = make_rsrc(a.DX0), r_dha = make_rsrc(a.DHATT);
   const int e_row = tid >> 4, e_col = tid & 15;
   float dc_state = 0.f;
   long long tk_att = 0;
   long long tb[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) tb[i] = 0;
-  const bool timing = a.dbg != 0;
+  const bool timing = NL == 1 && a.dbg != 0;
   long long tlast = timing ? wall_clock64() : 0;
 #define TB(i) if (timing) { const long long now_ = wall_clock64(); tb[i] += now_ - tlast; tlast = now_; }
 
@@ -1121,13 +1250,13 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
       if (a.tick_out) tk_att += wall_clock64() - tb0;
       TB(5)
     }
-    // ================= B5: cell backward =================
+    // ================= B5: cell backward (one per decoder layer, top first) =================
     if (has5) {
-      const int bt = b5_bt, m0 = bt * 16;
+      const int bt = b5_bt, m0 = bt * 16, l = b5_l;
       const int rows_bt = min(16, B - bt * 16);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       if (n > 0) {       // dh_rec = dz_{s+1} Wl: independent of this step's chain
-        if (!wg_wait_sh(CTR(PB5, bt), H / 16, n, a.ab, &s_flag)) return;
+        if (!wg_wait_sh(CTR(PB5 + l, bt), H / 16, n, a.ab, &s_flag)) return;
         wmac_chunked<NB_B5, 16>(acc, wreg, r_g, ((long)(s + 1) * B + min(m0 + r16, B - 1)) * K4, K4, lane, wave);
       }
       const float v = reduce16(acc, red);
@@ -1137,27 +1266,41 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
       float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
       float ccur = 0.f, cp = 0.f, mk = 1.f;
       if (ev) {
-        g = *reinterpret_cast<const float4*>(a.Gt + ((long)s * B + row) * K4 + 4 * u);
-        ccur = a.Cst[((long)(s + 1) * B + row) * H + u];
-        cp = a.Cst[((long)s * B + row) * H + u];
-        if (a.rnn_mask) mk = a.rnn_mask[((long)s * B + row) * H + u];
+        g = *reinterpret_cast<const float4*>(a.Gt[l] + ((long)s * B + row) * K4 + 4 * u);
+        ccur = a.Cst[l][((long)(s + 1) * B + row) * H + u];
+        cp = a.Cst[l][((long)s * B + row) * H + u];
+        if (a.rnn_mask[l]) mk = a.rnn_mask[l][((long)s * B + row) * H + u];
       }
       TB(6)
-      if (!wg_wait_multi(ROWCTR(m0), CTRS, rows_bt, (unsigned)(a.nsplit * (n + 1)), a.ab, &s_flag)) return;
-      TB(7)
-      if (ev) {
-        float dy = ld_sc1(a.DCVH + ((long)s * B + row) * 2 * H + H + u);
-        float hs = 0.f;
-        for (int k0 = 0; k0 < a.nsplit; k0 += 8) {      // 8 partial loads in flight (a plain loop waits for each one)
-          float hv[8];
+      float dy = 0.f;
+      if (NL == 1 || l == TOP) {
+        if (!wg_wait_multi(ROWCTR(m0), CTRS, rows_bt, (unsigned)(a.nsplit * (n + 1)), a.ab, &s_flag)) return;
+        TB(7)
+        if (ev) {
+          dy = ld_sc1(a.DCVH + ((long)s * B + row) * 2 * H + H + u);
+          float hs = 0.f;
+          for (int k0 = 0; k0 < a.nsplit; k0 += 8) {      // 8 partial loads in flight (a plain loop waits for each one)
+            float hv[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            hv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                r_dha, (int)(((((long)s * B + row) * a.nsplit + min(k0 + j, a.nsplit - 1)) * H + u) * 4), 0, 16));
+            for (int j = 0; j < 8; ++j)
+              hv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                  r_dha, (int)(((((long)s * B + row) * a.nsplit + min(k0 + j, a.nsplit - 1)) * H + u) * 4), 0, 16));
 #pragma unroll
-          for (int j = 0; j < 8; ++j) hs += k0 + j < a.nsplit ? hv[j] : 0.f;
+            for (int j = 0; j < 8; ++j) hs += k0 + j < a.nsplit ? hv[j] : 0.f;
+          }
+          dy += hs;
         }
-        dy += hs;
+      } else {
+        if constexpr (NL > 1) {
+          // gradient of this layer's dropped output: dz_{l+1,s} times this workgroup's 16 columns of Wu_{l+1}
+          if (!wg_wait_sh(CTR(PB5 + l + 1, bt), H / 16, n + 1, a.ab, &s_flag)) return;
+          TB(7)
+          f32x4 accu = {0.f, 0.f, 0.f, 0.f};
+          wmac_chunked<NB_B5, 16>(accu, wreg + OFF_B5UP, make_rsrc(a.Gt[l + 1]), ((long)s * B + min(m0 + r16, B - 1)) * K4, K4, lane, wave);
+          dy = reduce16(accu, red);
+        }
+      }
+      if (ev) {
         const float dh = v + dy * mk;
         const float tc = tanh_fast(ccur);
         const float dcv = dh * g.w * (1.f - tc * tc) + dc_state;
@@ -1167,7 +1310,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
         __builtin_amdgcn_raw_buffer_store_b128(o, r_g, (int)((((long)s * B + row) * K4 + 4 * u) * 4), 0, 16);
         dc_state = dcv * g.z;
       }
-      publish_sh(CTR(PB5, bt), b5_u0 / 16);
+      publish_sh(CTR(PB5 + l, bt), b5_u0 / 16);
       TB(8)
     }
     // ================= B6: d_x0 = dz Wu =================
@@ -1177,8 +1320,8 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
       if (!wg_wait_sh(CTR(PB5, bt), H / 16, n + 1, a.ab, &s_flag)) return;
       TB(9)
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      if (a.b6_split) wmac_chunked<NB_B6 / 2, 16>(acc, wreg, r_g, ((long)s * B + min(m0 + r16, B - 1)) * K4 + b6_k0, K4 / 2, lane, wave);
-      else wmac_chunked<NB_B6, 16>(acc, wreg, r_g, ((long)s * B + min(m0 + r16, B - 1)) * K4, K4, lane, wave);
+      if (a.b6_split) wmac_chunked<NB_B6 / 2, 16>(acc, wreg + OFF_B6, r_g0, ((long)s * B + min(m0 + r16, B - 1)) * K4 + b6_k0, K4 / 2, lane, wave);
+      else wmac_chunked<NB_B6, 16>(acc, wreg + OFF_B6, r_g0, ((long)s * B + min(m0 + r16, B - 1)) * K4, K4, lane, wave);
       const float v = reduce16(acc, red);
       const int row = m0 + e_row;
       if (row < B) {
@@ -1195,7 +1338,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
 #undef TB
   if (has5) {
     const int row = b5_bt * 16 + e_row, u = b5_u0 + e_col;
-    if (row < B) a.d_c0[(long)row * H + u] = dc_state;
+    if (row < B) a.d_c0[((long)b5_l * B + row) * H + u] = dc_state;
   }
   if (a.tick_out && tid == 0 && has_att) {
     atomicAdd(&a.tick_out[wg], (float)tk_att * 0.01f / (float)S);
@@ -1243,7 +1386,8 @@ __global__ __launch_bounds__(256) void k_dlogits_all(float* __restrict__ logits,
 
 struct DecPersistBuffers {
   int32_t *TOK, *PRED;
-  float *X0, *G, *C, *HR, *Q, *ALPHA, *CVH, *HT, *LOGITS, *LOSSROWS;
+  float *X0, *Q, *ALPHA, *CVH, *HT, *LOGITS, *LOSSROWS;
+  float *G[PDEC_MAX_LAYERS], *C[PDEC_MAX_LAYERS], *HR[PDEC_MAX_LAYERS], *HD[PDEC_MAX_LAYERS];
   float *LSE, *PART, *CESTAT, *ENCA, *ML;
   unsigned* ctr;
 };
@@ -1257,7 +1401,7 @@ static size_t pdec_lds_floats(int chunk, int H, int nsplit) {
 bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int* chunk_out) {
   const char* e = getenv("ASTK_DEC_PERSIST");
   if (e && e[0] == '0') return false;
-  if (d->n_layers != 1) return false;
+  if (d->n_layers < 1 || d->n_layers > PDEC_MAX_LAYERS) return false;
   if (device_cu_count() < G) return false;        // fixed roles over G workgroups, all of them resident (one per CU)
   if ((d->H % 64) || (d->A % 16) || (d->E % 16) || d->A < 16 || d->E < 16) return false;
   const int nbt = (d->B + 15) / 16, ntv = (d->V + 15) / 16;
@@ -1266,6 +1410,7 @@ bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int
   const int rest = G - n_cell;
   if (n_cell >= G || rest < nbt * (d->A / 16) || 2 * rest < nbt * ntv) return false;
   if (rest < d->B + nbt || d->B > G) return false;
+  if (d->n_layers > 1 && 2 * n_cell > G) return false;       // the top layer's cell items live on the upper workgroups
   int nsplit = G / d->B;
   if (nsplit > 64) nsplit = 64;
   if (nsplit > d->T) nsplit = d->T;
@@ -1278,6 +1423,14 @@ bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int
     if (Vp > 64 * NB_B1 || d->A > 64 * NB_B2 || 4 * d->H > 64 * NB_B5 || (XI % 16) || ((2 * d->H) % 32)) return false;
     if (nbt * (d->H / 16) + nbt * (XI / 16) + nbt * (d->A / 16) > G || nbt * (2 * d->H / 32) > nbt * (d->A / 16) + (G - nbt * (d->H / 16) - nbt * (XI / 16) - nbt * (d->A / 16))) return false;
     if ((2 * (size_t)chunk * d->H + 2 * (size_t)d->H + chunk + 20 + 640) * sizeof(float) > 148 * 1024) return false;
+    if (d->n_layers > 1) {
+      // per-layer cell-backward owners, d_pre/d_cvh owners at the end of the grid, the split d_x0 items on the last n6 workgroups
+      // (never on a workgroup that also holds the 64 float4 of a below-top cell backward)
+      const int n5 = nbt * (d->H / 16), n6 = 2 * nbt * (d->A / 16), n1 = nbt * (d->A / 16), n2 = nbt * (2 * d->H / 32);
+      const int n12 = n1 > n2 ? n1 : n2;
+      if ((4 * d->H) % 128) return false;
+      if (d->n_layers * n5 + n12 > G || n6 > G - (d->n_layers - 1) * n5) return false;
+    }
   }                       // pass-1 bookkeeping uses one thread per row
   if (pdec_lds_floats(chunk, d->H, nsplit) * sizeof(float) > 136 * 1024) return false;
   *nsplit_out = nsplit;
@@ -1290,17 +1443,43 @@ bool decoder_persist_b6_split(const astk_decoder_desc* d) {
   const int nbt = (d->B + 15) / 16;
   const int n5 = nbt * (d->H / 16), n6 = 2 * nbt * (d->A / 16), n1 = nbt * (d->A / 16), n2 = nbt * (2 * d->H / 32);
   if ((4 * d->H) % 128) return false;
+  if (d->n_layers > 1) return true;           // the multi-layer role layout always uses the split form (decoder_persist_applicable checked it)
   const char* e = getenv("ASTK_DEC_B6_SPLIT");
   if (e && e[0] == '0') return false;
   return n5 + n6 + (n1 > n2 ? n1 : n2) <= G;
 }
 
 struct DecPersistBwdBuffers {
-  const float *WoT, *WcT, *WlT, *WuT, *ENCA, *CVH, *HT, *LOGITS, *C, *ML;
-  float *ALPHA, *G, *DPRE, *DCVH, *DS, *DX0, *DHATT, *d_c0;
+  const float *WoT, *WcT, *ENCA, *CVH, *HT, *LOGITS, *ML;
+  const float *WlT[PDEC_MAX_LAYERS], *WuT[PDEC_MAX_LAYERS], *C[PDEC_MAX_LAYERS];
+  float *G[PDEC_MAX_LAYERS];
+  float *ALPHA, *DPRE, *DCVH, *DS, *DX0, *DHATT, *d_c0;
   float* DXH;        // [2][S][B][A] or null (no K split of the d_x0 phase)
   unsigned* ctr;
 };
+
+template <int NL>
+static void pdec_launch_bwd(bool special, size_t shm, hipStream_t s, const PDecBwdArgs& a) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)decoder_persist_bwd<0, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)decoder_persist_bwd<8, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_done = true;
+  }
+  if (special) hipLaunchKernelGGL((decoder_persist_bwd<8, NL>), dim3(G), dim3(256), shm, s, a);
+  else hipLaunchKernelGGL((decoder_persist_bwd<0, NL>), dim3(G), dim3(256), shm, s, a);
+}
+template <int NL>
+static void pdec_launch_fwd(bool special, size_t shm, hipStream_t s, const PDecArgs& a) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)decoder_persist_fwd<0, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024);
+    (void)hipFuncSetAttribute((const void*)decoder_persist_fwd<8, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024);
+    attr_done = true;
+  }
+  if (special) hipLaunchKernelGGL((decoder_persist_fwd<8, NL>), dim3(G), dim3(256), shm, s, a);
+  else hipLaunchKernelGGL((decoder_persist_fwd<0, NL>), dim3(G), dim3(256), shm, s, a);
+}
 
 int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, const float* rnn_masks, const DecPersistBwdBuffers& bf,
                                hipStream_t s) {
@@ -1310,11 +1489,17 @@ int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, con
   memset(&a, 0, sizeof(a));
   a.B = d->B; a.S = d->L - 1; a.L = d->L; a.T = d->T; a.Tp = (d->T + 3) / 4 * 4; a.H = d->H; a.E = d->E; a.A = d->A; a.V = d->V;
   a.Vp = (d->V + 3) / 4 * 4; a.XI = d->E + d->A; a.nbt = (d->B + 15) / 16; a.nsplit = nsplit; a.chunk = chunk;
-  a.WoT = bf.WoT; a.WcT = bf.WcT; a.WlT = bf.WlT; a.WuT = bf.WuT; a.enc = enc; a.encA = bf.ENCA; a.ALPHA = bf.ALPHA; a.CVH = bf.CVH; a.ML = bf.ML;
-  a.HT = bf.HT; a.LOGITS = bf.LOGITS; a.Cst = bf.C; a.rnn_mask = rnn_masks; a.Gt = bf.G; a.DPRE = bf.DPRE; a.DCVH = bf.DCVH; a.DS = bf.DS;
+  a.NL = d->n_layers;
+  a.WoT = bf.WoT; a.WcT = bf.WcT; a.enc = enc; a.encA = bf.ENCA; a.ALPHA = bf.ALPHA; a.CVH = bf.CVH; a.ML = bf.ML;
+  for (int l = 0; l < d->n_layers; ++l) {
+    a.WlT[l] = bf.WlT[l]; a.WuT[l] = bf.WuT[l]; a.Cst[l] = bf.C[l]; a.Gt[l] = bf.G[l];
+    a.rnn_mask[l] = rnn_masks ? rnn_masks + (size_t)l * (d->L - 1) * d->B * d->H : nullptr;
+  }
+  a.HT = bf.HT; a.LOGITS = bf.LOGITS; a.DPRE = bf.DPRE; a.DCVH = bf.DCVH; a.DS = bf.DS;
   a.DX0 = bf.DX0; a.DHATT = bf.DHATT; a.d_c0 = bf.d_c0;
   a.DXH = bf.DXH;
   a.b6_split = bf.DXH != nullptr && decoder_persist_b6_split(d) ? 1 : 0;
+  ASTK_CHECK(d->n_layers == 1 || a.b6_split, "decoder_persist_bwd: the multi-layer role layout needs the split d_x0 buffers");
   a.ctr = bf.ctr;
   a.ab = abort_ctl(bf.ctr + (size_t)NPHASE_SLOTS * NSH * a.nbt * CTRS, PERSIST_DEC_BWD);
   a.tick_out = prof_tick_buffer(1);
@@ -1322,16 +1507,12 @@ int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, con
   ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)NPHASE_SLOTS * NSH * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), s));
   size_t scratch = 2 * (size_t)a.H + (size_t)((chunk + 3) & ~3) + 16 + 640;   // + ds/alpha/fold of the specialised attention scan
   const size_t shm = (2 * (size_t)chunk * a.H + scratch) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    ASTK_HIP(hipFuncSetAttribute((const void*)decoder_persist_bwd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    ASTK_HIP(hipFuncSetAttribute((const void*)decoder_persist_bwd<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_done = true;
-  }
   {
     ProfScope prof(PROF_DEC_BWD, s);
-    if (a.H == 512 && chunk <= 32) hipLaunchKernelGGL(decoder_persist_bwd<8>, dim3(G), dim3(256), shm, s, a);
-    else hipLaunchKernelGGL(decoder_persist_bwd<0>, dim3(G), dim3(256), shm, s, a);
+    const bool special = a.H == 512 && chunk <= 32;
+    if (d->n_layers == 1) pdec_launch_bwd<1>(special, shm, s, a);
+    else if (d->n_layers == 2) pdec_launch_bwd<2>(special, shm, s, a);
+    else pdec_launch_bwd<3>(special, shm, s, a);
   }
   ASTK_LAUNCH_CHECK();
   return 0;
@@ -1350,10 +1531,15 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
   a.B = d->B; a.S = d->L - 1; a.L = d->L; a.T = d->T; a.Tp = (d->T + 3) / 4 * 4; a.H = d->H; a.E = d->E; a.A = d->A; a.V = d->V;
   a.Vp = (d->V + 3) / 4 * 4; a.XI = d->E + d->A; a.nbt = (d->B + 15) / 16; a.nsplit = nsplit; a.chunk = chunk;
   a.ntile_v = (d->V + 15) / 16;
-  a.embed = prm->embed; a.Wu = prm->lstm[0].Wu; a.bias = prm->lstm[0].b; a.Wl = prm->lstm[0].Wl;
+  a.embed = prm->embed;
+  for (int l = 0; l < d->n_layers; ++l) {
+    a.Wu[l] = prm->lstm[l].Wu; a.bias[l] = prm->lstm[l].b; a.Wl[l] = prm->lstm[l].Wl;
+    a.Gt[l] = bf.G[l]; a.Cst[l] = bf.C[l]; a.HR[l] = bf.HR[l]; a.HD[l] = bf.HD[l];
+    a.rnn_mask[l] = rnn_masks ? rnn_masks + (size_t)l * (d->L - 1) * d->B * d->H : nullptr;
+  }
   a.Wa = prm->Wa; a.ba = prm->ba; a.Wc = prm->Wc; a.bc = prm->bc; a.Wo = prm->Wo; a.bo = prm->bo; a.cw = prm->class_weight;
-  a.enc = enc; a.encA = bf.ENCA; a.y = y; a.use_truth = use_truth; a.emb_mask = emb_mask; a.rnn_mask = rnn_masks;
-  a.TOK = bf.TOK; a.PRED = bf.PRED; a.X0 = bf.X0; a.Gt = bf.G; a.Cst = bf.C; a.HR = bf.HR; a.Q = bf.Q; a.ALPHA = bf.ALPHA;
+  a.enc = enc; a.encA = bf.ENCA; a.y = y; a.use_truth = use_truth; a.emb_mask = emb_mask;
+  a.TOK = bf.TOK; a.PRED = bf.PRED; a.X0 = bf.X0; a.Q = bf.Q; a.ALPHA = bf.ALPHA;
   a.CVH = bf.CVH; a.HT = bf.HT; a.LOGITS = bf.LOGITS; a.LOSSROWS = bf.LOSSROWS; a.LSE = bf.LSE; a.PART = bf.PART; a.CESTAT = bf.CESTAT; a.ML = bf.ML;
   a.ctr = bf.ctr;
   a.ab = abort_ctl(bf.ctr + (size_t)NPHASE_SLOTS * NSH * a.nbt * CTRS, PERSIST_DEC_FWD);
@@ -1361,16 +1547,12 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
   a.tick_out = prof_tick_buffer(0);
   ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)NPHASE_SLOTS * NSH * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), s));
   const size_t shm = pdec_lds_floats(chunk, a.H, nsplit) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    ASTK_HIP(hipFuncSetAttribute((const void*)decoder_persist_fwd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024));
-    ASTK_HIP(hipFuncSetAttribute((const void*)decoder_persist_fwd<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024));
-    attr_done = true;
-  }
   {
     ProfScope prof(PROF_DEC_FWD, s);
-    if (a.H == 512 && chunk <= 32 && (size_t)nsplit * (a.H + 4) >= (size_t)a.H + 64 + 512) hipLaunchKernelGGL(decoder_persist_fwd<8>, dim3(G), dim3(256), shm, s, a);
-    else hipLaunchKernelGGL(decoder_persist_fwd<0>, dim3(G), dim3(256), shm, s, a);
+    const bool special = a.H == 512 && chunk <= 32 && (size_t)nsplit * (a.H + 4) >= (size_t)a.H + 64 + 512;
+    if (d->n_layers == 1) pdec_launch_fwd<1>(special, shm, s, a);
+    else if (d->n_layers == 2) pdec_launch_fwd<2>(special, shm, s, a);
+    else pdec_launch_fwd<3>(special, shm, s, a);
   }
   ASTK_LAUNCH_CHECK();
   // Q[s][b][:] = Wa h_top + ba for all steps (needed by the backward's deferred d_enc product)

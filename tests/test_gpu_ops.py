@@ -343,10 +343,16 @@ def _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=0):
                                                     (33, 4, 10, 64, 16, 64, 130, 1, True), (2, 2, 5, 8, 4, 8, 7, 1, False),
                                                     # 1 layer, H/A multiples of 16: the persistent decoder-loop kernel
                                                     (5, 9, 23, 64, 16, 32, 57, 1, False), (32, 7, 50, 512, 128, 512, 1098, 1, True),
-                                                    (17, 5, 200, 256, 64, 128, 300, 1, True)])
+                                                    (17, 5, 200, 256, 64, 128, 300, 1, True),
+                                                    # 2 and 3 layers fused into the persistent decoder-loop kernels (generic attention phase, small
+                                                    # and ragged batch tiles; then the shipped es_en_20h width with the H = 512 specialisation)
+                                                    (5, 9, 23, 64, 16, 32, 57, 2, False), (19, 8, 37, 128, 32, 64, 130, 3, True),
+                                                    (32, 7, 50, 512, 128, 512, 1098, 3, True), (30, 6, 200, 512, 128, 512, 1004, 2, False)])
 def test_decoder_fwd_bwd(lib, B, L, T, H, E, A, V, nl, masks):
     from oracle.ast_ref_torch import decoder_torch
     s = _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=B + L)
+    if H % 64 == 0 and A % 16 == 0 and E % 16 == 0 and nl <= 3:       # the shapes meant for the persistent kernels really take them
+        assert lib.astk_decoder_path(C.byref(s["d"])) & 1, "persistent decoder path not taken"
     cfg = {"rnn_config": {"dec_layers": nl, "attn_units": A}}
     Pt = {k: torch.tensor(v, requires_grad=True) for k, v in s["P"].items()}
     enc_t = torch.tensor(s["enc"], requires_grad=True)
