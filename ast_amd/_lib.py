@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libastk.so")
+LIB_PATH = os.environ.get("ASTK_LIB_PATH") or os.path.join(_HERE, "libastk.so")     # (override: timing experiments with debug builds)
 
 MAX_CNN = 4
 MAX_RNN = 8

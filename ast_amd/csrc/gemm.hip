@@ -29,7 +29,12 @@ constexpr int BK = ASTK_GEMM_BK;
 // Block tile edge TL: 128 (4 waves x 64x64, the throughput configuration) or 64 (4 waves x 32x32) for products too small to
 // give every CU a 128-tile's worth of k-iterations -- a k-iteration of a 128-tile is 32 MFMAs = 0.87 us per wave whatever the
 // problem size, so 40 such tiles with K = 512 cannot finish in less than 28 us; with 64-tiles the same product is 160 tiles of 7 us.
-constexpr int wgs_per_cu(int TL) { return TL == 64 ? 4 : (BK == 32 ? 2 : 3); }   // co-resident workgroups the grid is sized for (128-tiles,
+#ifndef ASTK_GEMM_X3_WGS
+#define ASTK_GEMM_X3_WGS 1
+#endif
+// co-resident workgroups the grid is sized for.  bf16x3 workgroups have 512 threads (2 waves per SIMD each)
+constexpr int wgs_per_cu(int TL, int prec = 0) { return prec != 0 ? (TL == 64 ? 2 : ASTK_GEMM_X3_WGS) : (TL == 64 ? 4 : (BK == 32 ? 2 : 3)); }
+constexpr int waves_per_simd(int TL, int prec) { return prec != 0 ? 2 * wgs_per_cu(TL, prec) : wgs_per_cu(TL, prec); }   // co-resident workgroups the grid is sized for (128-tiles,
                                                // BK = 16: 40 KB of LDS and <= 168 registers per workgroup; 2, 3 and 4 per CU are within 2 %)
 constexpr int LD_RK = BK + 4;  // LDS row stride (floats) of an operand staged from K-contiguous global rows: kept ROW-major [m][k'] with the
                                // tile's k order permuted to [even k | odd k], so that a thread's global float4 (4 consecutive k) is two
@@ -67,7 +72,43 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 //     owning thread then zeroes in LDS (zero_tail, taken once per tile at most and only when K is not a multiple of BK);
 //   * two-level K-major rows (the conv wgrad) are addressed like plain ones while a tile's BK rows lie inside one group (uniform
 //     test); only a tile that straddles groups computes per-row offsets.
-template <int TL, bool RK, bool TWOLVL>
+// ---- bf16x3 operands (PREC_BF16X3): every f32 operand value is split into three bf16 terms, x = hi + mid + lo with
+//   hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)   (round-to-nearest-even each; bf16 has f32's exponent range, so no scaling)
+// which carry 24 significant bits between them, and a product is summed from the six largest of the nine term products
+//   a b ~ lo.hi + hi.lo + mid.mid + mid.hi + hi.mid + hi.hi        (dropped: mid.lo, lo.mid, lo.lo <= 2^-23 |a b|)
+// on v_mfma_f32_32x32x16_bf16 with f32 accumulation: 6 MFMAs of 32 cycles for 16 k against 8 f32 MFMAs of 64 cycles, i.e. 2.7x the
+// f32-input MFMA rate at an error of the order of f32 rounding itself (a f32 fma chain rounds every product to 2^-24; here a product
+// is exact to 2^-23 and a K = 16 block is summed inside the MFMA).  The split runs in the stager (global f32 -> registers -> three
+// bf16 planes in LDS), so callers, layouts, addressing, stream-K and the epilogue are those of the f32 kernel.
+enum GemmPrec { PREC_F32 = 0, PREC_BF16X3 = 1 };
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// two values -> one dword of each plane (element 0 in the low half)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+  mid = cvt_pk_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
+  lo = cvt_pk_bf16(s0, s1);
+}
+// LDS images of one operand stage on the bf16x3 path (bytes).  RK operand (K-contiguous global rows): per plane two k-halves
+// [h = k / 8][row][8 k] of TL x 16 B, 16 B apart from a multiple of 128 B so that a stager's 8-byte writes and the MFMA lanes' 16-byte
+// row reads are both conflict-free.  KR operand (M/N-contiguous global rows): per plane K-major [k][m] rows of 2 TL + 64 B (the pad makes
+// the four k rows of a transposing read land 16 banks apart), read with ds_read_b64_tr_b16.
+constexpr int sp_hs(int TL) { return TL * 16 + 16; }          // RK: k-half stride
+constexpr int sp_rs(int TL) { return TL * 2 + 64; }           // KR: k-row stride
+constexpr int sp_plane(int TL, bool RK) { return RK ? 2 * sp_hs(TL) : BK * sp_rs(TL); }
+constexpr int sp_stage(int TL, bool RK) { return 3 * sp_plane(TL, RK); }
+
+// RING: register slots of staged tiles.  The f32 kernel keeps one tile in flight (an iteration is 2600 cycles and three workgroups per
+// CU cover each other's waits); a bf16x3 iteration is ~800 cycles on one workgroup per CU, so its staging waves keep RING = 4 tiles
+// (16 loads per thread) in flight to cover the memory latency.
+template <int TL, bool RK, bool TWOLVL, int PREC = PREC_F32, int RING = 1>
 struct Stager {
   static constexpr int LD_KR = ld_kr(TL);
   static constexpr int KQ = BK / 4;                  // RK: k-quads per row
@@ -75,7 +116,7 @@ struct Stager {
   static constexpr int RP = 256 / CQ;                // KR: k rows per pass (256 threads x 16 B)
   static constexpr int NP = RK ? TL * KQ / 256 : BK / RP;   // passes over the TL x BK tile
   static_assert(NP >= 1 && (RK || RP * NP == BK), "tile / thread-count mismatch");
-  float4 reg[NP];     // staged data
+  float4 reg[RING][NP];     // staged data
   unsigned voff[NP];  // RK and plain KR: byte offset of this thread's float4 from the tile's uniform base
   int tgrp, trem;     // two-level KR: group and position inside the group of row kcur (uniform)
   int tcol;           // two-level KR: this thread's (clamped) column
@@ -99,7 +140,7 @@ struct Stager {
       b = tid / CQ;
       // LDS column order of a 128-wide KR tile: [wm0 i0 | wm1 i0 | wm0 i1 | wm1 i1] x 32 (see ld_kr); lane a writes LDS columns 4a..4a+3,
       // which hold the tile's columns wm*64 + i*32 + 4*(a&7) with i = a>>4, wm = (a>>3)&1.  A 64-wide tile is stored in order.
-      const int m = TL == 128 ? ((a >> 3) & 1) * 64 + (a >> 4) * 32 + (a & 7) * 4 : 4 * a;
+      const int m = (TL == 128 && PREC == PREC_F32) ? ((a >> 3) & 1) * 64 + (a >> 4) * 32 + (a & 7) * 4 : 4 * a;   // bf16x3 image: natural order
       const int col = min(row0 + m, ((nrows + 3) & ~3) - 4);
 #pragma unroll
       for (int p = 0; p < NP; ++p)
@@ -109,7 +150,7 @@ struct Stager {
     }
   }
   // span: bytes from v.p to the end of the operand slice (gemm_prepare)
-  __device__ __forceinline__ void load(const MatView& v, unsigned span, int kend) {
+  __device__ __forceinline__ void load(const MatView& v, unsigned span, int kend, const int slot = 0) {
     if (RK || !TWOLVL) {
       const long adv = RK ? (long)kcur : (long)kcur * v.ld;
       const __amdgpu_buffer_rsrc_t r =
@@ -117,7 +158,7 @@ struct Stager {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff[p], 0, 0);
-        reg[p] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+        reg[slot][p] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
       }
     } else {
       if (trem + BK <= v.tn && kcur + BK <= kend) {   // the tile's BK rows exist and lie in one group (uniform): addressed like the plain case
@@ -126,13 +167,13 @@ struct Stager {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
           const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff[p], 0, 0);
-          reg[p] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+          reg[slot][p] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
         }
       } else {                   // the tile straddles groups (or runs past kend): per-row offsets, rows clamped to kend - 1
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
           const int kr = min(kcur + b + RP * p, kend - 1);
-          reg[p] = *reinterpret_cast<const float4*>(v.p + (long)(kr / v.tn) * v.sg + (long)(kr % v.tn) * v.st + tcol);
+          reg[slot][p] = *reinterpret_cast<const float4*>(v.p + (long)(kr / v.tn) * v.sg + (long)(kr % v.tn) * v.st + tcol);
         }
       }
       trem += BK;
@@ -144,12 +185,47 @@ struct Stager {
     if (RK) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        *reinterpret_cast<float2*>(&S[lds + p * LD_RK]) = make_float2(reg[p].x, reg[p].y);
-        *reinterpret_cast<float2*>(&S[lds + p * LD_RK + BK / 2]) = make_float2(reg[p].z, reg[p].w);
+        *reinterpret_cast<float2*>(&S[lds + p * LD_RK]) = make_float2(reg[0][p].x, reg[0][p].y);
+        *reinterpret_cast<float2*>(&S[lds + p * LD_RK + BK / 2]) = make_float2(reg[0][p].z, reg[0][p].w);
       }
     } else {
 #pragma unroll
-      for (int p = 0; p < NP; ++p) *reinterpret_cast<float4*>(&S[lds + RP * p * LD_KR]) = reg[p];
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<float4*>(&S[lds + RP * p * LD_KR]) = reg[0][p];
+    }
+  }
+  // bf16x3: registers -> three bf16 planes of the stage at byte address S.  Values with k >= kend are zeroed in registers (uniform
+  // branch, last tile of a K range only), so no LDS patching is needed.  ktile: first k of the tile being stored.
+  template <bool TAIL>
+  __device__ __forceinline__ void store_split(char* S, int ktile, int kend, const int slot) {
+    constexpr int PL = sp_plane(TL, RK);
+    float4 r[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) r[p] = reg[slot][p];
+    if (TAIL && ktile + BK > kend) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        if (RK) {
+          const int nv = kend - (ktile + a * 4);
+          if (nv < 1) r[p].x = 0.f;
+          if (nv < 2) r[p].y = 0.f;
+          if (nv < 3) r[p].z = 0.f;
+          if (nv < 4) r[p].w = 0.f;
+        } else if (ktile + b + RP * p >= kend) r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      unsigned h0, m0, l0, h1, m1, l1;
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 1)      // timing experiment: no split arithmetic
+      h0 = __float_as_uint(r[p].x); m0 = __float_as_uint(r[p].y); l0 = h0; h1 = __float_as_uint(r[p].z); m1 = __float_as_uint(r[p].w); l1 = h1;
+#else
+      split2(r[p].x, r[p].y, h0, m0, l0);
+      split2(r[p].z, r[p].w, h1, m1, l1);
+#endif
+      const int off = RK ? (a >> 1) * sp_hs(TL) + (NP * b + p) * 16 + (a & 1) * 8 : (b + RP * p) * sp_rs(TL) + a * 8;
+      *reinterpret_cast<uint2*>(S + off) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(S + PL + off) = make_uint2(m0, m1);
+      *reinterpret_cast<uint2*>(S + 2 * PL + off) = make_uint2(l0, l1);
     }
   }
   // Zeroes what this thread's store() wrote for k >= kend (ktile: first k of the tile in S).
@@ -178,24 +254,56 @@ struct Stager {
 // (for GEMM_STORE the launcher zeroes exactly those tiles first, k_zero_split_tiles).  With G = tiles (one tile each)
 // this degenerates to the classical data-parallel launch; with G = 256 or 512 every CU gets the same number of
 // k-iterations whatever the tile count -- a 400-tile product no longer runs as "2 waves, the second 56% full".
-template <int TL, bool A_RK, bool B_RK, bool TWOLVL>
-__global__ __launch_bounds__(256, wgs_per_cu(TL)) void gemm_f32_kernel(GemmGroup grp) {
+// bf16x3 kernels run 512 threads: waves 0-3 multiply (LDS fragment reads + MFMAs only), waves 4-7 stage (global loads, the
+// f32 -> 3 x bf16 split, LDS writes).  One wave of each kind sits on every SIMD, so the split's vector-ALU work issues in the gaps of
+// the other wave's MFMAs; with every wave doing both, the co-resident workgroups ran their VALU and MFMA phases in lockstep and the
+// matrix pipe idled more than half of the time (163 instead of 118 TFLOP/s at 4096^3, against > 300 for an MFMA-bound loop).
+constexpr int gemm_threads(int PREC) { return PREC == PREC_BF16X3 ? 512 : 256; }
+// TL: tile edge along N (and along M unless TLM says otherwise: the bf16x3 path also runs 256 x 128 tiles -- per k-iteration the split
+// costs vector-ALU issue slots in proportion to TLM + TL while the MFMAs grow with TLM x TL, and only from 256 x 128 on do the MFMAs
+// (1536 cycles per wave and iteration) outlast the split's issue time on the same SIMD).
+template <int TL, bool A_RK, bool B_RK, bool TWOLVL, int PREC, int TLM = TL>
+__global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void gemm_f32_kernel(GemmGroup grp) {
   constexpr int LD_KR = ld_kr(TL);
   constexpr int LDA = A_RK ? LD_RK : LD_KR;
   constexpr int LDB = B_RK ? LD_RK : LD_KR;
-  constexpr int NA = TL / 64;      // 32x32 accumulator tiles per wave and dimension (the wave's sub-tile is TL/2 x TL/2)
-  constexpr int WT = TL / 2;
-  __shared__ __attribute__((aligned(16))) float As[2][A_RK ? TL * LD_RK : BK * LD_KR];
-  __shared__ __attribute__((aligned(16))) float Bs[2][B_RK ? TL * LD_RK : BK * LD_KR];
+  constexpr int NA = TL / 64;      // 32x32 accumulator tiles per wave and dimension (the wave's sub-tile is TLM/2 x TL/2)
+  constexpr int NAM = TLM / 64;
+  constexpr int WT = TL / 2, WTM = TLM / 2;
+  constexpr bool SPLIT = PREC == PREC_BF16X3;
+  static_assert(SPLIT || TLM == TL, "the f32 path runs square tiles");
+  constexpr int A_FLOATS = SPLIT ? sp_stage(TLM, A_RK) / 4 : (A_RK ? TL * LD_RK : BK * LD_KR);
+  constexpr int B_FLOATS = SPLIT ? sp_stage(TL, B_RK) / 4 : (B_RK ? TL * LD_RK : BK * LD_KR);
+  constexpr int NST = SPLIT ? 3 : 2;      // LDS stages (bf16x3: the multiplying waves fetch tile kt+1's fragments while they multiply tile kt)
+  __shared__ __attribute__((aligned(16))) float As[NST][A_FLOATS];
+  __shared__ __attribute__((aligned(16))) float Bs[NST][B_FLOATS];
   static_assert(BK == 16 || BK == 32, "BK / 2 floats per lane and operand, read as BK / 8 float4");
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & 255;                 // stager / multiplier thread index inside its role
+  const bool producer = SPLIT && threadIdx.x >= 256;   // bf16x3: waves 4-7 stage, waves 0-3 multiply; f32: every wave does both
+  const bool stages = !SPLIT || producer, multiplies = !SPLIT || !producer;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lk = lane >> 5;
 
-  long it = grp.iters_total * (long)blockIdx.x / (long)gridDim.x;
-  const long it_end = grp.iters_total * (long)(blockIdx.x + 1) / (long)gridDim.x;
+  // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8 share one L2).  bf16x3: give every XCD a CONTIGUOUS eighth of the
+  // k-iteration sequence, so that the workgroups sharing an L2 work on neighbouring tiles (same A row panel, adjacent B panels): at
+  // 160+ TFLOP/s a 128-tile loop pulls > 5 TB/s of f32 operands into the CUs, which only the L2s can serve.
+  if constexpr (SPLIT) {
+    // One multiplying and one staging wave share each SIMD's issue port.  At equal priority the arbiter lets the staging wave's
+    // vector-ALU instructions queue in front of the next MFMA, and the matrix pipe idles between MFMAs (measured: multiplying waves
+    // alone 1100 cycles per k-iteration, staging waves alone 600, both together 1600-1900 = the SUM).  Static priority for the
+    // multiplying waves: their MFMAs issue the moment the pipe is free, the split fills the gaps.  (The branch must be provably
+    // wave-uniform: s_setprio ignores EXEC.)
+    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < 256) __builtin_amdgcn_s_setprio(3);
+  }
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 32)      // clock probe: shader cycles per 10 ns tick over the kernel's life (block 0)
+  const long long c0_ = clock64(), w0_ = wall_clock64();
+#endif
+  unsigned wgi = blockIdx.x;
+  if (SPLIT && (gridDim.x % 8) == 0) wgi = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+  long it = grp.iters_total * (long)wgi / (long)gridDim.x;
+  const long it_end = grp.iters_total * (long)(wgi + 1) / (long)gridDim.x;
   int prob = 0;
 
   while (it < it_end) {
@@ -211,7 +319,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(TL)) void gemm_f32_kernel(GemmGroup
     it += k1 - k0;
     const int zb = (int)(tile / g.tiles_mn);
     const int tmn = (int)(tile - (long)zb * g.tiles_mn);
-    const int m0 = (tmn / tiles_n) * TL, n0 = (tmn % tiles_n) * TL;
+    const int m0 = (tmn / tiles_n) * TLM, n0 = (tmn % tiles_n) * TL;
     const int kbeg = k0 * BK;
     const int kend = min(g.K, k1 * BK);
     const bool whole = (k0 == 0) && (k1 == kt_tile);
@@ -221,127 +329,287 @@ __global__ __launch_bounds__(256, wgs_per_cu(TL)) void gemm_f32_kernel(GemmGroup
     B.p += (long)zb * g.sB;
     float* C = g.C + (long)zb * g.sC;
 
-    Stager<TL, A_RK, TWOLVL> sa;
-    Stager<TL, B_RK, TWOLVL> sb;
-    sa.init(A, m0, g.M, kbeg, kend, tid);
-    sb.init(B, n0, g.N, kbeg, kend, tid);
-
-    f32x16 acc[NA][NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-#pragma unroll
-      for (int j = 0; j < NA; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr int RING = SPLIT ? 4 : 1;
+    Stager<TLM, A_RK, TWOLVL, PREC, RING> sa;
+    Stager<TL, B_RK, TWOLVL, PREC, RING> sb;
+    if (stages) {
+      sa.init(A, m0, g.M, kbeg, kend, tid);
+      sb.init(B, n0, g.N, kbeg, kend, tid);
+    }
 
     const int nk = k1 - k0;
+    const bool add_bias = g.bias != nullptr && k0 == 0;
+    const int mode = whole ? g.mode : GEMM_ATOMIC;
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    auto epilogue = [&](f32x16 (&acc)[NAM][NA]) {
+#pragma unroll
+      for (int i = 0; i < NAM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (row >= g.M) continue;
+          const long coff = g.c_tn > 0 ? (long)(row / g.c_tn) * g.c_sg + (long)(row % g.c_tn) * g.c_st : (long)row * g.ldc;
+#pragma unroll
+          for (int j = 0; j < NA; ++j) {
+            const int col = n0 + wn * WT + j * 32 + li;
+            if (col >= g.N) continue;
+            float v = acc[i][j][r];
+            if (add_bias) v += g.bias[col];
+            float* dst = C + coff + col;
+            if (mode == GEMM_STORE) *dst = v;
+            else if (mode == GEMM_ACCUM) *dst += v;
+            else atomicAdd(dst, v);
+          }
+        }
+      }
+    };
 
-    // Pipeline: tile kt is multiplied out of LDS buffer kt&1 while tile kt+1 moves registers -> the other buffer and
-    // tile kt+2 is in flight global -> registers; one barrier per k-iteration.
-    sa.load(A, g.spanA, kend);
-    sb.load(B, g.spanB, kend);
-    sa.store(As[0]);
-    sb.store(Bs[0]);
-    if (kbeg + BK > kend) { sa.zero_tail(As[0], kbeg, kend); sb.zero_tail(Bs[0], kbeg, kend); }
-    if (nk > 1) {
+    if constexpr (SPLIT) {
+      // ---- bf16x3 pipeline.  Staging waves: tile t sits in ring slot t % RING (registers) until it is split into LDS buffer t & 1 one
+      // iteration before the multiplying waves use it; a slot is reloaded with tile t + RING right after.  The two roles run separate
+      // loops with the same number of barriers.  The staging loop's steady state is straight-line code (no tail handling, no
+      // conditional loads), so that the compiler's s_waitcnt counts the RING tiles in flight instead of draining them.
+      // LDS: three stages; tile t lives in stage t % 3.  Iteration kt: the staging waves write tile kt+2, the multiplying waves read
+      // tile kt+1's fragments into registers while their MFMAs run on tile kt's (read one iteration earlier): the LDS read burst of
+      // 48 KB per workgroup and iteration (190+ cycles of the LDS pipe, plus latency) is off the matrix pipe's critical path.
+      auto stA = [&](int st) { return reinterpret_cast<char*>(As[0]) + st * (A_FLOATS * 4); };
+      auto stB = [&](int st) { return reinterpret_cast<char*>(Bs[0]) + st * (B_FLOATS * 4); };
+      if (producer) {
+        sa.load(A, g.spanA, kend, 0);
+        sb.load(B, g.spanB, kend, 0);
+#pragma unroll
+        for (int r = 1; r < RING; ++r)
+          if (r < nk) { sa.load(A, g.spanA, kend, r); sb.load(B, g.spanB, kend, r); }
+        sa.template store_split<true>(stA(0), kbeg, kend, 0);
+        sb.template store_split<true>(stB(0), kbeg, kend, 0);
+        if (RING < nk) { sa.load(A, g.spanA, kend, 0); sb.load(B, g.spanB, kend, 0); }
+        if (1 < nk) {
+          sa.template store_split<true>(stA(1), kbeg + BK, kend, 1);
+          sb.template store_split<true>(stB(1), kbeg + BK, kend, 1);
+          if (1 + RING < nk) { sa.load(A, g.spanA, kend, 1); sb.load(B, g.spanB, kend, 1); }
+        }
+        __syncthreads();
+        int kt = 0;
+        // iteration kt: tile kt+2 -> LDS stage (kt+2) % 3 from slot (kt+2) % RING, then tile kt+2+RING -> that slot
+        auto pstep = [&](auto posc, auto tailc, const int kt_) {
+          constexpr int pos = decltype(posc)::value;          // kt_ % 12
+          constexpr bool TAIL = decltype(tailc)::value;
+          constexpr int slot = (pos + 2) % RING, st = (pos + 2) % 3;
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 8)      // timing experiment: staging waves idle
+#else
+          if (!TAIL || kt_ + 2 < nk) {
+            sa.template store_split<TAIL>(stA(st), kbeg + (kt_ + 2) * BK, kend, slot);
+            sb.template store_split<TAIL>(stB(st), kbeg + (kt_ + 2) * BK, kend, slot);
+          }
+#endif
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 12)      // timing experiment: no global loads in the loop
+#else
+          if (!TAIL || kt_ + 2 + RING < nk) { sa.load(A, g.spanA, kend, slot); sb.load(B, g.spanB, kend, slot); }
+#endif
+          __syncthreads();
+        };
+        // steady state (12 = lcm(3 stages, 4 slots) iterations per trip): every tile stored in the trip is a full tile, every tile loaded exists
+        for (; kt + 13 + RING < nk && kbeg + (kt + 14) * BK <= kend; kt += 12) {
+          pstep(std::integral_constant<int, 0>{}, std::false_type{}, kt);
+          pstep(std::integral_constant<int, 1>{}, std::false_type{}, kt + 1);
+          pstep(std::integral_constant<int, 2>{}, std::false_type{}, kt + 2);
+          pstep(std::integral_constant<int, 3>{}, std::false_type{}, kt + 3);
+          pstep(std::integral_constant<int, 4>{}, std::false_type{}, kt + 4);
+          pstep(std::integral_constant<int, 5>{}, std::false_type{}, kt + 5);
+          pstep(std::integral_constant<int, 6>{}, std::false_type{}, kt + 6);
+          pstep(std::integral_constant<int, 7>{}, std::false_type{}, kt + 7);
+          pstep(std::integral_constant<int, 8>{}, std::false_type{}, kt + 8);
+          pstep(std::integral_constant<int, 9>{}, std::false_type{}, kt + 9);
+          pstep(std::integral_constant<int, 10>{}, std::false_type{}, kt + 10);
+          pstep(std::integral_constant<int, 11>{}, std::false_type{}, kt + 11);
+        }
+        for (; kt < nk; kt += 12) {
+          pstep(std::integral_constant<int, 0>{}, std::true_type{}, kt);
+          if (kt + 1 < nk) pstep(std::integral_constant<int, 1>{}, std::true_type{}, kt + 1);
+          if (kt + 2 < nk) pstep(std::integral_constant<int, 2>{}, std::true_type{}, kt + 2);
+          if (kt + 3 < nk) pstep(std::integral_constant<int, 3>{}, std::true_type{}, kt + 3);
+          if (kt + 4 < nk) pstep(std::integral_constant<int, 4>{}, std::true_type{}, kt + 4);
+          if (kt + 5 < nk) pstep(std::integral_constant<int, 5>{}, std::true_type{}, kt + 5);
+          if (kt + 6 < nk) pstep(std::integral_constant<int, 6>{}, std::true_type{}, kt + 6);
+          if (kt + 7 < nk) pstep(std::integral_constant<int, 7>{}, std::true_type{}, kt + 7);
+          if (kt + 8 < nk) pstep(std::integral_constant<int, 8>{}, std::true_type{}, kt + 8);
+          if (kt + 9 < nk) pstep(std::integral_constant<int, 9>{}, std::true_type{}, kt + 9);
+          if (kt + 10 < nk) pstep(std::integral_constant<int, 10>{}, std::true_type{}, kt + 10);
+          if (kt + 11 < nk) pstep(std::integral_constant<int, 11>{}, std::true_type{}, kt + 11);
+        }
+      } else {
+        // (the accumulators live in this branch only: the staging waves' code path must not carry 128 registers of them)
+        f32x16 acc[NAM][NA];
+#pragma unroll
+        for (int i = 0; i < NAM; ++i)
+#pragma unroll
+          for (int j = 0; j < NA; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        __syncthreads();
+        // operand fragments of v_mfma_f32_32x32x16_bf16: lane (r = lane & 31, h = lane >> 5) holds k = 8h .. 8h+7 of row / column r
+        auto frag = [&](const char* base, bool rk, auto tlc, int t0, int pl) -> bf16x8 {
+          constexpr int TLX = decltype(tlc)::value;          // tile edge of this operand
+          if (rk) return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + pl * sp_plane(TLX, true) + lk * sp_hs(TLX) + (t0 + li) * 16));
+          // K-major image: two transposing reads (k = 8h .. 8h+3 and 8h+4 .. 8h+7) of a 4 k x 16 m block per 16-lane group
+          const int g16 = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
+          const char* ad = base + pl * sp_plane(TLX, false) + (8 * lk + q) * sp_rs(TLX) + (t0 + 16 * g16 + 4 * pp) * 2;
+          typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ad));
+          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ad + 4 * sp_rs(TLX)));
+          struct { s16x4 a, b; } pr = {v0, v1};
+          return __builtin_bit_cast(bf16x8, pr);
+        };
+        struct Frags { bf16x8 a[NAM][3], b[NA][3]; };
+        auto fetch = [&](Frags& f, int st) {
+          const char* abase = stA(st);
+          const char* bbase = stB(st);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < NAM; ++i) f.a[i][pl] = frag(abase, A_RK, std::integral_constant<int, TLM>{}, wm * WTM + 32 * i, pl);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) f.b[i][pl] = frag(bbase, B_RK, std::integral_constant<int, TL>{}, wn * WT + 32 * i, pl);
+          }
+        };
+        auto mult = [&](const Frags& f) {
+          // smallest terms first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
+          constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 2)      // timing experiment: one MFMA per accumulator instead of six
+          for (int t = 0; t < 1; ++t)
+#else
+          for (int t = 0; t < 6; ++t)
+#endif
+#pragma unroll
+            for (int i = 0; i < NAM; ++i)
+#pragma unroll
+              for (int i2 = 0; i2 < NA; ++i2)
+                acc[i][i2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA[t]], f.b[i2][PB[t]], acc[i][i2], 0, 0, 0);
+        };
+        Frags f0, f1;
+        fetch(f0, 0);
+        // iteration kt (position pos = kt % 6): fetch tile kt+1 from stage (pos+1) % 3 into the other register set, multiply tile kt
+        auto cstep = [&](auto posc, const int kt_) {
+          constexpr int pos = decltype(posc)::value;
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 16)      // timing experiment: multiplying waves idle
+#else
+          if (kt_ + 1 < nk) fetch((pos & 1) ? f0 : f1, (pos + 1) % 3);
+          mult((pos & 1) ? f1 : f0);
+#endif
+          // the barrier stays BEHIND the MFMAs: hipcc otherwise hoists it (and the lgkmcnt(0) it needs) to right behind the first MFMA,
+          // which puts the fragment reads' latency back on the matrix pipe's critical path
+          __builtin_amdgcn_sched_barrier(0);
+          __syncthreads();
+        };
+        for (int kt = 0; kt < nk; kt += 6) {
+          cstep(std::integral_constant<int, 0>{}, kt);
+          if (kt + 1 < nk) cstep(std::integral_constant<int, 1>{}, kt + 1);
+          if (kt + 2 < nk) cstep(std::integral_constant<int, 2>{}, kt + 2);
+          if (kt + 3 < nk) cstep(std::integral_constant<int, 3>{}, kt + 3);
+          if (kt + 4 < nk) cstep(std::integral_constant<int, 4>{}, kt + 4);
+          if (kt + 5 < nk) cstep(std::integral_constant<int, 5>{}, kt + 5);
+        }
+        epilogue(acc);        // meanwhile the staging waves run the next tile's prologue
+      }
+    } else {
+      f32x16 acc[NAM][NA];
+#pragma unroll
+      for (int i = 0; i < NAM; ++i)
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      // Pipeline: tile kt is multiplied out of LDS buffer kt&1 while tile kt+1 moves registers -> the other buffer and
+      // tile kt+2 is in flight global -> registers; one barrier per k-iteration.
       sa.load(A, g.spanA, kend);
       sb.load(B, g.spanB, kend);
-    }
-    __syncthreads();
-
-    // (two k-iterations per trip, so that the LDS buffer index is a compile-time constant and every LDS address an immediate offset)
-    auto step = [&](auto curc, const int kt) {
-      constexpr int cur = decltype(curc)::value;
-      if (kt + 1 < nk) {
-        sa.store(As[cur ^ 1]);
-        sb.store(Bs[cur ^ 1]);
-        if (kbeg + (kt + 2) * BK > kend) { sa.zero_tail(As[cur ^ 1], kbeg + (kt + 1) * BK, kend); sb.zero_tail(Bs[cur ^ 1], kbeg + (kt + 1) * BK, kend); }
-      }
-      if (kt + 2 < nk) {
+      sa.store(As[0]);
+      sb.store(Bs[0]);
+      if (kbeg + BK > kend) { sa.zero_tail(As[0], kbeg, kend); sb.zero_tail(Bs[0], kbeg, kend); }
+      if (nk > 1) {
         sa.load(A, g.spanA, kend);
         sb.load(B, g.spanB, kend);
       }
-      // MFMA 32x32x2 operands: lane (li, lk) supplies row/col li of the 32-wide tile at k = KROW(j) + 2*lk, j = 0..BK/2-1.
-      //   RK operand: those 8 values are 8 consecutive floats of its LDS row (two 16-byte reads for the whole k-iteration)
-      //   KR operand: one ds_read2st64_b32 per k-pair (both 32-wide tiles), rolling one k-pair ahead of the MFMAs
-      float fa[NA][BK / 2], fb[NA][BK / 2];
-      const float* ap = As[cur] + (A_RK ? (wm * WT + li) * LDA + (BK / 2) * lk : 2 * lk * LDA + wm * 32 + li);
-      const float* bp = Bs[cur] + (B_RK ? (wn * WT + li) * LDB + (BK / 2) * lk : 2 * lk * LDB + wn * 32 + li);
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        if (A_RK) {
-#pragma unroll
-          for (int q = 0; q < BK / 8; ++q) *reinterpret_cast<float4*>(&fa[i][4 * q]) = *reinterpret_cast<const float4*>(ap + 32 * i * LDA + 4 * q);
-        } else fa[i][0] = ap[64 * i];
-        if (B_RK) {
-#pragma unroll
-          for (int q = 0; q < BK / 8; ++q) *reinterpret_cast<float4*>(&fb[i][4 * q]) = *reinterpret_cast<const float4*>(bp + 32 * i * LDB + 4 * q);
-        } else fb[i][0] = bp[64 * i];
-      }
-#pragma unroll
-      for (int j = 0; j < BK / 2; ++j) {
-        if (j + 1 < BK / 2) {
-#pragma unroll
-          for (int i = 0; i < NA; ++i) {
-            if (!A_RK) fa[i][j + 1] = ap[KROW(j + 1) * LDA + 64 * i];
-            if (!B_RK) fb[i][j + 1] = bp[KROW(j + 1) * LDB + 64 * i];
-          }
+      __syncthreads();
+
+      // (two k-iterations per trip, so that the LDS buffer index is a compile-time constant and every LDS address an immediate offset)
+      auto step = [&](auto curc, const int kt) {
+        constexpr int cur = decltype(curc)::value;
+        if (kt + 1 < nk) {
+          sa.store(As[cur ^ 1]);
+          sb.store(Bs[cur ^ 1]);
+          if (kbeg + (kt + 2) * BK > kend) { sa.zero_tail(As[cur ^ 1], kbeg + (kt + 1) * BK, kend); sb.zero_tail(Bs[cur ^ 1], kbeg + (kt + 1) * BK, kend); }
         }
-#pragma unroll
-        for (int i = 0; i < NA; ++i)
-#pragma unroll
-          for (int i2 = 0; i2 < NA; ++i2) acc[i][i2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[i2][j], acc[i][i2], 0, 0, 0);
-      }
-      // pin the interleave of the scalar (KR) operand reads: hipcc otherwise sinks every LDS read directly in front of its MFMAs with
-      // lgkmcnt(0).  One LDS read per KR operand and k-pair goes in front of the MFMAs of the previous k-pair.
-      if (!A_RK || !B_RK) {
-        constexpr int NR = (A_RK ? 0 : 1) + (B_RK ? 0 : 1);
-        constexpr int NRK = (A_RK ? NA * (BK / 8) : 0) + (B_RK ? NA * (BK / 8) : 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, NR + NRK, 0);
-#pragma unroll
-        for (int i = 0; i < BK / 2 - 1; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+        if (kt + 2 < nk) {
+          sa.load(A, g.spanA, kend);
+          sb.load(B, g.spanB, kend);
+        }
+        // MFMA 32x32x2 operands: lane (li, lk) supplies row/col li of the 32-wide tile at k = KROW(j) + 2*lk, j = 0..BK/2-1.
+        //   RK operand: those 8 values are 8 consecutive floats of its LDS row (two 16-byte reads for the whole k-iteration)
+        //   KR operand: one ds_read2st64_b32 per k-pair (both 32-wide tiles), rolling one k-pair ahead of the MFMAs
+        float fa[NA][BK / 2], fb[NA][BK / 2];
+        const float* ap = As[cur] + (A_RK ? (wm * WT + li) * LDA + (BK / 2) * lk : 2 * lk * LDA + wm * 32 + li);
+        const float* bp = Bs[cur] + (B_RK ? (wn * WT + li) * LDB + (BK / 2) * lk : 2 * lk * LDB + wn * 32 + li);
+  #pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          if (A_RK) {
+  #pragma unroll
+            for (int q = 0; q < BK / 8; ++q) *reinterpret_cast<float4*>(&fa[i][4 * q]) = *reinterpret_cast<const float4*>(ap + 32 * i * LDA + 4 * q);
+          } else fa[i][0] = ap[64 * i];
+          if (B_RK) {
+  #pragma unroll
+            for (int q = 0; q < BK / 8; ++q) *reinterpret_cast<float4*>(&fb[i][4 * q]) = *reinterpret_cast<const float4*>(bp + 32 * i * LDB + 4 * q);
+          } else fb[i][0] = bp[64 * i];
+        }
+  #pragma unroll
+        for (int j = 0; j < BK / 2; ++j) {
+          if (j + 1 < BK / 2) {
+  #pragma unroll
+            for (int i = 0; i < NA; ++i) {
+              if (!A_RK) fa[i][j + 1] = ap[KROW(j + 1) * LDA + 64 * i];
+              if (!B_RK) fb[i][j + 1] = bp[KROW(j + 1) * LDB + 64 * i];
+            }
+          }
+  #pragma unroll
+          for (int i = 0; i < NA; ++i)
+  #pragma unroll
+            for (int i2 = 0; i2 < NA; ++i2) acc[i][i2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[i2][j], acc[i][i2], 0, 0, 0);
+        }
+        // pin the interleave of the scalar (KR) operand reads: hipcc otherwise sinks every LDS read directly in front of its MFMAs with
+        // lgkmcnt(0).  One LDS read per KR operand and k-pair goes in front of the MFMAs of the previous k-pair.
+        if (!A_RK || !B_RK) {
+          constexpr int NR = (A_RK ? 0 : 1) + (B_RK ? 0 : 1);
+          constexpr int NRK = (A_RK ? NA * (BK / 8) : 0) + (B_RK ? NA * (BK / 8) : 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, NR + NRK, 0);
+  #pragma unroll
+          for (int i = 0; i < BK / 2 - 1; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NA * NA, 0);
+          }
           __builtin_amdgcn_sched_group_barrier(0x008, NA * NA, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, NA * NA, 0);
+        __syncthreads();
+      };
+      for (int kt = 0; kt < nk; kt += 2) {
+        step(std::integral_constant<int, 0>{}, kt);
+        if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
       }
-      __syncthreads();
-    };
-    for (int kt = 0; kt < nk; kt += 2) {
-      step(std::integral_constant<int, 0>{}, kt);
-      if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
-    }
-
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const bool add_bias = g.bias != nullptr && k0 == 0;
-    const int mode = whole ? g.mode : GEMM_ATOMIC;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row >= g.M) continue;
-        const long coff = g.c_tn > 0 ? (long)(row / g.c_tn) * g.c_sg + (long)(row % g.c_tn) * g.c_st : (long)row * g.ldc;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-          const int col = n0 + wn * WT + j * 32 + li;
-          if (col >= g.N) continue;
-          float v = acc[i][j][r];
-          if (add_bias) v += g.bias[col];
-          float* dst = C + coff + col;
-          if (mode == GEMM_STORE) *dst = v;
-          else if (mode == GEMM_ACCUM) *dst += v;
-          else atomicAdd(dst, v);
-        }
-      }
-    }
+      epilogue(acc);
+    }   // !SPLIT
   }
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 32)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long dc = clock64() - c0_, dw = wall_clock64() - w0_;
+    printf("gemm clock probe: %lld shader cycles in %lld x 10 ns = %.3f GHz\n", dc, dw, (double)dc / (double)dw * 0.1);
+  }
+#endif
 }
 
 // GEMM_STORE + split tiles: zero the tiles that more than one workgroup will accumulate into.  Block b looks at the
 // boundary between workgroups b and b+1.
 // (16-byte stores when every problem's C rows are 16-byte aligned -- `vec`, decided by the launcher -- else scalar)
-__global__ __launch_bounds__(256) void k_zero_split_tiles(GemmGroup grp, int G, int TL, int vec) {
+__global__ __launch_bounds__(256) void k_zero_split_tiles(GemmGroup grp, int G, int TLM, int TL, int vec) {
   const long git = grp.iters_total * (long)(blockIdx.x + 1) / (long)G;
   int prob = 0;
   while (git >= grp.iter_start[prob + 1]) ++prob;
@@ -353,13 +621,13 @@ __global__ __launch_bounds__(256) void k_zero_split_tiles(GemmGroup grp, int G, 
   const int tiles_n = (g.N + TL - 1) / TL;
   const int zb = (int)(tile / g.tiles_mn);
   const int tmn = (int)(tile - (long)zb * g.tiles_mn);
-  const int m0 = (tmn / tiles_n) * TL, n0 = (tmn % tiles_n) * TL;
+  const int m0 = (tmn / tiles_n) * TLM, n0 = (tmn % tiles_n) * TL;
   float* C = g.C + (long)zb * g.sC;
   const int w = vec ? 4 : 1;                    // floats per thread and row
   const int tpr = TL / w;                        // threads per row
   const int col = n0 + (threadIdx.x % tpr) * w;
   if (col >= g.N) return;
-  for (int r = threadIdx.x / tpr; r < TL; r += 256 / tpr) {
+  for (int r = threadIdx.x / tpr; r < TLM; r += 256 / tpr) {
     const int row = m0 + r;
     if (row >= g.M) break;
     const long coff = g.c_tn > 0 ? (long)(row / g.c_tn) * g.c_sg + (long)(row % g.c_tn) * g.c_st : (long)row * g.ldc;
@@ -371,7 +639,7 @@ __global__ __launch_bounds__(256) void k_zero_split_tiles(GemmGroup grp, int G, 
 
 }  // namespace
 
-static int gemm_prepare(int layout, const GemmArgs& g, GemmArgs& a, bool& twolvl, int TL) {
+static int gemm_prepare(int layout, const GemmArgs& g, GemmArgs& a, bool& twolvl, int TLM, int TL) {
   ASTK_CHECK(g.A.p && g.B.p && g.C, "gemm: null operand");
   ASTK_CHECK(aligned16(g.A.p) && aligned16(g.B.p), "gemm: A/B must be 16-byte aligned");
   ASTK_CHECK((g.A.ld % 4) == 0 && (g.B.ld % 4) == 0 && (g.A.sg % 4) == 0 && (g.A.st % 4) == 0 &&
@@ -397,7 +665,7 @@ static int gemm_prepare(int layout, const GemmArgs& g, GemmArgs& a, bool& twolvl
   a.spanB = (unsigned)(spb * 4);
   ASTK_CHECK(!(a_kr && g.A.rowidx) && !(b_kr && g.B.rowidx), "gemm: indexed rows are only supported on K-contiguous operands");
   twolvl = (a_kr && g.A.tn > 0) || (b_kr && g.B.tn > 0);
-  a.tiles_mn = cdiv(g.M, TL) * cdiv(g.N, TL);
+  a.tiles_mn = cdiv(g.M, TLM) * cdiv(g.N, TL);
   a.kt = cdiv(g.K, BK);
   a.iters_total = (long)a.tiles_mn * g.batch * a.kt;
   return 0;
@@ -419,17 +687,21 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   // threshold below, and either too few tiles for the CUs or tiles so shallow that their ramp dominates): then 64-tiles give 4x the
   // workgroups, each a quarter of the work.  ASTK_GEMM_TILE = 64 | 128 forces one.
   static const int force_tl = getenv("ASTK_GEMM_TILE") ? atoi(getenv("ASTK_GEMM_TILE")) : 0;
-  int TL = 128;
-  for (int pass = 0; pass < 2; ++pass) {
+  // operand precision: bf16x3 (three-term bf16 split, f32-level accuracy, up to 2.7x the f32 MFMA rate) unless ASTK_GEMM_PREC=f32 asks
+  // for the exact-f32 MFMA chain
+  static const int prec = (getenv("ASTK_GEMM_PREC") && !strcmp(getenv("ASTK_GEMM_PREC"), "f32")) ? PREC_F32 : PREC_BF16X3;
+  int TL = 128, TLM = 128;
+  for (int pass = 0; pass < 3; ++pass) {
     memset(&grp, 0, sizeof(grp));
     twolvl = any_store = false;
     tiles = 0; flops = 0; min_kt = 0x7fffffff;
+    bool tall_ok = true;       // 256-row tiles waste at most 10 % more rows than 128-row tiles on every problem
     for (int i = 0; i < n; ++i) {
       const GemmArgs& g = list[i];
       if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0) continue;
       GemmArgs& a = grp.g[grp.n];
       bool tl = false;
-      ASTK_TRY(gemm_prepare(layout, g, a, tl, TL));
+      ASTK_TRY(gemm_prepare(layout, g, a, tl, TLM, TL));
       twolvl = twolvl || tl;
       grp.iter_start[grp.n] = grp.iters_total;
       grp.iters_total += a.iters_total;
@@ -437,18 +709,22 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
       flops += 2.0 * g.M * g.N * (double)g.K * g.batch;
       any_store = any_store || g.mode == GEMM_STORE;
       min_kt = std::min(min_kt, a.kt);
+      tall_ok = tall_ok && cdiv(g.M, 256) * 256 * 10 <= cdiv(g.M, 128) * 128 * 11;
       ++grp.n;
     }
+    if (pass > 0) break;        // pass 0 sizes the launch with 128-tiles and picks; pass 1 re-plans with the chosen tile
     // (measured, scratch/gemm_bench.py: 40 tiles x 32 k-iterations 33 -> 18 us, 1 tile x 4800 57 -> 38 us, 600 tiles x 8 42 -> 38 us;
     //  200 tiles x 32 is 5 % faster with 128-tiles)
     int max_kt = 0;
     for (int i = 0; i < grp.n; ++i) max_kt = std::max(max_kt, grp.g[i].kt);
     const bool small = grp.iters_total < 256L * wgs_per_cu(128) * 10 * (32 / BK) && (tiles < 192 || max_kt <= 12 * (16 / BK > 0 ? 16 / BK : 1));
-    const int want = force_tl == 64 || force_tl == 128 ? force_tl : (small ? 64 : 128);
-    if (pass == 1 || want == TL) break;
-    TL = want;
+    int want = force_tl == 64 || force_tl == 128 || force_tl == 256 ? force_tl : (small ? 64 : 128);   // (256 x 128 tiles: ASTK_GEMM_TILE=256 only -- measured slower)
+    if (want == 256 && prec != PREC_BF16X3) want = 128;
+    if (want == 128) break;
+    TLM = want;
+    TL = want == 256 ? 128 : want;
   }
-  const int WGS_PER_CU = wgs_per_cu(TL);
+  const int WGS_PER_CU = wgs_per_cu(TL, prec);
   if (grp.n == 0) return 0;
   for (int i = grp.n; i <= GEMM_GROUP_MAX; ++i) grp.iter_start[i] = grp.iters_total;
   if (twolvl) {   // a plain operand next to a two-level one: express it as one group of INT_MAX rows
@@ -484,7 +760,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   if (log_shapes)
     for (int i = 0; i < grp.n; ++i)
       fprintf(stderr, "astk_gemm layout=%d M=%d N=%d K=%d batch=%d mode=%d twolvl=%d group=%d/%d G=%ld kt=%d tile=%d\n", layout, grp.g[i].M,
-              grp.g[i].N, grp.g[i].K, grp.g[i].batch, grp.g[i].mode, (int)twolvl, i, grp.n, G, grp.g[i].kt, TL);
+              grp.g[i].N, grp.g[i].K, grp.g[i].batch, grp.g[i].mode, (int)twolvl, i, grp.n, G, grp.g[i].kt, TLM * 1000 + TL);
   ProfScope prof(PROF_GEMM, s, flops);
   dim3 grid((unsigned)G, 1, 1);
   if (!aligned && any_store && G > 1) {
@@ -493,21 +769,25 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
       const GemmArgs& a = grp.g[i];
       vec = vec && aligned16(a.C) && (a.sC % 4) == 0 && (a.c_tn > 0 ? (a.c_sg % 4) == 0 && (a.c_st % 4) == 0 : (a.ldc % 4) == 0);
     }
-    hipLaunchKernelGGL(k_zero_split_tiles, dim3((unsigned)(G - 1)), dim3(256), 0, s, grp, (int)G, TL, vec ? 1 : 0);
+    hipLaunchKernelGGL(k_zero_split_tiles, dim3((unsigned)(G - 1)), dim3(256), 0, s, grp, (int)G, TLM, TL, vec ? 1 : 0);
   }
-#define ASTK_GEMM_LAUNCH(T_)                                                                                              \
-  switch (layout) {                                                                                                       \
-    case GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<T_, true, true, false>), grid, dim3(256), 0, s, grp); break;        \
-    case GEMM_NN:                                                                                                         \
-      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<T_, true, false, true>), grid, dim3(256), 0, s, grp);               \
-      else hipLaunchKernelGGL((gemm_f32_kernel<T_, true, false, false>), grid, dim3(256), 0, s, grp);                     \
-      break;                                                                                                              \
-    default:                                                                                                              \
-      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<T_, false, false, true>), grid, dim3(256), 0, s, grp);              \
-      else hipLaunchKernelGGL((gemm_f32_kernel<T_, false, false, false>), grid, dim3(256), 0, s, grp);                    \
-      break;                                                                                                              \
+#define ASTK_GEMM_LAUNCH(T_, P_, M_)                                                                                              \
+  switch (layout) {                                                                                                               \
+    case GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<T_, true, true, false, P_, M_>), grid, dim3(gemm_threads(P_)), 0, s, grp); break;  \
+    case GEMM_NN:                                                                                                                 \
+      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<T_, true, false, true, P_, M_>), grid, dim3(gemm_threads(P_)), 0, s, grp);  \
+      else hipLaunchKernelGGL((gemm_f32_kernel<T_, true, false, false, P_, M_>), grid, dim3(gemm_threads(P_)), 0, s, grp);        \
+      break;                                                                                                                      \
+    default:                                                                                                                      \
+      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<T_, false, false, true, P_, M_>), grid, dim3(gemm_threads(P_)), 0, s, grp); \
+      else hipLaunchKernelGGL((gemm_f32_kernel<T_, false, false, false, P_, M_>), grid, dim3(gemm_threads(P_)), 0, s, grp);       \
+      break;                                                                                                                      \
   }
-  if (TL == 64) { ASTK_GEMM_LAUNCH(64) } else { ASTK_GEMM_LAUNCH(128) }
+  if (prec == PREC_F32) {
+    if (TL == 64) { ASTK_GEMM_LAUNCH(64, PREC_F32, 64) } else { ASTK_GEMM_LAUNCH(128, PREC_F32, 128) }
+  } else if (TLM == 256) { ASTK_GEMM_LAUNCH(128, PREC_BF16X3, 256)
+  } else if (TL == 64) { ASTK_GEMM_LAUNCH(64, PREC_BF16X3, 64)
+  } else { ASTK_GEMM_LAUNCH(128, PREC_BF16X3, 128) }
 #undef ASTK_GEMM_LAUNCH
   ASTK_LAUNCH_CHECK();
   return 0;
