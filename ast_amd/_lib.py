@@ -100,9 +100,11 @@ SIGNATURES = {
     "astk_grad_sqnorm_scaled": (C.c_int, [_VP, _VP, _F, _F, _SZ, _VP, _VP]),
     "astk_decay_clip_amsgrad_step_scaled": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _SZ, _F, _F, _F, _VP, _F, _F, _F, _F, _I, _VP]),
     "astk_decay_clip_sgd_step_scaled": (C.c_int, [_VP, _VP, _SZ, _F, _F, _F, _VP, _F, _VP]),
+    "astk_decay_clip_noise": (C.c_int, [_VP, _VP, _SZ, _F, _F, _F, _VP, _F, _U64, _U64, _VP]),
     "astk_fill_dropout_mask": (C.c_int, [_VP, _SZ, _F, _U64, _U64, _VP]),
     "astk_fill_normal": (C.c_int, [_VP, _SZ, _F, _F, _U64, _U64, _VP]),
     "astk_scale_f32": (C.c_int, [_VP, _SZ, _F, _VP]),
+    "astk_zero_frames": (C.c_int, [_VP, _I, _I, _I, _VP, _F, _U64, _U64, _VP]),
     "astk_persist_status_snapshot": (C.c_int, [_VP, _VP]),
     "astk_persist_status": (C.c_int, [C.POINTER(C.c_uint), _I]),
     "astk_device_cu_count": (C.c_int, []),

@@ -221,6 +221,20 @@ __global__ void k_normal(float* out, size_t n, float mean, float sigma, uint64_t
   }
 }
 
+// dataloader.py:83-93 on the device: utterance b (true length len[b] <= T frames, zero-padded behind) gets int(rate * len[b]) of its
+// frames zeroed; the frames are drawn WITH replacement (np.random.choice's default), so fewer distinct frames may be hit.
+__global__ void k_zero_frames(float* X, int T, int D, const int32_t* len, float rate, uint64_t seed, uint64_t offset) {
+  const int b = blockIdx.x;
+  const int nb = min(max(len[b], 0), T);
+  const int n = (int)(rate * (float)nb);
+  float* xb = X + (size_t)b * T * D;
+  for (int i = threadIdx.x / 32; i < n; i += blockDim.x / 32) {        // 32 lanes clear one drawn frame
+    const uint64_t bits = mix64(seed ^ mix64(offset + (uint64_t)b * (uint64_t)T + (uint64_t)i));
+    const int r = (int)((bits >> 11) % (uint64_t)nb);
+    for (int d = threadIdx.x % 32; d < D; d += 32) xb[(size_t)r * D + d] = 0.f;
+  }
+}
+
 // ---- optimizer
 __global__ void k_sqnorm(const float* g, const float* p, float gsc, float l2, size_t n, double* out) {
   __shared__ double red[4];
@@ -261,6 +275,25 @@ __global__ void k_amsgrad(float* p, const float* g, float* m, float* v, float* v
       vhat[i] = vh;
     }
     p[i] = pi - lr_t * mi / (sqrtf(vh) + eps);
+  }
+}
+
+// GradientNoise behind WeightDecay and GradientClipping (hook order of nn.py:98-110): g <- clip(g gsc + l2 p) + sigma N(0,1), in place;
+// the update kernel then runs on the finished gradient (gsc = 1, l2 = 0, no clip)
+__global__ void k_decay_clip_noise(float* g, const float* p, size_t n, float gsc, float l2, float clip, const double* sqnorm, float sigma,
+                                   uint64_t seed, uint64_t offset) {
+  const float norm = (float)sqrt(*sqnorm);
+  const float rate = clip / norm;
+  const float gs = rate < 1.f ? rate : 1.f;
+  const size_t pairs = (n + 1) / 2;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t b = mix64(seed ^ mix64(offset + i));
+    const float u1 = u01(b), u2 = u01(mix64(b));
+    const float r = sqrtf(-2.f * logf(u1));
+    float sn, cs;
+    sincosf(6.2831853071795864f * u2, &sn, &cs);
+    g[2 * i] = (__fmul_rn(g[2 * i], gsc) + l2 * p[2 * i]) * gs + sigma * r * cs;
+    if (2 * i + 1 < n) g[2 * i + 1] = (__fmul_rn(g[2 * i + 1], gsc) + l2 * p[2 * i + 1]) * gs + sigma * r * sn;
   }
 }
 
@@ -454,6 +487,16 @@ int astk_decay_clip_sgd_step_scaled(float* p, const float* g, size_t n, float gr
   return 0;
 }
 
+int astk_decay_clip_noise(float* g, const float* p, size_t n, float grad_scale, float l2, float clip, const double* sqnorm, float sigma,
+                          uint64_t seed, uint64_t offset, void* stream) {
+  ASTK_CHECK(g && p && sqnorm && sigma >= 0.f, "decay_clip_noise: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_decay_clip_noise, dim3(grid_for((n + 1) / 2)), dim3(256), 0, (hipStream_t)stream, g, p, n, grad_scale, l2, clip, sqnorm,
+                     sigma, seed, offset);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
 int astk_fill_dropout_mask(float* out, size_t n, float ratio, uint64_t seed, uint64_t offset, void* stream) {
   ASTK_CHECK(out && ratio >= 0.f && ratio < 1.f, "fill_dropout_mask: bad arguments");
   if (n == 0) return 0;
@@ -467,6 +510,14 @@ int astk_fill_normal(float* out, size_t n, float mean, float sigma, uint64_t see
   ASTK_CHECK(out, "fill_normal: null pointer");
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_normal, dim3(grid_for((n + 1) / 2)), dim3(256), 0, (hipStream_t)stream, out, n, mean, sigma, seed, offset);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int astk_zero_frames(float* X, int B, int T, int D, const int32_t* lengths, float rate, uint64_t seed, uint64_t offset, void* stream) {
+  ASTK_CHECK(X && lengths && B > 0 && T > 0 && D > 0 && rate >= 0.f && rate <= 1.f, "zero_frames: bad arguments");
+  if (rate == 0.f) return 0;
+  hipLaunchKernelGGL(k_zero_frames, dim3(B), dim3(256), 0, (hipStream_t)stream, X, T, D, lengths, rate, seed, offset);
   ASTK_LAUNCH_CHECK();
   return 0;
 }

@@ -93,6 +93,8 @@ class DataLoader:
         self.n_utts = {k: sum(len(b) for b in v["buckets"]) for k, v in self.buckets.items()}
 
     def _drop_frames(self, x, rate):
+        if getattr(self, "_zero_on_device", False):      # the device path zeroes the frames of the uploaded batch (astk_zero_frames)
+            return x
         n = int(rate * len(x))
         if n <= 0:
             return x
@@ -157,6 +159,7 @@ class DataLoader:
         def padded(arrays, n_min):
             return max(max(len(a) for a in arrays), n_min)
         if self.device.type != "cuda":
+            self._zero_on_device = False
             for utts, pads in plan:
                 xs = [self._speech(u, set_key, max_sp) for u in utts]
                 out = {"X": pad_batch(xs, torch.float32, self.device, pads[0] if pads else 0), "utts": utts}
@@ -164,9 +167,12 @@ class DataLoader:
                     out["y"] = pad_batch([self._targets(u, set_key) for u in utts], torch.int32, self.device, pads[1] if pads else 0)
                 yield out
             return
-        # device batches: loading, frame zeroing and padding of batch k+1 run on a helper thread while batch k trains
+        # device batches: loading and padding of batch k+1 run on a helper thread while batch k trains; frame zeroing
+        # (dataloader.py:83-93) runs on the uploaded batch (astk_zero_frames: one launch instead of a NumPy pass per utterance)
         from concurrent.futures import ThreadPoolExecutor
         ring = self.__dict__.setdefault("_ring", _PinnedRing(self.device))
+        zero_rate = float(self.data_cfg.get("zero_input", 0) or 0) if "train" in set_key else 0.0
+        self._zero_on_device = zero_rate > 0 and os.environ.get("ASTK_ZERO_FRAMES_ON_HOST", "0") != "1"
 
         def stage(k):
             (utts, pads), slot = plan[k], k % ring.depth
@@ -174,6 +180,10 @@ class DataLoader:
             xs = [self._speech(u, set_key, max_sp) for u in utts]
             n = padded(xs, pads[0] if pads else 0)
             host = {"X": _pad_into(ring.host(slot, "X", (len(xs), n) + tuple(xs[0].shape[1:]), torch.float32), xs)}
+            if self._zero_on_device:
+                lens = ring.host(slot, "len", (len(xs),), torch.int32)
+                lens.copy_(torch.tensor([len(x) for x in xs], dtype=torch.int32))
+                host["len"] = lens
             if labels:
                 ys = [self._targets(u, set_key) for u in utts]
                 host["y"] = _pad_into(ring.host(slot, "y", (len(ys), padded(ys, pads[1] if pads else 0)), torch.int32), ys)
@@ -184,6 +194,17 @@ class DataLoader:
                 host = nxt.result()
                 nxt = pool.submit(stage, k + 1) if k + 1 < len(plan) else None
                 out = {name: h.to(self.device, non_blocking=True) for name, h in host.items()}
+                if "len" in out:
+                    import ctypes as C
+                    from . import _lib
+                    X = out["X"]
+                    seed = getattr(self, "zero_seed", 0x2E50F4A3E5)
+                    off = self.__dict__.get("_zero_counter", 0)
+                    self._zero_counter = off + X.shape[0] * X.shape[1]
+                    _lib.check(_lib.load().astk_zero_frames(C.c_void_p(X.data_ptr()), X.shape[0], X.shape[1], int(X[0, 0].numel()),
+                                                            C.c_void_p(out["len"].data_ptr()), zero_rate, seed, off,
+                                                            C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+                    del out["len"]
                 ring.mark_in_flight(k % ring.depth)
                 out["utts"] = utts
                 yield out

@@ -95,6 +95,7 @@ class NN:
         print("Clipping gradients at: {0:d}".format(opt_cfg["grad_clip"]))
         self.optimizer.add_hook(optimizers.GradientClipping(threshold=opt_cfg["grad_clip"]))
         if opt_cfg["grad_noise_eta"] > 0:
+            print("Adding gradient noise: {0:f}".format(opt_cfg["grad_noise_eta"]))
             self.optimizer.add_hook(optimizers.GradientNoise(eta=opt_cfg["grad_noise_eta"]))
         links = {n.split("/")[0] for n in (self.model.arena.shapes if self.model.arena is not None else [])}
         for l in opt_cfg["freeze"]:

@@ -21,8 +21,13 @@ class GradientClipping:
 
 
 class GradientNoise:
-    def __init__(self, eta):
-        raise NotImplementedError("GradientNoise (grad_noise_eta > 0) is not used by the shipped configs")
+    """chainer.optimizer.GradientNoise(eta) (nn.py:108-110): g += N(0, sigma^2), sigma^2 = eta / (1 + t)^0.55, t = the update count
+    (already incremented when the hooks run).  Applied behind WeightDecay and GradientClipping, the reference's insertion order."""
+
+    def __init__(self, eta, seed=0x6E015E):
+        self.eta = float(eta)
+        self.seed = seed
+        self.offset = 0
 
 
 class _Optimizer:
@@ -39,9 +44,32 @@ class _Optimizer:
         return self
 
     def add_hook(self, hook):
-        if isinstance(hook, WeightDecay) and any(isinstance(h, GradientClipping) for h in self.hooks):
-            raise NotImplementedError("the fused update implements the reference's order WeightDecay -> GradientClipping")
+        if isinstance(hook, WeightDecay) and any(isinstance(h, (GradientClipping, GradientNoise)) for h in self.hooks):
+            raise NotImplementedError("the fused update implements the reference's order WeightDecay -> GradientClipping -> GradientNoise")
+        if isinstance(hook, GradientClipping) and any(isinstance(h, GradientNoise) for h in self.hooks):
+            raise NotImplementedError("the fused update implements the reference's order WeightDecay -> GradientClipping -> GradientNoise")
         self.hooks.append(hook)
+
+    def _apply_noise(self, lib, a, l2, clip, s):
+        """If a GradientNoise hook is installed: finish the gradient in place (decay, clip, noise) and return the (l2, clip, scale) the
+        update kernel must use afterwards (none of them again); else pass the values through."""
+        noise = [h for h in self.hooks if isinstance(h, GradientNoise)]
+        if not noise:
+            return l2, clip, self.grad_scale
+        h = noise[0]
+        sigma = math.sqrt(h.eta / (1.0 + self.t) ** 0.55)
+        frozen = getattr(self.target, "_frozen", set())
+        # parameter by parameter over the exact extents: the arena's alignment pads must keep their zero gradient (and value)
+        for name, shp in a.shapes.items():
+            if name.split("/")[0] in frozen:
+                continue
+            off, n = a.offsets[name], 1
+            for d in shp:
+                n *= int(d)
+            check(lib.astk_decay_clip_noise(C.c_void_p(a.grad.data_ptr() + 4 * off), C.c_void_p(a.data.data_ptr() + 4 * off), n, self.grad_scale,
+                                            l2, clip, C.c_void_p(self.sqnorm.data_ptr()), sigma, h.seed, h.offset, s))
+            h.offset += (n + 1) // 2
+        return 0.0, 3.0e38, 1.0
 
     def _hook_values(self):
         l2 = sum(h.rate for h in self.hooks if isinstance(h, WeightDecay))
@@ -91,10 +119,11 @@ class Adam(_Optimizer):
             self.vhat = torch.zeros_like(a.data)
         self.t += 1
         lr_t = self.alpha * math.sqrt(1.0 - self.beta2 ** self.t) / (1.0 - self.beta1 ** self.t)
+        l2, clip, gscale = self._apply_noise(lib, a, l2, clip, s)
         for off, n in self.target.enabled_ranges():
             def p(t):
                 return C.c_void_p(t.data_ptr() + 4 * off)
-            check(lib.astk_decay_clip_amsgrad_step_scaled(p(a.data), p(a.grad), p(self.m), p(self.v), p(self.vhat), n, self.grad_scale, l2,
+            check(lib.astk_decay_clip_amsgrad_step_scaled(p(a.data), p(a.grad), p(self.m), p(self.v), p(self.vhat), n, gscale, l2,
                                                           clip, C.c_void_p(self.sqnorm.data_ptr()), lr_t, self.beta1, self.beta2,
                                                           self.eps, 1 if self.amsgrad else 0, s))
 
@@ -107,6 +136,7 @@ class SGD(_Optimizer):
     def update(self):
         lib, a, l2, clip, s = self._prepare()
         self.t += 1
+        l2, clip, gscale = self._apply_noise(lib, a, l2, clip, s)
         for off, n in self.target.enabled_ranges():
             check(lib.astk_decay_clip_sgd_step_scaled(C.c_void_p(a.data.data_ptr() + 4 * off), C.c_void_p(a.grad.data_ptr() + 4 * off), n,
-                                                      self.grad_scale, l2, clip, C.c_void_p(self.sqnorm.data_ptr()), self.lr, s))
+                                                      gscale, l2, clip, C.c_void_p(self.sqnorm.data_ptr()), self.lr, s))

@@ -155,6 +155,7 @@ class SpeechEncoderDecoder:
         self.inject = {}          # test hooks: enc_masks / emb_mask / rnn_masks / noise / use_truth
         self.rng_seed = 0x5EED
         self._rng_offset = 0
+        self.bn_N = 0                   # training-mode forward passes so far = Chainer's BatchNormalization persistent N (A10)
         self.enc_states = None
         self.loss = 0
         self._cur = None
@@ -386,6 +387,8 @@ class SpeechEncoderDecoder:
                 raise sx.error
             check(rc)
         st["bn_world"] = 1 if sx is None else sx.world
+        if config.train:
+            self.bn_N += 1
         wl = self._workspace("lstm", st["ws_lstm"])
         check(lib.astk_lstm_stack_fwd(C.byref(st["ld"]), st["lp"], _vp(st["xlstm"]), _vp(st["enc_masks"]), _vp(st["enc_states"]),
                                       _vp(st["cT"]), _vp(st["hT"]), _vp(wl), wl.numel(), s))

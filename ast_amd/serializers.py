@@ -8,10 +8,14 @@ def save_npz(path, model, optimizer=None):
     for k, v in model.persist.items():
         out[k] = v.detach().cpu().numpy()
     for i in range(len(model.cnns)):
-        out[f"CNN_{i}_bn/N"] = np.asarray(getattr(model, "bn_N", 0), dtype=np.int64)
+        # Chainer's BatchNormalization counts its training-mode calls in the persistent N (A10); every layer sees every train forward
+        out[f"CNN_{i}_bn/N"] = np.asarray(int(model.bn_N), dtype=np.int64)
     if optimizer is not None and getattr(optimizer, "m", None) is not None:
         # an extension over the reference (which never saves Adam state); Chainer's load_npz ignores extra keys
         out["__opt__/t"] = np.asarray(optimizer.t)
+        # where the dropout / speech-noise stream stands: a resumed run must not replay the masks of its first epochs
+        out["__opt__/rng_seed"] = np.asarray(int(model.rng_seed), dtype=np.uint64)
+        out["__opt__/rng_offset"] = np.asarray(int(model._rng_offset), dtype=np.uint64)
         out["__opt__/m"] = optimizer.m.cpu().numpy()
         out["__opt__/v"] = optimizer.v.cpu().numpy()
         out["__opt__/vhat"] = optimizer.vhat.cpu().numpy()
@@ -42,6 +46,8 @@ def load_npz(path, model, optimizer=None):
         for k, v in model.persist.items():
             if k in keys:
                 v.copy_(torch.from_numpy(np.asarray(z[k], dtype=np.float32)))
+        if "CNN_0_bn/N" in keys:
+            model.bn_N = int(z["CNN_0_bn/N"])
         if optimizer is not None:
             _restore_optimizer(z, keys, model, optimizer)
 
@@ -55,6 +61,8 @@ def _restore_optimizer(z, keys, model, optimizer):
     optimizer.m = torch.from_numpy(z["__opt__/m"]).to(dev)
     optimizer.v = torch.from_numpy(z["__opt__/v"]).to(dev)
     optimizer.vhat = torch.from_numpy(z["__opt__/vhat"]).to(dev)
+    if "__opt__/rng_offset" in keys:
+        model.rng_seed, model._rng_offset = int(z["__opt__/rng_seed"]), int(z["__opt__/rng_offset"])
     return True
 
 

@@ -231,9 +231,20 @@ int astk_decay_clip_sgd_step_scaled(float* p, const float* g, size_t n, float gr
 /* ---------------------------------------------------------------- utilities
  * Dropout keep-masks (Chainer-sem A5): out[i] = (u_i >= ratio) / (1-ratio), u from a counter-based hash RNG. */
 int astk_fill_dropout_mask(float* out, size_t n, float ratio, uint64_t seed, uint64_t offset, void* stream);
+/* chainer.optimizer.GradientNoise behind the other two hooks (nn.py:108-110; hooks run in insertion order WeightDecay -> GradientClipping ->
+ * GradientNoise, Chainer-sem A7): g <- clip(g * grad_scale + l2 * p) + sigma * N(0,1) in place, sigma^2 = eta / (1 + t)^0.55.  The update
+ * call that follows takes the finished gradient (grad_scale 1, l2 0, clip off).  Chainer draws from its unseeded global RNG (quirk Q7);
+ * this is a counter-based stream (seed, offset) consuming n / 2 counters. */
+int astk_decay_clip_noise(float* g, const float* p, size_t n, float grad_scale, float l2, float clip, const double* sqnorm, float sigma,
+                          uint64_t seed, uint64_t offset, void* stream);
 /* out[i] = 1 + sigma*N(0,1): the multiplicative speech noise of seq2seq.py:300-302, generated on device. */
 int astk_fill_normal(float* out, size_t n, float mean, float sigma, uint64_t seed, uint64_t offset, void* stream);
 int astk_scale_f32(float* x, size_t n, float s, void* stream);
+/* Frame zeroing of the training loader (dataloader.py:83-93, `zero_input`), on the padded device batch X (B,T,D): utterance b of true
+ * length lengths[b] gets int(rate * lengths[b]) frames zeroed, drawn with replacement from [0, lengths[b]) like
+ * np.random.choice(np.arange(T_b), size=n).  The reference's draw is unseeded (quirk Q7); this one is a counter-based stream
+ * (seed, offset), consuming B*T counters per call. */
+int astk_zero_frames(float* X, int B, int T, int D, const int32_t* lengths, float rate, uint64_t seed, uint64_t offset, void* stream);
 /* One wavefront that keeps `stream` busy for `usec` microseconds (<= 100 000) and then increments *flag (may be NULL).  For probing
  * whether two streams really execute concurrently: HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
  * default), and two streams that share one are serialised whatever their events say (ast_amd/seq2seq.py:_cu_streams). */

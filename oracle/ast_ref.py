@@ -391,8 +391,16 @@ class RefOptimizer:
         if rate < 1:
             for _, p in plist:
                 p.grad = p.grad * p.dtype.type(rate)
-        assert c.get("grad_noise_eta", 0) == 0
         self.t += 1
+        if c.get("grad_noise_eta", 0) > 0:
+            # chainer.optimizer.GradientNoise (A7): runs behind WeightDecay and GradientClipping; UpdateRule.update increments t before
+            # the hooks, so sigma^2 = eta / (1 + t)^0.55 with t = 1 at the first update.  Chainer draws from the unseeded global RNG
+            # (Q7); here the draw comes from `noise_rng` so that tests can reproduce it.
+            std = np.sqrt(c["grad_noise_eta"] / (1.0 + self.t) ** 0.55)
+            rng = getattr(self, "noise_rng", None) or np.random.default_rng(0)
+            self.noise_rng = rng
+            for _, p in plist:
+                p.grad = p.grad + (rng.standard_normal(p.grad.shape) * std).astype(p.grad.dtype)
         if c["type"] == 0:
             b1, b2, eps, alpha = 0.9, 0.999, 1e-8, c["lr"]
             lr_t = alpha * np.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
@@ -417,6 +425,32 @@ def train_step(model, opt, X, y, teach_ratio, add_noise=0, noise=None, pyrandom=
     loss.backward()
     opt.update()
     return float(loss.data), float(loss.data) / len(y)
+
+
+# --------------------------------------------------------------------------- checkpoints (train.py:73-75, nn.py:141-152; A10)
+def save_npz(path, model):
+    """What chainer.serializers.save_npz(path, model) writes for this Chain: one compressed .npz with '<link>/<param>' keys --
+    every parameter in Chainer's own layout, and the BatchNormalization persistents avg_mean / avg_var / N (N = number of
+    training-mode calls so far).  LSTM h / c are not persistent."""
+    out = {}
+    for k, v in model.p.items():
+        out[k] = np.asarray(v.data if isinstance(v, Parameter) else v)
+    for name, bn in model.bn.items():
+        out[name + "/N"] = np.asarray(bn.N, dtype=np.int64)
+    with open(path, "wb") as f:
+        np.savez_compressed(f, **out)
+
+
+def load_npz(path, model):
+    """chainer.serializers.load_npz(path, model): every parameter / persistent of the model must be in the file (strict=True)."""
+    with np.load(path) as z:
+        for k, v in model.p.items():
+            tgt = v.data if isinstance(v, Parameter) else v
+            if k not in z.files:
+                raise KeyError(f"{path}: missing {k}")
+            tgt[...] = np.asarray(z[k], dtype=tgt.dtype).reshape(tgt.shape)
+        for name, bn in model.bn.items():
+            bn.N = int(z[name + "/N"])
 
 
 # --------------------------------------------------------------------------- synthetic batches (SURVEY 8d)

@@ -192,6 +192,53 @@ def test_checkpoint_roundtrip(tmp_path):
         assert torch.equal(v, g2.arena.views[k]), k
 
 
+def test_checkpoints_cross_load_between_oracle_and_hip_model(tmp_path):
+    """train.py:73-75 / nn.py:141-152 at the file level: a Chainer-layout .npz WRITTEN BY THE ORACLE (oracle.ast_ref.save_npz: the keys,
+    layouts and BatchNorm persistents chainer.serializers.save_npz produces, after one oracle train step so that the running
+    statistics and N are not the initial ones) loads into a HIP model that then computes the oracle's eval-mode greedy decode and
+    train-mode loss; and a checkpoint written by the HIP model after a train step loads into a fresh oracle model with the same result."""
+    from oracle import ast_ref as R
+    from ast_amd import serializers
+    from ast_amd.seq2seq import SpeechEncoderDecoder, using_config
+    import copy
+    cfg = tiny_cfg(enc_layers=2, dec_layers=2, H=32, E=8, A=32, c0=8, c1=16, V=37, drop=0.0)
+    B, T, D, L, V = 3, 60, 26, 6, 37
+    P, X, y = _make(cfg, B, T, D, L, V, seed=7)
+    ref = R.RefModel(cfg, {k: v.astype(np.float64) for k, v in P.items()}, V)
+    opt = R.RefOptimizer(ref, OPT)
+    R.train_step(ref, opt, X.astype(np.float64), y, 1.0, pyrandom=random.Random(0))
+    path = str(tmp_path / "seq2seq_1.model")
+    R.save_npz(path, ref)
+    z = np.load(path)
+    assert int(z["CNN_0_bn/N"]) == 1 and int(z["CNN_1_bn/N"]) == 1 and z["L0_dec/upward/W"].shape == (4 * 32, 8 + 32)
+    # oracle file -> HIP model
+    g = SpeechEncoderDecoder(0, copy.deepcopy(cfg))
+    serializers.load_npz(path, g)
+    assert g.bn_N == 1 and g.in_dim == D
+    want = ref.predict(X.astype(np.float64), R.GO_ID, R.EOS_ID, 8)                    # eval mode: running statistics from the file
+    got = g.predict(torch.from_numpy(X), R.GO_ID, R.EOS_ID, 8)
+    assert got.shape == want.shape and (got == want).all()
+    flags = [1] * (L - 1)
+    lref = ref.forward_loss(X.astype(np.float64), y, 1.0, pyrandom=random.Random(0))
+    g.inject["use_truth"] = flags
+    with using_config("train", True):
+        lg = g.forward_loss(torch.from_numpy(X), torch.from_numpy(y), 1.0)
+        g.cleargrads()
+        lg.backward()
+    assert _rel(float(lg.data), float(lref.data)) < 1e-4
+    assert g.bn_N == 2
+    # HIP file -> oracle model
+    path2 = str(tmp_path / "seq2seq_2.model")
+    serializers.save_npz(path2, g)
+    ref2 = R.RefModel(cfg, {k: np.zeros_like(v, dtype=np.float64) for k, v in P.items()}, V)
+    R.load_npz(path2, ref2)
+    assert ref2.bn["CNN_0_bn"].N == 2
+    np.testing.assert_allclose(ref2.p["CNN_1_bn/avg_var"], ref.p["CNN_1_bn/avg_var"], rtol=2e-3, atol=1e-6)   # both saw the same second forward
+    want2 = ref2.predict(X.astype(np.float64), R.GO_ID, R.EOS_ID, 8)
+    got2 = g.predict(torch.from_numpy(X), R.GO_ID, R.EOS_ID, 8)
+    assert (got2 == want2).all()
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from ast_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
@@ -545,3 +592,29 @@ def test_persistent_kernel_timeout_raises_instead_of_training_on(monkeypatch):
     monkeypatch.delenv("ASTK_PERSIST_SPIN_LIMIT")
     loss = step()
     assert _rel(float(loss), float(rl.data)) < 1e-4
+
+
+def test_device_loader_zeroes_frames_like_the_host_loader(tmp_path):
+    """zero_input on the device path of the loader: every training utterance of a batch has between 1 and int(0.1 T_u) all-zero frames
+    inside its own length (the host path's rule, dataloader.py:83-93), targets are untouched, evaluation batches are not zeroed."""
+    from ast_amd.dataloader import SyntheticDataLoader
+    data = {"dataloader": "synthetic", "vocab_size": 31, "feat_dim": 13, "n_utts": {"syn_train": 40, "syn_dev": 8},
+            "frames": [60, 300], "targets": [2, 9], "buckets_num": 4, "buckets_width": 80, "max_pred": 12,
+            "zero_input": 0.1, "train_scale": 1, "dec_key": "bpe_w"}
+    gpu = SyntheticDataLoader(data, str(tmp_path), 0)
+    random.seed("seed-ast-20h")
+    n_checked = 0
+    for b in gpu.get_batch(8, "syn_train", train=True, labels=True):
+        X = b["X"].cpu().numpy()
+        for row, u in zip(X, b["utts"]):
+            t_u = min(int(gpu.info["syn_train"][u]["sp"]), 400)
+            zero = np.where((row[:t_u] == 0).all(axis=1))[0]
+            assert 1 <= len(zero) <= int(0.1 * t_u), (u, len(zero), t_u)
+            assert (row[t_u:] == 0).all()                       # padding
+            n_checked += 1
+    assert n_checked >= 36
+    for b in gpu.get_batch(8, "syn_dev", train=False, labels=False):
+        X = b["X"].cpu().numpy()
+        for row, u in zip(X, b["utts"]):
+            t_u = int(gpu.info["syn_dev"][u]["sp"])
+            assert not (row[:t_u] == 0).all(axis=1).any()

@@ -570,3 +570,77 @@ def test_spin_keeps_the_stream_busy(lib):
     torch.cuda.synchronize()
     assert int(flag.item()) == 1 and 0.4 <= e0.elapsed_time(e1) <= 5.0
     assert lib.astk_spin(200000, None, stream()) != 0          # bounded: at most 100 ms
+
+
+def test_zero_frames_on_device_follows_the_loaders_rule(lib):
+    """dataloader.py:83-93 on the device (astk_zero_frames): utterance b loses int(rate * T_b) frames drawn WITH replacement from its own
+    T_b frames -- never more than that many, at least one when n >= 1, never a padding row; whole frames; a different counter offset
+    draws different frames; and the number of distinct frames hit follows the with-replacement law (mean n_distinct = T (1 - (1 - 1/T)^n))."""
+    lens = np.array([400, 57, 80, 33, 9, 250], dtype=np.int32)
+    B, T, D, rate = len(lens), 400, 13, 0.1
+    X = torch.ones(B, T, D, device="cuda")
+    ld = dev(lens, torch.int32)
+    ok(lib, lib.astk_zero_frames(vp(X), B, T, D, vp(ld), rate, 1234, 0, stream()))
+    x = X.cpu().numpy()
+    rows0 = []
+    for b, n_b in enumerate(lens):
+        n = int(rate * n_b)
+        zero_rows = np.where((x[b] == 0).all(axis=1))[0]
+        partly = ((x[b] == 0).any(axis=1) & ~(x[b] == 0).all(axis=1)).sum()
+        assert partly == 0 and len(zero_rows) <= n and (n == 0 or len(zero_rows) >= 1), (b, len(zero_rows), n)
+        assert (zero_rows < n_b).all()
+        rows0.append(set(zero_rows.tolist()))
+    X2 = torch.ones(B, T, D, device="cuda")
+    ok(lib, lib.astk_zero_frames(vp(X2), B, T, D, vp(ld), rate, 1234, B * T, stream()))
+    assert set(np.where((X2[0].cpu().numpy() == 0).all(axis=1))[0].tolist()) != rows0[0]
+    # with-replacement law over many draws: T = 400, n = 40 -> 38.1 distinct frames on average
+    tot = 0
+    for k in range(50):
+        Xk = torch.ones(1, T, D, device="cuda")
+        ok(lib, lib.astk_zero_frames(vp(Xk), 1, T, D, vp(ld), rate, 99, k * T, stream()))
+        tot += int((Xk[0, :, 0] == 0).sum())
+    assert abs(tot / 50 - 400 * (1 - (1 - 1 / 400) ** 40)) < 1.0
+
+
+def test_gradient_noise_hook_follows_the_other_two(lib):
+    """nn.py:108-110: GradientNoise(eta) behind WeightDecay and GradientClipping (insertion order, A7).  Same gradients with and without
+    the hook: what is left in the gradient arena after update() is clip(g + l2 p) + noise, and the noise has mean 0 and variance
+    eta / (1 + t)^0.55 (t = 1 at the first update, 2 at the second)."""
+    import math
+    from ast_amd import optimizers as O
+    from ast_amd.params import ParamArena
+
+    class _M:
+        def __init__(self):
+            self.arena = ParamArena({"a/W": (300, 400), "b/W": (50001,)}, torch.device("cuda"))
+        def enabled_ranges(self):
+            return [(0, self.arena.size)]
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    m0, m1 = _M(), _M()
+    p0 = torch.randn(m0.arena.size, device="cuda", generator=gen)
+    eta, l2, clip = 0.3, 1e-2, 5.0
+    opts = []
+    for m, noisy in ((m0, False), (m1, True)):
+        m.arena.data.copy_(p0)
+        o = O.Adam(alpha=1e-3, amsgrad=True).setup(m)
+        o.add_hook(O.WeightDecay(l2))
+        o.add_hook(O.GradientClipping(clip))
+        if noisy:
+            o.add_hook(O.GradientNoise(eta))
+        opts.append(o)
+    for step in (1, 2):
+        g = torch.randn(m0.arena.size, device="cuda", generator=gen) * 0.05
+        for m, o in zip((m0, m1), opts):
+            m.arena.grad.copy_(g)
+            pb = m.arena.data.clone()
+            o.update()
+            if o is opts[0]:
+                norm = o.last_grad_norm
+                want = (g + l2 * pb) * min(1.0, clip / norm)
+        noise = m1.arena.grad - want if step == 1 else None
+        if step == 1:
+            assert torch.equal(m0.arena.grad, g)                              # without the hook the arena keeps the raw gradient
+            sig = math.sqrt(eta / 2.0 ** 0.55)
+            assert abs(float(noise.mean())) < 5 * sig / math.sqrt(noise.numel())
+            assert abs(float(noise.std()) - sig) < 0.01 * sig
+    assert float((m1.arena.data - m0.arena.data).abs().max()) > 0             # the noise reached the update

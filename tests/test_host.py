@@ -65,6 +65,66 @@ def test_arena_layout_is_16_byte_aligned_and_flat():
     assert a.range_of("a/W") == (0, 16)
 
 
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_bucket_histogram_of_the_reference_corpus_description():
+    """preprocessing/prep_buckets.py:41-63 on the reference-held data/fisher/fisher_20h.info (frame counts extracted into
+    tests/golden/fisher_20h_frames.json by make_fisher_frames.py): the Fisher-20h train histogram SURVEY.md 8(a) row a1 quotes, the
+    corpus totals of SURVEY.md section 6, and the bucket the benchmark's "T ~ 800" comes from."""
+    from ast_amd import prep_buckets
+    d = json.load(open(os.path.join(GOLD, "fisher_20h_frames.json")))
+    frames = d["frames"]["fisher_train"]
+    assert len(frames) == 17306 and sum(frames) == 7238296 and max(frames) == 2566
+    info = {"fisher_train": {f"u{i}": {"sp": t} for i, t in enumerate(frames)},
+            "fisher_dev": {f"d{i}": {"sp": t} for i, t in enumerate(d["frames"]["fisher_dev"])}}
+    out = prep_buckets.buckets_from_info(info, 20, 80, "sp", scale=1, seed="seed-ast-20h")
+    hist = [len(b) for b in out["fisher_train"]["buckets"]]
+    assert hist == [1025, 3516, 2543, 1939, 1486, 1188, 932, 736, 674, 603, 550, 505, 420, 342, 277, 189, 138, 86, 63, 94]
+    assert sum(len(b) for b in out["fisher_dev"]["buckets"]) == 3977
+    # T ~ 800: buckets 9 and 10 hold the 720..879-frame utterances; everything above 1680 frames is truncated by the loader
+    assert all(720 <= info["fisher_train"][u]["sp"] < 800 for u in out["fisher_train"]["buckets"][9])
+    assert sum(t > 1680 for t in frames) == sum(1 for t in frames if t // 80 >= 21)
+    assert d["vocab_types"]["bpe_w"] == 1098                   # dec_vocab_size of the shipped experiment (config.py:24)
+
+
+@pytest.mark.parametrize("exp,V,D", [("es_en_20h", 1098, 13), ("asr_gpfr", 1004, 13)])
+def test_reference_experiment_configs_load_through_config_and_model(tmp_path, exp, V, D):
+    """The reference's ACTUAL experiments/<exp>/{model,train}_cfg.json (committed as data fixtures under
+    tests/golden/ref_experiments/) go through Config (config.py:15-29), the model constructor (seq2seq.py:23-156: every key it reads)
+    and the optimizer set-up (nn.py:81-119); asr_gpfr has no n_attn / feed_attn keys (defaults) and dataloader = globalphone."""
+    import shutil
+    from ast_amd.config import Config
+    from ast_amd.params import param_shapes
+    from ast_amd.seq2seq import SpeechEncoderDecoder
+    from ast_amd import optimizers as O
+    for f in ("model_cfg.json", "train_cfg.json"):
+        shutil.copy(os.path.join(GOLD, "ref_experiments", exp, f), tmp_path / f)
+    tcfg = json.load(open(tmp_path / "train_cfg.json"))
+    dec_key = tcfg["data"]["dec_key"]
+    vocab = {dec_key: {"w2i": {str(i).encode(): i for i in range(V)}, "i2w": {}, "freq": {}}}
+    pickle.dump(vocab, open(tmp_path / "v.vocab", "wb"))
+    tcfg["data"]["vocab_path"] = str(tmp_path / "v.vocab")     # the vocab pickle itself is not in the reference tree's experiments
+    json.dump(tcfg, open(tmp_path / "train_cfg.json", "w"))
+    c = Config(str(tmp_path))
+    assert c.model["rnn_config"]["dec_vocab_size"] == V and c.model["model_dir"] == str(tmp_path)
+    assert c.train["seed"] == "seed-ast-20h" and c.train["batch_size"] == 32 and c.train["extras"]["teach_ratio"] == 0.8
+    assert c.train["data"]["buckets_num"] == 20 and c.train["data"]["buckets_width"] == 80 and c.train["data"]["max_pred"] == 175
+    m = SpeechEncoderDecoder(-1, c.model)                      # constructor only: no GPU here
+    assert (len(m.rnn_enc), len(m.rnn_rev_enc), len(m.rnn_dec), m.H, m.h, m.E, m.A) == (3, 3, 3, 512, 256, 128, 512)
+    assert m.rnn_dec == ["L0_dec", "L1_dec", "L2_dec"] and m.cnns == ["CNN_0", "CNN_1"]
+    train, persist = param_shapes(c.model, D, V)
+    assert train["L0_enc/upward/W"] == (1024, 512) and train["L2_dec/upward/W"] == (2048, 512) and train["out/W"] == (V, 512)
+    if exp == "es_en_20h":
+        assert sum(int(np.prod(s)) for s in train.values()) == 12333258
+    oc = c.train["optimizer"]
+    assert (oc["type"], oc["lr"], oc["l2"], oc["grad_clip"], oc["grad_noise_eta"], oc["freeze"]) == (0, 0.001, 0.0001, 2, 0, [])
+    opt = O.Adam(alpha=oc["lr"], beta1=0.9, beta2=0.999, eps=1e-8, amsgrad=True)
+    opt.add_hook(O.WeightDecay(oc["l2"]))
+    opt.add_hook(O.GradientClipping(oc["grad_clip"]))
+    assert [type(h).__name__ for h in opt.hooks] == ["WeightDecay", "GradientClipping"]
+
+
 def test_bucketing_matches_prep_buckets():
     from ast_amd import prep_buckets
     info = {"fisher_train": {f"u{i}": {"sp": t} for i, t in enumerate([27, 79, 80, 159, 160, 1599, 1600, 2566])},
