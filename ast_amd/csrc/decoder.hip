@@ -297,7 +297,7 @@ extern "C" {
 int astk_decoder_path(const astk_decoder_desc* d) {
   int ns = 1, ch = 1;
   if (!d || !decoder_persist_applicable(d, &ns, &ch)) return 0;
-  return 1 | ((d->H == 512 && ch <= 32) ? 2 : 0) | (d->n_layers << 8);
+  return 1 | ((d->H == 512 && ch <= 60) ? 2 : 0) | (d->n_layers << 8);      // (PDEC_CHUNK_MAX of decoder_persist.hip)
 }
 
 size_t astk_decoder_workspace_bytes(const astk_decoder_desc* d) {

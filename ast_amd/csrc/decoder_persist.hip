@@ -34,6 +34,10 @@ constexpr int CTRS = 64;          // counter stride in words (256 B)
 constexpr int G = 256;            // workgroups (one per CU)
 enum Phase { PH_CELL = 0 /* + layer: 0..2 */, PH_CELL1, PH_CELL2, PH_CMB, PH_CTX, PH_LOG, PH_CE, PH_N };
 constexpr int PDEC_MAX_LAYERS = 3;
+// Specialised attention phase (H = 512): at most this many rows of a (batch row, time chunk) slice stay resident in LDS (2 x 28 x 2 KB =
+// 112 KB of enc + encA); a chunk's remaining rows (chunks of up to 60 rows: T'' <= 480 at batch 32, i.e. the loader's longest
+// utterances of 1680 frames) are streamed from L2 / Infinity Cache every step -- they are the same bytes for every step of the loop.
+constexpr int PDEC_RES_ROWS = 28, PDEC_CHUNK_MAX = 60;
 constexpr int NPHASE_SLOTS = 8;   // counter lines reserved per batch tile ahead of the abort word and the per-row counters
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -204,7 +208,8 @@ constexpr int OFF_WC = 0, OFF_WL = NB_C, NWREG = 2 * CELLW;
 static_assert(OFF_WL + 2 * NB_L <= NWREG, "register budget");
 // NL > 1: two cell slots of 2 tiles x (8 + 8) k-blocks = 32 float4 each: [0, 32) layer 0 ([ht | lateral]; its embedding columns are
 // re-read every step, off the chain) or ctx / logits, [32, 64) a layer >= 1 ([upward | lateral]).  64 float4 = 256 registers = the
-// whole AGPR file: one float4 more and the compiler spills loop-invariant addresses to scratch inside the step loop.
+// whole AGPR file.  (Streaming the lateral weights of the second slot from L2 instead -- 48 float4 resident -- halved the spills of
+// the specialised attention phase but cost 4 us per decoder step: the reads compete with the chain's hand-offs.  Not kept.)
 constexpr int CELLW2 = 2 * NB_H, OFF_C2 = 2 * CELLW2, NWREG_ML = 4 * CELLW2;
 static_assert(OFF_WL + 2 * NB_L <= OFF_C2, "register budget");
 
@@ -228,9 +233,11 @@ __device__ __forceinline__ void aload_sc1(float4* a, __amdgpu_buffer_rsrc_t ra, 
   for (int i = 0; i < NB; ++i) a[i] = ldb128_sc1(ra, a_off + min(16 * (wave + 4 * i) + 4 * q, K - 4));
 }
 
-// NC > 0: H = 64 * NC and chunk <= 32 are compile-time facts for the attention phase (fully unrolled, batched LDS reads);
+// NC > 0: H = 64 * NC and chunk <= PDEC_CHUNK_MAX are compile-time facts for the attention phase (fully unrolled, batched reads);
 // NC = 0: generic loops.
-template <int NC, int NL>
+// XS: the slice has more rows than stay resident (chunk > PDEC_RES_ROWS): the streamed-row code is compiled into its own instantiation
+// so that the common short-chunk case keeps its register budget.
+template <int NC, int NL, bool XS>
 __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // enc slice [chunk][H], encA slice [chunk][H], scratch
   __shared__ __attribute__((aligned(16))) float red[4 * 256];
@@ -323,22 +330,24 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
   // ---------------- resident slices of enc_states and encA = enc Wa in LDS: rows [t0, t1) of batch row att_b
   const int t0 = att_sp * a.chunk, t1 = min(T, t0 + a.chunk);
   const int nrow = has_att ? t1 - t0 : 0;
+  const int cres = NC > 0 ? min(a.chunk, PDEC_RES_ROWS) : a.chunk;      // rows of the slice kept in LDS
+  const int nres = min(nrow, cres);
   float* encS = lds;
-  float* encAS = lds + a.chunk * H;
-  float* ebS = lds + 2 * a.chunk * H;            // [chunk] enc.ba, computed once
+  float* encAS = lds + cres * H;
+  float* ebS = lds + 2 * cres * H;               // [chunk] enc.ba, computed once
   float* scr = ebS + ((a.chunk + 3) & ~3);       // per-step scratch: hS[H] | score[chunk] | p[chunk]  -- or the combine's partial rows
+  const float* gEnc = a.enc + ((long)att_b * T + t0) * H;       // this slice in global memory (rows >= nres are read from here every step)
+  const float* gEncA = a.encA + ((long)att_b * T + t0) * H;
   if (has_att) {
-    const float* src = a.enc + ((long)att_b * T + t0) * H;
-    const float* srcA = a.encA + ((long)att_b * T + t0) * H;
-    const int n4 = nrow * H / 4;
+    const int n4 = nres * H / 4;
     for (int i = tid; i < n4; i += 256) {
-      reinterpret_cast<float4*>(encS)[i] = reinterpret_cast<const float4*>(src)[i];
-      reinterpret_cast<float4*>(encAS)[i] = reinterpret_cast<const float4*>(srcA)[i];
+      reinterpret_cast<float4*>(encS)[i] = reinterpret_cast<const float4*>(gEnc)[i];
+      reinterpret_cast<float4*>(encAS)[i] = reinterpret_cast<const float4*>(gEncA)[i];
     }
     __syncthreads();
     for (int t = tid; t < nrow; t += 256) {       // eb[t] = enc[t,:] . ba  (score = encA.h + eb)
       float d = 0.f;
-      for (int k = 0; k < H; ++k) d += encS[t * H + k] * a.ba[k];
+      for (int k = 0; k < H; ++k) d += gEnc[(long)t * H + k] * a.ba[k];
       ebS[t] = d;
     }
   }
@@ -518,16 +527,18 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       float m, l = 0.f, my_score;
       float* prow = a.PART + (((long)s * B + b) * a.nsplit + att_sp) * (H + 4);
       if constexpr (NC > 0) {
-        // ---- specialised scan: H = 64 NC, nrow <= 32.  Every LDS read of a pass is issued before its first use.
+        // ---- specialised scan: H = 64 NC, nrow <= 60: rows [0, nres) from LDS, rows [nres, nrow) (nx <= 32 of them) from global memory.
+        // Every read of a pass is issued before its first use.
         constexpr int HH = 64 * NC;
-        float* const pS_ = scr + HH + 32;                // scratch: hS[H] | scores[32] | p[32] | fold
-        if (tid >= nrow && tid < 32) scS[tid] = -INFINITY;
+        const int nx = XS ? nrow - nres : 0;
+        float* const pS_ = scr + HH + 64;                // scratch: hS[H] | scores[64] | p[64] | fold
+        if (tid >= nrow && tid < 64) scS[tid] = -INFINITY;
         __syncthreads();
         TICK(13)
         {
           // pass 1: 16 lanes per row; group g owns rows g and g + 16; lane l covers floats 4l + 64c of the row
           const int grp = tid >> 4, l16 = tid & 15;
-          const int ta = min(grp, nrow - 1), tb2 = min(grp + 16, nrow - 1);
+          const int ta = min(grp, nres - 1), tb2 = min(grp + 16, nres - 1);
           const float* e1 = encAS + ta * HH + 4 * l16;
           const float* e2 = encAS + tb2 * HH + 4 * l16;
           float4 hv[NC], x1[NC], x2[NC];
@@ -546,48 +557,88 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
 #pragma unroll
           for (int o = 8; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
           if (l16 == 0) {
-            if (grp < nrow) scS[grp] = d1 + ebS[grp];
-            if (grp + 16 < nrow) scS[grp + 16] = d2 + ebS[grp + 16];
+            if (grp < nres) scS[grp] = d1 + ebS[grp];
+            if (grp + 16 < nres) scS[grp + 16] = d2 + ebS[grp + 16];
+          }
+          if (nx > 0) {        // streamed rows nres + g, nres + g + 16 (workgroup-uniform branch)
+            const int ua = nres + min(grp, nx - 1), ub = nres + min(grp + 16, nx - 1);
+            const float* g1 = gEncA + (long)ua * HH + 4 * l16;
+            const float* g2 = gEncA + (long)ub * HH + 4 * l16;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              x1[c] = *reinterpret_cast<const float4*>(g1 + 64 * c);
+              x2[c] = *reinterpret_cast<const float4*>(g2 + 64 * c);
+            }
+            d1 = 0.f; d2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              d1 += x1[c].x * hv[c].x + x1[c].y * hv[c].y + x1[c].z * hv[c].z + x1[c].w * hv[c].w;
+              d2 += x2[c].x * hv[c].x + x2[c].y * hv[c].y + x2[c].z * hv[c].z + x2[c].w * hv[c].w;
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
+            if (l16 == 0) {
+              if (grp < nx) scS[nres + grp] = d1 + ebS[nres + grp];
+              if (grp + 16 < nx) scS[nres + grp + 16] = d2 + ebS[nres + grp + 16];
+            }
           }
         }
         TQ(0)
         __syncthreads();
         TQ(1)
         {
-          // chunk max / exp: every thread sweeps the 32 (padded) scores with 8 broadcast reads
-          float4 sv[8];
+          // chunk max / exp / sum: wave 0 holds one (padded) score per lane -- two shuffle reductions instead of 64-entry sweeps in
+          // every thread (32 float4 registers that the multi-layer variants, whose weights fill the AGPR file, do not have)
+          my_score = 0.f;
+          m = 0.f;
+          if (tid < 64) {
+            const float sc = scS[tid];
+            float mx = sc;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) sv[i] = *reinterpret_cast<const float4*>(scS + 4 * i);
-          m = -INFINITY;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) m = fmaxf(fmaxf(m, fmaxf(sv[i].x, sv[i].y)), fmaxf(sv[i].z, sv[i].w));
-          my_score = tid < nrow ? scS[tid] : 0.f;
-          if (tid < 32) pS_[tid] = tid < nrow ? expf(scS[tid] - m) : 0.f;
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            const float pe = tid < nrow ? expf(sc - mx) : 0.f;
+            pS_[tid] = pe;
+            l = wave_sum(pe);
+            m = mx;
+            my_score = tid < nrow ? sc : 0.f;
+          }
         }
         TQ(2)
         __syncthreads();
         TQ(3)
         {
-          // pass 2: context partial.  Thread (cq, rh): columns 4cq..4cq+3, rows rh, rh+RH, ... (16-byte LDS reads), the RH row groups
+          // pass 2: context partial.  Thread (cq, rh): columns 4cq..4cq+3, rows rh, rh+RH, ... (16-byte reads), the RH row groups
           // are folded through LDS and row group 0 publishes with 16-byte write-through stores.
           constexpr int RH = 256 / (16 * NC);            // row groups (2 for H = 512)
-          constexpr int RPT = (32 + RH - 1) / RH;        // rows per thread (max)
+          constexpr int RPT = (32 + RH - 1) / RH;        // rows per thread (max) of each half (resident / streamed)
           const int cq = tid % (16 * NC), rh = tid / (16 * NC);
           float4 ev[RPT];
           float pv[RPT];
 #pragma unroll
           for (int i = 0; i < RPT; ++i) {
             const int t = rh + RH * i;
-            const int tc = min(t, nrow - 1);
+            const int tc = min(t, nres - 1);
             ev[i] = *reinterpret_cast<const float4*>(encS + tc * HH + 4 * cq);
-            pv[i] = pS_[min(t, 31)];                      // rows beyond nrow have p = 0
+            pv[i] = t < nres ? pS_[t] : 0.f;
           }
           float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
           for (int i = 0; i < RPT; ++i) {
             acc4.x += pv[i] * ev[i].x; acc4.y += pv[i] * ev[i].y; acc4.z += pv[i] * ev[i].z; acc4.w += pv[i] * ev[i].w;
           }
-          float4* fold = reinterpret_cast<float4*>(scr + HH + 64);   // [RH-1][16 NC] float4 (the launcher checks the scratch size)
+          if (nx > 0) {
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+              const int t = rh + RH * i;
+              ev[i] = *reinterpret_cast<const float4*>(gEnc + (long)(nres + min(t, nx - 1)) * HH + 4 * cq);
+              pv[i] = t < nx ? pS_[nres + t] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+              acc4.x += pv[i] * ev[i].x; acc4.y += pv[i] * ev[i].y; acc4.z += pv[i] * ev[i].z; acc4.w += pv[i] * ev[i].w;
+            }
+          }
+          float4* fold = reinterpret_cast<float4*>(scr + HH + 128);   // [RH-1][16 NC] float4 (the launcher checks the scratch size)
           if (RH > 1) {
             if (rh > 0) fold[(rh - 1) * (16 * NC) + cq] = acc4;
             __syncthreads();
@@ -601,13 +652,6 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
             u32x4 u;
             u.x = __float_as_uint(acc4.x); u.y = __float_as_uint(acc4.y); u.z = __float_as_uint(acc4.z); u.w = __float_as_uint(acc4.w);
             __builtin_amdgcn_raw_buffer_store_b128(u, r_part, (int)((prow - a.PART + 4 + 4 * cq) * 4), 0, 16);
-          }
-          if (tid == 0) {
-            float4 pp[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) pp[i] = *reinterpret_cast<const float4*>(pS_ + 4 * i);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) l += (pp[i].x + pp[i].y) + (pp[i].z + pp[i].w);
           }
           TQ(4)
         }
@@ -925,7 +969,7 @@ __device__ __forceinline__ void wmac_chunked(f32x4& acc, const float4* w, __amdg
   }
 }
 
-template <int NC, int NL>   // as in decoder_persist_fwd: NC > 0 means H = 64 NC and chunk <= 32 at compile time for the attention phase
+template <int NC, int NL, bool XS>   // as in decoder_persist_fwd
 __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ __attribute__((aligned(16))) float red[4 * 256];
@@ -987,16 +1031,18 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   }
   const int t0 = att_sp * a.chunk, t1 = min(T, t0 + a.chunk);
   const int nrow = has_att ? t1 - t0 : 0;
+  const int cres = NC > 0 ? min(a.chunk, PDEC_RES_ROWS) : a.chunk;      // rows of the slice kept in LDS (as in the forward kernel)
+  const int nres = min(nrow, cres);
   float* encS = lds;
-  float* encAS = lds + a.chunk * H;
-  float* scr = lds + 2 * a.chunk * H;        // dS[H] (d_cv) | cvS[H] | ds[chunk] | wred[8]
+  float* encAS = lds + cres * H;
+  float* scr = lds + 2 * cres * H;           // dS[H] (d_cv) | cvS[H] | ds[chunk] | wred[8]
+  const float* gEnc = a.enc + ((long)att_b * T + t0) * H;
+  const float* gEncA = a.encA + ((long)att_b * T + t0) * H;
   if (has_att) {
-    const float* src = a.enc + ((long)att_b * T + t0) * H;
-    const float* srcA = a.encA + ((long)att_b * T + t0) * H;
-    const int n4 = nrow * H / 4;
+    const int n4 = nres * H / 4;
     for (int i = tid; i < n4; i += 256) {
-      reinterpret_cast<float4*>(encS)[i] = reinterpret_cast<const float4*>(src)[i];
-      reinterpret_cast<float4*>(encAS)[i] = reinterpret_cast<const float4*>(srcA)[i];
+      reinterpret_cast<float4*>(encS)[i] = reinterpret_cast<const float4*>(gEnc)[i];
+      reinterpret_cast<float4*>(encAS)[i] = reinterpret_cast<const float4*>(gEncA)[i];
     }
   }
   __syncthreads();
@@ -1069,14 +1115,15 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
       long long tb0 = 0;
       TB(15)
       if constexpr (NC > 0) {
-        // ---- specialised scan (H = 64 NC, nrow <= 32): everything that does not depend on this step's chain (alpha from the saved raw
-        // scores, cv) is fetched BEFORE the wait; every LDS read of a pass is issued before its first use; 16-byte stores.
+        // ---- specialised scan (H = 64 NC, nrow <= 60; rows >= nres come from global memory): everything that does not depend on this
+        // step's chain (alpha from the saved raw scores, cv) is fetched BEFORE the wait; every read of a pass is issued before its first use
         constexpr int HH = 64 * NC;
+        const int nx = XS ? nrow - nres : 0;
         float* dS = scr;                       // d_cv[b][:]
-        float* dsS = scr + 2 * HH;             // ds[32] (tail 0)
-        float* aS = dsS + 32;                  // alpha[32] (tail 0)
-        float* wred = aS + 32;                 // [8]
-        float4* fold = reinterpret_cast<float4*>(scr + 2 * HH + 96);
+        float* dsS = scr + 2 * HH;             // ds[64] (tail 0)
+        float* aS = dsS + 64;                  // alpha[64] (tail 0)
+        float* wred = aS + 64;                 // [8]
+        float4* fold = reinterpret_cast<float4*>(scr + 2 * HH + 160);
         float* al = a.ALPHA + ((long)s * B + b) * Tp + t0;
         float a_t = 0.f;
         float4 cv4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1096,13 +1143,13 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
         }
         cdp = wave_sum(cdp);
         if (lane == 0) wred[wave] = cdp;
-        if (tid < 32) { aS[tid] = a_t; dsS[tid] = 0.f; }
+        if (tid < 64) { aS[tid] = a_t; dsS[tid] = 0.f; }
         if (tid < nrow) al[tid] = a_t;          // normalised alpha for the deferred d_enc product (off the chain)
         __syncthreads();
         const float cd = wred[0] + wred[1] + wred[2] + wred[3];
         {
           const int grp = tid >> 4, l16 = tid & 15;
-          const int ta = min(grp, nrow - 1), tb2 = min(grp + 16, nrow - 1);
+          const int ta = min(grp, nres - 1), tb2 = min(grp + 16, nres - 1);
           const float* e1 = encS + ta * HH + 4 * l16;
           const float* e2 = encS + tb2 * HH + 4 * l16;
           float4 dv[NC], x1[NC], x2[NC];
@@ -1112,7 +1159,6 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
             x1[c] = *reinterpret_cast<const float4*>(e1 + 64 * c);
             x2[c] = *reinterpret_cast<const float4*>(e2 + 64 * c);
           }
-          const float a1 = aS[ta], a2 = aS[tb2];
           float d1 = 0.f, d2 = 0.f;
 #pragma unroll
           for (int c = 0; c < NC; ++c) {
@@ -1122,15 +1168,45 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
 #pragma unroll
           for (int o = 8; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
           if (l16 == 0) {
-            if (grp < nrow) {
-              const float g1 = a1 * (d1 - cd);
+            if (grp < nres) {
+              const float g1 = aS[grp] * (d1 - cd);
               dsS[grp] = g1;
               a.DS[((long)s * B + b) * Tp + t0 + grp] = g1;
             }
-            if (grp + 16 < nrow) {
-              const float g2 = a2 * (d2 - cd);
+            if (grp + 16 < nres) {
+              const float g2 = aS[grp + 16] * (d2 - cd);
               dsS[grp + 16] = g2;
               a.DS[((long)s * B + b) * Tp + t0 + grp + 16] = g2;
+            }
+          }
+          if (nx > 0) {        // streamed rows (workgroup-uniform branch)
+            const int ua = nres + min(grp, nx - 1), ub = nres + min(grp + 16, nx - 1);
+            const float* g1p = gEnc + (long)ua * HH + 4 * l16;
+            const float* g2p = gEnc + (long)ub * HH + 4 * l16;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              x1[c] = *reinterpret_cast<const float4*>(g1p + 64 * c);
+              x2[c] = *reinterpret_cast<const float4*>(g2p + 64 * c);
+            }
+            d1 = 0.f; d2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              d1 += x1[c].x * dv[c].x + x1[c].y * dv[c].y + x1[c].z * dv[c].z + x1[c].w * dv[c].w;
+              d2 += x2[c].x * dv[c].x + x2[c].y * dv[c].y + x2[c].z * dv[c].z + x2[c].w * dv[c].w;
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
+            if (l16 == 0) {
+              if (grp < nx) {
+                const float g1 = aS[nres + grp] * (d1 - cd);
+                dsS[nres + grp] = g1;
+                a.DS[((long)s * B + b) * Tp + t0 + nres + grp] = g1;
+              }
+              if (grp + 16 < nx) {
+                const float g2 = aS[nres + grp + 16] * (d2 - cd);
+                dsS[nres + grp + 16] = g2;
+                a.DS[((long)s * B + b) * Tp + t0 + nres + grp + 16] = g2;
+              }
             }
           }
         }
@@ -1144,13 +1220,25 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
 #pragma unroll
           for (int i = 0; i < RPT; ++i) {
             const int t = rh + RH * i;
-            ev[i] = *reinterpret_cast<const float4*>(encAS + min(t, nrow - 1) * HH + 4 * cq);
-            gv[i] = dsS[min(t, 31)];             // rows beyond nrow carry 0
+            ev[i] = *reinterpret_cast<const float4*>(encAS + min(t, nres - 1) * HH + 4 * cq);
+            gv[i] = t < nres ? dsS[t] : 0.f;
           }
           float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
           for (int i = 0; i < RPT; ++i) {
             acc4.x += gv[i] * ev[i].x; acc4.y += gv[i] * ev[i].y; acc4.z += gv[i] * ev[i].z; acc4.w += gv[i] * ev[i].w;
+          }
+          if (nx > 0) {
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+              const int t = rh + RH * i;
+              ev[i] = *reinterpret_cast<const float4*>(gEncA + (long)(nres + min(t, nx - 1)) * HH + 4 * cq);
+              gv[i] = t < nx ? dsS[nres + t] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+              acc4.x += gv[i] * ev[i].x; acc4.y += gv[i] * ev[i].y; acc4.z += gv[i] * ev[i].z; acc4.w += gv[i] * ev[i].w;
+            }
           }
           if (RH > 1) {
             if (rh > 0) fold[(rh - 1) * (16 * NC) + cq] = acc4;
@@ -1392,10 +1480,16 @@ struct DecPersistBuffers {
   unsigned* ctr;
 };
 
+static bool pdec_special(int H, int chunk) { return H == 512 && chunk <= PDEC_CHUNK_MAX; }     // the NC = 8 attention phase
+static int pdec_res_rows(int H, int chunk) { return pdec_special(H, chunk) && chunk > PDEC_RES_ROWS ? PDEC_RES_ROWS : chunk; }
 static size_t pdec_lds_floats(int chunk, int H, int nsplit) {
   size_t scratch = (size_t)H + 2 * (size_t)((chunk + 3) & ~3) + 16;
+  if (pdec_special(H, chunk) && scratch < (size_t)H + 128 + 512) scratch = (size_t)H + 128 + 512;
   if (scratch < (size_t)nsplit * (H + 4)) scratch = (size_t)nsplit * (H + 4);
-  return 2 * (size_t)chunk * H + (size_t)((chunk + 3) & ~3) + scratch;
+  return 2 * (size_t)pdec_res_rows(H, chunk) * H + (size_t)((chunk + 3) & ~3) + scratch;
+}
+static size_t pdec_bwd_lds_floats(int chunk, int H) {
+  return 2 * (size_t)pdec_res_rows(H, chunk) * H + 2 * (size_t)H + (size_t)((chunk + 3) & ~3) + 16 + 160 + 512;
 }
 
 bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int* chunk_out) {
@@ -1422,7 +1516,7 @@ bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int
     const int XI = d->E + d->A, Vp = (d->V + 3) / 4 * 4;
     if (Vp > 64 * NB_B1 || d->A > 64 * NB_B2 || 4 * d->H > 64 * NB_B5 || (XI % 16) || ((2 * d->H) % 32)) return false;
     if (nbt * (d->H / 16) + nbt * (XI / 16) + nbt * (d->A / 16) > G || nbt * (2 * d->H / 32) > nbt * (d->A / 16) + (G - nbt * (d->H / 16) - nbt * (XI / 16) - nbt * (d->A / 16))) return false;
-    if ((2 * (size_t)chunk * d->H + 2 * (size_t)d->H + chunk + 20 + 640) * sizeof(float) > 148 * 1024) return false;
+    if (pdec_bwd_lds_floats(chunk, d->H) * sizeof(float) > 148 * 1024) return false;
     if (d->n_layers > 1) {
       // per-layer cell-backward owners, d_pre/d_cvh owners at the end of the grid, the split d_x0 items on the last n6 workgroups
       // (never on a workgroup that also holds the 64 float4 of a below-top cell backward)
@@ -1459,26 +1553,30 @@ struct DecPersistBwdBuffers {
 };
 
 template <int NL>
-static void pdec_launch_bwd(bool special, size_t shm, hipStream_t s, const PDecBwdArgs& a) {
+static void pdec_launch_bwd(bool special, bool xs, size_t shm, hipStream_t s, const PDecBwdArgs& a) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)decoder_persist_bwd<0, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void*)decoder_persist_bwd<8, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)decoder_persist_bwd<0, NL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)decoder_persist_bwd<8, NL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)decoder_persist_bwd<8, NL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_done = true;
   }
-  if (special) hipLaunchKernelGGL((decoder_persist_bwd<8, NL>), dim3(G), dim3(256), shm, s, a);
-  else hipLaunchKernelGGL((decoder_persist_bwd<0, NL>), dim3(G), dim3(256), shm, s, a);
+  if (special && xs) hipLaunchKernelGGL((decoder_persist_bwd<8, NL, true>), dim3(G), dim3(256), shm, s, a);
+  else if (special) hipLaunchKernelGGL((decoder_persist_bwd<8, NL, false>), dim3(G), dim3(256), shm, s, a);
+  else hipLaunchKernelGGL((decoder_persist_bwd<0, NL, false>), dim3(G), dim3(256), shm, s, a);
 }
 template <int NL>
-static void pdec_launch_fwd(bool special, size_t shm, hipStream_t s, const PDecArgs& a) {
+static void pdec_launch_fwd(bool special, bool xs, size_t shm, hipStream_t s, const PDecArgs& a) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)decoder_persist_fwd<0, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024);
-    (void)hipFuncSetAttribute((const void*)decoder_persist_fwd<8, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024);
+    (void)hipFuncSetAttribute((const void*)decoder_persist_fwd<0, NL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024);
+    (void)hipFuncSetAttribute((const void*)decoder_persist_fwd<8, NL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024);
+    (void)hipFuncSetAttribute((const void*)decoder_persist_fwd<8, NL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024);
     attr_done = true;
   }
-  if (special) hipLaunchKernelGGL((decoder_persist_fwd<8, NL>), dim3(G), dim3(256), shm, s, a);
-  else hipLaunchKernelGGL((decoder_persist_fwd<0, NL>), dim3(G), dim3(256), shm, s, a);
+  if (special && xs) hipLaunchKernelGGL((decoder_persist_fwd<8, NL, true>), dim3(G), dim3(256), shm, s, a);
+  else if (special) hipLaunchKernelGGL((decoder_persist_fwd<8, NL, false>), dim3(G), dim3(256), shm, s, a);
+  else hipLaunchKernelGGL((decoder_persist_fwd<0, NL, false>), dim3(G), dim3(256), shm, s, a);
 }
 
 int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, const float* rnn_masks, const DecPersistBwdBuffers& bf,
@@ -1505,14 +1603,14 @@ int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, con
   a.tick_out = prof_tick_buffer(1);
   { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
   ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)NPHASE_SLOTS * NSH * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), s));
-  size_t scratch = 2 * (size_t)a.H + (size_t)((chunk + 3) & ~3) + 16 + 640;   // + ds/alpha/fold of the specialised attention scan
-  const size_t shm = (2 * (size_t)chunk * a.H + scratch) * sizeof(float);
+  const size_t shm = pdec_bwd_lds_floats(chunk, a.H) * sizeof(float);       // slices + dS/cvS/ds + ds/alpha/fold of the specialised scan
   {
     ProfScope prof(PROF_DEC_BWD, s);
-    const bool special = a.H == 512 && chunk <= 32;
-    if (d->n_layers == 1) pdec_launch_bwd<1>(special, shm, s, a);
-    else if (d->n_layers == 2) pdec_launch_bwd<2>(special, shm, s, a);
-    else pdec_launch_bwd<3>(special, shm, s, a);
+    const bool special = pdec_special(a.H, chunk);
+    const bool xs = special && chunk > PDEC_RES_ROWS;
+    if (d->n_layers == 1) pdec_launch_bwd<1>(special, xs, shm, s, a);
+    else if (d->n_layers == 2) pdec_launch_bwd<2>(special, xs, shm, s, a);
+    else pdec_launch_bwd<3>(special, xs, shm, s, a);
   }
   ASTK_LAUNCH_CHECK();
   return 0;
@@ -1549,10 +1647,11 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
   const size_t shm = pdec_lds_floats(chunk, a.H, nsplit) * sizeof(float);
   {
     ProfScope prof(PROF_DEC_FWD, s);
-    const bool special = a.H == 512 && chunk <= 32 && (size_t)nsplit * (a.H + 4) >= (size_t)a.H + 64 + 512;
-    if (d->n_layers == 1) pdec_launch_fwd<1>(special, shm, s, a);
-    else if (d->n_layers == 2) pdec_launch_fwd<2>(special, shm, s, a);
-    else pdec_launch_fwd<3>(special, shm, s, a);
+    const bool special = pdec_special(a.H, chunk);
+    const bool xs = special && chunk > PDEC_RES_ROWS;
+    if (d->n_layers == 1) pdec_launch_fwd<1>(special, xs, shm, s, a);
+    else if (d->n_layers == 2) pdec_launch_fwd<2>(special, xs, shm, s, a);
+    else pdec_launch_fwd<3>(special, xs, shm, s, a);
   }
   ASTK_LAUNCH_CHECK();
   // Q[s][b][:] = Wa h_top + ba for all steps (needed by the backward's deferred d_enc product)

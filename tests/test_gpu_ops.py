@@ -347,7 +347,11 @@ def _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=0):
                                                     # 2 and 3 layers fused into the persistent decoder-loop kernels (generic attention phase, small
                                                     # and ragged batch tiles; then the shipped es_en_20h width with the H = 512 specialisation)
                                                     (5, 9, 23, 64, 16, 32, 57, 2, False), (19, 8, 37, 128, 32, 64, 130, 3, True),
-                                                    (32, 7, 50, 512, 128, 512, 1098, 3, True), (30, 6, 200, 512, 128, 512, 1004, 2, False)])
+                                                    (32, 7, 50, 512, 128, 512, 1098, 3, True), (30, 6, 200, 512, 128, 512, 1004, 2, False),
+                                                    # long utterances: T'' = 300 / 420 (1200 / 1680 frames) at batch 32 -- slices of 38 / 53 rows, of which
+                                                    # 28 stay in LDS and the rest is streamed every step
+                                                    (32, 5, 300, 512, 128, 512, 1098, 1, False), (32, 4, 420, 512, 128, 512, 1098, 3, True),
+                                                    (32, 4, 233, 512, 128, 512, 300, 1, True)])
 def test_decoder_fwd_bwd(lib, B, L, T, H, E, A, V, nl, masks):
     from oracle.ast_ref_torch import decoder_torch
     s = _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=B + L)
