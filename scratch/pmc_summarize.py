@@ -1,0 +1,70 @@
+"""Summarises the rocprofv3 runs of scratch/profile_r2.sh into small JSON files (run on the GPU box, results under gpurun_out/prof_r2/).
+
+For every kernel family: dispatches, mean duration (kernel trace), FETCH_SIZE / WRITE_SIZE (separate --pmc passes; rocprofv3 reports
+them in KiB-like units of 1 KB per count), the HBM-byte estimate of MI355X_MICROARCH.md section HBM (FETCH_SIZE x 2 for 16-byte-per-lane
+streaming reads on gfx950, + WRITE_SIZE), and the SQ counters of the third pass."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+root = sys.argv[1]
+steps = int(sys.argv[2])          # train steps profiled in each pass (all of them, warm-ups included)
+
+
+def short(name):
+    for key in ("gemm_f32_kernel", "decoder_persist_fwd", "decoder_persist_bwd", "lstm_persist_fwd_g", "lstm_persist_bwd_rs", "k_zero_split_tiles"):
+        if key in name:
+            return key
+    return None
+
+
+def counters(d):
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(root, d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if k:
+                out[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+def durations(d):
+    out = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(root, d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if k:
+                out[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    return out
+
+
+fetch, write, sq, dur = counters("fetch"), counters("write"), counters("sq"), durations("fetch")
+res = {"command": "rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 "
+                  "(separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* + GRBM_GUI_ACTIVE)", "train_steps_per_pass": steps,
+       "units": "FETCH_SIZE / WRITE_SIZE in KB per dispatch (mean); hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md (gfx950 halves FETCH_SIZE for wide reads)",
+       "kernels": {}}
+for k in sorted(set(fetch) | set(write) | set(sq)):
+    e = {"dispatches_per_step": round(len(fetch[k].get("FETCH_SIZE", [])) / steps, 2)}
+    if dur.get(k):
+        e["mean_us"] = round(sum(dur[k]) / len(dur[k]), 2)
+        e["us_per_step"] = round(sum(dur[k]) / steps, 1)
+    f = fetch[k].get("FETCH_SIZE", [])
+    w = write[k].get("WRITE_SIZE", [])
+    if f:
+        e["FETCH_SIZE_KB"] = round(sum(f) / len(f), 1)
+    if w:
+        e["WRITE_SIZE_KB"] = round(sum(w) / len(w), 1)
+    if f and w:
+        e["hbm_bytes_per_dispatch"] = round((2 * sum(f) / len(f) + sum(w) / len(w)) * 1024)
+        e["hbm_bytes_per_step"] = round((2 * sum(f) + sum(w)) * 1024 / steps)
+    for c, v in sq[k].items():
+        e[c] = round(sum(v) / len(v), 1)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in sq[k] and "GRBM_GUI_ACTIVE" in sq[k]:
+        # busy cycles summed over the 1024 SIMDs / (kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs)
+        e["mfma_pipe_busy_frac"] = round(sum(sq[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024.0 / (sum(sq[k]["GRBM_GUI_ACTIVE"]) / 8.0), 4)
+    res["kernels"][k] = e
+json.dump(res, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1)
+print(json.dumps(res, indent=1))
