@@ -65,6 +65,8 @@ _VP, _I, _L, _SZ, _F, _U64 = C.c_void_p, C.c_int, C.c_long, C.c_size_t, C.c_floa
 SIGNATURES = {
     "astk_version": (C.c_int, []),
     "astk_last_error": (C.c_char_p, []),
+    "astk_set_low_precision_gemms": (C.c_int, [_I]),
+    "astk_get_low_precision_gemms": (C.c_int, []),
     "astk_gemm_f32": (C.c_int, [_I, _I, _I, _I, _VP, _L, _VP, _L, _VP, _L, _VP, _I, _I, _I, _L, _L, _L, _VP]),
     "astk_conv_bn_relu_out_dims": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "astk_conv_bn_relu_workspace_bytes": (_SZ, [C.POINTER(CnnDesc)]),

@@ -127,6 +127,7 @@ struct GemmArgs {
   int ksplit;
   int batch;
   long sA, sB, sC;
+  int lowp;          // 1: this product may run with fp16 operands when astk_set_low_precision_gemms(1) is in force (K6 / K9 and their backward)
   // filled by gemm_launch (work decomposition)
   unsigned spanA, spanB;  // bytes from A.p / B.p to the end of one batch slice (buffer-load range)
   int kt;            // k-iterations per tile = ceil(K / BK)
@@ -141,7 +142,9 @@ static inline GemmArgs gemm_args(int M, int N, int K, MatView A, MatView B, floa
   g.mode = mode; g.ksplit = ksplit; g.batch = 1;
   return g;
 }
+static inline GemmArgs lowp(GemmArgs g) { g.lowp = 1; return g; }
 int gemm_launch(int layout, const GemmArgs& g, hipStream_t s);
+int low_precision_gemms();      // the mode set by astk_set_low_precision_gemms
 // Scoped cap on the co-resident GEMM workgroups per CU for launches made by this thread (0 = none): work that is meant to run
 // BESIDE a persistent recurrence kernel must leave registers free on every CU, or that kernel cannot become resident until the
 // stream-K workgroups (which live for the whole launch) have finished.

@@ -400,7 +400,7 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
       const long prow = (long)(P.Tn[i - 1] + 2 * P.padA[i - 1]) * Ci;
       GemmArgs g = gemm_args(rows, C, KT * Ci, mat2(P.HP[i - 1], P.Tn[i], prow, (long)d->st[i] * Ci), mat(P.Wr[i], (long)KT * Ci),
                              P.Y[i], C);
-      ASTK_TRY(gemm_launch(GEMM_NT, g, s));
+      ASTK_TRY(gemm_launch(GEMM_NT, lowp(g), s));            // K6
     }
     // ---- batch statistics -> scale/shift
     if (train) {
@@ -487,7 +487,7 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
         MatView A = mat2(P.DY[i] + (long)P.dF[i] * C, P.Tn[i], dyrow, C);
         MatView Bm = mat2(P.HP[i - 1], P.Tn[i], hprow, (long)st * Ci);
         const long tiles = (long)cdiv(C, 128) * cdiv(KT * Ci, 128);
-        ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(C, KT * Ci, rows, A, Bm, P.dWr[i], (long)KT * Ci, nullptr, GEMM_ATOMIC, ksplit_for(tiles, rows)), s));
+        ASTK_TRY(gemm_launch(GEMM_TN, lowp(gemm_args(C, KT * Ci, rows, A, Bm, P.dWr[i], (long)KT * Ci, nullptr, GEMM_ATOMIC, ksplit_for(tiles, rows))), s));
       }
       hipLaunchKernelGGL(k_unpack_dw, dim3(gridn((size_t)C * Ci * KT)), dim3(256), 0, s, P.dWr[i], Gr[i].dW, C, Ci, KT);
       ASTK_LAUNCH_CHECK();
@@ -509,7 +509,7 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
         g.c_tn = nj;
         g.c_sg = (long)P.Tn[i - 1] * Ci;
         g.c_st = (long)st * Ci;
-        ASTK_TRY(gemm_launch(GEMM_NT, g, s));
+        ASTK_TRY(gemm_launch(GEMM_NT, lowp(g), s));
       }
     }
   }

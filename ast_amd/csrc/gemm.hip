@@ -80,7 +80,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // f32-input MFMA rate at an error of the order of f32 rounding itself (a f32 fma chain rounds every product to 2^-24; here a product
 // is exact to 2^-23 and a K = 16 block is summed inside the MFMA).  The split runs in the stager (global f32 -> registers -> three
 // bf16 planes in LDS), so callers, layouts, addressing, stream-K and the epilogue are those of the f32 kernel.
-enum GemmPrec { PREC_F32 = 0, PREC_BF16X3 = 1 };
+// PREC_F16 (BASELINE configs[4], "fp16 MFMA GEMMs"): operands rounded to ONE fp16 term (round-to-nearest-even), one
+// v_mfma_f32_32x32x16_f16 per tile and 16 k, f32 accumulation.  Reduced precision (11 significant bits): only launches their caller marks
+// low-precision-eligible take it, and only when astk_set_low_precision_gemms(1) is in force.
+enum GemmPrec { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_F16 = 2 };
+constexpr int prec_planes(int prec) { return prec == PREC_BF16X3 ? 3 : 1; }
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
@@ -103,7 +109,7 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
 constexpr int sp_hs(int TL) { return TL * 16 + 16; }          // RK: k-half stride
 constexpr int sp_rs(int TL) { return TL * 2 + 64; }           // KR: k-row stride
 constexpr int sp_plane(int TL, bool RK) { return RK ? 2 * sp_hs(TL) : BK * sp_rs(TL); }
-constexpr int sp_stage(int TL, bool RK) { return 3 * sp_plane(TL, RK); }
+constexpr int sp_stage(int TL, bool RK, int prec = PREC_BF16X3) { return prec_planes(prec) * sp_plane(TL, RK); }
 
 // RING: register slots of staged tiles.  The f32 kernel keeps one tile in flight (an iteration is 2600 cycles and three workgroups per
 // CU cover each other's waits); a bf16x3 iteration is ~800 cycles on one workgroup per CU, so its staging waves keep RING = 4 tiles
@@ -215,17 +221,22 @@ struct Stager {
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      unsigned h0, m0, l0, h1, m1, l1;
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 1)      // timing experiment: no split arithmetic
-      h0 = __float_as_uint(r[p].x); m0 = __float_as_uint(r[p].y); l0 = h0; h1 = __float_as_uint(r[p].z); m1 = __float_as_uint(r[p].w); l1 = h1;
-#else
-      split2(r[p].x, r[p].y, h0, m0, l0);
-      split2(r[p].z, r[p].w, h1, m1, l1);
-#endif
       const int off = RK ? (a >> 1) * sp_hs(TL) + (NP * b + p) * 16 + (a & 1) * 8 : (b + RP * p) * sp_rs(TL) + a * 8;
-      *reinterpret_cast<uint2*>(S + off) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(S + PL + off) = make_uint2(m0, m1);
-      *reinterpret_cast<uint2*>(S + 2 * PL + off) = make_uint2(l0, l1);
+      if constexpr (PREC == PREC_F16) {
+        const f16x2 lo2 = {(_Float16)r[p].x, (_Float16)r[p].y}, hi2 = {(_Float16)r[p].z, (_Float16)r[p].w};
+        *reinterpret_cast<uint2*>(S + off) = make_uint2(__builtin_bit_cast(unsigned, lo2), __builtin_bit_cast(unsigned, hi2));
+      } else {
+        unsigned h0, m0, l0, h1, m1, l1;
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 1)      // timing experiment: no split arithmetic
+        h0 = __float_as_uint(r[p].x); m0 = __float_as_uint(r[p].y); l0 = h0; h1 = __float_as_uint(r[p].z); m1 = __float_as_uint(r[p].w); l1 = h1;
+#else
+        split2(r[p].x, r[p].y, h0, m0, l0);
+        split2(r[p].z, r[p].w, h1, m1, l1);
+#endif
+        *reinterpret_cast<uint2*>(S + off) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(S + PL + off) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(S + 2 * PL + off) = make_uint2(l0, l1);
+      }
     }
   }
   // Zeroes what this thread's store() wrote for k >= kend (ktile: first k of the tile in S).
@@ -258,7 +269,7 @@ struct Stager {
 // f32 -> 3 x bf16 split, LDS writes).  One wave of each kind sits on every SIMD, so the split's vector-ALU work issues in the gaps of
 // the other wave's MFMAs; with every wave doing both, the co-resident workgroups ran their VALU and MFMA phases in lockstep and the
 // matrix pipe idled more than half of the time (163 instead of 118 TFLOP/s at 4096^3, against > 300 for an MFMA-bound loop).
-constexpr int gemm_threads(int PREC) { return PREC == PREC_BF16X3 ? 512 : 256; }
+constexpr int gemm_threads(int PREC) { return PREC != PREC_F32 ? 512 : 256; }
 // TL: tile edge along N (and along M unless TLM says otherwise: the bf16x3 path also runs 256 x 128 tiles -- per k-iteration the split
 // costs vector-ALU issue slots in proportion to TLM + TL while the MFMAs grow with TLM x TL, and only from 256 x 128 on do the MFMAs
 // (1536 cycles per wave and iteration) outlast the split's issue time on the same SIMD).
@@ -270,10 +281,11 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
   constexpr int NA = TL / 64;      // 32x32 accumulator tiles per wave and dimension (the wave's sub-tile is TLM/2 x TL/2)
   constexpr int NAM = TLM / 64;
   constexpr int WT = TL / 2, WTM = TLM / 2;
-  constexpr bool SPLIT = PREC == PREC_BF16X3;
+  constexpr bool SPLIT = PREC != PREC_F32;     // operands staged as 16-bit planes (three bf16 terms, or one fp16 term)
+  constexpr int NPL = prec_planes(PREC);
   static_assert(SPLIT || TLM == TL, "the f32 path runs square tiles");
-  constexpr int A_FLOATS = SPLIT ? sp_stage(TLM, A_RK) / 4 : (A_RK ? TL * LD_RK : BK * LD_KR);
-  constexpr int B_FLOATS = SPLIT ? sp_stage(TL, B_RK) / 4 : (B_RK ? TL * LD_RK : BK * LD_KR);
+  constexpr int A_FLOATS = SPLIT ? sp_stage(TLM, A_RK, PREC) / 4 : (A_RK ? TL * LD_RK : BK * LD_KR);
+  constexpr int B_FLOATS = SPLIT ? sp_stage(TL, B_RK, PREC) / 4 : (B_RK ? TL * LD_RK : BK * LD_KR);
   constexpr int NST = SPLIT ? 3 : 2;      // LDS stages (bf16x3: the multiplying waves fetch tile kt+1's fragments while they multiply tile kt)
   __shared__ __attribute__((aligned(16))) float As[NST][A_FLOATS];
   __shared__ __attribute__((aligned(16))) float Bs[NST][B_FLOATS];
@@ -460,12 +472,12 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
           struct { s16x4 a, b; } pr = {v0, v1};
           return __builtin_bit_cast(bf16x8, pr);
         };
-        struct Frags { bf16x8 a[NAM][3], b[NA][3]; };
+        struct Frags { bf16x8 a[NAM][NPL], b[NA][NPL]; };
         auto fetch = [&](Frags& f, int st) {
           const char* abase = stA(st);
           const char* bbase = stB(st);
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
+          for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
             for (int i = 0; i < NAM; ++i) f.a[i][pl] = frag(abase, A_RK, std::integral_constant<int, TLM>{}, wm * WTM + 32 * i, pl);
 #pragma unroll
@@ -473,6 +485,14 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
           }
         };
         auto mult = [&](const Frags& f) {
+          if constexpr (PREC == PREC_F16) {
+#pragma unroll
+            for (int i = 0; i < NAM; ++i)
+#pragma unroll
+              for (int i2 = 0; i2 < NA; ++i2)
+                acc[i][i2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[i][0]), __builtin_bit_cast(f16x8, f.b[i2][0]),
+                                                                    acc[i][i2], 0, 0, 0);
+          } else {
           // smallest terms first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
           constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -486,6 +506,7 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
 #pragma unroll
               for (int i2 = 0; i2 < NA; ++i2)
                 acc[i][i2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA[t]], f.b[i2][PB[t]], acc[i][i2], 0, 0, 0);
+          }
         };
         Frags f0, f1;
         fetch(f0, 0);
@@ -671,6 +692,8 @@ static int gemm_prepare(int layout, const GemmArgs& g, GemmArgs& a, bool& twolvl
   return 0;
 }
 
+static int g_lowp_mode = 0;
+int low_precision_gemms() { return g_lowp_mode; }
 static thread_local int tl_wg_cap = 0;
 GemmWgCap::GemmWgCap(int per_cu) : prev(tl_wg_cap) { tl_wg_cap = per_cu; }
 GemmWgCap::~GemmWgCap() { tl_wg_cap = prev; }
@@ -689,7 +712,13 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   static const int force_tl = getenv("ASTK_GEMM_TILE") ? atoi(getenv("ASTK_GEMM_TILE")) : 0;
   // operand precision: bf16x3 (three-term bf16 split, f32-level accuracy, up to 2.7x the f32 MFMA rate) unless ASTK_GEMM_PREC=f32 asks
   // for the exact-f32 MFMA chain
-  static const int prec = (getenv("ASTK_GEMM_PREC") && !strcmp(getenv("ASTK_GEMM_PREC"), "f32")) ? PREC_F32 : PREC_BF16X3;
+  static const int prec_default = (getenv("ASTK_GEMM_PREC") && !strcmp(getenv("ASTK_GEMM_PREC"), "f32")) ? PREC_F32 : PREC_BF16X3;
+  int prec = prec_default;
+  if (g_lowp_mode != 0 && n > 0) {        // fp16 operands only if every product of the launch is marked eligible by its caller
+    bool all = true;
+    for (int i = 0; i < n; ++i) all = all && list[i].lowp != 0;
+    if (all) prec = PREC_F16;
+  }
   int TL = 128, TLM = 128;
   for (int pass = 0; pass < 3; ++pass) {
     memset(&grp, 0, sizeof(grp));
@@ -720,6 +749,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     const bool small = grp.iters_total < 256L * wgs_per_cu(128) * 10 * (32 / BK) && (tiles < 192 || max_kt <= 12 * (16 / BK > 0 ? 16 / BK : 1));
     int want = force_tl == 64 || force_tl == 128 || force_tl == 256 ? force_tl : (small ? 64 : 128);   // (256 x 128 tiles: ASTK_GEMM_TILE=256 only -- measured slower)
     if (want == 256 && prec != PREC_BF16X3) want = 128;
+    if (want == 64 && prec == PREC_F16) want = 128;        // (the fp16 variant is instantiated for 128-tiles only)
     if (want == 128) break;
     TLM = want;
     TL = want == 256 ? 128 : want;
@@ -785,6 +815,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   }
   if (prec == PREC_F32) {
     if (TL == 64) { ASTK_GEMM_LAUNCH(64, PREC_F32, 64) } else { ASTK_GEMM_LAUNCH(128, PREC_F32, 128) }
+  } else if (prec == PREC_F16) { ASTK_GEMM_LAUNCH(128, PREC_F16, 128)
   } else if (TLM == 256) { ASTK_GEMM_LAUNCH(128, PREC_BF16X3, 256)
   } else if (TL == 64) { ASTK_GEMM_LAUNCH(64, PREC_BF16X3, 64)
   } else { ASTK_GEMM_LAUNCH(128, PREC_BF16X3, 128) }
@@ -794,5 +825,16 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
 }
 
 int gemm_launch(int layout, const GemmArgs& g, hipStream_t s) { return gemm_launch_group(layout, &g, 1, s); }
+
+}  // namespace astk
+
+extern "C" int astk_set_low_precision_gemms(int mode) {
+  if (mode != 0 && mode != 1) { astk::set_error("set_low_precision_gemms: mode must be 0 or 1"); return -1; }
+  astk::g_lowp_mode = mode;
+  return 0;
+}
+extern "C" int astk_get_low_precision_gemms(void) { return astk::g_lowp_mode; }
+
+namespace astk {
 
 }  // namespace astk

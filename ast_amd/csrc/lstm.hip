@@ -13,6 +13,7 @@
 // HBM layout (per direction d, layer l, all f32, step-major):
 //   ZG (T,B,4h) gates -> dz | HR (T,B,h) raw h | CC (T,B,h) cell | HD (T,B,h) dropped output (only with masks)
 #include "common.h"
+#include <algorithm>
 
 namespace astk {
 
@@ -22,9 +23,11 @@ struct PersistCellHost {
   const float* WuT;
   float *PR, *PD;
   const float* PD_up;
+  int up_external;
   int reverse_pos, layer;
 };
 bool lstm_persist_applicable(int T, int B, int h, int nl, int nd);
+int lstm_persist_layers_per_launch(int B, int h, int nl, int nd);
 size_t lstm_persist_pr_floats(int B, int h);
 size_t lstm_persist_pd_floats(int T, int B, int h);
 int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters, hipStream_t s);
@@ -153,7 +156,7 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
       const astk_lstm_params& p0 = prm[dd * P.nl];
       ASTK_CHECK(p0.Wu && p0.b && p0.Wl, "lstm_stack_fwd: null parameter (dir %d layer 0)", dd);
       MatView A = dd == 0 ? mat(x, P.in) : mat_idx(x, P.in, rows_perm);
-      ASTK_TRY(gemm_launch(GEMM_NT, gemm_args(T * B, 4 * h, P.in, A, mat(p0.Wu, P.in), P.ZG[dd][0], 4 * h, p0.b), s));
+      ASTK_TRY(gemm_launch(GEMM_NT, lowp(gemm_args(T * B, 4 * h, P.in, A, mat(p0.Wu, P.in), P.ZG[dd][0], 4 * h, p0.b)), s));     // K9
       for (int l = 0; l < P.nl; ++l) {
         const astk_lstm_params& p = prm[dd * P.nl + l];
         ASTK_CHECK(p.Wu && p.b && p.Wl, "lstm_stack_fwd: null parameter (dir %d layer %d)", dd, l);
@@ -174,7 +177,18 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
         c.layer = l;
       }
     }
-    ASTK_TRY(lstm_persist_fwd_launch(cells, P.nd * P.nl, P.nl, T, B, h, H, P.counters, s));
+    {
+      // one launch per group of layers (normally a single group: the whole stack); a later group finds the outputs of the layer
+      // below complete (its sentinel polls succeed at once)
+      const int lpl = lstm_persist_layers_per_launch(B, h, P.nl, P.nd);
+      for (int l0 = 0; l0 < P.nl; l0 += lpl) {
+        const int ngl = std::min(lpl, P.nl - l0);
+        PersistCellHost grp[16];
+        for (int dd = 0; dd < P.nd; ++dd)
+          for (int l = 0; l < ngl; ++l) grp[dd * ngl + l] = cells[dd * P.nl + l0 + l];
+        ASTK_TRY(lstm_persist_fwd_launch(grp, P.nd * ngl, ngl, T, B, h, H, P.counters, s));
+      }
+    }
     CopySegs cp;   // final states of every cell: one launch
     cp.n = 0;
     for (int dd = 0; dd < P.nd; ++dd)
@@ -291,7 +305,24 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
         c.layer = l;
       }
     ASTK_TRY(stream_order(s, sr));     // the recurrence kernel may live on its own (CU-masked) stream, see astk.h
-    ASTK_TRY(lstm_persist_bwd_launch(cells, P.nd * P.nl, P.nl, T, B, h, H, P.counters, sr));
+    {
+      // groups of layers, top group first; the top layer of a lower group reads the partial dx tiles the previous launch left
+      const int lpl = lstm_persist_layers_per_launch(B, h, P.nl, P.nd);
+      int l1 = P.nl;
+      while (l1 > 0) {
+        // same grouping as the forward pass (groups start at multiples of lpl)
+        const int l0 = ((l1 - 1) / lpl) * lpl;
+        const int ngl = l1 - l0;
+        PersistCellHost grp[16];
+        for (int dd = 0; dd < P.nd; ++dd)
+          for (int l = 0; l < ngl; ++l) {
+            grp[dd * ngl + l] = cells[dd * P.nl + l0 + l];
+            if (l == ngl - 1 && l1 < P.nl) grp[dd * ngl + l].up_external = 1;
+          }
+        ASTK_TRY(lstm_persist_bwd_launch(grp, P.nd * ngl, ngl, T, B, h, H, P.counters, sr));
+        l1 = l0;
+      }
+    }
     ASTK_TRY(stream_order(sr, s));
   }
   GemmArgs wg[GEMM_GROUP_MAX];   // weight-gradient products, issued as grouped launches
@@ -357,8 +388,9 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
             dzu = P.GATH;
           }
         } else Xv = mat(masks ? P.HD[dd][l - 1] : P.HR[dd][l - 1], h);
-        if (l == 0 && dd == 1) {   // GATH is a single scratch buffer: issue this product right away
-          ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(4 * h, in, rows, mat(dzu, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, 1), s));
+        if (l == 0 && (dd == 1 || low_precision_gemms())) {   // GATH is a single scratch buffer: issue this product right away
+          // (K9's weight gradient; in low-precision mode also direction 0's, which otherwise rides in the grouped launch)
+          ASTK_TRY(gemm_launch(GEMM_TN, lowp(gemm_args(4 * h, in, rows, mat(dzu, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, 1)), s));
         } else {
           if (nwg == GEMM_GROUP_MAX) { ASTK_TRY(gemm_launch_group(GEMM_TN, wg, nwg, s)); nwg = 0; }
           wg[nwg++] = gemm_args(4 * h, in, rows, mat(dzu, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, 1);
@@ -371,7 +403,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
       } else if (dx) {
         // dx (T,B,in) in frame order: direction 0 stores, direction 1 accumulates through the inverse permutation
         MatView A = dd == 0 ? mat(dz, 4 * h) : mat_idx(dz, 4 * h, rows_inv);
-        ASTK_TRY(gemm_launch(GEMM_NN, gemm_args(rows, in, 4 * h, A, mat(p.Wu, in), dx, in, nullptr, dd == 0 ? GEMM_STORE : GEMM_ACCUM), s));
+        ASTK_TRY(gemm_launch(GEMM_NN, lowp(gemm_args(rows, in, 4 * h, A, mat(p.Wu, in), dx, in, nullptr, dd == 0 ? GEMM_STORE : GEMM_ACCUM)), s));
       }
     }
   }

@@ -64,6 +64,7 @@ struct PCellB {
   float* PR;            // ring [PR_RING][nbt][nslice consumer][nslice producer][16 col][16 row]: partial dh_rec of this cell
   float* PD;            // [T][nbt][nslice consumer][nslice producer][16][16]: partial dx handed to the layer below (null: layer 0)
   const float* PD_up;   // PD of the layer above (null: top layer)
+  int up_external;      // PD_up was completed by an EARLIER launch (layer groups): read it without waiting on a counter of this launch
   int reverse_pos;
   int layer;
 };
@@ -426,9 +427,11 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
     }
     float v1 = 0.f;
     if (has_up) {                            // partials handed down by the layer above (it runs ahead)
-      if (tid == 0) s_ok1 = wait_ge(upB, (unsigned)(NS * (stepno + 1)), a.ab) ? 1 : 0;
-      __syncthreads();
-      if (!s_ok1) break;
+      if (!c.up_external) {
+        if (tid == 0) s_ok1 = wait_ge(upB, (unsigned)(NS * (stepno + 1)), a.ab) ? 1 : 0;
+        __syncthreads();
+        if (!s_ok1) break;
+      }
       const int base = (int)((((long)t * nbt + bt) * NS + j) * cons_stride) + tid * 4;
       float pv[NS];
 #pragma unroll
@@ -529,14 +532,28 @@ struct PersistCellHost {
   const float* WuT;               // backward: this cell's transposed upward weight (layers >= 1)
   float *PR, *PD;                 // backward, reduce-scatter path: partial-sum buffers of this cell
   const float* PD_up;
+  int up_external;
   int reverse_pos, layer;
 };
+
+// Layers per launch.  One workgroup per CU must hold a launch's whole grid; a stack with more (direction, layer) cells than fit is
+// run as consecutive launches over groups of layers (all directions of `lpl` layers each): the wavefront overlap between the
+// groups is lost, everything else stays (BASELINE configs[4]: 6 layers x 2 directions x 32 unit slices x 2 batch tiles = 768
+// workgroups -> 3 launches of 2 layers; batch 64 at the shipped width: 2 launches).  0 = not applicable.
+int lstm_persist_layers_per_launch(int B, int h, int nl, int nd) {
+  const long per_layer = (long)(h / 16) * ((B + 15) / 16) * nd;
+  const long cus = device_cu_count();
+  if (per_layer < 1 || per_layer > cus) return 0;
+  long lpl = cus / per_layer;
+  if (lpl > nl) lpl = nl;
+  while (lpl * nd > 16) --lpl;
+  return (int)lpl;
+}
 
 bool lstm_persist_applicable(int T, int B, int h, int nl, int nd) {
   if (!(h == 64 || h == 128 || h == 256 || h == 512)) return false;
   if (B < 1 || T < 1) return false;
-  const long wgs = (long)(h / 16) * ((B + 15) / 16) * nl * nd;
-  if (wgs > device_cu_count() || nl * nd > 16) return false;        // one workgroup per CU must hold the whole grid
+  if (lstm_persist_layers_per_launch(B, h, nl, nd) < 1) return false;
   // hand-off buffers are addressed with 32-bit byte offsets
   if ((long)T * B * h * 16 >= (1L << 31) || (long)T * ((B + 15) / 16) * (h / 16) * (h / 16) * 1024 >= (1L << 31)) return false;
   const char* e = getenv("ASTK_LSTM_PERSIST");
@@ -593,7 +610,7 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
     PCellB& d = a.c[i];
     d.WlT = c.WlT; d.gates_dz = c.gates; d.C = c.C; d.mask = c.mask; d.d_enc = c.d_enc;
     d.d_hT = c.d_hT; d.d_cT = c.d_cT; d.reverse_pos = c.reverse_pos; d.layer = c.layer;
-    d.WuT = c.WuT; d.PR = c.PR; d.PD = c.PD; d.PD_up = c.PD_up;
+    d.WuT = c.WuT; d.PR = c.PR; d.PD = c.PD; d.PD_up = c.PD_up; d.up_external = c.up_external;
   }
   a.ncells = ncells; a.nl = nl; a.T = T; a.B = B; a.h = h; a.H = H;
   a.done = counters;

@@ -71,6 +71,14 @@ class NN:
         if adist.is_distributed():
             self.data_loader.rank, self.data_loader.world = adist.rank(), adist.world_size()
         self.get_model()
+        # extension key (BASELINE configs[4], "fp16 MFMA GEMMs"): extras.gemm_operands = "fp16" runs the batched products of the CNN
+        # layers >= 1 and of the encoder's input projection with fp16 operands / f32 accumulation; default "f32" (f32-accurate products)
+        ops = self.cfg.train.get("extras", {}).get("gemm_operands", "f32")
+        if ops not in ("f32", "fp16"):
+            raise ValueError("extras.gemm_operands must be 'f32' or 'fp16'")
+        from . import _lib
+        if torch.cuda.is_available():
+            _lib.check(_lib.load().astk_set_low_precision_gemms(1 if ops == "fp16" else 0))
         self.init_optimizer(self.cfg.train["optimizer"])
         if self.cfg.train.get("save_optimizer", False) and self.loaded_from and self.model.arena is not None:
             # extension key: checkpoints also carry the Adam moments, so a resumed run continues instead of re-warming them

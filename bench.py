@@ -88,9 +88,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)        # >= 50 timed steps after >= 10 warm-ups
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--model", default="cfg1", choices=["cfg1", "es_en_20h"],
+    ap.add_argument("--model", default="cfg1", choices=["cfg1", "es_en_20h", "cfg5"],
                     help="cfg1 = BASELINE configs[1] (1-layer LSTM-512 decoder, the metric's workload); es_en_20h = the shipped "
-                         "experiments/es_en_20h model (3 decoder layers) on the same synthetic batch")
+                         "experiments/es_en_20h model (3 decoder layers) on the same synthetic batch; cfg5 = the shape of BASELINE "
+                         "configs[4] (6-layer encoder, hidden 1024 = 512 per direction, V = 8004): use with --gemm-operands fp16")
+    ap.add_argument("--gemm-operands", default="f32", choices=["f32", "fp16"],
+                    help="fp16: operands of the CNN / encoder-input GEMMs rounded to fp16, f32 accumulation (configs[4]); f32 (default): "
+                         "f32-accurate products")
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--frames", type=int, default=800)
     ap.add_argument("--feat", type=int, default=80)
@@ -122,6 +126,10 @@ def main():
     cfg = copy.deepcopy(MODEL_CFG)
     if args.model == "es_en_20h":
         cfg["rnn_config"]["dec_layers"] = 3          # /root/reference/experiments/es_en_20h/model_cfg.json:12
+    if args.model == "cfg5":                         # BASELINE configs[4]: "BiLSTM-1024" read as the concatenated width (512 per direction)
+        cfg["rnn_config"].update(enc_layers=6, hidden_units=1024, attn_units=1024, dec_vocab_size=8004)
+        V = 8004
+    _lib.check(lib.astk_set_low_precision_gemms(1 if args.gemm_operands == "fp16" else 0))
     n_dec = cfg["rnn_config"]["dec_layers"]
     model = SpeechEncoderDecoder(local, cfg).materialize(D, seed=0)       # identical replicas
     opt = O.Adam(alpha=TRAIN["lr"], beta1=0.9, beta2=0.999, eps=1e-8, amsgrad=True).setup(model)
@@ -253,12 +261,14 @@ def main():
         if res[17] > 0:
             extra["decoder_persistent_ms_per_step"] = round((res[16] + res[18]) / args.profile_steps, 3)
 
-    dec_name = f"{n_dec}-layer LSTM-512 dec"
+    dec_name = f"{n_dec}-layer LSTM-{cfg['rnn_config']['hidden_units']} dec"
     out = {"metric": "speech frames/s (train step)", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": (f"BASELINE configs[1]: " if args.model == "cfg1" else "shipped es_en_20h model (configs[0]'s model at configs[1]'s batch): ") +
-                                  f"synthetic fbank T={T} D={D} batch {B}/GPU, 2xConv+BN -> 3-layer 2x256 LSTM enc -> "
+           "vs_baseline": None, "dtype": "f32" if args.gemm_operands == "f32" else "f32 (fp16 operands / f32 accumulate in the CNN and encoder-input GEMMs)",
+           "data": "synthetic",
+           "config": {"workload": {"cfg1": "BASELINE configs[1]: ", "es_en_20h": "shipped es_en_20h model (configs[0]'s model at configs[1]'s batch): ",
+                                   "cfg5": "shape of BASELINE configs[4] (6-layer encoder, 2x512, V=8004): "}[args.model] +
+                                  f"synthetic fbank T={T} D={D} batch {B}/GPU, 2xConv+BN -> {cfg['rnn_config']['enc_layers']}-layer 2x{cfg['rnn_config']['hidden_units'] // 2} LSTM enc -> "
                                   f"attention -> {dec_name}, V={V}, L={L}, dropout .3, noise .25, teach .8, Adam(amsgrad)+L2+clip",
                       "global_batch": world * B, "frames": T, "feat_dim": D, "tgt_len": L, "parallelism": f"dp{world}", "batchnorm": "global-batch statistics" if (world > 1 and args.sync_bn) else "per-replica statistics",
                       "launches": "plain stream launches (the step is GPU-bound: the host enqueues it in 0.6 ms)"},

@@ -41,6 +41,13 @@ int astk_gemm_f32(int layout, int M, int N, int K,
                   const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                   const float* bias, int mode, int ksplit, int batch, long sA, long sB, long sC, void* stream);
 
+/* BASELINE configs[4] ("fp16 MFMA GEMMs"): mode 1 lets the batched products of the CNN layers >= 1 (K6) and of the encoder's layer-0
+ * input projection (K9), forward and backward, run with operands rounded to fp16 (one v_mfma_f32_32x32x16_f16 per tile, f32
+ * accumulation) instead of the f32-accurate three-term bf16 split.  Reduced precision: the 1e-4 fp32 parity gate does not apply in
+ * this mode (SURVEY.md 8d asks for the loss drift instead: tests/test_gpu_model.py).  Process-wide; 0 (default) = off. */
+int astk_set_low_precision_gemms(int mode);
+int astk_get_low_precision_gemms(void);
+
 /* ---------------------------------------------------------------- CNN front-end  (seq2seq.py:158-180)
  * [Conv2D(no bias) -> BatchNorm(train: batch stats) -> ReLU] x n_layers, then the (T'',B,C*F') time-major
  * re-layout with feature index c*F'+f (quirk Q9).  Layer 0: in_channels 1, kernel (kt,kf), stride (st,sf),

@@ -214,7 +214,11 @@ def test_cnn_fwd_bwd(lib, B, T, D, c0, c1, with_noise):
 @pytest.mark.parametrize("T,B,in_dim,h,nl,masks", [(7, 3, 12, 4, 2, False), (9, 5, 24, 20, 3, True), (5, 33, 64, 36, 1, True), (1, 2, 8, 4, 2, False),
                                                    # h in {64,128,256,512}: the persistent wavefront kernels
                                                    (12, 5, 24, 64, 3, True), (7, 33, 16, 128, 2, False), (6, 16, 32, 256, 3, True),
-                                                   (3, 4, 16, 512, 1, False), (1, 3, 8, 64, 2, True)])
+                                                   (3, 4, 16, 512, 1, False), (1, 3, 8, 64, 2, True),
+                                                   # stacks whose (direction, layer) cells exceed one workgroup per CU: consecutive launches over
+                                                   # groups of layers -- 3 layers as (2, 1) at batch 200 / h = 64, 6 layers as (2, 2, 2) at h = 512
+                                                   # (the encoder of BASELINE configs[4]), 3 layers as (2, 1) at batch 64 / h = 256
+                                                   (5, 200, 16, 64, 3, True), (4, 20, 24, 512, 6, False), (6, 64, 32, 256, 3, True)])
 def test_lstm_stack(lib, T, B, in_dim, h, nl, masks):
     from ast_amd._lib import LstmGrads, LstmParams, LstmStackDesc
     from oracle.ast_ref_torch import encoder_torch
@@ -238,6 +242,8 @@ def test_lstm_stack(lib, T, B, in_dim, h, nl, masks):
     g_enc, g_c, g_h = rng.standard_normal(enc.shape), rng.standard_normal(cT.shape), rng.standard_normal(hT.shape)
     (enc * torch.tensor(g_enc)).sum().add((cT * torch.tensor(g_c)).sum()).add((hT * torch.tensor(g_h)).sum()).backward()
     d = LstmStackDesc(T, B, in_dim, h, nl, 2)
+    if h in (64, 128, 256, 512):
+        assert lib.astk_lstm_stack_path(C.byref(d)) == 1, "persistent encoder path not taken"
     prm = {k: dev(v) for k, v in P.items()}
     grd = {k: torch.zeros_like(v) for k, v in prm.items()}
     lp, lg = (LstmParams * (2 * nl))(), (LstmGrads * (2 * nl))()
