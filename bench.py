@@ -224,6 +224,15 @@ def main():
                     "avg_launch_us": round(ms_gemm * 1e3 / max(1, n_gemm), 1), "launches_per_step": n_gemm,
                     "method": "2*M*N*K per launch / HIP events around every launch on the launch stream; traffic = FETCH_SIZE*2 + WRITE_SIZE "
                               "of the same kernels from separate rocprofv3 --pmc passes (profiles/), per step"}
+            prec_env = os.environ.get("ASTK_GEMM_PREC", "bf16x3")
+            if prec_env != "f32":
+                # how the products execute: f32 operands split into three bf16 terms, six v_mfma_f32_32x32x16_bf16 per 16 k (f32-level
+                # accuracy); `peak` above stays the f32-input MFMA peak the useful flops are priced against
+                roof["executed"] = {"scheme": "bf16x3 split (6 bf16 MFMAs per useful product block); fp16 single-term for the CNN / encoder-input "
+                                              "GEMMs when --gemm-operands fp16" if args.gemm_operands == "fp16" else "bf16x3 split (6 bf16 MFMAs per useful product block)",
+                                    "bf16_tflops": round(tfl * 6, 1), "bf16_peak_tflops": 2500.0, "frac_of_bf16_peak": round(tfl * 6 / 2500.0, 4)}
+            else:
+                roof["executed"] = {"scheme": "exact f32 chain on v_mfma_f32_32x32x2_f32"}
         if res[17] > 0 and res[19] > 0:
             # Attention scan (north_star's "HBM roofline on the attention scan").  The scan is a PHASE of the two persistent decoder
             # launches, not a launch of its own, and its enc / encA slices are LDS-resident after step 0: the launches are LATENCY-bound
