@@ -129,6 +129,8 @@ struct GemmArgs {
   long sA, sB, sC;
   int lowp;          // 1: this product may run with fp16 operands when astk_set_low_precision_gemms(1) is in force (K6 / K9 and their backward)
   // filled by gemm_launch (work decomposition)
+  const unsigned long long* amaxA;   // fp16x2 path: the operands' absolute-maximum words; null on entry = gemm_launch runs the pass itself
+  const unsigned long long* amaxB;
   unsigned spanA, spanB;  // bytes from A.p / B.p to the end of one batch slice (buffer-load range)
   int kt;            // k-iterations per tile = ceil(K / BK)
   int tiles_mn;      // tiles per batch matrix
@@ -143,7 +145,15 @@ static inline GemmArgs gemm_args(int M, int N, int K, MatView A, MatView B, floa
   return g;
 }
 static inline GemmArgs lowp(GemmArgs g) { g.lowp = 1; return g; }
+static inline GemmArgs with_amax_a(GemmArgs g, const unsigned long long* a) { g.amaxA = a; return g; }
+static inline GemmArgs with_amax_b(GemmArgs g, const unsigned long long* b) { g.amaxB = b; return g; }
 int gemm_launch(int layout, const GemmArgs& g, hipStream_t s);
+// The fp16x2 GEMMs scale every operand by a power of two taken from its absolute maximum, normally found by a pass in front of the
+// launch.  A caller that feeds the same rows x inner matrix (row stride ld) to several launches runs that pass once, here, and hands
+// the result to each of them with with_amax_a / with_amax_b (null when the GEMMs run in another precision: then nothing is needed).
+// The handle stays valid for the next 511 calls of gemm_amax; the matrix must not change between the pass and the launches.  A
+// maximum taken over a superset of the operand (more rows of the same buffer) is fine: it can only make the scale more conservative.
+const unsigned long long* gemm_amax(const float* p, long rows, long ld, int inner, hipStream_t s);
 int low_precision_gemms();      // the mode set by astk_set_low_precision_gemms
 // Scoped cap on the co-resident GEMM workgroups per CU for launches made by this thread (0 = none): work that is meant to run
 // BESIDE a persistent recurrence kernel must leave registers free on every CU, or that kernel cannot become resident until the
@@ -158,6 +168,7 @@ struct GemmWgCap {
 constexpr int GEMM_GROUP_MAX = 12;
 struct GemmGroup {
   int n;
+  int unit;          // granule of the stream-K split in k-iterations (1, or 2 when every kt is even)
   long iters_total;
   long iter_start[GEMM_GROUP_MAX + 1];
   GemmArgs g[GEMM_GROUP_MAX];

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 
 namespace astk {
@@ -29,6 +30,15 @@ constexpr int BK = ASTK_GEMM_BK;
 // Block tile edge TL: 128 (4 waves x 64x64, the throughput configuration) or 64 (4 waves x 32x32) for products too small to
 // give every CU a 128-tile's worth of k-iterations -- a k-iteration of a 128-tile is 32 MFMAs = 0.87 us per wave whatever the
 // problem size, so 40 such tiles with K = 512 cannot finish in less than 28 us; with 64-tiles the same product is 160 tiles of 7 us.
+#ifndef ASTK_GEMM_RING
+#define ASTK_GEMM_RING 4        // register slots of staged tiles on the split paths (must divide 12, the staging loop's trip)
+#endif
+#ifndef ASTK_GEMM_PAIR
+#define ASTK_GEMM_PAIR 1        // K-contiguous operands: fetch two k-tiles (one 128-byte line per row) at a time
+#endif
+#ifndef ASTK_GEMM_F16X2_ACC2
+#define ASTK_GEMM_F16X2_ACC2 0
+#endif
 #ifndef ASTK_GEMM_X3_WGS
 #define ASTK_GEMM_X3_WGS 1
 #endif
@@ -53,6 +63,13 @@ __device__ __forceinline__ long rowoff(const MatView& v, int r) {
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// First k-iteration of workgroup w of G (stream-K split of the launch's iteration sequence).  grp.unit = 2 when every product of
+// the launch has an even number of k-iterations per tile: ranges then begin on even k-iterations, i.e. on 128-byte lines of a
+// K-contiguous f32 operand, which the paired tile loads rely on for whole-line fetches.
+__host__ __device__ __forceinline__ long wg_first_iter(const GemmGroup& grp, unsigned w, unsigned G) {
+  return (grp.iters_total / grp.unit) * (long)w / (long)G * grp.unit;
+}
 
 // Position j (0..BK/2-1) of the k values a lane of k-group lk (0/1) feeds to the MFMAs of one k-iteration is
 // k = KROW(j) + 2*lk: a staged float4 (4 consecutive k) then splits into the register pairs (x,y) -> lk 0 and (z,w) -> lk 1.
@@ -83,8 +100,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // PREC_F16 (BASELINE configs[4], "fp16 MFMA GEMMs"): operands rounded to ONE fp16 term (round-to-nearest-even), one
 // v_mfma_f32_32x32x16_f16 per tile and 16 k, f32 accumulation.  Reduced precision (11 significant bits): only launches their caller marks
 // low-precision-eligible take it, and only when astk_set_low_precision_gemms(1) is in force.
-enum GemmPrec { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_F16 = 2 };
-constexpr int prec_planes(int prec) { return prec == PREC_BF16X3 ? 3 : 1; }
+// PREC_F16X2: every operand is scaled by a power of two s (its absolute maximum lands in [2^13, 2^14): fp16 has only 5 exponent bits)
+// and split into TWO fp16 terms, x s = hi + lo / 2048 with hi = fp16_rtz(x s), lo = fp16((x s - hi) 2048): 22 significant bits for
+// every value down to 2^-28 of the operand's maximum, an absolute floor of 2^-50 of the maximum below that.  A product is summed
+// from three of the four term products on v_mfma_f32_32x32x16_f16 (hi.hi into one accumulator set, hi.lo + lo.hi into a second one that
+// enters with the factor 2^-11 in the epilogue; lo.lo <= 2^-22 |a b| is dropped): HALF the matrix-pipe work of bf16x3 at an error of
+// 2^-22 per product.  The scales come from an absolute-maximum pass over both operands in front of the launch (gemm_absmax).
+enum GemmPrec { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_F16 = 2, PREC_F16X2 = 3 };
+constexpr int prec_planes(int prec) { return prec == PREC_BF16X3 ? 3 : (prec == PREC_F16X2 ? 2 : 1); }
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -101,6 +124,33 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
   mid = cvt_pk_bf16(r0, r1);
   const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
   lo = cvt_pk_bf16(s0, s1);
+}
+// fp16x2: two values times the operand's scale -> one dword of the hi plane and one of the lo plane.  Five vector-ALU instructions per
+// pair: v_pk_mul_f32 (scale), v_cvt_pkrtz_f16_f32 (hi, truncated: the residual carries what truncation leaves), two v_fma_mix_f32
+// (residual = x s - hi, reading the fp16 halves directly) and v_cvt_pk_f16_f32 (lo, round-to-nearest-even).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2h(float x0, float x1, float scl, unsigned& hi, unsigned& lo) {
+  const f32x2 xs = (f32x2){x0, x1} * (f32x2){scl, scl};
+  const f16x2 h = {(_Float16)xs[0], (_Float16)xs[1]};
+  hi = __builtin_bit_cast(unsigned, h);
+  float r0, r1;      // (hipcc converts the halves back with v_cvt_f32_f16 before a packed fma; the mix form reads them in place)
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(xs[0]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(xs[1]));
+#if ASTK_GEMM_F16X2_ACC2
+  r0 *= 2048.f; r1 *= 2048.f;
+#endif
+  const f16x2 l = {(_Float16)r0, (_Float16)r1};
+  lo = __builtin_bit_cast(unsigned, l);
+}
+// The power of two that brings an operand's absolute maximum into [2^13, 2^14), as the biased exponent of a float (amax: the word
+// gemm_absmax left: launch generation in the high half, the maximum's float bits in the low half; null or zero maximum: 1.0).
+__device__ __forceinline__ int scale_exp(const unsigned long long* amax) {
+  if (amax == nullptr) return 127;
+  unsigned long long w = amax[0];       // AMAX_SHARDS words; one left by an earlier launch (older generation) loses to any of this one's
+#pragma unroll
+  for (int i = 1; i < 16; ++i) w = max(w, amax[i]);
+  const int e = (int)(((unsigned)w) >> 23) & 0xff;
+  return e == 0 ? 127 : min(max(267 - e, 1), 253);
 }
 // LDS images of one operand stage on the bf16x3 path (bytes).  RK operand (K-contiguous global rows): per plane two k-halves
 // [h = k / 8][row][8 k] of TL x 16 B, 16 B apart from a multiple of 128 B so that a stager's 8-byte writes and the MFMA lanes' 16-byte
@@ -129,6 +179,7 @@ struct Stager {
   int a, b;           // RK: a = k-quad (0..KQ-1), b = row group (rows NP*b .. NP*b+NP-1).  KR: a = column quad, b = krow0 (0..RP-1)
   int kcur;           // first k of the tile the next load() fetches
   int lds;            // float offset of this thread's first LDS write
+  float scl;          // fp16x2: the operand's power-of-two scale
 
   // row0 / nrows: the tile's first M (N) index and the operand's M (N) extent; [kbeg, kend): this workgroup's K range.
   // Leading dimensions are multiples of 4 and >= the extent, so a float4 at any multiple of 4 below round_up(extent, 4)
@@ -139,7 +190,11 @@ struct Stager {
       a = tid % KQ;
       b = tid / KQ;
 #pragma unroll
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 128)     // timing experiment (wrong results): 8 lanes per row = whole 128-byte lines per wave instruction
+      for (int p = 0; p < NP; ++p) voff[p] = (unsigned)((rowoff(v, min(row0 + (NP * (tid / 8) + p) % TL, nrows - 1)) + (tid % 8) * 4) * 4);
+#else
       for (int p = 0; p < NP; ++p) voff[p] = (unsigned)((rowoff(v, min(row0 + NP * b + p, nrows - 1)) + a * 4) * 4);
+#endif
       lds = NP * b * LD_RK + 2 * a;   // a thread's NP rows are neighbours: one LDS address register serves all its writes
     } else {
       a = tid % CQ;
@@ -158,7 +213,11 @@ struct Stager {
   // span: bytes from v.p to the end of the operand slice (gemm_prepare)
   __device__ __forceinline__ void load(const MatView& v, unsigned span, int kend, const int slot = 0) {
     if (RK || !TWOLVL) {
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 64)
+      const long adv = RK ? (long)(kcur & 63) : (long)(kcur & 63) * v.ld;
+#else
       const long adv = RK ? (long)kcur : (long)kcur * v.ld;
+#endif
       const __amdgpu_buffer_rsrc_t r =
           __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(v.p + adv), 0, (int)(span - (unsigned)(adv * 4)), 0x00020000);
 #pragma unroll
@@ -186,6 +245,29 @@ struct Stager {
       while (trem >= v.tn) { trem -= v.tn; ++tgrp; }
     }
     kcur += BK;
+  }
+  // RK operands on the split paths: tiles t (-> slot) and t + 1 (-> slot + 1, if `second`) in one go.  A tile row is 64 bytes, half a
+  // cache line; fetched one tile at a time the other half is long evicted from the 32 KB vector L1 when the next tile asks for it
+  // (4 tiles x 256 rows in flight), so every line crosses the L2 -> L1 path twice.  Issued back to back the two halves are one miss.
+  __device__ __forceinline__ void load_pair(const MatView& v, unsigned span, const int slot, bool second) {
+    static_assert(RING == 1 || (RING % 2) == 0, "pairs of slots");
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 64)      // timing experiment: every load an L2 hit (k wraps inside 256 bytes per row)
+    const long adv = (long)(kcur & 63);
+#else
+    const long adv = (long)kcur;
+#endif
+    const __amdgpu_buffer_rsrc_t r =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(v.p + adv), 0, (int)(span - (unsigned)(adv * 4)), 0x00020000);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff[p], 0, 0);
+      reg[slot][p] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+      if (second) {
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff[p] + BK * 4, 0, 0);
+        reg[(slot + 1) % RING][p] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+      }
+    }
+    kcur += 2 * BK;
   }
   __device__ __forceinline__ void store(float* S) const {
     if (RK) {
@@ -225,6 +307,12 @@ struct Stager {
       if constexpr (PREC == PREC_F16) {
         const f16x2 lo2 = {(_Float16)r[p].x, (_Float16)r[p].y}, hi2 = {(_Float16)r[p].z, (_Float16)r[p].w};
         *reinterpret_cast<uint2*>(S + off) = make_uint2(__builtin_bit_cast(unsigned, lo2), __builtin_bit_cast(unsigned, hi2));
+      } else if constexpr (PREC == PREC_F16X2) {
+        unsigned h0, l0, h1, l1;
+        split2h(r[p].x, r[p].y, scl, h0, l0);
+        split2h(r[p].z, r[p].w, scl, h1, l1);
+        *reinterpret_cast<uint2*>(S + off) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(S + PL + off) = make_uint2(l0, l1);
       } else {
         unsigned h0, m0, l0, h1, m1, l1;
 #if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 1)      // timing experiment: no split arithmetic
@@ -314,8 +402,8 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
 #endif
   unsigned wgi = blockIdx.x;
   if (SPLIT && (gridDim.x % 8) == 0) wgi = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
-  long it = grp.iters_total * (long)wgi / (long)gridDim.x;
-  const long it_end = grp.iters_total * (long)(wgi + 1) / (long)gridDim.x;
+  long it = wg_first_iter(grp, wgi, gridDim.x);
+  const long it_end = wg_first_iter(grp, wgi + 1, gridDim.x);
   int prob = 0;
 
   while (it < it_end) {
@@ -341,12 +429,19 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
     B.p += (long)zb * g.sB;
     float* C = g.C + (long)zb * g.sC;
 
-    constexpr int RING = SPLIT ? 4 : 1;
+    constexpr int RING = SPLIT ? ASTK_GEMM_RING : 1;
     Stager<TLM, A_RK, TWOLVL, PREC, RING> sa;
     Stager<TL, B_RK, TWOLVL, PREC, RING> sb;
-    if (stages) {
-      sa.init(A, m0, g.M, kbeg, kend, tid);
-      sb.init(B, n0, g.N, kbeg, kend, tid);
+    // (every wave runs init: a field assigned only under the role branch, which depends on threadIdx, is a divergent value to hipcc
+    //  -- and a divergent kcur puts the operand base pointer into vector registers and a waterfall loop around every buffer load)
+    sa.init(A, m0, g.M, kbeg, kend, tid);
+    sb.init(B, n0, g.N, kbeg, kend, tid);
+    int seA = 127, seB = 127;
+    if constexpr (PREC == PREC_F16X2) {
+      seA = scale_exp(g.amaxA);
+      seB = scale_exp(g.amaxB);
+      sa.scl = __uint_as_float((unsigned)seA << 23);
+      sb.scl = __uint_as_float((unsigned)seB << 23);
     }
 
     const int nk = k1 - k0;
@@ -386,19 +481,45 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
       // 48 KB per workgroup and iteration (190+ cycles of the LDS pipe, plus latency) is off the matrix pipe's critical path.
       auto stA = [&](int st) { return reinterpret_cast<char*>(As[0]) + st * (A_FLOATS * 4); };
       auto stB = [&](int st) { return reinterpret_cast<char*>(Bs[0]) + st * (B_FLOATS * 4); };
-      if (producer) {
-        sa.load(A, g.spanA, kend, 0);
-        sb.load(B, g.spanB, kend, 0);
+      // refill(st, V, span, t, slot): tile t has just left register slot `slot` = t % RING; fetch tile t + RING into it.  K-contiguous
+      // operands fetch PAIRS of tiles (Stager::load_pair) when the odd slot of a pair comes free.
+      auto refill = [&](auto& st, const MatView& V, unsigned span, auto rkc, auto steadyc, const int t, const int slot) {
+        constexpr bool PAIR = decltype(rkc)::value && ASTK_GEMM_PAIR;
+        constexpr bool STEADY = decltype(steadyc)::value;       // every tile asked for exists
+        if constexpr (PAIR) {
+          if (slot & 1) {
+            if (STEADY || t - 1 + RING < nk) st.load_pair(V, span, slot - 1, STEADY || t + RING < nk);
+          }
+        } else {
+          if (STEADY || t + RING < nk) st.load(V, span, kend, slot);
+        }
+      };
+      auto prefetch = [&](auto& st, const MatView& V, unsigned span, auto rkc) {      // tiles 0 .. RING-1 of the range
+        constexpr bool PAIR = decltype(rkc)::value && ASTK_GEMM_PAIR;
+        if constexpr (PAIR) {
 #pragma unroll
-        for (int r = 1; r < RING; ++r)
-          if (r < nk) { sa.load(A, g.spanA, kend, r); sb.load(B, g.spanB, kend, r); }
+          for (int r = 0; r < RING; r += 2)
+            if (r < nk) st.load_pair(V, span, r, r + 1 < nk);
+        } else {
+#pragma unroll
+          for (int r = 0; r < RING; ++r)
+            if (r < nk) st.load(V, span, kend, r);
+        }
+      };
+      constexpr std::integral_constant<bool, A_RK> ARK{};
+      constexpr std::integral_constant<bool, B_RK> BRK{};
+      if (producer) {
+        prefetch(sa, A, g.spanA, ARK);
+        prefetch(sb, B, g.spanB, BRK);
         sa.template store_split<true>(stA(0), kbeg, kend, 0);
         sb.template store_split<true>(stB(0), kbeg, kend, 0);
-        if (RING < nk) { sa.load(A, g.spanA, kend, 0); sb.load(B, g.spanB, kend, 0); }
+        refill(sa, A, g.spanA, ARK, std::false_type{}, 0, 0);
+        refill(sb, B, g.spanB, BRK, std::false_type{}, 0, 0);
         if (1 < nk) {
           sa.template store_split<true>(stA(1), kbeg + BK, kend, 1);
           sb.template store_split<true>(stB(1), kbeg + BK, kend, 1);
-          if (1 + RING < nk) { sa.load(A, g.spanA, kend, 1); sb.load(B, g.spanB, kend, 1); }
+          refill(sa, A, g.spanA, ARK, std::false_type{}, 1, 1);
+          refill(sb, B, g.spanB, BRK, std::false_type{}, 1, 1);
         }
         __syncthreads();
         int kt = 0;
@@ -416,7 +537,8 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
 #endif
 #if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 12)      // timing experiment: no global loads in the loop
 #else
-          if (!TAIL || kt_ + 2 + RING < nk) { sa.load(A, g.spanA, kend, slot); sb.load(B, g.spanB, kend, slot); }
+          refill(sa, A, g.spanA, ARK, std::integral_constant<bool, !TAIL>{}, kt_ + 2, slot);
+          refill(sb, B, g.spanB, BRK, std::integral_constant<bool, !TAIL>{}, kt_ + 2, slot);
 #endif
           __syncthreads();
         };
@@ -451,13 +573,19 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
         }
       } else {
         // (the accumulators live in this branch only: the staging waves' code path must not carry 128 registers of them)
+        constexpr bool ACC2 = PREC == PREC_F16X2 && ASTK_GEMM_F16X2_ACC2;
+        constexpr int NA2 = ACC2 ? NA : 0, NAM2 = ACC2 ? NAM : 0;
         f32x16 acc[NAM][NA];
+        f32x16 acc2[NAM2 + 1][NA2 + 1];        // fp16x2: the hi.lo + lo.hi sums (scaled by 2^11)
 #pragma unroll
         for (int i = 0; i < NAM; ++i)
 #pragma unroll
           for (int j = 0; j < NA; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+              acc[i][j][r] = 0.f;
+              if constexpr (ACC2) acc2[i][j][r] = 0.f;
+            }
         __syncthreads();
         // operand fragments of v_mfma_f32_32x32x16_bf16: lane (r = lane & 31, h = lane >> 5) holds k = 8h .. 8h+7 of row / column r
         auto frag = [&](const char* base, bool rk, auto tlc, int t0, int pl) -> bf16x8 {
@@ -492,6 +620,17 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
               for (int i2 = 0; i2 < NA; ++i2)
                 acc[i][i2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[i][0]), __builtin_bit_cast(f16x8, f.b[i2][0]),
                                                                     acc[i][i2], 0, 0, 0);
+          } else if constexpr (PREC == PREC_F16X2) {
+            constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};      // lo.hi, hi.lo -> acc2; hi.hi -> acc
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+              for (int i = 0; i < NAM; ++i)
+#pragma unroll
+                for (int i2 = 0; i2 < NA; ++i2) {
+                  f32x16& d = (ACC2 && t < 2) ? acc2[i][i2] : acc[i][i2];
+                  d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[i][PA[t]]), __builtin_bit_cast(f16x8, f.b[i2][PB[t]]), d, 0, 0, 0);
+                }
           } else {
           // smallest terms first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
           constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
@@ -530,6 +669,15 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
           if (kt + 3 < nk) cstep(std::integral_constant<int, 3>{}, kt + 3);
           if (kt + 4 < nk) cstep(std::integral_constant<int, 4>{}, kt + 4);
           if (kt + 5 < nk) cstep(std::integral_constant<int, 5>{}, kt + 5);
+        }
+        if constexpr (PREC == PREC_F16X2) {
+          const float ia = __uint_as_float((unsigned)(254 - seA) << 23), ib = __uint_as_float((unsigned)(254 - seB) << 23);
+#pragma unroll
+          for (int i = 0; i < NAM; ++i)
+#pragma unroll
+            for (int j = 0; j < NA; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[i][j][r] = (ACC2 ? fmaf(acc2[i][j][r], 1.f / 2048.f, acc[i][j][r]) : acc[i][j][r]) * ia * ib;
         }
         epilogue(acc);        // meanwhile the staging waves run the next tile's prologue
       }
@@ -627,11 +775,95 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
 #endif
 }
 
+// ---- fp16x2: absolute maxima of the operands, one pass in front of the launch.  A region is `nb` slices (stride sb) of `rows` rows
+// (stride ld) of `inner` contiguous floats; its maximum goes to *slot as (generation << 32 | float bits) with a 64-bit atomic max, so
+// that a slot never has to be cleared: a later launch's generation outranks whatever an earlier user left there.
+constexpr int AMAX_REGIONS = 4 * GEMM_GROUP_MAX;
+constexpr int AMAX_SHARDS = 16;
+struct AmaxRegion {
+  const float* p;
+  long nb, sb, rows, ld;
+  int inner;
+  unsigned long long* slot;
+};
+struct AmaxJobs {
+  int n;
+  unsigned gen;
+  int blk_start[AMAX_REGIONS + 1];
+  AmaxRegion r[AMAX_REGIONS];
+};
+__global__ __launch_bounds__(256) void k_absmax(AmaxJobs jobs) {
+  int ri = 0;
+  while ((int)blockIdx.x >= jobs.blk_start[ri + 1]) ++ri;
+  const AmaxRegion& R = jobs.r[ri];
+  const int nblk = jobs.blk_start[ri + 1] - jobs.blk_start[ri], blk = (int)blockIdx.x - jobs.blk_start[ri];
+  const int quads = R.inner >> 2, tailn = R.inner & 3;
+  int tq = 1;
+  while (tq < quads && tq < 256) tq <<= 1;       // threads along a row (power of two), 256 / tq rows per pass
+  const int tx = threadIdx.x & (tq - 1), ty = threadIdx.x / tq, rpp = 256 / tq;
+  const long total_rows = R.nb * R.rows;
+  float m = 0.f;
+  auto amax4 = [](float acc, const float4& v) { return fmaxf(fmaxf(acc, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); };
+  // (no 64-bit division on the streaming path: it costs more than the loads)
+  const bool one = R.nb == 1;
+  const unsigned nrows32 = (unsigned)R.rows;
+  auto rowptr = [&](long row) {
+    if (one) return R.p + row * R.ld;
+    if ((R.nb * R.rows) >> 32) return R.p + (row / R.rows) * R.sb + (row % R.rows) * R.ld;
+    const unsigned sl = (unsigned)row / nrows32, rr = (unsigned)row - sl * nrows32;
+    return R.p + (long)sl * R.sb + (long)rr * R.ld;
+  };
+  const long step = (long)nblk * rpp;
+  long row = (long)blk * rpp + ty;
+  if (quads <= tq) {
+    // short rows (one quad per thread): eight rows in flight per thread; a row index past the end re-reads the last row (harmless
+    // for a maximum), so that the remainder costs no extra round trip
+    const bool has = tx < quads;
+    for (; row < total_rows; row += 8 * step) {
+      float4 v[8];
+      float t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float* q = rowptr(min(row + j * step, total_rows - 1));
+        v[j] = has ? *reinterpret_cast<const float4*>(q + 4 * tx) : make_float4(0.f, 0.f, 0.f, 0.f);
+        t[j] = tx < tailn ? q[4 * quads + tx] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = fmaxf(amax4(m, v[j]), fabsf(t[j]));
+    }
+  } else {
+    for (; row < total_rows; row += step) {
+      const float* q = rowptr(row);
+      int c = tx;
+      for (; c + 3 * tq < quads; c += 4 * tq) {        // long rows: four quads in flight per thread
+        const float4 v0 = *reinterpret_cast<const float4*>(q + 4 * c), v1 = *reinterpret_cast<const float4*>(q + 4 * (c + tq));
+        const float4 v2 = *reinterpret_cast<const float4*>(q + 4 * (c + 2 * tq)), v3 = *reinterpret_cast<const float4*>(q + 4 * (c + 3 * tq));
+        m = amax4(amax4(amax4(amax4(m, v0), v1), v2), v3);
+      }
+      for (; c < quads; c += tq) m = amax4(m, *reinterpret_cast<const float4*>(q + 4 * c));
+      if (tx < tailn) m = fmaxf(m, fabsf(q[4 * quads + tx]));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (!(m <= 3.0e38f)) m = 3.0e38f;            // (an infinite entry: the product is not finite either way)
+    // (same-address atomics retire one after the other, ~40 ns each: 16 shards per region, the reader takes the maximum of all)
+    atomicMax(R.slot + (blk & (AMAX_SHARDS - 1)), ((unsigned long long)jobs.gen << 32) | (unsigned long long)__float_as_uint(m));
+  }
+}
+constexpr int AMAX_SLOTS = 16384;      // 64-bit words: two halves of 512 sharded maxima each
+__device__ unsigned long long g_amax_ring[AMAX_SLOTS];
+
 // GEMM_STORE + split tiles: zero the tiles that more than one workgroup will accumulate into.  Block b looks at the
 // boundary between workgroups b and b+1.
 // (16-byte stores when every problem's C rows are 16-byte aligned -- `vec`, decided by the launcher -- else scalar)
 __global__ __launch_bounds__(256) void k_zero_split_tiles(GemmGroup grp, int G, int TLM, int TL, int vec) {
-  const long git = grp.iters_total * (long)(blockIdx.x + 1) / (long)G;
+  const long git = wg_first_iter(grp, blockIdx.x + 1, G);
   int prob = 0;
   while (git >= grp.iter_start[prob + 1]) ++prob;
   const GemmArgs& g = grp.g[prob];
@@ -698,6 +930,50 @@ static thread_local int tl_wg_cap = 0;
 GemmWgCap::GemmWgCap(int per_cu) : prev(tl_wg_cap) { tl_wg_cap = per_cu; }
 GemmWgCap::~GemmWgCap() { tl_wg_cap = prev; }
 
+// operand precision: fp16x2 (scaled two-term fp16 split) unless ASTK_GEMM_PREC = bf16x3 (three-term bf16 split) or f32 (exact f32 MFMA chain)
+static int default_prec() {
+  static const int p = !getenv("ASTK_GEMM_PREC") ? PREC_F16X2
+                       : !strcmp(getenv("ASTK_GEMM_PREC"), "f32") ? PREC_F32
+                       : !strcmp(getenv("ASTK_GEMM_PREC"), "bf16x3") ? PREC_BF16X3 : PREC_F16X2;
+  return p;
+}
+static unsigned long long* amax_ring() {
+  static unsigned long long* ring = nullptr;
+  if (!ring && hipGetSymbolAddress((void**)&ring, HIP_SYMBOL(g_amax_ring)) != hipSuccess) ring = nullptr;
+  return ring;
+}
+static std::atomic<unsigned> g_amax_counter{1};
+// slots [0, AMAX_SLOTS / 2) serve the launches' own passes, [AMAX_SLOTS / 2, AMAX_SLOTS) the callers' handles (gemm_amax)
+static std::atomic<unsigned> g_amax_handle{0};
+
+// Adds the region(s) of one operand: exact rows x inner when the rows are plain (r * ld), the contiguous span from p to the slice's end
+// when they are two-level windows or indexed (every byte of the span is activation data or zero padding of the same array; the
+// maximum of a superset can only make the scale more conservative).
+static void amax_add(AmaxJobs& J, const MatView& v, bool kr, int rows, int K, int batch, long sbatch, long span_floats, unsigned long long* slot) {
+  auto push = [&](const float* p, long nb, long sb, long nrows, long ld, int inner) {
+    if (inner <= 0 || nrows <= 0 || J.n >= AMAX_REGIONS) return;
+    AmaxRegion& R = J.r[J.n];
+    R.p = p; R.nb = nb; R.sb = sb; R.rows = nrows; R.ld = ld; R.inner = inner; R.slot = slot;
+    const double bytes = 4.0 * nb * nrows * inner;
+    const int blocks = (int)std::min(1024.0, std::max(1.0, bytes / (32.0 * 1024.0)));
+    J.blk_start[J.n + 1] = J.blk_start[J.n] + blocks;
+    ++J.n;
+  };
+  const long outer = kr ? K : rows;            // rows of the global array the operand's rows map to
+  const int inner = kr ? rows : K;
+  if (v.tn > 0 || v.rowidx) {
+    const long n = span_floats;                // contiguous: whole 1024-float rows and a tail row
+    push(v.p, batch, sbatch, n / 1024, 1024, 1024);
+    push(v.p + (n / 1024) * 1024, batch, sbatch, 1, 0, (int)(n % 1024));
+  } else if (v.ld == inner && batch == 1) {
+    const long n = outer * (long)inner;
+    push(v.p, 1, 0, n / 1024, 1024, 1024);
+    push(v.p + (n / 1024) * 1024, 1, 0, 1, 0, (int)(n % 1024));
+  } else {
+    push(v.p, batch, sbatch, outer, v.ld, inner);
+  }
+}
+
 int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   ASTK_CHECK(layout == GEMM_NT || layout == GEMM_NN || layout == GEMM_TN, "gemm: bad layout %d", layout);
   ASTK_CHECK(n >= 0 && n <= GEMM_GROUP_MAX, "gemm: group of %d products (max %d)", n, GEMM_GROUP_MAX);
@@ -712,8 +988,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   static const int force_tl = getenv("ASTK_GEMM_TILE") ? atoi(getenv("ASTK_GEMM_TILE")) : 0;
   // operand precision: bf16x3 (three-term bf16 split, f32-level accuracy, up to 2.7x the f32 MFMA rate) unless ASTK_GEMM_PREC=f32 asks
   // for the exact-f32 MFMA chain
-  static const int prec_default = (getenv("ASTK_GEMM_PREC") && !strcmp(getenv("ASTK_GEMM_PREC"), "f32")) ? PREC_F32 : PREC_BF16X3;
-  int prec = prec_default;
+  int prec = default_prec();
   if (g_lowp_mode != 0 && n > 0) {        // fp16 operands only if every product of the launch is marked eligible by its caller
     bool all = true;
     for (int i = 0; i < n; ++i) all = all && list[i].lowp != 0;
@@ -757,6 +1032,9 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   const int WGS_PER_CU = wgs_per_cu(TL, prec);
   if (grp.n == 0) return 0;
   for (int i = grp.n; i <= GEMM_GROUP_MAX; ++i) grp.iter_start[i] = grp.iters_total;
+  grp.unit = prec != PREC_F32 ? 2 : 1;
+  for (int i = 0; i < grp.n; ++i)
+    if (grp.g[i].kt & 1) grp.unit = 1;
   if (twolvl) {   // a plain operand next to a two-level one: express it as one group of INT_MAX rows
     const bool a_kr = layout == GEMM_TN, b_kr = layout != GEMM_NT;
     for (int i = 0; i < grp.n; ++i) {
@@ -793,6 +1071,36 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
               grp.g[i].N, grp.g[i].K, grp.g[i].batch, grp.g[i].mode, (int)twolvl, i, grp.n, G, grp.g[i].kt, TLM * 1000 + TL);
   ProfScope prof(PROF_GEMM, s, flops);
   dim3 grid((unsigned)G, 1, 1);
+  if (prec == PREC_F16X2) {
+    // one absolute-maximum pass over both operands of every product (part of the GEMM's cost, inside its timing scope)
+    unsigned long long* ring = amax_ring();
+    ASTK_CHECK(ring != nullptr, "gemm: no absmax ring");
+    AmaxJobs J;
+    memset(&J, 0, sizeof(J));
+    const unsigned gen = g_amax_counter.fetch_add(1);
+    J.gen = gen;
+    const bool a_kr = layout == GEMM_TN, b_kr = layout != GEMM_NT;
+    auto list_view = [](MatView v) { if (v.tn == 0x7fffffff) v.tn = 0; return v; };    // (a plain operand dressed as one group, see above)
+    for (int i = 0; i < grp.n; ++i) {
+      GemmArgs& a = grp.g[i];
+      unsigned long long* sl = ring + (((size_t)gen * (2 * GEMM_GROUP_MAX) + 2 * i) % (AMAX_SLOTS / 2 / AMAX_SHARDS)) * AMAX_SHARDS;
+      const long spa = a.A.tn > 0 && a.A.tn != 0x7fffffff && a_kr ? (long)((a.K - 1) / a.A.tn) * a.A.sg + (long)((a.K - 1) % a.A.tn) * a.A.st + ((a.M + 3) & ~3L) : a.spanA / 4;
+      const long spb = a.B.tn > 0 && a.B.tn != 0x7fffffff && b_kr ? (long)((a.K - 1) / a.B.tn) * a.B.sg + (long)((a.K - 1) % a.B.tn) * a.B.st + ((a.N + 3) & ~3L) : a.spanB / 4;
+      if (!a.amaxA) {          // (a caller that uses an operand in several launches passes its maximum in: gemm_amax)
+        a.amaxA = sl;
+        amax_add(J, list_view(a.A), a_kr, a.M, a.K, a.batch, a.sA, spa, sl);
+      }
+      if (!a.amaxB) {
+        a.amaxB = sl + AMAX_SHARDS;
+        amax_add(J, list_view(a.B), b_kr, a.N, a.K, a.batch, a.sB, spb, sl + AMAX_SHARDS);
+      }
+    }
+    if (log_shapes)
+      for (int i = 0; i < J.n; ++i)
+        fprintf(stderr, "astk_gemm absmax region %d/%d: %ld x %ld rows (ld %ld) x %d floats = %.1f MB, %d blocks\n", i, J.n, J.r[i].nb, J.r[i].rows, J.r[i].ld,
+                J.r[i].inner, 4e-6 * J.r[i].nb * J.r[i].rows * J.r[i].inner, J.blk_start[i + 1] - J.blk_start[i]);
+    if (J.n > 0) hipLaunchKernelGGL(k_absmax, dim3((unsigned)J.blk_start[J.n]), dim3(256), 0, s, J);
+  }
   if (!aligned && any_store && G > 1) {
     bool vec = true;
     for (int i = 0; i < grp.n; ++i) {
@@ -816,6 +1124,8 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   if (prec == PREC_F32) {
     if (TL == 64) { ASTK_GEMM_LAUNCH(64, PREC_F32, 64) } else { ASTK_GEMM_LAUNCH(128, PREC_F32, 128) }
   } else if (prec == PREC_F16) { ASTK_GEMM_LAUNCH(128, PREC_F16, 128)
+  } else if (prec == PREC_F16X2) {
+    if (TL == 64) { ASTK_GEMM_LAUNCH(64, PREC_F16X2, 64) } else { ASTK_GEMM_LAUNCH(128, PREC_F16X2, 128) }
   } else if (TLM == 256) { ASTK_GEMM_LAUNCH(128, PREC_BF16X3, 256)
   } else if (TL == 64) { ASTK_GEMM_LAUNCH(64, PREC_BF16X3, 64)
   } else { ASTK_GEMM_LAUNCH(128, PREC_BF16X3, 128) }
@@ -825,6 +1135,19 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
 }
 
 int gemm_launch(int layout, const GemmArgs& g, hipStream_t s) { return gemm_launch_group(layout, &g, 1, s); }
+
+const unsigned long long* gemm_amax(const float* p, long rows, long ld, int inner, hipStream_t s) {
+  if (default_prec() != PREC_F16X2 || !p || rows <= 0 || inner <= 0) return nullptr;
+  unsigned long long* ring = amax_ring();
+  if (!ring) return nullptr;
+  unsigned long long* slot = ring + AMAX_SLOTS / 2 + (g_amax_handle.fetch_add(1) % (AMAX_SLOTS / 2 / AMAX_SHARDS)) * AMAX_SHARDS;
+  AmaxJobs J;
+  memset(&J, 0, sizeof(J));
+  J.gen = g_amax_counter.fetch_add(1);
+  amax_add(J, mat(p, ld), false, (int)rows, inner, 1, 0, 0, slot);
+  hipLaunchKernelGGL(k_absmax, dim3((unsigned)J.blk_start[J.n]), dim3(256), 0, s, J);
+  return slot;
+}
 
 }  // namespace astk
 

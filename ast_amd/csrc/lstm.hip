@@ -152,11 +152,12 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
     // ---- persistent wavefront path: layer-0 upward projection batched over time, everything else in ONE launch
     PersistCellHost cells[16];
     memset(cells, 0, sizeof(cells));
+    const unsigned long long* ax = gemm_amax(x, (long)T * B, P.in, P.in, s);      // both directions multiply the same frames
     for (int dd = 0; dd < P.nd; ++dd) {
       const astk_lstm_params& p0 = prm[dd * P.nl];
       ASTK_CHECK(p0.Wu && p0.b && p0.Wl, "lstm_stack_fwd: null parameter (dir %d layer 0)", dd);
       MatView A = dd == 0 ? mat(x, P.in) : mat_idx(x, P.in, rows_perm);
-      ASTK_TRY(gemm_launch(GEMM_NT, lowp(gemm_args(T * B, 4 * h, P.in, A, mat(p0.Wu, P.in), P.ZG[dd][0], 4 * h, p0.b)), s));     // K9
+      ASTK_TRY(gemm_launch(GEMM_NT, with_amax_a(lowp(gemm_args(T * B, 4 * h, P.in, A, mat(p0.Wu, P.in), P.ZG[dd][0], 4 * h, p0.b)), ax), s));     // K9
       for (int l = 0; l < P.nl; ++l) {
         const astk_lstm_params& p = prm[dd * P.nl + l];
         ASTK_CHECK(p.Wu && p.b && p.Wl, "lstm_stack_fwd: null parameter (dir %d layer %d)", dd, l);
@@ -327,6 +328,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
   }
   GemmArgs wg[GEMM_GROUP_MAX];   // weight-gradient products, issued as grouped launches
   int nwg = 0;
+  const unsigned long long* ax = gemm_amax(x, (long)T * B, P.in, P.in, s);      // the frames: B operand of both directions' layer-0 dWu
   ColsumBatch cb;                // bias gradients of all cells: one launch (dz of every cell is final when the recurrence kernel has run)
   for (int l = P.nl - 1; l >= 0; --l) {
     const bool top = l == P.nl - 1;
@@ -371,10 +373,12 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
       const astk_lstm_grads& g = gr[dd * P.nl + l];
       const float* dz = P.ZG[dd][l];
       const int rows = T * B;
+      // dz feeds up to three products (dWl, dWu, the input gradient): one absolute-maximum pass for all of them
+      const unsigned long long* adz = gemm_amax(dz, rows, 4 * h, 4 * h, s);
       // dWl (4h,h) += sum_{i>=1} dz_i^T h_{i-1}
       if (T > 1) {
         if (nwg == GEMM_GROUP_MAX) { ASTK_TRY(gemm_launch_group(GEMM_TN, wg, nwg, s)); nwg = 0; }
-        wg[nwg++] = gemm_args(4 * h, h, rows - B, mat(dz + (size_t)B * 4 * h, 4 * h), mat(P.HR[dd][l], h), g.dWl, h, nullptr, GEMM_ATOMIC, 1);
+        wg[nwg++] = with_amax_a(gemm_args(4 * h, h, rows - B, mat(dz + (size_t)B * 4 * h, 4 * h), mat(P.HR[dd][l], h), g.dWl, h, nullptr, GEMM_ATOMIC, 1), adz);
       }
       // dWu (4h,in) += dz^T X   (reverse stack, layer 0: dz is first re-ordered to frame order, sum_i dz_i^T x[perm i] = sum_f dz[inv f]^T x_f)
       {
@@ -390,20 +394,21 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
         } else Xv = mat(masks ? P.HD[dd][l - 1] : P.HR[dd][l - 1], h);
         if (l == 0 && (dd == 1 || low_precision_gemms())) {   // GATH is a single scratch buffer: issue this product right away
           // (K9's weight gradient; in low-precision mode also direction 0's, which otherwise rides in the grouped launch)
-          ASTK_TRY(gemm_launch(GEMM_TN, lowp(gemm_args(4 * h, in, rows, mat(dzu, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, 1)), s));
+          // (the gathered copy holds the same values as dz: same maximum)
+          ASTK_TRY(gemm_launch(GEMM_TN, with_amax_b(with_amax_a(lowp(gemm_args(4 * h, in, rows, mat(dzu, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, 1)), adz), l == 0 ? ax : nullptr), s));
         } else {
           if (nwg == GEMM_GROUP_MAX) { ASTK_TRY(gemm_launch_group(GEMM_TN, wg, nwg, s)); nwg = 0; }
-          wg[nwg++] = gemm_args(4 * h, in, rows, mat(dzu, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, 1);
+          wg[nwg++] = with_amax_b(with_amax_a(gemm_args(4 * h, in, rows, mat(dzu, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, 1), adz), l == 0 ? ax : nullptr);
         }
       }
       ASTK_TRY(cb.add(g.db, dz, 4 * h, rows, 4 * h, s));
       // gradient wrt the layer input
       if (l > 0) {
-        if (!persist) ASTK_TRY(gemm_launch(GEMM_NN, gemm_args(rows, h, 4 * h, mat(dz, 4 * h), mat(p.Wu, h), P.DX[dd], h), s));
+        if (!persist) ASTK_TRY(gemm_launch(GEMM_NN, with_amax_a(gemm_args(rows, h, 4 * h, mat(dz, 4 * h), mat(p.Wu, h), P.DX[dd], h), adz), s));
       } else if (dx) {
         // dx (T,B,in) in frame order: direction 0 stores, direction 1 accumulates through the inverse permutation
         MatView A = dd == 0 ? mat(dz, 4 * h) : mat_idx(dz, 4 * h, rows_inv);
-        ASTK_TRY(gemm_launch(GEMM_NN, lowp(gemm_args(rows, in, 4 * h, A, mat(p.Wu, in), dx, in, nullptr, dd == 0 ? GEMM_STORE : GEMM_ACCUM)), s));
+        ASTK_TRY(gemm_launch(GEMM_NN, with_amax_a(lowp(gemm_args(rows, in, 4 * h, A, mat(p.Wu, in), dx, in, nullptr, dd == 0 ? GEMM_STORE : GEMM_ACCUM)), adz), s));
       }
     }
   }

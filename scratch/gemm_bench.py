@@ -10,7 +10,7 @@ def run(layout, M, N, K, iters=20, ks=1, mode=0):
     c = torch.zeros(M, N, device='cuda')
     lda, ldb = a.shape[1], b.shape[1]
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for _ in range(3): lib.astk_gemm_f32(layout, M, N, K, vp(a), lda, vp(b), ldb, vp(c), N, None, mode, ks, 1, 0, 0, 0, s)
+    for _ in range(3): assert lib.astk_gemm_f32(layout, M, N, K, vp(a), lda, vp(b), ldb, vp(c), N, None, mode, ks, 1, 0, 0, 0, s) == 0, _lib.last_error() if hasattr(_lib, 'last_error') else 'gemm failed'
     torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters): lib.astk_gemm_f32(layout, M, N, K, vp(a), lda, vp(b), ldb, vp(c), N, None, mode, ks, 1, 0, 0, 0, s)

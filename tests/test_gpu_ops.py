@@ -536,6 +536,36 @@ def test_gemm_random_shapes_against_float64(lib):
         assert np.array_equal(c[:, :, N:].cpu().numpy(), c0[:, :, N:].astype(np.float32)), msg + ": wrote outside N"
 
 
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("sa,sb", [(1e-20, 1e15), (3e7, 2e-3), (1.0, 1e-30)])
+def test_gemm_operand_magnitudes(lib, layout, sa, sb):
+    """The default GEMM splits every operand into two fp16 terms behind a per-operand power-of-two scale taken from an absolute-maximum
+    pass: operands far outside fp16's range must come out as accurately as N(0,1) ones, and rows 1e-4 below the operand's largest
+    entries must keep their own relative accuracy (22 significant bits down to 2^-17 of the maximum, gemm.hip)."""
+    rng = np.random.default_rng(int(abs(np.log10(sa))) + 31 * layout)
+    M, N, K = 150, 130, 333
+    rowscale = 10.0 ** (-(np.arange(M) % 5))
+    A = rng.standard_normal((M, K)) * rowscale[:, None] * sa
+    B = rng.standard_normal((N, K)) * sb
+    A32, B32 = A.astype(np.float32).astype(np.float64), B.astype(np.float32).astype(np.float64)
+    ref = A32 @ B32.T
+    pad = lambda n: (n + 3) // 4 * 4
+    def store(X, transpose):
+        X = X.T if transpose else X
+        P = np.zeros((X.shape[0], pad(X.shape[1])))
+        P[:, :X.shape[1]] = X
+        return P
+    Ad, Bd = store(A32, layout == 2), store(B32, layout != 0)
+    a, b = dev(Ad), dev(Bd)
+    c = torch.zeros(M, pad(N), device="cuda")
+    ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(a), Ad.shape[1], vp(b), Bd.shape[1], vp(c), c.shape[1], None, 0, 1, 1, 0, 0, 0, stream()))
+    got = c[:, :N].cpu().double().numpy()
+    rowmax = np.abs(ref).max(axis=1)
+    err = np.abs(got - ref).max(axis=1) / rowmax
+    assert np.isfinite(got).all()
+    assert err.max() < 2e-5, (layout, sa, sb, err.max(), int(err.argmax()))
+
+
 def test_optimizer_grad_scale_equals_scaling_first(lib):
     """astk_*_scaled read the gradient as grad_scale * g (the 1/world mean of data parallelism applied on the fly, rounded like a
     separate scaling pass would round it): same result as scaling the buffer first and calling the unscaled entry points, up to the
