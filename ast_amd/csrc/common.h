@@ -154,6 +154,8 @@ int gemm_launch(int layout, const GemmArgs& g, hipStream_t s);
 // The handle stays valid for the next 511 calls of gemm_amax; the matrix must not change between the pass and the launches.  A
 // maximum taken over a superset of the operand (more rows of the same buffer) is fine: it can only make the scale more conservative.
 const unsigned long long* gemm_amax(const float* p, long rows, long ld, int inner, hipStream_t s);
+struct AmaxMatrix { const float* p; long rows, ld; int inner; };
+void gemm_amax_many(const AmaxMatrix* m, int n, const unsigned long long** out, hipStream_t s);     // several matrices, one launch
 int low_precision_gemms();      // the mode set by astk_set_low_precision_gemms
 // Scoped cap on the co-resident GEMM workgroups per CU for launches made by this thread (0 = none): work that is meant to run
 // BESIDE a persistent recurrence kernel must leave registers free on every CU, or that kernel cannot become resident until the

@@ -482,12 +482,14 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
       const int Ci = P.Cn[i - 1], KT = d->kt[i], st = d->st[i], pt = d->pt[i];
       const long dyrow = (long)Tp * C;                                  // per (b,f) group of the padded dY
       const long hprow = (long)(P.Tn[i - 1] + 2 * P.padA[i - 1]) * Ci;  // per (b,f) group of HP[i-1]
+      // the padded dY feeds the weight gradient and every stride phase of the input gradient: one absolute-maximum pass (fp16x2 GEMM scale)
+      const unsigned long long* ady = gemm_amax(P.DY[i], (long)B * F, dyrow, (int)dyrow, s);
       // ---- wgrad: dWr[co][kt*Ci+ci] = sum_rows DY[row][co] * window(row)[k]
       {
         MatView A = mat2(P.DY[i] + (long)P.dF[i] * C, P.Tn[i], dyrow, C);
         MatView Bm = mat2(P.HP[i - 1], P.Tn[i], hprow, (long)st * Ci);
         const long tiles = (long)cdiv(C, 128) * cdiv(KT * Ci, 128);
-        ASTK_TRY(gemm_launch(GEMM_TN, lowp(gemm_args(C, KT * Ci, rows, A, Bm, P.dWr[i], (long)KT * Ci, nullptr, GEMM_ATOMIC, ksplit_for(tiles, rows))), s));
+        ASTK_TRY(gemm_launch(GEMM_TN, with_amax_a(lowp(gemm_args(C, KT * Ci, rows, A, Bm, P.dWr[i], (long)KT * Ci, nullptr, GEMM_ATOMIC, ksplit_for(tiles, rows))), ady), s));
       }
       hipLaunchKernelGGL(k_unpack_dw, dim3(gridn((size_t)C * Ci * KT)), dim3(256), 0, s, P.dWr[i], Gr[i].dW, C, Ci, KT);
       ASTK_LAUNCH_CHECK();
@@ -509,7 +511,7 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
         g.c_tn = nj;
         g.c_sg = (long)P.Tn[i - 1] * Ci;
         g.c_st = (long)st * Ci;
-        ASTK_TRY(gemm_launch(GEMM_NT, lowp(g), s));
+        ASTK_TRY(gemm_launch(GEMM_NT, with_amax_a(lowp(g), ady), s));
       }
     }
   }

@@ -158,7 +158,7 @@ __device__ __forceinline__ int scale_exp(const unsigned long long* amax) {
 // the four k rows of a transposing read land 16 banks apart), read with ds_read_b64_tr_b16.
 constexpr int sp_hs(int TL) { return TL * 16 + 16; }          // RK: k-half stride
 constexpr int sp_rs(int TL) { return TL * 2 + 64; }           // KR: k-row stride
-constexpr int sp_plane(int TL, bool RK) { return RK ? 2 * sp_hs(TL) : BK * sp_rs(TL); }
+constexpr int sp_plane(int TL, bool RK) { return RK ? (BK / 8) * sp_hs(TL) : BK * sp_rs(TL); }
 constexpr int sp_stage(int TL, bool RK, int prec = PREC_BF16X3) { return prec_planes(prec) * sp_plane(TL, RK); }
 
 // RING: register slots of staged tiles.  The f32 kernel keeps one tile in flight (an iteration is 2600 cycles and three workgroups per
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
       // refill(st, V, span, t, slot): tile t has just left register slot `slot` = t % RING; fetch tile t + RING into it.  K-contiguous
       // operands fetch PAIRS of tiles (Stager::load_pair) when the odd slot of a pair comes free.
       auto refill = [&](auto& st, const MatView& V, unsigned span, auto rkc, auto steadyc, const int t, const int slot) {
-        constexpr bool PAIR = decltype(rkc)::value && ASTK_GEMM_PAIR;
+        constexpr bool PAIR = decltype(rkc)::value && ASTK_GEMM_PAIR && BK == 16;
         constexpr bool STEADY = decltype(steadyc)::value;       // every tile asked for exists
         if constexpr (PAIR) {
           if (slot & 1) {
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
         }
       };
       auto prefetch = [&](auto& st, const MatView& V, unsigned span, auto rkc) {      // tiles 0 .. RING-1 of the range
-        constexpr bool PAIR = decltype(rkc)::value && ASTK_GEMM_PAIR;
+        constexpr bool PAIR = decltype(rkc)::value && ASTK_GEMM_PAIR && BK == 16;
         if constexpr (PAIR) {
 #pragma unroll
           for (int r = 0; r < RING; r += 2)
@@ -588,37 +588,42 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
             }
         __syncthreads();
         // operand fragments of v_mfma_f32_32x32x16_bf16: lane (r = lane & 31, h = lane >> 5) holds k = 8h .. 8h+7 of row / column r
-        auto frag = [&](const char* base, bool rk, auto tlc, int t0, int pl) -> bf16x8 {
+        auto frag = [&](const char* base, bool rk, auto tlc, int t0, int pl, int ks) -> bf16x8 {      // ks: 16-k step inside the tile
           constexpr int TLX = decltype(tlc)::value;          // tile edge of this operand
-          if (rk) return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + pl * sp_plane(TLX, true) + lk * sp_hs(TLX) + (t0 + li) * 16));
+          if (rk) return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + pl * sp_plane(TLX, true) + (2 * ks + lk) * sp_hs(TLX) + (t0 + li) * 16));
           // K-major image: two transposing reads (k = 8h .. 8h+3 and 8h+4 .. 8h+7) of a 4 k x 16 m block per 16-lane group
           const int g16 = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
-          const char* ad = base + pl * sp_plane(TLX, false) + (8 * lk + q) * sp_rs(TLX) + (t0 + 16 * g16 + 4 * pp) * 2;
+          const char* ad = base + pl * sp_plane(TLX, false) + (16 * ks + 8 * lk + q) * sp_rs(TLX) + (t0 + 16 * g16 + 4 * pp) * 2;
           typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
           const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ad));
           const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ad + 4 * sp_rs(TLX)));
           struct { s16x4 a, b; } pr = {v0, v1};
           return __builtin_bit_cast(bf16x8, pr);
         };
-        struct Frags { bf16x8 a[NAM][NPL], b[NA][NPL]; };
+        constexpr int NKS = BK / 16;        // MFMA k-steps per tile
+        struct Frags { bf16x8 a[NKS][NAM][NPL], b[NKS][NA][NPL]; };
         auto fetch = [&](Frags& f, int st) {
           const char* abase = stA(st);
           const char* bbase = stB(st);
 #pragma unroll
-          for (int pl = 0; pl < NPL; ++pl) {
+          for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-            for (int i = 0; i < NAM; ++i) f.a[i][pl] = frag(abase, A_RK, std::integral_constant<int, TLM>{}, wm * WTM + 32 * i, pl);
+            for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) f.b[i][pl] = frag(bbase, B_RK, std::integral_constant<int, TL>{}, wn * WT + 32 * i, pl);
-          }
+              for (int i = 0; i < NAM; ++i) f.a[ks][i][pl] = frag(abase, A_RK, std::integral_constant<int, TLM>{}, wm * WTM + 32 * i, pl, ks);
+#pragma unroll
+              for (int i = 0; i < NA; ++i) f.b[ks][i][pl] = frag(bbase, B_RK, std::integral_constant<int, TL>{}, wn * WT + 32 * i, pl, ks);
+            }
         };
         auto mult = [&](const Frags& f) {
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) {
           if constexpr (PREC == PREC_F16) {
 #pragma unroll
             for (int i = 0; i < NAM; ++i)
 #pragma unroll
               for (int i2 = 0; i2 < NA; ++i2)
-                acc[i][i2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[i][0]), __builtin_bit_cast(f16x8, f.b[i2][0]),
+                acc[i][i2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[ks][i][0]), __builtin_bit_cast(f16x8, f.b[ks][i2][0]),
                                                                     acc[i][i2], 0, 0, 0);
           } else if constexpr (PREC == PREC_F16X2) {
             constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};      // lo.hi, hi.lo -> acc2; hi.hi -> acc
@@ -629,7 +634,7 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
 #pragma unroll
                 for (int i2 = 0; i2 < NA; ++i2) {
                   f32x16& d = (ACC2 && t < 2) ? acc2[i][i2] : acc[i][i2];
-                  d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[i][PA[t]]), __builtin_bit_cast(f16x8, f.b[i2][PB[t]]), d, 0, 0, 0);
+                  d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[ks][i][PA[t]]), __builtin_bit_cast(f16x8, f.b[ks][i2][PB[t]]), d, 0, 0, 0);
                 }
           } else {
           // smallest terms first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
@@ -644,8 +649,9 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
             for (int i = 0; i < NAM; ++i)
 #pragma unroll
               for (int i2 = 0; i2 < NA; ++i2)
-                acc[i][i2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA[t]], f.b[i2][PB[t]], acc[i][i2], 0, 0, 0);
+                acc[i][i2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][i][PA[t]], f.b[ks][i2][PB[t]], acc[i][i2], 0, 0, 0);
           }
+        }
         };
         Frags f0, f1;
         fetch(f0, 0);
@@ -1023,7 +1029,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     for (int i = 0; i < grp.n; ++i) max_kt = std::max(max_kt, grp.g[i].kt);
     const bool small = grp.iters_total < 256L * wgs_per_cu(128) * 10 * (32 / BK) && (tiles < 192 || max_kt <= 12 * (16 / BK > 0 ? 16 / BK : 1));
     int want = force_tl == 64 || force_tl == 128 || force_tl == 256 ? force_tl : (small ? 64 : 128);   // (256 x 128 tiles: ASTK_GEMM_TILE=256 only -- measured slower)
-    if (want == 256 && prec != PREC_BF16X3) want = 128;
+    if (want == 256 && (prec != PREC_BF16X3 || BK != 16)) want = 128;
     if (want == 64 && prec == PREC_F16) want = 128;        // (the fp16 variant is instantiated for 128-tiles only)
     if (want == 128) break;
     TLM = want;
@@ -1126,7 +1132,8 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   } else if (prec == PREC_F16) { ASTK_GEMM_LAUNCH(128, PREC_F16, 128)
   } else if (prec == PREC_F16X2) {
     if (TL == 64) { ASTK_GEMM_LAUNCH(64, PREC_F16X2, 64) } else { ASTK_GEMM_LAUNCH(128, PREC_F16X2, 128) }
-  } else if (TLM == 256) { ASTK_GEMM_LAUNCH(128, PREC_BF16X3, 256)
+  } else if (TLM == 256) {
+    if constexpr (BK == 16) { ASTK_GEMM_LAUNCH(128, PREC_BF16X3, 256) }      // (three 256-row stages of a 32-deep tile do not fit LDS)
   } else if (TL == 64) { ASTK_GEMM_LAUNCH(64, PREC_BF16X3, 64)
   } else { ASTK_GEMM_LAUNCH(128, PREC_BF16X3, 128) }
 #undef ASTK_GEMM_LAUNCH
@@ -1136,17 +1143,33 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
 
 int gemm_launch(int layout, const GemmArgs& g, hipStream_t s) { return gemm_launch_group(layout, &g, 1, s); }
 
-const unsigned long long* gemm_amax(const float* p, long rows, long ld, int inner, hipStream_t s) {
-  if (default_prec() != PREC_F16X2 || !p || rows <= 0 || inner <= 0) return nullptr;
+void gemm_amax_many(const AmaxMatrix* m, int n, const unsigned long long** out, hipStream_t s) {
+  for (int i = 0; i < n; ++i) out[i] = nullptr;
   unsigned long long* ring = amax_ring();
-  if (!ring) return nullptr;
-  unsigned long long* slot = ring + AMAX_SLOTS / 2 + (g_amax_handle.fetch_add(1) % (AMAX_SLOTS / 2 / AMAX_SHARDS)) * AMAX_SHARDS;
+  if (default_prec() != PREC_F16X2 || !ring) return;
   AmaxJobs J;
   memset(&J, 0, sizeof(J));
   J.gen = g_amax_counter.fetch_add(1);
-  amax_add(J, mat(p, ld), false, (int)rows, inner, 1, 0, 0, slot);
-  hipLaunchKernelGGL(k_absmax, dim3((unsigned)J.blk_start[J.n]), dim3(256), 0, s, J);
-  return slot;
+  for (int i = 0; i < n; ++i) {
+    if (!m[i].p || m[i].rows <= 0 || m[i].inner <= 0) continue;
+    if (J.n + 2 > AMAX_REGIONS) {          // (two regions per contiguous matrix)
+      hipLaunchKernelGGL(k_absmax, dim3((unsigned)J.blk_start[J.n]), dim3(256), 0, s, J);
+      const unsigned gen = J.gen;
+      memset(&J, 0, sizeof(J));
+      J.gen = gen;
+    }
+    unsigned long long* slot = ring + AMAX_SLOTS / 2 + (g_amax_handle.fetch_add(1) % (AMAX_SLOTS / 2 / AMAX_SHARDS)) * AMAX_SHARDS;
+    amax_add(J, mat(m[i].p, m[i].ld), false, (int)m[i].rows, m[i].inner, 1, 0, 0, slot);
+    out[i] = slot;
+  }
+  if (J.n > 0) hipLaunchKernelGGL(k_absmax, dim3((unsigned)J.blk_start[J.n]), dim3(256), 0, s, J);
+}
+
+const unsigned long long* gemm_amax(const float* p, long rows, long ld, int inner, hipStream_t s) {
+  const AmaxMatrix m = {p, rows, ld, inner};
+  const unsigned long long* h = nullptr;
+  gemm_amax_many(&m, 1, &h, s);
+  return h;
 }
 
 }  // namespace astk

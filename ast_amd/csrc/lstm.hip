@@ -328,7 +328,23 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
   }
   GemmArgs wg[GEMM_GROUP_MAX];   // weight-gradient products, issued as grouped launches
   int nwg = 0;
-  const unsigned long long* ax = gemm_amax(x, (long)T * B, P.in, P.in, s);      // the frames: B operand of both directions' layer-0 dWu
+  // Absolute maxima (fp16x2 GEMM scales) of the matrices that feed several products, one launch when dz of every cell is final already:
+  // the frames (B operand of both directions' layer-0 dWu) and every cell's dz (dWl, dWu, input gradient).
+  const unsigned long long* ax = nullptr;
+  const unsigned long long* adz_all[16] = {nullptr};
+  {
+    AmaxMatrix am[17];
+    const unsigned long long* out[17];
+    int n = 0;
+    am[n++] = AmaxMatrix{x, (long)T * B, (long)P.in, P.in};
+    if (persist)
+      for (int dd = 0; dd < P.nd; ++dd)
+        for (int l = 0; l < P.nl; ++l) am[n++] = AmaxMatrix{P.ZG[dd][l], (long)T * B, 4L * h, 4 * h};
+    gemm_amax_many(am, n, out, s);
+    ax = out[0];
+    if (persist)
+      for (int i = 1; i < n; ++i) adz_all[i - 1] = out[i];
+  }
   ColsumBatch cb;                // bias gradients of all cells: one launch (dz of every cell is final when the recurrence kernel has run)
   for (int l = P.nl - 1; l >= 0; --l) {
     const bool top = l == P.nl - 1;
@@ -374,7 +390,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
       const float* dz = P.ZG[dd][l];
       const int rows = T * B;
       // dz feeds up to three products (dWl, dWu, the input gradient): one absolute-maximum pass for all of them
-      const unsigned long long* adz = gemm_amax(dz, rows, 4 * h, 4 * h, s);
+      const unsigned long long* adz = persist ? adz_all[dd * P.nl + l] : gemm_amax(dz, rows, 4 * h, 4 * h, s);
       // dWl (4h,h) += sum_{i>=1} dz_i^T h_{i-1}
       if (T > 1) {
         if (nwg == GEMM_GROUP_MAX) { ASTK_TRY(gemm_launch_group(GEMM_TN, wg, nwg, s)); nwg = 0; }
