@@ -1147,6 +1147,7 @@ void gemm_amax_many(const AmaxMatrix* m, int n, const unsigned long long** out, 
   for (int i = 0; i < n; ++i) out[i] = nullptr;
   unsigned long long* ring = amax_ring();
   if (default_prec() != PREC_F16X2 || !ring) return;
+  ProfScope prof(PROF_GEMM, s, 0.0);       // part of the GEMMs' cost: timed with them (no flops of its own)
   AmaxJobs J;
   memset(&J, 0, sizeof(J));
   J.gen = g_amax_counter.fetch_add(1);

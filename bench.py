@@ -217,22 +217,28 @@ def main():
             # THE dominant kernel family (half of the step): every batched dense product of the step on f32-input MFMA
             tfl = res[6] / (res[4] * 1e-3) / 1e12
             ms_gemm, n_gemm = res[4] / args.profile_steps, int(res[5] / args.profile_steps)
-            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<NT|NN|TN> + k_zero_split_tiles (all batched dense products of the step)",
+            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<NT|NN|TN> + k_absmax + k_zero_split_tiles (all batched dense products of the step)",
                     "achieved": round(tfl, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
                     "traffic": profile_json("gemm_traffic.json").get("hbm_bytes_per_step"),
                     "flops_per_step": round(res[6] / args.profile_steps), "ms_per_step": round(ms_gemm, 3),
                     "avg_launch_us": round(ms_gemm * 1e3 / max(1, n_gemm), 1), "launches_per_step": n_gemm,
                     "method": "2*M*N*K per launch / HIP events around every launch on the launch stream; traffic = FETCH_SIZE*2 + WRITE_SIZE "
                               "of the same kernels from separate rocprofv3 --pmc passes (profiles/), per step"}
-            prec_env = os.environ.get("ASTK_GEMM_PREC", "bf16x3")
-            if prec_env != "f32":
-                # how the products execute: f32 operands split into three bf16 terms, six v_mfma_f32_32x32x16_bf16 per 16 k (f32-level
-                # accuracy); `peak` above stays the f32-input MFMA peak the useful flops are priced against
-                roof["executed"] = {"scheme": "bf16x3 split (6 bf16 MFMAs per useful product block); fp16 single-term for the CNN / encoder-input "
-                                              "GEMMs when --gemm-operands fp16" if args.gemm_operands == "fp16" else "bf16x3 split (6 bf16 MFMAs per useful product block)",
-                                    "bf16_tflops": round(tfl * 6, 1), "bf16_peak_tflops": 2500.0, "frac_of_bf16_peak": round(tfl * 6 / 2500.0, 4)}
-            else:
+            prec_env = os.environ.get("ASTK_GEMM_PREC", "fp16x2")
+            if prec_env == "f32":
                 roof["executed"] = {"scheme": "exact f32 chain on v_mfma_f32_32x32x2_f32"}
+            else:
+                # how the products execute: every f32 operand is split in the kernel into 16-bit terms whose partial products sum to the
+                # f32-accurate product -- fp16x2: two fp16 terms behind a per-operand power-of-two scale (absolute-maximum pass inside the
+                # timed scope), 3 v_mfma_f32_32x32x16_f16 per 16 k; bf16x3 (ASTK_GEMM_PREC=bf16x3): three bf16 terms, 6 MFMAs.  `peak`
+                # above stays the f32-input MFMA peak the useful flops are priced against (the scheme may exceed it).
+                nprod = 6 if prec_env == "bf16x3" else 3
+                scheme = ("bf16x3 split (6 bf16 MFMAs per useful product block)" if prec_env == "bf16x3" else
+                          "fp16x2 split (3 fp16 MFMAs per useful product block; scales from an absolute-maximum pass, timed with the GEMMs)")
+                if args.gemm_operands == "fp16":
+                    scheme += "; single-term fp16 for the CNN / encoder-input GEMMs (--gemm-operands fp16)"
+                roof["executed"] = {"scheme": scheme, "mfma_16bit_tflops": round(tfl * nprod, 1), "mfma_16bit_peak_tflops": 2500.0,
+                                    "frac_of_16bit_peak": round(tfl * nprod / 2500.0, 4)}
         if res[17] > 0 and res[19] > 0:
             # Attention scan (north_star's "HBM roofline on the attention scan").  The scan is a PHASE of the two persistent decoder
             # launches, not a launch of its own, and its enc / encA slices are LDS-resident after step 0: the launches are LATENCY-bound

@@ -15,7 +15,7 @@ steps = int(sys.argv[2])          # train steps profiled in each pass (all of th
 
 
 def short(name):
-    for key in ("gemm_f32_kernel", "decoder_persist_fwd", "decoder_persist_bwd", "lstm_persist_fwd_g", "lstm_persist_bwd_rs", "k_zero_split_tiles"):
+    for key in ("gemm_f32_kernel", "decoder_persist_fwd", "decoder_persist_bwd", "lstm_persist_fwd_g", "lstm_persist_bwd_rs", "k_zero_split_tiles", "k_absmax"):
         if key in name:
             return key
     return None
@@ -67,4 +67,18 @@ for k in sorted(set(fetch) | set(write) | set(sq)):
         e["mfma_pipe_busy_frac"] = round(sum(sq[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024.0 / (sum(sq[k]["GRBM_GUI_ACTIVE"]) / 8.0), 4)
     res["kernels"][k] = e
 json.dump(res, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1)
+# what bench.py reads for roofline.traffic / roofline_scan.traffic
+K = res["kernels"]
+gem = sum(K[k].get("hbm_bytes_per_step", 0) for k in ("gemm_f32_kernel", "k_zero_split_tiles", "k_absmax") if k in K)
+json.dump({"hbm_bytes_per_step": gem,
+           "source": "pmc_summary.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of gemm_f32_kernel + k_absmax + k_zero_split_tiles per train step; the "
+                     "memory-side counters include Infinity-Cache hits (MI355X_MICROARCH.md, HBM)"},
+          open(os.path.join(root, "gemm_traffic.json"), "w"), indent=1)
+if "decoder_persist_fwd" in K and "decoder_persist_bwd" in K:
+    scans = 78
+    dec = K["decoder_persist_fwd"].get("hbm_bytes_per_dispatch", 0) + K["decoder_persist_bwd"].get("hbm_bytes_per_dispatch", 0)
+    json.dump({"hbm_bytes_per_launch": round(dec / scans),
+               "source": "pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE of decoder_persist_fwd + decoder_persist_bwd, / 78 scans): everything the two "
+                         "launches move, an upper bound for the scan phase"},
+              open(os.path.join(root, "attn_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -14,6 +14,8 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/sq -- $B > $OUT/sq.log 2>&1
 python3 scratch/pmc_summarize.py $OUT 4 > $OUT/pmc_summary.log 2>&1
 ASTK_PERSIST_DBG=8 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 0 > $OUT/phase_stamps.log 2>&1
+ASTK_GEMM_PREC=bf16x3 python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline > $OUT/bench_bf16x3.log 2>&1
+ASTK_GEMM_PREC=f32 python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline > $OUT/bench_f32.log 2>&1
 python3 bench.py --steps 50 --warmup 10 > $OUT/bench_default.log 2>&1
 python3 bench.py --model es_en_20h --steps 50 --warmup 10 > $OUT/bench_es_en_20h.log 2>&1
 # keep the summaries, drop the bulky per-dispatch traces
