@@ -79,6 +79,50 @@ __device__ __forceinline__ void abort_raise(const AbortCtl& ab) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- fp16x2 products (device side; gemm.hip describes the scheme): an f32 value times a power-of-two scale is split into two fp16
+// terms, x s = hi + lo, and a product is summed from lo.hi + hi.lo + hi.hi on the fp16 MFMAs with f32 accumulation.
+#if defined(__HIPCC__)
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32q __attribute__((ext_vector_type(4)));
+typedef float f32pair __attribute__((ext_vector_type(2)));
+// two values -> one dword of the hi plane and one of the lo plane (5 vector-ALU instructions: v_pk_mul_f32, v_cvt_pk_f16_f32, two
+// v_fma_mix_f32 reading the fp16 halves in place, v_cvt_pk_f16_f32)
+__device__ __forceinline__ void split2h(float x0, float x1, float scl, unsigned& hi, unsigned& lo) {
+  const f32pair xs = (f32pair){x0, x1} * (f32pair){scl, scl};
+  const h16x2 h = {(_Float16)xs[0], (_Float16)xs[1]};
+  hi = __builtin_bit_cast(unsigned, h);
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(xs[0]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(xs[1]));
+  const h16x2 l = {(_Float16)r0, (_Float16)r1};
+  lo = __builtin_bit_cast(unsigned, l);
+}
+// eight values (two float4: k = 0..3 and 4..7 of a lane's slice of a v_mfma_f32_16x16x32_f16 operand) -> hi / lo fragments
+struct HL8 { u32q hi, lo; };
+__device__ __forceinline__ HL8 split8(const float4& a, const float4& b, float scl) {
+  HL8 o;
+  unsigned h, l;
+  split2h(a.x, a.y, scl, h, l); o.hi.x = h; o.lo.x = l;
+  split2h(a.z, a.w, scl, h, l); o.hi.y = h; o.lo.y = l;
+  split2h(b.x, b.y, scl, h, l); o.hi.z = h; o.lo.z = l;
+  split2h(b.z, b.w, scl, h, l); o.hi.w = h; o.lo.w = l;
+  return o;
+}
+// acc += A B over 32 k on v_mfma_f32_16x16x32_f16, three term products (smallest first)
+#define MFMA32H(ACC, A, W)                                                                                                                    \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, (A).lo), __builtin_bit_cast(h16x8, (W).hi), ACC, 0, 0, 0);          \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, (A).hi), __builtin_bit_cast(h16x8, (W).lo), ACC, 0, 0, 0);          \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, (A).hi), __builtin_bit_cast(h16x8, (W).hi), ACC, 0, 0, 0);
+// The power of two (as a float) that brings an absolute maximum into [2^13, 2^14), and its reciprocal; 1 for a zero maximum.
+__device__ __forceinline__ float pow2_scale_for(float amax, float& inv) {
+  const int e = (int)(__float_as_uint(amax) >> 23) & 0xff;
+  const int se = e == 0 ? 127 : min(max(267 - e, 1), 253);
+  inv = __uint_as_float((unsigned)(254 - se) << 23);
+  return __uint_as_float((unsigned)se << 23);
+}
+#endif
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -154,6 +198,9 @@ int gemm_launch(int layout, const GemmArgs& g, hipStream_t s);
 // The handle stays valid for the next 511 calls of gemm_amax; the matrix must not change between the pass and the launches.  A
 // maximum taken over a superset of the operand (more rows of the same buffer) is fine: it can only make the scale more conservative.
 const unsigned long long* gemm_amax(const float* p, long rows, long ld, int inner, hipStream_t s);
+// For a kernel that takes the maximum of a matrix while it writes it: n handles (16 sharded 64-bit words each) and the generation
+// tag; the kernel does atomicMax(slot + (block & 15), (u64)gen << 32 | float_bits(block maximum)) from every block.
+void gemm_amax_reserve(int n, unsigned long long** slots, unsigned* gen);
 struct AmaxMatrix { const float* p; long rows, ld; int inner; };
 void gemm_amax_many(const AmaxMatrix* m, int n, const unsigned long long** out, hipStream_t s);     // several matrices, one launch
 int low_precision_gemms();      // the mode set by astk_set_low_precision_gemms

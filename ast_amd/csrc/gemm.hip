@@ -36,9 +36,6 @@ constexpr int BK = ASTK_GEMM_BK;
 #ifndef ASTK_GEMM_PAIR
 #define ASTK_GEMM_PAIR 1        // K-contiguous operands: fetch two k-tiles (one 128-byte line per row) at a time
 #endif
-#ifndef ASTK_GEMM_F16X2_ACC2
-#define ASTK_GEMM_F16X2_ACC2 0
-#endif
 #ifndef ASTK_GEMM_X3_WGS
 #define ASTK_GEMM_X3_WGS 1
 #endif
@@ -101,11 +98,11 @@ __host__ __device__ __forceinline__ long wg_first_iter(const GemmGroup& grp, uns
 // v_mfma_f32_32x32x16_f16 per tile and 16 k, f32 accumulation.  Reduced precision (11 significant bits): only launches their caller marks
 // low-precision-eligible take it, and only when astk_set_low_precision_gemms(1) is in force.
 // PREC_F16X2: every operand is scaled by a power of two s (its absolute maximum lands in [2^13, 2^14): fp16 has only 5 exponent bits)
-// and split into TWO fp16 terms, x s = hi + lo / 2048 with hi = fp16_rtz(x s), lo = fp16((x s - hi) 2048): 22 significant bits for
-// every value down to 2^-28 of the operand's maximum, an absolute floor of 2^-50 of the maximum below that.  A product is summed
-// from three of the four term products on v_mfma_f32_32x32x16_f16 (hi.hi into one accumulator set, hi.lo + lo.hi into a second one that
-// enters with the factor 2^-11 in the epilogue; lo.lo <= 2^-22 |a b| is dropped): HALF the matrix-pipe work of bf16x3 at an error of
-// 2^-22 per product.  The scales come from an absolute-maximum pass over both operands in front of the launch (gemm_absmax).
+// and split into TWO fp16 terms, x s = hi + lo with hi = fp16(x s), lo = fp16(x s - hi), both round-to-nearest-even (common.h:
+// split2h): 22 significant bits for every value down to 2^-17 of the operand's maximum, an absolute floor of 2^-39 of the maximum below
+// that.  A product is summed from three of the four term products on v_mfma_f32_32x32x16_f16 (lo.hi + hi.lo + hi.hi; lo.lo <= 2^-22 |a b|
+// is dropped) and unscaled by 1 / (s_A s_B) in the epilogue: HALF the matrix-pipe work of bf16x3 at an error of 2^-22 per product.  The
+// scales come from an absolute-maximum pass over both operands in front of the launch (k_absmax) or from the caller (gemm_amax).
 enum GemmPrec { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_F16 = 2, PREC_F16X2 = 3 };
 constexpr int prec_planes(int prec) { return prec == PREC_BF16X3 ? 3 : (prec == PREC_F16X2 ? 2 : 1); }
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -124,23 +121,6 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
   mid = cvt_pk_bf16(r0, r1);
   const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
   lo = cvt_pk_bf16(s0, s1);
-}
-// fp16x2: two values times the operand's scale -> one dword of the hi plane and one of the lo plane.  Five vector-ALU instructions per
-// pair: v_pk_mul_f32 (scale), v_cvt_pkrtz_f16_f32 (hi, truncated: the residual carries what truncation leaves), two v_fma_mix_f32
-// (residual = x s - hi, reading the fp16 halves directly) and v_cvt_pk_f16_f32 (lo, round-to-nearest-even).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split2h(float x0, float x1, float scl, unsigned& hi, unsigned& lo) {
-  const f32x2 xs = (f32x2){x0, x1} * (f32x2){scl, scl};
-  const f16x2 h = {(_Float16)xs[0], (_Float16)xs[1]};
-  hi = __builtin_bit_cast(unsigned, h);
-  float r0, r1;      // (hipcc converts the halves back with v_cvt_f32_f16 before a packed fma; the mix form reads them in place)
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(xs[0]));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(xs[1]));
-#if ASTK_GEMM_F16X2_ACC2
-  r0 *= 2048.f; r1 *= 2048.f;
-#endif
-  const f16x2 l = {(_Float16)r0, (_Float16)r1};
-  lo = __builtin_bit_cast(unsigned, l);
 }
 // The power of two that brings an operand's absolute maximum into [2^13, 2^14), as the biased exponent of a float (amax: the word
 // gemm_absmax left: launch generation in the high half, the maximum's float bits in the low half; null or zero maximum: 1.0).
@@ -573,19 +553,13 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
         }
       } else {
         // (the accumulators live in this branch only: the staging waves' code path must not carry 128 registers of them)
-        constexpr bool ACC2 = PREC == PREC_F16X2 && ASTK_GEMM_F16X2_ACC2;
-        constexpr int NA2 = ACC2 ? NA : 0, NAM2 = ACC2 ? NAM : 0;
         f32x16 acc[NAM][NA];
-        f32x16 acc2[NAM2 + 1][NA2 + 1];        // fp16x2: the hi.lo + lo.hi sums (scaled by 2^11)
 #pragma unroll
         for (int i = 0; i < NAM; ++i)
 #pragma unroll
           for (int j = 0; j < NA; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              acc[i][j][r] = 0.f;
-              if constexpr (ACC2) acc2[i][j][r] = 0.f;
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         __syncthreads();
         // operand fragments of v_mfma_f32_32x32x16_bf16: lane (r = lane & 31, h = lane >> 5) holds k = 8h .. 8h+7 of row / column r
         auto frag = [&](const char* base, bool rk, auto tlc, int t0, int pl, int ks) -> bf16x8 {      // ks: 16-k step inside the tile
@@ -626,16 +600,14 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
                 acc[i][i2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[ks][i][0]), __builtin_bit_cast(f16x8, f.b[ks][i2][0]),
                                                                     acc[i][i2], 0, 0, 0);
           } else if constexpr (PREC == PREC_F16X2) {
-            constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};      // lo.hi, hi.lo -> acc2; hi.hi -> acc
+            constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};      // lo.hi, hi.lo, hi.hi
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
               for (int i = 0; i < NAM; ++i)
 #pragma unroll
-                for (int i2 = 0; i2 < NA; ++i2) {
-                  f32x16& d = (ACC2 && t < 2) ? acc2[i][i2] : acc[i][i2];
-                  d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[ks][i][PA[t]]), __builtin_bit_cast(f16x8, f.b[ks][i2][PB[t]]), d, 0, 0, 0);
-                }
+                for (int i2 = 0; i2 < NA; ++i2)
+                  acc[i][i2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[ks][i][PA[t]]), __builtin_bit_cast(f16x8, f.b[ks][i2][PB[t]]), acc[i][i2], 0, 0, 0);
           } else {
           // smallest terms first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
           constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
@@ -683,7 +655,7 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
 #pragma unroll
             for (int j = 0; j < NA; ++j)
 #pragma unroll
-              for (int r = 0; r < 16; ++r) acc[i][j][r] = (ACC2 ? fmaf(acc2[i][j][r], 1.f / 2048.f, acc[i][j][r]) : acc[i][j][r]) * ia * ib;
+              for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * ia * ib;
         }
         epilogue(acc);        // meanwhile the staging waves run the next tile's prologue
       }
@@ -1164,6 +1136,14 @@ void gemm_amax_many(const AmaxMatrix* m, int n, const unsigned long long** out, 
     out[i] = slot;
   }
   if (J.n > 0) hipLaunchKernelGGL(k_absmax, dim3((unsigned)J.blk_start[J.n]), dim3(256), 0, s, J);
+}
+
+void gemm_amax_reserve(int n, unsigned long long** slots, unsigned* gen) {
+  unsigned long long* ring = amax_ring();
+  const bool on = default_prec() == PREC_F16X2 && ring != nullptr;
+  *gen = on ? g_amax_counter.fetch_add(1) : 0;
+  for (int i = 0; i < n; ++i)
+    slots[i] = on ? ring + AMAX_SLOTS / 2 + (g_amax_handle.fetch_add(1) % (AMAX_SLOTS / 2 / AMAX_SHARDS)) * AMAX_SHARDS : nullptr;
 }
 
 const unsigned long long* gemm_amax(const float* p, long rows, long ld, int inner, hipStream_t s) {

@@ -25,13 +25,15 @@ struct PersistCellHost {
   const float* PD_up;
   int up_external;
   int reverse_pos, layer;
+  unsigned long long* amax;
 };
 bool lstm_persist_applicable(int T, int B, int h, int nl, int nd);
 int lstm_persist_layers_per_launch(int B, int h, int nl, int nd);
 size_t lstm_persist_pr_floats(int B, int h);
 size_t lstm_persist_pd_floats(int T, int B, int h);
 int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters, hipStream_t s);
-int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters, hipStream_t s);
+int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters, unsigned amax_gen,
+                            hipStream_t s);
 
 namespace {
 
@@ -272,6 +274,8 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
   const size_t bh = (size_t)B * h;
   const bool persist = lstm_persist_applicable(T, B, h, P.nl, P.nd);
   const bool rs_path = persist;
+  unsigned long long* dz_amax[16] = {nullptr};
+  unsigned dz_amax_gen = 0;
   if (persist) {
     PersistCellHost cells[16];
     memset(cells, 0, sizeof(cells));
@@ -305,6 +309,9 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
         c.reverse_pos = dd == 1;
         c.layer = l;
       }
+    // the recurrence kernel leaves max |dz| of every cell for the batched products behind it (fp16x2 GEMM scales)
+    gemm_amax_reserve(P.nd * P.nl, dz_amax, &dz_amax_gen);
+    for (int i = 0; i < P.nd * P.nl; ++i) cells[i].amax = dz_amax[i];
     ASTK_TRY(stream_order(s, sr));     // the recurrence kernel may live on its own (CU-masked) stream, see astk.h
     {
       // groups of layers, top group first; the top layer of a lower group reads the partial dx tiles the previous launch left
@@ -320,7 +327,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
             grp[dd * ngl + l] = cells[dd * P.nl + l0 + l];
             if (l == ngl - 1 && l1 < P.nl) grp[dd * ngl + l].up_external = 1;
           }
-        ASTK_TRY(lstm_persist_bwd_launch(grp, P.nd * ngl, ngl, T, B, h, H, P.counters, sr));
+        ASTK_TRY(lstm_persist_bwd_launch(grp, P.nd * ngl, ngl, T, B, h, H, P.counters, dz_amax_gen, sr));
         l1 = l0;
       }
     }
@@ -328,23 +335,12 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
   }
   GemmArgs wg[GEMM_GROUP_MAX];   // weight-gradient products, issued as grouped launches
   int nwg = 0;
-  // Absolute maxima (fp16x2 GEMM scales) of the matrices that feed several products, one launch when dz of every cell is final already:
-  // the frames (B operand of both directions' layer-0 dWu) and every cell's dz (dWl, dWu, input gradient).
-  const unsigned long long* ax = nullptr;
+  // Absolute maxima (fp16x2 GEMM scales) of the matrices that feed several products: the frames (B operand of both directions'
+  // layer-0 dWu) by a pass here, every cell's dz (dWl, dWu, input gradient) by the recurrence kernel itself on the persistent path.
+  const unsigned long long* ax = gemm_amax(x, (long)T * B, P.in, P.in, s);
   const unsigned long long* adz_all[16] = {nullptr};
-  {
-    AmaxMatrix am[17];
-    const unsigned long long* out[17];
-    int n = 0;
-    am[n++] = AmaxMatrix{x, (long)T * B, (long)P.in, P.in};
-    if (persist)
-      for (int dd = 0; dd < P.nd; ++dd)
-        for (int l = 0; l < P.nl; ++l) am[n++] = AmaxMatrix{P.ZG[dd][l], (long)T * B, 4L * h, 4 * h};
-    gemm_amax_many(am, n, out, s);
-    ax = out[0];
-    if (persist)
-      for (int i = 1; i < n; ++i) adz_all[i - 1] = out[i];
-  }
+  if (persist)
+    for (int i = 0; i < P.nd * P.nl; ++i) adz_all[i] = dz_amax[i];
   ColsumBatch cb;                // bias gradients of all cells: one launch (dz of every cell is final when the recurrence kernel has run)
   for (int l = P.nl - 1; l >= 0; --l) {
     const bool top = l == P.nl - 1;

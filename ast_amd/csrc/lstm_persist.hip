@@ -67,11 +67,13 @@ struct PCellB {
   int up_external;      // PD_up was completed by an EARLIER launch (layer groups): read it without waiting on a counter of this launch
   int reverse_pos;
   int layer;
+  u64* amax;            // 16 sharded words for max |dz| of this cell (the fp16x2 GEMMs' operand scale, gemm_amax_reserve), or null
 };
 struct PBwdArgs {
   PCellB c[16];
   int ncells, nl, T, B, h, H;
   int dbg;
+  unsigned amax_gen;    // generation tag of the maxima (high half of the words)
   unsigned* done;
   AbortCtl ab;
 };
@@ -126,6 +128,49 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
   _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) ACC[g_] = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).y, (W)[g_].y, ACC[g_], 0, 0, 0); \
   _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) ACC[g_] = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).z, (W)[g_].z, ACC[g_], 0, 0, 0); \
   _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) ACC[g_] = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).w, (W)[g_].w, ACC[g_], 0, 0, 0);
+
+// fp16x2 form of the recurrences' products (ASTK_PERSIST_F16X2, default on): the weights a workgroup keeps in registers are split ONCE
+// into fp16 hi / lo fragments behind a per-workgroup power-of-two scale, the 16 x K activation fragments of a step are split when they
+// arrive (scale 2^10: |h| < 1 and a dropped-out input is at most 1 / (1 - p)), and 32 k of a product are three
+// v_mfma_f32_16x16x32_f16 of 16 cycles instead of eight v_mfma_f32_16x16x4_f32 of 32: the matrix part of a step's critical path drops
+// from 0.93 us to 0.18 us at the same 2^-22 product accuracy as the batched GEMMs (gemm.hip).
+#ifndef ASTK_PERSIST_F16X2
+#define ASTK_PERSIST_F16X2 1
+#endif
+constexpr float ACT_SCALE = 1024.f, ACT_SCALE_INV = 1.f / 1024.f;
+// four independent accumulators (the gates) interleaved, three term products of 32 k each
+#define MFMA32HG(ACC, A, W)                                                                                                     \
+  _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                                                              \
+    ACC[g_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, (A).lo), __builtin_bit_cast(h16x8, (W)[g_].hi), ACC[g_], 0, 0, 0); \
+  _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                                                              \
+    ACC[g_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, (A).hi), __builtin_bit_cast(h16x8, (W)[g_].lo), ACC[g_], 0, 0, 0); \
+  _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                                                              \
+    ACC[g_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, (A).hi), __builtin_bit_cast(h16x8, (W)[g_].hi), ACC[g_], 0, 0, 0);
+// workgroup-wide maximum of a per-thread value (256 threads; `red` = 4 floats of LDS scratch; ends with a barrier)
+__device__ __forceinline__ float wg_max(float m, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  return m;
+}
+// maximum over the 64 lanes of a wave of a NON-NEGATIVE value, in every lane: five v_max_f32 with DPP row / bank operands and one
+// cross-half readlane (a ds_bpermute butterfly costs an LDS round trip per step)
+__device__ __forceinline__ float wave_max_nonneg(float m) {
+  int v = __float_as_int(m);
+#define DPP_MAX_STEP(ctrl) v = __float_as_int(fmaxf(__int_as_float(v), __int_as_float(__builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, true))));
+  DPP_MAX_STEP(0x111)   // row_shr:1
+  DPP_MAX_STEP(0x112)   // row_shr:2
+  DPP_MAX_STEP(0x114)   // row_shr:4
+  DPP_MAX_STEP(0x118)   // row_shr:8   -> lane 15 of every row of 16 holds the row's maximum
+#undef DPP_MAX_STEP
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(v, 15)), r1 = __int_as_float(__builtin_amdgcn_readlane(v, 31));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(v, 47)), r3 = __int_as_float(__builtin_amdgcn_readlane(v, 63));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ float amax4f(float m, const float4& v) { return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); }
 
 // ------------------------------------------------------------------ forward, sentinel hand-off
 // ---- tag-free hand-off: the data is the flag.
@@ -188,17 +233,43 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
   const int m0 = bt * 16;
   bool dead = false;
 
+  auto wl_at = [&](int i, int g) { return *reinterpret_cast<const float4*>(c.Wl + (long)(4 * (j0 + r) + g) * h + 16 * (wave + 4 * i) + 4 * q); };
+  auto wu_at = [&](int i, int g) { return *reinterpret_cast<const float4*>(c.Wu + (long)(4 * (j0 + r) + g) * h + 16 * (wave + 4 * i) + 4 * q); };
+#if ASTK_PERSIST_F16X2
+  // the resident weights as fp16 hi / lo fragments of v_mfma_f32_16x16x32_f16: 16-k blocks i, i+1 of this wave form one 32-k operand
+  // (the k order inside a product is free as long as activations and weights agree); one scale for the workgroup's whole slice.
+  // Two sweeps over the slice (maximum, then split): holding the f32 values and their fragments at once would take 512 registers.
+  constexpr int NPR = (KB + 1) / 2;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float zscale;
+  HL8 wlh[NPR][4], wuh[HAS_UP ? NPR : 1][4];
+  {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < KB; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { m = amax4f(m, wl_at(i, g)); if (HAS_UP) m = amax4f(m, wu_at(i, g)); }
+    float winv;
+    const float wscl = pow2_scale_for(wg_max(m, red0), winv);
+    zscale = winv * ACT_SCALE_INV;
+#pragma unroll
+    for (int p = 0; p < NPR; ++p)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        wlh[p][g] = split8(wl_at(2 * p, g), 2 * p + 1 < KB ? wl_at(2 * p + 1, g) : zero4, wscl);
+        if (HAS_UP) wuh[p][g] = split8(wu_at(2 * p, g), 2 * p + 1 < KB ? wu_at(2 * p + 1, g) : zero4, wscl);
+      }
+  }
+#else
   float4 wl[KB][4], wu[HAS_UP ? KB : 1][4];
 #pragma unroll
-  for (int i = 0; i < KB; ++i) {
-    const int s = wave + 4 * i;
+  for (int i = 0; i < KB; ++i)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const long row = 4 * (j0 + r) + g;
-      wl[i][g] = *reinterpret_cast<const float4*>(c.Wl + row * h + 16 * s + 4 * q);
-      if (HAS_UP) wu[i][g] = *reinterpret_cast<const float4*>(c.Wu + row * h + 16 * s + 4 * q);
+      wl[i][g] = wl_at(i, g);
+      if (HAS_UP) wu[i][g] = wu_at(i, g);
     }
-  }
+#endif
   const __amdgpu_buffer_rsrc_t r_own = make_rsrc(c.HR);
   const __amdgpu_buffer_rsrc_t r_below = make_rsrc(HAS_UP ? c.xin : c.HR);
   const int arow = min(m0 + r, B - 1);
@@ -214,6 +285,15 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
   const int frag0 = (arow * h + 4 * q) * 4;   // byte offset of this lane's fragment row at step 0
   u32x4 gx[KB];
   float4 ax[KB];
+#if ASTK_PERSIST_F16X2
+  HL8 axh[NPR];
+  auto take_x = [&]() {
+#pragma unroll
+    for (int p = 0; p < NPR; ++p) axh[p] = split8(ax[2 * p], 2 * p + 1 < KB ? ax[2 * p + 1] : zero4, ACT_SCALE);
+  };
+#else
+  auto take_x = [&]() {};
+#endif
   // what only later launches read, stored half a step late
   float4 p_gates = make_float4(0.f, 0.f, 0.f, 0.f);
   float p_hd = 0.f, p_c = 0.f;
@@ -242,6 +322,7 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
     if (!frag_ok<KB>(gx)) frag_wait<KB>(r_below, frag0, wave, gx, dead, a.ab);
 #pragma unroll
     for (int i = 0; i < KB; ++i) ax[i] = frag_vals(gx[i]);
+    take_x();
     frag_issue<KB>(r_below, frag0 + min(1, T - 1) * step_bytes, wave, gx);
   }
 
@@ -257,8 +338,13 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
     if (!FIRST) frag_issue<KB>(r_own, frag - step_bytes, wave, gh);   // in flight behind the upward MFMAs
     __builtin_amdgcn_sched_barrier(0);
     if (HAS_UP) {
+#if ASTK_PERSIST_F16X2
+#pragma unroll
+      for (int p = 0; p < NPR; ++p) { MFMA32HG(acc, axh[p], wuh[p]) }
+#else
 #pragma unroll
       for (int i = 0; i < KB; ++i) { MFMA4G(acc, ax[i], wu[i]) }
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     TICK(0, t0)
@@ -272,6 +358,7 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
       if (!frag_ok<KB>(gx)) { ++slow_x; frag_wait<KB>(r_below, frag0 + t1 * step_bytes, wave, gx, dead, a.ab); }
 #pragma unroll
       for (int i = 0; i < KB; ++i) ax[i] = frag_vals(gx[i]);
+      take_x();
     }
     // Everything issued so far has landed (that is what W_t is); saying so explicitly lets the compiler drop its own
     // conservative waits behind the slow path's merge, which would otherwise stall the recurrent MFMAs on the off-path
@@ -289,11 +376,19 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
     __builtin_amdgcn_sched_barrier(0);
     TICK(3, t0)
     if (!FIRST) {
+#if ASTK_PERSIST_F16X2
+#pragma unroll
+      for (int p = 0; p < NPR; ++p) {
+        const HL8 ah = split8(frag_vals(gh[2 * p]), 2 * p + 1 < KB ? frag_vals(gh[2 * p + 1 < KB ? 2 * p + 1 : 0]) : zero4, ACT_SCALE);
+        MFMA32HG(acc, ah, wlh[p])
+      }
+#else
 #pragma unroll
       for (int i = 0; i < KB; ++i) {
         const float4 ah = frag_vals(gh[i]);
         MFMA4G(acc, ah, wl[i])
       }
+#endif
     }
     // ---- 4-wave K reduction through LDS (double-buffered: one barrier per step)
     float* rd = (t & 1) ? red1 : red0;
@@ -309,6 +404,10 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         z[g] = rd[(0 * 4 + g) * 256 + src] + rd[(1 * 4 + g) * 256 + src] + rd[(2 * 4 + g) * 256 + src] + rd[(3 * 4 + g) * 256 + src];
+#if ASTK_PERSIST_F16X2
+#pragma unroll
+      for (int g = 0; g < 4; ++g) z[g] *= zscale;      // 1 / (weight scale x activation scale)
+#endif
       const float ga = tanh_fast(z[0] + zadd.x), gi = sigm_fast(z[1] + zadd.y), gf = sigm_fast(z[2] + zadd.z), go = sigm_fast(z[3] + zadd.w);
       c_state = ga * gi + gf * c_state;
       const float hh = go * tanh_fast(c_state);
@@ -372,16 +471,36 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
   const int m0 = bt * 16;
 
   // resident weight fragments: product tile tl = wave*KB + nt covers output units 16 tl .. 16 tl + 15; K = this slice's 64 gate columns
+  auto wl_at = [&](int nt, int s4) { return *reinterpret_cast<const float4*>(c.WlT + (long)(16 * (wave * KB + nt) + r16) * K + 64 * j + 16 * s4 + 4 * q); };
+  auto wd_at = [&](int nt, int s4) {
+    return has_down ? *reinterpret_cast<const float4*>(c.WuT + (long)(16 * (wave * KB + nt) + r16) * K + 64 * j + 16 * s4 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+#if ASTK_PERSIST_F16X2
+  // fp16 hi / lo fragments behind one power-of-two scale per workgroup (see the forward kernel); the 64 gate columns are two 32-k operands
+  HL8 wlh[KB][2], wdh[KB][2];
+  float winv;
+  {
+    float m = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < KB; ++nt)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) m = amax4f(amax4f(m, wl_at(nt, s4)), wd_at(nt, s4));
+    const float wscl = pow2_scale_for(wg_max(m, dzS), winv);
+#pragma unroll
+    for (int nt = 0; nt < KB; ++nt)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        wlh[nt][p] = split8(wl_at(nt, 2 * p), wl_at(nt, 2 * p + 1), wscl);
+        wdh[nt][p] = split8(wd_at(nt, 2 * p), wd_at(nt, 2 * p + 1), wscl);
+      }
+  }
+#else
   float4 wl[KB][4], wd[KB][4];
 #pragma unroll
-  for (int nt = 0; nt < KB; ++nt) {
-    const long n = 16 * (wave * KB + nt) + r16;
+  for (int nt = 0; nt < KB; ++nt)
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      wl[nt][s4] = *reinterpret_cast<const float4*>(c.WlT + n * K + 64 * j + 16 * s4 + 4 * q);
-      wd[nt][s4] = has_down ? *reinterpret_cast<const float4*>(c.WuT + n * K + 64 * j + 16 * s4 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
+    for (int s4 = 0; s4 < 4; ++s4) { wl[nt][s4] = wl_at(nt, s4); wd[nt][s4] = wd_at(nt, s4); }
+#endif
   const __amdgpu_buffer_rsrc_t r_pr = make_rsrc(c.PR);
   const __amdgpu_buffer_rsrc_t r_pd = make_rsrc(has_down ? c.PD : c.PR);
   const __amdgpu_buffer_rsrc_t r_pu = make_rsrc(has_up ? c.PD_up : c.PR);
@@ -389,7 +508,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
   const int eu = j0 + u, eb = m0 + r;
   const bool evalid = eb < B;
   const long ebc = evalid ? eb : B - 1;
-  float dc_state = 0.f, dhadd = 0.f;
+  float dc_state = 0.f, dhadd = 0.f, dzmax = 0.f;
   if (c.d_cT) dc_state = c.d_cT[ebc * h + eu];
   if (c.d_hT) dhadd = c.d_hT[ebc * h + eu];
   const int tile_bytes = 256 * 4;                          // one 16x16 partial tile
@@ -466,6 +585,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
       dz = make_float4(dcv * g.y * (1.f - g.x * g.x), dcv * g.x * g.y * (1.f - g.y), dcv * cp * g.z * (1.f - g.z), dh * tc * g.w * (1.f - g.w));
       dc_state = dcv * g.z;
       *reinterpret_cast<float4*>(&dzS[r * 64 + 4 * u]) = dz;
+      dzmax = fmaxf(fmaxf(dzmax, fmaxf(fabsf(dz.x), fabsf(dz.y))), fmaxf(fabsf(dz.z), fabsf(dz.w)));   // (rows past B repeat row B-1)
     }
     TICK(3, t0)
     __syncthreads();
@@ -473,14 +593,33 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
     float4 af[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) af[s4] = *reinterpret_cast<const float4*>(&dzS[r16 * 64 + 16 * s4 + 4 * q]);
+#if ASTK_PERSIST_F16X2
+    // dz is unbounded: its scale is taken from this step's tile (every wave holds the whole 16 x 64 tile across its lanes)
+    float pscale;       // 1 / (weight scale x dz scale), applied to the partial sums
+    HL8 afh[2];
+    {
+      const float m = wave_max_nonneg(amax4f(amax4f(amax4f(amax4f(0.f, af[0]), af[1]), af[2]), af[3]));
+      float ainv;
+      const float ascl = pow2_scale_for(m, ainv);
+      pscale = ainv * winv;
+      afh[0] = split8(af[0], af[1], ascl);
+      afh[1] = split8(af[2], af[3], ascl);
+    }
+#endif
     // ---- product 1: partial dh_rec for every slice of this cell -> write-through stores
     {
       const int slot = t % PR_RING;
 #pragma unroll
       for (int nt = 0; nt < KB; ++nt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#if ASTK_PERSIST_F16X2
+        MFMA32H(acc, afh[0], wlh[nt][0])
+        MFMA32H(acc, afh[1], wlh[nt][1])
+        acc *= pscale;
+#else
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc, af[s4], wl[nt][s4]) }
+#endif
         const int tl = wave * KB + nt;
         u32x4 o;
         o.x = __float_as_uint(acc[0]); o.y = __float_as_uint(acc[1]); o.z = __float_as_uint(acc[2]); o.w = __float_as_uint(acc[3]);
@@ -496,8 +635,14 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
 #pragma unroll
       for (int nt = 0; nt < KB1; ++nt) {
         acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if ASTK_PERSIST_F16X2
+        MFMA32H(acc2[nt], afh[0], wdh[nt][0])
+        MFMA32H(acc2[nt], afh[1], wdh[nt][1])
+        acc2[nt] *= pscale;
+#else
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc2[nt], af[s4], wd[nt][s4]) }
+#endif
       }
     }
     TICK(4, t0)
@@ -508,8 +653,14 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
 #pragma unroll
       for (int nt = KB1; nt < KB; ++nt) {
         acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if ASTK_PERSIST_F16X2
+        MFMA32H(acc2[nt], afh[0], wdh[nt][0])
+        MFMA32H(acc2[nt], afh[1], wdh[nt][1])
+        acc2[nt] *= pscale;
+#else
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc2[nt], af[s4], wd[nt][s4]) }
+#endif
       }
       store_down(t);
       pending_b = true;
@@ -517,6 +668,19 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
     TICK(6, t0)
   }
   if (pending_b) publish(ctrB);
+  if (c.amax) {
+    // max |dz| of the cell for the batched products behind this launch: block maximum, one 64-bit atomic into one of 16 shards
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dzmax = fmaxf(dzmax, __shfl_xor(dzmax, o));
+    __syncthreads();
+    if (lane == 0) dzS[wave] = dzmax;
+    __syncthreads();
+    if (tid == 0) {
+      float m = fmaxf(fmaxf(dzS[0], dzS[1]), fmaxf(dzS[2], dzS[3]));
+      if (!(m <= 3.0e38f)) m = 3.0e38f;
+      atomicMax(c.amax + ((blockIdx.x + blockIdx.y * gridDim.x) & 15), ((u64)a.amax_gen << 32) | (u64)__float_as_uint(m));
+    }
+  }
   if (timing && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0)
     printf("bwd_rs cell %d (layer %d): per-step 10ns: up wait+loads %lld  own wait %lld  own loads+sum %lld  epilogue %lld  barrier+mfma1+stores %lld  publishA %lld  product2+publishB %lld\n",
            cell, c.layer, tk[0] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T, tk[5] / T, tk[6] / T);
@@ -534,6 +698,7 @@ struct PersistCellHost {
   const float* PD_up;
   int up_external;
   int reverse_pos, layer;
+  unsigned long long* amax;       // backward: where max |dz| of the cell goes (16 sharded words, gemm_amax_reserve), null: not wanted
 };
 
 // Layers per launch.  One workgroup per CU must hold a launch's whole grid; a stack with more (direction, layer) cells than fit is
@@ -601,7 +766,7 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
 }
 
 int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters,
-                            hipStream_t s) {
+                            unsigned amax_gen, hipStream_t s) {
   PBwdArgs a;
   memset(&a, 0, sizeof(a));
   const int nbt = (B + 15) / 16;
@@ -611,8 +776,10 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
     d.WlT = c.WlT; d.gates_dz = c.gates; d.C = c.C; d.mask = c.mask; d.d_enc = c.d_enc;
     d.d_hT = c.d_hT; d.d_cT = c.d_cT; d.reverse_pos = c.reverse_pos; d.layer = c.layer;
     d.WuT = c.WuT; d.PR = c.PR; d.PD = c.PD; d.PD_up = c.PD_up; d.up_external = c.up_external;
+    d.amax = (u64*)c.amax;
   }
   a.ncells = ncells; a.nl = nl; a.T = T; a.B = B; a.h = h; a.H = H;
+  a.amax_gen = amax_gen;
   a.done = counters;
   { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
   ASTK_CHECK(cells[0].PR != nullptr, "lstm_persist_bwd: partial-sum buffers missing");
