@@ -242,12 +242,21 @@ __global__ void k_sqnorm(const float* g, const float* p, float gsc, float l2, si
   const size_t n4 = n / 4;
   const float4* g4 = reinterpret_cast<const float4*>(g);
   const float4* p4 = reinterpret_cast<const float4*>(p);
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    float4 a = g4[i], b = p4[i];
+  // (one double atomic per block at the end: same-address atomics retire one after the other, so few blocks with several loads in
+  //  flight each -- 2048 blocks spent more time in that queue than reading the two arrays)
+  auto term = [&](const float4& a, const float4& b) {
     // __fmul_rn: the scaled gradient is rounded before the decay term is added, exactly as if the buffer had been scaled first
-    float x = __fmul_rn(a.x, gsc) + l2 * b.x, y = __fmul_rn(a.y, gsc) + l2 * b.y, z = __fmul_rn(a.z, gsc) + l2 * b.z, w = __fmul_rn(a.w, gsc) + l2 * b.w;
-    s += (double)(x * x + y * y) + (double)(z * z + w * w);
+    const float x = __fmul_rn(a.x, gsc) + l2 * b.x, y = __fmul_rn(a.y, gsc) + l2 * b.y, z = __fmul_rn(a.z, gsc) + l2 * b.z, w = __fmul_rn(a.w, gsc) + l2 * b.w;
+    return (double)(x * x + y * y) + (double)(z * z + w * w);
+  };
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 a0 = g4[i], a1 = g4[i + stride], a2 = g4[i + 2 * stride], a3 = g4[i + 3 * stride];
+    const float4 b0 = p4[i], b1 = p4[i + stride], b2 = p4[i + 2 * stride], b3 = p4[i + 3 * stride];
+    s += (term(a0, b0) + term(a1, b1)) + (term(a2, b2) + term(a3, b3));
   }
+  for (; i < n4; i += stride) s += term(g4[i], p4[i]);
   if (blockIdx.x == 0 && threadIdx.x == 0)
     for (size_t i = n4 * 4; i < n; ++i) { float x = __fmul_rn(g[i], gsc) + l2 * p[i]; s += (double)x * x; }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -453,7 +462,7 @@ int astk_grad_sqnorm_scaled(const float* g, const float* p, float grad_scale, fl
   ASTK_CHECK(g && p && sqnorm, "grad_sqnorm: null pointer");
   ASTK_CHECK(aligned16(g) && aligned16(p), "grad_sqnorm: buffers must be 16-byte aligned");
   ASTK_HIP(hipMemsetAsync(sqnorm, 0, sizeof(double), s));
-  hipLaunchKernelGGL(k_sqnorm, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, g, p, grad_scale, l2, n, sqnorm);
+  hipLaunchKernelGGL(k_sqnorm, dim3(std::min(512u, grid_for(n / 4 + 1))), dim3(256), 0, s, g, p, grad_scale, l2, n, sqnorm);
   ASTK_LAUNCH_CHECK();
   return 0;
 }
