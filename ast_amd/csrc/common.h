@@ -114,10 +114,10 @@ __device__ __forceinline__ HL8 split8(const float4& a, const float4& b, float sc
   ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, (A).lo), __builtin_bit_cast(h16x8, (W).hi), ACC, 0, 0, 0);          \
   ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, (A).hi), __builtin_bit_cast(h16x8, (W).lo), ACC, 0, 0, 0);          \
   ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, (A).hi), __builtin_bit_cast(h16x8, (W).hi), ACC, 0, 0, 0);
-// The power of two (as a float) that brings an absolute maximum into [2^13, 2^14), and its reciprocal; 1 for a zero maximum.
+// The power of two (as a float) that brings an absolute maximum into [2^14, 2^15), and its reciprocal; 1 for a zero maximum.
 __device__ __forceinline__ float pow2_scale_for(float amax, float& inv) {
   const int e = (int)(__float_as_uint(amax) >> 23) & 0xff;
-  const int se = e == 0 ? 127 : min(max(267 - e, 1), 253);
+  const int se = e == 0 ? 127 : min(max(268 - e, 1), 253);
   inv = __uint_as_float((unsigned)(254 - se) << 23);
   return __uint_as_float((unsigned)se << 23);
 }

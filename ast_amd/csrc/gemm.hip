@@ -97,7 +97,7 @@ __host__ __device__ __forceinline__ long wg_first_iter(const GemmGroup& grp, uns
 // PREC_F16 (BASELINE configs[4], "fp16 MFMA GEMMs"): operands rounded to ONE fp16 term (round-to-nearest-even), one
 // v_mfma_f32_32x32x16_f16 per tile and 16 k, f32 accumulation.  Reduced precision (11 significant bits): only launches their caller marks
 // low-precision-eligible take it, and only when astk_set_low_precision_gemms(1) is in force.
-// PREC_F16X2: every operand is scaled by a power of two s (its absolute maximum lands in [2^13, 2^14): fp16 has only 5 exponent bits)
+// PREC_F16X2: every operand is scaled by a power of two s (its absolute maximum lands in [2^14, 2^15): fp16 has only 5 exponent bits)
 // and split into TWO fp16 terms, x s = hi + lo with hi = fp16(x s), lo = fp16(x s - hi), both round-to-nearest-even (common.h:
 // split2h): 22 significant bits for every value down to 2^-17 of the operand's maximum, an absolute floor of 2^-39 of the maximum below
 // that.  A product is summed from three of the four term products on v_mfma_f32_32x32x16_f16 (lo.hi + hi.lo + hi.hi; lo.lo <= 2^-22 |a b|
@@ -122,7 +122,7 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
   const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
   lo = cvt_pk_bf16(s0, s1);
 }
-// The power of two that brings an operand's absolute maximum into [2^13, 2^14), as the biased exponent of a float (amax: the word
+// The power of two that brings an operand's absolute maximum into [2^14, 2^15), as the biased exponent of a float (amax: the word
 // gemm_absmax left: launch generation in the high half, the maximum's float bits in the low half; null or zero maximum: 1.0).
 __device__ __forceinline__ int scale_exp(const unsigned long long* amax) {
   if (amax == nullptr) return 127;
@@ -130,7 +130,7 @@ __device__ __forceinline__ int scale_exp(const unsigned long long* amax) {
 #pragma unroll
   for (int i = 1; i < 16; ++i) w = max(w, amax[i]);
   const int e = (int)(((unsigned)w) >> 23) & 0xff;
-  return e == 0 ? 127 : min(max(267 - e, 1), 253);
+  return e == 0 ? 127 : min(max(268 - e, 1), 253);
 }
 // LDS images of one operand stage on the bf16x3 path (bytes).  RK operand (K-contiguous global rows): per plane two k-halves
 // [h = k / 8][row][8 k] of TL x 16 B, 16 B apart from a multiple of 128 B so that a stager's 8-byte writes and the MFMA lanes' 16-byte
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256) void k_absmax(AmaxJobs jobs) {
   const AmaxRegion& R = jobs.r[ri];
   const int nblk = jobs.blk_start[ri + 1] - jobs.blk_start[ri], blk = (int)blockIdx.x - jobs.blk_start[ri];
   const int quads = R.inner >> 2, tailn = R.inner & 3;
-  int tq = 1;
+  int tq = 4;                                    // (at least 4: the up-to-3 elements behind the last whole quad are read by tx < tailn)
   while (tq < quads && tq < 256) tq <<= 1;       // threads along a row (power of two), 256 / tq rows per pass
   const int tx = threadIdx.x & (tq - 1), ty = threadIdx.x / tq, rpp = 256 / tq;
   const long total_rows = R.nb * R.rows;

@@ -566,6 +566,36 @@ def test_gemm_operand_magnitudes(lib, layout, sa, sb):
     assert err.max() < 2e-5, (layout, sa, sb, err.max(), int(err.argmax()))
 
 
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(7, 5, 3), (9, 6, 2), (33, 3, 7), (5, 3, 1), (130, 66, 19)])
+def test_gemm_maximum_in_the_ragged_tail(lib, layout, M, N, K):
+    """The operand scales of the fp16x2 GEMMs come from an absolute-maximum pass that reads rows in float4 quads plus a scalar tail: an
+    operand whose largest entries sit in the last (non-multiple-of-4) positions of its rows must still be scaled by them -- a maximum
+    taken too small overflows fp16 and the result is inf / NaN."""
+    rng = np.random.default_rng(M * 131 + N * 17 + K + layout)
+    A = rng.standard_normal((M, K)) * 1e-3
+    B = rng.standard_normal((N, K)) * 1e-3
+    A[:, K - 1] = 500.0 * (1 + rng.random(M))        # last k of every row
+    A[M - 1, :] *= 3.0                                # ... and the last row
+    B[N - 1, :] = 800.0 * (1 + rng.random(K))        # last row of B = last column of B^T
+    B[:, K - 1] += 300.0
+    A32, B32 = A.astype(np.float32).astype(np.float64), B.astype(np.float32).astype(np.float64)
+    ref = A32 @ B32.T
+    pad = lambda n: (n + 3) // 4 * 4
+    def store(X, transpose):
+        X = X.T if transpose else X
+        P = np.zeros((X.shape[0], pad(X.shape[1])))
+        P[:, :X.shape[1]] = X
+        return P
+    Ad, Bd = store(A32, layout == 2), store(B32, layout != 0)
+    a, b = dev(Ad), dev(Bd)
+    c = torch.zeros(M, pad(N), device="cuda")
+    ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(a), Ad.shape[1], vp(b), Bd.shape[1], vp(c), c.shape[1], None, 0, 1, 1, 0, 0, 0, stream()))
+    got = c[:, :N].cpu().double().numpy()
+    assert np.isfinite(got).all(), (layout, M, N, K)
+    close(got, ref, rtol=2e-5, msg=f"layout {layout} {M}x{N}x{K}")
+
+
 def test_optimizer_grad_scale_equals_scaling_first(lib):
     """astk_*_scaled read the gradient as grad_scale * g (the 1/world mean of data parallelism applied on the fly, rounded like a
     separate scaling pass would round it): same result as scaling the buffer first and calling the unscaled entry points, up to the
