@@ -430,27 +430,46 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
     //  lane -- 6400 x 3072 x 1024: 306 us against 232 with atomics)
     const int mode = !whole || g.mode == GEMM_ACCUM ? GEMM_ATOMIC : g.mode;
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // (everything the element loop needs from the launch arguments is copied into locals first: read through `g`, a reference into
+    //  the kernel-argument block, hipcc re-loads the field behind every global store -- the stores might alias it -- and waits for the
+    //  scalar load, 64 times per lane and tile)
+    const float* const e_bias = add_bias ? g.bias : nullptr;
+    const int e_M = g.M, e_N = g.N, e_ctn = g.c_tn;
+    const long e_ldc = g.ldc, e_csg = g.c_sg, e_cst = g.c_st;
     auto epilogue = [&](f32x16 (&acc)[NAM][NA]) {
+      if (e_bias) {       // (uniform) this lane's two bias values go into the accumulators first: no load behind the stores
 #pragma unroll
-      for (int i = 0; i < NAM; ++i) {
+        for (int j = 0; j < NA; ++j) {
+          const int col = n0 + wn * WT + j * 32 + li;
+          const float b = e_bias[min(col, e_N - 1)];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-          if (row >= g.M) continue;
-          const long coff = g.c_tn > 0 ? (long)(row / g.c_tn) * g.c_sg + (long)(row % g.c_tn) * g.c_st : (long)row * g.ldc;
+          for (int i = 0; i < NAM; ++i)
 #pragma unroll
-          for (int j = 0; j < NA; ++j) {
-            const int col = n0 + wn * WT + j * 32 + li;
-            if (col >= g.N) continue;
-            float v = acc[i][j][r];
-            if (add_bias) v += g.bias[col];
-            float* dst = C + coff + col;
-            if (mode == GEMM_STORE) *dst = v;
-            else if (mode == GEMM_ACCUM) *dst += v;
-            else atomicAdd(dst, v);
-          }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += b;
         }
       }
+      const int col0 = n0 + wn * WT + li;
+      auto body = [&](auto storec) {          // one copy of the element loops per output mode (decided once per tile)
+        constexpr bool STORE = decltype(storec)::value;
+#pragma unroll
+        for (int i = 0; i < NAM; ++i) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (row >= e_M) continue;
+            const long coff = e_ctn > 0 ? (long)(row / e_ctn) * e_csg + (long)(row % e_ctn) * e_cst : (long)row * e_ldc;
+            float* rp = C + coff + col0;       // one 64-bit address per row, the column tiles at immediate offsets
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+              if (col0 + j * 32 >= e_N) continue;
+              if constexpr (STORE) rp[j * 32] = acc[i][j][r];
+              else atomicAdd(rp + j * 32, acc[i][j][r]);
+            }
+          }
+        }
+      };
+      if (mode == GEMM_STORE) body(std::true_type{});
+      else body(std::false_type{});
     };
 
     if constexpr (SPLIT) {
