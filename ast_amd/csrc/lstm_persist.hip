@@ -229,7 +229,8 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int bt = blockIdx.y, j0 = blockIdx.x * 16;
-  const int T = a.T, B = a.B, h = a.h;
+  const int T = a.T, B = a.B, h = a.h, HH = a.H, dbg = a.dbg;
+  const AbortCtl ab = a.ab;       // (locals: see the note on the kernel-argument block in lstm_persist_fwd_g)
   const int m0 = bt * 16;
   bool dead = false;
 
@@ -304,12 +305,12 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
     c.C[tbs * h + eu] = p_c;
     if (c.enc) {
       const int pos = c.reverse_pos ? T - 1 - ts : ts;
-      c.enc[((long)eb * T + pos) * a.H + eu] = p_hd;
+      c.enc[((long)eb * T + pos) * HH + eu] = p_hd;
     }
   };
   long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int slow_x = 0, slow_h = 0;
-  const bool timing = (a.dbg & 8) != 0;
+  const bool timing = (dbg & 8) != 0;
 #define TICK(i, t0) if (timing) { __builtin_amdgcn_sched_barrier(0); const long long now_ = wall_clock64(); tk[i] += now_ - t0; t0 = now_; __builtin_amdgcn_sched_barrier(0); }
 
   // ---- prologue: inputs of step 0; x_0 into registers, x_1 in flight
@@ -319,7 +320,7 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
   mk_raw = maskp[ebc * h + eu];
   if (HAS_UP) {
     frag_issue<KB>(r_below, frag0, wave, gx);
-    if (!frag_ok<KB>(gx)) frag_wait<KB>(r_below, frag0, wave, gx, dead, a.ab);
+    if (!frag_ok<KB>(gx)) frag_wait<KB>(r_below, frag0, wave, gx, dead, ab);
 #pragma unroll
     for (int i = 0; i < KB; ++i) ax[i] = frag_vals(gx[i]);
     take_x();
@@ -350,12 +351,12 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
     TICK(0, t0)
     // ---- W_t
     if (!FIRST) {
-      if (!frag_ok<KB>(gh)) { ++slow_h; frag_wait<KB>(r_own, frag - step_bytes, wave, gh, dead, a.ab); }
+      if (!frag_ok<KB>(gh)) { ++slow_h; frag_wait<KB>(r_own, frag - step_bytes, wave, gh, dead, ab); }
     }
     TICK(1, t0)
     const int t1 = min(t + 1, T - 1), t2 = min(t + 2, T - 1);
     if (HAS_UP) {   // x_{t+1}: issued a whole step ago
-      if (!frag_ok<KB>(gx)) { ++slow_x; frag_wait<KB>(r_below, frag0 + t1 * step_bytes, wave, gx, dead, a.ab); }
+      if (!frag_ok<KB>(gx)) { ++slow_x; frag_wait<KB>(r_below, frag0 + t1 * step_bytes, wave, gx, dead, ab); }
 #pragma unroll
       for (int i = 0; i < KB; ++i) ax[i] = frag_vals(gx[i]);
       take_x();
@@ -436,7 +437,9 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
 template <int KB>
 __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_g(PFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float red[2][4 * 4 * 256];
-  const PCellF& c = a.c[blockIdx.z];
+  // (a COPY, not a reference into the kernel-argument block: fields read through a dynamically indexed reference are re-loaded behind
+  //  every global store of the step loop -- the stores might alias them -- and each re-load is a scalar-cache round trip on the chain)
+  const PCellF c = a.c[blockIdx.z];
   if (c.layer > 0) lstm_fwd_steps<KB, true>(a, c, red[0], red[1]);
   else lstm_fwd_steps<KB, false>(a, c, red[0], red[1]);
 }
@@ -460,8 +463,10 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, q = lane >> 4;
   const int cell = blockIdx.z, bt = blockIdx.y, j = blockIdx.x, j0 = j * 16;
-  const PCellB& c = a.c[cell];
-  const int T = a.T, B = a.B, h = a.h;
+  const PCellB c = a.c[cell];      // a copy (see lstm_persist_fwd_g)
+  const int T = a.T, B = a.B, h = a.h, HH = a.H, dbg = a.dbg;
+  const AbortCtl ab = a.ab;
+  const unsigned amax_gen = a.amax_gen;
   const int nbt = gridDim.y;
   const int K = 4 * h;
   const bool has_up = c.PD_up != nullptr, has_down = c.PD != nullptr;
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
   };
 
   long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool timing = a.dbg != 0;
+  const bool timing = dbg != 0;
 #define TICK(i, t0) if (timing) { const long long now_ = wall_clock64(); tk[i] += now_ - t0; t0 = now_; }
   for (int t = T - 1; t >= 0; --t) {
     long long t0 = timing ? wall_clock64() : 0;
@@ -542,12 +547,12 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
     float dye = 0.f;
     if (c.d_enc) {
       const int pos = c.reverse_pos ? T - 1 - t : t;
-      dye = c.d_enc[(ebc * T + pos) * a.H + eu];
+      dye = c.d_enc[(ebc * T + pos) * HH + eu];
     }
     float v1 = 0.f;
     if (has_up) {                            // partials handed down by the layer above (it runs ahead)
       if (!c.up_external) {
-        if (tid == 0) s_ok1 = wait_ge(upB, (unsigned)(NS * (stepno + 1)), a.ab) ? 1 : 0;
+        if (tid == 0) s_ok1 = wait_ge(upB, (unsigned)(NS * (stepno + 1)), ab) ? 1 : 0;
         __syncthreads();
         if (!s_ok1) break;
       }
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
     TICK(0, t0)
     float v0 = 0.f;
     if (stepno > 0) {                        // partial dh_rec tiles of this cell's step t+1
-      if (tid == 0) s_ok2 = wait_ge(ctrA, (unsigned)(NS * stepno), a.ab) ? 1 : 0;
+      if (tid == 0) s_ok2 = wait_ge(ctrA, (unsigned)(NS * stepno), ab) ? 1 : 0;
       __syncthreads();
       if (!s_ok2) break;
       TICK(1, t0)
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
     if (tid == 0) {
       float m = fmaxf(fmaxf(dzS[0], dzS[1]), fmaxf(dzS[2], dzS[3]));
       if (!(m <= 3.0e38f)) m = 3.0e38f;
-      atomicMax(c.amax + ((blockIdx.x + blockIdx.y * gridDim.x) & 15), ((u64)a.amax_gen << 32) | (u64)__float_as_uint(m));
+      atomicMax(c.amax + ((blockIdx.x + blockIdx.y * gridDim.x) & 15), ((u64)amax_gen << 32) | (u64)__float_as_uint(m));
     }
   }
   if (timing && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0)
