@@ -1028,6 +1028,13 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     TLM = want;
     TL = want == 256 ? 128 : want;
   }
+  // A small launch does not repay an absolute-maximum pass (a launch of its own, 6 us at least): three-term bf16 operands need no scales
+  static const double small_flops = getenv("ASTK_GEMM_X3_BELOW") ? atof(getenv("ASTK_GEMM_X3_BELOW")) : 3e9;
+  if (prec == PREC_F16X2 && flops < small_flops) {
+    bool given = true;      // ... unless the caller supplied every maximum already
+    for (int i = 0; i < grp.n; ++i) given = given && grp.g[i].amaxA && grp.g[i].amaxB;
+    if (!given) prec = PREC_BF16X3;
+  }
   const int WGS_PER_CU = wgs_per_cu(TL, prec);
   if (grp.n == 0) return 0;
   for (int i = grp.n; i <= GEMM_GROUP_MAX; ++i) grp.iter_start[i] = grp.iters_total;
