@@ -148,7 +148,8 @@ def _cnn_desc(cfg, B, T, D):
     return cd
 
 
-@pytest.mark.parametrize("B,T,D,c0,c1", [(3, 21, 26, 4, 8), (2, 50, 80, 8, 12), (2, 16, 13, 4, 4)])
+# (the last case: the shipped channel counts on 13-d features -- the conv GEMMs there are the small, 64-tile, two-level-row variants)
+@pytest.mark.parametrize("B,T,D,c0,c1", [(3, 21, 26, 4, 8), (2, 50, 80, 8, 12), (2, 16, 13, 4, 4), (16, 400, 13, 128, 512)])
 @pytest.mark.parametrize("with_noise", [False, True])
 def test_cnn_fwd_bwd(lib, B, T, D, c0, c1, with_noise):
     from ast_amd._lib import CnnLayerGrads, CnnLayerParams
