@@ -791,7 +791,7 @@ struct AmaxJobs {
   int blk_start[AMAX_REGIONS + 1];
   AmaxRegion r[AMAX_REGIONS];
 };
-__global__ __launch_bounds__(256) void k_absmax(AmaxJobs jobs) {
+__device__ __forceinline__ void absmax_block(const AmaxJobs& jobs) {
   int ri = 0;
   while ((int)blockIdx.x >= jobs.blk_start[ri + 1]) ++ri;
   const AmaxRegion& R = jobs.r[ri];
@@ -855,14 +855,15 @@ __global__ __launch_bounds__(256) void k_absmax(AmaxJobs jobs) {
     atomicMax(R.slot + (blk & (AMAX_SHARDS - 1)), ((unsigned long long)jobs.gen << 32) | (unsigned long long)__float_as_uint(m));
   }
 }
+__global__ __launch_bounds__(256) void k_absmax(AmaxJobs jobs) { absmax_block(jobs); }
 constexpr int AMAX_SLOTS = 16384;      // 64-bit words: two halves of 512 sharded maxima each
 __device__ unsigned long long g_amax_ring[AMAX_SLOTS];
 
 // GEMM_STORE + split tiles: zero the tiles that more than one workgroup will accumulate into.  Block b looks at the
 // boundary between workgroups b and b+1.
 // (16-byte stores when every problem's C rows are 16-byte aligned -- `vec`, decided by the launcher -- else scalar)
-__global__ __launch_bounds__(256) void k_zero_split_tiles(GemmGroup grp, int G, int TLM, int TL, int vec) {
-  const long git = wg_first_iter(grp, blockIdx.x + 1, G);
+__device__ __forceinline__ void zero_split_block(const GemmGroup& grp, int G, int TLM, int TL, int vec, unsigned b) {
+  const long git = wg_first_iter(grp, b + 1, G);
   int prob = 0;
   while (git >= grp.iter_start[prob + 1]) ++prob;
   const GemmArgs& g = grp.g[prob];
@@ -887,6 +888,16 @@ __global__ __launch_bounds__(256) void k_zero_split_tiles(GemmGroup grp, int G, 
     else
       for (int c = col; c < min(col + w, g.N); ++c) C[coff + c] = 0.f;
   }
+}
+__global__ __launch_bounds__(256) void k_zero_split_tiles(GemmGroup grp, int G, int TLM, int TL, int vec) {
+  zero_split_block(grp, G, TLM, TL, vec, blockIdx.x);
+}
+// Both preparations of a fp16x2 GEMM_STORE stream-K launch in ONE launch (a dependent launch costs ~10 us of stream time whatever it
+// does): blocks [0, nb) take the operands' absolute maxima, the G - 1 blocks behind them zero the split tiles.  (6 KB of arguments.)
+__global__ __launch_bounds__(256) void k_absmax_zero(AmaxJobs jobs, GemmGroup grp, int G, int TLM, int TL, int vec) {
+  const unsigned nb = (unsigned)jobs.blk_start[jobs.n];
+  if (blockIdx.x < nb) absmax_block(jobs);
+  else zero_split_block(grp, G, TLM, TL, vec, blockIdx.x - nb);
 }
 
 }  // namespace
@@ -1077,6 +1088,14 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
               grp.g[i].N, grp.g[i].K, grp.g[i].batch, grp.g[i].mode, (int)twolvl, i, grp.n, G, grp.g[i].kt, TLM * 1000 + TL);
   ProfScope prof(PROF_GEMM, s, flops);
   dim3 grid((unsigned)G, 1, 1);
+  // GEMM_STORE + split tiles: the tiles several workgroups accumulate into are zeroed first (with the maximum pass when there is one)
+  const bool need_zero = !aligned && any_store && G > 1;
+  bool zero_vec = true;
+  for (int i = 0; i < grp.n; ++i) {
+    const GemmArgs& a = grp.g[i];
+    zero_vec = zero_vec && aligned16(a.C) && (a.sC % 4) == 0 && (a.c_tn > 0 ? (a.c_sg % 4) == 0 && (a.c_st % 4) == 0 : (a.ldc % 4) == 0);
+  }
+  int amax_blocks = 0;
   if (prec == PREC_F16X2) {
     // one absolute-maximum pass over both operands of every product (part of the GEMM's cost, inside its timing scope)
     unsigned long long* ring = amax_ring();
@@ -1105,16 +1124,13 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
       for (int i = 0; i < J.n; ++i)
         fprintf(stderr, "astk_gemm absmax region %d/%d: %ld x %ld rows (ld %ld) x %d floats = %.1f MB, %d blocks\n", i, J.n, J.r[i].nb, J.r[i].rows, J.r[i].ld,
                 J.r[i].inner, 4e-6 * J.r[i].nb * J.r[i].rows * J.r[i].inner, J.blk_start[i + 1] - J.blk_start[i]);
-    if (J.n > 0) hipLaunchKernelGGL(k_absmax, dim3((unsigned)J.blk_start[J.n]), dim3(256), 0, s, J);
-  }
-  if (!aligned && any_store && G > 1) {
-    bool vec = true;
-    for (int i = 0; i < grp.n; ++i) {
-      const GemmArgs& a = grp.g[i];
-      vec = vec && aligned16(a.C) && (a.sC % 4) == 0 && (a.c_tn > 0 ? (a.c_sg % 4) == 0 && (a.c_st % 4) == 0 : (a.ldc % 4) == 0);
+    amax_blocks = J.n > 0 ? J.blk_start[J.n] : 0;
+    if (amax_blocks > 0) {
+      if (need_zero) hipLaunchKernelGGL(k_absmax_zero, dim3((unsigned)(amax_blocks + G - 1)), dim3(256), 0, s, J, grp, (int)G, TLM, TL, zero_vec ? 1 : 0);
+      else hipLaunchKernelGGL(k_absmax, dim3((unsigned)amax_blocks), dim3(256), 0, s, J);
     }
-    hipLaunchKernelGGL(k_zero_split_tiles, dim3((unsigned)(G - 1)), dim3(256), 0, s, grp, (int)G, TLM, TL, vec ? 1 : 0);
   }
+  if (need_zero && amax_blocks == 0) hipLaunchKernelGGL(k_zero_split_tiles, dim3((unsigned)(G - 1)), dim3(256), 0, s, grp, (int)G, TLM, TL, zero_vec ? 1 : 0);
 #define ASTK_GEMM_LAUNCH(T_, P_, M_)                                                                                              \
   switch (layout) {                                                                                                               \
     case GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<T_, true, true, false, P_, M_>), grid, dim3(gemm_threads(P_)), 0, s, grp); break;  \
