@@ -234,7 +234,8 @@ def main():
                 # above stays the f32-input MFMA peak the useful flops are priced against (the scheme may exceed it).
                 nprod = 6 if prec_env == "bf16x3" else 3
                 scheme = ("bf16x3 split (6 bf16 MFMAs per useful product block)" if prec_env == "bf16x3" else
-                          "fp16x2 split (3 fp16 MFMAs per useful product block; scales from an absolute-maximum pass, timed with the GEMMs)")
+                          "fp16x2 split (3 fp16 MFMAs per useful product block; scales from an absolute-maximum pass, timed with the GEMMs; launches "
+                          "below 3 GFLOP: bf16x3 split, 6 MFMAs)")
                 if args.gemm_operands == "fp16":
                     scheme += "; single-term fp16 for the CNN / encoder-input GEMMs (--gemm-operands fp16)"
                 roof["executed"] = {"scheme": scheme, "mfma_16bit_tflops": round(tfl * nprod, 1), "mfma_16bit_peak_tflops": 2500.0,
