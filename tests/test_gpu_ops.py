@@ -597,6 +597,36 @@ def test_gemm_maximum_in_the_ragged_tail(lib, layout, M, N, K):
     close(got, ref, rtol=2e-5, msg=f"layout {layout} {M}x{N}x{K}")
 
 
+def test_gemm_scale_slots_survive_ring_wraparound(lib):
+    """The fp16x2 GEMMs keep their operands' absolute maxima in a ring of generation-tagged slots that is never cleared (gemm.hip):
+    a launch must never pick up the scale of an earlier user of its slots.  1500 launches (the ring holds the slots of ~21) whose
+    operand magnitudes jump by random powers of two -- an inherited maximum that is too small overflows fp16 (inf / NaN), one that is
+    too large costs accuracy -- and whose operands are small and large matrices in turn (different numbers of maximum blocks, hence
+    of shards written per slot), each result checked against float64."""
+    rng = np.random.default_rng(77)
+    shapes = [(1024, 1024, 1536), (2048, 512, 1600), (96, 8192, 2048)]          # all above the bf16x3 threshold (3 GFLOP)
+    base = {}
+    for (M, N, K) in shapes:
+        a = torch.randn(M, K, device="cuda", generator=torch.Generator(device="cuda").manual_seed(M + K))
+        b = torch.randn(N, K, device="cuda", generator=torch.Generator(device="cuda").manual_seed(N + K + 1))
+        base[(M, N, K)] = (a, b, a.double() @ b.double().T)
+    worst = 0.0
+    for it in range(1500):
+        M, N, K = shapes[int(rng.integers(0, len(shapes)))]
+        a0, b0, ref0 = base[(M, N, K)]
+        ea, eb = int(rng.integers(-40, 30)), int(rng.integers(-40, 30))
+        a, b = a0 * (2.0 ** ea), b0 * (2.0 ** eb)
+        c = torch.empty(M, N, device="cuda")
+        ok(lib, lib.astk_gemm_f32(0, M, N, K, vp(a), K, vp(b), K, vp(c), N, None, 0, 1, 1, 0, 0, 0, stream()))
+        if it % 10 == 0 or it > 1480:           # (every launch runs; every tenth is compared)
+            got = c.double() * (2.0 ** -(ea + eb))
+            assert bool(torch.isfinite(got).all()), (it, M, N, K, ea, eb)
+            err = float((got - ref0).abs().max() / ref0.abs().max())
+            worst = max(worst, err)
+            assert err < 2e-5, (it, M, N, K, ea, eb, err)
+    assert worst > 0.0
+
+
 def test_optimizer_grad_scale_equals_scaling_first(lib):
     """astk_*_scaled read the gradient as grad_scale * g (the 1/world mean of data parallelism applied on the fly, rounded like a
     separate scaling pass would round it): same result as scaling the buffer first and calling the unscaled entry points, up to the
