@@ -935,6 +935,7 @@ static int gemm_prepare(int layout, const GemmArgs& g, GemmArgs& a, bool& twolvl
 }
 
 static int g_lowp_mode = 0;
+static std::atomic<double> g_small_flops{getenv("ASTK_GEMM_X3_BELOW") ? atof(getenv("ASTK_GEMM_X3_BELOW")) : 3e9};
 int low_precision_gemms() { return g_lowp_mode; }
 static thread_local int tl_wg_cap = 0;
 GemmWgCap::GemmWgCap(int per_cu) : prev(tl_wg_cap) { tl_wg_cap = per_cu; }
@@ -1040,8 +1041,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     TL = want == 256 ? 128 : want;
   }
   // A small launch does not repay an absolute-maximum pass (a launch of its own, 6 us at least): three-term bf16 operands need no scales
-  static const double small_flops = getenv("ASTK_GEMM_X3_BELOW") ? atof(getenv("ASTK_GEMM_X3_BELOW")) : 3e9;
-  if (prec == PREC_F16X2 && flops < small_flops) {
+  if (prec == PREC_F16X2 && flops < g_small_flops.load()) {
     bool given = true;      // ... unless the caller supplied every maximum already
     for (int i = 0; i < grp.n; ++i) given = given && grp.g[i].amaxA && grp.g[i].amaxB;
     if (!given) prec = PREC_BF16X3;
@@ -1205,6 +1205,7 @@ extern "C" int astk_set_low_precision_gemms(int mode) {
   return 0;
 }
 extern "C" int astk_get_low_precision_gemms(void) { return astk::g_lowp_mode; }
+extern "C" double astk_set_gemm_bf16_split_below(double flops) { return astk::g_small_flops.exchange(flops < 0 ? 0.0 : flops); }
 
 namespace astk {
 

@@ -43,10 +43,15 @@ int astk_gemm_f32(int layout, int M, int N, int K,
 
 /* BASELINE configs[4] ("fp16 MFMA GEMMs"): mode 1 lets the batched products of the CNN layers >= 1 (K6) and of the encoder's layer-0
  * input projection (K9), forward and backward, run with operands rounded to fp16 (one v_mfma_f32_32x32x16_f16 per tile, f32
- * accumulation) instead of the f32-accurate three-term bf16 split.  Reduced precision: the 1e-4 fp32 parity gate does not apply in
+ * accumulation) instead of the f32-accurate split (below).  Reduced precision: the 1e-4 fp32 parity gate does not apply in
  * this mode (SURVEY.md 8d asks for the loss drift instead: tests/test_gpu_model.py).  Process-wide; 0 (default) = off. */
 int astk_set_low_precision_gemms(int mode);
 int astk_get_low_precision_gemms(void);
+/* The f32-accurate GEMMs split every operand into 16-bit terms inside the kernel: two fp16 terms behind a per-operand power-of-two
+ * scale (an absolute-maximum pass in front of the launch; three MFMAs per 16 k), or -- for launches below `flops` floating-point
+ * operations, which do not repay that pass -- three bf16 terms (no scales, six MFMAs).  Default 3e9 (environment:
+ * ASTK_GEMM_X3_BELOW); 0 = fp16 terms always.  Process-wide; returns the previous value. */
+double astk_set_gemm_bf16_split_below(double flops);
 
 /* ---------------------------------------------------------------- CNN front-end  (seq2seq.py:158-180)
  * [Conv2D(no bias) -> BatchNorm(train: batch stats) -> ReLU] x n_layers, then the (T'',B,C*F') time-major

@@ -20,6 +20,17 @@ def lib():
     return _lib.load()
 
 
+@pytest.fixture(params=["fp16x2", "auto"])
+def gemm_split(request, lib):
+    """The f32-accurate GEMMs run two operand schemes: two fp16 terms behind per-operand scales, and -- below 3 GFLOP, which is every
+    shape of the small op tests -- three bf16 terms.  "fp16x2" forces the first on all sizes (astk_set_gemm_bf16_split_below(0)),
+    "auto" is the default dispatch."""
+    lib.astk_set_gemm_bf16_split_below.restype = C.c_double
+    prev = lib.astk_set_gemm_bf16_split_below(C.c_double(0.0 if request.param == "fp16x2" else 3e9))
+    yield request.param
+    lib.astk_set_gemm_bf16_split_below(C.c_double(prev))
+
+
 def dev(a, dtype=torch.float32):
     return torch.as_tensor(np.asarray(a)).to("cuda", dtype).contiguous()
 
@@ -68,7 +79,7 @@ def close(got, ref, rtol=2e-4, atol=None, msg=""):
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 72, 120), (37, 1098, 512), (6, 8, 44), (300, 260, 1000), (1, 1, 4)])
-def test_gemm_layouts(lib, layout, M, N, K):
+def test_gemm_layouts(lib, layout, M, N, K, gemm_split):
     rng = np.random.default_rng(M * 7 + N * 3 + K + layout)
     A = rng.standard_normal((M, K))
     B = rng.standard_normal((N, K))
@@ -101,7 +112,7 @@ def test_gemm_layouts(lib, layout, M, N, K):
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(70, 45, 37), (130, 129, 16), (5, 3, 1), (129, 70, 531)])
-def test_gemm_never_reads_padding_into_the_result(lib, layout, M, N, K):
+def test_gemm_never_reads_padding_into_the_result(lib, layout, M, N, K, gemm_split):
     """Row padding (ld > extent) and whatever follows a ragged K tail hold NaNs: none may reach C, nor the columns beyond N."""
     rng = np.random.default_rng(M + N + K + layout)
     A = rng.standard_normal((M, K))
@@ -121,7 +132,7 @@ def test_gemm_never_reads_padding_into_the_result(lib, layout, M, N, K):
     assert float(c[:, N:].min()) == 7.0 and float(c[:, N:].max()) == 7.0, "wrote outside N"
 
 
-def test_gemm_batched_tn(lib):
+def test_gemm_batched_tn(lib, gemm_split):
     rng = np.random.default_rng(3)
     Bt, M, N, K = 5, 22, 40, 9
     A = rng.standard_normal((K, Bt, 24))       # rows k, batch stride 24, M=22 valid cols
@@ -151,7 +162,7 @@ def _cnn_desc(cfg, B, T, D):
 # (the last case: the shipped channel counts on 13-d features -- the conv GEMMs there are the small, 64-tile, two-level-row variants)
 @pytest.mark.parametrize("B,T,D,c0,c1", [(3, 21, 26, 4, 8), (2, 50, 80, 8, 12), (2, 16, 13, 4, 4), (16, 400, 13, 128, 512)])
 @pytest.mark.parametrize("with_noise", [False, True])
-def test_cnn_fwd_bwd(lib, B, T, D, c0, c1, with_noise):
+def test_cnn_fwd_bwd(lib, B, T, D, c0, c1, with_noise, gemm_split):
     from ast_amd._lib import CnnLayerGrads, CnnLayerParams
     from oracle.ast_ref import init_params
     from oracle.ast_ref_torch import cnn_torch
@@ -220,7 +231,7 @@ def test_cnn_fwd_bwd(lib, B, T, D, c0, c1, with_noise):
                                                    # groups of layers -- 3 layers as (2, 1) at batch 200 / h = 64, 6 layers as (2, 2, 2) at h = 512
                                                    # (the encoder of BASELINE configs[4]), 3 layers as (2, 1) at batch 64 / h = 256
                                                    (5, 200, 16, 64, 3, True), (4, 20, 24, 512, 6, False), (6, 64, 32, 256, 3, True)])
-def test_lstm_stack(lib, T, B, in_dim, h, nl, masks):
+def test_lstm_stack(lib, T, B, in_dim, h, nl, masks, gemm_split):
     from ast_amd._lib import LstmGrads, LstmParams, LstmStackDesc
     from oracle.ast_ref_torch import encoder_torch
     rng = np.random.default_rng(T + B)
@@ -359,7 +370,7 @@ def _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=0):
                                                     # 28 stay in LDS and the rest is streamed every step
                                                     (32, 5, 300, 512, 128, 512, 1098, 1, False), (32, 4, 420, 512, 128, 512, 1098, 3, True),
                                                     (32, 4, 233, 512, 128, 512, 300, 1, True)])
-def test_decoder_fwd_bwd(lib, B, L, T, H, E, A, V, nl, masks):
+def test_decoder_fwd_bwd(lib, B, L, T, H, E, A, V, nl, masks, gemm_split):
     from oracle.ast_ref_torch import decoder_torch
     s = _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=B + L)
     if H % 64 == 0 and A % 16 == 0 and E % 16 == 0 and nl <= 3:       # the shapes meant for the persistent kernels really take them
@@ -503,7 +514,7 @@ def test_rng_fills(lib):
     assert abs(float(z.mean()) - 1.0) < 2e-3 and abs(float(z.std()) - 0.25) < 2e-3
 
 
-def test_gemm_random_shapes_against_float64(lib):
+def test_gemm_random_shapes_against_float64(lib, gemm_split):
     """Seeded sweep over layouts, ragged extents, leading-dimension padding (poisoned with NaN), batches and output modes."""
     rng = np.random.default_rng(2026)
     pad4 = lambda n: (n + 3) // 4 * 4
@@ -539,7 +550,7 @@ def test_gemm_random_shapes_against_float64(lib):
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("sa,sb", [(1e-20, 1e15), (3e7, 2e-3), (1.0, 1e-30)])
-def test_gemm_operand_magnitudes(lib, layout, sa, sb):
+def test_gemm_operand_magnitudes(lib, layout, sa, sb, gemm_split):
     """The default GEMM splits every operand into two fp16 terms behind a per-operand power-of-two scale taken from an absolute-maximum
     pass: operands far outside fp16's range must come out as accurately as N(0,1) ones, and rows 1e-4 below the operand's largest
     entries must keep their own relative accuracy (22 significant bits down to 2^-17 of the maximum, gemm.hip)."""
@@ -569,7 +580,7 @@ def test_gemm_operand_magnitudes(lib, layout, sa, sb):
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(7, 5, 3), (9, 6, 2), (33, 3, 7), (5, 3, 1), (130, 66, 19)])
-def test_gemm_maximum_in_the_ragged_tail(lib, layout, M, N, K):
+def test_gemm_maximum_in_the_ragged_tail(lib, layout, M, N, K, gemm_split):
     """The operand scales of the fp16x2 GEMMs come from an absolute-maximum pass that reads rows in float4 quads plus a scalar tail: an
     operand whose largest entries sit in the last (non-multiple-of-4) positions of its rows must still be scaled by them -- a maximum
     taken too small overflows fp16 and the result is inf / NaN."""
