@@ -1,14 +1,20 @@
-// f32-input MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32: exact f32, k-ordered fma chain).
+// Batched dense products of the train step on the gfx950 matrix pipe (SURVEY.md K6, K9, K24 and all dgrad / wgrad products):
+// C[M,N] (+)= op(A) op(B) (+bias), f32 in, f32 out, f32-level accuracy.
 //
-// One kernel family covers every batched dense product of the train step (SURVEY.md K6, K9, K24 and
-// all dgrad / wgrad products): C[M,N] (+)= op(A) op(B) (+bias).
-//   128x128x16 block tile (BK = 16, double-buffered in LDS), 256 threads = 4 waves as 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles
-//   (64 accumulator VGPRs), three workgroups per CU, k-iterations split evenly over the grid (stream-K); 64x64x16 tiles (each wave
-//   one 32x32 MFMA tile) for launches too small to occupy the chip with 128-tiles.  An operand whose global
-//   rows are K-contiguous is kept row-major in LDS with the tile's k order permuted to [even | odd] (two 8-byte writes per
-//   staged float4, two 16-byte reads per lane and k-iteration); an operand whose rows are M/N-contiguous is kept K-major
-//   (16-byte writes, one ds_read2st64_b32 per k-pair).  Global loads are 16 B per lane, register-staged two k-tiles ahead of
-//   the MFMAs, and the k loop is free of vector-ALU work (see Stager).
+// One kernel template, three operand schemes (GemmPrec below):
+//   * fp16x2 (default): every operand value is split INSIDE the kernel into two fp16 terms behind a per-operand power-of-two scale, three
+//     v_mfma_f32_32x32x16_f16 per 16 k; the scales come from an absolute-maximum pass in front of the launch (k_absmax) or from the caller
+//   * bf16x3 (launches below 3 GFLOP, or ASTK_GEMM_PREC=bf16x3): three bf16 terms, no scales, six v_mfma_f32_32x32x16_bf16 per 16 k
+//   * f32 (ASTK_GEMM_PREC=f32): v_mfma_f32_32x32x2_f32, the exact k-ordered f32 fma chain (round 1's kernel)
+// (+ single-term fp16 operands for the launches their callers mark `lowp` when astk_set_low_precision_gemms(1) is in force).
+//   128x128x16 block tile (BK = 16), 64x64x16 tiles for launches too small to occupy the chip with 128-tiles; k-iterations split evenly
+//   over the grid (stream-K).  Split schemes: 512 threads -- waves 0-3 multiply out of LDS (fragments of tile kt+1 fetched behind tile
+//   kt's MFMAs), waves 4-7 stage (4-deep register ring of raw f32 tiles, the split, LDS writes) -- three LDS stages of 16-bit planes,
+//   one workgroup per CU.  f32 scheme: 256 threads = 4 waves as 2x2, every wave stages and multiplies, double-buffered f32 tiles in
+//   LDS, three workgroups per CU.  An operand whose global rows are K-contiguous ("RK") is kept row-major in LDS, one whose rows are
+//   M/N-contiguous ("KR") K-major (split schemes: read with the transposing ds_read_b64_tr_b16).  Global loads are 16 B per lane raw
+//   buffer loads off a uniform base (see Stager); K-contiguous operands of the split schemes fetch two k-tiles (one 128-byte line per
+//   row) at a time.
 // Rows of A, B and C can use two-level or indexed addressing (MatView) so the conv layers run as
 // zero-copy "window" GEMMs over padded channels-last activations and the reverse LSTM direction reads
 // frames through its permutation table instead of a permuted copy.
@@ -39,7 +45,7 @@ constexpr int BK = ASTK_GEMM_BK;
 #ifndef ASTK_GEMM_X3_WGS
 #define ASTK_GEMM_X3_WGS 1
 #endif
-// co-resident workgroups the grid is sized for.  bf16x3 workgroups have 512 threads (2 waves per SIMD each)
+// co-resident workgroups the grid is sized for.  Workgroups of the split schemes have 512 threads (2 waves per SIMD each)
 constexpr int wgs_per_cu(int TL, int prec = 0) { return prec != 0 ? (TL == 64 ? 2 : ASTK_GEMM_X3_WGS) : (TL == 64 ? 4 : (BK == 32 ? 2 : 3)); }
 constexpr int waves_per_simd(int TL, int prec) { return prec != 0 ? 2 * wgs_per_cu(TL, prec) : wgs_per_cu(TL, prec); }   // co-resident workgroups the grid is sized for (128-tiles,
                                                // BK = 16: 40 KB of LDS and <= 168 registers per workgroup; 2, 3 and 4 per CU are within 2 %)
@@ -132,7 +138,7 @@ __device__ __forceinline__ int scale_exp(const unsigned long long* amax) {
   const int e = (int)(((unsigned)w) >> 23) & 0xff;
   return e == 0 ? 127 : min(max(268 - e, 1), 253);
 }
-// LDS images of one operand stage on the bf16x3 path (bytes).  RK operand (K-contiguous global rows): per plane two k-halves
+// LDS images of one operand stage on the split paths (bytes).  RK operand (K-contiguous global rows): per plane two k-halves
 // [h = k / 8][row][8 k] of TL x 16 B, 16 B apart from a multiple of 128 B so that a stager's 8-byte writes and the MFMA lanes' 16-byte
 // row reads are both conflict-free.  KR operand (M/N-contiguous global rows): per plane K-major [k][m] rows of 2 TL + 64 B (the pad makes
 // the four k rows of a transposing read land 16 banks apart), read with ds_read_b64_tr_b16.
@@ -142,7 +148,7 @@ constexpr int sp_plane(int TL, bool RK) { return RK ? (BK / 8) * sp_hs(TL) : BK 
 constexpr int sp_stage(int TL, bool RK, int prec = PREC_BF16X3) { return prec_planes(prec) * sp_plane(TL, RK); }
 
 // RING: register slots of staged tiles.  The f32 kernel keeps one tile in flight (an iteration is 2600 cycles and three workgroups per
-// CU cover each other's waits); a bf16x3 iteration is ~800 cycles on one workgroup per CU, so its staging waves keep RING = 4 tiles
+// CU cover each other's waits); an iteration of the split schemes is 600-800 cycles on one workgroup per CU, so their staging waves keep RING = 4 tiles
 // (16 loads per thread) in flight to cover the memory latency.
 template <int TL, bool RK, bool TWOLVL, int PREC = PREC_F32, int RING = 1>
 struct Stager {
@@ -181,7 +187,7 @@ struct Stager {
       b = tid / CQ;
       // LDS column order of a 128-wide KR tile: [wm0 i0 | wm1 i0 | wm0 i1 | wm1 i1] x 32 (see ld_kr); lane a writes LDS columns 4a..4a+3,
       // which hold the tile's columns wm*64 + i*32 + 4*(a&7) with i = a>>4, wm = (a>>3)&1.  A 64-wide tile is stored in order.
-      const int m = (TL == 128 && PREC == PREC_F32) ? ((a >> 3) & 1) * 64 + (a >> 4) * 32 + (a & 7) * 4 : 4 * a;   // bf16x3 image: natural order
+      const int m = (TL == 128 && PREC == PREC_F32) ? ((a >> 3) & 1) * 64 + (a >> 4) * 32 + (a & 7) * 4 : 4 * a;   // images of the split schemes: natural order
       const int col = min(row0 + m, ((nrows + 3) & ~3) - 4);
 #pragma unroll
       for (int p = 0; p < NP; ++p)
@@ -261,7 +267,7 @@ struct Stager {
       for (int p = 0; p < NP; ++p) *reinterpret_cast<float4*>(&S[lds + RP * p * LD_KR]) = reg[0][p];
     }
   }
-  // bf16x3: registers -> three bf16 planes of the stage at byte address S.  Values with k >= kend are zeroed in registers (uniform
+  // split schemes: registers -> the 16-bit planes of the stage at byte address S.  Values with k >= kend are zeroed in registers (uniform
   // branch, last tile of a K range only), so no LDS patching is needed.  ktile: first k of the tile being stored.
   template <bool TAIL>
   __device__ __forceinline__ void store_split(char* S, int ktile, int kend, const int slot) {
@@ -333,7 +339,7 @@ struct Stager {
 // (for GEMM_STORE the launcher zeroes exactly those tiles first, k_zero_split_tiles).  With G = tiles (one tile each)
 // this degenerates to the classical data-parallel launch; with G = 256 or 512 every CU gets the same number of
 // k-iterations whatever the tile count -- a 400-tile product no longer runs as "2 waves, the second 56% full".
-// bf16x3 kernels run 512 threads: waves 0-3 multiply (LDS fragment reads + MFMAs only), waves 4-7 stage (global loads, the
+// The split schemes' kernels run 512 threads: waves 0-3 multiply (LDS fragment reads + MFMAs only), waves 4-7 stage (global loads, the
 // f32 -> 3 x bf16 split, LDS writes).  One wave of each kind sits on every SIMD, so the split's vector-ALU work issues in the gaps of
 // the other wave's MFMAs; with every wave doing both, the co-resident workgroups ran their VALU and MFMA phases in lockstep and the
 // matrix pipe idled more than half of the time (163 instead of 118 TFLOP/s at 4096^3, against > 300 for an MFMA-bound loop).
@@ -354,19 +360,19 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
   static_assert(SPLIT || TLM == TL, "the f32 path runs square tiles");
   constexpr int A_FLOATS = SPLIT ? sp_stage(TLM, A_RK, PREC) / 4 : (A_RK ? TL * LD_RK : BK * LD_KR);
   constexpr int B_FLOATS = SPLIT ? sp_stage(TL, B_RK, PREC) / 4 : (B_RK ? TL * LD_RK : BK * LD_KR);
-  constexpr int NST = SPLIT ? 3 : 2;      // LDS stages (bf16x3: the multiplying waves fetch tile kt+1's fragments while they multiply tile kt)
+  constexpr int NST = SPLIT ? 3 : 2;      // LDS stages (split schemes: the multiplying waves fetch tile kt+1's fragments while they multiply tile kt)
   __shared__ __attribute__((aligned(16))) float As[NST][A_FLOATS];
   __shared__ __attribute__((aligned(16))) float Bs[NST][B_FLOATS];
   static_assert(BK == 16 || BK == 32, "BK / 2 floats per lane and operand, read as BK / 8 float4");
 
   const int tid = threadIdx.x & 255;                 // stager / multiplier thread index inside its role
-  const bool producer = SPLIT && threadIdx.x >= 256;   // bf16x3: waves 4-7 stage, waves 0-3 multiply; f32: every wave does both
+  const bool producer = SPLIT && threadIdx.x >= 256;   // split schemes: waves 4-7 stage, waves 0-3 multiply; f32: every wave does both
   const bool stages = !SPLIT || producer, multiplies = !SPLIT || !producer;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lk = lane >> 5;
 
-  // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8 share one L2).  bf16x3: give every XCD a CONTIGUOUS eighth of the
+  // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8 share one L2).  Split schemes: give every XCD a CONTIGUOUS eighth of the
   // k-iteration sequence, so that the workgroups sharing an L2 work on neighbouring tiles (same A row panel, adjacent B panels): at
   // 160+ TFLOP/s a 128-tile loop pulls > 5 TB/s of f32 operands into the CUs, which only the L2s can serve.
   if constexpr (SPLIT) {
@@ -473,7 +479,7 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
     };
 
     if constexpr (SPLIT) {
-      // ---- bf16x3 pipeline.  Staging waves: tile t sits in ring slot t % RING (registers) until it is split into LDS buffer t & 1 one
+      // ---- pipeline of the split schemes.  Staging waves: tile t sits in ring slot t % RING (registers) until it is split into LDS buffer t & 1 one
       // iteration before the multiplying waves use it; a slot is reloaded with tile t + RING right after.  The two roles run separate
       // loops with the same number of barriers.  The staging loop's steady state is straight-line code (no tail handling, no
       // conditional loads), so that the compiler's s_waitcnt counts the RING tiles in flight instead of draining them.
@@ -997,8 +1003,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   // threshold below, and either too few tiles for the CUs or tiles so shallow that their ramp dominates): then 64-tiles give 4x the
   // workgroups, each a quarter of the work.  ASTK_GEMM_TILE = 64 | 128 forces one.
   static const int force_tl = getenv("ASTK_GEMM_TILE") ? atoi(getenv("ASTK_GEMM_TILE")) : 0;
-  // operand precision: bf16x3 (three-term bf16 split, f32-level accuracy, up to 2.7x the f32 MFMA rate) unless ASTK_GEMM_PREC=f32 asks
-  // for the exact-f32 MFMA chain
+  // operand scheme of the launch (default_prec: fp16x2 unless the environment asks for bf16x3 or f32)
   int prec = default_prec();
   if (g_lowp_mode != 0 && n > 0) {        // fp16 operands only if every product of the launch is marked eligible by its caller
     bool all = true;
