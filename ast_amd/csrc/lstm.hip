@@ -155,11 +155,12 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
     PersistCellHost cells[16];
     memset(cells, 0, sizeof(cells));
     const unsigned long long* ax = gemm_amax(x, (long)T * B, P.in, P.in, s);      // both directions multiply the same frames
+    GemmArgs k9[2];      // the layer-0 upward projections of both directions: one grouped launch
     for (int dd = 0; dd < P.nd; ++dd) {
       const astk_lstm_params& p0 = prm[dd * P.nl];
       ASTK_CHECK(p0.Wu && p0.b && p0.Wl, "lstm_stack_fwd: null parameter (dir %d layer 0)", dd);
       MatView A = dd == 0 ? mat(x, P.in) : mat_idx(x, P.in, rows_perm);
-      ASTK_TRY(gemm_launch(GEMM_NT, with_amax_a(lowp(gemm_args(T * B, 4 * h, P.in, A, mat(p0.Wu, P.in), P.ZG[dd][0], 4 * h, p0.b)), ax), s));     // K9
+      k9[dd] = with_amax_a(lowp(gemm_args(T * B, 4 * h, P.in, A, mat(p0.Wu, P.in), P.ZG[dd][0], 4 * h, p0.b)), ax);     // K9
       for (int l = 0; l < P.nl; ++l) {
         const astk_lstm_params& p = prm[dd * P.nl + l];
         ASTK_CHECK(p.Wu && p.b && p.Wl, "lstm_stack_fwd: null parameter (dir %d layer %d)", dd, l);
@@ -180,6 +181,7 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
         c.layer = l;
       }
     }
+    ASTK_TRY(gemm_launch_group(GEMM_NT, k9, P.nd, s));
     {
       // one launch per group of layers (normally a single group: the whole stack); a later group finds the outputs of the layer
       // below complete (its sentinel polls succeed at once)
