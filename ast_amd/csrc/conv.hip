@@ -38,7 +38,9 @@ struct CnnPlan {
   float* G;                         // [rows_max][Cmax] gradient wrt post-ReLU output (row layout)
   float* DY[ASTK_MAX_CNN_LAYERS];   // padded dY (i>=1) / plain dY (i=0)
   float* dWr[ASTK_MAX_CNN_LAYERS];    // per layer scratch for re-packed weight gradients
-  float* Wd;                        // phase weights for dgrad
+  float* Wd;                        // phase weights for dgrad: wd_copies buffers of wd_stride floats
+  size_t wd_stride;
+  int wd_copies;
   size_t bytes;
 };
 
@@ -108,7 +110,12 @@ int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
   P.zero_fwd_bytes = off_dwr - off_stat;
   P.zero_bwd_bytes = c.off - off_stat;
   P.G = c.take<float>(rowsmax_c);
-  P.Wd = c.take<float>(wd_max ? wd_max : 4);
+  // one phase-weight buffer per stride phase of a grouped dgrad launch
+  int st_max = 1;
+  for (int i = 1; i < P.n; ++i) st_max = d->st[i] > st_max ? d->st[i] : st_max;
+  P.wd_stride = (wd_max ? wd_max : 4);
+  P.wd_copies = st_max < GEMM_GROUP_MAX ? st_max : GEMM_GROUP_MAX;
+  P.Wd = c.take<float>(P.wd_stride * P.wd_copies);
   P.bytes = c.total();
   return 0;
 }
@@ -493,7 +500,9 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
       }
       hipLaunchKernelGGL(k_unpack_dw, dim3(gridn((size_t)C * Ci * KT)), dim3(256), 0, s, P.dWr[i], Gr[i].dW, C, Ci, KT);
       ASTK_LAUNCH_CHECK();
-      // ---- dgrad: one window GEMM per stride phase rho of the input position t_in = rho + st*j
+      // ---- dgrad: one window GEMM per stride phase rho of the input position t_in = rho + st*j, all phases in one grouped launch
+      GemmArgs ph[GEMM_GROUP_MAX];
+      int nph = 0;
       for (int rho = 0; rho < st && rho < P.Tn[i - 1]; ++rho) {
         const int r = (rho + pt) % st;
         const int na = (KT - r + st - 1) / st;
@@ -502,17 +511,20 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
         }
         const int nj = (P.Tn[i - 1] - rho + st - 1) / st;
         const int q0 = (rho + pt) / st;
-        hipLaunchKernelGGL(k_phase_w, dim3(gridn((size_t)Ci * na * C)), dim3(256), 0, s, L[i].W, P.Wd, C, Ci, KT, r, st, na);
+        if (nph == P.wd_copies) { ASTK_TRY(gemm_launch_group(GEMM_NT, ph, nph, s)); nph = 0; }      // (more phases than buffers: flush)
+        float* wd = P.Wd + (size_t)nph * P.wd_stride;
+        hipLaunchKernelGGL(k_phase_w, dim3(gridn((size_t)Ci * na * C)), dim3(256), 0, s, L[i].W, wd, C, Ci, KT, r, st, na);
         ASTK_LAUNCH_CHECK();
         const long start = (long)(q0 - na + 1 + P.dF[i]);
         ASTK_CHECK(start >= 0, "cnn dgrad: negative window start");
-        GemmArgs g = gemm_args(B * F * nj, Ci, na * C, mat2(P.DY[i] + start * C, nj, dyrow, C), mat(P.Wd, (long)na * C),
+        GemmArgs g = gemm_args(B * F * nj, Ci, na * C, mat2(P.DY[i] + start * C, nj, dyrow, C), mat(wd, (long)na * C),
                                P.G + (long)rho * Ci, Ci);
         g.c_tn = nj;
         g.c_sg = (long)P.Tn[i - 1] * Ci;
         g.c_st = (long)st * Ci;
-        ASTK_TRY(gemm_launch(GEMM_NT, with_amax_a(lowp(g), ady), s));
+        ph[nph++] = with_amax_a(lowp(g), ady);
       }
+      if (nph > 0) ASTK_TRY(gemm_launch_group(GEMM_NT, ph, nph, s));
     }
   }
   return 0;
