@@ -24,7 +24,7 @@ struct DecPersistBuffers {
 bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int* chunk_out);
 int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_params* prm, const float* enc, const int32_t* y,
                                const int32_t* use_truth, const float* emb_mask, const float* rnn_masks, const DecPersistBuffers& bf,
-                               hipStream_t s);
+                               float* loss, int32_t* pred_out, hipStream_t s);
 
 struct DecPersistBwdBuffers {
   const float *WoT, *WcT, *ENCA, *CVH, *HT, *LOGITS, *ML;
@@ -349,13 +349,7 @@ int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
       for (int l = 0; l < nl; ++l) { bf.G[l] = P.G[l]; bf.C[l] = P.C[l]; bf.HR[l] = P.HR[l]; bf.HD[l] = P.HD[l]; }
       bf.CVH = P.CVH; bf.HT = P.HT; bf.LOGITS = P.LOGITS; bf.LOSSROWS = P.LOSSROWS; bf.LSE = P.LSE; bf.PART = P.PART;
       bf.CESTAT = P.CESTAT; bf.ENCA = P.ENCA; bf.ML = P.MLB; bf.ctr = P.PCTR;
-      ASTK_TRY(decoder_persist_fwd_launch(d, prm, enc, y, use_truth, emb_mask, rnn_masks, bf, s));
-      hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, s, P.LOSSROWS, S * B, loss);
-      ASTK_LAUNCH_CHECK();
-      if (pred) {
-        hipLaunchKernelGGL(k_copy_i32, dim3(cdiv(S * B, 256)), dim3(256), 0, s, pred, P.PRED, S * B);
-        ASTK_LAUNCH_CHECK();
-      }
+      ASTK_TRY(decoder_persist_fwd_launch(d, prm, enc, y, use_truth, emb_mask, rnn_masks, bf, loss, pred, s));   // (incl. loss sum and predictions)
       return 0;
     }
   }
