@@ -217,7 +217,7 @@ def main():
             # THE dominant kernel family (half of the step): every batched dense product of the step on f32-input MFMA
             tfl = res[6] / (res[4] * 1e-3) / 1e12
             ms_gemm, n_gemm = res[4] / args.profile_steps, int(res[5] / args.profile_steps)
-            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<NT|NN|TN> + k_absmax + k_zero_split_tiles (all batched dense products of the step)",
+            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<NT|NN|TN> + k_absmax / k_absmax_zero / k_zero_split_tiles (all batched dense products of the step with their preparation launches)",
                     "achieved": round(tfl, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
                     "traffic": profile_json("gemm_traffic.json").get("hbm_bytes_per_step"),
                     "flops_per_step": round(res[6] / args.profile_steps), "ms_per_step": round(ms_gemm, 3),
