@@ -154,13 +154,23 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
     // ---- persistent wavefront path: layer-0 upward projection batched over time, everything else in ONE launch
     PersistCellHost cells[16];
     memset(cells, 0, sizeof(cells));
-    const unsigned long long* ax = gemm_amax(x, (long)T * B, P.in, P.in, s);      // both directions multiply the same frames
+    // maxima (fp16x2 GEMM scales) of the frames -- both directions multiply the same ones -- and of the two layer-0 upward weights in
+    // ONE launch: the grouped projection launch below then needs no maximum pass of its own
+    const unsigned long long* ax = nullptr;
+    const unsigned long long* aw0[2] = {nullptr, nullptr};
+    {
+      AmaxMatrix am[3] = {{x, (long)T * B, (long)P.in, P.in}, {prm[0].Wu, 4L * h, (long)P.in, P.in},
+                          {P.nd > 1 ? prm[P.nl].Wu : nullptr, 4L * h, (long)P.in, P.in}};
+      const unsigned long long* out[3];
+      gemm_amax_many(am, 3, out, s);
+      ax = out[0]; aw0[0] = out[1]; aw0[1] = out[2];
+    }
     GemmArgs k9[2];      // the layer-0 upward projections of both directions: one grouped launch
     for (int dd = 0; dd < P.nd; ++dd) {
       const astk_lstm_params& p0 = prm[dd * P.nl];
       ASTK_CHECK(p0.Wu && p0.b && p0.Wl, "lstm_stack_fwd: null parameter (dir %d layer 0)", dd);
       MatView A = dd == 0 ? mat(x, P.in) : mat_idx(x, P.in, rows_perm);
-      k9[dd] = with_amax_a(lowp(gemm_args(T * B, 4 * h, P.in, A, mat(p0.Wu, P.in), P.ZG[dd][0], 4 * h, p0.b)), ax);     // K9
+      k9[dd] = with_amax_b(with_amax_a(lowp(gemm_args(T * B, 4 * h, P.in, A, mat(p0.Wu, P.in), P.ZG[dd][0], 4 * h, p0.b)), ax), aw0[dd]);     // K9
       for (int l = 0; l < P.nl; ++l) {
         const astk_lstm_params& p = prm[dd * P.nl + l];
         ASTK_CHECK(p.Wu && p.b && p.Wl, "lstm_stack_fwd: null parameter (dir %d layer %d)", dd, l);
@@ -339,7 +349,15 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
   int nwg = 0;
   // Absolute maxima (fp16x2 GEMM scales) of the matrices that feed several products: the frames (B operand of both directions'
   // layer-0 dWu) by a pass here, every cell's dz (dWl, dWu, input gradient) by the recurrence kernel itself on the persistent path.
-  const unsigned long long* ax = gemm_amax(x, (long)T * B, P.in, P.in, s);
+  const unsigned long long* ax = nullptr;
+  const unsigned long long* aw0[2] = {nullptr, nullptr};
+  {
+    AmaxMatrix am[3] = {{x, (long)T * B, (long)P.in, P.in}, {dx ? prm[0].Wu : nullptr, 4L * h, (long)P.in, P.in},
+                        {dx && P.nd > 1 ? prm[P.nl].Wu : nullptr, 4L * h, (long)P.in, P.in}};
+    const unsigned long long* out[3];
+    gemm_amax_many(am, 3, out, s);
+    ax = out[0]; aw0[0] = out[1]; aw0[1] = out[2];
+  }
   const unsigned long long* adz_all[16] = {nullptr};
   if (persist)
     for (int i = 0; i < P.nd * P.nl; ++i) adz_all[i] = dz_amax[i];
@@ -422,7 +440,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
       } else if (dx) {
         // dx (T,B,in) in frame order: direction 0 stores, direction 1 accumulates through the inverse permutation
         MatView A = dd == 0 ? mat(dz, 4 * h) : mat_idx(dz, 4 * h, rows_inv);
-        ASTK_TRY(gemm_launch(GEMM_NN, with_amax_a(lowp(gemm_args(rows, in, 4 * h, A, mat(p.Wu, in), dx, in, nullptr, dd == 0 ? GEMM_STORE : GEMM_ACCUM)), adz), s));
+        ASTK_TRY(gemm_launch(GEMM_NN, with_amax_b(with_amax_a(lowp(gemm_args(rows, in, 4 * h, A, mat(p.Wu, in), dx, in, nullptr, dd == 0 ? GEMM_STORE : GEMM_ACCUM)), adz), aw0[dd]), s));
       }
     }
   }
