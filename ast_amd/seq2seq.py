@@ -493,7 +493,11 @@ class SpeechEncoderDecoder:
 
     def forward_loss(self, X, y, teach_ratio, random_out=0, add_noise=0):
         if random_out:
-            raise NotImplementedError("random_out > 0 (quirk Q8) is not part of the shipped configs")
+            # seq2seq.py:457-465 replaces a target with xp.random.randint(4, dec_vocab_size + 1): the upper end is INCLUSIVE of
+            # dec_vocab_size, one past the last class, so Chainer's softmax_cross_entropy raises (NumPy) or reads out of bounds
+            # (CuPy) about once per thousand replacements -- the option cannot have been used as written; no shipped config sets it
+            raise NotImplementedError("random_out > 0 (quirk Q8): the reference draws replacement targets from [4, dec_vocab_size] inclusive, "
+                                      "an out-of-range class id; not part of the shipped configs")
         lib = self._require_gpu()
         X = self._as_input(X)
         if isinstance(y, np.ndarray):
