@@ -17,6 +17,7 @@ bool prof_enabled();
 float* prof_tick_buffer(int which);   // device buffer [257] for in-kernel phase timing (0: decoder fwd, 1: decoder bwd) or null
 void prof_start(int cat, hipStream_t s, double work);
 void prof_stop(int cat, hipStream_t s);
+void prof_add_bytes(int cat, double bytes);
 struct ProfScope {
   int cat; hipStream_t s; bool on;
   ProfScope(int c, hipStream_t st, double work = 0.0) : cat(c), s(st), on(prof_enabled()) { if (on) prof_start(cat, s, work); }

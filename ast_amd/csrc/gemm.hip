@@ -1092,6 +1092,14 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
       fprintf(stderr, "astk_gemm layout=%d M=%d N=%d K=%d batch=%d mode=%d twolvl=%d group=%d/%d G=%ld kt=%d tile=%d\n", layout, grp.g[i].M,
               grp.g[i].N, grp.g[i].K, grp.g[i].batch, grp.g[i].mode, (int)twolvl, i, grp.n, G, grp.g[i].kt, TLM * 1000 + TL);
   ProfScope prof(PROF_GEMM, s, flops);
+  if (prof_enabled()) {       // algorithmic bytes of the launch: every operand element read once, every result element written once
+    double bytes = 0;
+    for (int i = 0; i < grp.n; ++i) {
+      const GemmArgs& a = grp.g[i];
+      bytes += 4.0 * a.batch * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N * (a.mode == GEMM_STORE ? 1 : 2));
+    }
+    prof_add_bytes(PROF_GEMM, bytes);
+  }
   dim3 grid((unsigned)G, 1, 1);
   // GEMM_STORE + split tiles: the tiles several workgroups accumulate into are zeroed first (with the maximum pass when there is one)
   const bool need_zero = !aligned && any_store && G > 1;

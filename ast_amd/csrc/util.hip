@@ -23,11 +23,13 @@ struct ProfState {
   bool on = false;
   std::vector<hipEvent_t> ev[PROF_NCAT];   // start/stop pairs
   double work[PROF_NCAT] = {0, 0, 0, 0, 0, 0};
+  double bytes[PROF_NCAT] = {0, 0, 0, 0, 0, 0};     // algorithmic bytes (operands read once + results written once)
 };
 static ProfState g_prof;
 static float* g_tick = nullptr;     // [2][512] in-kernel phase timers of the persistent decoder kernels
 float* prof_tick_buffer(int which) { return (g_prof.on && g_tick) ? g_tick + 512 * which : nullptr; }
 bool prof_enabled() { return g_prof.on; }
+void prof_add_bytes(int cat, double bytes) { if (g_prof.on) g_prof.bytes[cat] += bytes; }
 void prof_start(int cat, hipStream_t s, double work) {
   hipEvent_t e;
   if (hipEventCreate(&e) != hipSuccess) return;
@@ -581,7 +583,7 @@ int astk_persist_status(unsigned* mask_out, int reset) {
 int astk_device_cu_count(void) { return device_cu_count(); }
 
 int astk_prof_begin(void) {
-  for (int c = 0; c < PROF_NCAT; ++c) { g_prof.ev[c].clear(); g_prof.work[c] = 0; }
+  for (int c = 0; c < PROF_NCAT; ++c) { g_prof.ev[c].clear(); g_prof.work[c] = 0; g_prof.bytes[c] = 0; }
   if (!g_tick) ASTK_HIP(hipMalloc((void**)&g_tick, 1024 * sizeof(float)));
   ASTK_HIP(hipMemset(g_tick, 0, 1024 * sizeof(float)));
   g_prof.on = true;
@@ -611,6 +613,7 @@ int astk_prof_end(double* res) {
   // [11] launches ; [12] bwd mean, [13] bwd max, [14] launches
   for (int k = 9; k < 24; ++k) res[k] = 0;
   res[16] = ms[PROF_DEC_FWD]; res[17] = n[PROF_DEC_FWD]; res[18] = ms[PROF_DEC_BWD]; res[19] = n[PROF_DEC_BWD];
+  res[20] = g_prof.bytes[PROF_GEMM];
   if (g_tick) {
     float h[1024];
     ASTK_HIP(hipMemcpy(h, g_tick, sizeof(h), hipMemcpyDeviceToHost));

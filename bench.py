@@ -220,6 +220,10 @@ def main():
             roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<NT|NN|TN> + k_absmax / k_absmax_zero / k_zero_split_tiles (all batched dense products of the step with their preparation launches)",
                     "achieved": round(tfl, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
                     "traffic": profile_json("gemm_traffic.json").get("hbm_bytes_per_step"),
+                    # logical operand / result bytes (window operands of the conv GEMMs counted at their im2col extent, not at the
+                    # smaller extent of the arrays they address); `traffic` is what crosses the L2's memory side, Infinity-Cache hits
+                    # included: the stream-K workgroups of an XCD sit at unrelated k positions, so a panel is re-fetched by every tile
+                    "algorithmic_bytes_per_step": round(res[20] / args.profile_steps),
                     "flops_per_step": round(res[6] / args.profile_steps), "ms_per_step": round(ms_gemm, 3),
                     "avg_launch_us": round(ms_gemm * 1e3 / max(1, n_gemm), 1), "launches_per_step": n_gemm,
                     "method": "2*M*N*K per launch / HIP events around every launch on the launch stream; traffic = FETCH_SIZE*2 + WRITE_SIZE "
