@@ -323,7 +323,6 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
     if (!frag_ok<KB>(gx)) frag_wait<KB>(r_below, frag0, wave, gx, dead, ab);
 #pragma unroll
     for (int i = 0; i < KB; ++i) ax[i] = frag_vals(gx[i]);
-    take_x();
     frag_issue<KB>(r_below, frag0 + min(1, T - 1) * step_bytes, wave, gx);
   }
 
@@ -340,6 +339,7 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
     __builtin_amdgcn_sched_barrier(0);
     if (HAS_UP) {
 #if ASTK_PERSIST_F16X2
+      take_x();       // x_t (taken at W_{t-1}) is split HERE, in front of the wait for h, not between that wait and the recurrent MFMAs
 #pragma unroll
       for (int p = 0; p < NPR; ++p) { MFMA32HG(acc, axh[p], wuh[p]) }
 #else
@@ -359,7 +359,6 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
       if (!frag_ok<KB>(gx)) { ++slow_x; frag_wait<KB>(r_below, frag0 + t1 * step_bytes, wave, gx, dead, ab); }
 #pragma unroll
       for (int i = 0; i < KB; ++i) ax[i] = frag_vals(gx[i]);
-      take_x();
     }
     // Everything issued so far has landed (that is what W_t is); saying so explicitly lets the compiler drop its own
     // conservative waits behind the slow path's merge, which would otherwise stall the recurrent MFMAs on the off-path

@@ -3,6 +3,6 @@
 for rep in 1 2; do
   for v in base loc; do
     echo -n "== $v (rep $rep): "
-    ASTK_LIB_PATH=$PWD/scratch/libastk_$v.so python bench.py --steps 30 --warmup 5 --no-cpu-baseline $AB_ARGS 2>/dev/null | grep "^{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('step', d['ms_per_step'], 'gemm', d['roofline']['ms_per_step'], d['roofline_scan']['us_per_decoder_step'])"
+    ASTK_LIB_PATH=$PWD/scratch/libastk_$v.so python bench.py --steps 30 --warmup 5 --no-cpu-baseline $AB_ARGS 2>/dev/null | grep "^{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('step', d['ms_per_step'], 'gemm', d['roofline']['ms_per_step'], d['kernels'])"
   done
 done
