@@ -478,20 +478,32 @@ def test_full_size_batch_permutation_and_gradient_accumulation(T, dec_layers, D)
     # 200- to 300-step recurrence carries into the loss
     assert abs(l1 - l0) <= (2e-5 if T <= 800 else 1e-4) * abs(l0), (l0, l1)
     assert float((e1 - e0[perm]).abs().max()) <= 2e-4 * float(e0.abs().max())
-    # Gradients: compared in the 2-norm (5e-4), with a loose bound on single entries (2e-3 of the largest).  Of the 5 M Conv+BN
-    # pre-activations of a batch a few lie within float32 rounding of their ReLU kink, so two valid float32 evaluations (another row
-    # order, hence another summation order of the statistics; another GEMM precision) differ in the sign of single units of single
-    # rows, and each such unit moves the ~100 weight-gradient entries of its channel by its row's whole share -- percents of small
-    # entries -- while loss and activations agree to 1e-7.  Seen with D = 13 under every GEMM precision, the exact-f32 chain included,
-    # as discrete states of the CNN gradients (scratch/perm_probe.py, scratch/cnn_probe.py: 3e-4, 5e-3, 5e-2 of CNN_1/W's largest
-    # entry); isolated GEMMs of the same shapes are accurate to 4e-7 (scratch/gemm_check_shapes.py).  A kernel that coupled batch
-    # rows wrongly would be off by far more than either bound.
-    gscale, gnorm = float(g0.abs().max()), float(g0.norm())
-    assert float((g1 - g0).norm()) <= 5e-4 * gnorm, float((g1 - g0).norm()) / gnorm
-    assert float((g1 - g0).abs().max()) <= 2e-3 * gscale, float((g1 - g0).abs().max()) / gscale
+    # Gradients, tensor by tensor in the 2-norm.  Everything behind the CNN agrees to ~2e-6 of its own norm (bound 5e-5).  The Conv+BN
+    # tensors get 2e-2: of the 5 M Conv+BN pre-activations of a batch a few lie within float32 rounding of their ReLU kink, so two
+    # valid float32 evaluations (another row order, hence another summation order of the statistics; another GEMM precision) differ
+    # in the sign of single units of single rows, and one unit among N incoherent contributions is ~1/sqrt(N) ~ 1e-3 of a weight
+    # gradient's norm -- while loss, activations and every other gradient agree to 1e-6.  Seen under every GEMM precision, the
+    # exact-f32 chain included, as discrete states of the CNN gradients only (scratch/perm_margin.py: 1e-6, 2.5e-4, 2.5e-3 of the
+    # tensors' norms over six permutations at D = 13; scratch/perm_probe.py, scratch/cnn_probe.py); isolated GEMMs of the same
+    # shapes are accurate to 4e-7 (scratch/gemm_check_shapes.py).  A kernel that coupled batch rows wrongly would be off by far
+    # more than either bound, and not in the CNN alone.
+    gnorm = float(g0.norm())
+
+    def worst(ga, gb):
+        w = {"cnn": 0.0, "rest": 0.0}
+        for name in m.arena.shapes:
+            o, n = m.arena.range_of(name)
+            d = float((ga[o:o + n] - gb[o:o + n]).norm()) / max(float(gb[o:o + n].norm()), 1e-6 * gnorm)
+            k = "cnn" if name.startswith("CNN_") else "rest"
+            w[k] = max(w[k], d)
+        return w
+
+    w = worst(g1, g0)
+    assert w["rest"] <= 5e-5 and w["cnn"] <= 2e-2, w
     # accumulate: same batch again without cleargrads
     _, g2, _ = run(X[perm].contiguous(), y[perm].contiguous(), clear=False)
-    assert float((g2 - 2 * g1).norm()) <= 5e-4 * gnorm and float((g2 - 2 * g1).abs().max()) <= 2e-3 * gscale
+    w = worst(g2, 2 * g1)
+    assert w["rest"] <= 5e-5 and w["cnn"] <= 2e-2, w
 
 
 @pytest.mark.parametrize("dec_layers", [1, 2])     # persistent decoder loop / per-launch decoder loop
