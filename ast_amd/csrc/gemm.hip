@@ -295,8 +295,12 @@ struct Stager {
         *reinterpret_cast<uint2*>(S + off) = make_uint2(__builtin_bit_cast(unsigned, lo2), __builtin_bit_cast(unsigned, hi2));
       } else if constexpr (PREC == PREC_F16X2) {
         unsigned h0, l0, h1, l1;
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 1)      // timing experiment (wrong results): no split arithmetic = operands that arrive as fp16 planes
+        h0 = __float_as_uint(r[p].x); l0 = __float_as_uint(r[p].y); h1 = __float_as_uint(r[p].z); l1 = __float_as_uint(r[p].w);
+#else
         split2h(r[p].x, r[p].y, scl, h0, l0);
         split2h(r[p].z, r[p].w, scl, h1, l1);
+#endif
         *reinterpret_cast<uint2*>(S + off) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(S + PL + off) = make_uint2(l0, l1);
       } else {
