@@ -12,10 +12,12 @@
 //                        with 0xFFFFFFFF before the launch, producers store each value once (sc1), consumers re-read until no
 //                        word is the sentinel -- no counter, drain, atomic or barrier on the chain.
 //   lstm_persist_bwd_rs  backward.  Reduce-scatter: the owner of 64 gate columns of dz multiplies them with its rows of W_l
-//                        (and W_u for the layer below) and hands out 16x16 partial tiles; COUNTER hand-off (R1 of
+//                        (and W_u for the layer below) and hands out 16x16 partial tiles.  Inside a cell (the recurrence's chain)
+//                        the partial tiles are a 4-deep SENTINEL ring: a consumer polls its 16 KB themselves and puts the
+//                        sentinel back behind the step's barrier.  To the layer below (which lags): COUNTER hand-off (R1 of
 //                        cdna_hip_programming.md Guideline 16: write-through stores, every storing wave drains vmcnt,
-//                        barrier, ONE lane adds to the arrival counter on its own 256-byte line; consumers poll it with
-//                        ONE lane, barrier, sc1 loads).  Counters are zeroed by a memset before every launch.
+//                        barrier, ONE lane adds to the arrival counter on its own 256-byte line; the consumer asks one step ahead
+//                        with ONE lane and fetches the partials a step early).  Counters are zeroed before every launch.
 // Every spin is bounded: on time-out a workgroup raises the abort word, every poll loop checks it, and the grid drains.
 // Residency: the launcher only uses this path when the whole grid fits one workgroup per CU (<= 256 workgroups).
 #include "common.h"
@@ -454,21 +456,29 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_g(PFwdArgs a) {
 // 16-byte pieces, are read back with fully coalesced 4-byte loads.  Counter protocol (R1): partials are written through (sc1),
 // drained, one arrival per workgroup and step on counter A (own cell) and, after the second product, counter B (layer below).
 constexpr int PR_RING = 4;
-template <int KB>
-__global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
+// Own-cell hand-off of lstm_persist_bwd_rs (the partial dh_rec tiles, on the recurrence's critical path).  1: the data is the flag, as in
+// the forward kernel -- the ring is sentinel-filled before the launch, a consumer polls its 16 KB of partial words themselves and puts the
+// sentinel back behind its read; a slot comes round again PR_RING steps later, and the consumer's per-step vmcnt(0) orders its reset in
+// front of everything its peers can have seen of it since.  No drain, barrier, counter or counter poll on the chain.  0: counter A.
+#ifndef ASTK_BWD_SENTINEL
+#define ASTK_BWD_SENTINEL 1
+#endif
+// HAS_UP: the cell has a layer above it in this stack (a template parameter so that the loads of that layer's partials are unconditional
+// code: a conditionally issued load becomes a phi whose copy makes hipcc wait for the load where it is issued)
+template <int KB, bool HAS_UP>
+__device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCellB& c, float (*dzS2)[16 * 64], int* s_ok1, int& s_ok2) {
   constexpr int NS = 4 * KB;          // slices of a cell = 16x16 output tiles of a product = partial tiles per consumer
-  __shared__ __attribute__((aligned(16))) float dzS[16 * 64];
-  __shared__ int s_ok1, s_ok2;
+  float* const dzS = dzS2[0];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, q = lane >> 4;
   const int cell = blockIdx.z, bt = blockIdx.y, j = blockIdx.x, j0 = j * 16;
-  const PCellB c = a.c[cell];      // a copy (see lstm_persist_fwd_g)
   const int T = a.T, B = a.B, h = a.h, HH = a.H, dbg = a.dbg;
   const AbortCtl ab = a.ab;
   const unsigned amax_gen = a.amax_gen;
   const int nbt = gridDim.y;
   const int K = 4 * h;
-  const bool has_up = c.PD_up != nullptr, has_down = c.PD != nullptr;
+  constexpr bool has_up = HAS_UP;
+  const bool has_down = c.PD != nullptr;
   unsigned* ctrA = a.done + (cell * nbt + bt) * CTR_STRIDE;
   unsigned* ctrB = a.done + ((a.ncells + cell) * nbt + bt) * CTR_STRIDE;
   const unsigned* upB = has_up ? a.done + ((a.ncells + cell + 1) * nbt + bt) * CTR_STRIDE : nullptr;
@@ -517,7 +527,27 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
   if (c.d_hT) dhadd = c.d_hT[ebc * h + eu];
   const int tile_bytes = 256 * 4;                          // one 16x16 partial tile
   const long cons_stride = (long)NS * tile_bytes;          // bytes between consumers
+  // Partials of the layer above: at rest in HBM when they are wanted (that layer runs ahead), i.e. a full memory latency (2.1-2.6 us in
+  // the stamps) in front of the gate epilogue if they are fetched when the step begins.  They are fetched a step early instead, right behind the barrier, when
+  // the counter says that the layer above has published them (it has, except while the pipeline fills).
+  // In front of the barrier of step t one lane makes sure that the layer above has published step t-1 (asked when the step begins, the
+  // answer is a memory round trip away; it blocks only while the pipeline fills), behind the barrier everybody fetches.
+  constexpr bool UP_PREFETCH = ASTK_BWD_SENTINEL && HAS_UP && KB <= 4;      // (32 more live registers do not fit the h = 512 kernel)
+  float pu[NS];
+  bool alive = true;
+  if (UP_PREFETCH) {
+    if (!c.up_external) {
+      if (tid == 0) s_ok1[0] = wait_ge(upB, (unsigned)NS, ab) ? 1 : 0;
+      __syncthreads();
+      alive = s_ok1[0] != 0;
+      __syncthreads();
+    }
+    const int base = (int)((((long)(T - 1) * nbt + bt) * NS + j) * cons_stride) + tid * 4;
+#pragma unroll
+    for (int p = 0; p < NS; ++p) pu[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pu, base + p * tile_bytes, 0, 16));
+  }
   bool pending_b = false;
+  bool dead = false;      // this wave gave up waiting (abort / time-out): it runs the remaining steps without waiting, so that barriers still match
   f32x4 acc2[KB];
 #pragma unroll
   for (int nt = 0; nt < KB; ++nt) acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -534,9 +564,10 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
   long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool timing = dbg != 0;
 #define TICK(i, t0) if (timing) { const long long now_ = wall_clock64(); tk[i] += now_ - t0; t0 = now_; }
-  for (int t = T - 1; t >= 0; --t) {
+  for (int t = alive ? T - 1 : -1; t >= 0; --t) {
     long long t0 = timing ? wall_clock64() : 0;
     const int stepno = T - 1 - t;
+    float* const dzT = dzS2[stepno & 1];
     const long tb = (long)t * B + ebc;
     // inputs from earlier launches: issue before any wait
     const float4 g = *reinterpret_cast<const float4*>(c.gates_dz + tb * K + 4 * eu);
@@ -549,38 +580,78 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
       dye = c.d_enc[(ebc * T + pos) * HH + eu];
     }
     float v1 = 0.f;
+    unsigned up_seen = 0;
     if (has_up) {                            // partials handed down by the layer above (it runs ahead)
-      if (!c.up_external) {
-        if (tid == 0) s_ok1 = wait_ge(upB, (unsigned)(NS * (stepno + 1)), ab) ? 1 : 0;
-        __syncthreads();
-        if (!s_ok1) break;
+      if (!UP_PREFETCH) {
+        if (!c.up_external) {
+          if (tid == 0) s_ok1[0] = wait_ge(upB, (unsigned)(NS * (stepno + 1)), ab) ? 1 : 0;
+          __syncthreads();
+          if (!s_ok1[0]) break;
+        }
+        const int base = (int)((((long)t * nbt + bt) * NS + j) * cons_stride) + tid * 4;
+#pragma unroll
+        for (int p = 0; p < NS; ++p) pu[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pu, base + p * tile_bytes, 0, 16));
       }
-      const int base = (int)((((long)t * nbt + bt) * NS + j) * cons_stride) + tid * 4;
-      float pv[NS];
 #pragma unroll
-      for (int p = 0; p < NS; ++p) pv[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pu, base + p * tile_bytes, 0, 16));
-#pragma unroll
-      for (int p = 0; p < NS; ++p) v1 += pv[p];
+      for (int p = 0; p < NS; ++p) v1 += pu[p];
+      if (UP_PREFETCH && !c.up_external && tid == 0) up_seen = ld_flag(upB);
     }
     TICK(0, t0)
     float v0 = 0.f;
+    int reset_base = -1;
     if (stepno > 0) {                        // partial dh_rec tiles of this cell's step t+1
+      const int slot = (t + 1) % PR_RING;
+      const int base = (int)((((long)slot * nbt + bt) * NS + j) * cons_stride) + tid * 4;
+#if ASTK_BWD_SENTINEL
+      unsigned pw[NS];
+#pragma unroll
+      for (int p = 0; p < NS; ++p) pw[p] = __builtin_amdgcn_raw_buffer_load_b32(r_pr, base + p * tile_bytes, 0, 16);
+      bool ok = true;
+#pragma unroll
+      for (int p = 0; p < NS; ++p) ok = ok && pw[p] != SENTINEL;
+      if (!__all(ok)) {
+        // slow path: poll ONE word per lane (its first missing one) until the wave has them all, then re-read everything; bounded
+        unsigned spins = 0;
+        while (!dead) {
+          int moff = base;
+#pragma unroll
+          for (int p = NS - 1; p >= 0; --p) moff = pw[p] == SENTINEL ? base + p * tile_bytes : moff;
+          const unsigned cw = __builtin_amdgcn_raw_buffer_load_b32(r_pr, moff, 0, 16);
+          if (__all(cw != SENTINEL)) {
+#pragma unroll
+            for (int p = 0; p < NS; ++p) pw[p] = __builtin_amdgcn_raw_buffer_load_b32(r_pr, base + p * tile_bytes, 0, 16);
+            ok = true;
+#pragma unroll
+            for (int p = 0; p < NS; ++p) ok = ok && pw[p] != SENTINEL;
+            if (__all(ok)) break;
+          }
+          if (++spins > (ab.limit >> 1)) { abort_raise(ab); dead = true; }
+          else if ((spins & 63u) == 0 && abort_seen(ab)) dead = true;
+        }
+      }
+      TICK(1, t0)
+#pragma unroll
+      for (int p = 0; p < NS; ++p) v0 += __uint_as_float(pw[p]);
+      reset_base = base - tid * 4;      // (the slot's words go back to the sentinel behind this step's barrier and product-1 stores)
+#else
       if (tid == 0) s_ok2 = wait_ge(ctrA, (unsigned)(NS * stepno), ab) ? 1 : 0;
       __syncthreads();
       if (!s_ok2) break;
       TICK(1, t0)
-      const int slot = (t + 1) % PR_RING;
-      const int base = (int)((((long)slot * nbt + bt) * NS + j) * cons_stride) + tid * 4;
       float pv[NS];
 #pragma unroll
       for (int p = 0; p < NS; ++p) pv[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pr, base + p * tile_bytes, 0, 16));
 #pragma unroll
       for (int p = 0; p < NS; ++p) v0 += pv[p];
+#endif
     }
     TICK(2, t0)
-    // every vector memory operation of this wave so far has completed (the partial loads were just consumed; the previous
-    // step's down-partials went out a whole step ago): this is the drain the deferred publish of counter B needs
+    // every vector memory operation of this wave up to the partial loads has completed (they were just consumed, vmcnt retires in
+    // order; the previous step's down-partials and sentinel resets went out a whole step ago): this is the drain the deferred
+    // publish of counter B needs, and what orders a reset in front of the slot's next use
+#if !ASTK_BWD_SENTINEL
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     float4 dz;
     {
       const float dh = v0 + (v1 + dye) * mk + (stepno == 0 ? dhadd : 0.f);
@@ -588,15 +659,25 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
       const float dcv = dh * g.w * (1.f - tc * tc) + dc_state;
       dz = make_float4(dcv * g.y * (1.f - g.x * g.x), dcv * g.x * g.y * (1.f - g.y), dcv * cp * g.z * (1.f - g.z), dh * tc * g.w * (1.f - g.w));
       dc_state = dcv * g.z;
-      *reinterpret_cast<float4*>(&dzS[r * 64 + 4 * u]) = dz;
+      *reinterpret_cast<float4*>(&dzT[r * 64 + 4 * u]) = dz;
       dzmax = fmaxf(fmaxf(dzmax, fmaxf(fabsf(dz.x), fabsf(dz.y))), fmaxf(fabsf(dz.z), fabsf(dz.w)));   // (rows past B repeat row B-1)
     }
     TICK(3, t0)
+    if (UP_PREFETCH && !c.up_external && tid == 0) {
+      const unsigned want = (unsigned)(NS * (stepno + 2));
+      s_ok1[stepno & 1] = (t == 0 || up_seen >= want || wait_ge(upB, want, ab)) ? 1 : 0;
+    }
     __syncthreads();
     if (pending_b && tid == 0) __hip_atomic_fetch_add(ctrB, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // down-partials of step t+1
+    if (UP_PREFETCH) {
+      if (!c.up_external && !s_ok1[stepno & 1]) break;
+      const int base = (int)((((long)max(t - 1, 0) * nbt + bt) * NS + j) * cons_stride) + tid * 4;      // (the last step fetches its own again)
+#pragma unroll
+      for (int p = 0; p < NS; ++p) pu[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pu, base + p * tile_bytes, 0, 16));
+    }
     float4 af[4];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) af[s4] = *reinterpret_cast<const float4*>(&dzS[r16 * 64 + 16 * s4 + 4 * q]);
+    for (int s4 = 0; s4 < 4; ++s4) af[s4] = *reinterpret_cast<const float4*>(&dzT[r16 * 64 + 16 * s4 + 4 * q]);
 #if ASTK_PERSIST_F16X2
     // dz is unbounded: its scale is taken from this step's tile (every wave holds the whole 16 x 64 tile across its lanes)
     float pscale;       // 1 / (weight scale x dz scale), applied to the partial sums
@@ -650,7 +731,15 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
       }
     }
     TICK(4, t0)
+#if ASTK_BWD_SENTINEL
+    if (reset_base >= 0) {   // behind the step's barrier every reader of the slot just consumed is done with it: the sentinel goes back (16 KB in a row)
+      const u32x4 sent = {SENTINEL, SENTINEL, SENTINEL, SENTINEL};
+#pragma unroll
+      for (int i = 0; i < NS / 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(sent, r_pr, reset_base + (i * 256 + tid) * 16, 0, 16);
+    }
+#else
     publish(ctrA);      // drain (product-1 stores only), barrier, one arrival
+#endif
     TICK(5, t0)
     if (evalid) *reinterpret_cast<float4*>(c.gates_dz + tb * K + 4 * eu) = dz;   // for the batched products after the launch
     if (has_down) {
@@ -689,6 +778,17 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
     printf("bwd_rs cell %d (layer %d): per-step 10ns: up wait+loads %lld  own wait %lld  own loads+sum %lld  epilogue %lld  barrier+mfma1+stores %lld  publishA %lld  product2+publishB %lld\n",
            cell, c.layer, tk[0] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T, tk[5] / T, tk[6] / T);
 #undef TICK
+}
+
+template <int KB>
+__global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
+  // (two copies of the dz tile, used alternately: with the sentinel hand-off the step's ONE barrier sits between a tile's writes and its
+  //  reads, and only the copy keeps a wave that is a step ahead from writing into what a slower wave still reads; the flags likewise)
+  __shared__ __attribute__((aligned(16))) float dzS2[2][16 * 64];
+  __shared__ int s_ok1[2], s_ok2;
+  const PCellB c = a.c[blockIdx.z];      // a copy (see lstm_persist_fwd_g)
+  if (c.PD_up != nullptr) lstm_bwd_rs_steps<KB, true>(a, c, dzS2, s_ok1, s_ok2);
+  else lstm_bwd_rs_steps<KB, false>(a, c, dzS2, s_ok1, s_ok2);
 }
 
 }  // namespace
@@ -769,6 +869,7 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   return 0;
 }
 
+size_t lstm_persist_pr_floats(int B, int h);
 int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters,
                             unsigned amax_gen, hipStream_t s) {
   PBwdArgs a;
@@ -789,7 +890,21 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   ASTK_CHECK(cells[0].PR != nullptr, "lstm_persist_bwd: partial-sum buffers missing");
   // counters A and B per (cell, batch tile), then the abort word
   a.ab = abort_ctl(counters + (size_t)2 * ncells * nbt * 64, PERSIST_ENC_BWD);
+#if ASTK_BWD_SENTINEL
+  {
+    // the partial dh_rec rings are hand-off buffers of the sentinel kind: filled before every launch (the counters / abort word ride along, zeroed)
+    FillSegs f;
+    f.n = 0;
+    fill_seg_add(f, counters, ((size_t)2 * ncells * nbt + 1) * 64 * sizeof(unsigned), 0u);
+    for (int i = 0; i < ncells; ++i) {
+      if (f.n + 1 > FILL_SEG_MAX) { ASTK_TRY(fill_u32_segments(f, 0xffffffffu, s)); f.n = 0; }
+      fill_seg_add(f, cells[i].PR, lstm_persist_pr_floats(B, h) * sizeof(float));
+    }
+    ASTK_TRY(fill_u32_segments(f, 0xffffffffu, s));
+  }
+#else
   ASTK_HIP(hipMemsetAsync(counters, 0, ((size_t)2 * ncells * nbt + 1) * 64 * sizeof(unsigned), s));
+#endif
   dim3 grid(h / 16, nbt, ncells), blk(256);
   ProfScope prof(PROF_CELL, s);
   switch (h) {
