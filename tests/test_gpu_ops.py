@@ -227,6 +227,9 @@ def test_cnn_fwd_bwd(lib, B, T, D, c0, c1, with_noise, gemm_split):
                                                    # h in {64,128,256,512}: the persistent wavefront kernels
                                                    (12, 5, 24, 64, 3, True), (7, 33, 16, 128, 2, False), (6, 16, 32, 256, 3, True),
                                                    (3, 4, 16, 512, 1, False), (1, 3, 8, 64, 2, True),
+                                                   # 2 steps (the backward fetches the layer above's partials one step early; its last step has
+                                                   # nothing left to fetch), 23 steps (the 4-deep sentinel ring of partial tiles comes round 5 times)
+                                                   (2, 5, 16, 128, 3, True), (23, 17, 16, 64, 3, True),
                                                    # stacks whose (direction, layer) cells exceed one workgroup per CU: consecutive launches over
                                                    # groups of layers -- 3 layers as (2, 1) at batch 200 / h = 64, 6 layers as (2, 2, 2) at h = 512
                                                    # (the encoder of BASELINE configs[4]), 3 layers as (2, 1) at batch 64 / h = 256
