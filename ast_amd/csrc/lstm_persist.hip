@@ -460,9 +460,15 @@ constexpr int PR_RING = 4;
 // the forward kernel -- the ring is sentinel-filled before the launch, a consumer polls its 16 KB of partial words themselves and puts the
 // sentinel back behind its read; a slot comes round again PR_RING steps later, and the consumer's per-step vmcnt(0) orders its reset in
 // front of everything its peers can have seen of it since.  No drain, barrier, counter or counter poll on the chain.  0: counter A.
+// Used up to h = 256 (KB <= 4): at h = 512 a consumer's slice is 32 KB per step and the counter form is the faster one (BASELINE
+// configs[4] shape: 22.0 against 22.5 ms per train step).
 #ifndef ASTK_BWD_SENTINEL
 #define ASTK_BWD_SENTINEL 1
 #endif
+#ifndef ASTK_BWD_SENTINEL_MAXKB
+#define ASTK_BWD_SENTINEL_MAXKB 4
+#endif
+constexpr bool bwd_sentinel(int KB) { return ASTK_BWD_SENTINEL && KB <= ASTK_BWD_SENTINEL_MAXKB; }
 // HAS_UP: the cell has a layer above it in this stack (a template parameter so that the loads of that layer's partials are unconditional
 // code: a conditionally issued load becomes a phi whose copy makes hipcc wait for the load where it is issued)
 template <int KB, bool HAS_UP>
@@ -532,7 +538,8 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
   // the counter says that the layer above has published them (it has, except while the pipeline fills).
   // In front of the barrier of step t one lane makes sure that the layer above has published step t-1 (asked when the step begins, the
   // answer is a memory round trip away; it blocks only while the pipeline fills), behind the barrier everybody fetches.
-  constexpr bool UP_PREFETCH = ASTK_BWD_SENTINEL && HAS_UP && KB <= 4;      // (32 more live registers do not fit the h = 512 kernel)
+  constexpr bool SENT = bwd_sentinel(KB);
+  constexpr bool UP_PREFETCH = SENT && HAS_UP && KB <= 4;      // (32 more live registers do not fit the h = 512 kernel)
   float pu[NS];
   bool alive = true;
   if (UP_PREFETCH) {
@@ -602,7 +609,7 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     if (stepno > 0) {                        // partial dh_rec tiles of this cell's step t+1
       const int slot = (t + 1) % PR_RING;
       const int base = (int)((((long)slot * nbt + bt) * NS + j) * cons_stride) + tid * 4;
-#if ASTK_BWD_SENTINEL
+      if constexpr (SENT) {
       unsigned pw[NS];
 #pragma unroll
       for (int p = 0; p < NS; ++p) pw[p] = __builtin_amdgcn_raw_buffer_load_b32(r_pr, base + p * tile_bytes, 0, 16);
@@ -633,7 +640,7 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
 #pragma unroll
       for (int p = 0; p < NS; ++p) v0 += __uint_as_float(pw[p]);
       reset_base = base - tid * 4;      // (the slot's words go back to the sentinel behind this step's barrier and product-1 stores)
-#else
+      } else {
       if (tid == 0) s_ok2 = wait_ge(ctrA, (unsigned)(NS * stepno), ab) ? 1 : 0;
       __syncthreads();
       if (!s_ok2) break;
@@ -643,15 +650,13 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
       for (int p = 0; p < NS; ++p) pv[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pr, base + p * tile_bytes, 0, 16));
 #pragma unroll
       for (int p = 0; p < NS; ++p) v0 += pv[p];
-#endif
+      }
     }
     TICK(2, t0)
     // every vector memory operation of this wave up to the partial loads has completed (they were just consumed, vmcnt retires in
     // order; the previous step's down-partials and sentinel resets went out a whole step ago): this is the drain the deferred
     // publish of counter B needs, and what orders a reset in front of the slot's next use
-#if !ASTK_BWD_SENTINEL
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+    if constexpr (!SENT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float4 dz;
     {
       const float dh = v0 + (v1 + dye) * mk + (stepno == 0 ? dhadd : 0.f);
@@ -731,15 +736,15 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
       }
     }
     TICK(4, t0)
-#if ASTK_BWD_SENTINEL
+    if constexpr (SENT) {
     if (reset_base >= 0) {   // behind the step's barrier every reader of the slot just consumed is done with it: the sentinel goes back (16 KB in a row)
       const u32x4 sent = {SENTINEL, SENTINEL, SENTINEL, SENTINEL};
 #pragma unroll
       for (int i = 0; i < NS / 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(sent, r_pr, reset_base + (i * 256 + tid) * 16, 0, 16);
     }
-#else
-    publish(ctrA);      // drain (product-1 stores only), barrier, one arrival
-#endif
+    } else {
+      publish(ctrA);      // drain (product-1 stores only), barrier, one arrival
+    }
     TICK(5, t0)
     if (evalid) *reinterpret_cast<float4*>(c.gates_dz + tb * K + 4 * eu) = dz;   // for the batched products after the launch
     if (has_down) {
@@ -890,8 +895,7 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   ASTK_CHECK(cells[0].PR != nullptr, "lstm_persist_bwd: partial-sum buffers missing");
   // counters A and B per (cell, batch tile), then the abort word
   a.ab = abort_ctl(counters + (size_t)2 * ncells * nbt * 64, PERSIST_ENC_BWD);
-#if ASTK_BWD_SENTINEL
-  {
+  if (bwd_sentinel(h / 64)) {
     // the partial dh_rec rings are hand-off buffers of the sentinel kind: filled before every launch (the counters / abort word ride along, zeroed)
     FillSegs f;
     f.n = 0;
@@ -901,10 +905,9 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
       fill_seg_add(f, cells[i].PR, lstm_persist_pr_floats(B, h) * sizeof(float));
     }
     ASTK_TRY(fill_u32_segments(f, 0xffffffffu, s));
+  } else {
+    ASTK_HIP(hipMemsetAsync(counters, 0, ((size_t)2 * ncells * nbt + 1) * 64 * sizeof(unsigned), s));
   }
-#else
-  ASTK_HIP(hipMemsetAsync(counters, 0, ((size_t)2 * ncells * nbt + 1) * 64 * sizeof(unsigned), s));
-#endif
   dim3 grid(h / 16, nbt, ncells), blk(256);
   ProfScope prof(PROF_CELL, s);
   switch (h) {
