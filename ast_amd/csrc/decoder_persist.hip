@@ -39,6 +39,10 @@ constexpr int PDEC_MAX_LAYERS = 3;
 // utterances of 1680 frames) are streamed from L2 / Infinity Cache every step -- they are the same bytes for every step of the loop.
 constexpr int PDEC_RES_ROWS = 28, PDEC_CHUNK_MAX = 60;
 constexpr int NPHASE_SLOTS = 8;   // counter lines reserved per batch tile ahead of the abort word and the per-row counters
+#ifndef ASTK_PDEC_SENT_H
+#define ASTK_PDEC_SENT_H 1
+#endif
+constexpr unsigned PDEC_SENTINEL = 0xffffffffu;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -354,6 +358,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
   __syncthreads();
 
   const __amdgpu_buffer_rsrc_t r_x0 = make_rsrc(a.X0), r_hr = make_rsrc(a.HR[0]), r_cvh = make_rsrc(a.CVH), r_ht = make_rsrc(a.HT);
+  bool att_dead = false;     // this wave gave up polling a sentinel hand-off (abort / time-out): it goes on without waiting
   const __amdgpu_buffer_rsrc_t r_part = make_rsrc(a.PART), r_ces = make_rsrc(a.CESTAT);
   // cell epilogue ownership: threads 0..127: tile = tid>>6, (row = (tid>>2)&15, unit = tid&3)
   const int ce_tile = tid >> 6, ce_row = (tid >> 2) & 15, ce_u = tid & 3;
@@ -516,14 +521,33 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
     if (has_att) {
       const int b = att_b, bt = b / 16;
       TICK(15)
-      if (!wg_wait_sh(CTR(PH_CELL + TOP, bt), H / 8, s + 1, a.ab, &s_flag)) return;
-      TICK(4)
-      const long long ta0 = a.tick_out ? wall_clock64() : 0;
       const int c4 = (a.chunk + 3) & ~3;
       float* hS = scr;                 // [H]
       float* scS = scr + H;            // [c4] raw scores (tail padded with -inf)
       float* pS = scr + H + c4;        // [c4] exp(score - m) (tail 0)
+#if ASTK_PDEC_SENT_H
+      // The data is the flag (lstm_persist.hip): the h half of CVH is sentinel-filled before the launch and this row's 2 KB are polled
+      // themselves -- no drain, counter, counter poll or barrier between the top cell's stores and the scan.
+      if (tid < H / 4) {
+        const int off = (int)((((long)s * B + b) * 2 * H + H + 4 * tid) * 4);
+        u32x4 v;
+        unsigned spins = 0;
+        for (;;) {
+          v = __builtin_amdgcn_raw_buffer_load_b128(r_cvh, off, 0, 16);
+          if (__all((v.x != PDEC_SENTINEL) & (v.y != PDEC_SENTINEL) & (v.z != PDEC_SENTINEL) & (v.w != PDEC_SENTINEL)) || att_dead) break;
+          if (++spins > (a.ab.limit >> 1)) { abort_raise(a.ab); att_dead = true; }
+          else if ((spins & 63u) == 0 && abort_seen(a.ab)) att_dead = true;
+        }
+        *reinterpret_cast<float4*>(hS + 4 * tid) = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      }
+      TICK(4)
+      const long long ta0 = a.tick_out ? wall_clock64() : 0;
+#else
+      if (!wg_wait_sh(CTR(PH_CELL + TOP, bt), H / 8, s + 1, a.ab, &s_flag)) return;
+      TICK(4)
+      const long long ta0 = a.tick_out ? wall_clock64() : 0;
       if (tid < H / 4) *reinterpret_cast<float4*>(hS + 4 * tid) = ldb128_sc1(r_cvh, ((long)s * B + b) * 2 * H + H + 4 * tid);
+#endif
       float m, l = 0.f, my_score;
       float* prow = a.PART + (((long)s * B + b) * a.nsplit + att_sp) * (H + 4);
       if constexpr (NC > 0) {
@@ -1658,7 +1682,17 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
   a.ab = abort_ctl(bf.ctr + (size_t)NPHASE_SLOTS * NSH * a.nbt * CTRS, PERSIST_DEC_FWD);
   { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.tick_out = prof_tick_buffer(0);
+#if ASTK_PDEC_SENT_H
+  {
+    FillSegs f;
+    f.n = 0;
+    fill_seg_add(f, bf.ctr, ((size_t)NPHASE_SLOTS * NSH * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), 0u);
+    fill_seg_add(f, bf.CVH, (size_t)a.S * a.B * 2 * a.H * sizeof(float));
+    ASTK_TRY(fill_u32_segments(f, PDEC_SENTINEL, s));
+  }
+#else
   ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)NPHASE_SLOTS * NSH * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), s));
+#endif
   const size_t shm = pdec_lds_floats(chunk, a.H, nsplit) * sizeof(float);
   {
     ProfScope prof(PROF_DEC_FWD, s);
