@@ -23,7 +23,14 @@ def run(layout, M, N, K, mode=0):
     us = e0.elapsed_time(e1) / 20 * 1e3
     tot += us
     print(f"layout {layout} {M}x{N}x{K} mode {mode}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:6.1f} TFLOP/s", flush=True)
-for (l, M, N, K, mode) in ((0, 6400, 1024, 2560, 0), (1, 6400, 2560, 1024, 0), (2, 1024, 2560, 6400, 2), (0, 38400, 512, 1152, 0), (1, 38400, 1152, 512, 0),
-                           (2, 512, 1152, 38400, 2), (0, 4096, 4096, 4096, 0), (1, 4096, 4096, 4096, 0)):
+import os
+shapes = ((0, 6400, 1024, 2560, 0), (1, 6400, 2560, 1024, 0), (2, 1024, 2560, 6400, 2), (0, 38400, 512, 1152, 0), (1, 38400, 1152, 512, 0),
+          (2, 512, 1152, 38400, 2), (0, 4096, 4096, 4096, 0), (1, 4096, 4096, 4096, 0))
+if os.environ.get("SHAPES") == "ksweep":      # same work, different tile counts / k depths
+    shapes = ((1, 6400, 3072, 1024, 0), (1, 3200, 3072, 2048, 0), (1, 1600, 3072, 4096, 0), (1, 6144, 3072, 1024, 0), (1, 6400, 3072, 512, 0),
+              (0, 6400, 1024, 3072, 0), (0, 3200, 2048, 3072, 0), (0, 6400, 1024, 1024, 0))
+if os.environ.get("SHAPES") == "msweep":
+    shapes = tuple((1, m, 3072, 1024, 0) for m in (5120, 5632, 6016, 6144, 6272, 6400, 6528, 6656, 7168, 7680, 8192))
+for (l, M, N, K, mode) in shapes:
     run(l, M, N, K, mode)
 print(f"sum {tot:.1f} us")
