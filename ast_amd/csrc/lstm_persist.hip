@@ -189,10 +189,12 @@ __device__ __forceinline__ void frag_issue(__amdgpu_buffer_rsrc_t rs, int byte_o
 }
 template <int NB>
 __device__ __forceinline__ bool frag_ok(const u32x4 (&g)[NB]) {
-  bool ok = true;
+  // (the sentinel is the largest unsigned word: one running maximum and ONE compare -- a chain of && compiles to a branch per word,
+  //  0.25 us per check on the recurrence's critical path)
+  unsigned m = 0;
 #pragma unroll
-  for (int i = 0; i < NB; ++i) ok = ok && (g[i].x != SENTINEL) && (g[i].y != SENTINEL) && (g[i].z != SENTINEL) && (g[i].w != SENTINEL);
-  return __all(ok);
+  for (int i = 0; i < NB; ++i) m = max(max(m, g[i].x), max(max(g[i].y, g[i].z), g[i].w));
+  return __all(m != SENTINEL);
 }
 // Slow path: some fragment was not there yet.  Poll ONE fragment per lane until it is complete (waiting waves must not
 // flood the fabric with full sweeps), then re-read everything; repeat until complete.  Bounded; a time-out raises the
@@ -311,7 +313,8 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
     }
   };
   long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int slow_x = 0, slow_h = 0;
+  int slow_x = 0, slow_h = 0, nbig2 = 0;
+  long long big2 = 0;
   const bool timing = (dbg & 8) != 0;
 #define TICK(i, t0) if (timing) { __builtin_amdgcn_sched_barrier(0); const long long now_ = wall_clock64(); tk[i] += now_ - t0; t0 = now_; __builtin_amdgcn_sched_barrier(0); }
 
@@ -349,6 +352,12 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
       for (int i = 0; i < KB; ++i) { MFMA4G(acc, ax[i], wu[i]) }
 #endif
     }
+    const int t1 = min(t + 1, T - 1), t2 = min(t + 2, T - 1);
+    if (HAS_UP) {   // x_{t+1}: issued a whole step ago, taken over HERE, while h_{t-1} is still in flight (behind the wait it was 0.27 us of the chain)
+      if (!frag_ok<KB>(gx)) { ++slow_x; frag_wait<KB>(r_below, frag0 + t1 * step_bytes, wave, gx, dead, ab); }
+#pragma unroll
+      for (int i = 0; i < KB; ++i) ax[i] = frag_vals(gx[i]);
+    }
     __builtin_amdgcn_sched_barrier(0);
     TICK(0, t0)
     // ---- W_t
@@ -356,17 +365,11 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
       if (!frag_ok<KB>(gh)) { ++slow_h; frag_wait<KB>(r_own, frag - step_bytes, wave, gh, dead, ab); }
     }
     TICK(1, t0)
-    const int t1 = min(t + 1, T - 1), t2 = min(t + 2, T - 1);
-    if (HAS_UP) {   // x_{t+1}: issued a whole step ago
-      if (!frag_ok<KB>(gx)) { ++slow_x; frag_wait<KB>(r_below, frag0 + t1 * step_bytes, wave, gx, dead, ab); }
-#pragma unroll
-      for (int i = 0; i < KB; ++i) ax[i] = frag_vals(gx[i]);
-    }
     // Everything issued so far has landed (that is what W_t is); saying so explicitly lets the compiler drop its own
     // conservative waits behind the slow path's merge, which would otherwise stall the recurrent MFMAs on the off-path
     // loads issued next.
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    TICK(2, t0)
+    { const long long b2_ = tk[2]; TICK(2, t0) if (timing && tk[2] - b2_ > 100) { big2 += tk[2] - b2_; ++nbig2; } }
     // ---- off-path traffic
     if (HAS_UP) frag_issue<KB>(r_below, frag0 + t2 * step_bytes, wave, gx);
     {
@@ -430,8 +433,8 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
   for (int t = 1; t < T; ++t) step(std::false_type{}, t);
   store_saved(T - 1);
   if (timing && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0)
-    printf("persist_fwd_g cell %d (layer %d) wave %d: per-step 10ns ticks: issue+xmfma %lld  h_wait %lld  take_x %lld  traffic %lld  hmfma+lds %lld  barrier %lld  epilogue %lld  slow x %d h %d\n",
-           (int)blockIdx.z, c.layer, wave, tk[0] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T, tk[5] / T, tk[6] / T, slow_x, slow_h);
+    printf("persist_fwd_g cell %d (layer %d) wave %d: per-step 10ns ticks: issue+xmfma %lld  h_wait %lld  take_x %lld  traffic %lld  hmfma+lds %lld  barrier %lld  epilogue %lld  slow x %d h %d  take_x > 1 us: %d times, %lld ticks\n",
+           (int)blockIdx.z, c.layer, wave, tk[0] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T, tk[5] / T, tk[6] / T, slow_x, slow_h, nbig2, big2);
 #undef TICK
 }
 
@@ -613,10 +616,10 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
       unsigned pw[NS];
 #pragma unroll
       for (int p = 0; p < NS; ++p) pw[p] = __builtin_amdgcn_raw_buffer_load_b32(r_pr, base + p * tile_bytes, 0, 16);
-      bool ok = true;
+      unsigned mx = 0;      // (the sentinel is the largest unsigned word: a running maximum and one compare, not a branch per word)
 #pragma unroll
-      for (int p = 0; p < NS; ++p) ok = ok && pw[p] != SENTINEL;
-      if (!__all(ok)) {
+      for (int p = 0; p < NS; ++p) mx = max(mx, pw[p]);
+      if (!__all(mx != SENTINEL)) {
         // slow path: poll ONE word per lane (its first missing one) until the wave has them all, then re-read everything; bounded
         unsigned spins = 0;
         while (!dead) {
@@ -627,10 +630,10 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
           if (__all(cw != SENTINEL)) {
 #pragma unroll
             for (int p = 0; p < NS; ++p) pw[p] = __builtin_amdgcn_raw_buffer_load_b32(r_pr, base + p * tile_bytes, 0, 16);
-            ok = true;
+            mx = 0;
 #pragma unroll
-            for (int p = 0; p < NS; ++p) ok = ok && pw[p] != SENTINEL;
-            if (__all(ok)) break;
+            for (int p = 0; p < NS; ++p) mx = max(mx, pw[p]);
+            if (__all(mx != SENTINEL)) break;
           }
           if (++spins > (ab.limit >> 1)) { abort_raise(ab); dead = true; }
           else if ((spins & 63u) == 0 && abort_seen(ab)) dead = true;
