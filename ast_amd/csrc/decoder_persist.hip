@@ -151,8 +151,8 @@ __device__ __forceinline__ void publish(unsigned* ctr) {
 __device__ __forceinline__ void publish_sh(unsigned* base, int item) { publish(base + (item & (NSH - 1)) * CTRS); }
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 // gate / tanh activations on the decoder chain: v_exp_f32 / v_rcp_f32 based (absolute error <= ~2e-7), as in lstm_persist.hip
-__device__ __forceinline__ float sigm_fast(float x) { return __frcp_rn(1.f + __expf(-x)); }
-__device__ __forceinline__ float tanh_fast(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
+__device__ __forceinline__ float sigm_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

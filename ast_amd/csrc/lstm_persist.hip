@@ -109,8 +109,8 @@ __device__ __forceinline__ void publish(unsigned* ctr) {
 
 // Gate activations of the persistent kernels' epilogues (on the recurrence's critical path): v_exp_f32 / v_rcp_f32 based,
 // absolute error <= ~2e-7 (libdevice's tanhf/expf with full-precision division cost ~0.25 us more per step).
-__device__ __forceinline__ float sigm_fast(float x) { return __frcp_rn(1.f + __expf(-x)); }
-__device__ __forceinline__ float tanh_fast(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
+__device__ __forceinline__ float sigm_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // raw buffer descriptor over a hand-off buffer: lets the compiler track 16-byte sc1 loads / stores itself
@@ -370,16 +370,6 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
     // loads issued next.
     __builtin_amdgcn_s_waitcnt(0x0F70);
     { const long long b2_ = tk[2]; TICK(2, t0) if (timing && tk[2] - b2_ > 100) { big2 += tk[2] - b2_; ++nbig2; } }
-    // ---- off-path traffic
-    if (HAS_UP) frag_issue<KB>(r_below, frag0 + t2 * step_bytes, wave, gx);
-    {
-      const long tbs = (long)t1 * B + ebc;
-      if (!HAS_UP) zadd_n = *reinterpret_cast<const float4*>(c.zx + tbs * 4 * h + 4 * eu);
-      mk_raw_n = maskp[tbs * h + eu];
-    }
-    if (!FIRST) store_saved(t - 1);
-    __builtin_amdgcn_sched_barrier(0);
-    TICK(3, t0)
     if (!FIRST) {
 #if ASTK_PERSIST_F16X2
 #pragma unroll
@@ -395,6 +385,18 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
       }
 #endif
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- off-path traffic: issued BEHIND the recurrent MFMAs (they run in the matrix pipe meanwhile; in front of them these loads, stores and their
+    // address arithmetic were 0.18 us of the chain)
+    if (HAS_UP) frag_issue<KB>(r_below, frag0 + t2 * step_bytes, wave, gx);
+    {
+      const long tbs = (long)t1 * B + ebc;
+      if (!HAS_UP) zadd_n = *reinterpret_cast<const float4*>(c.zx + tbs * 4 * h + 4 * eu);
+      mk_raw_n = maskp[tbs * h + eu];
+    }
+    if (!FIRST) store_saved(t - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    TICK(3, t0)
     // ---- 4-wave K reduction through LDS (double-buffered: one barrier per step)
     float* rd = (t & 1) ? red1 : red0;
 #pragma unroll
@@ -433,7 +435,7 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
   for (int t = 1; t < T; ++t) step(std::false_type{}, t);
   store_saved(T - 1);
   if (timing && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0)
-    printf("persist_fwd_g cell %d (layer %d) wave %d: per-step 10ns ticks: issue+xmfma %lld  h_wait %lld  take_x %lld  traffic %lld  hmfma+lds %lld  barrier %lld  epilogue %lld  slow x %d h %d  take_x > 1 us: %d times, %lld ticks\n",
+    printf("persist_fwd_g cell %d (layer %d) wave %d: per-step 10ns ticks: issue+xmfma %lld  h_wait %lld  take_x %lld  hmfma+traffic %lld  lds %lld  barrier %lld  epilogue %lld  slow x %d h %d  take_x > 1 us: %d times, %lld ticks\n",
            (int)blockIdx.z, c.layer, wave, tk[0] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T, tk[5] / T, tk[6] / T, slow_x, slow_h, nbig2, big2);
 #undef TICK
 }
