@@ -182,6 +182,9 @@ __device__ __forceinline__ float amax4f(float m, const float4& v) { return fmaxf
 // word is the sentinel.  4-byte stores are single-copy atomic, nothing is reused within a launch, so no tag, no flag, no
 // drain, no barrier is needed, and the buffers double as the saved activations the later launches read.
 constexpr unsigned SENTINEL = 0xffffffffu;
+#ifndef ASTK_FRAG_WAIT_SWEEP
+#define ASTK_FRAG_WAIT_SWEEP 3
+#endif
 template <int NB>
 __device__ __forceinline__ void frag_issue(__amdgpu_buffer_rsrc_t rs, int byte_off, int wave, u32x4 (&g)[NB]) {
 #pragma unroll
@@ -203,6 +206,16 @@ template <int NB>
 __device__ __forceinline__ void frag_wait(__amdgpu_buffer_rsrc_t rs, int byte_off, int wave, u32x4 (&g)[NB], bool& dead, const AbortCtl& ab) {
   unsigned spins = 0;
   while (!dead) {
+#if ASTK_FRAG_WAIT_SWEEP
+    // the first retries are whole sweeps: a miss then costs one more round trip, not two (poll, then re-read); a producer that is
+    // really late is polled with one fragment per lane as before
+    if (spins < ASTK_FRAG_WAIT_SWEEP) {
+      frag_issue<NB>(rs, byte_off, wave, g);
+      if (frag_ok<NB>(g)) return;
+      ++spins;
+      continue;
+    }
+#endif
     const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off + 64 * wave, 0, 16);
     if (__all((c.x != SENTINEL) & (c.y != SENTINEL) & (c.z != SENTINEL) & (c.w != SENTINEL))) {
       frag_issue<NB>(rs, byte_off, wave, g);
@@ -625,6 +638,18 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
         // slow path: poll ONE word per lane (its first missing one) until the wave has them all, then re-read everything; bounded
         unsigned spins = 0;
         while (!dead) {
+#if ASTK_FRAG_WAIT_SWEEP
+          if (spins < ASTK_FRAG_WAIT_SWEEP) {      // the first retries are whole sweeps (see frag_wait)
+#pragma unroll
+            for (int p = 0; p < NS; ++p) pw[p] = __builtin_amdgcn_raw_buffer_load_b32(r_pr, base + p * tile_bytes, 0, 16);
+            mx = 0;
+#pragma unroll
+            for (int p = 0; p < NS; ++p) mx = max(mx, pw[p]);
+            if (__all(mx != SENTINEL)) break;
+            ++spins;
+            continue;
+          }
+#endif
           int moff = base;
 #pragma unroll
           for (int p = NS - 1; p >= 0; --p) moff = pw[p] == SENTINEL ? base + p * tile_bytes : moff;
