@@ -68,6 +68,9 @@ SIGNATURES = {
     "astk_set_low_precision_gemms": (C.c_int, [_I]),
     "astk_get_low_precision_gemms": (C.c_int, []),
     "astk_set_gemm_bf16_split_below": (C.c_double, [C.c_double]),
+    "astk_set_gemm_precision": (C.c_int, [_I]),
+    "astk_get_gemm_precision": (C.c_int, []),
+    "astk_debug_set_amax_generation": (C.c_int, [C.c_uint]),
     "astk_gemm_f32": (C.c_int, [_I, _I, _I, _I, _VP, _L, _VP, _L, _VP, _L, _VP, _I, _I, _I, _L, _L, _L, _VP]),
     "astk_conv_bn_relu_out_dims": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "astk_conv_bn_relu_workspace_bytes": (_SZ, [C.POINTER(CnnDesc)]),

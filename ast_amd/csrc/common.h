@@ -201,10 +201,11 @@ int gemm_launch(int layout, const GemmArgs& g, hipStream_t s);
 const unsigned long long* gemm_amax(const float* p, long rows, long ld, int inner, hipStream_t s);
 // For a kernel that takes the maximum of a matrix while it writes it: n handles (16 sharded 64-bit words each) and the generation
 // tag; the kernel does atomicMax(slot + (block & 15), (u64)gen << 32 | float_bits(block maximum)) from every block.
-void gemm_amax_reserve(int n, unsigned long long** slots, unsigned* gen);
+void gemm_amax_reserve(int n, unsigned long long** slots, unsigned* gen, hipStream_t s);
 struct AmaxMatrix { const float* p; long rows, ld; int inner; };
 void gemm_amax_many(const AmaxMatrix* m, int n, const unsigned long long** out, hipStream_t s);     // several matrices, one launch
 int low_precision_gemms();      // the mode set by astk_set_low_precision_gemms
+int gemm_precision_mode();      // astk_set_gemm_precision: 0 fp16x2, 1 bf16x3, 2 f32
 // Scoped cap on the co-resident GEMM workgroups per CU for launches made by this thread (0 = none): work that is meant to run
 // BESIDE a persistent recurrence kernel must leave registers free on every CU, or that kernel cannot become resident until the
 // stream-K workgroups (which live for the whole launch) have finished.

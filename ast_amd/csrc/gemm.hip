@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <type_traits>
 
 namespace astk {
@@ -291,7 +292,9 @@ struct Stager {
     for (int p = 0; p < NP; ++p) {
       const int off = RK ? (a >> 1) * sp_hs(TL) + (NP * b + p) * 16 + (a & 1) * 8 : (b + RP * p) * sp_rs(TL) + a * 8;
       if constexpr (PREC == PREC_F16) {
-        const f16x2 lo2 = {(_Float16)r[p].x, (_Float16)r[p].y}, hi2 = {(_Float16)r[p].z, (_Float16)r[p].w};
+        // (behind the operand's power-of-two scale when its caller measured it -- the backward products' dY / dz would otherwise flush
+        //  to zero below 6e-8 and overflow above 65504; scale 1 for operands nobody measured: weights, forward activations)
+        const f16x2 lo2 = {(_Float16)(r[p].x * scl), (_Float16)(r[p].y * scl)}, hi2 = {(_Float16)(r[p].z * scl), (_Float16)(r[p].w * scl)};
         *reinterpret_cast<uint2*>(S + off) = make_uint2(__builtin_bit_cast(unsigned, lo2), __builtin_bit_cast(unsigned, hi2));
       } else if constexpr (PREC == PREC_F16X2) {
         unsigned h0, l0, h1, l1;
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
     sa.init(A, m0, g.M, kbeg, kend, tid);
     sb.init(B, n0, g.N, kbeg, kend, tid);
     int seA = 127, seB = 127;
-    if constexpr (PREC == PREC_F16X2) {
+    if constexpr (PREC == PREC_F16X2 || PREC == PREC_F16) {
       seA = scale_exp(g.amaxA);
       seB = scale_exp(g.amaxB);
       sa.scl = __uint_as_float((unsigned)seA << 23);
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
           if (kt + 4 < nk) cstep(std::integral_constant<int, 4>{}, kt + 4);
           if (kt + 5 < nk) cstep(std::integral_constant<int, 5>{}, kt + 5);
         }
-        if constexpr (PREC == PREC_F16X2) {
+        if constexpr (PREC == PREC_F16X2 || PREC == PREC_F16) {
           const float ia = __uint_as_float((unsigned)(254 - seA) << 23), ib = __uint_as_float((unsigned)(254 - seB) << 23);
 #pragma unroll
           for (int i = 0; i < NAM; ++i)
@@ -951,19 +954,42 @@ static thread_local int tl_wg_cap = 0;
 GemmWgCap::GemmWgCap(int per_cu) : prev(tl_wg_cap) { tl_wg_cap = per_cu; }
 GemmWgCap::~GemmWgCap() { tl_wg_cap = prev; }
 
-// operand precision: fp16x2 (scaled two-term fp16 split) unless ASTK_GEMM_PREC = bf16x3 (three-term bf16 split) or f32 (exact f32 MFMA chain)
-static int default_prec() {
-  static const int p = !getenv("ASTK_GEMM_PREC") ? PREC_F16X2
-                       : !strcmp(getenv("ASTK_GEMM_PREC"), "f32") ? PREC_F32
-                       : !strcmp(getenv("ASTK_GEMM_PREC"), "bf16x3") ? PREC_BF16X3 : PREC_F16X2;
-  return p;
+// operand precision of the f32-accurate products: fp16x2 (scaled two-term fp16 split) unless ASTK_GEMM_PREC = bf16x3 (three-term bf16
+// split) or f32 (exact f32 MFMA chain) is in the environment at load time, or astk_set_gemm_precision() has been called since
+static int prec_from_env() {
+  const char* e = getenv("ASTK_GEMM_PREC");
+  return !e ? PREC_F16X2 : !strcmp(e, "f32") ? PREC_F32 : !strcmp(e, "bf16x3") ? PREC_BF16X3 : PREC_F16X2;
 }
+static std::atomic<int> g_prec{prec_from_env()};
+static int default_prec() { return g_prec.load(std::memory_order_relaxed); }
+int gemm_precision_mode() { const int p = default_prec(); return p == PREC_F32 ? 2 : (p == PREC_BF16X3 ? 1 : 0); }
 static unsigned long long* amax_ring() {
   static unsigned long long* ring = nullptr;
   if (!ring && hipGetSymbolAddress((void**)&ring, HIP_SYMBOL(g_amax_ring)) != hipSuccess) ring = nullptr;
   return ring;
 }
 static std::atomic<unsigned> g_amax_counter{1};
+// The generation tag of an absolute-maximum pass (high half of the 64-bit atomicMax words: a slot never has to be cleared, a word of an
+// older pass loses to any word of a newer one).  The tag is 32 bits wide: at ~40 passes per train step it would wrap after about a
+// week of training in one process, and from then on every new word would LOSE to the stale ones (frozen scales: overflow to inf or
+// silently lost bits).  So the counter never wraps: when it comes within reach of the end, the whole ring is zeroed ON THE LAUNCH
+// STREAM (ordered behind every launch that still reads an old word, in front of every pass that writes a new one) and counting
+// restarts at 1.  Like the ring itself this relies on all GEMM launches of a process being ordered on one stream at a time (the
+// opt-in side-stream overlap of ast_amd/seq2seq.py keeps its launches on bf16x3 operands, which use no slots: GemmWgCap).
+constexpr unsigned AMAX_GEN_WRAP = 0xFFFFFF00u;
+static std::mutex g_amax_wrap_mutex;
+static unsigned next_amax_gen(hipStream_t s) {
+  unsigned gen = g_amax_counter.fetch_add(1);
+  if (gen < AMAX_GEN_WRAP) return gen;
+  std::lock_guard<std::mutex> lock(g_amax_wrap_mutex);
+  if (g_amax_counter.load() >= AMAX_GEN_WRAP) {      // first thread to get here restarts the count
+    unsigned long long* ring = nullptr;
+    if (hipGetSymbolAddress((void**)&ring, HIP_SYMBOL(g_amax_ring)) == hipSuccess && ring) (void)hipMemsetAsync(ring, 0, sizeof(unsigned long long) * AMAX_SLOTS, s);
+    g_amax_counter.store(2);
+    return 1;
+  }
+  return g_amax_counter.fetch_add(1);
+}
 // slots [0, AMAX_SLOTS / 2) serve the launches' own passes, [AMAX_SLOTS / 2, AMAX_SLOTS) the callers' handles (gemm_amax)
 static std::atomic<unsigned> g_amax_handle{0};
 
@@ -1014,6 +1040,9 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     for (int i = 0; i < n; ++i) all = all && list[i].lowp != 0;
     if (all) prec = PREC_F16;
   }
+  // launches capped to share the CUs with a recurrence kernel are the ones a caller puts on a SIDE stream: the scale slots of the
+  // fp16x2 scheme are a process-wide ring ordered by one stream, so these launches take the scheme that needs none
+  if (prec == PREC_F16X2 && tl_wg_cap > 0) prec = PREC_BF16X3;
   int TL = 128, TLM = 128;
   for (int pass = 0; pass < 3; ++pass) {
     memset(&grp, 0, sizeof(grp));
@@ -1119,7 +1148,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     ASTK_CHECK(ring != nullptr, "gemm: no absmax ring");
     AmaxJobs J;
     memset(&J, 0, sizeof(J));
-    const unsigned gen = g_amax_counter.fetch_add(1);
+    const unsigned gen = next_amax_gen(s);
     J.gen = gen;
     const bool a_kr = layout == GEMM_TN, b_kr = layout != GEMM_NT;
     auto list_view = [](MatView v) { if (v.tn == 0x7fffffff) v.tn = 0; return v; };    // (a plain operand dressed as one group, see above)
@@ -1183,7 +1212,7 @@ void gemm_amax_many(const AmaxMatrix* m, int n, const unsigned long long** out, 
   ProfScope prof(PROF_GEMM, s, 0.0);       // part of the GEMMs' cost: timed with them (no flops of its own)
   AmaxJobs J;
   memset(&J, 0, sizeof(J));
-  J.gen = g_amax_counter.fetch_add(1);
+  J.gen = next_amax_gen(s);
   for (int i = 0; i < n; ++i) {
     if (!m[i].p || m[i].rows <= 0 || m[i].inner <= 0) continue;
     if (J.n + 2 > AMAX_REGIONS) {          // (two regions per contiguous matrix)
@@ -1199,10 +1228,10 @@ void gemm_amax_many(const AmaxMatrix* m, int n, const unsigned long long** out, 
   if (J.n > 0) hipLaunchKernelGGL(k_absmax, dim3((unsigned)J.blk_start[J.n]), dim3(256), 0, s, J);
 }
 
-void gemm_amax_reserve(int n, unsigned long long** slots, unsigned* gen) {
+void gemm_amax_reserve(int n, unsigned long long** slots, unsigned* gen, hipStream_t s) {
   unsigned long long* ring = amax_ring();
   const bool on = default_prec() == PREC_F16X2 && ring != nullptr;
-  *gen = on ? g_amax_counter.fetch_add(1) : 0;
+  *gen = on ? next_amax_gen(s) : 0;
   for (int i = 0; i < n; ++i)
     slots[i] = on ? ring + AMAX_SLOTS / 2 + (g_amax_handle.fetch_add(1) % (AMAX_SLOTS / 2 / AMAX_SHARDS)) * AMAX_SHARDS : nullptr;
 }
@@ -1222,6 +1251,14 @@ extern "C" int astk_set_low_precision_gemms(int mode) {
   return 0;
 }
 extern "C" int astk_get_low_precision_gemms(void) { return astk::g_lowp_mode; }
+extern "C" int astk_set_gemm_precision(int mode) {
+  if (mode < 0 || mode > 2) { astk::set_error("set_gemm_precision: mode must be 0 (fp16x2), 1 (bf16x3) or 2 (f32)"); return -1; }
+  const int prev = astk::gemm_precision_mode();
+  astk::g_prec.store(mode == 2 ? astk::PREC_F32 : (mode == 1 ? astk::PREC_BF16X3 : astk::PREC_F16X2));
+  return prev;
+}
+extern "C" int astk_get_gemm_precision(void) { return astk::gemm_precision_mode(); }
+extern "C" int astk_debug_set_amax_generation(unsigned gen) { astk::g_amax_counter.store(gen ? gen : 1u); return 0; }
 extern "C" double astk_set_gemm_bf16_split_below(double flops) { return astk::g_small_flops.exchange(flops < 0 ? 0.0 : flops); }
 
 namespace astk {

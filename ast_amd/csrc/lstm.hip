@@ -322,7 +322,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
         c.layer = l;
       }
     // the recurrence kernel leaves max |dz| of every cell for the batched products behind it (fp16x2 GEMM scales)
-    gemm_amax_reserve(P.nd * P.nl, dz_amax, &dz_amax_gen);
+    gemm_amax_reserve(P.nd * P.nl, dz_amax, &dz_amax_gen, s);
     for (int i = 0; i < P.nd * P.nl; ++i) cells[i].amax = dz_amax[i];
     ASTK_TRY(stream_order(s, sr));     // the recurrence kernel may live on its own (CU-masked) stream, see astk.h
     {

@@ -131,14 +131,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
   _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) ACC[g_] = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).z, (W)[g_].z, ACC[g_], 0, 0, 0); \
   _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) ACC[g_] = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).w, (W)[g_].w, ACC[g_], 0, 0, 0);
 
-// fp16x2 form of the recurrences' products (ASTK_PERSIST_F16X2, default on): the weights a workgroup keeps in registers are split ONCE
+// fp16x2 form of the recurrences' products (template parameter X2): the weights a workgroup keeps in registers are split ONCE
 // into fp16 hi / lo fragments behind a per-workgroup power-of-two scale, the 16 x K activation fragments of a step are split when they
 // arrive (scale 2^10: |h| < 1 and a dropped-out input is at most 1 / (1 - p)), and 32 k of a product are three
 // v_mfma_f32_16x16x32_f16 of 16 cycles instead of eight v_mfma_f32_16x16x4_f32 of 32: the matrix part of a step's critical path drops
 // from 0.93 us to 0.18 us at the same 2^-22 product accuracy as the batched GEMMs (gemm.hip).
-#ifndef ASTK_PERSIST_F16X2
-#define ASTK_PERSIST_F16X2 1
-#endif
+// X2 is a template parameter of both kernels: the launchers pick it from astk_set_gemm_precision (fp16x2 mode only; bf16x3 / f32 modes run
+// the exact-f32 MFMAs), so that one process can time the step under every arithmetic.
 constexpr float ACT_SCALE = 1024.f, ACT_SCALE_INV = 1.f / 1024.f;
 // four independent accumulators (the gates) interleaved, three term products of 32 k each
 #define MFMA32HG(ACC, A, W)                                                                                                     \
@@ -241,7 +240,7 @@ __device__ __forceinline__ float4 frag_vals(const u32x4& g) {
 // Code shape: everything a wait depends on is UNCONDITIONAL inside the loop (HAS_UP is a template parameter, step 0 is
 // peeled, prefetch indices are clamped instead of guarded): a conditionally issued load becomes a phi of "old registers /
 // load result", and hipcc then copies the result right behind the load, i.e. waits for it at the point of issue.
-template <int KB, bool HAS_UP>
+template <int KB, bool HAS_UP, bool X2>
 __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& c, float* red0, float* red1) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -253,15 +252,15 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
 
   auto wl_at = [&](int i, int g) { return *reinterpret_cast<const float4*>(c.Wl + (long)(4 * (j0 + r) + g) * h + 16 * (wave + 4 * i) + 4 * q); };
   auto wu_at = [&](int i, int g) { return *reinterpret_cast<const float4*>(c.Wu + (long)(4 * (j0 + r) + g) * h + 16 * (wave + 4 * i) + 4 * q); };
-#if ASTK_PERSIST_F16X2
-  // the resident weights as fp16 hi / lo fragments of v_mfma_f32_16x16x32_f16: 16-k blocks i, i+1 of this wave form one 32-k operand
+  // X2: the resident weights as fp16 hi / lo fragments of v_mfma_f32_16x16x32_f16: 16-k blocks i, i+1 of this wave form one 32-k operand
   // (the k order inside a product is free as long as activations and weights agree); one scale for the workgroup's whole slice.
   // Two sweeps over the slice (maximum, then split): holding the f32 values and their fragments at once would take 512 registers.
   constexpr int NPR = (KB + 1) / 2;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float zscale;
-  HL8 wlh[NPR][4], wuh[HAS_UP ? NPR : 1][4];
-  {
+  float zscale = 1.f;
+  HL8 wlh[X2 ? NPR : 1][4], wuh[(X2 && HAS_UP) ? NPR : 1][4];
+  float4 wl[X2 ? 1 : KB][4], wu[(!X2 && HAS_UP) ? KB : 1][4];
+  if constexpr (X2) {
     float m = 0.f;
 #pragma unroll
     for (int i = 0; i < KB; ++i)
@@ -275,19 +274,17 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         wlh[p][g] = split8(wl_at(2 * p, g), 2 * p + 1 < KB ? wl_at(2 * p + 1, g) : zero4, wscl);
-        if (HAS_UP) wuh[p][g] = split8(wu_at(2 * p, g), 2 * p + 1 < KB ? wu_at(2 * p + 1, g) : zero4, wscl);
+        if constexpr (HAS_UP) wuh[p][g] = split8(wu_at(2 * p, g), 2 * p + 1 < KB ? wu_at(2 * p + 1, g) : zero4, wscl);
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < KB; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        wl[i][g] = wl_at(i, g);
+        if constexpr (HAS_UP) wu[i][g] = wu_at(i, g);
       }
   }
-#else
-  float4 wl[KB][4], wu[HAS_UP ? KB : 1][4];
-#pragma unroll
-  for (int i = 0; i < KB; ++i)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      wl[i][g] = wl_at(i, g);
-      if (HAS_UP) wu[i][g] = wu_at(i, g);
-    }
-#endif
   const __amdgpu_buffer_rsrc_t r_own = make_rsrc(c.HR);
   const __amdgpu_buffer_rsrc_t r_below = make_rsrc(HAS_UP ? c.xin : c.HR);
   const int arow = min(m0 + r, B - 1);
@@ -303,15 +300,13 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
   const int frag0 = (arow * h + 4 * q) * 4;   // byte offset of this lane's fragment row at step 0
   u32x4 gx[KB];
   float4 ax[KB];
-#if ASTK_PERSIST_F16X2
-  HL8 axh[NPR];
+  HL8 axh[X2 ? NPR : 1];
   auto take_x = [&]() {
+    if constexpr (X2) {
 #pragma unroll
-    for (int p = 0; p < NPR; ++p) axh[p] = split8(ax[2 * p], 2 * p + 1 < KB ? ax[2 * p + 1] : zero4, ACT_SCALE);
+      for (int p = 0; p < NPR; ++p) axh[p] = split8(ax[2 * p], 2 * p + 1 < KB ? ax[2 * p + 1] : zero4, ACT_SCALE);
+    }
   };
-#else
-  auto take_x = [&]() {};
-#endif
   // what only later launches read, stored half a step late
   float4 p_gates = make_float4(0.f, 0.f, 0.f, 0.f);
   float p_hd = 0.f, p_c = 0.f;
@@ -355,15 +350,15 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
     u32x4 gh[KB];
     if (!FIRST) frag_issue<KB>(r_own, frag - step_bytes, wave, gh);   // in flight behind the upward MFMAs
     __builtin_amdgcn_sched_barrier(0);
-    if (HAS_UP) {
-#if ASTK_PERSIST_F16X2
-      take_x();       // x_t (taken at W_{t-1}) is split HERE, in front of the wait for h, not between that wait and the recurrent MFMAs
+    if constexpr (HAS_UP) {
+      if constexpr (X2) {
+        take_x();       // x_t (taken at W_{t-1}) is split HERE, in front of the wait for h, not between that wait and the recurrent MFMAs
 #pragma unroll
-      for (int p = 0; p < NPR; ++p) { MFMA32HG(acc, axh[p], wuh[p]) }
-#else
+        for (int p = 0; p < NPR; ++p) { MFMA32HG(acc, axh[p], wuh[p]) }
+      } else {
 #pragma unroll
-      for (int i = 0; i < KB; ++i) { MFMA4G(acc, ax[i], wu[i]) }
-#endif
+        for (int i = 0; i < KB; ++i) { MFMA4G(acc, ax[i], wu[i]) }
+      }
     }
     const int t1 = min(t + 1, T - 1), t2 = min(t + 2, T - 1);
     if (HAS_UP) {   // x_{t+1}: issued a whole step ago, taken over HERE, while h_{t-1} is still in flight (behind the wait it was 0.27 us of the chain)
@@ -384,19 +379,19 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
     __builtin_amdgcn_s_waitcnt(0x0F70);
     { const long long b2_ = tk[2]; TICK(2, t0) if (timing && tk[2] - b2_ > 100) { big2 += tk[2] - b2_; ++nbig2; } }
     if (!FIRST) {
-#if ASTK_PERSIST_F16X2
+      if constexpr (X2) {
 #pragma unroll
-      for (int p = 0; p < NPR; ++p) {
-        const HL8 ah = split8(frag_vals(gh[2 * p]), 2 * p + 1 < KB ? frag_vals(gh[2 * p + 1 < KB ? 2 * p + 1 : 0]) : zero4, ACT_SCALE);
-        MFMA32HG(acc, ah, wlh[p])
-      }
-#else
+        for (int p = 0; p < NPR; ++p) {
+          const HL8 ah = split8(frag_vals(gh[2 * p]), 2 * p + 1 < KB ? frag_vals(gh[2 * p + 1 < KB ? 2 * p + 1 : 0]) : zero4, ACT_SCALE);
+          MFMA32HG(acc, ah, wlh[p])
+        }
+      } else {
 #pragma unroll
-      for (int i = 0; i < KB; ++i) {
-        const float4 ah = frag_vals(gh[i]);
-        MFMA4G(acc, ah, wl[i])
+        for (int i = 0; i < KB; ++i) {
+          const float4 ah = frag_vals(gh[i]);
+          MFMA4G(acc, ah, wl[i])
+        }
       }
-#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- off-path traffic: issued BEHIND the recurrent MFMAs (they run in the matrix pipe meanwhile; in front of them these loads, stores and their
@@ -424,10 +419,10 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         z[g] = rd[(0 * 4 + g) * 256 + src] + rd[(1 * 4 + g) * 256 + src] + rd[(2 * 4 + g) * 256 + src] + rd[(3 * 4 + g) * 256 + src];
-#if ASTK_PERSIST_F16X2
+      if constexpr (X2) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) z[g] *= zscale;      // 1 / (weight scale x activation scale)
-#endif
+        for (int g = 0; g < 4; ++g) z[g] *= zscale;      // 1 / (weight scale x activation scale)
+      }
       const float ga = tanh_fast(z[0] + zadd.x), gi = sigm_fast(z[1] + zadd.y), gf = sigm_fast(z[2] + zadd.z), go = sigm_fast(z[3] + zadd.w);
       c_state = ga * gi + gf * c_state;
       const float hh = go * tanh_fast(c_state);
@@ -453,14 +448,14 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
 #undef TICK
 }
 
-template <int KB>
+template <int KB, bool X2>
 __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_g(PFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float red[2][4 * 4 * 256];
   // (a COPY, not a reference into the kernel-argument block: fields read through a dynamically indexed reference are re-loaded behind
   //  every global store of the step loop -- the stores might alias them -- and each re-load is a scalar-cache round trip on the chain)
   const PCellF c = a.c[blockIdx.z];
-  if (c.layer > 0) lstm_fwd_steps<KB, true>(a, c, red[0], red[1]);
-  else lstm_fwd_steps<KB, false>(a, c, red[0], red[1]);
+  if (c.layer > 0) lstm_fwd_steps<KB, true, X2>(a, c, red[0], red[1]);
+  else lstm_fwd_steps<KB, false, X2>(a, c, red[0], red[1]);
 }
 
 
@@ -489,7 +484,7 @@ constexpr int PR_RING = 4;
 constexpr bool bwd_sentinel(int KB) { return ASTK_BWD_SENTINEL && KB <= ASTK_BWD_SENTINEL_MAXKB; }
 // HAS_UP: the cell has a layer above it in this stack (a template parameter so that the loads of that layer's partials are unconditional
 // code: a conditionally issued load becomes a phi whose copy makes hipcc wait for the load where it is issued)
-template <int KB, bool HAS_UP>
+template <int KB, bool HAS_UP, bool X2>
 __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCellB& c, float (*dzS2)[16 * 64], int* s_ok1, int& s_ok2) {
   constexpr int NS = 4 * KB;          // slices of a cell = 16x16 output tiles of a product = partial tiles per consumer
   float* const dzS = dzS2[0];
@@ -513,11 +508,11 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
   auto wd_at = [&](int nt, int s4) {
     return has_down ? *reinterpret_cast<const float4*>(c.WuT + (long)(16 * (wave * KB + nt) + r16) * K + 64 * j + 16 * s4 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
-#if ASTK_PERSIST_F16X2
-  // fp16 hi / lo fragments behind one power-of-two scale per workgroup (see the forward kernel); the 64 gate columns are two 32-k operands
-  HL8 wlh[KB][2], wdh[KB][2];
-  float winv;
-  {
+  // X2: fp16 hi / lo fragments behind one power-of-two scale per workgroup (see the forward kernel); the 64 gate columns are two 32-k operands
+  HL8 wlh[X2 ? KB : 1][2], wdh[X2 ? KB : 1][2];
+  float4 wl[X2 ? 1 : KB][4], wd[X2 ? 1 : KB][4];
+  float winv = 1.f;
+  if constexpr (X2) {
     float m = 0.f;
 #pragma unroll
     for (int nt = 0; nt < KB; ++nt)
@@ -531,14 +526,12 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
         wlh[nt][p] = split8(wl_at(nt, 2 * p), wl_at(nt, 2 * p + 1), wscl);
         wdh[nt][p] = split8(wd_at(nt, 2 * p), wd_at(nt, 2 * p + 1), wscl);
       }
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < KB; ++nt)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) { wl[nt][s4] = wl_at(nt, s4); wd[nt][s4] = wd_at(nt, s4); }
   }
-#else
-  float4 wl[KB][4], wd[KB][4];
-#pragma unroll
-  for (int nt = 0; nt < KB; ++nt)
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) { wl[nt][s4] = wl_at(nt, s4); wd[nt][s4] = wd_at(nt, s4); }
-#endif
   const __amdgpu_buffer_rsrc_t r_pr = make_rsrc(c.PR);
   const __amdgpu_buffer_rsrc_t r_pd = make_rsrc(has_down ? c.PD : c.PR);
   const __amdgpu_buffer_rsrc_t r_pu = make_rsrc(has_up ? c.PD_up : c.PR);
@@ -713,11 +706,10 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     float4 af[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) af[s4] = *reinterpret_cast<const float4*>(&dzT[r16 * 64 + 16 * s4 + 4 * q]);
-#if ASTK_PERSIST_F16X2
-    // dz is unbounded: its scale is taken from this step's tile (every wave holds the whole 16 x 64 tile across its lanes)
-    float pscale;       // 1 / (weight scale x dz scale), applied to the partial sums
+    // X2: dz is unbounded: its scale is taken from this step's tile (every wave holds the whole 16 x 64 tile across its lanes)
+    float pscale = 1.f;       // 1 / (weight scale x dz scale), applied to the partial sums
     HL8 afh[2];
-    {
+    if constexpr (X2) {
       const float m = wave_max_nonneg(amax4f(amax4f(amax4f(amax4f(0.f, af[0]), af[1]), af[2]), af[3]));
       float ainv;
       const float ascl = pow2_scale_for(m, ainv);
@@ -725,21 +717,20 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
       afh[0] = split8(af[0], af[1], ascl);
       afh[1] = split8(af[2], af[3], ascl);
     }
-#endif
     // ---- product 1: partial dh_rec for every slice of this cell -> write-through stores
     {
       const int slot = t % PR_RING;
 #pragma unroll
       for (int nt = 0; nt < KB; ++nt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#if ASTK_PERSIST_F16X2
-        MFMA32H(acc, afh[0], wlh[nt][0])
-        MFMA32H(acc, afh[1], wlh[nt][1])
-        acc *= pscale;
-#else
+        if constexpr (X2) {
+          MFMA32H(acc, afh[0], wlh[nt][0])
+          MFMA32H(acc, afh[1], wlh[nt][1])
+          acc *= pscale;
+        } else {
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc, af[s4], wl[nt][s4]) }
-#endif
+          for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc, af[s4], wl[nt][s4]) }
+        }
         const int tl = wave * KB + nt;
         u32x4 o;
         o.x = __float_as_uint(acc[0]); o.y = __float_as_uint(acc[1]); o.z = __float_as_uint(acc[2]); o.w = __float_as_uint(acc[3]);
@@ -755,14 +746,14 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
 #pragma unroll
       for (int nt = 0; nt < KB1; ++nt) {
         acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if ASTK_PERSIST_F16X2
-        MFMA32H(acc2[nt], afh[0], wdh[nt][0])
-        MFMA32H(acc2[nt], afh[1], wdh[nt][1])
-        acc2[nt] *= pscale;
-#else
+        if constexpr (X2) {
+          MFMA32H(acc2[nt], afh[0], wdh[nt][0])
+          MFMA32H(acc2[nt], afh[1], wdh[nt][1])
+          acc2[nt] *= pscale;
+        } else {
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc2[nt], af[s4], wd[nt][s4]) }
-#endif
+          for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc2[nt], af[s4], wd[nt][s4]) }
+        }
       }
     }
     TICK(4, t0)
@@ -781,14 +772,14 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
 #pragma unroll
       for (int nt = KB1; nt < KB; ++nt) {
         acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if ASTK_PERSIST_F16X2
-        MFMA32H(acc2[nt], afh[0], wdh[nt][0])
-        MFMA32H(acc2[nt], afh[1], wdh[nt][1])
-        acc2[nt] *= pscale;
-#else
+        if constexpr (X2) {
+          MFMA32H(acc2[nt], afh[0], wdh[nt][0])
+          MFMA32H(acc2[nt], afh[1], wdh[nt][1])
+          acc2[nt] *= pscale;
+        } else {
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc2[nt], af[s4], wd[nt][s4]) }
-#endif
+          for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc2[nt], af[s4], wd[nt][s4]) }
+        }
       }
       store_down(t);
       pending_b = true;
@@ -815,15 +806,15 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
 #undef TICK
 }
 
-template <int KB>
+template <int KB, bool X2>
 __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
   // (two copies of the dz tile, used alternately: with the sentinel hand-off the step's ONE barrier sits between a tile's writes and its
   //  reads, and only the copy keeps a wave that is a step ahead from writing into what a slower wave still reads; the flags likewise)
   __shared__ __attribute__((aligned(16))) float dzS2[2][16 * 64];
   __shared__ int s_ok1[2], s_ok2;
   const PCellB c = a.c[blockIdx.z];      // a copy (see lstm_persist_fwd_g)
-  if (c.PD_up != nullptr) lstm_bwd_rs_steps<KB, true>(a, c, dzS2, s_ok1, s_ok2);
-  else lstm_bwd_rs_steps<KB, false>(a, c, dzS2, s_ok1, s_ok2);
+  if (c.PD_up != nullptr) lstm_bwd_rs_steps<KB, true, X2>(a, c, dzS2, s_ok1, s_ok2);
+  else lstm_bwd_rs_steps<KB, false, X2>(a, c, dzS2, s_ok1, s_ok2);
 }
 
 }  // namespace
@@ -894,11 +885,20 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
     ASTK_TRY(fill_u32_segments(f, 0xffffffffu, s));
   }
   ProfScope prof(PROF_CELL, s);
-  switch (h) {
-    case 64: hipLaunchKernelGGL((lstm_persist_fwd_g<1>), grid, blk, 0, s, a); break;
-    case 128: hipLaunchKernelGGL((lstm_persist_fwd_g<2>), grid, blk, 0, s, a); break;
-    case 256: hipLaunchKernelGGL((lstm_persist_fwd_g<4>), grid, blk, 0, s, a); break;
-    default: hipLaunchKernelGGL((lstm_persist_fwd_g<8>), grid, blk, 0, s, a); break;
+  if (gemm_precision_mode() == 0) {       // fp16x2 mode: the recurrences' products run as two-term fp16 splits too
+    switch (h) {
+      case 64: hipLaunchKernelGGL((lstm_persist_fwd_g<1, true>), grid, blk, 0, s, a); break;
+      case 128: hipLaunchKernelGGL((lstm_persist_fwd_g<2, true>), grid, blk, 0, s, a); break;
+      case 256: hipLaunchKernelGGL((lstm_persist_fwd_g<4, true>), grid, blk, 0, s, a); break;
+      default: hipLaunchKernelGGL((lstm_persist_fwd_g<8, true>), grid, blk, 0, s, a); break;
+    }
+  } else {
+    switch (h) {
+      case 64: hipLaunchKernelGGL((lstm_persist_fwd_g<1, false>), grid, blk, 0, s, a); break;
+      case 128: hipLaunchKernelGGL((lstm_persist_fwd_g<2, false>), grid, blk, 0, s, a); break;
+      case 256: hipLaunchKernelGGL((lstm_persist_fwd_g<4, false>), grid, blk, 0, s, a); break;
+      default: hipLaunchKernelGGL((lstm_persist_fwd_g<8, false>), grid, blk, 0, s, a); break;
+    }
   }
   ASTK_LAUNCH_CHECK();
   return 0;
@@ -940,11 +940,20 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   }
   dim3 grid(h / 16, nbt, ncells), blk(256);
   ProfScope prof(PROF_CELL, s);
-  switch (h) {
-    case 64: hipLaunchKernelGGL((lstm_persist_bwd_rs<1>), grid, blk, 0, s, a); break;
-    case 128: hipLaunchKernelGGL((lstm_persist_bwd_rs<2>), grid, blk, 0, s, a); break;
-    case 256: hipLaunchKernelGGL((lstm_persist_bwd_rs<4>), grid, blk, 0, s, a); break;
-    default: hipLaunchKernelGGL((lstm_persist_bwd_rs<8>), grid, blk, 0, s, a); break;
+  if (gemm_precision_mode() == 0) {
+    switch (h) {
+      case 64: hipLaunchKernelGGL((lstm_persist_bwd_rs<1, true>), grid, blk, 0, s, a); break;
+      case 128: hipLaunchKernelGGL((lstm_persist_bwd_rs<2, true>), grid, blk, 0, s, a); break;
+      case 256: hipLaunchKernelGGL((lstm_persist_bwd_rs<4, true>), grid, blk, 0, s, a); break;
+      default: hipLaunchKernelGGL((lstm_persist_bwd_rs<8, true>), grid, blk, 0, s, a); break;
+    }
+  } else {
+    switch (h) {
+      case 64: hipLaunchKernelGGL((lstm_persist_bwd_rs<1, false>), grid, blk, 0, s, a); break;
+      case 128: hipLaunchKernelGGL((lstm_persist_bwd_rs<2, false>), grid, blk, 0, s, a); break;
+      case 256: hipLaunchKernelGGL((lstm_persist_bwd_rs<4, false>), grid, blk, 0, s, a); break;
+      default: hipLaunchKernelGGL((lstm_persist_bwd_rs<8, false>), grid, blk, 0, s, a); break;
+    }
   }
   ASTK_LAUNCH_CHECK();
   return 0;

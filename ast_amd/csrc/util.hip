@@ -268,7 +268,10 @@ __global__ void k_sqnorm(const float* g, const float* p, float gsc, float l2, si
 }
 
 __global__ void k_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, size_t n, float gsc, float l2, float clip,
-                          const double* sqnorm, float lr_t, float b1, float b2, float eps, int amsgrad) {
+                          const double* sqnorm, float lr_t, float b1, float b2, float eps, int amsgrad, const unsigned* status) {
+  // a persistent kernel of this step timed out (sticky status word): its loss and gradients are garbage, the host finds out when it
+  // reads the loss back one step later -- the parameters and moments must not have moved by then
+  if (status && *status != 0u) return;
   const float norm = (float)sqrt(*sqnorm);
   const float rate = clip / norm;                    // A7: r = c / n, applied only when r < 1
   const float gs = rate < 1.f ? rate : 1.f;
@@ -308,7 +311,8 @@ __global__ void k_decay_clip_noise(float* g, const float* p, size_t n, float gsc
   }
 }
 
-__global__ void k_sgd(float* p, const float* g, size_t n, float gsc, float l2, float clip, const double* sqnorm, float lr) {
+__global__ void k_sgd(float* p, const float* g, size_t n, float gsc, float l2, float clip, const double* sqnorm, float lr, const unsigned* status) {
+  if (status && *status != 0u) return;      // (see k_amsgrad)
   const float norm = (float)sqrt(*sqnorm);
   const float rate = clip / norm;
   const float gs = rate < 1.f ? rate : 1.f;
@@ -480,7 +484,7 @@ int astk_decay_clip_amsgrad_step_scaled(float* p, const float* g, float* m, floa
   ASTK_CHECK(p && g && m && v && sqnorm && (vhat || !amsgrad), "amsgrad_step: null pointer");
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_amsgrad, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vhat, n, grad_scale, l2, clip, sqnorm,
-                     lr_t, beta1, beta2, eps, amsgrad);
+                     lr_t, beta1, beta2, eps, amsgrad, (const unsigned*)persist_status_ptr());
   ASTK_LAUNCH_CHECK();
   return 0;
 }
@@ -493,7 +497,8 @@ int astk_decay_clip_sgd_step_scaled(float* p, const float* g, size_t n, float gr
                                     float lr, void* stream) {
   ASTK_CHECK(p && g && sqnorm, "sgd_step: null pointer");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_sgd, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, n, grad_scale, l2, clip, sqnorm, lr);
+  hipLaunchKernelGGL(k_sgd, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, n, grad_scale, l2, clip, sqnorm, lr,
+                     (const unsigned*)persist_status_ptr());
   ASTK_LAUNCH_CHECK();
   return 0;
 }

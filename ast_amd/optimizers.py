@@ -21,8 +21,9 @@ class GradientClipping:
 
 
 class GradientNoise:
-    """chainer.optimizer.GradientNoise(eta) (nn.py:108-110): g += N(0, sigma^2), sigma^2 = eta / (1 + t)^0.55, t = the update count
-    (already incremented when the hooks run).  Applied behind WeightDecay and GradientClipping, the reference's insertion order."""
+    """chainer.optimizer.GradientNoise(eta) (nn.py:108-110): g += N(0, sigma^2), sigma^2 = eta / (1 + t)^0.55 with t = the optimizer's
+    update count BEFORE this update (Chainer's GradientMethod.update calls the 'pre' hooks, then increments t; exponential_decay_noise
+    reads opt.t): sigma^2 = eta at the first update.  Applied behind WeightDecay and GradientClipping, the reference's insertion order."""
 
     def __init__(self, eta, seed=0x6E015E):
         self.eta = float(eta)
@@ -57,7 +58,7 @@ class _Optimizer:
         if not noise:
             return l2, clip, self.grad_scale
         h = noise[0]
-        sigma = math.sqrt(h.eta / (1.0 + self.t) ** 0.55)
+        sigma = math.sqrt(h.eta / (1.0 + (self.t - 1)) ** 0.55)      # self.t was incremented just above; the hook saw t - 1
         frozen = getattr(self.target, "_frozen", set())
         # parameter by parameter over the exact extents: the arena's alignment pads must keep their zero gradient (and value)
         for name, shp in a.shapes.items():

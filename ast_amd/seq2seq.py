@@ -69,22 +69,55 @@ def raise_if_aborted(status, where="train step"):
                              "ASTK_LSTM_PERSIST=0 / ASTK_DEC_PERSIST=0 to use the per-launch kernels on a shared device")
 
 
+class LossData:
+    """`loss.data` (nn.py:189: `float(loss.data)`): the 0-d device scalar, read through the persistent kernels' status word.  float(),
+    .item(), .tolist() and NumPy conversion all read the [loss, status] pair in ONE copy and raise AstkError when a kernel of the step
+    timed out -- a drop-in caller that only ever touches `.data` cannot train on with garbage.  `.tensor` is the raw 0-d tensor (no
+    check, no synchronisation) for callers that keep the value on the device."""
+
+    def __init__(self, pair):
+        self._pair = pair
+
+    @property
+    def tensor(self):
+        return self._pair[0]
+
+    def _checked(self):
+        v = self._pair.tolist()
+        raise_if_aborted(v[1])
+        return v[0]
+
+    def __float__(self):
+        return self._checked()
+
+    def item(self):
+        return self._checked()
+
+    def tolist(self):
+        return self._checked()
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self._checked(), dtype=dtype or np.float32)
+
+    def __getattr__(self, name):              # shape / dtype / device / clone() ... of the 0-d tensor
+        return getattr(self._pair[0], name)
+
+
 class Loss:
-    """What forward_loss returns: `.data` (0-d tensor), float(), `.backward()` (nn.py:175-189).  `.pair` = [loss, status] on the
-    device: the status word of the persistent kernels rides next to the scalar, so one read-back serves both."""
+    """What forward_loss returns: `.data` (the 0-d loss, status-checked when it is read: LossData), float(), `.backward()`
+    (nn.py:175-189).  `.pair` = [loss, status] on the device: the status word of the persistent kernels rides next to the scalar, so one
+    read-back serves both."""
 
     def __init__(self, model, pair):
         self._model = model
         self.pair = pair
-        self.data = pair[0]
+        self.data = LossData(pair)
 
     def backward(self):
         self._model._backward()
 
     def __float__(self):
-        v = self.pair.tolist()
-        raise_if_aborted(v[1])
-        return v[0]
+        return float(self.data)
 
 
 def _vp(t):

@@ -7,6 +7,7 @@ configs[1]: synthetic fbank (T=800, 80-d) batch 32, 2x[Conv+BN+ReLU] -> 3-layer 
 
     python bench.py --gpus 1 --steps 50 --warmup 10            # BASELINE configs[1] (1-layer decoder): the metric's workload
     python bench.py --model es_en_20h                          # the shipped model (3 decoder layers, experiments/es_en_20h)
+    python bench.py --gpus N                                   # N > 1 without a launcher: starts the N ranks itself (child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -15,6 +16,8 @@ import ctypes as C
 import json
 import os
 import random
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,6 +36,11 @@ MODEL_CFG = {
 TRAIN = {"teach_ratio": 0.8, "speech_noise": 0.25, "lr": 1e-3, "l2": 1e-4, "grad_clip": 2}
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA dense peak
+MFMA_16BIT_PEAK_TFLOPS = 2500.0  # fp16 / bf16 dense MFMA peak (MI355X_MICROARCH.md; no sparsity)
+PRECISIONS = {0: ("fp16x2", "f32 storage / f32 accumulate, products as fp16x2 splits (two fp16 terms per operand behind a power-of-two scale: 22 significant "
+                            "bits per operand value) in the batched GEMMs and the encoder recurrences; decoder loop, attention, softmax-CE, optimizer in IEEE f32"),
+              1: ("bf16x3", "f32 storage / f32 accumulate, batched GEMMs as bf16x3 splits (24 significant bits), everything else IEEE f32"),
+              2: ("f32", "IEEE f32 products everywhere (f32-input MFMA), f32 accumulate")}
 
 
 def synth_batch(B, T, D, L, V, seed):
@@ -83,6 +91,39 @@ def cpu_baseline(model_cfg, B, T, D, L, V, budget_s=30.0):
                       "path, per-step Python loop and one BLAS sgemm per Linear like Chainer-on-NumPy (Chainer is not installable offline)"}
 
 
+def self_launch_command(gpus, argv, port=None):
+    """The command `python bench.py --gpus N` (N > 1, no launcher in the environment) runs as a CHILD process: one rank per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve), the same arguments."""
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_self_launch(args, argv):
+    """N > 1 ranks asked for, but this process was not started by a launcher (WORLD_SIZE unset): start them, relay rank 0's JSON line,
+    exit with the launcher's code.  A child process, never an exec; nothing here has touched HIP / torch.cuda yet."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    cmd = self_launch_command(args.gpus, argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this stack (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.lstrip().startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    raise SystemExit(rc if rc != 0 or line is not None else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,7 +143,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-bn", action="store_true", help="N>1: BatchNorm statistics over the global batch (4 extra 5-10 KB all-reduces)")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps with per-kernel HIP-event timing")
+    ap.add_argument("--no-alt-precisions", action="store_true", help="skip the bf16x3 / f32 re-timings of the same step")
     args = ap.parse_args()
+    maybe_self_launch(args, sys.argv[1:])
 
     import numpy as np
     import torch
@@ -114,8 +157,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     torch.cuda.set_device(local)
     if world > 1:
@@ -214,36 +256,35 @@ def main():
             f = os.path.join(ROOT, "profiles", name)
             return json.load(open(f)) if os.path.exists(f) else {}
         if res[5] > 0:
-            # THE dominant kernel family (half of the step): every batched dense product of the step on f32-input MFMA
+            # THE dominant kernel family (40 % of the step): every batched dense product of the step.  `achieved` / `frac` price what the
+            # matrix pipe EXECUTES against the pipe that executes it: in the default mode every f32 operand is split in the kernel into two
+            # fp16 terms (22 significant bits) and a product is three v_mfma_f32_32x32x16_f16 -- 3x the useful flops on the 2.5 PFLOP/s
+            # fp16 pipe.  `useful_*` carries the 2*M*N*K figure and, for reference only, its ratio to the f32-input MFMA peak (which this
+            # scheme is not bound by).
             tfl = res[6] / (res[4] * 1e-3) / 1e12
             ms_gemm, n_gemm = res[4] / args.profile_steps, int(res[5] / args.profile_steps)
+            mode = lib.astk_get_gemm_precision()
+            nprod, peak, pipe = {0: (3, MFMA_16BIT_PEAK_TFLOPS, "fp16 MFMA (v_mfma_f32_32x32x16_f16), 3 per useful 16-k product block (fp16x2 split)"),
+                                 1: (6, MFMA_16BIT_PEAK_TFLOPS, "bf16 MFMA (v_mfma_f32_32x32x16_bf16), 6 per useful 16-k product block (bf16x3 split)"),
+                                 2: (1, MFMA_F32_PEAK_TFLOPS, "f32-input MFMA (v_mfma_f32_32x32x2_f32)")}[mode]
+            tj = profile_json("r3_gemm_traffic.json") or profile_json("gemm_traffic.json")
             roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<NT|NN|TN> + k_absmax / k_absmax_zero / k_zero_split_tiles (all batched dense products of the step with their preparation launches)",
-                    "achieved": round(tfl, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
-                    "traffic": profile_json("gemm_traffic.json").get("hbm_bytes_per_step"),
+                    "pipe": pipe,
+                    "achieved": round(tfl * nprod, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tfl * nprod / peak, 4),
+                    "useful_tflops": round(tfl, 2), "useful_frac_of_pipe_peak": round(tfl / peak, 4),
+                    "useful_over_f32_mfma_peak": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
+                    "traffic": tj.get("hbm_bytes_per_step"),
+                    "traffic_source": ("STATIC FILE, not measured in this run: " + tj.get("source", "profiles/gemm_traffic.json (rocprofv3 --pmc passes of an earlier build)")) if tj else None,
                     # logical operand / result bytes (window operands of the conv GEMMs counted at their im2col extent, not at the
                     # smaller extent of the arrays they address); `traffic` is what crosses the L2's memory side, Infinity-Cache hits
                     # included: the stream-K workgroups of an XCD sit at unrelated k positions, so a panel is re-fetched by every tile
                     "algorithmic_bytes_per_step": round(res[20] / args.profile_steps),
                     "flops_per_step": round(res[6] / args.profile_steps), "ms_per_step": round(ms_gemm, 3),
                     "avg_launch_us": round(ms_gemm * 1e3 / max(1, n_gemm), 1), "launches_per_step": n_gemm,
-                    "method": "2*M*N*K per launch / HIP events around every launch on the launch stream; traffic = FETCH_SIZE*2 + WRITE_SIZE "
-                              "of the same kernels from separate rocprofv3 --pmc passes (profiles/), per step"}
-            prec_env = os.environ.get("ASTK_GEMM_PREC", "fp16x2")
-            if prec_env == "f32":
-                roof["executed"] = {"scheme": "exact f32 chain on v_mfma_f32_32x32x2_f32"}
-            else:
-                # how the products execute: every f32 operand is split in the kernel into 16-bit terms whose partial products sum to the
-                # f32-accurate product -- fp16x2: two fp16 terms behind a per-operand power-of-two scale (absolute-maximum pass inside the
-                # timed scope), 3 v_mfma_f32_32x32x16_f16 per 16 k; bf16x3 (ASTK_GEMM_PREC=bf16x3): three bf16 terms, 6 MFMAs.  `peak`
-                # above stays the f32-input MFMA peak the useful flops are priced against (the scheme may exceed it).
-                nprod = 6 if prec_env == "bf16x3" else 3
-                scheme = ("bf16x3 split (6 bf16 MFMAs per useful product block)" if prec_env == "bf16x3" else
-                          "fp16x2 split (3 fp16 MFMAs per useful product block; scales from an absolute-maximum pass, timed with the GEMMs; launches "
-                          "below 3 GFLOP: bf16x3 split, 6 MFMAs)")
-                if args.gemm_operands == "fp16":
-                    scheme += "; single-term fp16 for the CNN / encoder-input GEMMs (--gemm-operands fp16)"
-                roof["executed"] = {"scheme": scheme, "mfma_16bit_tflops": round(tfl * nprod, 1), "mfma_16bit_peak_tflops": 2500.0,
-                                    "frac_of_16bit_peak": round(tfl * nprod / 2500.0, 4)}
+                    "method": "useful flops = 2*M*N*K per launch, executed = useful x MFMAs per product block; time = HIP events around every launch "
+                              "(preparation launches included) on the launch stream, live in this run"}
+            if args.gemm_operands == "fp16":
+                roof["pipe"] += "; single-term fp16 (1 MFMA) for the launches marked eligible (--gemm-operands fp16): executed flops are over-counted for those"
         if res[17] > 0 and res[19] > 0:
             # Attention scan (north_star's "HBM roofline on the attention scan").  The scan is a PHASE of the two persistent decoder
             # launches, not a launch of its own, and its enc / encA slices are LDS-resident after step 0: the launches are LATENCY-bound
@@ -251,11 +292,13 @@ def main():
             # over the launch's duration.  Phase-level (in-kernel stamps, hand-off satisfied -> partial published) is given for
             # reference only: it is an HBM-EQUIVALENT rate of an on-chip pass, not HBM traffic.
             k_fwd_us, k_bwd_us = res[16] / res[17] * 1e3, res[18] / res[19] * 1e3
+            attn_traffic = profile_json("r3_attn_traffic.json") or profile_json("attn_traffic.json")
             ach = S * bytes_scan / ((k_fwd_us + k_bwd_us) / 2 * 1e-6) / 1e9
             scan = {"bound": "latency (priced against the HBM roofline north_star names; slices are LDS-resident, measured HBM traffic < algorithmic bytes)",
                     "kernel": "decoder_persist_fwd / decoder_persist_bwd (all S decoder steps per launch)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": profile_json("attn_traffic.json").get("hbm_bytes_per_launch"),
+                    "traffic": attn_traffic.get("hbm_bytes_per_launch"), "traffic_per_scan": attn_traffic.get("hbm_bytes_per_scan"),
+                    "traffic_source": "STATIC FILE, not measured in this run: " + attn_traffic.get("source", "profiles/attn_traffic.json") if attn_traffic else None,
                     "bytes_per_launch": S * bytes_scan, "avg_launch_us": round((k_fwd_us + k_bwd_us) / 2, 1), "launches_per_step": 2,
                     "us_per_decoder_step": {"fwd": round(k_fwd_us / S, 2), "bwd": round(k_bwd_us / S, 2)},
                     "method": "algorithmic bytes (S scans x B*T''*H*4) / HIP-event duration of the launch",
@@ -281,10 +324,36 @@ def main():
         if res[17] > 0:
             extra["decoder_persistent_ms_per_step"] = round((res[16] + res[18]) / args.profile_steps, 3)
 
+    # ---- the SAME step, same process, under the other two arithmetic schemes (runtime switch astk_set_gemm_precision): a driver-timed
+    # figure for the f32-equivalent (bf16x3, 24-bit) and the exact-f32 arithmetic next to the default's
+    base_mode = lib.astk_get_gemm_precision()
+    alt = []
+    if not args.no_alt_precisions:
+        for mode in (0, 1, 2):
+            if mode == base_mode:
+                continue
+            lib.astk_set_gemm_precision(mode)
+            for _ in range(min(3, args.warmup)):
+                step()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                l2_ = step()
+            barrier()
+            d1 = time.perf_counter() - t1
+            if world > 1:
+                tt = torch.tensor([d1], dtype=torch.float64, device="cuda")
+                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+                d1 = float(tt.item())
+            alt.append({"scheme": PRECISIONS[mode][0], "dtype": PRECISIONS[mode][1], "steps": args.steps, "ms_per_step": round(d1 / args.steps * 1e3, 3),
+                        "value": round(world * B * T / (d1 / args.steps), 1), "loss": round(float(l2_), 4)})
+        lib.astk_set_gemm_precision(base_mode)
+
     dec_name = f"{n_dec}-layer LSTM-{cfg['rnn_config']['hidden_units']} dec"
     out = {"metric": "speech frames/s (train step)", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32" if args.gemm_operands == "f32" else "f32 (fp16 operands / f32 accumulate in the CNN and encoder-input GEMMs)",
+           "vs_baseline": None, "dtype": PRECISIONS[base_mode][1] + ("" if args.gemm_operands == "f32" else "; single-term fp16 operands in the CNN / encoder-input / decoder-output GEMMs (--gemm-operands fp16)"),
+           "precision": PRECISIONS[base_mode][0],
            "data": "synthetic",
            "config": {"workload": {"cfg1": "BASELINE configs[1]: ", "es_en_20h": "shipped es_en_20h model (configs[0]'s model at configs[1]'s batch): ",
                                    "cfg5": "shape of BASELINE configs[4] (6-layer encoder, 2x512, V=8004): "}[args.model] +
@@ -292,7 +361,7 @@ def main():
                                   f"attention -> {dec_name}, V={V}, L={L}, dropout .3, noise .25, teach .8, Adam(amsgrad)+L2+clip",
                       "global_batch": world * B, "frames": T, "feat_dim": D, "tgt_len": L, "parallelism": f"dp{world}", "batchnorm": "global-batch statistics" if (world > 1 and args.sync_bn) else "per-replica statistics",
                       "launches": "plain stream launches (the step is GPU-bound: the host enqueues it in 0.6 ms)"},
-           "loss": round(loss_val, 4), "paths": paths, "roofline": roof, "roofline_scan": scan}
+           "loss": round(loss_val, 4), "alt_precisions": alt, "paths": paths, "roofline": roof, "roofline_scan": scan}
     if world > 1:
         out["dp"] = {"rccl_ranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
                      "buckets": list(model.grad_buckets.ranges), "bucket_launch": "dec+enc behind the encoder recurrence, cnn behind the CNN backward"}

@@ -52,6 +52,16 @@ int astk_get_low_precision_gemms(void);
  * operations, which do not repay that pass -- three bf16 terms (no scales, six MFMAs).  Default 3e9 (environment:
  * ASTK_GEMM_X3_BELOW); 0 = fp16 terms always.  Process-wide; returns the previous value. */
 double astk_set_gemm_bf16_split_below(double flops);
+/* Arithmetic of the f32-accurate products, process-wide, switchable at run time (bench.py times the same step under each):
+ *   0  fp16x2 (default): two fp16 terms per operand behind a power-of-two scale, 22 significant bits per operand value, in the batched
+ *      GEMMs AND in the encoder's persistent recurrence kernels;
+ *   1  bf16x3: three bf16 terms (24 bits, no scales) in the batched GEMMs, exact-f32 MFMAs in the recurrences;
+ *   2  f32: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 everywhere (IEEE f32 products, the reference's arithmetic).
+ * The environment variable ASTK_GEMM_PREC = fp16x2 | bf16x3 | f32 sets the initial mode.  Returns the previous mode (<0: error). */
+int astk_set_gemm_precision(int mode);
+int astk_get_gemm_precision(void);
+/* Test hook: sets the generation counter of the fp16x2 scale slots (tests preset it close to the 32-bit wrap). */
+int astk_debug_set_amax_generation(unsigned gen);
 
 /* ---------------------------------------------------------------- CNN front-end  (seq2seq.py:158-180)
  * [Conv2D(no bias) -> BatchNorm(train: batch stats) -> ReLU] x n_layers, then the (T'',B,C*F') time-major
@@ -223,7 +233,9 @@ int astk_softmax_ce_fwd(int B, int V, long ld, float* logits_inout, const int32_
 /* ---------------------------------------------------------------- optimizer  (nn.py:81-119, Chainer-sem A7/A8)
  * One flat parameter / gradient buffer.  sqnorm[0] = sum (g + l2*p)^2 in float64 (the clip norm of hook order
  * WeightDecay -> GradientClipping); the step applies decay, the clip rate min(1, clip/sqrt(sqnorm)) and
- * AMSGrad-Adam with lr_t = alpha*sqrt(1-b2^t)/(1-b1^t) computed by the caller. */
+ * AMSGrad-Adam with lr_t = alpha*sqrt(1-b2^t)/(1-b1^t) computed by the caller.  Both update kernels leave p (and the moments)
+ * untouched while the persistent kernels' sticky status word is non-zero (a kernel of the step timed out: the gradients are
+ * garbage, and the host only learns of it when it reads the loss back). */
 int astk_grad_sqnorm(const float* g, const float* p, float l2, size_t n, double* sqnorm, void* stream);
 int astk_decay_clip_amsgrad_step(float* p, const float* g, float* m, float* v, float* vhat, size_t n,
                                  float l2, float clip, const double* sqnorm, float lr_t, float beta1, float beta2,
@@ -244,7 +256,7 @@ int astk_decay_clip_sgd_step_scaled(float* p, const float* g, size_t n, float gr
  * Dropout keep-masks (Chainer-sem A5): out[i] = (u_i >= ratio) / (1-ratio), u from a counter-based hash RNG. */
 int astk_fill_dropout_mask(float* out, size_t n, float ratio, uint64_t seed, uint64_t offset, void* stream);
 /* chainer.optimizer.GradientNoise behind the other two hooks (nn.py:108-110; hooks run in insertion order WeightDecay -> GradientClipping ->
- * GradientNoise, Chainer-sem A7): g <- clip(g * grad_scale + l2 * p) + sigma * N(0,1) in place, sigma^2 = eta / (1 + t)^0.55.  The update
+ * GradientNoise, Chainer-sem A7): g <- clip(g * grad_scale + l2 * p) + sigma * N(0,1) in place, sigma^2 = eta / (1 + t)^0.55 (t = updates done before this one; the caller passes sigma).  The update
  * call that follows takes the finished gradient (grad_scale 1, l2 0, clip off).  Chainer draws from its unseeded global RNG (quirk Q7);
  * this is a counter-based stream (seed, offset) consuming n / 2 counters. */
 int astk_decay_clip_noise(float* g, const float* p, size_t n, float grad_scale, float l2, float clip, const double* sqnorm, float sigma,

@@ -393,10 +393,11 @@ class RefOptimizer:
                 p.grad = p.grad * p.dtype.type(rate)
         self.t += 1
         if c.get("grad_noise_eta", 0) > 0:
-            # chainer.optimizer.GradientNoise (A7): runs behind WeightDecay and GradientClipping; UpdateRule.update increments t before
-            # the hooks, so sigma^2 = eta / (1 + t)^0.55 with t = 1 at the first update.  Chainer draws from the unseeded global RNG
-            # (Q7); here the draw comes from `noise_rng` so that tests can reproduce it.
-            std = np.sqrt(c["grad_noise_eta"] / (1.0 + self.t) ** 0.55)
+            # chainer.optimizer.GradientNoise (A7): runs behind WeightDecay and GradientClipping.  GradientMethod.update calls the
+            # 'pre' hooks BEFORE `self.t += 1` and exponential_decay_noise reads the optimizer's t, so sigma^2 = eta / (1 + t)^0.55
+            # with t = 0 at the first update (self.t was already incremented above for the Adam step, hence t - 1).  Chainer draws
+            # from the unseeded global RNG (Q7); here the draw comes from `noise_rng` so that tests can reproduce it.
+            std = np.sqrt(c["grad_noise_eta"] / (1.0 + (self.t - 1)) ** 0.55)
             rng = getattr(self, "noise_rng", None) or np.random.default_rng(0)
             self.noise_rng = rng
             for _, p in plist:

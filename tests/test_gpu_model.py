@@ -607,12 +607,30 @@ def test_persistent_kernel_timeout_raises_instead_of_training_on(monkeypatch):
         float(loss)
     assert lib.astk_persist_status(C.byref(mask), 0) == 0 and mask.value == 0          # cleared by the raise
     loss = step()
+    with pytest.raises(_lib.AstkError, match="timed out"):                             # the accessor nn.py:189 uses: float(loss.data)
+        float(loss.data)
+    loss = step()
+    with pytest.raises(_lib.AstkError, match="timed out"):
+        loss.data.item()
+    # the update of a timed-out step must not move the parameters or the moments (the host learns of the time-out one step late)
+    from ast_amd import optimizers as O
+    opt = O.Adam(alpha=1e-3, amsgrad=True).setup(g)
+    opt.add_hook(O.WeightDecay(1e-4))
+    opt.add_hook(O.GradientClipping(2))
+    loss = step()
+    before = g.arena.data.clone()
+    opt.update()
+    torch.cuda.synchronize()
+    assert torch.equal(g.arena.data, before) and float(opt.m.abs().max()) == 0.0
     pair = loss.pair.clone()                                                            # what NN.train_epoch keeps for its late read
     with pytest.raises(_lib.AstkError, match="NN.train_epoch"):
         raise_if_aborted(pair.tolist()[1], "NN.train_epoch")
     monkeypatch.delenv("ASTK_PERSIST_SPIN_LIMIT")
     loss = step()
-    assert _rel(float(loss), float(rl.data)) < 1e-4
+    assert _rel(float(loss.data), float(rl.data)) < 1e-4
+    opt.update()
+    torch.cuda.synchronize()
+    assert not torch.equal(g.arena.data, before)                                       # a clean step updates again
 
 
 def test_device_loader_zeroes_frames_like_the_host_loader(tmp_path):

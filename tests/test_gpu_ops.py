@@ -641,6 +641,31 @@ def test_gemm_scale_slots_survive_ring_wraparound(lib):
     assert worst > 0.0
 
 
+def test_gemm_scale_generation_counter_survives_its_32_bit_wrap(lib):
+    """The generation tag of the scale slots is the high half of a 64-bit atomicMax word; a tag that wrapped to a small value would lose
+    to every stale word and freeze the scales (a week of training at ~40 passes per step).  The counter is preset 40 generations short
+    of the wrap threshold: 120 launches whose operand magnitudes jump by up to 2^60 run across it and every result is checked -- a stale
+    (larger or smaller) maximum shows as inf / NaN or as lost bits."""
+    rng = np.random.default_rng(78)
+    M, N, K = 1024, 1024, 1536
+    a0 = torch.randn(M, K, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    b0 = torch.randn(N, K, device="cuda", generator=torch.Generator(device="cuda").manual_seed(6))
+    ref0 = a0.double() @ b0.double().T
+    assert lib.astk_debug_set_amax_generation(0xFFFFFF00 - 40) == 0
+    try:
+        for it in range(120):
+            ea, eb = int(rng.integers(-30, 30)), int(rng.integers(-30, 30))
+            a, b = a0 * (2.0 ** ea), b0 * (2.0 ** eb)
+            c = torch.empty(M, N, device="cuda")
+            ok(lib, lib.astk_gemm_f32(0, M, N, K, vp(a), K, vp(b), K, vp(c), N, None, 0, 1, 1, 0, 0, 0, stream()))
+            got = c.double() * (2.0 ** -(ea + eb))
+            assert bool(torch.isfinite(got).all()), (it, ea, eb)
+            err = float((got - ref0).abs().max() / ref0.abs().max())
+            assert err < 2e-5, (it, ea, eb, err)
+    finally:
+        torch.cuda.synchronize()
+
+
 def test_optimizer_grad_scale_equals_scaling_first(lib):
     """astk_*_scaled read the gradient as grad_scale * g (the 1/world mean of data parallelism applied on the fly, rounded like a
     separate scaling pass would round it): same result as scaling the buffer first and calling the unscaled entry points, up to the
@@ -720,7 +745,7 @@ def test_zero_frames_on_device_follows_the_loaders_rule(lib):
 def test_gradient_noise_hook_follows_the_other_two(lib):
     """nn.py:108-110: GradientNoise(eta) behind WeightDecay and GradientClipping (insertion order, A7).  Same gradients with and without
     the hook: what is left in the gradient arena after update() is clip(g + l2 p) + noise, and the noise has mean 0 and variance
-    eta / (1 + t)^0.55 (t = 1 at the first update, 2 at the second)."""
+    eta / (1 + t)^0.55 with the optimizer's count BEFORE the update (t = 0 at the first update: Chainer runs the hooks, then increments t)."""
     import math
     from ast_amd import optimizers as O
     from ast_amd.params import ParamArena
@@ -755,7 +780,7 @@ def test_gradient_noise_hook_follows_the_other_two(lib):
         noise = m1.arena.grad - want if step == 1 else None
         if step == 1:
             assert torch.equal(m0.arena.grad, g)                              # without the hook the arena keeps the raw gradient
-            sig = math.sqrt(eta / 2.0 ** 0.55)
+            sig = math.sqrt(eta / 1.0 ** 0.55)
             assert abs(float(noise.mean())) < 5 * sig / math.sqrt(noise.numel())
             assert abs(float(noise.std()) - sig) < 0.01 * sig
     assert float((m1.arena.data - m0.arena.data).abs().max()) > 0             # the noise reached the update

@@ -367,3 +367,47 @@ def test_file_loaders_follow_the_reference_schemas(tmp_path, kind):
     assert int(dl._targets("spk0_000", "fisher_train")[-2]) == SYMBOLS.UNK_ID
     hyps = dl.get_hyps([("u", [4, 5, 6, 7, 8, 2]), ("v", [1, 8, 0])])
     assert hyps == {"u": ["hello", "world", "a"], "v": ["a"]}
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did(monkeypatch, capsys):
+    """`python bench.py --gpus N` (N > 1) without WORLD_SIZE in the environment: bench.py starts torch.distributed.run as a CHILD process
+    (one rank per GPU, rendezvous on 127.0.0.1, same arguments), relays rank 0's JSON line and exits with the child's code -- before
+    anything touches HIP.  With WORLD_SIZE set (a launcher started us) or N = 1 nothing is spawned."""
+    import subprocess
+    import sys
+    import types
+    import bench
+    argv = ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    cmd = bench.self_launch_command(8, argv, port=29555)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
+    k = cmd.index(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    assert cmd[k + 1:] == argv
+    auto = bench.self_launch_command(2, argv)          # a free port is picked when none is given
+    assert 1024 < int(auto[auto.index("--master-port") + 1]) < 65536
+
+    calls = []
+
+    class FakeProc:
+        def __init__(self, cmd, **kw):
+            calls.append((cmd, kw))
+            self.stdout = iter(["rank 1 chatter\n", '{"metric": "speech frames/s (train step)", "value": 1.0, "n_gpus": 8}\n'])
+
+        def wait(self):
+            return 0
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    args = types.SimpleNamespace(gpus=8)
+    with pytest.raises(SystemExit) as e:
+        bench.maybe_self_launch(args, argv)
+    assert e.value.code == 0 and len(calls) == 1
+    assert calls[0][0][-len(argv):] == argv and "env" in calls[0][1] and calls[0][1]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    out = capsys.readouterr()
+    assert json.loads(out.out.strip())["n_gpus"] == 8 and "chatter" in out.err
+    # a launcher already started us, or one GPU: no child
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    bench.maybe_self_launch(args, argv)
+    monkeypatch.delenv("WORLD_SIZE")
+    bench.maybe_self_launch(types.SimpleNamespace(gpus=1), ["--gpus", "1"])
+    assert len(calls) == 1
