@@ -75,12 +75,17 @@ def init_params(cfg, in_dim, vocab_size=None, seed=0, dtype=np.float32):
         cin = co
     rnn_in = cin * fdim
 
+    ln = rc.get("ln", False)
+
     def lstm_params(name, n_in, n_out):
         P[f"{name}/upward/W"] = normal((4 * n_out, n_in), np.sqrt(1.0 / n_in))
         b = np.zeros(4 * n_out, dtype)
         b[2::4] = 1                                 # forget gate entries b[4j+2] (A9)
         P[f"{name}/upward/b"] = b
         P[f"{name}/lateral/W"] = normal((4 * n_out, n_out), np.sqrt(1.0 / n_out))
+        if ln:                                      # seq2seq.py:85-87, 141-143: L.LayerNormalization(units), gamma 1 / beta 0
+            P[f"{name}_ln/gamma"] = np.ones(n_out, dtype)
+            P[f"{name}_ln/beta"] = np.zeros(n_out, dtype)
 
     Hh = rc["hidden_units"] // 2 if rc["bi_rnn"] else rc["hidden_units"]
     stacks = ["L{}_enc"] + (["L{}_rev_enc"] if rc["bi_rnn"] else [])
@@ -88,11 +93,24 @@ def init_params(cfg, in_dim, vocab_size=None, seed=0, dtype=np.float32):
         n_in = rnn_in
         for i in range(rc["enc_layers"]):
             lstm_params(pat.format(i), n_in, Hh)
-            n_in = Hh
+            # L.LSTM(None, units) takes its input width from the first batch: the layer below's output (units per direction), or --
+            # with linear_proj -- the projection of the CONCATENATED states (hidden_units), seq2seq.py:250-286
+            n_in = rc["hidden_units"] if rc.get("linear_proj", False) else Hh
     H, E, A = rc["hidden_units"], rc["embedding_units"], rc["attn_units"]
+    if rc.get("linear_proj", False):                # seq2seq.py:89-99: Linear(H, H) + BatchNormalization(H) between encoder layers
+        for i in range(rc["enc_layers"] - 1):
+            P[f"enc_proj{i}/W"] = normal((H, H), np.sqrt(1.0 / H))
+            P[f"enc_proj{i}/b"] = np.zeros(H, dtype)
+            P[f"enc_proj{i}_bn/gamma"] = np.ones(H, dtype)
+            P[f"enc_proj{i}_bn/beta"] = np.zeros(H, dtype)
+            P[f"enc_proj{i}_bn/avg_mean"] = np.zeros(H, dtype)
+            P[f"enc_proj{i}_bn/avg_var"] = np.ones(H, dtype)
     n_attn = rc.get("n_attn", 1)
     P["attn_Wa/W"] = normal((H, H), np.sqrt(1.0 / H))
     P["attn_Wa/b"] = np.zeros(H, dtype)
+    for i in range(1, n_attn):                      # seq2seq.py:114-116
+        P[f"attn_Wa{i}/W"] = normal((H, H), np.sqrt(1.0 / H))
+        P[f"attn_Wa{i}/b"] = np.zeros(H, dtype)
     P["context/W"] = normal((A, (n_attn + 1) * H), np.sqrt(1.0 / ((n_attn + 1) * H)))
     P["context/b"] = np.zeros(A, dtype)
     P["embed_dec/W"] = normal((V, E), 1.0)
@@ -146,17 +164,21 @@ class RefModel:
         self.n_enc, self.n_dec = rc["enc_layers"], rc["dec_layers"]
         self.n_attn = rc.get("n_attn", 1)
         self.feed_attn = rc.get("feed_attn", True)
-        assert not rc.get("ln", False) and not rc.get("linear_proj", False), "outside the hot-path scope"
-        assert self.n_attn == 1
+        self.rnn_ln = rc.get("ln", False)                        # seq2seq.py:81
+        self.rnn_linear_proj = bool(rc.get("linear_proj", False))   # seq2seq.py:90-92
         self.cnn_layers = cfg["cnn_config"]["cnn_layers"]
         self.cnn_bn = cfg["cnn_config"]["bn"]
         self.bn = {}
-        if self.cnn_bn:
-            for i in range(len(self.cnn_layers)):
-                n = f"CNN_{i}_bn"
-                self.bn[n] = F.BatchNormState(self.p[n + "/gamma"], self.p[n + "/beta"],
-                                              self.p[n + "/avg_mean"], self.p[n + "/avg_var"])
-        mk = lambda n: F.LSTMLink(self.p[n + "/upward/W"], self.p[n + "/upward/b"], self.p[n + "/lateral/W"])
+        bn_names = [f"CNN_{i}_bn" for i in range(len(self.cnn_layers))] if self.cnn_bn else []
+        if self.rnn_linear_proj:
+            bn_names += [f"enc_proj{i}_bn" for i in range(self.n_enc - 1)]
+        for n in bn_names:
+            self.bn[n] = F.BatchNormState(self.p[n + "/gamma"], self.p[n + "/beta"], self.p[n + "/avg_mean"], self.p[n + "/avg_var"])
+
+        def mk(n):
+            link = F.LSTMLink(self.p[n + "/upward/W"], self.p[n + "/upward/b"], self.p[n + "/lateral/W"])
+            link.ln = (self.p[n + "_ln/gamma"], self.p[n + "_ln/beta"]) if self.rnn_ln else None
+            return link
         self.enc = [mk(f"L{i}_enc") for i in range(self.n_enc)]
         self.rev = [mk(f"L{i}_rev_enc") for i in range(self.n_enc)] if self.bi else []
         self.dec = [mk(f"L{i}_dec") for i in range(self.n_dec)]
@@ -179,7 +201,8 @@ class RefModel:
     def forward_cnn(self, X):
         h = F.swapaxes(F.expand_dims(X, 2), 1, 2)               # (B,T,D) -> (B,1,T,D)
         for i, l in enumerate(self.cnn_layers):
-            h = F.convolution_2d(h, self.p[f"CNN_{i}/W"], tuple(l["stride"]), tuple(l["pad"]))
+            h = F.convolution_2d(h, self.p[f"CNN_{i}/W"], tuple(l["stride"]), tuple(l["pad"]),
+                                 None if self.cnn_bn else self.p[f"CNN_{i}/b"])      # nobias=self.cnn_bn (seq2seq.py:52-54)
             if self.cnn_bn:
                 h = self.bn[f"CNN_{i}_bn"](h, train=self.train)
             h = F.relu(h)
@@ -197,6 +220,8 @@ class RefModel:
         ratio = self.cfg["dropout"]["rnn"]
         for k, link in enumerate(links):
             hs = F.dropout(link(hs), ratio, self.masks, (stack, k, step), self.train)
+            if self.rnn_ln:                                       # seq2seq.py:200-202: LN of the DROPPED output; the link's own h stays raw
+                hs = F.layer_normalization(hs, link.ln[0], link.ln[1], 1e-6)
         return hs
 
     # ---- seq2seq.py:205-242  (Q1: reverse stack reads X[-i]: 0, T''-1, ..., 1)
@@ -213,13 +238,45 @@ class RefModel:
         states = F.concat((h_fwd, F.flipud(h_rev)), axis=2) if self.bi else h_fwd
         self.enc_states = F.swapaxes(states, 0, 1)              # (B,T'',H)
 
+    # ---- seq2seq.py:244-291 (rnn_config.linear_proj).  Kept as written, including: the reverse stack is fed enc_states[-1] -- the LAST
+    # frame of the layer's input -- at EVERY step (:256, quirk Q8); no LayerNorm (feed_rnn is not used); the projection's
+    # BatchNormalization sees one (B, H) time step per call, so its statistics are over the B rows of that step and its running
+    # averages / N advance T'' times per layer; and `enc_states` is only reassigned inside the projection branch, so what the attention
+    # reads is the LAST PROJECTION's output (the CNN output itself for a 1-layer encoder) -- the top LSTM layer reaches the loss only
+    # through its final (c, h), which seed the decoder.
+    def forward_rnn_encode_proj(self, X):
+        self.reset_rnn_state()
+        n = X.shape[0]
+        ratio = self.cfg["dropout"]["rnn"]
+        enc_states = X
+        for cur in range(self.n_enc):
+            h_fwd = h_rev = None
+            for i in range(n):
+                f = F.expand_dims(F.dropout(self.enc[cur](enc_states[i]), ratio, self.masks, ("enc", cur, i), self.train), 0)
+                h_fwd = f if h_fwd is None else F.concat((h_fwd, f), axis=0)
+                if self.bi:
+                    r = F.expand_dims(F.dropout(self.rev[cur](enc_states[-1]), ratio, self.masks, ("rev", cur, i), self.train), 0)
+                    h_rev = r if h_rev is None else F.concat((h_rev, r), axis=0)
+            states = F.concat((h_fwd, F.flipud(h_rev)), axis=2) if self.bi else h_fwd
+            if cur < self.n_enc - 1:
+                nxt = None
+                for i in range(n):
+                    z = F.linear(states[i], self.p[f"enc_proj{cur}/W"], self.p[f"enc_proj{cur}/b"])
+                    hcur = F.expand_dims(F.relu(self.bn[f"enc_proj{cur}_bn"](z, train=self.train)), 0)
+                    nxt = hcur if nxt is None else F.concat((nxt, hcur), axis=0)
+                enc_states = nxt
+        self.enc_states = F.swapaxes(enc_states, 0, 1)
+
     # ---- seq2seq.py:293-314
     def encode(self, X, add_noise=0, noise=None):
         X = F.as_variable(X)
         if add_noise > 0 and self.train:
             assert noise is not None, "inject the N(1,sigma) tensor (Q7: the reference's draw is unseeded)"
             X = F.mul(X, Variable(noise.astype(self.dtype)))
-        self.forward_rnn_encode(self.forward_cnn(X))
+        if self.rnn_linear_proj:
+            self.forward_rnn_encode_proj(self.forward_cnn(X))
+        else:
+            self.forward_rnn_encode(self.forward_cnn(X))
 
     # ---- seq2seq.py:318-333
     def init_decoder_state(self):
@@ -231,8 +288,8 @@ class RefModel:
                 d.set_state(e.c, e.h)
 
     # ---- seq2seq.py:336-357
-    def compute_context_vector(self, dec_h):
-        q = F.linear(dec_h, self.p["attn_Wa/W"], self.p["attn_Wa/b"])
+    def compute_context_vector(self, dec_h, wa="attn_Wa"):
+        q = F.linear(dec_h, self.p[wa + "/W"], self.p[wa + "/b"])
         scores = F.batch_matmul(self.enc_states, q)              # (B,T'',1)
         alphas = F.softmax(scores)                               # over time, no padding mask (Q2)
         cv = F.squeeze(F.batch_matmul(F.swapaxes(self.enc_states, 2, 1), alphas), 2)
@@ -245,13 +302,20 @@ class RefModel:
         rnn_in = F.concat((emb, ht), axis=1) if self.feed_attn else emb
         h = self.feed_rnn(rnn_in, self.dec, "dec", step)
         cv, alphas = self.compute_context_vector(h)
+        for k in range(1, self.n_attn):                          # seq2seq.py:381-383: further heads on the SAME h; their alphas are dropped
+            new_cv, _ = self.compute_context_vector(h, f"attn_Wa{k}")
+            cv = F.concat((cv, new_cv), axis=1)
         ht = F.tanh(F.linear(F.concat((cv, h), axis=1), self.p["context/W"], self.p["context/b"]))
         logits = F.dropout(F.linear(ht, self.p["out/W"], self.p["out/b"]), dr["out"], self.masks, ("out", 0, step), self.train)
         return logits, ht, alphas
 
     # ---- seq2seq.py:399-473
-    def forward_loss(self, X, y, teach_ratio, random_out=0, add_noise=0, noise=None, pyrandom=_pyrandom):
-        assert random_out == 0, "random_out>0 (Q8) is outside the restated path"
+    def forward_loss(self, X, y, teach_ratio, random_out=0, add_noise=0, noise=None, pyrandom=_pyrandom, randint=None):
+        """random_out > 0 (seq2seq.py:456-465): behind each step's decode, every target >= 4 is replaced -- when
+        `random.random() > random_out`, the same Python stream as the teacher-forcing coin -- by xp.random.randint(4, V + 1), whose upper
+        end is one past the last class (quirk Q8): Chainer's softmax_cross_entropy raises on that id with NumPy and reads out of bounds
+        with CuPy.  DEVIATION, the only one in this restatement: the drawn id is clamped to V - 1.  `randint(low, high)` is the
+        replacement draw (the reference's is the unseeded global xp RNG, quirk Q7); self.targets records the targets that were scored."""
         y = np.asarray(y.data if isinstance(y, Variable) else y)
         B = X.shape[0]
         self.encode(X, add_noise, noise)
@@ -262,6 +326,7 @@ class RefModel:
         ht = Variable(np.zeros((B, A), dtype=self.dtype))
         loss = 0
         self.use_truth = []
+        self.targets = []
         dec_in = None
         for i in range(L - 1):
             cur, nxt = yT[i], yT[i + 1]
@@ -274,7 +339,13 @@ class RefModel:
                 dec_in = cur
             logits, ht, _ = self.decode_step(dec_in, ht, step=i)
             dec_in = F.argmax(logits, axis=1)
-            loss = loss + F.softmax_cross_entropy(logits, nxt.copy(), class_weight=self.mask_pad_id)
+            target = nxt.copy()
+            if random_out > 0:
+                for b in range(len(target)):
+                    if int(target[b]) >= 4 and pyrandom.random() > random_out:
+                        target[b] = min(int(randint(4, self.V + 1)), self.V - 1)
+            self.targets.append(target)
+            loss = loss + F.softmax_cross_entropy(logits, target, class_weight=self.mask_pad_id)
         return loss
 
     # ---- seq2seq.py:475-527
@@ -418,10 +489,10 @@ class RefOptimizer:
                 p.data -= p.dtype.type(c["lr"]) * p.grad
 
 
-def train_step(model, opt, X, y, teach_ratio, add_noise=0, noise=None, pyrandom=_pyrandom):
+def train_step(model, opt, X, y, teach_ratio, add_noise=0, noise=None, pyrandom=_pyrandom, random_out=0, randint=None):
     """nn.py:174-189: forward_loss -> cleargrads -> backward -> update; reports loss/B (Q5)."""
     model.train = True
-    loss = model.forward_loss(X, y, teach_ratio, 0, add_noise, noise, pyrandom)
+    loss = model.forward_loss(X, y, teach_ratio, random_out, add_noise, noise, pyrandom, randint)
     model.cleargrads()
     loss.backward()
     opt.update()

@@ -499,18 +499,21 @@ def _col2im(gcol, x_shape, kh, kw, sy, sx, ph, pw):
 
 
 class _Conv2D(Function):
-    """A3: NCHW cross-correlation, W (out,in,kh,kw), cover_all=False, no bias (seq2seq.py:52-54)."""
+    """A3: NCHW cross-correlation, W (out,in,kh,kw), cover_all=False; bias only when cnn_config.bn is false (seq2seq.py:52-54:
+    nobias=self.cnn_bn)."""
 
     def __init__(self, stride, pad):
         self.sy, self.sx = stride
         self.ph, self.pw = pad
 
     def forward(self, xs):
-        x, W = xs
+        x, W = xs[0], xs[1]
         self.x_shape, self.W = x.shape, W
         kh, kw = W.shape[2], W.shape[3]
         self.col, oh, ow = _im2col(x, kh, kw, self.sy, self.sx, self.ph, self.pw)
         y = np.tensordot(self.col, W, ((1, 2, 3), (1, 2, 3)))      # (B,oh,ow,O): im2col + one sgemm
+        if len(xs) == 3:
+            y = y + xs[2]
         return np.ascontiguousarray(np.rollaxis(y, 3, 1))
 
     def backward(self, gys):
@@ -520,34 +523,37 @@ class _Conv2D(Function):
         gcol = np.tensordot(self.W, gy, (0, 1))                     # (C,kh,kw,B,oh,ow)
         gcol = np.rollaxis(gcol, 3)
         gx = _col2im(gcol, self.x_shape, kh, kw, self.sy, self.sx, self.ph, self.pw)
+        if len(self.inputs) == 3:
+            return gx, gW, gy.sum(axis=(0, 2, 3))
         return gx, gW
 
 
-def convolution_2d(x, W, stride, pad):
-    return _Conv2D(stride, pad)(x, W)
+def convolution_2d(x, W, stride, pad, b=None):
+    return _Conv2D(stride, pad)(x, W) if b is None else _Conv2D(stride, pad)(x, W, b)
 
 
 class _BatchNormTrain(Function):
-    """A4: 4-D input, statistics over axes (0,2,3), biased variance, eps=2e-5."""
+    """A4: statistics over every axis but the channel axis 1 -- (0,2,3) for the CNN's 4-D input, (0,) for the 2-D (B, units) input of
+    the linear_proj encoder (seq2seq.py:281) -- biased variance, eps=2e-5."""
 
     def __init__(self, eps):
         self.eps = eps
 
     def forward(self, xs):
         x, gamma, beta = xs
-        ax = (0, 2, 3)
+        ax = self.ax = (0,) + tuple(range(2, x.ndim))
+        self.ex = (None, slice(None)) + (None,) * (x.ndim - 2)
         self.mean = x.mean(axis=ax)
         self.var = x.var(axis=ax)
         self.inv_std = (self.var + x.dtype.type(self.eps)) ** x.dtype.type(-0.5)
-        ex = (None, slice(None), None, None)
+        ex = self.ex
         self.x_hat = (x - self.mean[ex]) * self.inv_std[ex]
         self.gamma = gamma
         return gamma[ex] * self.x_hat + beta[ex]
 
     def backward(self, gys):
         gy = gys[0]
-        ax = (0, 2, 3)
-        ex = (None, slice(None), None, None)
+        ax, ex = self.ax, self.ex
         m = gy.size // self.gamma.size
         gbeta = gy.sum(axis=ax)
         ggamma = (gy * self.x_hat).sum(axis=ax)
@@ -578,11 +584,45 @@ class BatchNormState:
             self.avg_var += dt((1 - self.decay) * adjust) * f.var
             self.N += 1
             return y
-        ex = (None, slice(None), None, None)
+        ex = (None, slice(None)) + (None,) * (x.ndim - 2)
         inv = (self.avg_var + self.avg_var.dtype.type(self.eps)) ** -0.5
         scale = as_variable((self.gamma.data * inv)[ex])
         shift = as_variable((self.beta.data - self.gamma.data * inv * self.avg_mean)[ex])
         return add(mul(x, scale), shift)
+
+
+# --------------------------------------------------------------------------- L.LayerNormalization
+class _LayerNorm(Function):
+    """F.layer_normalization(x, gamma, beta, eps) on (B, units): per-row mean and BIASED variance over the units axis,
+    x_hat = (x - mu) / sqrt(var + eps), y = x_hat * gamma + beta.  L.LayerNormalization(size) passes its own eps = 1e-6 (the function's
+    default would be 1e-5); gamma initialised to 1, beta to 0.  Used behind every LSTM when rnn_config.ln is set (seq2seq.py:85-87,
+    141-143, 200-202)."""
+
+    def __init__(self, eps):
+        self.eps = eps
+
+    def forward(self, xs):
+        x, gamma, beta = xs
+        mu = x.mean(axis=1, keepdims=True)
+        xm = x - mu
+        var = (xm * xm).mean(axis=1, keepdims=True)
+        self.inv_std = 1.0 / np.sqrt(var + x.dtype.type(self.eps))
+        self.x_hat = xm * self.inv_std
+        self.gamma = gamma
+        return self.x_hat * gamma[None, :] + beta[None, :]
+
+    def backward(self, gys):
+        gy = gys[0]
+        gbeta = gy.sum(axis=0)
+        ggamma = (gy * self.x_hat).sum(axis=0)
+        g = gy * self.gamma[None, :]
+        n = gy.shape[1]
+        gx = self.inv_std * (g - g.mean(axis=1, keepdims=True) - self.x_hat * (g * self.x_hat).sum(axis=1, keepdims=True) / n)
+        return gx, ggamma, gbeta
+
+
+def layer_normalization(x, gamma, beta, eps=1e-6):
+    return _LayerNorm(eps)(x, gamma, beta)
 
 
 # --------------------------------------------------------------------------- L.LSTM link state
