@@ -8,6 +8,7 @@ LIB_PATH = os.environ.get("ASTK_LIB_PATH") or os.path.join(_HERE, "libastk.so") 
 
 MAX_CNN = 4
 MAX_RNN = 8
+MAX_ATTN = 4
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int32)
@@ -18,16 +19,16 @@ class CnnDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("D", C.c_int), ("n_layers", C.c_int),
                 ("C", C.c_int * MAX_CNN), ("kt", C.c_int * MAX_CNN), ("kf", C.c_int * MAX_CNN),
                 ("st", C.c_int * MAX_CNN), ("sf", C.c_int * MAX_CNN), ("pt", C.c_int * MAX_CNN),
-                ("bn_eps", C.c_float), ("bn_decay", C.c_float)]
+                ("bn_eps", C.c_float), ("bn_decay", C.c_float), ("no_bn", C.c_int)]
 
 
 class CnnLayerParams(C.Structure):
     _fields_ = [("W", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
-                ("avg_mean", C.c_void_p), ("avg_var", C.c_void_p)]
+                ("avg_mean", C.c_void_p), ("avg_var", C.c_void_p), ("bias", C.c_void_p)]
 
 
 class CnnLayerGrads(C.Structure):
-    _fields_ = [("dW", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+    _fields_ = [("dW", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dbias", C.c_void_p)]
 
 
 class LstmStackDesc(C.Structure):
@@ -45,19 +46,24 @@ class LstmGrads(C.Structure):
 
 class DecoderDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("L", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int),
-                ("A", C.c_int), ("V", C.c_int), ("n_layers", C.c_int)]
+                ("A", C.c_int), ("V", C.c_int), ("n_layers", C.c_int),
+                ("n_attn", C.c_int), ("no_feed_attn", C.c_int), ("ln", C.c_int)]
 
 
 class DecoderParams(C.Structure):
     _fields_ = [("embed", C.c_void_p), ("lstm", LstmParams * MAX_RNN),
                 ("Wa", C.c_void_p), ("ba", C.c_void_p), ("Wc", C.c_void_p), ("bc", C.c_void_p),
-                ("Wo", C.c_void_p), ("bo", C.c_void_p), ("class_weight", C.c_void_p)]
+                ("Wo", C.c_void_p), ("bo", C.c_void_p), ("class_weight", C.c_void_p),
+                ("Wa_x", C.c_void_p * (MAX_ATTN - 1)), ("ba_x", C.c_void_p * (MAX_ATTN - 1)),
+                ("ln_gamma", C.c_void_p * MAX_RNN), ("ln_beta", C.c_void_p * MAX_RNN)]
 
 
 class DecoderGrads(C.Structure):
     _fields_ = [("d_embed", C.c_void_p), ("lstm", LstmGrads * MAX_RNN),
                 ("dWa", C.c_void_p), ("dba", C.c_void_p), ("dWc", C.c_void_p), ("dbc", C.c_void_p),
-                ("dWo", C.c_void_p), ("dbo", C.c_void_p)]
+                ("dWo", C.c_void_p), ("dbo", C.c_void_p),
+                ("dWa_x", C.c_void_p * (MAX_ATTN - 1)), ("dba_x", C.c_void_p * (MAX_ATTN - 1)),
+                ("d_ln_gamma", C.c_void_p * MAX_RNN), ("d_ln_beta", C.c_void_p * MAX_RNN)]
 
 
 # every symbol include/astk.h declares: name -> (restype, argtypes)
@@ -92,6 +98,14 @@ SIGNATURES = {
     "astk_decoder_workspace_bytes": (_SZ, [C.POINTER(DecoderDesc)]),
     "astk_decoder_fwd": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderParams), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                                    _VP, _SZ, _VP]),
+    "astk_decoder_fwd_ex": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderParams), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
+                                      _VP, _SZ, _VP]),
+    "astk_decoder_bwd_phase_ex": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderParams), C.POINTER(DecoderGrads), _VP, _VP, _VP, _VP,
+                                            _VP, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _I, _VP]),
+    "astk_layernorm_fwd": (C.c_int, [_I, _I, _VP, _L, _VP, _VP, _F, _VP, _L, _VP]),
+    "astk_layernorm_bwd": (C.c_int, [_I, _I, _VP, _L, _VP, _F, _VP, _L, _VP, _L, _VP, _VP, _VP]),
+    "astk_step_bn_relu_fwd": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _VP, _VP, _F, _F, _I, _VP, _VP, _VP]),
+    "astk_step_bn_relu_bwd": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _F, _VP, _VP, _VP, _VP, _VP, _VP]),
     "astk_decoder_bwd": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderParams), C.POINTER(DecoderGrads), _VP, _VP, _VP, _VP,
                                    _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "astk_decoder_bwd_phase": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderParams), C.POINTER(DecoderGrads), _VP, _VP, _VP, _VP,
@@ -110,6 +124,8 @@ SIGNATURES = {
     "astk_fill_dropout_mask": (C.c_int, [_VP, _SZ, _F, _U64, _U64, _VP]),
     "astk_fill_normal": (C.c_int, [_VP, _SZ, _F, _F, _U64, _U64, _VP]),
     "astk_scale_f32": (C.c_int, [_VP, _SZ, _F, _VP]),
+    "astk_add_f32": (C.c_int, [_VP, _VP, _SZ, _VP]),
+    "astk_colsum_add_f32": (C.c_int, [_VP, _VP, _L, _I, _I, _VP]),
     "astk_zero_frames": (C.c_int, [_VP, _I, _I, _I, _VP, _F, _U64, _U64, _VP]),
     "astk_persist_status_snapshot": (C.c_int, [_VP, _VP]),
     "astk_persist_status": (C.c_int, [C.POINTER(C.c_uint), _I]),

@@ -351,6 +351,14 @@ int attn_bwd_launch(int B, int T, int H, const float* enc, const float* alpha, c
 size_t attn_ws_bytes(int B, int T, int H);
 int attn_ws_init(void* ws, int B, int T, int H, hipStream_t s);   // zero the ticket counters (once per workspace use)
 
+// ---- normalisation / small row kernels of the optional model features (norm.hip)
+int layernorm_fwd_launch(int rows, int n, const float* x, long ldx, const float* gamma, const float* beta, float eps, float* y, long ldy,
+                         hipStream_t s);
+int layernorm_bwd_launch(int rows, int n, const float* x, long ldx, const float* gamma, float eps, const float* dy, long lddy, float* dx,
+                         long lddx, float* dgamma, float* dbeta, hipStream_t s);     // dgamma / dbeta accumulated (may be null)
+int mul_rows_launch(float* x, long ldx, const float* m, long ldm, int rows, int cols, hipStream_t s);   // x[r][c] *= m[r][c]
+constexpr float LN_EPS = 1e-6f;        // L.LayerNormalization's default eps
+
 // ---- decoder helpers (decoder.hip)
 int softmax_ce_launch(int B, int V, long ld, float* logits, const int32_t* targets, long t_stride, const float* cw,
                       float inv_count, float* loss_rows, int32_t* argmax, hipStream_t s);

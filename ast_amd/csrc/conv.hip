@@ -229,6 +229,21 @@ __global__ void k_bn_finalize(const double* __restrict__ stat, int C, double m, 
   bn[3 * C + c] = beta[c] - mean * sc;
 }
 
+// cnn_config.bn = false (seq2seq.py:43-57: Convolution2D with bias, no BatchNormalization): the same scale / shift slots the ReLU
+// kernels read, filled with scale 1 and shift = bias (mean 0, inv_std 1 for the backward's x_hat, which it then ignores)
+__global__ void k_bias_affine(const float* __restrict__ bias, int C, float* __restrict__ bn) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  bn[c] = 0.f;
+  bn[C + c] = 1.f;
+  bn[2 * C + c] = 1.f;
+  bn[3 * C + c] = bias[c];
+}
+__global__ void k_bias_grad(const double* __restrict__ stat, int C, float* __restrict__ dbias) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) dbias[c] += (float)stat[c];
+}
+
 // dst[prow(m)][c] = relu(Y[m][c]*scale + shift), prow(m) = (m/Tn)*(Tn+2*pad) + pad + m%Tn  (float4 over channels)
 __global__ void k_bn_relu_rows(const float* __restrict__ Y, const float* __restrict__ bn, float* __restrict__ dst, int rows, int C,
                                int Tn, int pad) {
@@ -386,7 +401,7 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
                                void* stream) {
   hipStream_t s = (hipStream_t)stream;
   ASTK_CHECK(world >= 1, "conv_bn_relu_fwd: world %d", world);
-  if (world == 1) exchange = nullptr;
+  if (world == 1 || d->no_bn) exchange = nullptr;
   CnnPlan P;
   ASTK_TRY(make_plan(d, ws, P));
   ASTK_CHECK(ws && ws_bytes >= P.bytes, "conv_bn_relu_fwd: workspace too small (%zu < %zu)", ws_bytes, P.bytes);
@@ -410,6 +425,11 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
       ASTK_TRY(gemm_launch(GEMM_NT, lowp(g), s));            // K6
     }
     // ---- batch statistics -> scale/shift
+    if (d->no_bn) {
+      ASTK_CHECK(L[i].bias, "conv_bn_relu_fwd: no_bn needs a bias (layer %d)", i);
+      hipLaunchKernelGGL(k_bias_affine, dim3(cdiv(C, 256)), dim3(256), 0, s, L[i].bias, C, P.bn[i]);
+      ASTK_LAUNCH_CHECK();
+    } else {
     if (train) {
       if (i == 0) ASTK_TRY(fill_zero(P.stat[0], P.zero_fwd_bytes, s));   // the statistics of every layer
       hipLaunchKernelGGL(k_colstats, colreduce_grid(rows, C), dim3(256), 0, s, P.Y[i], rows, C, P.stat[i]);
@@ -419,6 +439,7 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
     hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, s, P.stat[i], C, (double)rows * (exchange ? world : 1), L[i].gamma, L[i].beta,
                        L[i].avg_mean, L[i].avg_var, P.bn[i], d->bn_eps, d->bn_decay, train);
     ASTK_LAUNCH_CHECK();
+    }
     if (i < P.n - 1) {
       if (P.padA[i] > 0) {
         hipLaunchKernelGGL(k_zero_pads, dim3(gridn((size_t)B * F * 2 * P.padA[i] * C / 4)), dim3(256), 0, s, P.HP[i], B * F, P.Tn[i], P.padA[i],
@@ -447,7 +468,7 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
                                void* ws, size_t ws_bytes, astk_stat_exchange_fn exchange, void* user, int world, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   ASTK_CHECK(world >= 1, "conv_bn_relu_bwd: world %d", world);
-  if (world == 1) exchange = nullptr;
+  if (world == 1 || d->no_bn) exchange = nullptr;      // (no statistics to exchange without BatchNorm)
   CnnPlan P;
   ASTK_TRY(make_plan(d, ws, P));
   ASTK_CHECK(ws && ws_bytes >= P.bytes, "conv_bn_relu_bwd: workspace too small");
@@ -476,10 +497,16 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
                          P.dB[i], C);
       ASTK_LAUNCH_CHECK();
     }
+    // (no_bn: the ReLU mask alone -- scale 1 and a zero 1/m switch the BatchNorm terms off; the column sums of g are the bias gradient)
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(gridn((size_t)rows * C / 4)), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], P.stat[i], P.DY[i], rows, C,
-                       P.Tn[i], P.dF[i], P.dB[i], exchange ? nullptr : Gr[i].dgamma, exchange ? nullptr : Gr[i].dbeta,
-                       1.f / ((float)rows * (exchange ? world : 1)));
+                       P.Tn[i], P.dF[i], P.dB[i], (exchange || d->no_bn) ? nullptr : Gr[i].dgamma, (exchange || d->no_bn) ? nullptr : Gr[i].dbeta,
+                       d->no_bn ? 0.f : 1.f / ((float)rows * (exchange ? world : 1)));
     ASTK_LAUNCH_CHECK();
+    if (d->no_bn) {
+      ASTK_CHECK(Gr[i].dbias, "conv_bn_relu_bwd: no_bn needs a bias gradient (layer %d)", i);
+      hipLaunchKernelGGL(k_bias_grad, dim3(cdiv(C, 256)), dim3(256), 0, s, P.stat[i], C, Gr[i].dbias);
+      ASTK_LAUNCH_CHECK();
+    }
     if (i == 0) {
       // ---- wgrad layer 0: dW0p[C0][K0p] = DY0^T P0
       const int ks = ksplit_for(1, rows);

@@ -23,7 +23,7 @@ struct DecPersistBuffers {
 };
 bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int* chunk_out);
 int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_params* prm, const float* enc, const int32_t* y,
-                               const int32_t* use_truth, const float* emb_mask, const float* rnn_masks, const DecPersistBuffers& bf,
+                               const int32_t* ytgt, const int32_t* use_truth, const float* emb_mask, const float* rnn_masks, const DecPersistBuffers& bf,
                                float* loss, int32_t* pred_out, hipStream_t s);
 
 struct DecPersistBwdBuffers {
@@ -42,6 +42,11 @@ namespace {
 
 struct DecPlan {
   int B, L, S, T, Tp, H, E, A, V, Vp, XI, nl;
+  int NA, CW;    // attention heads; width of the [cv_0; ..; cv_{NA-1}; h] buffer = (NA+1)*H
+  bool feed, ln; // input feeding (ht_{s-1} behind the embedding); LayerNorm behind every LSTM's dropped output
+  float* HDL[ASTK_MAX_RNN_LAYERS];   // ln: [S][B][H] dropped outputs BEFORE the LayerNorm (its saved input)
+  float* DLN;    // ln: [B][H] gradient wrt a LayerNorm's output / input (scratch)
+  float* DLN2;
   int* TOK;      // [S][B] token fed at step s
   int* PRED;     // [S][B] argmax of step s
   float* X0;     // [S][B][XI]  concat(emb, ht_prev)
@@ -49,23 +54,23 @@ struct DecPlan {
   float* C[ASTK_MAX_RNN_LAYERS];    // [(S+1)][B][H], C[0] = c0
   float* HR[ASTK_MAX_RNN_LAYERS];   // [(S+1)][B][H], HR[0] = h0
   float* HD[ASTK_MAX_RNN_LAYERS];   // [S][B][H] dropped outputs of layers < top (with masks)
-  float* Q;      // [S][B][H]
-  float* ALPHA;  // [S][B][Tp]
-  float* CVH;    // [S][B][2H]  concat(cv, h_top_dropped)
+  float* Q;      // [NA][S][B][H]
+  float* ALPHA;  // [NA][S][B][Tp]
+  float* CVH;    // [S][B][CW]  concat(cv_0, .., cv_{NA-1}, h_top_dropped)
   float* HT;     // [(S+1)][B][A], HT[0] = 0
   float* LOGITS; // [S][B][Vp] -> dlogits
   float* LOSSROWS;  // [S][B]
   // backward
   float* DPRE;   // [S][B][A]
-  float* DCVH;   // [S][B][2H]
-  float* DS;     // [S][B][Tp]
-  float* DQ;     // [S][B][H]
+  float* DCVH;   // [S][B][CW]
+  float* DS;     // [NA][S][B][Tp]
+  float* DQ;     // [NA][S][B][H]
   float* DX0;    // [S][B][XI]
   float* DHTOP;  // [B][H]
   float* DC[ASTK_MAX_RNN_LAYERS][2];
   float* WoT;    // [A][Vp]
-  float* WcT;    // [2H][A]
-  float* WaT;    // [H][H]
+  float* WcT;    // [CW][A]
+  float* WaT;    // [NA][H][H]
   float* WuT[ASTK_MAX_RNN_LAYERS];  // [in][4H]
   float* WlT[ASTK_MAX_RNN_LAYERS];  // [H][4H]
   float *LSE, *PART, *CESTAT, *ENCA, *MLB, *DXH;       // persistent path only
@@ -79,9 +84,15 @@ int make_plan(const astk_decoder_desc* d, void* ws, DecPlan& P) {
   ASTK_CHECK(d->n_layers >= 1 && d->n_layers <= ASTK_MAX_RNN_LAYERS, "decoder: layers");
   ASTK_CHECK((d->H % 4) == 0 && (d->E % 4) == 0 && (d->A % 4) == 0, "decoder: H, E, A must be multiples of 4");
   P.B = d->B; P.L = d->L; P.S = d->L - 1; P.T = d->T; P.Tp = (d->T + 3) / 4 * 4;
-  P.H = d->H; P.E = d->E; P.A = d->A; P.V = d->V; P.Vp = (d->V + 3) / 4 * 4; P.XI = d->E + d->A; P.nl = d->n_layers;
+  P.H = d->H; P.E = d->E; P.A = d->A; P.V = d->V; P.Vp = (d->V + 3) / 4 * 4; P.nl = d->n_layers;
+  ASTK_CHECK(d->n_attn >= 0 && d->n_attn <= ASTK_MAX_ATTN, "decoder: n_attn %d (max %d)", d->n_attn, ASTK_MAX_ATTN);
+  P.NA = d->n_attn > 1 ? d->n_attn : 1;
+  P.CW = (P.NA + 1) * d->H;
+  P.feed = d->no_feed_attn == 0;
+  P.ln = d->ln != 0;
+  P.XI = P.feed ? d->E + d->A : d->E;
   Carver c(ws);
-  const size_t S = P.S, B = P.B, H = P.H;
+  const size_t S = P.S, B = P.B, H = P.H, NA = P.NA, CW = P.CW;
   P.TOK = c.take<int>(S * B);
   P.PRED = c.take<int>(S * B);
   P.X0 = c.take<float>(S * B * P.XI);
@@ -95,22 +106,25 @@ int make_plan(const astk_decoder_desc* d, void* ws, DecPlan& P) {
     const size_t in = l == 0 ? P.XI : H;
     P.WuT[l] = c.take<float>(in * 4 * H);
     P.WlT[l] = c.take<float>(H * 4 * H);
+    P.HDL[l] = c.take<float>(P.ln ? S * B * H : 4);
   }
-  P.Q = c.take<float>(S * B * H);
-  P.ALPHA = c.take<float>(S * B * P.Tp);
-  P.CVH = c.take<float>(S * B * 2 * H);
+  P.DLN = c.take<float>(B * H);
+  P.DLN2 = c.take<float>(B * H);
+  P.Q = c.take<float>(NA * S * B * H);
+  P.ALPHA = c.take<float>(NA * S * B * P.Tp);
+  P.CVH = c.take<float>(S * B * CW);
   P.HT = c.take<float>((S + 1) * B * P.A);
   P.LOGITS = c.take<float>(S * B * P.Vp);
   P.LOSSROWS = c.take<float>(S * B);
   P.DPRE = c.take<float>(S * B * P.A);
-  P.DCVH = c.take<float>(S * B * 2 * H);
-  P.DS = c.take<float>(S * B * P.Tp);
-  P.DQ = c.take<float>(S * B * H);
+  P.DCVH = c.take<float>(S * B * CW);
+  P.DS = c.take<float>(NA * S * B * P.Tp);
+  P.DQ = c.take<float>(NA * S * B * H);
   P.DX0 = c.take<float>(S * B * P.XI);
   P.DHTOP = c.take<float>(B * H);
   P.WoT = c.take<float>((size_t)P.A * P.Vp);
-  P.WcT = c.take<float>(2 * H * P.A);
-  P.WaT = c.take<float>(H * H);
+  P.WcT = c.take<float>(CW * P.A);
+  P.WaT = c.take<float>(NA * H * H);
   P.attn_ws = c.take<char>(attn_ws_bytes(P.B, P.T, P.H));
   {
     int ns = 1, ch = 1;
@@ -314,13 +328,20 @@ int astk_softmax_ce_fwd(int B, int V, long ld, float* logits_inout, const int32_
 int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* prm, const float* enc, const float* c0, const float* h0,
                      const int32_t* y, const int32_t* use_truth, const float* emb_mask, const float* rnn_masks, float* loss,
                      int32_t* pred, void* ws, size_t ws_bytes, void* stream) {
+  return astk_decoder_fwd_ex(d, prm, enc, c0, h0, y, use_truth, emb_mask, rnn_masks, nullptr, nullptr, loss, pred, ws, ws_bytes, stream);
+}
+
+int astk_decoder_fwd_ex(const astk_decoder_desc* d, const astk_decoder_params* prm, const float* enc, const float* c0, const float* h0,
+                        const int32_t* y, const int32_t* use_truth, const float* emb_mask, const float* rnn_masks, const float* out_mask,
+                        const int32_t* targets, float* loss, int32_t* pred, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   DecPlan P;
   ASTK_TRY(make_plan(d, ws, P));
   ASTK_CHECK(ws && ws_bytes >= P.bytes, "decoder_fwd: workspace too small (%zu < %zu)", ws_bytes, P.bytes);
   ASTK_CHECK(prm && enc && c0 && h0 && y && use_truth && loss, "decoder_fwd: null pointer");
-  const int B = P.B, S = P.S, H = P.H, E = P.E, A = P.A, V = P.V, XI = P.XI, nl = P.nl;
+  const int B = P.B, S = P.S, H = P.H, E = P.E, A = P.A, V = P.V, XI = P.XI, nl = P.nl, NA = P.NA, CW = P.CW;
   const size_t bh = (size_t)B * H;
+  const int32_t* tgt = targets ? targets : y;       // class ids scored at step s: column s + 1
   // initial states and zero attention vector (seq2seq.py:318-333, :420)
   {
     CopySegs cp;
@@ -340,7 +361,8 @@ int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
   const int top = nl - 1;
   {
     int ns = 1, ch = 1;
-    const bool persist = decoder_persist_applicable(d, &ns, &ch);
+    // (dropout on the logits is not part of the persistent loop's CE role: per-launch loop)
+    const bool persist = !out_mask && decoder_persist_applicable(d, &ns, &ch);
     if (!persist) ASTK_TRY(attn_ws_init(P.attn_ws, B, P.T, H, s));   // the persistent loop has its own counters
     if (persist) {
       DecPersistBuffers bf;
@@ -349,7 +371,7 @@ int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
       for (int l = 0; l < nl; ++l) { bf.G[l] = P.G[l]; bf.C[l] = P.C[l]; bf.HR[l] = P.HR[l]; bf.HD[l] = P.HD[l]; }
       bf.CVH = P.CVH; bf.HT = P.HT; bf.LOGITS = P.LOGITS; bf.LOSSROWS = P.LOSSROWS; bf.LSE = P.LSE; bf.PART = P.PART;
       bf.CESTAT = P.CESTAT; bf.ENCA = P.ENCA; bf.ML = P.MLB; bf.ctr = P.PCTR;
-      ASTK_TRY(decoder_persist_fwd_launch(d, prm, enc, y, use_truth, emb_mask, rnn_masks, bf, loss, pred, s));   // (incl. loss sum and predictions)
+      ASTK_TRY(decoder_persist_fwd_launch(d, prm, enc, y, tgt, use_truth, emb_mask, rnn_masks, bf, loss, pred, s));   // (incl. loss sum and predictions)
       return 0;
     }
   }
@@ -358,7 +380,8 @@ int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
     hipLaunchKernelGGL(k_embed, dim3(B), dim3(128), 0, s, prm->embed, y, P.L, st, use_truth, st > 0 ? P.PRED + (size_t)(st - 1) * B : nullptr,
                        (const int32_t*)nullptr, P.TOK + (size_t)st * B, emb_mask ? emb_mask + (size_t)st * B * E : nullptr, x0, B, E, XI, V);
     ASTK_LAUNCH_CHECK();
-    float* cvh = P.CVH + (size_t)st * B * 2 * H;
+    float* cvh = P.CVH + (size_t)st * B * CW;
+    float* htop = cvh + (size_t)NA * H;        // the top layer's (dropped, normalised) output sits behind the NA context vectors
     const float* x_in = x0;
     long ld_x = XI;
     int in = XI;
@@ -366,27 +389,39 @@ int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
       const float* mask = rnn_masks ? rnn_masks + ((size_t)l * S + st) * bh : nullptr;
       float* hd;
       long ld_hd;
-      if (l == top) { hd = cvh + H; ld_hd = 2 * H; }
+      if (l == top) { hd = htop; ld_hd = CW; }
       else { hd = P.HD[l] + (size_t)st * bh; ld_hd = H; }
-      ASTK_TRY(cell_fwd(P, prm, l, x_in, ld_x, in, P.HR[l] + (size_t)st * bh, P.C[l] + (size_t)st * bh, P.G[l] + (size_t)st * B * 4 * H,
-                        P.C[l] + (size_t)(st + 1) * bh, P.HR[l] + (size_t)(st + 1) * bh, mask, hd, ld_hd, s));
+      if (P.ln) {
+        // hs = LN(dropout(LSTM(x))) (seq2seq.py:198-202): the cell leaves the dropped output in HDL, the LayerNorm writes the layer's output
+        float* pre = P.HDL[l] + (size_t)st * bh;
+        ASTK_TRY(cell_fwd(P, prm, l, x_in, ld_x, in, P.HR[l] + (size_t)st * bh, P.C[l] + (size_t)st * bh, P.G[l] + (size_t)st * B * 4 * H,
+                          P.C[l] + (size_t)(st + 1) * bh, P.HR[l] + (size_t)(st + 1) * bh, mask, pre, H, s));
+        ASTK_CHECK(prm->ln_gamma[l] && prm->ln_beta[l], "decoder_fwd: ln parameters missing (layer %d)", l);
+        ASTK_TRY(layernorm_fwd_launch(B, H, pre, H, prm->ln_gamma[l], prm->ln_beta[l], LN_EPS, hd, ld_hd, s));
+      } else {
+        ASTK_TRY(cell_fwd(P, prm, l, x_in, ld_x, in, P.HR[l] + (size_t)st * bh, P.C[l] + (size_t)st * bh, P.G[l] + (size_t)st * B * 4 * H,
+                          P.C[l] + (size_t)(st + 1) * bh, P.HR[l] + (size_t)(st + 1) * bh, mask, hd, ld_hd, s));
+      }
       x_in = hd; ld_x = ld_hd; in = H;
     }
-    // q = Wa h + ba
-    float* q = P.Q + (size_t)st * bh;
-    {
-      RowGemmArgs a = rg(B, H, cvh + H, 2 * H, prm->Wa, H, H, q, H);
-      a.bias = prm->ba;
+    // every attention head on the same h (seq2seq.py:379-383): q_k = Wa_k h + ba_k, scan -> cv_k
+    for (int k = 0; k < NA; ++k) {
+      const float* Wa = k == 0 ? prm->Wa : prm->Wa_x[k - 1];
+      const float* ba = k == 0 ? prm->ba : prm->ba_x[k - 1];
+      ASTK_CHECK(Wa && ba, "decoder_fwd: attention head %d has no parameters", k);
+      float* q = P.Q + ((size_t)k * S + st) * bh;
+      RowGemmArgs a = rg(B, H, htop, CW, Wa, H, H, q, H);
+      a.bias = ba;
       ASTK_TRY(rowgemm_launch(a, s));
+      ASTK_TRY(attn_fwd_launch(B, P.T, H, enc, q, H, P.ALPHA + ((size_t)k * S + st) * B * P.Tp, cvh + (size_t)k * H, CW, nullptr, 0, P.attn_ws, s));
     }
-    ASTK_TRY(attn_fwd_launch(B, P.T, H, enc, q, H, P.ALPHA + (size_t)st * B * P.Tp, cvh, 2 * H, nullptr, 0, P.attn_ws, s));
-    // ht = tanh(Wc [cv;h] + bc) -> HT[st+1] and the next step's concat buffer
+    // ht = tanh(Wc [cv..;h] + bc) -> HT[st+1] and (input feeding) the next step's concat buffer
     float* ht = P.HT + (size_t)(st + 1) * B * A;
     {
-      RowGemmArgs a = rg(B, A, cvh, 2 * H, prm->Wc, 2 * H, 2 * H, ht, A);
+      RowGemmArgs a = rg(B, A, cvh, CW, prm->Wc, CW, CW, ht, A);
       a.bias = prm->bc;
       a.act = ACT_TANH;
-      if (st + 1 < S) { a.out2 = P.X0 + (size_t)(st + 1) * B * XI + E; a.ld_out2 = XI; }
+      if (P.feed && st + 1 < S) { a.out2 = P.X0 + (size_t)(st + 1) * B * XI + E; a.ld_out2 = XI; }
       ASTK_TRY(rowgemm_launch(a, s));
     }
     float* lg = P.LOGITS + (size_t)st * B * P.Vp;
@@ -395,8 +430,12 @@ int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
       a.bias = prm->bo;
       ASTK_TRY(rowgemm_launch(a, s));
     }
-    ASTK_TRY(softmax_ce_launch(B, V, P.Vp, lg, y + st + 1, P.L, prm->class_weight, 1.f / (float)B, P.LOSSROWS + (size_t)st * B,
+    // dropout on the logits (seq2seq.py:394): argmax feedback and loss see the dropped logits; the gradient passes the same mask
+    const float* om = out_mask ? out_mask + (size_t)st * B * V : nullptr;
+    if (om) ASTK_TRY(mul_rows_launch(lg, P.Vp, om, V, B, V, s));
+    ASTK_TRY(softmax_ce_launch(B, V, P.Vp, lg, tgt + st + 1, P.L, prm->class_weight, 1.f / (float)B, P.LOSSROWS + (size_t)st * B,
                                P.PRED + (size_t)st * B, s));
+    if (om) ASTK_TRY(mul_rows_launch(lg, P.Vp, om, V, B, V, s));
   }
   hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, s, P.LOSSROWS, S * B, loss);
   ASTK_LAUNCH_CHECK();
@@ -410,12 +449,19 @@ int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
 int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* prm, const astk_decoder_grads* g, const float* enc,
                      const float* c0, const float* h0, const int32_t* y, const float* emb_mask, const float* rnn_masks, float* d_enc,
                      float* d_c0, float* d_h0, void* ws, size_t ws_bytes, void* stream) {
-  return astk_decoder_bwd_phase(d, prm, g, enc, c0, h0, y, emb_mask, rnn_masks, d_enc, d_c0, d_h0, ws, ws_bytes, ASTK_DEC_BWD_ALL, stream);
+  return astk_decoder_bwd_phase_ex(d, prm, g, enc, c0, h0, y, emb_mask, rnn_masks, nullptr, d_enc, d_c0, d_h0, ws, ws_bytes, ASTK_DEC_BWD_ALL, stream);
 }
 
 int astk_decoder_bwd_phase(const astk_decoder_desc* d, const astk_decoder_params* prm, const astk_decoder_grads* g, const float* enc,
                            const float* c0, const float* h0, const int32_t* y, const float* emb_mask, const float* rnn_masks,
                            float* d_enc, float* d_c0, float* d_h0, void* ws, size_t ws_bytes, int phase, void* stream) {
+  return astk_decoder_bwd_phase_ex(d, prm, g, enc, c0, h0, y, emb_mask, rnn_masks, nullptr, d_enc, d_c0, d_h0, ws, ws_bytes, phase, stream);
+}
+
+int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_params* prm, const astk_decoder_grads* g, const float* enc,
+                              const float* c0, const float* h0, const int32_t* y, const float* emb_mask, const float* rnn_masks,
+                              const float* out_mask, float* d_enc, float* d_c0, float* d_h0, void* ws, size_t ws_bytes, int phase,
+                              void* stream) {
   hipStream_t s = (hipStream_t)stream;
   (void)c0; (void)h0; (void)y;
   ASTK_CHECK(phase == ASTK_DEC_BWD_ALL || phase == ASTK_DEC_BWD_CHAIN || phase == ASTK_DEC_BWD_PARAMS, "decoder_bwd: bad phase %d", phase);
@@ -424,11 +470,11 @@ int astk_decoder_bwd_phase(const astk_decoder_desc* d, const astk_decoder_params
   ASTK_TRY(make_plan(d, ws, P));
   ASTK_CHECK(ws && ws_bytes >= P.bytes, "decoder_bwd: workspace too small");
   ASTK_CHECK(prm && g && enc && d_enc && d_c0 && d_h0, "decoder_bwd: null pointer");
-  const int B = P.B, S = P.S, H = P.H, E = P.E, A = P.A, V = P.V, Vp = P.Vp, XI = P.XI, nl = P.nl, T = P.T, Tp = P.Tp;
+  const int B = P.B, S = P.S, H = P.H, E = P.E, A = P.A, V = P.V, Vp = P.Vp, XI = P.XI, nl = P.nl, T = P.T, Tp = P.Tp, NA = P.NA, CW = P.CW;
   const size_t bh = (size_t)B * H;
   const int top = nl - 1;
   int ns_ = 1, ch_ = 1;
-  const bool persist = decoder_persist_applicable(d, &ns_, &ch_);
+  const bool persist = !out_mask && decoder_persist_applicable(d, &ns_, &ch_);      // (the forward pass took the same decision)
   const bool b6s = persist && decoder_persist_b6_split(d);
   if (do_chain) {
   // transposed weights for the data-path products (dY W as row-panel NT products)
@@ -436,8 +482,8 @@ int astk_decoder_bwd_phase(const astk_decoder_desc* d, const astk_decoder_params
     TransposeJobs tj;
     tj.n = 0;
     transpose_add(tj, P.WoT, Vp, prm->Wo, A, V, A);          // (V,A) -> (A,Vp)
-    transpose_add(tj, P.WcT, A, prm->Wc, 2 * H, A, 2 * H);   // (A,2H) -> (2H,A)
-    transpose_add(tj, P.WaT, H, prm->Wa, H, H, H);
+    transpose_add(tj, P.WcT, A, prm->Wc, CW, A, CW);         // (A,CW) -> (CW,A)
+    for (int k = 0; k < NA; ++k) transpose_add(tj, P.WaT + (size_t)k * H * H, H, k == 0 ? prm->Wa : prm->Wa_x[k - 1], H, H, H);
     for (int l = 0; l < nl; ++l) {
       const int in = l == 0 ? XI : H;
       if (tj.n + 2 > FILL_SEG_MAX) { ASTK_TRY(transpose_batch(tj, s)); tj.n = 0; }
@@ -464,24 +510,36 @@ int astk_decoder_bwd_phase(const astk_decoder_desc* d, const astk_decoder_params
     // d_pre = (dlogits Wo + d_ht carried from step st+1 through input feeding) * (1 - ht^2)
     {
       RowGemmArgs a = rg(B, A, dl, Vp, P.WoT, Vp, Vp, dpre, A);
-      if (!last) { a.addend = P.DX0 + (size_t)(st + 1) * B * XI + E; a.ld_add = XI; }
+      if (P.feed && !last) { a.addend = P.DX0 + (size_t)(st + 1) * B * XI + E; a.ld_add = XI; }
       a.act = ACT_DTANH;
       a.aux = P.HT + (size_t)(st + 1) * B * A;
       a.ld_aux = A;
       ASTK_TRY(rowgemm_launch(a, s));
     }
-    float* dcvh = P.DCVH + (size_t)st * B * 2 * H;
-    ASTK_TRY(rowgemm_launch(rg(B, 2 * H, dpre, A, P.WcT, A, A, dcvh, 2 * H), s));
-    float* cvh = P.CVH + (size_t)st * B * 2 * H;
-    float* dq = P.DQ + (size_t)st * bh;
-    ASTK_TRY(attn_bwd_launch(B, T, H, enc, P.ALPHA + (size_t)st * B * Tp, cvh, 2 * H, dcvh, 2 * H, P.DS + (size_t)st * B * Tp, dq,
-                             P.attn_ws, s));
-    // gradient wrt the dropped top-layer output: dh_top = dcvh[:, H:] + dq Wa
+    float* dcvh = P.DCVH + (size_t)st * B * CW;
+    ASTK_TRY(rowgemm_launch(rg(B, CW, dpre, A, P.WcT, A, A, dcvh, CW), s));
+    float* cvh = P.CVH + (size_t)st * B * CW;
+    for (int k = 0; k < NA; ++k)
+      ASTK_TRY(attn_bwd_launch(B, T, H, enc, P.ALPHA + ((size_t)k * S + st) * B * Tp, cvh + (size_t)k * H, CW, dcvh + (size_t)k * H, CW,
+                               P.DS + ((size_t)k * S + st) * B * Tp, P.DQ + ((size_t)k * S + st) * bh, P.attn_ws, s));
+    // gradient wrt the top layer's output: dh_top = dcvh[:, NA*H:] + sum_k dq_k Wa_k   (two heads per row-panel launch)
     {
-      RowGemmArgs a = rg(B, H, dq, H, P.WaT, H, H, P.DHTOP, H);
-      a.addend = dcvh + H;
-      a.ld_add = 2 * H;
-      ASTK_TRY(rowgemm_launch(a, s));
+      const float* add = dcvh + (size_t)NA * H;
+      long ld_add = CW;
+      float* outb = P.DHTOP;
+      for (int k = 0; k < NA; k += 2) {
+        RowGemmArgs a = rg(B, H, P.DQ + ((size_t)k * S + st) * bh, H, P.WaT + (size_t)k * H * H, H, H, outb, H);
+        if (k + 1 < NA) {
+          a.npairs = 2;
+          a.p[1].A = P.DQ + ((size_t)(k + 1) * S + st) * bh; a.p[1].lda = H; a.p[1].W = P.WaT + (size_t)(k + 1) * H * H; a.p[1].ldw = H; a.p[1].K = H;
+        }
+        a.addend = add;
+        a.ld_add = ld_add;
+        ASTK_TRY(rowgemm_launch(a, s));
+        add = outb; ld_add = H;
+        outb = outb == P.DHTOP ? P.DLN2 : P.DHTOP;       // (a launch never adds into the buffer it reads)
+      }
+      if (add != P.DHTOP) ASTK_TRY(copy_f32(P.DHTOP, add, bh, s));
     }
     for (int l = top; l >= 0; --l) {
       LstmCellBwdArgs c;
@@ -489,7 +547,18 @@ int astk_decoder_bwd_phase(const astk_decoder_desc* d, const astk_decoder_params
       c.npairs = 1;
       c.p[0].A = last ? nullptr : P.G[l] + (size_t)(st + 1) * B * 4 * H;
       c.p[0].lda = 4 * H; c.p[0].W = P.WlT[l]; c.p[0].ldw = 4 * H; c.p[0].K = last ? 0 : 4 * H;
-      if (l < top) {   // gradient from the layer above at the same step: dz_{l+1,st} Wu_{l+1}
+      if (P.ln) {
+        // gradient wrt the LayerNorm's output (top: dh_top; below: dz_{l+1,st} Wu_{l+1}) -> through the LayerNorm -> the cell's dropped output
+        const float* dout = P.DHTOP;
+        if (l < top) {
+          ASTK_TRY(rowgemm_launch(rg(B, H, P.G[l + 1] + (size_t)st * B * 4 * H, 4 * H, P.WuT[l + 1], 4 * H, 4 * H, P.DLN, H), s));
+          dout = P.DLN;
+        }
+        ASTK_TRY(layernorm_bwd_launch(B, H, P.HDL[l] + (size_t)st * bh, H, prm->ln_gamma[l], LN_EPS, dout, H, P.DLN2, H, g->d_ln_gamma[l],
+                                      g->d_ln_beta[l], s));
+        c.dy = P.DLN2;
+        c.ld_dy = H;
+      } else if (l < top) {   // gradient from the layer above at the same step: dz_{l+1,st} Wu_{l+1}
         c.npairs = 2;
         c.p[1].A = P.G[l + 1] + (size_t)st * B * 4 * H;
         c.p[1].lda = 4 * H; c.p[1].W = P.WuT[l + 1]; c.p[1].ldw = 4 * H; c.p[1].K = 4 * H;
@@ -507,7 +576,7 @@ int astk_decoder_bwd_phase(const astk_decoder_desc* d, const astk_decoder_params
       c.dc_prev = P.DC[l][st & 1];
       ASTK_TRY(lstm_cell_bwd_launch(&c, 1, s));
     }
-    // gradient wrt the concat input [emb ; ht_{st-1}]
+    // gradient wrt the layer-0 input [emb ; ht_{st-1}] (or the embedding alone)
     ASTK_TRY(rowgemm_launch(rg(B, XI, P.G[0] + (size_t)st * B * 4 * H, 4 * H, P.WuT[0], 4 * H, 4 * H, P.DX0 + (size_t)st * B * XI, XI), s));
   }
   // ---- gradients wrt the initial states (flow into the encoder's final states, seq2seq.py:326-329)
@@ -515,12 +584,13 @@ int astk_decoder_bwd_phase(const astk_decoder_desc* d, const astk_decoder_params
     ASTK_TRY(rowgemm_launch(rg(B, H, P.G[l], 4 * H, P.WlT[l], 4 * H, 4 * H, d_h0 + l * bh, H), s));
     if (!persist) ASTK_TRY(copy_f32(d_c0 + l * bh, P.DC[l][0], bh, s));
   }
-  // ---- d_enc[b] = alpha_b^T d_cv_b + ds_b^T q_b   (batched over b, K = S)
-  {
-    GemmArgs ga = gemm_args(T, H, S, mat(P.ALPHA, (long)B * Tp), mat(P.DCVH, (long)B * 2 * H), d_enc, H);
-    ga.batch = B; ga.sA = Tp; ga.sB = 2 * H; ga.sC = (long)T * H;
+  // ---- d_enc[b] = sum_k alpha_k,b^T d_cv_k,b + ds_k,b^T q_k,b   (batched over b, K = S)
+  for (int k = 0; k < NA; ++k) {
+    GemmArgs ga = gemm_args(T, H, S, mat(P.ALPHA + (size_t)k * S * B * Tp, (long)B * Tp), mat(P.DCVH + (size_t)k * H, (long)B * CW), d_enc, H, nullptr,
+                            k == 0 ? GEMM_STORE : GEMM_ACCUM);
+    ga.batch = B; ga.sA = Tp; ga.sB = CW; ga.sC = (long)T * H;
     ASTK_TRY(gemm_launch(GEMM_TN, ga, s));
-    GemmArgs gb = gemm_args(T, H, S, mat(P.DS, (long)B * Tp), mat(P.Q, (long)B * H), d_enc, H, nullptr, GEMM_ACCUM);
+    GemmArgs gb = gemm_args(T, H, S, mat(P.DS + (size_t)k * S * B * Tp, (long)B * Tp), mat(P.Q + (size_t)k * S * bh, (long)B * H), d_enc, H, nullptr, GEMM_ACCUM);
     gb.batch = B; gb.sA = Tp; gb.sB = H; gb.sC = (long)T * H;
     ASTK_TRY(gemm_launch(GEMM_TN, gb, s));
   }
@@ -543,16 +613,21 @@ int astk_decoder_bwd_phase(const astk_decoder_desc* d, const astk_decoder_params
   ColsumBatch cb;   // the bias gradients: one launch
   ASTK_TRY(wb.add(g->dWo, A, V, A, P.LOGITS, Vp, P.HT + (size_t)B * A, A, SB, s));
   ASTK_TRY(cb.add(g->dbo, P.LOGITS, Vp, SB, V, s));
-  ASTK_TRY(wb.add(g->dWc, 2 * H, A, 2 * H, P.DPRE, A, P.CVH, 2 * H, SB, s));
+  ASTK_TRY(wb.add(g->dWc, CW, A, CW, P.DPRE, A, P.CVH, CW, SB, s));
   ASTK_TRY(cb.add(g->dbc, P.DPRE, A, SB, A, s));
-  ASTK_TRY(wb.add(g->dWa, H, H, H, P.DQ, H, P.CVH + H, 2 * H, SB, s));
-  ASTK_TRY(cb.add(g->dba, P.DQ, H, SB, H, s));
+  for (int k = 0; k < NA; ++k) {
+    float* dWa = k == 0 ? g->dWa : g->dWa_x[k - 1];
+    float* dba = k == 0 ? g->dba : g->dba_x[k - 1];
+    ASTK_CHECK(dWa && dba, "decoder_bwd: attention head %d has no gradient buffers", k);
+    ASTK_TRY(wb.add(dWa, H, H, H, P.DQ + (size_t)k * S * bh, H, P.CVH + (size_t)NA * H, CW, SB, s));
+    ASTK_TRY(cb.add(dba, P.DQ + (size_t)k * S * bh, H, SB, H, s));
+  }
   for (int l = 0; l < nl; ++l) {
     const int in = l == 0 ? XI : H;
     const float* xin;
     long ldx;
     if (l == 0) { xin = P.X0; ldx = XI; }
-    else if (rnn_masks) { xin = P.HD[l - 1]; ldx = H; }
+    else if (rnn_masks || P.ln) { xin = P.HD[l - 1]; ldx = H; }       // (with LayerNorm the layer's input is always the normalised copy)
     else { xin = P.HR[l - 1] + bh; ldx = H; }
     ASTK_TRY(wb.add(g->lstm[l].dWu, in, 4 * H, in, P.G[l], 4 * H, xin, ldx, SB, s));
     ASTK_TRY(wb.add(g->lstm[l].dWl, H, 4 * H, H, P.G[l], 4 * H, P.HR[l], H, SB, s));
@@ -573,36 +648,41 @@ int astk_decoder_step_infer(const astk_decoder_desc* d, const astk_decoder_param
   ASTK_TRY(make_plan(d, ws, P));
   ASTK_CHECK(ws && ws_bytes >= P.bytes, "decoder_step_infer: workspace too small");
   ASTK_CHECK(prm && enc && c && h && ht && tokens && logits, "decoder_step_infer: null pointer");
-  const int B = P.B, H = P.H, E = P.E, A = P.A, V = P.V, XI = P.XI, nl = P.nl;
+  const int B = P.B, H = P.H, E = P.E, A = P.A, V = P.V, XI = P.XI, nl = P.nl, NA = P.NA, CW = P.CW;
   const size_t bh = (size_t)B * H;
   float* x0 = P.X0;
   ASTK_TRY(attn_ws_init(P.attn_ws, B, P.T, H, s));
   hipLaunchKernelGGL(k_embed, dim3(B), dim3(128), 0, s, prm->embed, (const int32_t*)nullptr, 0, 0, (const int32_t*)nullptr,
                      (const int32_t*)nullptr, tokens, (int32_t*)nullptr, (const float*)nullptr, x0, B, E, XI, V);
   ASTK_LAUNCH_CHECK();
-  ASTK_TRY(copy2d_f32(x0 + E, XI, ht, A, B, A, A, s));
+  if (P.feed) ASTK_TRY(copy2d_f32(x0 + E, XI, ht, A, B, A, A, s));
   float* cvh = P.CVH;
+  float* htop = cvh + (size_t)NA * H;
   const float* x_in = x0;
   long ld_x = XI;
   int in = XI;
   for (int l = 0; l < nl; ++l) {
-    float* hd = l == nl - 1 ? cvh + H : P.HD[l];
-    const long ld_hd = l == nl - 1 ? 2 * H : H;
+    float* hd = l == nl - 1 ? htop : P.HD[l];
+    const long ld_hd = l == nl - 1 ? CW : H;
+    float* raw = P.ln ? P.HDL[l] : hd;          // ln: the cell's output goes through the LayerNorm first
     // new states go to scratch first (the cell reads h_prev while other workgroups write h_out)
-    ASTK_TRY(cell_fwd(P, prm, l, x_in, ld_x, in, h + l * bh, c + l * bh, P.G[l], P.C[l], P.HR[l], nullptr, hd, ld_hd, s));
+    ASTK_TRY(cell_fwd(P, prm, l, x_in, ld_x, in, h + l * bh, c + l * bh, P.G[l], P.C[l], P.HR[l], nullptr, raw, P.ln ? H : ld_hd, s));
+    if (P.ln) ASTK_TRY(layernorm_fwd_launch(B, H, raw, H, prm->ln_gamma[l], prm->ln_beta[l], LN_EPS, hd, ld_hd, s));
     ASTK_TRY(copy_f32(c + l * bh, P.C[l], bh, s));
     ASTK_TRY(copy_f32(h + l * bh, P.HR[l], bh, s));
     x_in = hd; ld_x = ld_hd; in = H;
   }
-  {
-    RowGemmArgs a = rg(B, H, cvh + H, 2 * H, prm->Wa, H, H, P.Q, H);
-    a.bias = prm->ba;
+  for (int k = 0; k < NA; ++k) {
+    float* q = P.Q + (size_t)k * bh;
+    RowGemmArgs a = rg(B, H, htop, CW, k == 0 ? prm->Wa : prm->Wa_x[k - 1], H, H, q, H);
+    a.bias = k == 0 ? prm->ba : prm->ba_x[k - 1];
     ASTK_TRY(rowgemm_launch(a, s));
+    // (the alphas handed back are the FIRST head's, seq2seq.py:379-383)
+    ASTK_TRY(attn_fwd_launch(B, P.T, H, enc, q, H, k == 0 ? P.ALPHA : P.DS, cvh + (size_t)k * H, CW, nullptr, 0, P.attn_ws, s));
   }
-  ASTK_TRY(attn_fwd_launch(B, P.T, H, enc, P.Q, H, P.ALPHA, cvh, 2 * H, nullptr, 0, P.attn_ws, s));
   if (alpha) ASTK_TRY(copy2d_f32(alpha, P.T, P.ALPHA, P.Tp, B, P.T, P.T, s));
   {
-    RowGemmArgs a = rg(B, A, cvh, 2 * H, prm->Wc, 2 * H, 2 * H, ht, A);
+    RowGemmArgs a = rg(B, A, cvh, CW, prm->Wc, CW, CW, ht, A);
     a.bias = prm->bc;
     a.act = ACT_TANH;
     ASTK_TRY(rowgemm_launch(a, s));

@@ -53,6 +53,7 @@ struct PDecArgs {
   const float* enc;
   const float* encA;       // enc . Wa  (B,T,H): score = encA.h + enc.ba
   const int32_t* y;
+  const int32_t* ytgt;     // (B,L) class ids scored by the CE role (column s+1): y, or forward_loss's random_out replacements
   const int32_t* use_truth;
   const float* emb_mask;   // [S][B][E] or null
   const float* rnn_mask[PDEC_MAX_LAYERS];   // [S][B][H] per layer, or null
@@ -870,7 +871,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       float se = ok ? expf(x - mx) : 0.f;
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o);
-      const int tgt = row < B ? a.y[(long)row * a.L + s + 1] : 0;
+      const int tgt = row < B ? a.ytgt[(long)row * a.L + s + 1] : 0;
       float xt = (ok && n == tgt) ? x : 0.f;
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) xt += __shfl_xor(xt, o);
@@ -911,7 +912,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       }
       if (sub == 0 && row < B) {
         const float lse = mx + logf(se);
-        const int tgt = a.y[(long)row * a.L + s + 1];
+        const int tgt = a.ytgt[(long)row * a.L + s + 1];
         const float w = a.cw ? a.cw[tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt)] : 1.f;
         a.LSE[(long)s * B + row] = lse;
         a.LOSSROWS[(long)s * B + row] = -(xt - lse) * w / (float)B;
@@ -1534,6 +1535,7 @@ static size_t pdec_bwd_lds_floats(int chunk, int H) {
 bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int* chunk_out) {
   const char* e = getenv("ASTK_DEC_PERSIST");
   if (e && e[0] == '0') return false;
+  if (d->n_attn > 1 || d->no_feed_attn || d->ln) return false;      // optional model features: per-launch loop (decoder.hip)
   if (d->n_layers < 1 || d->n_layers > PDEC_MAX_LAYERS) return false;
   if (device_cu_count() < G) return false;        // fixed roles over G workgroups, all of them resident (one per CU)
   if ((d->H % 64) || (d->A % 16) || (d->E % 16) || d->A < 16 || d->E < 16) return false;
@@ -1656,7 +1658,7 @@ int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, con
 }
 
 int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_params* prm, const float* enc, const int32_t* y,
-                               const int32_t* use_truth, const float* emb_mask, const float* rnn_masks, const DecPersistBuffers& bf,
+                               const int32_t* ytgt, const int32_t* use_truth, const float* emb_mask, const float* rnn_masks, const DecPersistBuffers& bf,
                                float* loss, int32_t* pred_out, hipStream_t s) {
   int nsplit = 1, chunk = 1;
   // encA = enc . Wa (one batched GEMM): the score of decoder step s is encA[b,t,:].h_s + enc[b,t,:].ba, so the per-step
@@ -1675,7 +1677,7 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
     a.rnn_mask[l] = rnn_masks ? rnn_masks + (size_t)l * (d->L - 1) * d->B * d->H : nullptr;
   }
   a.Wa = prm->Wa; a.ba = prm->ba; a.Wc = prm->Wc; a.bc = prm->bc; a.Wo = prm->Wo; a.bo = prm->bo; a.cw = prm->class_weight;
-  a.enc = enc; a.encA = bf.ENCA; a.y = y; a.use_truth = use_truth; a.emb_mask = emb_mask;
+  a.enc = enc; a.encA = bf.ENCA; a.y = y; a.ytgt = ytgt ? ytgt : y; a.use_truth = use_truth; a.emb_mask = emb_mask;
   a.TOK = bf.TOK; a.PRED = bf.PRED; a.X0 = bf.X0; a.Q = bf.Q; a.ALPHA = bf.ALPHA;
   a.CVH = bf.CVH; a.HT = bf.HT; a.LOGITS = bf.LOGITS; a.LOSSROWS = bf.LOSSROWS; a.LSE = bf.LSE; a.PART = bf.PART; a.CESTAT = bf.CESTAT; a.ML = bf.ML;
   a.ctr = bf.ctr;

@@ -553,6 +553,15 @@ int astk_scale_f32(float* x, size_t n, float s, void* stream) {
   return 0;
 }
 
+int astk_add_f32(float* dst, const float* src, size_t n, void* stream) {
+  ASTK_CHECK(dst && src, "add: null pointer");
+  return n ? axpy_rows(dst, src, n, (hipStream_t)stream) : 0;
+}
+int astk_colsum_add_f32(float* dst, const float* src, long lds, int rows, int cols, void* stream) {
+  ASTK_CHECK(dst && src && rows > 0 && cols > 0 && lds >= cols, "colsum_add: bad arguments");
+  return colsum_add_f32(dst, src, lds, rows, cols, (hipStream_t)stream);
+}
+
 int astk_gemm_f32(int layout, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                   const float* bias, int mode, int ksplit, int batch, long sA, long sB, long sC, void* stream) {
   GemmArgs g = gemm_args(M, N, K, mat(A, lda), mat(B, ldb), C, ldc, bias, mode, ksplit);

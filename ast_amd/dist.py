@@ -113,7 +113,9 @@ def make_grad_buckets(model):
     groups = {"cnn": [], "enc": [], "dec": []}
     for name in model.arena.shapes:
         link = name.split("/")[0]
-        groups["cnn" if link.startswith("CNN_") else "enc" if link.endswith("_enc") else "dec"].append(name)
+        # (L{i}_enc / L{i}_rev_enc, their _ln links and the enc_proj{i} links of the optional encoder variants are encoder parameters)
+        is_enc = link.endswith(("_enc", "_enc_ln")) or link.startswith("enc_proj")
+        groups["cnn" if link.startswith("CNN_") else "enc" if is_enc else "dec"].append(name)
     return GradBuckets(model.arena, groups, defer_scale=True)
 
 

@@ -29,30 +29,49 @@ def param_shapes(cfg, in_dim, vocab_size=None):
             train[f"CNN_{i}_bn/beta"] = (co,)
             persist[f"CNN_{i}_bn/avg_mean"] = (co,)
             persist[f"CNN_{i}_bn/avg_var"] = (co,)
+        else:
+            train[f"CNN_{i}/b"] = (co,)                     # nobias=self.cnn_bn (seq2seq.py:52-54)
         fdim = conv_out(fdim, kw, l["stride"][1], l["pad"][1])
         cin = co
     rnn_in = cin * fdim
     Hh = rc["hidden_units"] // 2 if rc["bi_rnn"] else rc["hidden_units"]
+    ln, proj = bool(rc.get("ln", False)), bool(rc.get("linear_proj", False))
+
+    def lstm(n, n_in, n_out):
+        train[f"{n}/upward/W"] = (4 * n_out, n_in)
+        train[f"{n}/upward/b"] = (4 * n_out,)
+        train[f"{n}/lateral/W"] = (4 * n_out, n_out)
+        if ln:                                              # L.LayerNormalization(units) behind the LSTM (seq2seq.py:85-87, 141-143)
+            train[f"{n}_ln/gamma"] = (n_out,)
+            train[f"{n}_ln/beta"] = (n_out,)
     for pat in ["L{}_enc"] + (["L{}_rev_enc"] if rc["bi_rnn"] else []):
         n_in = rnn_in
         for i in range(rc["enc_layers"]):
-            n = pat.format(i)
-            train[f"{n}/upward/W"] = (4 * Hh, n_in)
-            train[f"{n}/upward/b"] = (4 * Hh,)
-            train[f"{n}/lateral/W"] = (4 * Hh, Hh)
-            n_in = Hh
+            lstm(pat.format(i), n_in, Hh)
+            # the lazily-shaped L.LSTM(None, units) takes the width of what it is first fed: the layer below (units per direction), or
+            # -- with linear_proj -- the projection of the concatenated states (hidden_units), seq2seq.py:250-286
+            n_in = rc["hidden_units"] if proj else Hh
     H, E, A = rc["hidden_units"], rc["embedding_units"], rc["attn_units"]
+    if proj:                                                # seq2seq.py:89-99
+        for i in range(rc["enc_layers"] - 1):
+            train[f"enc_proj{i}/W"] = (H, H)
+            train[f"enc_proj{i}/b"] = (H,)
+            train[f"enc_proj{i}_bn/gamma"] = (H,)
+            train[f"enc_proj{i}_bn/beta"] = (H,)
+            persist[f"enc_proj{i}_bn/avg_mean"] = (H,)
+            persist[f"enc_proj{i}_bn/avg_var"] = (H,)
     n_attn = rc.get("n_attn", 1)
     train["attn_Wa/W"] = (H, H)
     train["attn_Wa/b"] = (H,)
+    for i in range(1, n_attn):                              # seq2seq.py:114-116
+        train[f"attn_Wa{i}/W"] = (H, H)
+        train[f"attn_Wa{i}/b"] = (H,)
     train["context/W"] = (A, (n_attn + 1) * H)
     train["context/b"] = (A,)
     train["embed_dec/W"] = (V, E)
     n_in = E + A if rc.get("feed_attn", True) else E
     for i in range(rc["dec_layers"]):
-        train[f"L{i}_dec/upward/W"] = (4 * H, n_in)
-        train[f"L{i}_dec/upward/b"] = (4 * H,)
-        train[f"L{i}_dec/lateral/W"] = (4 * H, H)
+        lstm(f"L{i}_dec", n_in, H)
         n_in = H
     train["out/W"] = (V, A)
     train["out/b"] = (V,)

@@ -157,11 +157,14 @@ class SpeechEncoderDecoder:
         self.gpuid = gpuid
         self.cfg = cfg
         rc, cc = cfg["rnn_config"], cfg["cnn_config"]
-        if rc.get("ln", False) or rc.get("linear_proj", False) or rc.get("n_attn", 1) != 1 or not rc.get("feed_attn", True):
-            raise NotImplementedError("ln / linear_proj / n_attn>1 / feed_attn=False are outside the MI355X hot path "
-                                      "(SURVEY.md 8f rank 4); the shipped experiments do not use them")
-        if not cc["bn"]:
-            raise NotImplementedError("cnn_config.bn=false is not part of the shipped configs")
+        # Optional features of the reference's model (seq2seq.py:43-57, 81-121, 244-291, 369-394; none is set by a shipped config).
+        # They run on per-launch kernels / layer-by-layer stacks instead of the persistent kernels of the default model: `paths()` says so.
+        self.rnn_ln = bool(rc.get("ln", False))
+        self.rnn_linear_proj = bool(rc.get("linear_proj", False))
+        self.feed_attn = bool(rc.get("feed_attn", True))
+        n_attn = int(rc.get("n_attn", 1))
+        if not 1 <= n_attn <= _lib.MAX_ATTN:
+            raise ValueError(f"rnn_config.n_attn = {n_attn}: 1..{_lib.MAX_ATTN} attention heads are supported")
         if not rc["bi_rnn"]:
             self.n_dirs = 1
         else:
@@ -172,7 +175,9 @@ class SpeechEncoderDecoder:
         self.rnn_rev_enc = [f"L{i}_rev_enc" for i in range(rc["enc_layers"])] if rc["bi_rnn"] else []
         self.rnn_dec = [f"L{i}_dec" for i in range(rc["dec_layers"])]
         self.bi_rnn = rc["bi_rnn"]
-        self.n_attn = 1
+        self.n_attn = n_attn
+        self.enc_variant = None         # ast_amd.enc_variants.LayerNormEncoder / LinearProjEncoder (set in materialize)
+        self.proj_bn_N = [0] * max(0, rc["enc_layers"] - 1)     # BatchNormalization N of the enc_proj{i}_bn links (one call per time step)
         self.h = rc["hidden_units"] // 2 if rc["bi_rnn"] else rc["hidden_units"]
         self.H, self.E, self.A = rc["hidden_units"], rc["embedding_units"], rc["attn_units"]
         self.V = rc.get("dec_vocab_size")
@@ -217,7 +222,24 @@ class SpeechEncoderDecoder:
         w[0] = 0                                             # seq2seq.py:152-156
         self.mask_pad_id = w.to(self.device)
         self._shape_cache.clear()
+        if self.rnn_linear_proj:                             # (seq2seq.py:311-314: linear_proj takes precedence; that path has no LayerNorm)
+            from .enc_variants import LinearProjEncoder
+            self.enc_variant = LinearProjEncoder(self)
+        elif self.rnn_ln:
+            from .enc_variants import LayerNormEncoder
+            self.enc_variant = LayerNormEncoder(self)
         return self
+
+    def paths(self):
+        """Which kernels this model's train step takes (bench.py / logs): the optional features leave the persistent kernels."""
+        opts = [n for n, on in (("ln", self.rnn_ln), ("linear_proj", self.rnn_linear_proj), (f"n_attn={self.n_attn}", self.n_attn > 1),
+                                ("feed_attn=false", not self.feed_attn), ("cnn bn=false", not self.cnn_bn),
+                                ("dropout.out", bool(self.cfg["dropout"].get("out", 0)))) if on]
+        return {"options": opts,
+                "encoder": "layer-by-layer one-layer stacks + " + ("Linear/BatchNorm/ReLU projections" if self.rnn_linear_proj else "LayerNorm kernels")
+                if self.enc_variant is not None else "one stack call (persistent wavefront kernels when the shape fits)",
+                "decoder": "per-launch loop (optional features)" if (self.rnn_ln or self.n_attn > 1 or not self.feed_attn or self.cfg["dropout"].get("out", 0))
+                else "persistent loop when the shape fits"}
 
     def to_gpu(self, gpuid=None):
         if gpuid is not None and gpuid != self.gpuid:
@@ -302,6 +324,7 @@ class SpeechEncoderDecoder:
             if l["pad"][1] != 0 or l.get("dilate", 1) != 1:
                 raise NotImplementedError("frequency padding / dilation are not used by the shipped configs")
         cd.bn_eps, cd.bn_decay = 2e-5, 0.9
+        cd.no_bn = 0 if self.cnn_bn else 1
         t2, f2, feat = C.c_int(), C.c_int(), C.c_int()
         check(lib.astk_conv_bn_relu_out_dims(C.byref(cd), C.byref(t2), C.byref(f2), C.byref(feat)))
         T2, feat = t2.value, feat.value
@@ -314,10 +337,14 @@ class SpeechEncoderDecoder:
         cg = (CnnLayerGrads * len(cc))()
         for i in range(len(cc)):
             n = f"CNN_{i}"
-            cp[i].W, cp[i].gamma, cp[i].beta = a.p(n + "/W"), a.p(n + "_bn/gamma"), a.p(n + "_bn/beta")
-            cp[i].avg_mean = self.persist[n + "_bn/avg_mean"].data_ptr()
-            cp[i].avg_var = self.persist[n + "_bn/avg_var"].data_ptr()
-            cg[i].dW, cg[i].dgamma, cg[i].dbeta = a.g(n + "/W"), a.g(n + "_bn/gamma"), a.g(n + "_bn/beta")
+            cp[i].W, cg[i].dW = a.p(n + "/W"), a.g(n + "/W")
+            if self.cnn_bn:
+                cp[i].gamma, cp[i].beta = a.p(n + "_bn/gamma"), a.p(n + "_bn/beta")
+                cp[i].avg_mean = self.persist[n + "_bn/avg_mean"].data_ptr()
+                cp[i].avg_var = self.persist[n + "_bn/avg_var"].data_ptr()
+                cg[i].dgamma, cg[i].dbeta = a.g(n + "_bn/gamma"), a.g(n + "_bn/beta")
+            else:                                            # Convolution2D with bias, no BatchNormalization (seq2seq.py:52-57)
+                cp[i].bias, cg[i].dbias = a.p(n + "/b"), a.g(n + "/b")
         nl, nd, h, H = len(self.rnn_enc), self.n_dirs, self.h, self.H
         ld = LstmStackDesc(T2, B, feat, h, nl, nd)
         lp = (LstmParams * (nl * nd))()
@@ -328,12 +355,18 @@ class SpeechEncoderDecoder:
                 lp[k].Wu, lp[k].b, lp[k].Wl = a.p(n + "/upward/W"), a.p(n + "/upward/b"), a.p(n + "/lateral/W")
                 lg[k].dWu, lg[k].db, lg[k].dWl = a.g(n + "/upward/W"), a.g(n + "/upward/b"), a.g(n + "/lateral/W")
         nld = len(self.rnn_dec)
-        dd = DecoderDesc(B, max(L, 2), T2, H, self.E, self.A, self.V, nld)
+        dd = DecoderDesc(B, max(L, 2), T2, H, self.E, self.A, self.V, nld, self.n_attn, 0 if self.feed_attn else 1, 1 if self.rnn_ln else 0)
         dp, dg = DecoderParams(), DecoderGrads()
         dp.embed, dg.d_embed = a.p("embed_dec/W"), a.g("embed_dec/W")
         for l, n in enumerate(self.rnn_dec):
             dp.lstm[l].Wu, dp.lstm[l].b, dp.lstm[l].Wl = a.p(n + "/upward/W"), a.p(n + "/upward/b"), a.p(n + "/lateral/W")
             dg.lstm[l].dWu, dg.lstm[l].db, dg.lstm[l].dWl = a.g(n + "/upward/W"), a.g(n + "/upward/b"), a.g(n + "/lateral/W")
+            if self.rnn_ln:
+                dp.ln_gamma[l], dp.ln_beta[l] = a.p(n + "_ln/gamma"), a.p(n + "_ln/beta")
+                dg.d_ln_gamma[l], dg.d_ln_beta[l] = a.g(n + "_ln/gamma"), a.g(n + "_ln/beta")
+        for k in range(1, self.n_attn):
+            dp.Wa_x[k - 1], dp.ba_x[k - 1] = a.p(f"attn_Wa{k}/W"), a.p(f"attn_Wa{k}/b")
+            dg.dWa_x[k - 1], dg.dba_x[k - 1] = a.g(f"attn_Wa{k}/W"), a.g(f"attn_Wa{k}/b")
         dp.Wa, dp.ba, dp.Wc, dp.bc = a.p("attn_Wa/W"), a.p("attn_Wa/b"), a.p("context/W"), a.p("context/b")
         dp.Wo, dp.bo, dp.class_weight = a.p("out/W"), a.p("out/b"), self.mask_pad_id.data_ptr()
         dg.dWa, dg.dba, dg.dWc, dg.dbc = a.g("attn_Wa/W"), a.g("attn_Wa/b"), a.g("context/W"), a.g("context/b")
@@ -422,9 +455,15 @@ class SpeechEncoderDecoder:
         st["bn_world"] = 1 if sx is None else sx.world
         if config.train:
             self.bn_N += 1
-        wl = self._workspace("lstm", st["ws_lstm"])
-        check(lib.astk_lstm_stack_fwd(C.byref(st["ld"]), st["lp"], _vp(st["xlstm"]), _vp(st["enc_masks"]), _vp(st["enc_states"]),
-                                      _vp(st["cT"]), _vp(st["hT"]), _vp(wl), wl.numel(), s))
+        if self.enc_variant is not None:                     # rnn_config.ln / linear_proj: layer-by-layer (ast_amd/enc_variants.py)
+            if self.rnn_linear_proj:
+                self.enc_variant.forward(st, bool(config.train))
+            else:
+                self.enc_variant.forward(st)
+        else:
+            wl = self._workspace("lstm", st["ws_lstm"])
+            check(lib.astk_lstm_stack_fwd(C.byref(st["ld"]), st["lp"], _vp(st["xlstm"]), _vp(st["enc_masks"]), _vp(st["enc_states"]),
+                                          _vp(st["cT"]), _vp(st["hT"]), _vp(wl), wl.numel(), s))
         self.enc_states = st["enc_states"]
         self.loss = 0
 
@@ -525,18 +564,13 @@ class SpeechEncoderDecoder:
         ev.record(torch.cuda.current_stream(self.device))
 
     def forward_loss(self, X, y, teach_ratio, random_out=0, add_noise=0):
-        if random_out:
-            # seq2seq.py:457-465 replaces a target with xp.random.randint(4, dec_vocab_size + 1): the upper end is INCLUSIVE of
-            # dec_vocab_size, one past the last class, so Chainer's softmax_cross_entropy raises (NumPy) or reads out of bounds
-            # (CuPy) about once per thousand replacements -- the option cannot have been used as written; no shipped config sets it
-            raise NotImplementedError("random_out > 0 (quirk Q8): the reference draws replacement targets from [4, dec_vocab_size] inclusive, "
-                                      "an out-of-range class id; not part of the shipped configs")
         lib = self._require_gpu()
         X = self._as_input(X)
         if isinstance(y, np.ndarray):
             y = torch.from_numpy(y)
         if hasattr(y, "data") and not isinstance(y, torch.Tensor):
             y = y.data
+        y_host = y if (random_out and y.device.type == "cpu") else None
         y = y.to(self.device, torch.int32).contiguous()
         B, L = y.shape
         assert L >= 2, "targets need at least GO and EOS"
@@ -545,23 +579,41 @@ class SpeechEncoderDecoder:
         st = self._cur
         self.init_decoder_state()
         S = L - 1
-        # quirk Q4: one Python-`random` coin per step for 0 < i < L-2, truth otherwise (seq2seq.py:431-436)
+        # quirk Q4: one Python-`random` coin per step for 0 < i < L-2, truth otherwise (seq2seq.py:431-436).  With random_out > 0
+        # (seq2seq.py:456-465) the SAME stream also decides, behind each step's coin, which targets >= 4 are replaced (draw ABOVE
+        # random_out) by a class id from xp.random.randint(4, dec_vocab_size + 1).  That range is inclusive of dec_vocab_size, one past the
+        # last class (quirk Q8): Chainer's softmax_cross_entropy raises on it with NumPy and reads out of bounds with CuPy.  DEVIATION: the
+        # drawn id is clamped to dec_vocab_size - 1.  Nothing in a decoder step consumes either stream, so all draws are made here, in
+        # the reference's order, and the scored targets go to the device as a second (B, L) matrix.
+        targets = None
         if "use_truth" in self.inject:
             flags = [int(bool(v)) for v in self.inject["use_truth"]]
+            assert not random_out, "inject['use_truth'] bypasses the random stream random_out shares"
+        elif random_out:
+            yh = (y_host if y_host is not None else y.cpu()).numpy()
+            tg = yh.copy()
+            randint = self.inject.get("randint", np.random.randint)      # the reference's draw is the unseeded global xp RNG (quirk Q7)
+            flags = []
+            for i in range(S):
+                flags.append(int(random.random() < teach_ratio) if 0 < i < L - 2 else 1)
+                for b in range(B):
+                    if int(yh[b, i + 1]) >= 4 and random.random() > random_out:
+                        tg[b, i + 1] = min(int(randint(4, self.V + 1)), self.V - 1)
+            targets = torch.from_numpy(np.ascontiguousarray(tg, dtype=np.int32)).to(self.device)
         else:
             flags = [int(random.random() < teach_ratio) if 0 < i < L - 2 else 1 for i in range(S)]
         self.use_truth = flags
         self._upload_flags(st["flags"], flags)
         st["y"] = y
+        st["targets"] = targets
         dr = self.cfg["dropout"]
-        if dr.get("out", 0):
-            raise NotImplementedError("dropout.out > 0 is not used by the shipped configs")
         st["emb_mask"] = self._masks("emb_mask", (S, B, self.E), dr["embed"])
         st["rnn_masks"] = self._masks("rnn_masks", (len(self.rnn_dec), S, B, self.H), dr["rnn"])
+        st["out_mask"] = self._masks("out_mask", (S, B, self.V), dr.get("out", 0))       # dropout on the logits (seq2seq.py:394)
         wd = self._workspace("dec", st["ws_dec"])
-        check(lib.astk_decoder_fwd(C.byref(st["dd"]), C.byref(st["dp"]), _vp(st["enc_states"]), _vp(st["c0"]), _vp(st["h0"]),
-                                   _vp(y), _vp(st["flags"]), _vp(st["emb_mask"]), _vp(st["rnn_masks"]), _vp(st["loss"]),
-                                   _vp(st["pred"]), _vp(wd), wd.numel(), self._stream()))
+        check(lib.astk_decoder_fwd_ex(C.byref(st["dd"]), C.byref(st["dp"]), _vp(st["enc_states"]), _vp(st["c0"]), _vp(st["h0"]),
+                                      _vp(y), _vp(st["flags"]), _vp(st["emb_mask"]), _vp(st["rnn_masks"]), _vp(st["out_mask"]), _vp(targets),
+                                      _vp(st["loss"]), _vp(st["pred"]), _vp(wd), wd.numel(), self._stream()))
         check(lib.astk_persist_status_snapshot(C.c_void_p(st["loss"].data_ptr() + 4), self._stream()))
         self.loss = Loss(self, st["loss"])
         return self.loss
@@ -573,11 +625,11 @@ class SpeechEncoderDecoder:
         wd = self._workspace("dec", st["ws_dec"])
 
         def dec_bwd(phase, stream):
-            check(lib.astk_decoder_bwd_phase(C.byref(st["dd"]), C.byref(st["dp"]), C.byref(st["dg"]), _vp(st["enc_states"]), _vp(st["c0"]),
-                                             _vp(st["h0"]), _vp(st["y"]), _vp(st["emb_mask"]), _vp(st["rnn_masks"]), _vp(st["d_enc"]),
-                                             _vp(st["d_c0"]), _vp(st["d_h0"]), _vp(wd), wd.numel(), phase, stream))
+            check(lib.astk_decoder_bwd_phase_ex(C.byref(st["dd"]), C.byref(st["dp"]), C.byref(st["dg"]), _vp(st["enc_states"]), _vp(st["c0"]),
+                                                _vp(st["h0"]), _vp(st["y"]), _vp(st["emb_mask"]), _vp(st["rnn_masks"]), _vp(st["out_mask"]),
+                                                _vp(st["d_enc"]), _vp(st["d_c0"]), _vp(st["d_h0"]), _vp(wd), wd.numel(), phase, stream))
         joined, rec_stream = None, None
-        cu = self._cu_streams(st) if self.overlap_param_grads else None
+        cu = self._cu_streams(st) if (self.overlap_param_grads and self.enc_variant is None) else None
         if cu is not None:
             # The encoder's backward recurrence (1 ms; one workgroup on each of 192 CUs, one wave per SIMD) leaves the device mostly
             # idle and needs nothing from the decoder's parameter gradients (0.17 ms of GEMMs at full speed).  They run beside it:
@@ -605,9 +657,12 @@ class SpeechEncoderDecoder:
         for k in range(min(len(self.rnn_enc), len(self.rnn_dec))):
             st["d_cT"][:, k].copy_(st["d_c0"][k].view(-1, nd, h).permute(1, 0, 2))
             st["d_hT"][:, k].copy_(st["d_h0"][k].view(-1, nd, h).permute(1, 0, 2))
-        wl = self._workspace("lstm", st["ws_lstm"])
-        check(lib.astk_lstm_stack_bwd_on(C.byref(st["ld"]), st["lp"], st["lg"], _vp(st["xlstm"]), _vp(st["enc_masks"]), _vp(st["d_enc"]),
-                                         _vp(st["d_cT"]), _vp(st["d_hT"]), _vp(st["d_xlstm"]), _vp(wl), wl.numel(), s, rec_stream))
+        if self.enc_variant is not None:
+            self.enc_variant.backward(st, st["d_enc"], st["d_cT"], st["d_hT"], st["d_xlstm"])
+        else:
+            wl = self._workspace("lstm", st["ws_lstm"])
+            check(lib.astk_lstm_stack_bwd_on(C.byref(st["ld"]), st["lp"], st["lg"], _vp(st["xlstm"]), _vp(st["enc_masks"]), _vp(st["d_enc"]),
+                                             _vp(st["d_cT"]), _vp(st["d_hT"]), _vp(st["d_xlstm"]), _vp(wl), wl.numel(), s, rec_stream))
         if joined is not None:
             # the side stream finished long ago (0.5 ms of work beside a 1 ms kernel); from here on everything is on one stream again,
             # and the gradient exchange is launched from it

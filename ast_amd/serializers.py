@@ -7,9 +7,12 @@ def save_npz(path, model, optimizer=None):
     out = {k: v.detach().cpu().numpy() for k, v in model.arena.views.items()}
     for k, v in model.persist.items():
         out[k] = v.detach().cpu().numpy()
-    for i in range(len(model.cnns)):
+    for i in range(len(model.cnns) if model.cnn_bn else 0):
         # Chainer's BatchNormalization counts its training-mode calls in the persistent N (A10); every layer sees every train forward
         out[f"CNN_{i}_bn/N"] = np.asarray(int(model.bn_N), dtype=np.int64)
+    if getattr(model, "rnn_linear_proj", False):
+        for i, n in enumerate(model.proj_bn_N):              # the projection's BatchNormalization is called once per TIME STEP
+            out[f"enc_proj{i}_bn/N"] = np.asarray(int(n), dtype=np.int64)
     if optimizer is not None and getattr(optimizer, "m", None) is not None:
         # an extension over the reference (which never saves Adam state); Chainer's load_npz ignores extra keys
         out["__opt__/t"] = np.asarray(optimizer.t)
@@ -48,6 +51,9 @@ def load_npz(path, model, optimizer=None):
                 v.copy_(torch.from_numpy(np.asarray(z[k], dtype=np.float32)))
         if "CNN_0_bn/N" in keys:
             model.bn_N = int(z["CNN_0_bn/N"])
+        for i in range(len(getattr(model, "proj_bn_N", []))):
+            if f"enc_proj{i}_bn/N" in keys:
+                model.proj_bn_N[i] = int(z[f"enc_proj{i}_bn/N"])
         if optimizer is not None:
             _restore_optimizer(z, keys, model, optimizer)
 

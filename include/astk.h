@@ -23,9 +23,10 @@
 extern "C" {
 #endif
 
-#define ASTK_VERSION 100
+#define ASTK_VERSION 101
 #define ASTK_MAX_CNN_LAYERS 4
 #define ASTK_MAX_RNN_LAYERS 8
+#define ASTK_MAX_ATTN 4
 
 int astk_version(void);
 const char* astk_last_error(void);
@@ -64,7 +65,7 @@ int astk_get_gemm_precision(void);
 int astk_debug_set_amax_generation(unsigned gen);
 
 /* ---------------------------------------------------------------- CNN front-end  (seq2seq.py:158-180)
- * [Conv2D(no bias) -> BatchNorm(train: batch stats) -> ReLU] x n_layers, then the (T'',B,C*F') time-major
+ * [Conv2D(no bias) -> BatchNorm(train: batch stats) -> ReLU] x n_layers (or, with no_bn, [Conv2D(bias) -> ReLU]), then the (T'',B,C*F') time-major
  * re-layout with feature index c*F'+f (quirk Q9).  Layer 0: in_channels 1, kernel (kt,kf), stride (st,sf),
  * pad (pt,0).  Layers >= 1: kernel (kt,1), stride (st,1), pad (pt,0) -- the shipped cnn_config. */
 typedef struct {
@@ -76,6 +77,7 @@ typedef struct {
   int pt[ASTK_MAX_CNN_LAYERS];
   float bn_eps;    /* 2e-5  (Chainer-sem A4) */
   float bn_decay;  /* 0.9 */
+  int no_bn;       /* cnn_config.bn = false (seq2seq.py:43-57): Conv2D WITH bias -> ReLU, no BatchNorm; 0 = the shipped configs */
 } astk_cnn_desc;
 
 typedef struct {
@@ -84,12 +86,14 @@ typedef struct {
   const float* beta;   /* (C) */
   float* avg_mean;     /* (C) running stats, updated in train mode */
   float* avg_var;      /* (C) */
+  const float* bias;   /* (C) only with no_bn (gamma, beta, avg_* unused then) */
 } astk_cnn_layer_params;
 
 typedef struct {
   float* dW;
   float* dgamma;
   float* dbeta;
+  float* dbias;        /* only with no_bn */
 } astk_cnn_layer_grads;
 
 /* output dims: T_out = T'', F_out = F', feature dim = C_last*F' */
@@ -175,6 +179,11 @@ int astk_attn_step_bwd(int B, int T, int H, const float* enc, const float* alpha
  * with denominator B (quirk Q6), summed over the L-1 steps. */
 typedef struct {
   int B, L, T, H, E, A, V, n_layers;
+  /* optional features of the reference's model (rnn_config; zero = the shipped configs).  Any of them set routes the loop through
+   * the per-launch kernels (astk_decoder_path returns 0): the persistent loop is built for the shipped model only. */
+  int n_attn;        /* attention heads on the same decoder state (seq2seq.py:107-121, 381-383); 0 or 1 = one; context W is (A,(n_attn+1)H) */
+  int no_feed_attn;  /* rnn_config.feed_attn = false (seq2seq.py:369-374): the decoder LSTM input is the embedding alone (layer-0 in = E) */
+  int ln;            /* rnn_config.ln (seq2seq.py:141-143, 200-202): L.LayerNormalization(H) behind every decoder LSTM's dropped output */
 } astk_decoder_desc;
 
 typedef struct {
@@ -184,6 +193,10 @@ typedef struct {
   const float* Wc; const float* bc;           /* context (A,2H) */
   const float* Wo; const float* bo;           /* out     (V,A)  */
   const float* class_weight;                  /* (V) : mask_pad_id, seq2seq.py:152-156 */
+  const float* Wa_x[ASTK_MAX_ATTN - 1];       /* attn_Wa1.. (H,H) when n_attn > 1 */
+  const float* ba_x[ASTK_MAX_ATTN - 1];
+  const float* ln_gamma[ASTK_MAX_RNN_LAYERS]; /* L{i}_dec_ln (H) when ln */
+  const float* ln_beta[ASTK_MAX_RNN_LAYERS];
 } astk_decoder_params;
 
 typedef struct {
@@ -192,6 +205,10 @@ typedef struct {
   float* dWa; float* dba;
   float* dWc; float* dbc;
   float* dWo; float* dbo;
+  float* dWa_x[ASTK_MAX_ATTN - 1];
+  float* dba_x[ASTK_MAX_ATTN - 1];
+  float* d_ln_gamma[ASTK_MAX_RNN_LAYERS];
+  float* d_ln_beta[ASTK_MAX_RNN_LAYERS];
 } astk_decoder_grads;
 
 size_t astk_decoder_workspace_bytes(const astk_decoder_desc* d);
@@ -208,6 +225,16 @@ int astk_decoder_bwd(const astk_decoder_desc* d, const astk_decoder_params* p, c
                      const float* enc, const float* c0, const float* h0, const int32_t* y,
                      const float* emb_mask, const float* rnn_masks,
                      float* d_enc, float* d_c0, float* d_h0, void* ws, size_t ws_bytes, void* stream);
+/* The loop with the two per-call options of the reference's train step:
+ *   out_mask  NULL or (L-1,B,V) scaled keep-masks of dropout.out (seq2seq.py:394: dropout on the LOGITS; argmax feedback and the
+ *             loss both see the dropped logits);
+ *   targets   NULL or (B,L) int32: the class ids that are SCORED at step s (column s+1), when they differ from the tokens that are
+ *             FED (y): forward_loss's random_out replacement (seq2seq.py:456-465), drawn by the caller on the host.
+ * astk_decoder_fwd / astk_decoder_bwd_phase are these with both NULL. */
+int astk_decoder_fwd_ex(const astk_decoder_desc* d, const astk_decoder_params* p, const float* enc,
+                        const float* c0, const float* h0, const int32_t* y, const int32_t* use_truth,
+                        const float* emb_mask, const float* rnn_masks, const float* out_mask, const int32_t* targets,
+                        float* loss, int32_t* pred, void* ws, size_t ws_bytes, void* stream);
 /* The same backward in two phases, for callers that overlap them: ASTK_DEC_BWD_CHAIN runs the reversed loop and writes
  * everything the encoder's backward needs (d_enc, d_c0, d_h0); ASTK_DEC_BWD_PARAMS accumulates the parameter gradients from
  * what the chain phase left in `ws` -- it only has to be ordered after the chain phase (an event), so it can run on a second
@@ -218,11 +245,33 @@ int astk_decoder_bwd_phase(const astk_decoder_desc* d, const astk_decoder_params
                            const float* enc, const float* c0, const float* h0, const int32_t* y,
                            const float* emb_mask, const float* rnn_masks,
                            float* d_enc, float* d_c0, float* d_h0, void* ws, size_t ws_bytes, int phase, void* stream);
+int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_params* p, const astk_decoder_grads* g,
+                              const float* enc, const float* c0, const float* h0, const int32_t* y,
+                              const float* emb_mask, const float* rnn_masks, const float* out_mask,
+                              float* d_enc, float* d_c0, float* d_h0, void* ws, size_t ws_bytes, int phase, void* stream);
 /* eval-mode single step for predict()/beam (seq2seq.py:361-396 under train=False): states (n_layers,B,H)
  * and ht (B,A) are updated in place; logits (B,V) and alpha (B,T) written. */
 int astk_decoder_step_infer(const astk_decoder_desc* d, const astk_decoder_params* p, const float* enc,
                             float* c, float* h, float* ht, const int32_t* tokens, float* logits, float* alpha,
                             int32_t* argmax, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- normalisation layers of the optional encoder variants
+ * L.LayerNormalization(units) behind an LSTM (rnn_config.ln; seq2seq.py:85-87, 200-202): rows x n, row strides ld*, per-row mean and
+ * BIASED variance, y = (x - mu) / sqrt(var + eps) * gamma + beta (eps 1e-6, the link's default).  Backward recomputes the statistics
+ * from x; dgamma / dbeta are ACCUMULATED (NULL: skipped), dx written (NULL: skipped). */
+int astk_layernorm_fwd(int rows, int n, const float* x, long ldx, const float* gamma, const float* beta, float eps, float* y, long ldy,
+                       void* stream);
+int astk_layernorm_bwd(int rows, int n, const float* x, long ldx, const float* gamma, float eps, const float* dy, long lddy, float* dx,
+                       long lddx, float* dgamma, float* dbeta, void* stream);
+/* The projection between encoder layers of rnn_config.linear_proj (seq2seq.py:89-99, 280-286): out_t = relu(BN(z_t)) for every time
+ * step t, z (T,B,C) = the Linear's output (a GEMM of the caller).  The reference calls its BatchNormalization link once per step on
+ * a (B,C) matrix: batch statistics over the B rows OF THAT STEP, running averages advanced T times in step order (m = B samples).
+ * stats (T,2,C) receives every step's mean and biased variance (read by the backward); train = 0 uses the running statistics. */
+int astk_step_bn_relu_fwd(int T, int B, int C, const float* z, const float* gamma, const float* beta, float* avg_mean, float* avg_var,
+                          float eps, float decay, int train, float* out, float* stats, void* stream);
+/* dz written; dgamma / dbeta ACCUMULATED. */
+int astk_step_bn_relu_bwd(int T, int B, int C, const float* z, const float* stats, const float* gamma, float eps, const float* out,
+                          const float* d_out, float* dz, float* dgamma, float* dbeta, void* stream);
 
 /* ---------------------------------------------------------------- softmax cross-entropy  (seq2seq.py:468-470)
  * rows = B: loss_rows[b] = -w[t_b] log_softmax(x_b)[t_b] / B ; dlogits = w[t_b](softmax - onehot)/B written in
@@ -264,6 +313,10 @@ int astk_decay_clip_noise(float* g, const float* p, size_t n, float grad_scale, 
 /* out[i] = 1 + sigma*N(0,1): the multiplicative speech noise of seq2seq.py:300-302, generated on device. */
 int astk_fill_normal(float* out, size_t n, float mean, float sigma, uint64_t seed, uint64_t offset, void* stream);
 int astk_scale_f32(float* x, size_t n, float s, void* stream);
+/* dst += src (n floats); dst[c] += sum_r src[r*lds + c] (bias gradients; the sum over time of the linear_proj encoder's reverse-stack
+ * input gradient, whose input is one frame fed at every step). */
+int astk_add_f32(float* dst, const float* src, size_t n, void* stream);
+int astk_colsum_add_f32(float* dst, const float* src, long lds, int rows, int cols, void* stream);
 /* Frame zeroing of the training loader (dataloader.py:83-93, `zero_input`), on the padded device batch X (B,T,D): utterance b of true
  * length lengths[b] gets int(rate * lengths[b]) frames zeroed, drawn with replacement from [0, lengths[b]) like
  * np.random.choice(np.arange(T_b), size=n).  The reference's draw is unseeded (quirk Q7); this one is a counter-based stream

@@ -132,6 +132,12 @@ def masks_from_recording(cfg, rec, T2, S, B):
         for s in range(S):
             emb[s] = rec[("emb", 0, s)]
         out["emb_mask"] = emb
+    if cfg["dropout"].get("out", 0) > 0:                      # dropout on the logits (seq2seq.py:394)
+        V = rec[("out", 0, 0)].shape[1]
+        om = np.ones((S, B, V), np.float32)
+        for s in range(S):
+            om[s] = rec[("out", 0, s)]
+        out["out_mask"] = om
     return out
 
 

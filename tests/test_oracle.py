@@ -174,3 +174,200 @@ def test_train_step_reports_loss_over_batch_Q5():
     assert rep == pytest.approx(loss / len(y))
     assert opt.last_grad_norm > 0 and not np.allclose(before, m.p["out/W"].data)
     assert m.p["out/W"].data.dtype == np.float32
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# Optional model features of the NEW path (seq2seq.py:43-57, 81-121, 244-291, 369-394, 456-465)
+def _opt_cfg(**kw):
+    """tiny_cfg with rnn_config / cnn_config / dropout options switched on."""
+    cfg = tiny_cfg(enc_layers=kw.pop("enc_layers", 2), dec_layers=kw.pop("dec_layers", 2), drop=kw.pop("drop", 0.0), V=kw.pop("V", 11))
+    for k in ("ln", "linear_proj", "n_attn", "feed_attn"):
+        if k in kw:
+            cfg["rnn_config"][k] = kw.pop(k)
+    if "bn" in kw:
+        cfg["cnn_config"]["bn"] = kw.pop("bn")
+    if "out" in kw:
+        cfg["dropout"]["out"] = kw.pop("out")
+    assert not kw, kw
+    return cfg
+
+
+OPTION_SETS = {
+    "ln": dict(ln=True),
+    "ln-drop": dict(ln=True, drop=0.3, enc_layers=3, dec_layers=1),
+    "n_attn3": dict(n_attn=3),
+    "no-feed": dict(feed_attn=False),
+    "no-bn": dict(bn=False),
+    "out-drop": dict(out=0.4, drop=0.2),
+    "proj": dict(linear_proj=True, enc_layers=3),
+    "proj-drop": dict(linear_proj=True, enc_layers=2, drop=0.3),
+    "all": dict(ln=True, n_attn=2, feed_attn=False, bn=False, out=0.3, drop=0.2, enc_layers=2, dec_layers=3),
+}
+
+
+@pytest.mark.parametrize("name", sorted(OPTION_SETS))
+def test_option_sets_pass_finite_differences_f64(name):
+    """Every optional feature's backward in the define-by-run oracle against float64 central differences of its own forward pass
+    (dropout masks replayed, teacher forcing mixed): two entries of every parameter."""
+    cfg = _opt_cfg(**OPTION_SETS[name])
+    V, D, B, T, L = 11, 26, 3, 21, 6
+    P = R.init_params(cfg, D, V, seed=3, dtype=np.float64)
+    rng = np.random.default_rng(11)
+    for k in P:                                    # away from the initial gamma = 1 / beta = 0 / b = 0, which hide mistakes
+        if k.endswith(("gamma", "beta", "/b")) and "upward" not in k:
+            P[k] = P[k] + 0.3 * rng.standard_normal(P[k].shape)
+    X, y = R.synth_batch(B, T, D, L, V, seed=4, dtype=np.float64)
+    drop = max(cfg["dropout"].values()) > 0
+    rec = R.RecordingMasks(5) if drop else None
+
+    class Replay:
+        def __call__(self, shape, ratio, tag):
+            return rec.masks[tag]
+
+    def run(Pv, masks):
+        m = R.RefModel(cfg, {k: v.copy() for k, v in Pv.items()}, V)
+        if masks is not None:
+            m.masks = masks
+        loss = m.forward_loss(X, y, 0.5, pyrandom=random.Random(2))
+        return m, loss
+    m, loss = run(P, rec)
+    flags = list(m.use_truth)
+    assert not all(flags), "the case should feed back its own argmax at some step"
+    m.cleargrads()
+    loss.backward()
+    unreached = []
+    for k, p in m.params():
+        # (a parameter the loss does not depend on keeps grad None, like Chainer's; the optimizer treats it as zeros: with linear_proj the
+        #  top encoder layer matters only through the final states that seed a decoder layer of the same index)
+        g = p.grad if p.grad is not None else np.zeros_like(p.data)
+        if p.grad is None:
+            unreached.append(k)
+        for _ in range(2):
+            idx = tuple(int(rng.integers(0, s)) for s in g.shape)
+            eps = 1e-6
+            Pp = {n: v.copy() for n, v in P.items()}
+            Pm = {n: v.copy() for n, v in P.items()}
+            Pp[k][idx] += eps
+            Pm[k][idx] -= eps
+            num = (float(run(Pp, Replay() if drop else None)[1].data) - float(run(Pm, Replay() if drop else None)[1].data)) / (2 * eps)
+            assert abs(num - g[idx]) <= 2e-6 * max(1.0, abs(num)) + 5e-8, (k, idx, num, g[idx])
+    assert all(k.startswith(("L2_enc", "L2_rev_enc")) for k in unreached) and (name == "proj") == bool(unreached), unreached
+
+
+def test_layer_normalization_known_answer():
+    """L.LayerNormalization: per-ROW statistics over the units, biased variance, eps = 1e-6 inside the square root, then gamma / beta."""
+    x = np.array([[1.0, 2.0, 3.0, 6.0], [0.0, 0.0, 0.0, 0.0]])
+    g, b = np.array([1.0, 2.0, 0.5, -1.0]), np.array([0.1, 0.0, -0.2, 0.3])
+    y = F.layer_normalization(F.Variable(x), F.Variable(g), F.Variable(b), 1e-6).data
+    mu, var = 3.0, (4 + 1 + 0 + 9) / 4.0
+    want0 = (x[0] - mu) / np.sqrt(var + 1e-6) * g + b
+    np.testing.assert_allclose(y[0], want0, atol=1e-14)
+    np.testing.assert_allclose(y[1], b, atol=1e-14)            # a constant row normalises to 0 (eps keeps it finite)
+
+
+def test_layernorm_sits_behind_dropout_and_leaves_the_recurrent_state_raw():
+    """seq2seq.py:198-202: hs = LN(dropout(LSTM(hs))); the link's own h (next step's lateral input, decoder seed) stays un-normalised."""
+    cfg = _opt_cfg(ln=True, enc_layers=1, dec_layers=1)
+    V, D = 11, 26
+    P = R.init_params(cfg, D, V, seed=0, dtype=np.float64)
+    P["L0_enc_ln/gamma"] = P["L0_enc_ln/gamma"] * 1.7
+    P["L0_enc_ln/beta"] = P["L0_enc_ln/beta"] + 0.2
+    X, _ = R.synth_batch(2, 21, D, 5, V, seed=1, dtype=np.float64)
+    m = R.RefModel(cfg, P, V)
+    m.encode(X)
+    h_raw = m.enc[0].h.data                                     # state after the last frame
+    Hh = cfg["rnn_config"]["hidden_units"] // 2
+    mu = h_raw.mean(1, keepdims=True)
+    want = (h_raw - mu) / np.sqrt(((h_raw - mu) ** 2).mean(1, keepdims=True) + 1e-6) * 1.7 + 0.2
+    np.testing.assert_allclose(m.enc_states.data[:, -1, :Hh], want, atol=1e-12)
+    assert abs(h_raw).max() < 1.0                               # raw LSTM output, |h| < 1
+
+
+def test_linear_proj_encoder_quirks():
+    """seq2seq.py:244-291 as written: (i) the reverse stack sees the LAST frame of its layer's input at every step; (ii) the attention
+    memory is the last PROJECTION's output, not the top LSTM layer's; (iii) the projection's BatchNorm normalises each time step over
+    its B rows and advances its running statistics and N once per step."""
+    cfg = _opt_cfg(linear_proj=True, enc_layers=2, dec_layers=1)
+    V, D, B = 11, 26, 3
+    H = cfg["rnn_config"]["hidden_units"]
+    P = R.init_params(cfg, D, V, seed=0, dtype=np.float64)
+    assert P["L1_enc/upward/W"].shape == (4 * (H // 2), H) and P["enc_proj0/W"].shape == (H, H) and "enc_proj1/W" not in P
+    X, _ = R.synth_batch(B, 21, D, 5, V, seed=1, dtype=np.float64)
+    m = R.RefModel(cfg, {k: v.copy() for k, v in P.items()}, V)
+    feats = m.forward_cnn(F.Variable(X))
+    m.forward_rnn_encode_proj(feats)
+    T2 = feats.shape[0]
+    assert m.enc_states.shape == (B, T2, H)
+    # (i) layer-0 reverse stack: T2 steps on the constant input feats[-1]
+    link = F.LSTMLink(*(F.Variable(P[f"L0_rev_enc/{n}"]) for n in ("upward/W", "upward/b", "lateral/W")))
+    outs = [link(F.Variable(feats.data[-1])).data for _ in range(T2)]
+    fwd = F.LSTMLink(*(F.Variable(P[f"L0_enc/{n}"]) for n in ("upward/W", "upward/b", "lateral/W")))
+    fo = [fwd(F.Variable(feats.data[i])).data for i in range(T2)]
+    # (ii) + (iii): enc_states[:, i] = relu(BN_step(Linear([fwd_i ; rev_{T2-1-i}]))) with the statistics of that step's B rows
+    for i in (0, 3, T2 - 1):
+        z = np.concatenate([fo[i], outs[T2 - 1 - i]], 1) @ P["enc_proj0/W"].T + P["enc_proj0/b"]
+        zn = (z - z.mean(0)) / np.sqrt(z.var(0) + 2e-5)
+        np.testing.assert_allclose(m.enc_states.data[:, i], np.maximum(zn, 0), atol=1e-10)
+    assert m.bn["enc_proj0_bn"].N == T2
+    # running mean after T2 sequential updates of decay 0.9
+    means = [(np.concatenate([fo[i], outs[T2 - 1 - i]], 1) @ P["enc_proj0/W"].T + P["enc_proj0/b"]).mean(0) for i in range(T2)]
+    avg = np.zeros(H)
+    for mu in means:
+        avg = 0.9 * avg + 0.1 * mu
+    np.testing.assert_allclose(m.p["enc_proj0_bn/avg_mean"], avg, atol=1e-12)
+    # the top layer reaches the decoder through its final states only
+    m.init_decoder_state()
+    assert m.dec[0].h.shape == (B, H)
+
+
+def test_multiple_attention_heads_share_h_and_widen_the_context_layer():
+    cfg = _opt_cfg(n_attn=3, enc_layers=1, dec_layers=1)
+    V, D = 11, 26
+    H, A = cfg["rnn_config"]["hidden_units"], cfg["rnn_config"]["attn_units"]
+    P = R.init_params(cfg, D, V, seed=0, dtype=np.float64)
+    assert P["context/W"].shape == (A, 4 * H) and P["attn_Wa2/W"].shape == (H, H)
+    X, y = R.synth_batch(2, 21, D, 5, V, seed=1, dtype=np.float64)
+    m = R.RefModel(cfg, P, V)
+    m.train = False
+    m.encode(X)
+    m.init_decoder_state()
+    logits, ht, alphas = m.decode_step(np.array([1, 1], dtype=np.int32), F.Variable(np.zeros((2, A))))
+    h = m.dec[0].h.data
+    enc = m.enc_states.data
+    cvs = []
+    for name in ("attn_Wa", "attn_Wa1", "attn_Wa2"):
+        q = h @ P[name + "/W"].T + P[name + "/b"]
+        s = np.einsum("bth,bh->bt", enc, q)
+        a = np.exp(s - s.max(1, keepdims=True))
+        a /= a.sum(1, keepdims=True)
+        cvs.append(np.einsum("bt,bth->bh", a, enc))
+        if name == "attn_Wa":
+            np.testing.assert_allclose(alphas.data[:, :, 0], a, atol=1e-12)       # the returned alphas are the FIRST head's
+    want = np.tanh(np.concatenate(cvs + [h], 1) @ P["context/W"].T + P["context/b"])
+    np.testing.assert_allclose(ht.data, want, atol=1e-12)
+
+
+def test_random_out_draw_order_and_clamp_Q8():
+    """seq2seq.py:456-465: per step, BEHIND the teacher-forcing coin of that step, one random.random() per target >= 4 (none for special
+    symbols), replacement when the draw is ABOVE random_out, id from randint(4, V + 1) -- clamped here to V - 1 (the one deviation)."""
+    cfg = _opt_cfg(enc_layers=1, dec_layers=1)
+    V, D, B, L = 11, 26, 3, 6
+    P = R.init_params(cfg, D, V, seed=0, dtype=np.float64)
+    X, y = R.synth_batch(B, 21, D, L, V, seed=1, dtype=np.float64)
+    draws = iter([V, 4, 7, V, 5, 6, 9, 8, 4, 4, 4, 4, 4, 4, 4])           # V is the out-of-range id the reference can draw
+    m = R.RefModel(cfg, P, V)
+    rnd = random.Random(7)
+    m.forward_loss(X, y, 0.5, random_out=0.4, pyrandom=rnd, randint=lambda lo, hi: next(draws))
+    # replay the stream by hand
+    rnd2 = random.Random(7)
+    drawn = iter([V, 4, 7, V, 5, 6, 9, 8, 4, 4, 4, 4, 4, 4, 4])
+    for i in range(L - 1):
+        if 0 < i < L - 2:
+            rnd2.random()
+        want = y[:, i + 1].copy()
+        for b in range(B):
+            if want[b] >= 4 and rnd2.random() > 0.4:
+                want[b] = min(next(drawn), V - 1)
+        np.testing.assert_array_equal(m.targets[i], want)
+    assert max(int(t.max()) for t in m.targets) == V - 1
+    assert rnd.random() == rnd2.random()                                   # same number of draws consumed
