@@ -1465,7 +1465,8 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
 //   * TOK[s][b] (the token that was fed) and X0[s][b][:E] = embed[TOK] * mask for the backward's wgrad / scatter,
 //   * dlogits = w[t] (softmax - onehot) / B in place of the saved logits,
 //   * the copy of the prediction; block 0 also sums the per-row losses (in double).
-__global__ __launch_bounds__(256) void k_decoder_post(const float* __restrict__ embed, const int32_t* __restrict__ y, const int32_t* __restrict__ use_truth,
+__global__ __launch_bounds__(256) void k_decoder_post(const float* __restrict__ embed, const int32_t* __restrict__ y, const int32_t* __restrict__ ytgt,
+                                                      const int32_t* __restrict__ use_truth,
                                                       const int32_t* __restrict__ pred, const float* __restrict__ emb_mask, int32_t* __restrict__ tok_out,
                                                       float* __restrict__ x0, float* __restrict__ logits, const float* __restrict__ lse,
                                                       const float* __restrict__ cw, const float* __restrict__ lossrows, float* __restrict__ loss,
@@ -1485,7 +1486,7 @@ __global__ __launch_bounds__(256) void k_decoder_post(const float* __restrict__ 
     }
   }
   {
-    int t = y[(long)b * L + s + 1];
+    int t = ytgt[(long)b * L + s + 1];        // the class that was SCORED (y, or forward_loss's random_out replacement)
     t = t < 0 ? 0 : (t >= V ? V - 1 : t);
     const float scale = (cw ? cw[t] : 1.f) / (float)B;
     const float ls = lse[r];
@@ -1707,7 +1708,7 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
   ASTK_LAUNCH_CHECK();
   // Q[s][b][:] = Wa h_top + ba for all steps (needed by the backward's deferred d_enc product)
   ASTK_TRY(gemm_launch(GEMM_NT, gemm_args(a.S * a.B, a.H, a.H, mat(bf.CVH + a.H, 2 * a.H), mat(prm->Wa, a.H), bf.Q, a.H, prm->ba), s));
-  hipLaunchKernelGGL(k_decoder_post, dim3(a.S * a.B), dim3(256), 0, s, prm->embed, y, use_truth, bf.PRED, emb_mask, bf.TOK, bf.X0, bf.LOGITS, bf.LSE,
+  hipLaunchKernelGGL(k_decoder_post, dim3(a.S * a.B), dim3(256), 0, s, prm->embed, y, ytgt ? ytgt : y, use_truth, bf.PRED, emb_mask, bf.TOK, bf.X0, bf.LOGITS, bf.LSE,
                      prm->class_weight, bf.LOSSROWS, loss, pred_out, a.S, a.B, a.L, a.E, a.XI, a.V, a.Vp);
   ASTK_LAUNCH_CHECK();
   return 0;

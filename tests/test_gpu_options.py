@@ -116,6 +116,10 @@ def test_optional_features_train_step_parity(name):
     for k, want in ref["grads"].items():
         err = np.abs(grads[k] - want).max()
         tol = 3e-4 * max(np.abs(want).max(), 1e-3 * gmax)
+        if k.startswith("enc_proj") and k.endswith("/b"):
+            # a bias in front of a BatchNorm has NO gradient (the normalisation removes it): the exact value is 0 (1e-17 in the float64
+            # oracle) and what float32 leaves is the rounding of a sum of dz entries that cancel -- priced against the weight's gradient
+            tol = 3e-4 * np.abs(ref["grads"][k[:-1] + "W"]).max()
         assert err <= tol, f"{name}: grad {k}: err {err:.3e} tol {tol:.3e}"
     after = g.arena.to_numpy()
     num = sum(float(((after[k].astype(np.float64) - ref["after"][k]) ** 2).sum()) for k in after)
@@ -158,7 +162,9 @@ def test_random_out_replaces_scored_targets_like_the_reference():
     from oracle import ast_ref as R
     from ast_amd.seq2seq import using_config
     for persist in (False, True):
-        cfg = _cfg(H=128, A=64, dec_layers=1, V=57) if persist else _cfg()
+        # (persist: the persistent decoder loop -- its CE role and its post kernel read the scored-targets matrix; else: the per-launch
+        #  loop, forced by a second attention head)
+        cfg = _cfg(H=128, A=64, dec_layers=1, V=57) if persist else _cfg(n_attn=2)
         V = cfg["rnn_config"]["dec_vocab_size"]
         B, T, D, L = (18, 70, 80, 8) if persist else (5, 64, 80, 7)
         P = R.init_params(cfg, D, V, seed=2, dtype=np.float32)
@@ -181,9 +187,8 @@ def test_random_out_replaces_scored_targets_like_the_reference():
         gmax = max(np.abs(v).max() for v in ref["grads"].values())
         for k, want in ref["grads"].items():
             assert np.abs(grads[k] - want).max() <= 3e-4 * max(np.abs(want).max(), 1e-3 * gmax), (persist, k)
-        if persist:
-            import ast_amd._lib as L_
-            assert L_.load().astk_decoder_path(C.byref(g._cur["dd"])) & 1      # the scored-targets matrix reaches the persistent loop's CE role
+        import ast_amd._lib as L_
+        assert bool(L_.load().astk_decoder_path(C.byref(g._cur["dd"])) & 1) == persist
 
 
 def _vp(t):
