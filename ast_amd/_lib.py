@@ -82,6 +82,8 @@ SIGNATURES = {
     "astk_conv_bn_relu_workspace_bytes": (_SZ, [C.POINTER(CnnDesc)]),
     "astk_conv_bn_relu_fwd": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(CnnLayerParams), _VP, _VP, _VP, _VP, _SZ, _I, _VP]),
     "astk_conv_bn_relu_bwd": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(CnnLayerParams), C.POINTER(CnnLayerGrads), _VP, _VP, _SZ, _VP]),
+    "astk_conv_debug_preact": (C.c_int, [C.POINTER(CnnDesc), _VP, _SZ, _I, _VP, _VP]),
+    "astk_conv_debug_kill_units": (C.c_int, [_VP, _I]),
     # the exchange callback is passed as an opaque pointer (a ctypes CFUNCTYPE instance converts itself)
     "astk_conv_bn_relu_fwd_sync": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(CnnLayerParams), _VP, _VP, _VP, _VP, _SZ, _I, _VP, _VP, _I, _VP]),
     "astk_conv_bn_relu_bwd_sync": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(CnnLayerParams), C.POINTER(CnnLayerGrads), _VP, _VP, _SZ, _VP, _VP,
@@ -126,7 +128,8 @@ SIGNATURES = {
     "astk_scale_f32": (C.c_int, [_VP, _SZ, _F, _VP]),
     "astk_add_f32": (C.c_int, [_VP, _VP, _SZ, _VP]),
     "astk_colsum_add_f32": (C.c_int, [_VP, _VP, _L, _I, _I, _VP]),
-    "astk_zero_frames": (C.c_int, [_VP, _I, _I, _I, _VP, _F, _U64, _U64, _VP]),
+    "astk_zero_frames": (C.c_int, [_VP, _I, _I, _I, _VP, C.c_double, _U64, _U64, _VP]),
+    "astk_zero_frames_draws": (C.c_int, [_I, _I, _VP, C.c_double, _U64, _U64, _VP, _I, _VP, _VP]),
     "astk_persist_status_snapshot": (C.c_int, [_VP, _VP]),
     "astk_persist_status": (C.c_int, [C.POINTER(C.c_uint), _I]),
     "astk_device_cu_count": (C.c_int, []),

@@ -346,6 +346,25 @@ __global__ void k_bn_param_grads(const double* __restrict__ stat, int C, float* 
   dbeta[c] += (float)stat[c];
 }
 
+// ---- test instrumentation (tests/test_gpu_model.py: the batch-permutation property): the post-BatchNorm pre-activations of a layer,
+// and a list of units whose upstream gradient is dropped by the next backward passes.  Two valid float32 evaluations of the same
+// batch (another row order) can differ in the SIGN of a pre-activation that lies within rounding of the ReLU kink; the test names
+// those units and checks that nothing else differs.
+__global__ void k_preact(const float* __restrict__ Y, const float* __restrict__ bn, float* __restrict__ out, long n, int C) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    out[i] = Y[i] * bn[2 * C + c] + bn[3 * C + c];
+  }
+}
+__global__ void k_kill_units(float* __restrict__ G, const int32_t* __restrict__ units, int n, int layer, int rows, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || units[3 * i] != layer) return;
+  const int r = units[3 * i + 1], c = units[3 * i + 2];
+  if (r >= 0 && r < rows && c >= 0 && c < C) G[(long)r * C + c] = 0.f;
+}
+const int32_t* g_kill_units = nullptr;
+int g_kill_n = 0;
+
 inline unsigned gridn(size_t n) {
   size_t b = (n + 255) / 256;
   if (b < 1) b = 1;
@@ -459,6 +478,22 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
   return 0;
 }
 
+int astk_conv_debug_preact(const astk_cnn_desc* d, void* ws, size_t ws_bytes, int layer, float* out, void* stream) {
+  CnnPlan P;
+  ASTK_TRY(make_plan(d, ws, P));
+  ASTK_CHECK(ws && ws_bytes >= P.bytes && out && layer >= 0 && layer < P.n, "conv_debug_preact: bad arguments");
+  const long n = (long)P.rows[layer] * P.Cn[layer];
+  hipLaunchKernelGGL(k_preact, dim3(gridn((size_t)n)), dim3(256), 0, (hipStream_t)stream, P.Y[layer], P.bn[layer], out, n, P.Cn[layer]);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int astk_conv_debug_kill_units(const int32_t* units, int n) {
+  g_kill_units = n > 0 ? units : nullptr;
+  g_kill_n = n > 0 && units ? n : 0;
+  return 0;
+}
+
 int astk_conv_bn_relu_bwd(const astk_cnn_desc* d, const astk_cnn_layer_params* L, const astk_cnn_layer_grads* Gr, float* d_out,
                           void* ws, size_t ws_bytes, void* stream) {
   return astk_conv_bn_relu_bwd_sync(d, L, Gr, d_out, ws, ws_bytes, nullptr, nullptr, 1, stream);
@@ -482,6 +517,10 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
   }
   for (int i = P.n - 1; i >= 0; --i) {
     const int C = P.Cn[i], rows = P.rows[i];
+    if (g_kill_n > 0) {      // test instrumentation (astk_conv_debug_kill_units): drop the upstream gradient of the listed units
+      hipLaunchKernelGGL(k_kill_units, dim3(cdiv(g_kill_n, 256)), dim3(256), 0, s, P.G, g_kill_units, g_kill_n, i, rows, C);
+      ASTK_LAUNCH_CHECK();
+    }
     // ---- ReLU + BatchNorm backward: G (grad wrt post-ReLU) -> DY[i] (grad wrt raw conv output)
     if (i == P.n - 1) ASTK_TRY(fill_zero(P.stat[0], P.zero_bwd_bytes, s));   // statistics and dWr scratch of every layer
     hipLaunchKernelGGL(k_bn_bwd_stats, colreduce_grid(rows, C), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], rows, C, P.stat[i]);

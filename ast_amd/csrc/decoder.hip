@@ -262,9 +262,13 @@ int ksplit_rows(long tiles, int rows) {
 struct WgradBatch {
   GemmArgs list[GEMM_GROUP_MAX];
   int n = 0;
+  bool low = false;      // every product of this batch may run with fp16 operands under astk_set_low_precision_gemms(1) (K18 / K24)
+  explicit WgradBatch(bool lowp_eligible = false) : low(lowp_eligible) {}
   int add(float* dW, long ldw, int M, int N, const float* A, long lda, const float* Bm, long ldb, int rows, hipStream_t s) {
     if (n == GEMM_GROUP_MAX) ASTK_TRY(flush(s));
-    list[n++] = gemm_args(M, N, rows, mat(A, lda), mat(Bm, ldb), dW, ldw, nullptr, GEMM_ATOMIC, 1);
+    list[n] = gemm_args(M, N, rows, mat(A, lda), mat(Bm, ldb), dW, ldw, nullptr, GEMM_ATOMIC, 1);
+    if (low) list[n] = lowp(list[n]);
+    ++n;
     return 0;
   }
   int flush(hipStream_t s) {
@@ -601,7 +605,7 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
   // caller may run this phase on a second stream beside the encoder's backward recurrence (ASTK_DEC_BWD_PARAMS)
   if (persist) {
     // split mode: the embedding columns of d_x0 (only the embedding scatter reads them) are one batched product over all steps
-    if (b6s) ASTK_TRY(gemm_launch(GEMM_NN, gemm_args(S * B, E, 4 * H, mat(P.G[0], 4 * H), mat(prm->lstm[0].Wu, XI), P.DX0, XI), s));
+    if (b6s) ASTK_TRY(gemm_launch(GEMM_NN, lowp(gemm_args(S * B, E, 4 * H, mat(P.G[0], 4 * H), mat(prm->lstm[0].Wu, XI), P.DX0, XI)), s));      // (K18's input gradient)
     // dq[s][b][:] = sum_t ds[s][b][t] enc[b][t][:]  (batched over b) -- only the weight gradients of attn_Wa need it
     GemmArgs gq = gemm_args(S, H, T, mat(P.DS, (long)B * Tp), mat(enc, H), P.DQ, (long)B * H);
     gq.batch = B; gq.sA = Tp; gq.sB = (long)T * H; gq.sC = H;
@@ -609,9 +613,12 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
   }
   // ---- weight gradients: one batched TN GEMM each over the S*B saved rows
   const int SB = S * B;
-  WgradBatch wb;
+  // BASELINE configs[4] ("fp16 MFMA GEMMs"; SURVEY 8d: fp16 operands for K6, K9, K18, K24): the batched products of the decoder LSTMs (K18)
+  // and of the output layer (K24) form their own grouped launch, eligible for fp16 operands under astk_set_low_precision_gemms(1);
+  // attention and context products stay f32-accurate.  (Without that mode both groups run exactly as one did.)
+  WgradBatch wb, wbl(true);
   ColsumBatch cb;   // the bias gradients: one launch
-  ASTK_TRY(wb.add(g->dWo, A, V, A, P.LOGITS, Vp, P.HT + (size_t)B * A, A, SB, s));
+  ASTK_TRY(wbl.add(g->dWo, A, V, A, P.LOGITS, Vp, P.HT + (size_t)B * A, A, SB, s));
   ASTK_TRY(cb.add(g->dbo, P.LOGITS, Vp, SB, V, s));
   ASTK_TRY(wb.add(g->dWc, CW, A, CW, P.DPRE, A, P.CVH, CW, SB, s));
   ASTK_TRY(cb.add(g->dbc, P.DPRE, A, SB, A, s));
@@ -629,12 +636,22 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
     if (l == 0) { xin = P.X0; ldx = XI; }
     else if (rnn_masks || P.ln) { xin = P.HD[l - 1]; ldx = H; }       // (with LayerNorm the layer's input is always the normalised copy)
     else { xin = P.HR[l - 1] + bh; ldx = H; }
-    ASTK_TRY(wb.add(g->lstm[l].dWu, in, 4 * H, in, P.G[l], 4 * H, xin, ldx, SB, s));
-    ASTK_TRY(wb.add(g->lstm[l].dWl, H, 4 * H, H, P.G[l], 4 * H, P.HR[l], H, SB, s));
+    ASTK_TRY(wbl.add(g->lstm[l].dWu, in, 4 * H, in, P.G[l], 4 * H, xin, ldx, SB, s));
+    ASTK_TRY(wbl.add(g->lstm[l].dWl, H, 4 * H, H, P.G[l], 4 * H, P.HR[l], H, SB, s));
     ASTK_TRY(cb.add(g->lstm[l].db, P.G[l], 4 * H, SB, 4 * H, s));
   }
   ASTK_TRY(cb.flush(s));
-  ASTK_TRY(wb.flush(s));
+  if (low_precision_gemms()) {
+    ASTK_TRY(wb.flush(s));
+    ASTK_TRY(wbl.flush(s));
+  } else {            // one grouped launch, as before the two were told apart
+    for (int i = 0; i < wbl.n; ++i) {
+      if (wb.n == GEMM_GROUP_MAX) ASTK_TRY(wb.flush(s));
+      wb.list[wb.n++] = wbl.list[i];
+    }
+    wbl.n = 0;
+    ASTK_TRY(wb.flush(s));
+  }
   hipLaunchKernelGGL(k_embed_bwd, dim3(SB), dim3(128), 0, s, g->d_embed, P.TOK, P.DX0, emb_mask, SB, E, XI);
   ASTK_LAUNCH_CHECK();
   return 0;

@@ -225,16 +225,29 @@ __global__ void k_normal(float* out, size_t n, float mean, float sigma, uint64_t
 
 // dataloader.py:83-93 on the device: utterance b (true length len[b] <= T frames, zero-padded behind) gets int(rate * len[b]) of its
 // frames zeroed; the frames are drawn WITH replacement (np.random.choice's default), so fewer distinct frames may be hit.
-__global__ void k_zero_frames(float* X, int T, int D, const int32_t* len, float rate, uint64_t seed, uint64_t offset) {
+// (the count is int(drop_rate * len(x_data)) in double precision, exactly as Python evaluates it)
+__device__ __forceinline__ int zero_frames_draw(uint64_t seed, uint64_t offset, int b, int T, int i, int nb) {
+  const uint64_t bits = mix64(seed ^ mix64(offset + (uint64_t)b * (uint64_t)T + (uint64_t)i));
+  return (int)((bits >> 11) % (uint64_t)nb);
+}
+__global__ void k_zero_frames(float* X, int T, int D, const int32_t* len, double rate, uint64_t seed, uint64_t offset) {
   const int b = blockIdx.x;
   const int nb = min(max(len[b], 0), T);
-  const int n = (int)(rate * (float)nb);
+  const int n = (int)(rate * (double)nb);
   float* xb = X + (size_t)b * T * D;
   for (int i = threadIdx.x / 32; i < n; i += blockDim.x / 32) {        // 32 lanes clear one drawn frame
-    const uint64_t bits = mix64(seed ^ mix64(offset + (uint64_t)b * (uint64_t)T + (uint64_t)i));
-    const int r = (int)((bits >> 11) % (uint64_t)nb);
+    const int r = zero_frames_draw(seed, offset, b, T, i, nb);
     for (int d = threadIdx.x % 32; d < D; d += 32) xb[(size_t)r * D + d] = 0.f;
   }
+}
+// the same draws, written out instead of applied: idx[b][i] = i-th frame drawn for utterance b (i < counts[b] <= max_draws)
+__global__ void k_zero_frames_draws(int T, const int32_t* len, double rate, uint64_t seed, uint64_t offset, int32_t* idx, int max_draws,
+                                    int32_t* counts) {
+  const int b = blockIdx.x;
+  const int nb = min(max(len[b], 0), T);
+  const int n = (int)(rate * (double)nb);
+  if (threadIdx.x == 0) counts[b] = n;
+  for (int i = threadIdx.x; i < n && i < max_draws; i += blockDim.x) idx[(size_t)b * max_draws + i] = zero_frames_draw(seed, offset, b, T, i, nb);
 }
 
 // ---- optimizer
@@ -530,9 +543,17 @@ int astk_fill_normal(float* out, size_t n, float mean, float sigma, uint64_t see
   return 0;
 }
 
-int astk_zero_frames(float* X, int B, int T, int D, const int32_t* lengths, float rate, uint64_t seed, uint64_t offset, void* stream) {
-  ASTK_CHECK(X && lengths && B > 0 && T > 0 && D > 0 && rate >= 0.f && rate <= 1.f, "zero_frames: bad arguments");
-  if (rate == 0.f) return 0;
+int astk_zero_frames_draws(int B, int T, const int32_t* lengths, double rate, uint64_t seed, uint64_t offset, int32_t* idx, int max_draws,
+                           int32_t* counts, void* stream) {
+  ASTK_CHECK(lengths && idx && counts && B > 0 && T > 0 && max_draws > 0 && rate >= 0. && rate <= 1., "zero_frames_draws: bad arguments");
+  hipLaunchKernelGGL(k_zero_frames_draws, dim3(B), dim3(256), 0, (hipStream_t)stream, T, lengths, rate, seed, offset, idx, max_draws, counts);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int astk_zero_frames(float* X, int B, int T, int D, const int32_t* lengths, double rate, uint64_t seed, uint64_t offset, void* stream) {
+  ASTK_CHECK(X && lengths && B > 0 && T > 0 && D > 0 && rate >= 0. && rate <= 1., "zero_frames: bad arguments");
+  if (rate == 0.) return 0;
   hipLaunchKernelGGL(k_zero_frames, dim3(B), dim3(256), 0, (hipStream_t)stream, X, T, D, lengths, rate, seed, offset);
   ASTK_LAUNCH_CHECK();
   return 0;

@@ -42,9 +42,11 @@ int astk_gemm_f32(int layout, int M, int N, int K,
                   const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                   const float* bias, int mode, int ksplit, int batch, long sA, long sB, long sC, void* stream);
 
-/* BASELINE configs[4] ("fp16 MFMA GEMMs"): mode 1 lets the batched products of the CNN layers >= 1 (K6) and of the encoder's layer-0
- * input projection (K9), forward and backward, run with operands rounded to fp16 (one v_mfma_f32_32x32x16_f16 per tile, f32
- * accumulation) instead of the f32-accurate split (below).  Reduced precision: the 1e-4 fp32 parity gate does not apply in
+/* BASELINE configs[4] ("fp16 MFMA GEMMs"): mode 1 lets the batched products of the CNN layers >= 1 (K6), of the encoder's layer-0
+ * input projection (K9) -- forward and backward -- and of the decoder LSTMs' and the output layer's backward (K18, K24: their weight
+ * gradients over all steps, the embedding columns of the input gradient) run with operands rounded to fp16 behind the operand's
+ * power-of-two scale where its caller measured it (one v_mfma_f32_32x32x16_f16 per tile, f32 accumulation) instead of the f32-accurate
+ * split (below).  The per-step products of K18 / K24 live inside the latency-bound decoder loop kernels and stay on f32 MFMAs.  Reduced precision: the 1e-4 fp32 parity gate does not apply in
  * this mode (SURVEY.md 8d asks for the loss drift instead: tests/test_gpu_model.py).  Process-wide; 0 (default) = off. */
 int astk_set_low_precision_gemms(int mode);
 int astk_get_low_precision_gemms(void);
@@ -106,6 +108,14 @@ int astk_conv_bn_relu_fwd(const astk_cnn_desc* d, const astk_cnn_layer_params* l
 /* d_out (T'',B,C_last*F') is overwritten.  Gradients are ACCUMULATED into grads (caller zeroes = cleargrads). */
 int astk_conv_bn_relu_bwd(const astk_cnn_desc* d, const astk_cnn_layer_params* layers,
                           const astk_cnn_layer_grads* grads, float* d_out, void* ws, size_t ws_bytes, void* stream);
+/* Test instrumentation (tests/test_gpu_model.py, the batch-permutation property).  astk_conv_debug_preact: after a forward call, out
+ * [(b,f,t)][c] = the post-BatchNorm pre-activation of `layer` (what the ReLU sees), rows = B*F'*T_layer.  astk_conv_debug_kill_units:
+ * the following backward calls of this process zero the upstream gradient of the listed units (n triples layer, row, channel in
+ * device memory, caller-owned; n = 0 switches it off).  Two valid float32 evaluations of one batch can disagree on the SIGN of a
+ * pre-activation that lies within rounding of the ReLU kink; the test names those units and shows that nothing else differs. */
+int astk_conv_debug_preact(const astk_cnn_desc* d, void* ws, size_t ws_bytes, int layer, float* out, void* stream);
+int astk_conv_debug_kill_units(const int32_t* units, int n);
+
 /* Data-parallel BatchNorm with GLOBAL batch statistics (SURVEY.md 8e "SyncBN"): the same two calls with an exchange step.
  * After a layer's local per-channel sums are on the device -- forward (sum y, sum y^2), backward (sum g, sum g*xhat), `n` = 2*C
  * doubles at `stat`, inside the caller's workspace -- the library calls `exchange(user, stat, n, stream)` on the host; the callee
@@ -321,7 +331,12 @@ int astk_colsum_add_f32(float* dst, const float* src, long lds, int rows, int co
  * length lengths[b] gets int(rate * lengths[b]) frames zeroed, drawn with replacement from [0, lengths[b]) like
  * np.random.choice(np.arange(T_b), size=n).  The reference's draw is unseeded (quirk Q7); this one is a counter-based stream
  * (seed, offset), consuming B*T counters per call. */
-int astk_zero_frames(float* X, int B, int T, int D, const int32_t* lengths, float rate, uint64_t seed, uint64_t offset, void* stream);
+int astk_zero_frames(float* X, int B, int T, int D, const int32_t* lengths, double rate, uint64_t seed, uint64_t offset, void* stream);
+/* The draws astk_zero_frames makes for the same (lengths, rate, seed, offset), written out instead of applied: counts[b] =
+ * int(rate * lengths[b]) (double precision, as Python evaluates it), idx[b*max_draws + i] = the i-th frame drawn for utterance b.
+ * Lets a test feed the device's stream to the oracle's _drop_frames (oracle/loader_ref.py) and compare whole batches bit for bit. */
+int astk_zero_frames_draws(int B, int T, const int32_t* lengths, double rate, uint64_t seed, uint64_t offset, int32_t* idx, int max_draws,
+                           int32_t* counts, void* stream);
 /* One wavefront that keeps `stream` busy for `usec` microseconds (<= 100 000) and then increments *flag (may be NULL).  For probing
  * whether two streams really execute concurrently: HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
  * default), and two streams that share one are serialised whatever their events say (ast_amd/seq2seq.py:_cu_streams). */

@@ -16,6 +16,8 @@ Cases (BASELINE.json configs):
   cfg1      configs[1]: B=32 T=800 D=80 L=40, 3 enc layers (2x256), 1 dec layer 512, V=1098           (bench workload)
   es_en_20h configs[0]: the shipped es_en_20h model (3 enc / 3 dec, /root/reference/experiments/es_en_20h/model_cfg.json
             values restated in MODEL_ES_EN) at batch 2, T=800, D=80, L=40
+  cfg5      configs[4]'s shape (enc_layers 6, hidden_units 1024, attn_units 1024, V=8004) at B=4, T=160, L=12
+  cfg1_b64  configs[1]'s model at batch 64 (T=800, L=40)
   asr_gpfr  configs[3]'s shape: same model JSON (experiments/asr_gpfr/model_cfg.json has no n_attn/feed_attn keys:
             defaults equal), 13-d features, 3 dec layers, V=1004, L=60, batch 8, T=800
 Dropout / speech noise are 0 (quirk Q7: the reference's masks are unseeded; the masked variants are compared at small
@@ -40,9 +42,9 @@ OPT = {"type": 0, "lr": 1e-3, "l2": 1e-4, "grad_clip": 2, "grad_noise_eta": 0, "
 N_SAMPLES = 24
 
 
-def model_cfg(dec_layers, V, explicit_attn_keys=True):
-    rc = {"bi_rnn": True, "enc_layers": 3, "dec_layers": dec_layers, "hidden_units": 512, "embedding_units": 128,
-          "attn_units": 512, "ln": False, "dec_vocab_size": V}
+def model_cfg(dec_layers, V, explicit_attn_keys=True, enc_layers=3, hidden=512):
+    rc = {"bi_rnn": True, "enc_layers": enc_layers, "dec_layers": dec_layers, "hidden_units": hidden, "embedding_units": 128,
+          "attn_units": hidden, "ln": False, "dec_vocab_size": V}
     if explicit_attn_keys:
         rc.update(n_attn=1, feed_attn=True)
     return {"dropout": {"embed": 0.0, "rnn": 0.0, "out": 0}, "rnn_config": rc,
@@ -55,6 +57,10 @@ CASES = {
     "cfg1": dict(cfg=model_cfg(1, 1098), B=32, T=800, D=80, L=40, V=1098, seed=0, data_seed=20),
     "es_en_20h": dict(cfg=model_cfg(3, 1098), B=2, T=800, D=80, L=40, V=1098, seed=0, data_seed=20),
     "asr_gpfr": dict(cfg=model_cfg(3, 1004, explicit_attn_keys=False), B=8, T=800, D=13, L=60, V=1004, seed=0, data_seed=20),
+    # round 3: the SHAPE of configs[4] (6-layer BiLSTM, 1024 = 2 x 512 units, H = A = 1024 decoder, BPE-8k: `bench.py --model cfg5`) at a
+    # size the float64 oracle affords, and configs[1]'s model at batch 64 per GPU (grouped encoder launches; the decoder's 64-row path)
+    "cfg5": dict(cfg=model_cfg(1, 8004, enc_layers=6, hidden=1024), B=4, T=160, D=80, L=12, V=8004, seed=0, data_seed=20),
+    "cfg1_b64": dict(cfg=model_cfg(1, 1098), B=64, T=800, D=80, L=40, V=1098, seed=0, data_seed=20),
 }
 
 

@@ -582,6 +582,43 @@ def test_gemm_operand_magnitudes(lib, layout, sa, sb, gemm_split):
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(1024, 1536, 2048), (384, 6400, 1000)])
+def test_gemm_heavy_tailed_operands_fp16x2_against_the_exact_f32_kernel(lib, layout, M, N, K):
+    """fp16x2 on hard data: log-normal magnitudes spanning more than six decades INSIDE every row and column of both operands (trained
+    weights and BPTT gradients are heavy-tailed within rows; round-2's test spread whole rows).  The same product under the two-term fp16
+    split and under the exact-f32 MFMA chain (astk_set_gemm_precision), both against float64, element by element relative to the
+    natural scale of the entry, sum_k |a_ik| |b_jk|: the split may be at most twice as far off as the f32 kernel."""
+    rng = np.random.default_rng(1000 * layout + M)
+    def heavy(r, c):
+        mag = np.exp(rng.normal(0.0, 3.5, size=(r, c)))               # sigma 3.5 nats = 1.5 decades: +-2 sigma spans six decades
+        return (mag * rng.choice([-1.0, 1.0], size=(r, c))).astype(np.float32)
+    A, Bm = heavy(M, K), heavy(N, K)
+    assert np.log10(np.abs(A).max(1) / np.abs(A).min(1)).min() > 6 and np.log10(np.abs(Bm).max(0) / np.abs(Bm).min(0)).min() > 6
+    a64, b64 = torch.from_numpy(A).cuda().double(), torch.from_numpy(Bm).cuda().double()
+    ref = a64 @ b64.T
+    scale = a64.abs() @ b64.abs().T
+    Ad = torch.from_numpy(A.T.copy() if layout == 2 else A).cuda()
+    Bd = torch.from_numpy(Bm.T.copy() if layout != 0 else Bm).cuda()
+    errs = {}
+    prev = lib.astk_get_gemm_precision()
+    lib.astk_set_gemm_bf16_split_below.restype = C.c_double
+    below = lib.astk_set_gemm_bf16_split_below(C.c_double(0.0))       # fp16x2 whatever the size
+    try:
+        for mode, name in ((0, "fp16x2"), (1, "bf16x3"), (2, "f32")):
+            assert lib.astk_set_gemm_precision(mode) >= 0
+            c = torch.empty(M, N, device="cuda")
+            ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(Ad), Ad.shape[1], vp(Bd), Bd.shape[1], vp(c), N, None, 0, 1, 1, 0, 0, 0, stream()))
+            assert bool(torch.isfinite(c).all())
+            errs[name] = float(((c.double() - ref).abs() / scale).max())
+    finally:
+        lib.astk_set_gemm_precision(prev)
+        lib.astk_set_gemm_bf16_split_below(C.c_double(below))
+    assert errs["f32"] < 2e-6, errs
+    assert errs["fp16x2"] <= 2.0 * errs["f32"], errs
+    assert errs["bf16x3"] <= 2.0 * errs["f32"], errs
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(7, 5, 3), (9, 6, 2), (33, 3, 7), (5, 3, 1), (130, 66, 19)])
 def test_gemm_maximum_in_the_ragged_tail(lib, layout, M, N, K, gemm_split):
     """The operand scales of the fp16x2 GEMMs come from an absolute-maximum pass that reads rows in float4 quads plus a scalar tail: an

@@ -432,3 +432,67 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did(monkeypatch, capsys):
     monkeypatch.delenv("WORLD_SIZE")
     bench.maybe_self_launch(types.SimpleNamespace(gpus=1), ["--gpus", "1"])
     assert len(calls) == 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# oracle/loader_ref.py: the reference's batch construction restated with injectable draws
+def test_loader_oracle_known_answers():
+    """Hand-derived: the bucket rule, frame zeroing with replacement, targets [GO] + ids[:max_pred-2] + [EOS] with UNK, truncation to
+    (num_b + 1) * width_b frames, zero padding, and the order of the `random` calls (one shuffle per bucket, then the batch list)."""
+    from oracle import loader_ref as LR
+    info = {"a": {"sp": 5}, "b": {"sp": 79}, "c": {"sp": 80}, "d": {"sp": 400}, "e": {"sp": 239}}
+    bk = LR.create_buckets(info, 3, 80, "sp", 1, "haha")
+    assert bk["buckets"] == [["a", "b"], ["c"], ["d", "e"]]                       # min(frames // 80, 2)
+    x = np.arange(20, dtype=np.float32).reshape(10, 2) + 1
+    out = LR.drop_frames(x, 0.35, choice=lambda n, k: [2, 2, 9][:k])               # int(.35 * 10) = 3 draws, one repeated
+    assert np.array_equal(np.where((out == 0).all(1))[0], [2, 9]) and np.array_equal(out[[0, 1, 3]], x[[0, 1, 3]])
+    assert LR.drop_frames(x, 0.05) is x                                           # int(.5) = 0: untouched
+
+    calls = []
+
+    class Scripted:                       # reverses every list it is asked to shuffle, and records what it saw
+        def shuffle(self, lst):
+            calls.append(list(lst) if isinstance(lst[0], str) else "batches")
+            lst.reverse()
+    speech = {u: np.full((info[u]["sp"], 2), i + 1, dtype=np.float32) for i, u in enumerate(info)}
+    vocab = {"w": {"w2i": {b"x": 4, b"y": 5}}}
+    mp = {"train": {u: {"w": [b"x", b"y", b"q", b"x", b"y", b"x"][:n]} for u, n in zip(info, (1, 6, 3, 2, 4))}}
+    ld = LR.RefLoader({"zero_input": 0.0, "dec_key": "w", "max_pred": 5}, {"train": bk}, vocab, mp, lambda u, k: speech[u], pyrandom=Scripted())
+    got = list(ld.get_batch(2, "train", True, labels=True))
+    assert calls == [["a", "b"], ["c"], ["d", "e"], "batches"]
+    assert [b["utts"] for b in got] == [["e", "d"], ["c"], ["b", "a"]]           # buckets reversed inside, batch list reversed
+    assert got[0]["X"].shape == (2, 320, 2)                                      # d: 400 frames truncated to (3 + 1) * 80
+    assert (got[0]["X"][0, :239] == 5).all() and not got[0]["X"][0, 239:].any() and (got[0]["X"][1] == 4).all()
+    assert got[2]["y"].tolist() == [[1, 4, 5, 3, 2], [1, 4, 2, 0, 0]]            # b: 6 words -> 3 kept (max_pred - 2), q -> UNK; a padded
+    assert got[2]["y"].dtype == np.int32 and got[0]["X"].dtype == np.float32
+
+
+@pytest.mark.parametrize("kind", ["fisher-flat", "globalphone"])
+def test_host_loaders_reproduce_the_loader_oracle(tmp_path, kind):
+    """The product's file loaders (host path) against the restated reference over two epochs, same seeds for Python's `random` and for
+    NumPy's global RNG (frame zeroing, zero_input = 0.1): identical batch order, utterances, zeroed frames, padding and targets."""
+    from ast_amd.dataloader import FisherDataLoader, GlobalPhoneDataLoader
+    from oracle import loader_ref as LR
+    info, mp, speech = _write_corpus(tmp_path, nested=False)
+    data = {"map_path": str(tmp_path / "map.dict"), "vocab_path": str(tmp_path / "vocab.dict"), "info_path": str(tmp_path / "info.dict"),
+            "speech_path": str(tmp_path / ("speech.blob" if kind == "globalphone" else "speech")), "buckets_num": 3, "buckets_width": 80,
+            "train_scale": 1, "dec_key": "bpe_w", "max_pred": 6, "zero_input": 0.1}
+    dl = (GlobalPhoneDataLoader if kind == "globalphone" else FisherDataLoader)(data, str(tmp_path), -1)
+    vocab = pickle.load(open(tmp_path / "vocab.dict", "rb"))
+    buckets = {k: LR.create_buckets(info[k], 3, 80, "sp", 1, "haha") for k in info}
+    assert buckets["fisher_train"]["buckets"] == dl.buckets["fisher_train"]["buckets"]
+    ref = LR.RefLoader(data, buckets, vocab, mp, lambda u, k: speech[k][u])
+    for set_key, train in (("fisher_train", True), ("fisher_dev", False)):
+        random.seed("seed-ast-20h")
+        np.random.seed(5)
+        want = [b for _ in range(2) for b in ref.get_batch(4, set_key, train, labels=True)]
+        random.seed("seed-ast-20h")
+        np.random.seed(5)
+        got = [b for _ in range(2) for b in dl.get_batch(4, set_key, train=train, labels=True)]
+        assert len(got) == len(want) > 1
+        zeroed = 0
+        for w, g in zip(want, got):
+            assert w["utts"] == g["utts"]
+            assert np.array_equal(w["X"], g["X"].numpy()) and np.array_equal(w["y"], g["y"].numpy())
+            zeroed += sum(int((w["X"][i, :info[set_key][u]["sp"]] == 0).all(1).sum()) for i, u in enumerate(w["utts"]))
+        assert (zeroed > 0) == train                                               # only "train" sets lose frames (dataloader.py:105)
