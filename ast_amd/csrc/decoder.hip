@@ -296,6 +296,58 @@ int cell_fwd(const DecPlan& P, const astk_decoder_params* prm, int l, const floa
   return lstm_cell_fwd_launch(&c, 1, s);
 }
 
+// ---- row split.  The persistent loop holds at most 32 batch rows at the shipped width (its cell, context and logits items own 16 rows
+// each and the grid is one workgroup per CU).  The decoder couples no batch rows -- weights and the 1/B of the loss are all two rows
+// share -- so a larger batch runs as TWO persistent launches over halves of its rows, each a complete call of this library on a
+// contiguous sub-problem (inputs that are not contiguous per half -- initial states, dropout masks -- are staged; `loss_rows` keeps the
+// cross-entropy mean over the WHOLE batch; parameter gradients accumulate).  3.1 ms for batch 64 instead of the per-launch loop.
+struct SplitPlan {
+  bool on;
+  astk_decoder_desc sub[2];
+  int off[2];
+  void* ws[2];
+  size_t wsb[2];
+  float *c0[2], *h0[2], *dc0[2], *dh0[2], *emb[2], *rnn[2];
+  int32_t* pred[2];
+  float* loss2;
+  size_t bytes;
+};
+int make_split(const astk_decoder_desc* d, void* ws, SplitPlan& sp) {
+  sp.on = false;
+  sp.bytes = 0;
+  if (!d || d->B < 2 || d->n_attn > 1 || d->no_feed_attn || d->ln || d->L < 2) return 0;
+  int ns = 1, ch = 1;
+  if (decoder_persist_applicable(d, &ns, &ch)) return 0;
+  const int B0 = ((d->B / 2 + 15) / 16) * 16;
+  if (B0 >= d->B) return 0;
+  const int Bs[2] = {B0, d->B - B0};
+  for (int i = 0; i < 2; ++i) {
+    sp.sub[i] = *d;
+    sp.sub[i].B = Bs[i];
+    sp.sub[i].loss_rows = d->loss_rows > 0 ? d->loss_rows : d->B;
+    sp.off[i] = i == 0 ? 0 : B0;
+    if (!decoder_persist_applicable(&sp.sub[i], &ns, &ch)) return 0;
+  }
+  Carver c(ws);
+  const size_t S = d->L - 1, H = d->H, E = d->E, nl = d->n_layers;
+  for (int i = 0; i < 2; ++i) {
+    DecPlan P;
+    ASTK_TRY(make_plan(&sp.sub[i], nullptr, P));
+    sp.wsb[i] = P.bytes;
+    sp.ws[i] = c.take<char>(P.bytes);
+    const size_t b = Bs[i];
+    sp.c0[i] = c.take<float>(nl * b * H); sp.h0[i] = c.take<float>(nl * b * H);
+    sp.dc0[i] = c.take<float>(nl * b * H); sp.dh0[i] = c.take<float>(nl * b * H);
+    sp.emb[i] = c.take<float>(S * b * E);
+    sp.rnn[i] = c.take<float>(nl * S * b * H);
+    sp.pred[i] = c.take<int32_t>(S * b);
+  }
+  sp.loss2 = c.take<float>(4);
+  sp.bytes = c.total();
+  sp.on = true;
+  return 0;
+}
+
 }  // namespace
 
 int softmax_ce_launch(int B, int V, long ld, float* logits, const int32_t* targets, long t_stride, const float* cw, float inv_count,
@@ -314,13 +366,20 @@ extern "C" {
 
 int astk_decoder_path(const astk_decoder_desc* d) {
   int ns = 1, ch = 1;
-  if (!d || !decoder_persist_applicable(d, &ns, &ch)) return 0;
+  if (!d) return 0;
+  if (!decoder_persist_applicable(d, &ns, &ch)) {
+    SplitPlan sp;
+    if (make_split(d, nullptr, sp) != 0 || !sp.on) return 0;
+    return astk_decoder_path(&sp.sub[0]) | 4;                                // two persistent launches over halves of the rows
+  }
   return 1 | ((d->H == 512 && ch <= 60) ? 2 : 0) | (d->n_layers << 8);      // (PDEC_CHUNK_MAX of decoder_persist.hip)
 }
 
 size_t astk_decoder_workspace_bytes(const astk_decoder_desc* d) {
   DecPlan P;
   if (make_plan(d, nullptr, P) != 0) return 0;
+  SplitPlan sp;
+  if (make_split(d, nullptr, sp) == 0 && sp.on && sp.bytes > P.bytes) return sp.bytes;     // (dropout.out keeps the per-launch layout: the larger of the two)
   return P.bytes;
 }
 
@@ -339,6 +398,30 @@ int astk_decoder_fwd_ex(const astk_decoder_desc* d, const astk_decoder_params* p
                         const int32_t* y, const int32_t* use_truth, const float* emb_mask, const float* rnn_masks, const float* out_mask,
                         const int32_t* targets, float* loss, int32_t* pred, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  {
+    SplitPlan sp;
+    ASTK_TRY(make_split(d, ws, sp));
+    if (sp.on && !out_mask) {
+      ASTK_CHECK(ws && ws_bytes >= sp.bytes, "decoder_fwd: workspace too small (%zu < %zu)", ws_bytes, sp.bytes);
+      ASTK_CHECK(prm && enc && c0 && h0 && y && use_truth && loss, "decoder_fwd: null pointer");
+      const int B = d->B, S = d->L - 1, H = d->H, E = d->E, nl = d->n_layers;
+      for (int i = 0; i < 2; ++i) {
+        const int b = sp.sub[i].B, off = sp.off[i];
+        // initial states (n_layers, B, H) and masks (.., S, B, X): rows of this half, staged contiguously
+        ASTK_TRY(copy2d_f32(sp.c0[i], (long)b * H, c0 + (size_t)off * H, (long)B * H, nl, b * H, b * H, s));
+        ASTK_TRY(copy2d_f32(sp.h0[i], (long)b * H, h0 + (size_t)off * H, (long)B * H, nl, b * H, b * H, s));
+        if (emb_mask) ASTK_TRY(copy2d_f32(sp.emb[i], (long)b * E, emb_mask + (size_t)off * E, (long)B * E, S, b * E, b * E, s));
+        if (rnn_masks) ASTK_TRY(copy2d_f32(sp.rnn[i], (long)b * H, rnn_masks + (size_t)off * H, (long)B * H, nl * S, b * H, b * H, s));
+        ASTK_TRY(astk_decoder_fwd_ex(&sp.sub[i], prm, enc + (size_t)off * d->T * H, sp.c0[i], sp.h0[i], y + (size_t)off * d->L, use_truth,
+                                     emb_mask ? sp.emb[i] : nullptr, rnn_masks ? sp.rnn[i] : nullptr, nullptr,
+                                     targets ? targets + (size_t)off * d->L : nullptr, sp.loss2 + i, pred ? sp.pred[i] : nullptr, sp.ws[i], sp.wsb[i], stream));
+        if (pred) ASTK_TRY(copy2d_f32((float*)pred + off, B, (const float*)sp.pred[i], b, S, b, b, s));      // (S, b) -> columns of (S, B); a bit copy
+      }
+      hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, s, sp.loss2, 2, loss);
+      ASTK_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   DecPlan P;
   ASTK_TRY(make_plan(d, ws, P));
   ASTK_CHECK(ws && ws_bytes >= P.bytes, "decoder_fwd: workspace too small (%zu < %zu)", ws_bytes, P.bytes);
@@ -437,7 +520,7 @@ int astk_decoder_fwd_ex(const astk_decoder_desc* d, const astk_decoder_params* p
     // dropout on the logits (seq2seq.py:394): argmax feedback and loss see the dropped logits; the gradient passes the same mask
     const float* om = out_mask ? out_mask + (size_t)st * B * V : nullptr;
     if (om) ASTK_TRY(mul_rows_launch(lg, P.Vp, om, V, B, V, s));
-    ASTK_TRY(softmax_ce_launch(B, V, P.Vp, lg, tgt + st + 1, P.L, prm->class_weight, 1.f / (float)B, P.LOSSROWS + (size_t)st * B,
+    ASTK_TRY(softmax_ce_launch(B, V, P.Vp, lg, tgt + st + 1, P.L, prm->class_weight, 1.f / (float)(d->loss_rows > 0 ? d->loss_rows : B), P.LOSSROWS + (size_t)st * B,
                                P.PRED + (size_t)st * B, s));
     if (om) ASTK_TRY(mul_rows_launch(lg, P.Vp, om, V, B, V, s));
   }
@@ -469,6 +552,26 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
   hipStream_t s = (hipStream_t)stream;
   (void)c0; (void)h0; (void)y;
   ASTK_CHECK(phase == ASTK_DEC_BWD_ALL || phase == ASTK_DEC_BWD_CHAIN || phase == ASTK_DEC_BWD_PARAMS, "decoder_bwd: bad phase %d", phase);
+  {
+    SplitPlan sp;
+    ASTK_TRY(make_split(d, ws, sp));
+    if (sp.on && !out_mask) {       // the two halves the forward call ran (their masks are still staged in the workspace)
+      ASTK_CHECK(ws && ws_bytes >= sp.bytes, "decoder_bwd: workspace too small");
+      ASTK_CHECK(prm && g && enc && d_enc && d_c0 && d_h0, "decoder_bwd: null pointer");
+      const int B = d->B, H = d->H, nl = d->n_layers;
+      for (int i = 0; i < 2; ++i) {
+        const int b = sp.sub[i].B, off = sp.off[i];
+        ASTK_TRY(astk_decoder_bwd_phase_ex(&sp.sub[i], prm, g, enc + (size_t)off * d->T * H, sp.c0[i], sp.h0[i], nullptr, emb_mask ? sp.emb[i] : nullptr,
+                                           rnn_masks ? sp.rnn[i] : nullptr, nullptr, d_enc + (size_t)off * d->T * H, sp.dc0[i], sp.dh0[i], sp.ws[i], sp.wsb[i],
+                                           phase, stream));
+        if (phase != ASTK_DEC_BWD_PARAMS) {
+          ASTK_TRY(copy2d_f32(d_c0 + (size_t)off * H, (long)B * H, sp.dc0[i], (long)b * H, nl, b * H, b * H, s));
+          ASTK_TRY(copy2d_f32(d_h0 + (size_t)off * H, (long)B * H, sp.dh0[i], (long)b * H, nl, b * H, b * H, s));
+        }
+      }
+      return 0;
+    }
+  }
   const bool do_chain = phase != ASTK_DEC_BWD_PARAMS, do_params = phase != ASTK_DEC_BWD_CHAIN;
   DecPlan P;
   ASTK_TRY(make_plan(d, ws, P));

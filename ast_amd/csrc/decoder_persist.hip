@@ -48,6 +48,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct PDecArgs {
   int B, S, L, T, Tp, H, E, A, V, Vp, XI, nbt, nsplit, chunk, ntile_v;
+  float inv_count;         // 1 / (rows in the cross-entropy mean): 1 / B, or 1 / (the whole batch) when this launch scores a slice of it
   const float *embed, *Wa, *ba, *Wc, *bc, *Wo, *bo, *cw;
   const float *Wu[PDEC_MAX_LAYERS], *bias[PDEC_MAX_LAYERS], *Wl[PDEC_MAX_LAYERS];     // per decoder layer
   const float* enc;
@@ -915,7 +916,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
         const int tgt = a.ytgt[(long)row * a.L + s + 1];
         const float w = a.cw ? a.cw[tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt)] : 1.f;
         a.LSE[(long)s * B + row] = lse;
-        a.LOSSROWS[(long)s * B + row] = -(xt - lse) * w / (float)B;
+        a.LOSSROWS[(long)s * B + row] = -(xt - lse) * w * a.inv_count;
         sti_sc1(a.PRED + (long)s * B + row, mi);
       }
       publish_sh(CTR(PH_CE, bt), 0);
@@ -1470,7 +1471,7 @@ __global__ __launch_bounds__(256) void k_decoder_post(const float* __restrict__ 
                                                       const int32_t* __restrict__ pred, const float* __restrict__ emb_mask, int32_t* __restrict__ tok_out,
                                                       float* __restrict__ x0, float* __restrict__ logits, const float* __restrict__ lse,
                                                       const float* __restrict__ cw, const float* __restrict__ lossrows, float* __restrict__ loss,
-                                                      int32_t* __restrict__ pred_out, int S, int B, int L, int E, int XI, int V, int Vp) {
+                                                      int32_t* __restrict__ pred_out, int S, int B, int L, int E, int XI, int V, int Vp, float inv_count) {
   const int r = blockIdx.x, s = r / B, b = r % B;
   {
     int tok = (s == 0 || use_truth[s]) ? y[(long)b * L + s] : pred[(long)(s - 1) * B + b];
@@ -1488,7 +1489,7 @@ __global__ __launch_bounds__(256) void k_decoder_post(const float* __restrict__ 
   {
     int t = ytgt[(long)b * L + s + 1];        // the class that was SCORED (y, or forward_loss's random_out replacement)
     t = t < 0 ? 0 : (t >= V ? V - 1 : t);
-    const float scale = (cw ? cw[t] : 1.f) / (float)B;
+    const float scale = (cw ? cw[t] : 1.f) * inv_count;
     const float ls = lse[r];
     float* x = logits + (long)r * Vp;
     for (int v = threadIdx.x; v < Vp; v += 256) {
@@ -1671,6 +1672,7 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
   a.B = d->B; a.S = d->L - 1; a.L = d->L; a.T = d->T; a.Tp = (d->T + 3) / 4 * 4; a.H = d->H; a.E = d->E; a.A = d->A; a.V = d->V;
   a.Vp = (d->V + 3) / 4 * 4; a.XI = d->E + d->A; a.nbt = (d->B + 15) / 16; a.nsplit = nsplit; a.chunk = chunk;
   a.ntile_v = (d->V + 15) / 16;
+  a.inv_count = 1.f / (float)(d->loss_rows > 0 ? d->loss_rows : d->B);
   a.embed = prm->embed;
   for (int l = 0; l < d->n_layers; ++l) {
     a.Wu[l] = prm->lstm[l].Wu; a.bias[l] = prm->lstm[l].b; a.Wl[l] = prm->lstm[l].Wl;
@@ -1709,7 +1711,7 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
   // Q[s][b][:] = Wa h_top + ba for all steps (needed by the backward's deferred d_enc product)
   ASTK_TRY(gemm_launch(GEMM_NT, gemm_args(a.S * a.B, a.H, a.H, mat(bf.CVH + a.H, 2 * a.H), mat(prm->Wa, a.H), bf.Q, a.H, prm->ba), s));
   hipLaunchKernelGGL(k_decoder_post, dim3(a.S * a.B), dim3(256), 0, s, prm->embed, y, ytgt ? ytgt : y, use_truth, bf.PRED, emb_mask, bf.TOK, bf.X0, bf.LOGITS, bf.LSE,
-                     prm->class_weight, bf.LOSSROWS, loss, pred_out, a.S, a.B, a.L, a.E, a.XI, a.V, a.Vp);
+                     prm->class_weight, bf.LOSSROWS, loss, pred_out, a.S, a.B, a.L, a.E, a.XI, a.V, a.Vp, a.inv_count);
   ASTK_LAUNCH_CHECK();
   return 0;
 }

@@ -194,6 +194,8 @@ typedef struct {
   int n_attn;        /* attention heads on the same decoder state (seq2seq.py:107-121, 381-383); 0 or 1 = one; context W is (A,(n_attn+1)H) */
   int no_feed_attn;  /* rnn_config.feed_attn = false (seq2seq.py:369-374): the decoder LSTM input is the embedding alone (layer-0 in = E) */
   int ln;            /* rnn_config.ln (seq2seq.py:141-143, 200-202): L.LayerNormalization(H) behind every decoder LSTM's dropped output */
+  int loss_rows;     /* denominator of the per-step cross-entropy mean (quirk Q6: the batch size); 0 = B.  Set when this call scores a
+                        SLICE of a larger batch (the library's own row split of batches the persistent loop cannot hold in one launch) */
 } astk_decoder_desc;
 
 typedef struct {
@@ -355,7 +357,9 @@ int astk_persist_status_snapshot(float* dst, void* stream);
 /* Which path a shape takes on the current device (so that a silent fall-back shows up in logs / bench.py's JSON line):
  *   astk_lstm_stack_path  1 = persistent wavefront kernels (all T steps of all cells in one launch), 0 = one fused-cell launch per step
  *   astk_decoder_path     0 = per-launch decoder loop; otherwise bit 0 = persistent loop, bit 1 = attention phase specialised for
- *                         H = 512 / chunk <= 32, bits 8.. = number of decoder layers fused into the persistent kernels */
+ *                         H = 512 / chunk <= 32, bit 2 = the batch runs as TWO persistent launches over halves of its rows (more than
+ *                         32 rows at the shipped width: the decoder couples no batch rows, the halves share nothing but the weights
+ *                         and the loss's 1/B), bits 8.. = number of decoder layers fused into the persistent kernels */
 int astk_lstm_stack_path(const astk_lstm_stack_desc* d);
 int astk_decoder_path(const astk_decoder_desc* d);
 int astk_persist_status(unsigned* mask_out, int reset);

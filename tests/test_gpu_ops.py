@@ -372,12 +372,17 @@ def _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=0):
                                                     # long utterances: T'' = 300 / 420 (1200 / 1680 frames) at batch 32 -- slices of 38 / 53 rows, of which
                                                     # 28 stay in LDS and the rest is streamed every step
                                                     (32, 5, 300, 512, 128, 512, 1098, 1, False), (32, 4, 420, 512, 128, 512, 1098, 3, True),
-                                                    (32, 4, 233, 512, 128, 512, 300, 1, True)])
+                                                    (32, 4, 233, 512, 128, 512, 300, 1, True),
+                                                    # more than 32 rows at the shipped width: two persistent launches over halves of the rows (row split:
+                                                    # 64 = 32 + 32, 48 = 32 + 16, 37 = 32 + 5; masks and initial states staged per half, loss over all rows)
+                                                    (64, 6, 200, 512, 128, 512, 1098, 1, True), (48, 5, 200, 512, 128, 512, 1098, 3, True),
+                                                    (37, 5, 50, 512, 128, 512, 300, 1, False)])
 def test_decoder_fwd_bwd(lib, B, L, T, H, E, A, V, nl, masks, gemm_split):
     from oracle.ast_ref_torch import decoder_torch
     s = _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=B + L)
     if H % 64 == 0 and A % 16 == 0 and E % 16 == 0 and nl <= 3:       # the shapes meant for the persistent kernels really take them
         assert lib.astk_decoder_path(C.byref(s["d"])) & 1, "persistent decoder path not taken"
+        assert bool(lib.astk_decoder_path(C.byref(s["d"])) & 4) == (B > 32 and H == 512), "row split"
     cfg = {"rnn_config": {"dec_layers": nl, "attn_units": A}}
     Pt = {k: torch.tensor(v, requires_grad=True) for k, v in s["P"].items()}
     enc_t = torch.tensor(s["enc"], requires_grad=True)
