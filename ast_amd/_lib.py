@@ -33,7 +33,7 @@ class CnnLayerGrads(C.Structure):
 
 class LstmStackDesc(C.Structure):
     _fields_ = [("T", C.c_int), ("B", C.c_int), ("in_dim", C.c_int), ("h", C.c_int),
-                ("n_layers", C.c_int), ("n_dirs", C.c_int)]
+                ("n_layers", C.c_int), ("n_dirs", C.c_int), ("out_bound", C.c_float), ("x_amax", C.c_void_p)]
 
 
 class LstmParams(C.Structure):
@@ -82,6 +82,7 @@ SIGNATURES = {
     "astk_conv_bn_relu_workspace_bytes": (_SZ, [C.POINTER(CnnDesc)]),
     "astk_conv_bn_relu_fwd": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(CnnLayerParams), _VP, _VP, _VP, _VP, _SZ, _I, _VP]),
     "astk_conv_bn_relu_bwd": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(CnnLayerParams), C.POINTER(CnnLayerGrads), _VP, _VP, _SZ, _VP]),
+    "astk_conv_out_amax": (C.c_void_p, [C.POINTER(CnnDesc), _VP, _SZ]),
     "astk_conv_debug_preact": (C.c_int, [C.POINTER(CnnDesc), _VP, _SZ, _I, _VP, _VP]),
     "astk_conv_debug_kill_units": (C.c_int, [_VP, _I]),
     # the exchange callback is passed as an opaque pointer (a ctypes CFUNCTYPE instance converts itself)

@@ -124,6 +124,25 @@ __device__ __forceinline__ float pow2_scale_for(float amax, float& inv) {
 }
 #endif
 
+#if defined(__HIPCC__)
+// Block-wide (256 threads) maximum of a per-thread NON-NEGATIVE value into a 16-word maximum slot: wave shuffles, 4 floats of LDS, then
+// ONE sharded 64-bit atomicMax -- skipped when the shard already holds as much (a plain load: after the first blocks have published a
+// large value most blocks skip, so the same-address atomics do not queue up).  Every thread of the block must call it.
+__device__ __forceinline__ void amax_emit_block(unsigned long long* slot, float m, float* red4) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red4[0], red4[1]), fmaxf(red4[2], red4[3]));
+    if (!(m <= 3.0e38f)) m = 3.0e38f;
+    unsigned long long* w = slot + ((blockIdx.x + blockIdx.y * gridDim.x) & 15);
+    const unsigned long long v = (unsigned long long)__float_as_uint(m);
+    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) atomicMax(w, v);
+  }
+}
+#endif
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -202,6 +221,13 @@ const unsigned long long* gemm_amax(const float* p, long rows, long ld, int inne
 // For a kernel that takes the maximum of a matrix while it writes it: n handles (16 sharded 64-bit words each) and the generation
 // tag; the kernel does atomicMax(slot + (block & 15), (u64)gen << 32 | float_bits(block maximum)) from every block.
 void gemm_amax_reserve(int n, unsigned long long** slots, unsigned* gen, hipStream_t s);
+// A matrix whose entries are bounded by construction (LSTM outputs: |h| < 1, times a dropout scale) needs no pass either: a handle to
+// a constant maximum `bound` (a power of two).  Cached per device; the first use of a bound enqueues its one-word initialisation on s.
+const unsigned long long* gemm_amax_bound(float bound, hipStream_t s);
+// Kernels that WRITE a matrix a later GEMM reads can take its maximum on the way (amax_emit_block below): the slot is 16 64-bit words
+// in the caller's workspace, zeroed before the producing kernel runs (the generation half of the word stays 0), and is handed to the
+// GEMM with with_amax_a / with_amax_b like any other handle.
+constexpr int AMAX_SLOT_WORDS = 16;
 struct AmaxMatrix { const float* p; long rows, ld; int inner; };
 void gemm_amax_many(const AmaxMatrix* m, int n, const unsigned long long** out, hipStream_t s);     // several matrices, one launch
 int low_precision_gemms();      // the mode set by astk_set_low_precision_gemms

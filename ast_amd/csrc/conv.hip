@@ -34,6 +34,17 @@ struct CnnPlan {
   float* Wr[ASTK_MAX_CNN_LAYERS];   // repacked weights (i=0: padded (C0,K0p); i>=1: (C_i, kt*C_{i-1}))
   double* stat[ASTK_MAX_CNN_LAYERS];  // per layer [2][C] column sums (double)
   size_t zero_fwd_bytes, zero_bwd_bytes;  // one fill from stat[0] zeroes the statistics of all layers (forward) / and the dWr scratch (backward)
+  // Absolute maxima (fp16x2 GEMM operand scales) taken by the kernels that WRITE the matrices, 16 words each (common.h amax_emit_block):
+  //   a_hp[i]  HP[i], the padded activations (K6's A operand, forward; the weight gradient's B operand)    written by k_bn_relu_rows
+  //   a_wr[i]  Wr[i], the re-packed weights (K6's B operand)                                                written by k_repack_w
+  //   a_out    the (T'',B,C*F') output = the LSTM stacks' frames (astk_conv_out_amax hands the address on)  written by k_bn_relu_to_seq
+  //   a_dy[i]  the padded dY (weight gradient + every stride phase of the input gradient)                   written by k_bn_bwd_apply
+  //   a_wd[k]  the phase weights of a grouped dgrad launch                                                  written by k_phase_w
+  // The forward slots sit in front of the statistics (zeroed by the forward fill, untouched by the backward one), the backward slots
+  // behind them (zeroed by the backward fill).
+  unsigned long long *a_hp[ASTK_MAX_CNN_LAYERS], *a_wr[ASTK_MAX_CNN_LAYERS], *a_out, *a_dy[ASTK_MAX_CNN_LAYERS], *a_wd[GEMM_GROUP_MAX];
+  void* zero_fwd_from;
+  size_t zero_fwd_amax_bytes;             // the forward slots alone (eval mode: no statistics to zero)
   float* bn[ASTK_MAX_CNN_LAYERS];   // [4][C]: mean, inv_std, scale, shift
   float* G;                         // [rows_max][Cmax] gradient wrt post-ReLU output (row layout)
   float* DY[ASTK_MAX_CNN_LAYERS];   // padded dY (i>=1) / plain dY (i=0)
@@ -102,13 +113,21 @@ int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
     }
   }
   // the buffers that have to be zero before use, back to back: ONE fill per pass instead of one per layer and buffer
+  const size_t off_afwd = align_up(c.off, 256);
+  for (int i = 0; i < P.n; ++i) { P.a_hp[i] = c.take<unsigned long long>(AMAX_SLOT_WORDS); P.a_wr[i] = c.take<unsigned long long>(AMAX_SLOT_WORDS); }
+  P.a_out = c.take<unsigned long long>(AMAX_SLOT_WORDS);
+  P.zero_fwd_from = ws ? (char*)ws + off_afwd : nullptr;
   const size_t off_stat = align_up(c.off, 256);
+  P.zero_fwd_amax_bytes = off_stat - off_afwd;
   for (int i = 0; i < P.n; ++i) P.stat[i] = c.take<double>(2 * (size_t)P.Cn[i]);
+  const size_t off_abwd = align_up(c.off, 256);
+  for (int i = 0; i < P.n; ++i) P.a_dy[i] = c.take<unsigned long long>(AMAX_SLOT_WORDS);
+  for (int k = 0; k < GEMM_GROUP_MAX; ++k) P.a_wd[k] = c.take<unsigned long long>(AMAX_SLOT_WORDS);
   const size_t off_dwr = align_up(c.off, 256);
   for (int i = 0; i < P.n; ++i)
     P.dWr[i] = c.take<float>(i == 0 ? (size_t)d->C[0] * P.K0p : (size_t)P.Cn[i] * d->kt[i] * P.Cn[i - 1]);
-  P.zero_fwd_bytes = off_dwr - off_stat;
-  P.zero_bwd_bytes = c.off - off_stat;
+  P.zero_fwd_bytes = off_abwd - off_afwd;       // forward: the forward slots and the statistics
+  P.zero_bwd_bytes = c.off - off_stat;          // backward: statistics, backward slots, dWr scratch
   P.G = c.take<float>(rowsmax_c);
   // one phase-weight buffer per stride phase of a grouped dgrad launch
   int st_max = 1;
@@ -145,14 +164,19 @@ __global__ __launch_bounds__(256) void k_im2col0(const float* __restrict__ X, co
 }
 
 // Wr[co][kt*Ci + ci] = W[co][ci][kt]   (W is (Co,Ci,KT,1))
-__global__ void k_repack_w(const float* __restrict__ W, float* __restrict__ Wr, int Co, int Ci, int KT) {
+__global__ __launch_bounds__(256) void k_repack_w(const float* __restrict__ W, float* __restrict__ Wr, int Co, int Ci, int KT, unsigned long long* amax) {
+  __shared__ float red4[4];
   const long n = (long)Co * Ci * KT;
+  float m = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int ci = (int)(i % Ci);
     const int k = (int)((i / Ci) % KT);
     const int co = (int)(i / ((long)Ci * KT));
-    Wr[i] = W[((long)co * Ci + ci) * KT + k];
+    const float v = W[((long)co * Ci + ci) * KT + k];
+    Wr[i] = v;
+    m = fmaxf(m, fabsf(v));
   }
+  if (amax) amax_emit_block(amax, m, red4);
 }
 // dW[co][ci][kt] += dWr[co][kt*Ci + ci]
 __global__ void k_unpack_dw(const float* __restrict__ dWr, float* __restrict__ dW, int Co, int Ci, int KT) {
@@ -165,15 +189,21 @@ __global__ void k_unpack_dw(const float* __restrict__ dWr, float* __restrict__ d
   }
 }
 // dgrad phase weight: Wd[ci][a*Co + co] = W[co][ci][kt = r + st*(na-1-a)]
-__global__ void k_phase_w(const float* __restrict__ W, float* __restrict__ Wd, int Co, int Ci, int KT, int r, int st, int na) {
+__global__ __launch_bounds__(256) void k_phase_w(const float* __restrict__ W, float* __restrict__ Wd, int Co, int Ci, int KT, int r, int st, int na,
+                                                 unsigned long long* amax) {
+  __shared__ float red4[4];
   const long n = (long)Ci * na * Co;
+  float m = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int co = (int)(i % Co);
     const int a = (int)((i / Co) % na);
     const int ci = (int)(i / ((long)Co * na));
     const int k = r + st * (na - 1 - a);
-    Wd[i] = W[((long)co * Ci + ci) * KT + k];
+    const float v = W[((long)co * Ci + ci) * KT + k];
+    Wd[i] = v;
+    m = fmaxf(m, fabsf(v));
   }
+  if (amax) amax_emit_block(amax, m, red4);
 }
 
 // column sums of Y and Y^2 ( -> double atomics ), colreduce_block skeleton
@@ -245,10 +275,12 @@ __global__ void k_bias_grad(const double* __restrict__ stat, int C, float* __res
 }
 
 // dst[prow(m)][c] = relu(Y[m][c]*scale + shift), prow(m) = (m/Tn)*(Tn+2*pad) + pad + m%Tn  (float4 over channels)
-__global__ void k_bn_relu_rows(const float* __restrict__ Y, const float* __restrict__ bn, float* __restrict__ dst, int rows, int C,
-                               int Tn, int pad) {
+__global__ __launch_bounds__(256) void k_bn_relu_rows(const float* __restrict__ Y, const float* __restrict__ bn, float* __restrict__ dst, int rows, int C,
+                                                      int Tn, int pad, unsigned long long* amax) {
+  __shared__ float red4[4];
   const long n4 = (long)rows * C / 4;
   const int C4 = C / 4;
+  float mx = 0.f;           // (post-ReLU values: non-negative)
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const int m = (int)(i / C4), c = (int)(i % C4) * 4;
     const float4 y = *reinterpret_cast<const float4*>(Y + (long)m * C + c);
@@ -259,23 +291,30 @@ __global__ void k_bn_relu_rows(const float* __restrict__ Y, const float* __restr
     o.z = fmaxf(y.z * sc.z + sh.z, 0.f); o.w = fmaxf(y.w * sc.w + sh.w, 0.f);
     const long pr = (long)(m / Tn) * (Tn + 2 * pad) + pad + (m % Tn);
     *reinterpret_cast<float4*>(dst + pr * C + c) = o;
+    mx = fmaxf(fmaxf(mx, fmaxf(o.x, o.y)), fmaxf(o.z, o.w));
   }
+  if (amax) amax_emit_block(amax, mx, red4);
 }
 
 // out[t][b][c*F+f] = relu(bn(Y[(b,f,t)][c]))  -- one block per (t, b); LDS re-orders (f,c) -> (c,f)
 __global__ __launch_bounds__(256) void k_bn_relu_to_seq(const float* __restrict__ Y, const float* __restrict__ bn, float* __restrict__ out,
-                                                        int B, int F, int Tn, int C) {
+                                                        int B, int F, int Tn, int C, unsigned long long* amax) {
   extern __shared__ float tile[];   // [C*F]
+  __shared__ float red4[4];
   const int t = blockIdx.x, b = blockIdx.y;
   const int n = C * F;
+  float mx = 0.f;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int f = i / C, c = i % C;
     const float y = Y[(((long)b * F + f) * Tn + t) * C + c];
-    tile[c * F + f] = fmaxf(y * bn[2 * C + c] + bn[3 * C + c], 0.f);
+    const float v = fmaxf(y * bn[2 * C + c] + bn[3 * C + c], 0.f);
+    tile[c * F + f] = v;
+    mx = fmaxf(mx, v);
   }
   __syncthreads();
   float* o = out + ((long)t * B + b) * n;
   for (int i = threadIdx.x; i < n; i += blockDim.x) o[i] = tile[i];
+  if (amax) amax_emit_block(amax, mx, red4);
 }
 // G[(b,f,t)][c] = d_out[t][b][c*F+f]
 __global__ __launch_bounds__(256) void k_seq_to_rows(const float* __restrict__ d_out, float* __restrict__ G, int B, int F, int Tn, int C) {
@@ -312,11 +351,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_stats(const float* __restrict__ 
       [&](int col, int st, float v) { atomicAdd(&stat[st * C + col], (double)v); });
 }
 // dY[prow(m)][c] = scale*(g - (xhat*dgamma + dbeta)/rows) ; also accumulates dgamma/dbeta (block 0)
-__global__ void k_bn_bwd_apply(const float* __restrict__ Y, const float* __restrict__ G, const float* __restrict__ bn,
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ Y, const float* __restrict__ G, const float* __restrict__ bn,
                                const double* __restrict__ stat, float* __restrict__ dY, int rows, int C, int Tn, int padF, int padB,
-                               float* __restrict__ dgamma, float* __restrict__ dbeta, float invm) {
+                               float* __restrict__ dgamma, float* __restrict__ dbeta, float invm, unsigned long long* amax) {
+  __shared__ float red4[4];
   const int C4 = C / 4;   // C % 4 == 0 (checked by the launcher)
   const long n4 = (long)rows * C4;
+  float mx = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const int m = (int)(i / C4), c = (int)(i % C4) * 4;
     const float4 mean = *reinterpret_cast<const float4*>(bn + c), inv = *reinterpret_cast<const float4*>(bn + C + c);
@@ -331,7 +372,9 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ Y, const float* __restr
     v.w = sc.w * (((y.w * sc.w + sh.w > 0.f) ? gr.w : 0.f) - ((y.w - mean.w) * inv.w * dg3 + db3) * invm);
     const long pr = (long)(m / Tn) * (Tn + padF + padB) + padF + (m % Tn);
     *reinterpret_cast<float4*>(dY + pr * C + c) = v;
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
+  if (amax) amax_emit_block(amax, mx, red4);
   if (blockIdx.x == 0 && dgamma)
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       dgamma[c] += (float)stat[C + c];
@@ -426,6 +469,8 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
   ASTK_CHECK(ws && ws_bytes >= P.bytes, "conv_bn_relu_fwd: workspace too small (%zu < %zu)", ws_bytes, P.bytes);
   ASTK_CHECK(X && out && L, "conv_bn_relu_fwd: null pointer");
   const int B = P.B, F = P.F;
+  // the statistics of every layer (train) and the maximum slots the producing kernels fill: one fill
+  ASTK_TRY(fill_zero(P.zero_fwd_from, train ? P.zero_fwd_bytes : P.zero_fwd_amax_bytes, s));
   // ---- layer 0: im2col + GEMM
   hipLaunchKernelGGL(k_im2col0, dim3(P.Tn[0], B), dim3(256), 0, s, X, noise, P.P0, B, P.T, P.D, F, P.Tn[0], d->kt[0], d->kf[0],
                      d->st[0], d->sf[0], d->pt[0], P.K0p);
@@ -436,12 +481,13 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
     const int C = P.Cn[i], rows = P.rows[i];
     if (i > 0) {
       const int Ci = P.Cn[i - 1], KT = d->kt[i];
-      hipLaunchKernelGGL(k_repack_w, dim3(gridn((size_t)C * Ci * KT)), dim3(256), 0, s, L[i].W, P.Wr[i], C, Ci, KT);
+      hipLaunchKernelGGL(k_repack_w, dim3(gridn((size_t)C * Ci * KT)), dim3(256), 0, s, L[i].W, P.Wr[i], C, Ci, KT, P.a_wr[i]);
       ASTK_LAUNCH_CHECK();
       const long prow = (long)(P.Tn[i - 1] + 2 * P.padA[i - 1]) * Ci;
       GemmArgs g = gemm_args(rows, C, KT * Ci, mat2(P.HP[i - 1], P.Tn[i], prow, (long)d->st[i] * Ci), mat(P.Wr[i], (long)KT * Ci),
                              P.Y[i], C);
-      ASTK_TRY(gemm_launch(GEMM_NT, lowp(g), s));            // K6
+      // (both operands' maxima were taken by the kernels that wrote them: no absolute-maximum pass in front of this launch)
+      ASTK_TRY(gemm_launch(GEMM_NT, with_amax_b(with_amax_a(lowp(g), P.a_hp[i - 1]), P.a_wr[i]), s));            // K6
     }
     // ---- batch statistics -> scale/shift
     if (d->no_bn) {
@@ -450,7 +496,6 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
       ASTK_LAUNCH_CHECK();
     } else {
     if (train) {
-      if (i == 0) ASTK_TRY(fill_zero(P.stat[0], P.zero_fwd_bytes, s));   // the statistics of every layer
       hipLaunchKernelGGL(k_colstats, colreduce_grid(rows, C), dim3(256), 0, s, P.Y[i], rows, C, P.stat[i]);
       ASTK_LAUNCH_CHECK();
       if (exchange) ASTK_CHECK(exchange(user, P.stat[i], 2 * C, stream) == 0, "conv_bn_relu_fwd: statistics exchange failed (layer %d)", i);
@@ -466,16 +511,22 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
         ASTK_LAUNCH_CHECK();
       }
       hipLaunchKernelGGL(k_bn_relu_rows, dim3(gridn((size_t)rows * C / 4)), dim3(256), 0, s, P.Y[i], P.bn[i], P.HP[i], rows, C,
-                         P.Tn[i], P.padA[i]);
+                         P.Tn[i], P.padA[i], P.a_hp[i]);
       ASTK_LAUNCH_CHECK();
     } else {
       const size_t shm = (size_t)C * F * sizeof(float);
       ASTK_CHECK(shm <= 64 * 1024, "cnn: C*F' too large for the re-layout tile (%zu bytes)", shm);
-      hipLaunchKernelGGL(k_bn_relu_to_seq, dim3(P.Tn[i], B), dim3(256), shm, s, P.Y[i], P.bn[i], out, B, F, P.Tn[i], C);
+      hipLaunchKernelGGL(k_bn_relu_to_seq, dim3(P.Tn[i], B), dim3(256), shm, s, P.Y[i], P.bn[i], out, B, F, P.Tn[i], C, P.a_out);
       ASTK_LAUNCH_CHECK();
     }
   }
   return 0;
+}
+
+const void* astk_conv_out_amax(const astk_cnn_desc* d, void* ws, size_t ws_bytes) {
+  CnnPlan P;
+  if (make_plan(d, ws, P) != 0 || !ws || ws_bytes < P.bytes) return nullptr;
+  return P.a_out;
 }
 
 int astk_conv_debug_preact(const astk_cnn_desc* d, void* ws, size_t ws_bytes, int layer, float* out, void* stream) {
@@ -539,7 +590,7 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
     // (no_bn: the ReLU mask alone -- scale 1 and a zero 1/m switch the BatchNorm terms off; the column sums of g are the bias gradient)
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(gridn((size_t)rows * C / 4)), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], P.stat[i], P.DY[i], rows, C,
                        P.Tn[i], P.dF[i], P.dB[i], (exchange || d->no_bn) ? nullptr : Gr[i].dgamma, (exchange || d->no_bn) ? nullptr : Gr[i].dbeta,
-                       d->no_bn ? 0.f : 1.f / ((float)rows * (exchange ? world : 1)));
+                       d->no_bn ? 0.f : 1.f / ((float)rows * (exchange ? world : 1)), i > 0 ? P.a_dy[i] : nullptr);
     ASTK_LAUNCH_CHECK();
     if (d->no_bn) {
       ASTK_CHECK(Gr[i].dbias, "conv_bn_relu_bwd: no_bn needs a bias gradient (layer %d)", i);
@@ -555,14 +606,15 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
       const int Ci = P.Cn[i - 1], KT = d->kt[i], st = d->st[i], pt = d->pt[i];
       const long dyrow = (long)Tp * C;                                  // per (b,f) group of the padded dY
       const long hprow = (long)(P.Tn[i - 1] + 2 * P.padA[i - 1]) * Ci;  // per (b,f) group of HP[i-1]
-      // the padded dY feeds the weight gradient and every stride phase of the input gradient: one absolute-maximum pass (fp16x2 GEMM scale)
-      const unsigned long long* ady = gemm_amax(P.DY[i], (long)B * F, dyrow, (int)dyrow, s);
+      // the padded dY feeds the weight gradient and every stride phase of the input gradient: its maximum (fp16x2 GEMM scale) was taken
+      // by k_bn_bwd_apply when it wrote it; the activations' by k_bn_relu_rows in the forward pass
+      const unsigned long long* ady = P.a_dy[i];
       // ---- wgrad: dWr[co][kt*Ci+ci] = sum_rows DY[row][co] * window(row)[k]
       {
         MatView A = mat2(P.DY[i] + (long)P.dF[i] * C, P.Tn[i], dyrow, C);
         MatView Bm = mat2(P.HP[i - 1], P.Tn[i], hprow, (long)st * Ci);
         const long tiles = (long)cdiv(C, 128) * cdiv(KT * Ci, 128);
-        ASTK_TRY(gemm_launch(GEMM_TN, with_amax_a(lowp(gemm_args(C, KT * Ci, rows, A, Bm, P.dWr[i], (long)KT * Ci, nullptr, GEMM_ATOMIC, ksplit_for(tiles, rows))), ady), s));
+        ASTK_TRY(gemm_launch(GEMM_TN, with_amax_b(with_amax_a(lowp(gemm_args(C, KT * Ci, rows, A, Bm, P.dWr[i], (long)KT * Ci, nullptr, GEMM_ATOMIC, ksplit_for(tiles, rows))), ady), P.a_hp[i - 1]), s));
       }
       hipLaunchKernelGGL(k_unpack_dw, dim3(gridn((size_t)C * Ci * KT)), dim3(256), 0, s, P.dWr[i], Gr[i].dW, C, Ci, KT);
       ASTK_LAUNCH_CHECK();
@@ -579,7 +631,7 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
         const int q0 = (rho + pt) / st;
         if (nph == P.wd_copies) { ASTK_TRY(gemm_launch_group(GEMM_NT, ph, nph, s)); nph = 0; }      // (more phases than buffers: flush)
         float* wd = P.Wd + (size_t)nph * P.wd_stride;
-        hipLaunchKernelGGL(k_phase_w, dim3(gridn((size_t)Ci * na * C)), dim3(256), 0, s, L[i].W, wd, C, Ci, KT, r, st, na);
+        hipLaunchKernelGGL(k_phase_w, dim3(gridn((size_t)Ci * na * C)), dim3(256), 0, s, L[i].W, wd, C, Ci, KT, r, st, na, P.a_wd[nph]);
         ASTK_LAUNCH_CHECK();
         const long start = (long)(q0 - na + 1 + P.dF[i]);
         ASTK_CHECK(start >= 0, "cnn dgrad: negative window start");
@@ -588,7 +640,8 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
         g.c_tn = nj;
         g.c_sg = (long)P.Tn[i - 1] * Ci;
         g.c_st = (long)st * Ci;
-        ph[nph++] = with_amax_a(lowp(g), ady);
+        ph[nph] = with_amax_b(with_amax_a(lowp(g), ady), P.a_wd[nph]);
+        ++nph;
       }
       if (nph > 0) ASTK_TRY(gemm_launch_group(GEMM_NT, ph, nph, s));
     }

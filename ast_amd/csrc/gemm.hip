@@ -1236,6 +1236,31 @@ void gemm_amax_reserve(int n, unsigned long long** slots, unsigned* gen, hipStre
     slots[i] = on ? ring + AMAX_SLOTS / 2 + (g_amax_handle.fetch_add(1) % (AMAX_SLOTS / 2 / AMAX_SHARDS)) * AMAX_SHARDS : nullptr;
 }
 
+// constant maxima (bounded matrices): 8 slots of 16 words; word 0 of a slot holds the bound, the others stay 0
+__device__ unsigned long long g_amax_bounds[8 * AMAX_SLOT_WORDS];
+__global__ void k_set_u64(unsigned long long* p, unsigned long long v) { *p = v; }
+const unsigned long long* gemm_amax_bound(float bound, hipStream_t s) {
+  if (default_prec() != PREC_F16X2 && low_precision_gemms() == 0) return nullptr;
+  static std::mutex mu;
+  static float cached[16][8];          // per device: the bound each slot holds (0 = free)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  unsigned long long* base = nullptr;
+  if (hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_amax_bounds)) != hipSuccess || !base) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < 8; ++i) {
+    if (cached[dev][i] == bound) return base + i * AMAX_SLOT_WORDS;
+    if (cached[dev][i] == 0.f) {
+      unsigned bits;
+      memcpy(&bits, &bound, 4);
+      hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, s, base + i * AMAX_SLOT_WORDS, (unsigned long long)bits);
+      cached[dev][i] = bound;
+      return base + i * AMAX_SLOT_WORDS;
+    }
+  }
+  return nullptr;                      // (more than 8 distinct bounds: the caller's launch measures the matrix itself)
+}
+
 const unsigned long long* gemm_amax(const float* p, long rows, long ld, int inner, hipStream_t s) {
   const AmaxMatrix m = {p, rows, ld, inner};
   const unsigned long long* h = nullptr;

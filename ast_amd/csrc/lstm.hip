@@ -156,14 +156,16 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
     memset(cells, 0, sizeof(cells));
     // maxima (fp16x2 GEMM scales) of the frames -- both directions multiply the same ones -- and of the two layer-0 upward weights in
     // ONE launch: the grouped projection launch below then needs no maximum pass of its own
-    const unsigned long long* ax = nullptr;
+    // (the frames' maximum comes with them when the caller passes it on from the kernel that wrote them: desc.x_amax)
+    const unsigned long long* ax = (const unsigned long long*)d->x_amax;
     const unsigned long long* aw0[2] = {nullptr, nullptr};
     {
-      AmaxMatrix am[3] = {{x, (long)T * B, (long)P.in, P.in}, {prm[0].Wu, 4L * h, (long)P.in, P.in},
+      AmaxMatrix am[3] = {{ax ? nullptr : x, (long)T * B, (long)P.in, P.in}, {prm[0].Wu, 4L * h, (long)P.in, P.in},
                           {P.nd > 1 ? prm[P.nl].Wu : nullptr, 4L * h, (long)P.in, P.in}};
       const unsigned long long* out[3];
       gemm_amax_many(am, 3, out, s);
-      ax = out[0]; aw0[0] = out[1]; aw0[1] = out[2];
+      if (!ax) ax = out[0];
+      aw0[0] = out[1]; aw0[1] = out[2];
     }
     GemmArgs k9[2];      // the layer-0 upward projections of both directions: one grouped launch
     for (int dd = 0; dd < P.nd; ++dd) {
@@ -349,15 +351,18 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
   int nwg = 0;
   // Absolute maxima (fp16x2 GEMM scales) of the matrices that feed several products: the frames (B operand of both directions'
   // layer-0 dWu) by a pass here, every cell's dz (dWl, dWu, input gradient) by the recurrence kernel itself on the persistent path.
-  const unsigned long long* ax = nullptr;
+  const unsigned long long* ax = (const unsigned long long*)d->x_amax;
   const unsigned long long* aw0[2] = {nullptr, nullptr};
   {
-    AmaxMatrix am[3] = {{x, (long)T * B, (long)P.in, P.in}, {dx ? prm[0].Wu : nullptr, 4L * h, (long)P.in, P.in},
+    AmaxMatrix am[3] = {{ax ? nullptr : x, (long)T * B, (long)P.in, P.in}, {dx ? prm[0].Wu : nullptr, 4L * h, (long)P.in, P.in},
                         {dx && P.nd > 1 ? prm[P.nl].Wu : nullptr, 4L * h, (long)P.in, P.in}};
     const unsigned long long* out[3];
     gemm_amax_many(am, 3, out, s);
-    ax = out[0]; aw0[0] = out[1]; aw0[1] = out[2];
+    if (!ax) ax = out[0];
+    aw0[0] = out[1]; aw0[1] = out[2];
   }
+  // the layer outputs are bounded by construction (|h| < 1, times the dropout scale): no pass over them either
+  const unsigned long long* ahb = d->out_bound > 0.f ? gemm_amax_bound(exp2f(ceilf(log2f(d->out_bound))), s) : nullptr;
   const unsigned long long* adz_all[16] = {nullptr};
   if (persist)
     for (int i = 0; i < P.nd * P.nl; ++i) adz_all[i] = dz_amax[i];
@@ -410,7 +415,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
       // dWl (4h,h) += sum_{i>=1} dz_i^T h_{i-1}
       if (T > 1) {
         if (nwg == GEMM_GROUP_MAX) { ASTK_TRY(gemm_launch_group(GEMM_TN, wg, nwg, s)); nwg = 0; }
-        wg[nwg++] = with_amax_a(gemm_args(4 * h, h, rows - B, mat(dz + (size_t)B * 4 * h, 4 * h), mat(P.HR[dd][l], h), g.dWl, h, nullptr, GEMM_ATOMIC, 1), adz);
+        wg[nwg++] = with_amax_b(with_amax_a(gemm_args(4 * h, h, rows - B, mat(dz + (size_t)B * 4 * h, 4 * h), mat(P.HR[dd][l], h), g.dWl, h, nullptr, GEMM_ATOMIC, 1), adz), ahb);
       }
       // dWu (4h,in) += dz^T X   (reverse stack, layer 0: dz is first re-ordered to frame order, sum_i dz_i^T x[perm i] = sum_f dz[inv f]^T x_f)
       {
@@ -430,7 +435,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
           ASTK_TRY(gemm_launch(GEMM_TN, with_amax_b(with_amax_a(lowp(gemm_args(4 * h, in, rows, mat(dzu, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, 1)), adz), l == 0 ? ax : nullptr), s));
         } else {
           if (nwg == GEMM_GROUP_MAX) { ASTK_TRY(gemm_launch_group(GEMM_TN, wg, nwg, s)); nwg = 0; }
-          wg[nwg++] = with_amax_b(with_amax_a(gemm_args(4 * h, in, rows, mat(dzu, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, 1), adz), l == 0 ? ax : nullptr);
+          wg[nwg++] = with_amax_b(with_amax_a(gemm_args(4 * h, in, rows, mat(dzu, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, 1), adz), l == 0 ? ax : ahb);
         }
       }
       ASTK_TRY(cb.add(g.db, dz, 4 * h, rows, 4 * h, s));

@@ -347,6 +347,10 @@ class SpeechEncoderDecoder:
                 cp[i].bias, cg[i].dbias = a.p(n + "/b"), a.g(n + "/b")
         nl, nd, h, H = len(self.rnn_enc), self.n_dirs, self.h, self.H
         ld = LstmStackDesc(T2, B, feat, h, nl, nd)
+        # hints that spare the GEMMs absolute-maximum passes (include/astk.h): the layer outputs are bounded by the dropout scale; the
+        # frames' maximum is taken by the CNN kernel that writes them (set per call in encode(): it lives in the CNN workspace)
+        ratio = float(self.cfg["dropout"]["rnn"])
+        ld.out_bound = 1.0 / (1.0 - ratio) if 0 <= ratio < 1 else 0.0
         lp = (LstmParams * (nl * nd))()
         lg = (LstmGrads * (nl * nd))()
         for d_, names in enumerate([self.rnn_enc, self.rnn_rev_enc][:nd]):
@@ -455,6 +459,7 @@ class SpeechEncoderDecoder:
         st["bn_world"] = 1 if sx is None else sx.world
         if config.train:
             self.bn_N += 1
+        st["ld"].x_amax = lib.astk_conv_out_amax(C.byref(st["cd"]), _vp(wc), wc.numel())      # (None for bad arguments: the GEMM measures x itself)
         if self.enc_variant is not None:                     # rnn_config.ln / linear_proj: layer-by-layer (ast_amd/enc_variants.py)
             if self.rnn_linear_proj:
                 self.enc_variant.forward(st, bool(config.train))

@@ -108,6 +108,10 @@ int astk_conv_bn_relu_fwd(const astk_cnn_desc* d, const astk_cnn_layer_params* l
 /* d_out (T'',B,C_last*F') is overwritten.  Gradients are ACCUMULATED into grads (caller zeroes = cleargrads). */
 int astk_conv_bn_relu_bwd(const astk_cnn_desc* d, const astk_cnn_layer_params* layers,
                           const astk_cnn_layer_grads* grads, float* d_out, void* ws, size_t ws_bytes, void* stream);
+/* Where the forward call leaves the absolute maximum of `out` (16 64-bit words inside ws; taken by the kernel that writes `out`):
+ * pass it on as astk_lstm_stack_desc.x_amax.  Valid from the forward call until ws is reused.  NULL: bad arguments. */
+const void* astk_conv_out_amax(const astk_cnn_desc* d, void* ws, size_t ws_bytes);
+
 /* Test instrumentation (tests/test_gpu_model.py, the batch-permutation property).  astk_conv_debug_preact: after a forward call, out
  * [(b,f,t)][c] = the post-BatchNorm pre-activation of `layer` (what the ReLU sees), rows = B*F'*T_layer.  astk_conv_debug_kill_units:
  * the following backward calls of this process zero the upstream gradient of the listed units (n triples layer, row, channel in
@@ -137,6 +141,12 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
  * and its outputs are flipped before the concat, so enc_states[b,p,h:2h] is what seq2seq.py:231-242 builds. */
 typedef struct {
   int T, B, in_dim, h, n_layers, n_dirs;
+  /* Optional hints that spare the f32-accurate GEMMs their absolute-maximum passes (0 / NULL: every launch measures its operands):
+   *   out_bound  an upper bound of |layer output| as the next layer and the weight-gradient products read it: 1 without dropout
+   *              (|h| < 1), 1 / (1 - ratio) with the masks of astk_fill_dropout_mask;
+   *   x_amax     the maximum words of the input frames x, as left by the kernel that wrote them (astk_conv_out_amax). */
+  float out_bound;
+  const void* x_amax;
 } astk_lstm_stack_desc;
 
 typedef struct {
