@@ -112,9 +112,28 @@ class DataLoader:
         return np.asarray([SYMBOLS.GO_ID] + ids[:max_pred - 2] + [SYMBOLS.EOS_ID], dtype=np.int32)
 
     def batch_plan(self, batch_size, set_key):
-        """The shuffled list of (utterances, bucket width) -- consumes the seeded `random` stream exactly like the reference."""
+        """The shuffled list of (utterances, bucket width) -- consumes the seeded `random` stream exactly like the reference.
+        `batch_size` may also be the OLD path's dict {'max', 'med', 'min'} (+ optional 'curriculum'), nmt_run.py:406-447 create_batches:
+        the first third of the buckets (short utterances) is cut into batches of 'max', the second third of 'med', the rest of 'min';
+        the BUCKET order is shuffled first (one more `random.shuffle`), or kept ascending for a curriculum, in which case the batch
+        list is not shuffled either."""
         bk = self.buckets[set_key]
         plan = []
+        if isinstance(batch_size, dict):
+            num_b = bk["num_b"]
+            order = list(range(num_b))
+            curriculum = bool(batch_size.get("curriculum", False))
+            if not curriculum:
+                random.shuffle(order)
+            for b in order:
+                size = int(batch_size["max"] if b < num_b // 3 else batch_size["med"] if b < (num_b * 2) // 3 else batch_size["min"])
+                bucket = bk["buckets"][b]
+                random.shuffle(bucket)
+                for i in range(0, len(bucket), size):
+                    plan.append((bucket[i:i + size], (b + 1) * bk["width_b"]))
+            if not curriculum:
+                random.shuffle(plan)
+            return plan
         for b, bucket in enumerate(bk["buckets"]):
             random.shuffle(bucket)
             for i in range(0, len(bucket), batch_size):

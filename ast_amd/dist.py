@@ -47,6 +47,24 @@ def barrier():
         td.barrier()
 
 
+def reserve_cus_for_recurrence(need_cus, n_cu=256):
+    """Call BEFORE init(): caps RCCL's channel count so that its kernels and the persistent recurrence grids fit the device together.
+    An RCCL kernel occupies one CU per channel until every peer has arrived; the persistent encoder / decoder kernels need
+    `need_cus` workgroups resident at once (one per CU; 192 for the shipped encoder at batch 32, 256 for the decoder loop, which
+    therefore never overlaps a collective: ast_amd/seq2seq.py launches the all-reduces behind the recurrences).  With
+    NCCL_MAX_NCHANNELS <= n_cu - need_cus a collective that is still waiting for a late peer when the NEXT step's encoder recurrence
+    starts cannot keep it from becoming resident.  An explicit NCCL_MAX_NCHANNELS in the environment is respected (and checked).
+    Returns the cap in force."""
+    free = max(int(n_cu) - int(need_cus), 4)
+    cur = os.environ.get("NCCL_MAX_NCHANNELS")
+    if cur is None:
+        os.environ["NCCL_MAX_NCHANNELS"] = str(min(free, 32))
+    elif int(cur) > free:
+        raise RuntimeError(f"NCCL_MAX_NCHANNELS={cur} leaves fewer than the {need_cus} CUs the persistent recurrence grid needs "
+                           f"({n_cu} CUs): set it to {free} or less")
+    return int(os.environ["NCCL_MAX_NCHANNELS"])
+
+
 def allreduce_flat(buf):
     """In-place mean of one flat buffer over all ranks."""
     if not is_distributed():

@@ -230,6 +230,24 @@ class SpeechEncoderDecoder:
             self.enc_variant = LayerNormEncoder(self)
         return self
 
+    def add_weight_noise(self, mu, sigma):
+        """The OLD path's Gaussian weight noise (enc_dec.py:587-624, driven per epoch by nmt_run.py:850-853): N(mu, sigma) added, in place, to
+        every LSTM's upward W and b and lateral W (encoder, reverse encoder, decoder) and to the decoder embedding.  Drawn on the
+        device (the reference's draw is the unseeded global RNG, quirk Q7); inject['weight_noise'] = {name: tensor} replays given draws."""
+        lib = self._require_gpu()
+        names = []
+        for n in self.rnn_enc + self.rnn_rev_enc + self.rnn_dec:
+            names += [n + "/upward/W", n + "/upward/b", n + "/lateral/W"]
+        names.append("embed_dec/W")
+        for name in names:
+            w = self.arena.views[name]
+            if "weight_noise" in self.inject:
+                z = self.inject["weight_noise"][name].to(self.device, torch.float32).contiguous()
+            else:
+                z = self._pool("weight_noise", (w.numel() + (w.numel() & 1),))[:w.numel()]
+                check(lib.astk_fill_normal(_vp(z), w.numel(), float(mu), float(sigma), self.rng_seed ^ 0x5EED0015E, self._rng(w.numel() + 1), self._stream()))
+            check(lib.astk_add_f32(_vp(w), _vp(z), w.numel(), self._stream()))
+
     def paths(self):
         """Which kernels this model's train step takes (bench.py / logs): the optional features leave the persistent kernels."""
         opts = [n for n, on in (("ln", self.rnn_ln), ("linear_proj", self.rnn_linear_proj), (f"n_attn={self.n_attn}", self.n_attn > 1),

@@ -160,9 +160,24 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     torch.cuda.set_device(local)
-    if world > 1:
+    # ASTK_BENCH_FORCE_DP=1: a process group of ONE rank takes the data-parallel branch (bucketed asynchronous all-reduces, 1/world on the
+    # fly, rank-dependent seeds) against the real RCCL backend -- the only multi-rank code a one-GPU box can execute (tests/)
+    dp = world > 1 or os.environ.get("ASTK_BENCH_FORCE_DP", "0") == "1"
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        adist.init("nccl")
+        os.environ.setdefault("MASTER_PORT", "29613")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        # persistent grids: encoder (h/16) x ceil(B/16) x cells; the decoder loop takes every CU but never overlaps a collective
+        rc = MODEL_CFG["rnn_config"]
+        need = (rc["hidden_units"] // 2 // 16) * ((args.batch + 15) // 16) * 2 * rc["enc_layers"]
+        chan_cap = adist.reserve_cus_for_recurrence(min(need, 224))
+        import torch.distributed as td
+        if world > 1:
+            adist.init("nccl")
+        else:
+            td.init_process_group("nccl", world_size=1, rank=0)
+            adist.is_distributed = lambda: True
     lib = _lib.load()
     B, T, D, L, V = args.batch, args.frames, args.feat, args.tgt_len, MODEL_CFG["rnn_config"]["dec_vocab_size"]
     cfg = copy.deepcopy(MODEL_CFG)
@@ -177,7 +192,7 @@ def main():
     opt = O.Adam(alpha=TRAIN["lr"], beta1=0.9, beta2=0.999, eps=1e-8, amsgrad=True).setup(model)
     opt.add_hook(O.WeightDecay(TRAIN["l2"]))
     opt.add_hook(O.GradientClipping(TRAIN["grad_clip"]))
-    if world > 1:
+    if dp:
         # overlapped exchange: decoder / encoder / CNN gradient ranges are all-reduced as soon as their backward is enqueued
         model.grad_buckets = adist.make_grad_buckets(model)
         opt.grad_sync = model.grad_buckets.finish
@@ -202,7 +217,7 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if dp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -214,7 +229,7 @@ def main():
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
@@ -342,7 +357,7 @@ def main():
                 l2_ = step()
             barrier()
             d1 = time.perf_counter() - t1
-            if world > 1:
+            if dp:
                 tt = torch.tensor([d1], dtype=torch.float64, device="cuda")
                 torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
                 d1 = float(tt.item())
@@ -363,15 +378,16 @@ def main():
                       "global_batch": world * B, "frames": T, "feat_dim": D, "tgt_len": L, "parallelism": f"dp{world}", "batchnorm": "global-batch statistics" if (world > 1 and args.sync_bn) else "per-replica statistics",
                       "launches": "plain stream launches (the step is GPU-bound: the host enqueues it in 0.6 ms)"},
            "loss": round(loss_val, 4), "alt_precisions": alt, "paths": paths, "roofline": roof, "roofline_scan": scan}
-    if world > 1:
+    if dp:
         out["dp"] = {"rccl_ranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
-                     "buckets": list(model.grad_buckets.ranges), "bucket_launch": "dec+enc behind the encoder recurrence, cnn behind the CNN backward"}
+                     "buckets": list(model.grad_buckets.ranges), "bucket_launch": "dec+enc behind the encoder recurrence, cnn behind the CNN backward",
+                     "NCCL_MAX_NCHANNELS": chan_cap, "recurrence_grid_cus": need}
     out.update({"kernels": extra} if extra else {})
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, B, T, D, L, V)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp:
         torch.distributed.destroy_process_group()
 
 

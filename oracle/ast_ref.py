@@ -189,6 +189,21 @@ class RefModel:
         self.masks = NoMasks()
         self.enc_states = None
 
+    # ---- enc_dec.py:587-624 (OLD path): Gaussian weight noise on every LSTM's upward W / b and lateral W and on the decoder embedding
+    def add_weight_noise(self, mu, sigma, normal):
+        """normal(mu, sigma, shape) stands for xp.random.normal (unseeded in the reference, quirk Q7); returns the draws by name, in the
+        reference's order: per LSTM link upward.W, upward.b, lateral.W (encoder, reverse encoder, decoder links), then embed_dec.W."""
+        layers = [f"L{i}_enc" for i in range(self.n_enc)] + ([f"L{i}_rev_enc" for i in range(self.n_enc)] if self.bi else [])
+        layers += [f"L{i}_dec" for i in range(self.n_dec)]
+        draws = {}
+        for layer in layers:
+            for name in (f"{layer}/upward/W", f"{layer}/upward/b", f"{layer}/lateral/W"):
+                draws[name] = normal(mu, sigma, self.p[name].data.shape).astype(self.dtype)
+                self.p[name].data += draws[name]
+        draws["embed_dec/W"] = normal(mu, sigma, self.p["embed_dec/W"].data.shape).astype(self.dtype)
+        self.p["embed_dec/W"].data += draws["embed_dec/W"]
+        return draws
+
     # ---- chainer.Chain-like helpers
     def params(self):
         return [(k, v) for k, v in self.p.items() if isinstance(v, Parameter)]

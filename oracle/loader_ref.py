@@ -6,6 +6,7 @@ CPU restatement (NumPy) of the reference's batch construction -- what `FisherDat
   dataloader.py:83-93  (:227-237)       _drop_frames          -> drop_frames
   dataloader.py:95-108 (:239-246)       _load_speech          -> RefLoader.load_speech
   dataloader.py:111-164 (:249-297)      get_batch             -> RefLoader.get_batch
+  nmt_run.py:406-447 (OLD path)         create_batches        -> create_batches (per-bucket batch sizes, curriculum order)
 
 with every random draw INJECTABLE: `pyrandom` stands for Python's `random` module (the stream nn.py:54 seeds; bucket and batch shuffles),
 `choice(n_frames, n_drop)` for `np.random.choice(np.arange(n_frames), size=n_drop)` (unseeded in the reference, quirk Q7).  File I/O is
@@ -32,6 +33,33 @@ def create_buckets(cat_dict, num_b, width_b, key, scale, seed, pyrandom=_pyrando
         for i in range(num_b):
             buckets[i] = pyrandom.sample(buckets[i], int(len(buckets[i]) // scale))
     return {"buckets": buckets, "num_b": num_b, "width_b": width_b}
+
+
+def create_batches(b_dict, batch_size, curriculum=False, pyrandom=_pyrandom):
+    """nmt_run.py:406-447 (the OLD path's batch plan): bucket order shuffled (or ascending for a curriculum); per-bucket batch size
+    'max' / 'med' / 'min' by the bucket's third; every bucket shuffled and sliced; the batch list shuffled unless curriculum."""
+    num_b = b_dict["num_b"]
+    order = list(range(num_b))
+    if curriculum:
+        order = sorted(order)
+    else:
+        pyrandom.shuffle(order)
+    total, out = 0, []
+    for b in order:
+        if b < num_b // 3:
+            size = int(batch_size["max"])
+        elif b < (num_b * 2) // 3:
+            size = int(batch_size["med"])
+        else:
+            size = int(batch_size["min"])
+        bucket = b_dict["buckets"][b]
+        total += len(bucket)
+        pyrandom.shuffle(bucket)
+        for i in range(0, len(bucket), size):
+            out.append((bucket[i:i + size], b))
+    if not curriculum:
+        pyrandom.shuffle(out)
+    return out, total
 
 
 def default_choice(n_frames, n_drop):

@@ -45,4 +45,17 @@ rel = float((pa - pb).abs().max() / pa.abs().max())
 print("max parameter difference after 4 steps (relative):", rel)
 assert rel < 1e-3
 td.destroy_process_group()
+# bench.py's own data-parallel branch (what the driver's N > 1 runs execute), forced onto a process group of one rank: RCCL backend,
+# NCCL_MAX_NCHANNELS cap, bucketed exchange, max-over-ranks timing, the `dp` object of the JSON line
+import json, subprocess
+env = dict(os.environ, ASTK_BENCH_FORCE_DP="1", MASTER_PORT="29613")
+env.pop("NCCL_MAX_NCHANNELS", None)
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+                    "--no-alt-precisions", "--profile-steps", "0"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+print("bench dp branch:", line["dp"], line["ms_per_step"])
+assert line["dp"]["rccl_ranks"] == 1 and line["dp"]["backend"] == "nccl" and set(line["dp"]["buckets"]) == {"cnn", "enc", "dec"}
+assert line["dp"]["NCCL_MAX_NCHANNELS"] + line["dp"]["recurrence_grid_cus"] <= 256 and line["n_gpus"] == 1
 print("ok")

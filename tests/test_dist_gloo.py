@@ -102,3 +102,19 @@ def test_two_rank_gloo():
         assert ok2, f"rank {rank}: teacher-forcing streams differ"
         assert ok3, f"rank {rank}: averaged shard gradients != global-batch gradient"
         assert ok4, f"rank {rank}: BatchNorm statistics exchange wrong"
+
+
+def test_rccl_channel_cap_leaves_the_recurrence_grid_its_cus(monkeypatch):
+    """ast_amd.dist.reserve_cus_for_recurrence: RCCL kernels hold one CU per channel until every peer has arrived; the persistent
+    recurrence grids need their workgroups resident at once.  The cap keeps channels + grid within the device; an explicit, too large
+    NCCL_MAX_NCHANNELS is refused."""
+    from ast_amd import dist as adist
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
+    assert adist.reserve_cus_for_recurrence(192) == 32 and os.environ["NCCL_MAX_NCHANNELS"] == "32"
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS")
+    assert adist.reserve_cus_for_recurrence(240) == 16
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "8")
+    assert adist.reserve_cus_for_recurrence(192) == 8                 # an explicit smaller value stays
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "128")
+    with pytest.raises(RuntimeError):
+        adist.reserve_cus_for_recurrence(192)

@@ -265,3 +265,35 @@ def test_step_batchnorm_relu_kernels(T, B, Cc):
     _lib.check(lib.astk_step_bn_relu_fwd(T, B, Cc, _vp(z), _vp(gamma), _vp(beta), _vp(am2), _vp(av2), 2e-5, 0.9, 0, _vp(out), None, _stream()))
     oe = torch.relu((z.double() - am.double()) / torch.sqrt(av.double() + 2e-5) * gamma.double() + beta.double())
     assert float((out.double() - oe).abs().max()) < 2e-5 * float(oe.abs().max()) and torch.equal(am2, am) and torch.equal(av2, av)
+
+
+def test_weight_noise_of_the_old_path():
+    """enc_dec.py:587-624 / nmt_run.py:850-853: N(mu, sigma) on every LSTM's upward W, upward b, lateral W and on the decoder embedding,
+    nothing else.  With the oracle's draws replayed the parameters must be the oracle's bit for bit; drawn on the device they must have
+    the asked mean and spread, and differ from call to call."""
+    from oracle import ast_ref as R
+    cfg = _cfg(enc_layers=2, dec_layers=2)
+    V, D = cfg["rnn_config"]["dec_vocab_size"], 80
+    P = R.init_params(cfg, D, V, seed=2, dtype=np.float32)
+    ref = R.RefModel(cfg, {k: v.copy() for k, v in P.items()}, V)
+    rng = np.random.default_rng(3)
+    draws = ref.add_weight_noise(0.01, 0.05, lambda mu, sigma, shape: rng.normal(mu, sigma, shape).astype(np.float32))
+    g = _gpu(cfg, P, D, V)
+    g.inject["weight_noise"] = {k: torch.from_numpy(v) for k, v in draws.items()}
+    g.add_weight_noise(0.01, 0.05)
+    after = g.arena.to_numpy()
+    touched = set(draws)
+    assert touched == {k for k in P if ("/upward/" in k or "/lateral/" in k) or k == "embed_dec/W"}
+    for k in after:
+        want = ref.p[k].data if k in touched else P[k]
+        assert np.array_equal(after[k], want), k
+    g2 = _gpu(cfg, P, D, V)
+    g2.add_weight_noise(0.01, 0.05)
+    a1 = g2.arena.to_numpy()
+    g2.add_weight_noise(0.0, 0.05)
+    a2 = g2.arena.to_numpy()
+    d1 = np.concatenate([(a1[k] - P[k]).ravel() for k in sorted(touched)])
+    d2 = np.concatenate([(a2[k] - a1[k]).ravel() for k in sorted(touched)])
+    assert abs(d1.mean() - 0.01) < 5 * 0.05 / np.sqrt(d1.size) + 1e-4 and abs(d1.std() - 0.05) < 0.01 * 0.05
+    assert abs(d2.mean()) < 5 * 0.05 / np.sqrt(d2.size) + 1e-4 and abs(np.corrcoef(d1, d2)[0, 1]) < 0.01
+    assert all(np.array_equal(a2[k], P[k]) for k in a2 if k not in touched)

@@ -496,3 +496,27 @@ def test_host_loaders_reproduce_the_loader_oracle(tmp_path, kind):
             assert np.array_equal(w["X"], g["X"].numpy()) and np.array_equal(w["y"], g["y"].numpy())
             zeroed += sum(int((w["X"][i, :info[set_key][u]["sp"]] == 0).all(1).sum()) for i, u in enumerate(w["utts"]))
         assert (zeroed > 0) == train                                               # only "train" sets lose frames (dataloader.py:105)
+
+
+def test_per_bucket_batch_sizes_follow_the_old_paths_create_batches(tmp_path):
+    """nmt_run.py:406-447: batch_size = {'max','med','min'} by the bucket's third, bucket order shuffled first (or ascending for a
+    curriculum, then nothing else is shuffled between buckets) -- the product's batch_plan against the restated create_batches on the
+    same `random` stream."""
+    from ast_amd.dataloader import SyntheticDataLoader
+    from oracle import loader_ref as LR
+    data = {"dataloader": "synthetic", "vocab_size": 31, "feat_dim": 5, "n_utts": {"syn_train": 90}, "frames": [5, 470], "targets": [1, 9],
+            "buckets_num": 6, "buckets_width": 80, "max_pred": 12, "zero_input": 0.0, "train_scale": 1, "dec_key": "bpe_w"}
+    sizes = {"max": 7, "med": 4, "min": 2}
+    for curriculum in (False, True):
+        dl = SyntheticDataLoader(data, str(tmp_path), -1)
+        ref = {"buckets": [list(b) for b in dl.buckets["syn_train"]["buckets"]], "num_b": 6, "width_b": 80}
+        random.seed(12)
+        plan = dl.batch_plan(dict(sizes, curriculum=curriculum), "syn_train")
+        random.seed(12)
+        want, total = LR.create_batches(ref, sizes, curriculum=curriculum)
+        assert total == 90 and [u for u, _ in plan] == [u for u, _ in want]
+        assert [w for _, w in plan] == [(b + 1) * 80 for _, b in want]
+        by_third = {0: 7, 1: 7, 2: 4, 3: 4, 4: 2, 5: 2}
+        assert all(len(u) <= by_third[b] for u, b in want) and any(len(u) == 7 for u, _ in want)
+        if curriculum:
+            assert [b for _, b in want] == sorted(b for _, b in want)

@@ -31,6 +31,15 @@ if __name__ == "__main__":
         print("-" * 80)
         print("Experment: {0:s} epoch: {1:d} gpu: {2:d}".format(cfg_path, epoch, nn.gpuid))
         print("-" * 80)
+        # OLD-path extra (nmt_run.py:846-853): from epoch `iter_weight_noise` on, Gaussian noise on the LSTM / embedding weights before
+        # every epoch (keys iter_weight_noise, weight_noise_mean, weight_noise_sigma in train_cfg.json; absent or 0: off)
+        t_cfg = nn.cfg.train
+        if t_cfg.get("iter_weight_noise", 0) > 0 and epoch >= t_cfg["iter_weight_noise"]:
+            print("Adding Gaussian weight noise, mean={0:.2f}, stdev={1:0.6f}".format(t_cfg.get("weight_noise_mean", 0.0), t_cfg["weight_noise_sigma"]))
+            if nn.model.arena is not None:
+                nn.model.add_weight_noise(t_cfg.get("weight_noise_mean", 0.0), t_cfg["weight_noise_sigma"])
+                if adist.is_distributed():
+                    adist.broadcast_params(nn.model.arena)      # one draw for all replicas
         epoch_loss = nn.train_epoch(train_key)
         if adist.rank() == 0:
             with open(nn.train_log, mode="a") as f:
