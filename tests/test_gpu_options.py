@@ -297,3 +297,54 @@ def test_weight_noise_of_the_old_path():
     assert abs(d1.mean() - 0.01) < 5 * 0.05 / np.sqrt(d1.size) + 1e-4 and abs(d1.std() - 0.05) < 0.01 * 0.05
     assert abs(d2.mean()) < 5 * 0.05 / np.sqrt(d2.size) + 1e-4 and abs(np.corrcoef(d1, d2)[0, 1]) < 0.01
     assert all(np.array_equal(a2[k], P[k]) for k in a2 if k not in touched)
+
+
+@pytest.mark.parametrize("name", ["all", "proj-3"])
+def test_beam_search_and_checkpoints_with_optional_features(name, tmp_path):
+    """The callers either side of the train step on a model WITH the optional features: (i) a Chainer-layout checkpoint written by the
+    oracle after one train step (LayerNorm gamma / beta under '<link>_ln/', extra heads 'attn_Wa1/', conv biases 'CNN_i/b', the projection's
+    'enc_proj{i}/' + '_bn/' links with avg_mean / avg_var / N = one count per TIME STEP) loads into a HIP model; (ii) beam search through
+    the state API (nn.py:235-322) finds the oracle's N-best hypotheses and scores; (iii) the HIP model's own checkpoint loads back into
+    the oracle with the same counters."""
+    from oracle import ast_ref as R
+    from ast_amd import nn as gnn, serializers
+    from ast_amd.seq2seq import SpeechEncoderDecoder
+    kw, B, T, D, L = CASES[name]
+    cfg = _cfg(**{k: v for k, v in kw.items() if k not in ("drop", "out")})
+    V = cfg["rnn_config"]["dec_vocab_size"]
+    P = R.init_params(cfg, D, V, seed=8, dtype=np.float32)
+    P["out/W"] = (P["out/W"] * 4).astype(np.float32)
+    X, y = R.synth_batch(B, T, D, L, V, seed=9, dtype=np.float32)
+    ref = R.RefModel(cfg, {k: v.astype(np.float64) for k, v in P.items()}, V)
+    opt = R.RefOptimizer(ref, OPT)
+    R.train_step(ref, opt, X.astype(np.float64), y, 1.0, pyrandom=random.Random(0))
+    path = str(tmp_path / "seq2seq_1.model")
+    R.save_npz(path, ref)
+    z = np.load(path)
+    T2 = ref.enc_states.shape[1]
+    if name == "proj-3":
+        assert int(z["enc_proj0_bn/N"]) == T2 and "enc_proj1/W" in z.files and "enc_proj2/W" not in z.files
+    else:
+        assert {"L1_rev_enc_ln/gamma", "L2_dec_ln/beta", "attn_Wa1/W", "CNN_1/b"} <= set(z.files) and "CNN_0_bn/N" not in z.files
+    c = copy.deepcopy(cfg)
+    g = SpeechEncoderDecoder(0, c)
+    serializers.load_npz(path, g)
+    assert g.in_dim == D and g.V == V
+    if name == "proj-3":
+        assert g.proj_bn_N == [T2, T2]
+    X1 = X[:1]
+    want = R.decode_beam(ref, X1.astype(np.float64), stop_limit=6, N=3, K=4)
+    got = gnn.decode_beam(g, torch.from_numpy(X1), stop_limit=6, N=3, K=4)
+    assert len(got) == len(want) == 3
+    for a, b in zip(got, want):
+        assert a["hyp"] == b["hyp"], (a["hyp"], b["hyp"])
+        assert abs(a["score"] - b["score"]) <= 1e-4 * max(1.0, abs(b["score"]))
+        np.testing.assert_allclose(a["attn_history"][-1], b["attn_history"][-1], rtol=0, atol=1e-5)
+    path2 = str(tmp_path / "seq2seq_2.model")
+    serializers.save_npz(path2, g)
+    ref2 = R.RefModel(cfg, {k: np.zeros_like(v, dtype=np.float64) for k, v in P.items()}, V)
+    R.load_npz(path2, ref2)
+    for k, p in ref.params():
+        np.testing.assert_allclose(ref2.p[k].data, p.data, rtol=0, atol=1e-6 * max(1.0, float(np.abs(p.data).max())), err_msg=k)
+    if name == "proj-3":
+        assert ref2.bn["enc_proj1_bn"].N == T2
