@@ -77,6 +77,19 @@ __device__ __forceinline__ void abort_raise(const AbortCtl& ab) {
   __hip_atomic_fetch_or(ab.status, ab.bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+constexpr int AMAX_SLOT_WORDS = 16;
+// Producer slots keep their 16 shards on SEPARATE 128-byte lines (same-line atomics of thousands of blocks retire one after the other
+// in one L2 channel: with adjacent shards the emitting kernels ran 10-30 us longer than without).  Such a slot is 16 x 16 words and its
+// handle carries bit 0 set (pointers are 8-byte aligned): the GEMM reads word 16 i instead of word i.
+constexpr int AMAX_PSLOT_STRIDE = 16;
+constexpr int AMAX_PSLOT_WORDS = AMAX_SLOT_WORDS * AMAX_PSLOT_STRIDE;
+static inline unsigned long long* amax_pslot_handle(unsigned long long* p) { return p ? (unsigned long long*)((uintptr_t)p | 1u) : nullptr; }
+// word of shard `i` behind a handle of either kind (device and host)
+static inline __host__ __device__ unsigned long long* amax_shard(const unsigned long long* handle, int i) {
+  unsigned long long* base = (unsigned long long*)((uintptr_t)handle & ~(uintptr_t)1);
+  return base + (i & (AMAX_SLOT_WORDS - 1)) * (((uintptr_t)handle & 1u) ? AMAX_PSLOT_STRIDE : 1);
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -136,7 +149,10 @@ __device__ __forceinline__ void amax_emit_block(unsigned long long* slot, float 
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(red4[0], red4[1]), fmaxf(red4[2], red4[3]));
     if (!(m <= 3.0e38f)) m = 3.0e38f;
-    unsigned long long* w = slot + ((blockIdx.x + blockIdx.y * gridDim.x) & 15);
+    // (slot: a producer-slot handle, bit 0 set, shards 16 words apart -- or a plain 16-word slot)
+    const bool strided = ((uintptr_t)slot & 1u) != 0;
+    unsigned long long* base = (unsigned long long*)((uintptr_t)slot & ~(uintptr_t)1);
+    unsigned long long* w = base + ((blockIdx.x + blockIdx.y * gridDim.x) & 15) * (strided ? AMAX_PSLOT_STRIDE : 1);
     const unsigned long long v = (unsigned long long)__float_as_uint(m);
     if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) atomicMax(w, v);
   }
@@ -227,7 +243,6 @@ const unsigned long long* gemm_amax_bound(float bound, hipStream_t s);
 // Kernels that WRITE a matrix a later GEMM reads can take its maximum on the way (amax_emit_block below): the slot is 16 64-bit words
 // in the caller's workspace, zeroed before the producing kernel runs (the generation half of the word stays 0), and is handed to the
 // GEMM with with_amax_a / with_amax_b like any other handle.
-constexpr int AMAX_SLOT_WORDS = 16;
 struct AmaxMatrix { const float* p; long rows, ld; int inner; };
 void gemm_amax_many(const AmaxMatrix* m, int n, const unsigned long long** out, hipStream_t s);     // several matrices, one launch
 int low_precision_gemms();      // the mode set by astk_set_low_precision_gemms

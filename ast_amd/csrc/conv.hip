@@ -114,15 +114,19 @@ int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
   }
   // the buffers that have to be zero before use, back to back: ONE fill per pass instead of one per layer and buffer
   const size_t off_afwd = align_up(c.off, 256);
-  for (int i = 0; i < P.n; ++i) { P.a_hp[i] = c.take<unsigned long long>(AMAX_SLOT_WORDS); P.a_wr[i] = c.take<unsigned long long>(AMAX_SLOT_WORDS); }
-  P.a_out = c.take<unsigned long long>(AMAX_SLOT_WORDS);
+  // (producer slots: shards on separate lines; the handles carry bit 0, see common.h)
+  for (int i = 0; i < P.n; ++i) {
+    P.a_hp[i] = amax_pslot_handle(c.take<unsigned long long>(AMAX_PSLOT_WORDS));
+    P.a_wr[i] = amax_pslot_handle(c.take<unsigned long long>(AMAX_PSLOT_WORDS));
+  }
+  P.a_out = amax_pslot_handle(c.take<unsigned long long>(AMAX_PSLOT_WORDS));
   P.zero_fwd_from = ws ? (char*)ws + off_afwd : nullptr;
   const size_t off_stat = align_up(c.off, 256);
   P.zero_fwd_amax_bytes = off_stat - off_afwd;
   for (int i = 0; i < P.n; ++i) P.stat[i] = c.take<double>(2 * (size_t)P.Cn[i]);
   const size_t off_abwd = align_up(c.off, 256);
-  for (int i = 0; i < P.n; ++i) P.a_dy[i] = c.take<unsigned long long>(AMAX_SLOT_WORDS);
-  for (int k = 0; k < GEMM_GROUP_MAX; ++k) P.a_wd[k] = c.take<unsigned long long>(AMAX_SLOT_WORDS);
+  for (int i = 0; i < P.n; ++i) P.a_dy[i] = amax_pslot_handle(c.take<unsigned long long>(AMAX_PSLOT_WORDS));
+  for (int k = 0; k < GEMM_GROUP_MAX; ++k) P.a_wd[k] = amax_pslot_handle(c.take<unsigned long long>(AMAX_PSLOT_WORDS));
   const size_t off_dwr = align_up(c.off, 256);
   for (int i = 0; i < P.n; ++i)
     P.dWr[i] = c.take<float>(i == 0 ? (size_t)d->C[0] * P.K0p : (size_t)P.Cn[i] * d->kt[i] * P.Cn[i - 1]);
@@ -481,7 +485,7 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
     const int C = P.Cn[i], rows = P.rows[i];
     if (i > 0) {
       const int Ci = P.Cn[i - 1], KT = d->kt[i];
-      hipLaunchKernelGGL(k_repack_w, dim3(gridn((size_t)C * Ci * KT)), dim3(256), 0, s, L[i].W, P.Wr[i], C, Ci, KT, P.a_wr[i]);
+      hipLaunchKernelGGL(k_repack_w, dim3(gridn((size_t)C * Ci * KT / 8)), dim3(256), 0, s, L[i].W, P.Wr[i], C, Ci, KT, P.a_wr[i]);
       ASTK_LAUNCH_CHECK();
       const long prow = (long)(P.Tn[i - 1] + 2 * P.padA[i - 1]) * Ci;
       GemmArgs g = gemm_args(rows, C, KT * Ci, mat2(P.HP[i - 1], P.Tn[i], prow, (long)d->st[i] * Ci), mat(P.Wr[i], (long)KT * Ci),
@@ -631,7 +635,7 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
         const int q0 = (rho + pt) / st;
         if (nph == P.wd_copies) { ASTK_TRY(gemm_launch_group(GEMM_NT, ph, nph, s)); nph = 0; }      // (more phases than buffers: flush)
         float* wd = P.Wd + (size_t)nph * P.wd_stride;
-        hipLaunchKernelGGL(k_phase_w, dim3(gridn((size_t)Ci * na * C)), dim3(256), 0, s, L[i].W, wd, C, Ci, KT, r, st, na, P.a_wd[nph]);
+        hipLaunchKernelGGL(k_phase_w, dim3(gridn((size_t)Ci * na * C / 8)), dim3(256), 0, s, L[i].W, wd, C, Ci, KT, r, st, na, P.a_wd[nph]);
         ASTK_LAUNCH_CHECK();
         const long start = (long)(q0 - na + 1 + P.dF[i]);
         ASTK_CHECK(start >= 0, "cnn dgrad: negative window start");

@@ -133,9 +133,12 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
 // gemm_absmax left: launch generation in the high half, the maximum's float bits in the low half; null or zero maximum: 1.0).
 __device__ __forceinline__ int scale_exp(const unsigned long long* amax) {
   if (amax == nullptr) return 127;
+  // (bit 0 of the handle: a producer slot, its 16 shards one 128-byte line apart -- common.h AMAX_PSLOT_STRIDE)
+  const int st = ((uintptr_t)amax & 1u) ? AMAX_PSLOT_STRIDE : 1;
+  amax = (const unsigned long long*)((uintptr_t)amax & ~(uintptr_t)1);
   unsigned long long w = amax[0];       // AMAX_SHARDS words; one left by an earlier launch (older generation) loses to any of this one's
 #pragma unroll
-  for (int i = 1; i < 16; ++i) w = max(w, amax[i]);
+  for (int i = 1; i < 16; ++i) w = max(w, amax[i * st]);
   const int e = (int)(((unsigned)w) >> 23) & 0xff;
   return e == 0 ? 127 : min(max(268 - e, 1), 253);
 }
@@ -865,11 +868,14 @@ __device__ __forceinline__ void absmax_block(const AmaxJobs& jobs) {
     m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
     if (!(m <= 3.0e38f)) m = 3.0e38f;            // (an infinite entry: the product is not finite either way)
     // (same-address atomics retire one after the other, ~40 ns each: 16 shards per region, the reader takes the maximum of all)
-    atomicMax(R.slot + (blk & (AMAX_SHARDS - 1)), ((unsigned long long)jobs.gen << 32) | (unsigned long long)__float_as_uint(m));
+    atomicMax(amax_shard(R.slot, blk), ((unsigned long long)jobs.gen << 32) | (unsigned long long)__float_as_uint(m));
   }
 }
 __global__ __launch_bounds__(256) void k_absmax(AmaxJobs jobs) { absmax_block(jobs); }
-constexpr int AMAX_SLOTS = 16384;      // 64-bit words: two halves of 512 sharded maxima each
+// The ring: two halves of 512 slots; a slot = 16 shards on separate 128-byte lines (AMAX_PSLOT_WORDS words, handles carry bit 0: same-line
+// atomics of a thousand blocks retire one after the other in one L2 channel)
+constexpr int AMAX_RING_SLOTS = 1024;
+constexpr int AMAX_SLOTS = AMAX_RING_SLOTS * AMAX_PSLOT_WORDS;      // 64-bit words (2 MB)
 __device__ unsigned long long g_amax_ring[AMAX_SLOTS];
 
 // GEMM_STORE + split tiles: zero the tiles that more than one workgroup will accumulate into.  Block b looks at the
@@ -1154,16 +1160,17 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     auto list_view = [](MatView v) { if (v.tn == 0x7fffffff) v.tn = 0; return v; };    // (a plain operand dressed as one group, see above)
     for (int i = 0; i < grp.n; ++i) {
       GemmArgs& a = grp.g[i];
-      unsigned long long* sl = ring + (((size_t)gen * (2 * GEMM_GROUP_MAX) + 2 * i) % (AMAX_SLOTS / 2 / AMAX_SHARDS)) * AMAX_SHARDS;
+      unsigned long long* sl = ring + (((size_t)gen * (2 * GEMM_GROUP_MAX) + 2 * i) % (AMAX_RING_SLOTS / 2)) * AMAX_PSLOT_WORDS;
+      unsigned long long* slB = sl + AMAX_PSLOT_WORDS;
       const long spa = a.A.tn > 0 && a.A.tn != 0x7fffffff && a_kr ? (long)((a.K - 1) / a.A.tn) * a.A.sg + (long)((a.K - 1) % a.A.tn) * a.A.st + ((a.M + 3) & ~3L) : a.spanA / 4;
       const long spb = a.B.tn > 0 && a.B.tn != 0x7fffffff && b_kr ? (long)((a.K - 1) / a.B.tn) * a.B.sg + (long)((a.K - 1) % a.B.tn) * a.B.st + ((a.N + 3) & ~3L) : a.spanB / 4;
       if (!a.amaxA) {          // (a caller that uses an operand in several launches passes its maximum in: gemm_amax)
-        a.amaxA = sl;
-        amax_add(J, list_view(a.A), a_kr, a.M, a.K, a.batch, a.sA, spa, sl);
+        a.amaxA = amax_pslot_handle(sl);
+        amax_add(J, list_view(a.A), a_kr, a.M, a.K, a.batch, a.sA, spa, amax_pslot_handle(sl));
       }
       if (!a.amaxB) {
-        a.amaxB = sl + AMAX_SHARDS;
-        amax_add(J, list_view(a.B), b_kr, a.N, a.K, a.batch, a.sB, spb, sl + AMAX_SHARDS);
+        a.amaxB = amax_pslot_handle(slB);
+        amax_add(J, list_view(a.B), b_kr, a.N, a.K, a.batch, a.sB, spb, amax_pslot_handle(slB));
       }
     }
     if (log_shapes)
@@ -1221,7 +1228,7 @@ void gemm_amax_many(const AmaxMatrix* m, int n, const unsigned long long** out, 
       memset(&J, 0, sizeof(J));
       J.gen = gen;
     }
-    unsigned long long* slot = ring + AMAX_SLOTS / 2 + (g_amax_handle.fetch_add(1) % (AMAX_SLOTS / 2 / AMAX_SHARDS)) * AMAX_SHARDS;
+    unsigned long long* slot = amax_pslot_handle(ring + AMAX_SLOTS / 2 + (size_t)(g_amax_handle.fetch_add(1) % (AMAX_RING_SLOTS / 2)) * AMAX_PSLOT_WORDS);
     amax_add(J, mat(m[i].p, m[i].ld), false, (int)m[i].rows, m[i].inner, 1, 0, 0, slot);
     out[i] = slot;
   }
@@ -1233,7 +1240,7 @@ void gemm_amax_reserve(int n, unsigned long long** slots, unsigned* gen, hipStre
   const bool on = default_prec() == PREC_F16X2 && ring != nullptr;
   *gen = on ? next_amax_gen(s) : 0;
   for (int i = 0; i < n; ++i)
-    slots[i] = on ? ring + AMAX_SLOTS / 2 + (g_amax_handle.fetch_add(1) % (AMAX_SLOTS / 2 / AMAX_SHARDS)) * AMAX_SHARDS : nullptr;
+    slots[i] = on ? amax_pslot_handle(ring + AMAX_SLOTS / 2 + (size_t)(g_amax_handle.fetch_add(1) % (AMAX_RING_SLOTS / 2)) * AMAX_PSLOT_WORDS) : nullptr;
 }
 
 // constant maxima (bounded matrices): 8 slots of 16 words; word 0 of a slot holds the bound, the others stay 0

@@ -797,7 +797,7 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     if (tid == 0) {
       float m = fmaxf(fmaxf(dzS[0], dzS[1]), fmaxf(dzS[2], dzS[3]));
       if (!(m <= 3.0e38f)) m = 3.0e38f;
-      atomicMax(c.amax + ((blockIdx.x + blockIdx.y * gridDim.x) & 15), ((u64)amax_gen << 32) | (u64)__float_as_uint(m));
+      atomicMax(amax_shard(c.amax, blockIdx.x + blockIdx.y * gridDim.x), ((u64)amax_gen << 32) | (u64)__float_as_uint(m));
     }
   }
   if (timing && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0)
