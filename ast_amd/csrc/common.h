@@ -78,9 +78,11 @@ __device__ __forceinline__ void abort_raise(const AbortCtl& ab) {
 }
 
 constexpr int AMAX_SLOT_WORDS = 16;
-// Producer slots keep their 16 shards on SEPARATE 128-byte lines (same-line atomics of thousands of blocks retire one after the other
-// in one L2 channel: with adjacent shards the emitting kernels ran 10-30 us longer than without).  Such a slot is 16 x 16 words and its
-// handle carries bit 0 set (pointers are 8-byte aligned): the GEMM reads word 16 i instead of word i.
+// Producer slots of kernels with thousands of emitting blocks keep their 16 shards on SEPARATE 128-byte lines (same-line atomics of
+// thousands of blocks retire one after the other in one L2 channel: with adjacent shards those kernels ran 10-30 us longer than
+// without).  Such a slot is 16 x 16 words and its handle carries bit 0 set (pointers are 8-byte aligned).  A consuming GEMM reads a
+// slot at the start of every tile, and 16 separate lines THERE cost more than the producers save (0.18 ms per train step): before a
+// GEMM sees it a strided slot is folded into one word of a plain slot by a small kernel that runs in between anyway (amax_compact).
 constexpr int AMAX_PSLOT_STRIDE = 16;
 constexpr int AMAX_PSLOT_WORDS = AMAX_SLOT_WORDS * AMAX_PSLOT_STRIDE;
 static inline unsigned long long* amax_pslot_handle(unsigned long long* p) { return p ? (unsigned long long*)((uintptr_t)p | 1u) : nullptr; }
@@ -156,6 +158,18 @@ __device__ __forceinline__ void amax_emit_block(unsigned long long* slot, float 
     const unsigned long long v = (unsigned long long)__float_as_uint(m);
     if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) atomicMax(w, v);
   }
+}
+// Folds a strided producer slot into word 0 of a plain 16-word slot (the other words are zero): lanes 0..15 of the calling wave.
+// Called by ONE wave of a kernel that runs between the producer and the consuming GEMM (stream order makes the producer's atomics visible).
+__device__ __forceinline__ void amax_compact(const unsigned long long* strided_handle, unsigned long long* plain_slot) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long w = lane < AMAX_SLOT_WORDS ? *amax_shard(strided_handle, lane) : 0ull;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    const unsigned long long v = __shfl_xor(w, o);
+    w = v > w ? v : w;
+  }
+  if (lane < AMAX_SLOT_WORDS) plain_slot[lane] = lane == 0 ? w : 0ull;
 }
 #endif
 

@@ -42,7 +42,11 @@ struct CnnPlan {
   //   a_wd[k]  the phase weights of a grouped dgrad launch                                                  written by k_phase_w
   // The forward slots sit in front of the statistics (zeroed by the forward fill, untouched by the backward one), the backward slots
   // behind them (zeroed by the backward fill).
+  // a_hp, a_out and a_dy come from kernels with thousands of emitting blocks: STRIDED producer slots (`_s`, shards on separate lines)
+  // that a small kernel running in between anyway folds into the plain slot the GEMMs read (k_repack_w of the next layer folds a_hp, the
+  // first k_phase_w folds a_dy, the LSTM stack's k_perm_rows folds a_out); a_wr / a_wd come from small grids: plain slots.
   unsigned long long *a_hp[ASTK_MAX_CNN_LAYERS], *a_wr[ASTK_MAX_CNN_LAYERS], *a_out, *a_dy[ASTK_MAX_CNN_LAYERS], *a_wd[GEMM_GROUP_MAX];
+  unsigned long long *a_hp_s[ASTK_MAX_CNN_LAYERS], *a_dy_s[ASTK_MAX_CNN_LAYERS];
   void* zero_fwd_from;
   size_t zero_fwd_amax_bytes;             // the forward slots alone (eval mode: no statistics to zero)
   float* bn[ASTK_MAX_CNN_LAYERS];   // [4][C]: mean, inv_std, scale, shift
@@ -114,10 +118,10 @@ int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
   }
   // the buffers that have to be zero before use, back to back: ONE fill per pass instead of one per layer and buffer
   const size_t off_afwd = align_up(c.off, 256);
-  // (producer slots: shards on separate lines; the handles carry bit 0, see common.h)
   for (int i = 0; i < P.n; ++i) {
-    P.a_hp[i] = amax_pslot_handle(c.take<unsigned long long>(AMAX_PSLOT_WORDS));
-    P.a_wr[i] = amax_pslot_handle(c.take<unsigned long long>(AMAX_PSLOT_WORDS));
+    P.a_hp_s[i] = amax_pslot_handle(c.take<unsigned long long>(AMAX_PSLOT_WORDS));
+    P.a_hp[i] = c.take<unsigned long long>(AMAX_SLOT_WORDS);
+    P.a_wr[i] = c.take<unsigned long long>(AMAX_SLOT_WORDS);
   }
   P.a_out = amax_pslot_handle(c.take<unsigned long long>(AMAX_PSLOT_WORDS));
   P.zero_fwd_from = ws ? (char*)ws + off_afwd : nullptr;
@@ -125,8 +129,11 @@ int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
   P.zero_fwd_amax_bytes = off_stat - off_afwd;
   for (int i = 0; i < P.n; ++i) P.stat[i] = c.take<double>(2 * (size_t)P.Cn[i]);
   const size_t off_abwd = align_up(c.off, 256);
-  for (int i = 0; i < P.n; ++i) P.a_dy[i] = amax_pslot_handle(c.take<unsigned long long>(AMAX_PSLOT_WORDS));
-  for (int k = 0; k < GEMM_GROUP_MAX; ++k) P.a_wd[k] = amax_pslot_handle(c.take<unsigned long long>(AMAX_PSLOT_WORDS));
+  for (int i = 0; i < P.n; ++i) {
+    P.a_dy_s[i] = amax_pslot_handle(c.take<unsigned long long>(AMAX_PSLOT_WORDS));
+    P.a_dy[i] = c.take<unsigned long long>(AMAX_SLOT_WORDS);
+  }
+  for (int k = 0; k < GEMM_GROUP_MAX; ++k) P.a_wd[k] = c.take<unsigned long long>(AMAX_SLOT_WORDS);
   const size_t off_dwr = align_up(c.off, 256);
   for (int i = 0; i < P.n; ++i)
     P.dWr[i] = c.take<float>(i == 0 ? (size_t)d->C[0] * P.K0p : (size_t)P.Cn[i] * d->kt[i] * P.Cn[i - 1]);
@@ -168,8 +175,10 @@ __global__ __launch_bounds__(256) void k_im2col0(const float* __restrict__ X, co
 }
 
 // Wr[co][kt*Ci + ci] = W[co][ci][kt]   (W is (Co,Ci,KT,1))
-__global__ __launch_bounds__(256) void k_repack_w(const float* __restrict__ W, float* __restrict__ Wr, int Co, int Ci, int KT, unsigned long long* amax) {
+__global__ __launch_bounds__(256) void k_repack_w(const float* __restrict__ W, float* __restrict__ Wr, int Co, int Ci, int KT, unsigned long long* amax,
+                                                  const unsigned long long* fold_src, unsigned long long* fold_dst) {
   __shared__ float red4[4];
+  if (fold_src && blockIdx.x == 0 && threadIdx.x < 64) amax_compact(fold_src, fold_dst);     // (the layer below's activation maximum, see CnnPlan)
   const long n = (long)Co * Ci * KT;
   float m = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -194,8 +203,9 @@ __global__ void k_unpack_dw(const float* __restrict__ dWr, float* __restrict__ d
 }
 // dgrad phase weight: Wd[ci][a*Co + co] = W[co][ci][kt = r + st*(na-1-a)]
 __global__ __launch_bounds__(256) void k_phase_w(const float* __restrict__ W, float* __restrict__ Wd, int Co, int Ci, int KT, int r, int st, int na,
-                                                 unsigned long long* amax) {
+                                                 unsigned long long* amax, const unsigned long long* fold_src, unsigned long long* fold_dst) {
   __shared__ float red4[4];
+  if (fold_src && blockIdx.x == 0 && threadIdx.x < 64) amax_compact(fold_src, fold_dst);     // (the padded dY's maximum, see CnnPlan)
   const long n = (long)Ci * na * Co;
   float m = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -485,7 +495,8 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
     const int C = P.Cn[i], rows = P.rows[i];
     if (i > 0) {
       const int Ci = P.Cn[i - 1], KT = d->kt[i];
-      hipLaunchKernelGGL(k_repack_w, dim3(gridn((size_t)C * Ci * KT / 8)), dim3(256), 0, s, L[i].W, P.Wr[i], C, Ci, KT, P.a_wr[i]);
+      hipLaunchKernelGGL(k_repack_w, dim3(gridn((size_t)C * Ci * KT / 8)), dim3(256), 0, s, L[i].W, P.Wr[i], C, Ci, KT, P.a_wr[i],
+                         (const unsigned long long*)P.a_hp_s[i - 1], P.a_hp[i - 1]);
       ASTK_LAUNCH_CHECK();
       const long prow = (long)(P.Tn[i - 1] + 2 * P.padA[i - 1]) * Ci;
       GemmArgs g = gemm_args(rows, C, KT * Ci, mat2(P.HP[i - 1], P.Tn[i], prow, (long)d->st[i] * Ci), mat(P.Wr[i], (long)KT * Ci),
@@ -515,7 +526,7 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
         ASTK_LAUNCH_CHECK();
       }
       hipLaunchKernelGGL(k_bn_relu_rows, dim3(gridn((size_t)rows * C / 4)), dim3(256), 0, s, P.Y[i], P.bn[i], P.HP[i], rows, C,
-                         P.Tn[i], P.padA[i], P.a_hp[i]);
+                         P.Tn[i], P.padA[i], P.a_hp_s[i]);
       ASTK_LAUNCH_CHECK();
     } else {
       const size_t shm = (size_t)C * F * sizeof(float);
@@ -594,7 +605,7 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
     // (no_bn: the ReLU mask alone -- scale 1 and a zero 1/m switch the BatchNorm terms off; the column sums of g are the bias gradient)
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(gridn((size_t)rows * C / 4)), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], P.stat[i], P.DY[i], rows, C,
                        P.Tn[i], P.dF[i], P.dB[i], (exchange || d->no_bn) ? nullptr : Gr[i].dgamma, (exchange || d->no_bn) ? nullptr : Gr[i].dbeta,
-                       d->no_bn ? 0.f : 1.f / ((float)rows * (exchange ? world : 1)), i > 0 ? P.a_dy[i] : nullptr);
+                       d->no_bn ? 0.f : 1.f / ((float)rows * (exchange ? world : 1)), i > 0 ? P.a_dy_s[i] : nullptr);
     ASTK_LAUNCH_CHECK();
     if (d->no_bn) {
       ASTK_CHECK(Gr[i].dbias, "conv_bn_relu_bwd: no_bn needs a bias gradient (layer %d)", i);
@@ -613,18 +624,11 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
       // the padded dY feeds the weight gradient and every stride phase of the input gradient: its maximum (fp16x2 GEMM scale) was taken
       // by k_bn_bwd_apply when it wrote it; the activations' by k_bn_relu_rows in the forward pass
       const unsigned long long* ady = P.a_dy[i];
-      // ---- wgrad: dWr[co][kt*Ci+ci] = sum_rows DY[row][co] * window(row)[k]
-      {
-        MatView A = mat2(P.DY[i] + (long)P.dF[i] * C, P.Tn[i], dyrow, C);
-        MatView Bm = mat2(P.HP[i - 1], P.Tn[i], hprow, (long)st * Ci);
-        const long tiles = (long)cdiv(C, 128) * cdiv(KT * Ci, 128);
-        ASTK_TRY(gemm_launch(GEMM_TN, with_amax_b(with_amax_a(lowp(gemm_args(C, KT * Ci, rows, A, Bm, P.dWr[i], (long)KT * Ci, nullptr, GEMM_ATOMIC, ksplit_for(tiles, rows))), ady), P.a_hp[i - 1]), s));
-      }
-      hipLaunchKernelGGL(k_unpack_dw, dim3(gridn((size_t)C * Ci * KT)), dim3(256), 0, s, P.dWr[i], Gr[i].dW, C, Ci, KT);
-      ASTK_LAUNCH_CHECK();
-      // ---- dgrad: one window GEMM per stride phase rho of the input position t_in = rho + st*j, all phases in one grouped launch
+      // ---- dgrad, part 1: the phase weights of the stride phases rho of the input position t_in = rho + st*j (the first of these small
+      // kernels also folds dY's strided maximum slot into the plain one both products read, hence in front of the weight gradient)
       GemmArgs ph[GEMM_GROUP_MAX];
       int nph = 0;
+      bool folded = false;
       for (int rho = 0; rho < st && rho < P.Tn[i - 1]; ++rho) {
         const int r = (rho + pt) % st;
         const int na = (KT - r + st - 1) / st;
@@ -635,8 +639,12 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
         const int q0 = (rho + pt) / st;
         if (nph == P.wd_copies) { ASTK_TRY(gemm_launch_group(GEMM_NT, ph, nph, s)); nph = 0; }      // (more phases than buffers: flush)
         float* wd = P.Wd + (size_t)nph * P.wd_stride;
-        hipLaunchKernelGGL(k_phase_w, dim3(gridn((size_t)Ci * na * C / 8)), dim3(256), 0, s, L[i].W, wd, C, Ci, KT, r, st, na, P.a_wd[nph]);
+        // (a_wd[k] is zeroed once per backward call: a slot that is reused -- more phases than buffers, a deeper stack -- keeps the larger
+        //  of its users' maxima, i.e. a slightly conservative scale for phase weights of similar magnitude)
+        hipLaunchKernelGGL(k_phase_w, dim3(gridn((size_t)Ci * na * C / 8)), dim3(256), 0, s, L[i].W, wd, C, Ci, KT, r, st, na, P.a_wd[nph],
+                           folded ? nullptr : (const unsigned long long*)P.a_dy_s[i], P.a_dy[i]);
         ASTK_LAUNCH_CHECK();
+        folded = true;
         const long start = (long)(q0 - na + 1 + P.dF[i]);
         ASTK_CHECK(start >= 0, "cnn dgrad: negative window start");
         GemmArgs g = gemm_args(B * F * nj, Ci, na * C, mat2(P.DY[i] + start * C, nj, dyrow, C), mat(wd, (long)na * C),
@@ -647,6 +655,17 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
         ph[nph] = with_amax_b(with_amax_a(lowp(g), ady), P.a_wd[nph]);
         ++nph;
       }
+      if (!folded) ady = P.a_dy_s[i];      // (no phase kernel ran: the products read the strided slot itself)
+      // ---- wgrad: dWr[co][kt*Ci+ci] = sum_rows DY[row][co] * window(row)[k]
+      {
+        MatView A = mat2(P.DY[i] + (long)P.dF[i] * C, P.Tn[i], dyrow, C);
+        MatView Bm = mat2(P.HP[i - 1], P.Tn[i], hprow, (long)st * Ci);
+        const long tiles = (long)cdiv(C, 128) * cdiv(KT * Ci, 128);
+        ASTK_TRY(gemm_launch(GEMM_TN, with_amax_b(with_amax_a(lowp(gemm_args(C, KT * Ci, rows, A, Bm, P.dWr[i], (long)KT * Ci, nullptr, GEMM_ATOMIC, ksplit_for(tiles, rows))), ady), P.a_hp[i - 1]), s));
+      }
+      hipLaunchKernelGGL(k_unpack_dw, dim3(gridn((size_t)C * Ci * KT)), dim3(256), 0, s, P.dWr[i], Gr[i].dW, C, Ci, KT);
+      ASTK_LAUNCH_CHECK();
+      // ---- dgrad, part 2: one window GEMM per stride phase, all phases in one grouped launch
       if (nph > 0) ASTK_TRY(gemm_launch_group(GEMM_NT, ph, nph, s));
     }
   }

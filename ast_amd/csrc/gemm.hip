@@ -872,10 +872,12 @@ __device__ __forceinline__ void absmax_block(const AmaxJobs& jobs) {
   }
 }
 __global__ __launch_bounds__(256) void k_absmax(AmaxJobs jobs) { absmax_block(jobs); }
-// The ring: two halves of 512 slots; a slot = 16 shards on separate 128-byte lines (AMAX_PSLOT_WORDS words, handles carry bit 0: same-line
-// atomics of a thousand blocks retire one after the other in one L2 channel)
+// The ring: two halves of 512 slots of 16 ADJACENT shards (one 128-byte line: the consuming GEMM reads a slot with 16 scalar loads at
+// the start of every tile, and 16 separate lines there cost 0.18 ms per train step -- measured A/B in one call; the producing side's
+// same-line atomics cost less than that.  Kernels with thousands of emitting blocks use strided producer slots and have them
+// compacted into one line by a small kernel that runs in between anyway: common.h amax_compact.)
 constexpr int AMAX_RING_SLOTS = 1024;
-constexpr int AMAX_SLOTS = AMAX_RING_SLOTS * AMAX_PSLOT_WORDS;      // 64-bit words (2 MB)
+constexpr int AMAX_SLOTS = AMAX_RING_SLOTS * AMAX_SLOT_WORDS;      // 64-bit words (128 KB)
 __device__ unsigned long long g_amax_ring[AMAX_SLOTS];
 
 // GEMM_STORE + split tiles: zero the tiles that more than one workgroup will accumulate into.  Block b looks at the
@@ -1160,17 +1162,17 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     auto list_view = [](MatView v) { if (v.tn == 0x7fffffff) v.tn = 0; return v; };    // (a plain operand dressed as one group, see above)
     for (int i = 0; i < grp.n; ++i) {
       GemmArgs& a = grp.g[i];
-      unsigned long long* sl = ring + (((size_t)gen * (2 * GEMM_GROUP_MAX) + 2 * i) % (AMAX_RING_SLOTS / 2)) * AMAX_PSLOT_WORDS;
-      unsigned long long* slB = sl + AMAX_PSLOT_WORDS;
+      unsigned long long* sl = ring + (((size_t)gen * (2 * GEMM_GROUP_MAX) + 2 * i) % (AMAX_RING_SLOTS / 2)) * AMAX_SLOT_WORDS;
+      unsigned long long* slB = sl + AMAX_SLOT_WORDS;
       const long spa = a.A.tn > 0 && a.A.tn != 0x7fffffff && a_kr ? (long)((a.K - 1) / a.A.tn) * a.A.sg + (long)((a.K - 1) % a.A.tn) * a.A.st + ((a.M + 3) & ~3L) : a.spanA / 4;
       const long spb = a.B.tn > 0 && a.B.tn != 0x7fffffff && b_kr ? (long)((a.K - 1) / a.B.tn) * a.B.sg + (long)((a.K - 1) % a.B.tn) * a.B.st + ((a.N + 3) & ~3L) : a.spanB / 4;
       if (!a.amaxA) {          // (a caller that uses an operand in several launches passes its maximum in: gemm_amax)
-        a.amaxA = amax_pslot_handle(sl);
-        amax_add(J, list_view(a.A), a_kr, a.M, a.K, a.batch, a.sA, spa, amax_pslot_handle(sl));
+        a.amaxA = sl;
+        amax_add(J, list_view(a.A), a_kr, a.M, a.K, a.batch, a.sA, spa, sl);
       }
       if (!a.amaxB) {
-        a.amaxB = amax_pslot_handle(slB);
-        amax_add(J, list_view(a.B), b_kr, a.N, a.K, a.batch, a.sB, spb, amax_pslot_handle(slB));
+        a.amaxB = slB;
+        amax_add(J, list_view(a.B), b_kr, a.N, a.K, a.batch, a.sB, spb, slB);
       }
     }
     if (log_shapes)
@@ -1228,7 +1230,7 @@ void gemm_amax_many(const AmaxMatrix* m, int n, const unsigned long long** out, 
       memset(&J, 0, sizeof(J));
       J.gen = gen;
     }
-    unsigned long long* slot = amax_pslot_handle(ring + AMAX_SLOTS / 2 + (size_t)(g_amax_handle.fetch_add(1) % (AMAX_RING_SLOTS / 2)) * AMAX_PSLOT_WORDS);
+    unsigned long long* slot = ring + AMAX_SLOTS / 2 + (size_t)(g_amax_handle.fetch_add(1) % (AMAX_RING_SLOTS / 2)) * AMAX_SLOT_WORDS;
     amax_add(J, mat(m[i].p, m[i].ld), false, (int)m[i].rows, m[i].inner, 1, 0, 0, slot);
     out[i] = slot;
   }
@@ -1240,7 +1242,7 @@ void gemm_amax_reserve(int n, unsigned long long** slots, unsigned* gen, hipStre
   const bool on = default_prec() == PREC_F16X2 && ring != nullptr;
   *gen = on ? next_amax_gen(s) : 0;
   for (int i = 0; i < n; ++i)
-    slots[i] = on ? amax_pslot_handle(ring + AMAX_SLOTS / 2 + (size_t)(g_amax_handle.fetch_add(1) % (AMAX_RING_SLOTS / 2)) * AMAX_PSLOT_WORDS) : nullptr;
+    slots[i] = on ? ring + AMAX_SLOTS / 2 + (size_t)(g_amax_handle.fetch_add(1) % (AMAX_RING_SLOTS / 2)) * AMAX_SLOT_WORDS : nullptr;
 }
 
 // constant maxima (bounded matrices): 8 slots of 16 words; word 0 of a slot holds the bound, the others stay 0

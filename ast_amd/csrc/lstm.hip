@@ -50,6 +50,7 @@ struct LstmPlan {
   unsigned* counters;                  // arrival counters of the persistent kernels
   float* PR[2][ASTK_MAX_RNN_LAYERS];   // persistent backward (reduce-scatter): partial dh_rec ring of each cell
   float* PD[2][ASTK_MAX_RNN_LAYERS];   // partial dx handed to the layer below (layers >= 1)
+  unsigned long long* ax;              // the frames' maximum, folded from desc.x_amax into one line by the forward call (read by both calls)
   float* GATH;                         // (T,B,4h) dz of the reverse stack's layer 0 re-ordered to frame order
   float* DX[2];                        // (T,B,h) gradient wrt a layer's input (layers >= 1)
   float* DC[2][2];                     // dc ping-pong (B,h)
@@ -81,6 +82,7 @@ int make_plan(const astk_lstm_stack_desc* d, void* ws, bool with_masks, LstmPlan
   }
   (void)with_masks;
   P.GATH = c.take<float>(P.nd > 1 ? tb * 4 * P.h : 4);
+  P.ax = c.take<unsigned long long>(AMAX_SLOT_WORDS);
   P.counters = c.take<unsigned>(((size_t)2 * P.nd * P.nl * ((P.B + 15) / 16) + 2) * 64);
   {
     const bool pp = lstm_persist_applicable(P.T, P.B, P.h, P.nl, P.nd);
@@ -96,7 +98,10 @@ int make_plan(const astk_lstm_stack_desc* d, void* ws, bool with_masks, LstmPlan
 
 // quirk Q1: the reverse stack reads frame X[-i] = (T - i) % T at step i -- an involution, so the frame permutation is its own inverse.
 // One launch writes it (perm = inv) and its expansions to (T*B) row indices: rows[i*B+b] = perm[i]*B + b.
-__global__ void k_perm_rows(int* perm, int* inv, int* rows_perm, int* rows_inv, int T, int B) {
+__global__ void k_perm_rows(int* perm, int* inv, int* rows_perm, int* rows_inv, int T, int B, const unsigned long long* fold_src,
+                            unsigned long long* fold_dst) {
+  // (rides along: the frames' maximum arrives in a STRIDED producer slot -- thousands of blocks wrote it -- and the GEMMs read one line)
+  if (fold_src && blockIdx.x == 0 && threadIdx.x < 64) amax_compact(fold_src, fold_dst);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < T) {
     const int f = (T - i) % T;
@@ -147,7 +152,10 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
   const int T = P.T, B = P.B, h = P.h, H = P.nd * P.h;
   int* rows_perm = (int*)((char*)ws + P.bytes);
   int* rows_inv = (int*)((char*)rows_perm + align_up((size_t)T * B * sizeof(int), 256));
-  hipLaunchKernelGGL(k_perm_rows, dim3(cdiv(T * B, 256)), dim3(256), 0, s, P.perm, P.inv, rows_perm, rows_inv, T, B);
+  // a strided producer slot (bit 0 of the handle) is folded into the plan's plain slot; a plain one is used as it is
+  const bool x_strided = d->x_amax && (((uintptr_t)d->x_amax) & 1u);
+  hipLaunchKernelGGL(k_perm_rows, dim3(cdiv(T * B, 256)), dim3(256), 0, s, P.perm, P.inv, rows_perm, rows_inv, T, B,
+                     x_strided ? (const unsigned long long*)d->x_amax : nullptr, P.ax);
   ASTK_LAUNCH_CHECK();
   const size_t bh = (size_t)B * h;
   if (lstm_persist_applicable(T, B, h, P.nl, P.nd)) {
@@ -157,7 +165,7 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
     // maxima (fp16x2 GEMM scales) of the frames -- both directions multiply the same ones -- and of the two layer-0 upward weights in
     // ONE launch: the grouped projection launch below then needs no maximum pass of its own
     // (the frames' maximum comes with them when the caller passes it on from the kernel that wrote them: desc.x_amax)
-    const unsigned long long* ax = (const unsigned long long*)d->x_amax;
+    const unsigned long long* ax = x_strided ? P.ax : (const unsigned long long*)d->x_amax;
     const unsigned long long* aw0[2] = {nullptr, nullptr};
     {
       AmaxMatrix am[3] = {{ax ? nullptr : x, (long)T * B, (long)P.in, P.in}, {prm[0].Wu, 4L * h, (long)P.in, P.in},
@@ -351,7 +359,8 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
   int nwg = 0;
   // Absolute maxima (fp16x2 GEMM scales) of the matrices that feed several products: the frames (B operand of both directions'
   // layer-0 dWu) by a pass here, every cell's dz (dWl, dWu, input gradient) by the recurrence kernel itself on the persistent path.
-  const unsigned long long* ax = (const unsigned long long*)d->x_amax;
+  // (the forward call of this workspace folded a strided x_amax into P.ax)
+  const unsigned long long* ax = (d->x_amax && (((uintptr_t)d->x_amax) & 1u)) ? P.ax : (const unsigned long long*)d->x_amax;
   const unsigned long long* aw0[2] = {nullptr, nullptr};
   {
     AmaxMatrix am[3] = {{ax ? nullptr : x, (long)T * B, (long)P.in, P.in}, {dx ? prm[0].Wu : nullptr, 4L * h, (long)P.in, P.in},

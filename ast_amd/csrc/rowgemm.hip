@@ -2,7 +2,7 @@
 // backward counterparts): out[M<=~64, N] = sum_p A_p[M,K_p] W_p[N,K_p]^T with a fused epilogue.
 //
 // These products have M = batch (16-64 rows), so they are weight-streaming / latency bound, not
-// MFMA bound.  Design: one workgroup owns a 16-row x (16*NT)-column output tile and splits K over
+// MFMA bound.  Design: one workgroup owns a 16-row (32-row above 16 rows: two row tiles on the same weight fragments) x (16*NT)-column output tile and splits K over
 // its 4 waves; operands go straight from global memory (L2 / MALL resident) into the
 // v_mfma_f32_16x16x4_f32 operand registers with 16-byte loads -- lane (r = l&15, q = l>>4) loads
 // floats [16s+4q, 16s+4q+4) of row r for k-block s and feeds them to 4 consecutive MFMAs, so that the
@@ -22,24 +22,29 @@ struct WRows {   // W row for (tile t, column j) = base + j*sj + t*st ; valid co
 };
 
 // CH k-blocks per wave are loaded back to back (one exposed memory round trip per trip) before their MFMAs issue.
-template <int NT, int CH>
+// MT: row tiles (16 rows each) of one workgroup that share the weight fragments -- these products stream their weights once per
+// workgroup, so a batch of 17-32 rows as two workgroups per column tile reads every weight twice (round 3: MT = 2 above 16 rows).
+template <int MT, int NT, int CH>
 __device__ __forceinline__ void tile_dot(const RowPair& pr, int m0, int M, WRows wr, int jvalid, int lane, int wave,
-                                         f32x4 (&acc)[NT]) {
+                                         f32x4 (&acc)[MT][NT]) {
   const int K = pr.K;
   if (K <= 0) return;
   const int r = lane & 15, q = lane >> 4;
-  const int arow = min(m0 + r, M - 1);
-  const float* ap = pr.A + (long)arow * pr.lda + 4 * q;
+  const float* ap[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) ap[mt] = pr.A + (long)min(m0 + 16 * mt + r, M - 1) * pr.lda + 4 * q;
   const int j = min(r, jvalid - 1);
   const float* wp[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) wp[t] = pr.W + (long)(wr.base + j * wr.sj + t * wr.st) * pr.ldw + 4 * q;
   const int nblk = (K + 15) >> 4;
-  f32x4 acc2[NT];   // second accumulator chain: consecutive MFMAs never wait on each other's result
+  f32x4 acc2[MT][NT];   // second accumulator chain: consecutive MFMAs never wait on each other's result
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc2[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int sb = wave; sb < nblk; sb += 4 * CH) {
-    float4 av[CH], wv[CH][NT];
+    float4 av[MT][CH], wv[CH][NT];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       // branch-free: the address is clamped inside the row (K % 4 == 0), out-of-range k-blocks are zeroed by a select on the
@@ -47,9 +52,12 @@ __device__ __forceinline__ void tile_dot(const RowPair& pr, int m0, int M, WRows
       const int s = sb + 4 * i;
       const int ko = min(16 * s + 4 * q, K - 4) - 4 * q;
       const bool v = (16 * s + 4 * q) < K;
-      float4 x = *reinterpret_cast<const float4*>(ap + ko);
-      x.x = v ? x.x : 0.f; x.y = v ? x.y : 0.f; x.z = v ? x.z : 0.f; x.w = v ? x.w : 0.f;
-      av[i] = x;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        float4 x = *reinterpret_cast<const float4*>(ap[mt] + ko);
+        x.x = v ? x.x : 0.f; x.y = v ? x.y : 0.f; x.z = v ? x.z : 0.f; x.w = v ? x.w : 0.f;
+        av[mt][i] = x;
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t) wv[i][t] = *reinterpret_cast<const float4*>(wp[t] + ko);
     }
@@ -59,17 +67,22 @@ __device__ __forceinline__ void tile_dot(const RowPair& pr, int m0, int M, WRows
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, wv[i][t].x, acc[t], 0, 0, 0);
+      for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, wv[i][t].y, acc2[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][i].x, wv[i][t].x, acc[mt][t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, wv[i][t].z, acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc2[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][i].y, wv[i][t].y, acc2[mt][t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, wv[i][t].w, acc2[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][i].z, wv[i][t].z, acc[mt][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc2[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][i].w, wv[i][t].w, acc2[mt][t], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] += acc2[t];
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[mt][t] += acc2[mt][t];
 }
 
 // 4-wave K reduction.  D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
@@ -98,29 +111,37 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NT]) {
 // ------------------------------------------------------------------ generic row-panel GEMM
 // One workgroup = 16 rows x 16 columns (N/16 x M/16 workgroups: these products are latency bound, so they are
 // spread over as many CUs as possible and each wave's whole K share is fetched in at most a few round trips).
+template <int MT>
 __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
-  constexpr int NT = 1;
-  __shared__ __attribute__((aligned(16))) float red[4 * NT * 256];
+  __shared__ __attribute__((aligned(16))) float red[4 * MT * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
-  f32x4 acc[NT];
-  zero_acc<NT>(acc);
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MT;
+  f32x4 acc[MT][1];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int jv = min(16, a.N - n0);
-  for (int p = 0; p < a.npairs; ++p) tile_dot<NT, 8>(a.p[p], m0, a.M, WRows{n0, 1, 0}, jv, lane, wave, acc);
-  float vals[NT];
-  reduce_waves<NT>(acc, vals, red);
-  const int row = m0 + (threadIdx.x >> 4), n = n0 + (threadIdx.x & 15);
-  if (row >= a.M || n >= a.N) return;
-  float v = vals[0];
-  if (a.bias) v += a.bias[n];
-  if (a.addend) v += a.addend[(long)row * a.ld_add + n];
-  if (a.act == ACT_TANH) v = tanhf(v);
-  else if (a.act == ACT_DTANH) {
-    const float y = a.aux[(long)row * a.ld_aux + n];
-    v *= (1.f - y * y);
+  for (int p = 0; p < a.npairs; ++p) tile_dot<MT, 1, 8>(a.p[p], m0, a.M, WRows{n0, 1, 0}, jv, lane, wave, acc);
+  f32x4 flat[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) flat[mt] = acc[mt][0];
+  float vals[MT];
+  reduce_waves<MT>(flat, vals, red);
+  const int n = n0 + (threadIdx.x & 15);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = m0 + 16 * mt + (threadIdx.x >> 4);
+    if (row >= a.M || n >= a.N) continue;
+    float v = vals[mt];
+    if (a.bias) v += a.bias[n];
+    if (a.addend) v += a.addend[(long)row * a.ld_add + n];
+    if (a.act == ACT_TANH) v = tanhf(v);
+    else if (a.act == ACT_DTANH) {
+      const float y = a.aux[(long)row * a.ld_aux + n];
+      v *= (1.f - y * y);
+    }
+    a.out[(long)row * a.ld_out + n] = v;
+    if (a.out2) a.out2[(long)row * a.ld_out2 + n] = v;
   }
-  a.out[(long)row * a.ld_out + n] = v;
-  if (a.out2) a.out2[(long)row * a.ld_out2 + n] = v;
 }
 
 // ------------------------------------------------------------------ LSTM cell forward (Chainer-sem A1)
@@ -132,24 +153,31 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 
 // One workgroup = 16 batch rows x 4 hidden units: the 16 MFMA columns are the 16 consecutive gate rows 4*j0 .. 4*j0+15 of
 // Chainer's interleaved layout, so a cell spreads over (h/4) x (B/16) workgroups and each streams only 16 weight rows.
+template <int MT>
 __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(CellFwdBatch batch) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 256];
-  __shared__ __attribute__((aligned(16))) float zt[256];
+  __shared__ __attribute__((aligned(16))) float red[4 * MT * 256];
+  __shared__ __attribute__((aligned(16))) float zt[MT * 256];
   const LstmCellFwdArgs& a = batch.c[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int u0 = blockIdx.x * 4, m0 = blockIdx.y * 16;
-  f32x4 acc[1];
-  zero_acc<1>(acc);
+  const int u0 = blockIdx.x * 4, m0 = blockIdx.y * 16 * MT;
+  f32x4 acc[MT][1];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int jv = min(16, 4 * (a.h - u0));
-  for (int p = 0; p < a.npairs; ++p) tile_dot<1, 8>(a.p[p], m0, a.B, WRows{4 * u0, 1, 0}, jv, lane, wave, acc);
-  float v[1];
-  reduce_waves<1>(acc, v, red);
-  zt[threadIdx.x] = v[0];                 // zt[row][col], col = 4*unit + gate
+  for (int p = 0; p < a.npairs; ++p) tile_dot<MT, 1, 8>(a.p[p], m0, a.B, WRows{4 * u0, 1, 0}, jv, lane, wave, acc);
+  f32x4 flat[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) flat[mt] = acc[mt][0];
+  float v[MT];
+  reduce_waves<MT>(flat, v, red);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) zt[mt * 256 + threadIdx.x] = v[mt];                 // zt[tile][row][col], col = 4*unit + gate
   __syncthreads();
-  if (threadIdx.x >= 64) return;
-  const int b = m0 + (threadIdx.x >> 2), u = u0 + (threadIdx.x & 3);
+  if (threadIdx.x >= 64 * MT) return;
+  const int mt = threadIdx.x >> 6, t64 = threadIdx.x & 63;
+  const int b = m0 + 16 * mt + (t64 >> 2), u = u0 + (t64 & 3);
   if (b >= a.B || u >= a.h) return;
-  float4 z = *reinterpret_cast<const float4*>(&zt[(threadIdx.x >> 2) * 16 + (threadIdx.x & 3) * 4]);
+  float4 z = *reinterpret_cast<const float4*>(&zt[mt * 256 + (t64 >> 2) * 16 + (t64 & 3) * 4]);
   if (a.zx) {
     const float4 zx = *reinterpret_cast<const float4*>(a.zx + (long)b * a.ld_zx + 4 * u);
     z.x += zx.x; z.y += zx.y; z.z += zx.z; z.w += zx.w;
@@ -175,48 +203,52 @@ struct CellBwdBatch {
   LstmCellBwdArgs c[8];
 };
 
+template <int MT>
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(CellBwdBatch batch) {
-  constexpr int NT = 2;   // tile 0: dh_rec = dz_next WlT ; tile 1: dx = dz_above WuT_above
-  __shared__ __attribute__((aligned(16))) float red[4 * NT * 256];
+  constexpr int NT = 2;   // product 0: dh_rec = dz_next WlT ; product 1: dx = dz_above WuT_above
+  __shared__ __attribute__((aligned(16))) float red[4 * NT * MT * 256];
   const LstmCellBwdArgs& a = batch.c[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const int j0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MT;
   const int jv = min(16, a.h - j0);
-  f32x4 acc[NT];
-  zero_acc<NT>(acc);
-  {
-    f32x4 one[1];
-    one[0] = acc[0];
-    tile_dot<1, 16>(a.p[0], m0, a.B, WRows{j0, 1, 0}, jv, lane, wave, one);
-    acc[0] = one[0];
-    if (a.npairs > 1) {
-      one[0] = acc[1];
-      tile_dot<1, 16>(a.p[1], m0, a.B, WRows{j0, 1, 0}, jv, lane, wave, one);
-      acc[1] = one[0];
-    }
+  f32x4 accp[NT][MT][1];
+#pragma unroll
+  for (int p = 0; p < NT; ++p)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) accp[p][mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  tile_dot<MT, 1, 16>(a.p[0], m0, a.B, WRows{j0, 1, 0}, jv, lane, wave, accp[0]);
+  if (a.npairs > 1) tile_dot<MT, 1, 16>(a.p[1], m0, a.B, WRows{j0, 1, 0}, jv, lane, wave, accp[1]);
+  f32x4 flat[NT * MT];
+#pragma unroll
+  for (int p = 0; p < NT; ++p)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) flat[p * MT + mt] = accp[p][mt][0];
+  float v[NT * MT];
+  reduce_waves<NT * MT>(flat, v, red);
+  const int u = j0 + (threadIdx.x & 15);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int b = m0 + 16 * mt + (threadIdx.x >> 4);
+    if (b >= a.B || u >= a.h) continue;
+    const long bu = (long)b * a.h + u;
+    float dy = v[MT + mt];
+    if (a.dy) dy += a.dy[(long)b * a.ld_dy + u];
+    if (a.dy2) dy += a.dy2[(long)b * a.ld_dy2 + u];
+    if (a.mask) dy *= a.mask[bu];
+    float dh = v[mt] + dy;
+    if (a.dh_add) dh += a.dh_add[bu];
+    float* gp = a.gates_dz + (long)b * a.ld_g + 4 * u;
+    const float4 g = *reinterpret_cast<const float4*>(gp);
+    const float ga = g.x, gi = g.y, gf = g.z, go = g.w;
+    const float tc = tanhf(a.c_cur[bu]);
+    const float cp = a.c_prev ? a.c_prev[bu] : 0.f;
+    float dc = dh * go * (1.f - tc * tc);
+    if (a.dc_next) dc += a.dc_next[bu];
+    const float4 dz = make_float4(dc * gi * (1.f - ga * ga), dc * ga * gi * (1.f - gi), dc * cp * gf * (1.f - gf),
+                                  dh * tc * go * (1.f - go));
+    *reinterpret_cast<float4*>(gp) = dz;
+    a.dc_prev[bu] = dc * gf;
   }
-  float v[NT];
-  reduce_waves<NT>(acc, v, red);
-  const int b = m0 + (threadIdx.x >> 4), u = j0 + (threadIdx.x & 15);
-  if (b >= a.B || u >= a.h) return;
-  const long bu = (long)b * a.h + u;
-  float dy = v[1];
-  if (a.dy) dy += a.dy[(long)b * a.ld_dy + u];
-  if (a.dy2) dy += a.dy2[(long)b * a.ld_dy2 + u];
-  if (a.mask) dy *= a.mask[bu];
-  float dh = v[0] + dy;
-  if (a.dh_add) dh += a.dh_add[bu];
-  float* gp = a.gates_dz + (long)b * a.ld_g + 4 * u;
-  const float4 g = *reinterpret_cast<const float4*>(gp);
-  const float ga = g.x, gi = g.y, gf = g.z, go = g.w;
-  const float tc = tanhf(a.c_cur[bu]);
-  const float cp = a.c_prev ? a.c_prev[bu] : 0.f;
-  float dc = dh * go * (1.f - tc * tc);
-  if (a.dc_next) dc += a.dc_next[bu];
-  const float4 dz = make_float4(dc * gi * (1.f - ga * ga), dc * ga * gi * (1.f - gi), dc * cp * gf * (1.f - gf),
-                                dh * tc * go * (1.f - go));
-  *reinterpret_cast<float4*>(gp) = dz;
-  a.dc_prev[bu] = dc * gf;
 }
 
 int check_pair(const RowPair& p, const char* who) {
@@ -232,7 +264,9 @@ int check_pair(const RowPair& p, const char* who) {
 int rowgemm_launch(const RowGemmArgs& a, hipStream_t s) {
   ASTK_CHECK(a.M > 0 && a.N > 0 && a.out && a.npairs >= 1 && a.npairs <= 2, "rowgemm: bad arguments");
   for (int p = 0; p < a.npairs; ++p) ASTK_TRY(check_pair(a.p[p], "rowgemm"));
-  hipLaunchKernelGGL(rowgemm_kernel, dim3(cdiv(a.N, 16), cdiv(a.M, 16)), dim3(256), 0, s, a);
+  // two row tiles per workgroup halve the weight traffic but also the number of workgroups: only when the chip stays full
+  if (a.M > 16 && (long)cdiv(a.N, 16) * cdiv(a.M, 32) >= device_cu_count()) hipLaunchKernelGGL(rowgemm_kernel<2>, dim3(cdiv(a.N, 16), cdiv(a.M, 32)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(rowgemm_kernel<1>, dim3(cdiv(a.N, 16), cdiv(a.M, 16)), dim3(256), 0, s, a);
   ASTK_LAUNCH_CHECK();
   return 0;
 }
@@ -250,7 +284,8 @@ int lstm_cell_fwd_launch(const LstmCellFwdArgs* cells, int ncells, hipStream_t s
     batch.c[i] = c;
   }
   ProfScope prof(PROF_CELL, s);
-  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv(cells[0].h, 4), cdiv(cells[0].B, 16), ncells), dim3(256), 0, s, batch);
+  if (cells[0].B > 16 && (long)cdiv(cells[0].h, 4) * cdiv(cells[0].B, 32) * ncells >= device_cu_count()) hipLaunchKernelGGL(lstm_cell_fwd_kernel<2>, dim3(cdiv(cells[0].h, 4), cdiv(cells[0].B, 32), ncells), dim3(256), 0, s, batch);
+  else hipLaunchKernelGGL(lstm_cell_fwd_kernel<1>, dim3(cdiv(cells[0].h, 4), cdiv(cells[0].B, 16), ncells), dim3(256), 0, s, batch);
   ASTK_LAUNCH_CHECK();
   return 0;
 }
@@ -266,7 +301,8 @@ int lstm_cell_bwd_launch(const LstmCellBwdArgs* cells, int ncells, hipStream_t s
     batch.c[i] = c;
   }
   ProfScope prof(PROF_CELL, s);
-  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv(cells[0].h, 16), cdiv(cells[0].B, 16), ncells), dim3(256), 0, s, batch);
+  if (cells[0].B > 16 && (long)cdiv(cells[0].h, 16) * cdiv(cells[0].B, 32) * ncells >= device_cu_count()) hipLaunchKernelGGL(lstm_cell_bwd_kernel<2>, dim3(cdiv(cells[0].h, 16), cdiv(cells[0].B, 32), ncells), dim3(256), 0, s, batch);
+  else hipLaunchKernelGGL(lstm_cell_bwd_kernel<1>, dim3(cdiv(cells[0].h, 16), cdiv(cells[0].B, 16), ncells), dim3(256), 0, s, batch);
   ASTK_LAUNCH_CHECK();
   return 0;
 }
