@@ -356,6 +356,14 @@ struct RowGemmArgs {
   float* out2;          // optional second copy of the result (e.g. into the input-feeding concat buffer)
   long ld_out2;
   int act;
+  // optional in-place "carry" (decoder backward with input feeding): for columns n >= carry_col0, with j = n - carry_col0,
+  //   carry[row][j] = (result + carry[row][j]) * (1 - carry_aux[row][j]^2)
+  // i.e. the d_ht this product hands to the previous decoder step, added to that step's batched dlogits Wo and sent through tanh'
+  float* carry;
+  long ld_carry;
+  const float* carry_aux;
+  long ld_carry_aux;
+  int carry_col0;
 };
 int rowgemm_launch(const RowGemmArgs& a, hipStream_t s);
 

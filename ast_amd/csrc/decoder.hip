@@ -69,6 +69,7 @@ struct DecPlan {
   float* DHTOP;  // [B][H]
   float* DC[ASTK_MAX_RNN_LAYERS][2];
   float* WoT;    // [A][Vp]
+  float* LG1;    // [B][Vp] logits of a step whose argmax is fed back (when every step is scored behind the loop)
   float* WcT;    // [CW][A]
   float* WaT;    // [NA][H][H]
   float* WuT[ASTK_MAX_RNN_LAYERS];  // [in][4H]
@@ -123,6 +124,7 @@ int make_plan(const astk_decoder_desc* d, void* ws, DecPlan& P) {
   P.DX0 = c.take<float>(S * B * P.XI);
   P.DHTOP = c.take<float>(B * H);
   P.WoT = c.take<float>((size_t)P.A * P.Vp);
+  P.LG1 = c.take<float>((size_t)P.B * P.Vp);
   P.WcT = c.take<float>(CW * P.A);
   P.WaT = c.take<float>(NA * H * H);
   P.attn_ws = c.take<char>(attn_ws_bytes(P.B, P.T, P.H));
@@ -172,12 +174,18 @@ __global__ void k_embed_bwd(float* __restrict__ d_embed, const int32_t* __restri
 }
 
 // One block per row: log-softmax, weighted NLL / count, first-max argmax, dlogits in place (Chainer-sem A6).
+// Row r is (step r / rows_per_step, batch row r % rows_per_step); its class id is targets[(r % rows_per_step) * t_stride + r / rows_per_step]
+// (one decoder step: rows_per_step = B and `targets` points at the step's column).  argmax_only: feedback tokens of a step whose loss is
+// scored later (the batched pass); fed_flags (the loop's use_truth, n_steps entries): that batched pass leaves the argmax of the steps
+// whose token was fed back (flag of the NEXT step 0) as the loop wrote it.
 __global__ __launch_bounds__(256) void k_softmax_ce(int V, long ld, float* __restrict__ logits, const int32_t* __restrict__ targets,
-                                                    long t_stride, const float* __restrict__ cw, float inv_count,
-                                                    float* __restrict__ loss_rows, int32_t* __restrict__ argmax) {
+                                                    long t_stride, int rows_per_step, const float* __restrict__ cw, float inv_count,
+                                                    float* __restrict__ loss_rows, int32_t* __restrict__ argmax, int argmax_only,
+                                                    const int32_t* __restrict__ fed_flags, int n_steps) {
   __shared__ float sv[4];
   __shared__ int si[4];
   const int b = blockIdx.x;
+  const int step = b / rows_per_step, brow = b - step * rows_per_step;
   float* x = logits + (long)b * ld;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float mx = -INFINITY;
@@ -197,6 +205,10 @@ __global__ __launch_bounds__(256) void k_softmax_ce(int V, long ld, float* __res
   for (int w = 1; w < 4; ++w)
     if (sv[w] > mx || (sv[w] == mx && si[w] < mi)) { mx = sv[w]; mi = si[w]; }
   __syncthreads();
+  if (argmax_only) {
+    if (threadIdx.x == 0 && argmax) argmax[b] = mi;
+    return;
+  }
   float sum = 0.f;
   for (int v = threadIdx.x; v < V; v += 256) sum += expf(x[v] - mx);
   for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(256) void k_softmax_ce(int V, long ld, float* __res
   __syncthreads();
   sum = sv[0] + sv[1] + sv[2] + sv[3];
   const float lse = mx + logf(sum);
-  int t = targets[(long)b * t_stride];
+ int t = targets[(long)brow * t_stride + step];
   const bool ignore = t < 0;                      // ignore_label = -1 never occurs on this path (PAD is 0)
   t = t < 0 ? 0 : (t >= V ? V - 1 : t);
   const float w = ignore ? 0.f : (cw ? cw[t] : 1.f);
@@ -212,7 +224,8 @@ __global__ __launch_bounds__(256) void k_softmax_ce(int V, long ld, float* __res
   __syncthreads();
   if (threadIdx.x == 0) {
     if (loss_rows) loss_rows[b] = -(xt - lse) * w * inv_count;
-    if (argmax) argmax[b] = mi;
+    const bool fed = fed_flags && step + 1 < n_steps && fed_flags[step + 1] == 0;
+    if (argmax && !fed) argmax[b] = mi;
   }
   const float scale = w * inv_count;
   for (int v = threadIdx.x; v < ld; v += 256) {
@@ -238,6 +251,14 @@ __global__ void k_sum_to(const float* __restrict__ src, int n, float* __restrict
 __global__ void k_copy_i32(int32_t* dst, const int32_t* src, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i];
+}
+
+// x *= 1 - y^2 (the tanh' factor of d_pre on the rows that take no carry from a later step)
+__global__ void k_dtanh_inplace(float* __restrict__ x, const float* __restrict__ y, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float t = y[i];
+    x[i] *= 1.f - t * t;
+  }
 }
 
 RowGemmArgs rg(int M, int N, const float* A, long lda, const float* W, long ldw, int K, float* out, long ld_out) {
@@ -353,7 +374,8 @@ int make_split(const astk_decoder_desc* d, void* ws, SplitPlan& sp) {
 int softmax_ce_launch(int B, int V, long ld, float* logits, const int32_t* targets, long t_stride, const float* cw, float inv_count,
                       float* loss_rows, int32_t* argmax, hipStream_t s) {
   ASTK_CHECK(B > 0 && V > 0 && ld >= V && logits && targets, "softmax_ce: bad arguments");
-  hipLaunchKernelGGL(k_softmax_ce, dim3(B), dim3(256), 0, s, V, ld, logits, targets, t_stride, cw, inv_count, loss_rows, argmax);
+  hipLaunchKernelGGL(k_softmax_ce, dim3(B), dim3(256), 0, s, V, ld, logits, targets, t_stride, B, cw, inv_count, loss_rows, argmax, 0,
+                     (const int32_t*)nullptr, 0);
   ASTK_LAUNCH_CHECK();
   return 0;
 }
@@ -462,6 +484,8 @@ int astk_decoder_fwd_ex(const astk_decoder_desc* d, const astk_decoder_params* p
       return 0;
     }
   }
+  const int32_t* uth = d->use_truth_host;      // optional host copy of use_truth: which steps feed their argmax back
+  const float inv_count = 1.f / (float)(d->loss_rows > 0 ? d->loss_rows : B);
   for (int st = 0; st < S; ++st) {
     float* x0 = P.X0 + (size_t)st * B * XI;
     hipLaunchKernelGGL(k_embed, dim3(B), dim3(128), 0, s, prm->embed, y, P.L, st, use_truth, st > 0 ? P.PRED + (size_t)(st - 1) * B : nullptr,
@@ -511,18 +535,34 @@ int astk_decoder_fwd_ex(const astk_decoder_desc* d, const astk_decoder_params* p
       if (P.feed && st + 1 < S) { a.out2 = P.X0 + (size_t)(st + 1) * B * XI + E; a.ld_out2 = XI; }
       ASTK_TRY(rowgemm_launch(a, s));
     }
-    float* lg = P.LOGITS + (size_t)st * B * P.Vp;
-    {
+    // logits, dropout on the logits (seq2seq.py:394: argmax feedback and loss see the dropped logits; the gradient passes the same mask),
+    // softmax cross-entropy.  With the caller's host copy of the flags only the steps whose argmax is FED BACK compute their logits
+    // inside the loop (into a scratch panel, argmax only); every step is scored by one product and one launch behind the loop.
+    const float* om = out_mask ? out_mask + (size_t)st * B * V : nullptr;
+    const bool fed_back = st + 1 < S && (!uth || uth[st + 1] == 0);
+    if (!uth || fed_back) {
+      float* lg = uth ? P.LG1 : P.LOGITS + (size_t)st * B * P.Vp;
       RowGemmArgs a = rg(B, V, ht, A, prm->Wo, A, A, lg, P.Vp);
       a.bias = prm->bo;
       ASTK_TRY(rowgemm_launch(a, s));
+      if (om) ASTK_TRY(mul_rows_launch(lg, P.Vp, om, V, B, V, s));
+      if (uth) {
+        hipLaunchKernelGGL(k_softmax_ce, dim3(B), dim3(256), 0, s, V, (long)P.Vp, lg, tgt + st + 1, (long)P.L, B, (const float*)nullptr, 1.f,
+                           (float*)nullptr, P.PRED + (size_t)st * B, 1, (const int32_t*)nullptr, 0);
+        ASTK_LAUNCH_CHECK();
+      } else {
+        ASTK_TRY(softmax_ce_launch(B, V, P.Vp, lg, tgt + st + 1, P.L, prm->class_weight, inv_count, P.LOSSROWS + (size_t)st * B, P.PRED + (size_t)st * B, s));
+        if (om) ASTK_TRY(mul_rows_launch(lg, P.Vp, om, V, B, V, s));
+      }
     }
-    // dropout on the logits (seq2seq.py:394): argmax feedback and loss see the dropped logits; the gradient passes the same mask
-    const float* om = out_mask ? out_mask + (size_t)st * B * V : nullptr;
-    if (om) ASTK_TRY(mul_rows_launch(lg, P.Vp, om, V, B, V, s));
-    ASTK_TRY(softmax_ce_launch(B, V, P.Vp, lg, tgt + st + 1, P.L, prm->class_weight, 1.f / (float)(d->loss_rows > 0 ? d->loss_rows : B), P.LOSSROWS + (size_t)st * B,
-                               P.PRED + (size_t)st * B, s));
-    if (om) ASTK_TRY(mul_rows_launch(lg, P.Vp, om, V, B, V, s));
+  }
+  if (uth) {
+    ASTK_TRY(gemm_launch(GEMM_NT, gemm_args(S * B, V, A, mat(P.HT + (size_t)B * A, A), mat(prm->Wo, A), P.LOGITS, P.Vp, prm->bo), s));
+    if (out_mask) ASTK_TRY(mul_rows_launch(P.LOGITS, P.Vp, out_mask, V, S * B, V, s));
+    hipLaunchKernelGGL(k_softmax_ce, dim3(S * B), dim3(256), 0, s, V, (long)P.Vp, P.LOGITS, tgt + 1, (long)P.L, B, prm->class_weight, inv_count,
+                       P.LOSSROWS, P.PRED, 0, use_truth, S);
+    ASTK_LAUNCH_CHECK();
+    if (out_mask) ASTK_TRY(mul_rows_launch(P.LOGITS, P.Vp, out_mask, V, S * B, V, s));
   }
   hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, s, P.LOSSROWS, S * B, loss);
   ASTK_LAUNCH_CHECK();
@@ -588,7 +628,7 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
   {
     TransposeJobs tj;
     tj.n = 0;
-    transpose_add(tj, P.WoT, Vp, prm->Wo, A, V, A);          // (V,A) -> (A,Vp)
+    if (persist) transpose_add(tj, P.WoT, Vp, prm->Wo, A, V, A);          // (V,A) -> (A,Vp); the per-launch loop batches dlogits Wo over the steps
     transpose_add(tj, P.WcT, A, prm->Wc, CW, A, CW);         // (A,CW) -> (CW,A)
     for (int k = 0; k < NA; ++k) transpose_add(tj, P.WaT + (size_t)k * H * H, H, k == 0 ? prm->Wa : prm->Wa_x[k - 1], H, H, H);
     for (int l = 0; l < nl; ++l) {
@@ -610,19 +650,19 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
     bf.DXH = b6s ? P.DXH : nullptr;
     ASTK_TRY(decoder_persist_bwd_launch(d, enc, rnn_masks, bf, s));
   }
+  if (!persist) {
+    // d_pre = (dlogits Wo + d_ht carried from step st+1 through input feeding) * (1 - ht^2).  dlogits Wo does not depend on the recurrence:
+    // ONE product over all S*B rows (K = V; as a per-step row panel it is 2*ceil(B/16)*A/16 workgroups walking K = V each), then tanh' on
+    // the rows that take no carry -- the last step, or every step without input feeding; the others get carry and tanh' from the epilogue
+    // of step st+1's d_x0 product (RowGemmArgs::carry).
+    ASTK_TRY(gemm_launch(GEMM_NN, gemm_args(S * B, A, V, mat(P.LOGITS, Vp), mat(prm->Wo, A), P.DPRE, A), s));
+    const long r0 = P.feed ? (long)(S - 1) * B * A : 0, n = (long)S * B * A - r0;
+    hipLaunchKernelGGL(k_dtanh_inplace, dim3((unsigned)std::min<long>(cdiv(n, 256), 2048)), dim3(256), 0, s, P.DPRE + r0, P.HT + (size_t)B * A + r0, n);
+    ASTK_LAUNCH_CHECK();
+  }
   for (int st = S - 1; st >= 0 && !persist; --st) {
     const bool last = st == S - 1;
-    float* dl = P.LOGITS + (size_t)st * B * Vp;
     float* dpre = P.DPRE + (size_t)st * B * A;
-    // d_pre = (dlogits Wo + d_ht carried from step st+1 through input feeding) * (1 - ht^2)
-    {
-      RowGemmArgs a = rg(B, A, dl, Vp, P.WoT, Vp, Vp, dpre, A);
-      if (P.feed && !last) { a.addend = P.DX0 + (size_t)(st + 1) * B * XI + E; a.ld_add = XI; }
-      a.act = ACT_DTANH;
-      a.aux = P.HT + (size_t)(st + 1) * B * A;
-      a.ld_aux = A;
-      ASTK_TRY(rowgemm_launch(a, s));
-    }
     float* dcvh = P.DCVH + (size_t)st * B * CW;
     ASTK_TRY(rowgemm_launch(rg(B, CW, dpre, A, P.WcT, A, A, dcvh, CW), s));
     float* cvh = P.CVH + (size_t)st * B * CW;
@@ -684,7 +724,15 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
       ASTK_TRY(lstm_cell_bwd_launch(&c, 1, s));
     }
     // gradient wrt the layer-0 input [emb ; ht_{st-1}] (or the embedding alone)
-    ASTK_TRY(rowgemm_launch(rg(B, XI, P.G[0] + (size_t)st * B * 4 * H, 4 * H, P.WuT[0], 4 * H, 4 * H, P.DX0 + (size_t)st * B * XI, XI), s));
+    {
+      RowGemmArgs a = rg(B, XI, P.G[0] + (size_t)st * B * 4 * H, 4 * H, P.WuT[0], 4 * H, 4 * H, P.DX0 + (size_t)st * B * XI, XI);
+      if (P.feed && st > 0) {     // columns E.. are d_ht of step st-1: finish that step's d_pre in place
+        a.carry = P.DPRE + (size_t)(st - 1) * B * A; a.ld_carry = A;
+        a.carry_aux = P.HT + (size_t)st * B * A; a.ld_carry_aux = A;
+        a.carry_col0 = E;
+      }
+      ASTK_TRY(rowgemm_launch(a, s));
+    }
   }
   // ---- gradients wrt the initial states (flow into the encoder's final states, seq2seq.py:326-329)
   for (int l = 0; l < nl; ++l) {

@@ -141,6 +141,12 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
     }
     a.out[(long)row * a.ld_out + n] = v;
     if (a.out2) a.out2[(long)row * a.ld_out2 + n] = v;
+    if (a.carry && n >= a.carry_col0) {
+      const int j = n - a.carry_col0;
+      const float y = a.carry_aux[(long)row * a.ld_carry_aux + j];
+      float* c = a.carry + (long)row * a.ld_carry + j;
+      *c = (v + *c) * (1.f - y * y);
+    }
   }
 }
 

@@ -627,6 +627,8 @@ class SpeechEncoderDecoder:
             flags = [int(random.random() < teach_ratio) if 0 < i < L - 2 else 1 for i in range(S)]
         self.use_truth = flags
         self._upload_flags(st["flags"], flags)
+        st["flags_host"] = (C.c_int32 * S)(*flags)          # the per-launch loop scores the teacher-forced steps behind the loop (astk.h)
+        st["dd"].use_truth_host = C.cast(st["flags_host"], C.POINTER(C.c_int32))
         st["y"] = y
         st["targets"] = targets
         dr = self.cfg["dropout"]

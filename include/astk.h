@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ASTK_VERSION 101
+#define ASTK_VERSION 102
 #define ASTK_MAX_CNN_LAYERS 4
 #define ASTK_MAX_RNN_LAYERS 8
 #define ASTK_MAX_ATTN 4
@@ -206,6 +206,9 @@ typedef struct {
   int ln;            /* rnn_config.ln (seq2seq.py:141-143, 200-202): L.LayerNormalization(H) behind every decoder LSTM's dropped output */
   int loss_rows;     /* denominator of the per-step cross-entropy mean (quirk Q6: the batch size); 0 = B.  Set when this call scores a
                         SLICE of a larger batch (the library's own row split of batches the persistent loop cannot hold in one launch) */
+  const int32_t* use_truth_host; /* optional HOST copy of the use_truth flags handed to astk_decoder_fwd(_ex) (L-1 entries), or NULL.  A hint for
+                        the per-launch loop only: it then computes logits inside the loop just for the steps whose argmax is fed back and
+                        scores every step with one product and one softmax-CE launch behind the loop.  Read during the call, not kept. */
 } astk_decoder_desc;
 
 typedef struct {

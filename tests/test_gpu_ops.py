@@ -378,11 +378,32 @@ def _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=0):
                                                     (64, 6, 200, 512, 128, 512, 1098, 1, True), (48, 5, 200, 512, 128, 512, 1098, 3, True),
                                                     (37, 5, 50, 512, 128, 512, 300, 1, False)])
 def test_decoder_fwd_bwd(lib, B, L, T, H, E, A, V, nl, masks, gemm_split):
-    from oracle.ast_ref_torch import decoder_torch
     s = _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=B + L)
     if H % 64 == 0 and A % 16 == 0 and E % 16 == 0 and nl <= 3:       # the shapes meant for the persistent kernels really take them
         assert lib.astk_decoder_path(C.byref(s["d"])) & 1, "persistent decoder path not taken"
         assert bool(lib.astk_decoder_path(C.byref(s["d"])) & 4) == (B > 32 and H == 512), "row split"
+    _decoder_case(lib, s, B, L, T, H, E, A, V, nl, masks)
+
+
+@pytest.mark.parametrize("B,L,T,H,E,A,V,nl,masks", [(5, 9, 23, 32, 12, 24, 57, 3, True), (32, 9, 50, 512, 128, 512, 1098, 1, True),
+                                                    (19, 8, 37, 128, 32, 64, 130, 2, False), (2, 2, 5, 8, 4, 8, 7, 1, False),
+                                                    # configs[4]'s decoder width and vocabulary: no persistent loop holds it, this is its path
+                                                    (32, 8, 40, 1024, 128, 1024, 8004, 1, False)])
+def test_decoder_per_launch_loop_scored_behind_the_loop(lib, monkeypatch, B, L, T, H, E, A, V, nl, masks, gemm_split):
+    """The per-launch loop with the caller's HOST copy of the flags (astk_decoder_desc.use_truth_host): logits inside the loop only for the
+    steps whose argmax is fed back, every step scored by one product and one softmax-CE launch behind it; in the backward, dlogits Wo as
+    one product in front of the loop and the carry through input feeding from the epilogue of the next step's d_x0 product."""
+    monkeypatch.setenv("ASTK_DEC_PERSIST", "0")
+    s = _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=B + L + 1)
+    assert not (lib.astk_decoder_path(C.byref(s["d"])) & 1)
+    host = (C.c_int32 * s["S"])(*[int(f) for f in s["flags"]])
+    s["d"].use_truth_host = C.cast(host, C.POINTER(C.c_int32))
+    assert 0 in list(host) or s["S"] < 3, "the case should feed at least one argmax back"
+    _decoder_case(lib, s, B, L, T, H, E, A, V, nl, masks)
+
+
+def _decoder_case(lib, s, B, L, T, H, E, A, V, nl, masks):
+    from oracle.ast_ref_torch import decoder_torch
     cfg = {"rnn_config": {"dec_layers": nl, "attn_units": A}}
     Pt = {k: torch.tensor(v, requires_grad=True) for k, v in s["P"].items()}
     enc_t = torch.tensor(s["enc"], requires_grad=True)
