@@ -24,7 +24,9 @@ struct WRows {   // W row for (tile t, column j) = base + j*sj + t*st ; valid co
 // CH k-blocks per wave are loaded back to back (one exposed memory round trip per trip) before their MFMAs issue.
 // MT: row tiles (16 rows each) of one workgroup that share the weight fragments -- these products stream their weights once per
 // workgroup, so a batch of 17-32 rows as two workgroups per column tile reads every weight twice (round 3: MT = 2 above 16 rows).
-template <int MT, int NT, int CH>
+// NW: waves of the workgroup that share the K range (4, or 8 when K is long: a wave's share is fetched in ceil(K / 16 / NW / CH) exposed
+// round trips, and at K = 2176 / 4096 -- the H = 1024 decoder's cell products -- four waves need 5 / 4 of them).
+template <int MT, int NT, int CH, int NW = 4>
 __device__ __forceinline__ void tile_dot(const RowPair& pr, int m0, int M, WRows wr, int jvalid, int lane, int wave,
                                          f32x4 (&acc)[MT][NT]) {
   const int K = pr.K;
@@ -43,13 +45,13 @@ __device__ __forceinline__ void tile_dot(const RowPair& pr, int m0, int M, WRows
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc2[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int sb = wave; sb < nblk; sb += 4 * CH) {
+  for (int sb = wave; sb < nblk; sb += NW * CH) {
     float4 av[MT][CH], wv[CH][NT];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       // branch-free: the address is clamped inside the row (K % 4 == 0), out-of-range k-blocks are zeroed by a select on the
       // A operand only (0 * w = 0) -- a `cond ? load : 0` would serialise every load behind a vmcnt(0)
-      const int s = sb + 4 * i;
+      const int s = sb + NW * i;
       const int ko = min(16 * s + 4 * q, K - 4) - 4 * q;
       const bool v = (16 * s + 4 * q) < K;
 #pragma unroll
@@ -87,19 +89,24 @@ __device__ __forceinline__ void tile_dot(const RowPair& pr, int m0, int M, WRows
 
 // 4-wave K reduction.  D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
 // After the call thread tid holds, for each tile t, the full sum of element (row = tid>>4, col = tid&15).
-template <int NT>
-__device__ __forceinline__ void reduce_waves(f32x4 (&acc)[NT], float (&vals)[NT], float* red /* [4][NT][256] */) {
+// (NW = 8: threads 256.. only contribute their partial sums; the caller's epilogue runs on threads 0..255.)
+template <int NT, int NW = 4>
+__device__ __forceinline__ void reduce_waves(f32x4 (&acc)[NT], float (&vals)[NT], float* red /* [NW][NT][256] */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
     *reinterpret_cast<f32x4*>(&red[((wave * NT + t) * 64 + lane) * 4]) = acc[t];
   __syncthreads();
-  const int row = tid >> 4, col = tid & 15;
+  const int t256 = tid & 255;
+  const int row = t256 >> 4, col = t256 & 15;
   const int src = ((row >> 2) * 16 + col) * 4 + (row & 3);
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-    vals[t] = red[(0 * NT + t) * 256 + src] + red[(1 * NT + t) * 256 + src] + red[(2 * NT + t) * 256 + src] +
-              red[(3 * NT + t) * 256 + src];
+  for (int t = 0; t < NT; ++t) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += red[(w * NT + t) * 256 + src];
+    vals[t] = v;
+  }
 }
 
 template <int NT>
@@ -111,21 +118,22 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NT]) {
 // ------------------------------------------------------------------ generic row-panel GEMM
 // One workgroup = 16 rows x 16 columns (N/16 x M/16 workgroups: these products are latency bound, so they are
 // spread over as many CUs as possible and each wave's whole K share is fetched in at most a few round trips).
-template <int MT>
-__global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[4 * MT * 256];
+template <int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void rowgemm_kernel(RowGemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[NW * MT * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MT;
   f32x4 acc[MT][1];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int jv = min(16, a.N - n0);
-  for (int p = 0; p < a.npairs; ++p) tile_dot<MT, 1, 8>(a.p[p], m0, a.M, WRows{n0, 1, 0}, jv, lane, wave, acc);
+  for (int p = 0; p < a.npairs; ++p) tile_dot<MT, 1, 8, NW>(a.p[p], m0, a.M, WRows{n0, 1, 0}, jv, lane, wave, acc);
   f32x4 flat[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) flat[mt] = acc[mt][0];
   float vals[MT];
-  reduce_waves<MT>(flat, vals, red);
+  reduce_waves<MT, NW>(flat, vals, red);
+  if (NW > 4 && threadIdx.x >= 256) return;
   const int n = n0 + (threadIdx.x & 15);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -159,9 +167,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 
 // One workgroup = 16 batch rows x 4 hidden units: the 16 MFMA columns are the 16 consecutive gate rows 4*j0 .. 4*j0+15 of
 // Chainer's interleaved layout, so a cell spreads over (h/4) x (B/16) workgroups and each streams only 16 weight rows.
-template <int MT>
-__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(CellFwdBatch batch) {
-  __shared__ __attribute__((aligned(16))) float red[4 * MT * 256];
+template <int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void lstm_cell_fwd_kernel(CellFwdBatch batch) {
+  __shared__ __attribute__((aligned(16))) float red[NW * MT * 256];
   __shared__ __attribute__((aligned(16))) float zt[MT * 256];
   const LstmCellFwdArgs& a = batch.c[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -170,14 +178,16 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(CellFwdBatch batch) 
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int jv = min(16, 4 * (a.h - u0));
-  for (int p = 0; p < a.npairs; ++p) tile_dot<MT, 1, 8>(a.p[p], m0, a.B, WRows{4 * u0, 1, 0}, jv, lane, wave, acc);
+  for (int p = 0; p < a.npairs; ++p) tile_dot<MT, 1, 8, NW>(a.p[p], m0, a.B, WRows{4 * u0, 1, 0}, jv, lane, wave, acc);
   f32x4 flat[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) flat[mt] = acc[mt][0];
   float v[MT];
-  reduce_waves<MT>(flat, v, red);
+  reduce_waves<MT, NW>(flat, v, red);
+  if (threadIdx.x < 256) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) zt[mt * 256 + threadIdx.x] = v[mt];                 // zt[tile][row][col], col = 4*unit + gate
+    for (int mt = 0; mt < MT; ++mt) zt[mt * 256 + threadIdx.x] = v[mt];               // zt[tile][row][col], col = 4*unit + gate
+  }
   __syncthreads();
   if (threadIdx.x >= 64 * MT) return;
   const int mt = threadIdx.x >> 6, t64 = threadIdx.x & 63;
@@ -209,10 +219,10 @@ struct CellBwdBatch {
   LstmCellBwdArgs c[8];
 };
 
-template <int MT>
-__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(CellBwdBatch batch) {
+template <int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void lstm_cell_bwd_kernel(CellBwdBatch batch) {
   constexpr int NT = 2;   // product 0: dh_rec = dz_next WlT ; product 1: dx = dz_above WuT_above
-  __shared__ __attribute__((aligned(16))) float red[4 * NT * MT * 256];
+  __shared__ __attribute__((aligned(16))) float red[NW * NT * MT * 256];
   const LstmCellBwdArgs& a = batch.c[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MT;
@@ -222,15 +232,16 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(CellBwdBatch batch) 
   for (int p = 0; p < NT; ++p)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) accp[p][mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-  tile_dot<MT, 1, 16>(a.p[0], m0, a.B, WRows{j0, 1, 0}, jv, lane, wave, accp[0]);
-  if (a.npairs > 1) tile_dot<MT, 1, 16>(a.p[1], m0, a.B, WRows{j0, 1, 0}, jv, lane, wave, accp[1]);
+  tile_dot<MT, 1, 16, NW>(a.p[0], m0, a.B, WRows{j0, 1, 0}, jv, lane, wave, accp[0]);
+  if (a.npairs > 1) tile_dot<MT, 1, 16, NW>(a.p[1], m0, a.B, WRows{j0, 1, 0}, jv, lane, wave, accp[1]);
   f32x4 flat[NT * MT];
 #pragma unroll
   for (int p = 0; p < NT; ++p)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) flat[p * MT + mt] = accp[p][mt][0];
   float v[NT * MT];
-  reduce_waves<NT * MT>(flat, v, red);
+  reduce_waves<NT * MT, NW>(flat, v, red);
+  if (NW > 4 && threadIdx.x >= 256) return;
   const int u = j0 + (threadIdx.x & 15);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -257,6 +268,17 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(CellBwdBatch batch) 
   }
 }
 
+// eight waves share K once a four-wave workgroup would need more than two exposed round trips per wave (ASTK_ROW_LONGK overrides the
+// threshold, 0 = never: for A/B runs)
+bool long_k(int k) {
+  static int thr = -1;
+  if (thr < 0) {
+    const char* e = getenv("ASTK_ROW_LONGK");
+    thr = e ? atoi(e) : 2048;
+  }
+  return thr > 0 && k >= thr;
+}
+
 int check_pair(const RowPair& p, const char* who) {
   if (p.K <= 0) return 0;
   ASTK_CHECK(p.A && p.W, "%s: null operand", who);
@@ -271,8 +293,17 @@ int rowgemm_launch(const RowGemmArgs& a, hipStream_t s) {
   ASTK_CHECK(a.M > 0 && a.N > 0 && a.out && a.npairs >= 1 && a.npairs <= 2, "rowgemm: bad arguments");
   for (int p = 0; p < a.npairs; ++p) ASTK_TRY(check_pair(a.p[p], "rowgemm"));
   // two row tiles per workgroup halve the weight traffic but also the number of workgroups: only when the chip stays full
-  if (a.M > 16 && (long)cdiv(a.N, 16) * cdiv(a.M, 32) >= device_cu_count()) hipLaunchKernelGGL(rowgemm_kernel<2>, dim3(cdiv(a.N, 16), cdiv(a.M, 32)), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(rowgemm_kernel<1>, dim3(cdiv(a.N, 16), cdiv(a.M, 16)), dim3(256), 0, s, a);
+  const bool two = a.M > 16 && (long)cdiv(a.N, 16) * cdiv(a.M, 32) >= device_cu_count();
+  int ktot = 0;
+  for (int p = 0; p < a.npairs; ++p) ktot += a.p[p].K;
+  const dim3 grid(cdiv(a.N, 16), cdiv(a.M, two ? 32 : 16));
+  if (long_k(ktot)) {
+    if (two) hipLaunchKernelGGL((rowgemm_kernel<2, 8>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((rowgemm_kernel<1, 8>), grid, dim3(512), 0, s, a);
+  } else {
+    if (two) hipLaunchKernelGGL((rowgemm_kernel<2, 4>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((rowgemm_kernel<1, 4>), grid, dim3(256), 0, s, a);
+  }
   ASTK_LAUNCH_CHECK();
   return 0;
 }
@@ -290,8 +321,17 @@ int lstm_cell_fwd_launch(const LstmCellFwdArgs* cells, int ncells, hipStream_t s
     batch.c[i] = c;
   }
   ProfScope prof(PROF_CELL, s);
-  if (cells[0].B > 16 && (long)cdiv(cells[0].h, 4) * cdiv(cells[0].B, 32) * ncells >= device_cu_count()) hipLaunchKernelGGL(lstm_cell_fwd_kernel<2>, dim3(cdiv(cells[0].h, 4), cdiv(cells[0].B, 32), ncells), dim3(256), 0, s, batch);
-  else hipLaunchKernelGGL(lstm_cell_fwd_kernel<1>, dim3(cdiv(cells[0].h, 4), cdiv(cells[0].B, 16), ncells), dim3(256), 0, s, batch);
+  const bool two = cells[0].B > 16 && (long)cdiv(cells[0].h, 4) * cdiv(cells[0].B, 32) * ncells >= device_cu_count();
+  const dim3 grid(cdiv(cells[0].h, 4), cdiv(cells[0].B, two ? 32 : 16), ncells);
+  int ktot = 0;
+  for (int p = 0; p < cells[0].npairs; ++p) ktot += cells[0].p[p].K;
+  if (long_k(ktot)) {
+    if (two) hipLaunchKernelGGL((lstm_cell_fwd_kernel<2, 8>), grid, dim3(512), 0, s, batch);
+    else hipLaunchKernelGGL((lstm_cell_fwd_kernel<1, 8>), grid, dim3(512), 0, s, batch);
+  } else {
+    if (two) hipLaunchKernelGGL((lstm_cell_fwd_kernel<2, 4>), grid, dim3(256), 0, s, batch);
+    else hipLaunchKernelGGL((lstm_cell_fwd_kernel<1, 4>), grid, dim3(256), 0, s, batch);
+  }
   ASTK_LAUNCH_CHECK();
   return 0;
 }
@@ -307,8 +347,17 @@ int lstm_cell_bwd_launch(const LstmCellBwdArgs* cells, int ncells, hipStream_t s
     batch.c[i] = c;
   }
   ProfScope prof(PROF_CELL, s);
-  if (cells[0].B > 16 && (long)cdiv(cells[0].h, 16) * cdiv(cells[0].B, 32) * ncells >= device_cu_count()) hipLaunchKernelGGL(lstm_cell_bwd_kernel<2>, dim3(cdiv(cells[0].h, 16), cdiv(cells[0].B, 32), ncells), dim3(256), 0, s, batch);
-  else hipLaunchKernelGGL(lstm_cell_bwd_kernel<1>, dim3(cdiv(cells[0].h, 16), cdiv(cells[0].B, 16), ncells), dim3(256), 0, s, batch);
+  const bool two = cells[0].B > 16 && (long)cdiv(cells[0].h, 16) * cdiv(cells[0].B, 32) * ncells >= device_cu_count();
+  const dim3 grid(cdiv(cells[0].h, 16), cdiv(cells[0].B, two ? 32 : 16), ncells);
+  int kmax = 0;
+  for (int p = 0; p < cells[0].npairs; ++p) kmax = cells[0].p[p].K > kmax ? cells[0].p[p].K : kmax;
+  if (long_k(kmax)) {
+    if (two) hipLaunchKernelGGL((lstm_cell_bwd_kernel<2, 8>), grid, dim3(512), 0, s, batch);
+    else hipLaunchKernelGGL((lstm_cell_bwd_kernel<1, 8>), grid, dim3(512), 0, s, batch);
+  } else {
+    if (two) hipLaunchKernelGGL((lstm_cell_bwd_kernel<2, 4>), grid, dim3(256), 0, s, batch);
+    else hipLaunchKernelGGL((lstm_cell_bwd_kernel<1, 4>), grid, dim3(256), 0, s, batch);
+  }
   ASTK_LAUNCH_CHECK();
   return 0;
 }
