@@ -19,7 +19,8 @@ class CnnDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("D", C.c_int), ("n_layers", C.c_int),
                 ("C", C.c_int * MAX_CNN), ("kt", C.c_int * MAX_CNN), ("kf", C.c_int * MAX_CNN),
                 ("st", C.c_int * MAX_CNN), ("sf", C.c_int * MAX_CNN), ("pt", C.c_int * MAX_CNN),
-                ("bn_eps", C.c_float), ("bn_decay", C.c_float), ("no_bn", C.c_int)]
+                ("bn_eps", C.c_float), ("bn_decay", C.c_float), ("no_bn", C.c_int),
+                ("pool_t", C.c_int * MAX_CNN), ("pool_f", C.c_int * MAX_CNN)]
 
 
 class CnnLayerParams(C.Structure):

@@ -20,16 +20,25 @@ namespace {
 
 struct CnnPlan {
   int n;
-  int B, T, D, F;
-  int Tn[ASTK_MAX_CNN_LAYERS];      // output time length of layer i
+  int B, T, D;
+  // Tn / Fn / rows: what layer i hands on (after its optional max-pool, enc_dec.py:444-456); Tc / Fc / rowsc: its convolution's output.
+  // Without pooling (every shipped config) the two sets are equal and YC[i] == Y[i].
+  int Tn[ASTK_MAX_CNN_LAYERS], Fn[ASTK_MAX_CNN_LAYERS];
+  int Tc[ASTK_MAX_CNN_LAYERS], Fc[ASTK_MAX_CNN_LAYERS];
+  int pwt[ASTK_MAX_CNN_LAYERS], pwf[ASTK_MAX_CNN_LAYERS];   // pooling windows (1 = none)
+  bool pooled[ASTK_MAX_CNN_LAYERS];
   int Cn[ASTK_MAX_CNN_LAYERS];
-  int rows[ASTK_MAX_CNN_LAYERS];    // B*F*Tn[i]
+  int rows[ASTK_MAX_CNN_LAYERS];    // B*Fn[i]*Tn[i]
+  int rowsc[ASTK_MAX_CNN_LAYERS];   // B*Fc[i]*Tc[i]
   int K0, K0p;                      // layer-0 patch size and its padded width
   int padA[ASTK_MAX_CNN_LAYERS];    // time padding of HP_i (= pt of layer i+1), front == back
   int dF[ASTK_MAX_CNN_LAYERS], dB[ASTK_MAX_CNN_LAYERS];  // front/back padding of DYP_i for the dgrad windows (i>=1)
   // workspace slices
   float* P0;
-  float* Y[ASTK_MAX_CNN_LAYERS];
+  float* Y[ASTK_MAX_CNN_LAYERS];    // what BatchNorm sees: the convolution's output, max-pooled when the layer pools
+  float* YC[ASTK_MAX_CNN_LAYERS];   // the convolution's output (== Y[i] without pooling)
+  int32_t* IDX[ASTK_MAX_CNN_LAYERS];  // pooled layers: [rows][C] row of YC that won the window
+  float* DYP[ASTK_MAX_CNN_LAYERS];    // pooled layers: gradient wrt Y[i] (un-pooled into DY[i] by k_unpool)
   float* HP[ASTK_MAX_CNN_LAYERS];   // i < n-1
   float* Wr[ASTK_MAX_CNN_LAYERS];   // repacked weights (i=0: padded (C0,K0p); i>=1: (C_i, kt*C_{i-1}))
   double* stat[ASTK_MAX_CNN_LAYERS];  // per layer [2][C] column sums (double)
@@ -66,8 +75,7 @@ int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
   ASTK_CHECK(d->B > 0 && d->T > 0 && d->D > 0, "cnn: bad input dims");
   P.n = d->n_layers; P.B = d->B; P.T = d->T; P.D = d->D;
   ASTK_CHECK(d->kf[0] >= 1 && d->kf[0] <= d->D && d->sf[0] >= 1, "cnn: bad layer-0 frequency kernel");
-  P.F = conv_out(d->D, d->kf[0], d->sf[0], 0);
-  int t = d->T;
+  int t = d->T, f = conv_out(d->D, d->kf[0], d->sf[0], 0);
   size_t cmax = 0, rowsmax_c = 0;
   for (int i = 0; i < P.n; ++i) {
     ASTK_CHECK(d->kt[i] >= 1 && d->st[i] >= 1 && d->pt[i] >= 0 && d->C[i] >= 1, "cnn: bad layer %d", i);
@@ -75,10 +83,18 @@ int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
     ASTK_CHECK(d->kt[i] >= d->st[i], "cnn: time kernel must be >= time stride (layer %d)", i);
     ASTK_CHECK((d->C[i] % 4) == 0, "cnn: channel counts must be multiples of 4 (layer %d: %d)", i, d->C[i]);
     t = conv_out(t, d->kt[i], d->st[i], d->pt[i]);
-    ASTK_CHECK(t >= 1 && P.F >= 1, "cnn: input too short for layer %d", i);
-    P.Tn[i] = t;
+    ASTK_CHECK(t >= 1 && f >= 1, "cnn: input too short for layer %d", i);
+    P.Tc[i] = t; P.Fc[i] = f;
+    P.rowsc[i] = d->B * f * t;
+    ASTK_CHECK(d->pool_t[i] >= -1 && d->pool_f[i] >= -1, "cnn: bad pooling window (layer %d)", i);
+    P.pwt[i] = d->pool_t[i] == -1 ? t : (d->pool_t[i] > 1 ? d->pool_t[i] : 1);
+    P.pwf[i] = d->pool_f[i] == -1 ? f : (d->pool_f[i] > 1 ? d->pool_f[i] : 1);
+    P.pooled[i] = P.pwt[i] > 1 || P.pwf[i] > 1;
+    t = (t + P.pwt[i] - 1) / P.pwt[i];      // cover_all: the last window may be partial
+    f = (f + P.pwf[i] - 1) / P.pwf[i];
+    P.Tn[i] = t; P.Fn[i] = f;
     P.Cn[i] = d->C[i];
-    P.rows[i] = d->B * P.F * t;
+    P.rows[i] = d->B * f * t;
     cmax = cmax > (size_t)d->C[i] ? cmax : (size_t)d->C[i];
     size_t rc = (size_t)P.rows[i] * d->C[i];
     rowsmax_c = rowsmax_c > rc ? rowsmax_c : rc;
@@ -86,14 +102,21 @@ int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
   P.K0 = d->kt[0] * d->kf[0];
   P.K0p = (P.K0 + 3) / 4 * 4;
   Carver c(ws);
-  P.P0 = c.take<float>((size_t)P.rows[0] * P.K0p);
+  P.P0 = c.take<float>((size_t)P.rowsc[0] * P.K0p);
   size_t wd_max = 0;
   for (int i = 0; i < P.n; ++i) {
     P.Y[i] = c.take<float>((size_t)P.rows[i] * P.Cn[i]);
+    if (P.pooled[i]) {
+      P.YC[i] = c.take<float>((size_t)P.rowsc[i] * P.Cn[i]);
+      P.IDX[i] = c.take<int32_t>((size_t)P.rows[i] * P.Cn[i]);
+      P.DYP[i] = c.take<float>((size_t)P.rows[i] * P.Cn[i]);
+    } else {
+      P.YC[i] = P.Y[i]; P.IDX[i] = nullptr; P.DYP[i] = nullptr;
+    }
     P.bn[i] = c.take<float>(4 * (size_t)P.Cn[i]);
     if (i < P.n - 1) {
       P.padA[i] = d->pt[i + 1];
-      P.HP[i] = c.take<float>((size_t)d->B * P.F * (P.Tn[i] + 2 * P.padA[i]) * P.Cn[i]);
+      P.HP[i] = c.take<float>((size_t)d->B * P.Fn[i] * (P.Tn[i] + 2 * P.padA[i]) * P.Cn[i]);
     } else {
       P.padA[i] = 0;
       P.HP[i] = nullptr;
@@ -101,7 +124,7 @@ int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
     if (i == 0) {
       P.Wr[0] = c.take<float>((size_t)d->C[0] * P.K0p);
       P.dF[0] = P.dB[0] = 0;
-      P.DY[0] = c.take<float>((size_t)P.rows[0] * P.Cn[0]);
+      P.DY[0] = c.take<float>((size_t)P.rowsc[0] * P.Cn[0]);
     } else {
       const int KT = d->kt[i], st = d->st[i], pt = d->pt[i];
       P.Wr[i] = c.take<float>((size_t)P.Cn[i] * KT * P.Cn[i - 1]);
@@ -109,9 +132,9 @@ int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
       int f = na_max - 1 - pt / st;
       P.dF[i] = f > 0 ? f : 0;
       const int qmax = (P.Tn[i - 1] - 1 + pt) / st;
-      int bk = qmax - (P.Tn[i] - 1);
+      int bk = qmax - (P.Tc[i] - 1);
       P.dB[i] = bk > 0 ? bk : 0;
-      P.DY[i] = c.take<float>((size_t)d->B * P.F * (P.Tn[i] + P.dF[i] + P.dB[i]) * P.Cn[i]);
+      P.DY[i] = c.take<float>((size_t)d->B * P.Fc[i] * (P.Tc[i] + P.dF[i] + P.dB[i]) * P.Cn[i]);
       size_t wd = (size_t)P.Cn[i - 1] * na_max * P.Cn[i];
       wd_max = wd_max > wd ? wd_max : wd;
     }
@@ -344,6 +367,57 @@ __global__ __launch_bounds__(256) void k_seq_to_rows(const float* __restrict__ d
   }
 }
 
+// Max-pool between a layer's convolution and its BatchNorm (enc_dec.py:444-456: F.max_pooling_nd, window = stride, cover_all): pooled row
+// (b, f', t') = max over the conv rows (b, f'*pf .. , t'*pt ..) that exist; idx keeps the winning conv row (first maximum in the window's
+// (time, frequency) scan order, like Chainer's argmax over the flattened window).  float4 over channels.
+__global__ __launch_bounds__(256) void k_maxpool(const float* __restrict__ YC, float* __restrict__ Y, int32_t* __restrict__ idx, int B, int Fc, int Tc,
+                                                 int Fn, int Tn, int pf, int pt, int C) {
+  const int C4 = C / 4;
+  const long n4 = (long)B * Fn * Tn * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const long rp = i / C4;
+    const int t1 = (int)(rp % Tn), f1 = (int)((rp / Tn) % Fn), b = (int)(rp / ((long)Tn * Fn));
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int i0 = -1, i1 = -1, i2 = -1, i3 = -1;
+    for (int t = t1 * pt; t < min(Tc, (t1 + 1) * pt); ++t)
+      for (int f = f1 * pf; f < min(Fc, (f1 + 1) * pf); ++f) {
+        const int rc = (b * Fc + f) * Tc + t;
+        const float4 y = *reinterpret_cast<const float4*>(YC + (long)rc * C + c);
+        if (y.x > m.x || i0 < 0) { m.x = y.x; i0 = rc; }
+        if (y.y > m.y || i1 < 0) { m.y = y.y; i1 = rc; }
+        if (y.z > m.z || i2 < 0) { m.z = y.z; i2 = rc; }
+        if (y.w > m.w || i3 < 0) { m.w = y.w; i3 = rc; }
+      }
+    *reinterpret_cast<float4*>(Y + rp * C + c) = m;
+    *reinterpret_cast<int4*>(idx + rp * C + c) = make_int4(i0, i1, i2, i3);
+  }
+}
+// its backward: the gradient of a pooled element goes to the conv row that won, every other conv row gets zero; written straight into the
+// time-padded dY layout the weight- and input-gradient products read (a gather over conv rows: windows do not overlap, no atomics)
+__global__ __launch_bounds__(256) void k_unpool(const float* __restrict__ dYp, const int32_t* __restrict__ idx, float* __restrict__ dY, int B, int Fc,
+                                                int Tc, int Fn, int Tn, int pf, int pt, int C, int padF, int padB, unsigned long long* amax) {
+  __shared__ float red4[4];
+  const int C4 = C / 4;
+  const long n4 = (long)B * Fc * Tc * C4;
+  float mx = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const long rc = i / C4;
+    const int t = (int)(rc % Tc), f = (int)((rc / Tc) % Fc), b = (int)(rc / ((long)Tc * Fc));
+    const long rp = ((long)b * Fn + f / pf) * Tn + t / pt;
+    const int4 w = *reinterpret_cast<const int4*>(idx + rp * C + c);
+    const float4 g = *reinterpret_cast<const float4*>(dYp + rp * C + c);
+    float4 v;
+    v.x = w.x == (int)rc ? g.x : 0.f; v.y = w.y == (int)rc ? g.y : 0.f;
+    v.z = w.z == (int)rc ? g.z : 0.f; v.w = w.w == (int)rc ? g.w : 0.f;
+    const long pr = (rc / Tc) * (Tc + padF + padB) + padF + t;
+    *reinterpret_cast<float4*>(dY + pr * C + c) = v;
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (amax) amax_emit_block(amax, mx, red4);
+}
+
 // backward statistics: stat[c] = sum g, stat[C+c] = sum g*xhat, g = G*(bn(Y)>0)   (colreduce_block skeleton)
 __global__ __launch_bounds__(256) void k_bn_bwd_stats(const float* __restrict__ Y, const float* __restrict__ G, const float* __restrict__ bn,
                                                       int rows, int C, double* __restrict__ stat) {
@@ -446,8 +520,8 @@ int cnn_out_dims(const astk_cnn_desc* d, int* T_out, int* F_out, int* feat) {
   CnnPlan P;
   ASTK_TRY(make_plan(d, nullptr, P));
   if (T_out) *T_out = P.Tn[P.n - 1];
-  if (F_out) *F_out = P.F;
-  if (feat) *feat = P.Cn[P.n - 1] * P.F;
+  if (F_out) *F_out = P.Fn[P.n - 1];
+  if (feat) *feat = P.Cn[P.n - 1] * P.Fn[P.n - 1];
   return 0;
 }
 
@@ -482,27 +556,32 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
   ASTK_TRY(make_plan(d, ws, P));
   ASTK_CHECK(ws && ws_bytes >= P.bytes, "conv_bn_relu_fwd: workspace too small (%zu < %zu)", ws_bytes, P.bytes);
   ASTK_CHECK(X && out && L, "conv_bn_relu_fwd: null pointer");
-  const int B = P.B, F = P.F;
+  const int B = P.B;
   // the statistics of every layer (train) and the maximum slots the producing kernels fill: one fill
   ASTK_TRY(fill_zero(P.zero_fwd_from, train ? P.zero_fwd_bytes : P.zero_fwd_amax_bytes, s));
   // ---- layer 0: im2col + GEMM
-  hipLaunchKernelGGL(k_im2col0, dim3(P.Tn[0], B), dim3(256), 0, s, X, noise, P.P0, B, P.T, P.D, F, P.Tn[0], d->kt[0], d->kf[0],
+  hipLaunchKernelGGL(k_im2col0, dim3(P.Tc[0], B), dim3(256), 0, s, X, noise, P.P0, B, P.T, P.D, P.Fc[0], P.Tc[0], d->kt[0], d->kf[0],
                      d->st[0], d->sf[0], d->pt[0], P.K0p);
   ASTK_LAUNCH_CHECK();
   ASTK_TRY(copy2d_f32(P.Wr[0], P.K0p, L[0].W, P.K0, P.Cn[0], P.K0, P.K0p, s));
-  ASTK_TRY(gemm_launch(GEMM_NT, gemm_args(P.rows[0], P.Cn[0], P.K0p, mat(P.P0, P.K0p), mat(P.Wr[0], P.K0p), P.Y[0], P.Cn[0]), s));
+  ASTK_TRY(gemm_launch(GEMM_NT, gemm_args(P.rowsc[0], P.Cn[0], P.K0p, mat(P.P0, P.K0p), mat(P.Wr[0], P.K0p), P.YC[0], P.Cn[0]), s));
   for (int i = 0; i < P.n; ++i) {
-    const int C = P.Cn[i], rows = P.rows[i];
+    const int C = P.Cn[i], rows = P.rows[i], F = P.Fn[i];
     if (i > 0) {
       const int Ci = P.Cn[i - 1], KT = d->kt[i];
       hipLaunchKernelGGL(k_repack_w, dim3(gridn((size_t)C * Ci * KT / 8)), dim3(256), 0, s, L[i].W, P.Wr[i], C, Ci, KT, P.a_wr[i],
                          (const unsigned long long*)P.a_hp_s[i - 1], P.a_hp[i - 1]);
       ASTK_LAUNCH_CHECK();
       const long prow = (long)(P.Tn[i - 1] + 2 * P.padA[i - 1]) * Ci;
-      GemmArgs g = gemm_args(rows, C, KT * Ci, mat2(P.HP[i - 1], P.Tn[i], prow, (long)d->st[i] * Ci), mat(P.Wr[i], (long)KT * Ci),
-                             P.Y[i], C);
+      GemmArgs g = gemm_args(P.rowsc[i], C, KT * Ci, mat2(P.HP[i - 1], P.Tc[i], prow, (long)d->st[i] * Ci), mat(P.Wr[i], (long)KT * Ci),
+                             P.YC[i], C);
       // (both operands' maxima were taken by the kernels that wrote them: no absolute-maximum pass in front of this launch)
       ASTK_TRY(gemm_launch(GEMM_NT, with_amax_b(with_amax_a(lowp(g), P.a_hp[i - 1]), P.a_wr[i]), s));            // K6
+    }
+    if (P.pooled[i]) {     // old-path extra: max-pool in front of the BatchNorm (enc_dec.py:444-456)
+      hipLaunchKernelGGL(k_maxpool, dim3(gridn((size_t)rows * C / 4)), dim3(256), 0, s, P.YC[i], P.Y[i], P.IDX[i], B, P.Fc[i], P.Tc[i], P.Fn[i], P.Tn[i],
+                         P.pwf[i], P.pwt[i], C);
+      ASTK_LAUNCH_CHECK();
     }
     // ---- batch statistics -> scale/shift
     if (d->no_bn) {
@@ -574,11 +653,11 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
   ASTK_TRY(make_plan(d, ws, P));
   ASTK_CHECK(ws && ws_bytes >= P.bytes, "conv_bn_relu_bwd: workspace too small");
   ASTK_CHECK(d_out && L && Gr, "conv_bn_relu_bwd: null pointer");
-  const int B = P.B, F = P.F;
+  const int B = P.B;
   {
     const int i = P.n - 1;
-    const size_t shm = (size_t)P.Cn[i] * F * sizeof(float);
-    hipLaunchKernelGGL(k_seq_to_rows, dim3(P.Tn[i], B), dim3(256), shm, s, d_out, P.G, B, F, P.Tn[i], P.Cn[i]);
+    const size_t shm = (size_t)P.Cn[i] * P.Fn[i] * sizeof(float);
+    hipLaunchKernelGGL(k_seq_to_rows, dim3(P.Tn[i], B), dim3(256), shm, s, d_out, P.G, B, P.Fn[i], P.Tn[i], P.Cn[i]);
     ASTK_LAUNCH_CHECK();
   }
   for (int i = P.n - 1; i >= 0; --i) {
@@ -596,17 +675,25 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
       ASTK_LAUNCH_CHECK();
       ASTK_CHECK(exchange(user, P.stat[i], 2 * C, stream) == 0, "conv_bn_relu_bwd: statistics exchange failed (layer %d)", i);
     }
-    const int Tp = P.Tn[i] + P.dF[i] + P.dB[i];
+    const int F = P.Fc[i];             // (b, f) groups of this layer's convolution output = of its input
+    const int Tp = P.Tc[i] + P.dF[i] + P.dB[i];
     if (P.dF[i] + P.dB[i] > 0) {
-      hipLaunchKernelGGL(k_zero_pads, dim3(gridn((size_t)B * F * (P.dF[i] + P.dB[i]) * C / 4)), dim3(256), 0, s, P.DY[i], B * F, P.Tn[i], P.dF[i],
+      hipLaunchKernelGGL(k_zero_pads, dim3(gridn((size_t)B * F * (P.dF[i] + P.dB[i]) * C / 4)), dim3(256), 0, s, P.DY[i], B * F, P.Tc[i], P.dF[i],
                          P.dB[i], C);
       ASTK_LAUNCH_CHECK();
     }
     // (no_bn: the ReLU mask alone -- scale 1 and a zero 1/m switch the BatchNorm terms off; the column sums of g are the bias gradient)
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(gridn((size_t)rows * C / 4)), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], P.stat[i], P.DY[i], rows, C,
-                       P.Tn[i], P.dF[i], P.dB[i], (exchange || d->no_bn) ? nullptr : Gr[i].dgamma, (exchange || d->no_bn) ? nullptr : Gr[i].dbeta,
-                       d->no_bn ? 0.f : 1.f / ((float)rows * (exchange ? world : 1)), i > 0 ? P.a_dy_s[i] : nullptr);
+    // pooled layers: the gradient wrt the POOLED output goes to DYP (plain rows), k_unpool spreads it over the padded dY of the convolution
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(gridn((size_t)rows * C / 4)), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], P.stat[i], P.pooled[i] ? P.DYP[i] : P.DY[i],
+                       rows, C, P.Tn[i], P.pooled[i] ? 0 : P.dF[i], P.pooled[i] ? 0 : P.dB[i], (exchange || d->no_bn) ? nullptr : Gr[i].dgamma,
+                       (exchange || d->no_bn) ? nullptr : Gr[i].dbeta, d->no_bn ? 0.f : 1.f / ((float)rows * (exchange ? world : 1)),
+                       (i > 0 && !P.pooled[i]) ? P.a_dy_s[i] : nullptr);
     ASTK_LAUNCH_CHECK();
+    if (P.pooled[i]) {
+      hipLaunchKernelGGL(k_unpool, dim3(gridn((size_t)P.rowsc[i] * C / 4)), dim3(256), 0, s, P.DYP[i], P.IDX[i], P.DY[i], B, P.Fc[i], P.Tc[i], P.Fn[i],
+                         P.Tn[i], P.pwf[i], P.pwt[i], C, P.dF[i], P.dB[i], i > 0 ? P.a_dy_s[i] : nullptr);
+      ASTK_LAUNCH_CHECK();
+    }
     if (d->no_bn) {
       ASTK_CHECK(Gr[i].dbias, "conv_bn_relu_bwd: no_bn needs a bias gradient (layer %d)", i);
       hipLaunchKernelGGL(k_bias_grad, dim3(cdiv(C, 256)), dim3(256), 0, s, P.stat[i], C, Gr[i].dbias);
@@ -614,8 +701,8 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
     }
     if (i == 0) {
       // ---- wgrad layer 0: dW0p[C0][K0p] = DY0^T P0
-      const int ks = ksplit_for(1, rows);
-      ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(C, P.K0p, rows, mat(P.DY[0], C), mat(P.P0, P.K0p), P.dWr[0], P.K0p, nullptr, GEMM_ATOMIC, ks), s));
+      const int ks = ksplit_for(1, P.rowsc[0]);
+      ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(C, P.K0p, P.rowsc[0], mat(P.DY[0], C), mat(P.P0, P.K0p), P.dWr[0], P.K0p, nullptr, GEMM_ATOMIC, ks), s));
       ASTK_TRY(add2d_f32(Gr[0].dW, P.K0, P.dWr[0], P.K0p, C, P.K0, s));
     } else {
       const int Ci = P.Cn[i - 1], KT = d->kt[i], st = d->st[i], pt = d->pt[i];
@@ -658,10 +745,10 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
       if (!folded) ady = P.a_dy_s[i];      // (no phase kernel ran: the products read the strided slot itself)
       // ---- wgrad: dWr[co][kt*Ci+ci] = sum_rows DY[row][co] * window(row)[k]
       {
-        MatView A = mat2(P.DY[i] + (long)P.dF[i] * C, P.Tn[i], dyrow, C);
-        MatView Bm = mat2(P.HP[i - 1], P.Tn[i], hprow, (long)st * Ci);
+        MatView A = mat2(P.DY[i] + (long)P.dF[i] * C, P.Tc[i], dyrow, C);
+        MatView Bm = mat2(P.HP[i - 1], P.Tc[i], hprow, (long)st * Ci);
         const long tiles = (long)cdiv(C, 128) * cdiv(KT * Ci, 128);
-        ASTK_TRY(gemm_launch(GEMM_TN, with_amax_b(with_amax_a(lowp(gemm_args(C, KT * Ci, rows, A, Bm, P.dWr[i], (long)KT * Ci, nullptr, GEMM_ATOMIC, ksplit_for(tiles, rows))), ady), P.a_hp[i - 1]), s));
+        ASTK_TRY(gemm_launch(GEMM_TN, with_amax_b(with_amax_a(lowp(gemm_args(C, KT * Ci, P.rowsc[i], A, Bm, P.dWr[i], (long)KT * Ci, nullptr, GEMM_ATOMIC, ksplit_for(tiles, P.rowsc[i]))), ady), P.a_hp[i - 1]), s));
       }
       hipLaunchKernelGGL(k_unpack_dw, dim3(gridn((size_t)C * Ci * KT)), dim3(256), 0, s, P.dWr[i], Gr[i].dW, C, Ci, KT);
       ASTK_LAUNCH_CHECK();

@@ -32,6 +32,9 @@ def param_shapes(cfg, in_dim, vocab_size=None):
         else:
             train[f"CNN_{i}/b"] = (co,)                     # nobias=self.cnn_bn (seq2seq.py:52-54)
         fdim = conv_out(fdim, kw, l["stride"][1], l["pad"][1])
+        if "cnn_pool" in cc:                                # OLD-path extra (enc_dec.py:444-456): max-pool, cover_all; -1 = whole extent
+            kf = cc["cnn_pool"][i][1]
+            fdim = 1 if kf == -1 else -(-fdim // max(int(kf), 1))
         cin = co
     rnn_in = cin * fdim
     Hh = rc["hidden_units"] // 2 if rc["bi_rnn"] else rc["hidden_units"]

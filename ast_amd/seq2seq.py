@@ -252,7 +252,8 @@ class SpeechEncoderDecoder:
         """Which kernels this model's train step takes (bench.py / logs): the optional features leave the persistent kernels."""
         opts = [n for n, on in (("ln", self.rnn_ln), ("linear_proj", self.rnn_linear_proj), (f"n_attn={self.n_attn}", self.n_attn > 1),
                                 ("feed_attn=false", not self.feed_attn), ("cnn bn=false", not self.cnn_bn),
-                                ("dropout.out", bool(self.cfg["dropout"].get("out", 0)))) if on]
+                                ("dropout.out", bool(self.cfg["dropout"].get("out", 0))),
+                                ("cnn_pool (max-pool, old path)", "cnn_pool" in self.cfg["cnn_config"])) if on]
         return {"options": opts,
                 "encoder": "layer-by-layer one-layer stacks + " + ("Linear/BatchNorm/ReLU projections" if self.rnn_linear_proj else "LayerNorm kernels")
                 if self.enc_variant is not None else "one stack call (persistent wavefront kernels when the shape fits)",
@@ -343,6 +344,8 @@ class SpeechEncoderDecoder:
                 raise NotImplementedError("frequency padding / dilation are not used by the shipped configs")
         cd.bn_eps, cd.bn_decay = 2e-5, 0.9
         cd.no_bn = 0 if self.cnn_bn else 1
+        for i, (kt, kf) in enumerate(self.cfg["cnn_config"].get("cnn_pool", [])):     # OLD-path extra (enc_dec.py:444-456), -1 = whole extent
+            cd.pool_t[i], cd.pool_f[i] = int(kt), int(kf)
         t2, f2, feat = C.c_int(), C.c_int(), C.c_int()
         check(lib.astk_conv_bn_relu_out_dims(C.byref(cd), C.byref(t2), C.byref(f2), C.byref(feat)))
         T2, feat = t2.value, feat.value

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ASTK_VERSION 102
+#define ASTK_VERSION 103
 #define ASTK_MAX_CNN_LAYERS 4
 #define ASTK_MAX_RNN_LAYERS 8
 #define ASTK_MAX_ATTN 4
@@ -67,7 +67,7 @@ int astk_get_gemm_precision(void);
 int astk_debug_set_amax_generation(unsigned gen);
 
 /* ---------------------------------------------------------------- CNN front-end  (seq2seq.py:158-180)
- * [Conv2D(no bias) -> BatchNorm(train: batch stats) -> ReLU] x n_layers (or, with no_bn, [Conv2D(bias) -> ReLU]), then the (T'',B,C*F') time-major
+ * [Conv2D(no bias) -> (max-pool) -> BatchNorm(train: batch stats) -> ReLU] x n_layers (or, with no_bn, [Conv2D(bias) -> ReLU]), then the (T'',B,C*F') time-major
  * re-layout with feature index c*F'+f (quirk Q9).  Layer 0: in_channels 1, kernel (kt,kf), stride (st,sf),
  * pad (pt,0).  Layers >= 1: kernel (kt,1), stride (st,1), pad (pt,0) -- the shipped cnn_config. */
 typedef struct {
@@ -80,6 +80,10 @@ typedef struct {
   float bn_eps;    /* 2e-5  (Chainer-sem A4) */
   float bn_decay;  /* 0.9 */
   int no_bn;       /* cnn_config.bn = false (seq2seq.py:43-57): Conv2D WITH bias -> ReLU, no BatchNorm; 0 = the shipped configs */
+  /* OLD-path extra (enc_dec.py:444-456, `cnn_pool`): F.max_pooling_nd(h, (pool_t, pool_f)) between a layer's convolution and its
+   * BatchNorm -- window = stride, no padding, cover_all (the last window may be partial: out = ceil(in / window)).  0 or 1 = none,
+   * -1 = the whole extent.  No shipped config sets it. */
+  int pool_t[ASTK_MAX_CNN_LAYERS], pool_f[ASTK_MAX_CNN_LAYERS];
 } astk_cnn_desc;
 
 typedef struct {

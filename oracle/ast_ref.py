@@ -47,6 +47,14 @@ def cnn_out_dims(cnn_layers, T, D):
     return T, D, c
 
 
+def pool_window(cnn_config, i, extent, axis):
+    """enc_dec.py:444-451 (OLD path, `cnn_pool`): per-layer (time_pool, freq_pool), -1 = the whole extent; absent: no pooling."""
+    if "cnn_pool" not in cnn_config:
+        return 1
+    k = cnn_config["cnn_pool"][i][axis]
+    return extent if k == -1 else max(int(k), 1)
+
+
 # --------------------------------------------------------------------------- parameters
 def init_params(cfg, in_dim, vocab_size=None, seed=0, dtype=np.float32):
     """Reference initialisers (A9): conv HeNormal, Linear/LSTM LeCunNormal, forget bias 1,
@@ -72,6 +80,7 @@ def init_params(cfg, in_dim, vocab_size=None, seed=0, dtype=np.float32):
         else:
             P[f"CNN_{i}/b"] = np.zeros(co, dtype)
         fdim = conv_out(fdim, kw, l["stride"][1], l["pad"][1])
+        fdim = -(-fdim // pool_window(cc, i, fdim, 1))      # max-pool over frequency, cover_all (enc_dec.py:449-456)
         cin = co
     rnn_in = cin * fdim
 
@@ -218,6 +227,10 @@ class RefModel:
         for i, l in enumerate(self.cnn_layers):
             h = F.convolution_2d(h, self.p[f"CNN_{i}/W"], tuple(l["stride"]), tuple(l["pad"]),
                                  None if self.cnn_bn else self.p[f"CNN_{i}/b"])      # nobias=self.cnn_bn (seq2seq.py:52-54)
+            if "cnn_pool" in self.cfg["cnn_config"]:              # OLD-path extra, enc_dec.py:444-456: between convolution and BatchNorm
+                kt = pool_window(self.cfg["cnn_config"], i, h.shape[-2], 0)
+                kf = pool_window(self.cfg["cnn_config"], i, h.shape[-1], 1)
+                h = F.max_pooling_nd(h, (kt, kf))
             if self.cnn_bn:
                 h = self.bn[f"CNN_{i}_bn"](h, train=self.train)
             h = F.relu(h)

@@ -20,6 +20,10 @@ def cnn_torch(cfg, P, X, noise=None, bn_eps=2e-5):
     h = X.unsqueeze(1)                                        # (B,1,T,D)
     for i, l in enumerate(cfg["cnn_config"]["cnn_layers"]):
         h = TF.conv2d(h, P[f"CNN_{i}/W"], stride=tuple(l["stride"]), padding=tuple(l["pad"]))
+        if "cnn_pool" in cfg["cnn_config"]:                     # old path, enc_dec.py:444-456: max_pooling_nd, stride = window, cover_all
+            kt, kf = cfg["cnn_config"]["cnn_pool"][i]
+            k = (h.shape[2] if kt == -1 else max(kt, 1), h.shape[3] if kf == -1 else max(kf, 1))
+            h = TF.max_pool2d(h, k, stride=k, ceil_mode=True)
         if cfg["cnn_config"]["bn"]:
             h = TF.batch_norm(h, None, None, P[f"CNN_{i}_bn/gamma"], P[f"CNN_{i}_bn/beta"], training=True, eps=bn_eps)
         h = torch.relu(h)

@@ -532,6 +532,41 @@ def convolution_2d(x, W, stride, pad, b=None):
     return _Conv2D(stride, pad)(x, W) if b is None else _Conv2D(stride, pad)(x, W, b)
 
 
+class _MaxPoolingND(Function):
+    """F.max_pooling_nd(x, ksize) on (B,C,H,W) as the OLD path calls it (enc_dec.py:456): stride = ksize, pad = 0, cover_all = True
+    (Chainer's default for max pooling: out = ceil(in / k), the last window may be partial and is padded with -inf).  The gradient goes
+    to the first maximum of the window in (kh, kw) order, like Chainer's argmax over the flattened window."""
+
+    def __init__(self, ksize):
+        self.kh, self.kw = ksize
+
+    def forward(self, xs):
+        x = xs[0]
+        B, C, H, W = x.shape
+        kh, kw = self.kh, self.kw
+        oh, ow = -(-H // kh), -(-W // kw)
+        xp = np.full((B, C, oh * kh, ow * kw), -np.inf, dtype=x.dtype)
+        xp[:, :, :H, :W] = x
+        win = xp.reshape(B, C, oh, kh, ow, kw).transpose(0, 1, 2, 4, 3, 5).reshape(B, C, oh, ow, kh * kw)
+        self.arg = win.argmax(axis=4)                      # first maximum in (kh, kw) order
+        self.x_shape = x.shape
+        return np.ascontiguousarray(win.max(axis=4))
+
+    def backward(self, gys):
+        gy = gys[0]
+        B, C, H, W = self.x_shape
+        kh, kw = self.kh, self.kw
+        oh, ow = gy.shape[2], gy.shape[3]
+        gwin = np.zeros((B, C, oh, ow, kh * kw), dtype=gy.dtype)
+        np.put_along_axis(gwin, self.arg[..., None], gy[..., None], axis=4)
+        gxp = gwin.reshape(B, C, oh, ow, kh, kw).transpose(0, 1, 2, 4, 3, 5).reshape(B, C, oh * kh, ow * kw)
+        return np.ascontiguousarray(gxp[:, :, :H, :W])
+
+
+def max_pooling_nd(x, ksize):
+    return _MaxPoolingND(ksize)(x)
+
+
 class _BatchNormTrain(Function):
     """A4: statistics over every axis but the channel axis 1 -- (0,2,3) for the CNN's 4-D input, (0,) for the 2-D (B, units) input of
     the linear_proj encoder (seq2seq.py:281) -- biased variance, eps=2e-5."""

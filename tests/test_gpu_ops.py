@@ -222,6 +222,58 @@ def test_cnn_fwd_bwd(lib, B, T, D, c0, c1, with_noise, gemm_split):
     close(out, hh.permute(2, 0, 1, 3).reshape(T2, B, Cc * F2), msg="eval-mode out")
 
 
+@pytest.mark.parametrize("B,T,D,c0,c1,pool", [(3, 42, 80, 4, 8, [[2, 1], [1, 1]]), (2, 50, 80, 8, 12, [[3, 2], [2, -1]]),
+                                              (2, 76, 80, 4, 4, [[1, 4], [3, 2]]), (8, 400, 80, 128, 512, [[2, 2], [1, 3]]),
+                                              (2, 30, 26, 4, 8, [[-1, 1], [1, 1]])])
+def test_cnn_max_pool_fwd_bwd(lib, B, T, D, c0, c1, pool, gemm_split):
+    """The old path's cnn_pool (enc_dec.py:444-456): max-pool between each convolution and its BatchNorm, per-layer (time, frequency)
+    windows, -1 = whole extent, ragged last windows (cover_all) -- output and every parameter gradient against the torch restatement
+    (max_pool2d with ceil_mode, the same operator)."""
+    from ast_amd._lib import CnnLayerGrads, CnnLayerParams
+    from oracle.ast_ref import init_params
+    from oracle.ast_ref_torch import cnn_torch
+    cfg = tiny_cfg(c0=c0, c1=c1)
+    cfg["cnn_config"]["cnn_pool"] = pool
+    P = init_params(cfg, D, 11, seed=1, dtype=np.float64)
+    rng = np.random.default_rng(0)
+    for i in range(2):
+        P[f"CNN_{i}_bn/gamma"] = 1 + 0.3 * rng.standard_normal(P[f"CNN_{i}_bn/gamma"].shape)
+        P[f"CNN_{i}_bn/beta"] = 0.2 * rng.standard_normal(P[f"CNN_{i}_bn/beta"].shape)
+    X = rng.standard_normal((B, T, D))
+    Pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=k.startswith("CNN") and "avg" not in k) for k, v in P.items()}
+    out_ref = cnn_torch(cfg, Pt, torch.tensor(X), None)
+    gout = rng.standard_normal(out_ref.shape)
+    out_ref.backward(torch.tensor(gout))
+    cd = _cnn_desc(cfg, B, T, D)
+    for i, (kt, kf) in enumerate(pool):
+        cd.pool_t[i], cd.pool_f[i] = kt, kf
+    t2, f2, feat = C.c_int(), C.c_int(), C.c_int()
+    ok(lib, lib.astk_conv_bn_relu_out_dims(C.byref(cd), C.byref(t2), C.byref(f2), C.byref(feat)))
+    assert (t2.value, B, feat.value) == tuple(out_ref.shape)
+    assert feat.value == P["L0_enc/upward/W"].shape[1], "the oracle's LSTM input width follows the pooled frequency bins"
+    names = ["CNN_0", "CNN_1"]
+    prm = {n + s: dev(P[n + s]) for n in names for s in ("/W", "_bn/gamma", "_bn/beta", "_bn/avg_mean", "_bn/avg_var")}
+    grd = {k: torch.zeros_like(v) for k, v in prm.items()}
+    cp, cg = (CnnLayerParams * 2)(), (CnnLayerGrads * 2)()
+    for i, n in enumerate(names):
+        cp[i].W, cp[i].gamma, cp[i].beta = prm[n + "/W"].data_ptr(), prm[n + "_bn/gamma"].data_ptr(), prm[n + "_bn/beta"].data_ptr()
+        cp[i].avg_mean, cp[i].avg_var = prm[n + "_bn/avg_mean"].data_ptr(), prm[n + "_bn/avg_var"].data_ptr()
+        cg[i].dW, cg[i].dgamma, cg[i].dbeta = grd[n + "/W"].data_ptr(), grd[n + "_bn/gamma"].data_ptr(), grd[n + "_bn/beta"].data_ptr()
+    nbytes = lib.astk_conv_bn_relu_workspace_bytes(C.byref(cd))
+    ws = GuardedWS(nbytes)
+    out = torch.empty(t2.value, B, feat.value, device="cuda")
+    xd = dev(X)
+    ok(lib, lib.astk_conv_bn_relu_fwd(C.byref(cd), cp, vp(xd), None, vp(out), vp(ws), nbytes, 1, stream()))
+    ws.check("cnn fwd")
+    close(out, out_ref, msg="cnn out")
+    g = dev(gout)
+    ok(lib, lib.astk_conv_bn_relu_bwd(C.byref(cd), cp, cg, vp(g), vp(ws), nbytes, stream()))
+    ws.check("cnn bwd")
+    for n in names:
+        for s in ("/W", "_bn/gamma", "_bn/beta"):
+            close(grd[n + s], Pt[n + s].grad, rtol=5e-4, msg="grad " + n + s)
+
+
 # ------------------------------------------------------------------ encoder LSTM stacks
 @pytest.mark.parametrize("T,B,in_dim,h,nl,masks", [(7, 3, 12, 4, 2, False), (9, 5, 24, 20, 3, True), (5, 33, 64, 36, 1, True), (1, 2, 8, 4, 2, False),
                                                    # h in {64,128,256,512}: the persistent wavefront kernels

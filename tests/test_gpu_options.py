@@ -1,5 +1,6 @@
 """GPU parity tests of the reference model's OPTIONAL features (seq2seq.py:43-57, 81-121, 244-291, 369-394,
-456-465): rnn_config.ln / linear_proj / n_attn > 1 / feed_attn = false, cnn_config.bn = false, dropout.out, forward_loss's random_out.
+456-465): rnn_config.ln / linear_proj / n_attn > 1 / feed_attn = false, cnn_config.bn = false, dropout.out, forward_loss's random_out;
+the old path's cnn_pool (enc_dec.py:444-456).
 Every case is one full train step of the HIP path (through the C ABI) against the float64 CPU oracle on identical inputs, weights,
 dropout masks and random draws -- loss and clip norm within 1e-4, every gradient tensor, the encoder states, and the parameters after
 the update -- plus greedy decoding in eval mode, and op-level checks of the new kernels (csrc/norm.hip)."""
@@ -23,6 +24,8 @@ def _cfg(enc_layers=2, dec_layers=2, H=64, E=16, A=32, c0=8, c1=16, V=41, drop=0
     cfg["dropout"]["out"] = out
     bn = rc.pop("bn", True)
     cfg["cnn_config"]["bn"] = bn
+    if "cnn_pool" in rc:
+        cfg["cnn_config"]["cnn_pool"] = rc.pop("cnn_pool")
     cfg["rnn_config"].update(rc)
     return cfg
 
@@ -45,6 +48,12 @@ CASES = {
     "proj-3": (dict(linear_proj=True, enc_layers=3, dec_layers=2), 5, 64, 80, 7),
     "proj-2-drop": (dict(linear_proj=True, enc_layers=2, dec_layers=2, drop=0.3), 4, 64, 80, 6),
     "proj-persist-h64": (dict(linear_proj=True, H=128, A=64, enc_layers=2, dec_layers=1), 17, 70, 80, 6),
+    # OLD-path extra (enc_dec.py:444-456): max-pool between convolution and BatchNorm, (time, frequency) windows per layer, -1 = whole extent,
+    # cover_all (ragged last windows: 19 frames by 3; 3 bins by 2)
+    "pool-t2": (dict(cnn_pool=[[2, 1], [1, 1]]), 5, 64, 80, 7),
+    "pool-f2-t3-ragged": (dict(cnn_pool=[[1, 2], [3, 2]], drop=0.2), 4, 76, 80, 6),
+    "pool-whole-freq": (dict(cnn_pool=[[1, -1], [2, 1]]), 5, 64, 80, 7),
+    "pool-nobn": (dict(bn=False, cnn_pool=[[2, 2], [1, 1]], drop=0.2), 3, 90, 80, 6),
     "all": (dict(ln=True, n_attn=2, feed_attn=False, bn=False, out=0.3, drop=0.2, enc_layers=2, dec_layers=3), 4, 64, 80, 7),
 }
 

@@ -371,3 +371,49 @@ def test_random_out_draw_order_and_clamp_Q8():
         np.testing.assert_array_equal(m.targets[i], want)
     assert max(int(t.max()) for t in m.targets) == V - 1
     assert rnd.random() == rnd2.random()                                   # same number of draws consumed
+
+
+@pytest.mark.parametrize("shape,k", [((2, 3, 7, 6), (2, 2)), ((1, 2, 5, 3), (3, 2)), ((2, 2, 4, 1), (4, 1)), ((1, 1, 9, 6), (1, 6))])
+def test_max_pooling_nd_cover_all_against_torch(shape, k):
+    """The old path's F.max_pooling_nd(h, (time_pool, freq_pool)) (enc_dec.py:456): stride = window, cover_all -- out = ceil(in / k), ragged
+    last windows; torch's max_pool2d(ceil_mode=True) is the same operator.  Forward, and the gradient's routing to the window's maximum."""
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(shape)
+    v = F.Variable(x.copy())
+    y = F.max_pooling_nd(v, k)
+    xt = torch.tensor(x, requires_grad=True)
+    yt = torch.nn.functional.max_pool2d(xt, k, stride=k, ceil_mode=True)
+    assert y.shape == tuple(yt.shape) == (shape[0], shape[1], -(-shape[2] // k[0]), -(-shape[3] // k[1]))
+    np.testing.assert_array_equal(y.data, yt.detach().numpy())
+    gy = rng.standard_normal(y.shape)
+    y.grad = gy
+    y.backward()
+    yt.backward(torch.tensor(gy))
+    np.testing.assert_array_equal(v.grad, xt.grad.numpy())
+
+
+def test_cnn_pool_changes_the_lstm_input_width_and_passes_finite_differences():
+    """cnn_pool = [[time, freq], ...] per layer, -1 = the whole extent (enc_dec.py:444-451); the pooled frequency bins set the encoder
+    LSTMs' input width (C_last * F'), and the whole model still passes float64 finite differences."""
+    cfg = tiny_cfg(enc_layers=1, dec_layers=1, V=11)
+    cfg["cnn_config"]["cnn_pool"] = [[2, 2], [1, -1]]
+    D = 80                                            # 6 frequency bins behind layer 0 -> 3 behind its pool -> 1
+    P = R.init_params(cfg, D, 11, seed=0, dtype=np.float64)
+    c_last = cfg["cnn_config"]["cnn_layers"][-1]["out_channels"]
+    assert P["L0_enc/upward/W"].shape[1] == c_last * 1
+    X, y = R.synth_batch(2, 40, D, 5, 11, seed=1, dtype=np.float64)
+    m, loss = _loss(cfg, P, X, y, 11)
+    assert m.enc_states.shape[1] == 5                # 40 frames -> 20 (conv) -> 10 (pool 2) -> 5 (conv)
+    m.cleargrads()
+    loss.backward()
+    rng = np.random.default_rng(0)
+    for name in ("CNN_0/W", "CNN_1/W", "CNN_0_bn/gamma", "L0_enc/upward/W"):
+        g = dict(m.params())[name].grad
+        for _ in range(3):
+            idx = tuple(rng.integers(0, s) for s in g.shape)
+            eps = 1e-6
+            Pp, Pm = {k: v.copy() for k, v in P.items()}, {k: v.copy() for k, v in P.items()}
+            Pp[name][idx] += eps
+            Pm[name][idx] -= eps
+            fd = (float(_loss(cfg, Pp, X, y, 11)[1].data) - float(_loss(cfg, Pm, X, y, 11)[1].data)) / (2 * eps)
+            assert abs(fd - g[idx]) <= 1e-5 * max(abs(fd), 1e-3), (name, idx, fd, g[idx])
