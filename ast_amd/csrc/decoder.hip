@@ -9,6 +9,7 @@
 // step: the per-step data-path gradients (dz, d_pre, dq, ...) are saved and every dW is one batched TN GEMM
 // over S*B rows after the loop; d_enc_states is one batched GEMM over the saved (alpha, ds).
 #include "common.h"
+#include "decoder_wide.h"
 
 namespace astk {
 
@@ -70,6 +71,8 @@ struct DecPlan {
   float* DC[ASTK_MAX_RNN_LAYERS][2];
   float* WoT;    // [A][Vp]
   float* LG1;    // [B][Vp] logits of a step whose argmax is fed back (when every step is scored behind the loop)
+  float* WPART;  // wide persistent forward loop (decoder_wide.hip): partial attention sums, counters
+  unsigned* WCTR;
   float* WcT;    // [CW][A]
   float* WaT;    // [NA][H][H]
   float* WuT[ASTK_MAX_RNN_LAYERS];  // [in][4H]
@@ -125,6 +128,8 @@ int make_plan(const astk_decoder_desc* d, void* ws, DecPlan& P) {
   P.DHTOP = c.take<float>(B * H);
   P.WoT = c.take<float>((size_t)P.A * P.Vp);
   P.LG1 = c.take<float>((size_t)P.B * P.Vp);
+  P.WPART = c.take<float>(decoder_wide_part_floats(d));
+  P.WCTR = c.take<unsigned>(decoder_wide_ctr_words(d));
   P.WcT = c.take<float>(CW * P.A);
   P.WaT = c.take<float>(NA * H * H);
   P.attn_ws = c.take<char>(attn_ws_bytes(P.B, P.T, P.H));
@@ -178,7 +183,7 @@ __global__ void k_embed_bwd(float* __restrict__ d_embed, const int32_t* __restri
 // (one decoder step: rows_per_step = B and `targets` points at the step's column).  argmax_only: feedback tokens of a step whose loss is
 // scored later (the batched pass); fed_flags (the loop's use_truth, n_steps entries): that batched pass leaves the argmax of the steps
 // whose token was fed back (flag of the NEXT step 0) as the loop wrote it.
-__global__ __launch_bounds__(256) void k_softmax_ce(int V, long ld, float* __restrict__ logits, const int32_t* __restrict__ targets,
+__global__ __launch_bounds__(256) void k_softmax_ce(int V, long ld, float* logits, const int32_t* __restrict__ targets,
                                                     long t_stride, int rows_per_step, const float* __restrict__ cw, float inv_count,
                                                     float* __restrict__ loss_rows, int32_t* __restrict__ argmax, int argmax_only,
                                                     const int32_t* __restrict__ fed_flags, int n_steps) {
@@ -220,13 +225,18 @@ __global__ __launch_bounds__(256) void k_softmax_ce(int V, long ld, float* __res
   const bool ignore = t < 0;                      // ignore_label = -1 never occurs on this path (PAD is 0)
   t = t < 0 ? 0 : (t >= V ? V - 1 : t);
   const float w = ignore ? 0.f : (cw ? cw[t] : 1.f);
-  const float xt = x[t];
-  __syncthreads();
+  // The target's logit has to be READ before any thread overwrites the row with the gradient below.  It used to be an ordinary load in
+  // front of the barrier whose only use sat behind it; with `logits` declared __restrict__ the compiler was free to sink the load to
+  // that use, i.e. behind the barrier, where thread (t % 256) may already have stored the gradient: one loss row in a few thousand
+  // came out wrong by the difference, depending on which wave ran first (found at the end of round 3; the gradient was never affected).
+  // Now: no __restrict__ on the row, a volatile load, and the loss row is finished in front of the barrier.
+  const float xt = *reinterpret_cast<const volatile float*>(&x[t]);
   if (threadIdx.x == 0) {
     if (loss_rows) loss_rows[b] = -(xt - lse) * w * inv_count;
     const bool fed = fed_flags && step + 1 < n_steps && fed_flags[step + 1] == 0;
     if (argmax && !fed) argmax[b] = mi;
   }
+  __syncthreads();
   const float scale = w * inv_count;
   for (int v = threadIdx.x; v < ld; v += 256) {
     float g = 0.f;
@@ -391,7 +401,7 @@ int astk_decoder_path(const astk_decoder_desc* d) {
   if (!d) return 0;
   if (!decoder_persist_applicable(d, &ns, &ch)) {
     SplitPlan sp;
-    if (make_split(d, nullptr, sp) != 0 || !sp.on) return 0;
+    if (make_split(d, nullptr, sp) != 0 || !sp.on) return decoder_wide_applicable(d, nullptr, nullptr) ? 16 : 0;   // 16: wide forward loop (decoder_wide.hip)
     return astk_decoder_path(&sp.sub[0]) | 4;                                // two persistent launches over halves of the rows
   }
   return 1 | ((d->H == 512 && ch <= 60) ? 2 : 0) | (d->n_layers << 8);      // (PDEC_CHUNK_MAX of decoder_persist.hip)
@@ -486,7 +496,28 @@ int astk_decoder_fwd_ex(const astk_decoder_desc* d, const astk_decoder_params* p
   }
   const int32_t* uth = d->use_truth_host;      // optional host copy of use_truth: which steps feed their argmax back
   const float inv_count = 1.f / (float)(d->loss_rows > 0 ? d->loss_rows : B);
-  for (int st = 0; st < S; ++st) {
+  // The wide decoder (configs[4]: H = A = 1024) on its persistent forward loop (decoder_wide.hip): one launch per SEGMENT of the loop, a
+  // segment ending at a step whose argmax is fed back (that step's logits and argmax come from the two launches below, then the next
+  // segment starts); every step is scored behind the loop like in the per-launch form.
+  const bool wide = uth && !out_mask && decoder_wide_applicable(d, nullptr, nullptr);
+  for (int st = 0; wide && st < S;) {
+    int s1 = st;
+    while (s1 + 1 < S && uth[s1 + 1] != 0) ++s1;           // step s1 + 1 is not teacher-forced (or there is none): the segment ends at s1
+    DecWideBuffers wb;
+    wb.TOK = P.TOK; wb.PRED = P.PRED; wb.X0 = P.X0; wb.G = P.G[0]; wb.C = P.C[0]; wb.HR = P.HR[0]; wb.Q = P.Q; wb.ALPHA = P.ALPHA;
+    wb.CVH = P.CVH; wb.HT = P.HT; wb.PART = P.WPART; wb.ctr = P.WCTR;
+    ASTK_TRY(decoder_wide_fwd_launch(d, prm, enc, y, use_truth, emb_mask, rnn_masks, wb, st, s1, s));
+    if (s1 + 1 < S) {
+      RowGemmArgs a = rg(B, V, P.HT + (size_t)(s1 + 1) * B * A, A, prm->Wo, A, A, P.LG1, P.Vp);
+      a.bias = prm->bo;
+      ASTK_TRY(rowgemm_launch(a, s));
+      hipLaunchKernelGGL(k_softmax_ce, dim3(B), dim3(256), 0, s, V, (long)P.Vp, P.LG1, tgt + s1 + 1, (long)P.L, B, (const float*)nullptr, 1.f,
+                         (float*)nullptr, P.PRED + (size_t)s1 * B, 1, (const int32_t*)nullptr, 0);
+      ASTK_LAUNCH_CHECK();
+    }
+    st = s1 + 1;
+  }
+  for (int st = 0; st < S && !wide; ++st) {
     float* x0 = P.X0 + (size_t)st * B * XI;
     hipLaunchKernelGGL(k_embed, dim3(B), dim3(128), 0, s, prm->embed, y, P.L, st, use_truth, st > 0 ? P.PRED + (size_t)(st - 1) * B : nullptr,
                        (const int32_t*)nullptr, P.TOK + (size_t)st * B, emb_mask ? emb_mask + (size_t)st * B * E : nullptr, x0, B, E, XI, V);
