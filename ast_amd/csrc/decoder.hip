@@ -73,6 +73,8 @@ struct DecPlan {
   float* LG1;    // [B][Vp] logits of a step whose argmax is fed back (when every step is scored behind the loop)
   float* WPART;  // wide persistent forward loop (decoder_wide.hip): partial attention sums, counters
   unsigned* WCTR;
+  float* WBWD;   // wide persistent backward loop: partial sums, counters
+  unsigned* WBCTR;
   float* WcT;    // [CW][A]
   float* WaT;    // [NA][H][H]
   float* WuT[ASTK_MAX_RNN_LAYERS];  // [in][4H]
@@ -130,6 +132,8 @@ int make_plan(const astk_decoder_desc* d, void* ws, DecPlan& P) {
   P.LG1 = c.take<float>((size_t)P.B * P.Vp);
   P.WPART = c.take<float>(decoder_wide_part_floats(d));
   P.WCTR = c.take<unsigned>(decoder_wide_ctr_words(d));
+  P.WBWD = c.take<float>(decoder_wide_bwd_floats(d));
+  P.WBCTR = c.take<unsigned>(decoder_wide_bwd_ctr_words(d));
   P.WcT = c.take<float>(CW * P.A);
   P.WaT = c.take<float>(NA * H * H);
   P.attn_ws = c.take<char>(attn_ws_bytes(P.B, P.T, P.H));
@@ -654,6 +658,7 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
   int ns_ = 1, ch_ = 1;
   const bool persist = !out_mask && decoder_persist_applicable(d, &ns_, &ch_);      // (the forward pass took the same decision)
   const bool b6s = persist && decoder_persist_b6_split(d);
+  const bool wide_b = !persist && decoder_wide_applicable(d, nullptr, nullptr);     // the whole reversed loop in one launch (decoder_wide.hip)
   if (do_chain) {
   // transposed weights for the data-path products (dY W as row-panel NT products)
   {
@@ -691,7 +696,14 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
     hipLaunchKernelGGL(k_dtanh_inplace, dim3((unsigned)std::min<long>(cdiv(n, 256), 2048)), dim3(256), 0, s, P.DPRE + r0, P.HT + (size_t)B * A + r0, n);
     ASTK_LAUNCH_CHECK();
   }
-  for (int st = S - 1; st >= 0 && !persist; --st) {
+  if (wide_b) {
+    DecWideBwdBuffers wb;
+    wb.WcT = P.WcT; wb.WaT = P.WaT; wb.WlT = P.WlT[0]; wb.WuT = P.WuT[0]; wb.ALPHA = P.ALPHA; wb.CVH = P.CVH; wb.HT = P.HT; wb.C = P.C[0];
+    wb.G = P.G[0]; wb.DPRE = P.DPRE; wb.DCVH = P.DCVH; wb.DS = P.DS; wb.DQ = P.DQ; wb.DHTOP = P.DHTOP; wb.DC0 = P.DC[0][0];
+    wb.scratch = P.WBWD; wb.ctr = P.WBCTR;
+    ASTK_TRY(decoder_wide_bwd_launch(d, enc, rnn_masks, wb, s));
+  }
+  for (int st = S - 1; st >= 0 && !persist && !wide_b; --st) {
     const bool last = st == S - 1;
     float* dpre = P.DPRE + (size_t)st * B * A;
     float* dcvh = P.DCVH + (size_t)st * B * CW;
@@ -785,6 +797,8 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
   GemmWgCap cap(phase == ASTK_DEC_BWD_PARAMS ? 2 : 0);   // on its own stream this phase shares the CUs with the encoder's recurrence kernel
   // ==== parameter gradients: read only what the chain phase left in the workspace; nothing downstream of the decoder needs them, so a
   // caller may run this phase on a second stream beside the encoder's backward recurrence (ASTK_DEC_BWD_PARAMS)
+  if (wide_b)      // the embedding columns of d_x0 (only the embedding scatter reads them): one batched product over all steps
+    ASTK_TRY(gemm_launch(GEMM_NN, lowp(gemm_args(S * B, E, 4 * H, mat(P.G[0], 4 * H), mat(prm->lstm[0].Wu, XI), P.DX0, XI)), s));
   if (persist) {
     // split mode: the embedding columns of d_x0 (only the embedding scatter reads them) are one batched product over all steps
     if (b6s) ASTK_TRY(gemm_launch(GEMM_NN, lowp(gemm_args(S * B, E, 4 * H, mat(P.G[0], 4 * H), mat(prm->lstm[0].Wu, XI), P.DX0, XI)), s));      // (K18's input gradient)

@@ -18,4 +18,15 @@ int decoder_wide_fwd_launch(const astk_decoder_desc* d, const astk_decoder_param
                             const int32_t* use_truth, const float* emb_mask, const float* rnn_mask, const DecWideBuffers& bf, int s0, int s1,
                             hipStream_t s);
 
+struct DecWideBwdBuffers {
+  const float *WcT, *WaT, *WlT, *WuT, *ALPHA, *CVH, *HT, *C;
+  float *G, *DPRE, *DCVH, *DS, *DQ, *DHTOP, *DC0;
+  float* scratch;           // decoder_wide_bwd_floats
+  unsigned* ctr;            // decoder_wide_bwd_ctr_words
+};
+size_t decoder_wide_bwd_floats(const astk_decoder_desc* d);
+size_t decoder_wide_bwd_ctr_words(const astk_decoder_desc* d);
+// the whole reversed loop in one launch; expects d_pre's linear part (dlogits Wo) in DPRE and tanh' applied to its last step
+int decoder_wide_bwd_launch(const astk_decoder_desc* d, const float* enc, const float* rnn_mask, const DecWideBwdBuffers& bf, hipStream_t s);
+
 }  // namespace astk

@@ -411,6 +411,252 @@ __global__ __launch_bounds__(256, 1) void decoder_wide_fwd(WideArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- backward loop
+// All S steps of the reversed loop in ONE launch (no argmax dependence in the backward).  Per step st, S-1 .. 0:
+//   P1    workgroups 0..127:  d_cvh = d_pre Wc                       (16 of the 2048 columns each, K = 1024)
+//   ATTB  workgroup (b, chunk): ds_t = alpha_t (e_t . d_cv - cv . d_cv), partial dq = sum_t ds_t e_t   (encoder slice in LDS)
+//   DQC   workgroups 128..128+B-1: dq[b] = sum of the chunks' partials
+//   P3    workgroups 128..191: dh_top = d_cvh[:, H:] + dq Wa         (16 columns each, K = 1024)
+//   CELLB all 256 workgroups (tile j = w / 4 of 16 units, quarter kq = w % 4: units 16j + 4kq ..+3): dh = mask dh_top + sum of the four
+//         K-quarter partials of dz_{st+1} Wl, the LSTM cell's pointwise backward -> dz_st (in place of the saved gates), dc carried in registers
+//   DZ    all 256 workgroups: K-quarter kq of dz_st (1024 of the 4096 gate rows) against TWO resident weight slices: the recurrent one
+//         (partial of dz_st Wl for step st-1's CELLB) and the input-feeding one (partial of the carry dz_st Wu[:, E:])
+//   P5R   workgroups 192..255: d_pre[st-1] = (dlogits Wo (batched in front of the launch) + sum of the four carry partials) (1 - ht^2)
+// Chain: P1 -> ATTB -> DQC -> P3 -> CELLB -> DZ -> P5R -> next P1.  The embedding columns of d_x0 are one batched product behind the loop.
+constexpr int BP1 = 0, BP3 = 128, BDQC = 128, BP5R = 192;
+constexpr int NP1 = 2 * WH / 16, NP3 = WH / 16, NTILE = WH / 16;
+enum { D_P1 = 0, D_DQC, D_P3, D_CELL, D_DPRE, D_N };
+
+struct WideBwdArgs {
+  int B, S, T, Tp, nsplit, chunk;
+  const float *WcT, *WaT, *WlT, *WuT;      // K-contiguous transposes: [2H][A], [H][H], [H][4H], [E+A][4H]
+  const float* enc;
+  const float *ALPHA, *CVH, *HT, *C, *rnn_mask;
+  float *G, *DPRE, *DCVH, *DS, *DQ, *DHTOP, *DC0;
+  float *PARTB;        // [B][nsplit][H]
+  float *PREC, *PCAR;  // [64 tiles][4][32][16] partial sums of the recurrent / carry products
+  unsigned* ctr;       // [D_N][NSH] lines | [B] per-row lines | [64] rec-tile lines | [64] carry-tile lines | abort
+  AbortCtl ab;
+};
+
+__global__ __launch_bounds__(256, 1) void decoder_wide_bwd(WideBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* s_enc = lds;
+  float* s_acc = s_enc + (size_t)a.chunk * WH;      // [4][WH]
+  float* s_red = s_acc + 4 * WH;                    // [2048]
+  float* s_zt = s_red + 2048;                       // [512]
+  __shared__ int s_flag;
+  const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q4 = (lane >> 4) * 4;
+  const int B = a.B, S = a.S;
+  const int row0 = min(r, B - 1), row1 = min(16 + r, B - 1);
+  unsigned* c_p1 = a.ctr + (size_t)D_P1 * NSH * CTRS;
+  unsigned* c_dqc = a.ctr + (size_t)D_DQC * NSH * CTRS;
+  unsigned* c_p3 = a.ctr + (size_t)D_P3 * NSH * CTRS;
+  unsigned* c_cell = a.ctr + (size_t)D_CELL * NSH * CTRS;
+  unsigned* c_dpre = a.ctr + (size_t)D_DPRE * NSH * CTRS;
+  unsigned* c_row = a.ctr + (size_t)D_N * NSH * CTRS;
+  unsigned* c_rec = c_row + (size_t)32 * CTRS;
+  unsigned* c_car = c_rec + (size_t)NTILE * CTRS;
+  const bool is_p1 = w < NP1, is_p3 = w >= BP3 && w < BP3 + NP3, is_dqc = w >= BDQC && w < BDQC + B, is_p5r = w >= BP5R;
+  const bool is_att = w < B * a.nsplit;
+  const int ab_ = w % B, asp = w / B;
+  const int t0 = asp * a.chunk, nrow = is_att ? max(0, min(a.chunk, a.T - t0)) : 0;
+  const int tj = w >> 2, kq = w & 3;                 // CELLB / DZ item: tile of 16 units, K quarter
+
+  // ---- resident weights
+  float4 wRec[16], wCar[16], wX[16];
+  wload<16>(wRec, a.WlT, 4 * WH, 16 * tj + r, 1024 * kq, lane, wave);            // dz Wl: output unit 16 tj + r, gate rows of quarter kq
+  wload<16>(wCar, a.WuT, 4 * WH, WE + 16 * tj + r, 1024 * kq, lane, wave);       // dz Wu[:, E + ...]: carry column 16 tj + r
+  if (is_p1) wload<16>(wX, a.WcT, WA, 16 * w + r, 0, lane, wave);
+  if (is_p3) wload<16>(wX, a.WaT, WH, 16 * (w - BP3) + r, 0, lane, wave);
+  for (int i = tid; i < nrow * (WH / 4); i += 256) {
+    const int j = i / (WH / 4), c = (i % (WH / 4)) * 4;
+    *reinterpret_cast<float4*>(&s_enc[j * WH + c]) = *reinterpret_cast<const float4*>(a.enc + ((long)ab_ * a.T + t0 + j) * WH + c);
+  }
+  const int crow = tid >> 2, cu = 16 * tj + 4 * kq + (tid & 3), ccol = 4 * kq + (tid & 3);
+  float dc_next = 0.f;
+  const __amdgpu_buffer_rsrc_t r_dpre = make_rsrc(a.DPRE), r_dcvh = make_rsrc(a.DCVH), r_dq = make_rsrc(a.DQ), r_g = make_rsrc(a.G),
+                               r_part = make_rsrc(a.PARTB);
+  __syncthreads();
+
+  for (int st = S - 1; st >= 0; --st) {
+    const int n = S - st;                            // arrivals per item up to and including this step
+    // ================= P1: d_cvh[st] = d_pre[st] Wc
+    if (is_p1) {
+      if (n > 1 && !wait_sh(c_dpre, NTILE, n - 1, a.ab, &s_flag)) return;
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      mac2<16>(acc, wX, r_dpre, ((long)st * B + row0) * WA + q4, ((long)st * B + row1) * WA + q4, wave);
+      float v[2];
+      reduce2(acc, v, s_red);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int rw = 16 * mt + (tid >> 4);
+        if (rw < B) st_sc1(a.DCVH + ((long)st * B + rw) * 2 * WH + 16 * w + (tid & 15), v[mt]);
+      }
+      publish(c_p1 + (w & (NSH - 1)) * CTRS);
+    }
+    // ================= ATTB
+    if (is_att) {
+      if (!wait_sh(c_p1, NP1, n, a.ab, &s_flag)) return;
+      float4 dcv[4], cvv[4], ac[4];
+      float c0 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        dcv[c] = ldb128_sc1(r_dcvh, ((long)st * B + ab_) * 2 * WH + 256 * c + 4 * lane);
+        cvv[c] = *reinterpret_cast<const float4*>(a.CVH + ((long)st * B + ab_) * 2 * WH + 256 * c + 4 * lane);
+        c0 += dcv[c].x * cvv[c].x + dcv[c].y * cvv[c].y + dcv[c].z * cvv[c].z + dcv[c].w * cvv[c].w;
+        ac[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      c0 = wave_sum(c0);
+      for (int j = wave; j < nrow; j += 4) {
+        float4 e[4];
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          e[c] = *reinterpret_cast<const float4*>(&s_enc[j * WH + 256 * c + 4 * lane]);
+          d += e[c].x * dcv[c].x + e[c].y * dcv[c].y + e[c].z * dcv[c].z + e[c].w * dcv[c].w;
+        }
+        const float al = a.ALPHA[((long)st * B + ab_) * a.Tp + t0 + j];
+        const float ds = al * (wave_sum(d) - c0);
+        if (lane == 0) a.DS[((long)st * B + ab_) * a.Tp + t0 + j] = ds;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          ac[c].x += ds * e[c].x; ac[c].y += ds * e[c].y; ac[c].z += ds * e[c].z; ac[c].w += ds * e[c].w;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) *reinterpret_cast<float4*>(&s_acc[wave * WH + 256 * c + 4 * lane]) = ac[c];
+      __syncthreads();
+      float* prow = a.PARTB + ((long)ab_ * a.nsplit + asp) * WH;
+      for (int i = tid; i < WH; i += 256) st_sc1(&prow[i], s_acc[i] + s_acc[WH + i] + s_acc[2 * WH + i] + s_acc[3 * WH + i]);
+      publish(c_row + (size_t)ab_ * CTRS);
+    }
+    // ================= DQC: dq[b] = sum of the chunks' partials
+    if (is_dqc) {
+      const int b = w - BDQC;
+      if (!wait_one(c_row + (size_t)b * CTRS, (unsigned)(a.nsplit * n), a.ab, &s_flag)) return;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k0 = 0; k0 < a.nsplit; k0 += 8) {
+        float4 p[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] = ldb128_sc1(r_part, ((long)b * a.nsplit + min(k0 + k, a.nsplit - 1)) * WH + 4 * tid);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k0 + k < a.nsplit) { v.x += p[k].x; v.y += p[k].y; v.z += p[k].z; v.w += p[k].w; }
+      }
+      float* dq = a.DQ + ((long)st * B + b) * WH + 4 * tid;
+      st_sc1(dq, v.x); st_sc1(dq + 1, v.y); st_sc1(dq + 2, v.z); st_sc1(dq + 3, v.w);
+      publish(c_dqc + (b & (NSH - 1)) * CTRS);
+    }
+    // ================= P3: dh_top = d_cvh[:, H:] + dq Wa
+    if (is_p3) {
+      if (!wait_sh(c_dqc, B, n, a.ab, &s_flag)) return;
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      mac2<16>(acc, wX, r_dq, ((long)st * B + row0) * WH + q4, ((long)st * B + row1) * WH + q4, wave);
+      float v[2];
+      reduce2(acc, v, s_red);
+      const int col = 16 * (w - BP3) + (tid & 15);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int rw = 16 * mt + (tid >> 4);
+        if (rw < B) st_sc1(a.DHTOP + (long)rw * WH + col, v[mt] + ld_sc1(a.DCVH + ((long)st * B + rw) * 2 * WH + WH + col));
+      }
+      publish(c_p3 + ((w - BP3) & (NSH - 1)) * CTRS);
+    }
+    // ================= CELLB: pointwise LSTM backward of this workgroup's 4 units
+    {
+      if (!wait_sh(c_p3, NP3, n, a.ab, &s_flag)) return;
+      if (n > 1 && !wait_one(c_rec + (size_t)tj * CTRS, (unsigned)(4 * (n - 1)), a.ab, &s_flag)) return;
+      if (tid < 128 && crow < B) {
+        const long bu = (long)crow * WH + cu;
+        float dy = ld_sc1(a.DHTOP + bu);
+        if (a.rnn_mask) dy *= a.rnn_mask[(long)st * B * WH + bu];
+        float dh = dy;
+        if (n > 1) {
+          const float* pr = a.PREC + ((long)tj * 4 * 32 + crow) * 16 + ccol;
+          dh += ld_sc1(pr) + ld_sc1(pr + 512) + ld_sc1(pr + 1024) + ld_sc1(pr + 1536);
+        }
+        float* gp = a.G + ((long)st * B + crow) * 4 * WH + 4 * cu;
+        const float4 g = ldb128_sc1(r_g, ((long)st * B + crow) * 4 * WH + 4 * cu);      // the saved gates a, i, f, o (dz goes in their place)
+        const float ga = g.x, gi = g.y, gf = g.z, go = g.w;
+        const float tc = tanhf(a.C[(long)(st + 1) * B * WH + bu]);
+        const float cp = a.C[(long)st * B * WH + bu];
+        const float dc = dh * go * (1.f - tc * tc) + dc_next;
+        st_sc1(gp, dc * gi * (1.f - ga * ga));
+        st_sc1(gp + 1, dc * ga * gi * (1.f - gi));
+        st_sc1(gp + 2, dc * cp * gf * (1.f - gf));
+        st_sc1(gp + 3, dh * tc * go * (1.f - go));
+        dc_next = dc * gf;
+        if (st == 0) a.DC0[bu] = dc_next;
+      }
+      publish(c_cell + (w & (NSH - 1)) * CTRS);
+    }
+    if (st == 0) break;
+    // ================= DZ: quarter kq of dz_st against the recurrent and the carry weight slices
+    {
+      if (!wait_sh(c_cell, WG_, n, a.ab, &s_flag)) return;
+      const long o0 = ((long)st * B + row0) * 4 * WH + 1024 * kq + q4, o1 = ((long)st * B + row1) * 4 * WH + 1024 * kq + q4;
+      float4 a0[16], a1[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        a0[i] = ldb128_sc1(r_g, o0 + 16 * (wave + 4 * i));
+        a1[i] = ldb128_sc1(r_g, o1 + 16 * (wave + 4 * i));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 rec[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, car[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        rec[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i].x, wRec[i].x, rec[0], 0, 0, 0);
+        rec[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i].x, wRec[i].x, rec[1], 0, 0, 0);
+        car[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i].x, wCar[i].x, car[0], 0, 0, 0);
+        car[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i].x, wCar[i].x, car[1], 0, 0, 0);
+        rec[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i].y, wRec[i].y, rec[0], 0, 0, 0);
+        rec[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i].y, wRec[i].y, rec[1], 0, 0, 0);
+        car[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i].y, wCar[i].y, car[0], 0, 0, 0);
+        car[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i].y, wCar[i].y, car[1], 0, 0, 0);
+        rec[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i].z, wRec[i].z, rec[0], 0, 0, 0);
+        rec[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i].z, wRec[i].z, rec[1], 0, 0, 0);
+        car[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i].z, wCar[i].z, car[0], 0, 0, 0);
+        car[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i].z, wCar[i].z, car[1], 0, 0, 0);
+        rec[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i].w, wRec[i].w, rec[0], 0, 0, 0);
+        rec[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i].w, wRec[i].w, rec[1], 0, 0, 0);
+        car[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i].w, wCar[i].w, car[0], 0, 0, 0);
+        car[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i].w, wCar[i].w, car[1], 0, 0, 0);
+      }
+      float v[2];
+      float* pc = a.PCAR + (long)w * 512;            // [tile][quarter] = [w]: [32 rows][16 cols]
+      reduce2(car, v, s_red);
+      st_sc1(pc + tid, v[0]);
+      st_sc1(pc + 256 + tid, v[1]);
+      publish(c_car + (size_t)tj * CTRS);          // the carry first: it is on the chain
+      float* pr = a.PREC + (long)w * 512;
+      reduce2(rec, v, s_red);
+      st_sc1(pr + tid, v[0]);
+      st_sc1(pr + 256 + tid, v[1]);
+      publish(c_rec + (size_t)tj * CTRS);
+    }
+    // ================= P5R: d_pre[st-1] = (dlogits Wo + carry) (1 - ht_{st-1}^2)
+    if (is_p5r) {
+      const int j = w - BP5R;
+      if (!wait_one(c_car + (size_t)j * CTRS, (unsigned)(4 * n), a.ab, &s_flag)) return;
+      const float* pc = a.PCAR + (long)j * 4 * 512;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int rw = 16 * mt + (tid >> 4), col = 16 * j + (tid & 15);
+        if (rw < B) {
+          const int e = mt * 256 + tid;
+          const float carry = ld_sc1(pc + e) + ld_sc1(pc + 512 + e) + ld_sc1(pc + 1024 + e) + ld_sc1(pc + 1536 + e);
+          float* dp = a.DPRE + ((long)(st - 1) * B + rw) * WA + col;
+          const float y = a.HT[((long)st * B + rw) * WA + col];
+          st_sc1(dp, (*dp + carry) * (1.f - y * y));
+        }
+      }
+      publish(c_dpre + (j & (NSH - 1)) * CTRS);
+    }
+  }
+}
+
 size_t wide_lds_bytes(int chunk) { return ((size_t)chunk * WH + 4 * WH + 2048 + 512 + 16) * sizeof(float); }
 
 }  // namespace
@@ -466,6 +712,41 @@ int decoder_wide_fwd_launch(const astk_decoder_desc* d, const astk_decoder_param
     attr_done = true;
   }
   hipLaunchKernelGGL(decoder_wide_fwd, dim3(WG_), dim3(256), shm, s, a);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t decoder_wide_bwd_floats(const astk_decoder_desc* d) {       // PARTB + PREC + PCAR
+  int ns = 1, ch = 1;
+  return decoder_wide_applicable(d, &ns, &ch) ? (size_t)d->B * ns * WH + 2 * (size_t)WG_ * 512 : 4;
+}
+size_t decoder_wide_bwd_ctr_words(const astk_decoder_desc* d) {
+  return decoder_wide_applicable(d, nullptr, nullptr) ? ((size_t)D_N * NSH + 32 + 2 * NTILE + 1) * CTRS : 4;
+}
+
+int decoder_wide_bwd_launch(const astk_decoder_desc* d, const float* enc, const float* rnn_mask, const DecWideBwdBuffers& bf, hipStream_t s) {
+  int nsplit = 1, chunk = 1;
+  ASTK_CHECK(decoder_wide_applicable(d, &nsplit, &chunk), "decoder_wide_bwd: not applicable");
+  WideBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = d->B; a.S = d->L - 1; a.T = d->T; a.Tp = (d->T + 3) / 4 * 4; a.nsplit = nsplit; a.chunk = chunk;
+  a.WcT = bf.WcT; a.WaT = bf.WaT; a.WlT = bf.WlT; a.WuT = bf.WuT; a.enc = enc;
+  a.ALPHA = bf.ALPHA; a.CVH = bf.CVH; a.HT = bf.HT; a.C = bf.C; a.rnn_mask = rnn_mask;
+  a.G = bf.G; a.DPRE = bf.DPRE; a.DCVH = bf.DCVH; a.DS = bf.DS; a.DQ = bf.DQ; a.DHTOP = bf.DHTOP; a.DC0 = bf.DC0;
+  a.PARTB = bf.scratch;
+  a.PREC = bf.scratch + (size_t)d->B * nsplit * WH;
+  a.PCAR = a.PREC + (size_t)WG_ * 512;
+  a.ctr = bf.ctr;
+  const size_t nctr = ((size_t)D_N * NSH + 32 + 2 * NTILE + 1) * CTRS;
+  a.ab = abort_ctl(bf.ctr + nctr - CTRS, PERSIST_DEC_BWD);
+  ASTK_HIP(hipMemsetAsync(bf.ctr, 0, nctr * sizeof(unsigned), s));
+  const size_t shm = wide_lds_bytes(chunk);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)decoder_wide_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(decoder_wide_bwd, dim3(WG_), dim3(256), shm, s, a);
   ASTK_LAUNCH_CHECK();
   return 0;
 }
