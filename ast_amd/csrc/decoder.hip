@@ -171,10 +171,12 @@ __global__ void k_embed(const float* __restrict__ embed, const int32_t* __restri
 
 // d_embed[tok][e] += dx0[s][b][e] * mask  for all (s,b)
 __global__ void k_embed_bwd(float* __restrict__ d_embed, const int32_t* __restrict__ tok, const float* __restrict__ dx0,
-                            const float* __restrict__ mask, int SB, int E, int XI) {
+                            const float* __restrict__ mask, int SB, int E, int XI, int V) {
   const int r = blockIdx.x;
   if (r >= SB) return;
-  const int t = tok[r];
+  // (clamped: after a forward launch that timed out -- the step is discarded, but its backward still runs before the host reads the status
+  // word -- the token buffer may hold whatever the workspace held; never an index outside the table)
+  const int t = min(max(tok[r], 0), V - 1);
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
     float v = dx0[(long)r * XI + e];
     if (mask) v *= mask[(long)r * E + e];
@@ -848,7 +850,7 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
     wbl.n = 0;
     ASTK_TRY(wb.flush(s));
   }
-  hipLaunchKernelGGL(k_embed_bwd, dim3(SB), dim3(128), 0, s, g->d_embed, P.TOK, P.DX0, emb_mask, SB, E, XI);
+  hipLaunchKernelGGL(k_embed_bwd, dim3(SB), dim3(128), 0, s, g->d_embed, P.TOK, P.DX0, emb_mask, SB, E, XI, V);
   ASTK_LAUNCH_CHECK();
   return 0;
 }

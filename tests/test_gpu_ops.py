@@ -461,6 +461,38 @@ def test_decoder_per_launch_loop_scored_behind_the_loop(lib, monkeypatch, B, L, 
     _decoder_case(lib, s, B, L, T, H, E, A, V, nl, masks)
 
 
+def test_wide_decoder_path_and_bounded_spins(lib, monkeypatch):
+    """configs[4]'s decoder (H = A = 1024, E = 128, one layer, 32 rows, T'' = 200, V = 8004) reports decoder_wide.hip's persistent loops
+    (astk_decoder_path bit 4), and their spins are bounded like every other persistent kernel's: with ASTK_PERSIST_SPIN_LIMIT = 1 the
+    launches give up, drain and leave the decoder bits in the library's sticky status word instead of hanging."""
+    from ast_amd._lib import DecoderDesc
+    assert lib.astk_decoder_path(C.byref(DecoderDesc(32, 40, 200, 1024, 128, 1024, 8004, 1))) == 16
+    assert lib.astk_decoder_path(C.byref(DecoderDesc(32, 40, 300, 1024, 128, 1024, 8004, 1))) == 0      # slices of 38 rows do not fit LDS
+    assert lib.astk_decoder_path(C.byref(DecoderDesc(32, 40, 200, 1024, 128, 1024, 8004, 2))) == 0      # one layer only
+    B, L, T, H, E, A, V, nl = 8, 6, 24, 1024, 128, 1024, 300, 1
+    s = _dec_setup(lib, B, L, T, H, E, A, V, nl, False, seed=3)
+    host = (C.c_int32 * s["S"])(*[int(f) for f in s["flags"]])
+    s["d"].use_truth_host = C.cast(host, C.POINTER(C.c_int32))
+    nbytes = lib.astk_decoder_workspace_bytes(C.byref(s["d"]))
+    ws = GuardedWS(nbytes)
+    enc_d, c0_d, h0_d = dev(s["enc"]), dev(s["c0"]), dev(s["h0"])
+    y_d, fl_d = dev(s["y"], torch.int32), dev(np.asarray(s["flags"]), torch.int32)
+    loss_d, pred_d = torch.zeros(1, device="cuda"), torch.zeros(s["S"], B, dtype=torch.int32, device="cuda")
+    mask = C.c_uint(0)
+    assert lib.astk_persist_status(C.byref(mask), 1) == 0
+    monkeypatch.setenv("ASTK_PERSIST_SPIN_LIMIT", "1")
+    ok(lib, lib.astk_decoder_fwd(C.byref(s["d"]), C.byref(s["dp"]), vp(enc_d), vp(c0_d), vp(h0_d), vp(y_d), vp(fl_d), None, None,
+                                 vp(loss_d), vp(pred_d), vp(ws), nbytes, stream()))
+    assert lib.astk_persist_status(C.byref(mask), 1) == 0 and mask.value & 4, mask.value           # PERSIST_DEC_FWD
+    d_enc = torch.zeros(B, T, H, device="cuda")
+    d_c0, d_h0 = torch.zeros(nl, B, H, device="cuda"), torch.zeros(nl, B, H, device="cuda")
+    ok(lib, lib.astk_decoder_bwd(C.byref(s["d"]), C.byref(s["dp"]), C.byref(s["dg"]), vp(enc_d), vp(c0_d), vp(h0_d), vp(y_d), None,
+                                 None, vp(d_enc), vp(d_c0), vp(d_h0), vp(ws), nbytes, stream()))
+    assert lib.astk_persist_status(C.byref(mask), 1) == 0 and mask.value & 8, mask.value           # PERSIST_DEC_BWD
+    monkeypatch.delenv("ASTK_PERSIST_SPIN_LIMIT")
+    ws.check("wide decoder, timed-out launches")
+
+
 def _decoder_case(lib, s, B, L, T, H, E, A, V, nl, masks):
     from oracle.ast_ref_torch import decoder_torch
     cfg = {"rnn_config": {"dec_layers": nl, "attn_units": A}}
