@@ -354,7 +354,7 @@ int make_split(const astk_decoder_desc* d, void* ws, SplitPlan& sp) {
   sp.bytes = 0;
   if (!d || d->B < 2 || d->n_attn > 1 || d->no_feed_attn || d->ln || d->L < 2) return 0;
   int ns = 1, ch = 1;
-  if (decoder_persist_applicable(d, &ns, &ch)) return 0;
+  if (decoder_persist_applicable(d, &ns, &ch) || decoder_wide_applicable(d, nullptr, nullptr)) return 0;
   const int B0 = ((d->B / 2 + 15) / 16) * 16;
   if (B0 >= d->B) return 0;
   const int Bs[2] = {B0, d->B - B0};
@@ -363,7 +363,9 @@ int make_split(const astk_decoder_desc* d, void* ws, SplitPlan& sp) {
     sp.sub[i].B = Bs[i];
     sp.sub[i].loss_rows = d->loss_rows > 0 ? d->loss_rows : d->B;
     sp.off[i] = i == 0 ? 0 : B0;
-    if (!decoder_persist_applicable(&sp.sub[i], &ns, &ch)) return 0;
+    // (the wide decoder's loops only for more than 32 rows: at 32 rows and slices too long for LDS two half launches are no faster than the
+    //  per-launch loop)
+    if (!decoder_persist_applicable(&sp.sub[i], &ns, &ch) && !(d->B > 32 && decoder_wide_applicable(&sp.sub[i], nullptr, nullptr))) return 0;
   }
   Carver c(ws);
   const size_t S = d->L - 1, H = d->H, E = d->E, nl = d->n_layers;

@@ -444,7 +444,7 @@ def test_decoder_fwd_bwd(lib, B, L, T, H, E, A, V, nl, masks, gemm_split):
                                                     # the wide forward loop: ragged batch tiles, dropout masks, slices of 25 rows, one-row slices
                                                     (19, 6, 200, 1024, 128, 1024, 300, 1, True), (4, 12, 40, 1024, 128, 1024, 8004, 1, True),
                                                     (32, 5, 256, 1024, 128, 1024, 1098, 1, False), (32, 4, 263, 1024, 128, 1024, 300, 1, False),
-                                                    (1, 7, 7, 1024, 128, 1024, 50, 1, False)])
+                                                    (1, 7, 7, 1024, 128, 1024, 50, 1, False), (64, 6, 200, 1024, 128, 1024, 300, 1, True), (45, 5, 40, 1024, 128, 1024, 300, 1, False)])
 def test_decoder_per_launch_loop_scored_behind_the_loop(lib, monkeypatch, B, L, T, H, E, A, V, nl, masks, gemm_split):
     """The per-launch loop with the caller's HOST copy of the flags (astk_decoder_desc.use_truth_host): logits inside the loop only for the
     steps whose argmax is fed back, every step scored by one product and one softmax-CE launch behind it; in the backward, dlogits Wo as
@@ -453,8 +453,10 @@ def test_decoder_per_launch_loop_scored_behind_the_loop(lib, monkeypatch, B, L, 
     s = _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=B + L + 1)
     assert not (lib.astk_decoder_path(C.byref(s["d"])) & 1)
     # configs[4]'s width: the FORWARD loop is decoder_wide.hip's persistent kernel, one launch per teacher-forced segment
-    slice_rows = -(-T // max(1, min(256 // B, T, 64)))          # rows of enc_states a workgroup keeps in LDS (4 KB each)
-    assert bool(lib.astk_decoder_path(C.byref(s["d"])) & 16) == (H == 1024 and A == 1024 and E == 128 and nl == 1 and B <= 32 and slice_rows <= 32)
+    Bw = B if B <= 32 else 32                                   # (more than 32 rows: two launches over halves, like the shipped width)
+    slice_rows = -(-T // max(1, min(256 // Bw, T, 64)))         # rows of enc_states a workgroup keeps in LDS (4 KB each)
+    assert bool(lib.astk_decoder_path(C.byref(s["d"])) & 16) == (H == 1024 and A == 1024 and E == 128 and nl == 1 and B <= 64 and slice_rows <= 32)
+    assert bool(lib.astk_decoder_path(C.byref(s["d"])) & 4) == (H == 1024 and B > 32)
     host = (C.c_int32 * s["S"])(*[int(f) for f in s["flags"]])
     s["d"].use_truth_host = C.cast(host, C.POINTER(C.c_int32))
     assert 0 in list(host) or s["S"] < 3, "the case should feed at least one argmax back"
