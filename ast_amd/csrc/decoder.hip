@@ -504,26 +504,15 @@ int astk_decoder_fwd_ex(const astk_decoder_desc* d, const astk_decoder_params* p
   }
   const int32_t* uth = d->use_truth_host;      // optional host copy of use_truth: which steps feed their argmax back
   const float inv_count = 1.f / (float)(d->loss_rows > 0 ? d->loss_rows : B);
-  // The wide decoder (configs[4]: H = A = 1024) on its persistent forward loop (decoder_wide.hip): one launch per SEGMENT of the loop, a
-  // segment ending at a step whose argmax is fed back (that step's logits and argmax come from the two launches below, then the next
-  // segment starts); every step is scored behind the loop like in the per-launch form.
-  const bool wide = uth && !out_mask && decoder_wide_applicable(d, nullptr, nullptr);
-  for (int st = 0; wide && st < S;) {
-    int s1 = st;
-    while (s1 + 1 < S && uth[s1 + 1] != 0) ++s1;           // step s1 + 1 is not teacher-forced (or there is none): the segment ends at s1
+  // The wide decoder (configs[4]: H = A = 1024) on its persistent forward loop (decoder_wide.hip): ONE launch for all steps.  The kernel
+  // computes logits itself on the steps whose argmax is fed back (streamed weights) and leaves the class in PRED; every step is scored
+  // behind the loop like in the per-launch form with host flags.
+  const bool wide = !out_mask && decoder_wide_applicable(d, nullptr, nullptr);
+  if (wide) {
     DecWideBuffers wb;
     wb.TOK = P.TOK; wb.PRED = P.PRED; wb.X0 = P.X0; wb.G = P.G[0]; wb.C = P.C[0]; wb.HR = P.HR[0]; wb.Q = P.Q; wb.ALPHA = P.ALPHA;
     wb.CVH = P.CVH; wb.HT = P.HT; wb.PART = P.WPART; wb.ctr = P.WCTR;
-    ASTK_TRY(decoder_wide_fwd_launch(d, prm, enc, y, use_truth, emb_mask, rnn_masks, wb, st, s1, s));
-    if (s1 + 1 < S) {
-      RowGemmArgs a = rg(B, V, P.HT + (size_t)(s1 + 1) * B * A, A, prm->Wo, A, A, P.LG1, P.Vp);
-      a.bias = prm->bo;
-      ASTK_TRY(rowgemm_launch(a, s));
-      hipLaunchKernelGGL(k_softmax_ce, dim3(B), dim3(256), 0, s, V, (long)P.Vp, P.LG1, tgt + s1 + 1, (long)P.L, B, (const float*)nullptr, 1.f,
-                         (float*)nullptr, P.PRED + (size_t)s1 * B, 1, (const int32_t*)nullptr, 0);
-      ASTK_LAUNCH_CHECK();
-    }
-    st = s1 + 1;
+    ASTK_TRY(decoder_wide_fwd_launch(d, prm, enc, y, use_truth, emb_mask, rnn_masks, wb, 0, S - 1, s));
   }
   for (int st = 0; st < S && !wide; ++st) {
     float* x0 = P.X0 + (size_t)st * B * XI;
@@ -595,7 +584,7 @@ int astk_decoder_fwd_ex(const astk_decoder_desc* d, const astk_decoder_params* p
       }
     }
   }
-  if (uth) {
+  if (uth || wide) {
     ASTK_TRY(gemm_launch(GEMM_NT, gemm_args(S * B, V, A, mat(P.HT + (size_t)B * A, A), mat(prm->Wo, A), P.LOGITS, P.Vp, prm->bo), s));
     if (out_mask) ASTK_TRY(mul_rows_launch(P.LOGITS, P.Vp, out_mask, V, S * B, V, s));
     hipLaunchKernelGGL(k_softmax_ce, dim3(S * B), dim3(256), 0, s, V, (long)P.Vp, P.LOGITS, tgt + 1, (long)P.L, B, prm->class_weight, inv_count,

@@ -1,16 +1,18 @@
 // Persistent forward loop for the WIDE decoder of BASELINE configs[4] (H = A = 1024, E = 128, one layer, one attention head, input
-// feeding; seq2seq.py:361-397): a run of consecutive teacher-forced decoder steps in ONE launch.
+// feeding; seq2seq.py:361-397): all decoder steps in ONE launch.
 //
 // decoder_persist.hip keeps every decoder weight in registers; at this width they are 77 MB (cell 35.6, context 8.4, logits 32.8), 300 of
-// the 512 registers of every lane on the chip.  This kernel drops the logits from the loop (decoder.hip scores all steps with one product
-// behind the loop and computes logits inside it only for the steps whose argmax is fed back: the loop is cut into SEGMENTS there, one
-// launch of this kernel per segment) and shares the remaining weight slices between the two 16-row batch tiles:
+// the 512 registers of every lane on the chip.  This kernel drops the logits from the chain (decoder.hip scores all steps with one product
+// behind the loop; only the steps whose argmax is fed back compute logits here, from weights streamed through L2) and shares the remaining
+// weight slices between the two 16-row batch tiles:
 //   CELL  all 256 workgroups: 4 hidden units (the 16 gate rows 16w..16w+15 of Chainer's interleaved layout), K = E + A + H = 2176 split over
 //         the 4 waves: 34 float4 of weights per lane; embedding rows gathered straight from the table
 //   Q     workgroups 64..127:  q = Wa h + ba, 16 columns each (16 float4 per lane)
 //   ATT   workgroup (b, chunk): its slice of enc_states stays in LDS for all steps (32 x 8 slices of 25 rows x 4 KB at T'' = 200)
 //   CMB   workgroups 192..192+B-1: merges a batch row's partial softmax / context sums, normalises alpha
 //   CTX   workgroups 128..191: ht = tanh(Wc [cv; h] + bc), 16 columns each (32 float4 per lane)
+//   LOG / ARG (only when the next step is not teacher-forced): every workgroup streams its 16-column logits tiles, one workgroup per batch
+//         row reduces the per-tile maxima to the class that is fed back
 // Chain per step: CELL -> Q -> ATT -> CMB -> CTX -> next CELL; hand-offs as in decoder_persist.hip (write-through stores, drained, one arrival
 // add on a sharded counter; consumers poll, then sc1 loads).  The h part of the next cell product needs only CELL, so it runs while CTX is in
 // flight.  Saved state = decoder.hip's DecPlan, so its per-launch backward runs on it unchanged.  All spins are bounded (abort word).
@@ -26,16 +28,19 @@ constexpr int CTRS = 64;              // counter stride in words (256 B)
 constexpr int NSH = 32;               // shards of a phase counter
 constexpr int Q0 = 64, CTX0 = 128, CMB0 = 192;   // first workgroup of the Q / CTX / CMB roles
 constexpr int NQ = WH / 16, NCTX = WA / 16;
-enum { C_CELL = 0, C_Q, C_CMB, C_CTX, C_N };
+enum { C_CELL = 0, C_Q, C_CMB, C_CTX, C_LOG, C_ARG, C_N };
 constexpr int PARTW = WH + 4;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct WideArgs {
   int B, S, L, T, Tp, V, s0, s1, nsplit, chunk;
-  const float *embed, *Wu, *bias, *Wl, *Wa, *ba, *Wc, *bc;
+  const float *embed, *Wu, *bias, *Wl, *Wa, *ba, *Wc, *bc, *Wo, *bo;
   const float* enc;
-  const int32_t *y, *use_truth, *PRED;
+  const int32_t *y, *use_truth;
+  int32_t* PRED;
+  float* LMAX;         // [B][ntile][2]: per (batch row, 16-column logits tile) maximum and its class id (fed-back steps only)
+  int ntile;
   const float *emb_mask, *rnn_mask;
   int32_t* TOK;
   float *X0, *G, *C, *HR, *Q, *ALPHA, *CVH, *HT, *PART;
@@ -46,6 +51,8 @@ struct WideArgs {
 __device__ __forceinline__ unsigned ld_flag(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ldi_sc1(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sti_sc1(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
@@ -179,6 +186,8 @@ __global__ __launch_bounds__(256, 1) void decoder_wide_fwd(WideArgs a) {
   unsigned* c_q = a.ctr + (size_t)C_Q * NSH * CTRS;
   unsigned* c_cmb = a.ctr + (size_t)C_CMB * NSH * CTRS;
   unsigned* c_ctx = a.ctr + (size_t)C_CTX * NSH * CTRS;
+  unsigned* c_log = a.ctr + (size_t)C_LOG * NSH * CTRS;
+  unsigned* c_arg = a.ctr + (size_t)C_ARG * NSH * CTRS;
   unsigned* c_row = a.ctr + (size_t)C_N * NSH * CTRS;
   const bool is_q = w >= Q0 && w < Q0 + NQ, is_ctx = w >= CTX0 && w < CTX0 + NCTX, is_cmb = w >= CMB0 && w < CMB0 + B;
   const bool is_att = w < B * a.nsplit;
@@ -203,21 +212,25 @@ __global__ __launch_bounds__(256, 1) void decoder_wide_fwd(WideArgs a) {
   float c_state = 0.f;
   if (tid < 128 && crow < B) c_state = a.C[((long)a.s0 * B + crow) * WH + cu];
   const float4 bz = tid < 128 ? *reinterpret_cast<const float4*>(a.bias + 4 * cu) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const __amdgpu_buffer_rsrc_t r_hr = make_rsrc(a.HR), r_x0 = make_rsrc(a.X0), r_cvh = make_rsrc(a.CVH), r_q = make_rsrc(a.Q);
+  const __amdgpu_buffer_rsrc_t r_hr = make_rsrc(a.HR), r_x0 = make_rsrc(a.X0), r_cvh = make_rsrc(a.CVH), r_q = make_rsrc(a.Q),
+                               r_ht = make_rsrc(a.HT);
+  int nfed = 0;                                               // steps of this launch whose argmax was fed back so far
   __syncthreads();
 
   for (int s = a.s0; s <= a.s1; ++s) {
     const int n = s - a.s0 + 1;                               // arrivals per item up to and including this step
+    const bool fed_in = s > a.s0 && a.use_truth[s] == 0;      // this step's token is the previous step's argmax, found inside this launch
     // ================= CELL
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if (n > 1 && !wait_sh(c_cell, WG_, n - 1, a.ab, &s_flag)) return;      // h_{s-1} of every unit
     mac2<16>(acc, wHh, r_hr, ((long)s * B + row0) * WH + q4, ((long)s * B + row1) * WH + q4, wave);
-    {   // embedding part (off the chain): rows gathered from the table, times the embedding dropout mask
+    if (fed_in && !wait_sh(c_arg, B, nfed, a.ab, &s_flag)) return;          // the fed-back tokens (ARG of step s - 1)
+    {   // embedding part (off the chain unless the token is fed back): rows gathered from the table, times the embedding dropout mask
       int tok[2];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int rw = mt ? row1 : row0;
-        int t = (a.use_truth[s] || s == 0) ? a.y[(long)rw * a.L + s] : a.PRED[(long)(s - 1) * B + rw];
+        int t = (a.use_truth[s] || s == 0) ? a.y[(long)rw * a.L + s] : ldi_sc1(a.PRED + (long)(s - 1) * B + rw);
         tok[mt] = t < 0 ? 0 : (t >= a.V ? a.V - 1 : t);
       }
       f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void decoder_wide_fwd(WideArgs a) {
       acc[1] += b1;
       // the saved embedding rows (the weight gradients' operand) and tokens: workgroup b writes row b
       if (w < B) {
-        int t = (a.use_truth[s] || s == 0) ? a.y[(long)w * a.L + s] : a.PRED[(long)(s - 1) * B + w];
+        int t = (a.use_truth[s] || s == 0) ? a.y[(long)w * a.L + s] : ldi_sc1(a.PRED + (long)(s - 1) * B + w);
         t = t < 0 ? 0 : (t >= a.V ? a.V - 1 : t);
         if (tid == 0) a.TOK[(long)s * B + w] = t;
         if (tid < WE) {
@@ -402,11 +415,79 @@ __global__ __launch_bounds__(256, 1) void decoder_wide_fwd(WideArgs a) {
         const int rw = 16 * mt + (tid >> 4);
         if (rw < B) {
           const float ht = tanh_fast(v[mt] + bb);
-          a.HT[((long)(s + 1) * B + rw) * WA + col] = ht;
+          st_sc1(a.HT + ((long)(s + 1) * B + rw) * WA + col, ht);
           if (s + 1 < a.S) st_sc1(a.X0 + ((long)(s + 1) * B + rw) * WXI + WE + col, ht);
         }
       }
       publish(c_ctx + ((w - CTX0) & (NSH - 1)) * CTRS);
+    }
+    // ================= LOG / ARG: only when the NEXT step is not teacher-forced (its token is this step's argmax; every step's loss is
+    // scored behind the loop by decoder.hip).  The logits weights are not resident: each workgroup streams the rows of its 16-column tiles
+    // (two at V = 8004: 128 KB) from L2 / Infinity Cache, keeps a per-(row, tile) maximum, and one workgroup per batch row picks the class.
+    if (s + 1 < a.S && s < a.s1 && a.use_truth[s + 1] == 0) {
+      ++nfed;
+      if (!wait_sh(c_ctx, NCTX, n, a.ab, &s_flag)) return;
+      for (int t = w; t < a.ntile; t += WG_) {
+        f32x4 lg[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const float* wrow = a.Wo + (long)min(16 * t + r, a.V - 1) * WA + q4;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          float4 wt[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) wt[i] = *reinterpret_cast<const float4*>(wrow + 512 * half + 16 * (wave + 4 * i));
+          mac2<8>(lg, wt, r_ht, ((long)(s + 1) * B + row0) * WA + q4 + 512 * half, ((long)(s + 1) * B + row1) * WA + q4 + 512 * half, wave);
+        }
+        float v[2];
+        reduce2(lg, v, s_red);
+        const int cls = 16 * t + (tid & 15);
+        const float bb = a.bo[min(cls, a.V - 1)];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          float m = cls < a.V ? v[mt] + bb : -INFINITY;
+          int mi = cls;
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) {           // the 16 lanes of a row: maximum, lowest class id on ties
+            const float om = __shfl_xor(m, o);
+            const int oi = __shfl_xor(mi, o);
+            if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+          }
+          const int rw = 16 * mt + (tid >> 4);
+          if ((tid & 15) == 0 && rw < B) {
+            float* lm = a.LMAX + ((long)rw * a.ntile + t) * 2;
+            st_sc1(lm, m);
+            st_sc1(lm + 1, __int_as_float(mi));
+          }
+        }
+      }
+      publish(c_log + (w & (NSH - 1)) * CTRS);
+      if (w < B) {
+        if (!wait_sh(c_log, WG_, nfed, a.ab, &s_flag)) return;
+        float m = -INFINITY;
+        int mi = 0x7fffffff;
+        for (int t = tid; t < a.ntile; t += 256) {
+          const float* lm = a.LMAX + ((long)w * a.ntile + t) * 2;
+          const float om = ld_sc1(lm);
+          const int oi = __float_as_int(ld_sc1(lm + 1));
+          if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float om = __shfl_xor(m, o);
+          const int oi = __shfl_xor(mi, o);
+          if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+        }
+        if (lane == 0) { s_ml[wave] = m; s_ml[8 + wave] = __int_as_float(mi); }
+        __syncthreads();
+        if (tid == 0) {
+          for (int k = 1; k < 4; ++k) {
+            const float om = s_ml[k];
+            const int oi = __float_as_int(s_ml[8 + k]);
+            if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+          }
+          sti_sc1(a.PRED + (long)s * B + w, mi);
+        }
+        publish(c_arg + (w & (NSH - 1)) * CTRS);
+      }
     }
   }
 }
@@ -681,7 +762,7 @@ bool decoder_wide_applicable(const astk_decoder_desc* d, int* nsplit_out, int* c
 
 size_t decoder_wide_part_floats(const astk_decoder_desc* d) {
   int ns = 1, ch = 1;
-  return decoder_wide_applicable(d, &ns, &ch) ? (size_t)d->B * ns * PARTW : 4;
+  return decoder_wide_applicable(d, &ns, &ch) ? (size_t)d->B * ns * PARTW + (size_t)d->B * ((d->V + 15) / 16) * 2 : 4;
 }
 size_t decoder_wide_ctr_words(const astk_decoder_desc* d) {
   return decoder_wide_applicable(d, nullptr, nullptr) ? ((size_t)C_N * NSH + d->B + 1) * CTRS : 4;
@@ -698,7 +779,9 @@ int decoder_wide_fwd_launch(const astk_decoder_desc* d, const astk_decoder_param
   a.B = d->B; a.S = d->L - 1; a.L = d->L; a.T = d->T; a.Tp = (d->T + 3) / 4 * 4; a.V = d->V; a.s0 = s0; a.s1 = s1;
   a.nsplit = nsplit; a.chunk = chunk;
   a.embed = prm->embed; a.Wu = prm->lstm[0].Wu; a.bias = prm->lstm[0].b; a.Wl = prm->lstm[0].Wl;
-  a.Wa = prm->Wa; a.ba = prm->ba; a.Wc = prm->Wc; a.bc = prm->bc;
+  a.Wa = prm->Wa; a.ba = prm->ba; a.Wc = prm->Wc; a.bc = prm->bc; a.Wo = prm->Wo; a.bo = prm->bo;
+  a.ntile = (d->V + 15) / 16;
+  a.LMAX = bf.PART + (size_t)d->B * nsplit * PARTW;
   a.enc = enc; a.y = y; a.use_truth = use_truth; a.PRED = bf.PRED; a.emb_mask = emb_mask; a.rnn_mask = rnn_mask;
   a.TOK = bf.TOK; a.X0 = bf.X0; a.G = bf.G; a.C = bf.C; a.HR = bf.HR; a.Q = bf.Q; a.ALPHA = bf.ALPHA; a.CVH = bf.CVH; a.HT = bf.HT;
   a.PART = bf.PART; a.ctr = bf.ctr;

@@ -428,10 +428,15 @@ def _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=0):
                                                     # more than 32 rows at the shipped width: two persistent launches over halves of the rows (row split:
                                                     # 64 = 32 + 32, 48 = 32 + 16, 37 = 32 + 5; masks and initial states staged per half, loss over all rows)
                                                     (64, 6, 200, 512, 128, 512, 1098, 1, True), (48, 5, 200, 512, 128, 512, 1098, 3, True),
-                                                    (37, 5, 50, 512, 128, 512, 300, 1, False)])
+                                                    (37, 5, 50, 512, 128, 512, 300, 1, False),
+                                                    # configs[4]'s decoder width on decoder_wide.hip's loops, WITHOUT the host copy of the flags (the
+                                                    # kernel reads the device flags and computes the fed-back steps' logits itself)
+                                                    (32, 7, 40, 1024, 128, 1024, 1098, 1, True), (9, 6, 30, 1024, 128, 1024, 8004, 1, False)])
 def test_decoder_fwd_bwd(lib, B, L, T, H, E, A, V, nl, masks, gemm_split):
     s = _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=B + L)
-    if H % 64 == 0 and A % 16 == 0 and E % 16 == 0 and nl <= 3:       # the shapes meant for the persistent kernels really take them
+    if H == 1024:
+        assert lib.astk_decoder_path(C.byref(s["d"])) == 16
+    elif H % 64 == 0 and A % 16 == 0 and E % 16 == 0 and nl <= 3:       # the shapes meant for the persistent kernels really take them
         assert lib.astk_decoder_path(C.byref(s["d"])) & 1, "persistent decoder path not taken"
         assert bool(lib.astk_decoder_path(C.byref(s["d"])) & 4) == (B > 32 and H == 512), "row split"
     _decoder_case(lib, s, B, L, T, H, E, A, V, nl, masks)
