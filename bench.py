@@ -245,7 +245,7 @@ def main():
     dpath = lib.astk_decoder_path(C.byref(st["dd"]))
     paths["decoder"] = (f"persistent loop, {dpath >> 8} layer(s) fused" + (", attention phase specialised (H=512, chunk<=32)" if dpath & 2 else ", generic attention phase")
                         + (", two launches over halves of the batch rows" if dpath & 4 else "")) \
-        if dpath & 1 else ("persistent loops of the wide decoder (decoder_wide.hip): forward one launch per teacher-forced segment, backward one launch"
+        if dpath & 1 else ("persistent loops of the wide decoder (decoder_wide.hip): one forward and one backward launch for all steps"
                            if dpath & 16 else "per-launch loop (fallback)")
     paths["encoder_persistent"], paths["decoder_persistent"] = bool(lib.astk_lstm_stack_path(C.byref(st["ld"]))), bool(dpath & 17)
     paths["cu_count"] = int(lib.astk_device_cu_count())

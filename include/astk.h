@@ -377,8 +377,8 @@ int astk_persist_status_snapshot(float* dst, void* stream);
  *                         H = 512 / chunk <= 32, bit 2 = the batch runs as TWO persistent launches over halves of its rows (more than
  *                         32 rows at the shipped width: the decoder couples no batch rows, the halves share nothing but the weights
  *                         and the loss's 1/B), bit 4 (alone) = the wide decoder of configs[4] (H = A = 1024, E = 128, one layer, up to 32 rows,
- *                         T'' <= 256 at 32 rows) on decoder_wide.hip's persistent loops: the backward in one launch, the forward in one
- *                         launch per teacher-forced segment when the caller passes use_truth_host (else step by step); bits 8.. = number of decoder layers fused into the persistent kernels */
+ *                         T'' <= 256 at 32 rows) on decoder_wide.hip's persistent loops, one launch for the forward and one for the backward
+ *                         (with bit 2: two of each, over halves of more than 32 rows); bits 8.. = number of decoder layers fused into the persistent kernels */
 int astk_lstm_stack_path(const astk_lstm_stack_desc* d);
 int astk_decoder_path(const astk_decoder_desc* d);
 int astk_persist_status(unsigned* mask_out, int reset);

@@ -457,7 +457,7 @@ def test_decoder_per_launch_loop_scored_behind_the_loop(lib, monkeypatch, B, L, 
     monkeypatch.setenv("ASTK_DEC_PERSIST", "0")
     s = _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=B + L + 1)
     assert not (lib.astk_decoder_path(C.byref(s["d"])) & 1)
-    # configs[4]'s width: the FORWARD loop is decoder_wide.hip's persistent kernel, one launch per teacher-forced segment
+    # configs[4]'s width: decoder_wide.hip's persistent loops
     Bw = B if B <= 32 else 32                                   # (more than 32 rows: two launches over halves, like the shipped width)
     slice_rows = -(-T // max(1, min(256 // Bw, T, 64)))         # rows of enc_states a workgroup keeps in LDS (4 KB each)
     assert bool(lib.astk_decoder_path(C.byref(s["d"])) & 16) == (H == 1024 and A == 1024 and E == 128 and nl == 1 and B <= 64 and slice_rows <= 32)
