@@ -593,6 +593,28 @@ def test_softmax_ce(lib):
     assert (am.cpu().numpy() == x.argmax(1)).all()
 
 
+def test_softmax_ce_loss_rows_are_read_before_the_gradient_overwrites_the_logits(lib):
+    """The kernel turns the logits into their gradient IN PLACE and the loss row needs the target's logit: that read has to happen in
+    front of the barrier that precedes the overwrite.  Until the end of round 3 it was an ordinary load whose only use sat behind the
+    barrier (through a __restrict__ pointer), and about one loss row in a few thousand came out with exp(x - lse) * scale - scale in place
+    of the logit, depending on which wave reached the store first; the gradient was never affected.  Many rows, every row checked."""
+    rng = np.random.default_rng(5)
+    B, V, ld = 16384, 300, 300
+    x = (rng.standard_normal((B, V)) * 2).astype(np.float32)
+    t = rng.integers(1, V, B).astype(np.int32)
+    xt = torch.tensor(x, dtype=torch.float64)
+    want = torch.nn.functional.cross_entropy(xt, torch.tensor(t).long(), reduction="none").numpy() / 32
+    t_d = dev(t, torch.int32)
+    worst = 0.0
+    for rep in range(4):
+        buf = dev(x).clone()
+        rows = torch.zeros(B, device="cuda")
+        ok(lib, lib.astk_softmax_ce_fwd(B, V, ld, vp(buf), vp(t_d), 1, None, 1.0 / 32, vp(rows), None, stream()))
+        err = np.abs(rows.cpu().numpy().astype(np.float64) - want)
+        worst = max(worst, float((err / np.maximum(want, 1e-3)).max()))
+    assert worst < 1e-5, worst
+
+
 def test_optimizer_step_matches_reference(lib):
     from oracle.ast_ref import RefOptimizer
     from oracle import minichainer as F
