@@ -75,6 +75,9 @@ __device__ __forceinline__ void acquire_handoff() {
 }
 // lanes 0..NSH-1 of wave 0 poll the shards of a phase counter until `n_items` items have arrived `steps` times each
 __device__ __forceinline__ bool wait_sh(const unsigned* base, int n_items, int steps, const AbortCtl& ab, int* s_flag) {
+#ifdef ASTK_WIDE_NOWAIT      // timing experiment only (wrong results): how long is a step without its hand-offs?
+  return true;
+#endif
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     const unsigned target = lane < NSH ? (unsigned)(((n_items - lane + NSH - 1) / NSH) * steps) : 0u;
@@ -95,6 +98,9 @@ __device__ __forceinline__ bool wait_sh(const unsigned* base, int n_items, int s
   return ok;
 }
 __device__ __forceinline__ bool wait_one(const unsigned* ctr, unsigned target, const AbortCtl& ab, int* s_flag) {
+#ifdef ASTK_WIDE_NOWAIT
+  return true;
+#endif
   if (threadIdx.x == 0) {
     bool ok = true;
     unsigned spins = 0;
