@@ -6,9 +6,16 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ASTK_LIB_PATH") or os.path.join(_HERE, "libastk.so")     # (override: timing experiments with debug builds)
 
+TEST_LIB_PATH = os.path.join(_HERE, "libastk_test.so")     # the same library built with -DASTK_TEST_HOOKS (tests only: load_test_hooks)
+
 MAX_CNN = 4
 MAX_RNN = 8
 MAX_ATTN = 4
+# astk.h: arithmetic of an op's products (descriptor field `precision`) and operand mode (`gemm_operands`)
+PREC_DEFAULT, PREC_FP16X2, PREC_BF16X3, PREC_F32 = 0, 1, 2, 3
+OPERANDS_DEFAULT, OPERANDS_F32, OPERANDS_FP16 = 0, 1, 2
+OPERANDS_BY_NAME = {None: OPERANDS_DEFAULT, "default": OPERANDS_DEFAULT, "f32": OPERANDS_F32, "fp16": OPERANDS_FP16}
+PREC_BY_NAME = {None: PREC_DEFAULT, "default": PREC_DEFAULT, "fp16x2": PREC_FP16X2, "bf16x3": PREC_BF16X3, "f32": PREC_F32}
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int32)
@@ -20,7 +27,8 @@ class CnnDesc(C.Structure):
                 ("C", C.c_int * MAX_CNN), ("kt", C.c_int * MAX_CNN), ("kf", C.c_int * MAX_CNN),
                 ("st", C.c_int * MAX_CNN), ("sf", C.c_int * MAX_CNN), ("pt", C.c_int * MAX_CNN),
                 ("bn_eps", C.c_float), ("bn_decay", C.c_float), ("no_bn", C.c_int),
-                ("pool_t", C.c_int * MAX_CNN), ("pool_f", C.c_int * MAX_CNN)]
+                ("pool_t", C.c_int * MAX_CNN), ("pool_f", C.c_int * MAX_CNN),
+                ("precision", C.c_int), ("gemm_operands", C.c_int)]
 
 
 class CnnLayerParams(C.Structure):
@@ -34,7 +42,8 @@ class CnnLayerGrads(C.Structure):
 
 class LstmStackDesc(C.Structure):
     _fields_ = [("T", C.c_int), ("B", C.c_int), ("in_dim", C.c_int), ("h", C.c_int),
-                ("n_layers", C.c_int), ("n_dirs", C.c_int), ("out_bound", C.c_float), ("x_amax", C.c_void_p)]
+                ("n_layers", C.c_int), ("n_dirs", C.c_int), ("out_bound", C.c_float), ("x_amax", C.c_void_p),
+                ("precision", C.c_int), ("gemm_operands", C.c_int)]
 
 
 class LstmParams(C.Structure):
@@ -49,7 +58,7 @@ class DecoderDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("L", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int),
                 ("A", C.c_int), ("V", C.c_int), ("n_layers", C.c_int),
                 ("n_attn", C.c_int), ("no_feed_attn", C.c_int), ("ln", C.c_int), ("loss_rows", C.c_int),
-                ("use_truth_host", C.POINTER(C.c_int32))]
+                ("use_truth_host", C.POINTER(C.c_int32)), ("precision", C.c_int), ("gemm_operands", C.c_int)]
 
 
 class DecoderParams(C.Structure):
@@ -78,15 +87,13 @@ SIGNATURES = {
     "astk_set_gemm_bf16_split_below": (C.c_double, [C.c_double]),
     "astk_set_gemm_precision": (C.c_int, [_I]),
     "astk_get_gemm_precision": (C.c_int, []),
-    "astk_debug_set_amax_generation": (C.c_int, [C.c_uint]),
     "astk_gemm_f32": (C.c_int, [_I, _I, _I, _I, _VP, _L, _VP, _L, _VP, _L, _VP, _I, _I, _I, _L, _L, _L, _VP]),
+    "astk_gemm_f32_ex": (C.c_int, [_I, _I, _I, _I, _VP, _L, _VP, _L, _VP, _L, _VP, _I, _I, _I, _L, _L, _L, _I, _VP]),
     "astk_conv_bn_relu_out_dims": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "astk_conv_bn_relu_workspace_bytes": (_SZ, [C.POINTER(CnnDesc)]),
     "astk_conv_bn_relu_fwd": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(CnnLayerParams), _VP, _VP, _VP, _VP, _SZ, _I, _VP]),
     "astk_conv_bn_relu_bwd": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(CnnLayerParams), C.POINTER(CnnLayerGrads), _VP, _VP, _SZ, _VP]),
     "astk_conv_out_amax": (C.c_void_p, [C.POINTER(CnnDesc), _VP, _SZ]),
-    "astk_conv_debug_preact": (C.c_int, [C.POINTER(CnnDesc), _VP, _SZ, _I, _VP, _VP]),
-    "astk_conv_debug_kill_units": (C.c_int, [_VP, _I]),
     # the exchange callback is passed as an opaque pointer (a ctypes CFUNCTYPE instance converts itself)
     "astk_conv_bn_relu_fwd_sync": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(CnnLayerParams), _VP, _VP, _VP, _VP, _SZ, _I, _VP, _VP, _I, _VP]),
     "astk_conv_bn_relu_bwd_sync": (C.c_int, [C.POINTER(CnnDesc), C.POINTER(CnnLayerParams), C.POINTER(CnnLayerGrads), _VP, _VP, _SZ, _VP, _VP,
@@ -134,6 +141,7 @@ SIGNATURES = {
     "astk_zero_frames": (C.c_int, [_VP, _I, _I, _I, _VP, C.c_double, _U64, _U64, _VP]),
     "astk_zero_frames_draws": (C.c_int, [_I, _I, _VP, C.c_double, _U64, _U64, _VP, _I, _VP, _VP]),
     "astk_persist_status_snapshot": (C.c_int, [_VP, _VP]),
+    "astk_persist_status_merge": (C.c_int, [_VP, _VP]),
     "astk_persist_status": (C.c_int, [C.POINTER(C.c_uint), _I]),
     "astk_device_cu_count": (C.c_int, []),
     "astk_lstm_stack_path": (C.c_int, [C.POINTER(LstmStackDesc)]),
@@ -142,7 +150,15 @@ SIGNATURES = {
     "astk_prof_end": (C.c_int, [C.POINTER(C.c_double)]),
 }
 
+# exported by libastk_test.so only (the #ifdef ASTK_TEST_HOOKS sections of include/astk.h)
+TEST_HOOK_SIGNATURES = {
+    "astk_debug_set_amax_generation": (C.c_int, [C.c_uint]),
+    "astk_conv_debug_preact": (C.c_int, [C.POINTER(CnnDesc), _VP, _SZ, _I, _VP, _VP]),
+    "astk_conv_debug_kill_units": (C.c_int, [_VP, _I]),
+}
+
 _lib = None
+_test_lib = None
 
 
 class AstkError(RuntimeError):
@@ -158,12 +174,39 @@ def load():
         raise AstkError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(there is no CPU or PyTorch fallback for the compute path)")
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    _bind(lib, SIGNATURES)
+    _lib = lib
+    return lib
+
+
+def _bind(lib, sigs):
+    for name, (res, args) in sigs.items():
         fn = getattr(lib, name)          # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
-    return lib
+
+
+class load_test_hooks:
+    """Context manager for the tests that need the instrumented build: inside it load() returns libastk_test.so (the same sources
+    compiled with -DASTK_TEST_HOOKS, which adds the astk_conv_debug_* / astk_debug_* entry points), so a model built and run inside
+    the block executes on the instrumented library.  The product library exports none of those symbols."""
+
+    def __enter__(self):
+        global _lib, _test_lib
+        if _test_lib is None:
+            if not os.path.exists(TEST_LIB_PATH):
+                raise AstkError(f"{TEST_LIB_PATH} not found: ast_amd/csrc/build.sh builds it next to libastk.so")
+            t = C.CDLL(TEST_LIB_PATH)
+            _bind(t, SIGNATURES)
+            _bind(t, TEST_HOOK_SIGNATURES)
+            _test_lib = t
+        self.prev, _lib = _lib, _test_lib
+        return _test_lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
 
 
 def check(rc):

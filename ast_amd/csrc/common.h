@@ -254,13 +254,23 @@ void gemm_amax_reserve(int n, unsigned long long** slots, unsigned* gen, hipStre
 // A matrix whose entries are bounded by construction (LSTM outputs: |h| < 1, times a dropout scale) needs no pass either: a handle to
 // a constant maximum `bound` (a power of two).  Cached per device; the first use of a bound enqueues its one-word initialisation on s.
 const unsigned long long* gemm_amax_bound(float bound, hipStream_t s);
+// Called by the first op of a train step (no maximum handle is live there): restarts the generation count of the maximum slots when
+// it comes within reach of its 32-bit limit (see next_amax_gen in gemm.hip).
+void gemm_amax_step_boundary(hipStream_t s);
 // Kernels that WRITE a matrix a later GEMM reads can take its maximum on the way (amax_emit_block below): the slot is 16 64-bit words
 // in the caller's workspace, zeroed before the producing kernel runs (the generation half of the word stays 0), and is handed to the
 // GEMM with with_amax_a / with_amax_b like any other handle.
 struct AmaxMatrix { const float* p; long rows, ld; int inner; };
 void gemm_amax_many(const AmaxMatrix* m, int n, const unsigned long long** out, hipStream_t s);     // several matrices, one launch
-int low_precision_gemms();      // the mode set by astk_set_low_precision_gemms
-int gemm_precision_mode();      // astk_set_gemm_precision: 0 fp16x2, 1 bf16x3, 2 f32
+int low_precision_gemms();      // fp16-operand mode in force for this thread's launches (descriptor, else astk_set_low_precision_gemms)
+int gemm_precision_mode();      // arithmetic in force for this thread's launches: 0 fp16x2, 1 bf16x3, 2 f32 (descriptor, else the process default)
+// The arithmetic a descriptor asks for (ASTK_PREC_* / ASTK_OPERANDS_*; 0 = process default), in force for the launches this thread makes
+// while the scope lives.  Every C-ABI entry point that takes a descriptor opens one.
+struct PrecScope {
+  PrecScope(int precision, int operands);
+  ~PrecScope();
+  int prev_p, prev_l;
+};
 // Scoped cap on the co-resident GEMM workgroups per CU for launches made by this thread (0 = none): work that is meant to run
 // BESIDE a persistent recurrence kernel must leave registers free on every CU, or that kernel cannot become resident until the
 // stream-K workgroups (which live for the whole launch) have finished.

@@ -477,7 +477,8 @@ __global__ void k_bn_param_grads(const double* __restrict__ stat, int C, float* 
   dbeta[c] += (float)stat[c];
 }
 
-// ---- test instrumentation (tests/test_gpu_model.py: the batch-permutation property): the post-BatchNorm pre-activations of a layer,
+#ifdef ASTK_TEST_HOOKS
+// ---- test instrumentation, libastk_test.so only (tests/test_gpu_model.py: the batch-permutation property): the post-BatchNorm pre-activations of a layer,
 // and a list of units whose upstream gradient is dropped by the next backward passes.  Two valid float32 evaluations of the same
 // batch (another row order) can differ in the SIGN of a pre-activation that lies within rounding of the ReLU kink; the test names
 // those units and checks that nothing else differs.
@@ -495,6 +496,7 @@ __global__ void k_kill_units(float* __restrict__ G, const int32_t* __restrict__ 
 }
 const int32_t* g_kill_units = nullptr;
 int g_kill_n = 0;
+#endif
 
 inline unsigned gridn(size_t n) {
   size_t b = (n + 255) / 256;
@@ -550,6 +552,9 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
                                void* ws, size_t ws_bytes, int train, astk_stat_exchange_fn exchange, void* user, int world,
                                void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  ASTK_CHECK(d, "conv_bn_relu_fwd: null descriptor");
+  PrecScope prec_scope(d->precision, d->gemm_operands);
+  gemm_amax_step_boundary(s);         // the first op of a step: no operand-maximum handle is live here
   ASTK_CHECK(world >= 1, "conv_bn_relu_fwd: world %d", world);
   if (world == 1 || d->no_bn) exchange = nullptr;
   CnnPlan P;
@@ -623,6 +628,7 @@ const void* astk_conv_out_amax(const astk_cnn_desc* d, void* ws, size_t ws_bytes
   return P.a_out;
 }
 
+#ifdef ASTK_TEST_HOOKS
 int astk_conv_debug_preact(const astk_cnn_desc* d, void* ws, size_t ws_bytes, int layer, float* out, void* stream) {
   CnnPlan P;
   ASTK_TRY(make_plan(d, ws, P));
@@ -638,6 +644,7 @@ int astk_conv_debug_kill_units(const int32_t* units, int n) {
   g_kill_n = n > 0 && units ? n : 0;
   return 0;
 }
+#endif
 
 int astk_conv_bn_relu_bwd(const astk_cnn_desc* d, const astk_cnn_layer_params* L, const astk_cnn_layer_grads* Gr, float* d_out,
                           void* ws, size_t ws_bytes, void* stream) {
@@ -647,6 +654,8 @@ int astk_conv_bn_relu_bwd(const astk_cnn_desc* d, const astk_cnn_layer_params* L
 int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_params* L, const astk_cnn_layer_grads* Gr, float* d_out,
                                void* ws, size_t ws_bytes, astk_stat_exchange_fn exchange, void* user, int world, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  ASTK_CHECK(d, "conv_bn_relu_bwd: null descriptor");
+  PrecScope prec_scope(d->precision, d->gemm_operands);
   ASTK_CHECK(world >= 1, "conv_bn_relu_bwd: world %d", world);
   if (world == 1 || d->no_bn) exchange = nullptr;      // (no statistics to exchange without BatchNorm)
   CnnPlan P;
@@ -662,10 +671,12 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
   }
   for (int i = P.n - 1; i >= 0; --i) {
     const int C = P.Cn[i], rows = P.rows[i];
+#ifdef ASTK_TEST_HOOKS
     if (g_kill_n > 0) {      // test instrumentation (astk_conv_debug_kill_units): drop the upstream gradient of the listed units
       hipLaunchKernelGGL(k_kill_units, dim3(cdiv(g_kill_n, 256)), dim3(256), 0, s, P.G, g_kill_units, g_kill_n, i, rows, C);
       ASTK_LAUNCH_CHECK();
     }
+#endif
     // ---- ReLU + BatchNorm backward: G (grad wrt post-ReLU) -> DY[i] (grad wrt raw conv output)
     if (i == P.n - 1) ASTK_TRY(fill_zero(P.stat[0], P.zero_bwd_bytes, s));   // statistics and dWr scratch of every layer
     hipLaunchKernelGGL(k_bn_bwd_stats, colreduce_grid(rows, C), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], rows, C, P.stat[i]);

@@ -9,6 +9,7 @@
 // step: the per-step data-path gradients (dz, d_pre, dq, ...) are saved and every dW is one batched TN GEMM
 // over S*B rows after the loop; d_enc_states is one batched GEMM over the saved (alpha, ds).
 #include "common.h"
+#include <mutex>
 #include "decoder_wide.h"
 
 namespace astk {
@@ -84,6 +85,27 @@ struct DecPlan {
   void* attn_ws;
   size_t bytes;
 };
+
+// Which kernel path a forward call took on a workspace (diagnostics only, never read by a kernel): the path and the workspace carve are
+// re-derived from the shape AND the environment (ASTK_DEC_PERSIST / ASTK_DEC_WIDE) at every call, so a backward call made under another
+// environment than its forward call would read the saved activations at shifted offsets without any error.  The forward records
+// (workspace, path), the backward refuses a workspace whose record differs.
+struct PathRecord { const void* ws; int path; };
+static std::mutex g_path_mu;
+static PathRecord g_path_ring[64];
+static unsigned g_path_next = 0;
+static void path_record(const void* ws, int path) {
+  std::lock_guard<std::mutex> lock(g_path_mu);
+  for (auto& r : g_path_ring)
+    if (r.ws == ws) { r.path = path; return; }
+  g_path_ring[g_path_next++ % 64] = PathRecord{ws, path};
+}
+static int path_lookup(const void* ws) {      // -1: no forward call recorded for this workspace
+  std::lock_guard<std::mutex> lock(g_path_mu);
+  for (auto& r : g_path_ring)
+    if (r.ws == ws) return r.path;
+  return -1;
+}
 
 int make_plan(const astk_decoder_desc* d, void* ws, DecPlan& P) {
   ASTK_CHECK(d && d->B > 0 && d->L >= 2 && d->T > 0 && d->V > 1, "decoder: bad dims");
@@ -227,7 +249,7 @@ __global__ __launch_bounds__(256) void k_softmax_ce(int V, long ld, float* logit
   __syncthreads();
   sum = sv[0] + sv[1] + sv[2] + sv[3];
   const float lse = mx + logf(sum);
- int t = targets[(long)brow * t_stride + step];
+  int t = targets[(long)brow * t_stride + step];
   const bool ignore = t < 0;                      // ignore_label = -1 never occurs on this path (PAD is 0)
   t = t < 0 ? 0 : (t >= V ? V - 1 : t);
   const float w = ignore ? 0.f : (cw ? cw[t] : 1.f);
@@ -438,6 +460,8 @@ int astk_decoder_fwd_ex(const astk_decoder_desc* d, const astk_decoder_params* p
                         const int32_t* y, const int32_t* use_truth, const float* emb_mask, const float* rnn_masks, const float* out_mask,
                         const int32_t* targets, float* loss, int32_t* pred, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  ASTK_CHECK(d, "decoder_fwd: null descriptor");
+  PrecScope prec_scope(d->precision, d->gemm_operands);
   {
     SplitPlan sp;
     ASTK_TRY(make_split(d, ws, sp));
@@ -490,6 +514,7 @@ int astk_decoder_fwd_ex(const astk_decoder_desc* d, const astk_decoder_params* p
     int ns = 1, ch = 1;
     // (dropout on the logits is not part of the persistent loop's CE role: per-launch loop)
     const bool persist = !out_mask && decoder_persist_applicable(d, &ns, &ch);
+    path_record(ws, persist ? 1 : ((!out_mask && decoder_wide_applicable(d, nullptr, nullptr)) ? 2 : 0));
     if (!persist) ASTK_TRY(attn_ws_init(P.attn_ws, B, P.T, H, s));   // the persistent loop has its own counters
     if (persist) {
       DecPersistBuffers bf;
@@ -619,6 +644,8 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
                               void* stream) {
   hipStream_t s = (hipStream_t)stream;
   (void)c0; (void)h0; (void)y;
+  ASTK_CHECK(d, "decoder_bwd: null descriptor");
+  PrecScope prec_scope(d->precision, d->gemm_operands);
   ASTK_CHECK(phase == ASTK_DEC_BWD_ALL || phase == ASTK_DEC_BWD_CHAIN || phase == ASTK_DEC_BWD_PARAMS, "decoder_bwd: bad phase %d", phase);
   {
     SplitPlan sp;
@@ -651,7 +678,12 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
   int ns_ = 1, ch_ = 1;
   const bool persist = !out_mask && decoder_persist_applicable(d, &ns_, &ch_);      // (the forward pass took the same decision)
   const bool b6s = persist && decoder_persist_b6_split(d);
-  const bool wide_b = !persist && decoder_wide_applicable(d, nullptr, nullptr);     // the whole reversed loop in one launch (decoder_wide.hip)
+  const bool wide_b = !persist && !out_mask && decoder_wide_applicable(d, nullptr, nullptr);     // the whole reversed loop in one launch (decoder_wide.hip)
+  {
+    const int fwd_path = path_lookup(ws), bwd_path = persist ? 1 : (wide_b ? 2 : 0);
+    ASTK_CHECK(fwd_path < 0 || fwd_path == bwd_path, "decoder_bwd: the forward call on this workspace took kernel path %d, this call would take %d "
+               "(ASTK_DEC_PERSIST / ASTK_DEC_WIDE changed between the two calls?)", fwd_path, bwd_path);
+  }
   if (do_chain) {
   // transposed weights for the data-path products (dY W as row-panel NT products)
   {
@@ -850,6 +882,8 @@ int astk_decoder_step_infer(const astk_decoder_desc* d, const astk_decoder_param
                             const int32_t* tokens, float* logits, float* alpha, int32_t* argmax, void* ws, size_t ws_bytes,
                             void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  ASTK_CHECK(d, "decoder_step_infer: null descriptor");
+  PrecScope prec_scope(d->precision, d->gemm_operands);
   DecPlan P;
   ASTK_TRY(make_plan(d, ws, P));
   ASTK_CHECK(ws && ws_bytes >= P.bytes, "decoder_step_infer: workspace too small");

@@ -957,19 +957,34 @@ static int gemm_prepare(int layout, const GemmArgs& g, GemmArgs& a, bool& twolvl
 
 static int g_lowp_mode = 0;
 static std::atomic<double> g_small_flops{getenv("ASTK_GEMM_X3_BELOW") ? atof(getenv("ASTK_GEMM_X3_BELOW")) : 3e9};
-int low_precision_gemms() { return g_lowp_mode; }
+// Per-call arithmetic (astk_*_desc.precision / .gemm_operands, astk_gemm_f32_ex): the entry points open a PrecScope, the launches of
+// this thread inside it use the descriptor's choice; outside a scope (or with ASTK_PREC_DEFAULT) the process-wide default applies.
+static thread_local int tl_prec = -1;       // GemmPrec, or -1 = process default
+static thread_local int tl_lowp = -1;       // 0 / 1, or -1 = process default
+int low_precision_gemms() { return tl_lowp >= 0 ? tl_lowp : g_lowp_mode; }
 static thread_local int tl_wg_cap = 0;
 GemmWgCap::GemmWgCap(int per_cu) : prev(tl_wg_cap) { tl_wg_cap = per_cu; }
 GemmWgCap::~GemmWgCap() { tl_wg_cap = prev; }
 
-// operand precision of the f32-accurate products: fp16x2 (scaled two-term fp16 split) unless ASTK_GEMM_PREC = bf16x3 (three-term bf16
-// split) or f32 (exact f32 MFMA chain) is in the environment at load time, or astk_set_gemm_precision() has been called since
+// operand precision of the f32-accurate products.  Process default: bf16x3 (three-term bf16 split: every f32 operand value is represented
+// EXACTLY, f32 exponent range, products exact to 2^-26) -- the reference computes in float32 (seq2seq.py:154,302,420), and this is the
+// fastest scheme here that is at least as accurate as an f32 fma chain on ANY data.  fp16x2 (two scaled fp16 terms: 22 bits per operand
+// value, and only for values within 2^-17 of the operand's maximum) is faster but narrower: opt-in only (ASTK_GEMM_PREC=fp16x2 in the
+// environment at load time, astk_set_gemm_precision(0), or a descriptor's precision field); f32 = the exact f32 MFMA chain.
 static int prec_from_env() {
   const char* e = getenv("ASTK_GEMM_PREC");
-  return !e ? PREC_F16X2 : !strcmp(e, "f32") ? PREC_F32 : !strcmp(e, "bf16x3") ? PREC_BF16X3 : PREC_F16X2;
+  return !e ? PREC_BF16X3 : !strcmp(e, "f32") ? PREC_F32 : !strcmp(e, "fp16x2") ? PREC_F16X2 : PREC_BF16X3;
 }
 static std::atomic<int> g_prec{prec_from_env()};
-static int default_prec() { return g_prec.load(std::memory_order_relaxed); }
+static int default_prec() { return tl_prec >= 0 ? tl_prec : g_prec.load(std::memory_order_relaxed); }
+PrecScope::PrecScope(int precision, int operands) : prev_p(tl_prec), prev_l(tl_lowp) {
+  if (precision == ASTK_PREC_FP16X2) tl_prec = PREC_F16X2;
+  else if (precision == ASTK_PREC_BF16X3) tl_prec = PREC_BF16X3;
+  else if (precision == ASTK_PREC_F32) tl_prec = PREC_F32;
+  if (operands == ASTK_OPERANDS_F32) tl_lowp = 0;
+  else if (operands == ASTK_OPERANDS_FP16) tl_lowp = 1;
+}
+PrecScope::~PrecScope() { tl_prec = prev_p; tl_lowp = prev_l; }
 int gemm_precision_mode() { const int p = default_prec(); return p == PREC_F32 ? 2 : (p == PREC_BF16X3 ? 1 : 0); }
 static unsigned long long* amax_ring() {
   static unsigned long long* ring = nullptr;
@@ -984,16 +999,30 @@ static std::atomic<unsigned> g_amax_counter{1};
 // STREAM (ordered behind every launch that still reads an old word, in front of every pass that writes a new one) and counting
 // restarts at 1.  Like the ring itself this relies on all GEMM launches of a process being ordered on one stream at a time (the
 // opt-in side-stream overlap of ast_amd/seq2seq.py keeps its launches on bf16x3 operands, which use no slots: GemmWgCap).
+// The restart zeroes the callers' handles too (gemm_amax / gemm_amax_reserve: their words carry old, large generations that would
+// outrank every new one), so it must not fall between a caller taking a handle and the launches that read it: ops that hold handles
+// across launches call gemm_amax_step_boundary() where none is live (the first op of a train step), which restarts EARLY, at
+// AMAX_GEN_SOFT; the hard limit inside next_amax_gen only serves processes that never reach such a boundary (plain astk_gemm_f32
+// users, which hold no handles).
 constexpr unsigned AMAX_GEN_WRAP = 0xFFFFFF00u;
+constexpr unsigned AMAX_GEN_SOFT = 0xFFF00000u;       // ~1M generations (tens of thousands of steps) in front of the hard limit
 static std::mutex g_amax_wrap_mutex;
+static void amax_restart_locked(hipStream_t s) {
+  unsigned long long* ring = nullptr;
+  if (hipGetSymbolAddress((void**)&ring, HIP_SYMBOL(g_amax_ring)) == hipSuccess && ring) (void)hipMemsetAsync(ring, 0, sizeof(unsigned long long) * AMAX_SLOTS, s);
+  g_amax_counter.store(2);
+}
+void gemm_amax_step_boundary(hipStream_t s) {
+  if (g_amax_counter.load(std::memory_order_relaxed) < AMAX_GEN_SOFT) return;
+  std::lock_guard<std::mutex> lock(g_amax_wrap_mutex);
+  if (g_amax_counter.load() >= AMAX_GEN_SOFT) amax_restart_locked(s);
+}
 static unsigned next_amax_gen(hipStream_t s) {
   unsigned gen = g_amax_counter.fetch_add(1);
   if (gen < AMAX_GEN_WRAP) return gen;
   std::lock_guard<std::mutex> lock(g_amax_wrap_mutex);
   if (g_amax_counter.load() >= AMAX_GEN_WRAP) {      // first thread to get here restarts the count
-    unsigned long long* ring = nullptr;
-    if (hipGetSymbolAddress((void**)&ring, HIP_SYMBOL(g_amax_ring)) == hipSuccess && ring) (void)hipMemsetAsync(ring, 0, sizeof(unsigned long long) * AMAX_SLOTS, s);
-    g_amax_counter.store(2);
+    amax_restart_locked(s);
     return 1;
   }
   return g_amax_counter.fetch_add(1);
@@ -1043,7 +1072,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   static const int force_tl = getenv("ASTK_GEMM_TILE") ? atoi(getenv("ASTK_GEMM_TILE")) : 0;
   // operand scheme of the launch (default_prec: fp16x2 unless the environment asks for bf16x3 or f32)
   int prec = default_prec();
-  if (g_lowp_mode != 0 && n > 0) {        // fp16 operands only if every product of the launch is marked eligible by its caller
+  if (low_precision_gemms() != 0 && n > 0) {        // fp16 operands only if every product of the launch is marked eligible by its caller
     bool all = true;
     for (int i = 0; i < n; ++i) all = all && list[i].lowp != 0;
     if (all) prec = PREC_F16;
@@ -1247,7 +1276,6 @@ void gemm_amax_reserve(int n, unsigned long long** slots, unsigned* gen, hipStre
 
 // constant maxima (bounded matrices): 8 slots of 16 words; word 0 of a slot holds the bound, the others stay 0
 __device__ unsigned long long g_amax_bounds[8 * AMAX_SLOT_WORDS];
-__global__ void k_set_u64(unsigned long long* p, unsigned long long v) { *p = v; }
 const unsigned long long* gemm_amax_bound(float bound, hipStream_t s) {
   if (default_prec() != PREC_F16X2 && low_precision_gemms() == 0) return nullptr;
   static std::mutex mu;
@@ -1262,7 +1290,11 @@ const unsigned long long* gemm_amax_bound(float bound, hipStream_t s) {
     if (cached[dev][i] == 0.f) {
       unsigned bits;
       memcpy(&bits, &bound, 4);
-      hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, s, base + i * AMAX_SLOT_WORDS, (unsigned long long)bits);
+      // synchronous (once per bound and process): the handle is cached for every later caller on ANY stream, so its one-word
+      // initialisation must not be ordered on the first caller's stream only
+      const unsigned long long word = (unsigned long long)bits;
+      if (hipMemcpy(base + i * AMAX_SLOT_WORDS, &word, sizeof(word), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+      (void)s;
       cached[dev][i] = bound;
       return base + i * AMAX_SLOT_WORDS;
     }
@@ -1287,12 +1319,18 @@ extern "C" int astk_set_low_precision_gemms(int mode) {
 extern "C" int astk_get_low_precision_gemms(void) { return astk::g_lowp_mode; }
 extern "C" int astk_set_gemm_precision(int mode) {
   if (mode < 0 || mode > 2) { astk::set_error("set_gemm_precision: mode must be 0 (fp16x2), 1 (bf16x3) or 2 (f32)"); return -1; }
-  const int prev = astk::gemm_precision_mode();
+  const int p = astk::g_prec.load();
+  const int prev = p == astk::PREC_F32 ? 2 : (p == astk::PREC_BF16X3 ? 1 : 0);
   astk::g_prec.store(mode == 2 ? astk::PREC_F32 : (mode == 1 ? astk::PREC_BF16X3 : astk::PREC_F16X2));
   return prev;
 }
-extern "C" int astk_get_gemm_precision(void) { return astk::gemm_precision_mode(); }
+extern "C" int astk_get_gemm_precision(void) {
+  const int p = astk::g_prec.load();
+  return p == astk::PREC_F32 ? 2 : (p == astk::PREC_BF16X3 ? 1 : 0);
+}
+#ifdef ASTK_TEST_HOOKS
 extern "C" int astk_debug_set_amax_generation(unsigned gen) { astk::g_amax_counter.store(gen ? gen : 1u); return 0; }
+#endif
 extern "C" double astk_set_gemm_bf16_split_below(double flops) { return astk::g_small_flops.exchange(flops < 0 ? 0.0 : flops); }
 
 namespace astk {

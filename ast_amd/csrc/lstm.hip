@@ -144,6 +144,8 @@ size_t astk_lstm_stack_workspace_bytes(const astk_lstm_stack_desc* d) {
 int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* prm, const float* x, const float* masks,
                         float* enc_states, float* cT, float* hT, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  ASTK_CHECK(d, "lstm_stack_fwd: null descriptor");
+  PrecScope prec_scope(d->precision, d->gemm_operands);
   LstmPlan P;
   ASTK_TRY(make_plan(d, ws, masks != nullptr, P));
   const size_t need = astk_lstm_stack_workspace_bytes(d);
@@ -285,6 +287,8 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
                            size_t ws_bytes, void* stream, void* recurrence_stream) {
   hipStream_t s = (hipStream_t)stream;
   hipStream_t sr = recurrence_stream ? (hipStream_t)recurrence_stream : s;
+  ASTK_CHECK(d, "lstm_stack_bwd: null descriptor");
+  PrecScope prec_scope(d->precision, d->gemm_operands);
   LstmPlan P;
   ASTK_TRY(make_plan(d, ws, masks != nullptr, P));
   const size_t need = astk_lstm_stack_workspace_bytes(d);

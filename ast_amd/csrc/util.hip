@@ -84,6 +84,7 @@ namespace {
 
 __global__ void k_status_snapshot(const unsigned* status, float* dst) { *dst = (float)(*status); }
 __global__ void k_status_reset(unsigned* status) { *status = 0u; }
+__global__ void k_status_merge(unsigned* status, const float* summed) { if (*summed != 0.f) atomicOr(status, 16u); }
 
 __global__ void k_copy2d(float* dst, long ldd, const float* src, long lds, int rows, int cols, int cols_dst) {
   const long n = (long)rows * cols_dst;
@@ -583,12 +584,18 @@ int astk_colsum_add_f32(float* dst, const float* src, long lds, int rows, int co
   return colsum_add_f32(dst, src, lds, rows, cols, (hipStream_t)stream);
 }
 
-int astk_gemm_f32(int layout, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
-                  const float* bias, int mode, int ksplit, int batch, long sA, long sB, long sC, void* stream) {
+int astk_gemm_f32_ex(int layout, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                     const float* bias, int mode, int ksplit, int batch, long sA, long sB, long sC, int precision, void* stream) {
+  ASTK_CHECK(precision >= ASTK_PREC_DEFAULT && precision <= ASTK_PREC_F32, "gemm: precision must be one of ASTK_PREC_*");
+  PrecScope ps(precision, ASTK_OPERANDS_DEFAULT);
   GemmArgs g = gemm_args(M, N, K, mat(A, lda), mat(B, ldb), C, ldc, bias, mode, ksplit);
   g.batch = batch < 1 ? 1 : batch;
   g.sA = sA; g.sB = sB; g.sC = sC;
   return gemm_launch(layout, g, (hipStream_t)stream);
+}
+int astk_gemm_f32(int layout, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                  const float* bias, int mode, int ksplit, int batch, long sA, long sB, long sC, void* stream) {
+  return astk_gemm_f32_ex(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, mode, ksplit, batch, sA, sB, sC, ASTK_PREC_DEFAULT, stream);
 }
 
 int astk_persist_status_snapshot(float* dst, void* stream) {
@@ -596,6 +603,15 @@ int astk_persist_status_snapshot(float* dst, void* stream) {
   unsigned* st = persist_status_ptr();
   ASTK_CHECK(st, "persist_status: no status word");
   hipLaunchKernelGGL(k_status_snapshot, dim3(1), dim3(1), 0, (hipStream_t)stream, st, dst);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int astk_persist_status_merge(const float* summed, void* stream) {
+  ASTK_CHECK(summed, "persist_status_merge: null pointer");
+  unsigned* st = persist_status_ptr();
+  ASTK_CHECK(st, "persist_status: no status word");
+  hipLaunchKernelGGL(k_status_merge, dim3(1), dim3(1), 0, (hipStream_t)stream, st, summed);
   ASTK_LAUNCH_CHECK();
   return 0;
 }

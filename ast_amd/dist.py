@@ -26,14 +26,25 @@ def local_rank():
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init(backend=None):
-    """Initialises torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
+# persistent grids of the shipped models: encoder recurrences (h/16) x ceil(B/16) x cells = 192 workgroups at batch 32, up to 224 for the
+# widths the launchers accept beside a collective; the decoder loop takes every CU but never overlaps a collective (seq2seq.py)
+DEFAULT_RECURRENCE_CUS = 224
+channel_cap = None          # NCCL_MAX_NCHANNELS in force after init("nccl")
+
+
+def init(backend=None, recurrence_cus=None):
+    """Initialises torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_*).  For the RCCL backend the channel
+    count is capped FIRST (reserve_cus_for_recurrence) so that a collective waiting for a late peer cannot keep the next step's
+    persistent recurrence grid from becoming resident: training (train.py -> NN) and bench.py run the same configuration.
+    `recurrence_cus`: the largest persistent grid that can run beside a collective (default 224)."""
+    global channel_cap
     if int(os.environ.get("WORLD_SIZE", "1")) <= 1 or td.is_initialized():
         return
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
+        channel_cap = reserve_cus_for_recurrence(DEFAULT_RECURRENCE_CUS if recurrence_cus is None else recurrence_cus)
         torch.cuda.set_device(local_rank())
     # rank 0 alone runs the dev pass and writes checkpoints between epochs while the others wait at a barrier (train.py): the
     # collective watchdog must outlast a dev decode
@@ -86,11 +97,19 @@ class GradBuckets:
     waits for everything and applies the 1/world mean.  xGMI is point-to-point and a 53 MB all-reduce is ~1 ms of an ~9.5 ms
     step: behind the encoder / CNN backward it costs nothing.  Numerically identical to `allreduce_grads` (same sums)."""
 
-    def __init__(self, arena, param_groups, defer_scale=False):
+    def __init__(self, arena, param_groups, defer_scale=False, status_fn=None):
         # param_groups: ordered {bucket name: [param names]}; every group must be one contiguous arena range.
         # defer_scale: finish() leaves the SUM in the arena and returns 1/world for the optimizer kernels to apply on the fly.
+        # status_fn(tail): writes this rank's abort status (0 = healthy) into the one-float tensor `tail` on the current stream.  The
+        #   tail sits directly behind the LAST arena range and rides in that range's all-reduce, so after the exchange every rank holds
+        #   the SUM of all ranks' status words: a persistent kernel that timed out on one rank (its results are garbage) makes EVERY
+        #   rank skip the update of that step and raise at the same loss read-back, instead of the healthy ranks training on and then
+        #   sitting in the next all-reduce until the watchdog (round-3 review, item 6).  Default: the library's sticky status word
+        #   (astk_persist_status_snapshot) on a GPU, nothing on the CPU.
         self.arena = arena
         self.defer_scale = defer_scale
+        self.status_fn = status_fn if status_fn is not None else _library_status
+        self.status_sum = arena.status_tail if getattr(arena, "status_tail", None) is not None else None
         self.ranges = {}
         covered = []
         for gname, names in param_groups.items():
@@ -110,7 +129,12 @@ class GradBuckets:
         if not is_distributed() or name in self.pending or name not in self.ranges:
             return
         lo, hi = self.ranges[name]
-        self.pending[name] = td.all_reduce(self.arena.grad[lo:hi], op=td.ReduceOp.SUM, async_op=True)
+        buf = self.arena.grad[lo:hi]
+        if hi == self.arena.size and self.status_sum is not None:
+            # the range that ends the arena carries the status tail: [gradients | status | 3 pad floats] in one all-reduce
+            self.status_fn(self.status_sum)
+            buf = self.arena.grad_full[lo:hi + self.arena.TAIL]
+        self.pending[name] = td.all_reduce(buf, op=td.ReduceOp.SUM, async_op=True)
 
     def finish(self, arena=None):
         if not is_distributed():
@@ -121,9 +145,39 @@ class GradBuckets:
         for work in self.pending.values():
             work.wait()
         self.pending = {}
+        if self.status_sum is not None and self.status_sum.is_cuda:
+            # a non-zero SUM marks the step as aborted in this rank's sticky status word too (bit 16): the update kernels that follow
+            # skip on every rank alike, and every rank's next loss read-back raises (seq2seq.raise_if_aborted)
+            import ctypes as C
+            from . import _lib
+            _lib.check(_lib.load().astk_persist_status_merge(C.c_void_p(self.status_sum.data_ptr()),
+                                                             C.c_void_p(torch.cuda.current_stream(self.status_sum.device).cuda_stream)))
         if self.defer_scale:
             return 1.0 / world_size()
         self.arena.grad.mul_(1.0 / world_size())
+
+
+def _library_status(tail):
+    """This rank's sticky status word of the persistent kernels, as a float, into `tail` on the current stream (GPU only)."""
+    if tail.is_cuda:
+        import ctypes as C
+        from . import _lib
+        _lib.check(_lib.load().astk_persist_status_snapshot(C.c_void_p(tail.data_ptr()), C.c_void_p(torch.cuda.current_stream(tail.device).cuda_stream)))
+    else:
+        tail.zero_()
+
+
+def raise_if_any_rank_aborted(buckets, where="train step"):
+    """Host-side check of the all-reduced status word (synchronises; the GPU train loop does not need it -- the merged word travels
+    through astk_persist_status_merge into the sticky word every rank reads next to its loss -- but CPU tests and callers without the
+    loss read-back do): raises on EVERY rank when any rank reported an abort in the step just exchanged."""
+    if buckets is None or buckets.status_sum is None:
+        return
+    v = float(buckets.status_sum[0])
+    if v != 0.0:
+        from . import _lib
+        raise _lib.AstkError(f"{where}: a persistent kernel timed out on at least one rank (summed status word {v:g}); the step's update "
+                             "was skipped on every rank")
 
 
 def make_grad_buckets(model):

@@ -40,6 +40,12 @@ class _Layerwise:
         g[0].dWu, g[0].db, g[0].dWl = a.g(n + "/upward/W"), a.g(n + "/upward/b"), a.g(n + "/lateral/W")
         return n, p, g
 
+    def _desc(self, T, B, in_dim, h, nl, nd):
+        """A stack descriptor that carries the model's per-call arithmetic (include/astk.h: precision / gemm_operands)."""
+        d = LstmStackDesc(T, B, in_dim, h, nl, nd)
+        d.precision, d.gemm_operands = _lib.PREC_BY_NAME[self.m.gemm_precision], _lib.OPERANDS_BY_NAME[self.m.gemm_operands]
+        return d
+
     def _ws(self, key, desc):
         lib = _lib.load()
         nbytes = int(lib.astk_lstm_stack_workspace_bytes(C.byref(desc)))
@@ -90,7 +96,7 @@ class LayerNormEncoder(_Layerwise):
         masks = st["enc_masks"]                                   # (nd, nl, T2, B, h) or None
         sv = st["encv"] = {}
         # ---- layer 0: both directions in one call, output (B, T2, nd*h) with direction 1 flipped to frame positions
-        d0 = LstmStackDesc(T2, B, st["feat"], h, 1, nd)
+        d0 = self._desc(T2, B, st["feat"], h, 1, nd)
         p0, g0 = (LstmParams * nd)(), (LstmGrads * nd)()
         for d in range(nd):
             _, p, g = self._cell(d, 0)
@@ -107,7 +113,7 @@ class LayerNormEncoder(_Layerwise):
         sv.update(d0=d0, p0=p0, g0=g0, mk0=mk0, U0=U0)
         # per direction, (B, T2, h) in LOOP-STEP order (direction 1: position p of the flipped half is loop step T2-1-p)
         seq = [V0[:, :, :h], V0[:, :, h:].flip(1)] if nd == 2 else [V0]
-        d1 = LstmStackDesc(T2, B, h, h, 1, 1)
+        d1 = self._desc(T2, B, h, h, 1, 1)
         for l in range(1, nl):
             for d in range(nd):
                 name, p, g = self._cell(d, l)
@@ -175,7 +181,7 @@ class LinearProjEncoder(_Layerwise):
         cur, width = st["xlstm"], st["feat"]
         s = m._stream()
         for l in range(nl):
-            desc = LstmStackDesc(T2, B, width, h, 1, 1)
+            desc = self._desc(T2, B, width, h, 1, 1)
             U = []
             for d in range(nd):
                 _, p, g = self._cell(d, l)

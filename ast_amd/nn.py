@@ -73,12 +73,15 @@ class NN:
         self.get_model()
         # extension key (BASELINE configs[4], "fp16 MFMA GEMMs"): extras.gemm_operands = "fp16" runs the batched products of the CNN
         # layers >= 1 and of the encoder's input projection with fp16 operands / f32 accumulation; default "f32" (f32-accurate products)
+        # extras.gemm_precision = "bf16x3" (library default: exact f32 operands as three bf16 terms) | "f32" (f32-input MFMAs) | "fp16x2"
+        # (two scaled fp16 terms: faster, narrower than float32).  Both go into the op descriptors of THIS model (no process-wide state).
         ops = self.cfg.train.get("extras", {}).get("gemm_operands", "f32")
         if ops not in ("f32", "fp16"):
             raise ValueError("extras.gemm_operands must be 'f32' or 'fp16'")
-        from . import _lib
-        if torch.cuda.is_available():
-            _lib.check(_lib.load().astk_set_low_precision_gemms(1 if ops == "fp16" else 0))
+        prec = self.cfg.train.get("extras", {}).get("gemm_precision")
+        if prec not in (None, "bf16x3", "f32", "fp16x2"):
+            raise ValueError("extras.gemm_precision must be 'bf16x3', 'f32' or 'fp16x2'")
+        self.model.gemm_operands, self.model.gemm_precision = ops, prec
         self.init_optimizer(self.cfg.train["optimizer"])
         if self.cfg.train.get("save_optimizer", False) and self.loaded_from and self.model.arena is not None:
             # extension key: checkpoints also carry the Adam moments, so a resumed run continues instead of re-warming them

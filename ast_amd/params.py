@@ -113,6 +113,8 @@ def init_values(cfg, in_dim, vocab_size=None, seed=0):
 
 
 class ParamArena:
+    TAIL = 4
+
     def __init__(self, shapes, device):
         self.shapes = dict(shapes)
         self.offsets = {}
@@ -124,7 +126,11 @@ class ParamArena:
         self.size = off
         self.device = device
         self.data = torch.zeros(off, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        # the gradient buffer carries TAIL extra floats behind the last parameter: [0] = the abort status word that rides in the last
+        # range's all-reduce under data parallelism (ast_amd.dist.GradBuckets); not a parameter, never seen by cleargrads / the optimizer
+        self.grad_full = torch.zeros(off + self.TAIL, dtype=torch.float32, device=device)
+        self.grad = self.grad_full[:off]
+        self.status_tail = self.grad_full[off:off + 1]
         self.views, self.gviews = {}, {}
         for name, shp in self.shapes.items():
             o, n = self.offsets[name], int(np.prod(shp))

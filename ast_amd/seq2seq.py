@@ -62,11 +62,48 @@ def raise_if_aborted(status, where="train step"):
     RCCL kernels holding CUs, a partitioned device), the kernels drained, and the step's loss and gradients are garbage."""
     mask = int(status)
     if mask:
-        names = [n for b, n in ((1, "encoder forward"), (2, "encoder backward"), (4, "decoder forward"), (8, "decoder backward")) if mask & b]
+        names = [n for b, n in ((1, "encoder forward"), (2, "encoder backward"), (4, "decoder forward"), (8, "decoder backward"),
+                                (16, "reported by a peer rank of the data-parallel job")) if mask & b]
         _lib.load().astk_persist_status(None, 1)          # clear the sticky word: the caller may retry (e.g. with ASTK_*_PERSIST=0)
         raise _lib.AstkError(f"{where}: persistent kernel(s) timed out waiting for a peer workgroup ({', '.join(names)}); the results "
                              "of this step are invalid.  The whole grid must be resident (one workgroup per CU); set "
                              "ASTK_LSTM_PERSIST=0 / ASTK_DEC_PERSIST=0 to use the per-launch kernels on a shared device")
+
+
+def draw_flags_and_targets(yh, teach_ratio, random_out, V, randint, rank=None, world=None, gather=None):
+    """forward_loss's draws from the seeded Python `random` stream in the reference's order (seq2seq.py:431-436, 456-465): per decoder
+    step one teacher-forcing coin (0 < i < L-2), then one draw per target >= 4 of THE BATCH -- above `random_out` the scored target is
+    replaced by randint(4, V + 1), clamped to V - 1 (quirk Q8).  Returns (flags, scored targets of the local rows).
+    Data parallelism: the stream also feeds next epoch's shuffles and must stay IDENTICAL on every rank, but the number of draws depends
+    on the targets -- and the ranks hold different rows.  So every rank makes the draws of the WHOLE global batch, in the row order of
+    the unsharded batch (the loader gives rank r rows r::world: global row b * world + r), and keeps the replacements of its own rows:
+    the `y` of all ranks is gathered first (`gather(yh) -> [yh of rank 0, ..]`; default torch.distributed.all_gather_object)."""
+    from . import dist as adist
+    world = adist.world_size() if world is None else world
+    rank = adist.rank() if rank is None else rank
+    B, L = yh.shape
+    S = L - 1
+    tg = yh.copy()
+    if world > 1:
+        if gather is None:
+            def gather(a):
+                out = [None] * world
+                td_ = __import__("torch.distributed", fromlist=["x"])
+                td_.all_gather_object(out, np.ascontiguousarray(a))
+                return out
+        parts = gather(yh)
+        assert len(parts) == world and all(p.shape == yh.shape for p in parts), "shards of one bucketed batch share (B, L) (dataloader.get_batch)"
+        rows = [(parts[g % world], g // world, g % world == rank) for g in range(B * world)]
+    else:
+        rows = [(yh, b, True) for b in range(B)]
+    flags = []
+    for i in range(S):
+        flags.append(int(random.random() < teach_ratio) if 0 < i < L - 2 else 1)
+        for src, b, mine in rows:
+            if int(src[b, i + 1]) >= 4 and random.random() > random_out:
+                if mine:
+                    tg[b, i + 1] = min(int(randint(4, V + 1)), V - 1)
+    return flags, tg
 
 
 class LossData:
@@ -100,6 +137,8 @@ class LossData:
         return np.asarray(self._checked(), dtype=dtype or np.float32)
 
     def __getattr__(self, name):              # shape / dtype / device / clone() ... of the 0-d tensor
+        if name.startswith("_"):              # (copy / pickle probe dunder names before _pair exists: no recursion)
+            raise AttributeError(name)
         return getattr(self._pair[0], name)
 
 
@@ -206,6 +245,11 @@ class SpeechEncoderDecoder:
         # hardware queues -- and a pairwise concurrency probe does not see it coming.  Off by default for that reason.
         self.overlap_param_grads = os.environ.get("ASTK_OVERLAP_PARAM_GRADS", "0") == "1"
         self.mask_pad_id = None
+        # Arithmetic of the batched products, per model (-> the descriptors' `precision` / `gemm_operands` fields): None = the library's
+        # process-wide default (bf16x3: exact f32 operands on the 16-bit matrix pipe); "bf16x3" | "f32" | "fp16x2" (narrower, opt-in);
+        # gemm_operands "fp16" = single-term fp16 operands for the eligible products (BASELINE configs[4]; reduced precision).
+        self.gemm_precision = None
+        self.gemm_operands = None
 
     # ------------------------------------------------------------------ parameters
     def materialize(self, in_dim, values=None, seed=0):
@@ -324,6 +368,15 @@ class SpeechEncoderDecoder:
         return buf[:n].view(shape)
 
     def _shape_state(self, B, T, D, L):
+        """The descriptors, parameter tables and buffers of one batch shape (cached); the arithmetic the model currently asks for
+        (`gemm_precision`, `gemm_operands`) goes into the descriptors' per-call fields (include/astk.h: ASTK_PREC_* / ASTK_OPERANDS_*)."""
+        st = self._shape_state_cached(B, T, D, L)
+        prec, ops = _lib.PREC_BY_NAME[self.gemm_precision], _lib.OPERANDS_BY_NAME[self.gemm_operands]
+        for k in ("cd", "ld", "dd"):
+            st[k].precision, st[k].gemm_operands = prec, ops
+        return st
+
+    def _shape_state_cached(self, B, T, D, L):
         key = (B, T, D, L)
         st = self._shape_cache.get(key)
         if st is not None:
@@ -617,14 +670,8 @@ class SpeechEncoderDecoder:
             assert not random_out, "inject['use_truth'] bypasses the random stream random_out shares"
         elif random_out:
             yh = (y_host if y_host is not None else y.cpu()).numpy()
-            tg = yh.copy()
             randint = self.inject.get("randint", np.random.randint)      # the reference's draw is the unseeded global xp RNG (quirk Q7)
-            flags = []
-            for i in range(S):
-                flags.append(int(random.random() < teach_ratio) if 0 < i < L - 2 else 1)
-                for b in range(B):
-                    if int(yh[b, i + 1]) >= 4 and random.random() > random_out:
-                        tg[b, i + 1] = min(int(randint(4, self.V + 1)), self.V - 1)
+            flags, tg = draw_flags_and_targets(yh, teach_ratio, random_out, self.V, randint)
             targets = torch.from_numpy(np.ascontiguousarray(tg, dtype=np.int32)).to(self.device)
         else:
             flags = [int(random.random() < teach_ratio) if 0 < i < L - 2 else 1 for i in range(S)]

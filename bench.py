@@ -37,10 +37,14 @@ TRAIN = {"teach_ratio": 0.8, "speech_noise": 0.25, "lr": 1e-3, "l2": 1e-4, "grad
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA dense peak
 MFMA_16BIT_PEAK_TFLOPS = 2500.0  # fp16 / bf16 dense MFMA peak (MI355X_MICROARCH.md; no sparsity)
-PRECISIONS = {0: ("fp16x2", "f32 storage / f32 accumulate, products as fp16x2 splits (two fp16 terms per operand behind a power-of-two scale: 22 significant "
-                            "bits per operand value) in the batched GEMMs and the encoder recurrences; decoder loop, attention, softmax-CE, optimizer in IEEE f32"),
-              1: ("bf16x3", "f32 storage / f32 accumulate, batched GEMMs as bf16x3 splits (24 significant bits), everything else IEEE f32"),
-              2: ("f32", "IEEE f32 products everywhere (f32-input MFMA), f32 accumulate")}
+PRECISIONS = {"fp16x2": "f32 storage / f32 accumulate, products as fp16x2 splits (two fp16 terms per operand behind a power-of-two scale: 22 significant "
+                        "bits per operand value, limited exponent range -- NARROWER than the reference's float32; opt-in) in the batched GEMMs and the "
+                        "encoder recurrences; decoder loop, attention, softmax-CE, optimizer in IEEE f32",
+              "bf16x3": "f32 storage / f32 accumulate; batched GEMMs as bf16x3 splits on the bf16 MFMA pipe (every f32 operand value represented EXACTLY by "
+                        "three bf16 terms, f32 exponent range, six term products, each product exact to 2^-26: >= float32 on any data); encoder "
+                        "recurrences, decoder loop, attention, softmax-CE, optimizer in IEEE f32 (f32-input MFMAs / f32 FMAs)",
+              "f32": "IEEE f32 products everywhere (f32-input MFMA v_mfma_f32_32x32x2_f32 / 16x16x4_f32), f32 accumulate"}
+SCHEME_OF_MODE = {0: "fp16x2", 1: "bf16x3", 2: "f32"}       # astk_get_gemm_precision()
 
 
 def synth_batch(B, T, D, L, V, seed):
@@ -143,7 +147,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-bn", action="store_true", help="N>1: BatchNorm statistics over the global batch (4 extra 5-10 KB all-reduces)")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps with per-kernel HIP-event timing")
-    ap.add_argument("--no-alt-precisions", action="store_true", help="skip the bf16x3 / f32 re-timings of the same step")
+    ap.add_argument("--no-alt-precisions", action="store_true", help="skip the re-timings of the same step under the other two arithmetic schemes")
+    ap.add_argument("--precision", default=None, choices=["bf16x3", "f32", "fp16x2"],
+                    help="arithmetic of the batched products for the headline (default: the library's default, bf16x3 = exact f32 operands "
+                         "as three bf16 terms; f32 = f32-input MFMAs; fp16x2 = two scaled fp16 terms, narrower than float32)")
+    ap.add_argument("--no-also", action="store_true", help="skip the second workload (the shipped es_en_20h model) of the default cfg1 run")
     args = ap.parse_args()
     maybe_self_launch(args, sys.argv[1:])
 
@@ -179,119 +187,165 @@ def main():
             td.init_process_group("nccl", world_size=1, rank=0)
             adist.is_distributed = lambda: True
     lib = _lib.load()
-    B, T, D, L, V = args.batch, args.frames, args.feat, args.tgt_len, MODEL_CFG["rnn_config"]["dec_vocab_size"]
-    cfg = copy.deepcopy(MODEL_CFG)
-    if args.model == "es_en_20h":
-        cfg["rnn_config"]["dec_layers"] = 3          # /root/reference/experiments/es_en_20h/model_cfg.json:12
-    if args.model == "cfg5":                         # BASELINE configs[4]: "BiLSTM-1024" read as the concatenated width (512 per direction)
-        cfg["rnn_config"].update(enc_layers=6, hidden_units=1024, attn_units=1024, dec_vocab_size=8004)
-        V = 8004
-    _lib.check(lib.astk_set_low_precision_gemms(1 if args.gemm_operands == "fp16" else 0))
-    n_dec = cfg["rnn_config"]["dec_layers"]
-    model = SpeechEncoderDecoder(local, cfg).materialize(D, seed=0)       # identical replicas
-    opt = O.Adam(alpha=TRAIN["lr"], beta1=0.9, beta2=0.999, eps=1e-8, amsgrad=True).setup(model)
-    opt.add_hook(O.WeightDecay(TRAIN["l2"]))
-    opt.add_hook(O.GradientClipping(TRAIN["grad_clip"]))
-    if dp:
-        # overlapped exchange: decoder / encoder / CNN gradient ranges are all-reduced as soon as their backward is enqueued
-        model.grad_buckets = adist.make_grad_buckets(model)
-        opt.grad_sync = model.grad_buckets.finish
-        model.rng_seed = (model.rng_seed + 0x9E3779B97F4A7C15 * rank) & 0xFFFFFFFFFFFFFFFF   # per-replica dropout / noise streams
-        if args.sync_bn:
-            model.stat_exchange = adist.StatExchange()
-    random.seed("seed-ast-20h")                                           # same teacher-forcing stream on every rank
-    Xh, yh = synth_batch(B, T, D, L, V, 20 + rank)                        # each rank owns its shard of the global batch
-    X, y = torch.from_numpy(Xh).cuda(), torch.from_numpy(yh).cuda()
-
+    B, T, D, L = args.batch, args.frames, args.feat, args.tgt_len
+    # the headline's arithmetic: the library default (bf16x3) unless --precision names another scheme; it travels in the op descriptors
+    base_scheme = args.precision or SCHEME_OF_MODE[lib.astk_get_gemm_precision()]
+    compute = torch.cuda.Stream()
     # The step runs on a stream of its own, not on the legacy default stream (measured 0.05 ms per step faster; also what the
     # opt-in CU-masked side streams of ast_amd/seq2seq.py need, which synchronise implicitly with stream 0).
-    compute = torch.cuda.Stream()
-    torch.cuda.synchronize()
 
-    def step():
-        with torch.cuda.stream(compute), using_config("train", True):
-            loss = model.forward_loss(X=X, y=y, teach_ratio=TRAIN["teach_ratio"], random_out=0, add_noise=TRAIN["speech_noise"])
-            model.cleargrads()
-            loss.backward()
-            opt.update()
-        return loss
+    def model_cfg(name):
+        cfg = copy.deepcopy(MODEL_CFG)
+        if name == "es_en_20h":
+            cfg["rnn_config"]["dec_layers"] = 3          # /root/reference/experiments/es_en_20h/model_cfg.json:12
+        if name == "cfg5":                               # BASELINE configs[4]: "BiLSTM-1024" read as the concatenated width (512 per direction)
+            cfg["rnn_config"].update(enc_layers=6, hidden_units=1024, attn_units=1024, dec_vocab_size=8004)
+        return cfg
 
     def barrier():
         if dp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        loss = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dp:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
-    loss_val = float(loss)                      # raises AstkError if a persistent kernel timed out (status word next to the loss)
-    assert np.isfinite(loss_val), "loss is not finite"
+    class Workload:
+        """One model + optimizer + resident synthetic batch; step() = the whole train step of SURVEY.md 8(d)."""
+
+        def __init__(self, name):
+            self.name, self.cfg = name, model_cfg(name)
+            self.V = self.cfg["rnn_config"]["dec_vocab_size"]
+            m = self.model = SpeechEncoderDecoder(local, self.cfg).materialize(D, seed=0)       # identical replicas
+            m.gemm_precision = base_scheme
+            m.gemm_operands = args.gemm_operands
+            o = self.opt = O.Adam(alpha=TRAIN["lr"], beta1=0.9, beta2=0.999, eps=1e-8, amsgrad=True).setup(m)
+            o.add_hook(O.WeightDecay(TRAIN["l2"]))
+            o.add_hook(O.GradientClipping(TRAIN["grad_clip"]))
+            if dp:
+                # overlapped exchange: decoder / encoder / CNN gradient ranges are all-reduced as soon as their backward is enqueued
+                m.grad_buckets = adist.make_grad_buckets(m)
+                o.grad_sync = m.grad_buckets.finish
+                m.rng_seed = (m.rng_seed + 0x9E3779B97F4A7C15 * rank) & 0xFFFFFFFFFFFFFFFF   # per-replica dropout / noise streams
+                if args.sync_bn:
+                    m.stat_exchange = adist.StatExchange()
+            random.seed("seed-ast-20h")                                       # same teacher-forcing stream on every rank
+            Xh, yh = synth_batch(B, T, D, L, self.V, 20 + rank)               # each rank owns its shard of the global batch
+            self.X, self.y = torch.from_numpy(Xh).cuda(), torch.from_numpy(yh).cuda()
+            torch.cuda.synchronize()
+
+        def step(self):
+            with torch.cuda.stream(compute), using_config("train", True):
+                loss = self.model.forward_loss(X=self.X, y=self.y, teach_ratio=TRAIN["teach_ratio"], random_out=0, add_noise=TRAIN["speech_noise"])
+                self.model.cleargrads()
+                loss.backward()
+                self.opt.update()
+            return loss
+
+        def timed(self, warmup, steps):
+            """W untimed warm-ups, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+            for _ in range(warmup):
+                loss = self.step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = self.step()
+            barrier()
+            dt = time.perf_counter() - t0
+            if dp:
+                tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+                dt = float(tt.item())
+            lv = float(loss)                    # raises AstkError if a persistent kernel timed out (status word next to the loss)
+            assert np.isfinite(lv), "loss is not finite"
+            return dt, lv
+
+        def profile(self, nsteps):
+            """`nsteps` extra steps with per-kernel HIP-event timing on the launch stream (astk_prof_*): res[] of include/astk.h."""
+            m = self.model
+            # per-kernel figures are taken with every kernel alone on the device: with the opt-in side-stream overlap
+            # (decoder parameter gradients on 64 masked CUs beside the encoder recurrence) those GEMMs would be priced as slow ones
+            overlap, m.overlap_param_grads = m.overlap_param_grads, False
+            lib.astk_prof_begin()
+            for _ in range(nsteps):
+                self.step()
+            torch.cuda.synchronize()
+            m.overlap_param_grads = overlap
+            res = (C.c_double * 24)()
+            lib.astk_prof_end(res)
+            return res
+
+        def describe(self):
+            rc = self.cfg["rnn_config"]
+            return ({"cfg1": "BASELINE configs[1]: ", "es_en_20h": "shipped es_en_20h model (configs[0]'s model at configs[1]'s batch): ",
+                     "cfg5": "shape of BASELINE configs[4] (6-layer encoder, 2x512, V=8004): "}[self.name] +
+                    f"synthetic fbank T={T} D={D} batch {B}/GPU, 2xConv+BN -> {rc['enc_layers']}-layer 2x{rc['hidden_units'] // 2} LSTM enc -> "
+                    f"attention -> {rc['dec_layers']}-layer LSTM-{rc['hidden_units']} dec, V={self.V}, L={L}, dropout .3, noise .25, teach .8, Adam(amsgrad)+L2+clip")
+
+    w = Workload(args.model)
+    model, cfg, V = w.model, w.cfg, w.V
+    dt, loss_val = w.timed(args.warmup, args.steps)
     ms = dt / args.steps * 1e3
     value = world * B * T / (dt / args.steps)
 
     # ---- which kernels ran (a silent fall-back to the per-launch paths must show in the driver's line)
-    st = model._cur
-    paths = {"encoder": "persistent wavefront kernels (one launch for all steps of all cells)" if lib.astk_lstm_stack_path(C.byref(st["ld"]))
-             else "per-step fused-cell launches (fallback)"}
-    dpath = lib.astk_decoder_path(C.byref(st["dd"]))
-    paths["decoder"] = (f"persistent loop, {dpath >> 8} layer(s) fused" + (", attention phase specialised (H=512, chunk<=32)" if dpath & 2 else ", generic attention phase")
-                        + (", two launches over halves of the batch rows" if dpath & 4 else "")) \
-        if dpath & 1 else ("persistent loops of the wide decoder (decoder_wide.hip): one forward and one backward launch for all steps"
-                           if dpath & 16 else "per-launch loop (fallback)")
-    paths["encoder_persistent"], paths["decoder_persistent"] = bool(lib.astk_lstm_stack_path(C.byref(st["ld"]))), bool(dpath & 17)
-    paths["cu_count"] = int(lib.astk_device_cu_count())
-    paths["overlap_param_grads"] = bool(model.overlap_param_grads)
+    def paths_of(model):
+        st = model._cur
+        paths = {"encoder": "persistent wavefront kernels (one launch for all steps of all cells)" if lib.astk_lstm_stack_path(C.byref(st["ld"]))
+                 else "per-step fused-cell launches (fallback)"}
+        dpath = lib.astk_decoder_path(C.byref(st["dd"]))
+        paths["decoder"] = (f"persistent loop, {dpath >> 8} layer(s) fused" + (", attention phase specialised (H=512, chunk<=32)" if dpath & 2 else ", generic attention phase")
+                            + (", two launches over halves of the batch rows" if dpath & 4 else "")) \
+            if dpath & 1 else ("persistent loops of the wide decoder (decoder_wide.hip): one forward and one backward launch for all steps"
+                               if dpath & 16 else "per-launch loop (fallback)")
+        paths["encoder_persistent"], paths["decoder_persistent"] = bool(lib.astk_lstm_stack_path(C.byref(st["ld"]))), bool(dpath & 17)
+        paths["cu_count"] = int(lib.astk_device_cu_count())
+        paths["overlap_param_grads"] = bool(model.overlap_param_grads)
+        return paths
+    paths = paths_of(model)
+
+    def profile_json(name):
+        f = os.path.join(ROOT, "profiles", name)
+        return json.load(open(f)) if os.path.exists(f) else {}
+
+    def kernel_extras(res, nsteps, T2):
+        extra = {}
+        if res[5] > 0:
+            extra["gemm_family_ms_per_step"] = round(res[4] / nsteps, 3)
+        if res[8] > 0:
+            extra["encoder_lstm_persistent_ms_per_step"] = round(res[7] / nsteps, 3)
+            extra["encoder_us_per_time_step"] = round(res[7] / nsteps * 1e3 / 2 / T2, 2)     # fwd + bwd launches
+        if res[17] > 0:
+            extra["decoder_persistent_ms_per_step"] = round((res[16] + res[18]) / nsteps, 3)
+            S_ = L - 1
+            extra["decoder_us_per_decoder_step"] = {"fwd": round(res[16] / res[17] * 1e3 / S_, 2), "bwd": round(res[18] / res[19] * 1e3 / S_, 2)}
+        return extra
 
     # ---- per-kernel timing with HIP events on the launch stream (in situ), plus in-kernel phase stamps of the persistent decoder
     roof, scan, extra = None, None, {}
     if args.profile_steps > 0:
-        # per-kernel figures are taken with every kernel alone on the device: with the opt-in side-stream overlap
-        # (decoder parameter gradients on 64 masked CUs beside the encoder recurrence) those GEMMs would be priced as slow ones
-        overlap, model.overlap_param_grads = model.overlap_param_grads, False
-        lib.astk_prof_begin()
-        for _ in range(args.profile_steps):
-            step()
-        torch.cuda.synchronize()
-        model.overlap_param_grads = overlap
-        res = (C.c_double * 24)()
-        lib.astk_prof_end(res)
+        res = w.profile(args.profile_steps)
         T2 = model._cur["T2"]
         H = cfg["rnn_config"]["hidden_units"]
         S = L - 1
         bytes_scan = B * T2 * H * 4                                    # one streaming read of enc_states (SURVEY.md 8d)
-
-        def profile_json(name):
-            f = os.path.join(ROOT, "profiles", name)
-            return json.load(open(f)) if os.path.exists(f) else {}
         if res[5] > 0:
-            # THE dominant kernel family (40 % of the step): every batched dense product of the step.  `achieved` / `frac` price what the
-            # matrix pipe EXECUTES against the pipe that executes it: in the default mode every f32 operand is split in the kernel into two
-            # fp16 terms (22 significant bits) and a product is three v_mfma_f32_32x32x16_f16 -- 3x the useful flops on the 2.5 PFLOP/s
-            # fp16 pipe.  `useful_*` carries the 2*M*N*K figure and, for reference only, its ratio to the f32-input MFMA peak (which this
-            # scheme is not bound by).
+            # THE dominant kernel family: every batched dense product of the step.  `achieved` / `frac` price what the matrix pipe EXECUTES
+            # against the pipe that executes it: under bf16x3 every f32 operand is split in the kernel into three bf16 terms and a useful
+            # product is six v_mfma_f32_32x32x16_bf16 -- 6x the useful flops on the 2.5 PFLOP/s bf16 pipe (fp16x2: 3x on the fp16 pipe;
+            # f32: 1x on the 157.3 TFLOP/s f32-input MFMA pipe).  `useful_*` carries the algorithmic 2*M*N*K figure and its fraction of
+            # the executing pipe's peak -- the number to compare across schemes.
             tfl = res[6] / (res[4] * 1e-3) / 1e12
             ms_gemm, n_gemm = res[4] / args.profile_steps, int(res[5] / args.profile_steps)
-            mode = lib.astk_get_gemm_precision()
-            nprod, peak, pipe = {0: (3, MFMA_16BIT_PEAK_TFLOPS, "fp16 MFMA (v_mfma_f32_32x32x16_f16), 3 per useful 16-k product block (fp16x2 split)"),
-                                 1: (6, MFMA_16BIT_PEAK_TFLOPS, "bf16 MFMA (v_mfma_f32_32x32x16_bf16), 6 per useful 16-k product block (bf16x3 split)"),
-                                 2: (1, MFMA_F32_PEAK_TFLOPS, "f32-input MFMA (v_mfma_f32_32x32x2_f32)")}[mode]
-            tj = profile_json("r3_gemm_traffic.json") or profile_json("gemm_traffic.json")
-            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<NT|NN|TN> + k_absmax / k_absmax_zero / k_zero_split_tiles (all batched dense products of the step with their preparation launches)",
-                    "pipe": pipe,
+            nprod, peak, pipe = {"fp16x2": (3, MFMA_16BIT_PEAK_TFLOPS, "fp16 MFMA (v_mfma_f32_32x32x16_f16), 3 per useful 16-k product block (fp16x2 split)"),
+                                 "bf16x3": (6, MFMA_16BIT_PEAK_TFLOPS, "bf16 MFMA (v_mfma_f32_32x32x16_bf16), 6 per useful 16-k product block (bf16x3 split)"),
+                                 "f32": (1, MFMA_F32_PEAK_TFLOPS, "f32-input MFMA (v_mfma_f32_32x32x2_f32)")}[base_scheme]
+            tj = (profile_json("r4_gemm_traffic.json") or {}).get(base_scheme) or {}
+            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<NT|NN|TN> (+ k_zero_split_tiles; fp16x2 also k_absmax): all batched dense products of the step with their preparation launches",
+                    "scheme": base_scheme, "pipe": pipe,
                     "achieved": round(tfl * nprod, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tfl * nprod / peak, 4),
                     "useful_tflops": round(tfl, 2), "useful_frac_of_pipe_peak": round(tfl / peak, 4),
                     "useful_over_f32_mfma_peak": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
                     "traffic": tj.get("hbm_bytes_per_step"),
-                    "traffic_source": ("STATIC FILE, not measured in this run: " + tj.get("source", "profiles/gemm_traffic.json (rocprofv3 --pmc passes of an earlier build)")) if tj else None,
+                    "traffic_source": ("STATIC FILE, not measured in this run: " + tj.get("source", "profiles/r4_gemm_traffic.json")) if tj else None,
+                    "mfma_pipe_busy_frac_pmc": tj.get("mfma_pipe_busy_frac"),
                     # logical operand / result bytes (window operands of the conv GEMMs counted at their im2col extent, not at the
                     # smaller extent of the arrays they address); `traffic` is what crosses the L2's memory side, Infinity-Cache hits
                     # included: the stream-K workgroups of an XCD sit at unrelated k positions, so a panel is re-fetched by every tile
@@ -309,7 +363,7 @@ def main():
             # over the launch's duration.  Phase-level (in-kernel stamps, hand-off satisfied -> partial published) is given for
             # reference only: it is an HBM-EQUIVALENT rate of an on-chip pass, not HBM traffic.
             k_fwd_us, k_bwd_us = res[16] / res[17] * 1e3, res[18] / res[19] * 1e3
-            attn_traffic = profile_json("r3_attn_traffic.json") or profile_json("attn_traffic.json")
+            attn_traffic = profile_json("r4_attn_traffic.json") or profile_json("r3_attn_traffic.json") or profile_json("attn_traffic.json")
             ach = S * bytes_scan / ((k_fwd_us + k_bwd_us) / 2 * 1e-6) / 1e9
             scan = {"bound": "latency (priced against the HBM roofline north_star names; slices are LDS-resident, measured HBM traffic < algorithmic bytes)",
                     "kernel": "decoder_persist_fwd / decoder_persist_bwd (all S decoder steps per launch)",
@@ -335,50 +389,43 @@ def main():
                 scan = {"bound": "hbm", "kernel": "attn_fwd_partial+attn_bwd_partial (per-launch decoder loop)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": bytes_scan,
                         "avg_launch_us": round(avg_us, 3), "launches_per_step": int(n_attn / args.profile_steps)}
-        if res[8] > 0:
-            extra["encoder_lstm_persistent_ms_per_step"] = round(res[7] / args.profile_steps, 3)
-            extra["encoder_us_per_time_step"] = round(res[7] / args.profile_steps * 1e3 / 2 / T2, 2)     # fwd + bwd launches
-        if res[17] > 0:
-            extra["decoder_persistent_ms_per_step"] = round((res[16] + res[18]) / args.profile_steps, 3)
+        extra = kernel_extras(res, args.profile_steps, T2)
 
-    # ---- the SAME step, same process, under the other two arithmetic schemes (runtime switch astk_set_gemm_precision): a driver-timed
-    # figure for the f32-equivalent (bf16x3, 24-bit) and the exact-f32 arithmetic next to the default's
-    base_mode = lib.astk_get_gemm_precision()
+    # ---- the SAME step, same process, under the other two arithmetic schemes (the model's gemm_precision -> the descriptors' precision
+    # field): driver-timed figures for the literal f32 MFMA chain and for the narrower opt-in fp16x2 split next to the headline's
     alt = []
     if not args.no_alt_precisions:
-        for mode in (0, 1, 2):
-            if mode == base_mode:
+        for scheme in ("bf16x3", "f32", "fp16x2"):
+            if scheme == base_scheme:
                 continue
-            lib.astk_set_gemm_precision(mode)
-            for _ in range(min(3, args.warmup)):
-                step()
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                l2_ = step()
-            barrier()
-            d1 = time.perf_counter() - t1
-            if dp:
-                tt = torch.tensor([d1], dtype=torch.float64, device="cuda")
-                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-                d1 = float(tt.item())
-            alt.append({"scheme": PRECISIONS[mode][0], "dtype": PRECISIONS[mode][1], "steps": args.steps, "ms_per_step": round(d1 / args.steps * 1e3, 3),
-                        "value": round(world * B * T / (d1 / args.steps), 1), "loss": round(float(l2_), 4)})
-        lib.astk_set_gemm_precision(base_mode)
+            model.gemm_precision = scheme
+            d1, l2_ = w.timed(min(3, args.warmup), args.steps)
+            alt.append({"scheme": scheme, "dtype": PRECISIONS[scheme], "steps": args.steps, "ms_per_step": round(d1 / args.steps * 1e3, 3),
+                        "value": round(world * B * T / (d1 / args.steps), 1), "loss": round(l2_, 4)})
+        model.gemm_precision = base_scheme
 
-    dec_name = f"{n_dec}-layer LSTM-{cfg['rnn_config']['hidden_units']} dec"
+    # ---- second workload of the default run: the SHIPPED es_en_20h model (3 decoder layers: the model north_star's >= 50x target is
+    # quoted on), same batch, same scheme, same step definition, `--steps` timed steps after 3 warm-ups
+    also = []
+    w2 = None
+    if args.model == "cfg1" and not args.no_also:
+        w2 = Workload("es_en_20h")
+        d2, l2v = w2.timed(min(3, max(1, args.warmup)), args.steps)
+        e2 = {"workload": w2.describe(), "precision": base_scheme, "steps": args.steps, "ms_per_step": round(d2 / args.steps * 1e3, 3),
+              "value": round(world * B * T / (d2 / args.steps), 1), "unit": "frames/s", "loss": round(l2v, 4), "paths": paths_of(w2.model)}
+        if args.profile_steps > 0:
+            e2["kernels"] = kernel_extras(w2.profile(args.profile_steps), args.profile_steps, w2.model._cur["T2"])
+        also.append(e2)
+
     out = {"metric": "speech frames/s (train step)", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": PRECISIONS[base_mode][1] + ("" if args.gemm_operands == "f32" else "; single-term fp16 operands in the CNN / encoder-input / decoder-output GEMMs (--gemm-operands fp16)"),
-           "precision": PRECISIONS[base_mode][0],
+           "vs_baseline": None, "dtype": PRECISIONS[base_scheme] + ("" if args.gemm_operands == "f32" else "; single-term fp16 operands in the CNN / encoder-input / decoder-output GEMMs (--gemm-operands fp16)"),
+           "precision": base_scheme,
            "data": "synthetic",
-           "config": {"workload": {"cfg1": "BASELINE configs[1]: ", "es_en_20h": "shipped es_en_20h model (configs[0]'s model at configs[1]'s batch): ",
-                                   "cfg5": "shape of BASELINE configs[4] (6-layer encoder, 2x512, V=8004): "}[args.model] +
-                                  f"synthetic fbank T={T} D={D} batch {B}/GPU, 2xConv+BN -> {cfg['rnn_config']['enc_layers']}-layer 2x{cfg['rnn_config']['hidden_units'] // 2} LSTM enc -> "
-                                  f"attention -> {dec_name}, V={V}, L={L}, dropout .3, noise .25, teach .8, Adam(amsgrad)+L2+clip",
+           "config": {"workload": w.describe(),
                       "global_batch": world * B, "frames": T, "feat_dim": D, "tgt_len": L, "parallelism": f"dp{world}", "batchnorm": "global-batch statistics" if (world > 1 and args.sync_bn) else "per-replica statistics",
                       "launches": "plain stream launches (the step is GPU-bound: the host enqueues it in 0.6 ms)"},
-           "loss": round(loss_val, 4), "alt_precisions": alt, "paths": paths, "roofline": roof, "roofline_scan": scan}
+           "loss": round(loss_val, 4), "alt_precisions": alt, "also": also, "paths": paths, "roofline": roof, "roofline_scan": scan}
     if dp:
         out["dp"] = {"rccl_ranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
                      "buckets": list(model.grad_buckets.ranges), "bucket_launch": "dec+enc behind the encoder recurrence, cnn behind the CNN backward",
@@ -386,7 +433,10 @@ def main():
     out.update({"kernels": extra} if extra else {})
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            # bounded CPU samples (the NumPy oracle on this box's host cores): ~30 s for the headline's model, ~15 s for the shipped one
             out["cpu_baseline"] = cpu_baseline(cfg, B, T, D, L, V)
+            if also:
+                also[0]["cpu_baseline"] = cpu_baseline(w2.cfg, B, T, D, L, w2.V, budget_s=15.0)
         print(json.dumps(out), flush=True)
     if dp:
         torch.distributed.destroy_process_group()

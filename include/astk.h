@@ -12,7 +12,13 @@
  *   - return 0 on success, <0 on error; astk_last_error() gives the thread-local message;
  *   - weight layouts are Chainer's (A1/A2/A3/A10 of SURVEY.md): Linear W (out,in), LSTM gates
  *     interleaved (unit j, gate k -> row 4j+k, k = a,i,f,o), Conv W (out,in,kh,kw).
- * All arithmetic is float32 (f32-input MFMA for the GEMMs), matching the reference's dtype.
+ * Storage and accumulation are float32 everywhere, matching the reference's dtype (seq2seq.py:154,302,420).  The PRODUCTS of the
+ * batched dense GEMMs run on the 16-bit matrix pipe as bf16x3 splits by default: every f32 operand value is split inside the kernel
+ * into three bf16 terms that represent it EXACTLY (f32 exponent range), six term products per useful product, each product exact to
+ * 2^-26 -- at least as accurate as an f32 fma chain on any data.  ASTK_PREC_F32 selects the literal f32-input MFMA chain,
+ * ASTK_PREC_FP16X2 a faster, NARROWER two-term fp16 split (22 bits, limited exponent range; opt-in, never the default).  Decoder loop,
+ * attention, softmax-CE and optimizer are IEEE f32 in every mode; the encoder recurrences follow the mode (f32 MFMAs unless fp16x2).
+ * The arithmetic is chosen per call by the descriptors' `precision` field (ASTK_PREC_DEFAULT = the process-wide default).
  */
 #ifndef ASTK_H
 #define ASTK_H
@@ -23,13 +29,25 @@
 extern "C" {
 #endif
 
-#define ASTK_VERSION 103
+#define ASTK_VERSION 104
 #define ASTK_MAX_CNN_LAYERS 4
 #define ASTK_MAX_RNN_LAYERS 8
 #define ASTK_MAX_ATTN 4
 
 int astk_version(void);
 const char* astk_last_error(void);
+
+/* Arithmetic of an op's f32-accurate products: field `precision` of the descriptors below, argument of astk_gemm_f32_ex.
+ *   ASTK_PREC_DEFAULT  the process-wide default (bf16x3 unless astk_set_gemm_precision / ASTK_GEMM_PREC changed it)
+ *   ASTK_PREC_FP16X2   two fp16 terms per operand behind a per-operand power-of-two scale: 22 significant bits, and only for values within
+ *                      2^-17 of the operand's maximum (NARROWER than float32: opt-in), three MFMAs per 16 k; encoder recurrences likewise
+ *   ASTK_PREC_BF16X3   three bf16 terms per operand (exact representation of every f32 value, f32 exponent range), six MFMAs per 16 k
+ *   ASTK_PREC_F32      v_mfma_f32_32x32x2_f32 / 16x16x4_f32: IEEE f32 products, the reference's literal arithmetic
+ * `gemm_operands`: ASTK_OPERANDS_FP16 lets the products a caller marks eligible (K6, K9, batched K18 / K24: BASELINE configs[4]) run with
+ * ONE fp16 term per operand (reduced precision; the 1e-4 parity gate does not apply); ASTK_OPERANDS_F32 forces the f32-accurate scheme;
+ * ASTK_OPERANDS_DEFAULT = the process-wide setting of astk_set_low_precision_gemms. */
+enum { ASTK_PREC_DEFAULT = 0, ASTK_PREC_FP16X2 = 1, ASTK_PREC_BF16X3 = 2, ASTK_PREC_F32 = 3 };
+enum { ASTK_OPERANDS_DEFAULT = 0, ASTK_OPERANDS_F32 = 1, ASTK_OPERANDS_FP16 = 2 };
 
 /* ---------------------------------------------------------------- generic f32 MFMA GEMM
  * C[M,N] (+)= op(A) op(B) (+ bias[n]).  layout: 0 = "NT"  A[M,K] K-contiguous, B[N,K] K-contiguous (Linear forward)
@@ -41,30 +59,36 @@ const char* astk_last_error(void);
 int astk_gemm_f32(int layout, int M, int N, int K,
                   const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                   const float* bias, int mode, int ksplit, int batch, long sA, long sB, long sC, void* stream);
+/* The same product under the arithmetic `precision` names (ASTK_PREC_*); astk_gemm_f32 = ASTK_PREC_DEFAULT. */
+int astk_gemm_f32_ex(int layout, int M, int N, int K,
+                     const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                     const float* bias, int mode, int ksplit, int batch, long sA, long sB, long sC, int precision, void* stream);
 
 /* BASELINE configs[4] ("fp16 MFMA GEMMs"): mode 1 lets the batched products of the CNN layers >= 1 (K6), of the encoder's layer-0
  * input projection (K9) -- forward and backward -- and of the decoder LSTMs' and the output layer's backward (K18, K24: their weight
  * gradients over all steps, the embedding columns of the input gradient) run with operands rounded to fp16 behind the operand's
  * power-of-two scale where its caller measured it (one v_mfma_f32_32x32x16_f16 per tile, f32 accumulation) instead of the f32-accurate
  * split (below).  The per-step products of K18 / K24 live inside the latency-bound decoder loop kernels and stay on f32 MFMAs.  Reduced precision: the 1e-4 fp32 parity gate does not apply in
- * this mode (SURVEY.md 8d asks for the loss drift instead: tests/test_gpu_model.py).  Process-wide; 0 (default) = off. */
+ * this mode (SURVEY.md 8d asks for the loss drift instead: tests/test_gpu_model.py).  Process-wide DEFAULT for descriptors whose
+ * gemm_operands field is ASTK_OPERANDS_DEFAULT; 0 (default) = off. */
 int astk_set_low_precision_gemms(int mode);
 int astk_get_low_precision_gemms(void);
-/* The f32-accurate GEMMs split every operand into 16-bit terms inside the kernel: two fp16 terms behind a per-operand power-of-two
- * scale (an absolute-maximum pass in front of the launch; three MFMAs per 16 k), or -- for launches below `flops` floating-point
- * operations, which do not repay that pass -- three bf16 terms (no scales, six MFMAs).  Default 3e9 (environment:
- * ASTK_GEMM_X3_BELOW); 0 = fp16 terms always.  Process-wide; returns the previous value. */
+/* fp16x2 mode only: launches below `flops` floating-point operations do not repay the absolute-maximum pass the scaled fp16 terms
+ * need and run as bf16x3 instead.  Default 3e9 (environment: ASTK_GEMM_X3_BELOW); 0 = fp16 terms always.  Process-wide; returns the
+ * previous value. */
 double astk_set_gemm_bf16_split_below(double flops);
-/* Arithmetic of the f32-accurate products, process-wide, switchable at run time (bench.py times the same step under each):
- *   0  fp16x2 (default): two fp16 terms per operand behind a power-of-two scale, 22 significant bits per operand value, in the batched
- *      GEMMs AND in the encoder's persistent recurrence kernels;
- *   1  bf16x3: three bf16 terms (24 bits, no scales) in the batched GEMMs, exact-f32 MFMAs in the recurrences;
- *   2  f32: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 everywhere (IEEE f32 products, the reference's arithmetic).
+/* The process-wide DEFAULT arithmetic (what ASTK_PREC_DEFAULT resolves to), switchable at run time (bench.py times the same step under each):
+ *   0  fp16x2: two fp16 terms per operand behind a power-of-two scale, 22 significant bits per operand value, in the batched GEMMs AND in
+ *      the encoder's persistent recurrence kernels -- NARROWER than float32, opt-in;
+ *   1  bf16x3 (default): three bf16 terms (exact operands, no scales) in the batched GEMMs, exact-f32 MFMAs in the recurrences;
+ *   2  f32: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 everywhere (IEEE f32 products, the reference's literal arithmetic).
  * The environment variable ASTK_GEMM_PREC = fp16x2 | bf16x3 | f32 sets the initial mode.  Returns the previous mode (<0: error). */
 int astk_set_gemm_precision(int mode);
 int astk_get_gemm_precision(void);
-/* Test hook: sets the generation counter of the fp16x2 scale slots (tests preset it close to the 32-bit wrap). */
+#ifdef ASTK_TEST_HOOKS
+/* Test hook (libastk_test.so only): sets the generation counter of the fp16x2 scale slots (tests preset it close to the 32-bit wrap). */
 int astk_debug_set_amax_generation(unsigned gen);
+#endif
 
 /* ---------------------------------------------------------------- CNN front-end  (seq2seq.py:158-180)
  * [Conv2D(no bias) -> (max-pool) -> BatchNorm(train: batch stats) -> ReLU] x n_layers (or, with no_bn, [Conv2D(bias) -> ReLU]), then the (T'',B,C*F') time-major
@@ -84,6 +108,8 @@ typedef struct {
    * BatchNorm -- window = stride, no padding, cover_all (the last window may be partial: out = ceil(in / window)).  0 or 1 = none,
    * -1 = the whole extent.  No shipped config sets it. */
   int pool_t[ASTK_MAX_CNN_LAYERS], pool_f[ASTK_MAX_CNN_LAYERS];
+  int precision;       /* ASTK_PREC_*: arithmetic of this op's products (0 = process default) */
+  int gemm_operands;   /* ASTK_OPERANDS_* (0 = process default) */
 } astk_cnn_desc;
 
 typedef struct {
@@ -116,13 +142,15 @@ int astk_conv_bn_relu_bwd(const astk_cnn_desc* d, const astk_cnn_layer_params* l
  * pass it on as astk_lstm_stack_desc.x_amax.  Valid from the forward call until ws is reused.  NULL: bad arguments. */
 const void* astk_conv_out_amax(const astk_cnn_desc* d, void* ws, size_t ws_bytes);
 
-/* Test instrumentation (tests/test_gpu_model.py, the batch-permutation property).  astk_conv_debug_preact: after a forward call, out
+#ifdef ASTK_TEST_HOOKS
+/* Test instrumentation, compiled into libastk_test.so only (tests/test_gpu_model.py, the batch-permutation property).  astk_conv_debug_preact: after a forward call, out
  * [(b,f,t)][c] = the post-BatchNorm pre-activation of `layer` (what the ReLU sees), rows = B*F'*T_layer.  astk_conv_debug_kill_units:
  * the following backward calls of this process zero the upstream gradient of the listed units (n triples layer, row, channel in
  * device memory, caller-owned; n = 0 switches it off).  Two valid float32 evaluations of one batch can disagree on the SIGN of a
  * pre-activation that lies within rounding of the ReLU kink; the test names those units and shows that nothing else differs. */
 int astk_conv_debug_preact(const astk_cnn_desc* d, void* ws, size_t ws_bytes, int layer, float* out, void* stream);
 int astk_conv_debug_kill_units(const int32_t* units, int n);
+#endif
 
 /* Data-parallel BatchNorm with GLOBAL batch statistics (SURVEY.md 8e "SyncBN"): the same two calls with an exchange step.
  * After a layer's local per-channel sums are on the device -- forward (sum y, sum y^2), backward (sum g, sum g*xhat), `n` = 2*C
@@ -151,6 +179,8 @@ typedef struct {
    *   x_amax     the maximum words of the input frames x, as left by the kernel that wrote them (astk_conv_out_amax). */
   float out_bound;
   const void* x_amax;
+  int precision;       /* ASTK_PREC_*: batched products AND the persistent recurrence kernels (0 = process default) */
+  int gemm_operands;   /* ASTK_OPERANDS_* (0 = process default) */
 } astk_lstm_stack_desc;
 
 typedef struct {
@@ -213,6 +243,8 @@ typedef struct {
   const int32_t* use_truth_host; /* optional HOST copy of the use_truth flags handed to astk_decoder_fwd(_ex) (L-1 entries), or NULL.  A hint for
                         the per-launch loop only: it then computes logits inside the loop just for the steps whose argmax is fed back and
                         scores every step with one product and one softmax-CE launch behind the loop.  Read during the call, not kept. */
+  int precision;       /* ASTK_PREC_*: the batched products around the loop (encA, weight gradients, d_enc); the loop itself is IEEE f32 */
+  int gemm_operands;   /* ASTK_OPERANDS_* (0 = process default) */
 } astk_decoder_desc;
 
 typedef struct {
@@ -313,7 +345,9 @@ int astk_softmax_ce_fwd(int B, int V, long ld, float* logits_inout, const int32_
  * WeightDecay -> GradientClipping); the step applies decay, the clip rate min(1, clip/sqrt(sqnorm)) and
  * AMSGrad-Adam with lr_t = alpha*sqrt(1-b2^t)/(1-b1^t) computed by the caller.  Both update kernels leave p (and the moments)
  * untouched while the persistent kernels' sticky status word is non-zero (a kernel of the step timed out: the gradients are
- * garbage, and the host only learns of it when it reads the loss back). */
+ * garbage, and the host only learns of it when it reads the loss back).  The word stays set until astk_persist_status(.., reset = 1):
+ * a caller must read the status next to the loss at least once per step (the Python shim's loss.data / float(loss) do, and raise) --
+ * one that never looks would silently drop every later update while its own step counter advances. */
 int astk_grad_sqnorm(const float* g, const float* p, float l2, size_t n, double* sqnorm, void* stream);
 int astk_decay_clip_amsgrad_step(float* p, const float* g, float* m, float* v, float* vhat, size_t n,
                                  float l2, float clip, const double* sqnorm, float lr_t, float beta1, float beta2,
@@ -365,12 +399,18 @@ int astk_spin(unsigned usec, unsigned* flag, void* stream);
  * other (lstm_persist.hip, decoder_persist.hip); that needs the whole grid resident (one workgroup per CU), which the launchers
  * check against the device's CU count but cannot guarantee against other tenants of the GPU (RCCL kernels under data
  * parallelism, another process).  Every spin is bounded: a time-out drains the grid and sets a bit in a STICKY status word
- * (1 encoder fwd, 2 encoder bwd, 4 decoder fwd, 8 decoder bwd); the results of such a step are garbage.
+ * (1 encoder fwd, 2 encoder bwd, 4 decoder fwd, 8 decoder bwd, 16 a peer rank reported one of these: astk_persist_status_merge); the
+ * results of such a step are garbage.
  *   astk_persist_status_snapshot  enqueues a copy of the word (as a float) to *dst on `stream`: the Python shim places it next to
  *                                 the loss scalar, so the loss read-back of nn.py:189 sees it without an extra synchronisation;
  *   astk_persist_status           synchronises the device, returns the word in *mask_out (may be NULL) and clears it if `reset`.
  * ASTK_PERSIST_SPIN_LIMIT=<polls> (environment, read at every launch) shrinks the spin bound; tests use it to force a time-out. */
 int astk_persist_status_snapshot(float* dst, void* stream);
+/* Data parallelism: `summed` = the SUM over all ranks of the words astk_persist_status_snapshot wrote (the Python shim appends the
+ * word to the last gradient range, so the gradient all-reduce carries it: ast_amd/dist.py).  Non-zero: some rank's step is garbage --
+ * bit 16 is set in THIS rank's sticky word, so that the update kernels enqueued behind it skip on every rank alike and every rank
+ * raises at its next loss read-back instead of waiting in the next collective for a peer that has already failed. */
+int astk_persist_status_merge(const float* summed, void* stream);
 /* Which path a shape takes on the current device (so that a silent fall-back shows up in logs / bench.py's JSON line):
  *   astk_lstm_stack_path  1 = persistent wavefront kernels (all T steps of all cells in one launch), 0 = one fused-cell launch per step
  *   astk_decoder_path     0 = per-launch decoder loop; otherwise bit 0 = persistent loop, bit 1 = attention phase specialised for

@@ -26,3 +26,13 @@ def tiny_cfg(enc_layers=2, dec_layers=2, H=8, E=4, A=8, c0=4, c1=6, V=11, drop=0
 @pytest.fixture
 def tiny():
     return tiny_cfg
+
+
+SCHEMES = ["bf16x3", "f32", "fp16x2"]      # include/astk.h ASTK_PREC_*: the library default first, then the literal f32 chain, then the opt-in narrow scheme
+
+
+@pytest.fixture(params=SCHEMES)
+def gemm_scheme(request):
+    """The whole-model parity tests run once under EVERY arithmetic scheme bench.py times (round-3 review, item 1b): the test sets
+    `model.gemm_precision = gemm_scheme`, which goes into the op descriptors' `precision` field (per call, no process-wide state)."""
+    return request.param

@@ -44,6 +44,39 @@ assert all(abs(x - z) <= 1e-4 * abs(x) for x, z in zip(a, b)), "losses differ"
 rel = float((pa - pb).abs().max() / pa.abs().max())
 print("max parameter difference after 4 steps (relative):", rel)
 assert rel < 1e-3
+# ---- the abort word across ranks (round-3 review item 6), against the real backend: a status word that some rank reports as non-zero
+# comes back from the all-reduce, astk_persist_status_merge marks THIS rank's sticky word (bit 16), the update kernels skip, and the next
+# loss read-back raises.  (One rank: the "peer" is a status_fn that reports a decoder-forward time-out.)
+from ast_amd import _lib
+m = SpeechEncoderDecoder(0, cfg).materialize(D, seed=0)
+opt = O.Adam(alpha=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, amsgrad=True).setup(m)
+opt.add_hook(O.WeightDecay(1e-4)); opt.add_hook(O.GradientClipping(2))
+m.grad_buckets = adist.make_grad_buckets(m)
+opt.grad_sync = m.grad_buckets.finish
+random.seed("seed-ast-20h")
+def one_step():
+    with using_config("train", True):
+        l = m.forward_loss(X=X, y=y, teach_ratio=0.8, random_out=0, add_noise=0.25)
+        m.cleargrads(); l.backward(); opt.update()
+    return l
+l = one_step()
+assert float(l.data) > 0 and float(m.grad_buckets.status_sum[0]) == 0.0            # healthy: the tail rides along and sums to zero
+before = m.arena.data.clone()
+m.grad_buckets.status_fn = lambda tail: tail.fill_(4.0)                            # "a peer's decoder forward timed out"
+l = one_step()                                                                      # the snapshot next to THIS loss was taken before the exchange
+torch.cuda.synchronize()
+assert float(m.grad_buckets.status_sum[0]) == 4.0
+assert torch.equal(before, m.arena.data), "the update of the aborted step was applied"
+m.grad_buckets.status_fn = adist._library_status
+try:
+    float(one_step().data)                                                          # the next read-back sees the merged sticky word
+    raise SystemExit("no AstkError after a peer's abort")
+except _lib.AstkError as e:
+    assert "peer rank" in str(e), str(e)
+    print("abort propagated:", str(e)[:120])
+assert torch.equal(before, m.arena.data), "updates were applied while the status word was set"
+float(one_step().data)                                                              # the raise cleared the word: training can go on
+assert not torch.equal(before, m.arena.data)
 td.destroy_process_group()
 # bench.py's own data-parallel branch (what the driver's N > 1 runs execute), forced onto a process group of one rank: RCCL backend,
 # NCCL_MAX_NCHANNELS cap, bucketed exchange, max-over-ranks timing, the `dp` object of the JSON line

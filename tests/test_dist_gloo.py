@@ -104,6 +104,127 @@ def test_two_rank_gloo():
         assert ok4, f"rank {rank}: BatchNorm statistics exchange wrong"
 
 
+def _abort_worker(rank, world, port):
+    """Rank 1 reports a persistent-kernel time-out in its status word; the word rides behind the last gradient range, so after the
+    exchange BOTH ranks see it, skip the step and raise -- nobody is left waiting in the next collective."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from ast_amd import dist as adist
+    from ast_amd.dist import GradBuckets
+    from ast_amd.params import ParamArena
+    adist.init("gloo")
+    shapes = {"CNN_0/W": (3, 1, 2, 2), "L0_enc/upward/W": (8, 5), "attn_Wa/W": (4, 4), "out/b": (7,)}
+    arena = ParamArena(shapes, torch.device("cpu"))
+    groups = {"cnn": ["CNN_0/W"], "enc": ["L0_enc/upward/W"], "dec": ["attn_Wa/W", "out/b"]}
+    base = torch.arange(arena.size, dtype=torch.float32) + 1
+    status = {"v": 0.0}
+    gb = GradBuckets(arena, groups, defer_scale=True, status_fn=lambda tail: tail.fill_(status["v"]))
+    # step 1: healthy on both ranks -> the tail sums to 0, gradients are the plain sums, nothing raises
+    arena.grad.copy_(base * (rank + 1))
+    gb.launch("dec"); gb.launch("enc")
+    scale = gb.finish()
+    assert scale == 1.0 / world and float(gb.status_sum[0]) == 0.0
+    assert torch.allclose(arena.grad, base * sum(r + 1 for r in range(world)))
+    adist.raise_if_any_rank_aborted(gb)
+    # step 2: rank 1's decoder forward (bit 4) timed out
+    status["v"] = 4.0 if rank == 1 else 0.0
+    arena.grad.copy_(base)
+    gb.launch("dec"); gb.launch("enc")
+    gb.finish()
+    assert float(gb.status_sum[0]) == 4.0, (rank, float(gb.status_sum[0]))       # every rank holds the SUM
+    assert torch.allclose(arena.grad, base * world)                               # the tail did not disturb the gradients
+    adist.raise_if_any_rank_aborted(gb, "gloo test step 2")                       # raises AstkError on BOTH ranks -> exit code 1
+    td.destroy_process_group()                                                    # not reached
+
+
+def test_abort_word_reaches_every_rank_through_the_gradient_all_reduce():
+    """Round-3 review item 6: a persistent-kernel time-out on ONE rank must stop ALL ranks in the same step.  Two gloo ranks; rank 1
+    reports a fake time-out; both must exit non-zero within seconds (before: rank 0 trained on and then waited in the next all-reduce
+    until the 120-minute watchdog)."""
+    import time
+    ctx = mp.get_context("spawn")
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_abort_worker, args=(r, 2, port)) for r in range(2)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert time.time() - t0 < 120
+    assert [p.exitcode for p in procs] == [1, 1], [p.exitcode for p in procs]
+
+
+def _random_out_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from ast_amd import dist as adist
+    from ast_amd.seq2seq import draw_flags_and_targets
+    adist.init("gloo")
+    V, B, L = 23, 3, 9
+    rng = np.random.default_rng(100 + rank)                     # DIFFERENT shards: different numbers of targets >= 4 per rank
+    y = np.zeros((B, L), dtype=np.int32)
+    for b in range(B):
+        n = int(rng.integers(4, L + 1))
+        y[b, 0], y[b, 1:n - 1], y[b, n - 1] = 1, rng.integers(4, V, size=n - 2), 2
+    random.seed("seed-ast-20h")
+    flags, tg = draw_flags_and_targets(y, 0.8, 0.3, V, lambda lo, hi: hi - 1)          # replaced entries become V - 1 (clamped from V)
+    state = random.getstate()
+    after = random.random()
+    q.put((rank, flags, y.tolist(), tg.tolist(), list(state[1][-8:]), after))      # (tail of the Mersenne state + its index)
+    td.destroy_process_group()
+
+
+def test_random_out_draws_keep_the_shared_random_stream_identical_on_every_rank():
+    """with random_out > 0 the number of draws from the seeded Python `random` stream depended on each rank's own
+    rows, so the ranks' streams -- which also shuffle next epoch's batches -- drifted apart.  Now every rank makes the draws of the whole
+    global batch in the unsharded row order and keeps its own rows' replacements: same flags, same stream state, and together the
+    ranks' scored targets are exactly what ONE process computes on the concatenated batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    world = 2
+    procs = [ctx.Process(target=_random_out_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, f0, y0, t0, s0, a0), (_, f1, y1, t1, s1, a1) = res
+    assert f0 == f1 and s0 == s1 and a0 == a1, "the ranks' random streams drifted apart"
+    assert t0 != y0 or t1 != y1, "nothing was replaced: the test draws nothing"
+    # one process on the concatenated batch (global row b * world + r = row b of rank r)
+    sys.path.insert(0, ROOT)
+    from ast_amd.seq2seq import draw_flags_and_targets
+    yg = np.empty((2 * len(y0), len(y0[0])), dtype=np.int32)
+    yg[0::2], yg[1::2] = np.asarray(y0), np.asarray(y1)
+    random.seed("seed-ast-20h")
+    fg, tg = draw_flags_and_targets(yg, 0.8, 0.3, 23, lambda lo, hi: hi - 1, rank=0, world=1)
+    assert fg == f0 and random.random() == a0
+    assert tg[0::2].tolist() == t0 and tg[1::2].tolist() == t1
+
+
+def test_init_caps_the_rccl_channels_like_bench_does(monkeypatch):
+    """the channel cap used to be applied by bench.py only; train.py -> dist.init() ran uncapped.  init("nccl")
+    now applies it itself (checked here without a process group: WORLD_SIZE 2, torch.distributed stubbed)."""
+    from ast_amd import dist as adist
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    called = {}
+    monkeypatch.setattr(adist.td, "is_initialized", lambda: False)
+    monkeypatch.setattr(adist.td, "init_process_group", lambda **kw: called.update(kw))
+    monkeypatch.setattr(adist.torch.cuda, "set_device", lambda d: called.update(device=d))
+    adist.init("nccl")
+    assert called["backend"] == "nccl" and os.environ["NCCL_MAX_NCHANNELS"] == "32" and adist.channel_cap == 32
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS")
+    adist.init("nccl", recurrence_cus=240)
+    assert os.environ["NCCL_MAX_NCHANNELS"] == "16"
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS")
+    adist.init("gloo")
+    assert "NCCL_MAX_NCHANNELS" not in os.environ                 # only the RCCL backend is capped
+
+
 def test_rccl_channel_cap_leaves_the_recurrence_grid_its_cus(monkeypatch):
     """ast_amd.dist.reserve_cus_for_recurrence: RCCL kernels hold one CU per channel until every peer has arrived; the persistent
     recurrence grids need their workgroups resident at once.  The cap keeps channels + grid within the device; an explicit, too large

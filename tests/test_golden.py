@@ -53,7 +53,7 @@ def test_oracle_reproduces_golden(path, dtype, tol):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
-def test_hip_path_matches_golden(path):
+def test_hip_path_matches_golden(path, gemm_scheme):
     import torch
     from ast_amd import optimizers as O
     from ast_amd.seq2seq import SpeechEncoderDecoder, using_config
@@ -61,6 +61,7 @@ def test_hip_path_matches_golden(path):
     V = cfg["rnn_config"]["dec_vocab_size"]
     D = z["X"].shape[2]
     g = SpeechEncoderDecoder(0, cfg).materialize(D, values={k: v.astype(np.float32) for k, v in P.items()})
+    g.gemm_precision = gemm_scheme
     opt = O.Adam(alpha=1e-3, amsgrad=True).setup(g)
     opt.add_hook(O.WeightDecay(1e-4))
     opt.add_hook(O.GradientClipping(2))
@@ -136,15 +137,17 @@ def test_oracle_reproduces_fullsize_golden_es_en_20h():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", sorted(FULL))
-def test_hip_path_matches_fullsize_golden(case):
-    """north_star gate at full size: loss and clip norm within 1e-4 relative of the float64 oracle; per-tensor gradient norms within
-    3e-4, sampled gradient entries within 1e-3 of the tensor's largest entry; encoder states (norm 1e-4, entries 2e-4 of the max)."""
+def test_hip_path_matches_fullsize_golden(case, gemm_scheme):
+    """north_star gate at full size, under every arithmetic scheme bench.py times (bf16x3 = the default and the headline, f32, fp16x2):
+    loss and clip norm within 1e-4 relative of the float64 oracle; per-tensor gradient norms within 3e-4, sampled gradient entries
+    within 1e-3 of the tensor's largest entry; encoder states (norm 1e-4, entries 2e-4 of the max)."""
     import torch
     from ast_amd import optimizers as O
     from ast_amd.seq2seq import SpeechEncoderDecoder, using_config
     c = FULL[case]
     P, X, y = _full_inputs(c)
     g = SpeechEncoderDecoder(0, c["cfg"]).materialize(c["D"], values=P)
+    g.gemm_precision = gemm_scheme
     opt = O.Adam(alpha=1e-3, amsgrad=True).setup(g)
     opt.add_hook(O.WeightDecay(1e-4))
     opt.add_hook(O.GradientClipping(2))
@@ -170,7 +173,7 @@ def test_hip_path_matches_fullsize_golden(case):
         assert abs(gn - v["norm"]) <= 3e-4 * max(v["norm"], 1e-3 * nmax), (case, k, gn, v["norm"])
         # single entries at the far end of the chain (CNN_0/W sits behind two 200-step recurrences) carry more float32 rounding than
         # the tensor's norm does: 1e-3 of the tensor's largest entry (the fixture records how far the float32 ORACLE's entries are
-        # from the float64 ones, f32_oracle_entry_err_over_absmax, for comparison).  Which arithmetic needed it: the default fp16x2 products,
+        # from the float64 ones, f32_oracle_entry_err_over_absmax, for comparison).  Which arithmetic needed it: the fp16x2 products,
         # at cfg1's CNN_0/W (3.03e-4 of the tensor's maximum in round 2, when the bound was 3e-4 and the GEMMs had just moved from exact-f32
         # MFMAs to fp16x2); the float32 ORACLE itself is 8e-3 off on that tensor.
         err = np.abs(got.ravel()[v["index"]] - np.asarray(v["value"])).max()

@@ -20,15 +20,19 @@ def lib():
     return _lib.load()
 
 
-@pytest.fixture(params=["fp16x2", "auto"])
+@pytest.fixture(params=["bf16x3", "fp16x2", "f32"])
 def gemm_split(request, lib):
-    """The f32-accurate GEMMs run two operand schemes: two fp16 terms behind per-operand scales, and -- below 3 GFLOP, which is every
-    shape of the small op tests -- three bf16 terms.  "fp16x2" forces the first on all sizes (astk_set_gemm_bf16_split_below(0)),
-    "auto" is the default dispatch."""
-    lib.astk_set_gemm_bf16_split_below.restype = C.c_double
-    prev = lib.astk_set_gemm_bf16_split_below(C.c_double(0.0 if request.param == "fp16x2" else 3e9))
+    """Every operator test runs under the three arithmetic schemes of the f32-accurate products (include/astk.h): "bf16x3" = the
+    library's default (three bf16 terms, exact operands), "f32" = the f32-input MFMA chain, "fp16x2" = the opt-in two-term fp16 split,
+    forced on all sizes (astk_set_gemm_bf16_split_below(0): by itself it hands launches below 3 GFLOP -- every shape of the small op
+    tests -- to bf16x3).  The fixture moves the PROCESS DEFAULT, which is what descriptors with precision = ASTK_PREC_DEFAULT resolve to."""
+    assert lib.astk_get_gemm_precision() == 1, "the library's default arithmetic must be bf16x3 (a reference-width scheme)"
+    prev_below = lib.astk_set_gemm_bf16_split_below(C.c_double(0.0 if request.param == "fp16x2" else 3e9))
+    prev = lib.astk_set_gemm_precision({"fp16x2": 0, "bf16x3": 1, "f32": 2}[request.param])
+    assert prev == 1
     yield request.param
-    lib.astk_set_gemm_bf16_split_below(C.c_double(prev))
+    lib.astk_set_gemm_precision(prev)
+    lib.astk_set_gemm_bf16_split_below(C.c_double(prev_below))
 
 
 def dev(a, dtype=torch.float32):
@@ -729,7 +733,7 @@ def test_gemm_operand_magnitudes(lib, layout, sa, sb, gemm_split):
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K,sigma", [(1024, 1536, 2048, 2.5), (1024, 6400, 1024, 2.5), (1024, 1536, 2048, 3.5)])
-def test_gemm_heavy_tailed_operands_fp16x2_against_the_exact_f32_kernel(lib, layout, M, N, K, sigma):
+def test_gemm_heavy_tailed_operands_every_scheme_against_the_exact_f32_kernel(lib, layout, M, N, K, sigma):
     """fp16x2 on hard data: log-normal magnitudes INSIDE every row and column of both operands (trained weights and BPTT gradients are
     heavy-tailed within rows; round-2's test spread whole rows).  The same product under the two-term fp16 split, the three-term bf16
     split and the exact-f32 MFMA chain (astk_set_gemm_precision), each against float64, element by element relative to the natural
@@ -756,26 +760,31 @@ def test_gemm_heavy_tailed_operands_fp16x2_against_the_exact_f32_kernel(lib, lay
     Ad = torch.from_numpy(A.T.copy() if layout == 2 else A).cuda()
     Bd = torch.from_numpy(Bm.T.copy() if layout != 0 else Bm).cuda()
     errs = {}
-    prev = lib.astk_get_gemm_precision()
-    lib.astk_set_gemm_bf16_split_below.restype = C.c_double
+    from ast_amd import _lib as L_
     below = lib.astk_set_gemm_bf16_split_below(C.c_double(0.0))       # fp16x2 whatever the size
     try:
-        for mode, name in ((0, "fp16x2"), (1, "bf16x3"), (2, "f32")):
-            assert lib.astk_set_gemm_precision(mode) >= 0
+        # per-call arithmetic (astk_gemm_f32_ex: the `precision` every descriptor carries), and the process default last
+        for name, prec in (("fp16x2", L_.PREC_FP16X2), ("bf16x3", L_.PREC_BF16X3), ("f32", L_.PREC_F32), ("default", L_.PREC_DEFAULT)):
             c = torch.empty(M, N, device="cuda")
-            ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(Ad), Ad.shape[1], vp(Bd), Bd.shape[1], vp(c), N, None, 0, 1, 1, 0, 0, 0, stream()))
+            ok(lib, lib.astk_gemm_f32_ex(layout, M, N, K, vp(Ad), Ad.shape[1], vp(Bd), Bd.shape[1], vp(c), N, None, 0, 1, 1, 0, 0, 0, prec, stream()))
             assert bool(torch.isfinite(c).all())
             errs[name] = float(((c.double() - ref).abs() / scale).max())
+            if name == "bf16x3":
+                c_x3 = c
+            if name == "default":
+                assert torch.equal(c, c_x3), "ASTK_PREC_DEFAULT must resolve to bf16x3"
     finally:
-        lib.astk_set_gemm_precision(prev)
         lib.astk_set_gemm_bf16_split_below(C.c_double(below))
     print("heavy-tailed GEMM errors (relative to sum |a||b|):", sigma, errs)
+    assert lib.astk_get_gemm_precision() == 1
     assert errs["f32"] < 4e-6, errs
     assert errs["bf16x3"] <= 2.0 * errs["f32"], errs
+    # THE DEFAULT ARITHMETIC is f32-equivalent on any data, sigma = 3.5 included (round-3 review, item 1a)
+    assert errs["default"] <= 2.0 * errs["f32"], errs
     if sigma <= 2.5:
         assert errs["fp16x2"] <= 2.0 * errs["f32"], errs
     else:
-        assert errs["fp16x2"] < 2e-3, errs
+        assert errs["fp16x2"] < 2e-3, errs       # the opt-in scheme's documented domain limit
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
@@ -828,7 +837,7 @@ def test_gemm_scale_slots_survive_ring_wraparound(lib):
         ea, eb = int(rng.integers(-40, 30)), int(rng.integers(-40, 30))
         a, b = a0 * (2.0 ** ea), b0 * (2.0 ** eb)
         c = torch.empty(M, N, device="cuda")
-        ok(lib, lib.astk_gemm_f32(0, M, N, K, vp(a), K, vp(b), K, vp(c), N, None, 0, 1, 1, 0, 0, 0, stream()))
+        ok(lib, lib.astk_gemm_f32_ex(0, M, N, K, vp(a), K, vp(b), K, vp(c), N, None, 0, 1, 1, 0, 0, 0, 1, stream()))      # ASTK_PREC_FP16X2
         if it % 10 == 0 or it > 1480:           # (every launch runs; every tenth is compared)
             got = c.double() * (2.0 ** -(ea + eb))
             assert bool(torch.isfinite(got).all()), (it, M, N, K, ea, eb)
@@ -838,29 +847,31 @@ def test_gemm_scale_slots_survive_ring_wraparound(lib):
     assert worst > 0.0
 
 
-def test_gemm_scale_generation_counter_survives_its_32_bit_wrap(lib):
-    """The generation tag of the scale slots is the high half of a 64-bit atomicMax word; a tag that wrapped to a small value would lose
+def test_gemm_scale_generation_counter_survives_its_32_bit_wrap():
+    """The generation tag of the fp16x2 scale slots is the high half of a 64-bit atomicMax word; a tag that wrapped to a small value would lose
     to every stale word and freeze the scales (a week of training at ~40 passes per step).  The counter is preset 40 generations short
     of the wrap threshold: 120 launches whose operand magnitudes jump by up to 2^60 run across it and every result is checked -- a stale
-    (larger or smaller) maximum shows as inf / NaN or as lost bits."""
+    (larger or smaller) maximum shows as inf / NaN or as lost bits.  The preset is a test hook: it exists in libastk_test.so only."""
+    from ast_amd import _lib as L_
     rng = np.random.default_rng(78)
     M, N, K = 1024, 1024, 1536
     a0 = torch.randn(M, K, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
     b0 = torch.randn(N, K, device="cuda", generator=torch.Generator(device="cuda").manual_seed(6))
     ref0 = a0.double() @ b0.double().T
-    assert lib.astk_debug_set_amax_generation(0xFFFFFF00 - 40) == 0
-    try:
-        for it in range(120):
-            ea, eb = int(rng.integers(-30, 30)), int(rng.integers(-30, 30))
-            a, b = a0 * (2.0 ** ea), b0 * (2.0 ** eb)
-            c = torch.empty(M, N, device="cuda")
-            ok(lib, lib.astk_gemm_f32(0, M, N, K, vp(a), K, vp(b), K, vp(c), N, None, 0, 1, 1, 0, 0, 0, stream()))
-            got = c.double() * (2.0 ** -(ea + eb))
-            assert bool(torch.isfinite(got).all()), (it, ea, eb)
-            err = float((got - ref0).abs().max() / ref0.abs().max())
-            assert err < 2e-5, (it, ea, eb, err)
-    finally:
-        torch.cuda.synchronize()
+    with L_.load_test_hooks() as lib:
+        assert lib.astk_debug_set_amax_generation(0xFFFFFF00 - 40) == 0
+        try:
+            for it in range(120):
+                ea, eb = int(rng.integers(-30, 30)), int(rng.integers(-30, 30))
+                a, b = a0 * (2.0 ** ea), b0 * (2.0 ** eb)
+                c = torch.empty(M, N, device="cuda")
+                ok(lib, lib.astk_gemm_f32_ex(0, M, N, K, vp(a), K, vp(b), K, vp(c), N, None, 0, 1, 1, 0, 0, 0, L_.PREC_FP16X2, stream()))
+                got = c.double() * (2.0 ** -(ea + eb))
+                assert bool(torch.isfinite(got).all()), (it, ea, eb)
+                err = float((got - ref0).abs().max() / ref0.abs().max())
+                assert err < 2e-5, (it, ea, eb, err)
+        finally:
+            torch.cuda.synchronize()
 
 
 def test_optimizer_grad_scale_equals_scaling_first(lib):

@@ -84,7 +84,7 @@ def _gpu(cfg, P, D, V):
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_optional_features_train_step_parity(name):
+def test_optional_features_train_step_parity(name, gemm_scheme):
     from oracle import ast_ref as R
     from oracle.ast_ref_torch import masks_from_recording
     from ast_amd import optimizers as O
@@ -101,6 +101,7 @@ def test_optional_features_train_step_parity(name):
     X, y = R.synth_batch(B, T, D, L, V, seed=3, dtype=np.float32)
     ref = _oracle_step(cfg, P, X, y, V, 0.6, drop)
     g = _gpu(cfg, P, D, V)
+    g.gemm_precision = gemm_scheme
     assert g.paths()["options"], name
     if drop:
         packed = masks_from_recording(cfg, ref["rec"].masks, ref["enc"].shape[1], L - 1, B)

@@ -21,14 +21,28 @@ SHIPPED = {"dropout": {"embed": 0.3, "rnn": 0.3, "out": 0},
 
 
 def test_library_exports_every_declared_symbol():
+    """include/astk.h is the boundary: the product library exports exactly the symbols it declares outside its #ifdef ASTK_TEST_HOOKS
+    sections; the test instrumentation declared inside them (astk_conv_debug_*, astk_debug_*) exists in libastk_test.so only."""
     from ast_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "astk.h")).read()
-    declared = set(re.findall(r"\b(astk_[a-z0-9_]+)\s*\(", hdr))
+    hook_sections = re.findall(r"#ifdef ASTK_TEST_HOOKS(.*?)#endif", hdr, flags=re.S)
+    product_hdr = re.sub(r"#ifdef ASTK_TEST_HOOKS.*?#endif", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(astk_[a-z0-9_]+)\s*\(", product_hdr))
+    hooks = set(re.findall(r"\b(astk_[a-z0-9_]+)\s*\(", "\n".join(hook_sections)))
     assert len(declared) >= 25
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert hooks == set(_lib.TEST_HOOK_SIGNATURES) and hooks, hooks ^ set(_lib.TEST_HOOK_SIGNATURES)
     lib = _lib.load()                                   # raises if the .so or a symbol is missing
     for name in declared:
         assert isinstance(getattr(lib, name), ctypes._CFuncPtr)
+    for name in hooks:                                  # debug hooks are not part of the product ABI
+        assert not hasattr(lib, name), f"libastk.so exports the test hook {name}"
+    assert "astk_conv_debug_kill_units" in hooks
+    with _lib.load_test_hooks() as tlib:                # ... and the instrumented build has everything
+        for name in declared | hooks:
+            assert isinstance(getattr(tlib, name), ctypes._CFuncPtr)
+        assert _lib.load() is tlib
+    assert _lib.load() is lib
     assert lib.astk_version() >= 100
 
 
