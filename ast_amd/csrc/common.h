@@ -130,6 +130,48 @@ __device__ __forceinline__ HL8 split8(const float4& a, const float4& b, float sc
   ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, (A).lo), __builtin_bit_cast(h16x8, (W).hi), ACC, 0, 0, 0);          \
   ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, (A).hi), __builtin_bit_cast(h16x8, (W).lo), ACC, 0, 0, 0);          \
   ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, (A).hi), __builtin_bit_cast(h16x8, (W).hi), ACC, 0, 0, 0);
+// ---- bf16x3 products (device side; gemm.hip describes the scheme): an f32 value is split into three bf16 terms, x = hi + mid + lo
+// (round-to-nearest-even each: the three terms represent every normal f32 value EXACTLY, no scale needed: bf16 has f32's exponent
+// range), and a product is summed from the six largest term products on the bf16 MFMAs with f32 accumulation (the dropped ones are
+// <= 2^-26 of the product).
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+// v_cvt_pk_bf16_f32 (round-to-nearest-even), through the compiler's own lowering of the vector conversion -- NOT inline asm: behind an
+// asm statement hipcc does not know that a vector-ALU instruction wrote the register and inserts ONE wait state in front of an MFMA
+// that reads it where the hardware needs TWO (the MFMA then reads the register's previous content: seen as run-to-run varying errors
+// of the h = 64 recurrence kernels, whose last conversion sits directly in front of the first MFMA).
+__device__ __forceinline__ unsigned cvt_pk_bf16_f32(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32pair){lo, hi}, b16x2));
+}
+// two values -> one dword of each plane (element 0 in the low half): 9 vector-ALU instructions (three v_cvt_pk_bf16_f32, two shifts and two
+// ands to widen the packed terms again, two v_pk_add_f32 for the residuals)
+__device__ __forceinline__ void split2b(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = cvt_pk_bf16_f32(x0, x1);
+  const f32pair r = (f32pair){x0, x1} - (f32pair){__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+  mid = cvt_pk_bf16_f32(r[0], r[1]);
+  const f32pair q = r - (f32pair){__uint_as_float(mid << 16), __uint_as_float(mid & 0xffff0000u)};
+  lo = cvt_pk_bf16_f32(q[0], q[1]);
+}
+// eight values (two float4: k = 0..3 and 4..7 of a lane's slice of a v_mfma_f32_16x16x32_bf16 operand) -> hi / mid / lo fragments
+struct HML8 { u32q hi, mid, lo; };
+__device__ __forceinline__ HML8 split8b(const float4& a, const float4& b) {
+  HML8 o;
+  unsigned h, m, l;
+  split2b(a.x, a.y, h, m, l); o.hi.x = h; o.mid.x = m; o.lo.x = l;
+  split2b(a.z, a.w, h, m, l); o.hi.y = h; o.mid.y = m; o.lo.y = l;
+  split2b(b.x, b.y, h, m, l); o.hi.z = h; o.mid.z = m; o.lo.z = l;
+  split2b(b.z, b.w, h, m, l); o.hi.w = h; o.mid.w = m; o.lo.w = l;
+  return o;
+}
+#define MFMA_B16_(ACC, X, Y) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b16x8, X), __builtin_bit_cast(b16x8, Y), ACC, 0, 0, 0);
+// acc += A B over 32 k on v_mfma_f32_16x16x32_bf16, six term products (smallest first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi)
+#define MFMA32B(ACC, A, W)        \
+  MFMA_B16_(ACC, (A).lo, (W).hi)  \
+  MFMA_B16_(ACC, (A).hi, (W).lo)  \
+  MFMA_B16_(ACC, (A).mid, (W).mid) \
+  MFMA_B16_(ACC, (A).mid, (W).hi) \
+  MFMA_B16_(ACC, (A).hi, (W).mid) \
+  MFMA_B16_(ACC, (A).hi, (W).hi)
 // The power of two (as a float) that brings an absolute maximum into [2^14, 2^15), and its reciprocal; 1 for a zero maximum.
 __device__ __forceinline__ float pow2_scale_for(float amax, float& inv) {
   const int e = (int)(__float_as_uint(amax) >> 23) & 0xff;

@@ -116,18 +116,52 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+// two values -> one dword of each plane (element 0 in the low half).  (Inline asm is safe HERE: the planes go to LDS, no MFMA reads a
+// converted register directly -- see common.h cvt_pk_bf16_f32 for where it is not.)
+#ifndef ASTK_GEMM_SPLIT_ASM
+#define ASTK_GEMM_SPLIT_ASM 1
+#endif
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+#if ASTK_GEMM_SPLIT_ASM
   unsigned r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
+#else
+  return cvt_pk_bf16_f32(lo, hi);
+#endif
 }
-// two values -> one dword of each plane (element 0 in the low half)
+// ASTK_GEMM_SPLIT_ASM == 2: the residuals through v_dot2c_f32_bf16 -- r0 = x0 + hi_pk . (-1, 0), r1 = x1 + hi_pk . (0, -1): the dot
+// product reads the packed bf16 terms in place, so the two instructions that widen them again (shift, and) disappear: 7 vector-ALU
+// instructions per pair of values instead of 11.  Exact (the result is representable: scratch/dot2_split_probe.hip checks 1M values bit
+// for bit).  The (-1, 0) / (0, -1) selectors must come from REGISTERS: as literals hipcc folds them into inline constants that the
+// hardware reads differently (the probe's second column).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned opaque_const(unsigned v) {
+  unsigned r;
+  asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "i"(v));
+  return r;
+}
+__device__ __forceinline__ void split2_dot(float x0, float x1, unsigned m0, unsigned m1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  // (the conversions through the compiler's own lowering, not inline asm: a dot instruction that reads a register an asm statement wrote
+  //  gets no hazard protection from hipcc -- wrong results, seen)
+  hi = cvt_pk_bf16_f32(x0, x1);
+  const bf16x2_t h = __builtin_bit_cast(bf16x2_t, hi), s0 = __builtin_bit_cast(bf16x2_t, m0), s1 = __builtin_bit_cast(bf16x2_t, m1);
+  const float r0 = __builtin_amdgcn_fdot2_f32_bf16(h, s0, x0, false), r1 = __builtin_amdgcn_fdot2_f32_bf16(h, s1, x1, false);
+  mid = cvt_pk_bf16_f32(r0, r1);
+  const bf16x2_t m = __builtin_bit_cast(bf16x2_t, mid);
+  const float q0 = __builtin_amdgcn_fdot2_f32_bf16(m, s0, r0, false), q1 = __builtin_amdgcn_fdot2_f32_bf16(m, s1, r1, false);
+  lo = cvt_pk_bf16_f32(q0, q1);
+}
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+#if ASTK_GEMM_SPLIT_ASM
   hi = cvt_pk_bf16(x0, x1);
   const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
   mid = cvt_pk_bf16(r0, r1);
   const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
   lo = cvt_pk_bf16(s0, s1);
+#else
+  split2b(x0, x1, hi, mid, lo);
+#endif
 }
 // The power of two that brings an operand's absolute maximum into [2^14, 2^15), as the biased exponent of a float (amax: the word
 // gemm_absmax left: launch generation in the high half, the maximum's float bits in the low half; null or zero maximum: 1.0).
@@ -170,12 +204,21 @@ struct Stager {
   int kcur;           // first k of the tile the next load() fetches
   int lds;            // float offset of this thread's first LDS write
   float scl;          // fp16x2: the operand's power-of-two scale
+  unsigned sel0, sel1;  // bf16x3 (dot2 form of the split): the packed bf16 selectors (-1, 0) and (0, -1), in registers
+  int row0_edge;      // KR: 1 when this tile reaches past the operand's last column (uniform)
+  int nvc;            // KR, dot2 form: how many of this thread's 4 columns exist (1..4).  The dot product couples the two values of a pair
+                      // (0 x NaN = NaN), so a padding column -- uninitialised memory, by the ABI -- must not reach it next to a real one
 
   // row0 / nrows: the tile's first M (N) index and the operand's M (N) extent; [kbeg, kend): this workgroup's K range.
   // Leading dimensions are multiples of 4 and >= the extent, so a float4 at any multiple of 4 below round_up(extent, 4)
   // stays inside its row.
   __device__ __forceinline__ void init(const MatView& v, int row0, int nrows, int kbeg, int kend, int tid) {
     kcur = kbeg;
+    row0_edge = row0 + TL > nrows ? 1 : 0;
+    nvc = 4;
+#if ASTK_GEMM_SPLIT_ASM == 2
+    if constexpr (PREC == PREC_BF16X3) { sel0 = opaque_const(0x0000bf80u); sel1 = opaque_const(0xbf800000u); }
+#endif
     if (RK) {
       a = tid % KQ;
       b = tid / KQ;
@@ -197,6 +240,7 @@ struct Stager {
       for (int p = 0; p < NP; ++p)
         voff[p] = (unsigned)(((long)(b + RP * p) * (TWOLVL ? v.st : v.ld) + col) * 4);
       if (TWOLVL) { tgrp = kbeg / v.tn; trem = kbeg % v.tn; tcol = col; }
+      nvc = nrows - col;
       lds = b * LD_KR + 4 * a;
     }
   }
@@ -314,8 +358,18 @@ struct Stager {
 #if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 1)      // timing experiment: no split arithmetic
         h0 = __float_as_uint(r[p].x); m0 = __float_as_uint(r[p].y); l0 = h0; h1 = __float_as_uint(r[p].z); m1 = __float_as_uint(r[p].w); l1 = h1;
 #else
+#if ASTK_GEMM_SPLIT_ASM == 2
+        if (!RK && __builtin_amdgcn_readfirstlane((int)(row0_edge)) != 0) {      // (uniform: only the tile at the operand's edge pays)
+          if (nvc < 2) r[p].y = 0.f;
+          if (nvc < 3) r[p].z = 0.f;
+          if (nvc < 4) r[p].w = 0.f;
+        }
+        split2_dot(r[p].x, r[p].y, sel0, sel1, h0, m0, l0);
+        split2_dot(r[p].z, r[p].w, sel0, sel1, h1, m1, l1);
+#else
         split2(r[p].x, r[p].y, h0, m0, l0);
         split2(r[p].z, r[p].w, h1, m1, l1);
+#endif
 #endif
         *reinterpret_cast<uint2*>(S + off) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(S + PL + off) = make_uint2(m0, m1);

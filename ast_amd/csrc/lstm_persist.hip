@@ -136,8 +136,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
 // arrive (scale 2^10: |h| < 1 and a dropped-out input is at most 1 / (1 - p)), and 32 k of a product are three
 // v_mfma_f32_16x16x32_f16 of 16 cycles instead of eight v_mfma_f32_16x16x4_f32 of 32: the matrix part of a step's critical path drops
 // from 0.93 us to 0.18 us at the same 2^-22 product accuracy as the batched GEMMs (gemm.hip).
-// X2 is a template parameter of both kernels: the launchers pick it from astk_set_gemm_precision (fp16x2 mode only; bf16x3 / f32 modes run
-// the exact-f32 MFMAs), so that one process can time the step under every arithmetic.
+// bf16x3 form (XS = 3): the same structure with THREE bf16 terms per value and six v_mfma_f32_16x16x32_bf16 per 32 k (common.h:
+// split8b / MFMA32B): every f32 weight and activation is represented exactly (no scales: bf16 has f32's exponent range), a product is
+// exact to 2^-26 -- at least the accuracy of the f32 MFMA chain -- at 6 x 16 cycles per 32 k instead of 8 x 32.  The resident weights take
+// 1.5 x the registers of the f32 fragments (192 per lane at h = 256): shapes whose slices do not fit (h = 512) keep the f32 MFMAs.
+// XS (0 f32 MFMAs, 2 fp16x2, 3 bf16x3) is a template parameter of both kernels: the launchers pick it from the arithmetic in force for the call
+// (descriptor precision, else the process default), so that one process can time the step under every arithmetic.
 constexpr float ACT_SCALE = 1024.f, ACT_SCALE_INV = 1.f / 1024.f;
 // four independent accumulators (the gates) interleaved, three term products of 32 k each
 #define MFMA32HG(ACC, A, W)                                                                                                     \
@@ -147,6 +151,23 @@ constexpr float ACT_SCALE = 1024.f, ACT_SCALE_INV = 1.f / 1024.f;
     ACC[g_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, (A).hi), __builtin_bit_cast(h16x8, (W)[g_].lo), ACC[g_], 0, 0, 0); \
   _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                                                              \
     ACC[g_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, (A).hi), __builtin_bit_cast(h16x8, (W)[g_].hi), ACC[g_], 0, 0, 0);
+// bf16x3: four independent accumulators (the gates) interleaved, six term products of 32 k each (smallest first)
+#define MFMA32BG_T_(ACC, AP, W, WP) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) { MFMA_B16_(ACC[g_], AP, (W)[g_].WP) }
+#define MFMA32BG(ACC, A, W)          \
+  MFMA32BG_T_(ACC, (A).lo, W, hi)    \
+  MFMA32BG_T_(ACC, (A).hi, W, lo)    \
+  MFMA32BG_T_(ACC, (A).mid, W, mid)  \
+  MFMA32BG_T_(ACC, (A).mid, W, hi)   \
+  MFMA32BG_T_(ACC, (A).hi, W, mid)   \
+  MFMA32BG_T_(ACC, (A).hi, W, hi)
+// fragment type and helpers of a split scheme XS (2: fp16 hi / lo behind a scale, 3: bf16 hi / mid / lo)
+template <int XS> struct FragOf { typedef HL8 type; };
+template <> struct FragOf<3> { typedef HML8 type; };
+template <int XS>
+__device__ __forceinline__ typename FragOf<XS>::type split_frag(const float4& a, const float4& b, float scl) {
+  if constexpr (XS == 3) return split8b(a, b);
+  else return split8(a, b, scl);
+}
 // workgroup-wide maximum of a per-thread value (256 threads; `red` = 4 floats of LDS scratch; ends with a barrier)
 __device__ __forceinline__ float wg_max(float m, float* red) {
 #pragma unroll
@@ -240,7 +261,7 @@ __device__ __forceinline__ float4 frag_vals(const u32x4& g) {
 // Code shape: everything a wait depends on is UNCONDITIONAL inside the loop (HAS_UP is a template parameter, step 0 is
 // peeled, prefetch indices are clamped instead of guarded): a conditionally issued load becomes a phi of "old registers /
 // load result", and hipcc then copies the result right behind the load, i.e. waits for it at the point of issue.
-template <int KB, bool HAS_UP, bool X2>
+template <int KB, bool HAS_UP, int XS>
 __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& c, float* red0, float* red1) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -256,25 +277,30 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
   // (the k order inside a product is free as long as activations and weights agree); one scale for the workgroup's whole slice.
   // Two sweeps over the slice (maximum, then split): holding the f32 values and their fragments at once would take 512 registers.
   constexpr int NPR = (KB + 1) / 2;
+  constexpr bool X2 = XS != 0;          // a split scheme (16-bit MFMAs); XS == 2 additionally scales
+  typedef typename FragOf<XS>::type Frag;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float zscale = 1.f;
-  HL8 wlh[X2 ? NPR : 1][4], wuh[(X2 && HAS_UP) ? NPR : 1][4];
+  Frag wlh[X2 ? NPR : 1][4], wuh[(X2 && HAS_UP) ? NPR : 1][4];
   float4 wl[X2 ? 1 : KB][4], wu[(!X2 && HAS_UP) ? KB : 1][4];
   if constexpr (X2) {
-    float m = 0.f;
+    float wscl = 1.f;
+    if constexpr (XS == 2) {
+      float m = 0.f;
 #pragma unroll
-    for (int i = 0; i < KB; ++i)
+      for (int i = 0; i < KB; ++i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) { m = amax4f(m, wl_at(i, g)); if (HAS_UP) m = amax4f(m, wu_at(i, g)); }
-    float winv;
-    const float wscl = pow2_scale_for(wg_max(m, red0), winv);
-    zscale = winv * ACT_SCALE_INV;
+        for (int g = 0; g < 4; ++g) { m = amax4f(m, wl_at(i, g)); if (HAS_UP) m = amax4f(m, wu_at(i, g)); }
+      float winv;
+      wscl = pow2_scale_for(wg_max(m, red0), winv);
+      zscale = winv * ACT_SCALE_INV;
+    }
 #pragma unroll
     for (int p = 0; p < NPR; ++p)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        wlh[p][g] = split8(wl_at(2 * p, g), 2 * p + 1 < KB ? wl_at(2 * p + 1, g) : zero4, wscl);
-        if constexpr (HAS_UP) wuh[p][g] = split8(wu_at(2 * p, g), 2 * p + 1 < KB ? wu_at(2 * p + 1, g) : zero4, wscl);
+        wlh[p][g] = split_frag<XS>(wl_at(2 * p, g), 2 * p + 1 < KB ? wl_at(2 * p + 1, g) : zero4, wscl);
+        if constexpr (HAS_UP) wuh[p][g] = split_frag<XS>(wu_at(2 * p, g), 2 * p + 1 < KB ? wu_at(2 * p + 1, g) : zero4, wscl);
       }
   } else {
 #pragma unroll
@@ -300,11 +326,11 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
   const int frag0 = (arow * h + 4 * q) * 4;   // byte offset of this lane's fragment row at step 0
   u32x4 gx[KB];
   float4 ax[KB];
-  HL8 axh[X2 ? NPR : 1];
+  Frag axh[X2 ? NPR : 1];
   auto take_x = [&]() {
     if constexpr (X2) {
 #pragma unroll
-      for (int p = 0; p < NPR; ++p) axh[p] = split8(ax[2 * p], 2 * p + 1 < KB ? ax[2 * p + 1] : zero4, ACT_SCALE);
+      for (int p = 0; p < NPR; ++p) axh[p] = split_frag<XS>(ax[2 * p], 2 * p + 1 < KB ? ax[2 * p + 1] : zero4, ACT_SCALE);
     }
   };
   // what only later launches read, stored half a step late
@@ -354,7 +380,9 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
       if constexpr (X2) {
         take_x();       // x_t (taken at W_{t-1}) is split HERE, in front of the wait for h, not between that wait and the recurrent MFMAs
 #pragma unroll
-        for (int p = 0; p < NPR; ++p) { MFMA32HG(acc, axh[p], wuh[p]) }
+        for (int p = 0; p < NPR; ++p) {
+          if constexpr (XS == 3) { MFMA32BG(acc, axh[p], wuh[p]) } else { MFMA32HG(acc, axh[p], wuh[p]) }
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < KB; ++i) { MFMA4G(acc, ax[i], wu[i]) }
@@ -382,8 +410,8 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
       if constexpr (X2) {
 #pragma unroll
         for (int p = 0; p < NPR; ++p) {
-          const HL8 ah = split8(frag_vals(gh[2 * p]), 2 * p + 1 < KB ? frag_vals(gh[2 * p + 1 < KB ? 2 * p + 1 : 0]) : zero4, ACT_SCALE);
-          MFMA32HG(acc, ah, wlh[p])
+          const Frag ah = split_frag<XS>(frag_vals(gh[2 * p]), 2 * p + 1 < KB ? frag_vals(gh[2 * p + 1 < KB ? 2 * p + 1 : 0]) : zero4, ACT_SCALE);
+          if constexpr (XS == 3) { MFMA32BG(acc, ah, wlh[p]) } else { MFMA32HG(acc, ah, wlh[p]) }
         }
       } else {
 #pragma unroll
@@ -419,7 +447,7 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         z[g] = rd[(0 * 4 + g) * 256 + src] + rd[(1 * 4 + g) * 256 + src] + rd[(2 * 4 + g) * 256 + src] + rd[(3 * 4 + g) * 256 + src];
-      if constexpr (X2) {
+      if constexpr (XS == 2) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) z[g] *= zscale;      // 1 / (weight scale x activation scale)
       }
@@ -448,14 +476,14 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
 #undef TICK
 }
 
-template <int KB, bool X2>
+template <int KB, int XS>
 __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_g(PFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float red[2][4 * 4 * 256];
   // (a COPY, not a reference into the kernel-argument block: fields read through a dynamically indexed reference are re-loaded behind
   //  every global store of the step loop -- the stores might alias them -- and each re-load is a scalar-cache round trip on the chain)
   const PCellF c = a.c[blockIdx.z];
-  if (c.layer > 0) lstm_fwd_steps<KB, true, X2>(a, c, red[0], red[1]);
-  else lstm_fwd_steps<KB, false, X2>(a, c, red[0], red[1]);
+  if (c.layer > 0) lstm_fwd_steps<KB, true, XS>(a, c, red[0], red[1]);
+  else lstm_fwd_steps<KB, false, XS>(a, c, red[0], red[1]);
 }
 
 
@@ -484,7 +512,7 @@ constexpr int PR_RING = 4;
 constexpr bool bwd_sentinel(int KB) { return ASTK_BWD_SENTINEL && KB <= ASTK_BWD_SENTINEL_MAXKB; }
 // HAS_UP: the cell has a layer above it in this stack (a template parameter so that the loads of that layer's partials are unconditional
 // code: a conditionally issued load becomes a phi whose copy makes hipcc wait for the load where it is issued)
-template <int KB, bool HAS_UP, bool X2>
+template <int KB, bool HAS_UP, int XS>
 __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCellB& c, float (*dzS2)[16 * 64], int* s_ok1, int& s_ok2) {
   constexpr int NS = 4 * KB;          // slices of a cell = 16x16 output tiles of a product = partial tiles per consumer
   float* const dzS = dzS2[0];
@@ -509,22 +537,27 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     return has_down ? *reinterpret_cast<const float4*>(c.WuT + (long)(16 * (wave * KB + nt) + r16) * K + 64 * j + 16 * s4 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   // X2: fp16 hi / lo fragments behind one power-of-two scale per workgroup (see the forward kernel); the 64 gate columns are two 32-k operands
-  HL8 wlh[X2 ? KB : 1][2], wdh[X2 ? KB : 1][2];
+  constexpr bool X2 = XS != 0;          // a split scheme (16-bit MFMAs); XS == 2 additionally scales
+  typedef typename FragOf<XS>::type Frag;
+  Frag wlh[X2 ? KB : 1][2], wdh[X2 ? KB : 1][2];
   float4 wl[X2 ? 1 : KB][4], wd[X2 ? 1 : KB][4];
   float winv = 1.f;
   if constexpr (X2) {
-    float m = 0.f;
+    float wscl = 1.f;
+    if constexpr (XS == 2) {
+      float m = 0.f;
 #pragma unroll
-    for (int nt = 0; nt < KB; ++nt)
+      for (int nt = 0; nt < KB; ++nt)
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) m = amax4f(amax4f(m, wl_at(nt, s4)), wd_at(nt, s4));
-    const float wscl = pow2_scale_for(wg_max(m, dzS), winv);
+        for (int s4 = 0; s4 < 4; ++s4) m = amax4f(amax4f(m, wl_at(nt, s4)), wd_at(nt, s4));
+      wscl = pow2_scale_for(wg_max(m, dzS), winv);
+    }
 #pragma unroll
     for (int nt = 0; nt < KB; ++nt)
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
-        wlh[nt][p] = split8(wl_at(nt, 2 * p), wl_at(nt, 2 * p + 1), wscl);
-        wdh[nt][p] = split8(wd_at(nt, 2 * p), wd_at(nt, 2 * p + 1), wscl);
+        wlh[nt][p] = split_frag<XS>(wl_at(nt, 2 * p), wl_at(nt, 2 * p + 1), wscl);
+        wdh[nt][p] = split_frag<XS>(wd_at(nt, 2 * p), wd_at(nt, 2 * p + 1), wscl);
       }
   } else {
 #pragma unroll
@@ -708,14 +741,17 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     for (int s4 = 0; s4 < 4; ++s4) af[s4] = *reinterpret_cast<const float4*>(&dzT[r16 * 64 + 16 * s4 + 4 * q]);
     // X2: dz is unbounded: its scale is taken from this step's tile (every wave holds the whole 16 x 64 tile across its lanes)
     float pscale = 1.f;       // 1 / (weight scale x dz scale), applied to the partial sums
-    HL8 afh[2];
-    if constexpr (X2) {
+    Frag afh[2];
+    if constexpr (XS == 2) {
       const float m = wave_max_nonneg(amax4f(amax4f(amax4f(amax4f(0.f, af[0]), af[1]), af[2]), af[3]));
       float ainv;
       const float ascl = pow2_scale_for(m, ainv);
       pscale = ainv * winv;
       afh[0] = split8(af[0], af[1], ascl);
       afh[1] = split8(af[2], af[3], ascl);
+    } else if constexpr (XS == 3) {      // bf16 has f32's exponent range: no scale, however small or large dz is
+      afh[0] = split8b(af[0], af[1]);
+      afh[1] = split8b(af[2], af[3]);
     }
     // ---- product 1: partial dh_rec for every slice of this cell -> write-through stores
     {
@@ -723,10 +759,13 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
 #pragma unroll
       for (int nt = 0; nt < KB; ++nt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (X2) {
+        if constexpr (XS == 2) {
           MFMA32H(acc, afh[0], wlh[nt][0])
           MFMA32H(acc, afh[1], wlh[nt][1])
           acc *= pscale;
+        } else if constexpr (XS == 3) {
+          MFMA32B(acc, afh[0], wlh[nt][0])
+          MFMA32B(acc, afh[1], wlh[nt][1])
         } else {
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc, af[s4], wl[nt][s4]) }
@@ -746,10 +785,13 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
 #pragma unroll
       for (int nt = 0; nt < KB1; ++nt) {
         acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (X2) {
+        if constexpr (XS == 2) {
           MFMA32H(acc2[nt], afh[0], wdh[nt][0])
           MFMA32H(acc2[nt], afh[1], wdh[nt][1])
           acc2[nt] *= pscale;
+        } else if constexpr (XS == 3) {
+          MFMA32B(acc2[nt], afh[0], wdh[nt][0])
+          MFMA32B(acc2[nt], afh[1], wdh[nt][1])
         } else {
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc2[nt], af[s4], wd[nt][s4]) }
@@ -772,10 +814,13 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
 #pragma unroll
       for (int nt = KB1; nt < KB; ++nt) {
         acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (X2) {
+        if constexpr (XS == 2) {
           MFMA32H(acc2[nt], afh[0], wdh[nt][0])
           MFMA32H(acc2[nt], afh[1], wdh[nt][1])
           acc2[nt] *= pscale;
+        } else if constexpr (XS == 3) {
+          MFMA32B(acc2[nt], afh[0], wdh[nt][0])
+          MFMA32B(acc2[nt], afh[1], wdh[nt][1])
         } else {
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc2[nt], af[s4], wd[nt][s4]) }
@@ -806,15 +851,15 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
 #undef TICK
 }
 
-template <int KB, bool X2>
+template <int KB, int XS>
 __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
   // (two copies of the dz tile, used alternately: with the sentinel hand-off the step's ONE barrier sits between a tile's writes and its
   //  reads, and only the copy keeps a wave that is a step ahead from writing into what a slower wave still reads; the flags likewise)
   __shared__ __attribute__((aligned(16))) float dzS2[2][16 * 64];
   __shared__ int s_ok1[2], s_ok2;
   const PCellB c = a.c[blockIdx.z];      // a copy (see lstm_persist_fwd_g)
-  if (c.PD_up != nullptr) lstm_bwd_rs_steps<KB, true, X2>(a, c, dzS2, s_ok1, s_ok2);
-  else lstm_bwd_rs_steps<KB, false, X2>(a, c, dzS2, s_ok1, s_ok2);
+  if (c.PD_up != nullptr) lstm_bwd_rs_steps<KB, true, XS>(a, c, dzS2, s_ok1, s_ok2);
+  else lstm_bwd_rs_steps<KB, false, XS>(a, c, dzS2, s_ok1, s_ok2);
 }
 
 }  // namespace
@@ -885,21 +930,19 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
     ASTK_TRY(fill_u32_segments(f, 0xffffffffu, s));
   }
   ProfScope prof(PROF_CELL, s);
-  if (gemm_precision_mode() == 0) {       // fp16x2 mode: the recurrences' products run as two-term fp16 splits too
-    switch (h) {
-      case 64: hipLaunchKernelGGL((lstm_persist_fwd_g<1, true>), grid, blk, 0, s, a); break;
-      case 128: hipLaunchKernelGGL((lstm_persist_fwd_g<2, true>), grid, blk, 0, s, a); break;
-      case 256: hipLaunchKernelGGL((lstm_persist_fwd_g<4, true>), grid, blk, 0, s, a); break;
-      default: hipLaunchKernelGGL((lstm_persist_fwd_g<8, true>), grid, blk, 0, s, a); break;
-    }
-  } else {
-    switch (h) {
-      case 64: hipLaunchKernelGGL((lstm_persist_fwd_g<1, false>), grid, blk, 0, s, a); break;
-      case 128: hipLaunchKernelGGL((lstm_persist_fwd_g<2, false>), grid, blk, 0, s, a); break;
-      case 256: hipLaunchKernelGGL((lstm_persist_fwd_g<4, false>), grid, blk, 0, s, a); break;
-      default: hipLaunchKernelGGL((lstm_persist_fwd_g<8, false>), grid, blk, 0, s, a); break;
-    }
+  // arithmetic of the recurrences' products: the mode in force for this call (fp16x2: two-term fp16 splits; bf16x3: three-term bf16 splits
+  // where the weight fragments fit the registers, h <= 256; f32, or bf16x3 at h = 512: f32 MFMAs).  ASTK_LSTM_X3=0 keeps f32 MFMAs under bf16x3.
+  const int mode = gemm_precision_mode();
+  static const bool x3_off = getenv("ASTK_LSTM_X3") && getenv("ASTK_LSTM_X3")[0] == '0';
+  const int xs = mode == 0 ? 2 : (mode == 1 && h <= 256 && !x3_off ? 3 : 0);
+#define ASTK_LSTM_FWD_(KB_, XS_) hipLaunchKernelGGL((lstm_persist_fwd_g<KB_, XS_>), grid, blk, 0, s, a)
+  switch (h) {
+    case 64: if (xs == 2) ASTK_LSTM_FWD_(1, 2); else if (xs == 3) ASTK_LSTM_FWD_(1, 3); else ASTK_LSTM_FWD_(1, 0); break;
+    case 128: if (xs == 2) ASTK_LSTM_FWD_(2, 2); else if (xs == 3) ASTK_LSTM_FWD_(2, 3); else ASTK_LSTM_FWD_(2, 0); break;
+    case 256: if (xs == 2) ASTK_LSTM_FWD_(4, 2); else if (xs == 3) ASTK_LSTM_FWD_(4, 3); else ASTK_LSTM_FWD_(4, 0); break;
+    default: if (xs == 2) ASTK_LSTM_FWD_(8, 2); else ASTK_LSTM_FWD_(8, 0); break;
   }
+#undef ASTK_LSTM_FWD_
   ASTK_LAUNCH_CHECK();
   return 0;
 }
@@ -940,21 +983,17 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   }
   dim3 grid(h / 16, nbt, ncells), blk(256);
   ProfScope prof(PROF_CELL, s);
-  if (gemm_precision_mode() == 0) {
-    switch (h) {
-      case 64: hipLaunchKernelGGL((lstm_persist_bwd_rs<1, true>), grid, blk, 0, s, a); break;
-      case 128: hipLaunchKernelGGL((lstm_persist_bwd_rs<2, true>), grid, blk, 0, s, a); break;
-      case 256: hipLaunchKernelGGL((lstm_persist_bwd_rs<4, true>), grid, blk, 0, s, a); break;
-      default: hipLaunchKernelGGL((lstm_persist_bwd_rs<8, true>), grid, blk, 0, s, a); break;
-    }
-  } else {
-    switch (h) {
-      case 64: hipLaunchKernelGGL((lstm_persist_bwd_rs<1, false>), grid, blk, 0, s, a); break;
-      case 128: hipLaunchKernelGGL((lstm_persist_bwd_rs<2, false>), grid, blk, 0, s, a); break;
-      case 256: hipLaunchKernelGGL((lstm_persist_bwd_rs<4, false>), grid, blk, 0, s, a); break;
-      default: hipLaunchKernelGGL((lstm_persist_bwd_rs<8, false>), grid, blk, 0, s, a); break;
-    }
+  const int mode = gemm_precision_mode();      // (see lstm_persist_fwd_launch)
+  static const bool x3_off = getenv("ASTK_LSTM_X3") && getenv("ASTK_LSTM_X3")[0] == '0';
+  const int xs = mode == 0 ? 2 : (mode == 1 && h <= 256 && !x3_off ? 3 : 0);
+#define ASTK_LSTM_BWD_(KB_, XS_) hipLaunchKernelGGL((lstm_persist_bwd_rs<KB_, XS_>), grid, blk, 0, s, a)
+  switch (h) {
+    case 64: if (xs == 2) ASTK_LSTM_BWD_(1, 2); else if (xs == 3) ASTK_LSTM_BWD_(1, 3); else ASTK_LSTM_BWD_(1, 0); break;
+    case 128: if (xs == 2) ASTK_LSTM_BWD_(2, 2); else if (xs == 3) ASTK_LSTM_BWD_(2, 3); else ASTK_LSTM_BWD_(2, 0); break;
+    case 256: if (xs == 2) ASTK_LSTM_BWD_(4, 2); else if (xs == 3) ASTK_LSTM_BWD_(4, 3); else ASTK_LSTM_BWD_(4, 0); break;
+    default: if (xs == 2) ASTK_LSTM_BWD_(8, 2); else ASTK_LSTM_BWD_(8, 0); break;
   }
+#undef ASTK_LSTM_BWD_
   ASTK_LAUNCH_CHECK();
   return 0;
 }

@@ -8,8 +8,11 @@ def vp(t): return C.c_void_p(t.data_ptr())
 tot = 0.0
 def run(layout, M, N, K, mode=0):
     global tot
-    a = torch.rand(K if layout == 2 else M, M if layout == 2 else K, device='cuda') + 0.5
-    b = torch.rand(N if layout == 0 else K, K if layout == 0 else N, device='cuda') + 0.5
+    mk = (lambda *sh: torch.randn(*sh, device='cuda')) if os.environ.get("DATA") == "randn" else (lambda *sh: torch.rand(*sh, device='cuda') + 0.5)
+    if os.environ.get("DATA") == "relu":      # half zeros, like the activations behind a ReLU / a dropout mask
+        mk = lambda *sh: torch.relu(torch.randn(*sh, device='cuda'))
+    a = mk(K if layout == 2 else M, M if layout == 2 else K)
+    b = mk(N if layout == 0 else K, K if layout == 0 else N)
     c = torch.zeros(M, N, device='cuda')
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     def f():

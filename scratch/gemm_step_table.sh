@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/gemm_step
 rm -rf $OUT && mkdir -p $OUT
 export ASTK_GEMM_LOG=1
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-alt-precisions --no-also ${BENCH_ARGS} > $OUT/run.log 2>&1
 python3 - <<'PY'
 import csv, glob, re
 f = sorted(glob.glob('gpurun_out/gemm_step/**/*kernel_trace.csv', recursive=True))[-1]
