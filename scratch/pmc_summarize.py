@@ -13,6 +13,8 @@ import sys
 root = sys.argv[1]
 steps = int(sys.argv[2])          # train steps profiled in each pass (all of them, warm-ups included)
 stamp = sys.argv[3] if len(sys.argv) > 3 else ""      # build / time the passes were taken on (goes into the `source` strings)
+rnd = sys.argv[4] if len(sys.argv) > 4 else "r3"      # round prefix of the files under profiles/ the `source` strings name
+scheme = sys.argv[5] if len(sys.argv) > 5 else None   # arithmetic scheme of the passes (round 4 on: gemm_traffic.json is keyed by scheme)
 
 
 def short(name):
@@ -71,15 +73,16 @@ json.dump(res, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1)
 # what bench.py reads for roofline.traffic / roofline_scan.traffic
 K = res["kernels"]
 gem = sum(K[k].get("hbm_bytes_per_step", 0) for k in ("gemm_f32_kernel", "k_zero_split_tiles", "k_absmax") if k in K)
-json.dump({"hbm_bytes_per_step": gem,
-           "source": "profiles/r3_pmc_summary.json (" + stamp + "): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of gemm_f32_kernel + k_absmax + k_zero_split_tiles per "
-                     "train step, separate rocprofv3 --pmc passes; the memory-side counters include Infinity-Cache hits (MI355X_MICROARCH.md, HBM)"},
-          open(os.path.join(root, "gemm_traffic.json"), "w"), indent=1)
+entry = {"hbm_bytes_per_step": gem,
+         "mfma_pipe_busy_frac": K.get("gemm_f32_kernel", {}).get("mfma_pipe_busy_frac"),
+         "source": "profiles/" + rnd + "_pmc_summary.json (" + stamp + "): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of gemm_f32_kernel + k_absmax + k_zero_split_tiles per "
+                   "train step, separate rocprofv3 --pmc passes; the memory-side counters include Infinity-Cache hits (MI355X_MICROARCH.md, HBM)"}
+json.dump({scheme: entry} if scheme else entry, open(os.path.join(root, "gemm_traffic.json"), "w"), indent=1)
 if "decoder_persist_fwd" in K and "decoder_persist_bwd" in K:
     scans = 78
     dec = K["decoder_persist_fwd"].get("hbm_bytes_per_dispatch", 0) + K["decoder_persist_bwd"].get("hbm_bytes_per_dispatch", 0)
     json.dump({"hbm_bytes_per_launch": round(dec / 2), "hbm_bytes_per_scan": round(dec / scans),
-               "source": "profiles/r3_pmc_summary.json (" + stamp + "): FETCH_SIZE x 2 + WRITE_SIZE of decoder_persist_fwd and decoder_persist_bwd, everything "
+               "source": "profiles/" + rnd + "_pmc_summary.json (" + stamp + "): FETCH_SIZE x 2 + WRITE_SIZE of decoder_persist_fwd and decoder_persist_bwd, everything "
                          "the two launches move: per launch = mean of the two (39 scans each), per scan = their sum / 78 (an upper bound for the scan phase)"},
               open(os.path.join(root, "attn_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
