@@ -332,6 +332,8 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
   if (has_cell) {
     for (int i = tid; i < 16 * a.L; i += 256) yS[i] = a.y[(long)min(cell_bt * 16 + i / a.L, B - 1) * a.L + (i % a.L)];
     for (int i = tid; i < S; i += 256) flagS[i] = a.use_truth[i];
+  } else if (has_ce) {
+    for (int i = tid; i < S; i += 256) flagS[i] = a.use_truth[i];     // (which steps feed their argmax back: decides when P6 may be deferred)
   }
   // ---------------- resident slices of enc_states and encA = enc Wa in LDS: rows [t0, t1) of batch row att_b
   const int t0 = att_sp * a.chunk, t1 = min(T, t0 + a.chunk);
@@ -391,6 +393,46 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
   long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define TQ(i) if (timing) { const long long now_ = wall_clock64(); tq[i] += now_ - tlast; tlast = now_; }
 #define TICK(i) if (timing) { const long long now_ = wall_clock64(); tk[i] += now_ - tlast; tlast = now_; }
+  int p6_pending = -1;
+  auto run_p6 = [&](const int s) -> bool {
+      const int bt = ce_rank, m0 = bt * 16;
+      if (!wg_wait_sh(CTR(PH_LOG, bt), a.ntile_v, s + 1, a.ab, &s_flag)) return false;
+      const int row = m0 + (tid >> 4), sub = tid & 15;       // 16 threads per row sweep the tiles
+      float mx = -INFINITY, se = 0.f, xt = 0.f;
+      int mi = 0x7fffffff;
+      if (row < B)
+        for (int k = sub; k < a.ntile_v; k += 16) {
+          const float4 cs = ldb128_sc1(r_ces, (((long)s * B + row) * a.ntile_v + k) * 4);
+          const float tm = cs.x, ts = cs.y, tx = cs.w;
+          const int ti = __float_as_int(cs.z);
+          const float nm = fmaxf(mx, tm);
+          se = se * expf(mx - nm) + ts * expf(tm - nm);
+          if (tm > mx || (tm == mx && ti < mi)) mi = ti;
+          mx = nm;
+          xt += tx;
+        }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        const float om = __shfl_xor(mx, o), os = __shfl_xor(se, o), ox = __shfl_xor(xt, o);
+        const int oi = __shfl_xor(mi, o);
+        const float nm = fmaxf(mx, om);
+        se = (mx == -INFINITY ? 0.f : se * expf(mx - nm)) + (om == -INFINITY ? 0.f : os * expf(om - nm));
+        if (om > mx || (om == mx && oi < mi)) mi = oi;
+        mx = nm;
+        xt += ox;
+      }
+      if (sub == 0 && row < B) {
+        const float lse = mx + logf(se);
+        const int tgt = a.ytgt[(long)row * a.L + s + 1];
+        const float w = a.cw ? a.cw[tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt)] : 1.f;
+        a.LSE[(long)s * B + row] = lse;
+        a.LOSSROWS[(long)s * B + row] = -(xt - lse) * w * a.inv_count;
+        sti_sc1(a.PRED + (long)s * B + row, mi);
+      }
+      publish_sh(CTR(PH_CE, bt), 0);
+      TICK(12)
+    return true;
+  };
   for (int s = 0; s < S; ++s) {
     // ================= P1: embed + LSTM cell =================
     if (has_cell) {
@@ -757,6 +799,10 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       if (tid < nrow) a.ALPHA[((long)s * B + b) * Tp + t0 + tid] = my_score;   // raw score, normalised by the backward (M, 1/L in ML)
       TICK(5)
     }
+    if (has_ce && p6_pending >= 0) {       // P6 of the previous step, deferred behind this step's attention partial (see P6 below)
+      if (!run_p6(p6_pending)) return;
+      p6_pending = -1;
+    }
     // ================= P3b: combine the nsplit partials of one batch row =================
     if (has_cmb) {
       const int b = cmb_b, bt = b / 16;
@@ -884,45 +930,19 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       TICK(11)
     }
     // ================= P6: cross-entropy combine per batch tile =================
+    // The CE workgroups also own attention items of the NEXT step's chain.  P6(s) ends ~4 us after h_{s+1} is there (it waits for the
+    // last logits tile), so run in program order it delayed those attention partials -- and with them their batch rows' combine, the
+    // whole batch tile's ht and every later step -- by 3.3 us per decoder step (phase stamps: the combine of row 31 waited 4.8 us for
+    // its partials, that of row 0 1.5 us).  Nothing on the chain needs P6(s) when step s+1 is teacher-forced (its token is the truth):
+    // it is then DEFERRED behind the workgroup's P3 of step s+1.  When step s+1 feeds the argmax back its cells wait for PH_CE(s)
+    // anyway and P6(s) runs in place (deferring it there would dead-lock: P3(s+1) waits for cells that wait for P6(s)).
     if (has_ce) {
-      const int bt = ce_rank, m0 = bt * 16;
-      if (!wg_wait_sh(CTR(PH_LOG, bt), a.ntile_v, s + 1, a.ab, &s_flag)) return;
-      const int row = m0 + (tid >> 4), sub = tid & 15;       // 16 threads per row sweep the tiles
-      float mx = -INFINITY, se = 0.f, xt = 0.f;
-      int mi = 0x7fffffff;
-      if (row < B)
-        for (int k = sub; k < a.ntile_v; k += 16) {
-          const float4 cs = ldb128_sc1(r_ces, (((long)s * B + row) * a.ntile_v + k) * 4);
-          const float tm = cs.x, ts = cs.y, tx = cs.w;
-          const int ti = __float_as_int(cs.z);
-          const float nm = fmaxf(mx, tm);
-          se = se * expf(mx - nm) + ts * expf(tm - nm);
-          if (tm > mx || (tm == mx && ti < mi)) mi = ti;
-          mx = nm;
-          xt += tx;
-        }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        const float om = __shfl_xor(mx, o), os = __shfl_xor(se, o), ox = __shfl_xor(xt, o);
-        const int oi = __shfl_xor(mi, o);
-        const float nm = fmaxf(mx, om);
-        se = (mx == -INFINITY ? 0.f : se * expf(mx - nm)) + (om == -INFINITY ? 0.f : os * expf(om - nm));
-        if (om > mx || (om == mx && oi < mi)) mi = oi;
-        mx = nm;
-        xt += ox;
-      }
-      if (sub == 0 && row < B) {
-        const float lse = mx + logf(se);
-        const int tgt = a.ytgt[(long)row * a.L + s + 1];
-        const float w = a.cw ? a.cw[tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt)] : 1.f;
-        a.LSE[(long)s * B + row] = lse;
-        a.LOSSROWS[(long)s * B + row] = -(xt - lse) * w * a.inv_count;
-        sti_sc1(a.PRED + (long)s * B + row, mi);
-      }
-      publish_sh(CTR(PH_CE, bt), 0);
-      TICK(12)
+      const bool defer = s + 1 < S && flagS[s + 1] != 0;
+      if (defer) p6_pending = s;
+      else if (!run_p6(s)) return;
     }
   }
+  if (has_ce && p6_pending >= 0) { if (!run_p6(p6_pending)) return; }
   if (a.tick_out && tid == 0 && has_att) {     // attention phase = hand-off satisfied -> partial published (10 ns ticks -> us)
     atomicAdd(&a.tick_out[wg], (float)tk_att * 0.01f / (float)S);
     if (wg == 0) atomicAdd(&a.tick_out[G], 1.0f);

@@ -512,8 +512,13 @@ constexpr int PR_RING = 4;
 constexpr bool bwd_sentinel(int KB) { return ASTK_BWD_SENTINEL && KB <= ASTK_BWD_SENTINEL_MAXKB; }
 // HAS_UP: the cell has a layer above it in this stack (a template parameter so that the loads of that layer's partials are unconditional
 // code: a conditionally issued load becomes a phi whose copy makes hipcc wait for the load where it is issued)
+// Row stride of the 16 x 64 dz tile in LDS: 68 floats, not 64.  Writers (unit u = tid >> 4, row r = tid & 15) and readers (row r16 = lane & 15,
+// k-quad q = lane >> 4) both move 16 bytes per lane with 16 consecutive lanes on 16 DIFFERENT rows of the same columns: with a 256-byte
+// row stride those 16 lanes sit on the same four banks (16-way conflicts on every access: 25.8 M SQ_LDS_BANK_CONFLICT cycles per launch
+// against 4.9 M in the forward kernel, round-3 PMC pass); 68 moves consecutive rows four banks on and the accesses are conflict-free.
+constexpr int DZ_LD = 68;
 template <int KB, bool HAS_UP, int XS>
-__device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCellB& c, float (*dzS2)[16 * 64], int* s_ok1, int& s_ok2) {
+__device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCellB& c, float (*dzS2)[16 * DZ_LD], int* s_ok1, int& s_ok2) {
   constexpr int NS = 4 * KB;          // slices of a cell = 16x16 output tiles of a product = partial tiles per consumer
   float* const dzS = dzS2[0];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -720,7 +725,7 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
       const float dcv = dh * g.w * (1.f - tc * tc) + dc_state;
       dz = make_float4(dcv * g.y * (1.f - g.x * g.x), dcv * g.x * g.y * (1.f - g.y), dcv * cp * g.z * (1.f - g.z), dh * tc * g.w * (1.f - g.w));
       dc_state = dcv * g.z;
-      *reinterpret_cast<float4*>(&dzT[r * 64 + 4 * u]) = dz;
+      *reinterpret_cast<float4*>(&dzT[r * DZ_LD + 4 * u]) = dz;
       dzmax = fmaxf(fmaxf(dzmax, fmaxf(fabsf(dz.x), fabsf(dz.y))), fmaxf(fabsf(dz.z), fabsf(dz.w)));   // (rows past B repeat row B-1)
     }
     TICK(3, t0)
@@ -738,7 +743,7 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     }
     float4 af[4];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) af[s4] = *reinterpret_cast<const float4*>(&dzT[r16 * 64 + 16 * s4 + 4 * q]);
+    for (int s4 = 0; s4 < 4; ++s4) af[s4] = *reinterpret_cast<const float4*>(&dzT[r16 * DZ_LD + 16 * s4 + 4 * q]);
     // X2: dz is unbounded: its scale is taken from this step's tile (every wave holds the whole 16 x 64 tile across its lanes)
     float pscale = 1.f;       // 1 / (weight scale x dz scale), applied to the partial sums
     Frag afh[2];
@@ -855,7 +860,7 @@ template <int KB, int XS>
 __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
   // (two copies of the dz tile, used alternately: with the sentinel hand-off the step's ONE barrier sits between a tile's writes and its
   //  reads, and only the copy keeps a wave that is a step ahead from writing into what a slower wave still reads; the flags likewise)
-  __shared__ __attribute__((aligned(16))) float dzS2[2][16 * 64];
+  __shared__ __attribute__((aligned(16))) float dzS2[2][16 * DZ_LD];
   __shared__ int s_ok1[2], s_ok2;
   const PCellB c = a.c[blockIdx.z];      // a copy (see lstm_persist_fwd_g)
   if (c.PD_up != nullptr) lstm_bwd_rs_steps<KB, true, XS>(a, c, dzS2, s_ok1, s_ok2);

@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--gemm-operands", default="f32", choices=["f32", "fp16"],
                     help="fp16: operands of the CNN / encoder-input GEMMs rounded to fp16, f32 accumulation (configs[4]); f32 (default): "
                          "f32-accurate products")
+    ap.add_argument("--hidden", type=int, default=0, help="cfg5 only: hidden_units (= attn_units) override, e.g. 2048 = 1024 per direction, the "
+                    "other reading of BASELINE configs[4] (encoder and decoder then run their per-launch fall-back kernels: see `paths`)")
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--frames", type=int, default=800)
     ap.add_argument("--feat", type=int, default=80)
@@ -199,7 +201,8 @@ def main():
         if name == "es_en_20h":
             cfg["rnn_config"]["dec_layers"] = 3          # /root/reference/experiments/es_en_20h/model_cfg.json:12
         if name == "cfg5":                               # BASELINE configs[4]: "BiLSTM-1024" read as the concatenated width (512 per direction)
-            cfg["rnn_config"].update(enc_layers=6, hidden_units=1024, attn_units=1024, dec_vocab_size=8004)
+            hu = args.hidden if args.hidden > 0 else 1024
+            cfg["rnn_config"].update(enc_layers=6, hidden_units=hu, attn_units=hu, dec_vocab_size=8004)
         return cfg
 
     def barrier():
@@ -275,7 +278,7 @@ def main():
         def describe(self):
             rc = self.cfg["rnn_config"]
             return ({"cfg1": "BASELINE configs[1]: ", "es_en_20h": "shipped es_en_20h model (configs[0]'s model at configs[1]'s batch): ",
-                     "cfg5": "shape of BASELINE configs[4] (6-layer encoder, 2x512, V=8004): "}[self.name] +
+                     "cfg5": f"shape of BASELINE configs[4] (6-layer encoder, 2x{rc['hidden_units'] // 2}, V=8004): "}[self.name] +
                     f"synthetic fbank T={T} D={D} batch {B}/GPU, 2xConv+BN -> {rc['enc_layers']}-layer 2x{rc['hidden_units'] // 2} LSTM enc -> "
                     f"attention -> {rc['dec_layers']}-layer LSTM-{rc['hidden_units']} dec, V={self.V}, L={L}, dropout .3, noise .25, teach .8, Adam(amsgrad)+L2+clip")
 
@@ -338,11 +341,15 @@ def main():
                                  "bf16x3": (6, MFMA_16BIT_PEAK_TFLOPS, "bf16 MFMA (v_mfma_f32_32x32x16_bf16), 6 per useful 16-k product block (bf16x3 split)"),
                                  "f32": (1, MFMA_F32_PEAK_TFLOPS, "f32-input MFMA (v_mfma_f32_32x32x2_f32)")}[base_scheme]
             tj = (profile_json("r4_gemm_traffic.json") or {}).get(base_scheme) or {}
+            # `achieved` / `frac` = ALGORITHMIC flops (2*M*N*K) over the launches' time against the dense peak of the pipe that executes
+            # them -- the task's definition; `executed_*` = the same rate times the MFMAs a useful product costs under the scheme (what
+            # the matrix pipe really does: 6x under bf16x3), `algorithmic_over_f32_mfma_peak` = the same algorithmic rate against what
+            # the native f32-input MFMA pipe could deliver at best (157.3 TFLOP/s) -- the ceiling an f32 computation has WITHOUT the split.
             roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<NT|NN|TN> (+ k_zero_split_tiles; fp16x2 also k_absmax): all batched dense products of the step with their preparation launches",
                     "scheme": base_scheme, "pipe": pipe,
-                    "achieved": round(tfl * nprod, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tfl * nprod / peak, 4),
-                    "useful_tflops": round(tfl, 2), "useful_frac_of_pipe_peak": round(tfl / peak, 4),
-                    "useful_over_f32_mfma_peak": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
+                    "achieved": round(tfl, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tfl / peak, 4),
+                    "executed_tflops": round(tfl * nprod, 2), "executed_frac_of_pipe_peak": round(tfl * nprod / peak, 4),
+                    "algorithmic_over_f32_mfma_peak": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
                     "traffic": tj.get("hbm_bytes_per_step"),
                     "traffic_source": ("STATIC FILE, not measured in this run: " + tj.get("source", "profiles/r4_gemm_traffic.json")) if tj else None,
                     "mfma_pipe_busy_frac_pmc": tj.get("mfma_pipe_busy_frac"),
@@ -352,8 +359,8 @@ def main():
                     "algorithmic_bytes_per_step": round(res[20] / args.profile_steps),
                     "flops_per_step": round(res[6] / args.profile_steps), "ms_per_step": round(ms_gemm, 3),
                     "avg_launch_us": round(ms_gemm * 1e3 / max(1, n_gemm), 1), "launches_per_step": n_gemm,
-                    "method": "useful flops = 2*M*N*K per launch, executed = useful x MFMAs per product block; time = HIP events around every launch "
-                              "(preparation launches included) on the launch stream, live in this run"}
+                    "method": "algorithmic flops = 2*M*N*K per launch (summed by the launcher), executed = algorithmic x MFMAs per product block; time = HIP "
+                              "events around every launch (preparation launches included) on the launch stream, live in this run"}
             if args.gemm_operands == "fp16":
                 roof["pipe"] += "; single-term fp16 (1 MFMA) for the launches marked eligible (--gemm-operands fp16): executed flops are over-counted for those"
         if res[17] > 0 and res[19] > 0:

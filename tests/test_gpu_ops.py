@@ -291,7 +291,10 @@ def test_cnn_max_pool_fwd_bwd(lib, B, T, D, c0, c1, pool, gemm_split):
                                                    # (the encoder of BASELINE configs[4]), 3 layers as (2, 1) at batch 64 / h = 256
                                                    (5, 200, 16, 64, 3, True), (4, 20, 24, 512, 6, False), (6, 64, 32, 256, 3, True),
                                                    # h = 64: one 16-k block per wave (half-empty 32-k MFMA operands of the split schemes)
-                                                   (2, 5, 16, 64, 1, False), (2, 5, 16, 64, 2, False), (5, 5, 16, 64, 1, True), (5, 16, 16, 64, 2, False)])
+                                                   (2, 5, 16, 64, 1, False), (2, 5, 16, 64, 2, False), (5, 5, 16, 64, 1, True), (5, 16, 16, 64, 2, False),
+                                                   # h = 1024 per direction (the other reading of BASELINE configs[4]): the weight slices do not fit the
+                                                   # persistent kernels' registers, the stack runs one fused-cell launch per step
+                                                   (3, 4, 16, 1024, 2, False)])
 def test_lstm_stack(lib, T, B, in_dim, h, nl, masks, gemm_split):
     from ast_amd._lib import LstmGrads, LstmParams, LstmStackDesc
     from oracle.ast_ref_torch import encoder_torch
