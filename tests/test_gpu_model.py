@@ -441,6 +441,47 @@ def test_nn_trains_predicts_and_resumes_through_train_py(tmp_path):
     assert len(lines) == 7 and lines[-1] == ""
 
 
+def test_descriptor_precision_overrides_the_process_default_for_every_op():
+    """include/astk.h: the arithmetic of an op's products travels in its descriptor (`precision`), the process-wide setter only supplies
+    what ASTK_PREC_DEFAULT resolves to.  A model that ASKS for f32 while the process default is bf16x3 must produce exactly the bits of
+    a model without a wish while the process default is f32 (CNN, encoder stack incl. the persistent recurrences, decoder, all batched
+    products) -- and other bits than the default arithmetic."""
+    from oracle import ast_ref as R
+    from ast_amd import _lib
+    from ast_amd.seq2seq import using_config
+    lib = _lib.load()
+    cfg = tiny_cfg(enc_layers=2, dec_layers=1, H=128, E=16, A=64, c0=8, c1=16, V=57, drop=0.0)
+    B, T, D, L, V = 18, 70, 80, 8, 57
+    P = R.init_params(cfg, D, V, seed=4, dtype=np.float32)
+    X, y = R.synth_batch(B, T, D, L, V, seed=41, dtype=np.float32)
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+
+    def run(model_prec):
+        g = _gpu_model(cfg, P, D, V)
+        g.gemm_precision = model_prec
+        g.inject = {"use_truth": [1] * (L - 1)}
+        with using_config("train", True):
+            loss = g.forward_loss(X=Xd, y=yd, teach_ratio=1.0)
+            g.cleargrads()
+            loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.data), g.enc_states.clone(), g.arena.grad.clone()
+    assert lib.astk_get_gemm_precision() == 1                      # the library default: bf16x3
+    l_def, e_def, _ = run(None)
+    l_ask, e_ask, g_ask = run("f32")                               # descriptor asks for f32, process default bf16x3
+    prev = lib.astk_set_gemm_precision(2)
+    try:
+        l_f32, e_f32, g_f32 = run(None)                            # process default f32, descriptor silent
+        l_x3, e_x3, _ = run("bf16x3")                              # ... and a descriptor that asks for bf16x3 under it
+    finally:
+        lib.astk_set_gemm_precision(prev)
+    assert l_ask == l_f32 and torch.equal(e_ask, e_f32)
+    # (gradients: float atomics in the split tiles make the last bits run-dependent; everything else is bit-identical)
+    assert float((g_ask - g_f32).abs().max()) <= 1e-6 * float(g_f32.abs().max())
+    assert torch.equal(e_x3, e_def) and l_x3 == l_def
+    assert not torch.equal(e_def, e_f32), "the two arithmetics produced identical bits: the descriptor field is not in force"
+
+
 @pytest.mark.parametrize("scheme", ["fp16x2", "bf16x3", "f32"])
 def test_thirty_update_trajectory_against_the_float64_oracle(scheme):
     """The arithmetic schemes of the batched GEMMs and the encoder recurrences over a TRAJECTORY, not only at initialisation: 30 updates
