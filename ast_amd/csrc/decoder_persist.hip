@@ -26,6 +26,10 @@
 // register budgets below, grid of 256 workgroups fully resident.  All spins are bounded (abort word).
 #include "common.h"
 
+// -DASTK_PDEC_TIMING_ALL=1: the per-phase timers of ASTK_PERSIST_DBG in the multi-layer variants too (16 more registers per lane there)
+#ifndef ASTK_PDEC_TIMING_ALL
+#define ASTK_PDEC_TIMING_ALL 0
+#endif
 namespace astk {
 
 namespace {
@@ -171,16 +175,33 @@ __device__ __forceinline__ void wload(float4* w, const float* W, long ldw, int r
     w[i] = k < K ? *reinterpret_cast<const float4*>(W + (long)row * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
+// A fragments of a handed-off row block: 16-byte loads (AUX = 16: sc1) at float offset a_off + k, k = 16 (wave + 4 (i0 + i)) + 4 q.
+// Blocks that all lie inside K (the shipped widths): ONE address register and immediate offsets.  Otherwise k is clamped (the matching w
+// is zero beyond K) -- one address register per load: in the multi-layer kernels those were spilled, and a scratch reload between two
+// buffer loads waits for every load issued before it (vmcnt counts in order): the 16 loads of a product came back in 8 round trips.
+template <int NB, int AUX = 16>
+__device__ __forceinline__ void aload_sc1(float4* a, __amdgpu_buffer_rsrc_t ra, long a_off, int K, int lane, int wave, int i0 = 0) {
+  const int kb = 16 * (wave + 4 * i0) + 4 * (lane >> 4);
+  if (64 * (i0 + NB) <= K) {
+    const int vo = (int)((a_off + kb) * 4);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, vo + 256 * i, 0, AUX);
+      a[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)((a_off + min(kb + 64 * i, K - 4)) * 4), 0, AUX);
+      a[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+  }
+}
 // acc += A[arow][0:K] . W^T : A read with sc1 loads through `ra` at float offset a_off (+k)
 template <int NB>
 __device__ __forceinline__ void wmac(f32x4& acc, const float4* w, __amdgpu_buffer_rsrc_t ra, long a_off, int K, int lane, int wave) {
-  const int q = lane >> 4;
   float4 a[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int k = min(16 * (wave + 4 * i) + 4 * q, K - 4);       // clamped: the matching w[i] is zero beyond K
-    a[i] = ldb128_sc1(ra, a_off + k);
-  }
+  aload_sc1<NB>(a, ra, a_off, K, lane, wave);
   __builtin_amdgcn_sched_barrier(0);
   f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -230,13 +251,6 @@ __device__ __forceinline__ void mfma_blocks(f32x4& acc, const float4* a, const f
     acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, w[i].w, acc2, 0, 0, 0);
   }
   acc += acc2;
-}
-// A fragments of a handed-off row block: sc1 16-byte loads at float offset a_off + k, k clamped (matching w is zero beyond K)
-template <int NB>
-__device__ __forceinline__ void aload_sc1(float4* a, __amdgpu_buffer_rsrc_t ra, long a_off, int K, int lane, int wave) {
-  const int q = lane >> 4;
-#pragma unroll
-  for (int i = 0; i < NB; ++i) a[i] = ldb128_sc1(ra, a_off + min(16 * (wave + 4 * i) + 4 * q, K - 4));
 }
 
 // NC > 0: H = 64 * NC and chunk <= PDEC_CHUNK_MAX are compile-time facts for the attention phase (fully unrolled, batched reads);
@@ -387,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) tk[i] = 0;
   // per-phase debug timers (ASTK_PERSIST_DBG): 50 registers when live -- compiled in only where they fit without spills (one layer)
-  const bool timing = NL == 1 && a.dbg != 0;
+  const bool timing = (NL == 1 || ASTK_PDEC_TIMING_ALL) && a.dbg != 0;
   long long tlast = timing ? wall_clock64() : 0;
   long long tk_att = 0;
   long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -988,6 +1002,10 @@ struct PDecBwdArgs {
   float* DXH;                              // b6_split: [2][S][B][A] K-halves of d_x0[:, E:] (the carry of the next step's B1)
   int b6_split;                            // 1: B6 covers only the ht columns, every item split into two K halves (the embedding
                                            //    columns are one batched GEMM after the launch)
+                                           // 2: no B6 role and no d_pre hand-off: the B1 items (two K halves each) add dz_{s+1} Wu[:, ht cols]
+                                           //    to their half of dlogits Wo and leave the two partial pre-activations in DXH; B2 forms
+                                           //    d_pre = (p0 + p1) (1 - ht^2) while it loads its operand (two hand-offs less on the chain; the
+                                           //    embedding columns as under 1)
   float *d_c0;                             // [NL][B][H]
   unsigned* ctr;
   AbortCtl ab;
@@ -1004,12 +1022,12 @@ constexpr int NWB_ML = 64, OFF_B5UP = NB_B5, OFF_B6_ML = 48;
 // acc += A . W over NB blocks, A fetched in chunks of CH blocks (bounds the live A registers)
 template <int NB, int CH>
 __device__ __forceinline__ void wmac_chunked(f32x4& acc, const float4* w, __amdgpu_buffer_rsrc_t ra, long a_off, int K, int lane, int wave) {
-  const int q = lane >> 4;
 #pragma unroll
   for (int c0 = 0; c0 < NB; c0 += CH) {
+    if (c0 > 0 && 64 * c0 >= K) break;     // a chunk wholly beyond K (narrow models in the full-width register layout): its round trip
+                                           // would sit on the chain for nothing
     float4 a[CH];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) a[i] = ldb128_sc1(ra, a_off + min(16 * (wave + 4 * (c0 + i)) + 4 * q, K - 4));
+    aload_sc1<CH>(a, ra, a_off, K, lane, wave, c0);
     __builtin_amdgcn_sched_barrier(0);
     mfma_blocks<CH>(acc, a, w + c0);
   }
@@ -1030,7 +1048,8 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   // ---------------- roles.  NL == 1: [0,n5) cell bwd, [n5, n5+n6) dx0, [n5+n6, n5+n6+n1) d_pre + d_cvh ; attention: all.
   // NL > 1: [l n5, (l+1) n5) cell bwd of layer l ; d_pre + d_cvh on the last max(n1, n2) workgroups ; dx0 (split) on the last n6
   constexpr int TOP = NL - 1;
-  const int n5 = nbt * (H / 16), n6 = a.b6_split ? 2 * nbt * (A / 16) : nbt * (XI / 16), n1 = nbt * (A / 16), n2 = nbt * (2 * H / 32);
+  const bool fused6 = a.b6_split == 2;
+  const int n5 = nbt * (H / 16), n6 = fused6 ? 0 : (a.b6_split ? 2 * nbt * (A / 16) : nbt * (XI / 16)), n1 = nbt * (A / 16), n2 = nbt * (2 * H / 32);
   const int n12 = n1 > n2 ? n1 : n2;
   const bool has5 = wg < NL * n5;
   const int b5_l = has5 ? wg / n5 : 0, b5_i = has5 ? wg % n5 : 0;
@@ -1043,11 +1062,17 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   const int b6_per_bt = a.b6_split ? A / 16 : XI / 16;
   const int b6_bt = has6 ? b6_item / b6_per_bt : 0, b6_n0 = has6 ? (a.b6_split ? E : 0) + (b6_item % b6_per_bt) * 16 : 0;
   const int b6_k0 = b6_half * (K4 / 2);
-  const int r1 = NL > 1 ? wg - (G - n12) : wg - n5 - n6;
-  const bool has1 = r1 >= 0 && r1 < n1;
-  const int b1_bt = has1 ? r1 / (A / 16) : 0, b1_n0 = has1 ? (r1 % (A / 16)) * 16 : 0;
-  const bool has2 = r1 >= 0 && r1 < n2;
-  const int b2_bt = has2 ? r1 / (2 * H / 32) : 0, b2_n0 = has2 ? (r1 % (2 * H / 32)) * 32 : 0;
+  // fused form: 2 n1 half-items of the pre-activation, on other workgroups than the d_cvh items
+  const int n1f = fused6 ? 2 * n1 : n1;
+  const int r1 = fused6 ? (NL > 1 ? wg - (G - n1f) : wg - n5) : (NL > 1 ? wg - (G - n12) : wg - n5 - n6);
+  const bool has1 = r1 >= 0 && r1 < n1f;
+  const int b1_half = fused6 ? (r1 & 1) : 0, b1_item = fused6 ? (r1 >> 1) : r1;
+  const int b1_bt = has1 ? b1_item / (A / 16) : 0, b1_n0 = has1 ? (b1_item % (A / 16)) * 16 : 0;
+  constexpr int KV_HALF = 64 * (NB_B1 / 2);          // fused form: dlogits Wo split at this k (9 k-blocks per wave and half)
+  const int b1_kv0 = b1_half * KV_HALF, b1_kvn = b1_half ? Vp - KV_HALF : min(Vp, KV_HALF);
+  const int r2 = fused6 ? (NL > 1 ? wg - (G - n1f - n2) : wg - n5 - n1f) : r1;
+  const bool has2 = r2 >= 0 && r2 < n2;
+  const int b2_bt = has2 ? r2 / (2 * H / 32) : 0, b2_n0 = has2 ? (r2 % (2 * H / 32)) * 32 : 0;
   const int n_att = B * a.nsplit;
   const bool has_att = wg < n_att;
   const int att_b = has_att ? wg % B : 0, att_sp = has_att ? wg / B : 0;
@@ -1069,7 +1094,12 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
     else wload<NB_B6>(wreg + OFF_B6, a.WuT[0], K4, b6_n0 + r16, K4, lane, wave);
   }
   if (!has5 && (NL > 1 || !has6)) {
-    if (has1) wload<NB_B1>(wreg, a.WoT, Vp, b1_n0 + r16, Vp, lane, wave);
+    if (has1) {
+      if (fused6) {
+        wload<NB_B1 / 2>(wreg, a.WoT + b1_kv0, Vp, b1_n0 + r16, b1_kvn, lane, wave);
+        wload<NB_B6 / 2>(wreg + NB_B1 / 2, a.WuT[0] + b1_half * (K4 / 2), K4, E + b1_n0 + r16, K4 / 2, lane, wave);
+      } else wload<NB_B1>(wreg, a.WoT, Vp, b1_n0 + r16, Vp, lane, wave);
+    }
     if (has2) {
       wload<NB_B2>(wreg + NB_B1, a.WcT, A, b2_n0 + r16, A, lane, wave);
       wload<NB_B2>(wreg + NB_B1 + NB_B2, a.WcT, A, b2_n0 + 16 + r16, A, lane, wave);
@@ -1100,7 +1130,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   long long tb[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) tb[i] = 0;
-  const bool timing = NL == 1 && a.dbg != 0;
+  const bool timing = (NL == 1 || ASTK_PDEC_TIMING_ALL) && a.dbg != 0;
   long long tlast = timing ? wall_clock64() : 0;
 #define TB(i) if (timing) { const long long now_ = wall_clock64(); tb[i] += now_ - tlast; tlast = now_; }
 
@@ -1110,37 +1140,72 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
     if (has1) {
       const int bt = b1_bt, m0 = bt * 16;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      wmac_chunked<NB_B1, 9>(acc, wreg, r_dl, ((long)s * B + min(m0 + r16, B - 1)) * Vp, Vp, lane, wave);   // no dependency on the chain
-      const float v = reduce16(acc, red);
       const int row = m0 + e_row, col = b1_n0 + e_col;
-      float carry = 0.f;
-      TB(0)
-      if (n > 0) {
-        if (!wg_wait_sh(CTR(PB6, bt), a.b6_split ? 2 * (A / 16) : XI / 16, n, a.ab, &s_flag)) return;
-        TB(1)
+      if (fused6) {
+        // this half of dlogits Wo (no dependency on the chain), then -- in the same accumulators -- this half of the carry
+        // d_x0[s+1][:, E + col] = dz_{0,s+1} Wu_0[:, E + col]: the cell backward of step s+1 hands its dz straight to this product
+        if (b1_kvn > 0) wmac_chunked<NB_B1 / 2, 9>(acc, wreg, r_dl, ((long)s * B + min(m0 + r16, B - 1)) * Vp + b1_kv0, b1_kvn, lane, wave);
+        TB(0)
+        if (n > 0) {
+          if (!wg_wait_sh(CTR(PB5, bt), H / 16, n, a.ab, &s_flag)) return;
+          TB(1)
+          wmac_chunked<NB_B6 / 2, 16>(acc, wreg + NB_B1 / 2, r_g0, ((long)(s + 1) * B + min(m0 + r16, B - 1)) * K4 + b1_half * (K4 / 2), K4 / 2, lane, wave);
+        }
+        const float v = reduce16(acc, red);
+        if (row < B) st_sc1(a.DXH + ((long)(b1_half * S + s) * B + row) * A + col, v);
+      } else {
+        wmac_chunked<NB_B1, 9>(acc, wreg, r_dl, ((long)s * B + min(m0 + r16, B - 1)) * Vp, Vp, lane, wave);   // no dependency on the chain
+        const float v = reduce16(acc, red);
+        float carry = 0.f;
+        TB(0)
+        if (n > 0) {
+          if (!wg_wait_sh(CTR(PB6, bt), a.b6_split ? 2 * (A / 16) : XI / 16, n, a.ab, &s_flag)) return;
+          TB(1)
+          if (row < B) {
+            if (a.b6_split) {
+              const float c0 = ld_sc1(a.DXH + ((long)(s + 1) * B + row) * A + col);
+              const float c1 = ld_sc1(a.DXH + ((long)(S + s + 1) * B + row) * A + col);
+              carry = c0 + c1;
+            } else carry = ld_sc1(a.DX0 + ((long)(s + 1) * B + row) * XI + E + col);
+          }
+        }
         if (row < B) {
-          if (a.b6_split) {
-            const float c0 = ld_sc1(a.DXH + ((long)(s + 1) * B + row) * A + col);
-            const float c1 = ld_sc1(a.DXH + ((long)(S + s + 1) * B + row) * A + col);
-            carry = c0 + c1;
-          } else carry = ld_sc1(a.DX0 + ((long)(s + 1) * B + row) * XI + E + col);
+          const float y = a.HT[((long)(s + 1) * B + row) * A + col];
+          st_sc1(a.DPRE + ((long)s * B + row) * A + col, (v + carry) * (1.f - y * y));
         }
       }
-      if (row < B) {
-        const float y = a.HT[((long)(s + 1) * B + row) * A + col];
-        st_sc1(a.DPRE + ((long)s * B + row) * A + col, (v + carry) * (1.f - y * y));
-      }
-      publish_sh(CTR(PB1, bt), b1_n0 / 16);
+      publish_sh(CTR(PB1, bt), fused6 ? 2 * (b1_n0 / 16) + b1_half : b1_n0 / 16);
       TB(2)
     }
     // ================= B2 =================
     if (has2) {
       const int bt = b2_bt, m0 = bt * 16;
       TB(15)
-      if (!wg_wait_sh(CTR(PB1, bt), A / 16, n + 1, a.ab, &s_flag)) return;
-      TB(3)
       float4 av[NB_B2];
-      aload_sc1<NB_B2>(av, r_dpre, ((long)s * B + min(m0 + r16, B - 1)) * A, A, lane, wave);
+      if (fused6) {
+        // d_pre = (p0 + p1) (1 - ht^2) formed on the operand fragments; ht fetched in front of the wait; every item leaves its share
+        // of the 4 NB_B2 fragments of d_pre for the weight gradients behind the launch
+        float4 yv[NB_B2], p1[NB_B2];
+        const __amdgpu_buffer_rsrc_t r_ht = make_rsrc(a.HT), r_dxh = make_rsrc(a.DXH);
+        const long rowo = (long)s * B + min(m0 + r16, B - 1);
+        aload_sc1<NB_B2, 0>(yv, r_ht, (rowo + B) * A, A, lane, wave);
+        if (!wg_wait_sh(CTR(PB1, bt), 2 * (A / 16), n + 1, a.ab, &s_flag)) return;
+        TB(3)
+        aload_sc1<NB_B2>(av, r_dxh, rowo * A, A, lane, wave);
+        aload_sc1<NB_B2>(p1, r_dxh, ((long)S * B + rowo) * A, A, lane, wave);
+        const int nb2 = 2 * H / 32, my = b2_n0 / 32;
+#pragma unroll
+        for (int i = 0; i < NB_B2; ++i) {
+          av[i].x = (av[i].x + p1[i].x) * (1.f - yv[i].x * yv[i].x); av[i].y = (av[i].y + p1[i].y) * (1.f - yv[i].y * yv[i].y);
+          av[i].z = (av[i].z + p1[i].z) * (1.f - yv[i].z * yv[i].z); av[i].w = (av[i].w + p1[i].w) * (1.f - yv[i].w * yv[i].w);
+          const int k = 16 * (wave + 4 * i) + 4 * (lane >> 4);
+          if ((wave * NB_B2 + i) % nb2 == my && k < A && m0 + r16 < B) *reinterpret_cast<float4*>(a.DPRE + rowo * A + k) = av[i];
+        }
+      } else {
+        if (!wg_wait_sh(CTR(PB1, bt), A / 16, n + 1, a.ab, &s_flag)) return;
+        TB(3)
+        aload_sc1<NB_B2>(av, r_dpre, ((long)s * B + min(m0 + r16, B - 1)) * A, A, lane, wave);
+      }
       __builtin_amdgcn_sched_barrier(0);
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       mfma_blocks<NB_B2>(acc0, av, wreg + NB_B1);
@@ -1154,6 +1219,31 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
       }
       publish_sh(CTR(PB2, bt), b2_n0 / 32);
       TB(4)
+    }
+    // ================= B5, the part that does not depend on this step's chain: dh_rec = dz_{s+1} Wl and the saved forward state.
+    // In FRONT of the attention phase in program order: dz_{s+1} has been there since the previous step's cell backward, and a cell
+    // workgroup that started this product only after its own attention item kept its batch tile's dz -- the whole chain -- waiting
+    // for it (5 us per step in the phase timers) =================
+    float v = 0.f;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ccur = 0.f, cp = 0.f, mk = 1.f;
+    if (has5) {
+      const int bt = b5_bt, m0 = bt * 16, l = b5_l;
+      TB(15)
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (n > 0) {
+        if (!wg_wait_sh(CTR(PB5 + l, bt), H / 16, n, a.ab, &s_flag)) return;
+        wmac_chunked<NB_B5, 16>(acc, wreg, r_g, ((long)(s + 1) * B + min(m0 + r16, B - 1)) * K4, K4, lane, wave);
+      }
+      v = reduce16(acc, red);
+      const int row = m0 + e_row, u = b5_u0 + e_col;
+      if (row < B) {
+        g = *reinterpret_cast<const float4*>(a.Gt[l] + ((long)s * B + row) * K4 + 4 * u);
+        ccur = a.Cst[l][((long)(s + 1) * B + row) * H + u];
+        cp = a.Cst[l][((long)s * B + row) * H + u];
+        if (a.rnn_mask[l]) mk = a.rnn_mask[l][((long)s * B + row) * H + u];
+      }
+      TB(6)
     }
     // ================= B3: attention backward =================
     if (has_att) {
@@ -1388,24 +1478,9 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
     if (has5) {
       const int bt = b5_bt, m0 = bt * 16, l = b5_l;
       const int rows_bt = min(16, B - bt * 16);
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      if (n > 0) {       // dh_rec = dz_{s+1} Wl: independent of this step's chain
-        if (!wg_wait_sh(CTR(PB5 + l, bt), H / 16, n, a.ab, &s_flag)) return;
-        wmac_chunked<NB_B5, 16>(acc, wreg, r_g, ((long)(s + 1) * B + min(m0 + r16, B - 1)) * K4, K4, lane, wave);
-      }
-      const float v = reduce16(acc, red);
       const int row = m0 + e_row, u = b5_u0 + e_col;
       const bool ev = row < B;
-      // saved forward state of this (row, unit): plain loads issued before the wait
-      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-      float ccur = 0.f, cp = 0.f, mk = 1.f;
-      if (ev) {
-        g = *reinterpret_cast<const float4*>(a.Gt[l] + ((long)s * B + row) * K4 + 4 * u);
-        ccur = a.Cst[l][((long)(s + 1) * B + row) * H + u];
-        cp = a.Cst[l][((long)s * B + row) * H + u];
-        if (a.rnn_mask[l]) mk = a.rnn_mask[l][((long)s * B + row) * H + u];
-      }
-      TB(6)
+      TB(15)
       float dy = 0.f;
       if (NL == 1 || l == TOP) {
         if (!wg_wait_multi(ROWCTR(m0), CTRS, rows_bt, (unsigned)(a.nsplit * (n + 1)), a.ab, &s_flag)) return;
@@ -1466,7 +1541,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
       TB(10)
     }
   }
-  if (timing && tid == 0 && (wg == 0 || wg == n5 || wg == n5 + 20 || wg == n5 + n6 || wg == n5 + n6 + n1 - 1 || wg == G - 1))
+  if (timing && tid == 0 && (wg == 0 || wg == n5 || wg == n5 + 20 || wg == 2 * n5 + 1 || wg == n5 + n6 || wg == n5 + n6 + n1 - 1 || wg == G - 1))
     printf("pdecb wg %3d per-step 10ns: B1[pre %lld wait %lld tail %lld] B2[wait %lld work %lld] B3[wait+work %lld] B5[pre %lld wait %lld tail %lld] B6[wait %lld work %lld] other %lld\n",
            wg, tb[0] / S, tb[1] / S, tb[2] / S, tb[3] / S, tb[4] / S, tb[5] / S, tb[6] / S, tb[7] / S, tb[8] / S, tb[9] / S, tb[10] / S, tb[15] / S);
 #undef TB
@@ -1660,6 +1735,11 @@ int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, con
   a.DX0 = bf.DX0; a.DHATT = bf.DHATT; a.d_c0 = bf.d_c0;
   a.DXH = bf.DXH;
   a.b6_split = bf.DXH != nullptr && decoder_persist_b6_split(d) ? 1 : 0;
+  if (a.b6_split) {          // ASTK_DEC_B6_FUSED=0: the d_x0 role of rounds 2-3 (kept for A/B runs)
+    const char* e = getenv("ASTK_DEC_B6_FUSED");
+    const int n5 = a.nbt * (a.H / 16), n1 = a.nbt * (a.A / 16), n2 = a.nbt * (2 * a.H / 32);
+    if (!(e && e[0] == '0') && d->n_layers * n5 + 2 * n1 + n2 <= G) a.b6_split = 2;
+  }
   ASTK_CHECK(d->n_layers == 1 || a.b6_split, "decoder_persist_bwd: the multi-layer role layout needs the split d_x0 buffers");
   a.ctr = bf.ctr;
   a.ab = abort_ctl(bf.ctr + (size_t)NPHASE_SLOTS * NSH * a.nbt * CTRS, PERSIST_DEC_BWD);
