@@ -1070,7 +1070,9 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   const int b1_bt = has1 ? b1_item / (A / 16) : 0, b1_n0 = has1 ? (b1_item % (A / 16)) * 16 : 0;
   constexpr int KV_HALF = 64 * (NB_B1 / 2);          // fused form: dlogits Wo split at this k (9 k-blocks per wave and half)
   const int b1_kv0 = b1_half * KV_HALF, b1_kvn = b1_half ? Vp - KV_HALF : min(Vp, KV_HALF);
-  const int r2 = fused6 ? (NL > 1 ? wg - (G - n1f - n2) : wg - n5 - n1f) : r1;
+  // (NL > 1: the pre-activation half-items on the last 2 n1 workgroups -- top-layer cell owners among them, never a lower layer's --
+  //  and the d_cvh items on the last n2, none of which owns a cell: decoder_persist_bwd_launch checked both)
+  const int r2 = fused6 ? (NL > 1 ? wg - (G - n2) : wg - n5 - n1f) : r1;
   const bool has2 = r2 >= 0 && r2 < n2;
   const int b2_bt = has2 ? r2 / (2 * H / 32) : 0, b2_n0 = has2 ? (r2 % (2 * H / 32)) * 32 : 0;
   const int n_att = B * a.nsplit;
@@ -1079,6 +1081,10 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
 
   constexpr int NW = NL > 1 ? NWB_ML : NWB;
   constexpr int OFF_B6 = NL > 1 ? OFF_B6_ML : 0;
+  // fused form: the pre-activation half-item's 9 + 16 blocks.  NL > 1: behind the d_cvh item's blocks [NB_B1, NB_B1 + 2 NB_B2) and a
+  // top-layer cell owner's [0, NB_B5), either of which the same workgroup may hold
+  constexpr int OFF_B1F = NL > 1 ? NB_B1 + 2 * NB_B2 : 0;
+  static_assert(OFF_B1F + NB_B1 / 2 + NB_B6 / 2 <= NW && NB_B5 <= NB_B1 + 2 * NB_B2, "fused pre-activation fragments");
   float4 wreg[NW];
 #pragma unroll
   for (int i = 0; i < NW; ++i) wreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1093,13 +1099,17 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
     if (a.b6_split) wload<NB_B6 / 2>(wreg + OFF_B6, a.WuT[0] + b6_k0, K4, b6_n0 + r16, K4 / 2, lane, wave);
     else wload<NB_B6>(wreg + OFF_B6, a.WuT[0], K4, b6_n0 + r16, K4, lane, wave);
   }
-  if (!has5 && (NL > 1 || !has6)) {
+  if (fused6) {
     if (has1) {
-      if (fused6) {
-        wload<NB_B1 / 2>(wreg, a.WoT + b1_kv0, Vp, b1_n0 + r16, b1_kvn, lane, wave);
-        wload<NB_B6 / 2>(wreg + NB_B1 / 2, a.WuT[0] + b1_half * (K4 / 2), K4, E + b1_n0 + r16, K4 / 2, lane, wave);
-      } else wload<NB_B1>(wreg, a.WoT, Vp, b1_n0 + r16, Vp, lane, wave);
+      wload<NB_B1 / 2>(wreg + OFF_B1F, a.WoT + b1_kv0, Vp, b1_n0 + r16, b1_kvn, lane, wave);
+      wload<NB_B6 / 2>(wreg + OFF_B1F + NB_B1 / 2, a.WuT[0] + b1_half * (K4 / 2), K4, E + b1_n0 + r16, K4 / 2, lane, wave);
     }
+    if (has2) {
+      wload<NB_B2>(wreg + NB_B1, a.WcT, A, b2_n0 + r16, A, lane, wave);
+      wload<NB_B2>(wreg + NB_B1 + NB_B2, a.WcT, A, b2_n0 + 16 + r16, A, lane, wave);
+    }
+  } else if (!has5 && (NL > 1 || !has6)) {
+    if (has1) wload<NB_B1>(wreg, a.WoT, Vp, b1_n0 + r16, Vp, lane, wave);
     if (has2) {
       wload<NB_B2>(wreg + NB_B1, a.WcT, A, b2_n0 + r16, A, lane, wave);
       wload<NB_B2>(wreg + NB_B1 + NB_B2, a.WcT, A, b2_n0 + 16 + r16, A, lane, wave);
@@ -1144,12 +1154,12 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
       if (fused6) {
         // this half of dlogits Wo (no dependency on the chain), then -- in the same accumulators -- this half of the carry
         // d_x0[s+1][:, E + col] = dz_{0,s+1} Wu_0[:, E + col]: the cell backward of step s+1 hands its dz straight to this product
-        if (b1_kvn > 0) wmac_chunked<NB_B1 / 2, 9>(acc, wreg, r_dl, ((long)s * B + min(m0 + r16, B - 1)) * Vp + b1_kv0, b1_kvn, lane, wave);
+        if (b1_kvn > 0) wmac_chunked<NB_B1 / 2, 9>(acc, wreg + OFF_B1F, r_dl, ((long)s * B + min(m0 + r16, B - 1)) * Vp + b1_kv0, b1_kvn, lane, wave);
         TB(0)
         if (n > 0) {
           if (!wg_wait_sh(CTR(PB5, bt), H / 16, n, a.ab, &s_flag)) return;
           TB(1)
-          wmac_chunked<NB_B6 / 2, 16>(acc, wreg + NB_B1 / 2, r_g0, ((long)(s + 1) * B + min(m0 + r16, B - 1)) * K4 + b1_half * (K4 / 2), K4 / 2, lane, wave);
+          wmac_chunked<NB_B6 / 2, 16>(acc, wreg + OFF_B1F + NB_B1 / 2, r_g0, ((long)(s + 1) * B + min(m0 + r16, B - 1)) * K4 + b1_half * (K4 / 2), K4 / 2, lane, wave);
         }
         const float v = reduce16(acc, red);
         if (row < B) st_sc1(a.DXH + ((long)(b1_half * S + s) * B + row) * A + col, v);
@@ -1738,7 +1748,8 @@ int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, con
   if (a.b6_split) {          // ASTK_DEC_B6_FUSED=0: the d_x0 role of rounds 2-3 (kept for A/B runs)
     const char* e = getenv("ASTK_DEC_B6_FUSED");
     const int n5 = a.nbt * (a.H / 16), n1 = a.nbt * (a.A / 16), n2 = a.nbt * (2 * a.H / 32);
-    if (!(e && e[0] == '0') && d->n_layers * n5 + 2 * n1 + n2 <= G) a.b6_split = 2;
+    const bool fits = d->n_layers == 1 ? n5 + 2 * n1 + n2 <= G : ((d->n_layers - 1) * n5 + 2 * n1 <= G && d->n_layers * n5 + n2 <= G);
+    if (!(e && e[0] == '0') && fits) a.b6_split = 2;
   }
   ASTK_CHECK(d->n_layers == 1 || a.b6_split, "decoder_persist_bwd: the multi-layer role layout needs the split d_x0 buffers");
   a.ctr = bf.ctr;
