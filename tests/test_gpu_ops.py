@@ -477,6 +477,21 @@ def test_decoder_per_launch_loop_scored_behind_the_loop(lib, monkeypatch, B, L, 
     _decoder_case(lib, s, B, L, T, H, E, A, V, nl, masks)
 
 
+@pytest.mark.parametrize("env", ["ASTK_DEC_B6_FUSED", "ASTK_DEC_B6_SPLIT"])
+@pytest.mark.parametrize("B,L,T,H,E,A,V,nl,masks", [(32, 7, 50, 512, 128, 512, 1098, 1, True), (17, 5, 60, 256, 64, 128, 300, 1, False),
+                                                    (32, 6, 50, 512, 128, 512, 1098, 3, True)])
+def test_decoder_backward_older_role_layouts(lib, monkeypatch, env, B, L, T, H, E, A, V, nl, masks):
+    """The persistent backward kernel's role layouts of rounds 2-3, kept behind switches for A/B runs: ASTK_DEC_B6_FUSED=0 = a d_x0 role
+    (two K halves per item) handing the carry to the d_pre items; ASTK_DEC_B6_SPLIT=0 (one layer only) = whole d_x0 items inside the kernel.
+    The default (no d_x0 role, d_pre formed by the d_cvh items) is what every other decoder test runs."""
+    if env == "ASTK_DEC_B6_SPLIT" and nl > 1:
+        pytest.skip("the multi-layer role layout always splits the d_x0 items")
+    monkeypatch.setenv(env, "0")
+    s = _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=B + L + 2)
+    assert lib.astk_decoder_path(C.byref(s["d"])) & 1, "persistent decoder path not taken"
+    _decoder_case(lib, s, B, L, T, H, E, A, V, nl, masks)
+
+
 def test_wide_decoder_path_and_bounded_spins(lib, monkeypatch):
     """configs[4]'s decoder (H = A = 1024, E = 128, one layer, 32 rows, T'' = 200, V = 8004) reports decoder_wide.hip's persistent loops
     (astk_decoder_path bit 4), and their spins are bounded like every other persistent kernel's: with ASTK_PERSIST_SPIN_LIMIT = 1 the
