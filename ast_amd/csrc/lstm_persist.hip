@@ -617,6 +617,25 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     }
   };
 
+  // Saved forward state and the incoming gradient of a step: from earlier launches, i.e. fetchable at any time.  Fetched ONE STEP EARLY,
+  // right behind the step's barrier: at the top of a step the wave's memory queue is still full of the previous step's write-through
+  // stores (partials, sentinel resets, dz), and loads issued there -- and the sweep behind them -- wait for the queue, not for data.
+  float4 in_g = make_float4(0.f, 0.f, 0.f, 0.f);
+  float in_cc = 0.f, in_cp = 0.f, in_mk = 1.f, in_dye = 0.f;
+  auto fetch_inputs = [&](const int ts) {          // ts >= 0 (callers clamp)
+    const long tbs = (long)ts * B + ebc;
+    in_g = *reinterpret_cast<const float4*>(c.gates_dz + tbs * K + 4 * eu);
+    in_cc = c.C[tbs * h + eu];
+    in_cp = c.C[max(tbs - B, 0L) * h + eu];
+    // (unconditional loads through a selected pointer: a load under `if (c.d_enc)` is a phi of "old value / load result", which hipcc
+    //  resolves by waiting for the load where it is issued -- a full memory latency per step, 1.75 us in the top layer's timers)
+    const float* const mp = c.mask ? c.mask + tbs * h + eu : c.C + tbs * h + eu;
+    const float* const dp = c.d_enc ? c.d_enc + (ebc * T + (c.reverse_pos ? T - 1 - ts : ts)) * HH + eu : c.C + tbs * h + eu;
+    const float mv = *mp, dv = *dp;
+    in_mk = c.mask ? mv : 1.f;
+    in_dye = c.d_enc ? dv : 0.f;
+  };
+  if (alive && T > 0) fetch_inputs(T - 1);
   long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool timing = dbg != 0;
 #define TICK(i, t0) if (timing) { const long long now_ = wall_clock64(); tk[i] += now_ - t0; t0 = now_; }
@@ -625,16 +644,9 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     const int stepno = T - 1 - t;
     float* const dzT = dzS2[stepno & 1];
     const long tb = (long)t * B + ebc;
-    // inputs from earlier launches: issue before any wait
-    const float4 g = *reinterpret_cast<const float4*>(c.gates_dz + tb * K + 4 * eu);
-    const float ccur = c.C[tb * h + eu];
-    const float cp = t > 0 ? c.C[(tb - B) * h + eu] : 0.f;
-    const float mk = c.mask ? c.mask[tb * h + eu] : 1.f;
-    float dye = 0.f;
-    if (c.d_enc) {
-      const int pos = c.reverse_pos ? T - 1 - t : t;
-      dye = c.d_enc[(ebc * T + pos) * HH + eu];
-    }
+    // inputs from earlier launches (fetched a step ago, see fetch_inputs)
+    const float4 g = in_g;
+    const float ccur = in_cc, cp = t > 0 ? in_cp : 0.f, mk = in_mk, dye = in_dye;
     float v1 = 0.f;
     unsigned up_seen = 0;
     if (has_up) {                            // partials handed down by the layer above (it runs ahead)
@@ -741,6 +753,7 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
 #pragma unroll
       for (int p = 0; p < NS; ++p) pu[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pu, base + p * tile_bytes, 0, 16));
     }
+    fetch_inputs(max(t - 1, 0));
     float4 af[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) af[s4] = *reinterpret_cast<const float4*>(&dzT[r16 * DZ_LD + 16 * s4 + 4 * q]);
