@@ -137,6 +137,7 @@ SIGNATURES = {
     "astk_fill_normal": (C.c_int, [_VP, _SZ, _F, _F, _U64, _U64, _VP]),
     "astk_scale_f32": (C.c_int, [_VP, _SZ, _F, _VP]),
     "astk_add_f32": (C.c_int, [_VP, _VP, _SZ, _VP]),
+    "astk_bridge_states": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
     "astk_colsum_add_f32": (C.c_int, [_VP, _VP, _L, _I, _I, _VP]),
     "astk_zero_frames": (C.c_int, [_VP, _I, _I, _I, _VP, C.c_double, _U64, _U64, _VP]),
     "astk_zero_frames_draws": (C.c_int, [_I, _I, _VP, C.c_double, _U64, _U64, _VP, _I, _VP, _VP]),

@@ -26,6 +26,7 @@ struct PersistCellHost {
   int up_external;
   int reverse_pos, layer;
   unsigned long long* amax;
+  float* db;
 };
 bool lstm_persist_applicable(int T, int B, int h, int nl, int nd);
 int lstm_persist_layers_per_launch(int B, int h, int nl, int nd);
@@ -305,27 +306,19 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
   if (persist) {
     PersistCellHost cells[16];
     memset(cells, 0, sizeof(cells));
-    TransposeJobs tj;   // transposed recurrent / upward weights of every cell: one launch
-    tj.n = 0;
-    for (int dd = 0; dd < P.nd; ++dd)
-      for (int l = 0; l < P.nl; ++l) {
-        const astk_lstm_params& p = prm[dd * P.nl + l];
-        if (tj.n + 2 > FILL_SEG_MAX) { ASTK_TRY(transpose_batch(tj, s)); tj.n = 0; }
-        transpose_add(tj, P.WlT[dd][l], 4 * h, p.Wl, h, 4 * h, h);
-        if (l > 0) transpose_add(tj, P.WuT[dd][l], 4 * h, p.Wu, h, 4 * h, h);
-      }
-    ASTK_TRY(transpose_batch(tj, s));
+    // (the recurrence kernel reads its weight fragments straight from the (4h, h) parameters: no transposed copies)
     for (int dd = 0; dd < P.nd; ++dd)
       for (int l = 0; l < P.nl; ++l) {
         PersistCellHost& c = cells[dd * P.nl + l];
         const bool top = l == P.nl - 1;
-        c.WlT = P.WlT[dd][l];
+        c.Wl = prm[dd * P.nl + l].Wl;
         if (rs_path) {
-          c.WuT = l > 0 ? P.WuT[dd][l] : nullptr;
+          c.Wu = l > 0 ? prm[dd * P.nl + l].Wu : nullptr;
           c.PR = P.PR[dd][l];
           c.PD = l > 0 ? P.PD[dd][l] : nullptr;
           c.PD_up = top ? nullptr : P.PD[dd][l + 1];
         }
+        c.db = gr[dd * P.nl + l].db;      // the recurrence kernel sums its dz columns itself
         c.gates = P.ZG[dd][l];
         c.C = P.CC[dd][l];
         c.mask = masks ? masks + ((size_t)dd * P.nl + l) * T * bh : nullptr;
@@ -451,7 +444,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
           wg[nwg++] = with_amax_b(with_amax_a(gemm_args(4 * h, in, rows, mat(dzu, 4 * h), Xv, g.dWu, in, nullptr, GEMM_ATOMIC, 1), adz), l == 0 ? ax : ahb);
         }
       }
-      ASTK_TRY(cb.add(g.db, dz, 4 * h, rows, 4 * h, s));
+      if (!persist) ASTK_TRY(cb.add(g.db, dz, 4 * h, rows, 4 * h, s));
       // gradient wrt the layer input
       if (l > 0) {
         if (!persist) ASTK_TRY(gemm_launch(GEMM_NN, with_amax_a(gemm_args(rows, h, 4 * h, mat(dz, 4 * h), mat(p.Wu, h), P.DX[dd], h), adz), s));

@@ -54,7 +54,7 @@ struct PFwdArgs {
 };
 
 struct PCellB {
-  const float* WlT;     // (h, 4h)
+  const float* Wl;      // (4h, h): the recurrent weight as the parameters hold it
   float* gates_dz;      // (T,B,4h): activated gates in, dz out (in place; the batched products after the launch read it)
   const float* C;       // (T,B,h)
   const float* mask;    // (T,B,h) or null
@@ -62,7 +62,7 @@ struct PCellB {
   const float* d_hT;    // (B,h) or null
   const float* d_cT;    // (B,h) or null
   // reduce-scatter path (lstm_persist_bwd_rs):
-  const float* WuT;     // (h, 4h): transposed upward weight of THIS cell (layers >= 1), for the partials handed DOWN
+  const float* Wu;      // (4h, h): upward weight of THIS cell (layers >= 1), for the partials handed DOWN
   float* PR;            // ring [PR_RING][nbt][nslice consumer][nslice producer][16 col][16 row]: partial dh_rec of this cell
   float* PD;            // [T][nbt][nslice consumer][nslice producer][16][16]: partial dx handed to the layer below (null: layer 0)
   const float* PD_up;   // PD of the layer above (null: top layer)
@@ -70,6 +70,7 @@ struct PCellB {
   int reverse_pos;
   int layer;
   u64* amax;            // 16 sharded words for max |dz| of this cell (the fp16x2 GEMMs' operand scale, gemm_amax_reserve), or null
+  float* db;            // (4h) bias gradient, += the column sums of dz over all steps and rows (null: the caller sums dz itself)
 };
 struct PBwdArgs {
   PCellB c[16];
@@ -537,10 +538,14 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
   const int m0 = bt * 16;
 
   // resident weight fragments: product tile tl = wave*KB + nt covers output units 16 tl .. 16 tl + 15; K = this slice's 64 gate columns
-  auto wl_at = [&](int nt, int s4) { return *reinterpret_cast<const float4*>(c.WlT + (long)(16 * (wave * KB + nt) + r16) * K + 64 * j + 16 * s4 + 4 * q); };
-  auto wd_at = [&](int nt, int s4) {
-    return has_down ? *reinterpret_cast<const float4*>(c.WuT + (long)(16 * (wave * KB + nt) + r16) * K + 64 * j + 16 * s4 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // (read straight from the (4h, h) parameters: four 4-byte loads per fragment quad, 16 consecutive lanes on 64 consecutive bytes, once per
+  //  launch -- the transposed copies a launch of its own used to make every step, 8 us, are gone)
+  auto w_at = [&](const float* W, int nt, int s4) {
+    const float* p = W + (long)(64 * j + 16 * s4 + 4 * q) * h + 16 * (wave * KB + nt) + r16;
+    return make_float4(p[0], p[h], p[2 * (long)h], p[3 * (long)h]);
   };
+  auto wl_at = [&](int nt, int s4) { return w_at(c.Wl, nt, s4); };
+  auto wd_at = [&](int nt, int s4) { return has_down ? w_at(c.Wu, nt, s4) : make_float4(0.f, 0.f, 0.f, 0.f); };
   // X2: fp16 hi / lo fragments behind one power-of-two scale per workgroup (see the forward kernel); the 64 gate columns are two 32-k operands
   constexpr bool X2 = XS != 0;          // a split scheme (16-bit MFMAs); XS == 2 additionally scales
   typedef typename FragOf<XS>::type Frag;
@@ -578,6 +583,9 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
   const bool evalid = eb < B;
   const long ebc = evalid ? eb : B - 1;
   float dc_state = 0.f, dhadd = 0.f, dzmax = 0.f;
+  // bias gradient = column sums of dz over all steps and rows: this thread's (row, unit) element of every step summed in registers, the
+  // 16 rows and the batch tiles at the end -- the separate pass over the six cells' dz (157 MB, 32 us per train step) is gone
+  float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c.d_cT) dc_state = c.d_cT[ebc * h + eu];
   if (c.d_hT) dhadd = c.d_hT[ebc * h + eu];
   const int tile_bytes = 256 * 4;                          // one 16x16 partial tile
@@ -828,6 +836,7 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     }
     TICK(5, t0)
     if (evalid) *reinterpret_cast<float4*>(c.gates_dz + tb * K + 4 * eu) = dz;   // for the batched products after the launch
+    dbacc.x += dz.x; dbacc.y += dz.y; dbacc.z += dz.z; dbacc.w += dz.w;
     if (has_down) {
 #pragma unroll
       for (int nt = KB1; nt < KB; ++nt) {
@@ -850,6 +859,18 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     TICK(6, t0)
   }
   if (pending_b) publish(ctrB);
+  if (c.db) {
+    if (!evalid) dbacc = make_float4(0.f, 0.f, 0.f, 0.f);        // (rows past B repeat row B - 1)
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {        // the 16 rows of a unit are 16 consecutive lanes
+      dbacc.x += __shfl_xor(dbacc.x, o); dbacc.y += __shfl_xor(dbacc.y, o);
+      dbacc.z += __shfl_xor(dbacc.z, o); dbacc.w += __shfl_xor(dbacc.w, o);
+    }
+    if (r == 0) {
+      atomicAdd(c.db + 4 * eu, dbacc.x); atomicAdd(c.db + 4 * eu + 1, dbacc.y);
+      atomicAdd(c.db + 4 * eu + 2, dbacc.z); atomicAdd(c.db + 4 * eu + 3, dbacc.w);
+    }
+  }
   if (c.amax) {
     // max |dz| of the cell for the batched products behind this launch: block maximum, one 64-bit atomic into one of 16 shards
 #pragma unroll
@@ -892,6 +913,7 @@ struct PersistCellHost {
   int up_external;
   int reverse_pos, layer;
   unsigned long long* amax;       // backward: where max |dz| of the cell goes (16 sharded words, gemm_amax_reserve), null: not wanted
+  float* db;                      // backward: bias gradient accumulated by the recurrence kernel itself (null: not wanted)
 };
 
 // Layers per launch.  One workgroup per CU must hold a launch's whole grid; a stack with more (direction, layer) cells than fit is
@@ -974,10 +996,11 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   for (int i = 0; i < ncells; ++i) {
     const PersistCellHost& c = cells[i];
     PCellB& d = a.c[i];
-    d.WlT = c.WlT; d.gates_dz = c.gates; d.C = c.C; d.mask = c.mask; d.d_enc = c.d_enc;
+    d.Wl = c.Wl; d.gates_dz = c.gates; d.C = c.C; d.mask = c.mask; d.d_enc = c.d_enc;
     d.d_hT = c.d_hT; d.d_cT = c.d_cT; d.reverse_pos = c.reverse_pos; d.layer = c.layer;
-    d.WuT = c.WuT; d.PR = c.PR; d.PD = c.PD; d.PD_up = c.PD_up; d.up_external = c.up_external;
+    d.Wu = c.PD ? c.Wu : nullptr; d.PR = c.PR; d.PD = c.PD; d.PD_up = c.PD_up; d.up_external = c.up_external;
     d.amax = (u64*)c.amax;
+    d.db = c.db;
   }
   a.ncells = ncells; a.nl = nl; a.T = T; a.B = B; a.h = h; a.H = H;
   a.amax_gen = amax_gen;

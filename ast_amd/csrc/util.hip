@@ -94,6 +94,24 @@ __global__ void k_copy2d(float* dst, long ldd, const float* src, long lds, int r
   }
 }
 
+// init_decoder_state and its backward: both tensors (c, h), all bridged layers, one launch (float4 over units)
+__global__ __launch_bounds__(256) void k_bridge_states(float* __restrict__ dec_c, float* __restrict__ dec_h, float* __restrict__ enc_c,
+                                                       float* __restrict__ enc_h, int nd, int nl_enc, int n, int B, int h, int to_dec) {
+  const int h4 = h / 4;
+  const long per = (long)n * B * nd * h4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < 2 * per; i += (long)gridDim.x * blockDim.x) {
+    const bool second = i >= per;
+    long r = second ? i - per : i;
+    const int u4 = (int)(r % h4); r /= h4;
+    const int d = (int)(r % nd); r /= nd;
+    const int b = (int)(r % B);
+    const int k = (int)(r / B);
+    float4* dq = reinterpret_cast<float4*>((second ? dec_h : dec_c) + (((long)k * B + b) * nd + d) * h) + u4;
+    float4* eq = reinterpret_cast<float4*>((second ? enc_h : enc_c) + (((long)d * nl_enc + k) * B + b) * h) + u4;
+    if (to_dec) *dq = *eq;
+    else *eq = *dq;
+  }
+}
 __global__ void k_add2d(float* dst, long ldd, const float* src, long lds, int rows, int cols) {
   const long n = (long)rows * cols;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -578,6 +596,17 @@ int astk_scale_f32(float* x, size_t n, float s, void* stream) {
 int astk_add_f32(float* dst, const float* src, size_t n, void* stream) {
   ASTK_CHECK(dst && src, "add: null pointer");
   return n ? axpy_rows(dst, src, n, (hipStream_t)stream) : 0;
+}
+int astk_bridge_states(float* dec_c, float* dec_h, float* enc_c, float* enc_h, int nd, int nl_enc, int n, int B, int h, int to_decoder,
+                       void* stream) {
+  ASTK_CHECK(dec_c && dec_h && enc_c && enc_h, "bridge_states: null pointer");
+  ASTK_CHECK(nd >= 1 && nl_enc >= 1 && n >= 0 && n <= nl_enc && B >= 1 && h >= 4 && (h % 4) == 0, "bridge_states: bad dimensions");
+  ASTK_CHECK(aligned16(dec_c) && aligned16(dec_h) && aligned16(enc_c) && aligned16(enc_h), "bridge_states: tensors must be 16-byte aligned");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_bridge_states, dim3(grid_for((size_t)2 * n * B * nd * (h / 4))), dim3(256), 0, (hipStream_t)stream, dec_c, dec_h, enc_c,
+                     enc_h, nd, nl_enc, n, B, h, to_decoder);
+  ASTK_LAUNCH_CHECK();
+  return 0;
 }
 int astk_colsum_add_f32(float* dst, const float* src, long lds, int rows, int cols, void* stream) {
   ASTK_CHECK(dst && src && rows > 0 && cols > 0 && lds >= cols, "colsum_add: bad arguments");

@@ -380,6 +380,12 @@ int astk_scale_f32(float* x, size_t n, float s, void* stream);
  * input gradient, whose input is one frame fed at every step). */
 int astk_add_f32(float* dst, const float* src, size_t n, void* stream);
 int astk_colsum_add_f32(float* dst, const float* src, long lds, int rows, int cols, void* stream);
+/* init_decoder_state (seq2seq.py:318-333) and its backward as ONE launch each: decoder layer k < n starts from [fwd_k ; rev_k] of the
+ * encoder's final states.  enc_c / enc_h: (nd, nl_enc, B, h) as astk_lstm_stack_fwd leaves them; dec_c / dec_h: (>= n, B, nd*h).
+ * to_decoder != 0: dec[k][b][d*h + u] = enc[d][k][b][u]; to_decoder == 0 (gradients): enc[d][k][b][u] = dec[k][b][d*h + u].
+ * Layers >= n of either side are not touched. */
+int astk_bridge_states(float* dec_c, float* dec_h, float* enc_c, float* enc_h, int nd, int nl_enc, int n, int B, int h, int to_decoder,
+                       void* stream);
 /* Frame zeroing of the training loader (dataloader.py:83-93, `zero_input`), on the padded device batch X (B,T,D): utterance b of true
  * length lengths[b] gets int(rate * lengths[b]) frames zeroed, drawn with replacement from [0, lengths[b]) like
  * np.random.choice(np.arange(T_b), size=n).  The reference's draw is unseeded (quirk Q7); this one is a counter-based stream
