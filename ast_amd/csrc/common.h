@@ -547,12 +547,15 @@ template <int NS, class Acc, class Emit>
 __device__ __forceinline__ void colreduce_block(int rows, int cols, Acc acc, Emit emit) {
   colreduce_block<NS>(rows, cols, acc, emit, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
-// grid for colreduce_block: enough row slabs for ~2 blocks per CU, at least 16 rows per lane
+// grid for colreduce_block: one block per CU, at least 16 rows per lane.  (Every block ends in same-address double atomics, one per column and
+// statistic: with 512 blocks the layer-0 BatchNorm statistics -- 128 columns, i.e. 256 arrivals per address -- took 29 us for a 39 MB read, with
+// 256 blocks 19; 128 blocks lose on the wide layers.  ASTK_COLREDUCE_BLOCKS overrides.)
 static inline dim3 colreduce_grid(int rows, int cols) {
   const int q = (cols + 3) / 4;
   const int CL = q < COLREDUCE_CL ? q : COLREDUCE_CL, NR = 256 / CL;
   const int gx = (q + CL - 1) / CL;
-  int gy = 512 / gx;
+  static const int blocks = getenv("ASTK_COLREDUCE_BLOCKS") ? atoi(getenv("ASTK_COLREDUCE_BLOCKS")) : 256;
+  int gy = blocks / gx;
   const int max_gy = (rows + 16 * NR - 1) / (16 * NR);
   if (gy > max_gy) gy = max_gy;
   if (gy < 1) gy = 1;

@@ -475,16 +475,16 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
 // re-order it into rows first (a pass of its own: 79 MB read + 79 MB written, 48 us of the train step); here a block owns SEQ_CH channels, takes
 // the contiguous C*F piece of SEQ_PP (t, b) pairs at a time through LDS (re-ordered (c, f) -> [f][c] on the way in) and works on the
 // F rows (b, f, t) of each pair -- Y rows and dY rows are touched 256 bytes at a time, like the row kernels do.
-constexpr int SEQ_PP = 8;             // (t, b) pairs per block iteration
 constexpr int SEQ_CH = 64;            // channels per block (16 lanes x 4)
 constexpr int SEQ_LD = SEQ_CH + 4;    // LDS row stride (floats): consecutive f rows four banks apart
-constexpr int SEQ_UNR = 4;            // rows a thread has in flight
-static size_t seq_tile_bytes(int F) { return std::max((size_t)SEQ_PP * F * SEQ_LD * sizeof(float), (size_t)2 * 256 * sizeof(float4)); }
-static bool seq_bwd_applicable(int C, int F) { return (C % SEQ_CH) == 0 && F >= 1 && F <= 16; }
+constexpr int SEQ_UNR = 4;            // rows a thread works on per block iteration: 16 row groups x 4 = 64 (pair, f) slots
+static int seq_pp(int F) { return 64 / F; }      // (t, b) pairs per block iteration: pp * F <= 64 slots
+static size_t seq_tile_bytes(int F) { return std::max((size_t)seq_pp(F) * F * SEQ_LD * sizeof(float), (size_t)2 * 256 * sizeof(float4)); }
+static bool seq_bwd_applicable(int C, int F, long npairs) { return (C % SEQ_CH) == 0 && F >= 1 && F <= 16 && npairs < (1L << 30); }
 // tile[pl][f][c - c0] = d_out[pair p0 + pl][c * F + f] for the block's channels (pairs past the end: the last pair again, never used)
-__device__ __forceinline__ void seq_tile_load(const float* __restrict__ d_out, float* tile, long p0, long npairs, int c0, int C, int F) {
+__device__ __forceinline__ void seq_tile_load(const float* __restrict__ d_out, float* tile, int p0, int npairs, int PP, int c0, int C, int F) {
   const int per_pair4 = SEQ_CH * F / 4;
-  for (int i = threadIdx.x; i < SEQ_PP * per_pair4; i += 256) {
+  for (int i = threadIdx.x; i < PP * per_pair4; i += 256) {
     const int pl = i / per_pair4, q4 = i % per_pair4;
     const long p = min(p0 + pl, npairs - 1);
     const float4 v = *reinterpret_cast<const float4*>(d_out + (p * C + c0) * F + 4 * q4);
@@ -496,41 +496,53 @@ __device__ __forceinline__ void seq_tile_load(const float* __restrict__ d_out, f
     tp[f * SEQ_LD + c] = v.w;
   }
 }
+// A thread's four (pair, f) slots are the same in every block iteration (slot = row group + 16 u): set up once.
+struct SeqSlots {
+  int pl[SEQ_UNR], f[SEQ_UNR], off[SEQ_UNR];
+  bool ok[SEQ_UNR];
+  __device__ __forceinline__ void init(int g16, int n, int F, int cl) {
+#pragma unroll
+    for (int u = 0; u < SEQ_UNR; ++u) {
+      const int slot = min(g16 + 16 * u, n - 1);
+      ok[u] = g16 + 16 * u < n;
+      pl[u] = slot / F; f[u] = slot % F;
+      off[u] = slot * SEQ_LD + cl;
+    }
+  }
+};
 // stat[c] += sum g, stat[C + c] += sum g * xhat over all rows, g = d_out * (bn(Y) > 0): grid (C / SEQ_CH, row slabs)
 __global__ __launch_bounds__(256) void k_bn_bwd_stats_seq(const float* __restrict__ Y, const float* __restrict__ d_out, const float* __restrict__ bn,
-                                                          int B, int F, int Tn, int C, double* __restrict__ stat) {
+                                                          int B, int F, int Tn, int C, int PP, double* __restrict__ stat) {
   extern __shared__ __attribute__((aligned(16))) float seq_tile[];
   const int c0 = blockIdx.x * SEQ_CH, cl = 4 * (threadIdx.x & 15), c = c0 + cl, g16 = threadIdx.x >> 4;
-  const long npairs = (long)Tn * B;
+  const int npairs = Tn * B;
   const float4 mean = *reinterpret_cast<const float4*>(bn + c), inv = *reinterpret_cast<const float4*>(bn + C + c);
   const float4 sc = *reinterpret_cast<const float4*>(bn + 2 * C + c), sh = *reinterpret_cast<const float4*>(bn + 3 * C + c);
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-  const int n = SEQ_PP * F;
-  for (long p0 = (long)blockIdx.y * SEQ_PP; p0 < npairs; p0 += (long)gridDim.y * SEQ_PP) {
-    __syncthreads();
-    seq_tile_load(d_out, seq_tile, p0, npairs, c0, C, F);
-    __syncthreads();
-    for (int base = g16; base < n; base += 16 * SEQ_UNR) {
-      float4 y[SEQ_UNR], gr[SEQ_UNR];
-      float w[SEQ_UNR];
+  SeqSlots sl;
+  sl.init(g16, PP * F, F, cl);
+  for (int p0 = blockIdx.y * PP; p0 < npairs; p0 += gridDim.y * PP) {
+    // the rows of Y first (they do not wait for the tile): both streams of the iteration are in flight together
+    float4 y[SEQ_UNR];
+    float w[SEQ_UNR];
 #pragma unroll
-      for (int u = 0; u < SEQ_UNR; ++u) {          // (clamped, unconditional loads; a slot past the end counts with weight 0)
-        const int combo = min(base + 16 * u, n - 1);
-        const int pl = combo / F, f = combo % F;
-        const long pp = min(p0 + pl, npairs - 1);
-        w[u] = (base + 16 * u < n && p0 + pl < npairs) ? 1.f : 0.f;
-        const int t = (int)(pp / B), b = (int)(pp % B);
-        y[u] = *reinterpret_cast<const float4*>(Y + (((long)b * F + f) * Tn + t) * C + c);
-        gr[u] = *reinterpret_cast<const float4*>(seq_tile + combo * SEQ_LD + cl);
-      }
+    for (int u = 0; u < SEQ_UNR; ++u) {          // (clamped, unconditional loads; a slot past the end counts with weight 0)
+      const int pp = min(p0 + sl.pl[u], npairs - 1);
+      w[u] = (sl.ok[u] && p0 + sl.pl[u] < npairs) ? 1.f : 0.f;
+      const int t = pp / B, b = pp - t * B;
+      y[u] = *reinterpret_cast<const float4*>(Y + (((long)b * F + sl.f[u]) * Tn + t) * C + c);
+    }
+    __syncthreads();
+    seq_tile_load(d_out, seq_tile, p0, npairs, PP, c0, C, F);
+    __syncthreads();
 #pragma unroll
-      for (int u = 0; u < SEQ_UNR; ++u) {
-        const float g0 = (y[u].x * sc.x + sh.x > 0.f) ? gr[u].x * w[u] : 0.f, g1 = (y[u].y * sc.y + sh.y > 0.f) ? gr[u].y * w[u] : 0.f;
-        const float g2 = (y[u].z * sc.z + sh.z > 0.f) ? gr[u].z * w[u] : 0.f, g3 = (y[u].w * sc.w + sh.w > 0.f) ? gr[u].w * w[u] : 0.f;
-        a0.x += g0; a0.y += g1; a0.z += g2; a0.w += g3;
-        a1.x += g0 * (y[u].x - mean.x) * inv.x; a1.y += g1 * (y[u].y - mean.y) * inv.y;
-        a1.z += g2 * (y[u].z - mean.z) * inv.z; a1.w += g3 * (y[u].w - mean.w) * inv.w;
-      }
+    for (int u = 0; u < SEQ_UNR; ++u) {
+      const float4 gr = *reinterpret_cast<const float4*>(seq_tile + sl.off[u]);
+      const float g0 = (y[u].x * sc.x + sh.x > 0.f) ? gr.x * w[u] : 0.f, g1 = (y[u].y * sc.y + sh.y > 0.f) ? gr.y * w[u] : 0.f;
+      const float g2 = (y[u].z * sc.z + sh.z > 0.f) ? gr.z * w[u] : 0.f, g3 = (y[u].w * sc.w + sh.w > 0.f) ? gr.w * w[u] : 0.f;
+      a0.x += g0; a0.y += g1; a0.z += g2; a0.w += g3;
+      a1.x += g0 * (y[u].x - mean.x) * inv.x; a1.y += g1 * (y[u].y - mean.y) * inv.y;
+      a1.z += g2 * (y[u].z - mean.z) * inv.z; a1.w += g3 * (y[u].w - mean.w) * inv.w;
     }
   }
   __syncthreads();
@@ -550,51 +562,46 @@ __global__ __launch_bounds__(256) void k_bn_bwd_stats_seq(const float* __restric
 }
 // dY[prow(b, f, t)][c] = scale * (g - (xhat * dgamma + dbeta) / rows), the k_bn_bwd_apply of the last layer with g read from d_out
 __global__ __launch_bounds__(256) void k_bn_bwd_apply_seq(const float* __restrict__ Y, const float* __restrict__ d_out, const float* __restrict__ bn,
-                                                          const double* __restrict__ stat, float* __restrict__ dY, int B, int F, int Tn, int C, int padF,
-                                                          int padB, float* __restrict__ dgamma, float* __restrict__ dbeta, float invm,
+                                                          const double* __restrict__ stat, float* __restrict__ dY, int B, int F, int Tn, int C, int PP,
+                                                          int padF, int padB, float* __restrict__ dgamma, float* __restrict__ dbeta, float invm,
                                                           unsigned long long* amax) {
   extern __shared__ __attribute__((aligned(16))) float seq_tile[];
   __shared__ float red4[4];
   const int c0 = blockIdx.x * SEQ_CH, cl = 4 * (threadIdx.x & 15), c = c0 + cl, g16 = threadIdx.x >> 4;
-  const long npairs = (long)Tn * B;
+  const int npairs = Tn * B;
   const float4 mean = *reinterpret_cast<const float4*>(bn + c), inv = *reinterpret_cast<const float4*>(bn + C + c);
   const float4 sc = *reinterpret_cast<const float4*>(bn + 2 * C + c), sh = *reinterpret_cast<const float4*>(bn + 3 * C + c);
-  const float dg0 = (float)stat[C + c] * invm, dg1 = (float)stat[C + c + 1] * invm, dg2 = (float)stat[C + c + 2] * invm, dg3 = (float)stat[C + c + 3] * invm;
-  const float db0 = (float)stat[c] * invm, db1 = (float)stat[c + 1] * invm, db2 = (float)stat[c + 2] * invm, db3 = (float)stat[c + 3] * invm;
-  const int n = SEQ_PP * F;
+  const float dg0 = (float)stat[C + c], dg1 = (float)stat[C + c + 1], dg2 = (float)stat[C + c + 2], dg3 = (float)stat[C + c + 3];
+  const float db0 = (float)stat[c], db1 = (float)stat[c + 1], db2 = (float)stat[c + 2], db3 = (float)stat[c + 3];
+  SeqSlots sl;
+  sl.init(g16, PP * F, F, cl);
   float mx = 0.f;
-  for (long p0 = (long)blockIdx.y * SEQ_PP; p0 < npairs; p0 += (long)gridDim.y * SEQ_PP) {
-    __syncthreads();
-    seq_tile_load(d_out, seq_tile, p0, npairs, c0, C, F);
-    __syncthreads();
-    for (int base = g16; base < n; base += 16 * SEQ_UNR) {
-      float4 y[SEQ_UNR];
-      long row[SEQ_UNR];
-      bool ok[SEQ_UNR];
-      int cmb[SEQ_UNR];
+  for (int p0 = blockIdx.y * PP; p0 < npairs; p0 += gridDim.y * PP) {
+    float4 y[SEQ_UNR];
+    long row[SEQ_UNR];
+    bool ok[SEQ_UNR];
 #pragma unroll
-      for (int u = 0; u < SEQ_UNR; ++u) {
-        const int combo = min(base + 16 * u, n - 1);
-        const int pl = combo / F, f = combo % F;
-        const long pp = min(p0 + pl, npairs - 1);
-        ok[u] = base + 16 * u < n && p0 + pl < npairs;
-        const int t = (int)(pp / B), b = (int)(pp % B);
-        cmb[u] = combo;
-        row[u] = ((long)b * F + f) * (Tn + padF + padB) + padF + t;
-        y[u] = *reinterpret_cast<const float4*>(Y + (((long)b * F + f) * Tn + t) * C + c);
-      }
+    for (int u = 0; u < SEQ_UNR; ++u) {
+      const int pp = min(p0 + sl.pl[u], npairs - 1);
+      ok[u] = sl.ok[u] && p0 + sl.pl[u] < npairs;
+      const int t = pp / B, b = pp - t * B;
+      row[u] = ((long)b * F + sl.f[u]) * (Tn + padF + padB) + padF + t;
+      y[u] = *reinterpret_cast<const float4*>(Y + (((long)b * F + sl.f[u]) * Tn + t) * C + c);
+    }
+    __syncthreads();
+    seq_tile_load(d_out, seq_tile, p0, npairs, PP, c0, C, F);
+    __syncthreads();
 #pragma unroll
-      for (int u = 0; u < SEQ_UNR; ++u) {
-        const float4 gr = *reinterpret_cast<const float4*>(seq_tile + cmb[u] * SEQ_LD + cl);
-        float4 v;
-        v.x = sc.x * (((y[u].x * sc.x + sh.x > 0.f) ? gr.x : 0.f) - ((y[u].x - mean.x) * inv.x * dg0 + db0));
-        v.y = sc.y * (((y[u].y * sc.y + sh.y > 0.f) ? gr.y : 0.f) - ((y[u].y - mean.y) * inv.y * dg1 + db1));
-        v.z = sc.z * (((y[u].z * sc.z + sh.z > 0.f) ? gr.z : 0.f) - ((y[u].z - mean.z) * inv.z * dg2 + db2));
-        v.w = sc.w * (((y[u].w * sc.w + sh.w > 0.f) ? gr.w : 0.f) - ((y[u].w - mean.w) * inv.w * dg3 + db3));
-        if (ok[u]) {
-          *reinterpret_cast<float4*>(dY + row[u] * C + c) = v;
-          mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-        }
+    for (int u = 0; u < SEQ_UNR; ++u) {
+      const float4 gr = *reinterpret_cast<const float4*>(seq_tile + sl.off[u]);
+      float4 v;      // (the same expression, term for term, as k_bn_bwd_apply)
+      v.x = sc.x * (((y[u].x * sc.x + sh.x > 0.f) ? gr.x : 0.f) - ((y[u].x - mean.x) * inv.x * dg0 + db0) * invm);
+      v.y = sc.y * (((y[u].y * sc.y + sh.y > 0.f) ? gr.y : 0.f) - ((y[u].y - mean.y) * inv.y * dg1 + db1) * invm);
+      v.z = sc.z * (((y[u].z * sc.z + sh.z > 0.f) ? gr.z : 0.f) - ((y[u].z - mean.z) * inv.z * dg2 + db2) * invm);
+      v.w = sc.w * (((y[u].w * sc.w + sh.w > 0.f) ? gr.w : 0.f) - ((y[u].w - mean.w) * inv.w * dg3 + db3) * invm);
+      if (ok[u]) {
+        *reinterpret_cast<float4*>(dY + row[u] * C + c) = v;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
       }
     }
   }
@@ -801,7 +808,7 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
   // the last layer's BatchNorm backward reads d_out in its (T'', B, C*F') layout itself (k_bn_bwd_*_seq); shapes those kernels do not take
   // (and the test hook that edits G) go through the re-ordered copy G as before.  ASTK_CNN_SEQ_BWD=0: always the copy.
   static const bool seq_off = getenv("ASTK_CNN_SEQ_BWD") && getenv("ASTK_CNN_SEQ_BWD")[0] == '0';
-  bool seq_last = !seq_off && seq_bwd_applicable(P.Cn[P.n - 1], P.Fn[P.n - 1]);
+  bool seq_last = !seq_off && seq_bwd_applicable(P.Cn[P.n - 1], P.Fn[P.n - 1], (long)P.Tn[P.n - 1] * B);
 #ifdef ASTK_TEST_HOOKS
   if (g_kill_n > 0) seq_last = false;
 #endif
@@ -824,9 +831,10 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
     const bool seq = seq_last && i == P.n - 1;
     const int seq_gx = C / SEQ_CH;
     if (seq) {
-      const int gy = std::max(1, std::min(512 / seq_gx, cdiv(P.Tn[i] * B, SEQ_PP)));
+      static const int sb = getenv("ASTK_SEQ_STATS_BLOCKS") ? atoi(getenv("ASTK_SEQ_STATS_BLOCKS")) : 1024;
+      const int gy = std::max(1, std::min(sb / seq_gx, cdiv(P.Tn[i] * B, seq_pp(P.Fn[i]))));
       hipLaunchKernelGGL(k_bn_bwd_stats_seq, dim3(seq_gx, gy), dim3(256), seq_tile_bytes(P.Fn[i]), s, P.Y[i], d_out, P.bn[i], B, P.Fn[i], P.Tn[i], C,
-                         P.stat[i]);
+                         seq_pp(P.Fn[i]), P.stat[i]);
     } else
       hipLaunchKernelGGL(k_bn_bwd_stats, colreduce_grid(rows, C), dim3(256), 0, s, P.Y[i], P.G, P.bn[i], rows, C, P.stat[i]);
     ASTK_LAUNCH_CHECK();
@@ -845,9 +853,10 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
     // (no_bn: the ReLU mask alone -- scale 1 and a zero 1/m switch the BatchNorm terms off; the column sums of g are the bias gradient)
     // pooled layers: the gradient wrt the POOLED output goes to DYP (plain rows), k_unpool spreads it over the padded dY of the convolution
     if (seq) {
-      const int gy = std::max(1, std::min(1024 / seq_gx, cdiv(P.Tn[i] * B, SEQ_PP)));
+      static const int ab = getenv("ASTK_SEQ_APPLY_BLOCKS") ? atoi(getenv("ASTK_SEQ_APPLY_BLOCKS")) : 1024;
+      const int gy = std::max(1, std::min(ab / seq_gx, cdiv(P.Tn[i] * B, seq_pp(P.Fn[i]))));
       hipLaunchKernelGGL(k_bn_bwd_apply_seq, dim3(seq_gx, gy), dim3(256), seq_tile_bytes(P.Fn[i]), s, P.Y[i], d_out, P.bn[i], P.stat[i],
-                         P.pooled[i] ? P.DYP[i] : P.DY[i], B, P.Fn[i], P.Tn[i], C, P.pooled[i] ? 0 : P.dF[i], P.pooled[i] ? 0 : P.dB[i],
+                         P.pooled[i] ? P.DYP[i] : P.DY[i], B, P.Fn[i], P.Tn[i], C, seq_pp(P.Fn[i]), P.pooled[i] ? 0 : P.dF[i], P.pooled[i] ? 0 : P.dB[i],
                          (exchange || d->no_bn) ? nullptr : Gr[i].dgamma, (exchange || d->no_bn) ? nullptr : Gr[i].dbeta,
                          d->no_bn ? 0.f : 1.f / ((float)rows * (exchange ? world : 1)), (i > 0 && !P.pooled[i]) ? P.a_dy_s[i] : nullptr);
     } else

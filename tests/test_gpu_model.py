@@ -645,7 +645,9 @@ def test_full_size_batch_permutation_and_gradient_accumulation(model, B, T, D, o
                 va, vb = float(za[perm[j], r, c]), float(zb[j, r, c])
                 # (pre-activations are O(1): BatchNorm output; with fp16 operands the conv output itself carries 11-bit products and
                 #  the two evaluations' statistics differ a little more)
-                assert max(abs(va), abs(vb)) < (1e-5 if operands == "f32" else 1e-4), (i, j, r, c, va, vb)
+                # (fp16 bound: 2e-4, the mode's own self-agreement -- the two evaluations of one pre-activation differ by up to ~1.3e-4
+                #  there, so a unit at +1.1e-4 in one of them can sit below zero in the other)
+                assert max(abs(va), abs(vb)) < (1e-5 if operands == "f32" else 2e-4), (i, j, r, c, va, vb)
                 rows_per_b = za.shape[1]
                 flips1.append((i, j * rows_per_b + r, c))
                 flips0.append((i, int(perm[j]) * rows_per_b + r, c))
