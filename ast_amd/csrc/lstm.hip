@@ -27,7 +27,9 @@ struct PersistCellHost {
   int reverse_pos, layer;
   unsigned long long* amax;
   float* db;
+  long dy_sb, dy_st;
 };
+bool lstm_persist_hoisted(int h);
 bool lstm_persist_applicable(int T, int B, int h, int nl, int nd);
 int lstm_persist_layers_per_launch(int B, int h, int nl, int nd);
 size_t lstm_persist_pr_floats(int B, int h);
@@ -89,8 +91,10 @@ int make_plan(const astk_lstm_stack_desc* d, void* ws, bool with_masks, LstmPlan
     const bool pp = lstm_persist_applicable(P.T, P.B, P.h, P.nl, P.nd);
     for (int dd = 0; dd < P.nd; ++dd)
       for (int l = 0; l < P.nl; ++l) {
-        P.PR[dd][l] = c.take<float>(pp ? lstm_persist_pr_floats(P.B, P.h) : 4);
-        P.PD[dd][l] = c.take<float>(pp && l > 0 ? lstm_persist_pd_floats(P.T, P.B, P.h) : 4);
+        // (hoisted form: the layers run one launch after the other, every cell of a direction uses the ring of layer 0; no down partials)
+        const bool hoist = lstm_persist_hoisted(P.h);
+        P.PR[dd][l] = (hoist && l > 0) ? P.PR[dd][0] : c.take<float>(pp ? lstm_persist_pr_floats(P.B, P.h) : 4);
+        P.PD[dd][l] = c.take<float>(pp && l > 0 && !hoist ? lstm_persist_pd_floats(P.T, P.B, P.h) : 4);
       }
   }
   P.bytes = c.total();
@@ -205,7 +209,23 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
       }
     }
     ASTK_TRY(gemm_launch_group(GEMM_NT, k9, P.nd, s));
-    {
+    if (lstm_persist_hoisted(h)) {
+      // hoisted form: every layer a launch of its own over "layer-0 like" cells -- the input projection of all time steps comes from a
+      // batched product in front of the launch (written into the gates buffer, where the cell replaces it step by step)
+      for (int l = 0; l < P.nl; ++l) {
+        PersistCellHost grp[16];
+        GemmArgs up[2];
+        for (int dd = 0; dd < P.nd; ++dd) {
+          PersistCellHost& c = cells[dd * P.nl + l];
+          if (l > 0) up[dd] = gemm_args(T * B, 4 * h, h, mat(c.xin, h), mat(c.Wu, h), P.ZG[dd][l], 4 * h, c.bias);
+          c.Wu = nullptr; c.bias = nullptr; c.xin = nullptr;
+          c.zx = P.ZG[dd][l];
+          grp[dd] = c;
+        }
+        if (l > 0) ASTK_TRY(gemm_launch_group(GEMM_NT, up, P.nd, s));
+        ASTK_TRY(lstm_persist_fwd_launch(grp, P.nd, 1, T, B, h, H, P.counters, s));
+      }
+    } else {
       // one launch per group of layers (normally a single group: the whole stack); a later group finds the outputs of the layer
       // below complete (its sentinel polls succeed at once)
       const int lpl = lstm_persist_layers_per_launch(B, h, P.nl, P.nd);
@@ -323,6 +343,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
         c.C = P.CC[dd][l];
         c.mask = masks ? masks + ((size_t)dd * P.nl + l) * T * bh : nullptr;
         c.d_enc = top ? d_enc + (size_t)dd * h : nullptr;
+        c.dy_sb = (long)T * H; c.dy_st = H;
         c.d_hT = d_hT ? d_hT + ((size_t)dd * P.nl + l) * bh : nullptr;
         c.d_cT = d_cT ? d_cT + ((size_t)dd * P.nl + l) * bh : nullptr;
         c.reverse_pos = dd == 1;
@@ -332,7 +353,23 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
     gemm_amax_reserve(P.nd * P.nl, dz_amax, &dz_amax_gen, s);
     for (int i = 0; i < P.nd * P.nl; ++i) cells[i].amax = dz_amax[i];
     ASTK_TRY(stream_order(s, sr));     // the recurrence kernel may live on its own (CU-masked) stream, see astk.h
-    {
+    if (lstm_persist_hoisted(h)) {
+      // hoisted form: layer by layer from the top; a lower layer's incoming gradient is the dense (T,B,h) product dz W_u of the layer
+      // above, one batched product per direction between the launches (no partial tiles handed down)
+      for (int l = P.nl - 1; l >= 0; --l) {
+        PersistCellHost grp[16];
+        for (int dd = 0; dd < P.nd; ++dd) {
+          PersistCellHost& c = cells[dd * P.nl + l];
+          c.PD = nullptr; c.PD_up = nullptr; c.up_external = 0;
+          if (l < P.nl - 1) { c.d_enc = P.DX[dd]; c.dy_sb = h; c.dy_st = (long)B * h; c.reverse_pos = 0; }
+          grp[dd] = c;
+        }
+        ASTK_TRY(lstm_persist_bwd_launch(grp, P.nd, 1, T, B, h, H, P.counters, dz_amax_gen, sr));
+        if (l > 0)
+          for (int dd = 0; dd < P.nd; ++dd)
+            ASTK_TRY(gemm_launch(GEMM_NN, with_amax_a(gemm_args(T * B, h, 4 * h, mat(P.ZG[dd][l], 4 * h), mat(prm[dd * P.nl + l].Wu, h), P.DX[dd], h), dz_amax[dd * P.nl + l]), sr));
+      }
+    } else {
       // groups of layers, top group first; the top layer of a lower group reads the partial dx tiles the previous launch left
       const int lpl = lstm_persist_layers_per_launch(B, h, P.nl, P.nd);
       int l1 = P.nl;

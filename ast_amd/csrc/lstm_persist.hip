@@ -58,7 +58,10 @@ struct PCellB {
   float* gates_dz;      // (T,B,4h): activated gates in, dz out (in place; the batched products after the launch read it)
   const float* C;       // (T,B,h)
   const float* mask;    // (T,B,h) or null
-  const float* d_enc;   // top layer: d_enc_states + dir*h
+  const float* d_enc;   // gradient wrt this cell's (dropped-out) output that does not come as partial tiles: the top layer's slice of
+                        // d_enc_states (+ dir*h), or -- hoisted form -- the dense (T,B,h) product dz W_u of the layer above; element
+                        // (row b, position p, unit u) at d_enc[b * dy_sb + p * dy_st + u]
+  long dy_sb, dy_st;
   const float* d_hT;    // (B,h) or null
   const float* d_cT;    // (B,h) or null
   // reduce-scatter path (lstm_persist_bwd_rs):
@@ -483,8 +486,12 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_g(PFwdArgs a) {
   // (a COPY, not a reference into the kernel-argument block: fields read through a dynamically indexed reference are re-loaded behind
   //  every global store of the step loop -- the stores might alias them -- and each re-load is a scalar-cache round trip on the chain)
   const PCellF c = a.c[blockIdx.z];
-  if (c.layer > 0) lstm_fwd_steps<KB, true, XS>(a, c, red[0], red[1]);
-  else lstm_fwd_steps<KB, false, XS>(a, c, red[0], red[1]);
+  // a cell multiplies its input itself iff it was given the upward weight: layer 0 -- and, in the hoisted form (h = 1024: the weight
+  // fragments of ONE product fill the registers), every layer -- gets the projection of all time steps from a batched GEMM (zx)
+  if constexpr (KB <= 8) {
+    if (c.Wu != nullptr) { lstm_fwd_steps<KB, true, XS>(a, c, red[0], red[1]); return; }
+  }
+  lstm_fwd_steps<KB, false, XS>(a, c, red[0], red[1]);
 }
 
 
@@ -531,7 +538,10 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
   const int nbt = gridDim.y;
   const int K = 4 * h;
   constexpr bool has_up = HAS_UP;
-  const bool has_down = c.PD != nullptr;
+  // h = 1024 (KB = 16): one product's weight fragments fill the registers -- the gradient for the layer below is a batched GEMM behind
+  // the launch there (hoisted form), and the code of the down product is compiled out
+  constexpr bool CAN_DOWN = KB <= 8;
+  const bool has_down = CAN_DOWN && c.PD != nullptr;
   unsigned* ctrA = a.done + (cell * nbt + bt) * CTR_STRIDE;
   unsigned* ctrB = a.done + ((a.ncells + cell) * nbt + bt) * CTR_STRIDE;
   const unsigned* upB = has_up ? a.done + ((a.ncells + cell + 1) * nbt + bt) * CTR_STRIDE : nullptr;
@@ -549,8 +559,8 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
   // X2: fp16 hi / lo fragments behind one power-of-two scale per workgroup (see the forward kernel); the 64 gate columns are two 32-k operands
   constexpr bool X2 = XS != 0;          // a split scheme (16-bit MFMAs); XS == 2 additionally scales
   typedef typename FragOf<XS>::type Frag;
-  Frag wlh[X2 ? KB : 1][2], wdh[X2 ? KB : 1][2];
-  float4 wl[X2 ? 1 : KB][4], wd[X2 ? 1 : KB][4];
+  Frag wlh[X2 ? KB : 1][2], wdh[(X2 && CAN_DOWN) ? KB : 1][2];
+  float4 wl[X2 ? 1 : KB][4], wd[(!X2 && CAN_DOWN) ? KB : 1][4];
   float winv = 1.f;
   if constexpr (X2) {
     float wscl = 1.f;
@@ -559,7 +569,7 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
 #pragma unroll
       for (int nt = 0; nt < KB; ++nt)
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) m = amax4f(amax4f(m, wl_at(nt, s4)), wd_at(nt, s4));
+        for (int s4 = 0; s4 < 4; ++s4) m = amax4f(amax4f(m, wl_at(nt, s4)), CAN_DOWN ? wd_at(nt, s4) : make_float4(0.f, 0.f, 0.f, 0.f));
       wscl = pow2_scale_for(wg_max(m, dzS), winv);
     }
 #pragma unroll
@@ -567,13 +577,13 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         wlh[nt][p] = split_frag<XS>(wl_at(nt, 2 * p), wl_at(nt, 2 * p + 1), wscl);
-        wdh[nt][p] = split_frag<XS>(wd_at(nt, 2 * p), wd_at(nt, 2 * p + 1), wscl);
+        if constexpr (CAN_DOWN) wdh[nt][p] = split_frag<XS>(wd_at(nt, 2 * p), wd_at(nt, 2 * p + 1), wscl);
       }
   } else {
 #pragma unroll
     for (int nt = 0; nt < KB; ++nt)
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) { wl[nt][s4] = wl_at(nt, s4); wd[nt][s4] = wd_at(nt, s4); }
+      for (int s4 = 0; s4 < 4; ++s4) { wl[nt][s4] = wl_at(nt, s4); if constexpr (CAN_DOWN) wd[nt][s4] = wd_at(nt, s4); }
   }
   const __amdgpu_buffer_rsrc_t r_pr = make_rsrc(c.PR);
   const __amdgpu_buffer_rsrc_t r_pd = make_rsrc(has_down ? c.PD : c.PR);
@@ -612,12 +622,12 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
   }
   bool pending_b = false;
   bool dead = false;      // this wave gave up waiting (abort / time-out): it runs the remaining steps without waiting, so that barriers still match
-  f32x4 acc2[KB];
+  f32x4 acc2[CAN_DOWN ? KB : 1];
 #pragma unroll
-  for (int nt = 0; nt < KB; ++nt) acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int nt = 0; nt < (CAN_DOWN ? KB : 1); ++nt) acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto store_down = [&](int ts) {
 #pragma unroll
-    for (int nt = 0; nt < KB; ++nt) {
+    for (int nt = 0; nt < (CAN_DOWN ? KB : 0); ++nt) {
       const int tl = wave * KB + nt;
       u32x4 o;
       o.x = __float_as_uint(acc2[nt][0]); o.y = __float_as_uint(acc2[nt][1]); o.z = __float_as_uint(acc2[nt][2]); o.w = __float_as_uint(acc2[nt][3]);
@@ -638,7 +648,7 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     // (unconditional loads through a selected pointer: a load under `if (c.d_enc)` is a phi of "old value / load result", which hipcc
     //  resolves by waiting for the load where it is issued -- a full memory latency per step, 1.75 us in the top layer's timers)
     const float* const mp = c.mask ? c.mask + tbs * h + eu : c.C + tbs * h + eu;
-    const float* const dp = c.d_enc ? c.d_enc + (ebc * T + (c.reverse_pos ? T - 1 - ts : ts)) * HH + eu : c.C + tbs * h + eu;
+    const float* const dp = c.d_enc ? c.d_enc + ebc * c.dy_sb + (c.reverse_pos ? T - 1 - ts : ts) * c.dy_st + eu : c.C + tbs * h + eu;
     const float mv = *mp, dv = *dp;
     in_mk = c.mask ? mv : 1.f;
     in_dye = c.d_enc ? dv : 0.f;
@@ -807,7 +817,7 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     // behind the publish, with or without holding its stores back: 0.3-0.4 us per step slower -- the peers see counter A only
     // ~2 us after the atomic either way, so hiding the 0.5 us drain is what pays.)
     constexpr int KB1 = (KB + 1) / 2;     // first half of product 2 hides the drain, second half runs behind the publish
-    if (has_down) {
+    if constexpr (CAN_DOWN) if (has_down) {
 #pragma unroll
       for (int nt = 0; nt < KB1; ++nt) {
         acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -837,7 +847,7 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     TICK(5, t0)
     if (evalid) *reinterpret_cast<float4*>(c.gates_dz + tb * K + 4 * eu) = dz;   // for the batched products after the launch
     dbacc.x += dz.x; dbacc.y += dz.y; dbacc.z += dz.z; dbacc.w += dz.w;
-    if (has_down) {
+    if constexpr (CAN_DOWN) if (has_down) {
 #pragma unroll
       for (int nt = KB1; nt < KB; ++nt) {
         acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -914,25 +924,37 @@ struct PersistCellHost {
   int reverse_pos, layer;
   unsigned long long* amax;       // backward: where max |dz| of the cell goes (16 sharded words, gemm_amax_reserve), null: not wanted
   float* db;                      // backward: bias gradient accumulated by the recurrence kernel itself (null: not wanted)
+  long dy_sb, dy_st;              // backward: strides of d_enc (see PCellB)
 };
 
 // Layers per launch.  One workgroup per CU must hold a launch's whole grid; a stack with more (direction, layer) cells than fit is
 // run as consecutive launches over groups of layers (all directions of `lpl` layers each): the wavefront overlap between the
 // groups is lost, everything else stays (BASELINE configs[4]: 6 layers x 2 directions x 32 unit slices x 2 batch tiles = 768
 // workgroups -> 3 launches of 2 layers; batch 64 at the shipped width: 2 launches).  0 = not applicable.
+bool lstm_persist_hoisted(int h);
 int lstm_persist_layers_per_launch(int B, int h, int nl, int nd) {
   const long per_layer = (long)(h / 16) * ((B + 15) / 16) * nd;
   const long cus = device_cu_count();
   if (per_layer < 1 || per_layer > cus) return 0;
   long lpl = cus / per_layer;
+  if (lstm_persist_hoisted(h) && lpl > 1) lpl = 1;
   if (lpl > nl) lpl = nl;
   while (lpl * nd > 16) --lpl;
   return (int)lpl;
 }
 
+// Hoisted form (h = 1024): the weight fragments of one product fill a workgroup's registers, so every layer runs as a launch of its
+// own over cells that get their input projection from a batched GEMM in front of it (forward) and leave the gradient for the layer below
+// to a batched GEMM behind it (backward) -- the structure of the per-step path with T launches per layer replaced by one.
+bool lstm_persist_hoisted(int h) { return h >= 1024; }
+
 bool lstm_persist_applicable(int T, int B, int h, int nl, int nd) {
-  if (!(h == 64 || h == 128 || h == 256 || h == 512)) return false;
+  if (!(h == 64 || h == 128 || h == 256 || h == 512 || h == 1024)) return false;
   if (B < 1 || T < 1) return false;
+  if (lstm_persist_hoisted(h)) {
+    static const bool hoist_off = getenv("ASTK_LSTM_HOIST") && getenv("ASTK_LSTM_HOIST")[0] == '0';
+    if (hoist_off) return false;
+  }
   if (lstm_persist_layers_per_launch(B, h, nl, nd) < 1) return false;
   // hand-off buffers are addressed with 32-bit byte offsets
   if ((long)T * B * h * 16 >= (1L << 31) || (long)T * ((B + 15) / 16) * (h / 16) * (h / 16) * 1024 >= (1L << 31)) return false;
@@ -980,7 +1002,8 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
     case 64: if (xs == 2) ASTK_LSTM_FWD_(1, 2); else if (xs == 3) ASTK_LSTM_FWD_(1, 3); else ASTK_LSTM_FWD_(1, 0); break;
     case 128: if (xs == 2) ASTK_LSTM_FWD_(2, 2); else if (xs == 3) ASTK_LSTM_FWD_(2, 3); else ASTK_LSTM_FWD_(2, 0); break;
     case 256: if (xs == 2) ASTK_LSTM_FWD_(4, 2); else if (xs == 3) ASTK_LSTM_FWD_(4, 3); else ASTK_LSTM_FWD_(4, 0); break;
-    default: if (xs == 2) ASTK_LSTM_FWD_(8, 2); else ASTK_LSTM_FWD_(8, 0); break;
+    case 512: if (xs == 2) ASTK_LSTM_FWD_(8, 2); else ASTK_LSTM_FWD_(8, 0); break;
+    default: if (xs == 2) ASTK_LSTM_FWD_(16, 2); else ASTK_LSTM_FWD_(16, 0); break;
   }
 #undef ASTK_LSTM_FWD_
   ASTK_LAUNCH_CHECK();
@@ -998,6 +1021,7 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
     PCellB& d = a.c[i];
     d.Wl = c.Wl; d.gates_dz = c.gates; d.C = c.C; d.mask = c.mask; d.d_enc = c.d_enc;
     d.d_hT = c.d_hT; d.d_cT = c.d_cT; d.reverse_pos = c.reverse_pos; d.layer = c.layer;
+    d.dy_sb = c.dy_sb; d.dy_st = c.dy_st;
     d.Wu = c.PD ? c.Wu : nullptr; d.PR = c.PR; d.PD = c.PD; d.PD_up = c.PD_up; d.up_external = c.up_external;
     d.amax = (u64*)c.amax;
     d.db = c.db;
@@ -1032,7 +1056,8 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
     case 64: if (xs == 2) ASTK_LSTM_BWD_(1, 2); else if (xs == 3) ASTK_LSTM_BWD_(1, 3); else ASTK_LSTM_BWD_(1, 0); break;
     case 128: if (xs == 2) ASTK_LSTM_BWD_(2, 2); else if (xs == 3) ASTK_LSTM_BWD_(2, 3); else ASTK_LSTM_BWD_(2, 0); break;
     case 256: if (xs == 2) ASTK_LSTM_BWD_(4, 2); else if (xs == 3) ASTK_LSTM_BWD_(4, 3); else ASTK_LSTM_BWD_(4, 0); break;
-    default: if (xs == 2) ASTK_LSTM_BWD_(8, 2); else ASTK_LSTM_BWD_(8, 0); break;
+    case 512: if (xs == 2) ASTK_LSTM_BWD_(8, 2); else ASTK_LSTM_BWD_(8, 0); break;
+    default: if (xs == 2) ASTK_LSTM_BWD_(16, 2); else ASTK_LSTM_BWD_(16, 0); break;
   }
 #undef ASTK_LSTM_BWD_
   ASTK_LAUNCH_CHECK();

@@ -292,9 +292,12 @@ def test_cnn_max_pool_fwd_bwd(lib, B, T, D, c0, c1, pool, gemm_split):
                                                    (5, 200, 16, 64, 3, True), (4, 20, 24, 512, 6, False), (6, 64, 32, 256, 3, True),
                                                    # h = 64: one 16-k block per wave (half-empty 32-k MFMA operands of the split schemes)
                                                    (2, 5, 16, 64, 1, False), (2, 5, 16, 64, 2, False), (5, 5, 16, 64, 1, True), (5, 16, 16, 64, 2, False),
-                                                   # h = 1024 per direction (the other reading of BASELINE configs[4]): the weight slices do not fit the
-                                                   # persistent kernels' registers, the stack runs one fused-cell launch per step
-                                                   (3, 4, 16, 1024, 2, False)])
+                                                   # h = 1024 per direction (the other reading of BASELINE configs[4]): the weight fragments of ONE product
+                                                   # fill the registers -- the hoisted form of the persistent kernels (one launch per layer, the input
+                                                   # projection and the gradient for the layer below as batched products between the launches);
+                                                   # 32 rows = the two full batch tiles of that shape, 19 rows = a ragged second tile, 9 steps = the
+                                                   # 4-deep ring of partial tiles comes round twice
+                                                   (3, 4, 16, 1024, 2, False), (9, 19, 24, 1024, 3, True), (5, 32, 16, 1024, 2, True)])
 def test_lstm_stack(lib, T, B, in_dim, h, nl, masks, gemm_split):
     from ast_amd._lib import LstmGrads, LstmParams, LstmStackDesc
     from oracle.ast_ref_torch import encoder_torch
@@ -318,7 +321,7 @@ def test_lstm_stack(lib, T, B, in_dim, h, nl, masks, gemm_split):
     g_enc, g_c, g_h = rng.standard_normal(enc.shape), rng.standard_normal(cT.shape), rng.standard_normal(hT.shape)
     (enc * torch.tensor(g_enc)).sum().add((cT * torch.tensor(g_c)).sum()).add((hT * torch.tensor(g_h)).sum()).backward()
     d = LstmStackDesc(T, B, in_dim, h, nl, 2)
-    if h in (64, 128, 256, 512):
+    if h in (64, 128, 256, 512, 1024):
         assert lib.astk_lstm_stack_path(C.byref(d)) == 1, "persistent encoder path not taken"
     prm = {k: dev(v) for k, v in P.items()}
     grd = {k: torch.zeros_like(v) for k, v in prm.items()}
