@@ -18,7 +18,7 @@ Cases (BASELINE.json configs):
             values restated in MODEL_ES_EN) at batch 2, T=800, D=80, L=40
   cfg5      configs[4]'s shape (enc_layers 6, hidden_units 1024, attn_units 1024, V=8004) at B=4, T=160, L=12
   cfg1_b64  configs[1]'s model at batch 64 (T=800, L=40)
-  cfg5_wide configs[4] read as 1024 units per direction (hidden_units = attn_units = 2048) at B=20, T=96, L=8
+  cfg5_wide configs[4] read as 1024 units per direction (hidden_units = attn_units = 2048) at B=20, T=96, L=12
   asr_gpfr  configs[3]'s shape: same model JSON (experiments/asr_gpfr/model_cfg.json has no n_attn/feed_attn keys:
             defaults equal), 13-d features, 3 dec layers, V=1004, L=60, batch 8, T=800
 Dropout / speech noise are 0 (quirk Q7: the reference's masks are unseeded; the masked variants are compared at small
@@ -64,7 +64,7 @@ CASES = {
     "cfg1_b64": dict(cfg=model_cfg(1, 1098), B=64, T=800, D=80, L=40, V=1098, seed=0, data_seed=20),
     # round 4: the OTHER reading of configs[4] -- 1024 units per direction (hidden_units 2048: `bench.py --model cfg5 --hidden 2048`), the
     # hoisted form of the persistent encoder kernels (one launch per layer); 20 batch rows = a full and a ragged batch tile
-    "cfg5_wide": dict(cfg=model_cfg(1, 8004, enc_layers=6, hidden=2048), B=20, T=96, D=80, L=8, V=8004, seed=0, data_seed=20),
+    "cfg5_wide": dict(cfg=model_cfg(1, 8004, enc_layers=6, hidden=2048), B=20, T=96, D=80, L=12, V=8004, seed=0, data_seed=20),
 }
 
 

@@ -121,7 +121,9 @@ def test_fullsize_fixture_covers_the_baseline_configs():
         assert R.teacher_flags(c["L"], c["teach_ratio"], random.Random("seed-ast-20h")) == [bool(f) for f in c["flags"]]
         assert c["min_fed_argmax_margin"] is None or c["min_fed_argmax_margin"] > 1e-4
         assert abs(c["loss_f32_oracle"] - c["loss"]) <= 1e-4 * abs(c["loss"])
-        assert abs(c["grad_norm_f32_oracle"] - c["grad_norm"]) <= 1e-4 * c["grad_norm"]
+        # (cfg5_wide, six layers of 2 x 1024 units: the float32 NumPy oracle's clip norm itself sits 1.3e-4 from the float64 one -- its
+        #  sgemm accumulates in another order; the GPU test holds the HIP path to 1e-4 of the float64 value all the same)
+        assert abs(c["grad_norm_f32_oracle"] - c["grad_norm"]) <= (2e-4 if c["cfg"]["rnn_config"]["hidden_units"] >= 2048 else 1e-4) * c["grad_norm"]
 
 
 def test_oracle_reproduces_fullsize_golden_es_en_20h():
