@@ -33,6 +33,8 @@ struct CnnPlan {
   int rows[ASTK_MAX_CNN_LAYERS];    // B*Fn[i]*Tn[i]
   int rowsc[ASTK_MAX_CNN_LAYERS];   // B*Fc[i]*Tc[i]
   int K0, K0p;                      // layer-0 patch size and its padded width
+  int JG, K0g, xf_rows;             // direct layer-0 path: padded frequency-kernel width of XF, kt * JG, rows per (b, f) group
+  float* XF;
   int padA[ASTK_MAX_CNN_LAYERS];    // time padding of HP_i (= pt of layer i+1), front == back
   int dF[ASTK_MAX_CNN_LAYERS], dB[ASTK_MAX_CNN_LAYERS];  // front/back padding of DYP_i for the dgrad windows (i>=1)
   // workspace slices
@@ -105,6 +107,12 @@ int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
   P.K0p = (P.K0 + 3) / 4 * 4;
   Carver c(ws);
   P.P0 = c.take<float>((size_t)P.rowsc[0] * P.K0p);
+  // direct layer-0 convolution (k_conv0_fwd_x3): the noisy input in frequency-blocked, time-padded form [(b, f)][pt + T + pt][JG], which
+  // the weight gradient reads as a zero-copy window matrix (row (b, f, t1) = the kt*JG floats from row st*t1 on)
+  P.JG = (d->kf[0] + 1) & ~1;
+  P.K0g = d->kt[0] * P.JG;
+  P.xf_rows = (d->T + 2 * d->pt[0] + 1) & ~1;      // (even: the group stride of the window view must be a multiple of 4 floats)
+  P.XF = c.take<float>((size_t)d->B * P.Fc[0] * P.xf_rows * P.JG + 16);
   size_t wd_max = 0;
   for (int i = 0; i < P.n; ++i) {
     P.Y[i] = c.take<float>((size_t)P.rows[i] * P.Cn[i]);
@@ -161,7 +169,7 @@ int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
   for (int k = 0; k < GEMM_GROUP_MAX; ++k) P.a_wd[k] = c.take<unsigned long long>(AMAX_SLOT_WORDS);
   const size_t off_dwr = align_up(c.off, 256);
   for (int i = 0; i < P.n; ++i)
-    P.dWr[i] = c.take<float>(i == 0 ? (size_t)d->C[0] * P.K0p : (size_t)P.Cn[i] * d->kt[i] * P.Cn[i - 1]);
+    P.dWr[i] = c.take<float>(i == 0 ? (size_t)d->C[0] * std::max(P.K0p, (P.K0g + 3) & ~3) : (size_t)P.Cn[i] * d->kt[i] * P.Cn[i - 1]);
   P.zero_fwd_bytes = off_abwd - off_afwd;       // forward: the forward slots and the statistics
   P.zero_bwd_bytes = c.off - off_stat;          // backward: statistics, backward slots, dWr scratch
   P.G = c.take<float>(rowsmax_c);
@@ -196,6 +204,172 @@ __global__ __launch_bounds__(256) void k_im2col0(const float* __restrict__ X, co
       }
     }
     P0[(((long)b * F + f) * T1 + t1) * K0p + k] = v;
+  }
+}
+
+// ---- Layer 0 as a DIRECT convolution on the bf16 matrix pipe (default arithmetic, bf16x3).  im2col + GEMM moved 37 MB of patches out and
+// back for a product with K = 117: 28 + 47 us, overhead-bound (8 k-iterations per tile).  The frequency stride equals the frequency
+// kernel (13), so with the input of one (b, f) kept as [time][JP] in LDS the patch of output step t1 is simply the kt*JP CONTIGUOUS
+// elements from flat offset st*JP*t1 on (kt rows of JP, the pads multiplied by zero weights): the MFMA operand fragments are read straight
+// from that image -- no patch matrix anywhere.  JP = 20: st*JP*2 bytes = 80 per output step keeps every fragment 16-byte aligned and the
+// 16 lanes of a read on 16 different bank groups.  A workgroup owns C0_TT output steps of one (b, f) and all channels (wave w: channels
+// 32 w .. 32 w + 31, their weight fragments resident in registers as three bf16 planes); Y^T = W P^T, so a lane ends up with four
+// CONSECUTIVE channels of one output row (16-byte stores).  It also leaves the noisy input in the frequency-blocked, time-padded f32
+// form XF[(b, f)][pt + T + pt][JG] that the weight gradient reads as a zero-copy window matrix (the P0 patches are not built at all).
+constexpr int C0_JP = 20;
+constexpr int C0_TT = 80;
+constexpr int C0_NKS = 6;           // 32-k MFMA steps over kt * JP <= 192 (kt <= 9)
+static int conv0_win_elems(int st) { return st * C0_JP * (C0_TT - 1) + 32 * C0_NKS + 40; }    // (+ the rows the last tile of a group owns in XF)
+static bool conv0_direct_shape(const astk_cnn_desc* d) {
+  return conv0_win_elems(d->st[0]) <= 512 * 8 && (size_t)d->C[0] * d->kt[0] * d->kf[0] * 4 <= 64 * 1024 && d->kt[0] * C0_JP <= 32 * C0_NKS && d->kf[0] <= 14 && (d->st[0] % 2) == 0 && d->C[0] <= 128 && (d->C[0] % 16) == 0 && d->pool_t[0] <= 1 &&
+         d->pool_f[0] <= 1;
+}
+// the direct path is taken for the shipped layer-0 shapes under the default arithmetic (bf16x3, f32 operands); forward and backward decide
+// alike (same descriptor, same process default).  ASTK_CONV0_DIRECT=0: the im2col + GEMM path always.
+static bool conv0_direct(const astk_cnn_desc* d) {
+  static const bool off = getenv("ASTK_CONV0_DIRECT") && getenv("ASTK_CONV0_DIRECT")[0] == '0';
+  return !off && conv0_direct_shape(d) && gemm_precision_mode() == 1 && low_precision_gemms() == 0;
+}
+constexpr int C0_NPAIR = 8;           // pairs of window elements per thread and tile (256 threads x 8 x 2 >= the window)
+__global__ __launch_bounds__(256, 2) void k_conv0_fwd_x3(const float* __restrict__ X, const float* __restrict__ noise, const float* __restrict__ W,
+                                                         float* __restrict__ Y, float* __restrict__ XF, int B, int T, int D, int F, int T1, int C,
+                                                         int kt, int kf, int st, int sf, int pt, int JG, int xf_rows, int tiles_t, int total, int win) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short c0_planes[];      // [3][win] bf16; first the f32 weights [C][kt*kf]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int ch0 = wave * 32;
+  const float* const nz = noise ? noise : X;
+  // The window of a tile, pairs of elements per thread: element e = (row e / JP, column e % JP), row = padded input time st*t0 + e / JP;
+  // four pairs' loads in flight before the first is used (all eight at once, or the next tile's window fetched behind the products:
+  // 16 more live registers next to the 144 of the weight fragments spill -- 46 -> 53-58 us).
+  // ---- resident weight fragments ("A" operand: 16 channels x 32 k): lane (channel r, k-group q) holds k = 32 ks + 8 q .. + 7 of
+  // W16[c][i * JP + j] (zero in the pad columns).  Through LDS: the fragment gather straight from memory touched 16-32 cache lines per
+  // load instruction, 96 instructions per lane -- 9 us per workgroup.
+  HML8 wf[2][C0_NKS];
+  {
+    float* const wl = reinterpret_cast<float*>(c0_planes);
+    const int K0 = kt * kf;
+    for (int i0 = tid; i0 < C * K0; i0 += 256 * 8) {      // (eight loads in flight per thread)
+      float w8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w8[u] = W[min(i0 + 256 * u, C * K0 - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + 256 * u < C * K0) wl[i0 + 256 * u] = w8[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int ks = 0; ks < C0_NKS; ++ks) {
+        const int c = ch0 + 16 * ct + r;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = 32 * ks + 8 * q + e, i = k / C0_JP, j = k - i * C0_JP;
+          const bool ok = c < C && i < kt && j < kf;
+          const float w = wl[(min(c, C - 1) * kt + min(i, kt - 1)) * kf + min(j, kf - 1)];
+          v[e] = ok ? w : 0.f;
+        }
+        wf[ct][ks] = split8b(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+      }
+  }
+  unsigned short* const ph = c0_planes, * const pm = c0_planes + win, * const pl = c0_planes + 2 * win;
+  for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    const int tt = tile % tiles_t, bf = tile / tiles_t;
+    const int t0 = tt * C0_TT;
+    // rows of XF this tile owns: [st*t0, st*(t0 + TT)), the last tile of a group up to the group's end
+    const int own_hi = tt == tiles_t - 1 ? xf_rows - st * t0 : st * C0_TT;
+    float* const xf = XF + ((long)bf * xf_rows + (long)st * t0) * JG;
+    __syncthreads();                      // the previous tile's fragment reads (the first tile: the weight reads) are done
+    {
+      const int f = bf % F, b = bf / F, tb = st * t0 - pt;
+#pragma unroll 1
+      for (int u0 = 0; u0 < C0_NPAIR; u0 += 4) {
+        float px0[4], px1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = min(2 * tid + 512 * (u0 + u), win - 2);
+          const int tl = e / C0_JP, j = e - tl * C0_JP, t = tb + tl;
+          const bool ok0 = t >= 0 && t < T && j < kf;            // (kf odd: the pair's second element may be the first pad column)
+          const bool ok1 = ok0 && j + 1 < kf;
+          const long idx = ((long)b * T + min(max(t, 0), T - 1)) * D + f * sf + min(j, kf - 1);
+          const long idx1 = idx + (j + 1 < kf ? 1 : 0);
+          float x0 = X[idx], x1 = X[idx1];
+          const float n0 = nz[idx], n1 = nz[idx1];
+          if (noise) { x0 *= n0; x1 *= n1; }
+          px0[u] = ok0 ? x0 : 0.f;
+          px1[u] = ok1 ? x1 : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = 2 * tid + 512 * (u0 + u);
+          if (e < win) {
+            const int tl = e / C0_JP, j = e - tl * C0_JP;
+            unsigned h, m, l;
+            split2b(px0[u], px1[u], h, m, l);
+            *reinterpret_cast<unsigned*>(ph + e) = h;
+            *reinterpret_cast<unsigned*>(pm + e) = m;
+            *reinterpret_cast<unsigned*>(pl + e) = l;
+            if (tl < own_hi && j < JG) *reinterpret_cast<float2*>(xf + (long)tl * JG + j) = make_float2(px0[u], px1[u]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- products: Y^T[32 channels of this wave][16 steps] over kt * JP, two blocks of 16 output steps at a time: four independent
+    // accumulators, the six term products of a 32-k step issued term by term across them (back to back on ONE accumulator every MFMA
+    // waits for the one before it: 2.5 x the time)
+    auto xfrag = [&](int off, int ks) {
+      HML8 x;
+      x.hi = *reinterpret_cast<const u32q*>(ph + off + 32 * ks);
+      x.mid = *reinterpret_cast<const u32q*>(pm + off + 32 * ks);
+      x.lo = *reinterpret_cast<const u32q*>(pl + off + 32 * ks);
+      return x;
+    };
+    auto store_y = [&](int ti, const f32x4& a0, const f32x4& a1) {
+      const int t1 = t0 + 16 * ti + r;
+      if (t1 < T1) {
+        float* const yr = Y + ((long)bf * T1 + t1) * C;
+        const int c = ch0 + 4 * q;
+        if (c < C) *reinterpret_cast<float4*>(yr + c) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+        if (c + 16 < C) *reinterpret_cast<float4*>(yr + c + 16) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+      }
+    };
+#define C0_TERM4_(PA, PX) MFMA_B16_(a00, wf[0][ks].PA, xa.PX) MFMA_B16_(a10, wf[1][ks].PA, xa.PX) MFMA_B16_(a01, wf[0][ks].PA, xb.PX) MFMA_B16_(a11, wf[1][ks].PA, xb.PX)
+#define C0_TERM2_(PA, PX) MFMA_B16_(a00, wf[0][ks].PA, xa.PX) MFMA_B16_(a10, wf[1][ks].PA, xa.PX)
+#pragma unroll 1
+    for (int ti = 0; ti + 1 < C0_TT / 16; ti += 2) {
+      f32x4 a00 = {0.f, 0.f, 0.f, 0.f}, a10 = a00, a01 = a00, a11 = a00;
+      const int off = st * C0_JP * (16 * ti + r) + 8 * q;          // this lane's fragment: output step 16 ti + r, k = 8 q .. 8 q + 7 (+ 32 ks)
+#pragma unroll
+      for (int ks = 0; ks < C0_NKS; ++ks) {
+        const HML8 xa = xfrag(off, ks), xb = xfrag(off + st * C0_JP * 16, ks);
+        C0_TERM4_(lo, hi) C0_TERM4_(hi, lo) C0_TERM4_(mid, mid) C0_TERM4_(mid, hi) C0_TERM4_(hi, mid) C0_TERM4_(hi, hi)
+      }
+      store_y(ti, a00, a10);
+      store_y(ti + 1, a01, a11);
+    }
+    if constexpr ((C0_TT / 16) % 2 == 1) {
+      constexpr int ti = C0_TT / 16 - 1;
+      f32x4 a00 = {0.f, 0.f, 0.f, 0.f}, a10 = a00;
+      const int off = st * C0_JP * (16 * ti + r) + 8 * q;
+#pragma unroll
+      for (int ks = 0; ks < C0_NKS; ++ks) {
+        const HML8 xa = xfrag(off, ks);
+        C0_TERM2_(lo, hi) C0_TERM2_(hi, lo) C0_TERM2_(mid, mid) C0_TERM2_(mid, hi) C0_TERM2_(hi, mid) C0_TERM2_(hi, hi)
+      }
+      store_y(ti, a00, a10);
+    }
+#undef C0_TERM4_
+#undef C0_TERM2_
+  }
+}
+// dW[c][i * kf + j] += dWg[c * ldg + i * JG + j]: the layer-0 weight gradient taken over the padded window columns, back in the parameter's layout
+__global__ void k_conv0_unpad_dw(const float* __restrict__ dWg, float* __restrict__ dW, int C, int kt, int kf, int JG, int ldg) {
+  const int n = C * kt * kf;
+  for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
+    const int j = x % kf, i = (x / kf) % kt, c = x / (kf * kt);
+    dW[x] += dWg[(long)c * ldg + i * JG + j];
   }
 }
 
@@ -706,12 +880,22 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
   const int B = P.B;
   // the statistics of every layer (train) and the maximum slots the producing kernels fill: one fill
   ASTK_TRY(fill_zero(P.zero_fwd_from, train ? P.zero_fwd_bytes : P.zero_fwd_amax_bytes, s));
+  if (conv0_direct(d)) {
+    // ---- layer 0: direct convolution (bf16x3 on the matrix pipe), leaves XF for the weight gradient
+    const int tiles_t = cdiv(P.Tc[0], C0_TT), total = B * P.Fc[0] * tiles_t, win = conv0_win_elems(d->st[0]);
+    const int grid = std::min(total, 2 * device_cu_count());
+    const size_t lds0 = std::max((size_t)3 * win * sizeof(unsigned short), (size_t)P.Cn[0] * P.K0 * sizeof(float));
+    hipLaunchKernelGGL(k_conv0_fwd_x3, dim3(grid), dim3(256), lds0, s, X, noise, L[0].W, P.YC[0], P.XF, B, P.T, P.D,
+                       P.Fc[0], P.Tc[0], P.Cn[0], d->kt[0], d->kf[0], d->st[0], d->sf[0], d->pt[0], P.JG, P.xf_rows, tiles_t, total, win);
+    ASTK_LAUNCH_CHECK();
+  } else {
   // ---- layer 0: im2col + GEMM
   hipLaunchKernelGGL(k_im2col0, dim3(P.Tc[0], B), dim3(256), 0, s, X, noise, P.P0, B, P.T, P.D, P.Fc[0], P.Tc[0], d->kt[0], d->kf[0],
                      d->st[0], d->sf[0], d->pt[0], P.K0p);
   ASTK_LAUNCH_CHECK();
   ASTK_TRY(copy2d_f32(P.Wr[0], P.K0p, L[0].W, P.K0, P.Cn[0], P.K0, P.K0p, s));
   ASTK_TRY(gemm_launch(GEMM_NT, gemm_args(P.rowsc[0], P.Cn[0], P.K0p, mat(P.P0, P.K0p), mat(P.Wr[0], P.K0p), P.YC[0], P.Cn[0]), s));
+  }
   for (int i = 0; i < P.n; ++i) {
     const int C = P.Cn[i], rows = P.rows[i], F = P.Fn[i];
     if (i > 0) {
@@ -878,8 +1062,17 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
     if (i == 0) {
       // ---- wgrad layer 0: dW0p[C0][K0p] = DY0^T P0
       const int ks = ksplit_for(1, P.rowsc[0]);
+      if (conv0_direct(d)) {
+        // the patches as a zero-copy window matrix over XF: row (b, f, t1) = the kt * JG floats from row st * t1 of group (b, f) on
+        const int ldg = (P.K0g + 3) & ~3;
+        MatView Bm = mat2(P.XF, P.Tc[0], (long)P.xf_rows * P.JG, (long)d->st[0] * P.JG);
+        ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(C, P.K0g, P.rowsc[0], mat(P.DY[0], C), Bm, P.dWr[0], ldg, nullptr, GEMM_ATOMIC, ks), s));
+        hipLaunchKernelGGL(k_conv0_unpad_dw, dim3(cdiv(C * P.K0, 256)), dim3(256), 0, s, P.dWr[0], Gr[0].dW, C, d->kt[0], d->kf[0], P.JG, ldg);
+        ASTK_LAUNCH_CHECK();
+      } else {
       ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(C, P.K0p, P.rowsc[0], mat(P.DY[0], C), mat(P.P0, P.K0p), P.dWr[0], P.K0p, nullptr, GEMM_ATOMIC, ks), s));
       ASTK_TRY(add2d_f32(Gr[0].dW, P.K0, P.dWr[0], P.K0p, C, P.K0, s));
+      }
     } else {
       const int Ci = P.Cn[i - 1], KT = d->kt[i], st = d->st[i], pt = d->pt[i];
       const long dyrow = (long)Tp * C;                                  // per (b,f) group of the padded dY

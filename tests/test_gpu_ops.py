@@ -163,8 +163,11 @@ def _cnn_desc(cfg, B, T, D):
     return cd
 
 
-# (the last case: the shipped channel counts on 13-d features -- the conv GEMMs there are the small, 64-tile, two-level-row variants)
-@pytest.mark.parametrize("B,T,D,c0,c1", [(3, 21, 26, 4, 8), (2, 50, 80, 8, 12), (2, 16, 13, 4, 4), (16, 400, 13, 128, 512)])
+# (the fourth case: the shipped channel counts on 13-d features -- the conv GEMMs there are the small, 64-tile, two-level-row variants; the shapes with
+#  16 / 128 layer-0 channels take the DIRECT layer-0 convolution under the default arithmetic (k_conv0_fwd_x3 + the window-matrix weight gradient):
+#  80-d features = six frequency blocks, T = 331 / 170 = output lengths that are no multiple of the 80-step tiles, one shorter than a tile)
+@pytest.mark.parametrize("B,T,D,c0,c1", [(3, 21, 26, 4, 8), (2, 50, 80, 8, 12), (2, 16, 13, 4, 4), (16, 400, 13, 128, 512), (3, 331, 80, 128, 32),
+                                         (2, 170, 26, 16, 8), (2, 24, 80, 32, 8)])
 @pytest.mark.parametrize("with_noise", [False, True])
 def test_cnn_fwd_bwd(lib, B, T, D, c0, c1, with_noise, gemm_split):
     from ast_amd._lib import CnnLayerGrads, CnnLayerParams
