@@ -28,9 +28,13 @@ echo "default done"
 python3 bench.py --model cfg5 --steps 20 --warmup 5 --no-cpu-baseline --no-alt-precisions > $OUT/bench_cfg5.log 2>&1
 python3 bench.py --model cfg5 --gemm-operands fp16 --steps 20 --warmup 5 --no-cpu-baseline --no-alt-precisions > $OUT/bench_cfg5_fp16.log 2>&1
 python3 bench.py --batch 64 --steps 30 --warmup 10 --no-cpu-baseline --no-alt-precisions --no-also > $OUT/bench_b64.log 2>&1
+python3 bench.py --model cfg5 --hidden 2048 --steps 10 --warmup 3 --no-cpu-baseline --no-alt-precisions > $OUT/bench_cfg5_wide.log 2>&1
 python3 bench.py --frames 1200 --steps 30 --warmup 10 --no-cpu-baseline --no-alt-precisions --no-also > $OUT/bench_t1200.log 2>&1
 python3 bench.py --frames 1680 --steps 30 --warmup 10 --no-cpu-baseline --no-alt-precisions --no-also > $OUT/bench_t1680.log 2>&1
 echo "matrix done"
+PROF_ARGS="--no-also --no-alt-precisions" bash scratch/trace_step.sh && cp gpurun_out/trace_step.txt $OUT/trace_step_cfg1.txt
+PROF_ARGS="--model es_en_20h --no-also --no-alt-precisions" bash scratch/trace_step.sh && cp gpurun_out/trace_step.txt $OUT/trace_step_es_en_20h.txt
+echo "traces done"
 # keep the summaries, drop the bulky per-dispatch traces
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -delete
