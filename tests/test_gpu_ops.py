@@ -353,6 +353,31 @@ def test_lstm_stack(lib, T, B, in_dim, h, nl, masks, gemm_split):
         close(grd[k], ref_g, rtol=5e-4, atol=None if float(ref_g.abs().max()) > 0 else 1e-12, msg="grad " + k)
 
 
+@pytest.mark.parametrize("nd,nl_enc,n,B,h", [(2, 3, 3, 5, 8), (2, 3, 1, 32, 256), (1, 2, 2, 3, 12), (2, 6, 1, 33, 512)])
+def test_bridge_states_matches_the_strided_copies(lib, nd, nl_enc, n, B, h):
+    """init_decoder_state (seq2seq.py:318-333) and its backward as one launch each: decoder layer k < n gets [fwd_k ; rev_k] of the encoder's
+    final states (both tensors), the gradients go back the same way; layers >= n of either side are left alone."""
+    rng = np.random.default_rng(nd * 100 + h)
+    enc_c, enc_h = dev(rng.standard_normal((nd, nl_enc, B, h))), dev(rng.standard_normal((nd, nl_enc, B, h)))
+    dec_c, dec_h = dev(rng.standard_normal((n + 1, B, nd * h))), dev(rng.standard_normal((n + 1, B, nd * h)))
+    want_c, want_h = dec_c.clone(), dec_h.clone()
+    for k in range(n):
+        want_c[k].view(-1, nd, h).copy_(enc_c[:, k].permute(1, 0, 2))
+        want_h[k].view(-1, nd, h).copy_(enc_h[:, k].permute(1, 0, 2))
+    ok(lib, lib.astk_bridge_states(vp(dec_c), vp(dec_h), vp(enc_c), vp(enc_h), nd, nl_enc, n, B, h, 1, stream()))
+    assert torch.equal(dec_c, want_c) and torch.equal(dec_h, want_h)
+    # and back: the gradients of the bridged layers, the others untouched
+    g_c, g_h = dev(rng.standard_normal((n + 1, B, nd * h))), dev(rng.standard_normal((n + 1, B, nd * h)))
+    e_c, e_h = dev(rng.standard_normal((nd, nl_enc, B, h))), dev(rng.standard_normal((nd, nl_enc, B, h)))
+    w_c, w_h = e_c.clone(), e_h.clone()
+    for k in range(n):
+        w_c[:, k].copy_(g_c[k].view(-1, nd, h).permute(1, 0, 2))
+        w_h[:, k].copy_(g_h[k].view(-1, nd, h).permute(1, 0, 2))
+    ok(lib, lib.astk_bridge_states(vp(g_c), vp(g_h), vp(e_c), vp(e_h), nd, nl_enc, n, B, h, 0, stream()))
+    assert torch.equal(e_c, w_c) and torch.equal(e_h, w_h)
+    assert lib.astk_bridge_states(vp(g_c), vp(g_h), vp(e_c), vp(e_h), nd, nl_enc, nl_enc + 1, B, h, 0, stream()) != 0      # more layers than the encoder has
+
+
 # ------------------------------------------------------------------ attention scan
 @pytest.mark.parametrize("B,T,H", [(3, 6, 8), (32, 50, 512), (5, 201, 260), (2, 9, 1024)])
 def test_attention_step(lib, B, T, H):
