@@ -136,7 +136,7 @@ extern "C" {
 
 int astk_lstm_stack_path(const astk_lstm_stack_desc* d) {
   if (!d) return 0;
-  return lstm_persist_applicable(d->T, d->B, d->h, d->n_layers, d->n_dirs) ? 1 : 0;
+  return lstm_persist_applicable(d->T, d->B, d->h, d->n_layers, d->n_dirs) ? (lstm_persist_hoisted(d->h) ? 2 : 1) : 0;
 }
 
 size_t astk_lstm_stack_workspace_bytes(const astk_lstm_stack_desc* d) {

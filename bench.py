@@ -292,8 +292,10 @@ def main():
     # ---- which kernels ran (a silent fall-back to the per-launch paths must show in the driver's line)
     def paths_of(model):
         st = model._cur
-        paths = {"encoder": "persistent wavefront kernels (one launch for all steps of all cells)" if lib.astk_lstm_stack_path(C.byref(st["ld"]))
-                 else "per-step fused-cell launches (fallback)"}
+        epath = lib.astk_lstm_stack_path(C.byref(st["ld"]))
+        paths = {"encoder": {1: "persistent wavefront kernels (one launch for all steps of all cells)",
+                             2: "persistent kernels, hoisted form (h = 1024: one launch per layer for all steps, input projections and down gradients as batched products)"}.get(
+                                 epath, "per-step fused-cell launches (fallback)")}
         dpath = lib.astk_decoder_path(C.byref(st["dd"]))
         paths["decoder"] = (f"persistent loop, {dpath >> 8} layer(s) fused" + (", attention phase specialised (H=512, chunk<=32)" if dpath & 2 else ", generic attention phase")
                             + (", two launches over halves of the batch rows" if dpath & 4 else "")) \

@@ -418,7 +418,9 @@ int astk_persist_status_snapshot(float* dst, void* stream);
  * raises at its next loss read-back instead of waiting in the next collective for a peer that has already failed. */
 int astk_persist_status_merge(const float* summed, void* stream);
 /* Which path a shape takes on the current device (so that a silent fall-back shows up in logs / bench.py's JSON line):
- *   astk_lstm_stack_path  1 = persistent wavefront kernels (all T steps of all cells in one launch), 0 = one fused-cell launch per step
+ *   astk_lstm_stack_path  1 = persistent wavefront kernels (all T steps of all cells in one launch; stacks with more cells than CUs: one launch
+ *                         per group of layers), 2 = the hoisted form of the same kernels (h = 1024: one launch per layer, the input projection
+ *                         and the gradient for the layer below as batched products between the launches), 0 = one fused-cell launch per step
  *   astk_decoder_path     0 = per-launch decoder loop; otherwise bit 0 = persistent loop, bit 1 = attention phase specialised for
  *                         H = 512 / chunk <= 32, bit 2 = the batch runs as TWO persistent launches over halves of its rows (more than
  *                         32 rows at the shipped width: the decoder couples no batch rows, the halves share nothing but the weights
