@@ -534,3 +534,28 @@ def test_per_bucket_batch_sizes_follow_the_old_paths_create_batches(tmp_path):
         assert all(len(u) <= by_third[b] for u, b in want) and any(len(u) == 7 for u, _ in want)
         if curriculum:
             assert [b for _, b in want] == sorted(b for _, b in want)
+
+
+@pytest.mark.parametrize("T,D,kt,kf,st,pt", [(800, 80, 9, 13, 2, 4), (37, 26, 9, 13, 2, 4), (50, 80, 5, 7, 2, 1)])
+def test_layer0_patch_is_a_contiguous_window_of_the_frequency_blocked_input(T, D, kt, kf, st, pt):
+    """The identity the direct layer-0 convolution (conv.hip: k_conv0_fwd_x3) and its weight gradient rest on, restated in NumPy: when the
+    frequency stride equals the frequency kernel (seq2seq.py:43-57: ksize (9, 13), stride (2, 13)), the im2col patch of output step t1 of
+    frequency block f is the kt * J CONTIGUOUS elements from flat offset st * J * t1 of that block's [pt + T + pt][J] image (columns >= kf
+    zero), so W[c][i][j] placed at i * J + j reproduces the convolution -- for the kernel's LDS image (J = 20) and for XF (J = 14) alike."""
+    rng = np.random.default_rng(T + kt)
+    F, T1, C = (D - kf) // kf + 1, (T + 2 * pt - kt) // st + 1, 5
+    X, W = rng.standard_normal((T, D)), rng.standard_normal((C, kt, kf))
+    # reference: the convolution as the reference writes it (time padding pt, no frequency padding)
+    Xp = np.zeros((T + 2 * pt, D)); Xp[pt:pt + T] = X
+    ref = np.zeros((F, T1, C))
+    for f in range(F):
+        for t1 in range(T1):
+            ref[f, t1] = np.einsum("cij,ij->c", W, Xp[st * t1:st * t1 + kt, kf * f:kf * f + kf])
+    for J in (20, (kf + 1) & ~1):
+        rows = (T + 2 * pt + 1) & ~1
+        Wj = np.zeros((C, kt * J)); Wj.reshape(C, kt, J)[:, :, :kf] = W
+        for f in range(F):
+            img = np.zeros((rows + kt, J)); img[pt:pt + T, :kf] = X[:, kf * f:kf * f + kf]      # the frequency-blocked, time-padded image
+            flat = img.ravel()
+            got = np.stack([Wj @ flat[st * J * t1:st * J * t1 + kt * J] for t1 in range(T1)])
+            np.testing.assert_allclose(got, ref[f], rtol=0, atol=1e-12)
