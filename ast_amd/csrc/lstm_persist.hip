@@ -165,11 +165,41 @@ constexpr float ACT_SCALE = 1024.f, ACT_SCALE_INV = 1.f / 1024.f;
   MFMA32BG_T_(ACC, (A).hi, W, mid)   \
   MFMA32BG_T_(ACC, (A).hi, W, hi)
 // fragment type and helpers of a split scheme XS (2: fp16 hi / lo behind a scale, 3: bf16 hi / mid / lo)
+// XS = 4 forms of the two macros above: W holds hi / mid, LOP points at this thread's lo fragments in LDS (gate g at LOP[g * 256])
+#define MFMA32BG4_T_(ACC, AP, WEXPR) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) { MFMA_B16_(ACC[g_], AP, WEXPR) }
+#define MFMA32BG4(ACC, A, W, LOP)              \
+  {                                            \
+    u32q lo_[4];                               \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) lo_[g_] = (LOP)[g_ * 256]; \
+    MFMA32BG4_T_(ACC, (A).lo, (W)[g_].hi)      \
+    MFMA32BG4_T_(ACC, (A).hi, lo_[g_])         \
+    MFMA32BG4_T_(ACC, (A).mid, (W)[g_].mid)    \
+    MFMA32BG4_T_(ACC, (A).mid, (W)[g_].hi)     \
+    MFMA32BG4_T_(ACC, (A).hi, (W)[g_].mid)     \
+    MFMA32BG4_T_(ACC, (A).hi, (W)[g_].hi)      \
+  }
+#define MFMA32B4(ACC, A, W, LOV)   \
+  MFMA_B16_(ACC, (A).lo, (W).hi)  \
+  MFMA_B16_(ACC, (A).hi, LOV)     \
+  MFMA_B16_(ACC, (A).mid, (W).mid) \
+  MFMA_B16_(ACC, (A).mid, (W).hi) \
+  MFMA_B16_(ACC, (A).hi, (W).mid) \
+  MFMA_B16_(ACC, (A).hi, (W).hi)
 template <int XS> struct FragOf { typedef HL8 type; };
 template <> struct FragOf<3> { typedef HML8 type; };
+template <> struct FragOf<4> { typedef HML8 type; };
+// XS = 4: bf16x3 with the LO plane of the resident weight fragments in LDS.  At h = 512 (and for the one product of the hoisted h = 1024
+// form) the three bf16 planes of a workgroup's weights are 384 KB: 256 KB (hi, mid) stay in registers -- what the f32 fragments took --
+// and the lo plane, which enters ONE of the six term products, lives in 128 KB of LDS, every thread reading back its own 16 bytes per
+// fragment (no conflicts, no barrier).  Same six products as XS = 3; the f32-input MFMAs these shapes ran under the default arithmetic
+// were 3.9 us of matrix time per step against 1.5.
+struct HM8 { u32q hi, mid; };
+template <int XS> struct WFragOf { typedef typename FragOf<XS>::type type; };
+template <> struct WFragOf<4> { typedef HM8 type; };
+constexpr int LO_LDS_FRAGS = 32;          // weight fragments per thread whose lo plane lives in LDS (32 x 256 threads x 16 B = 128 KB)
 template <int XS>
 __device__ __forceinline__ typename FragOf<XS>::type split_frag(const float4& a, const float4& b, float scl) {
-  if constexpr (XS == 3) return split8b(a, b);
+  if constexpr (XS == 3 || XS == 4) return split8b(a, b);
   else return split8(a, b, scl);
 }
 // workgroup-wide maximum of a per-thread value (256 threads; `red` = 4 floats of LDS scratch; ends with a barrier)
@@ -266,7 +296,7 @@ __device__ __forceinline__ float4 frag_vals(const u32x4& g) {
 // peeled, prefetch indices are clamped instead of guarded): a conditionally issued load becomes a phi of "old registers /
 // load result", and hipcc then copies the result right behind the load, i.e. waits for it at the point of issue.
 template <int KB, bool HAS_UP, int XS>
-__device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& c, float* red0, float* red1) {
+__device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& c, float* red0, float* red1, u32q* lo_lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int bt = blockIdx.y, j0 = blockIdx.x * 16;
@@ -285,7 +315,10 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
   typedef typename FragOf<XS>::type Frag;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float zscale = 1.f;
-  Frag wlh[X2 ? NPR : 1][4], wuh[(X2 && HAS_UP) ? NPR : 1][4];
+  typedef typename WFragOf<XS>::type WFrag;
+  static_assert(XS != 4 || (HAS_UP ? 2 : 1) * NPR * 4 <= LO_LDS_FRAGS, "lo plane does not fit its LDS region");
+  u32q* const lo_l = lo_lds + tid, * const lo_u = lo_lds + NPR * 4 * 256 + tid;      // this thread's lo fragments: lateral [p][g], upward behind them
+  WFrag wlh[X2 ? NPR : 1][4], wuh[(X2 && HAS_UP) ? NPR : 1][4];
   float4 wl[X2 ? 1 : KB][4], wu[(!X2 && HAS_UP) ? KB : 1][4];
   if constexpr (X2) {
     float wscl = 1.f;
@@ -303,8 +336,19 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
     for (int p = 0; p < NPR; ++p)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+        if constexpr (XS == 4) {
+          const HML8 t = split8b(wl_at(2 * p, g), 2 * p + 1 < KB ? wl_at(2 * p + 1, g) : zero4);
+          wlh[p][g].hi = t.hi; wlh[p][g].mid = t.mid;
+          lo_l[(p * 4 + g) * 256] = t.lo;
+          if constexpr (HAS_UP) {
+            const HML8 u = split8b(wu_at(2 * p, g), 2 * p + 1 < KB ? wu_at(2 * p + 1, g) : zero4);
+            wuh[p][g].hi = u.hi; wuh[p][g].mid = u.mid;
+            lo_u[(p * 4 + g) * 256] = u.lo;
+          }
+        } else {
         wlh[p][g] = split_frag<XS>(wl_at(2 * p, g), 2 * p + 1 < KB ? wl_at(2 * p + 1, g) : zero4, wscl);
         if constexpr (HAS_UP) wuh[p][g] = split_frag<XS>(wu_at(2 * p, g), 2 * p + 1 < KB ? wu_at(2 * p + 1, g) : zero4, wscl);
+        }
       }
   } else {
 #pragma unroll
@@ -385,7 +429,7 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
         take_x();       // x_t (taken at W_{t-1}) is split HERE, in front of the wait for h, not between that wait and the recurrent MFMAs
 #pragma unroll
         for (int p = 0; p < NPR; ++p) {
-          if constexpr (XS == 3) { MFMA32BG(acc, axh[p], wuh[p]) } else { MFMA32HG(acc, axh[p], wuh[p]) }
+          if constexpr (XS == 4) { MFMA32BG4(acc, axh[p], wuh[p], lo_u + p * 4 * 256) } else if constexpr (XS == 3) { MFMA32BG(acc, axh[p], wuh[p]) } else { MFMA32HG(acc, axh[p], wuh[p]) }
         }
       } else {
 #pragma unroll
@@ -415,7 +459,7 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
 #pragma unroll
         for (int p = 0; p < NPR; ++p) {
           const Frag ah = split_frag<XS>(frag_vals(gh[2 * p]), 2 * p + 1 < KB ? frag_vals(gh[2 * p + 1 < KB ? 2 * p + 1 : 0]) : zero4, ACT_SCALE);
-          if constexpr (XS == 3) { MFMA32BG(acc, ah, wlh[p]) } else { MFMA32HG(acc, ah, wlh[p]) }
+          if constexpr (XS == 4) { MFMA32BG4(acc, ah, wlh[p], lo_l + p * 4 * 256) } else if constexpr (XS == 3) { MFMA32BG(acc, ah, wlh[p]) } else { MFMA32HG(acc, ah, wlh[p]) }
         }
       } else {
 #pragma unroll
@@ -485,13 +529,14 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_g(PFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float red[2][4 * 4 * 256];
   // (a COPY, not a reference into the kernel-argument block: fields read through a dynamically indexed reference are re-loaded behind
   //  every global store of the step loop -- the stores might alias them -- and each re-load is a scalar-cache round trip on the chain)
+  __shared__ __attribute__((aligned(16))) u32q lo_lds[XS == 4 ? LO_LDS_FRAGS * 256 : 1];
   const PCellF c = a.c[blockIdx.z];
   // a cell multiplies its input itself iff it was given the upward weight: layer 0 -- and, in the hoisted form (h = 1024: the weight
   // fragments of ONE product fill the registers), every layer -- gets the projection of all time steps from a batched GEMM (zx)
   if constexpr (KB <= 8) {
-    if (c.Wu != nullptr) { lstm_fwd_steps<KB, true, XS>(a, c, red[0], red[1]); return; }
+    if (c.Wu != nullptr) { lstm_fwd_steps<KB, true, XS>(a, c, red[0], red[1], lo_lds); return; }
   }
-  lstm_fwd_steps<KB, false, XS>(a, c, red[0], red[1]);
+  lstm_fwd_steps<KB, false, XS>(a, c, red[0], red[1], lo_lds);
 }
 
 
@@ -526,7 +571,7 @@ constexpr bool bwd_sentinel(int KB) { return ASTK_BWD_SENTINEL && KB <= ASTK_BWD
 // against 4.9 M in the forward kernel, round-3 PMC pass); 68 moves consecutive rows four banks on and the accesses are conflict-free.
 constexpr int DZ_LD = 68;
 template <int KB, bool HAS_UP, int XS>
-__device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCellB& c, float (*dzS2)[16 * DZ_LD], int* s_ok1, int& s_ok2) {
+__device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCellB& c, float (*dzS2)[16 * DZ_LD], int* s_ok1, int& s_ok2, u32q* lo_lds) {
   constexpr int NS = 4 * KB;          // slices of a cell = 16x16 output tiles of a product = partial tiles per consumer
   float* const dzS = dzS2[0];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -559,7 +604,10 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
   // X2: fp16 hi / lo fragments behind one power-of-two scale per workgroup (see the forward kernel); the 64 gate columns are two 32-k operands
   constexpr bool X2 = XS != 0;          // a split scheme (16-bit MFMAs); XS == 2 additionally scales
   typedef typename FragOf<XS>::type Frag;
-  Frag wlh[X2 ? KB : 1][2], wdh[(X2 && CAN_DOWN) ? KB : 1][2];
+  typedef typename WFragOf<XS>::type WFrag;
+  static_assert(XS != 4 || (CAN_DOWN ? 2 : 1) * KB * 2 <= LO_LDS_FRAGS, "lo plane does not fit its LDS region");
+  u32q* const lo_l = lo_lds + tid, * const lo_d = lo_lds + KB * 2 * 256 + tid;       // this thread's lo fragments: recurrent [nt][p], down behind them
+  WFrag wlh[X2 ? KB : 1][2], wdh[(X2 && CAN_DOWN) ? KB : 1][2];
   float4 wl[X2 ? 1 : KB][4], wd[(!X2 && CAN_DOWN) ? KB : 1][4];
   float winv = 1.f;
   if constexpr (X2) {
@@ -576,8 +624,19 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     for (int nt = 0; nt < KB; ++nt)
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
+        if constexpr (XS == 4) {
+          const HML8 t = split8b(wl_at(nt, 2 * p), wl_at(nt, 2 * p + 1));
+          wlh[nt][p].hi = t.hi; wlh[nt][p].mid = t.mid;
+          lo_l[(nt * 2 + p) * 256] = t.lo;
+          if constexpr (CAN_DOWN) {
+            const HML8 u = split8b(wd_at(nt, 2 * p), wd_at(nt, 2 * p + 1));
+            wdh[nt][p].hi = u.hi; wdh[nt][p].mid = u.mid;
+            lo_d[(nt * 2 + p) * 256] = u.lo;
+          }
+        } else {
         wlh[nt][p] = split_frag<XS>(wl_at(nt, 2 * p), wl_at(nt, 2 * p + 1), wscl);
         if constexpr (CAN_DOWN) wdh[nt][p] = split_frag<XS>(wd_at(nt, 2 * p), wd_at(nt, 2 * p + 1), wscl);
+        }
       }
   } else {
 #pragma unroll
@@ -785,7 +844,7 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
       pscale = ainv * winv;
       afh[0] = split8(af[0], af[1], ascl);
       afh[1] = split8(af[2], af[3], ascl);
-    } else if constexpr (XS == 3) {      // bf16 has f32's exponent range: no scale, however small or large dz is
+    } else if constexpr (XS == 3 || XS == 4) {      // bf16 has f32's exponent range: no scale, however small or large dz is
       afh[0] = split8b(af[0], af[1]);
       afh[1] = split8b(af[2], af[3]);
     }
@@ -799,6 +858,10 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
           MFMA32H(acc, afh[0], wlh[nt][0])
           MFMA32H(acc, afh[1], wlh[nt][1])
           acc *= pscale;
+        } else if constexpr (XS == 4) {
+          const u32q l0 = lo_l[(nt * 2) * 256], l1 = lo_l[(nt * 2 + 1) * 256];
+          MFMA32B4(acc, afh[0], wlh[nt][0], l0)
+          MFMA32B4(acc, afh[1], wlh[nt][1], l1)
         } else if constexpr (XS == 3) {
           MFMA32B(acc, afh[0], wlh[nt][0])
           MFMA32B(acc, afh[1], wlh[nt][1])
@@ -825,6 +888,10 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
           MFMA32H(acc2[nt], afh[0], wdh[nt][0])
           MFMA32H(acc2[nt], afh[1], wdh[nt][1])
           acc2[nt] *= pscale;
+        } else if constexpr (XS == 4) {
+          const u32q l0 = lo_d[(nt * 2) * 256], l1 = lo_d[(nt * 2 + 1) * 256];
+          MFMA32B4(acc2[nt], afh[0], wdh[nt][0], l0)
+          MFMA32B4(acc2[nt], afh[1], wdh[nt][1], l1)
         } else if constexpr (XS == 3) {
           MFMA32B(acc2[nt], afh[0], wdh[nt][0])
           MFMA32B(acc2[nt], afh[1], wdh[nt][1])
@@ -855,6 +922,10 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
           MFMA32H(acc2[nt], afh[0], wdh[nt][0])
           MFMA32H(acc2[nt], afh[1], wdh[nt][1])
           acc2[nt] *= pscale;
+        } else if constexpr (XS == 4) {
+          const u32q l0 = lo_d[(nt * 2) * 256], l1 = lo_d[(nt * 2 + 1) * 256];
+          MFMA32B4(acc2[nt], afh[0], wdh[nt][0], l0)
+          MFMA32B4(acc2[nt], afh[1], wdh[nt][1], l1)
         } else if constexpr (XS == 3) {
           MFMA32B(acc2[nt], afh[0], wdh[nt][0])
           MFMA32B(acc2[nt], afh[1], wdh[nt][1])
@@ -906,9 +977,10 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
   //  reads, and only the copy keeps a wave that is a step ahead from writing into what a slower wave still reads; the flags likewise)
   __shared__ __attribute__((aligned(16))) float dzS2[2][16 * DZ_LD];
   __shared__ int s_ok1[2], s_ok2;
+  __shared__ __attribute__((aligned(16))) u32q lo_lds[XS == 4 ? LO_LDS_FRAGS * 256 : 1];
   const PCellB c = a.c[blockIdx.z];      // a copy (see lstm_persist_fwd_g)
-  if (c.PD_up != nullptr) lstm_bwd_rs_steps<KB, true, XS>(a, c, dzS2, s_ok1, s_ok2);
-  else lstm_bwd_rs_steps<KB, false, XS>(a, c, dzS2, s_ok1, s_ok2);
+  if (c.PD_up != nullptr) lstm_bwd_rs_steps<KB, true, XS>(a, c, dzS2, s_ok1, s_ok2, lo_lds);
+  else lstm_bwd_rs_steps<KB, false, XS>(a, c, dzS2, s_ok1, s_ok2, lo_lds);
 }
 
 }  // namespace
@@ -996,14 +1068,15 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   // where the weight fragments fit the registers, h <= 256; f32, or bf16x3 at h = 512: f32 MFMAs).  ASTK_LSTM_X3=0 keeps f32 MFMAs under bf16x3.
   const int mode = gemm_precision_mode();
   static const bool x3_off = getenv("ASTK_LSTM_X3") && getenv("ASTK_LSTM_X3")[0] == '0';
-  const int xs = mode == 0 ? 2 : (mode == 1 && h <= 256 && !x3_off ? 3 : 0);
+  static const bool x4_off = getenv("ASTK_LSTM_X4") && getenv("ASTK_LSTM_X4")[0] == '0';
+  const int xs = mode == 0 ? 2 : (mode == 1 && !x3_off ? (h <= 256 ? 3 : (x4_off ? 0 : 4)) : 0);       // (4: bf16x3 with the weights' lo plane in LDS)
 #define ASTK_LSTM_FWD_(KB_, XS_) hipLaunchKernelGGL((lstm_persist_fwd_g<KB_, XS_>), grid, blk, 0, s, a)
   switch (h) {
     case 64: if (xs == 2) ASTK_LSTM_FWD_(1, 2); else if (xs == 3) ASTK_LSTM_FWD_(1, 3); else ASTK_LSTM_FWD_(1, 0); break;
     case 128: if (xs == 2) ASTK_LSTM_FWD_(2, 2); else if (xs == 3) ASTK_LSTM_FWD_(2, 3); else ASTK_LSTM_FWD_(2, 0); break;
     case 256: if (xs == 2) ASTK_LSTM_FWD_(4, 2); else if (xs == 3) ASTK_LSTM_FWD_(4, 3); else ASTK_LSTM_FWD_(4, 0); break;
-    case 512: if (xs == 2) ASTK_LSTM_FWD_(8, 2); else ASTK_LSTM_FWD_(8, 0); break;
-    default: if (xs == 2) ASTK_LSTM_FWD_(16, 2); else ASTK_LSTM_FWD_(16, 0); break;
+    case 512: if (xs == 2) ASTK_LSTM_FWD_(8, 2); else if (xs == 4) ASTK_LSTM_FWD_(8, 4); else ASTK_LSTM_FWD_(8, 0); break;
+    default: if (xs == 2) ASTK_LSTM_FWD_(16, 2); else if (xs == 4) ASTK_LSTM_FWD_(16, 4); else ASTK_LSTM_FWD_(16, 0); break;
   }
 #undef ASTK_LSTM_FWD_
   ASTK_LAUNCH_CHECK();
@@ -1050,14 +1123,15 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   ProfScope prof(PROF_CELL, s);
   const int mode = gemm_precision_mode();      // (see lstm_persist_fwd_launch)
   static const bool x3_off = getenv("ASTK_LSTM_X3") && getenv("ASTK_LSTM_X3")[0] == '0';
-  const int xs = mode == 0 ? 2 : (mode == 1 && h <= 256 && !x3_off ? 3 : 0);
+  static const bool x4_off = getenv("ASTK_LSTM_X4") && getenv("ASTK_LSTM_X4")[0] == '0';
+  const int xs = mode == 0 ? 2 : (mode == 1 && !x3_off ? (h <= 256 ? 3 : (x4_off ? 0 : 4)) : 0);
 #define ASTK_LSTM_BWD_(KB_, XS_) hipLaunchKernelGGL((lstm_persist_bwd_rs<KB_, XS_>), grid, blk, 0, s, a)
   switch (h) {
     case 64: if (xs == 2) ASTK_LSTM_BWD_(1, 2); else if (xs == 3) ASTK_LSTM_BWD_(1, 3); else ASTK_LSTM_BWD_(1, 0); break;
     case 128: if (xs == 2) ASTK_LSTM_BWD_(2, 2); else if (xs == 3) ASTK_LSTM_BWD_(2, 3); else ASTK_LSTM_BWD_(2, 0); break;
     case 256: if (xs == 2) ASTK_LSTM_BWD_(4, 2); else if (xs == 3) ASTK_LSTM_BWD_(4, 3); else ASTK_LSTM_BWD_(4, 0); break;
-    case 512: if (xs == 2) ASTK_LSTM_BWD_(8, 2); else ASTK_LSTM_BWD_(8, 0); break;
-    default: if (xs == 2) ASTK_LSTM_BWD_(16, 2); else ASTK_LSTM_BWD_(16, 0); break;
+    case 512: if (xs == 2) ASTK_LSTM_BWD_(8, 2); else if (xs == 4) ASTK_LSTM_BWD_(8, 4); else ASTK_LSTM_BWD_(8, 0); break;
+    default: if (xs == 2) ASTK_LSTM_BWD_(16, 2); else if (xs == 4) ASTK_LSTM_BWD_(16, 4); else ASTK_LSTM_BWD_(16, 0); break;
   }
 #undef ASTK_LSTM_BWD_
   ASTK_LAUNCH_CHECK();
