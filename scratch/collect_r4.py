@@ -1,0 +1,18 @@
+"""Copies the summaries of a scratch/profile_r4.sh run (gpurun_out/prof_r4) into profiles/ under their round-4 names."""
+import glob, json, os, shutil
+P = "gpurun_out/prof_r4"
+for tag, name in (("bf16x3", "cfg1_bf16x3"), ("f32", "cfg1_f32"), ("fp16x2", "cfg1_fp16x2"), ("es", "es_en_20h_bf16x3")):
+    shutil.copy(max(glob.glob(f"{P}/stats_{tag}/*/*kernel_stats.csv"), key=os.path.getmtime), f"profiles/r4_kernel_stats_{name}.csv")
+for a, b in (("pmc_summary.json", "r4_pmc_summary.json"), ("gemm_traffic.json", "r4_gemm_traffic.json"), ("attn_traffic.json", "r4_attn_traffic.json"),
+             ("trace_step_cfg1.txt", "r4_trace_step_cfg1.txt"), ("trace_step_es_en_20h.txt", "r4_trace_step_es_en_20h.txt")):
+    shutil.copy(f"{P}/{a}", f"profiles/{b}")
+# phase stamps: the fresh dump in front, the decoder-backward before / after timers of the round kept behind it
+old = open("profiles/r4_phase_stamps.txt").read().split("\n")
+i = [k for k, l in enumerate(old) if l.startswith("==== decoder backward, per-phase timers")][0]
+fresh = [l.rstrip("\n") for l in open(f"{P}/phase_stamps.log") if not l.startswith("{") and ("persist" in l or "bwd_rs" in l or "dec" in l)]
+open("profiles/r4_phase_stamps.txt", "w").write("\n".join(fresh + old[i:]))
+out = {}
+for n in ["bench_default", "bench_cfg5", "bench_cfg5_fp16", "bench_cfg5_wide", "bench_b64", "bench_t1200", "bench_t1680"]:
+    out[n] = json.loads([l for l in open(f"{P}/{n}.log") if l.startswith("{")][-1])
+json.dump(out, open("profiles/r4_bench_lines.json", "w"), indent=1)
+print({k: v["ms_per_step"] for k, v in out.items()})

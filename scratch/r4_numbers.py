@@ -14,7 +14,7 @@ for f in ["bench_default.log","bench_cfg5.log","bench_cfg5_fp16.log","bench_b64.
     if 'cpu_baseline' in d: print("     cpu", d['cpu_baseline']['value'], d['cpu_baseline']['cores'], d['cpu_baseline']['sample'][:100])
     if d.get('roofline_scan'): print("     scan", d['roofline_scan']['frac'], d['roofline_scan']['us_per_decoder_step'], (d['roofline_scan'].get('phase') or {}).get('us'))
 for tag in ("bf16x3","f32","fp16x2","es"):
-    f=glob.glob(f'stats_{tag}/*/*kernel_stats.csv')[0]
+    f=max(glob.glob(f'stats_{tag}/*/*kernel_stats.csv'), key=os.path.getmtime)
     rows=list(csv.DictReader(open(f)))
     steps=28
     tot=sum(float(r['TotalDurationNs']) for r in rows)/1e6/steps
