@@ -431,7 +431,22 @@ __global__ __launch_bounds__(256) void k_colstats(const float* __restrict__ Y, i
       [&](int col, int st, float v) { atomicAdd(&stat[st * C + col], (double)v); });
 }
 
-// zero only the pad rows of a time-padded channels-last buffer [(group)][padF + Tn + padB][C]: the interior is rewritten every step
+// zero only the pad rows of a time-padded channels-last buffer [(group)][padF + Tn + padB][C]: the interior is rewritten every step.
+// (A grid-stride loop every thread of the CALLING kernel runs: the kernels that write the interior rows zero the pads on the way out --
+//  a launch of its own cost 5 us twice per step.)
+__device__ __forceinline__ void zero_pad_rows(float* __restrict__ buf, int groups, int Tn, int padF, int padB, int C) {
+  const int np = padF + padB;
+  const long n4 = (long)groups * np * (C / 4);
+  const long nthreads = (long)gridDim.x * gridDim.y * blockDim.x;
+  for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += nthreads) {
+    const int c4 = (int)(i % (C / 4));
+    const long gp = i / (C / 4);
+    const int pr = (int)(gp % np);
+    const long grp = gp / np;
+    const int row = pr < padF ? pr : Tn + pr;     // rows [0, padF) and [padF + Tn, padF + Tn + padB)
+    reinterpret_cast<float4*>(buf + (grp * (padF + Tn + padB) + row) * C)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
 __global__ __launch_bounds__(256) void k_zero_pads(float* __restrict__ buf, int groups, int Tn, int padF, int padB, int C) {
   const int np = padF + padB;
   const long n4 = (long)groups * np * (C / 4);
@@ -506,6 +521,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_rows(const float* __restrict__ 
     *reinterpret_cast<float4*>(dst + pr * C + c) = o;
     mx = fmaxf(fmaxf(mx, fmaxf(o.x, o.y)), fmaxf(o.z, o.w));
   }
+  if (pad > 0) zero_pad_rows(dst, rows / Tn, Tn, pad, pad, C);
   if (amax) amax_emit_block(amax, mx, red4);
 }
 
@@ -638,6 +654,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     *reinterpret_cast<float4*>(dY + pr * C + c) = v;
     mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
+  if (padF + padB > 0) zero_pad_rows(dY, rows / Tn, Tn, padF, padB, C);
   if (amax) amax_emit_block(amax, mx, red4);
   if (blockIdx.x == 0 && dgamma)
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -779,6 +796,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_seq(const float* __restric
       }
     }
   }
+  if (padF + padB > 0) zero_pad_rows(dY, B * F, Tn, padF, padB, C);
   if (amax) amax_emit_block(amax, mx, red4);
   if (blockIdx.y == 0 && dgamma && g16 == 0) {
     dgamma[c] += (float)stat[C + c]; dgamma[c + 1] += (float)stat[C + c + 1]; dgamma[c + 2] += (float)stat[C + c + 2]; dgamma[c + 3] += (float)stat[C + c + 3];
@@ -930,11 +948,7 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
     ASTK_LAUNCH_CHECK();
     }
     if (i < P.n - 1) {
-      if (P.padA[i] > 0) {
-        hipLaunchKernelGGL(k_zero_pads, dim3(gridn((size_t)B * F * 2 * P.padA[i] * C / 4)), dim3(256), 0, s, P.HP[i], B * F, P.Tn[i], P.padA[i],
-                           P.padA[i], C);
-        ASTK_LAUNCH_CHECK();
-      }
+      // (k_bn_relu_rows zeroes the pad rows of HP[i] itself)
       hipLaunchKernelGGL(k_bn_relu_rows, dim3(gridn((size_t)rows * C / 4)), dim3(256), 0, s, P.Y[i], P.bn[i], P.HP[i], rows, C,
                          P.Tn[i], P.padA[i], P.a_hp_s[i]);
       ASTK_LAUNCH_CHECK();
@@ -1029,7 +1043,7 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
     }
     const int F = P.Fc[i];             // (b, f) groups of this layer's convolution output = of its input
     const int Tp = P.Tc[i] + P.dF[i] + P.dB[i];
-    if (P.dF[i] + P.dB[i] > 0) {
+    if (P.dF[i] + P.dB[i] > 0 && P.pooled[i]) {       // (un-pooled layers: the apply kernel zeroes the pad rows of the dY it writes)
       hipLaunchKernelGGL(k_zero_pads, dim3(gridn((size_t)B * F * (P.dF[i] + P.dB[i]) * C / 4)), dim3(256), 0, s, P.DY[i], B * F, P.Tc[i], P.dF[i],
                          P.dB[i], C);
       ASTK_LAUNCH_CHECK();
