@@ -135,7 +135,10 @@ size_t astk_conv_bn_relu_workspace_bytes(const astk_cnn_desc* d);
  * out (T'',B,C_last*F').  train=0 uses running statistics (chainer.config.train False). */
 int astk_conv_bn_relu_fwd(const astk_cnn_desc* d, const astk_cnn_layer_params* layers, const float* X,
                           const float* noise, float* out, void* ws, size_t ws_bytes, int train, void* stream);
-/* d_out (T'',B,C_last*F') is overwritten.  Gradients are ACCUMULATED into grads (caller zeroes = cleargrads). */
+/* d_out (T'',B,C_last*F') is overwritten.  Gradients are ACCUMULATED into grads (caller zeroes = cleargrads).
+ * The backward call must see the descriptor (incl. `precision` / `gemm_operands`) and the process defaults its forward call saw: which
+ * of the workspace's layer-0 buffers exists (the patch matrix of im2col + GEMM, or the frequency-blocked input of the direct convolution
+ * kernel, conv.hip) follows from them. */
 int astk_conv_bn_relu_bwd(const astk_cnn_desc* d, const astk_cnn_layer_params* layers,
                           const astk_cnn_layer_grads* grads, float* d_out, void* ws, size_t ws_bytes, void* stream);
 /* Where the forward call leaves the absolute maximum of `out` (16 64-bit words inside ws; taken by the kernel that writes `out`):
