@@ -665,7 +665,10 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
   // In front of the barrier of step t one lane makes sure that the layer above has published step t-1 (asked when the step begins, the
   // answer is a memory round trip away; it blocks only while the pipeline fills), behind the barrier everybody fetches.
   constexpr bool SENT = bwd_sentinel(KB);
-  constexpr bool UP_PREFETCH = SENT && HAS_UP && KB <= 4;      // (32 more live registers do not fit the h = 512 kernel)
+#ifndef ASTK_BWD_UP_PREFETCH
+#define ASTK_BWD_UP_PREFETCH 1
+#endif
+  constexpr bool UP_PREFETCH = ASTK_BWD_UP_PREFETCH && SENT && HAS_UP && KB <= 4;      // (32 more live registers do not fit the h = 512 kernel)
   float pu[NS];
   bool alive = true;
   if (UP_PREFETCH) {
@@ -806,7 +809,11 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     // every vector memory operation of this wave up to the partial loads has completed (they were just consumed, vmcnt retires in
     // order; the previous step's down-partials and sentinel resets went out a whole step ago): this is the drain the deferred
     // publish of counter B needs, and what orders a reset in front of the slot's next use
+#ifdef ASTK_BWD_DRAIN_B
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     if constexpr (!SENT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     float4 dz;
     {
       const float dh = v0 + (v1 + dye) * mk + (stepno == 0 ? dhadd : 0.f);
@@ -939,7 +946,20 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     }
     TICK(6, t0)
   }
-  if (pending_b) publish(ctrB);
+  if (pending_b) {
+    // The LAST arrival on counter B (step 0's down partials) needs nothing from the peers, all earlier ones do: a workgroup reaches the
+    // barrier of step s only behind its peers' partials of step s+1, i.e. behind their arrival for step s+2, so the 4 KB slices of a
+    // (cell, batch tile) are never more than one arrival apart and "count >= NS * k" means "everybody has published k steps".  Without
+    // this wait a workgroup that finished early made its T-th arrival while a peer had made T-2: the count reached NS * (T-1) one arrival
+    // short of that peer's, and a consumer of the layer below read the peer's tile of step 1 before it was written -- the previous
+    // launch's tile.  Once in ~4000 launches, on the last two steps of a layer-0 cell, 1e-4 of two gradient tensors (found by a soak over
+    // 3000 batches; scratch/enc_repeat.py reproduces it with two alternating inputs: with one input the stale tile is a copy of the right one).
+    if (T > 1) {
+      if (tid == 0) (void)wait_ge(ctrB, (unsigned)(NS * (T - 1)), ab);
+      __syncthreads();
+    }
+    publish(ctrB);
+  }
   if (c.db) {
     if (!evalid) dbacc = make_float4(0.f, 0.f, 0.f, 0.f);        // (rows past B repeat row B - 1)
 #pragma unroll

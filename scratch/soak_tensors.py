@@ -1,0 +1,47 @@
+"""Which tensors differ between two passes over the same batches at fixed weights (scratch/soak.py found identical losses but, once in
+~1000 batches, gradient norms 1e-5 apart): per batch and parameter tensor the gradient's L2 norm of both passes.
+    python3 scratch/soak_tensors.py <cfg1|es_en_20h> <batches> [ENV=VALUE ...]"""
+import copy, os, random, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+for kv in sys.argv[3:]:
+    k, v = kv.split("="); os.environ[k] = v
+import numpy as np, torch
+import bench
+from ast_amd.seq2seq import SpeechEncoderDecoder, using_config
+from oracle.ast_ref import synth_batch
+which, N = sys.argv[1], int(sys.argv[2])
+cfg = copy.deepcopy(bench.MODEL_CFG)
+V = cfg["rnn_config"]["dec_vocab_size"]
+if which == "es_en_20h":
+    cfg["rnn_config"]["dec_layers"] = 3
+B, T, D, L = 32, 800, 80, 40
+m = SpeechEncoderDecoder(0, cfg).materialize(D, seed=0)
+batches = []
+for i in range(8):
+    X, y = synth_batch(B, T, D, L, V, 100 + i)
+    batches.append((torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()))
+names = list(m.arena.shapes)
+rng_of = [m.arena.range_of(n) for n in names]
+def run():
+    random.seed("soak")
+    m.rng_seed = 12345; m._rng_offset = 0
+    out = torch.zeros(N, len(names) + 1, dtype=torch.float64, device="cuda")
+    for i in range(N):
+        X, y = batches[i % 8]
+        with using_config("train", True):
+            l = m.forward_loss(X=X, y=y, teach_ratio=0.8, random_out=0, add_noise=0.25)
+            m.cleargrads(); l.backward()
+        g = m.arena.grad.double()
+        for k, (o, n) in enumerate(rng_of):
+            out[i, k] = (g[o:o + n] ** 2).sum()
+        out[i, -1] = float(l.data)
+    return out.sqrt_().cpu().numpy() if False else out.cpu().numpy()
+a = run(); b = run()
+tot = np.sqrt(a[:, :-1].sum(1))
+rel = np.abs(np.sqrt(a[:, :-1]) - np.sqrt(b[:, :-1])) / tot[:, None]
+print("loss identical:", bool((a[:, -1] == b[:, -1]).all()))
+worst = np.argsort(-rel.max(1))[:6]
+for i in worst:
+    order = np.argsort(-rel[i])[:6]
+    print(f"batch {i}: total-norm rel diff {abs(np.sqrt(a[i,:-1].sum()) - np.sqrt(b[i,:-1].sum())) / tot[i]:.2e}; tensors:",
+          [(names[k], f"{rel[i, k]:.1e}", f"own {abs(np.sqrt(a[i,k]) - np.sqrt(b[i,k])) / max(np.sqrt(a[i,k]), 1e-30):.1e}") for k in order])
