@@ -717,7 +717,7 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
   };
   if (alive && T > 0) fetch_inputs(T - 1);
   long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool timing = dbg != 0;
+  const bool timing = (dbg & ~16) != 0;
 #define TICK(i, t0) if (timing) { const long long now_ = wall_clock64(); tk[i] += now_ - t0; t0 = now_; }
   for (int t = alive ? T - 1 : -1; t >= 0; --t) {
     long long t0 = timing ? wall_clock64() : 0;
@@ -881,6 +881,12 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
         o.x = __float_as_uint(acc[0]); o.y = __float_as_uint(acc[1]); o.z = __float_as_uint(acc[2]); o.w = __float_as_uint(acc[3]);
         __builtin_amdgcn_raw_buffer_store_b128(o, r_pr, (int)((((long)slot * nbt + bt) * NS + tl) * cons_stride) + j * tile_bytes + (r16 * 16 + 4 * q) * 4, 0, 16);
       }
+    }
+    // (ASTK_PERSIST_DBG & 16, the regression test of the last-arrival rule on counter B: slice 0 of every cell with a layer below dawdles for
+    //  30 us between its product-1 stores of step 1 and its down partials -- its peers need nothing else from it to finish the launch)
+    if ((dbg & 16) && has_down && j == 0 && t == 1) {
+      const long long until = wall_clock64() + 3000;
+      while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
     }
     // ---- product 2 (partial dx for the layer below): its MFMAs run while the product-1 stores land; its own stores go out
     // behind the publish of counter A and counter B is bumped at the next step's drain point.  (Measured alternatives: product 2

@@ -378,6 +378,58 @@ def test_bridge_states_matches_the_strided_copies(lib, nd, nl_enc, n, B, h):
     assert lib.astk_bridge_states(vp(g_c), vp(g_h), vp(e_c), vp(e_h), nd, nl_enc, nl_enc + 1, B, h, 0, stream()) != 0      # more layers than the encoder has
 
 
+def test_encoder_backward_last_arrival_waits_for_the_slowest_peer(lib, monkeypatch):
+    """Regression test of a hand-off race in lstm_persist_bwd_rs (round 4).  The layer below waits for `count >= NS * k` arrivals on the
+    down-partials counter, which means "every slice has published k steps" only while the slices are at most one arrival apart; a slice's
+    LAST arrival needs nothing from its peers, so a workgroup that finished early could make it while a slow peer was two arrivals behind,
+    and a consumer then read the slow peer's tile of step 1 before it was written -- getting the PREVIOUS launch's tile.  ASTK_PERSIST_DBG=16
+    makes slice 0 of every cell with a layer below dawdle exactly there; two different inputs alternate, so a stale tile is a wrong tile.
+    The bias gradients are summed inside the kernel in a fixed order (two commutative atomic adds per element): bit-identical or broken."""
+    from ast_amd._lib import LstmGrads, LstmParams, LstmStackDesc
+    T, B, in_dim, h, nl = 200, 32, 64, 256, 3           # (T * B = 6400 rows: the batched products take their deterministic two-contributor tiles)
+    rng = np.random.default_rng(11)
+    names, prm, grd = [], {}, {}
+    for pat in ("L{}_enc", "L{}_rev_enc"):
+        n_in = in_dim
+        for k in range(nl):
+            n = pat.format(k); names.append(n)
+            prm[n + "/Wu"], prm[n + "/b"] = dev(rng.standard_normal((4 * h, n_in)) / np.sqrt(n_in)), dev(rng.standard_normal(4 * h) * 0.3)
+            prm[n + "/Wl"] = dev(rng.standard_normal((4 * h, h)) / np.sqrt(h)); n_in = h
+    for k, v in prm.items():
+        grd[k] = torch.zeros_like(v)
+    lp, lg = (LstmParams * (2 * nl))(), (LstmGrads * (2 * nl))()
+    for i, n in enumerate(names):
+        lp[i].Wu, lp[i].b, lp[i].Wl = (prm[n + s].data_ptr() for s in ("/Wu", "/b", "/Wl"))
+        lg[i].dWu, lg[i].db, lg[i].dWl = (grd[n + s].data_ptr() for s in ("/Wu", "/b", "/Wl"))
+    d = LstmStackDesc(T, B, in_dim, h, nl, 2)
+    assert lib.astk_lstm_stack_path(C.byref(d)) == 1
+    nbytes = lib.astk_lstm_stack_workspace_bytes(C.byref(d))
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device="cuda")
+    sets = [(dev(rng.standard_normal((T, B, in_dim))), dev(rng.standard_normal((B, T, 2 * h)))) for _ in range(2)]
+    g_c, g_h = dev(rng.standard_normal((2, nl, B, h))), dev(rng.standard_normal((2, nl, B, h)))
+    enc, cT, hT = torch.zeros(B, T, 2 * h, device="cuda"), torch.zeros(2, nl, B, h, device="cuda"), torch.zeros(2, nl, B, h, device="cuda")
+    dx = torch.zeros(T, B, in_dim, device="cuda")
+
+    def run(which):
+        x, g_enc = sets[which]
+        for v in grd.values():
+            v.zero_()
+        ok(lib, lib.astk_lstm_stack_fwd(C.byref(d), lp, vp(x), None, vp(enc), vp(cT), vp(hT), vp(ws), nbytes, stream()))
+        ok(lib, lib.astk_lstm_stack_bwd(C.byref(d), lp, lg, vp(x), None, vp(g_enc), vp(g_c), vp(g_h), vp(dx), vp(ws), nbytes, stream()))
+        return {n: grd[n + "/b"].clone() for n in names}
+
+    ref = run(0)                       # no dawdling: the reference bias gradients of input 0
+    monkeypatch.setenv("ASTK_PERSIST_DBG", "16")
+    for it in range(12):
+        run(1)
+        got = run(0)
+        for n in names:
+            assert torch.equal(got[n], ref[n]), (it, n, float((got[n] - ref[n]).abs().max()))
+    st = C.c_uint(0)
+    lib.astk_persist_status(C.byref(st), 1)
+    assert st.value == 0
+
+
 # ------------------------------------------------------------------ attention scan
 @pytest.mark.parametrize("B,T,H", [(3, 6, 8), (32, 50, 512), (5, 201, 260), (2, 9, 1024)])
 def test_attention_step(lib, B, T, H):
