@@ -14,7 +14,9 @@ cfg = copy.deepcopy(bench.MODEL_CFG)
 V = cfg["rnn_config"]["dec_vocab_size"]
 if which == "es_en_20h":
     cfg["rnn_config"]["dec_layers"] = 3
-B, T, D, L = 32, 800, 80, 40
+if which == "cfg5":
+    cfg["rnn_config"].update(enc_layers=6, hidden_units=int(os.environ.get("HIDDEN", 1024)), attn_units=int(os.environ.get("HIDDEN", 1024)), dec_vocab_size=8004); V = 8004
+B, T, D, L = int(os.environ.get("BATCH", 32)), 800, 80, 40
 m = SpeechEncoderDecoder(0, cfg).materialize(D, seed=0)
 batches = []
 for i in range(8):
