@@ -673,18 +673,33 @@ static int seq_pp(int F) { return 64 / F; }      // (t, b) pairs per block itera
 static size_t seq_tile_bytes(int F) { return std::max((size_t)seq_pp(F) * F * SEQ_LD * sizeof(float), (size_t)2 * 256 * sizeof(float4)); }
 static bool seq_bwd_applicable(int C, int F, long npairs) { return (C % SEQ_CH) == 0 && F >= 1 && F <= 16 && npairs < (1L << 30); }
 // tile[pl][f][c - c0] = d_out[pair p0 + pl][c * F + f] for the block's channels (pairs past the end: the last pair again, never used)
-__device__ __forceinline__ void seq_tile_load(const float* __restrict__ d_out, float* tile, int p0, int npairs, int PP, int c0, int C, int F) {
-  const int per_pair4 = SEQ_CH * F / 4;
-  for (int i = threadIdx.x; i < PP * per_pair4; i += 256) {
+// in two halves: the 16-byte loads of the iteration's d_out piece (at most SEQ_TL per thread: pp * 16 F <= 1024), issued together with the Y
+// rows in front of the barrier, and the re-ordering stores into the tile behind it
+constexpr int SEQ_TL = 4;
+__device__ __forceinline__ void seq_tile_fetch(const float* __restrict__ d_out, float4 (&v)[SEQ_TL], int p0, int npairs, int PP, int c0, int C, int F) {
+  const int per_pair4 = SEQ_CH * F / 4, n4 = PP * per_pair4;
+#pragma unroll
+  for (int u = 0; u < SEQ_TL; ++u) {
+    const int i = min((int)threadIdx.x + 256 * u, n4 - 1);
     const int pl = i / per_pair4, q4 = i % per_pair4;
     const long p = min(p0 + pl, npairs - 1);
-    const float4 v = *reinterpret_cast<const float4*>(d_out + (p * C + c0) * F + 4 * q4);
-    float* tp = tile + pl * F * SEQ_LD;
-    int c = (4 * q4) / F, f = (4 * q4) % F;
-    tp[f * SEQ_LD + c] = v.x; if (++f == F) { f = 0; ++c; }
-    tp[f * SEQ_LD + c] = v.y; if (++f == F) { f = 0; ++c; }
-    tp[f * SEQ_LD + c] = v.z; if (++f == F) { f = 0; ++c; }
-    tp[f * SEQ_LD + c] = v.w;
+    v[u] = *reinterpret_cast<const float4*>(d_out + (p * C + c0) * F + 4 * q4);
+  }
+}
+__device__ __forceinline__ void seq_tile_store(float* tile, const float4 (&v)[SEQ_TL], int PP, int F) {
+  const int per_pair4 = SEQ_CH * F / 4, n4 = PP * per_pair4;
+#pragma unroll
+  for (int u = 0; u < SEQ_TL; ++u) {
+    const int i = (int)threadIdx.x + 256 * u;
+    if (i < n4) {
+      const int pl = i / per_pair4, q4 = i % per_pair4;
+      float* tp = tile + pl * F * SEQ_LD;
+      int c = (4 * q4) / F, f = (4 * q4) % F;
+      tp[f * SEQ_LD + c] = v[u].x; if (++f == F) { f = 0; ++c; }
+      tp[f * SEQ_LD + c] = v[u].y; if (++f == F) { f = 0; ++c; }
+      tp[f * SEQ_LD + c] = v[u].z; if (++f == F) { f = 0; ++c; }
+      tp[f * SEQ_LD + c] = v[u].w;
+    }
   }
 }
 // A thread's four (pair, f) slots are the same in every block iteration (slot = row group + 16 u): set up once.
@@ -723,8 +738,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_stats_seq(const float* __restric
       const int t = pp / B, b = pp - t * B;
       y[u] = *reinterpret_cast<const float4*>(Y + (((long)b * F + sl.f[u]) * Tn + t) * C + c);
     }
+    float4 tv[SEQ_TL];
+    seq_tile_fetch(d_out, tv, p0, npairs, PP, c0, C, F);
     __syncthreads();
-    seq_tile_load(d_out, seq_tile, p0, npairs, PP, c0, C, F);
+    seq_tile_store(seq_tile, tv, PP, F);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < SEQ_UNR; ++u) {
@@ -779,8 +796,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_seq(const float* __restric
       row[u] = ((long)b * F + sl.f[u]) * (Tn + padF + padB) + padF + t;
       y[u] = *reinterpret_cast<const float4*>(Y + (((long)b * F + sl.f[u]) * Tn + t) * C + c);
     }
+    float4 tv[SEQ_TL];
+    seq_tile_fetch(d_out, tv, p0, npairs, PP, c0, C, F);
     __syncthreads();
-    seq_tile_load(d_out, seq_tile, p0, npairs, PP, c0, C, F);
+    seq_tile_store(seq_tile, tv, PP, F);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < SEQ_UNR; ++u) {
