@@ -716,6 +716,48 @@ struct SeqSlots {
     }
   }
 };
+// out[t][b][c * F + f] = relu(bn(Y[(b, f, t)][c])), the forward mirror of the kernels below: a block owns SEQ_CH channels, reads the F conv rows of
+// PP (t, b) pairs 256 bytes at a time (16-byte loads), re-orders [f][c] -> [c][f] through LDS and writes each pair's piece of the frames as one
+// contiguous run of 16-byte stores (k_bn_relu_to_seq moves 4 bytes per lane both ways: 43 us for 158 MB)
+__global__ __launch_bounds__(256) void k_bn_relu_to_seq_tiled(const float* __restrict__ Y, const float* __restrict__ bn, float* __restrict__ out, int B, int F,
+                                                              int Tn, int C, int PP, unsigned long long* amax) {
+  extern __shared__ __attribute__((aligned(16))) float seq_tile[];       // [PP][SEQ_CH * F]: a pair's piece in the frames' own order
+  __shared__ float red4[4];
+  const int c0 = blockIdx.x * SEQ_CH, cl = 4 * (threadIdx.x & 15), c = c0 + cl, g16 = threadIdx.x >> 4;
+  const int npairs = Tn * B, piece = SEQ_CH * F;
+  const float4 sc = *reinterpret_cast<const float4*>(bn + 2 * C + c), sh = *reinterpret_cast<const float4*>(bn + 3 * C + c);
+  SeqSlots sl;
+  sl.init(g16, PP * F, F, cl);
+  float mx = 0.f;
+  for (int p0 = blockIdx.y * PP; p0 < npairs; p0 += gridDim.y * PP) {
+    float4 y[SEQ_UNR];
+#pragma unroll
+    for (int u = 0; u < SEQ_UNR; ++u) {
+      const int pp = min(p0 + sl.pl[u], npairs - 1);
+      const int t = pp / B, b = pp - t * B;
+      y[u] = *reinterpret_cast<const float4*>(Y + (((long)b * F + sl.f[u]) * Tn + t) * C + c);
+    }
+    __syncthreads();                 // the previous iteration's piece has been written out
+#pragma unroll
+    for (int u = 0; u < SEQ_UNR; ++u) {
+      if (sl.ok[u]) {
+        float* tp = seq_tile + sl.pl[u] * piece + cl * F + sl.f[u];
+        const float v0 = fmaxf(y[u].x * sc.x + sh.x, 0.f), v1 = fmaxf(y[u].y * sc.y + sh.y, 0.f);
+        const float v2 = fmaxf(y[u].z * sc.z + sh.z, 0.f), v3 = fmaxf(y[u].w * sc.w + sh.w, 0.f);
+        tp[0] = v0; tp[F] = v1; tp[2 * F] = v2; tp[3 * F] = v3;
+        if (p0 + sl.pl[u] < npairs) mx = fmaxf(fmaxf(mx, fmaxf(v0, v1)), fmaxf(v2, v3));
+      }
+    }
+    __syncthreads();
+    const int per_pair4 = piece / 4;
+    for (int i = threadIdx.x; i < PP * per_pair4; i += 256) {
+      const int pl = i / per_pair4, q4 = i - pl * per_pair4;
+      if (p0 + pl < npairs)
+        *reinterpret_cast<float4*>(out + ((long)(p0 + pl) * C + c0) * F + 4 * q4) = *reinterpret_cast<const float4*>(seq_tile + pl * piece + 4 * q4);
+    }
+  }
+  if (amax) amax_emit_block(amax, mx, red4);
+}
 // stat[c] += sum g, stat[C + c] += sum g * xhat over all rows, g = d_out * (bn(Y) > 0): grid (C / SEQ_CH, row slabs)
 __global__ __launch_bounds__(256) void k_bn_bwd_stats_seq(const float* __restrict__ Y, const float* __restrict__ d_out, const float* __restrict__ bn,
                                                           int B, int F, int Tn, int C, int PP, double* __restrict__ stat) {
@@ -972,9 +1014,16 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
                          P.Tn[i], P.padA[i], P.a_hp_s[i]);
       ASTK_LAUNCH_CHECK();
     } else {
+      static const bool tiled_off = getenv("ASTK_CNN_SEQ_FWD") && getenv("ASTK_CNN_SEQ_FWD")[0] == '0';
+      if (!tiled_off && seq_bwd_applicable(C, F, (long)P.Tn[i] * B)) {
+        const int pp = seq_pp(F), gy = std::max(1, std::min(2048 / (C / SEQ_CH), cdiv(P.Tn[i] * B, pp)));
+        hipLaunchKernelGGL(k_bn_relu_to_seq_tiled, dim3(C / SEQ_CH, gy), dim3(256), (size_t)pp * SEQ_CH * F * sizeof(float), s, P.Y[i], P.bn[i], out, B, F,
+                           P.Tn[i], C, pp, P.a_out);
+      } else {
       const size_t shm = (size_t)C * F * sizeof(float);
       ASTK_CHECK(shm <= 64 * 1024, "cnn: C*F' too large for the re-layout tile (%zu bytes)", shm);
       hipLaunchKernelGGL(k_bn_relu_to_seq, dim3(P.Tn[i], B), dim3(256), shm, s, P.Y[i], P.bn[i], out, B, F, P.Tn[i], C, P.a_out);
+      }
       ASTK_LAUNCH_CHECK();
     }
   }
