@@ -271,6 +271,8 @@ struct GemmArgs {
   int kt;            // k-iterations per tile = ceil(K / BK)
   int tiles_mn;      // tiles per batch matrix
   long iters_total;  // batch * tiles_mn * kt
+  int bm;            // tile order inside a batch matrix: super-rows of bm tile rows, inside a super-row column-major (tile t of a super-row
+                     // = row t % bm of column t / bm), so that G / 8 consecutive tiles form a bm x (G / 8 / bm) block; 1 = row-major
 };
 static inline GemmArgs gemm_args(int M, int N, int K, MatView A, MatView B, float* C, long ldc,
                                  const float* bias = nullptr, int mode = GEMM_STORE, int ksplit = 1) {
@@ -327,6 +329,11 @@ constexpr int GEMM_GROUP_MAX = 12;
 struct GemmGroup {
   int n;
   int unit;          // granule of the stream-K split in k-iterations (1, or 2 when every kt is even)
+  // Hybrid schedule (gemm.hip, "Work decomposition"): the first dp_waves * G tiles of the launch run data-parallel, one whole tile per
+  // workgroup and wave, in XCD-local blocks; only the iterations from rem_start on are split stream-K.  dp_waves = 0: all stream-K.
+  int dp_waves;
+  int dp_kt;         // the launch's uniform k-iterations per tile (hybrid launches only)
+  long rem_start;    // first k-iteration of the stream-K remainder = dp_waves * G * dp_kt
   long iters_total;
   long iter_start[GEMM_GROUP_MAX + 1];
   GemmArgs g[GEMM_GROUP_MAX];

@@ -40,6 +40,9 @@ constexpr int BK = ASTK_GEMM_BK;
 #ifndef ASTK_GEMM_RING
 #define ASTK_GEMM_RING 4        // register slots of staged tiles on the split paths (must divide 12, the staging loop's trip)
 #endif
+#ifndef ASTK_GEMM_RING8
+#define ASTK_GEMM_RING8 2
+#endif
 #ifndef ASTK_GEMM_PAIR
 #define ASTK_GEMM_PAIR 1        // K-contiguous operands: fetch two k-tiles (one 128-byte line per row) at a time
 #endif
@@ -71,8 +74,23 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // First k-iteration of workgroup w of G (stream-K split of the launch's iteration sequence).  grp.unit = 2 when every product of
 // the launch has an even number of k-iterations per tile: ranges then begin on even k-iterations, i.e. on 128-byte lines of a
 // K-contiguous f32 operand, which the paired tile loads rely on for whole-line fetches.
+// (hybrid launches: the stream-K part covers only [rem_start, iters_total); rem_start is a multiple of unit)
 __host__ __device__ __forceinline__ long wg_first_iter(const GemmGroup& grp, unsigned w, unsigned G) {
-  return (grp.iters_total / grp.unit) * (long)w / (long)G * grp.unit;
+  return grp.rem_start + ((grp.iters_total - grp.rem_start) / grp.unit) * (long)w / (long)G * grp.unit;
+}
+// Tile `tile` of a problem (batch-major, then the block order of GemmArgs::bm) -> batch slice and tile coordinates.
+__host__ __device__ __forceinline__ void decode_tile(const GemmArgs& g, long tile, int TLM, int TL, int& zb, int& m0, int& n0) {
+  const int tiles_n = (g.N + TL - 1) / TL;
+  zb = (int)(tile / g.tiles_mn);
+  const int tmn = (int)(tile - (long)zb * g.tiles_mn);
+  if (g.bm <= 1) { m0 = (tmn / tiles_n) * TLM; n0 = (tmn % tiles_n) * TL; return; }
+  const int tiles_m = g.tiles_mn / tiles_n;
+  const int per_sr = g.bm * tiles_n;
+  const int sr = tmn / per_sr, r = tmn - sr * per_sr;
+  const int rows = min(g.bm, tiles_m - sr * g.bm);
+  const int n = r / rows;
+  m0 = (sr * g.bm + (r - n * rows)) * TLM;
+  n0 = n * TL;
 }
 
 // Position j (0..BK/2-1) of the k values a lane of k-group lk (0/1) feeds to the MFMAs of one k-iteration is
@@ -407,19 +425,24 @@ struct Stager {
 // f32 -> 3 x bf16 split, LDS writes).  One wave of each kind sits on every SIMD, so the split's vector-ALU work issues in the gaps of
 // the other wave's MFMAs; with every wave doing both, the co-resident workgroups ran their VALU and MFMA phases in lockstep and the
 // matrix pipe idled more than half of the time (163 instead of 118 TFLOP/s at 4096^3, against > 300 for an MFMA-bound loop).
-constexpr int gemm_threads(int PREC) { return PREC != PREC_F32 ? 512 : 256; }
+// MW: multiplying waves of a split-scheme workgroup, 4 (2 x 2 over the tile) or 8 (4 x 2: 256 x 128 tiles, two multiplying waves and one
+// staging wave per SIMD); the staging role always has 256 threads.
+constexpr int gemm_mw(int TLM) { return TLM == 256 ? 8 : 4; }
+constexpr int gemm_threads(int PREC, int TLM = 128) { return PREC != PREC_F32 ? 256 + 64 * gemm_mw(TLM) : 256; }
+constexpr int gemm_min_waves(int TL, int PREC, int TLM) { return (PREC != PREC_F32 && TLM == 256) ? 3 : waves_per_simd(TL, PREC); }
 // TL: tile edge along N (and along M unless TLM says otherwise: the bf16x3 path also runs 256 x 128 tiles -- per k-iteration the split
 // costs vector-ALU issue slots in proportion to TLM + TL while the MFMAs grow with TLM x TL, and only from 256 x 128 on do the MFMAs
 // (1536 cycles per wave and iteration) outlast the split's issue time on the same SIMD).
 template <int TL, bool A_RK, bool B_RK, bool TWOLVL, int PREC, int TLM = TL>
-__global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void gemm_f32_kernel(GemmGroup grp) {
+__global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, TLM)) void gemm_f32_kernel(GemmGroup grp) {
   constexpr int LD_KR = ld_kr(TL);
   constexpr int LDA = A_RK ? LD_RK : LD_KR;
   constexpr int LDB = B_RK ? LD_RK : LD_KR;
-  constexpr int NA = TL / 64;      // 32x32 accumulator tiles per wave and dimension (the wave's sub-tile is TLM/2 x TL/2)
-  constexpr int NAM = TLM / 64;
-  constexpr int WT = TL / 2, WTM = TLM / 2;
   constexpr bool SPLIT = PREC != PREC_F32;     // operands staged as 16-bit planes (three bf16 terms, or one fp16 term)
+  constexpr int MW = SPLIT ? gemm_mw(TLM) : 4; // multiplying waves, MW/2 x 2 over the tile
+  constexpr int WT = TL / 2, WTM = TLM / (MW / 2);    // the wave's sub-tile is WTM x WT
+  constexpr int NA = WT / 32;      // 32x32 accumulator tiles per wave and dimension
+  constexpr int NAM = WTM / 32;
   constexpr int NPL = prec_planes(PREC);
   static_assert(SPLIT || TLM == TL, "the f32 path runs square tiles");
   constexpr int A_FLOATS = SPLIT ? sp_stage(TLM, A_RK, PREC) / 4 : (A_RK ? TL * LD_RK : BK * LD_KR);
@@ -429,8 +452,8 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
   __shared__ __attribute__((aligned(16))) float Bs[NST][B_FLOATS];
   static_assert(BK == 16 || BK == 32, "BK / 2 floats per lane and operand, read as BK / 8 float4");
 
-  const int tid = threadIdx.x & 255;                 // stager / multiplier thread index inside its role
-  const bool producer = SPLIT && threadIdx.x >= 256;   // split schemes: waves 4-7 stage, waves 0-3 multiply; f32: every wave does both
+  const bool producer = SPLIT && threadIdx.x >= 64 * MW;   // split schemes: the last four waves stage, waves 0 .. MW-1 multiply; f32: every wave does both
+  const int tid = producer ? threadIdx.x - 64 * MW : threadIdx.x;      // stager / multiplier thread index inside its role
   const bool stages = !SPLIT || producer, multiplies = !SPLIT || !producer;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -445,21 +468,35 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
     // alone 1100 cycles per k-iteration, staging waves alone 600, both together 1600-1900 = the SUM).  Static priority for the
     // multiplying waves: their MFMAs issue the moment the pipe is free, the split fills the gaps.  (The branch must be provably
     // wave-uniform: s_setprio ignores EXEC.)
-    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < 256) __builtin_amdgcn_s_setprio(3);
+    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64 * MW) __builtin_amdgcn_s_setprio(3);
   }
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 32)      // clock probe: shader cycles per 10 ns tick over the kernel's life (block 0)
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & (32 | 256))      // clock probe: shader cycles per 10 ns tick over the kernel's life (block 0)
   const long long c0_ = clock64(), w0_ = wall_clock64();
+  long long dbg_t[3] = {0, 0, 0};      // (& 256) per-role stamps: multiplying waves [fetch + MFMA issue, -, barrier]; staging waves [split + LDS writes, loads, barrier]
+  long dbg_n = 0;
 #endif
   unsigned wgi = blockIdx.x;
   if (SPLIT && (gridDim.x % 8) == 0) wgi = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
-  long it = wg_first_iter(grp, wgi, gridDim.x);
-  const long it_end = wg_first_iter(grp, wgi + 1, gridDim.x);
+  // Hybrid schedule: phases 0 .. dp_waves-1 are data-parallel waves -- in wave ph the gridDim.x / 8 workgroups of XCD x own the
+  // consecutive tiles [(8 ph + x) G/8, (8 ph + x + 1) G/8) of the block order, a bm x (G/8/bm) block of the output whose 32 workgroups
+  // start together and march through k side by side, so the XCD's L2 serves every operand panel of the block to all its users; the
+  // last phase is the stream-K split of what is left.
+  const int n_phases = grp.dp_waves + 1;
+  for (int ph = 0; ph < n_phases; ++ph) {
+  long it, it_end;
+  if (ph < grp.dp_waves) {
+    const long T = ((long)ph * 8 + blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+    it = T * grp.dp_kt;
+    it_end = it + grp.dp_kt;
+  } else {
+    it = wg_first_iter(grp, wgi, gridDim.x);
+    it_end = wg_first_iter(grp, wgi + 1, gridDim.x);
+  }
   int prob = 0;
 
   while (it < it_end) {
     while (it >= grp.iter_start[prob + 1]) ++prob;
     const GemmArgs& g = grp.g[prob];
-    const int tiles_n = (g.N + TL - 1) / TL;
     const int kt_tile = g.kt;
     const long lit = it - grp.iter_start[prob];
     const long lend = min(it_end, grp.iter_start[prob + 1]) - grp.iter_start[prob];
@@ -467,9 +504,9 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
     const int k0 = (int)(lit - tile * kt_tile);
     const int k1 = (int)min((long)kt_tile, (long)k0 + (lend - lit));
     it += k1 - k0;
-    const int zb = (int)(tile / g.tiles_mn);
-    const int tmn = (int)(tile - (long)zb * g.tiles_mn);
-    const int m0 = (tmn / tiles_n) * TLM, n0 = (tmn % tiles_n) * TL;
+    int zb, m0, n0;
+    decode_tile(g, tile, TLM, TL, zb, m0, n0);
+    const int m0_t = m0, n0_t = n0;
     const int kbeg = k0 * BK;
     const int kend = min(g.K, k1 * BK);
     const bool whole = (k0 == 0) && (k1 == kt_tile);
@@ -479,13 +516,14 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
     B.p += (long)zb * g.sB;
     float* C = g.C + (long)zb * g.sC;
 
-    constexpr int RING = SPLIT ? ASTK_GEMM_RING : 1;
+    // (the 12-wave kernel has 168 registers per lane: two staged tiles of 256 + 128 rows in flight, 48 registers, instead of four)
+    constexpr int RING = SPLIT ? (MW == 8 ? ASTK_GEMM_RING8 : ASTK_GEMM_RING) : 1;
     Stager<TLM, A_RK, TWOLVL, PREC, RING> sa;
     Stager<TL, B_RK, TWOLVL, PREC, RING> sb;
     // (every wave runs init: a field assigned only under the role branch, which depends on threadIdx, is a divergent value to hipcc
     //  -- and a divergent kcur puts the operand base pointer into vector registers and a waterfall loop around every buffer load)
-    sa.init(A, m0, g.M, kbeg, kend, tid);
-    sb.init(B, n0, g.N, kbeg, kend, tid);
+    sa.init(A, m0, g.M, kbeg, kend, tid & 255);
+    sb.init(B, n0, g.N, kbeg, kend, tid & 255);
     int seA = 127, seB = 127;
     if constexpr (PREC == PREC_F16X2 || PREC == PREC_F16) {
       seA = scale_exp(g.amaxA);
@@ -507,6 +545,10 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
     const int e_M = g.M, e_N = g.N, e_ctn = g.c_tn;
     const long e_ldc = g.ldc, e_csg = g.c_sg, e_cst = g.c_st;
     auto epilogue = [&](f32x16 (&acc)[NAM][NA]) {
+      // (the tile's origin through an opaque copy: the row / column offsets below depend on nothing the k loop computes, and hipcc would
+      //  otherwise form them in FRONT of the loop and carry ~36 registers of addresses through it -- spills in the 168-register kernel)
+      int m0 = m0_t, n0 = n0_t;
+      asm volatile("" : "+v"(m0), "+v"(n0));
       if (e_bias) {       // (uniform) this lane's two bias values go into the accumulators first: no load behind the stores
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -599,6 +641,9 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
           constexpr int pos = decltype(posc)::value;          // kt_ % 12
           constexpr bool TAIL = decltype(tailc)::value;
           constexpr int slot = (pos + 2) % RING, st = (pos + 2) % 3;
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
+          const long long q0_ = clock64();
+#endif
 #if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 8)      // timing experiment: staging waves idle
 #else
           if (!TAIL || kt_ + 2 < nk) {
@@ -608,10 +653,20 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
 #endif
 #if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 12)      // timing experiment: no global loads in the loop
 #else
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
+          const long long q1_ = clock64();
+#endif
           refill(sa, A, g.spanA, ARK, std::integral_constant<bool, !TAIL>{}, kt_ + 2, slot);
           refill(sb, B, g.spanB, BRK, std::integral_constant<bool, !TAIL>{}, kt_ + 2, slot);
 #endif
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
+          const long long q2_ = clock64();
           __syncthreads();
+          const long long q3_ = clock64();
+          dbg_t[0] += q1_ - q0_; dbg_t[1] += q2_ - q1_; dbg_t[2] += q3_ - q2_; ++dbg_n;
+#else
+          __syncthreads();
+#endif
         };
         // steady state (12 = lcm(3 stages, 4 slots) iterations per trip): every tile stored in the trip is a full tile, every tile loaded exists
         for (; kt + 13 + RING < nk && kbeg + (kt + 14) * BK <= kend; kt += 12) {
@@ -716,6 +771,66 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
           }
         }
         };
+        if constexpr (MW == 8 && PREC == PREC_BF16X3) {
+        // ---- 256 x 128 tiles, eight multiplying waves (two per SIMD) of 64 x 64: 168 registers per lane, so only the hi planes are double
+        // buffered.  Iteration kt: the mid / lo fragments of tile kt are fetched at the top and land behind the four hi.hi MFMAs, whose
+        // operands arrived during iteration kt-1; the hi fragments of tile kt+1 are fetched behind them.  (The order of the six term
+        // products inside one 16-k block is free: every one of them is added to an accumulator that already holds the sums of all earlier k.)
+        struct FragsH { bf16x8 a[NAM], b[NA]; };
+        struct FragsML { bf16x8 a[NAM][2], b[NA][2]; };      // [.][0] mid, [.][1] lo
+        auto fetch_h = [&](FragsH& f, int st) {
+#pragma unroll
+          for (int i = 0; i < NAM; ++i) f.a[i] = frag(stA(st), A_RK, std::integral_constant<int, TLM>{}, wm * WTM + 32 * i, 0, 0);
+#pragma unroll
+          for (int i = 0; i < NA; ++i) f.b[i] = frag(stB(st), B_RK, std::integral_constant<int, TL>{}, wn * WT + 32 * i, 0, 0);
+        };
+        auto fetch_ml = [&](FragsML& f, int st) {
+#pragma unroll
+          for (int pl = 1; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < NAM; ++i) f.a[i][pl - 1] = frag(stA(st), A_RK, std::integral_constant<int, TLM>{}, wm * WTM + 32 * i, pl, 0);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) f.b[i][pl - 1] = frag(stB(st), B_RK, std::integral_constant<int, TL>{}, wn * WT + 32 * i, pl, 0);
+          }
+        };
+        static_assert(BK == 16 || !(MW == 8), "the 12-wave kernel is written for 16-deep tiles");
+        FragsH h0, h1;
+        FragsML ml;
+        fetch_h(h0, 0);
+        auto cstep8 = [&](auto posc, const int kt_) {
+          constexpr int pos = decltype(posc)::value;
+          FragsH& hc = (pos & 1) ? h1 : h0;
+          FragsH& hn = (pos & 1) ? h0 : h1;
+          fetch_ml(ml, pos % 3);
+#pragma unroll
+          for (int i = 0; i < NAM; ++i)
+#pragma unroll
+            for (int i2 = 0; i2 < NA; ++i2) acc[i][i2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hc.a[i], hc.b[i2], acc[i][i2], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          fetch_h(hn, (pos + 1) % 3);         // (unconditional: behind the range's last tile this reads a stage nobody writes, and nobody uses the result)
+          // mid.hi, hi.mid, mid.mid, lo.hi, hi.lo
+#pragma unroll
+          for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int i = 0; i < NAM; ++i)
+#pragma unroll
+              for (int i2 = 0; i2 < NA; ++i2) {
+                const bf16x8 av = t == 0 ? ml.a[i][0] : t == 1 ? hc.a[i] : t == 2 ? ml.a[i][0] : t == 3 ? ml.a[i][1] : hc.a[i];
+                const bf16x8 bv = t == 0 ? hc.b[i2] : t == 1 ? ml.b[i2][0] : t == 2 ? ml.b[i2][0] : t == 3 ? hc.b[i2] : ml.b[i2][1];
+                acc[i][i2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][i2], 0, 0, 0);
+              }
+          __builtin_amdgcn_sched_barrier(0);
+          __syncthreads();
+        };
+        for (int kt = 0; kt < nk; kt += 6) {
+          cstep8(std::integral_constant<int, 0>{}, kt);
+          if (kt + 1 < nk) cstep8(std::integral_constant<int, 1>{}, kt + 1);
+          if (kt + 2 < nk) cstep8(std::integral_constant<int, 2>{}, kt + 2);
+          if (kt + 3 < nk) cstep8(std::integral_constant<int, 3>{}, kt + 3);
+          if (kt + 4 < nk) cstep8(std::integral_constant<int, 4>{}, kt + 4);
+          if (kt + 5 < nk) cstep8(std::integral_constant<int, 5>{}, kt + 5);
+        }
+        } else {
         Frags f0, f1;
         fetch(f0, 0);
         // iteration kt (position pos = kt % 6): fetch tile kt+1 from stage (pos+1) % 3 into the other register set, multiply tile kt
@@ -723,13 +838,23 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
           constexpr int pos = decltype(posc)::value;
 #if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 16)      // timing experiment: multiplying waves idle
 #else
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
+          const long long q0_ = clock64();
+#endif
           if (kt_ + 1 < nk) fetch((pos & 1) ? f0 : f1, (pos + 1) % 3);
           mult((pos & 1) ? f1 : f0);
 #endif
           // the barrier stays BEHIND the MFMAs: hipcc otherwise hoists it (and the lgkmcnt(0) it needs) to right behind the first MFMA,
           // which puts the fragment reads' latency back on the matrix pipe's critical path
           __builtin_amdgcn_sched_barrier(0);
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
+          const long long q1_ = clock64();
           __syncthreads();
+          const long long q2_ = clock64();
+          dbg_t[0] += q1_ - q0_; dbg_t[2] += q2_ - q1_; ++dbg_n;
+#else
+          __syncthreads();
+#endif
         };
         for (int kt = 0; kt < nk; kt += 6) {
           cstep(std::integral_constant<int, 0>{}, kt);
@@ -739,6 +864,7 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
           if (kt + 4 < nk) cstep(std::integral_constant<int, 4>{}, kt + 4);
           if (kt + 5 < nk) cstep(std::integral_constant<int, 5>{}, kt + 5);
         }
+        }   // MW == 4
         if constexpr (PREC == PREC_F16X2 || PREC == PREC_F16) {
           const float ia = __uint_as_float((unsigned)(254 - seA) << 23), ib = __uint_as_float((unsigned)(254 - seB) << 23);
 #pragma unroll
@@ -836,6 +962,14 @@ __global__ __launch_bounds__(gemm_threads(PREC), waves_per_simd(TL, PREC)) void 
       epilogue(acc);
     }   // !SPLIT
   }
+  }   // phases
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
+  if (blockIdx.x == 100 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 1 || (threadIdx.x >> 6) == 5)) {
+    const long long dc = clock64() - c0_, dw = wall_clock64() - w0_;
+    printf("gemm stamps wave %d: %ld its, per it: work %lld  loads %lld  barrier %lld cycles; kernel %lld cycles in %lld x 10 ns = %.3f GHz\n", (int)(threadIdx.x >> 6),
+           dbg_n, dbg_t[0] / max(dbg_n, 1L), dbg_t[1] / max(dbg_n, 1L), dbg_t[2] / max(dbg_n, 1L), dc, dw, (double)dc / (double)dw * 0.1);
+  }
+#endif
 #if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 32)
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     const long long dc = clock64() - c0_, dw = wall_clock64() - w0_;
@@ -946,10 +1080,8 @@ __device__ __forceinline__ void zero_split_block(const GemmGroup& grp, int G, in
   const long it = git - grp.iter_start[prob];
   if (it % g.kt == 0) return;
   const long tile = it / g.kt;
-  const int tiles_n = (g.N + TL - 1) / TL;
-  const int zb = (int)(tile / g.tiles_mn);
-  const int tmn = (int)(tile - (long)zb * g.tiles_mn);
-  const int m0 = (tmn / tiles_n) * TLM, n0 = (tmn % tiles_n) * TL;
+  int zb, m0, n0;
+  decode_tile(g, tile, TLM, TL, zb, m0, n0);
   float* C = g.C + (long)zb * g.sC;
   const int w = vec ? 4 : 1;                    // floats per thread and row
   const int tpr = TL / w;                        // threads per row
@@ -1162,7 +1294,12 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     int max_kt = 0;
     for (int i = 0; i < grp.n; ++i) max_kt = std::max(max_kt, grp.g[i].kt);
     const bool small = grp.iters_total < 256L * wgs_per_cu(128) * 10 * (32 / BK) && (tiles < 192 || max_kt <= 12 * (16 / BK > 0 ? 16 / BK : 1));
-    int want = force_tl == 64 || force_tl == 128 || force_tl == 256 ? force_tl : (small ? 64 : 128);   // (256 x 128 tiles: ASTK_GEMM_TILE=256 only -- measured slower)
+    // 256 x 128 tiles on the 12-wave kernel (round 5): launches of 20 GFLOP and more whose M extents waste at most 10 % more rows than
+    // with 128-row tiles -- measured per launch of the train step (scratch/r5_gemm_t256.sh): 3-6 % faster on every launch above 200 us,
+    // slower on the small ones (6400 x 512 x 512: 40 -> 58 us)
+    static const double big_flops = getenv("ASTK_GEMM_T256_ABOVE") ? atof(getenv("ASTK_GEMM_T256_ABOVE")) : 2e10;
+    const bool big = prec == PREC_BF16X3 && BK == 16 && tall_ok && flops >= big_flops && !small;
+    int want = force_tl == 64 || force_tl == 128 || force_tl == 256 ? force_tl : (small ? 64 : (big ? 256 : 128));
     if (want == 256 && (prec != PREC_BF16X3 || BK != 16)) want = 128;
     if (want == 64 && prec == PREC_F16) want = 128;        // (the fp16 variant is instantiated for 128-tiles only)
     if (want == 128) break;
@@ -1210,11 +1347,36 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     for (int i = 1; i < grp.n; ++i) uniform = uniform && grp.g[i].kt == grp.g[0].kt;
     if (!uniform) { G = std::min(256L * WGS_PER_CU, std::max(1L, grp.iters_total / std::max(1, min_kt))); aligned = false; }
   }
+  // Hybrid schedule (kernel: "Hybrid schedule"): a stream-K launch of the split schemes whose tiles all have the same depth and outnumber
+  // the grid runs floor(tiles / G) data-parallel waves of whole tiles in XCD-local blocks first; only the rest is split stream-K.
+  // (ASTK_GEMM_HYBRID=0: everything stream-K in row-major tile order, the schedule of rounds 1-4.)
+  static const int hybrid_on = getenv("ASTK_GEMM_HYBRID") ? atoi(getenv("ASTK_GEMM_HYBRID")) : 1;
+  grp.dp_waves = 0; grp.dp_kt = 0; grp.rem_start = 0;
+  if (hybrid_on && prec != PREC_F32 && !aligned && (G % 8) == 0 && tiles >= G) {
+    bool uniform = true;
+    for (int i = 1; i < grp.n; ++i) uniform = uniform && grp.g[i].kt == grp.g[0].kt;
+    // (C += AB goes out as atomic adds: in data-parallel waves all workgroups reach their epilogues together and the atomics arrive in
+    //  bursts -- 6400 x 3072 x 1024: 247 -> 271 us; those launches stay all stream-K, where the epilogues are staggered)
+    for (int i = 0; i < grp.n; ++i) uniform = uniform && grp.g[i].mode != GEMM_ACCUM;
+    if (uniform) {
+      grp.dp_waves = (int)(tiles / G);
+      grp.dp_kt = grp.g[0].kt;
+      grp.rem_start = (long)grp.dp_waves * G * grp.dp_kt;
+      const int chunk = (int)(G / 8);          // tiles of one XCD and wave
+      for (int i = 0; i < grp.n; ++i) {
+        GemmArgs& a = grp.g[i];
+        const int tiles_n = cdiv(a.N, TL);
+        int cols = 1;                          // block width: a power of two <= tiles_n, near sqrt(chunk) from above (rows + cols minimal)
+        while (cols * 2 <= tiles_n && cols * 2 * cols * 2 <= 2 * chunk) cols *= 2;
+        a.bm = std::max(1, chunk / cols);
+      }
+    }
+  }
   static const bool log_shapes = getenv("ASTK_GEMM_LOG") != nullptr;
   if (log_shapes)
     for (int i = 0; i < grp.n; ++i)
-      fprintf(stderr, "astk_gemm layout=%d M=%d N=%d K=%d batch=%d mode=%d twolvl=%d group=%d/%d G=%ld kt=%d tile=%d\n", layout, grp.g[i].M,
-              grp.g[i].N, grp.g[i].K, grp.g[i].batch, grp.g[i].mode, (int)twolvl, i, grp.n, G, grp.g[i].kt, TLM * 1000 + TL);
+      fprintf(stderr, "astk_gemm layout=%d M=%d N=%d K=%d batch=%d mode=%d twolvl=%d group=%d/%d G=%ld kt=%d tile=%d dp_waves=%d bm=%d\n", layout, grp.g[i].M,
+              grp.g[i].N, grp.g[i].K, grp.g[i].batch, grp.g[i].mode, (int)twolvl, i, grp.n, G, grp.g[i].kt, TLM * 1000 + TL, grp.dp_waves, grp.g[i].bm);
   ProfScope prof(PROF_GEMM, s, flops);
   if (prof_enabled()) {       // algorithmic bytes of the launch: every operand element read once, every result element written once
     double bytes = 0;
@@ -1271,14 +1433,14 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   if (need_zero && amax_blocks == 0) hipLaunchKernelGGL(k_zero_split_tiles, dim3((unsigned)(G - 1)), dim3(256), 0, s, grp, (int)G, TLM, TL, zero_vec ? 1 : 0);
 #define ASTK_GEMM_LAUNCH(T_, P_, M_)                                                                                              \
   switch (layout) {                                                                                                               \
-    case GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<T_, true, true, false, P_, M_>), grid, dim3(gemm_threads(P_)), 0, s, grp); break;  \
+    case GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<T_, true, true, false, P_, M_>), grid, dim3(gemm_threads(P_, M_)), 0, s, grp); break;  \
     case GEMM_NN:                                                                                                                 \
-      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<T_, true, false, true, P_, M_>), grid, dim3(gemm_threads(P_)), 0, s, grp);  \
-      else hipLaunchKernelGGL((gemm_f32_kernel<T_, true, false, false, P_, M_>), grid, dim3(gemm_threads(P_)), 0, s, grp);        \
+      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<T_, true, false, true, P_, M_>), grid, dim3(gemm_threads(P_, M_)), 0, s, grp);  \
+      else hipLaunchKernelGGL((gemm_f32_kernel<T_, true, false, false, P_, M_>), grid, dim3(gemm_threads(P_, M_)), 0, s, grp);        \
       break;                                                                                                                      \
     default:                                                                                                                      \
-      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<T_, false, false, true, P_, M_>), grid, dim3(gemm_threads(P_)), 0, s, grp); \
-      else hipLaunchKernelGGL((gemm_f32_kernel<T_, false, false, false, P_, M_>), grid, dim3(gemm_threads(P_)), 0, s, grp);       \
+      if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<T_, false, false, true, P_, M_>), grid, dim3(gemm_threads(P_, M_)), 0, s, grp); \
+      else hipLaunchKernelGGL((gemm_f32_kernel<T_, false, false, false, P_, M_>), grid, dim3(gemm_threads(P_, M_)), 0, s, grp);       \
       break;                                                                                                                      \
   }
   if (prec == PREC_F32) {

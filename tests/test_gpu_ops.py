@@ -805,6 +805,40 @@ def test_gemm_random_shapes_against_float64(lib, gemm_split):
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K,batch", [(4100, 1150, 330, 1), (2100, 2100, 300, 1), (1100, 1200, 330, 4), (33000, 200, 200, 1)])
+def test_gemm_hybrid_schedule_whole_tile_waves_and_stream_k_remainder(lib, layout, M, N, K, batch, gemm_split):
+    """Products with more tiles than workgroups (round 5: hybrid schedule of the split schemes -- floor(tiles / 256) data-parallel waves of
+    whole tiles in XCD-local blocks of the block tile order, then a stream-K split of the rest): ragged edges in M, N and K, every output
+    mode, batches, a one-column-of-tiles shape (block order degenerates to tall blocks).  Against float64."""
+    rng = np.random.default_rng(M + 3 * N + K + layout)
+    pad4 = lambda n: (n + 3) // 4 * 4
+    A = rng.standard_normal((batch, M, K)).astype(np.float32)
+    B = rng.standard_normal((batch, N, K)).astype(np.float32)
+    ref = np.einsum("bmk,bnk->bmn", A.astype(np.float64), B.astype(np.float64))
+
+    def store(X, transpose):
+        X = X.transpose(0, 2, 1) if transpose else X
+        P = np.full((batch, X.shape[1], pad4(X.shape[2]) + 4), np.nan, np.float32)
+        P[:, :, :X.shape[2]] = X
+        return P
+    Ad, Bd = store(A, layout == 2), store(B, layout != 0)
+    a, b = dev(Ad), dev(Bd)
+    ldc = pad4(N) + 4
+    bias = rng.standard_normal(N)
+    c = torch.full((batch, M, ldc), 7.0, device="cuda")
+    sa, sb, sc = Ad.shape[1] * Ad.shape[2], Bd.shape[1] * Bd.shape[2], M * ldc
+    ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(a), Ad.shape[2], vp(b), Bd.shape[2], vp(c), ldc, vp(dev(bias)), 0, 1, batch, sa, sb, sc, stream()))
+    close(c[:, :, :N], ref + bias, rtol=2e-5, msg="store")
+    assert float(c[:, :, N:].min()) == 7.0 and float(c[:, :, N:].max()) == 7.0, "wrote outside N"
+    ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(a), Ad.shape[2], vp(b), Bd.shape[2], vp(c), ldc, None, 1, 1, batch, sa, sb, sc, stream()))
+    close(c[:, :, :N], 2 * ref + bias, rtol=2e-5, msg="accum")
+    c.zero_()
+    ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(a), Ad.shape[2], vp(b), Bd.shape[2], vp(c), ldc, None, 2, 1, batch, sa, sb, sc, stream()))
+    close(c[:, :, :N], ref, rtol=2e-5, msg="atomic")
+    assert float(c[:, :, N:].abs().max()) == 0.0, "wrote outside N"
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("sa,sb", [(1e-20, 1e15), (3e7, 2e-3), (1.0, 1e-30)])
 def test_gemm_operand_magnitudes(lib, layout, sa, sb, gemm_split):
     """The default GEMM splits every operand into two fp16 terms behind a per-operand power-of-two scale taken from an absolute-maximum
