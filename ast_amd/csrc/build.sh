@@ -7,7 +7,7 @@ set -e
 cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $ASTK_EXTRA_FLAGS"
 SRCS="util gemm rowgemm attn conv norm lstm lstm_persist decoder decoder_persist decoder_wide"
-HOOKED="gemm conv"        # the translation units with #ifdef ASTK_TEST_HOOKS sections
+HOOKED="gemm conv lstm_persist decoder_persist"        # the translation units with #ifdef ASTK_TEST_HOOKS sections
 mkdir -p ../_obj ../_obj/test
 pids=()
 stale() { [ ! -f $2 ] || [ $1.hip -nt $2 ] || [ common.h -nt $2 ] || [ decoder_wide.h -nt $2 ] || [ ../../include/astk.h -nt $2 ]; }

@@ -13,6 +13,7 @@
 //   BatchNorm: column statistics of the raw conv output [rows][C] in float64 atomics, then one fused
 //             scale/shift/ReLU pass that writes the next layer's padded layout (or the LSTM layout).
 #include "common.h"
+#include <mutex>
 #include <algorithm>
 #include <cstdlib>
 
@@ -229,6 +230,26 @@ static bool conv0_direct_shape(const astk_cnn_desc* d) {
 static bool conv0_direct(const astk_cnn_desc* d) {
   static const bool off = getenv("ASTK_CONV0_DIRECT") && getenv("ASTK_CONV0_DIRECT")[0] == '0';
   return !off && conv0_direct_shape(d) && gemm_precision_mode() == 1 && low_precision_gemms() == 0;
+}
+// Which layer-0 path a forward call took on a workspace (host-side record, never read by a kernel): conv0_direct() is re-evaluated by
+// the backward call from the arithmetic in force THEN; if the process default moved in between while the descriptor says DEFAULT, the
+// backward would read a window matrix XF that was never written (or patches P0 that were never built) -- a silently wrong CNN_0/W
+// gradient from stale workspace.  The forward records (workspace, path); the backward refuses a workspace whose record differs.
+struct Conv0PathRecord { const void* ws; int direct; };
+static std::mutex g_conv0_mu;
+static Conv0PathRecord g_conv0_ring[64];
+static unsigned g_conv0_next = 0;
+static void conv0_path_record(const void* ws, bool direct) {
+  std::lock_guard<std::mutex> lock(g_conv0_mu);
+  for (auto& r : g_conv0_ring)
+    if (r.ws == ws) { r.direct = direct ? 1 : 0; return; }
+  g_conv0_ring[g_conv0_next++ % 64] = Conv0PathRecord{ws, direct ? 1 : 0};
+}
+static int conv0_path_lookup(const void* ws) {      // -1: no forward call recorded for this workspace
+  std::lock_guard<std::mutex> lock(g_conv0_mu);
+  for (auto& r : g_conv0_ring)
+    if (r.ws == ws) return r.direct;
+  return -1;
 }
 constexpr int C0_NPAIR = 8;           // pairs of window elements per thread and tile (256 threads x 8 x 2 >= the window)
 __global__ __launch_bounds__(256, 2) void k_conv0_fwd_x3(const float* __restrict__ X, const float* __restrict__ noise, const float* __restrict__ W,
@@ -959,6 +980,7 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
   const int B = P.B;
   // the statistics of every layer (train) and the maximum slots the producing kernels fill: one fill
   ASTK_TRY(fill_zero(P.zero_fwd_from, train ? P.zero_fwd_bytes : P.zero_fwd_amax_bytes, s));
+  conv0_path_record(ws, conv0_direct(d));
   if (conv0_direct(d)) {
     // ---- layer 0: direct convolution (bf16x3 on the matrix pipe), leaves XF for the weight gradient
     const int tiles_t = cdiv(P.Tc[0], C0_TT), total = B * P.Fc[0] * tiles_t, win = conv0_win_elems(d->st[0]);
@@ -1070,6 +1092,12 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
   ASTK_TRY(make_plan(d, ws, P));
   ASTK_CHECK(ws && ws_bytes >= P.bytes, "conv_bn_relu_bwd: workspace too small");
   ASTK_CHECK(d_out && L && Gr, "conv_bn_relu_bwd: null pointer");
+  {
+    const int fwd_direct = conv0_path_lookup(ws), bwd_direct = conv0_direct(d) ? 1 : 0;
+    ASTK_CHECK(fwd_direct < 0 || fwd_direct == bwd_direct, "conv_bn_relu_bwd: the forward call on this workspace took the %s layer-0 path, this call "
+               "would take the %s one (the process-default arithmetic changed between the two calls while the descriptor's precision is DEFAULT?)",
+               fwd_direct ? "direct-convolution" : "im2col", bwd_direct ? "direct-convolution" : "im2col");
+  }
   const int B = P.B;
   // the last layer's BatchNorm backward reads d_out in its (T'', B, C*F') layout itself (k_bn_bwd_*_seq); shapes those kernels do not take
   // (and the test hook that edits G) go through the re-ordered copy G as before.  ASTK_CNN_SEQ_BWD=0: always the copy.

@@ -27,6 +27,14 @@
 #include "common.h"
 
 // -DASTK_PDEC_TIMING_ALL=1: the per-phase timers of ASTK_PERSIST_DBG in the multi-layer variants too (16 more registers per lane there)
+// (the timers exist only in the test-hook build, libastk_test.so: the product library's kernels see dbg = 0 as a constant)
+#ifdef ASTK_TEST_HOOKS
+static int persist_dbg_env() { const char* e = getenv("ASTK_PERSIST_DBG"); return e ? atoi(e) : 0; }
+#define PERSIST_DBG(a) ((a).dbg)
+#else
+static int persist_dbg_env() { return 0; }
+#define PERSIST_DBG(a) 0
+#endif
 #ifndef ASTK_PDEC_TIMING_ALL
 #define ASTK_PDEC_TIMING_ALL 0
 #endif
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) tk[i] = 0;
   // per-phase debug timers (ASTK_PERSIST_DBG): 50 registers when live -- compiled in only where they fit without spills (one layer)
-  const bool timing = (NL == 1 || ASTK_PDEC_TIMING_ALL) && a.dbg != 0;
+  const bool timing = (NL == 1 || ASTK_PDEC_TIMING_ALL) && PERSIST_DBG(a) != 0;
   long long tlast = timing ? wall_clock64() : 0;
   long long tk_att = 0;
   long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1140,7 +1148,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_bwd(PDecBwdArgs a) {
   long long tb[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) tb[i] = 0;
-  const bool timing = (NL == 1 || ASTK_PDEC_TIMING_ALL) && a.dbg != 0;
+  const bool timing = (NL == 1 || ASTK_PDEC_TIMING_ALL) && PERSIST_DBG(a) != 0;
   long long tlast = timing ? wall_clock64() : 0;
 #define TB(i) if (timing) { const long long now_ = wall_clock64(); tb[i] += now_ - tlast; tlast = now_; }
 
@@ -1755,7 +1763,7 @@ int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, con
   a.ctr = bf.ctr;
   a.ab = abort_ctl(bf.ctr + (size_t)NPHASE_SLOTS * NSH * a.nbt * CTRS, PERSIST_DEC_BWD);
   a.tick_out = prof_tick_buffer(1);
-  { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
+  a.dbg = persist_dbg_env();
   ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)NPHASE_SLOTS * NSH * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), s));
   const size_t shm = pdec_bwd_lds_floats(chunk, a.H) * sizeof(float);       // slices + dS/cvS/ds + ds/alpha/fold of the specialised scan
   {
@@ -1796,7 +1804,7 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
   a.CVH = bf.CVH; a.HT = bf.HT; a.LOGITS = bf.LOGITS; a.LOSSROWS = bf.LOSSROWS; a.LSE = bf.LSE; a.PART = bf.PART; a.CESTAT = bf.CESTAT; a.ML = bf.ML;
   a.ctr = bf.ctr;
   a.ab = abort_ctl(bf.ctr + (size_t)NPHASE_SLOTS * NSH * a.nbt * CTRS, PERSIST_DEC_FWD);
-  { const char* e = getenv("ASTK_PERSIST_DBG"); a.dbg = e ? atoi(e) : 0; }
+  a.dbg = persist_dbg_env();
   a.tick_out = prof_tick_buffer(0);
 #if ASTK_PDEC_SENT_H
   {

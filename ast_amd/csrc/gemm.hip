@@ -43,6 +43,12 @@ constexpr int BK = ASTK_GEMM_BK;
 #ifndef ASTK_GEMM_RING8
 #define ASTK_GEMM_RING8 2
 #endif
+#ifndef ASTK_GEMM_PRIO8
+#define ASTK_GEMM_PRIO8 3       // s_setprio of the multiplying waves of the 12-wave kernel
+#endif
+#ifndef ASTK_GEMM_PRIO8S
+#define ASTK_GEMM_PRIO8S 0      // ... and of its staging waves
+#endif
 #ifndef ASTK_GEMM_PAIR
 #define ASTK_GEMM_PAIR 1        // K-contiguous operands: fetch two k-tiles (one 128-byte line per row) at a time
 #endif
@@ -468,7 +474,8 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
     // alone 1100 cycles per k-iteration, staging waves alone 600, both together 1600-1900 = the SUM).  Static priority for the
     // multiplying waves: their MFMAs issue the moment the pipe is free, the split fills the gaps.  (The branch must be provably
     // wave-uniform: s_setprio ignores EXEC.)
-    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64 * MW) __builtin_amdgcn_s_setprio(3);
+    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64 * MW) __builtin_amdgcn_s_setprio(MW == 8 ? ASTK_GEMM_PRIO8 : 3);
+    else if (MW == 8 && ASTK_GEMM_PRIO8S != 0) __builtin_amdgcn_s_setprio(ASTK_GEMM_PRIO8S);
   }
 #if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & (32 | 256))      // clock probe: shader cycles per 10 ns tick over the kernel's life (block 0)
   const long long c0_ = clock64(), w0_ = wall_clock64();
@@ -801,6 +808,13 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
           constexpr int pos = decltype(posc)::value;
           FragsH& hc = (pos & 1) ? h1 : h0;
           FragsH& hn = (pos & 1) ? h0 : h1;
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
+          const long long q0_ = clock64();
+#endif
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 16)      // timing experiment: multiplying waves idle
+          if (false)
+#endif
+          {
           fetch_ml(ml, pos % 3);
 #pragma unroll
           for (int i = 0; i < NAM; ++i)
@@ -819,8 +833,16 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
                 const bf16x8 bv = t == 0 ? hc.b[i2] : t == 1 ? ml.b[i2][0] : t == 2 ? ml.b[i2][0] : t == 3 ? hc.b[i2] : ml.b[i2][1];
                 acc[i][i2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][i2], 0, 0, 0);
               }
+          }
           __builtin_amdgcn_sched_barrier(0);
+#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
+          const long long q1_ = clock64();
           __syncthreads();
+          const long long q2_ = clock64();
+          dbg_t[0] += q1_ - q0_; dbg_t[2] += q2_ - q1_; ++dbg_n;
+#else
+          __syncthreads();
+#endif
         };
         for (int kt = 0; kt < nk; kt += 6) {
           cstep8(std::integral_constant<int, 0>{}, kt);
@@ -964,7 +986,7 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
   }
   }   // phases
 #if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
-  if (blockIdx.x == 100 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 1 || (threadIdx.x >> 6) == 5)) {
+  if (blockIdx.x == 100 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 1 || (threadIdx.x >> 6) == MW + 1)) {
     const long long dc = clock64() - c0_, dw = wall_clock64() - w0_;
     printf("gemm stamps wave %d: %ld its, per it: work %lld  loads %lld  barrier %lld cycles; kernel %lld cycles in %lld x 10 ns = %.3f GHz\n", (int)(threadIdx.x >> 6),
            dbg_n, dbg_t[0] / max(dbg_n, 1L), dbg_t[1] / max(dbg_n, 1L), dbg_t[2] / max(dbg_n, 1L), dc, dw, (double)dc / (double)dw * 0.1);

@@ -173,6 +173,14 @@ class DataLoader:
                 t_pad = max(min(int(self.info[set_key][u]["sp"]), max_sp) for u in utts)
                 l_pad = max(len(self._targets(u, set_key)) for u in utts) if labels else 0
                 pads = (t_pad, l_pad)
+                if labels and train:
+                    # the targets of the WHOLE batch in unsharded row order (global row b * world + r = row b of rank r): forward_loss's
+                    # random_out draws run over all of them on every rank, and take them from here instead of an all-gather per step
+                    yg = np.zeros((len(utts), l_pad), dtype=np.int32)
+                    for g_, u in enumerate(utts):
+                        t_ = self._targets(u, set_key)
+                        yg[g_, :len(t_)] = np.asarray(t_, dtype=np.int32)
+                    pads = (t_pad, l_pad, yg)
             plan.append((mine, pads))
 
         def padded(arrays, n_min):
@@ -184,6 +192,8 @@ class DataLoader:
                 out = {"X": pad_batch(xs, torch.float32, self.device, pads[0] if pads else 0), "utts": utts}
                 if labels:
                     out["y"] = pad_batch([self._targets(u, set_key) for u in utts], torch.int32, self.device, pads[1] if pads else 0)
+                if pads and len(pads) > 2:
+                    out["y_global"] = pads[2]
                 yield out
             return
         # device batches: loading and padding of batch k+1 run on a helper thread while batch k trains; frame zeroing
@@ -226,6 +236,8 @@ class DataLoader:
                     del out["len"]
                 ring.mark_in_flight(k % ring.depth)
                 out["utts"] = utts
+                if plan[k][1] and len(plan[k][1]) > 2:
+                    out["y_global"] = plan[k][1][2]
                 yield out
 
     def get_hyps(self, preds):

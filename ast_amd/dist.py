@@ -110,6 +110,13 @@ class GradBuckets:
         self.defer_scale = defer_scale
         self.status_fn = status_fn if status_fn is not None else _library_status
         self.status_sum = arena.status_tail if getattr(arena, "status_tail", None) is not None else None
+        # status_dest: the status word of the CURRENT step's [loss, status] pair (set by the model's backward).  The pair's own snapshot
+        # is taken at the end of the backward, BEFORE finish() merges the peers' words: in the pipelined train loop (the loss of step N is
+        # read back after step N+1 has been enqueued) the failing rank would then raise at the read-back of step N while the healthy ranks
+        # first see bit 16 in the pair of step N+1, i.e. only after they have enqueued the all-reduce of step N+2 -- which the failing rank
+        # never joins.  finish() therefore writes the MERGED word into the pair of the step it belongs to: every
+        # rank raises at the read-back of step N with the same collectives enqueued.
+        self.status_dest = None
         self.ranges = {}
         covered = []
         for gname, names in param_groups.items():
@@ -150,8 +157,15 @@ class GradBuckets:
             # skip on every rank alike, and every rank's next loss read-back raises (seq2seq.raise_if_aborted)
             import ctypes as C
             from . import _lib
-            _lib.check(_lib.load().astk_persist_status_merge(C.c_void_p(self.status_sum.data_ptr()),
-                                                             C.c_void_p(torch.cuda.current_stream(self.status_sum.device).cuda_stream)))
+            stream = C.c_void_p(torch.cuda.current_stream(self.status_sum.device).cuda_stream)
+            _lib.check(_lib.load().astk_persist_status_merge(C.c_void_p(self.status_sum.data_ptr()), stream))
+            if self.status_dest is not None:        # the merged word into this step's [loss, status] pair (see __init__)
+                _lib.check(_lib.load().astk_persist_status_snapshot(C.c_void_p(self.status_dest.data_ptr()), stream))
+        elif self.status_sum is not None and self.status_dest is not None:
+            # CPU (gloo tests): the library's sticky word does not exist here; the same rule on the tensors themselves -- a non-zero SUM sets
+            # mask 16 ("reported by a peer rank") in the pair's status word, next to whatever this rank reported itself
+            if float(self.status_sum[0]) != 0.0:
+                self.status_dest[0] = float(int(self.status_dest[0]) | 16)
         if self.defer_scale:
             return 1.0 / world_size()
         self.arena.grad.mul_(1.0 / world_size())

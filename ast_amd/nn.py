@@ -175,7 +175,8 @@ class NN:
             for batch in self.data_loader.get_batch(self.cfg.train["batch_size"], set_key, train=True, labels=True):
                 with using_config("train", True):
                     loss = self.model.forward_loss(X=batch["X"], y=batch["y"], teach_ratio=ex["teach_ratio"],
-                                                   random_out=ex["random_out"], add_noise=ex["speech_noise"])
+                                                   random_out=ex["random_out"], add_noise=ex["speech_noise"],
+                                                   y_global=batch.get("y_global"))
                     self.model.cleargrads()
                     loss.backward()
                     self.optimizer.update()

@@ -655,7 +655,10 @@ class SpeechEncoderDecoder:
         dst.copy_(buf[:len(flags)], non_blocking=True)
         ev.record(torch.cuda.current_stream(self.device))
 
-    def forward_loss(self, X, y, teach_ratio, random_out=0, add_noise=0):
+    def forward_loss(self, X, y, teach_ratio, random_out=0, add_noise=0, y_global=None):
+        """seq2seq.py:399-473.  y_global (data parallelism with random_out > 0 only): the targets of the WHOLE unsharded batch as a host
+        array, global row b * world + r = row b of rank r -- the loader has them before it shards (`batch["y_global"]`); without it the
+        ranks' targets are all-gathered, a host-blocking collective in front of every step."""
         lib = self._require_gpu()
         X = self._as_input(X)
         if isinstance(y, np.ndarray):
@@ -684,7 +687,13 @@ class SpeechEncoderDecoder:
         elif random_out:
             yh = (y_host if y_host is not None else y.cpu()).numpy()
             randint = self.inject.get("randint", np.random.randint)      # the reference's draw is the unseeded global xp RNG (quirk Q7)
-            flags, tg = draw_flags_and_targets(yh, teach_ratio, random_out, self.V, randint)
+            gather = None
+            if y_global is not None:
+                from . import dist as adist
+                yg, w_ = np.asarray(y_global), adist.world_size()
+                if w_ > 1 and yg.shape == (yh.shape[0] * w_, yh.shape[1]):
+                    gather = lambda a: [yg[r::w_] for r in range(w_)]          # noqa: E731  (no collective: every rank holds the same global rows)
+            flags, tg = draw_flags_and_targets(yh, teach_ratio, random_out, self.V, randint, gather=gather)
             targets = torch.from_numpy(np.ascontiguousarray(tg, dtype=np.int32)).to(self.device)
         else:
             flags = [int(random.random() < teach_ratio) if 0 < i < L - 2 else 1 for i in range(S)]
@@ -769,6 +778,10 @@ class SpeechEncoderDecoder:
         if self.grad_buckets is not None:
             self.grad_buckets.launch("cnn")
         check(lib.astk_persist_status_snapshot(C.c_void_p(st["loss"].data_ptr() + 4), s))
+        if self.grad_buckets is not None:
+            # ... and once more behind the gradient exchange, when the peers' words have been merged (GradBuckets.finish): every rank's
+            # pair of THIS step then carries the merged word
+            self.grad_buckets.status_dest = st["loss"][1:2]
 
     # ------------------------------------------------------------------ inference (seq2seq.py:361-396, 475-568)
     def decode_step(self, word, ht):

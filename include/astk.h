@@ -17,7 +17,8 @@
  * into three bf16 terms that represent it EXACTLY (f32 exponent range), six term products per useful product, each product exact to
  * 2^-26 -- at least as accurate as an f32 fma chain on any data.  ASTK_PREC_F32 selects the literal f32-input MFMA chain,
  * ASTK_PREC_FP16X2 a faster, NARROWER two-term fp16 split (22 bits, limited exponent range; opt-in, never the default).  Decoder loop,
- * attention, softmax-CE and optimizer are IEEE f32 in every mode; the encoder recurrences follow the mode (f32 MFMAs unless fp16x2).
+ * attention, softmax-CE and optimizer are IEEE f32 in every mode; the encoder recurrences follow the mode (bf16x3: weight fragments and
+ * every step's activations as exact three-term bf16 splits on v_mfma_f32_16x16x32_bf16; fp16x2: two scaled fp16 terms; f32: f32-input MFMAs).
  * The arithmetic is chosen per call by the descriptors' `precision` field (ASTK_PREC_DEFAULT = the process-wide default).
  */
 #ifndef ASTK_H

@@ -63,13 +63,14 @@ l = one_step()
 assert float(l.data) > 0 and float(m.grad_buckets.status_sum[0]) == 0.0            # healthy: the tail rides along and sums to zero
 before = m.arena.data.clone()
 m.grad_buckets.status_fn = lambda tail: tail.fill_(4.0)                            # "a peer's decoder forward timed out"
-l = one_step()                                                                      # the snapshot next to THIS loss was taken before the exchange
+l = one_step()                                                                      # round 5: the MERGED word is written into THIS step's [loss, status] pair
 torch.cuda.synchronize()
 assert float(m.grad_buckets.status_sum[0]) == 4.0
 assert torch.equal(before, m.arena.data), "the update of the aborted step was applied"
+assert int(l.pair[1].item()) & 16, "the merged status word did not reach the pair of the step it belongs to"
 m.grad_buckets.status_fn = adist._library_status
 try:
-    float(one_step().data)                                                          # the next read-back sees the merged sticky word
+    float(l.data)                                                                   # the read-back of the aborted step itself raises (on every rank alike)
     raise SystemExit("no AstkError after a peer's abort")
 except _lib.AstkError as e:
     assert "peer rank" in str(e), str(e)

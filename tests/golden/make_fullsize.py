@@ -21,6 +21,15 @@ Cases (BASELINE.json configs):
   cfg5_wide configs[4] read as 1024 units per direction (hidden_units = attn_units = 2048) at B=20, T=96, L=12
   asr_gpfr  configs[3]'s shape: same model JSON (experiments/asr_gpfr/model_cfg.json has no n_attn/feed_attn keys:
             defaults equal), 13-d features, 3 dec layers, V=1004, L=60, batch 8, T=800
+  cfg1_m, cfg1_b64_m, asr_gpfr_m (round 5)  the same three shapes with the output layer's weight times 8 (`out_scale`): the fed-back
+            argmax of the unscaled cases wins by only 1.6-1.8e-4 (one notch above the 1e-4 the fixture test demands: any re-ordering
+            of a float32 reduction could flip it, and the failure would read as a 1e-2 loss error); scaling the logits keeps every
+            argmax and widens the margins to >= 1.2e-3, so the gate tests arithmetic, not luck.  The unscaled cases stay as second cases.
+Near-kink units (round 5, cases below 4000 frames per batch: cfg5, cfg5_wide): a Conv+BN unit whose float64 pre-activation lies within
+KINK = 1e-5 of zero can come out on the other side of the ReLU in a float32 evaluation, and in these small batches ONE such unit is
+1e-3 of a BatchNorm gradient's maximum.  The fixture NAMES those units (`kink_units`: layer, row (b, f, t), channel, pre-activation) and
+holds a second set of Conv+BN gradients computed with the upstream gradient of exactly those units dropped (`grads_kink_killed`); the GPU
+test drops the same units through astk_conv_debug_kill_units (libastk_test.so) and holds every tensor to the common 1e-3.
 Dropout / speech noise are 0 (quirk Q7: the reference's masks are unseeded; the masked variants are compared at small
 sizes with injected masks), teach_ratio 0.8 with the seeded flag stream.
 """
@@ -65,7 +74,25 @@ CASES = {
     # round 4: the OTHER reading of configs[4] -- 1024 units per direction (hidden_units 2048: `bench.py --model cfg5 --hidden 2048`), the
     # hoisted form of the persistent encoder kernels (one launch per layer); 20 batch rows = a full and a ragged batch tile
     "cfg5_wide": dict(cfg=model_cfg(1, 8004, enc_layers=6, hidden=2048), B=20, T=96, D=80, L=12, V=8004, seed=0, data_seed=20),
+    # round 5: fed-back argmax margins >= 1e-3 (module docstring)
+    "cfg1_m": dict(cfg=model_cfg(1, 1098), B=32, T=800, D=80, L=40, V=1098, seed=0, data_seed=20, out_scale=8.0),
+    "cfg1_b64_m": dict(cfg=model_cfg(1, 1098), B=64, T=800, D=80, L=40, V=1098, seed=0, data_seed=20, out_scale=8.0),
+    "asr_gpfr_m": dict(cfg=model_cfg(3, 1004, explicit_attn_keys=False), B=8, T=800, D=13, L=60, V=1004, seed=0, data_seed=20, out_scale=8.0),
 }
+KINK = 1e-5          # |float64 pre-activation| below which a Conv+BN unit is named in the fixture (pre-activations are O(1): BatchNorm output)
+
+
+class _KillGrad(F.Function):
+    """identity whose backward drops the gradient of the masked entries (astk_conv_debug_kill_units on the oracle side)"""
+
+    def __init__(self, keep):
+        self.keep = keep
+
+    def forward(self, xs):
+        return xs[0]
+
+    def backward(self, gys):
+        return gys[0] * self.keep
 
 
 def sample_index(name, shape, n=N_SAMPLES):
@@ -78,8 +105,12 @@ def sample_index(name, shape, n=N_SAMPLES):
 def run_case(name, c):
     cfg, B, T, D, L, V = c["cfg"], c["B"], c["T"], c["D"], c["L"], c["V"]
     P32 = R.init_params(cfg, D, V, seed=c["seed"], dtype=np.float32)
+    if c.get("out_scale"):
+        P32["out/W"] = (P32["out/W"] * np.float32(c["out_scale"])).astype(np.float32)
     X32, y = R.synth_batch(B, T, D, L, V, seed=c["data_seed"], dtype=np.float32)
     out = {"B": B, "T": T, "D": D, "L": L, "V": V, "seed": c["seed"], "data_seed": c["data_seed"], "cfg": cfg, "teach_ratio": 0.8}
+    if c.get("out_scale"):
+        out["out_scale"] = c["out_scale"]
     res = {}
     for dt in (np.float64, np.float32):
         t0 = time.time()
@@ -105,6 +136,8 @@ def run_case(name, c):
                        enc=m.enc_states.data.astype(np.float64), margins=margins, secs=time.time() - t0)
         print(f"[{name}] {dt.__name__}: loss {res[dt]['loss']:.10f} clip-norm {res[dt]['gnorm']:.10f} in {res[dt]['secs']:.0f} s", flush=True)
     r = res[np.float64]
+    if B * T < 4000:
+        out.update(kink_pass(cfg, P32, X32, y, V))
     flags = r["flags"]
     # margins of the steps whose argmax is actually fed back: step i+1 uses the argmax of step i iff flags[i+1] == 0
     fed = [r["margins"][i] for i in range(len(flags) - 1) if not flags[i + 1]]
@@ -124,6 +157,52 @@ def run_case(name, c):
                            "f32_oracle_norm_relerr": float(abs(np.sqrt((g32 ** 2).sum()) - np.sqrt((g ** 2).sum())) / max(np.sqrt((g ** 2).sum()), 1e-300)),
                            "f32_oracle_entry_err_over_absmax": float(np.abs(g32 - g).max() / max(np.abs(g).max(), 1e-300))}
     return out
+
+
+def kink_pass(cfg, P32, X32, y, V):
+    """Two more float64 evaluations: one that records the Conv+BN pre-activations (what the CNN's ReLUs see) and names the units within
+    KINK of zero, one whose backward drops the upstream gradient of exactly those units."""
+    orig_relu = R.F.relu
+    seen = []
+
+    def spy(x):
+        if x.data.ndim == 4:
+            seen.append(np.asarray(x.data, dtype=np.float64))
+        return orig_relu(x)
+
+    def run(relu_fn):
+        m = R.RefModel(copy.deepcopy(cfg), {k: v.astype(np.float64) for k, v in P32.items()}, V)
+        R.F.relu = relu_fn
+        try:
+            loss = m.forward_loss(X32.astype(np.float64), y, 0.8, pyrandom=random.Random("seed-ast-20h"))
+        finally:
+            R.F.relu = orig_relu
+        m.cleargrads()
+        loss.backward()
+        return {k: p.grad.astype(np.float64).copy() for k, p in m.params() if k.startswith("CNN_")}
+
+    run(spy)
+    units, keeps = [], []
+    for layer, z in enumerate(seen):            # (B, C, T', F') -> row (b, f, t), channel c: the layout astk_conv_debug_preact / _kill_units use
+        Bz, Cz, Tz, Fz = z.shape
+        keep = np.ones_like(z)
+        for b, c_, t, f in zip(*np.nonzero(np.abs(z) < KINK)):
+            units.append([layer, int((b * Fz + f) * Tz + t), int(c_), float(z[b, c_, t, f])])
+            keep[b, c_, t, f] = 0.0
+        keeps.append(keep)
+    it = iter(keeps)
+
+    def killing(x):
+        if x.data.ndim == 4:
+            return _KillGrad(next(it))(orig_relu(x))
+        return orig_relu(x)
+    gk = run(killing)
+    print(f"  {len(units)} near-kink units: {units}", flush=True)
+    killed = {}
+    for k, g in gk.items():
+        idx = sample_index(k, g.shape)
+        killed[k] = {"norm": float(np.sqrt((g ** 2).sum())), "absmax": float(np.abs(g).max()), "index": idx.tolist(), "value": g.ravel()[idx].tolist()}
+    return {"kink_eps": KINK, "kink_units": units, "grads_kink_killed": killed}
 
 
 def main():

@@ -154,6 +154,64 @@ def test_abort_word_reaches_every_rank_through_the_gradient_all_reduce():
     assert [p.exitcode for p in procs] == [1, 1], [p.exitcode for p in procs]
 
 
+def _pipelined_abort_worker(rank, world, port, q):
+    """NN.train_epoch's loop shape: the [loss, status] pair of step N is read back AFTER step N+1 has been enqueued.  Rank 1 reports a
+    time-out in step 2.  The merged word must land in the pair of step 2 on BOTH ranks (GradBuckets.status_dest), so that both raise at
+    the read-back of step 2 with the same collectives enqueued (steps 0..3) -- nobody is left waiting in the all-reduce of step 4."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from ast_amd import dist as adist
+    from ast_amd.dist import GradBuckets
+    from ast_amd.params import ParamArena
+    from ast_amd.seq2seq import raise_if_aborted
+    from ast_amd._lib import AstkError
+    adist.init("gloo")
+    shapes = {"CNN_0/W": (3, 1, 2, 2), "L0_enc/upward/W": (8, 5), "attn_Wa/W": (4, 4), "out/b": (7,)}
+    arena = ParamArena(shapes, torch.device("cpu"))
+    groups = {"cnn": ["CNN_0/W"], "enc": ["L0_enc/upward/W"], "dec": ["attn_Wa/W", "out/b"]}
+    status = {"v": 0.0}
+    gb = GradBuckets(arena, groups, defer_scale=True, status_fn=lambda tail: tail.fill_(status["v"]))
+    pending, enqueued, raised_at = None, 0, None
+    try:
+        for step in range(7):
+            status["v"] = 4.0 if (rank == 1 and step == 2) else 0.0          # rank 1's decoder forward times out in step 2
+            pair = torch.tensor([float(step + 1), status["v"]])              # the pair's own snapshot, taken before the exchange
+            gb.status_dest = pair[1:2]                                       # (what SpeechEncoderDecoder._backward sets)
+            arena.grad.fill_(1.0)
+            gb.launch("dec"); gb.launch("enc")
+            gb.finish()                                                      # optimizer.update(): the step's last collective + the merge
+            enqueued += 1
+            cur = (pair.clone(), step)
+            if pending is not None:
+                raised_at = pending[1]
+                raise_if_aborted(pending[0].tolist()[1], "gloo pipeline test")
+                raised_at = None
+            pending = cur
+    except AstkError:
+        q.put((rank, enqueued, raised_at))
+        td.destroy_process_group()
+        return
+    q.put((rank, enqueued, None))
+    td.destroy_process_group()
+
+
+def test_pipelined_loss_readback_raises_on_every_rank_at_the_same_step():
+    """with the loss of step N read back after step N+1 has been enqueued, the merged abort word has to be in
+    the pair of step N on every rank; otherwise the failing rank stops one step before the healthy ones, which then wait in an
+    all-reduce nobody joins."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_pipelined_abort_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, 4, 2), (1, 4, 2)], res          # both ranks: raised at the read-back of step 2, with steps 0..3 enqueued
+
+
 def _random_out_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))

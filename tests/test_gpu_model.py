@@ -686,6 +686,34 @@ def test_full_size_batch_permutation_and_gradient_accumulation(model, B, T, D, o
         hooks.__exit__(None, None, None)
 
 
+def test_cnn_backward_refuses_a_workspace_whose_forward_took_the_other_layer0_path():
+    """the layer-0 path (direct convolution + window-matrix weight gradient under the default arithmetic, im2col + GEMM
+    otherwise) is re-derived at every call from the arithmetic in force then.  With the descriptor at ASTK_PREC_DEFAULT a change of the
+    PROCESS default between forward and backward would make the backward read a window matrix that was never written: it must refuse."""
+    from ast_amd import _lib
+    from ast_amd.seq2seq import using_config
+    lib = _lib.load()
+    cfg = tiny_cfg(enc_layers=1, dec_layers=1, H=16, E=8, A=16, c0=16, c1=8, V=23, drop=0.0)
+    B, T, D, L, V = 2, 48, 80, 5, 23
+    P, X, y = _make(cfg, B, T, D, L, V)
+    m = _gpu_model(cfg, P, D, V)
+    assert m.gemm_precision is None and lib.astk_get_gemm_precision() == 1          # descriptors say DEFAULT, the default is bf16x3
+    with using_config("train", True):
+        loss = m.forward_loss(torch.from_numpy(X), torch.from_numpy(y), 1.0)
+        m.cleargrads()
+        prev = lib.astk_set_gemm_precision(2)                                       # the process default moves to the f32 chain ...
+        try:
+            with pytest.raises(_lib.AstkError, match="layer-0 path"):               # ... and the backward call says so instead of reading stale workspace
+                loss.backward()
+        finally:
+            lib.astk_set_gemm_precision(prev)
+            torch.cuda.synchronize()
+        loss = m.forward_loss(torch.from_numpy(X), torch.from_numpy(y), 1.0)        # same default on both sides: fine
+        m.cleargrads()
+        loss.backward()
+    assert np.isfinite(float(loss.data))
+
+
 @pytest.mark.parametrize("dec_layers", [1, 2])     # persistent decoder loop / per-launch decoder loop
 def test_overlapped_backward_equals_inline_backward(dec_layers):
     """With overlap_param_grads (opt-in) and a stream of its own the model runs the decoder's parameter gradients on a CU-masked side stream beside the encoder's

@@ -378,14 +378,22 @@ def test_bridge_states_matches_the_strided_copies(lib, nd, nl_enc, n, B, h):
     assert lib.astk_bridge_states(vp(g_c), vp(g_h), vp(e_c), vp(e_h), nd, nl_enc, nl_enc + 1, B, h, 0, stream()) != 0      # more layers than the encoder has
 
 
-def test_encoder_backward_last_arrival_waits_for_the_slowest_peer(lib, monkeypatch):
+def test_encoder_backward_last_arrival_waits_for_the_slowest_peer(monkeypatch):
     """Regression test of a hand-off race in lstm_persist_bwd_rs (round 4).  The layer below waits for `count >= NS * k` arrivals on the
     down-partials counter, which means "every slice has published k steps" only while the slices are at most one arrival apart; a slice's
     LAST arrival needs nothing from its peers, so a workgroup that finished early could make it while a slow peer was two arrivals behind,
     and a consumer then read the slow peer's tile of step 1 before it was written -- getting the PREVIOUS launch's tile.  ASTK_PERSIST_DBG=16
     makes slice 0 of every cell with a layer below dawdle exactly there; two different inputs alternate, so a stale tile is a wrong tile.
-    The bias gradients are summed inside the kernel in a fixed order (two commutative atomic adds per element): bit-identical or broken."""
+    The bias gradients are summed inside the kernel in a fixed order (two commutative atomic adds per element): bit-identical or broken.
+    The dawdle is a TEST HOOK: it exists in libastk_test.so only (round 5; the product library's kernels never read ASTK_PERSIST_DBG --
+    tests/test_host.py checks that), so the whole test runs on the instrumented build of the same kernel."""
+    from ast_amd import _lib as L_
     from ast_amd._lib import LstmGrads, LstmParams, LstmStackDesc
+    with L_.load_test_hooks() as lib:
+        _last_arrival_body(lib, monkeypatch, LstmGrads, LstmParams, LstmStackDesc)
+
+
+def _last_arrival_body(lib, monkeypatch, LstmGrads, LstmParams, LstmStackDesc):
     T, B, in_dim, h, nl = 200, 32, 64, 256, 3           # (T * B = 6400 rows: the batched products take their deterministic two-contributor tiles)
     rng = np.random.default_rng(11)
     names, prm, grd = [], {}, {}

@@ -44,6 +44,10 @@ def test_library_exports_every_declared_symbol():
         assert _lib.load() is tlib
     assert _lib.load() is lib
     assert lib.astk_version() >= 100
+    # in-kernel instrumentation of the persistent kernels (phase timers, the dawdling slice of the last-arrival regression test) is read
+    # from ASTK_PERSIST_DBG by the TEST-HOOK build only: the product library does not even contain the variable's name
+    assert b"ASTK_PERSIST_DBG" not in open(_lib.LIB_PATH, "rb").read()
+    assert b"ASTK_PERSIST_DBG" in open(_lib.TEST_LIB_PATH, "rb").read()
 
 
 def test_parameter_counts_match_the_reference_model():
