@@ -54,6 +54,14 @@ class LstmGrads(C.Structure):
     _fields_ = [("dWu", C.c_void_p), ("db", C.c_void_p), ("dWl", C.c_void_p)]
 
 
+class RandSeg(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("n", C.c_size_t), ("kind", C.c_int), ("a", C.c_float), ("b", C.c_float),
+                ("seed", C.c_uint64), ("offset", C.c_uint64)]
+
+
+RAND_DROPOUT, RAND_NORMAL, RAND_SEG_MAX = 0, 1, 8
+
+
 class DecoderDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("L", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int),
                 ("A", C.c_int), ("V", C.c_int), ("n_layers", C.c_int),
@@ -135,6 +143,7 @@ SIGNATURES = {
     "astk_decay_clip_noise": (C.c_int, [_VP, _VP, _SZ, _F, _F, _F, _VP, _F, _U64, _U64, _VP]),
     "astk_fill_dropout_mask": (C.c_int, [_VP, _SZ, _F, _U64, _U64, _VP]),
     "astk_fill_normal": (C.c_int, [_VP, _SZ, _F, _F, _U64, _U64, _VP]),
+    "astk_fill_random": (C.c_int, [C.POINTER(RandSeg), _I, _VP]),
     "astk_scale_f32": (C.c_int, [_VP, _SZ, _F, _VP]),
     "astk_add_f32": (C.c_int, [_VP, _VP, _SZ, _VP]),
     "astk_bridge_states": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),

@@ -242,6 +242,35 @@ __global__ void k_normal(float* out, size_t n, float mean, float sigma, uint64_t
   }
 }
 
+// Several independent fills of the two kinds above in ONE launch (the step's speech noise and its dropout masks: four launches of ~5-20 us
+// before).  Blocks are dealt to the segments in proportion to their sizes; every element gets exactly the value the single-segment kernels
+// give it (same counter), so fused and separate draws are interchangeable.
+struct RandJobs { int n; int blk_start[ASTK_RAND_SEG_MAX + 1]; astk_rand_seg s[ASTK_RAND_SEG_MAX]; };
+__global__ __launch_bounds__(256) void k_fill_random(RandJobs j) {
+  int q = 0;
+  while ((int)blockIdx.x >= j.blk_start[q + 1]) ++q;
+  const astk_rand_seg sg = j.s[q];
+  const size_t nblk = (size_t)(j.blk_start[q + 1] - j.blk_start[q]), blk = blockIdx.x - j.blk_start[q];
+  if (sg.kind == ASTK_RAND_DROPOUT) {
+    const float scale = 1.f / (1.f - sg.a);
+    for (size_t i = blk * 256 + threadIdx.x; i < sg.n; i += nblk * 256) {
+      const float u = u01(mix64(sg.seed ^ mix64(sg.offset + i)));
+      sg.out[i] = u >= sg.a ? scale : 0.f;
+    }
+  } else {
+    const size_t pairs = (sg.n + 1) / 2;
+    for (size_t i = blk * 256 + threadIdx.x; i < pairs; i += nblk * 256) {
+      const uint64_t b = mix64(sg.seed ^ mix64(sg.offset + i));
+      const float u1 = u01(b), u2 = u01(mix64(b));
+      const float r = sqrtf(-2.f * logf(u1));
+      float sn, cs;
+      sincosf(6.2831853071795864f * u2, &sn, &cs);
+      sg.out[2 * i] = sg.a + sg.b * r * cs;
+      if (2 * i + 1 < sg.n) sg.out[2 * i + 1] = sg.a + sg.b * r * sn;
+    }
+  }
+}
+
 // dataloader.py:83-93 on the device: utterance b (true length len[b] <= T frames, zero-padded behind) gets int(rate * len[b]) of its
 // frames zeroed; the frames are drawn WITH replacement (np.random.choice's default), so fewer distinct frames may be hit.
 // (the count is int(drop_rate * len(x_data)) in double precision, exactly as Python evaluates it)
@@ -550,6 +579,27 @@ int astk_fill_dropout_mask(float* out, size_t n, float ratio, uint64_t seed, uin
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_dropout_mask, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, n, ratio, 1.f / (1.f - ratio),
                      seed, offset);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+
+int astk_fill_random(const astk_rand_seg* segs, int n_segs, void* stream) {
+  ASTK_CHECK(segs && n_segs >= 0 && n_segs <= ASTK_RAND_SEG_MAX, "fill_random: %d segments (max %d)", n_segs, ASTK_RAND_SEG_MAX);
+  RandJobs j;
+  memset(&j, 0, sizeof(j));
+  for (int i = 0; i < n_segs; ++i) {
+    const astk_rand_seg& g = segs[i];
+    if (g.n == 0) continue;
+    ASTK_CHECK(g.out && (g.kind == ASTK_RAND_NORMAL || (g.kind == ASTK_RAND_DROPOUT && g.a >= 0.f && g.a < 1.f)), "fill_random: bad segment %d", i);
+    const size_t work = g.kind == ASTK_RAND_NORMAL ? (g.n + 1) / 2 : g.n;
+    const int blocks = (int)std::min<size_t>(2048, std::max<size_t>(1, (work + 2047) / 2048));      // ~8 elements per thread, bounded
+    j.s[j.n] = g;
+    j.blk_start[j.n + 1] = j.blk_start[j.n] + blocks;
+    ++j.n;
+  }
+  if (j.n == 0) return 0;
+  for (int i = j.n; i < ASTK_RAND_SEG_MAX; ++i) j.blk_start[i + 1] = j.blk_start[j.n];
+  hipLaunchKernelGGL(k_fill_random, dim3((unsigned)j.blk_start[j.n]), dim3(256), 0, (hipStream_t)stream, j);
   ASTK_LAUNCH_CHECK();
   return 0;
 }

@@ -232,6 +232,7 @@ class SpeechEncoderDecoder:
         self.inject = {}          # test hooks: enc_masks / emb_mask / rnn_masks / noise / use_truth
         self.rng_seed = 0x5EED
         self._rng_offset = 0
+        self._predrawn = {}             # random tensors of the current train step drawn ahead in one launch (_predraw)
         self.bn_N = 0                   # training-mode forward passes so far = Chainer's BatchNormalization persistent N (A10)
         self.enc_states = None
         self.loss = 0
@@ -485,10 +486,42 @@ class SpeechEncoderDecoder:
             return None if m is None else m.to(self.device, torch.float32).contiguous()
         if not config.train or ratio <= 0:
             return None
+        pre = self._predrawn.pop(name, None)
+        if pre is not None and tuple(pre.shape) == tuple(shape):
+            return pre
         t = self._pool("mask_" + name, shape)
         lib = _lib.load()
         check(lib.astk_fill_dropout_mask(_vp(t), t.numel(), float(ratio), self.rng_seed, self._rng(t.numel()), self._stream()))
         return t
+
+    def _predraw(self, X_shape, add_noise, st, L):
+        """All random tensors of a train step -- the speech noise and the four kinds of dropout masks -- in ONE launch (astk_fill_random)
+        instead of up to five; the (seed, offset) counters are consumed in the order the separate draws used, so every value is the one
+        they would have produced.  Injected tensors (parity tests) are left alone, as before."""
+        self._predrawn = {}
+        if not config.train:
+            return
+        dr = self.cfg["dropout"]
+        B, S = X_shape[0], L - 1
+        want = []
+        if add_noise > 0 and "noise" not in self.inject:
+            want.append(("noise", tuple(X_shape), _lib.RAND_NORMAL, 1.0, float(add_noise), self.rng_seed ^ 0xABCDEF))
+        masks = [("enc_masks", (self.n_dirs, len(self.rnn_enc), st["T2"], B, self.h), dr["rnn"])]
+        if L >= 2 and self._cur.get("pending_L"):
+            masks += [("emb_mask", (S, B, self.E), dr["embed"]), ("rnn_masks", (len(self.rnn_dec), S, B, self.H), dr["rnn"]),
+                      ("out_mask", (S, B, self.V), dr.get("out", 0))]
+        for name, shape, ratio in masks:
+            if name not in self.inject and ratio and ratio > 0:
+                want.append((name, shape, _lib.RAND_DROPOUT, float(ratio), 0.0, self.rng_seed))
+        if len(want) < 2 or len(want) > _lib.RAND_SEG_MAX:
+            return                                    # (a single draw keeps its own launch)
+        segs = (_lib.RandSeg * len(want))()
+        for i, (name, shape, kind, a, b, seed) in enumerate(want):
+            t = self._pool("noise" if name == "noise" else "mask_" + name, shape)
+            segs[i].out, segs[i].n, segs[i].kind, segs[i].a, segs[i].b = t.data_ptr(), t.numel(), kind, a, b
+            segs[i].seed, segs[i].offset = seed & 0xFFFFFFFFFFFFFFFF, self._rng(t.numel())
+            self._predrawn[name] = t
+        check(_lib.load().astk_fill_random(segs, len(want), self._stream()))
 
     # ------------------------------------------------------------------ encoder (seq2seq.py:293-314)
     def _as_input(self, X):
@@ -507,9 +540,12 @@ class SpeechEncoderDecoder:
         self._cur = st
         st["X"] = X
         noise = None
+        self._predraw(tuple(X.shape), add_noise, st, L)
         if add_noise > 0 and config.train:
             if "noise" in self.inject:
                 noise = self.inject["noise"].to(self.device, torch.float32).contiguous()
+            elif "noise" in self._predrawn:
+                noise = self._predrawn.pop("noise")
             else:
                 noise = self._pool("noise", tuple(X.shape))
                 check(lib.astk_fill_normal(_vp(noise), noise.numel(), 1.0, float(add_noise), self.rng_seed ^ 0xABCDEF,

@@ -379,6 +379,20 @@ int astk_decay_clip_noise(float* g, const float* p, size_t n, float grad_scale, 
                           uint64_t seed, uint64_t offset, void* stream);
 /* out[i] = 1 + sigma*N(0,1): the multiplicative speech noise of seq2seq.py:300-302, generated on device. */
 int astk_fill_normal(float* out, size_t n, float mean, float sigma, uint64_t seed, uint64_t offset, void* stream);
+/* Several fills of those two kinds in ONE launch (a train step's speech noise and dropout masks): every element gets exactly the value
+ * astk_fill_normal / astk_fill_dropout_mask give it for the same (seed, offset).  kind ASTK_RAND_DROPOUT: a = ratio; ASTK_RAND_NORMAL:
+ * a = mean, b = sigma.  Replaces the host-side np.random.normal of seq2seq.py:300 and Chainer's per-call F.dropout masks (A5). */
+#define ASTK_RAND_SEG_MAX 8
+#define ASTK_RAND_DROPOUT 0
+#define ASTK_RAND_NORMAL 1
+typedef struct {
+  float* out;
+  size_t n;
+  int kind;
+  float a, b;
+  uint64_t seed, offset;
+} astk_rand_seg;
+int astk_fill_random(const astk_rand_seg* segs, int n_segs, void* stream);
 int astk_scale_f32(float* x, size_t n, float s, void* stream);
 /* dst += src (n floats); dst[c] += sum_r src[r*lds + c] (bias gradients; the sum over time of the linear_proj encoder's reverse-stack
  * input gradient, whose input is one frame fed at every step). */

@@ -778,6 +778,30 @@ def test_rng_fills(lib):
     assert abs(float(z.mean()) - 1.0) < 2e-3 and abs(float(z.std()) - 0.25) < 2e-3
 
 
+def test_fused_random_fill_equals_the_separate_fills(lib):
+    """astk_fill_random (the step's speech noise and dropout masks in one launch) gives every element exactly the value astk_fill_normal /
+    astk_fill_dropout_mask give it for the same (seed, offset): bit-identical, ragged sizes, an odd-length normal segment, an empty one."""
+    from ast_amd._lib import RandSeg, RAND_DROPOUT, RAND_NORMAL
+    spec = [(RAND_NORMAL, 2048001, 1.0, 0.25, 0xABCDEF ^ 0x5EED, 0), (RAND_DROPOUT, 3 * 200 * 32 * 256 + 5, 0.3, 0.0, 0x5EED, 2048001),
+            (RAND_DROPOUT, 39 * 32 * 128, 0.3, 0.0, 0x5EED, 7000000), (RAND_NORMAL, 0, 0.0, 1.0, 1, 0), (RAND_DROPOUT, 17, 0.5, 0.0, 9, 3)]
+    segs = (RandSeg * len(spec))()
+    fused, ref = [], []
+    for i, (kind, n, a, b, seed, off) in enumerate(spec):
+        t = torch.full((max(n, 1),), 7.0, device="cuda")
+        fused.append(t)
+        segs[i].out, segs[i].n, segs[i].kind, segs[i].a, segs[i].b, segs[i].seed, segs[i].offset = t.data_ptr(), n, kind, a, b, seed, off
+        r = torch.full((max(n, 1),), 7.0, device="cuda")
+        if kind == RAND_NORMAL:
+            ok(lib, lib.astk_fill_normal(vp(r), n, a, b, seed, off, stream()))
+        else:
+            ok(lib, lib.astk_fill_dropout_mask(vp(r), n, a, seed, off, stream()))
+        ref.append(r)
+    ok(lib, lib.astk_fill_random(segs, len(spec), stream()))
+    torch.cuda.synchronize()
+    for f, r in zip(fused, ref):
+        assert torch.equal(f, r)
+
+
 def test_gemm_random_shapes_against_float64(lib, gemm_split):
     """Seeded sweep over layouts, ragged extents, leading-dimension padding (poisoned with NaN), batches and output modes."""
     rng = np.random.default_rng(2026)
