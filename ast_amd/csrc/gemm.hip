@@ -1093,7 +1093,11 @@ __device__ unsigned long long g_amax_ring[AMAX_SLOTS];
 // GEMM_STORE + split tiles: zero the tiles that more than one workgroup will accumulate into.  Block b looks at the
 // boundary between workgroups b and b+1.
 // (16-byte stores when every problem's C rows are 16-byte aligned -- `vec`, decided by the launcher -- else scalar)
-__device__ __forceinline__ void zero_split_block(const GemmGroup& grp, int G, int TLM, int TL, int vec, unsigned b) {
+// (round 5: a tile several boundaries fall into -- the remainder tiles of a hybrid launch are shared by G / tiles workgroups each -- is
+//  zeroed by the block of its FIRST boundary only, and ZERO_PARTS blocks share a tile's rows: 67 -> ~30 us per train step at 256 x 128 tiles)
+constexpr int ZERO_PARTS = 4;
+__device__ __forceinline__ void zero_split_block(const GemmGroup& grp, int G, int TLM, int TL, int vec, unsigned bb) {
+  const unsigned b = bb / ZERO_PARTS, part = bb % ZERO_PARTS;
   const long git = wg_first_iter(grp, b + 1, G);
   int prob = 0;
   while (git >= grp.iter_start[prob + 1]) ++prob;
@@ -1101,6 +1105,10 @@ __device__ __forceinline__ void zero_split_block(const GemmGroup& grp, int G, in
   if (g.mode != GEMM_STORE) return;
   const long it = git - grp.iter_start[prob];
   if (it % g.kt == 0) return;
+  if (b > 0) {      // the previous boundary inside the same tile: its block zeroes the tile
+    const long pit = wg_first_iter(grp, b, G) - grp.iter_start[prob];
+    if (pit >= 0 && pit / g.kt == it / g.kt && pit % g.kt != 0) return;
+  }
   const long tile = it / g.kt;
   int zb, m0, n0;
   decode_tile(g, tile, TLM, TL, zb, m0, n0);
@@ -1109,7 +1117,8 @@ __device__ __forceinline__ void zero_split_block(const GemmGroup& grp, int G, in
   const int tpr = TL / w;                        // threads per row
   const int col = n0 + (threadIdx.x % tpr) * w;
   if (col >= g.N) return;
-  for (int r = threadIdx.x / tpr; r < TLM; r += 256 / tpr) {
+  const int rows_part = TLM / ZERO_PARTS;
+  for (int r = part * rows_part + threadIdx.x / tpr; r < (int)(part + 1) * rows_part; r += 256 / tpr) {
     const int row = m0 + r;
     if (row >= g.M) break;
     const long coff = g.c_tn > 0 ? (long)(row / g.c_tn) * g.c_sg + (long)(row % g.c_tn) * g.c_st : (long)row * g.ldc;
@@ -1448,11 +1457,11 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
                 J.r[i].inner, 4e-6 * J.r[i].nb * J.r[i].rows * J.r[i].inner, J.blk_start[i + 1] - J.blk_start[i]);
     amax_blocks = J.n > 0 ? J.blk_start[J.n] : 0;
     if (amax_blocks > 0) {
-      if (need_zero) hipLaunchKernelGGL(k_absmax_zero, dim3((unsigned)(amax_blocks + G - 1)), dim3(256), 0, s, J, grp, (int)G, TLM, TL, zero_vec ? 1 : 0);
+      if (need_zero) hipLaunchKernelGGL(k_absmax_zero, dim3((unsigned)(amax_blocks + (G - 1) * ZERO_PARTS)), dim3(256), 0, s, J, grp, (int)G, TLM, TL, zero_vec ? 1 : 0);
       else hipLaunchKernelGGL(k_absmax, dim3((unsigned)amax_blocks), dim3(256), 0, s, J);
     }
   }
-  if (need_zero && amax_blocks == 0) hipLaunchKernelGGL(k_zero_split_tiles, dim3((unsigned)(G - 1)), dim3(256), 0, s, grp, (int)G, TLM, TL, zero_vec ? 1 : 0);
+  if (need_zero && amax_blocks == 0) hipLaunchKernelGGL(k_zero_split_tiles, dim3((unsigned)((G - 1) * ZERO_PARTS)), dim3(256), 0, s, grp, (int)G, TLM, TL, zero_vec ? 1 : 0);
 #define ASTK_GEMM_LAUNCH(T_, P_, M_)                                                                                              \
   switch (layout) {                                                                                                               \
     case GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<T_, true, true, false, P_, M_>), grid, dim3(gemm_threads(P_, M_)), 0, s, grp); break;  \

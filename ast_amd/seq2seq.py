@@ -494,7 +494,7 @@ class SpeechEncoderDecoder:
         check(lib.astk_fill_dropout_mask(_vp(t), t.numel(), float(ratio), self.rng_seed, self._rng(t.numel()), self._stream()))
         return t
 
-    def _predraw(self, X_shape, add_noise, st, L):
+    def _predraw(self, X_shape, add_noise, st, L, with_decoder):
         """All random tensors of a train step -- the speech noise and the four kinds of dropout masks -- in ONE launch (astk_fill_random)
         instead of up to five; the (seed, offset) counters are consumed in the order the separate draws used, so every value is the one
         they would have produced.  Injected tensors (parity tests) are left alone, as before."""
@@ -507,7 +507,7 @@ class SpeechEncoderDecoder:
         if add_noise > 0 and "noise" not in self.inject:
             want.append(("noise", tuple(X_shape), _lib.RAND_NORMAL, 1.0, float(add_noise), self.rng_seed ^ 0xABCDEF))
         masks = [("enc_masks", (self.n_dirs, len(self.rnn_enc), st["T2"], B, self.h), dr["rnn"])]
-        if L >= 2 and self._cur.get("pending_L"):
+        if with_decoder:
             masks += [("emb_mask", (S, B, self.E), dr["embed"]), ("rnn_masks", (len(self.rnn_dec), S, B, self.H), dr["rnn"]),
                       ("out_mask", (S, B, self.V), dr.get("out", 0))]
         for name, shape, ratio in masks:
@@ -535,12 +535,13 @@ class SpeechEncoderDecoder:
         lib = self._require_gpu()
         X = self._as_input(X)
         B, T, D = X.shape
-        L = self._cur["L"] if (self._cur and self._cur.get("pending_L")) else 2
+        in_forward_loss = bool(self._cur and self._cur.get("pending_L"))
+        L = self._cur["L"] if in_forward_loss else 2
         st = self._shape_state(B, T, D, L)
         self._cur = st
         st["X"] = X
         noise = None
-        self._predraw(tuple(X.shape), add_noise, st, L)
+        self._predraw(tuple(X.shape), add_noise, st, L, in_forward_loss)
         if add_noise > 0 and config.train:
             if "noise" in self.inject:
                 noise = self.inject["noise"].to(self.device, torch.float32).contiguous()
@@ -688,8 +689,27 @@ class SpeechEncoderDecoder:
         ring["i"] = (ring["i"] + 1) % len(ring["bufs"])
         ev.synchronize()                       # returns at once unless the host is 8 steps ahead
         buf[:len(flags)] = torch.tensor(flags, dtype=torch.int32)
-        dst.copy_(buf[:len(flags)], non_blocking=True)
-        ev.record(torch.cuda.current_stream(self.device))
+        # (round 5) The copy runs on a side stream BESIDE the CNN and the encoder of this step instead of between the encoder and the
+        # decoder on the compute stream (4.5 us of copy plus a 6 us gap around the switch to the copy engine, on the step's critical path):
+        # it waits for the last reader of the previous flags (event recorded behind the previous decoder forward / backward), and the
+        # compute stream waits for it in front of the decoder -- long done by then.
+        main = torch.cuda.current_stream(self.device)
+        side = self._ws.get("flag_stream")
+        if side is None:
+            side = self._ws["flag_stream"] = torch.cuda.Stream(device=self.device)
+            self._ws["flag_free"], self._ws["flag_done"] = torch.cuda.Event(), torch.cuda.Event()
+            self._ws["flag_free"].record(main)
+        side.wait_event(self._ws["flag_free"])
+        with torch.cuda.stream(side):
+            dst.copy_(buf[:len(flags)], non_blocking=True)
+            ev.record(side)
+            self._ws["flag_done"].record(side)
+        main.wait_event(self._ws["flag_done"])
+
+    def _flags_released(self):
+        """Called behind the last launch that reads the device copy of the teacher-forcing flags (decoder forward, decoder backward)."""
+        if "flag_free" in self._ws:
+            self._ws["flag_free"].record(torch.cuda.current_stream(self.device))
 
     def forward_loss(self, X, y, teach_ratio, random_out=0, add_noise=0, y_global=None):
         """seq2seq.py:399-473.  y_global (data parallelism with random_out > 0 only): the targets of the WHOLE unsharded batch as a host
@@ -748,6 +768,7 @@ class SpeechEncoderDecoder:
                                       _vp(y), _vp(st["flags"]), _vp(st["emb_mask"]), _vp(st["rnn_masks"]), _vp(st["out_mask"]), _vp(targets),
                                       _vp(st["loss"]), _vp(st["pred"]), _vp(wd), wd.numel(), self._stream()))
         check(lib.astk_persist_status_snapshot(C.c_void_p(st["loss"].data_ptr() + 4), self._stream()))
+        self._flags_released()
         self.loss = Loss(self, st["loss"])
         return self.loss
 
@@ -814,6 +835,7 @@ class SpeechEncoderDecoder:
         if self.grad_buckets is not None:
             self.grad_buckets.launch("cnn")
         check(lib.astk_persist_status_snapshot(C.c_void_p(st["loss"].data_ptr() + 4), s))
+        self._flags_released()
         if self.grad_buckets is not None:
             # ... and once more behind the gradient exchange, when the peers' words have been merged (GradBuckets.finish): every rank's
             # pair of THIS step then carries the merged word

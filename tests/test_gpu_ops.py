@@ -871,6 +871,41 @@ def test_gemm_hybrid_schedule_whole_tile_waves_and_stream_k_remainder(lib, layou
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
+def test_gemm_twelve_wave_256x128_kernel_on_a_big_ragged_product(lib, layout):
+    """Launches of 20 GFLOP and more run 256 x 128 tiles on the 12-wave kernel (8 multiplying + 4 staging waves, round 5) under the default
+    arithmetic: one such product per layout with ragged M (8200 = 32 tiles + 8 rows), N (1930) and K (1100), store / atomic modes, a bias,
+    against float64 at the tolerance of the seeded sweep."""
+    assert lib.astk_get_gemm_precision() == 1
+    M, N, K = 8200, 1930, 1100
+    assert 2.0 * M * N * K >= 2e10
+    rng = np.random.default_rng(500 + layout)
+    pad4 = lambda n: (n + 3) // 4 * 4
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    bias = rng.standard_normal(N)
+    ref = torch.from_numpy(A).double() @ torch.from_numpy(B).double().T
+    ref = ref.numpy()
+
+    def store(X, transpose):
+        X = X.T if transpose else X
+        P = np.full((X.shape[0], pad4(X.shape[1]) + 4), np.nan, np.float32)
+        P[:, :X.shape[1]] = X
+        return P
+    Ad, Bd = store(A, layout == 2), store(B, layout != 0)
+    a, b = dev(Ad), dev(Bd)
+    ldc = pad4(N) + 4
+    c = torch.full((M, ldc), 7.0, device="cuda")
+    ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(a), Ad.shape[1], vp(b), Bd.shape[1], vp(c), ldc, vp(dev(bias)), 0, 1, 1, 0, 0, 0, stream()))
+    close(c[:, :N], ref + bias, rtol=2e-5, msg="store")
+    assert float(c[:, N:].min()) == 7.0 and float(c[:, N:].max()) == 7.0, "wrote outside N"
+    c.zero_()
+    ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(a), Ad.shape[1], vp(b), Bd.shape[1], vp(c), ldc, None, 2, 1, 1, 0, 0, 0, stream()))
+    close(c[:, :N], ref, rtol=2e-5, msg="atomic")
+    ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(a), Ad.shape[1], vp(b), Bd.shape[1], vp(c), ldc, None, 1, 1, 1, 0, 0, 0, stream()))
+    close(c[:, :N], 2 * ref, rtol=2e-5, msg="accum")
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("sa,sb", [(1e-20, 1e15), (3e7, 2e-3), (1.0, 1e-30)])
 def test_gemm_operand_magnitudes(lib, layout, sa, sb, gemm_split):
     """The default GEMM splits every operand into two fp16 terms behind a per-operand power-of-two scale taken from an absolute-maximum
