@@ -22,6 +22,8 @@ struct DecPersistBuffers {
   float *G[PDEC_MAX_LAYERS], *C[PDEC_MAX_LAYERS], *HR[PDEC_MAX_LAYERS], *HD[PDEC_MAX_LAYERS];
   float *LSE, *PART, *CESTAT, *ENCA, *ML;
   unsigned* ctr;
+  // two small buffers the forward launcher zeroes with its own fill launch (HT of step -1 and the first concat row: decoder.hip)
+  void* zero_a; size_t zero_a_bytes; void* zero_b; size_t zero_b_bytes;
 };
 bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int* chunk_out);
 int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_params* prm, const float* enc, const int32_t* y,
@@ -503,11 +505,14 @@ int astk_decoder_fwd_ex(const astk_decoder_desc* d, const astk_decoder_params* p
       copy_seg_add(cp, P.HR[l], h0 + l * bh, bh * sizeof(float));
     }
     ASTK_TRY(copy_segments(cp, s));
-    FillSegs fz;
-    fz.n = 0;
-    fill_seg_add(fz, P.HT, (size_t)B * A * sizeof(float));
-    fill_seg_add(fz, P.X0, (size_t)B * XI * sizeof(float));   // ht_{-1} half of the first concat buffer
-    ASTK_TRY(fill_u32_segments(fz, 0u, s));
+    int ns_ = 1, ch_ = 1;
+    if (!(!out_mask && decoder_persist_applicable(d, &ns_, &ch_))) {      // (the persistent launcher zeroes them with its own fill: one launch less)
+      FillSegs fz;
+      fz.n = 0;
+      fill_seg_add(fz, P.HT, (size_t)B * A * sizeof(float));
+      fill_seg_add(fz, P.X0, (size_t)B * XI * sizeof(float));   // ht_{-1} half of the first concat buffer
+      ASTK_TRY(fill_u32_segments(fz, 0u, s));
+    }
   }
   const int top = nl - 1;
   {
@@ -523,6 +528,8 @@ int astk_decoder_fwd_ex(const astk_decoder_desc* d, const astk_decoder_params* p
       for (int l = 0; l < nl; ++l) { bf.G[l] = P.G[l]; bf.C[l] = P.C[l]; bf.HR[l] = P.HR[l]; bf.HD[l] = P.HD[l]; }
       bf.CVH = P.CVH; bf.HT = P.HT; bf.LOGITS = P.LOGITS; bf.LOSSROWS = P.LOSSROWS; bf.LSE = P.LSE; bf.PART = P.PART;
       bf.CESTAT = P.CESTAT; bf.ENCA = P.ENCA; bf.ML = P.MLB; bf.ctr = P.PCTR;
+      bf.zero_a = P.HT; bf.zero_a_bytes = (size_t)B * A * sizeof(float);
+      bf.zero_b = P.X0; bf.zero_b_bytes = (size_t)B * XI * sizeof(float);
       ASTK_TRY(decoder_persist_fwd_launch(d, prm, enc, y, tgt, use_truth, emb_mask, rnn_masks, bf, loss, pred, s));   // (incl. loss sum and predictions)
       return 0;
     }

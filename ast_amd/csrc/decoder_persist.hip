@@ -1633,6 +1633,8 @@ struct DecPersistBuffers {
   float *G[PDEC_MAX_LAYERS], *C[PDEC_MAX_LAYERS], *HR[PDEC_MAX_LAYERS], *HD[PDEC_MAX_LAYERS];
   float *LSE, *PART, *CESTAT, *ENCA, *ML;
   unsigned* ctr;
+  // two small buffers the forward launcher zeroes with its own fill launch (HT of step -1 and the first concat row: decoder.hip)
+  void* zero_a; size_t zero_a_bytes; void* zero_b; size_t zero_b_bytes;
 };
 
 static bool pdec_special(int H, int chunk) { return H == 512 && chunk <= PDEC_CHUNK_MAX; }     // the NC = 8 attention phase
@@ -1812,10 +1814,14 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
     f.n = 0;
     fill_seg_add(f, bf.ctr, ((size_t)NPHASE_SLOTS * NSH * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), 0u);
     fill_seg_add(f, bf.CVH, (size_t)a.S * a.B * 2 * a.H * sizeof(float));
+    if (bf.zero_a) fill_seg_add(f, bf.zero_a, bf.zero_a_bytes, 0u);
+    if (bf.zero_b) fill_seg_add(f, bf.zero_b, bf.zero_b_bytes, 0u);
     ASTK_TRY(fill_u32_segments(f, PDEC_SENTINEL, s));
   }
 #else
   ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)NPHASE_SLOTS * NSH * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), s));
+  if (bf.zero_a) ASTK_HIP(hipMemsetAsync(bf.zero_a, 0, bf.zero_a_bytes, s));
+  if (bf.zero_b) ASTK_HIP(hipMemsetAsync(bf.zero_b, 0, bf.zero_b_bytes, s));
 #endif
   const size_t shm = pdec_lds_floats(chunk, a.H, nsplit) * sizeof(float);
   {
