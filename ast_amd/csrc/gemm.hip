@@ -49,6 +49,9 @@ constexpr int BK = ASTK_GEMM_BK;
 #ifndef ASTK_GEMM_PRIO8S
 #define ASTK_GEMM_PRIO8S 0      // ... and of its staging waves
 #endif
+#ifndef ASTK_GEMM_REFILL_EARLY
+#define ASTK_GEMM_REFILL_EARLY 1
+#endif
 #ifndef ASTK_GEMM_PAIR
 #define ASTK_GEMM_PAIR 1        // K-contiguous operands: fetch two k-tiles (one 128-byte line per row) at a time
 #endif
@@ -653,12 +656,20 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
 #endif
 #if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 8)      // timing experiment: staging waves idle
 #else
+#if ASTK_GEMM_REFILL_EARLY
+          // (A's slot is reloaded right behind A's split: its loads' time in the L1's queue -- 16 cycles per 1 KB instruction -- runs beside B's split)
+          if (!TAIL || kt_ + 2 < nk) sa.template store_split<TAIL>(stA(st), kbeg + (kt_ + 2) * BK, kend, slot);
+          refill(sa, A, g.spanA, ARK, std::integral_constant<bool, !TAIL>{}, kt_ + 2, slot);
+          if (!TAIL || kt_ + 2 < nk) sb.template store_split<TAIL>(stB(st), kbeg + (kt_ + 2) * BK, kend, slot);
+          refill(sb, B, g.spanB, BRK, std::integral_constant<bool, !TAIL>{}, kt_ + 2, slot);
+#else
           if (!TAIL || kt_ + 2 < nk) {
             sa.template store_split<TAIL>(stA(st), kbeg + (kt_ + 2) * BK, kend, slot);
             sb.template store_split<TAIL>(stB(st), kbeg + (kt_ + 2) * BK, kend, slot);
           }
 #endif
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 12)      // timing experiment: no global loads in the loop
+#endif
+#if (defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 12)) || ASTK_GEMM_REFILL_EARLY      // timing experiment: no global loads in the loop
 #else
 #if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
           const long long q1_ = clock64();
