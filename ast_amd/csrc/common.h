@@ -315,6 +315,17 @@ struct PrecScope {
   ~PrecScope();
   int prev_p, prev_l;
 };
+// Forward entry points (conv, LSTM stack, decoder forward) open one: the hybrid schedule then runs one data-parallel wave FEWER, so that the
+// stream-K remainder holds at least as many tiles as workgroups and every split tile has at most TWO contributors -- two float atomic adds
+// into a zeroed tile commute, three or more do not, and with all workgroups entering the remainder together their order varies from run
+// to run: 1-ulp differences in the forward pass and, once in a few thousand batches, another fed-back argmax (found by the round-5 soak;
+// rounds 1-4 had bit-identical losses between two passes over the same batches, which is what makes the soak a race detector).  Backward
+// launches keep the full schedule: their weight-gradient products accumulate with many-contributor atomics anyway.
+struct GemmForwardScope {
+  GemmForwardScope();
+  ~GemmForwardScope();
+  int prev;
+};
 // Scoped cap on the co-resident GEMM workgroups per CU for launches made by this thread (0 = none): work that is meant to run
 // BESIDE a persistent recurrence kernel must leave registers free on every CU, or that kernel cannot become resident until the
 // stream-K workgroups (which live for the whole launch) have finished.

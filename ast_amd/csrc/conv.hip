@@ -970,6 +970,7 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
   hipStream_t s = (hipStream_t)stream;
   ASTK_CHECK(d, "conv_bn_relu_fwd: null descriptor");
   PrecScope prec_scope(d->precision, d->gemm_operands);
+  GemmForwardScope forward_scope;      // split tiles of this op's products have at most two contributors (reproducible forward pass)
   gemm_amax_step_boundary(s);         // the first op of a step: no operand-maximum handle is live here
   ASTK_CHECK(world >= 1, "conv_bn_relu_fwd: world %d", world);
   if (world == 1 || d->no_bn) exchange = nullptr;

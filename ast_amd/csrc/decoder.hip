@@ -464,6 +464,7 @@ int astk_decoder_fwd_ex(const astk_decoder_desc* d, const astk_decoder_params* p
   hipStream_t s = (hipStream_t)stream;
   ASTK_CHECK(d, "decoder_fwd: null descriptor");
   PrecScope prec_scope(d->precision, d->gemm_operands);
+  GemmForwardScope forward_scope;      // split tiles of this op's products have at most two contributors (reproducible forward pass)
   {
     SplitPlan sp;
     ASTK_TRY(make_split(d, ws, sp));

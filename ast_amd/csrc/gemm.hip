@@ -1190,6 +1190,9 @@ static std::atomic<double> g_small_flops{getenv("ASTK_GEMM_X3_BELOW") ? atof(get
 static thread_local int tl_prec = -1;       // GemmPrec, or -1 = process default
 static thread_local int tl_lowp = -1;       // 0 / 1, or -1 = process default
 int low_precision_gemms() { return tl_lowp >= 0 ? tl_lowp : g_lowp_mode; }
+static thread_local int tl_forward = 0;
+GemmForwardScope::GemmForwardScope() : prev(tl_forward) { tl_forward = 1; }
+GemmForwardScope::~GemmForwardScope() { tl_forward = prev; }
 static thread_local int tl_wg_cap = 0;
 GemmWgCap::GemmWgCap(int per_cu) : prev(tl_wg_cap) { tl_wg_cap = per_cu; }
 GemmWgCap::~GemmWgCap() { tl_wg_cap = prev; }
@@ -1402,6 +1405,9 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     for (int i = 0; i < grp.n; ++i) uniform = uniform && grp.g[i].mode != GEMM_ACCUM;
     if (uniform) {
       grp.dp_waves = (int)(tiles / G);
+      // (forward launches: one wave fewer -- the remainder then has >= G tiles, every stream-K range >= one tile, <= 2 contributors per split
+      //  tile: run-to-run reproducible sums, see GemmForwardScope)
+      if (tl_forward && grp.dp_waves > 0) --grp.dp_waves;
       grp.dp_kt = grp.g[0].kt;
       grp.rem_start = (long)grp.dp_waves * G * grp.dp_kt;
       const int chunk = (int)(G / 8);          // tiles of one XCD and wave

@@ -151,6 +151,7 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
   hipStream_t s = (hipStream_t)stream;
   ASTK_CHECK(d, "lstm_stack_fwd: null descriptor");
   PrecScope prec_scope(d->precision, d->gemm_operands);
+  GemmForwardScope forward_scope;      // split tiles of this op's products have at most two contributors (reproducible forward pass)
   LstmPlan P;
   ASTK_TRY(make_plan(d, ws, masks != nullptr, P));
   const size_t need = astk_lstm_stack_workspace_bytes(d);

@@ -689,27 +689,10 @@ class SpeechEncoderDecoder:
         ring["i"] = (ring["i"] + 1) % len(ring["bufs"])
         ev.synchronize()                       # returns at once unless the host is 8 steps ahead
         buf[:len(flags)] = torch.tensor(flags, dtype=torch.int32)
-        # (round 5) The copy runs on a side stream BESIDE the CNN and the encoder of this step instead of between the encoder and the
-        # decoder on the compute stream (4.5 us of copy plus a 6 us gap around the switch to the copy engine, on the step's critical path):
-        # it waits for the last reader of the previous flags (event recorded behind the previous decoder forward / backward), and the
-        # compute stream waits for it in front of the decoder -- long done by then.
-        main = torch.cuda.current_stream(self.device)
-        side = self._ws.get("flag_stream")
-        if side is None:
-            side = self._ws["flag_stream"] = torch.cuda.Stream(device=self.device)
-            self._ws["flag_free"], self._ws["flag_done"] = torch.cuda.Event(), torch.cuda.Event()
-            self._ws["flag_free"].record(main)
-        side.wait_event(self._ws["flag_free"])
-        with torch.cuda.stream(side):
-            dst.copy_(buf[:len(flags)], non_blocking=True)
-            ev.record(side)
-            self._ws["flag_done"].record(side)
-        main.wait_event(self._ws["flag_done"])
-
-    def _flags_released(self):
-        """Called behind the last launch that reads the device copy of the teacher-forcing flags (decoder forward, decoder backward)."""
-        if "flag_free" in self._ws:
-            self._ws["flag_free"].record(torch.cuda.current_stream(self.device))
+        # (round 5: a side stream for this copy, beside the encoder, was measured -- it trades the 4.5 us copy for a 6 us cross-queue wait on
+        #  the compute stream: nothing, and one more stream per model next to RCCL's; the copy stays in stream order)
+        dst.copy_(buf[:len(flags)], non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.device))
 
     def forward_loss(self, X, y, teach_ratio, random_out=0, add_noise=0, y_global=None):
         """seq2seq.py:399-473.  y_global (data parallelism with random_out > 0 only): the targets of the WHOLE unsharded batch as a host
@@ -768,7 +751,6 @@ class SpeechEncoderDecoder:
                                       _vp(y), _vp(st["flags"]), _vp(st["emb_mask"]), _vp(st["rnn_masks"]), _vp(st["out_mask"]), _vp(targets),
                                       _vp(st["loss"]), _vp(st["pred"]), _vp(wd), wd.numel(), self._stream()))
         check(lib.astk_persist_status_snapshot(C.c_void_p(st["loss"].data_ptr() + 4), self._stream()))
-        self._flags_released()
         self.loss = Loss(self, st["loss"])
         return self.loss
 
@@ -835,7 +817,6 @@ class SpeechEncoderDecoder:
         if self.grad_buckets is not None:
             self.grad_buckets.launch("cnn")
         check(lib.astk_persist_status_snapshot(C.c_void_p(st["loss"].data_ptr() + 4), s))
-        self._flags_released()
         if self.grad_buckets is not None:
             # ... and once more behind the gradient exchange, when the peers' words have been merged (GradBuckets.finish): every rank's
             # pair of THIS step then carries the merged word

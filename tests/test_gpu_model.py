@@ -686,6 +686,36 @@ def test_full_size_batch_permutation_and_gradient_accumulation(model, B, T, D, o
         hooks.__exit__(None, None, None)
 
 
+def test_forward_pass_is_bit_reproducible_from_run_to_run():
+    """The forward pass at BASELINE configs[1]'s shape, 25 times over the same batch and weights: loss and encoder states bit-identical.  The
+    batched products split some output tiles between workgroups and add the pieces with float atomics; two pieces into a zeroed tile
+    commute, three do not -- forward entry points therefore run the GEMM schedule that keeps every split tile at two contributors
+    (common.h GemmForwardScope; round 5: with three, the soak saw 1-ulp differences and one flipped fed-back argmax in 6000 batch passes).
+    The recurrences, the attention scan and the CE role are deterministic by construction."""
+    import bench
+    from ast_amd.seq2seq import using_config
+    import copy
+    cfg = copy.deepcopy(bench.MODEL_CFG)
+    cfg["dropout"] = {"embed": 0.0, "rnn": 0.0, "out": 0}          # (fresh masks per call would be a difference of their own)
+    V = cfg["rnn_config"]["dec_vocab_size"]
+    B, T, D, L = 32, 800, 80, 40
+    P, X, y = _make(cfg, B, T, D, L, V)
+    m = _gpu_model(cfg, P, D, V)
+    m.inject["use_truth"] = [1 if (i % 5) else 0 for i in range(L - 1)]
+    m.inject["use_truth"][0] = 1
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    ref = None
+    with using_config("train", True):
+        for it in range(25):
+            loss = m.forward_loss(Xd, yd, 0.8)
+            got = (float(loss.data), m.enc_states.clone())
+            if ref is None:
+                ref = got
+            else:
+                assert got[0] == ref[0], (it, got[0], ref[0])
+                assert torch.equal(got[1], ref[1]), it
+
+
 def test_cnn_backward_refuses_a_workspace_whose_forward_took_the_other_layer0_path():
     """the layer-0 path (direct convolution + window-matrix weight gradient under the default arithmetic, im2col + GEMM
     otherwise) is re-derived at every call from the arithmetic in force then.  With the descriptor at ASTK_PREC_DEFAULT a change of the
