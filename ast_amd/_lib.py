@@ -28,7 +28,7 @@ class CnnDesc(C.Structure):
                 ("st", C.c_int * MAX_CNN), ("sf", C.c_int * MAX_CNN), ("pt", C.c_int * MAX_CNN),
                 ("bn_eps", C.c_float), ("bn_decay", C.c_float), ("no_bn", C.c_int),
                 ("pool_t", C.c_int * MAX_CNN), ("pool_f", C.c_int * MAX_CNN),
-                ("precision", C.c_int), ("gemm_operands", C.c_int)]
+                ("precision", C.c_int), ("gemm_operands", C.c_int), ("status_dst", C.c_void_p)]
 
 
 class CnnLayerParams(C.Structure):
@@ -59,14 +59,14 @@ class RandSeg(C.Structure):
                 ("seed", C.c_uint64), ("offset", C.c_uint64)]
 
 
-RAND_DROPOUT, RAND_NORMAL, RAND_SEG_MAX = 0, 1, 8
+RAND_DROPOUT, RAND_NORMAL, RAND_SEG_MAX, RAND_WORDS_MAX = 0, 1, 8, 256
 
 
 class DecoderDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("L", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int),
                 ("A", C.c_int), ("V", C.c_int), ("n_layers", C.c_int),
                 ("n_attn", C.c_int), ("no_feed_attn", C.c_int), ("ln", C.c_int), ("loss_rows", C.c_int),
-                ("use_truth_host", C.POINTER(C.c_int32)), ("precision", C.c_int), ("gemm_operands", C.c_int)]
+                ("use_truth_host", C.POINTER(C.c_int32)), ("precision", C.c_int), ("gemm_operands", C.c_int), ("status_dst", C.c_void_p)]
 
 
 class DecoderParams(C.Structure):
@@ -144,6 +144,7 @@ SIGNATURES = {
     "astk_fill_dropout_mask": (C.c_int, [_VP, _SZ, _F, _U64, _U64, _VP]),
     "astk_fill_normal": (C.c_int, [_VP, _SZ, _F, _F, _U64, _U64, _VP]),
     "astk_fill_random": (C.c_int, [C.POINTER(RandSeg), _I, _VP]),
+    "astk_fill_random_ex": (C.c_int, [C.POINTER(RandSeg), _I, C.POINTER(C.c_int32), _I, _VP, _VP]),
     "astk_scale_f32": (C.c_int, [_VP, _SZ, _F, _VP]),
     "astk_add_f32": (C.c_int, [_VP, _VP, _SZ, _VP]),
     "astk_bridge_states": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),

@@ -347,21 +347,32 @@ struct GemmGroup {
   long rem_start;    // first k-iteration of the stream-K remainder = dp_waves * G * dp_kt
   long iters_total;
   long iter_start[GEMM_GROUP_MAX + 1];
+  // Ticket words of the split tiles (gemm.hip, "Split tiles without a zeroing launch"): word (tick_base[problem] + tile) * 8 + wave;
+  // nullptr: the split tiles are zeroed in front of the launch and every contribution is an atomic add
+  unsigned* tick;
+  int tick_base[GEMM_GROUP_MAX];
   GemmArgs g[GEMM_GROUP_MAX];
 };
 int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s);
+
+// The persistent kernels' sticky status word (util.hip) and a one-thread copy of it, as a float, to *dst (astk_persist_status_snapshot)
+const unsigned* persist_status_word();
+int status_snapshot_launch(float* dst, hipStream_t s);
 
 // ---- small utility kernels (util.hip)
 int fill_zero(void* p, size_t bytes, hipStream_t s);
 // One launch that fills up to FILL_SEG_MAX separate 16-byte aligned regions with a 32-bit pattern (the sentinel fill of the
 // persistent kernels' hand-off buffers; a hipMemsetAsync per buffer costs ~5 us each).
 constexpr int FILL_SEG_MAX = 16;
-struct FillSegs { int n; void* p[FILL_SEG_MAX]; size_t bytes[FILL_SEG_MAX]; unsigned val[FILL_SEG_MAX]; unsigned own[FILL_SEG_MAX]; };
+struct FillSegs { int n; void* p[FILL_SEG_MAX]; size_t bytes[FILL_SEG_MAX]; unsigned val[FILL_SEG_MAX]; unsigned own[FILL_SEG_MAX]; const void* src[FILL_SEG_MAX]; };
 static inline void fill_seg_add(FillSegs& f, void* p, size_t bytes) {          // filled with the launch's value
-  if (bytes > 0 && f.n < FILL_SEG_MAX) { f.p[f.n] = p; f.bytes[f.n] = bytes; f.own[f.n] = 0; f.val[f.n] = 0; ++f.n; }
+  if (bytes > 0 && f.n < FILL_SEG_MAX) { f.p[f.n] = p; f.bytes[f.n] = bytes; f.own[f.n] = 0; f.val[f.n] = 0; f.src[f.n] = nullptr; ++f.n; }
 }
 static inline void fill_seg_add(FillSegs& f, void* p, size_t bytes, unsigned value) {   // filled with its own value
-  if (bytes > 0 && f.n < FILL_SEG_MAX) { f.p[f.n] = p; f.bytes[f.n] = bytes; f.own[f.n] = 1; f.val[f.n] = value; ++f.n; }
+  if (bytes > 0 && f.n < FILL_SEG_MAX) { f.p[f.n] = p; f.bytes[f.n] = bytes; f.own[f.n] = 1; f.val[f.n] = value; f.src[f.n] = nullptr; ++f.n; }
+}
+static inline void fill_seg_add_copy(FillSegs& f, void* p, const void* src, size_t bytes) {   // a copy riding in the fill launch (16-byte aligned both)
+  if (bytes > 0 && f.n < FILL_SEG_MAX) { f.p[f.n] = p; f.bytes[f.n] = bytes; f.own[f.n] = 0; f.val[f.n] = 0; f.src[f.n] = src; ++f.n; }
 }
 int fill_u32_segments(const FillSegs& f, unsigned value, hipStream_t s);
 // One launch for up to FILL_SEG_MAX independent device-to-device copies (16-byte aligned, sizes multiples of 4 bytes) and one for

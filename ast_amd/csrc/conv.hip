@@ -13,6 +13,7 @@
 //   BatchNorm: column statistics of the raw conv output [rows][C] in float64 atomics, then one fused
 //             scale/shift/ReLU pass that writes the next layer's padded layout (or the LSTM layout).
 #include "common.h"
+#include <atomic>
 #include <mutex>
 #include <algorithm>
 #include <cstdlib>
@@ -63,6 +64,9 @@ struct CnnPlan {
   unsigned long long *a_hp_s[ASTK_MAX_CNN_LAYERS], *a_dy_s[ASTK_MAX_CNN_LAYERS];
   void* zero_fwd_from;
   size_t zero_fwd_amax_bytes;             // the forward slots alone (eval mode: no statistics to zero)
+  unsigned* fin_ctr;                      // [layer * 64], inside the forward slots' region
+  float* c0_part;                         // direct layer-0 kernel: [c0_tiles][2][C] sums of y and y^2 over each tile's output steps
+  int c0_tiles;
   float* bn[ASTK_MAX_CNN_LAYERS];   // [4][C]: mean, inv_std, scale, shift
   float* G;                         // [rows_max][Cmax] gradient wrt post-ReLU output (row layout)
   float* DY[ASTK_MAX_CNN_LAYERS];   // padded dY (i>=1) / plain dY (i=0)
@@ -114,6 +118,9 @@ int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
   P.K0g = d->kt[0] * P.JG;
   P.xf_rows = (d->T + 2 * d->pt[0] + 1) & ~1;      // (even: the group stride of the window view must be a multiple of 4 floats)
   P.XF = c.take<float>((size_t)d->B * P.Fc[0] * P.xf_rows * P.JG + 16);
+  // fused layer-0 statistics of the direct kernel: one row [2][C] of float sums per tile (C0_TT output steps of one (b, f))
+  P.c0_tiles = d->B * P.Fc[0] * cdiv(P.Tc[0], 80);
+  P.c0_part = c.take<float>((size_t)P.c0_tiles * 2 * P.Cn[0]);
   size_t wd_max = 0;
   for (int i = 0; i < P.n; ++i) {
     P.Y[i] = c.take<float>((size_t)P.rows[i] * P.Cn[i]);
@@ -158,6 +165,7 @@ int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
     P.a_wr[i] = c.take<unsigned long long>(AMAX_SLOT_WORDS);
   }
   P.a_out = amax_pslot_handle(c.take<unsigned long long>(AMAX_PSLOT_WORDS));
+  P.fin_ctr = c.take<unsigned>(64 * ASTK_MAX_CNN_LAYERS);       // arrival counters of k_colstats' blocks (the last one finalizes), 256 bytes apart
   P.zero_fwd_from = ws ? (char*)ws + off_afwd : nullptr;
   const size_t off_stat = align_up(c.off, 256);
   P.zero_fwd_amax_bytes = off_stat - off_afwd;
@@ -235,15 +243,17 @@ static bool conv0_direct(const astk_cnn_desc* d) {
 // the backward call from the arithmetic in force THEN; if the process default moved in between while the descriptor says DEFAULT, the
 // backward would read a window matrix XF that was never written (or patches P0 that were never built) -- a silently wrong CNN_0/W
 // gradient from stale workspace.  The forward records (workspace, path); the backward refuses a workspace whose record differs.
-struct Conv0PathRecord { const void* ws; int direct; };
+// (bwd_clean: the forward call's last kernel zeroed the region the backward accumulates into -- statistics, backward maximum slots, dWr
+//  scratch -- on its way out, so the backward call that follows needs no fill launch of its own; the backward call takes the mark away.)
+struct Conv0PathRecord { const void* ws; int direct; int bwd_clean; };
 static std::mutex g_conv0_mu;
 static Conv0PathRecord g_conv0_ring[64];
 static unsigned g_conv0_next = 0;
-static void conv0_path_record(const void* ws, bool direct) {
+static void conv0_path_record(const void* ws, bool direct, bool bwd_clean) {
   std::lock_guard<std::mutex> lock(g_conv0_mu);
   for (auto& r : g_conv0_ring)
-    if (r.ws == ws) { r.direct = direct ? 1 : 0; return; }
-  g_conv0_ring[g_conv0_next++ % 64] = Conv0PathRecord{ws, direct ? 1 : 0};
+    if (r.ws == ws) { r.direct = direct ? 1 : 0; r.bwd_clean = bwd_clean ? 1 : 0; return; }
+  g_conv0_ring[g_conv0_next++ % 64] = Conv0PathRecord{ws, direct ? 1 : 0, bwd_clean ? 1 : 0};
 }
 static int conv0_path_lookup(const void* ws) {      // -1: no forward call recorded for this workspace
   std::lock_guard<std::mutex> lock(g_conv0_mu);
@@ -251,11 +261,61 @@ static int conv0_path_lookup(const void* ws) {      // -1: no forward call recor
     if (r.ws == ws) return r.direct;
   return -1;
 }
+static bool conv_take_bwd_clean(const void* ws) {   // true once per marked forward call
+  std::lock_guard<std::mutex> lock(g_conv0_mu);
+  for (auto& r : g_conv0_ring)
+    if (r.ws == ws) { const bool c = r.bwd_clean != 0; r.bwd_clean = 0; return c; }
+  return false;
+}
+// Every thread of the calling grid: zero `bytes` (a multiple of 4) from the 16-byte aligned p.  A fill launch of its own costs ~5 us of
+// stream time; the kernels in front of the consumers do it on their way in / out instead.
+__device__ __forceinline__ void zero_region(void* p, size_t bytes) {
+  if (!p) return;
+  const size_t n16 = bytes / 16, n4 = bytes / 4;
+  const size_t nth = (size_t)gridDim.x * gridDim.y * blockDim.x;
+  const size_t me = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+  for (size_t i = me; i < n16; i += nth) reinterpret_cast<uint4*>(p)[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = n16 * 4 + me; i < n4; i += nth) reinterpret_cast<unsigned*>(p)[i] = 0u;
+}
+// bn[0]=mean, bn[1]=inv_std, bn[2]=scale, bn[3]=shift ; running statistics per Chainer-sem A4
+struct BnFinalize {
+  unsigned* ctr;          // k_colstats: arrival counter of the launch's blocks (zero before the launch); nullptr = no fused finalize
+  double m;
+  const float *gamma, *beta;
+  float *avg_mean, *avg_var, *bn;
+  float eps, decay;
+};
+__device__ __forceinline__ void bn_finalize_channel(int c, int C, double s0, double s1, const BnFinalize& f, int train) {
+  float mean, inv_std;
+  if (train) {
+    const double mu = s0 / f.m;
+    double var = s1 / f.m - mu * mu;
+    if (var < 0) var = 0;
+    mean = (float)mu;
+    inv_std = (float)(1.0 / sqrt(var + (double)f.eps));
+    const double adjust = f.m / (f.m - 1.0 > 1.0 ? f.m - 1.0 : 1.0);
+    f.avg_mean[c] = f.decay * f.avg_mean[c] + (1.f - f.decay) * mean;
+    f.avg_var[c] = f.decay * f.avg_var[c] + (float)((1.0 - (double)f.decay) * adjust * var);
+  } else {
+    mean = f.avg_mean[c];
+    inv_std = 1.f / sqrtf(f.avg_var[c] + f.eps);
+  }
+  const float sc = f.gamma[c] * inv_std;
+  f.bn[c] = mean;
+  f.bn[C + c] = inv_std;
+  f.bn[2 * C + c] = sc;
+  f.bn[3 * C + c] = f.beta[c] - mean * sc;
+}
 constexpr int C0_NPAIR = 8;           // pairs of window elements per thread and tile (256 threads x 8 x 2 >= the window)
 __global__ __launch_bounds__(256, 2) void k_conv0_fwd_x3(const float* __restrict__ X, const float* __restrict__ noise, const float* __restrict__ W,
                                                          float* __restrict__ Y, float* __restrict__ XF, int B, int T, int D, int F, int T1, int C,
-                                                         int kt, int kf, int st, int sf, int pt, int JG, int xf_rows, int tiles_t, int total, int win) {
+                                                         int kt, int kf, int st, int sf, int pt, int JG, int xf_rows, int tiles_t, int total, int win,
+                                                         void* zero_from, size_t zero_bytes, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) unsigned short c0_planes[];      // [3][win] bf16; first the f32 weights [C][kt*kf]
+  // BatchNorm statistics of the layer's output on the way out (part != nullptr; k_colstats read the 262 MB back: 19-21 us): per lane and
+  // tile, sums over the steps it stores; folded over the 16 step lanes behind the tile's products; one row [2][C] of float sums per TILE,
+  // plain stores -- the statistics kernel behind this one sums 6400 such rows (6.5 MB) instead of the layer's output.
+  zero_region(zero_from, zero_bytes);      // the statistics / maximum slots the kernels BEHIND this one accumulate into
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int ch0 = wave * 32;
   const float* const nz = noise ? noise : X;
@@ -347,6 +407,7 @@ __global__ __launch_bounds__(256, 2) void k_conv0_fwd_x3(const float* __restrict
       x.lo = *reinterpret_cast<const u32q*>(pl + off + 32 * ks);
       return x;
     };
+    float sa[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, qa[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // this tile: sum y, sum y^2 of the lane's 8 channels
     auto store_y = [&](int ti, const f32x4& a0, const f32x4& a1) {
       const int t1 = t0 + 16 * ti + r;
       if (t1 < T1) {
@@ -354,6 +415,13 @@ __global__ __launch_bounds__(256, 2) void k_conv0_fwd_x3(const float* __restrict
         const int c = ch0 + 4 * q;
         if (c < C) *reinterpret_cast<float4*>(yr + c) = make_float4(a0[0], a0[1], a0[2], a0[3]);
         if (c + 16 < C) *reinterpret_cast<float4*>(yr + c + 16) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+        if (part) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            sa[e] += a0[e]; qa[e] += a0[e] * a0[e];
+            sa[4 + e] += a1[e]; qa[4 + e] += a1[e] * a1[e];
+          }
+        }
       }
     };
 #define C0_TERM4_(PA, PX) MFMA_B16_(a00, wf[0][ks].PA, xa.PX) MFMA_B16_(a10, wf[1][ks].PA, xa.PX) MFMA_B16_(a01, wf[0][ks].PA, xb.PX) MFMA_B16_(a11, wf[1][ks].PA, xb.PX)
@@ -383,14 +451,55 @@ __global__ __launch_bounds__(256, 2) void k_conv0_fwd_x3(const float* __restrict
     }
 #undef C0_TERM4_
 #undef C0_TERM2_
+    if (part) {      // fold the 16 step lanes (same q = same channels); lane r == 0 writes the tile's sums
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          sa[e] += __shfl_xor(sa[e], o);
+          qa[e] += __shfl_xor(qa[e], o);
+        }
+      }
+      if (r == 0) {
+        float* const row = part + (long)tile * 2 * C;
+        const int c = ch0 + 4 * q;
+        if (c < C) {
+          *reinterpret_cast<float4*>(row + c) = make_float4(sa[0], sa[1], sa[2], sa[3]);
+          *reinterpret_cast<float4*>(row + C + c) = make_float4(qa[0], qa[1], qa[2], qa[3]);
+        }
+        if (c + 16 < C) {
+          *reinterpret_cast<float4*>(row + c + 16) = make_float4(sa[4], sa[5], sa[6], sa[7]);
+          *reinterpret_cast<float4*>(row + C + c + 16) = make_float4(qa[4], qa[5], qa[6], qa[7]);
+        }
+      }
+    }
   }
 }
-// dW[c][i * kf + j] += dWg[c * ldg + i * JG + j]: the layer-0 weight gradient taken over the padded window columns, back in the parameter's layout
-__global__ void k_conv0_unpad_dw(const float* __restrict__ dWg, float* __restrict__ dW, int C, int kt, int kf, int JG, int ldg) {
-  const int n = C * kt * kf;
-  for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
-    const int j = x % kf, i = (x / kf) % kt, c = x / (kf * kt);
-    dW[x] += dWg[(long)c * ldg + i * JG + j];
+// The weight gradients of every layer back in the parameters' layouts, ONE launch behind the layer loop (blockIdx.y = layer):
+//   layer 0 (direct path): dW[c][i * kf + j] += dWg[c * ldg + i * JG + j] -- taken over the padded window columns
+//   layer i >= 1:          dW[co][ci][kt]    += dWr[co][kt * Ci + ci]
+struct UnpackJobs {
+  int n;
+  const float* src[ASTK_MAX_CNN_LAYERS];
+  float* dW[ASTK_MAX_CNN_LAYERS];
+  int Co[ASTK_MAX_CNN_LAYERS], Ci[ASTK_MAX_CNN_LAYERS], KT[ASTK_MAX_CNN_LAYERS];      // layer 0: Ci = kf
+  int JG[ASTK_MAX_CNN_LAYERS], ldg[ASTK_MAX_CNN_LAYERS];                              // layer 0 only (ldg > 0 marks it)
+};
+__global__ void k_unpack_dw(UnpackJobs jobs, const unsigned* __restrict__ status, float* __restrict__ status_dst) {
+  const int q = blockIdx.y;
+  if (status_dst && blockIdx.x == 0 && q == 0 && threadIdx.x == 0) *status_dst = (float)(*status);     // (astk_cnn_desc.status_dst)
+  const float* const src = jobs.src[q];
+  float* const dW = jobs.dW[q];
+  const int Co = jobs.Co[q], Ci = jobs.Ci[q], KT = jobs.KT[q], JG = jobs.JG[q], ldg = jobs.ldg[q];
+  const long n = (long)Co * Ci * KT;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    if (ldg > 0) {
+      const int j = (int)(i % Ci), t = (int)((i / Ci) % KT), c = (int)(i / ((long)Ci * KT));
+      dW[i] += src[(long)c * ldg + t * JG + j];
+    } else {
+      const int k = (int)(i % KT), ci = (int)((i / KT) % Ci), co = (int)(i / ((long)Ci * KT));
+      dW[i] += src[((long)co * KT + k) * Ci + ci];
+    }
   }
 }
 
@@ -411,21 +520,20 @@ __global__ __launch_bounds__(256) void k_repack_w(const float* __restrict__ W, f
   }
   if (amax) amax_emit_block(amax, m, red4);
 }
-// dW[co][ci][kt] += dWr[co][kt*Ci + ci]
-__global__ void k_unpack_dw(const float* __restrict__ dWr, float* __restrict__ dW, int Co, int Ci, int KT) {
-  const long n = (long)Co * Ci * KT;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(i % KT);
-    const int ci = (int)((i / KT) % Ci);
-    const int co = (int)(i / ((long)Ci * KT));
-    dW[i] += dWr[((long)co * KT + k) * Ci + ci];
-  }
-}
-// dgrad phase weight: Wd[ci][a*Co + co] = W[co][ci][kt = r + st*(na-1-a)]
-__global__ __launch_bounds__(256) void k_phase_w(const float* __restrict__ W, float* __restrict__ Wd, int Co, int Ci, int KT, int r, int st, int na,
-                                                 unsigned long long* amax, const unsigned long long* fold_src, unsigned long long* fold_dst) {
+// dgrad phase weights: Wd[ci][a*Co + co] = W[co][ci][kt = r + st*(na-1-a)], the stride phases of one grouped dgrad launch in ONE launch
+// (blockIdx.y = phase; a launch per phase cost ~5 us of stream time each)
+struct PhaseWJobs {
+  int n;
+  float* wd[GEMM_GROUP_MAX];
+  int r[GEMM_GROUP_MAX], na[GEMM_GROUP_MAX];
+  unsigned long long* amax[GEMM_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void k_phase_w(const float* __restrict__ W, PhaseWJobs jobs, int Co, int Ci, int KT, int st,
+                                                 const unsigned long long* fold_src, unsigned long long* fold_dst) {
   __shared__ float red4[4];
-  if (fold_src && blockIdx.x == 0 && threadIdx.x < 64) amax_compact(fold_src, fold_dst);     // (the padded dY's maximum, see CnnPlan)
+  if (fold_src && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) amax_compact(fold_src, fold_dst);     // (the padded dY's maximum, see CnnPlan)
+  const int j = blockIdx.y, r = jobs.r[j], na = jobs.na[j];
+  float* const Wd = jobs.wd[j];
   const long n = (long)Ci * na * Co;
   float m = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -437,11 +545,15 @@ __global__ __launch_bounds__(256) void k_phase_w(const float* __restrict__ W, fl
     Wd[i] = v;
     m = fmaxf(m, fabsf(v));
   }
-  if (amax) amax_emit_block(amax, m, red4);
+  if (jobs.amax[j]) {      // (amax_emit_block shards by blockIdx.x + blockIdx.y * gridDim.x: fine for a plain slot)
+    amax_emit_block(jobs.amax[j], m, red4);
+  }
 }
 
-// column sums of Y and Y^2 ( -> double atomics ), colreduce_block skeleton
-__global__ __launch_bounds__(256) void k_colstats(const float* __restrict__ Y, int rows, int C, double* __restrict__ stat) {
+__device__ __forceinline__ void colstats_finalize(int C, double* __restrict__ stat, const BnFinalize& fin);
+// column sums of Y and Y^2 ( -> double atomics ), colreduce_block skeleton.  fin.ctr: the block that arrives LAST (every block drains its
+// atomics, then bumps the counter) turns the sums into scale / shift and the running statistics -- k_bn_finalize without its launch.
+__global__ __launch_bounds__(256) void k_colstats(const float* __restrict__ Y, int rows, int C, double* __restrict__ stat, BnFinalize fin) {
   colreduce_block<2>(
       rows, C,
       [&](int r, int c, float4* a) {
@@ -450,6 +562,33 @@ __global__ __launch_bounds__(256) void k_colstats(const float* __restrict__ Y, i
         a[1].x += v.x * v.x; a[1].y += v.y * v.y; a[1].z += v.z * v.z; a[1].w += v.w * v.w;
       },
       [&](int col, int st, float v) { atomicAdd(&stat[st * C + col], (double)v); });
+  colstats_finalize(C, stat, fin);
+}
+// ... from rows of PRE-SUMMED statistics [rows][2][C] (k_conv0_fwd_x3's per-tile sums): column sums of a (rows, 2 C) matrix land in stat's
+// [2][C] layout as they are
+__global__ __launch_bounds__(256) void k_colstats_tiles(const float* __restrict__ part, int rows, int C, double* __restrict__ stat, BnFinalize fin) {
+  colreduce_block<1>(
+      rows, 2 * C,
+      [&](int r, int c, float4* a) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (long)r * 2 * C + c);
+        a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
+      },
+      [&](int col, int st, float v) { atomicAdd(&stat[col], (double)v); });
+  colstats_finalize(C, stat, fin);
+}
+__device__ __forceinline__ void colstats_finalize(int C, double* __restrict__ stat, const BnFinalize& fin) {
+  if (!fin.ctr) return;
+  __shared__ int last;
+  // this thread's atomics have been performed (at the memory side: device-scope atomics; the last block reads them back with device-scope
+  // loads).  NOT __threadfence(): its L2 write-back + invalidate in every wave of 256 blocks cost the kernel 5-15 us.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) last = __hip_atomic_fetch_add(fin.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1;
+  __syncthreads();
+  if (!last) return;
+  for (int c = threadIdx.x; c < C; c += 256)
+    bn_finalize_channel(c, C, __hip_atomic_load(&stat[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                        __hip_atomic_load(&stat[C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), fin, 1);
 }
 
 // zero only the pad rows of a time-padded channels-last buffer [(group)][padF + Tn + padB][C]: the interior is rewritten every step.
@@ -481,31 +620,11 @@ __global__ __launch_bounds__(256) void k_zero_pads(float* __restrict__ buf, int 
   }
 }
 
-// bn[0]=mean, bn[1]=inv_std, bn[2]=scale, bn[3]=shift ; running statistics per Chainer-sem A4
-__global__ void k_bn_finalize(const double* __restrict__ stat, int C, double m, const float* __restrict__ gamma,
-                              const float* __restrict__ beta, float* __restrict__ avg_mean, float* __restrict__ avg_var,
-                              float* __restrict__ bn, float eps, float decay, int train) {
+// (the launch of its own: evaluation mode, and training with a statistics exchange between the sums and their use)
+__global__ void k_bn_finalize(const double* __restrict__ stat, int C, BnFinalize fin, int train) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float mean, inv_std;
-  if (train) {
-    const double mu = stat[c] / m;
-    double var = stat[C + c] / m - mu * mu;
-    if (var < 0) var = 0;
-    mean = (float)mu;
-    inv_std = (float)(1.0 / sqrt(var + (double)eps));
-    const double adjust = m / (m - 1.0 > 1.0 ? m - 1.0 : 1.0);
-    avg_mean[c] = decay * avg_mean[c] + (1.f - decay) * mean;
-    avg_var[c] = decay * avg_var[c] + (float)((1.0 - (double)decay) * adjust * var);
-  } else {
-    mean = avg_mean[c];
-    inv_std = 1.f / sqrtf(avg_var[c] + eps);
-  }
-  const float sc = gamma[c] * inv_std;
-  bn[c] = mean;
-  bn[C + c] = inv_std;
-  bn[2 * C + c] = sc;
-  bn[3 * C + c] = beta[c] - mean * sc;
+  bn_finalize_channel(c, C, train ? stat[c] : 0.0, train ? stat[C + c] : 0.0, fin, train);
 }
 
 // cnn_config.bn = false (seq2seq.py:43-57: Convolution2D with bias, no BatchNormalization): the same scale / shift slots the ReLU
@@ -548,9 +667,10 @@ __global__ __launch_bounds__(256) void k_bn_relu_rows(const float* __restrict__ 
 
 // out[t][b][c*F+f] = relu(bn(Y[(b,f,t)][c]))  -- one block per (t, b); LDS re-orders (f,c) -> (c,f)
 __global__ __launch_bounds__(256) void k_bn_relu_to_seq(const float* __restrict__ Y, const float* __restrict__ bn, float* __restrict__ out,
-                                                        int B, int F, int Tn, int C, unsigned long long* amax) {
+                                                        int B, int F, int Tn, int C, unsigned long long* amax, void* zero_from, size_t zero_bytes) {
   extern __shared__ float tile[];   // [C*F]
   __shared__ float red4[4];
+  zero_region(zero_from, zero_bytes);
   const int t = blockIdx.x, b = blockIdx.y;
   const int n = C * F;
   float mx = 0.f;
@@ -741,9 +861,10 @@ struct SeqSlots {
 // PP (t, b) pairs 256 bytes at a time (16-byte loads), re-orders [f][c] -> [c][f] through LDS and writes each pair's piece of the frames as one
 // contiguous run of 16-byte stores (k_bn_relu_to_seq moves 4 bytes per lane both ways: 43 us for 158 MB)
 __global__ __launch_bounds__(256) void k_bn_relu_to_seq_tiled(const float* __restrict__ Y, const float* __restrict__ bn, float* __restrict__ out, int B, int F,
-                                                              int Tn, int C, int PP, unsigned long long* amax) {
+                                                              int Tn, int C, int PP, unsigned long long* amax, void* zero_from, size_t zero_bytes) {
   extern __shared__ __attribute__((aligned(16))) float seq_tile[];       // [PP][SEQ_CH * F]: a pair's piece in the frames' own order
   __shared__ float red4[4];
+  zero_region(zero_from, zero_bytes);      // what the backward call accumulates into (every user of the forward statistics is behind us in the stream)
   const int c0 = blockIdx.x * SEQ_CH, cl = 4 * (threadIdx.x & 15), c = c0 + cl, g16 = threadIdx.x >> 4;
   const int npairs = Tn * B, piece = SEQ_CH * F;
   const float4 sc = *reinterpret_cast<const float4*>(bn + 2 * C + c), sh = *reinterpret_cast<const float4*>(bn + 3 * C + c);
@@ -980,15 +1101,23 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
   ASTK_CHECK(X && out && L, "conv_bn_relu_fwd: null pointer");
   const int B = P.B;
   // the statistics of every layer (train) and the maximum slots the producing kernels fill: one fill
-  ASTK_TRY(fill_zero(P.zero_fwd_from, train ? P.zero_fwd_bytes : P.zero_fwd_amax_bytes, s));
-  conv0_path_record(ws, conv0_direct(d));
+  const size_t zero_fwd = train ? P.zero_fwd_bytes : P.zero_fwd_amax_bytes;
+  if (!conv0_direct(d)) ASTK_TRY(fill_zero(P.zero_fwd_from, zero_fwd, s));       // (the direct layer-0 kernel does it on its way in)
+  // the backward's region: zeroed by this call's last kernel (train) -- a fill launch less in the backward call
+  const bool seq_out_zeroes = train != 0;
+  conv0_path_record(ws, conv0_direct(d), seq_out_zeroes);
+  void* const zb_from = seq_out_zeroes ? (void*)P.stat[0] : nullptr;
+  bool c0_stats = false;
   if (conv0_direct(d)) {
     // ---- layer 0: direct convolution (bf16x3 on the matrix pipe), leaves XF for the weight gradient
     const int tiles_t = cdiv(P.Tc[0], C0_TT), total = B * P.Fc[0] * tiles_t, win = conv0_win_elems(d->st[0]);
     const int grid = std::min(total, 2 * device_cu_count());
     const size_t lds0 = std::max((size_t)3 * win * sizeof(unsigned short), (size_t)P.Cn[0] * P.K0 * sizeof(float));
+    // the layer's BatchNorm statistics inside the kernel (and, without a statistics exchange, scale / shift and the running statistics)
+    c0_stats = train && !d->no_bn && total == P.c0_tiles;      // the layer's BatchNorm statistics: per-tile sums out of the kernel
     hipLaunchKernelGGL(k_conv0_fwd_x3, dim3(grid), dim3(256), lds0, s, X, noise, L[0].W, P.YC[0], P.XF, B, P.T, P.D,
-                       P.Fc[0], P.Tc[0], P.Cn[0], d->kt[0], d->kf[0], d->st[0], d->sf[0], d->pt[0], P.JG, P.xf_rows, tiles_t, total, win);
+                       P.Fc[0], P.Tc[0], P.Cn[0], d->kt[0], d->kf[0], d->st[0], d->sf[0], d->pt[0], P.JG, P.xf_rows, tiles_t, total, win,
+                       P.zero_fwd_from, zero_fwd, c0_stats ? P.c0_part : nullptr);
     ASTK_LAUNCH_CHECK();
   } else {
   // ---- layer 0: im2col + GEMM
@@ -1022,14 +1151,22 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
       hipLaunchKernelGGL(k_bias_affine, dim3(cdiv(C, 256)), dim3(256), 0, s, L[i].bias, C, P.bn[i]);
       ASTK_LAUNCH_CHECK();
     } else {
+    BnFinalize fin{nullptr, (double)rows * (exchange ? world : 1), L[i].gamma, L[i].beta, L[i].avg_mean, L[i].avg_var, P.bn[i], d->bn_eps, d->bn_decay};
+    const bool fused_fin = train && !exchange;        // the statistics kernel's last block finalizes
     if (train) {
-      hipLaunchKernelGGL(k_colstats, colreduce_grid(rows, C), dim3(256), 0, s, P.Y[i], rows, C, P.stat[i]);
+      BnFinalize f2 = fin;
+      if (fused_fin) f2.ctr = P.fin_ctr + 64 * i;
+      if (i == 0 && c0_stats)      // (layer 0, direct path: the tiles' sums came with the convolution -- 6.5 MB to add up instead of 262)
+        hipLaunchKernelGGL(k_colstats_tiles, colreduce_grid(P.c0_tiles, 2 * C), dim3(256), 0, s, P.c0_part, P.c0_tiles, C, P.stat[i], f2);
+      else
+      hipLaunchKernelGGL(k_colstats, colreduce_grid(rows, C), dim3(256), 0, s, P.Y[i], rows, C, P.stat[i], f2);
       ASTK_LAUNCH_CHECK();
       if (exchange) ASTK_CHECK(exchange(user, P.stat[i], 2 * C, stream) == 0, "conv_bn_relu_fwd: statistics exchange failed (layer %d)", i);
     }
-    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, s, P.stat[i], C, (double)rows * (exchange ? world : 1), L[i].gamma, L[i].beta,
-                       L[i].avg_mean, L[i].avg_var, P.bn[i], d->bn_eps, d->bn_decay, train);
-    ASTK_LAUNCH_CHECK();
+    if (!fused_fin) {
+      hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, s, P.stat[i], C, fin, train);
+      ASTK_LAUNCH_CHECK();
+    }
     }
     if (i < P.n - 1) {
       // (k_bn_relu_rows zeroes the pad rows of HP[i] itself)
@@ -1041,11 +1178,11 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
       if (!tiled_off && seq_bwd_applicable(C, F, (long)P.Tn[i] * B)) {
         const int pp = seq_pp(F), gy = std::max(1, std::min(2048 / (C / SEQ_CH), cdiv(P.Tn[i] * B, pp)));
         hipLaunchKernelGGL(k_bn_relu_to_seq_tiled, dim3(C / SEQ_CH, gy), dim3(256), (size_t)pp * SEQ_CH * F * sizeof(float), s, P.Y[i], P.bn[i], out, B, F,
-                           P.Tn[i], C, pp, P.a_out);
+                           P.Tn[i], C, pp, P.a_out, zb_from, P.zero_bwd_bytes);
       } else {
       const size_t shm = (size_t)C * F * sizeof(float);
       ASTK_CHECK(shm <= 64 * 1024, "cnn: C*F' too large for the re-layout tile (%zu bytes)", shm);
-      hipLaunchKernelGGL(k_bn_relu_to_seq, dim3(P.Tn[i], B), dim3(256), shm, s, P.Y[i], P.bn[i], out, B, F, P.Tn[i], C, P.a_out);
+      hipLaunchKernelGGL(k_bn_relu_to_seq, dim3(P.Tn[i], B), dim3(256), shm, s, P.Y[i], P.bn[i], out, B, F, P.Tn[i], C, P.a_out, zb_from, P.zero_bwd_bytes);
       }
       ASTK_LAUNCH_CHECK();
     }
@@ -1113,6 +1250,14 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
     hipLaunchKernelGGL(k_seq_to_rows, dim3(P.Tn[i], B), dim3(256), shm, s, d_out, P.G, B, P.Fn[i], P.Tn[i], P.Cn[i]);
     ASTK_LAUNCH_CHECK();
   }
+  UnpackJobs uj;
+  uj.n = 0;
+  size_t uj_max = 0;
+  auto unpack_add = [&](const float* src, float* dW, int Co, int Ci, int KT, int JG, int ldg) {
+    uj.src[uj.n] = src; uj.dW[uj.n] = dW; uj.Co[uj.n] = Co; uj.Ci[uj.n] = Ci; uj.KT[uj.n] = KT; uj.JG[uj.n] = JG; uj.ldg[uj.n] = ldg;
+    ++uj.n;
+    uj_max = std::max(uj_max, (size_t)Co * Ci * KT);
+  };
   for (int i = P.n - 1; i >= 0; --i) {
     const int C = P.Cn[i], rows = P.rows[i];
 #ifdef ASTK_TEST_HOOKS
@@ -1122,7 +1267,8 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
     }
 #endif
     // ---- ReLU + BatchNorm backward: G (grad wrt post-ReLU) -> DY[i] (grad wrt raw conv output)
-    if (i == P.n - 1) ASTK_TRY(fill_zero(P.stat[0], P.zero_bwd_bytes, s));   // statistics and dWr scratch of every layer
+    // statistics and dWr scratch of every layer: zeroed by the forward call's last kernel (conv0_path_record), else here
+    if (i == P.n - 1 && !conv_take_bwd_clean(ws)) ASTK_TRY(fill_zero(P.stat[0], P.zero_bwd_bytes, s));
     const bool seq = seq_last && i == P.n - 1;
     const int seq_gx = C / SEQ_CH;
     if (seq) {
@@ -1178,8 +1324,7 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
         const int ldg = (P.K0g + 3) & ~3;
         MatView Bm = mat2(P.XF, P.Tc[0], (long)P.xf_rows * P.JG, (long)d->st[0] * P.JG);
         ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(C, P.K0g, P.rowsc[0], mat(P.DY[0], C), Bm, P.dWr[0], ldg, nullptr, GEMM_ATOMIC, ks), s));
-        hipLaunchKernelGGL(k_conv0_unpad_dw, dim3(cdiv(C * P.K0, 256)), dim3(256), 0, s, P.dWr[0], Gr[0].dW, C, d->kt[0], d->kf[0], P.JG, ldg);
-        ASTK_LAUNCH_CHECK();
+        unpack_add(P.dWr[0], Gr[0].dW, C, d->kf[0], d->kt[0], P.JG, ldg);
       } else {
       ASTK_TRY(gemm_launch(GEMM_TN, gemm_args(C, P.K0p, P.rowsc[0], mat(P.DY[0], C), mat(P.P0, P.K0p), P.dWr[0], P.K0p, nullptr, GEMM_ATOMIC, ks), s));
       ASTK_TRY(add2d_f32(Gr[0].dW, P.K0, P.dWr[0], P.K0p, C, P.K0, s));
@@ -1196,6 +1341,17 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
       GemmArgs ph[GEMM_GROUP_MAX];
       int nph = 0;
       bool folded = false;
+      PhaseWJobs pj;
+      pj.n = 0;
+      int pj_na_max = 0;
+      auto launch_phase_w = [&]() {      // the phase weights gathered so far (wd buffers 0 .. pj.n-1)
+        if (pj.n == 0) return;
+        hipLaunchKernelGGL(k_phase_w, dim3(gridn((size_t)Ci * pj_na_max * C / 8), pj.n), dim3(256), 0, s, L[i].W, pj, C, Ci, KT, st,
+                           folded ? nullptr : (const unsigned long long*)P.a_dy_s[i], P.a_dy[i]);
+        folded = true;
+        pj.n = 0;
+        pj_na_max = 0;
+      };
       for (int rho = 0; rho < st && rho < P.Tn[i - 1]; ++rho) {
         const int r = (rho + pt) % st;
         const int na = (KT - r + st - 1) / st;
@@ -1204,14 +1360,18 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
         }
         const int nj = (P.Tn[i - 1] - rho + st - 1) / st;
         const int q0 = (rho + pt) / st;
-        if (nph == P.wd_copies) { ASTK_TRY(gemm_launch_group(GEMM_NT, ph, nph, s)); nph = 0; }      // (more phases than buffers: flush)
+        if (nph == P.wd_copies) {      // (more phases than buffers: flush)
+          launch_phase_w();
+          ASTK_LAUNCH_CHECK();
+          ASTK_TRY(gemm_launch_group(GEMM_NT, ph, nph, s));
+          nph = 0;
+        }
         float* wd = P.Wd + (size_t)nph * P.wd_stride;
         // (a_wd[k] is zeroed once per backward call: a slot that is reused -- more phases than buffers, a deeper stack -- keeps the larger
         //  of its users' maxima, i.e. a slightly conservative scale for phase weights of similar magnitude)
-        hipLaunchKernelGGL(k_phase_w, dim3(gridn((size_t)Ci * na * C / 8)), dim3(256), 0, s, L[i].W, wd, C, Ci, KT, r, st, na, P.a_wd[nph],
-                           folded ? nullptr : (const unsigned long long*)P.a_dy_s[i], P.a_dy[i]);
-        ASTK_LAUNCH_CHECK();
-        folded = true;
+        pj.wd[pj.n] = wd; pj.r[pj.n] = r; pj.na[pj.n] = na; pj.amax[pj.n] = P.a_wd[nph];
+        ++pj.n;
+        pj_na_max = std::max(pj_na_max, na);
         const long start = (long)(q0 - na + 1 + P.dF[i]);
         ASTK_CHECK(start >= 0, "cnn dgrad: negative window start");
         GemmArgs g = gemm_args(B * F * nj, Ci, na * C, mat2(P.DY[i] + start * C, nj, dyrow, C), mat(wd, (long)na * C),
@@ -1222,6 +1382,8 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
         ph[nph] = with_amax_b(with_amax_a(lowp(g), ady), P.a_wd[nph]);
         ++nph;
       }
+      launch_phase_w();
+      ASTK_LAUNCH_CHECK();
       if (!folded) ady = P.a_dy_s[i];      // (no phase kernel ran: the products read the strided slot itself)
       // ---- wgrad: dWr[co][kt*Ci+ci] = sum_rows DY[row][co] * window(row)[k]
       {
@@ -1230,11 +1392,16 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
         const long tiles = (long)cdiv(C, 128) * cdiv(KT * Ci, 128);
         ASTK_TRY(gemm_launch(GEMM_TN, with_amax_b(with_amax_a(lowp(gemm_args(C, KT * Ci, P.rowsc[i], A, Bm, P.dWr[i], (long)KT * Ci, nullptr, GEMM_ATOMIC, ksplit_for(tiles, P.rowsc[i]))), ady), P.a_hp[i - 1]), s));
       }
-      hipLaunchKernelGGL(k_unpack_dw, dim3(gridn((size_t)C * Ci * KT)), dim3(256), 0, s, P.dWr[i], Gr[i].dW, C, Ci, KT);
-      ASTK_LAUNCH_CHECK();
+      unpack_add(P.dWr[i], Gr[i].dW, C, Ci, KT, 0, 0);
       // ---- dgrad, part 2: one window GEMM per stride phase, all phases in one grouped launch
       if (nph > 0) ASTK_TRY(gemm_launch_group(GEMM_NT, ph, nph, s));
     }
+  }
+  if (uj.n > 0) {
+    hipLaunchKernelGGL(k_unpack_dw, dim3(gridn(uj_max), uj.n), dim3(256), 0, s, uj, persist_status_word(), d->status_dst);
+    ASTK_LAUNCH_CHECK();
+  } else if (d->status_dst) {
+    ASTK_TRY(status_snapshot_launch(d->status_dst, s));
   }
   return 0;
 }

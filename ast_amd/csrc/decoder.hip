@@ -24,6 +24,8 @@ struct DecPersistBuffers {
   unsigned* ctr;
   // two small buffers the forward launcher zeroes with its own fill launch (HT of step -1 and the first concat row: decoder.hip)
   void* zero_a; size_t zero_a_bytes; void* zero_b; size_t zero_b_bytes;
+  // ... and the initial states (n_layers, B, H) it copies into C[l] / HR[l] with the same launch (nullptr: the caller copied them)
+  const float *c0, *h0;
 };
 bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int* chunk_out);
 int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_params* prm, const float* enc, const int32_t* y,
@@ -384,6 +386,7 @@ int make_split(const astk_decoder_desc* d, void* ws, SplitPlan& sp) {
   const int Bs[2] = {B0, d->B - B0};
   for (int i = 0; i < 2; ++i) {
     sp.sub[i] = *d;
+    sp.sub[i].status_dst = nullptr;      // (the whole op's call takes the snapshot, once)
     sp.sub[i].B = Bs[i];
     sp.sub[i].loss_rows = d->loss_rows > 0 ? d->loss_rows : d->B;
     sp.off[i] = i == 0 ? 0 : B0;
@@ -458,9 +461,21 @@ int astk_decoder_fwd(const astk_decoder_desc* d, const astk_decoder_params* prm,
   return astk_decoder_fwd_ex(d, prm, enc, c0, h0, y, use_truth, emb_mask, rnn_masks, nullptr, nullptr, loss, pred, ws, ws_bytes, stream);
 }
 
+static int decoder_fwd_impl(const astk_decoder_desc* d, const astk_decoder_params* prm, const float* enc, const float* c0, const float* h0,
+                            const int32_t* y, const int32_t* use_truth, const float* emb_mask, const float* rnn_masks, const float* out_mask,
+                            const int32_t* targets, float* loss, int32_t* pred, void* ws, size_t ws_bytes, void* stream, bool* snapshot_taken);
 int astk_decoder_fwd_ex(const astk_decoder_desc* d, const astk_decoder_params* prm, const float* enc, const float* c0, const float* h0,
                         const int32_t* y, const int32_t* use_truth, const float* emb_mask, const float* rnn_masks, const float* out_mask,
                         const int32_t* targets, float* loss, int32_t* pred, void* ws, size_t ws_bytes, void* stream) {
+  bool taken = false;
+  ASTK_TRY(decoder_fwd_impl(d, prm, enc, c0, h0, y, use_truth, emb_mask, rnn_masks, out_mask, targets, loss, pred, ws, ws_bytes, stream, &taken));
+  // status_dst: the persistent loop's scoring kernel wrote it; every other path takes the snapshot with a launch behind the op
+  if (d->status_dst && !taken) ASTK_TRY(status_snapshot_launch(d->status_dst, (hipStream_t)stream));
+  return 0;
+}
+static int decoder_fwd_impl(const astk_decoder_desc* d, const astk_decoder_params* prm, const float* enc, const float* c0, const float* h0,
+                            const int32_t* y, const int32_t* use_truth, const float* emb_mask, const float* rnn_masks, const float* out_mask,
+                            const int32_t* targets, float* loss, int32_t* pred, void* ws, size_t ws_bytes, void* stream, bool* snapshot_taken) {
   hipStream_t s = (hipStream_t)stream;
   ASTK_CHECK(d, "decoder_fwd: null descriptor");
   PrecScope prec_scope(d->precision, d->gemm_operands);
@@ -497,23 +512,19 @@ int astk_decoder_fwd_ex(const astk_decoder_desc* d, const astk_decoder_params* p
   const size_t bh = (size_t)B * H;
   const int32_t* tgt = targets ? targets : y;       // class ids scored at step s: column s + 1
   // initial states and zero attention vector (seq2seq.py:318-333, :420)
-  {
-    CopySegs cp;
-    cp.n = 0;
+  int ns_ = 1, ch_ = 1;
+  const bool persist_path = !out_mask && decoder_persist_applicable(d, &ns_, &ch_);
+  if (!persist_path) {      // (the persistent launcher copies / zeroes them with its own fill launch: two launches less)
+    FillSegs fz;      // one launch: the two zero fills and the state copies
+    fz.n = 0;
+    fill_seg_add(fz, P.HT, (size_t)B * A * sizeof(float));
+    fill_seg_add(fz, P.X0, (size_t)B * XI * sizeof(float));   // ht_{-1} half of the first concat buffer
     for (int l = 0; l < nl; ++l) {
-      if (cp.n + 2 > FILL_SEG_MAX) { ASTK_TRY(copy_segments(cp, s)); cp.n = 0; }
-      copy_seg_add(cp, P.C[l], c0 + l * bh, bh * sizeof(float));
-      copy_seg_add(cp, P.HR[l], h0 + l * bh, bh * sizeof(float));
+      if (fz.n + 2 > FILL_SEG_MAX) { ASTK_TRY(fill_u32_segments(fz, 0u, s)); fz.n = 0; }
+      fill_seg_add_copy(fz, P.C[l], c0 + l * bh, bh * sizeof(float));
+      fill_seg_add_copy(fz, P.HR[l], h0 + l * bh, bh * sizeof(float));
     }
-    ASTK_TRY(copy_segments(cp, s));
-    int ns_ = 1, ch_ = 1;
-    if (!(!out_mask && decoder_persist_applicable(d, &ns_, &ch_))) {      // (the persistent launcher zeroes them with its own fill: one launch less)
-      FillSegs fz;
-      fz.n = 0;
-      fill_seg_add(fz, P.HT, (size_t)B * A * sizeof(float));
-      fill_seg_add(fz, P.X0, (size_t)B * XI * sizeof(float));   // ht_{-1} half of the first concat buffer
-      ASTK_TRY(fill_u32_segments(fz, 0u, s));
-    }
+    ASTK_TRY(fill_u32_segments(fz, 0u, s));
   }
   const int top = nl - 1;
   {
@@ -531,7 +542,9 @@ int astk_decoder_fwd_ex(const astk_decoder_desc* d, const astk_decoder_params* p
       bf.CESTAT = P.CESTAT; bf.ENCA = P.ENCA; bf.ML = P.MLB; bf.ctr = P.PCTR;
       bf.zero_a = P.HT; bf.zero_a_bytes = (size_t)B * A * sizeof(float);
       bf.zero_b = P.X0; bf.zero_b_bytes = (size_t)B * XI * sizeof(float);
+      bf.c0 = c0; bf.h0 = h0;
       ASTK_TRY(decoder_persist_fwd_launch(d, prm, enc, y, tgt, use_truth, emb_mask, rnn_masks, bf, loss, pred, s));   // (incl. loss sum and predictions)
+      *snapshot_taken = d->status_dst != nullptr;
       return 0;
     }
   }

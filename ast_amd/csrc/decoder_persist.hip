@@ -1584,8 +1584,10 @@ __global__ __launch_bounds__(256) void k_decoder_post(const float* __restrict__ 
                                                       const int32_t* __restrict__ pred, const float* __restrict__ emb_mask, int32_t* __restrict__ tok_out,
                                                       float* __restrict__ x0, float* __restrict__ logits, const float* __restrict__ lse,
                                                       const float* __restrict__ cw, const float* __restrict__ lossrows, float* __restrict__ loss,
-                                                      int32_t* __restrict__ pred_out, int S, int B, int L, int E, int XI, int V, int Vp, float inv_count) {
+                                                      int32_t* __restrict__ pred_out, int S, int B, int L, int E, int XI, int V, int Vp, float inv_count,
+                                                      const unsigned* __restrict__ status, float* __restrict__ status_dst) {
   const int r = blockIdx.x, s = r / B, b = r % B;
+  if (r == 0 && threadIdx.x == 0 && status_dst) *status_dst = (float)(*status);      // (astk_decoder_desc.status_dst: the snapshot without its launch)
   {
     int tok = (s == 0 || use_truth[s]) ? y[(long)b * L + s] : pred[(long)(s - 1) * B + b];
     tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
@@ -1635,6 +1637,8 @@ struct DecPersistBuffers {
   unsigned* ctr;
   // two small buffers the forward launcher zeroes with its own fill launch (HT of step -1 and the first concat row: decoder.hip)
   void* zero_a; size_t zero_a_bytes; void* zero_b; size_t zero_b_bytes;
+  // ... and the initial states (n_layers, B, H) it copies into C[l] / HR[l] with the same launch (nullptr: the caller copied them)
+  const float *c0, *h0;
 };
 
 static bool pdec_special(int H, int chunk) { return H == 512 && chunk <= PDEC_CHUNK_MAX; }     // the NC = 8 attention phase
@@ -1766,7 +1770,12 @@ int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, con
   a.ab = abort_ctl(bf.ctr + (size_t)NPHASE_SLOTS * NSH * a.nbt * CTRS, PERSIST_DEC_BWD);
   a.tick_out = prof_tick_buffer(1);
   a.dbg = persist_dbg_env();
-  ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)NPHASE_SLOTS * NSH * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), s));
+  {      // (a fill kernel, not hipMemsetAsync: the runtime's fill path left a 6 us gap in front of the launch)
+    FillSegs f;
+    f.n = 0;
+    fill_seg_add(f, bf.ctr, ((size_t)NPHASE_SLOTS * NSH * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned));
+    ASTK_TRY(fill_u32_segments(f, 0u, s));
+  }
   const size_t shm = pdec_bwd_lds_floats(chunk, a.H) * sizeof(float);       // slices + dS/cvS/ds + ds/alpha/fold of the specialised scan
   {
     ProfScope prof(PROF_DEC_BWD, s);
@@ -1816,9 +1825,27 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
     fill_seg_add(f, bf.CVH, (size_t)a.S * a.B * 2 * a.H * sizeof(float));
     if (bf.zero_a) fill_seg_add(f, bf.zero_a, bf.zero_a_bytes, 0u);
     if (bf.zero_b) fill_seg_add(f, bf.zero_b, bf.zero_b_bytes, 0u);
+    if (bf.c0 && bf.h0) {
+      const size_t bh = (size_t)d->B * d->H;
+      ASTK_CHECK(f.n + 2 * d->n_layers <= FILL_SEG_MAX, "decoder_persist: too many fill segments");
+      for (int l = 0; l < d->n_layers; ++l) {
+        fill_seg_add_copy(f, bf.C[l], bf.c0 + l * bh, bh * sizeof(float));
+        fill_seg_add_copy(f, bf.HR[l], bf.h0 + l * bh, bh * sizeof(float));
+      }
+    }
     ASTK_TRY(fill_u32_segments(f, PDEC_SENTINEL, s));
   }
 #else
+  if (bf.c0 && bf.h0) {
+    CopySegs cp;
+    cp.n = 0;
+    const size_t bh = (size_t)d->B * d->H;
+    for (int l = 0; l < d->n_layers; ++l) {
+      copy_seg_add(cp, bf.C[l], bf.c0 + l * bh, bh * sizeof(float));
+      copy_seg_add(cp, bf.HR[l], bf.h0 + l * bh, bh * sizeof(float));
+    }
+    ASTK_TRY(copy_segments(cp, s));
+  }
   ASTK_HIP(hipMemsetAsync(bf.ctr, 0, ((size_t)NPHASE_SLOTS * NSH * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), s));
   if (bf.zero_a) ASTK_HIP(hipMemsetAsync(bf.zero_a, 0, bf.zero_a_bytes, s));
   if (bf.zero_b) ASTK_HIP(hipMemsetAsync(bf.zero_b, 0, bf.zero_b_bytes, s));
@@ -1836,7 +1863,7 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
   // Q[s][b][:] = Wa h_top + ba for all steps (needed by the backward's deferred d_enc product)
   ASTK_TRY(gemm_launch(GEMM_NT, gemm_args(a.S * a.B, a.H, a.H, mat(bf.CVH + a.H, 2 * a.H), mat(prm->Wa, a.H), bf.Q, a.H, prm->ba), s));
   hipLaunchKernelGGL(k_decoder_post, dim3(a.S * a.B), dim3(256), 0, s, prm->embed, y, ytgt ? ytgt : y, use_truth, bf.PRED, emb_mask, bf.TOK, bf.X0, bf.LOGITS, bf.LSE,
-                     prm->class_weight, bf.LOSSROWS, loss, pred_out, a.S, a.B, a.L, a.E, a.XI, a.V, a.Vp, a.inv_count);
+                     prm->class_weight, bf.LOSSROWS, loss, pred_out, a.S, a.B, a.L, a.E, a.XI, a.V, a.Vp, a.inv_count, persist_status_word(), d->status_dst);
   ASTK_LAUNCH_CHECK();
   return 0;
 }

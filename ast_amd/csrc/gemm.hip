@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <vector>
 #include <type_traits>
 
 namespace astk {
@@ -436,6 +437,15 @@ struct Stager {
 // matrix pipe idled more than half of the time (163 instead of 118 TFLOP/s at 4096^3, against > 300 for an MFMA-bound loop).
 // MW: multiplying waves of a split-scheme workgroup, 4 (2 x 2 over the tile) or 8 (4 x 2: 256 x 128 tiles, two multiplying waves and one
 // staging wave per SIMD); the staging role always has 256 threads.
+// Split tiles without a zeroing launch (round 5; GemmGroup::tick): every (split tile, multiplying wave) has one word in a table that is zero
+// between launches -- bits 0-14 the k-iterations that have ARRIVED, bit 15 DONE, bits 16-31 the k-iterations that have DEPARTED.  A wave
+// with a partial sum adds its nk iterations to the arrivals.  Word was zero: it is the first -- it STORES its sub-tile (written through),
+// drains, then raises DONE with its departure.  Otherwise it waits for DONE (the first arrival is inside its epilogue: a bounded wait that
+// needs nobody else to be resident) and ADDS with atomics.  The departure that completes the tile's kt iterations writes the word back to
+// zero.  Two contributors: first + second, the same sum whoever came first.  (Before: a launch that zeroed the split tiles in front of every
+// such GEMM, 6 per train step and ~54 us, and the first arrival's 64 atomics per lane.)
+constexpr int TICK_WAVES = 8;
+constexpr unsigned TICK_DONE = 1u << 15;
 constexpr int gemm_mw(int TLM) { return TLM == 256 ? 8 : 4; }
 constexpr int gemm_threads(int PREC, int TLM = 128) { return PREC != PREC_F32 ? 256 + 64 * gemm_mw(TLM) : 256; }
 constexpr int gemm_min_waves(int TL, int PREC, int TLM) { return (PREC != PREC_F32 && TLM == 256) ? 3 : waves_per_simd(TL, PREC); }
@@ -547,6 +557,9 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
     // (GEMM_ACCUM goes out as atomic adds like the split tiles: a read-modify-write per element waits for its own load, 64 times per
     //  lane -- 6400 x 3072 x 1024: 306 us against 232 with atomics)
     const int mode = !whole || g.mode == GEMM_ACCUM ? GEMM_ATOMIC : g.mode;
+    // A split tile of a GEMM_STORE product under the ticket protocol (see "Split tiles without a zeroing launch" above the kernel)
+    const bool ticket = !whole && g.mode == GEMM_STORE && grp.tick != nullptr;
+    unsigned* const tick_word = ticket ? grp.tick + ((long)grp.tick_base[prob] + tile) * TICK_WAVES + wave : nullptr;
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     // (everything the element loop needs from the launch arguments is copied into locals first: read through `g`, a reference into
     //  the kernel-argument block, hipcc re-loads the field behind every global store -- the stores might alias it -- and waits for the
@@ -571,8 +584,20 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
         }
       }
       const int col0 = n0 + wn * WT + li;
+      bool tick_first = false;
+      if (ticket) {       // (wave-uniform) this wave's arrival at its quarter / eighth of the split tile
+        unsigned old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(tick_word, (unsigned)nk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+        tick_first = old == 0;
+        if (!tick_first && lane == 0) {      // the first arrival is inside its epilogue: a bounded wait
+          unsigned spins = 0;
+          while (!(__hip_atomic_load(tick_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & TICK_DONE) && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
+        }
+      }
       auto body = [&](auto storec) {          // one copy of the element loops per output mode (decided once per tile)
-        constexpr bool STORE = decltype(storec)::value;
+        constexpr int OUT = decltype(storec)::value;       // 0: atomic adds, 1: plain stores, 2: written-through stores (first arrival at a split tile)
+        constexpr bool STORE = OUT == 1;
 #pragma unroll
         for (int i = 0; i < NAM; ++i) {
 #pragma unroll
@@ -585,13 +610,24 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
             for (int j = 0; j < NA; ++j) {
               if (col0 + j * 32 >= e_N) continue;
               if constexpr (STORE) rp[j * 32] = acc[i][j][r];
+              else if constexpr (OUT == 2) __hip_atomic_store(rp + j * 32, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               else atomicAdd(rp + j * 32, acc[i][j][r]);
             }
           }
         }
       };
-      if (mode == GEMM_STORE) body(std::true_type{});
-      else body(std::false_type{});
+      if (mode == GEMM_STORE) body(std::integral_constant<int, 1>{});
+      else if (tick_first) body(std::integral_constant<int, 2>{});
+      else body(std::integral_constant<int, 0>{});
+      if (ticket) {
+        // departure: the first arrival's stores have landed (written through, drained) before DONE goes up; the departure that completes
+        // the tile's k-iterations puts the word back to zero for the next launch -- every contributor has passed its poll by then
+        if (tick_first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+          const unsigned old2 = __hip_atomic_fetch_add(tick_word, ((unsigned)nk << 16) | (tick_first ? TICK_DONE : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((int)(old2 >> 16) + nk == kt_tile) __hip_atomic_store(tick_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
     };
 
     if constexpr (SPLIT) {
@@ -1151,6 +1187,31 @@ __global__ __launch_bounds__(256) void k_absmax_zero(AmaxJobs jobs, GemmGroup gr
 
 }  // namespace
 
+// The ticket words of a stream's launches (zero between launches: the kernels leave them so).  One table per stream -- launches on one
+// stream run one after the other; it grows by being replaced behind a stream synchronisation.
+static unsigned* tick_table(hipStream_t s, size_t words) {
+  struct Table { hipStream_t s; unsigned* p; size_t words; };
+  static std::mutex mu;
+  static std::vector<Table> tables;
+  std::lock_guard<std::mutex> lock(mu);
+  Table* t = nullptr;
+  for (auto& e : tables)
+    if (e.s == s) t = &e;
+  if (!t) { tables.push_back(Table{s, nullptr, 0}); t = &tables.back(); }
+  if (t->words < words) {
+    if (t->p) {
+      if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+      (void)hipFree(t->p);
+      t->p = nullptr; t->words = 0;
+    }
+    const size_t n = std::max(words, (size_t)1 << 18);
+    if (hipMalloc((void**)&t->p, n * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(t->p, 0, n * sizeof(unsigned)) != hipSuccess) return nullptr;
+    t->words = n;
+  }
+  return t->p;
+}
+
 static int gemm_prepare(int layout, const GemmArgs& g, GemmArgs& a, bool& twolvl, int TLM, int TL) {
   ASTK_CHECK(g.A.p && g.B.p && g.C, "gemm: null operand");
   ASTK_CHECK(aligned16(g.A.p) && aligned16(g.B.p), "gemm: A/B must be 16-byte aligned");
@@ -1435,8 +1496,25 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     prof_add_bytes(PROF_GEMM, bytes);
   }
   dim3 grid((unsigned)G, 1, 1);
-  // GEMM_STORE + split tiles: the tiles several workgroups accumulate into are zeroed first (with the maximum pass when there is one)
-  const bool need_zero = !aligned && any_store && G > 1;
+  // GEMM_STORE + split tiles: the ticket protocol (kernel: "Split tiles without a zeroing launch"); ASTK_GEMM_TICKET=0 or a tile deeper than
+  // the arrival field: the tiles several workgroups accumulate into are zeroed first (with the maximum pass when there is one)
+  static const bool ticket_on = !(getenv("ASTK_GEMM_TICKET") && getenv("ASTK_GEMM_TICKET")[0] == '0');
+  grp.tick = nullptr;
+  bool need_zero = !aligned && any_store && G > 1;
+  if (need_zero && ticket_on) {
+    long ntiles = 0;
+    bool fits = true;
+    for (int i = 0; i < grp.n; ++i) {
+      grp.tick_base[i] = (int)ntiles;
+      ntiles += (grp.iter_start[i + 1] - grp.iter_start[i]) / grp.g[i].kt;
+      fits = fits && grp.g[i].kt < (int)TICK_DONE;
+    }
+    if (fits && ntiles < (1L << 27)) {
+      grp.tick = tick_table(s, (size_t)ntiles * TICK_WAVES);
+      ASTK_CHECK(grp.tick != nullptr, "gemm: no ticket table");
+      need_zero = false;
+    }
+  }
   bool zero_vec = true;
   for (int i = 0; i < grp.n; ++i) {
     const GemmArgs& a = grp.g[i];

@@ -245,8 +245,13 @@ __global__ void k_normal(float* out, size_t n, float mean, float sigma, uint64_t
 // Several independent fills of the two kinds above in ONE launch (the step's speech noise and its dropout masks: four launches of ~5-20 us
 // before).  Blocks are dealt to the segments in proportion to their sizes; every element gets exactly the value the single-segment kernels
 // give it (same counter), so fused and separate draws are interchangeable.
-struct RandJobs { int n; int blk_start[ASTK_RAND_SEG_MAX + 1]; astk_rand_seg s[ASTK_RAND_SEG_MAX]; };
+// (words: up to ASTK_RAND_WORDS_MAX host values that ride in the kernel arguments and are written to words_dst by block 0 -- the step's
+//  teacher-forcing flags, astk_fill_random_ex: a pinned-buffer copy of their own cost a launch and a cross-queue gap)
+struct RandJobs { int n; int blk_start[ASTK_RAND_SEG_MAX + 1]; astk_rand_seg s[ASTK_RAND_SEG_MAX]; int n_words; int32_t* words_dst; int32_t words[ASTK_RAND_WORDS_MAX]; };
 __global__ __launch_bounds__(256) void k_fill_random(RandJobs j) {
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < j.n_words; i += 256) j.words_dst[i] = j.words[i];
+  if (j.n == 0) return;
   int q = 0;
   while ((int)blockIdx.x >= j.blk_start[q + 1]) ++q;
   const astk_rand_seg sg = j.s[q];
@@ -299,6 +304,9 @@ __global__ void k_zero_frames_draws(int T, const int32_t* len, double rate, uint
 }
 
 // ---- optimizer
+constexpr unsigned SQNORM_BLOCKS = 512;
+__device__ double g_sq_part[SQNORM_BLOCKS];
+__device__ unsigned g_sq_ctr;
 __global__ void k_sqnorm(const float* g, const float* p, float gsc, float l2, size_t n, double* out) {
   __shared__ double red[4];
   double s = 0.0;
@@ -325,7 +333,26 @@ __global__ void k_sqnorm(const float* g, const float* p, float gsc, float l2, si
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  // Per-block partial sums, folded in block order by the block that arrives last: no zeroing launch in front (the counter goes back to
+  // zero here), and the norm is the same sum whatever order the blocks finish in.
+  __shared__ int last;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&g_sq_part[blockIdx.x], red[0] + red[1] + red[2] + red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // written through and acknowledged (no fence: its L2 write-back / invalidate costs 10 us here)
+    last = __hip_atomic_fetch_add(&g_sq_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  double t = 0.0;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) t += __hip_atomic_load(&g_sq_part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *out = (red[0] + red[1]) + (red[2] + red[3]);
+    __hip_atomic_store(&g_sq_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 __global__ void k_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, size_t n, float gsc, float l2, float clip,
@@ -336,20 +363,38 @@ __global__ void k_amsgrad(float* p, const float* g, float* m, float* v, float* v
   const float norm = (float)sqrt(*sqnorm);
   const float rate = clip / norm;                    // A7: r = c / n, applied only when r < 1
   const float gs = rate < 1.f ? rate : 1.f;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float pi = p[i];
-    const float gi = (__fmul_rn(g[i], gsc) + l2 * pi) * gs;
-    float mi = m[i], vi = v[i];
+  auto one = [&](float& pi, float gi_raw, float& mi, float& vi, float& vh) {      // vh: in = vhat (amsgrad), out = the denominator's v
+    const float gi = (__fmul_rn(gi_raw, gsc) + l2 * pi) * gs;
     mi += (1.f - b1) * (gi - mi);
     vi += (1.f - b2) * (gi * gi - vi);
+    vh = amsgrad ? fmaxf(vh, vi) : vi;
+    pi = pi - lr_t * mi / (sqrtf(vh) + eps);
+  };
+  const size_t stride = (size_t)gridDim.x * blockDim.x, tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  size_t done = 0;
+  // nine streams of 4 bytes per lane ran at 4.0 TB/s; 16 bytes per lane where the five arrays allow it (same arithmetic per element)
+  if (((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)(amsgrad ? vhat : p))) & 15) == 0) {
+    const size_t n4 = n / 4;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4 *m4 = reinterpret_cast<float4*>(m), *v4 = reinterpret_cast<float4*>(v), *h4 = reinterpret_cast<float4*>(vhat);
+    for (size_t i = tid; i < n4; i += stride) {
+      float4 P = p4[i], M = m4[i], V = v4[i], H = amsgrad ? h4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 G = g4[i];
+      one(P.x, G.x, M.x, V.x, H.x); one(P.y, G.y, M.y, V.y, H.y); one(P.z, G.z, M.z, V.z, H.z); one(P.w, G.w, M.w, V.w, H.w);
+      m4[i] = M; v4[i] = V;
+      if (amsgrad) h4[i] = H;
+      p4[i] = P;
+    }
+    done = n4 * 4;
+  }
+  for (size_t i = done + tid; i < n; i += stride) {
+    float pi = p[i], mi = m[i], vi = v[i], vh = amsgrad ? vhat[i] : 0.f;
+    one(pi, g[i], mi, vi, vh);
     m[i] = mi;
     v[i] = vi;
-    float vh = vi;
-    if (amsgrad) {
-      vh = fmaxf(vhat[i], vi);
-      vhat[i] = vh;
-    }
-    p[i] = pi - lr_t * mi / (sqrtf(vh) + eps);
+    if (amsgrad) vhat[i] = vh;
+    p[i] = pi;
   }
 }
 
@@ -394,6 +439,16 @@ __global__ __launch_bounds__(256) void k_fill_segments(FillSegs f, unsigned valu
   if (f.own[seg]) value = f.val[seg];
   const size_t n16 = f.bytes[seg] / 16;
   uint4* p = reinterpret_cast<uint4*>(f.p[seg]);
+  if (f.src[seg]) {      // a copy riding in this launch (fill_seg_add_copy)
+    const uint4* q = reinterpret_cast<const uint4*>(f.src[seg]);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = q[i];
+    if (blockIdx.x == 0) {
+      unsigned* w = reinterpret_cast<unsigned*>(f.p[seg]);
+      const unsigned* r = reinterpret_cast<const unsigned*>(f.src[seg]);
+      for (size_t i = n16 * 4 + threadIdx.x; i < f.bytes[seg] / 4; i += blockDim.x) w[i] = r[i];
+    }
+    return;
+  }
   const uint4 v = make_uint4(value, value, value, value);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
   if (blockIdx.x == 0) {   // tail words
@@ -406,7 +461,8 @@ __global__ __launch_bounds__(256) void k_fill_segments(FillSegs f, unsigned valu
 
 int fill_u32_segments(const FillSegs& f, unsigned value, hipStream_t s) {
   if (f.n <= 0) return 0;
-  for (int i = 0; i < f.n; ++i) ASTK_CHECK(aligned16(f.p[i]) && (f.bytes[i] % 4) == 0, "fill_u32_segments: segment %d must be 16-byte aligned, size a multiple of 4", i);
+  for (int i = 0; i < f.n; ++i)
+    ASTK_CHECK(aligned16(f.p[i]) && aligned16(f.src[i]) && (f.bytes[i] % 4) == 0, "fill_u32_segments: segment %d must be 16-byte aligned, size a multiple of 4", i);
   size_t mx = 0;
   for (int i = 0; i < f.n; ++i) mx = f.bytes[i] > mx ? f.bytes[i] : mx;
   unsigned gx = (unsigned)((mx / 16 + 256 * 8 - 1) / (256 * 8));
@@ -514,6 +570,17 @@ int ColsumBatch::flush(hipStream_t s) {
 
 }  // namespace astk
 
+namespace astk {
+const unsigned* persist_status_word() { return persist_status_ptr(); }
+int status_snapshot_launch(float* dst, hipStream_t s) {
+  unsigned* st = persist_status_ptr();
+  ASTK_CHECK(st, "persist_status: no status word");
+  hipLaunchKernelGGL(k_status_snapshot, dim3(1), dim3(1), 0, s, st, dst);
+  ASTK_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace astk
+
 using namespace astk;
 
 extern "C" {
@@ -528,8 +595,7 @@ int astk_grad_sqnorm_scaled(const float* g, const float* p, float grad_scale, fl
   hipStream_t s = (hipStream_t)stream;
   ASTK_CHECK(g && p && sqnorm, "grad_sqnorm: null pointer");
   ASTK_CHECK(aligned16(g) && aligned16(p), "grad_sqnorm: buffers must be 16-byte aligned");
-  ASTK_HIP(hipMemsetAsync(sqnorm, 0, sizeof(double), s));
-  hipLaunchKernelGGL(k_sqnorm, dim3(std::min(512u, grid_for(n / 4 + 1))), dim3(256), 0, s, g, p, grad_scale, l2, n, sqnorm);
+  hipLaunchKernelGGL(k_sqnorm, dim3(std::min(SQNORM_BLOCKS, grid_for(n / 4 + 1))), dim3(256), 0, s, g, p, grad_scale, l2, n, sqnorm);
   ASTK_LAUNCH_CHECK();
   return 0;
 }
@@ -584,9 +650,17 @@ int astk_fill_dropout_mask(float* out, size_t n, float ratio, uint64_t seed, uin
 }
 
 int astk_fill_random(const astk_rand_seg* segs, int n_segs, void* stream) {
-  ASTK_CHECK(segs && n_segs >= 0 && n_segs <= ASTK_RAND_SEG_MAX, "fill_random: %d segments (max %d)", n_segs, ASTK_RAND_SEG_MAX);
+  return astk_fill_random_ex(segs, n_segs, nullptr, 0, nullptr, stream);
+}
+int astk_fill_random_ex(const astk_rand_seg* segs, int n_segs, const int32_t* words, int n_words, int32_t* words_dst, void* stream) {
+  ASTK_CHECK((segs || n_segs == 0) && n_segs >= 0 && n_segs <= ASTK_RAND_SEG_MAX, "fill_random: %d segments (max %d)", n_segs, ASTK_RAND_SEG_MAX);
+  ASTK_CHECK(n_words >= 0 && n_words <= ASTK_RAND_WORDS_MAX && (n_words == 0 || (words && words_dst)), "fill_random: %d words (max %d)", n_words,
+             ASTK_RAND_WORDS_MAX);
   RandJobs j;
   memset(&j, 0, sizeof(j));
+  j.n_words = n_words;
+  j.words_dst = words_dst;
+  for (int i = 0; i < n_words; ++i) j.words[i] = words[i];
   for (int i = 0; i < n_segs; ++i) {
     const astk_rand_seg& g = segs[i];
     if (g.n == 0) continue;
@@ -597,9 +671,9 @@ int astk_fill_random(const astk_rand_seg* segs, int n_segs, void* stream) {
     j.blk_start[j.n + 1] = j.blk_start[j.n] + blocks;
     ++j.n;
   }
-  if (j.n == 0) return 0;
+  if (j.n == 0 && n_words == 0) return 0;
   for (int i = j.n; i < ASTK_RAND_SEG_MAX; ++i) j.blk_start[i + 1] = j.blk_start[j.n];
-  hipLaunchKernelGGL(k_fill_random, dim3((unsigned)j.blk_start[j.n]), dim3(256), 0, (hipStream_t)stream, j);
+  hipLaunchKernelGGL(k_fill_random, dim3((unsigned)std::max(1, j.blk_start[j.n])), dim3(256), 0, (hipStream_t)stream, j);
   ASTK_LAUNCH_CHECK();
   return 0;
 }
@@ -679,11 +753,7 @@ int astk_gemm_f32(int layout, int M, int N, int K, const float* A, long lda, con
 
 int astk_persist_status_snapshot(float* dst, void* stream) {
   ASTK_CHECK(dst, "persist_status_snapshot: null pointer");
-  unsigned* st = persist_status_ptr();
-  ASTK_CHECK(st, "persist_status: no status word");
-  hipLaunchKernelGGL(k_status_snapshot, dim3(1), dim3(1), 0, (hipStream_t)stream, st, dst);
-  ASTK_LAUNCH_CHECK();
-  return 0;
+  return status_snapshot_launch(dst, (hipStream_t)stream);
 }
 
 int astk_persist_status_merge(const float* summed, void* stream) {

@@ -233,6 +233,7 @@ class SpeechEncoderDecoder:
         self.rng_seed = 0x5EED
         self._rng_offset = 0
         self._predrawn = {}             # random tensors of the current train step drawn ahead in one launch (_predraw)
+        self._pending_flags = None      # the step's teacher-forcing flags on their way to the device with that launch
         self.bn_N = 0                   # training-mode forward passes so far = Chainer's BatchNormalization persistent N (A10)
         self.enc_states = None
         self.loss = 0
@@ -470,6 +471,9 @@ class SpeechEncoderDecoder:
                   ws_dec=int(lib.astk_decoder_workspace_bytes(C.byref(dd))))
         st.update(big)
         st.update(bs)
+        # the persistent kernels' status word rides in loss[1]: written by the decoder forward (the kernel that writes the loss) and once
+        # more by the CNN backward's last kernel -- include/astk.h status_dst, a launch less each than astk_persist_status_snapshot
+        dd.status_dst = cd.status_dst = bs["loss"].data_ptr() + 4
         assert st["ws_cnn"] and st["ws_lstm"] and st["ws_dec"], lib.astk_last_error().decode()
         self._shape_cache[key] = st
         return st
@@ -499,29 +503,35 @@ class SpeechEncoderDecoder:
         instead of up to five; the (seed, offset) counters are consumed in the order the separate draws used, so every value is the one
         they would have produced.  Injected tensors (parity tests) are left alone, as before."""
         self._predrawn = {}
-        if not config.train:
+        if not config.train and not (with_decoder and self._pending_flags is not None):
             return
         dr = self.cfg["dropout"]
         B, S = X_shape[0], L - 1
         want = []
-        if add_noise > 0 and "noise" not in self.inject:
+        if config.train and add_noise > 0 and "noise" not in self.inject:
             want.append(("noise", tuple(X_shape), _lib.RAND_NORMAL, 1.0, float(add_noise), self.rng_seed ^ 0xABCDEF))
         masks = [("enc_masks", (self.n_dirs, len(self.rnn_enc), st["T2"], B, self.h), dr["rnn"])]
         if with_decoder:
             masks += [("emb_mask", (S, B, self.E), dr["embed"]), ("rnn_masks", (len(self.rnn_dec), S, B, self.H), dr["rnn"]),
                       ("out_mask", (S, B, self.V), dr.get("out", 0))]
         for name, shape, ratio in masks:
-            if name not in self.inject and ratio and ratio > 0:
+            if config.train and name not in self.inject and ratio and ratio > 0:
                 want.append((name, shape, _lib.RAND_DROPOUT, float(ratio), 0.0, self.rng_seed))
-        if len(want) < 2 or len(want) > _lib.RAND_SEG_MAX:
+        flags = self._pending_flags if with_decoder else None
+        if len(want) > _lib.RAND_SEG_MAX or (len(want) < 2 and flags is None):
             return                                    # (a single draw keeps its own launch)
-        segs = (_lib.RandSeg * len(want))()
+        segs = (_lib.RandSeg * max(1, len(want)))()
         for i, (name, shape, kind, a, b, seed) in enumerate(want):
             t = self._pool("noise" if name == "noise" else "mask_" + name, shape)
             segs[i].out, segs[i].n, segs[i].kind, segs[i].a, segs[i].b = t.data_ptr(), t.numel(), kind, a, b
             segs[i].seed, segs[i].offset = seed & 0xFFFFFFFFFFFFFFFF, self._rng(t.numel())
             self._predrawn[name] = t
-        check(_lib.load().astk_fill_random(segs, len(want), self._stream()))
+        if flags is None:
+            check(_lib.load().astk_fill_random(segs, len(want), self._stream()))
+        else:
+            words = (C.c_int32 * len(flags))(*flags)
+            check(_lib.load().astk_fill_random_ex(segs, len(want), words, len(flags), _vp(st["flags"]), self._stream()))
+            self._pending_flags = None
 
     # ------------------------------------------------------------------ encoder (seq2seq.py:293-314)
     def _as_input(self, X):
@@ -708,10 +718,6 @@ class SpeechEncoderDecoder:
         y = y.to(self.device, torch.int32).contiguous()
         B, L = y.shape
         assert L >= 2, "targets need at least GO and EOS"
-        self._cur = {"L": L, "pending_L": True}
-        self.encode(X, add_noise=add_noise)
-        st = self._cur
-        self.init_decoder_state()
         S = L - 1
         # quirk Q4: one Python-`random` coin per step for 0 < i < L-2, truth otherwise (seq2seq.py:431-436).  With random_out > 0
         # (seq2seq.py:456-465) the SAME stream also decides, behind each step's coin, which targets >= 4 are replaced (draw ABOVE
@@ -737,7 +743,15 @@ class SpeechEncoderDecoder:
         else:
             flags = [int(random.random() < teach_ratio) if 0 < i < L - 2 else 1 for i in range(S)]
         self.use_truth = flags
-        self._upload_flags(st["flags"], flags)
+        # (the flags go to the device with the step's random tensors, in the kernel arguments of that one launch: _predraw)
+        self._pending_flags = flags if len(flags) <= _lib.RAND_WORDS_MAX else None
+        self._cur = {"L": L, "pending_L": True}
+        self.encode(X, add_noise=add_noise)
+        st = self._cur
+        self.init_decoder_state()
+        if self._pending_flags is not None or len(flags) > _lib.RAND_WORDS_MAX:      # (not taken by _predraw: a copy of their own)
+            self._pending_flags = None
+            self._upload_flags(st["flags"], flags)
         st["flags_host"] = (C.c_int32 * S)(*flags)          # the per-launch loop scores the teacher-forced steps behind the loop (astk.h)
         st["dd"].use_truth_host = C.cast(st["flags_host"], C.POINTER(C.c_int32))
         st["y"] = y
@@ -750,7 +764,7 @@ class SpeechEncoderDecoder:
         check(lib.astk_decoder_fwd_ex(C.byref(st["dd"]), C.byref(st["dp"]), _vp(st["enc_states"]), _vp(st["c0"]), _vp(st["h0"]),
                                       _vp(y), _vp(st["flags"]), _vp(st["emb_mask"]), _vp(st["rnn_masks"]), _vp(st["out_mask"]), _vp(targets),
                                       _vp(st["loss"]), _vp(st["pred"]), _vp(wd), wd.numel(), self._stream()))
-        check(lib.astk_persist_status_snapshot(C.c_void_p(st["loss"].data_ptr() + 4), self._stream()))
+        # (loss[1] = the persistent kernels' status word: written by the op itself, astk_decoder_desc.status_dst)
         self.loss = Loss(self, st["loss"])
         return self.loss
 
@@ -816,7 +830,7 @@ class SpeechEncoderDecoder:
             check(rc)
         if self.grad_buckets is not None:
             self.grad_buckets.launch("cnn")
-        check(lib.astk_persist_status_snapshot(C.c_void_p(st["loss"].data_ptr() + 4), s))
+        # (the status word once more, behind the backward recurrences: astk_cnn_desc.status_dst, written by the CNN backward's last kernel)
         if self.grad_buckets is not None:
             # ... and once more behind the gradient exchange, when the peers' words have been merged (GradBuckets.finish): every rank's
             # pair of THIS step then carries the merged word

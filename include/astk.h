@@ -111,6 +111,9 @@ typedef struct {
   int pool_t[ASTK_MAX_CNN_LAYERS], pool_f[ASTK_MAX_CNN_LAYERS];
   int precision;       /* ASTK_PREC_*: arithmetic of this op's products (0 = process default) */
   int gemm_operands;   /* ASTK_OPERANDS_* (0 = process default) */
+  float* status_dst;   /* optional (NULL = none): astk_conv_bn_relu_bwd(_sync) also leaves a copy of the persistent kernels' status word
+                          there, written by the op's last kernel -- astk_persist_status_snapshot without a launch of its own (the CNN
+                          backward is the train step's last op behind the recurrences).  Ignored by the forward call. */
 } astk_cnn_desc;
 
 typedef struct {
@@ -249,6 +252,9 @@ typedef struct {
                         scores every step with one product and one softmax-CE launch behind the loop.  Read during the call, not kept. */
   int precision;       /* ASTK_PREC_*: the batched products around the loop (encA, weight gradients, d_enc); the loop itself is IEEE f32 */
   int gemm_operands;   /* ASTK_OPERANDS_* (0 = process default) */
+  float* status_dst;   /* optional (NULL = none): astk_decoder_fwd(_ex) also leaves a copy of the persistent kernels' status word there (the
+                          Python shim passes &loss[1]), written by the kernel that writes the loss when the persistent loop runs --
+                          astk_persist_status_snapshot without a launch of its own.  Ignored by the backward calls. */
 } astk_decoder_desc;
 
 typedef struct {
@@ -393,6 +399,11 @@ typedef struct {
   uint64_t seed, offset;
 } astk_rand_seg;
 int astk_fill_random(const astk_rand_seg* segs, int n_segs, void* stream);
+/* ... and, in the same launch, n_words (<= ASTK_RAND_WORDS_MAX) HOST values written to the device array words_dst: the step's
+ * teacher-forcing flags (seq2seq.py:431-436 draws them on the host) travel in the kernel arguments instead of a copy of their own.
+ * n_segs may be 0. */
+#define ASTK_RAND_WORDS_MAX 256
+int astk_fill_random_ex(const astk_rand_seg* segs, int n_segs, const int32_t* words, int n_words, int32_t* words_dst, void* stream);
 int astk_scale_f32(float* x, size_t n, float s, void* stream);
 /* dst += src (n floats); dst[c] += sum_r src[r*lds + c] (bias gradients; the sum over time of the linear_proj encoder's reverse-stack
  * input gradient, whose input is one frame fed at every step). */

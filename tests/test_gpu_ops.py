@@ -870,6 +870,26 @@ def test_gemm_hybrid_schedule_whole_tile_waves_and_stream_k_remainder(lib, layou
     assert float(c[:, :, N:].abs().max()) == 0.0, "wrote outside N"
 
 
+@pytest.mark.parametrize("M,N,K", [(4100, 1150, 332), (300, 260, 20000), (130, 70, 5000), (8200, 1930, 1100)])
+def test_gemm_split_tiles_need_no_zeroing_and_leave_their_ticket_words_clean(lib, M, N, K, gemm_split):
+    """Store-mode products whose tiles are shared by several workgroups (stream-K ranges: two contributors per tile in the first shape,
+    tens in the deep ones; the last runs the 12-wave kernel under the default arithmetic) write NaN-poisoned outputs: the first arrival
+    at a split tile stores, the others add behind it (round 5, gemm.hip "Split tiles without a zeroing launch").  Twenty launches in a
+    row into the same poisoned buffer: a ticket word left non-zero by one launch would make the next one add onto the NaNs."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    ref = (torch.from_numpy(A).double() @ torch.from_numpy(B).double().T).numpy()
+    a, b = dev(A), dev(B)
+    ldc = (N + 3) // 4 * 4 + 4
+    for rep in range(20):
+        c = torch.full((M, ldc), float("nan"), device="cuda")
+        ok(lib, lib.astk_gemm_f32(0, M, N, K, vp(a), K, vp(b), K, vp(c), ldc, None, 0, 1, 1, 0, 0, 0, stream()))
+        assert bool(torch.isnan(c[:, N:]).all()), "wrote outside N"
+        assert bool(torch.isfinite(c[:, :N]).all()), f"launch {rep}: a split tile was added onto instead of stored"
+        close(c[:, :N], ref, rtol=2e-5, msg=f"launch {rep}")
+
+
 @pytest.mark.parametrize("layout", [0, 1, 2])
 def test_gemm_twelve_wave_256x128_kernel_on_a_big_ragged_product(lib, layout):
     """Launches of 20 GFLOP and more run 256 x 128 tiles on the 12-wave kernel (8 multiplying + 4 staging waves, round 5) under the default
