@@ -222,24 +222,37 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 }
 __device__ __forceinline__ float u01(uint64_t bits) { return (float)((bits >> 40) + 1) * (1.0f / 16777217.0f); }  // (0,1)
 
-__global__ void k_dropout_mask(float* out, size_t n, float ratio, float scale, uint64_t seed, uint64_t offset) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float u = u01(mix64(seed ^ mix64(offset + i)));
-    out[i] = u >= ratio ? scale : 0.f;
+// Dropout keep-masks: element i of a fill is a function of (seed, g = offset + i) alone -- the two halves of ONE 64-bit hash of the pair
+// g >> 1 serve the counters 2 (g >> 1) and 2 (g >> 1) + 1 (round 5: the hash is 16 quarter-rate integer multiplies, and one hash per
+// element made the 39 MB of encoder masks a 25 us compute-bound fill; fused and separate fills still agree element by element).
+__device__ __forceinline__ float u01_32(unsigned bits) { return (float)((bits >> 8) + 1) * (1.0f / 16777217.0f); }  // (0,1)
+__device__ __forceinline__ void dropout_fill(float* out, size_t n, float ratio, float scale, uint64_t seed, uint64_t offset, size_t first, size_t stride) {
+  if (n == 0) return;
+  const uint64_t p0 = offset >> 1, npairs = ((offset + n - 1) >> 1) - p0 + 1;
+  for (uint64_t j = first; j < npairs; j += stride) {
+    const uint64_t pr = p0 + j, h = mix64(seed ^ mix64(pr));
+    const uint64_t g0 = 2 * pr, g1 = g0 + 1;
+    if (g0 >= offset) out[g0 - offset] = u01_32((unsigned)h) >= ratio ? scale : 0.f;
+    if (g1 < offset + n) out[g1 - offset] = u01_32((unsigned)(h >> 32)) >= ratio ? scale : 0.f;
   }
 }
+__global__ void k_dropout_mask(float* out, size_t n, float ratio, float scale, uint64_t seed, uint64_t offset) {
+  dropout_fill(out, n, ratio, scale, seed, offset, blockIdx.x * (size_t)blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+}
 
+// Box-Muller pair i of a normal fill: both uniforms from ONE hash (its halves), the hardware's log2 / sin / cos (the sine unit takes its
+// argument in turns, u2 itself); absolute error ~1e-6 of a unit normal, far below what a noise tensor can tell apart (round 5: libdevice's
+// logf / sincosf with their range reductions made the 2 M noise values the slowest segment of the step's fused fill).
+__device__ __forceinline__ void normal_pair(float* out, size_t n, float mean, float sigma, uint64_t seed, uint64_t offset, size_t i) {
+  const uint64_t b = mix64(seed ^ mix64(offset + i));
+  const float u1 = u01_32((unsigned)b), u2 = u01_32((unsigned)(b >> 32));
+  const float r = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));      // -2 ln u1 = -2 ln2 log2 u1
+  out[2 * i] = mean + sigma * r * __builtin_amdgcn_cosf(u2);
+  if (2 * i + 1 < n) out[2 * i + 1] = mean + sigma * r * __builtin_amdgcn_sinf(u2);
+}
 __global__ void k_normal(float* out, size_t n, float mean, float sigma, uint64_t seed, uint64_t offset) {
   const size_t pairs = (n + 1) / 2;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
-    const uint64_t b = mix64(seed ^ mix64(offset + i));
-    const float u1 = u01(b), u2 = u01(mix64(b));
-    const float r = sqrtf(-2.f * logf(u1));
-    float sn, cs;
-    sincosf(6.2831853071795864f * u2, &sn, &cs);
-    out[2 * i] = mean + sigma * r * cs;
-    if (2 * i + 1 < n) out[2 * i + 1] = mean + sigma * r * sn;
-  }
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) normal_pair(out, n, mean, sigma, seed, offset, i);
 }
 
 // Several independent fills of the two kinds above in ONE launch (the step's speech noise and its dropout masks: four launches of ~5-20 us
@@ -257,22 +270,10 @@ __global__ __launch_bounds__(256) void k_fill_random(RandJobs j) {
   const astk_rand_seg sg = j.s[q];
   const size_t nblk = (size_t)(j.blk_start[q + 1] - j.blk_start[q]), blk = blockIdx.x - j.blk_start[q];
   if (sg.kind == ASTK_RAND_DROPOUT) {
-    const float scale = 1.f / (1.f - sg.a);
-    for (size_t i = blk * 256 + threadIdx.x; i < sg.n; i += nblk * 256) {
-      const float u = u01(mix64(sg.seed ^ mix64(sg.offset + i)));
-      sg.out[i] = u >= sg.a ? scale : 0.f;
-    }
+    dropout_fill(sg.out, sg.n, sg.a, 1.f / (1.f - sg.a), sg.seed, sg.offset, blk * 256 + threadIdx.x, nblk * 256);
   } else {
     const size_t pairs = (sg.n + 1) / 2;
-    for (size_t i = blk * 256 + threadIdx.x; i < pairs; i += nblk * 256) {
-      const uint64_t b = mix64(sg.seed ^ mix64(sg.offset + i));
-      const float u1 = u01(b), u2 = u01(mix64(b));
-      const float r = sqrtf(-2.f * logf(u1));
-      float sn, cs;
-      sincosf(6.2831853071795864f * u2, &sn, &cs);
-      sg.out[2 * i] = sg.a + sg.b * r * cs;
-      if (2 * i + 1 < sg.n) sg.out[2 * i + 1] = sg.a + sg.b * r * sn;
-    }
+    for (size_t i = blk * 256 + threadIdx.x; i < pairs; i += nblk * 256) normal_pair(sg.out, sg.n, sg.a, sg.b, sg.seed, sg.offset, i);
   }
 }
 
@@ -665,7 +666,7 @@ int astk_fill_random_ex(const astk_rand_seg* segs, int n_segs, const int32_t* wo
     const astk_rand_seg& g = segs[i];
     if (g.n == 0) continue;
     ASTK_CHECK(g.out && (g.kind == ASTK_RAND_NORMAL || (g.kind == ASTK_RAND_DROPOUT && g.a >= 0.f && g.a < 1.f)), "fill_random: bad segment %d", i);
-    const size_t work = g.kind == ASTK_RAND_NORMAL ? (g.n + 1) / 2 : g.n;
+    const size_t work = (g.n + 1) / 2;        // both kinds produce two elements per hash
     const int blocks = (int)std::min<size_t>(2048, std::max<size_t>(1, (work + 2047) / 2048));      // ~8 elements per thread, bounded
     j.s[j.n] = g;
     j.blk_start[j.n + 1] = j.blk_start[j.n] + blocks;

@@ -359,3 +359,93 @@ def wide_decoder_bwd_procs(W=4, B=2, nsplit=2, p1_items=(0, 1), p3_items=(2,), d
                 a.append(("add", ("dpre", j % NSH)))
         procs.append(a)
     return procs, mem
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# Split tiles of the stream-K GEMMs (ast_amd/csrc/gemm.hip, "Split tiles without a zeroing launch").  One process per contributing
+# workgroup (per multiplying wave, really: every wave runs the protocol on its own word); the processes BRANCH on what their atomics
+# return, so this model has its own little explorer.  Word fields: arrived k-iterations, DONE, departed k-iterations.
+#   step 0  old = fetch_add(word, nk)                            first = (old word == 0)
+#   first:  step 1 store the sub-tile     step 2 fetch_add(word, DONE | nk << 16)
+#   others: step 1 wait for DONE          step 2 add onto the sub-tile      step 3 fetch_add(word, nk << 16)
+#   the departure that completes kt iterations writes the word back to zero
+# Violations: a contribution added onto a tile nobody has stored yet, a store onto a tile that already holds data, a wave left waiting
+# for a DONE that can no longer come (deadlock), a word that is not zero -- or a tile that is not the sum of all contributions -- at the end.
+def explore_gemm_ticket(nks, launches=2, reset_by="departure", done_before_store=False, max_states=2_000_000):
+    """nks: k-iterations of the contributors of ONE split tile.  launches: the same word serves this many launches one after the other
+    (stream order: a launch starts when the one before has finished).  reset_by="arrival": the (wrong) variant in which the contributor
+    whose ARRIVAL completes the tile resets the word behind its own add.  done_before_store: the (wrong) variant in which the first
+    arrival raises DONE in front of its stores.  Returns the number of states visited; raises Violation."""
+    n, kt = len(nks), sum(nks)
+    visited = 0
+    for launch in range(launches):
+        # state: (pcs, firsts, olds, word=(arrived, done, departed), tile=(stored, adds))
+        start = (tuple([0] * n), tuple([False] * n), tuple([0] * n), (0, False, 0), (False, 0))
+        seen, stack = {start}, [start]
+        while stack:
+            pcs, firsts, olds, word, tile = stack.pop()
+            arrived, done, departed = word
+            stored, adds = tile
+            enabled = False
+            finished = all(pc == 99 for pc in pcs)
+            if finished:
+                if word != (0, False, 0):
+                    raise Violation(f"launch {launch}: ticket word left as {word}")
+                if not stored or adds != n - 1:
+                    raise Violation(f"launch {launch}: tile holds {tile}, not one store and {n - 1} adds")
+                continue
+            for i in range(n):
+                pc, nk = pcs[i], nks[i]
+                if pc == 99:
+                    continue
+                nword, ntile, nfirst, nold, npc = word, tile, firsts[i], olds[i], None
+                if pc == 0:                                   # arrival
+                    nfirst = word == (0, False, 0)
+                    nold = arrived
+                    nword = (arrived + nk, done, departed)
+                    npc = 1
+                elif firsts[i]:
+                    store_pc, done_pc = (2, 1) if done_before_store else (1, 2)
+                    if pc == store_pc:
+                        if stored or adds:
+                            raise Violation(f"launch {launch}: contributor {i} stores onto a tile that holds data {tile}")
+                        ntile = (True, adds)
+                        npc = 99 if done_before_store else 2
+                    elif pc == done_pc:                        # DONE goes up with the first arrival's departure
+                        nword = (arrived, True, departed + nk)
+                        if departed + nk == kt:
+                            nword = (0, False, 0)
+                        npc = 2 if done_before_store else 99
+                else:
+                    if pc == 1:                                # poll
+                        if not done:
+                            continue
+                        npc = 2
+                    elif pc == 2:                              # atomic adds
+                        if not stored:
+                            raise Violation(f"launch {launch}: contributor {i} adds onto a tile nobody has stored")
+                        ntile = (stored, adds + 1)
+                        if reset_by == "arrival":
+                            if olds[i] + nk == kt:
+                                nword = (0, False, 0)
+                            npc = 99
+                        else:
+                            npc = 3
+                    elif pc == 3:                              # departure
+                        nword = (arrived, done, departed + nk)
+                        if departed + nk == kt:
+                            nword = (0, False, 0)
+                        npc = 99
+                enabled = True
+                lp, lf, lo = list(pcs), list(firsts), list(olds)
+                lp[i], lf[i], lo[i] = npc, nfirst, nold
+                st = (tuple(lp), tuple(lf), tuple(lo), nword, ntile)
+                if st not in seen:
+                    seen.add(st)
+                    if len(seen) > max_states:
+                        raise RuntimeError(f"state space larger than {max_states}")
+                    stack.append(st)
+            if not enabled:
+                raise Violation(f"launch {launch}: deadlock, contributors at steps {pcs} with word {word}")
+        visited += len(seen)
+    return visited

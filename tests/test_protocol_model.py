@@ -2,13 +2,14 @@
   * the encoder backward's own-cell hand-off (data-as-flag ring / counter A) and its down-partials counter B, two layers,
   * the h = 512 form of the same kernel (counters on both hand-offs, no early fetch),
   * the wide decoder's phase counters, forward and backward loop,
+  * the ticket words of the stream-K GEMMs' split tiles (round 5: first arrival stores, the others add behind its DONE bit),
 is enumerated; no consumer may read a slot that does not carry its step's data, no slot may be overwritten before its reader is done
 with it, nobody may dead-lock.  The round-4 race (the LAST arrival on counter B needs nothing from the peers) is found by the model
 when the fix is taken out of it.  DESIGN.md, section "Hand-off protocols", states the invariants these models encode; the kernels are
 ast_amd/csrc/lstm_persist.hip (lstm_bwd_rs_steps) and ast_amd/csrc/decoder_wide.hip."""
 import pytest
 
-from protocol_model import Violation, encoder_backward_procs, explore, wide_decoder_bwd_procs, wide_decoder_fwd_procs
+from protocol_model import Violation, encoder_backward_procs, explore, explore_gemm_ticket, wide_decoder_bwd_procs, wide_decoder_fwd_procs
 
 
 def test_own_cell_sentinel_ring_needs_three_slots():
@@ -82,3 +83,17 @@ def test_wide_decoder_backward_phase_counters():
         return a
     with pytest.raises(Violation):
         explore([[short(a) for a in p] for p in procs], mem)
+
+
+@pytest.mark.parametrize("nks", [(3, 5), (2, 2, 4), (1, 6, 2, 3), (4, 1, 1, 1, 1)])
+def test_gemm_split_tile_ticket_word(nks):
+    """Split tiles of the stream-K GEMMs without a zeroing launch (gemm.hip): whoever arrives first -- in every interleaving of 2 to 5
+    contributors -- stores, nobody adds before those stores are out, nobody is left polling, and the word is back at zero for the next
+    launch.  Two wrong variants must be caught: (a) DONE raised in front of the stores, (b) the word reset by the contributor whose
+    ARRIVAL completes the tile (a slower contributor that has arrived but not yet seen DONE then polls a word that has been cleared)."""
+    assert explore_gemm_ticket(nks) > 2 * len(nks)
+    with pytest.raises(Violation, match="nobody has stored"):
+        explore_gemm_ticket(nks, done_before_store=True)
+    if len(nks) >= 3:
+        with pytest.raises(Violation, match="deadlock|ticket word"):
+            explore_gemm_ticket(nks, reset_by="arrival")
