@@ -444,6 +444,21 @@ struct Stager {
 // needs nobody else to be resident) and ADDS with atomics.  The departure that completes the tile's kt iterations writes the word back to
 // zero.  Two contributors: first + second, the same sum whoever came first.  (Before: a launch that zeroed the split tiles in front of every
 // such GEMM, 6 per train step and ~54 us, and the first arrival's 64 atomics per lane.)
+// MEASURED AND SWITCHED OFF (ASTK_GEMM_TICKET = 0, the zeroing launch stays): same box, same call, bench.py events over the family --
+// zeroing launch 2.56-2.58 ms; ticket protocol with the release fence the first arrival's plain stores need (L2 write-back of the whole
+// XCD) 2.63; without the fence (wrong: the stores can sit in one XCD's L2 while the adds land in memory) 2.53-2.57; with the first arrival's
+// stores written through (sc1) or as atomic exchanges instead of the fence -- a THIRD copy of the element loops -- 2.73: the 168-register
+// kernel's epilogue then spills ~60 values around the loops and every reload waits, by s_waitcnt vmcnt(0), for the epilogue's own stores.
+// The arrivals' round trips cost what the zeroing launches cost; the protocol itself is correct (tests/protocol_model.py, -m gpu test).
+// The instrumented build (libastk_test.so, -DASTK_TEST_HOOKS) compiles it IN, so that the protocol keeps being exercised on the GPU
+// (test_gemm_split_tiles_ticket_protocol_on_the_instrumented_build).
+#ifndef ASTK_GEMM_TICKET
+#ifdef ASTK_TEST_HOOKS
+#define ASTK_GEMM_TICKET 1
+#else
+#define ASTK_GEMM_TICKET 0
+#endif
+#endif
 constexpr int TICK_WAVES = 8;
 constexpr unsigned TICK_DONE = 1u << 15;
 constexpr int gemm_mw(int TLM) { return TLM == 256 ? 8 : 4; }
@@ -558,8 +573,10 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
     //  lane -- 6400 x 3072 x 1024: 306 us against 232 with atomics)
     const int mode = !whole || g.mode == GEMM_ACCUM ? GEMM_ATOMIC : g.mode;
     // A split tile of a GEMM_STORE product under the ticket protocol (see "Split tiles without a zeroing launch" above the kernel)
-    const bool ticket = !whole && g.mode == GEMM_STORE && grp.tick != nullptr;
-    unsigned* const tick_word = ticket ? grp.tick + ((long)grp.tick_base[prob] + tile) * TICK_WAVES + wave : nullptr;
+    // (carried through the k loop as ONE scalar: the word's index, -1 = no ticket; the address is formed in the epilogue -- `wave` is a
+    //  vector value to the compiler, and a per-lane 64-bit address alive through the loop costs the 168-register kernel two registers it
+    //  does not have: 60-100 spilled registers and a family 7 % slower, measured)
+    const int tick_idx = (ASTK_GEMM_TICKET && !whole && g.mode == GEMM_STORE && grp.tick != nullptr) ? (grp.tick_base[prob] + (int)tile) * TICK_WAVES : -1;
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     // (everything the element loop needs from the launch arguments is copied into locals first: read through `g`, a reference into
     //  the kernel-argument block, hipcc re-loads the field behind every global store -- the stores might alias it -- and waits for the
@@ -584,20 +601,36 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
         }
       }
       const int col0 = n0 + wn * WT + li;
+      // Ticket protocol of a split GEMM_STORE tile.  The element loops below are the two the kernel always had (plain stores / atomic
+      // adds), byte for byte: a third copy with written-through stores, or ticket state alive across them, pushed the 168-register kernel's
+      // epilogue over its budget -- 100 scratch reloads, each behind an s_waitcnt vmcnt(0) that also drains the epilogue's own stores: the
+      // whole family 7 % slower (measured, same box).  So: arrive (and, not being first, wait for DONE) in FRONT of the loops; the first
+      // arrival runs the plain-store copy and makes it visible with one release fence (L2 write-back) behind them; the word's address is
+      // formed twice, each time from the one scalar that crossed the k loop.
+      // Round trips on the way: ONE for the usual second arrival (its arrival returns a word with DONE up and everybody before it
+      // departed: no poll, and it knows it is the last to leave -- its reset is a plain store), one plus the fence for the first (its
+      // departure returns nothing it needs: nobody can have departed before DONE).
       bool tick_first = false;
-      if (ticket) {       // (wave-uniform) this wave's arrival at its quarter / eighth of the split tile
-        unsigned old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(tick_word, (unsigned)nk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-        tick_first = old == 0;
-        if (!tick_first && lane == 0) {      // the first arrival is inside its epilogue: a bounded wait
-          unsigned spins = 0;
-          while (!(__hip_atomic_load(tick_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & TICK_DONE) && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
+      int tick_last = 0;        // 1: the arrival already showed that this wave is the last to leave
+      if constexpr (ASTK_GEMM_TICKET) {
+        int tick_i = tick_idx;
+        asm volatile("" : "+s"(tick_i));      // (opaque: nothing below is formed in front of the loop)
+        if (tick_i >= 0) {       // (wave-uniform) this wave's arrival at its quarter / eighth of the split tile
+          unsigned* const tick_word = grp.tick + tick_i + __builtin_amdgcn_readfirstlane(wave);
+          unsigned old = 0;
+          if (lane == 0) old = __hip_atomic_fetch_add(tick_word, (unsigned)nk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+          tick_first = old == 0;
+          const int arrived = (int)(old & (TICK_DONE - 1u)), departed = (int)(old >> 16);
+          tick_last = (old & TICK_DONE) != 0u && departed == arrived && arrived + nk == kt_tile;
+          if (!tick_first && !(old & TICK_DONE) && lane == 0) {      // the first arrival is inside its epilogue: a bounded wait
+            unsigned spins = 0;
+            while (!(__hip_atomic_load(tick_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & TICK_DONE) && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
+          }
         }
       }
       auto body = [&](auto storec) {          // one copy of the element loops per output mode (decided once per tile)
-        constexpr int OUT = decltype(storec)::value;       // 0: atomic adds, 1: plain stores, 2: written-through stores (first arrival at a split tile)
-        constexpr bool STORE = OUT == 1;
+        constexpr bool STORE = decltype(storec)::value;
 #pragma unroll
         for (int i = 0; i < NAM; ++i) {
 #pragma unroll
@@ -610,22 +643,32 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
             for (int j = 0; j < NA; ++j) {
               if (col0 + j * 32 >= e_N) continue;
               if constexpr (STORE) rp[j * 32] = acc[i][j][r];
-              else if constexpr (OUT == 2) __hip_atomic_store(rp + j * 32, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               else atomicAdd(rp + j * 32, acc[i][j][r]);
             }
           }
         }
       };
-      if (mode == GEMM_STORE) body(std::integral_constant<int, 1>{});
-      else if (tick_first) body(std::integral_constant<int, 2>{});
-      else body(std::integral_constant<int, 0>{});
-      if (ticket) {
-        // departure: the first arrival's stores have landed (written through, drained) before DONE goes up; the departure that completes
-        // the tile's k-iterations puts the word back to zero for the next launch -- every contributor has passed its poll by then
-        if (tick_first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) {
-          const unsigned old2 = __hip_atomic_fetch_add(tick_word, ((unsigned)nk << 16) | (tick_first ? TICK_DONE : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((int)(old2 >> 16) + nk == kt_tile) __hip_atomic_store(tick_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (mode == GEMM_STORE || tick_first) body(std::true_type{});
+      else body(std::false_type{});
+      if constexpr (ASTK_GEMM_TICKET) {
+        int tick_i = tick_idx;
+        asm volatile("" : "+s"(tick_i));
+        if (tick_i >= 0) {
+          // departure: the first arrival's stores are in memory (release fence: this XCD's L2 written back, stores drained) before DONE goes
+          // up; the departure that completes the tile's k-iterations puts the word back to zero for the next launch -- every contributor
+          // has passed its poll by then
+          unsigned* const tick_word = grp.tick + tick_i + __builtin_amdgcn_readfirstlane(wave);
+          if (tick_first) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          if (lane == 0) {
+            if (tick_first) {
+              (void)__hip_atomic_fetch_add(tick_word, ((unsigned)nk << 16) | TICK_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (no one left before DONE: not the last)
+            } else if (tick_last) {
+              __hip_atomic_store(tick_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+              const unsigned old2 = __hip_atomic_fetch_add(tick_word, (unsigned)nk << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if ((int)(old2 >> 16) + nk == kt_tile) __hip_atomic_store(tick_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
         }
       }
     };
@@ -1496,9 +1539,9 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     prof_add_bytes(PROF_GEMM, bytes);
   }
   dim3 grid((unsigned)G, 1, 1);
-  // GEMM_STORE + split tiles: the ticket protocol (kernel: "Split tiles without a zeroing launch"); ASTK_GEMM_TICKET=0 or a tile deeper than
-  // the arrival field: the tiles several workgroups accumulate into are zeroed first (with the maximum pass when there is one)
-  static const bool ticket_on = !(getenv("ASTK_GEMM_TICKET") && getenv("ASTK_GEMM_TICKET")[0] == '0');
+  // GEMM_STORE + split tiles: the tiles several workgroups accumulate into are zeroed first (with the maximum pass when there is one).
+  // (Builds with -DASTK_GEMM_TICKET=1: the ticket protocol instead -- kernel: "Split tiles without a zeroing launch", measured, off.)
+  static const bool ticket_on = ASTK_GEMM_TICKET && !(getenv("ASTK_GEMM_TICKET") && getenv("ASTK_GEMM_TICKET")[0] == '0');
   grp.tick = nullptr;
   bool need_zero = !aligned && any_store && G > 1;
   if (need_zero && ticket_on) {

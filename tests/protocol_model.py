@@ -368,7 +368,8 @@ def wide_decoder_bwd_procs(W=4, B=2, nsplit=2, p1_items=(0, 1), p3_items=(2,), d
 #   step 0  old = fetch_add(word, nk)                            first = (old word == 0)
 #   first:  step 1 store the sub-tile     step 2 fetch_add(word, DONE | nk << 16)
 #   others: step 1 wait for DONE          step 2 add onto the sub-tile      step 3 fetch_add(word, nk << 16)
-#   the departure that completes kt iterations writes the word back to zero
+#   the departure that completes kt iterations writes the word back to zero; a wave whose ARRIVAL already returned "DONE up, everybody
+#   before me departed, my iterations complete the tile" skips step 3 and writes the zero itself (one round trip less on the usual path)
 # Violations: a contribution added onto a tile nobody has stored yet, a store onto a tile that already holds data, a wave left waiting
 # for a DONE that can no longer come (deadlock), a word that is not zero -- or a tile that is not the sum of all contributions -- at the end.
 def explore_gemm_ticket(nks, launches=2, reset_by="departure", done_before_store=False, max_states=2_000_000):
@@ -380,7 +381,7 @@ def explore_gemm_ticket(nks, launches=2, reset_by="departure", done_before_store
     visited = 0
     for launch in range(launches):
         # state: (pcs, firsts, olds, word=(arrived, done, departed), tile=(stored, adds))
-        start = (tuple([0] * n), tuple([False] * n), tuple([0] * n), (0, False, 0), (False, 0))
+        start = (tuple([0] * n), tuple([False] * n), tuple([(0, False)] * n), (0, False, 0), (False, 0))
         seen, stack = {start}, [start]
         while stack:
             pcs, firsts, olds, word, tile = stack.pop()
@@ -401,7 +402,9 @@ def explore_gemm_ticket(nks, launches=2, reset_by="departure", done_before_store
                 nword, ntile, nfirst, nold, npc = word, tile, firsts[i], olds[i], None
                 if pc == 0:                                   # arrival
                     nfirst = word == (0, False, 0)
-                    nold = arrived
+                    # (old arrivals, and whether this arrival already shows that the wave is the last to leave: DONE up, everybody before
+                    #  it departed, its own iterations complete the tile -- it then skips poll and departure and resets with a plain store)
+                    nold = (arrived, done and departed == arrived and arrived + nk == kt)
                     nword = (arrived + nk, done, departed)
                     npc = 1
                 elif firsts[i]:
@@ -426,8 +429,11 @@ def explore_gemm_ticket(nks, launches=2, reset_by="departure", done_before_store
                             raise Violation(f"launch {launch}: contributor {i} adds onto a tile nobody has stored")
                         ntile = (stored, adds + 1)
                         if reset_by == "arrival":
-                            if olds[i] + nk == kt:
+                            if olds[i][0] + nk == kt:
                                 nword = (0, False, 0)
+                            npc = 99
+                        elif olds[i][1]:                       # known last at its arrival: plain store of zero, no departure
+                            nword = (0, False, 0)
                             npc = 99
                         else:
                             npc = 3

@@ -870,24 +870,38 @@ def test_gemm_hybrid_schedule_whole_tile_waves_and_stream_k_remainder(lib, layou
     assert float(c[:, :, N:].abs().max()) == 0.0, "wrote outside N"
 
 
-@pytest.mark.parametrize("M,N,K", [(4100, 1150, 332), (300, 260, 20000), (130, 70, 5000), (8200, 1930, 1100)])
-def test_gemm_split_tiles_need_no_zeroing_and_leave_their_ticket_words_clean(lib, M, N, K, gemm_split):
-    """Store-mode products whose tiles are shared by several workgroups (stream-K ranges: two contributors per tile in the first shape,
-    tens in the deep ones; the last runs the 12-wave kernel under the default arithmetic) write NaN-poisoned outputs: the first arrival
-    at a split tile stores, the others add behind it (round 5, gemm.hip "Split tiles without a zeroing launch").  Twenty launches in a
-    row into the same poisoned buffer: a ticket word left non-zero by one launch would make the next one add onto the NaNs."""
+def _split_tiles_body(lib, M, N, K, reps):
     rng = np.random.default_rng(M + N + K)
     A = rng.standard_normal((M, K)).astype(np.float32)
     B = rng.standard_normal((N, K)).astype(np.float32)
     ref = (torch.from_numpy(A).double() @ torch.from_numpy(B).double().T).numpy()
     a, b = dev(A), dev(B)
     ldc = (N + 3) // 4 * 4 + 4
-    for rep in range(20):
+    for rep in range(reps):
         c = torch.full((M, ldc), float("nan"), device="cuda")
         ok(lib, lib.astk_gemm_f32(0, M, N, K, vp(a), K, vp(b), K, vp(c), ldc, None, 0, 1, 1, 0, 0, 0, stream()))
         assert bool(torch.isnan(c[:, N:]).all()), "wrote outside N"
-        assert bool(torch.isfinite(c[:, :N]).all()), f"launch {rep}: a split tile was added onto instead of stored"
+        assert bool(torch.isfinite(c[:, :N]).all()), f"launch {rep}: a split tile was added onto what the buffer held"
         close(c[:, :N], ref, rtol=2e-5, msg=f"launch {rep}")
+
+
+@pytest.mark.parametrize("M,N,K", [(4100, 1150, 332), (300, 260, 20000), (130, 70, 5000), (8200, 1930, 1100)])
+def test_gemm_split_tiles_of_store_products_overwrite_what_the_buffer_held(lib, M, N, K, gemm_split):
+    """Store-mode products whose tiles are shared by several workgroups (stream-K ranges: two contributors per tile in the first shape,
+    tens in the deep ones; the last runs the 12-wave kernel under the default arithmetic) into NaN-poisoned outputs, several launches in
+    a row: the split tiles are zeroed in front of the launch, the contributions are atomic adds."""
+    _split_tiles_body(lib, M, N, K, 5)
+
+
+@pytest.mark.parametrize("M,N,K", [(4100, 1150, 332), (300, 260, 20000), (130, 70, 5000), (8200, 1930, 1100)])
+def test_gemm_split_tiles_ticket_protocol_on_the_instrumented_build(M, N, K):
+    """The ticket protocol for the same tiles (round 5, gemm.hip "Split tiles without a zeroing launch": the first arrival at a split tile
+    stores, the others add behind its DONE bit; measured against the zeroing launch and switched off in the product build, compiled IN in
+    libastk_test.so).  Twenty launches in a row into the same poisoned buffer: a ticket word left non-zero by one launch would make the
+    next one add onto the NaNs; tests/test_protocol_model.py enumerates the interleavings."""
+    from ast_amd import _lib as L_
+    with L_.load_test_hooks() as lib:
+        _split_tiles_body(lib, M, N, K, 20)
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
