@@ -1,0 +1,8 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+: > gpurun_out/r5_final_soak.log
+timeout -k 10 500 python3 scratch/soak.py cfg1 3000 2>&1 | grep -v amdgpu.ids | tail -n 2 >> gpurun_out/r5_final_soak.log
+timeout -k 10 500 python3 scratch/soak.py es_en_20h 1500 2>&1 | grep -v amdgpu.ids | tail -n 2 >> gpurun_out/r5_final_soak.log
+timeout -k 10 300 python3 scratch/soak.py cfg5 300 2>&1 | grep -v amdgpu.ids | tail -n 2 >> gpurun_out/r5_final_soak.log
+cat gpurun_out/r5_final_soak.log
