@@ -86,6 +86,26 @@ struct PDecArgs {
 __device__ __forceinline__ unsigned ld_flag(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sti_sc1(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// A UNIFORM base pointer, re-formed where it is used (opaque to loop-invariant code motion).  An element address is then base (scalar
+// registers) + one 32-bit lane offset shared by all arrays of the same shape, instead of a hoisted 64-bit per-lane pointer per array: in the
+// multi-layer kernels (512 registers, the weights resident) ~30 such pointers were spilled, and a scratch reload between two written-through
+// stores waits (vmcnt counts in order) for the store in front of it -- a memory round trip per reload, on the decoder's chain.
+// ua(base, i): &base[i] with `base` uniform and i this lane's 32-bit element offset -- a scalar base + a 32-bit BYTE offset register, the
+// form the global instructions take as it is (a 64-bit element offset would be shifted and added per lane, and kept, and spilled).
+template <class T>
+__device__ __forceinline__ T* ua(T* base, unsigned i) {
+  unsigned long long v = (unsigned long long)base;
+  asm volatile("" : "+s"(v));
+  // (integer -> GLOBAL pointer: through a generic pointer the accesses become FLAT)
+  return (T*)((char __attribute__((address_space(1)))*)v + i * (unsigned)sizeof(T));
+}
+// Written-through store to base[i], `base` uniform, i this lane's 32-bit element offset: the instruction's scalar-base form, by hand -- for
+// an atomic store the compiler adds base and offset per lane into a 64-bit register pair (and keeps the extended offset alive, and spills it).
+// (The compiler does not count this store in its s_waitcnt bookkeeping: harmless -- memory operations return in order, an uncounted one can
+//  only make a wait longer -- and every publish() drains with an explicit s_waitcnt vmcnt(0).)
+__device__ __forceinline__ void st_sc1_u(float* base, unsigned i, float v) {
+  asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"(i * 4u), "v"(v), "s"(base) : "memory");
+}
 __device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int ldi_sc1(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
@@ -198,9 +218,11 @@ __device__ __forceinline__ void aload_sc1(float4* a, __amdgpu_buffer_rsrc_t ra, 
       a[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
   } else {
+    int kbv = kb;
+    asm volatile("" : "+v"(kbv));      // (opaque: the NB clamped offsets are formed here, not hoisted out of the step loop as NB live registers)
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)((a_off + min(kb + 64 * i, K - 4)) * 4), 0, AUX);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)((a_off + min(kbv + 64 * i, K - 4)) * 4), 0, AUX);
       a[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
   }
@@ -397,6 +419,8 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
   const int l2 = has_mid ? 1 : TOP;
   const int c2_bt = has_mid ? cell_bt : top_bt, c2_u0 = has_mid ? cell_u0 : top_u0;
   const int c2_b = c2_bt * 16 + ce_row, c2_u = c2_u0 + 4 * ce_tile + ce_u;
+  // this thread's (row, unit) element of a [.][B][H] array, as ONE 32-bit offset per cell slot (the arrays' uniform bases: ua(), st_sc1_u())
+  const unsigned cell_off = (unsigned)(cell_b * H + cell_u), c2_off = (unsigned)(c2_b * H + c2_u);
   const bool has_c2 = NL > 1 && (has_mid || has_top);
   float c_state2 = 0.f;
   float4 cbias2 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -445,11 +469,11 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       }
       if (sub == 0 && row < B) {
         const float lse = mx + logf(se);
-        const int tgt = a.ytgt[(long)row * a.L + s + 1];
+        const int tgt = *ua(a.ytgt + s + 1, (unsigned)(row * a.L));
         const float w = a.cw ? a.cw[tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt)] : 1.f;
-        a.LSE[(long)s * B + row] = lse;
-        a.LOSSROWS[(long)s * B + row] = -(xt - lse) * w * a.inv_count;
-        sti_sc1(a.PRED + (long)s * B + row, mi);
+        *ua(a.LSE + (long)s * B, (unsigned)row) = lse;
+        *ua(a.LOSSROWS + (long)s * B, (unsigned)row) = -(xt - lse) * w * a.inv_count;
+        sti_sc1(ua(a.PRED + (long)s * B, (unsigned)row), mi);
       }
       publish_sh(CTR(PH_CE, bt), 0);
       TICK(12)
@@ -462,7 +486,7 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       const int brow = min(m0 + r16, B - 1);             // this lane's A-operand batch row
       const bool truth = s == 0 || flagS[s] != 0;
       if (!truth) { if (!wg_wait_sh(CTR(PH_CE, bt), 1, s, a.ab, &s_flag)) return; }
-      int tok = truth ? yS[r16 * a.L + s] : ldi_sc1(a.PRED + (long)(s - 1) * B + brow);
+      int tok = truth ? yS[r16 * a.L + s] : ldi_sc1(ua(a.PRED + (long)(s - 1) * B, (unsigned)brow));
       tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
       if (s > 0) { if (!wg_wait_sh(CTR(PH_CELL, bt), H / 8, s, a.ab, &s_flag)) return; }
       f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -516,18 +540,18 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
         const float ga = tanh_fast(z.x + cbias.x), gi = sigm_fast(z.y + cbias.y), gf = sigm_fast(z.z + cbias.z), go = sigm_fast(z.w + cbias.w);
         c_state = ga * gi + gf * c_state;
         const float hh = go * tanh_fast(c_state);
-        const float hd = a.rnn_mask[0] ? hh * a.rnn_mask[0][((long)s * B + cell_b) * H + cell_u] : hh;
+        const float hd = a.rnn_mask[0] ? hh * *ua(a.rnn_mask[0] + (long)s * B * H, cell_off) : hh;
         gsave = make_float4(ga, gi, gf, go);
-        st_sc1(a.HR[0] + ((long)(s + 1) * B + cell_b) * H + cell_u, hh);
-        if constexpr (NL > 1) st_sc1(a.HD[0] + ((long)s * B + cell_b) * H + cell_u, hd);     // input of layer 1
-        else st_sc1(a.CVH + ((long)s * B + cell_b) * 2 * H + H + cell_u, hd);
+        st_sc1_u(a.HR[0] + (long)(s + 1) * B * H, cell_off, hh);
+        if constexpr (NL > 1) st_sc1_u(a.HD[0] + (long)s * B * H, cell_off, hd);     // input of layer 1
+        else st_sc1_u(a.CVH + (long)s * B * 2 * H + H, cell_off + cell_b * H, hd);
       }
       TICK(2)
       publish_sh(CTR(PH_CELL, bt), cell_u0 / 8);
       TICK(3)
       if (ev) {                                    // saved for the backward (plain stores, off the critical path)
-        *reinterpret_cast<float4*>(a.Gt[0] + ((long)s * B + cell_b) * 4 * H + 4 * cell_u) = gsave;
-        a.Cst[0][((long)(s + 1) * B + cell_b) * H + cell_u] = c_state;
+        *ua(reinterpret_cast<float4*>(a.Gt[0] + (long)s * B * 4 * H), cell_off) = gsave;
+        *ua(a.Cst[0] + (long)(s + 1) * B * H, cell_off) = c_state;
       }
     }
     // ================= P1b: decoder layers 1..NL-1 (one cell item per workgroup: layer 1 of a 3-layer stack on the lower
@@ -570,16 +594,16 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
           const float ga = tanh_fast(z.x + cbias2.x), gi = sigm_fast(z.y + cbias2.y), gf = sigm_fast(z.z + cbias2.z), go = sigm_fast(z.w + cbias2.w);
           c_state2 = ga * gi + gf * c_state2;
           const float hh = go * tanh_fast(c_state2);
-          const float hd = a.rnn_mask[l] ? hh * a.rnn_mask[l][((long)s * B + c2_b) * H + c2_u] : hh;
+          const float hd = a.rnn_mask[l] ? hh * *ua(a.rnn_mask[l] + (long)s * B * H, c2_off) : hh;
           gsave = make_float4(ga, gi, gf, go);
-          st_sc1(a.HR[l] + ((long)(s + 1) * B + c2_b) * H + c2_u, hh);
-          if (l == TOP) st_sc1(a.CVH + ((long)s * B + c2_b) * 2 * H + H + c2_u, hd);
-          else st_sc1(a.HD[l] + ((long)s * B + c2_b) * H + c2_u, hd);
+          st_sc1_u(a.HR[l] + (long)(s + 1) * B * H, c2_off, hh);
+          if (l == TOP) st_sc1_u(a.CVH + (long)s * B * 2 * H + H, c2_off + c2_b * H, hd);
+          else st_sc1_u(a.HD[l] + (long)s * B * H, c2_off, hd);
         }
         publish_sh(CTR(PH_CELL + l, bt), c2_u0 / 8);
         if (ev) {
-          *reinterpret_cast<float4*>(a.Gt[l] + ((long)s * B + c2_b) * 4 * H + 4 * c2_u) = gsave;
-          a.Cst[l][((long)(s + 1) * B + c2_b) * H + c2_u] = c_state2;
+          *ua(reinterpret_cast<float4*>(a.Gt[l] + (long)s * B * 4 * H), c2_off) = gsave;
+          *ua(a.Cst[l] + (long)(s + 1) * B * H, c2_off) = c_state2;
         }
       }
     }
@@ -907,8 +931,8 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       const int row = m0 + (tid >> 4), n = c_n0 + (tid & 15);
       if (row < B) {
         const float ht = tanh_fast(v + a.bc[n]);
-        st_sc1(a.HT + ((long)(s + 1) * B + row) * A + n, ht);
-        if (s + 1 < S) st_sc1(a.X0 + ((long)(s + 1) * B + row) * XI + E + n, ht);
+        st_sc1_u(a.HT + (long)(s + 1) * B * A, (unsigned)(row * A + n), ht);
+        if (s + 1 < S) st_sc1_u(a.X0 + (long)(s + 1) * B * XI + E, (unsigned)(row * XI + n), ht);
       }
       publish_sh(CTR(PH_CTX, bt), c_n0 / 16);
       TICK(9)
@@ -927,8 +951,8 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       const int row = m0 + (tid >> 4), n = n0 + (tid & 15);
       const bool ok = row < B && n < V;
       const float x = ok ? v + a.bo[n] : -INFINITY;
-      if (ok) a.LOGITS[((long)s * B + row) * a.Vp + n] = x;
-      else if (row < B && n < a.Vp) a.LOGITS[((long)s * B + row) * a.Vp + n] = 0.f;
+      if (ok) *ua(a.LOGITS + (long)s * B * a.Vp, (unsigned)(row * a.Vp + n)) = x;
+      else if (row < B && n < a.Vp) *ua(a.LOGITS + (long)s * B * a.Vp, (unsigned)(row * a.Vp + n)) = 0.f;
       float mx = x;
       int mi = n;
 #pragma unroll
@@ -940,12 +964,12 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
       float se = ok ? expf(x - mx) : 0.f;
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o);
-      const int tgt = row < B ? a.ytgt[(long)row * a.L + s + 1] : 0;
+      const int tgt = row < B ? *ua(a.ytgt + s + 1, (unsigned)(row * a.L)) : 0;
       float xt = (ok && n == tgt) ? x : 0.f;
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) xt += __shfl_xor(xt, o);
       if ((tid & 15) == 0 && row < B) {
-        float* cs = a.CESTAT + (((long)s * B + row) * a.ntile_v + tile) * 4;
+        float* cs = ua(a.CESTAT + ((long)s * B * a.ntile_v + tile) * 4, (unsigned)(row * a.ntile_v * 4));
         st_sc1(cs, mx); st_sc1(cs + 1, se); st_sc1(cs + 2, __int_as_float(mi)); st_sc1(cs + 3, xt);
       }
       publish_sh(CTR(PH_LOG, bt), tile);
