@@ -217,6 +217,20 @@ def test_cnn_fwd_bwd(lib, B, T, D, c0, c1, with_noise, gemm_split):
     for n in names:
         for s in ("/W", "_bn/gamma", "_bn/beta"):
             close(grd[n + s], Pt[n + s].grad, rtol=5e-4, msg="grad " + n + s)
+    # A second backward call on the SAME forward pass, then a fresh forward + backward: the same gradients every time.  (Round 5: the
+    # forward's last kernel zeroes the backward's accumulators -- statistics, maximum slots, weight-gradient scratch -- on its way out and
+    # the library remembers that per workspace; the backward call that finds the mark taken has to fill them itself.)
+    first = {k: v.clone() for k, v in grd.items()}
+    for rep in range(2):
+        for v in grd.values():
+            v.zero_()
+        if rep == 1:
+            ok(lib, lib.astk_conv_bn_relu_fwd(C.byref(cd), cp, vp(xd), vp(nd), vp(out), vp(ws), nbytes, 1, stream()))
+        g = dev(gout)
+        ok(lib, lib.astk_conv_bn_relu_bwd(C.byref(cd), cp, cg, vp(g), vp(ws), nbytes, stream()))
+        ws.check("cnn bwd again")
+        for k in ("CNN_0/W", "CNN_1/W", "CNN_0_bn/gamma", "CNN_1_bn/gamma", "CNN_0_bn/beta", "CNN_1_bn/beta"):
+            close(grd[k], first[k].double().cpu().numpy(), rtol=2e-5, msg=f"backward call {rep + 2}: {k}")
     # eval mode uses the running statistics
     ok(lib, lib.astk_conv_bn_relu_fwd(C.byref(cd), cp, vp(xd), None, vp(out), vp(ws), nbytes, 0, stream()))
     hh = torch.tensor(X).unsqueeze(1)
