@@ -51,6 +51,13 @@ constexpr int PDEC_MAX_LAYERS = 3;
 // utterances of 1680 frames) are streamed from L2 / Infinity Cache every step -- they are the same bytes for every step of the loop.
 constexpr int PDEC_RES_ROWS = 28, PDEC_CHUNK_MAX = 60;
 constexpr int NPHASE_SLOTS = 8;   // counter lines reserved per batch tile ahead of the abort word and the per-row counters
+// ... and the hand-off between decoder LAYERS the same way (round 5, ASTK_PDEC_SENT_HD=1): HD[l] -- the dropped output of layer l, one slot per
+// step, read by nobody but the cells of layer l + 1 -- sentinel-filled before the launch and polled itself by the waves that multiply it.
+// MEASURED AND OFF: es_en_20h (3 layers) 6.79 -> 6.83 ms in a same-box A/B -- 4 waves x 128 workgroups re-reading 8 KB each per poll cost the
+// chain more than the drain + counter they replace (the top cell's hand-off to the attention scan polls 2 KB per workgroup, once).
+#ifndef ASTK_PDEC_SENT_HD
+#define ASTK_PDEC_SENT_HD 0
+#endif
 #ifndef ASTK_PDEC_SENT_H
 #define ASTK_PDEC_SENT_H 1
 #endif
@@ -574,10 +581,32 @@ __global__ __launch_bounds__(256, 1) void decoder_persist_fwd(PDecArgs a) {
           mfma_blocks<NB_H>(acc[0], ah, wreg + OFF_C2 + NB_H);
           mfma_blocks<NB_H>(acc[1], ah, wreg + OFF_C2 + CELLW2 + NB_H);
         }
+#if !(ASTK_PDEC_SENT_HD && ASTK_PDEC_SENT_H)
         if (!wg_wait_sh(CTR(PH_CELL + l - 1, bt), H / 8, s + 1, a.ab, &s_flag)) return;
+#endif
         {
           float4 ax[NB_H];
+#if ASTK_PDEC_SENT_HD && ASTK_PDEC_SENT_H
+          // the data is the flag: every wave re-reads ITS fragments of the 16 rows until none of them holds the sentinel -- no drain,
+          // counter, counter poll or barrier between the lower cell's stores and this product
+          {
+            const __amdgpu_buffer_rsrc_t r_hd = make_rsrc(a.HD[l - 1]);
+            unsigned spins = 0;
+            for (;;) {
+              aload_sc1<NB_H>(ax, r_hd, ((long)s * B + brow) * H, H, lane, wave);
+              bool ok = true;
+#pragma unroll
+              for (int i = 0; i < NB_H; ++i)
+                ok = ok & (__float_as_uint(ax[i].x) != PDEC_SENTINEL) & (__float_as_uint(ax[i].y) != PDEC_SENTINEL) &
+                     (__float_as_uint(ax[i].z) != PDEC_SENTINEL) & (__float_as_uint(ax[i].w) != PDEC_SENTINEL);
+              if (__all(ok) || att_dead) break;
+              if (++spins > (a.ab.limit >> 1)) { abort_raise(a.ab); att_dead = true; }
+              else if ((spins & 63u) == 0 && abort_seen(a.ab)) att_dead = true;
+            }
+          }
+#else
           aload_sc1<NB_H>(ax, make_rsrc(a.HD[l - 1]), ((long)s * B + brow) * H, H, lane, wave);  // dropped output of the layer below
+#endif
           __builtin_amdgcn_sched_barrier(0);
           mfma_blocks<NB_H>(acc[0], ax, wreg + OFF_C2);
           mfma_blocks<NB_H>(acc[1], ax, wreg + OFF_C2 + CELLW2);
@@ -1847,6 +1876,9 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
     f.n = 0;
     fill_seg_add(f, bf.ctr, ((size_t)NPHASE_SLOTS * NSH * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned), 0u);
     fill_seg_add(f, bf.CVH, (size_t)a.S * a.B * 2 * a.H * sizeof(float));
+#if ASTK_PDEC_SENT_HD
+    for (int l = 0; l + 1 < d->n_layers; ++l) fill_seg_add(f, bf.HD[l], (size_t)a.S * a.B * a.H * sizeof(float));      // (the launch's value: the sentinel)
+#endif
     if (bf.zero_a) fill_seg_add(f, bf.zero_a, bf.zero_a_bytes, 0u);
     if (bf.zero_b) fill_seg_add(f, bf.zero_b, bf.zero_b_bytes, 0u);
     if (bf.c0 && bf.h0) {
