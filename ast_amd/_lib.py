@@ -66,7 +66,8 @@ class DecoderDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("L", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int),
                 ("A", C.c_int), ("V", C.c_int), ("n_layers", C.c_int),
                 ("n_attn", C.c_int), ("no_feed_attn", C.c_int), ("ln", C.c_int), ("loss_rows", C.c_int),
-                ("use_truth_host", C.POINTER(C.c_int32)), ("precision", C.c_int), ("gemm_operands", C.c_int), ("status_dst", C.c_void_p)]
+                ("use_truth_host", C.POINTER(C.c_int32)), ("precision", C.c_int), ("gemm_operands", C.c_int), ("status_dst", C.c_void_p),
+                ("zero_ptr", C.c_void_p), ("zero_bytes", C.c_size_t)]
 
 
 class DecoderParams(C.Structure):

@@ -33,6 +33,7 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
                                float* loss, int32_t* pred_out, hipStream_t s);
 
 struct DecPersistBwdBuffers {
+  void* zero_ptr; size_t zero_bytes;      // astk_decoder_desc.zero_ptr: zeroed by the launcher's fill launch
   const float *WoT, *WcT, *ENCA, *CVH, *HT, *LOGITS, *ML;
   const float *WlT[PDEC_MAX_LAYERS], *WuT[PDEC_MAX_LAYERS], *C[PDEC_MAX_LAYERS];
   float *G[PDEC_MAX_LAYERS];
@@ -387,6 +388,8 @@ int make_split(const astk_decoder_desc* d, void* ws, SplitPlan& sp) {
   for (int i = 0; i < 2; ++i) {
     sp.sub[i] = *d;
     sp.sub[i].status_dst = nullptr;      // (the whole op's call takes the snapshot, once)
+    sp.sub[i].zero_ptr = nullptr;        // (... and zeroes the caller's buffer, once: astk_decoder_bwd_phase_ex)
+    sp.sub[i].zero_bytes = 0;
     sp.sub[i].B = Bs[i];
     sp.sub[i].loss_rows = d->loss_rows > 0 ? d->loss_rows : d->B;
     sp.off[i] = i == 0 ? 0 : B0;
@@ -674,6 +677,7 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
     if (sp.on && !out_mask) {       // the two halves the forward call ran (their masks are still staged in the workspace)
       ASTK_CHECK(ws && ws_bytes >= sp.bytes, "decoder_bwd: workspace too small");
       ASTK_CHECK(prm && g && enc && d_enc && d_c0 && d_h0, "decoder_bwd: null pointer");
+      if (phase != ASTK_DEC_BWD_PARAMS && d->zero_ptr && d->zero_bytes) ASTK_TRY(fill_zero(d->zero_ptr, d->zero_bytes, s));   // (once, in front of both halves)
       const int B = d->B, H = d->H, nl = d->n_layers;
       for (int i = 0; i < 2; ++i) {
         const int b = sp.sub[i].B, off = sp.off[i];
@@ -706,6 +710,12 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
                "(ASTK_DEC_PERSIST / ASTK_DEC_WIDE changed between the two calls?)", fwd_path, bwd_path);
   }
   if (do_chain) {
+  // astk_decoder_desc.zero_ptr (the gradient arena): in front of everything this call accumulates -- the persistent launcher's fill takes
+  // it along (nothing in front of that launch touches the gradients), every other path fills here
+  if (d->zero_ptr && d->zero_bytes) {
+    ASTK_CHECK(aligned16(d->zero_ptr) && (d->zero_bytes % 4) == 0, "decoder_bwd: zero_ptr must be 16-byte aligned, zero_bytes a multiple of 4");
+    if (!persist) ASTK_TRY(fill_zero(d->zero_ptr, d->zero_bytes, s));
+  }
   // transposed weights for the data-path products (dY W as row-panel NT products)
   {
     TransposeJobs tj;
@@ -730,6 +740,7 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
     bf.HT = P.HT; bf.LOGITS = P.LOGITS; bf.DPRE = P.DPRE; bf.DCVH = P.DCVH; bf.DS = P.DS; bf.DX0 = P.DX0;
     bf.DHATT = P.PART; bf.d_c0 = d_c0; bf.ctr = P.PCTR;
     bf.DXH = b6s ? P.DXH : nullptr;
+    bf.zero_ptr = d->zero_ptr; bf.zero_bytes = d->zero_bytes;
     ASTK_TRY(decoder_persist_bwd_launch(d, enc, rnn_masks, bf, s));
   }
   if (!persist) {

@@ -112,6 +112,30 @@ def init_values(cfg, in_dim, vocab_size=None, seed=0):
     return out
 
 
+class _FlushingViews(dict):
+    """name -> gradient view; any read performs the arena's deferred zero fill first (ParamArena.flush_zero)."""
+
+    def __init__(self, arena):
+        super().__init__()
+        self._arena = arena
+
+    def __getitem__(self, k):
+        self._arena.flush_zero()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        self._arena.flush_zero()
+        return dict.get(self, k, default)
+
+    def items(self):
+        self._arena.flush_zero()
+        return dict.items(self)
+
+    def values(self):
+        self._arena.flush_zero()
+        return dict.values(self)
+
+
 class ParamArena:
     TAIL = 4
 
@@ -129,13 +153,35 @@ class ParamArena:
         # the gradient buffer carries TAIL extra floats behind the last parameter: [0] = the abort status word that rides in the last
         # range's all-reduce under data parallelism (ast_amd.dist.GradBuckets); not a parameter, never seen by cleargrads / the optimizer
         self.grad_full = torch.zeros(off + self.TAIL, dtype=torch.float32, device=device)
-        self.grad = self.grad_full[:off]
+        # cleargrads() may DEFER its zero fill to the backward pass that follows it (defer_zero / take_zero: the decoder backward's first
+        # fill launch takes the arena along, include/astk.h astk_decoder_desc.zero_ptr); every other reader of the gradients -- `grad`,
+        # `gviews[...]`, to_numpy(grads=True) -- goes through flush_zero() first, so nobody ever sees gradients cleargrads() has cleared
+        self._grad = self.grad_full[:off]
+        self._zero_pending = False
         self.status_tail = self.grad_full[off:off + 1]
-        self.views, self.gviews = {}, {}
+        self.views, self.gviews = {}, _FlushingViews(self)
         for name, shp in self.shapes.items():
             o, n = self.offsets[name], int(np.prod(shp))
             self.views[name] = self.data[o:o + n].view(shp)
-            self.gviews[name] = self.grad[o:o + n].view(shp)
+            dict.__setitem__(self.gviews, name, self._grad[o:o + n].view(shp))
+
+    @property
+    def grad(self):
+        self.flush_zero()
+        return self._grad
+
+    def defer_zero(self):
+        self._zero_pending = True
+
+    def take_zero(self):
+        """True once per deferred zero fill: the caller has taken it over."""
+        p, self._zero_pending = self._zero_pending, False
+        return p
+
+    def flush_zero(self):
+        if self._zero_pending:
+            self._zero_pending = False
+            self._grad.zero_()
 
     def range_of(self, name):
         o = self.offsets[name]
@@ -146,7 +192,7 @@ class ParamArena:
         return self.views[name].data_ptr()
 
     def g(self, name):
-        return self.gviews[name].data_ptr()
+        return dict.__getitem__(self.gviews, name).data_ptr()       # (an address, not a read: no flush)
 
     def load(self, values):
         for name in self.shapes:

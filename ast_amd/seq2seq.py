@@ -323,7 +323,15 @@ class SpeechEncoderDecoder:
         return list(self.arena.views.values())
 
     def cleargrads(self):
-        if self.arena is not None:
+        """Zero gradients (nn.py:180 calls it between forward_loss and backward).  Behind a forward_loss on the device the fill is DEFERRED to
+        the backward pass, whose first fill launch takes the arena along (a launch less per step); anything that reads the gradients before
+        that performs it first (ParamArena.flush_zero), so the deferral cannot be observed."""
+        if self.arena is None:
+            return
+        st = self._cur
+        if st and st.get("train_mode") and "dd" in st and st.get("pending_backward"):
+            self.arena.defer_zero()
+        else:
             self.arena.grad.zero_()
 
     def enabled_ranges(self):
@@ -765,6 +773,7 @@ class SpeechEncoderDecoder:
                                       _vp(y), _vp(st["flags"]), _vp(st["emb_mask"]), _vp(st["rnn_masks"]), _vp(st["out_mask"]), _vp(targets),
                                       _vp(st["loss"]), _vp(st["pred"]), _vp(wd), wd.numel(), self._stream()))
         # (loss[1] = the persistent kernels' status word: written by the op itself, astk_decoder_desc.status_dst)
+        st["pending_backward"] = True
         self.loss = Loss(self, st["loss"])
         return self.loss
 
@@ -773,6 +782,12 @@ class SpeechEncoderDecoder:
         st = self._cur
         s = self._stream()
         wd = self._workspace("dec", st["ws_dec"])
+        st["pending_backward"] = False
+        # a cleargrads() deferred to this pass: the decoder backward zeroes the arena in front of everything it accumulates (astk.h zero_ptr)
+        if self.arena.take_zero():
+            st["dd"].zero_ptr, st["dd"].zero_bytes = self.arena._grad.data_ptr(), 4 * self.arena.size
+        else:
+            st["dd"].zero_ptr, st["dd"].zero_bytes = None, 0
 
         def dec_bwd(phase, stream):
             check(lib.astk_decoder_bwd_phase_ex(C.byref(st["dd"]), C.byref(st["dp"]), C.byref(st["dg"]), _vp(st["enc_states"]), _vp(st["c0"]),

@@ -255,6 +255,12 @@ typedef struct {
   float* status_dst;   /* optional (NULL = none): astk_decoder_fwd(_ex) also leaves a copy of the persistent kernels' status word there (the
                           Python shim passes &loss[1]), written by the kernel that writes the loss when the persistent loop runs --
                           astk_persist_status_snapshot without a launch of its own.  Ignored by the backward calls. */
+  void* zero_ptr;      /* optional (NULL = none): zero_bytes bytes (16-byte aligned, a multiple of 4) that astk_decoder_bwd(_phase)(_ex) zeroes IN
+                          FRONT of everything it accumulates -- the Python shim passes the gradient arena when cleargrads() was called since the
+                          last backward pass (model.cleargrads() sits between forward_loss and backward in nn.py:175-189): the persistent loop's
+                          launcher does it with the fill launch it has anyway, the other paths with a fill of their own.  Ignored by the forward
+                          calls and by ASTK_DEC_BWD_PARAMS. */
+  size_t zero_bytes;
 } astk_decoder_desc;
 
 typedef struct {

@@ -716,6 +716,46 @@ def test_forward_pass_is_bit_reproducible_from_run_to_run():
                 assert torch.equal(got[1], ref[1]), it
 
 
+@pytest.mark.parametrize("dec_layers", [1, 2])
+def test_deferred_cleargrads_cannot_be_observed(dec_layers):
+    """cleargrads() behind a forward_loss defers its zero fill to the backward pass (the decoder backward's first fill launch takes the
+    gradient arena along: include/astk.h zero_ptr, a launch less per train step).  Whoever reads the gradients in between sees zeros; the
+    gradients of the step are those of an eagerly cleared arena."""
+    from ast_amd.seq2seq import using_config
+    cfg = tiny_cfg(enc_layers=1, dec_layers=dec_layers, H=64, E=16, A=64, c0=16, c1=8, V=23, drop=0.0)
+    B, T, D, L, V = 3, 48, 80, 6, 23
+    P, X, y = _make(cfg, B, T, D, L, V)
+    m = _gpu_model(cfg, P, D, V)
+    m.inject["use_truth"] = [1] * (L - 1)
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    with using_config("train", True):
+        # reference: eager zero (cleargrads in FRONT of forward_loss is never deferred)
+        m.arena.grad.fill_(7.0)
+        m.cleargrads()
+        assert not m.arena._zero_pending
+        loss = m.forward_loss(Xd, yd, 1.0)
+        loss.backward()
+        want = m.arena.grad.clone()
+        assert float(want.abs().max()) > 0
+        # deferred: garbage in the arena, cleargrads behind forward_loss, backward
+        m.arena.grad.fill_(7.0)
+        loss = m.forward_loss(Xd, yd, 1.0)
+        m.cleargrads()
+        assert m.arena._zero_pending, "the fill was expected to be deferred here"
+        loss.backward()
+        assert not m.arena._zero_pending
+        assert torch.allclose(m.arena.grad, want, rtol=0, atol=1e-6 * float(want.abs().max())), float((m.arena.grad - want).abs().max())
+        # a reader in between sees zeros, and the backward that follows still starts from zero
+        m.arena.grad.fill_(7.0)
+        loss = m.forward_loss(Xd, yd, 1.0)
+        m.cleargrads()
+        assert m.arena._zero_pending
+        assert float(m.arena.to_numpy(grads=True)["out/W"].max()) == 0.0 and not m.arena._zero_pending
+        assert float(m.arena.grad.abs().max()) == 0.0
+        loss.backward()
+        assert torch.allclose(m.arena.grad, want, rtol=0, atol=1e-6 * float(want.abs().max()))
+
+
 def test_cnn_backward_refuses_a_workspace_whose_forward_took_the_other_layer0_path():
     """the layer-0 path (direct convolution + window-matrix weight gradient under the default arithmetic, im2col + GEMM
     otherwise) is re-derived at every call from the arithmetic in force then.  With the descriptor at ASTK_PREC_DEFAULT a change of the
