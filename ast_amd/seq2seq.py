@@ -163,6 +163,9 @@ def _vp(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_LAZY_CLEARGRADS = os.environ.get("ASTK_LAZY_CLEARGRADS", "1") != "0"      # (0: cleargrads() always fills at once -- A/B runs)
+
+
 # Raw hipStream_t handles made with hipExtStreamCreateWithCUMask (opt-in overlap, _cu_streams).  torch only BORROWS them
 # (ExternalStream), so nothing ever destroyed them: they were still alive when the HIP runtime's static destructors ran, and five
 # rocprofv3 runs in a row ended with SIGSEGV inside __cxa_finalize after their results were written (round-1 logs ovl2/ovl3/sp/dpt/
@@ -329,7 +332,7 @@ class SpeechEncoderDecoder:
         if self.arena is None:
             return
         st = self._cur
-        if st and st.get("train_mode") and "dd" in st and st.get("pending_backward"):
+        if st and st.get("train_mode") and "dd" in st and st.get("pending_backward") and _LAZY_CLEARGRADS:
             self.arena.defer_zero()
         else:
             self.arena.grad.zero_()
