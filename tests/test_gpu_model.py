@@ -300,8 +300,11 @@ def test_full_size_directional_derivative_and_repeatability(dec_layers, D):
         assert abs(fd - gd) <= 3e-2 * abs(gd) + 1e-3, (trial, fd, gd, eps, lp, lm)
 
 
-def test_sync_batchnorm_two_replicas_match_one_process_on_the_concatenated_batch():
-    """Global-batch BatchNorm under data parallelism (include/astk.h astk_conv_bn_relu_*_sync, ast_amd.dist.StatExchange).
+@pytest.mark.parametrize("c0", [8, 16])
+def test_sync_batchnorm_two_replicas_match_one_process_on_the_concatenated_batch(c0):
+    """(c0 = 16: layer 0 as the direct convolution, whose per-tile sums feed the statistics kernel -- the exchange sits between that kernel
+    and a finalize launch of its own; c0 = 8: the im2col path.)
+    Global-batch BatchNorm under data parallelism (include/astk.h astk_conv_bn_relu_*_sync, ast_amd.dist.StatExchange).
     Two replicas with the two halves of a batch are emulated in ONE process: the exchange callback is replaced by one that
     plays back the sum of both replicas' statistics, which are collected exchange point by exchange point (4 per step: two
     layers forward, two backward) over repeated passes.  Result: the replicas' mean loss, mean gradient, encoder states and
@@ -309,7 +312,7 @@ def test_sync_batchnorm_two_replicas_match_one_process_on_the_concatenated_batch
     from oracle import ast_ref as R
     from ast_amd.dist import StatExchange
     from ast_amd.seq2seq import using_config
-    cfg = tiny_cfg(enc_layers=2, dec_layers=1, H=16, E=8, A=16, c0=8, c1=8, V=23, drop=0.0)
+    cfg = tiny_cfg(enc_layers=2, dec_layers=1, H=16, E=8, A=16, c0=c0, c1=8, V=23, drop=0.0)
     B, T, D, L, V, world = 6, 37, 26, 6, 23, 2
     P, X, y = _make(cfg, B, T, D, L, V)
     ref = R.RefModel(cfg, {k: v.astype(np.float64) for k, v in P.items()}, V)
