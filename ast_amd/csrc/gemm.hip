@@ -875,19 +875,41 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
         // products inside one 16-k block is free: every one of them is added to an accumulator that already holds the sums of all earlier k.)
         struct FragsH { bf16x8 a[NAM], b[NA]; };
         struct FragsML { bf16x8 a[NAM][2], b[NA][2]; };      // [.][0] mid, [.][1] lo
+        // Fragment addresses = (stage, plane, sub-tile: constants of the unrolled code) + this lane's offset inside an operand image.  The lane
+        // offsets are made OPAQUE at every fetch: with three stages the images span 110-130 KB, beyond the 64 KB a DS instruction's immediate
+        // reaches, and hipcc kept lane offset + 64 K (+ 128 K) per operand as loop invariants -- three of them SPILLED in this 168-register
+        // kernel, reloaded (scratch_load + s_waitcnt vmcnt(0)) in front of the fragment reads of every k-iteration.  One v_add per window
+        // where it is used costs nothing next to that.
+        const int g16_ = (lane >> 4) & 1, q_ = (lane & 15) >> 2, pp_ = lane & 3;
+        const int lane_a = A_RK ? lk * sp_hs(TLM) + (wm * WTM + li) * 16 : (8 * lk + q_) * sp_rs(TLM) + (wm * WTM + 16 * g16_ + 4 * pp_) * 2;
+        const int lane_b = B_RK ? lk * sp_hs(TL) + (wn * WT + li) * 16 : (8 * lk + q_) * sp_rs(TL) + (wn * WT + 16 * g16_ + 4 * pp_) * 2;
+        auto frag8 = [&](const char* base, bool rk, auto tlc, int t0, int pl, int lane_off) -> bf16x8 {      // frag(.., ks = 0) with the lane part given
+          constexpr int TLX = decltype(tlc)::value;
+          if (rk) return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + pl * sp_plane(TLX, true) + t0 * 16 + lane_off));
+          const char* ad = base + pl * sp_plane(TLX, false) + t0 * 2 + lane_off;
+          typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ad));
+          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ad + 4 * sp_rs(TLX)));
+          struct { s16x4 a, b; } pr = {v0, v1};
+          return __builtin_bit_cast(bf16x8, pr);
+        };
         auto fetch_h = [&](FragsH& f, int st) {
+          int la = lane_a, lb = lane_b;
+          asm volatile("" : "+v"(la), "+v"(lb));
 #pragma unroll
-          for (int i = 0; i < NAM; ++i) f.a[i] = frag(stA(st), A_RK, std::integral_constant<int, TLM>{}, wm * WTM + 32 * i, 0, 0);
+          for (int i = 0; i < NAM; ++i) f.a[i] = frag8(stA(st), A_RK, std::integral_constant<int, TLM>{}, 32 * i, 0, la);
 #pragma unroll
-          for (int i = 0; i < NA; ++i) f.b[i] = frag(stB(st), B_RK, std::integral_constant<int, TL>{}, wn * WT + 32 * i, 0, 0);
+          for (int i = 0; i < NA; ++i) f.b[i] = frag8(stB(st), B_RK, std::integral_constant<int, TL>{}, 32 * i, 0, lb);
         };
         auto fetch_ml = [&](FragsML& f, int st) {
+          int la = lane_a, lb = lane_b;
+          asm volatile("" : "+v"(la), "+v"(lb));
 #pragma unroll
           for (int pl = 1; pl < 3; ++pl) {
 #pragma unroll
-            for (int i = 0; i < NAM; ++i) f.a[i][pl - 1] = frag(stA(st), A_RK, std::integral_constant<int, TLM>{}, wm * WTM + 32 * i, pl, 0);
+            for (int i = 0; i < NAM; ++i) f.a[i][pl - 1] = frag8(stA(st), A_RK, std::integral_constant<int, TLM>{}, 32 * i, pl, la);
 #pragma unroll
-            for (int i = 0; i < NA; ++i) f.b[i][pl - 1] = frag(stB(st), B_RK, std::integral_constant<int, TL>{}, wn * WT + 32 * i, pl, 0);
+            for (int i = 0; i < NA; ++i) f.b[i][pl - 1] = frag8(stB(st), B_RK, std::integral_constant<int, TL>{}, 32 * i, pl, lb);
           }
         };
         static_assert(BK == 16 || !(MW == 8), "the 12-wave kernel is written for 16-deep tiles");
