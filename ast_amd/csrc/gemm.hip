@@ -50,6 +50,13 @@ constexpr int BK = ASTK_GEMM_BK;
 #ifndef ASTK_GEMM_PRIO8S
 #define ASTK_GEMM_PRIO8S 0      // ... and of its staging waves
 #endif
+// ASTK_GEMM_REFILL_FENCE=1: a scheduling barrier between a slot's split and its refill.  Without it hipcc starts the refill with one load in
+// front of the split's last uses of the old tile and waits with s_waitcnt vmcnt(0) in two of six iterations; with it every wait leaves the
+// new loads in flight (vmcnt(8..11)).  Measured, same box: family 2.418 -> 2.435 ms kernels only -- the drain was not what the staging
+// waves wait for.  Off.
+#ifndef ASTK_GEMM_REFILL_FENCE
+#define ASTK_GEMM_REFILL_FENCE 0
+#endif
 #ifndef ASTK_GEMM_REFILL_EARLY
 #define ASTK_GEMM_REFILL_EARLY 1
 #endif
@@ -738,8 +745,16 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
 #if ASTK_GEMM_REFILL_EARLY
           // (A's slot is reloaded right behind A's split: its loads' time in the L1's queue -- 16 cycles per 1 KB instruction -- runs beside B's split)
           if (!TAIL || kt_ + 2 < nk) sa.template store_split<TAIL>(stA(st), kbeg + (kt_ + 2) * BK, kend, slot);
+#if ASTK_GEMM_REFILL_FENCE
+          // (no load of the refill may move up into the split: hipcc started the refill with ONE load in front of the split's last uses of
+          //  the old tile and then waited with s_waitcnt vmcnt(0) -- for that load too, a full memory round trip in every second iteration)
+          __builtin_amdgcn_sched_barrier(0);
+#endif
           refill(sa, A, g.spanA, ARK, std::integral_constant<bool, !TAIL>{}, kt_ + 2, slot);
           if (!TAIL || kt_ + 2 < nk) sb.template store_split<TAIL>(stB(st), kbeg + (kt_ + 2) * BK, kend, slot);
+#if ASTK_GEMM_REFILL_FENCE
+          __builtin_amdgcn_sched_barrier(0);
+#endif
           refill(sb, B, g.spanB, BRK, std::integral_constant<bool, !TAIL>{}, kt_ + 2, slot);
 #else
           if (!TAIL || kt_ + 2 < nk) {
