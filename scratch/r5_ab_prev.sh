@@ -1,5 +1,8 @@
 #!/bin/bash
-# same-box A/B: the tree at the start of this session's launch work (scratch/prev_tree = d914766) against the working tree
+# same-box A/B: an earlier tree against the working tree, alternating inside ONE gpurun call (boxes differ by 3-4 %: only this kind of
+# comparison means anything).  Set-up (scratch/prev_tree is git-ignored, its built .so files travel with the snapshot):
+#   git worktree add -f scratch/prev_tree d914766 && bash scratch/prev_tree/ast_amd/csrc/build.sh
+# (d914766 = the tree in front of this round's launch / address work)
 cd /tmp && export TMPDIR=/tmp
 R="$GRAFT_REPO_ROOT"
 mkdir -p $R/gpurun_out
