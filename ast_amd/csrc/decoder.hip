@@ -34,6 +34,7 @@ int decoder_persist_fwd_launch(const astk_decoder_desc* d, const astk_decoder_pa
 
 struct DecPersistBwdBuffers {
   void* zero_ptr; size_t zero_bytes;      // astk_decoder_desc.zero_ptr: zeroed by the launcher's fill launch
+  void* zero2_ptr; size_t zero2_bytes;    // d_enc: zeroed there too, its two batched products then ADD into it from one grouped launch
   const float *WoT, *WcT, *ENCA, *CVH, *HT, *LOGITS, *ML;
   const float *WlT[PDEC_MAX_LAYERS], *WuT[PDEC_MAX_LAYERS], *C[PDEC_MAX_LAYERS];
   float *G[PDEC_MAX_LAYERS];
@@ -741,6 +742,7 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
     bf.DHATT = P.PART; bf.d_c0 = d_c0; bf.ctr = P.PCTR;
     bf.DXH = b6s ? P.DXH : nullptr;
     bf.zero_ptr = d->zero_ptr; bf.zero_bytes = d->zero_bytes;
+    bf.zero2_ptr = d_enc; bf.zero2_bytes = (size_t)B * T * H * sizeof(float);
     ASTK_TRY(decoder_persist_bwd_launch(d, enc, rnn_masks, bf, s));
   }
   if (!persist) {
@@ -840,6 +842,22 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
     if (!persist) ASTK_TRY(copy_f32(d_c0 + l * bh, P.DC[l][0], bh, s));
   }
   // ---- d_enc[b] = sum_k alpha_k,b^T d_cv_k,b + ds_k,b^T q_k,b   (batched over b, K = S)
+  if (persist && 2 * NA <= GEMM_GROUP_MAX) {
+    // (the persistent launcher's fill zeroed d_enc: both products of every head ADD into it, all of them in ONE grouped launch -- two
+    //  18-us launches of three k-iterations each were one after the other on the backward's chain; two contributions per element: the
+    //  same sum in either order)
+    GemmArgs list[GEMM_GROUP_MAX];
+    int n = 0;
+    for (int k = 0; k < NA; ++k) {
+      GemmArgs ga = gemm_args(T, H, S, mat(P.ALPHA + (size_t)k * S * B * Tp, (long)B * Tp), mat(P.DCVH + (size_t)k * H, (long)B * CW), d_enc, H, nullptr, GEMM_ATOMIC);
+      ga.batch = B; ga.sA = Tp; ga.sB = CW; ga.sC = (long)T * H;
+      list[n++] = ga;
+      GemmArgs gb = gemm_args(T, H, S, mat(P.DS + (size_t)k * S * B * Tp, (long)B * Tp), mat(P.Q + (size_t)k * S * bh, (long)B * H), d_enc, H, nullptr, GEMM_ATOMIC);
+      gb.batch = B; gb.sA = Tp; gb.sB = H; gb.sC = (long)T * H;
+      list[n++] = gb;
+    }
+    ASTK_TRY(gemm_launch_group(GEMM_TN, list, n, s));
+  } else
   for (int k = 0; k < NA; ++k) {
     GemmArgs ga = gemm_args(T, H, S, mat(P.ALPHA + (size_t)k * S * B * Tp, (long)B * Tp), mat(P.DCVH + (size_t)k * H, (long)B * CW), d_enc, H, nullptr,
                             k == 0 ? GEMM_STORE : GEMM_ACCUM);

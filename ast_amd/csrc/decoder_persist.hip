@@ -1760,6 +1760,7 @@ bool decoder_persist_b6_split(const astk_decoder_desc* d) {
 
 struct DecPersistBwdBuffers {
   void* zero_ptr; size_t zero_bytes;      // astk_decoder_desc.zero_ptr: zeroed by the launcher's fill launch
+  void* zero2_ptr; size_t zero2_bytes;    // d_enc: zeroed there too, its two batched products then ADD into it from one grouped launch
   const float *WoT, *WcT, *ENCA, *CVH, *HT, *LOGITS, *ML;
   const float *WlT[PDEC_MAX_LAYERS], *WuT[PDEC_MAX_LAYERS], *C[PDEC_MAX_LAYERS];
   float *G[PDEC_MAX_LAYERS];
@@ -1829,6 +1830,7 @@ int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, con
     f.n = 0;
     fill_seg_add(f, bf.ctr, ((size_t)NPHASE_SLOTS * NSH * a.nbt + 2 + a.B) * CTRS * sizeof(unsigned));
     if (bf.zero_ptr && bf.zero_bytes) fill_seg_add(f, bf.zero_ptr, bf.zero_bytes);      // (the caller's gradient arena: astk_decoder_desc.zero_ptr)
+    if (bf.zero2_ptr && bf.zero2_bytes) fill_seg_add(f, bf.zero2_ptr, bf.zero2_bytes);   // (d_enc: decoder.hip adds both of its products into it)
     ASTK_TRY(fill_u32_segments(f, 0u, s));
   }
   const size_t shm = pdec_bwd_lds_floats(chunk, a.H) * sizeof(float);       // slices + dS/cvS/ds + ds/alpha/fold of the specialised scan
