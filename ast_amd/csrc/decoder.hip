@@ -876,11 +876,17 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
     ASTK_TRY(gemm_launch(GEMM_NN, lowp(gemm_args(S * B, E, 4 * H, mat(P.G[0], 4 * H), mat(prm->lstm[0].Wu, XI), P.DX0, XI)), s));
   if (persist) {
     // split mode: the embedding columns of d_x0 (only the embedding scatter reads them) are one batched product over all steps
-    if (b6s) ASTK_TRY(gemm_launch(GEMM_NN, lowp(gemm_args(S * B, E, 4 * H, mat(P.G[0], 4 * H), mat(prm->lstm[0].Wu, XI), P.DX0, XI)), s));      // (K18's input gradient)
     // dq[s][b][:] = sum_t ds[s][b][t] enc[b][t][:]  (batched over b) -- only the weight gradients of attn_Wa need it
     GemmArgs gq = gemm_args(S, H, T, mat(P.DS, (long)B * Tp), mat(enc, H), P.DQ, (long)B * H);
     gq.batch = B; gq.sA = Tp; gq.sB = (long)T * H; gq.sC = H;
-    ASTK_TRY(gemm_launch(GEMM_NN, gq, s));
+    const GemmArgs gx = lowp(gemm_args(S * B, E, 4 * H, mat(P.G[0], 4 * H), mat(prm->lstm[0].Wu, XI), P.DX0, XI));      // (K18's input gradient)
+    if (b6s && low_precision_gemms() == 0) {      // two small independent NN products: one grouped launch (a launch less on the way to the weight gradients)
+      const GemmArgs two[2] = {gx, gq};
+      ASTK_TRY(gemm_launch_group(GEMM_NN, two, 2, s));
+    } else {
+      if (b6s) ASTK_TRY(gemm_launch(GEMM_NN, gx, s));
+      ASTK_TRY(gemm_launch(GEMM_NN, gq, s));
+    }
   }
   // ---- weight gradients: one batched TN GEMM each over the S*B saved rows
   const int SB = S * B;
