@@ -273,6 +273,10 @@ struct GemmArgs {
   long iters_total;  // batch * tiles_mn * kt
   int bm;            // tile order inside a batch matrix: super-rows of bm tile rows, inside a super-row column-major (tile t of a super-row
                      // = row t % bm of column t / bm), so that G / 8 consecutive tiles form a bm x (G / 8 / bm) block; 1 = row-major
+  // Chunk-major iteration order (gemm.hip "few tiles, deep K"): cs > 0 = k-iterations per chunk (a divisor of kt); the launch's linear
+  // iteration space then runs through ALL tiles of chunk 0, then all tiles of chunk 1, ... instead of all of tile 0's iterations first.
+  int cs;
+  long chunk_iters;  // tiles * cs
 };
 static inline GemmArgs gemm_args(int M, int N, int K, MatView A, MatView B, float* C, long ldc,
                                  const float* bias = nullptr, int mode = GEMM_STORE, int ksplit = 1) {

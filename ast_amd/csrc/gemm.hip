@@ -542,9 +542,21 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
     const int kt_tile = g.kt;
     const long lit = it - grp.iter_start[prob];
     const long lend = min(it_end, grp.iter_start[prob + 1]) - grp.iter_start[prob];
-    const long tile = lit / kt_tile;
-    const int k0 = (int)(lit - tile * kt_tile);
-    const int k1 = (int)min((long)kt_tile, (long)k0 + (lend - lit));
+    long tile;
+    int k0, k1;
+    if (g.cs > 0) {
+      // chunk-major (accumulating products of few tiles and deep K): consecutive workgroups -- the 32 of an XCD -- then work on the SAME
+      // k-range of neighbouring tiles and share its operand lines in their L2, instead of 32 different k-ranges of one or two tiles
+      const long c = lit / g.chunk_iters, r = lit - c * g.chunk_iters;
+      tile = r / g.cs;
+      const int kk = (int)(r - tile * g.cs);
+      k0 = (int)c * g.cs + kk;
+      k1 = (int)min((long)(k0 - kk + g.cs), (long)k0 + (lend - lit));
+    } else {
+      tile = lit / kt_tile;
+      k0 = (int)(lit - tile * kt_tile);
+      k1 = (int)min((long)kt_tile, (long)k0 + (lend - lit));
+    }
     it += k1 - k0;
     int zb, m0, n0;
     decode_tile(g, tile, TLM, TL, zb, m0, n0);
@@ -1561,11 +1573,23 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
       }
     }
   }
+  // Few tiles, deep K, accumulating output (the weight gradients: TN 512 x 1152 x 38400 is 18 tiles of 2400 k-iterations): chunk-major order,
+  // chunk = the divisor of kt nearest to a workgroup's share.  (ASTK_GEMM_CHUNK=0: tile-major always.)
+  static const bool chunk_on = !(getenv("ASTK_GEMM_CHUNK") && getenv("ASTK_GEMM_CHUNK")[0] == '0');
+  for (int i = 0; i < grp.n; ++i) { grp.g[i].cs = 0; grp.g[i].chunk_iters = 0; }
+  if (chunk_on && grp.n == 1 && !aligned && grp.dp_waves == 0 && grp.g[0].mode != GEMM_STORE && prec != PREC_F32 && tiles * 4 <= G && grp.g[0].kt >= 128) {
+    GemmArgs& a = grp.g[0];
+    const long share = grp.iters_total / G;      // k-iterations per workgroup
+    int best = 0;
+    for (int c = 2; c <= a.kt; c += 2)
+      if (a.kt % c == 0 && c >= share / 2 && c <= share * 2 && (best == 0 || labs(c - share) < labs(best - share))) best = c;
+    if (best > 0 && best < a.kt) { a.cs = best; a.chunk_iters = tiles * (long)best; }
+  }
   static const bool log_shapes = getenv("ASTK_GEMM_LOG") != nullptr;
   if (log_shapes)
     for (int i = 0; i < grp.n; ++i)
-      fprintf(stderr, "astk_gemm layout=%d M=%d N=%d K=%d batch=%d mode=%d twolvl=%d group=%d/%d G=%ld kt=%d tile=%d dp_waves=%d bm=%d\n", layout, grp.g[i].M,
-              grp.g[i].N, grp.g[i].K, grp.g[i].batch, grp.g[i].mode, (int)twolvl, i, grp.n, G, grp.g[i].kt, TLM * 1000 + TL, grp.dp_waves, grp.g[i].bm);
+      fprintf(stderr, "astk_gemm layout=%d M=%d N=%d K=%d batch=%d mode=%d twolvl=%d group=%d/%d G=%ld kt=%d tile=%d dp_waves=%d bm=%d cs=%d\n", layout, grp.g[i].M,
+              grp.g[i].N, grp.g[i].K, grp.g[i].batch, grp.g[i].mode, (int)twolvl, i, grp.n, G, grp.g[i].kt, TLM * 1000 + TL, grp.dp_waves, grp.g[i].bm, grp.g[i].cs);
   ProfScope prof(PROF_GEMM, s, flops);
   if (prof_enabled()) {       // algorithmic bytes of the launch: every operand element read once, every result element written once
     double bytes = 0;

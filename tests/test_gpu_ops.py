@@ -884,6 +884,33 @@ def test_gemm_hybrid_schedule_whole_tile_waves_and_stream_k_remainder(lib, layou
     assert float(c[:, :, N:].abs().max()) == 0.0, "wrote outside N"
 
 
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K,mode", [(512, 1152, 38400, 2), (260, 200, 51200, 2), (512, 640, 24000, 1)])
+def test_gemm_accumulating_products_of_few_tiles_and_deep_k(lib, layout, M, N, K, mode, gemm_split):
+    """Weight-gradient shaped products (a handful of output tiles, thousands of k-iterations, GEMM_ATOMIC / GEMM_ACCUM): the stream-K
+    ranges run CHUNK-major there (round 5: all tiles of one k-chunk, then the next chunk, so that the workgroups of an XCD share the
+    operand lines of one k-range) -- every (tile, chunk) piece must be added exactly once, ragged M / N included.  Against float64."""
+    rng = np.random.default_rng(M + N + K + layout)
+    pad4 = lambda n: (n + 3) // 4 * 4
+    A = (rng.standard_normal((M, K)) * 0.1).astype(np.float32)
+    B = (rng.standard_normal((N, K)) * 0.1).astype(np.float32)
+    ref = (torch.from_numpy(A).double().cuda() @ torch.from_numpy(B).double().cuda().T).cpu().numpy()
+
+    def store(X, transpose):
+        X = X.T if transpose else X
+        P = np.zeros((X.shape[0], pad4(X.shape[1]) + 4), np.float32)
+        P[:, :X.shape[1]] = X
+        return P
+    Ad, Bd = store(A, layout == 2), store(B, layout != 0)
+    a, b = dev(Ad), dev(Bd)
+    ldc = pad4(N) + 4
+    c = torch.full((M, ldc), 0.5, device="cuda")
+    for rep in range(2):
+        ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(a), Ad.shape[1], vp(b), Bd.shape[1], vp(c), ldc, None, mode, 1, 1, 0, 0, 0, stream()))
+        close(c[:, :N], 0.5 + (rep + 1) * ref, rtol=3e-5, msg=f"pass {rep}")
+        assert float(c[:, N:].min()) == 0.5 and float(c[:, N:].max()) == 0.5, "wrote outside N"
+
+
 def _split_tiles_body(lib, M, N, K, reps):
     rng = np.random.default_rng(M + N + K)
     A = rng.standard_normal((M, K)).astype(np.float32)
