@@ -1576,8 +1576,9 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   // Few tiles, deep K, accumulating output (the weight gradients: TN 512 x 1152 x 38400 is 18 tiles of 2400 k-iterations): chunk-major order,
   // chunk = the divisor of kt nearest to a workgroup's share.  (ASTK_GEMM_CHUNK=0: tile-major always.)
   static const bool chunk_on = !(getenv("ASTK_GEMM_CHUNK") && getenv("ASTK_GEMM_CHUNK")[0] == '0');
+  static const int chunk_div = getenv("ASTK_GEMM_CHUNK_DIV") ? atoi(getenv("ASTK_GEMM_CHUNK_DIV")) : 4;      // (tuning hook: tiles * div <= G)
   for (int i = 0; i < grp.n; ++i) { grp.g[i].cs = 0; grp.g[i].chunk_iters = 0; }
-  if (chunk_on && grp.n == 1 && !aligned && grp.dp_waves == 0 && grp.g[0].mode != GEMM_STORE && prec != PREC_F32 && tiles * 4 <= G && grp.g[0].kt >= 128) {
+  if (chunk_on && grp.n == 1 && !aligned && grp.dp_waves == 0 && grp.g[0].mode != GEMM_STORE && prec != PREC_F32 && tiles * chunk_div <= G && grp.g[0].kt >= 128) {
     GemmArgs& a = grp.g[0];
     const long share = grp.iters_total / G;      // k-iterations per workgroup
     int best = 0;
