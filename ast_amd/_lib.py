@@ -22,13 +22,28 @@ c_int_p = C.POINTER(C.c_int32)
 c_double_p = C.POINTER(C.c_double)
 
 
-class CnnDesc(C.Structure):
-    _fields_ = [("B", C.c_int), ("T", C.c_int), ("D", C.c_int), ("n_layers", C.c_int),
+class _Sized:
+    """Descriptors that start with `struct_size` (astk.h): zero-initialised, sized, then the positional / keyword fields BEHIND struct_size."""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+        names = [f[0] for f in self._fields_[1:]]
+        assert len(a) <= len(names)
+        for n, v in zip(names, a):
+            setattr(self, n, v)
+        for n, v in k.items():
+            setattr(self, n, v)
+        self.struct_size = C.sizeof(type(self))
+
+
+class CnnDesc(_Sized, C.Structure):
+    _fields_ = [("struct_size", C.c_size_t), ("B", C.c_int), ("T", C.c_int), ("D", C.c_int), ("n_layers", C.c_int),
                 ("C", C.c_int * MAX_CNN), ("kt", C.c_int * MAX_CNN), ("kf", C.c_int * MAX_CNN),
                 ("st", C.c_int * MAX_CNN), ("sf", C.c_int * MAX_CNN), ("pt", C.c_int * MAX_CNN),
                 ("bn_eps", C.c_float), ("bn_decay", C.c_float), ("no_bn", C.c_int),
                 ("pool_t", C.c_int * MAX_CNN), ("pool_f", C.c_int * MAX_CNN),
-                ("precision", C.c_int), ("gemm_operands", C.c_int), ("status_dst", C.c_void_p)]
+                ("precision", C.c_int), ("gemm_operands", C.c_int), ("status_dst", C.c_void_p), ("deterministic", C.c_int)]
+
 
 
 class CnnLayerParams(C.Structure):
@@ -40,10 +55,12 @@ class CnnLayerGrads(C.Structure):
     _fields_ = [("dW", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dbias", C.c_void_p)]
 
 
-class LstmStackDesc(C.Structure):
-    _fields_ = [("T", C.c_int), ("B", C.c_int), ("in_dim", C.c_int), ("h", C.c_int),
+class LstmStackDesc(_Sized, C.Structure):
+    _fields_ = [("struct_size", C.c_size_t), ("T", C.c_int), ("B", C.c_int), ("in_dim", C.c_int), ("h", C.c_int),
                 ("n_layers", C.c_int), ("n_dirs", C.c_int), ("out_bound", C.c_float), ("x_amax", C.c_void_p),
-                ("precision", C.c_int), ("gemm_operands", C.c_int)]
+                ("precision", C.c_int), ("gemm_operands", C.c_int), ("side_stream", C.c_void_p), ("side_wgs", C.c_int),
+                ("deterministic", C.c_int)]
+
 
 
 class LstmParams(C.Structure):
@@ -62,12 +79,13 @@ class RandSeg(C.Structure):
 RAND_DROPOUT, RAND_NORMAL, RAND_SEG_MAX, RAND_WORDS_MAX = 0, 1, 8, 256
 
 
-class DecoderDesc(C.Structure):
-    _fields_ = [("B", C.c_int), ("L", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int),
+class DecoderDesc(_Sized, C.Structure):
+    _fields_ = [("struct_size", C.c_size_t), ("B", C.c_int), ("L", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int),
                 ("A", C.c_int), ("V", C.c_int), ("n_layers", C.c_int),
                 ("n_attn", C.c_int), ("no_feed_attn", C.c_int), ("ln", C.c_int), ("loss_rows", C.c_int),
                 ("use_truth_host", C.POINTER(C.c_int32)), ("precision", C.c_int), ("gemm_operands", C.c_int), ("status_dst", C.c_void_p),
-                ("zero_ptr", C.c_void_p), ("zero_bytes", C.c_size_t)]
+                ("zero_ptr", C.c_void_p), ("zero_bytes", C.c_size_t), ("side_wgs", C.c_int), ("deterministic", C.c_int)]
+
 
 
 class DecoderParams(C.Structure):
@@ -91,6 +109,9 @@ _VP, _I, _L, _SZ, _F, _U64 = C.c_void_p, C.c_int, C.c_long, C.c_size_t, C.c_floa
 SIGNATURES = {
     "astk_version": (C.c_int, []),
     "astk_last_error": (C.c_char_p, []),
+    "astk_set_tuning": (C.c_int, [C.c_char_p, C.c_double]),
+    "astk_get_tuning": (C.c_int, [C.c_char_p, C.POINTER(C.c_double)]),
+    "astk_tuning_key": (C.c_char_p, [_I]),
     "astk_set_low_precision_gemms": (C.c_int, [_I]),
     "astk_get_low_precision_gemms": (C.c_int, []),
     "astk_set_gemm_bf16_split_below": (C.c_double, [C.c_double]),
@@ -218,6 +239,31 @@ class load_test_hooks:
     def __exit__(self, *exc):
         global _lib
         _lib = self.prev
+        return False
+
+
+def set_tuning(key, value):
+    """astk_set_tuning (include/astk.h): the library's documented knobs; returns the previous value."""
+    lib = load()
+    prev = C.c_double()
+    check(lib.astk_get_tuning(key.encode(), C.byref(prev)))
+    check(lib.astk_set_tuning(key.encode(), float(value)))
+    return prev.value
+
+
+class tuning:
+    """`with tuning({"dec.persist": 0}): ...` -- sets knobs of the CURRENTLY loaded library for the block and restores them."""
+
+    def __init__(self, knobs):
+        self.knobs = dict(knobs)
+
+    def __enter__(self):
+        self.prev = {k: set_tuning(k, v) for k, v in self.knobs.items()}
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            set_tuning(k, v)
         return False
 
 

@@ -32,6 +32,12 @@ struct ProfScope {
     }                                    \
   } while (0)
 
+// Every descriptor starts with struct_size (astk.h): a caller built against another layout fails here instead of handing over garbage pointers.
+#define ASTK_CHECK_DESC(d, type)                                                                                                        \
+  ASTK_CHECK((d) != nullptr && (d)->struct_size == sizeof(type),                                                                         \
+             #type ": null descriptor or struct_size %zu != %zu (zero-initialise the struct, set struct_size = sizeof(" #type "), astk.h)", \
+             (d) ? (size_t)(d)->struct_size : (size_t)0, sizeof(type))
+
 #define ASTK_HIP(expr)                                                               \
   do {                                                                               \
     hipError_t e_ = (expr);                                                          \
@@ -64,11 +70,24 @@ enum PersistBit { PERSIST_ENC_FWD = 1, PERSIST_ENC_BWD = 2, PERSIST_DEC_FWD = 4,
 struct AbortCtl {
   unsigned* word;     // per-launch abort word
   unsigned* status;   // sticky status word of the library (device memory owned by util.hip)
-  unsigned limit;     // spin bound (polls); ASTK_PERSIST_SPIN_LIMIT overrides the default of 1 << 22 (seconds)
+  unsigned limit;     // spin bound (polls); astk_set_tuning("persist.spin_limit") overrides the default of 1 << 22 (seconds)
   unsigned bit;       // PersistBit of the launching kernel
 };
 AbortCtl abort_ctl(unsigned* word, unsigned bit);     // host side: fills status / limit
 int device_cu_count();                                 // multiProcessorCount of the current device (cached per device)
+// Tuning knobs (astk_set_tuning / astk_get_tuning in astk.h: documented, process-wide, read at every launch -- they replace the environment
+// variables the library read in rounds 1-5; the product library reads NO environment variable).
+enum TuneKey {
+  TUNE_GEMM_TILE, TUNE_GEMM_T256_ABOVE, TUNE_GEMM_GRID, TUNE_GEMM_HYBRID, TUNE_GEMM_CHUNK, TUNE_GEMM_CHUNK_DIV, TUNE_GEMM_LOG, TUNE_GEMM_TICKET,
+  TUNE_GEMM_DETERMINISTIC,
+  TUNE_CONV_DIRECT0, TUNE_CONV_SEQ_FWD, TUNE_CONV_SEQ_BWD, TUNE_CONV_SEQ_STATS_BLOCKS, TUNE_CONV_SEQ_APPLY_BLOCKS,
+  TUNE_DEC_PERSIST, TUNE_DEC_B6_SPLIT, TUNE_DEC_B6_FUSED, TUNE_DEC_WIDE,
+  TUNE_LSTM_PERSIST, TUNE_LSTM_HOIST, TUNE_LSTM_X3, TUNE_LSTM_X4, TUNE_LSTM_ROWS32, TUNE_LSTM_OVERLAP_CHUNK,
+  TUNE_ROW_LONGK, TUNE_PERSIST_SPIN_LIMIT, TUNE_COLREDUCE_BLOCKS,
+  TUNE_COUNT
+};
+double tune(TuneKey k);
+inline bool tune_on(TuneKey k) { return tune(k) != 0.0; }
 __device__ __forceinline__ bool abort_seen(const AbortCtl& ab) {
   return __hip_atomic_load(ab.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
@@ -582,12 +601,12 @@ __device__ __forceinline__ void colreduce_block(int rows, int cols, Acc acc, Emi
 }
 // grid for colreduce_block: one block per CU, at least 16 rows per lane.  (Every block ends in same-address double atomics, one per column and
 // statistic: with 512 blocks the layer-0 BatchNorm statistics -- 128 columns, i.e. 256 arrivals per address -- took 29 us for a 39 MB read, with
-// 256 blocks 19; 128 blocks lose on the wide layers.  ASTK_COLREDUCE_BLOCKS overrides.)
+// 256 blocks 19; 128 blocks lose on the wide layers.  astk_set_tuning("colreduce.blocks") overrides.)
 static inline dim3 colreduce_grid(int rows, int cols) {
   const int q = (cols + 3) / 4;
   const int CL = q < COLREDUCE_CL ? q : COLREDUCE_CL, NR = 256 / CL;
   const int gx = (q + CL - 1) / CL;
-  static const int blocks = getenv("ASTK_COLREDUCE_BLOCKS") ? atoi(getenv("ASTK_COLREDUCE_BLOCKS")) : 256;
+  const int blocks = (int)tune(TUNE_COLREDUCE_BLOCKS);
   int gy = blocks / gx;
   const int max_gy = (rows + 16 * NR - 1) / (16 * NR);
   if (gy > max_gy) gy = max_gy;

@@ -80,6 +80,7 @@ struct CnnPlan {
 int conv_out(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
 
 int make_plan(const astk_cnn_desc* d, void* ws, CnnPlan& P) {
+  ASTK_CHECK_DESC(d, astk_cnn_desc);
   ASTK_CHECK(d && d->n_layers >= 1 && d->n_layers <= ASTK_MAX_CNN_LAYERS, "cnn: 1..%d layers", ASTK_MAX_CNN_LAYERS);
   ASTK_CHECK(d->B > 0 && d->T > 0 && d->D > 0, "cnn: bad input dims");
   P.n = d->n_layers; P.B = d->B; P.T = d->T; P.D = d->D;
@@ -234,9 +235,9 @@ static bool conv0_direct_shape(const astk_cnn_desc* d) {
          d->pool_f[0] <= 1;
 }
 // the direct path is taken for the shipped layer-0 shapes under the default arithmetic (bf16x3, f32 operands); forward and backward decide
-// alike (same descriptor, same process default).  ASTK_CONV0_DIRECT=0: the im2col + GEMM path always.
+// alike (same descriptor, same process default).  astk_set_tuning("conv.direct0", 0): the im2col + GEMM path always.
 static bool conv0_direct(const astk_cnn_desc* d) {
-  static const bool off = getenv("ASTK_CONV0_DIRECT") && getenv("ASTK_CONV0_DIRECT")[0] == '0';
+  const bool off = !tune_on(TUNE_CONV_DIRECT0);
   return !off && conv0_direct_shape(d) && gemm_precision_mode() == 1 && low_precision_gemms() == 0;
 }
 // Which layer-0 path a forward call took on a workspace (host-side record, never read by a kernel): conv0_direct() is re-evaluated by
@@ -1089,7 +1090,7 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
                                void* ws, size_t ws_bytes, int train, astk_stat_exchange_fn exchange, void* user, int world,
                                void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  ASTK_CHECK(d, "conv_bn_relu_fwd: null descriptor");
+  ASTK_CHECK_DESC(d, astk_cnn_desc);
   PrecScope prec_scope(d->precision, d->gemm_operands);
   GemmForwardScope forward_scope;      // split tiles of this op's products have at most two contributors (reproducible forward pass)
   gemm_amax_step_boundary(s);         // the first op of a step: no operand-maximum handle is live here
@@ -1174,7 +1175,7 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
                          P.Tn[i], P.padA[i], P.a_hp_s[i]);
       ASTK_LAUNCH_CHECK();
     } else {
-      static const bool tiled_off = getenv("ASTK_CNN_SEQ_FWD") && getenv("ASTK_CNN_SEQ_FWD")[0] == '0';
+      const bool tiled_off = !tune_on(TUNE_CONV_SEQ_FWD);
       if (!tiled_off && seq_bwd_applicable(C, F, (long)P.Tn[i] * B)) {
         const int pp = seq_pp(F), gy = std::max(1, std::min(2048 / (C / SEQ_CH), cdiv(P.Tn[i] * B, pp)));
         hipLaunchKernelGGL(k_bn_relu_to_seq_tiled, dim3(C / SEQ_CH, gy), dim3(256), (size_t)pp * SEQ_CH * F * sizeof(float), s, P.Y[i], P.bn[i], out, B, F,
@@ -1222,7 +1223,7 @@ int astk_conv_bn_relu_bwd(const astk_cnn_desc* d, const astk_cnn_layer_params* L
 int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_params* L, const astk_cnn_layer_grads* Gr, float* d_out,
                                void* ws, size_t ws_bytes, astk_stat_exchange_fn exchange, void* user, int world, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  ASTK_CHECK(d, "conv_bn_relu_bwd: null descriptor");
+  ASTK_CHECK_DESC(d, astk_cnn_desc);
   PrecScope prec_scope(d->precision, d->gemm_operands);
   ASTK_CHECK(world >= 1, "conv_bn_relu_bwd: world %d", world);
   if (world == 1 || d->no_bn) exchange = nullptr;      // (no statistics to exchange without BatchNorm)
@@ -1238,8 +1239,8 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
   }
   const int B = P.B;
   // the last layer's BatchNorm backward reads d_out in its (T'', B, C*F') layout itself (k_bn_bwd_*_seq); shapes those kernels do not take
-  // (and the test hook that edits G) go through the re-ordered copy G as before.  ASTK_CNN_SEQ_BWD=0: always the copy.
-  static const bool seq_off = getenv("ASTK_CNN_SEQ_BWD") && getenv("ASTK_CNN_SEQ_BWD")[0] == '0';
+  // (and the test hook that edits G) go through the re-ordered copy G as before.  astk_set_tuning("conv.seq_bwd", 0): always the copy.
+  const bool seq_off = !tune_on(TUNE_CONV_SEQ_BWD);
   bool seq_last = !seq_off && seq_bwd_applicable(P.Cn[P.n - 1], P.Fn[P.n - 1], (long)P.Tn[P.n - 1] * B);
 #ifdef ASTK_TEST_HOOKS
   if (g_kill_n > 0) seq_last = false;
@@ -1272,7 +1273,7 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
     const bool seq = seq_last && i == P.n - 1;
     const int seq_gx = C / SEQ_CH;
     if (seq) {
-      static const int sb = getenv("ASTK_SEQ_STATS_BLOCKS") ? atoi(getenv("ASTK_SEQ_STATS_BLOCKS")) : 1024;
+      const int sb = (int)tune(TUNE_CONV_SEQ_STATS_BLOCKS);
       const int gy = std::max(1, std::min(sb / seq_gx, cdiv(P.Tn[i] * B, seq_pp(P.Fn[i]))));
       hipLaunchKernelGGL(k_bn_bwd_stats_seq, dim3(seq_gx, gy), dim3(256), seq_tile_bytes(P.Fn[i]), s, P.Y[i], d_out, P.bn[i], B, P.Fn[i], P.Tn[i], C,
                          seq_pp(P.Fn[i]), P.stat[i]);
@@ -1294,7 +1295,7 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
     // (no_bn: the ReLU mask alone -- scale 1 and a zero 1/m switch the BatchNorm terms off; the column sums of g are the bias gradient)
     // pooled layers: the gradient wrt the POOLED output goes to DYP (plain rows), k_unpool spreads it over the padded dY of the convolution
     if (seq) {
-      static const int ab = getenv("ASTK_SEQ_APPLY_BLOCKS") ? atoi(getenv("ASTK_SEQ_APPLY_BLOCKS")) : 1024;
+      const int ab = (int)tune(TUNE_CONV_SEQ_APPLY_BLOCKS);
       const int gy = std::max(1, std::min(ab / seq_gx, cdiv(P.Tn[i] * B, seq_pp(P.Fn[i]))));
       hipLaunchKernelGGL(k_bn_bwd_apply_seq, dim3(seq_gx, gy), dim3(256), seq_tile_bytes(P.Fn[i]), s, P.Y[i], d_out, P.bn[i], P.stat[i],
                          P.pooled[i] ? P.DYP[i] : P.DY[i], B, P.Fn[i], P.Tn[i], C, seq_pp(P.Fn[i]), P.pooled[i] ? 0 : P.dF[i], P.pooled[i] ? 0 : P.dB[i],

@@ -93,7 +93,7 @@ struct DecPlan {
 };
 
 // Which kernel path a forward call took on a workspace (diagnostics only, never read by a kernel): the path and the workspace carve are
-// re-derived from the shape AND the environment (ASTK_DEC_PERSIST / ASTK_DEC_WIDE) at every call, so a backward call made under another
+// re-derived from the shape AND the tuning knobs ("dec.persist" / "dec.wide") at every call, so a backward call made under another
 // environment than its forward call would read the saved activations at shifted offsets without any error.  The forward records
 // (workspace, path), the backward refuses a workspace whose record differs.
 struct PathRecord { const void* ws; int path; };
@@ -114,6 +114,7 @@ static int path_lookup(const void* ws) {      // -1: no forward call recorded fo
 }
 
 int make_plan(const astk_decoder_desc* d, void* ws, DecPlan& P) {
+  ASTK_CHECK_DESC(d, astk_decoder_desc);
   ASTK_CHECK(d && d->B > 0 && d->L >= 2 && d->T > 0 && d->V > 1, "decoder: bad dims");
   ASTK_CHECK(d->n_layers >= 1 && d->n_layers <= ASTK_MAX_RNN_LAYERS, "decoder: layers");
   ASTK_CHECK((d->H % 4) == 0 && (d->E % 4) == 0 && (d->A % 4) == 0, "decoder: H, E, A must be multiples of 4");
@@ -437,7 +438,7 @@ extern "C" {
 
 int astk_decoder_path(const astk_decoder_desc* d) {
   int ns = 1, ch = 1;
-  if (!d) return 0;
+  if (!d || d->struct_size != sizeof(astk_decoder_desc)) return 0;
   if (!decoder_persist_applicable(d, &ns, &ch)) {
     SplitPlan sp;
     if (make_split(d, nullptr, sp) != 0 || !sp.on) return decoder_wide_applicable(d, nullptr, nullptr) ? 16 : 0;   // 16: wide forward loop (decoder_wide.hip)
@@ -481,7 +482,7 @@ static int decoder_fwd_impl(const astk_decoder_desc* d, const astk_decoder_param
                             const int32_t* y, const int32_t* use_truth, const float* emb_mask, const float* rnn_masks, const float* out_mask,
                             const int32_t* targets, float* loss, int32_t* pred, void* ws, size_t ws_bytes, void* stream, bool* snapshot_taken) {
   hipStream_t s = (hipStream_t)stream;
-  ASTK_CHECK(d, "decoder_fwd: null descriptor");
+  ASTK_CHECK_DESC(d, astk_decoder_desc);
   PrecScope prec_scope(d->precision, d->gemm_operands);
   GemmForwardScope forward_scope;      // split tiles of this op's products have at most two contributors (reproducible forward pass)
   {
@@ -669,7 +670,7 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
                               void* stream) {
   hipStream_t s = (hipStream_t)stream;
   (void)c0; (void)h0; (void)y;
-  ASTK_CHECK(d, "decoder_bwd: null descriptor");
+  ASTK_CHECK_DESC(d, astk_decoder_desc);
   PrecScope prec_scope(d->precision, d->gemm_operands);
   ASTK_CHECK(phase == ASTK_DEC_BWD_ALL || phase == ASTK_DEC_BWD_CHAIN || phase == ASTK_DEC_BWD_PARAMS, "decoder_bwd: bad phase %d", phase);
   {
@@ -708,7 +709,7 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
   {
     const int fwd_path = path_lookup(ws), bwd_path = persist ? 1 : (wide_b ? 2 : 0);
     ASTK_CHECK(fwd_path < 0 || fwd_path == bwd_path, "decoder_bwd: the forward call on this workspace took kernel path %d, this call would take %d "
-               "(ASTK_DEC_PERSIST / ASTK_DEC_WIDE changed between the two calls?)", fwd_path, bwd_path);
+               "(the dec.persist / dec.wide knobs changed between the two calls?)", fwd_path, bwd_path);
   }
   if (do_chain) {
   // astk_decoder_desc.zero_ptr (the gradient arena): in front of everything this call accumulates -- the persistent launcher's fill takes
@@ -938,7 +939,7 @@ int astk_decoder_step_infer(const astk_decoder_desc* d, const astk_decoder_param
                             const int32_t* tokens, float* logits, float* alpha, int32_t* argmax, void* ws, size_t ws_bytes,
                             void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  ASTK_CHECK(d, "decoder_step_infer: null descriptor");
+  ASTK_CHECK_DESC(d, astk_decoder_desc);
   PrecScope prec_scope(d->precision, d->gemm_operands);
   DecPlan P;
   ASTK_TRY(make_plan(d, ws, P));

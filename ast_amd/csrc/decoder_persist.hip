@@ -1707,8 +1707,7 @@ static size_t pdec_bwd_lds_floats(int chunk, int H) {
 }
 
 bool decoder_persist_applicable(const astk_decoder_desc* d, int* nsplit_out, int* chunk_out) {
-  const char* e = getenv("ASTK_DEC_PERSIST");
-  if (e && e[0] == '0') return false;
+  if (!tune_on(TUNE_DEC_PERSIST)) return false;
   if (d->n_attn > 1 || d->no_feed_attn || d->ln) return false;      // optional model features: per-launch loop (decoder.hip)
   if (d->n_layers < 1 || d->n_layers > PDEC_MAX_LAYERS) return false;
   if (device_cu_count() < G) return false;        // fixed roles over G workgroups, all of them resident (one per CU)
@@ -1753,8 +1752,7 @@ bool decoder_persist_b6_split(const astk_decoder_desc* d) {
   const int n5 = nbt * (d->H / 16), n6 = 2 * nbt * (d->A / 16), n1 = nbt * (d->A / 16), n2 = nbt * (2 * d->H / 32);
   if ((4 * d->H) % 128) return false;
   if (d->n_layers > 1) return true;           // the multi-layer role layout always uses the split form (decoder_persist_applicable checked it)
-  const char* e = getenv("ASTK_DEC_B6_SPLIT");
-  if (e && e[0] == '0') return false;
+  if (!tune_on(TUNE_DEC_B6_SPLIT)) return false;
   return n5 + n6 + (n1 > n2 ? n1 : n2) <= G;
 }
 
@@ -1814,11 +1812,10 @@ int decoder_persist_bwd_launch(const astk_decoder_desc* d, const float* enc, con
   a.DX0 = bf.DX0; a.DHATT = bf.DHATT; a.d_c0 = bf.d_c0;
   a.DXH = bf.DXH;
   a.b6_split = bf.DXH != nullptr && decoder_persist_b6_split(d) ? 1 : 0;
-  if (a.b6_split) {          // ASTK_DEC_B6_FUSED=0: the d_x0 role of rounds 2-3 (kept for A/B runs)
-    const char* e = getenv("ASTK_DEC_B6_FUSED");
+  if (a.b6_split) {          // astk_set_tuning("dec.b6_fused", 0): the d_x0 role of rounds 2-3 (kept for A/B runs)
     const int n5 = a.nbt * (a.H / 16), n1 = a.nbt * (a.A / 16), n2 = a.nbt * (2 * a.H / 32);
     const bool fits = d->n_layers == 1 ? n5 + 2 * n1 + n2 <= G : ((d->n_layers - 1) * n5 + 2 * n1 <= G && d->n_layers * n5 + n2 <= G);
-    if (!(e && e[0] == '0') && fits) a.b6_split = 2;
+    if (tune_on(TUNE_DEC_B6_FUSED) && fits) a.b6_split = 2;
   }
   ASTK_CHECK(d->n_layers == 1 || a.b6_split, "decoder_persist_bwd: the multi-layer role layout needs the split d_x0 buffers");
   a.ctr = bf.ctr;

@@ -75,9 +75,6 @@ __device__ __forceinline__ void acquire_handoff() {
 }
 // lanes 0..NSH-1 of wave 0 poll the shards of a phase counter until `n_items` items have arrived `steps` times each
 __device__ __forceinline__ bool wait_sh(const unsigned* base, int n_items, int steps, const AbortCtl& ab, int* s_flag) {
-#ifdef ASTK_WIDE_NOWAIT      // timing experiment only (wrong results): how long is a step without its hand-offs?
-  return true;
-#endif
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     const unsigned target = lane < NSH ? (unsigned)(((n_items - lane + NSH - 1) / NSH) * steps) : 0u;
@@ -98,9 +95,6 @@ __device__ __forceinline__ bool wait_sh(const unsigned* base, int n_items, int s
   return ok;
 }
 __device__ __forceinline__ bool wait_one(const unsigned* ctr, unsigned target, const AbortCtl& ab, int* s_flag) {
-#ifdef ASTK_WIDE_NOWAIT
-  return true;
-#endif
   if (threadIdx.x == 0) {
     bool ok = true;
     unsigned spins = 0;
@@ -751,8 +745,7 @@ size_t wide_lds_bytes(int chunk) { return ((size_t)chunk * WH + 4 * WH + 2048 + 
 // Applicable: configs[4]'s decoder shape, one layer, one attention head, input feeding, no LayerNorm; the device's CUs hold the grid; the
 // time slices fit LDS.  (decoder.hip additionally needs the host copy of the teacher-forcing flags to cut the loop into segments.)
 bool decoder_wide_applicable(const astk_decoder_desc* d, int* nsplit_out, int* chunk_out) {
-  const char* e = getenv("ASTK_DEC_WIDE");
-  if (e && e[0] == '0') return false;
+  if (!tune_on(TUNE_DEC_WIDE)) return false;
   if (d->H != WH || d->A != WA || d->E != WE || d->n_layers != 1 || d->n_attn > 1 || d->no_feed_attn || d->ln) return false;
   if (d->B < 1 || d->B > 32 || d->T < 1 || d->V < 2 || device_cu_count() < WG_) return false;
   int nsplit = WG_ / d->B;

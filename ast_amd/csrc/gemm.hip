@@ -1,11 +1,14 @@
 // Batched dense products of the train step on the gfx950 matrix pipe (SURVEY.md K6, K9, K24 and all dgrad / wgrad products):
 // C[M,N] (+)= op(A) op(B) (+bias), f32 in, f32 out, f32-level accuracy.
 //
-// One kernel template, three operand schemes (GemmPrec below):
-//   * fp16x2 (default): every operand value is split INSIDE the kernel into two fp16 terms behind a per-operand power-of-two scale, three
-//     v_mfma_f32_32x32x16_f16 per 16 k; the scales come from an absolute-maximum pass in front of the launch (k_absmax) or from the caller
-//   * bf16x3 (launches below 3 GFLOP, or ASTK_GEMM_PREC=bf16x3): three bf16 terms, no scales, six v_mfma_f32_32x32x16_bf16 per 16 k
-//   * f32 (ASTK_GEMM_PREC=f32): v_mfma_f32_32x32x2_f32, the exact k-ordered f32 fma chain (round 1's kernel)
+// One kernel template, three operand schemes (GemmPrec below; chosen per call by the descriptors' `precision`, astk.h):
+//   * bf16x3 (DEFAULT): every f32 operand value is split INSIDE the kernel into three bf16 terms that represent it exactly (f32 exponent range, no
+//     scales), six v_mfma_f32_32x32x16_bf16 per 16 k -- at least the accuracy of an f32 fma chain on any data; launches of >= 20 GFLOP take the
+//     12-wave 256 x 128 kernel
+//   * fp16x2 (opt-in, NARROWER than float32: ASTK_PREC_FP16X2 / astk_set_gemm_precision(0)): two fp16 terms behind a per-operand power-of-two scale,
+//     three v_mfma_f32_32x32x16_f16 per 16 k; the scales come from an absolute-maximum pass in front of the launch (k_absmax), from the kernel that
+//     wrote the operand, or from the caller; launches below 3 GFLOP do not repay that pass and run as bf16x3
+//   * f32 (ASTK_PREC_F32 / astk_set_gemm_precision(2)): v_mfma_f32_32x32x2_f32, the exact k-ordered f32 fma chain (round 1's kernel)
 // (+ single-term fp16 operands for the launches their callers mark `lowp` when astk_set_low_precision_gemms(1) is in force).
 //   128x128x16 block tile (BK = 16), 64x64x16 tiles for launches too small to occupy the chip with 128-tiles; k-iterations split evenly
 //   over the grid (stream-K).  Split schemes: 512 threads -- waves 0-3 multiply out of LDS (fragments of tile kt+1 fetched behind tile
@@ -49,16 +52,6 @@ constexpr int BK = ASTK_GEMM_BK;
 #endif
 #ifndef ASTK_GEMM_PRIO8S
 #define ASTK_GEMM_PRIO8S 0      // ... and of its staging waves
-#endif
-// ASTK_GEMM_REFILL_FENCE=1: a scheduling barrier between a slot's split and its refill.  Without it hipcc starts the refill with one load in
-// front of the split's last uses of the old tile and waits with s_waitcnt vmcnt(0) in two of six iterations; with it every wait leaves the
-// new loads in flight (vmcnt(8..11)).  Measured, same box: family 2.418 -> 2.435 ms kernels only -- the drain was not what the staging
-// waves wait for.  Off.
-#ifndef ASTK_GEMM_REFILL_FENCE
-#define ASTK_GEMM_REFILL_FENCE 0
-#endif
-#ifndef ASTK_GEMM_REFILL_EARLY
-#define ASTK_GEMM_REFILL_EARLY 1
 #endif
 #ifndef ASTK_GEMM_PAIR
 #define ASTK_GEMM_PAIR 1        // K-contiguous operands: fetch two k-tiles (one 128-byte line per row) at a time
@@ -153,50 +146,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 // two values -> one dword of each plane (element 0 in the low half).  (Inline asm is safe HERE: the planes go to LDS, no MFMA reads a
 // converted register directly -- see common.h cvt_pk_bf16_f32 for where it is not.)
-#ifndef ASTK_GEMM_SPLIT_ASM
-#define ASTK_GEMM_SPLIT_ASM 1
-#endif
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-#if ASTK_GEMM_SPLIT_ASM
   unsigned r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
-#else
-  return cvt_pk_bf16_f32(lo, hi);
-#endif
 }
-// ASTK_GEMM_SPLIT_ASM == 2: the residuals through v_dot2c_f32_bf16 -- r0 = x0 + hi_pk . (-1, 0), r1 = x1 + hi_pk . (0, -1): the dot
-// product reads the packed bf16 terms in place, so the two instructions that widen them again (shift, and) disappear: 7 vector-ALU
-// instructions per pair of values instead of 11.  Exact (the result is representable: scratch/dot2_split_probe.hip checks 1M values bit
-// for bit).  The (-1, 0) / (0, -1) selectors must come from REGISTERS: as literals hipcc folds them into inline constants that the
-// hardware reads differently (the probe's second column).
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned opaque_const(unsigned v) {
-  unsigned r;
-  asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "i"(v));
-  return r;
-}
-__device__ __forceinline__ void split2_dot(float x0, float x1, unsigned m0, unsigned m1, unsigned& hi, unsigned& mid, unsigned& lo) {
-  // (the conversions through the compiler's own lowering, not inline asm: a dot instruction that reads a register an asm statement wrote
-  //  gets no hazard protection from hipcc -- wrong results, seen)
-  hi = cvt_pk_bf16_f32(x0, x1);
-  const bf16x2_t h = __builtin_bit_cast(bf16x2_t, hi), s0 = __builtin_bit_cast(bf16x2_t, m0), s1 = __builtin_bit_cast(bf16x2_t, m1);
-  const float r0 = __builtin_amdgcn_fdot2_f32_bf16(h, s0, x0, false), r1 = __builtin_amdgcn_fdot2_f32_bf16(h, s1, x1, false);
-  mid = cvt_pk_bf16_f32(r0, r1);
-  const bf16x2_t m = __builtin_bit_cast(bf16x2_t, mid);
-  const float q0 = __builtin_amdgcn_fdot2_f32_bf16(m, s0, r0, false), q1 = __builtin_amdgcn_fdot2_f32_bf16(m, s1, r1, false);
-  lo = cvt_pk_bf16_f32(q0, q1);
-}
+// (the residuals through v_dot2c_f32_bf16 -- 7 instead of 11 vector-ALU instructions per pair -- were built, verified bit for bit and measured SLOWER:
+//  HISTORY.md round 4, scratch/dot2_split_probe.hip)
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
-#if ASTK_GEMM_SPLIT_ASM
   hi = cvt_pk_bf16(x0, x1);
   const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
   mid = cvt_pk_bf16(r0, r1);
   const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
   lo = cvt_pk_bf16(s0, s1);
-#else
-  split2b(x0, x1, hi, mid, lo);
-#endif
 }
 // The power of two that brings an operand's absolute maximum into [2^14, 2^15), as the biased exponent of a float (amax: the word
 // gemm_absmax left: launch generation in the high half, the maximum's float bits in the low half; null or zero maximum: 1.0).
@@ -239,30 +201,17 @@ struct Stager {
   int kcur;           // first k of the tile the next load() fetches
   int lds;            // float offset of this thread's first LDS write
   float scl;          // fp16x2: the operand's power-of-two scale
-  unsigned sel0, sel1;  // bf16x3 (dot2 form of the split): the packed bf16 selectors (-1, 0) and (0, -1), in registers
-  int row0_edge;      // KR: 1 when this tile reaches past the operand's last column (uniform)
-  int nvc;            // KR, dot2 form: how many of this thread's 4 columns exist (1..4).  The dot product couples the two values of a pair
-                      // (0 x NaN = NaN), so a padding column -- uninitialised memory, by the ABI -- must not reach it next to a real one
 
   // row0 / nrows: the tile's first M (N) index and the operand's M (N) extent; [kbeg, kend): this workgroup's K range.
   // Leading dimensions are multiples of 4 and >= the extent, so a float4 at any multiple of 4 below round_up(extent, 4)
   // stays inside its row.
   __device__ __forceinline__ void init(const MatView& v, int row0, int nrows, int kbeg, int kend, int tid) {
     kcur = kbeg;
-    row0_edge = row0 + TL > nrows ? 1 : 0;
-    nvc = 4;
-#if ASTK_GEMM_SPLIT_ASM == 2
-    if constexpr (PREC == PREC_BF16X3) { sel0 = opaque_const(0x0000bf80u); sel1 = opaque_const(0xbf800000u); }
-#endif
     if (RK) {
       a = tid % KQ;
       b = tid / KQ;
 #pragma unroll
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 128)     // timing experiment (wrong results): 8 lanes per row = whole 128-byte lines per wave instruction
-      for (int p = 0; p < NP; ++p) voff[p] = (unsigned)((rowoff(v, min(row0 + (NP * (tid / 8) + p) % TL, nrows - 1)) + (tid % 8) * 4) * 4);
-#else
       for (int p = 0; p < NP; ++p) voff[p] = (unsigned)((rowoff(v, min(row0 + NP * b + p, nrows - 1)) + a * 4) * 4);
-#endif
       lds = NP * b * LD_RK + 2 * a;   // a thread's NP rows are neighbours: one LDS address register serves all its writes
     } else {
       a = tid % CQ;
@@ -275,18 +224,13 @@ struct Stager {
       for (int p = 0; p < NP; ++p)
         voff[p] = (unsigned)(((long)(b + RP * p) * (TWOLVL ? v.st : v.ld) + col) * 4);
       if (TWOLVL) { tgrp = kbeg / v.tn; trem = kbeg % v.tn; tcol = col; }
-      nvc = nrows - col;
       lds = b * LD_KR + 4 * a;
     }
   }
   // span: bytes from v.p to the end of the operand slice (gemm_prepare)
   __device__ __forceinline__ void load(const MatView& v, unsigned span, int kend, const int slot = 0) {
     if (RK || !TWOLVL) {
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 64)
-      const long adv = RK ? (long)(kcur & 63) : (long)(kcur & 63) * v.ld;
-#else
       const long adv = RK ? (long)kcur : (long)kcur * v.ld;
-#endif
       const __amdgpu_buffer_rsrc_t r =
           __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(v.p + adv), 0, (int)(span - (unsigned)(adv * 4)), 0x00020000);
 #pragma unroll
@@ -320,11 +264,7 @@ struct Stager {
   // (4 tiles x 256 rows in flight), so every line crosses the L2 -> L1 path twice.  Issued back to back the two halves are one miss.
   __device__ __forceinline__ void load_pair(const MatView& v, unsigned span, const int slot, bool second) {
     static_assert(RING == 1 || (RING % 2) == 0, "pairs of slots");
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 64)      // timing experiment: every load an L2 hit (k wraps inside 256 bytes per row)
-    const long adv = (long)(kcur & 63);
-#else
     const long adv = (long)kcur;
-#endif
     const __amdgpu_buffer_rsrc_t r =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(v.p + adv), 0, (int)(span - (unsigned)(adv * 4)), 0x00020000);
 #pragma unroll
@@ -380,32 +320,14 @@ struct Stager {
         *reinterpret_cast<uint2*>(S + off) = make_uint2(__builtin_bit_cast(unsigned, lo2), __builtin_bit_cast(unsigned, hi2));
       } else if constexpr (PREC == PREC_F16X2) {
         unsigned h0, l0, h1, l1;
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 1)      // timing experiment (wrong results): no split arithmetic = operands that arrive as fp16 planes
-        h0 = __float_as_uint(r[p].x); l0 = __float_as_uint(r[p].y); h1 = __float_as_uint(r[p].z); l1 = __float_as_uint(r[p].w);
-#else
         split2h(r[p].x, r[p].y, scl, h0, l0);
         split2h(r[p].z, r[p].w, scl, h1, l1);
-#endif
         *reinterpret_cast<uint2*>(S + off) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(S + PL + off) = make_uint2(l0, l1);
       } else {
         unsigned h0, m0, l0, h1, m1, l1;
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 1)      // timing experiment: no split arithmetic
-        h0 = __float_as_uint(r[p].x); m0 = __float_as_uint(r[p].y); l0 = h0; h1 = __float_as_uint(r[p].z); m1 = __float_as_uint(r[p].w); l1 = h1;
-#else
-#if ASTK_GEMM_SPLIT_ASM == 2
-        if (!RK && __builtin_amdgcn_readfirstlane((int)(row0_edge)) != 0) {      // (uniform: only the tile at the operand's edge pays)
-          if (nvc < 2) r[p].y = 0.f;
-          if (nvc < 3) r[p].z = 0.f;
-          if (nvc < 4) r[p].w = 0.f;
-        }
-        split2_dot(r[p].x, r[p].y, sel0, sel1, h0, m0, l0);
-        split2_dot(r[p].z, r[p].w, sel0, sel1, h1, m1, l1);
-#else
         split2(r[p].x, r[p].y, h0, m0, l0);
         split2(r[p].z, r[p].w, h1, m1, l1);
-#endif
-#endif
         *reinterpret_cast<uint2*>(S + off) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(S + PL + off) = make_uint2(m0, m1);
         *reinterpret_cast<uint2*>(S + 2 * PL + off) = make_uint2(l0, l1);
@@ -512,11 +434,6 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
     if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64 * MW) __builtin_amdgcn_s_setprio(MW == 8 ? ASTK_GEMM_PRIO8 : 3);
     else if (MW == 8 && ASTK_GEMM_PRIO8S != 0) __builtin_amdgcn_s_setprio(ASTK_GEMM_PRIO8S);
   }
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & (32 | 256))      // clock probe: shader cycles per 10 ns tick over the kernel's life (block 0)
-  const long long c0_ = clock64(), w0_ = wall_clock64();
-  long long dbg_t[3] = {0, 0, 0};      // (& 256) per-role stamps: multiplying waves [fetch + MFMA issue, -, barrier]; staging waves [split + LDS writes, loads, barrier]
-  long dbg_n = 0;
-#endif
   unsigned wgi = blockIdx.x;
   if (SPLIT && (gridDim.x % 8) == 0) wgi = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
   // Hybrid schedule: phases 0 .. dp_waves-1 are data-parallel waves -- in wave ph the gridDim.x / 8 workgroups of XCD x own the
@@ -749,48 +666,12 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
           constexpr int pos = decltype(posc)::value;          // kt_ % 12
           constexpr bool TAIL = decltype(tailc)::value;
           constexpr int slot = (pos + 2) % RING, st = (pos + 2) % 3;
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
-          const long long q0_ = clock64();
-#endif
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 8)      // timing experiment: staging waves idle
-#else
-#if ASTK_GEMM_REFILL_EARLY
           // (A's slot is reloaded right behind A's split: its loads' time in the L1's queue -- 16 cycles per 1 KB instruction -- runs beside B's split)
           if (!TAIL || kt_ + 2 < nk) sa.template store_split<TAIL>(stA(st), kbeg + (kt_ + 2) * BK, kend, slot);
-#if ASTK_GEMM_REFILL_FENCE
-          // (no load of the refill may move up into the split: hipcc started the refill with ONE load in front of the split's last uses of
-          //  the old tile and then waited with s_waitcnt vmcnt(0) -- for that load too, a full memory round trip in every second iteration)
-          __builtin_amdgcn_sched_barrier(0);
-#endif
           refill(sa, A, g.spanA, ARK, std::integral_constant<bool, !TAIL>{}, kt_ + 2, slot);
           if (!TAIL || kt_ + 2 < nk) sb.template store_split<TAIL>(stB(st), kbeg + (kt_ + 2) * BK, kend, slot);
-#if ASTK_GEMM_REFILL_FENCE
-          __builtin_amdgcn_sched_barrier(0);
-#endif
           refill(sb, B, g.spanB, BRK, std::integral_constant<bool, !TAIL>{}, kt_ + 2, slot);
-#else
-          if (!TAIL || kt_ + 2 < nk) {
-            sa.template store_split<TAIL>(stA(st), kbeg + (kt_ + 2) * BK, kend, slot);
-            sb.template store_split<TAIL>(stB(st), kbeg + (kt_ + 2) * BK, kend, slot);
-          }
-#endif
-#endif
-#if (defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 12)) || ASTK_GEMM_REFILL_EARLY      // timing experiment: no global loads in the loop
-#else
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
-          const long long q1_ = clock64();
-#endif
-          refill(sa, A, g.spanA, ARK, std::integral_constant<bool, !TAIL>{}, kt_ + 2, slot);
-          refill(sb, B, g.spanB, BRK, std::integral_constant<bool, !TAIL>{}, kt_ + 2, slot);
-#endif
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
-          const long long q2_ = clock64();
           __syncthreads();
-          const long long q3_ = clock64();
-          dbg_t[0] += q1_ - q0_; dbg_t[1] += q2_ - q1_; dbg_t[2] += q3_ - q2_; ++dbg_n;
-#else
-          __syncthreads();
-#endif
         };
         // steady state (12 = lcm(3 stages, 4 slots) iterations per trip): every tile stored in the trip is a full tile, every tile loaded exists
         for (; kt + 13 + RING < nk && kbeg + (kt + 14) * BK <= kend; kt += 12) {
@@ -882,11 +763,7 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
           // smallest terms first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
           constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 2)      // timing experiment: one MFMA per accumulator instead of six
-          for (int t = 0; t < 1; ++t)
-#else
           for (int t = 0; t < 6; ++t)
-#endif
 #pragma unroll
             for (int i = 0; i < NAM; ++i)
 #pragma unroll
@@ -947,12 +824,6 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
           constexpr int pos = decltype(posc)::value;
           FragsH& hc = (pos & 1) ? h1 : h0;
           FragsH& hn = (pos & 1) ? h0 : h1;
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
-          const long long q0_ = clock64();
-#endif
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 16)      // timing experiment: multiplying waves idle
-          if (false)
-#endif
           {
           fetch_ml(ml, pos % 3);
 #pragma unroll
@@ -974,14 +845,7 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
               }
           }
           __builtin_amdgcn_sched_barrier(0);
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
-          const long long q1_ = clock64();
           __syncthreads();
-          const long long q2_ = clock64();
-          dbg_t[0] += q1_ - q0_; dbg_t[2] += q2_ - q1_; ++dbg_n;
-#else
-          __syncthreads();
-#endif
         };
         for (int kt = 0; kt < nk; kt += 6) {
           cstep8(std::integral_constant<int, 0>{}, kt);
@@ -997,25 +861,12 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
         // iteration kt (position pos = kt % 6): fetch tile kt+1 from stage (pos+1) % 3 into the other register set, multiply tile kt
         auto cstep = [&](auto posc, const int kt_) {
           constexpr int pos = decltype(posc)::value;
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 16)      // timing experiment: multiplying waves idle
-#else
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
-          const long long q0_ = clock64();
-#endif
           if (kt_ + 1 < nk) fetch((pos & 1) ? f0 : f1, (pos + 1) % 3);
           mult((pos & 1) ? f1 : f0);
-#endif
           // the barrier stays BEHIND the MFMAs: hipcc otherwise hoists it (and the lgkmcnt(0) it needs) to right behind the first MFMA,
           // which puts the fragment reads' latency back on the matrix pipe's critical path
           __builtin_amdgcn_sched_barrier(0);
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
-          const long long q1_ = clock64();
           __syncthreads();
-          const long long q2_ = clock64();
-          dbg_t[0] += q1_ - q0_; dbg_t[2] += q2_ - q1_; ++dbg_n;
-#else
-          __syncthreads();
-#endif
         };
         for (int kt = 0; kt < nk; kt += 6) {
           cstep(std::integral_constant<int, 0>{}, kt);
@@ -1124,19 +975,6 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
     }   // !SPLIT
   }
   }   // phases
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 256)
-  if (blockIdx.x == 100 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 1 || (threadIdx.x >> 6) == MW + 1)) {
-    const long long dc = clock64() - c0_, dw = wall_clock64() - w0_;
-    printf("gemm stamps wave %d: %ld its, per it: work %lld  loads %lld  barrier %lld cycles; kernel %lld cycles in %lld x 10 ns = %.3f GHz\n", (int)(threadIdx.x >> 6),
-           dbg_n, dbg_t[0] / max(dbg_n, 1L), dbg_t[1] / max(dbg_n, 1L), dbg_t[2] / max(dbg_n, 1L), dc, dw, (double)dc / (double)dw * 0.1);
-  }
-#endif
-#if defined(ASTK_GEMM_DBG) && (ASTK_GEMM_DBG & 32)
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const long long dc = clock64() - c0_, dw = wall_clock64() - w0_;
-    printf("gemm clock probe: %lld shader cycles in %lld x 10 ns = %.3f GHz\n", dc, dw, (double)dc / (double)dw * 0.1);
-  }
-#endif
 }
 
 // ---- fp16x2: absolute maxima of the operands, one pass in front of the launch.  A region is `nb` slices (stride sb) of `rows` rows
@@ -1337,7 +1175,7 @@ static int gemm_prepare(int layout, const GemmArgs& g, GemmArgs& a, bool& twolvl
 }
 
 static int g_lowp_mode = 0;
-static std::atomic<double> g_small_flops{getenv("ASTK_GEMM_X3_BELOW") ? atof(getenv("ASTK_GEMM_X3_BELOW")) : 3e9};
+static std::atomic<double> g_small_flops{3e9};
 // Per-call arithmetic (astk_*_desc.precision / .gemm_operands, astk_gemm_f32_ex): the entry points open a PrecScope, the launches of
 // this thread inside it use the descriptor's choice; outside a scope (or with ASTK_PREC_DEFAULT) the process-wide default applies.
 static thread_local int tl_prec = -1;       // GemmPrec, or -1 = process default
@@ -1353,13 +1191,9 @@ GemmWgCap::~GemmWgCap() { tl_wg_cap = prev; }
 // operand precision of the f32-accurate products.  Process default: bf16x3 (three-term bf16 split: every f32 operand value is represented
 // EXACTLY, f32 exponent range, products exact to 2^-26) -- the reference computes in float32 (seq2seq.py:154,302,420), and this is the
 // fastest scheme here that is at least as accurate as an f32 fma chain on ANY data.  fp16x2 (two scaled fp16 terms: 22 bits per operand
-// value, and only for values within 2^-17 of the operand's maximum) is faster but narrower: opt-in only (ASTK_GEMM_PREC=fp16x2 in the
-// environment at load time, astk_set_gemm_precision(0), or a descriptor's precision field); f32 = the exact f32 MFMA chain.
-static int prec_from_env() {
-  const char* e = getenv("ASTK_GEMM_PREC");
-  return !e ? PREC_BF16X3 : !strcmp(e, "f32") ? PREC_F32 : !strcmp(e, "fp16x2") ? PREC_F16X2 : PREC_BF16X3;
-}
-static std::atomic<int> g_prec{prec_from_env()};
+// value, and only for values within 2^-17 of the operand's maximum) is faster but narrower: opt-in only (astk_set_gemm_precision(0)
+// or a descriptor's precision field); f32 = the exact f32 MFMA chain.
+static std::atomic<int> g_prec{PREC_BF16X3};
 static int default_prec() { return tl_prec >= 0 ? tl_prec : g_prec.load(std::memory_order_relaxed); }
 PrecScope::PrecScope(int precision, int operands) : prev_p(tl_prec), prev_l(tl_lowp) {
   if (precision == ASTK_PREC_FP16X2) tl_prec = PREC_F16X2;
@@ -1452,8 +1286,8 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   int min_kt = 0x7fffffff;
   // Tile edge: 128 unless the whole launch is too small to keep the chip busy with 128-tiles (fewer k-iterations than the stream-K
   // threshold below, and either too few tiles for the CUs or tiles so shallow that their ramp dominates): then 64-tiles give 4x the
-  // workgroups, each a quarter of the work.  ASTK_GEMM_TILE = 64 | 128 forces one.
-  static const int force_tl = getenv("ASTK_GEMM_TILE") ? atoi(getenv("ASTK_GEMM_TILE")) : 0;
+  // workgroups, each a quarter of the work.  astk_set_tuning("gemm.tile", 64 | 128 | 256) forces one.
+  const int force_tl = (int)tune(TUNE_GEMM_TILE);
   // operand scheme of the launch (default_prec: fp16x2 unless the environment asks for bf16x3 or f32)
   int prec = default_prec();
   if (low_precision_gemms() != 0 && n > 0) {        // fp16 operands only if every product of the launch is marked eligible by its caller
@@ -1495,7 +1329,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     // 256 x 128 tiles on the 12-wave kernel (round 5): launches of 20 GFLOP and more whose M extents waste at most 10 % more rows than
     // with 128-row tiles -- measured per launch of the train step (scratch/r5_gemm_t256.sh): 3-6 % faster on every launch above 200 us,
     // slower on the small ones (6400 x 512 x 512: 40 -> 58 us)
-    static const double big_flops = getenv("ASTK_GEMM_T256_ABOVE") ? atof(getenv("ASTK_GEMM_T256_ABOVE")) : 2e10;
+    const double big_flops = tune(TUNE_GEMM_T256_ABOVE);
     const bool big = prec == PREC_BF16X3 && BK == 16 && tall_ok && flops >= big_flops && !small;
     int want = force_tl == 64 || force_tl == 128 || force_tl == 256 ? force_tl : (small ? 64 : (big ? 256 : 128));
     if (want == 256 && (prec != PREC_BF16X3 || BK != 16)) want = 128;
@@ -1529,7 +1363,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   // CUs are loaded unevenly: 600 workgroups for 1200 tiles ran 12 % slower than 768) -- 100-125 TFLOP/s on the train step's big
   // shapes against 60-93 for one-tile-per-workgroup launches.  Smaller products keep one tile per workgroup unless they have too
   // few tiles to occupy the chip; then their k range is split as well.
-  static const int force_g = getenv("ASTK_GEMM_G") ? atoi(getenv("ASTK_GEMM_G")) : -1;   // tuning hook: 0 = one tile per WG
+  const int force_g = (int)tune(TUNE_GEMM_GRID);   // tuning hook
   long G = tiles;
   bool aligned = true;   // workgroup boundaries fall on tile boundaries
   if (grp.iters_total >= 256L * WGS_PER_CU * 10 * (32 / BK)) { G = 256 * WGS_PER_CU; aligned = false; }
@@ -1547,8 +1381,8 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   }
   // Hybrid schedule (kernel: "Hybrid schedule"): a stream-K launch of the split schemes whose tiles all have the same depth and outnumber
   // the grid runs floor(tiles / G) data-parallel waves of whole tiles in XCD-local blocks first; only the rest is split stream-K.
-  // (ASTK_GEMM_HYBRID=0: everything stream-K in row-major tile order, the schedule of rounds 1-4.)
-  static const int hybrid_on = getenv("ASTK_GEMM_HYBRID") ? atoi(getenv("ASTK_GEMM_HYBRID")) : 1;
+  // ("gemm.hybrid" 0: everything stream-K in row-major tile order, the schedule of rounds 1-4.)
+  const bool hybrid_on = tune_on(TUNE_GEMM_HYBRID);
   grp.dp_waves = 0; grp.dp_kt = 0; grp.rem_start = 0;
   if (hybrid_on && prec != PREC_F32 && !aligned && (G % 8) == 0 && tiles >= G) {
     bool uniform = true;
@@ -1574,9 +1408,9 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     }
   }
   // Few tiles, deep K, accumulating output (the weight gradients: TN 512 x 1152 x 38400 is 18 tiles of 2400 k-iterations): chunk-major order,
-  // chunk = the divisor of kt nearest to a workgroup's share.  (ASTK_GEMM_CHUNK=0: tile-major always.)
-  static const bool chunk_on = !(getenv("ASTK_GEMM_CHUNK") && getenv("ASTK_GEMM_CHUNK")[0] == '0');
-  static const int chunk_div = getenv("ASTK_GEMM_CHUNK_DIV") ? atoi(getenv("ASTK_GEMM_CHUNK_DIV")) : 4;      // (tuning hook: tiles * div <= G)
+  // chunk = the divisor of kt nearest to a workgroup's share.  ("gemm.chunk" 0: tile-major always.)
+  const bool chunk_on = tune_on(TUNE_GEMM_CHUNK);
+  const int chunk_div = (int)tune(TUNE_GEMM_CHUNK_DIV);      // (tuning hook: tiles * div <= G)
   for (int i = 0; i < grp.n; ++i) { grp.g[i].cs = 0; grp.g[i].chunk_iters = 0; }
   if (chunk_on && grp.n == 1 && !aligned && grp.dp_waves == 0 && grp.g[0].mode != GEMM_STORE && prec != PREC_F32 && tiles * chunk_div <= G && grp.g[0].kt >= 128) {
     GemmArgs& a = grp.g[0];
@@ -1586,7 +1420,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
       if (a.kt % c == 0 && c >= share / 2 && c <= share * 2 && (best == 0 || labs(c - share) < labs(best - share))) best = c;
     if (best > 0 && best < a.kt) { a.cs = best; a.chunk_iters = tiles * (long)best; }
   }
-  static const bool log_shapes = getenv("ASTK_GEMM_LOG") != nullptr;
+  const bool log_shapes = tune_on(TUNE_GEMM_LOG);
   if (log_shapes)
     for (int i = 0; i < grp.n; ++i)
       fprintf(stderr, "astk_gemm layout=%d M=%d N=%d K=%d batch=%d mode=%d twolvl=%d group=%d/%d G=%ld kt=%d tile=%d dp_waves=%d bm=%d cs=%d\n", layout, grp.g[i].M,
@@ -1603,7 +1437,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   dim3 grid((unsigned)G, 1, 1);
   // GEMM_STORE + split tiles: the tiles several workgroups accumulate into are zeroed first (with the maximum pass when there is one).
   // (Builds with -DASTK_GEMM_TICKET=1: the ticket protocol instead -- kernel: "Split tiles without a zeroing launch", measured, off.)
-  static const bool ticket_on = ASTK_GEMM_TICKET && !(getenv("ASTK_GEMM_TICKET") && getenv("ASTK_GEMM_TICKET")[0] == '0');
+  const bool ticket_on = ASTK_GEMM_TICKET && tune_on(TUNE_GEMM_TICKET);
   grp.tick = nullptr;
   bool need_zero = !aligned && any_store && G > 1;
   if (need_zero && ticket_on) {

@@ -61,6 +61,7 @@ struct LstmPlan {
 };
 
 int make_plan(const astk_lstm_stack_desc* d, void* ws, bool with_masks, LstmPlan& P) {
+  ASTK_CHECK_DESC(d, astk_lstm_stack_desc);
   ASTK_CHECK(d && d->T > 0 && d->B > 0 && d->in_dim > 0 && d->h > 0, "lstm_stack: bad dims");
   ASTK_CHECK(d->n_layers >= 1 && d->n_layers <= ASTK_MAX_RNN_LAYERS && (d->n_dirs == 1 || d->n_dirs == 2), "lstm_stack: layers/dirs");
   ASTK_CHECK((d->in_dim % 4) == 0 && (d->h % 4) == 0, "lstm_stack: in_dim and h must be multiples of 4");
@@ -135,7 +136,7 @@ using namespace astk;
 extern "C" {
 
 int astk_lstm_stack_path(const astk_lstm_stack_desc* d) {
-  if (!d) return 0;
+  if (!d || d->struct_size != sizeof(astk_lstm_stack_desc)) return 0;
   return lstm_persist_applicable(d->T, d->B, d->h, d->n_layers, d->n_dirs) ? (lstm_persist_hoisted(d->h) ? 2 : 1) : 0;
 }
 
@@ -149,7 +150,7 @@ size_t astk_lstm_stack_workspace_bytes(const astk_lstm_stack_desc* d) {
 int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* prm, const float* x, const float* masks,
                         float* enc_states, float* cT, float* hT, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  ASTK_CHECK(d, "lstm_stack_fwd: null descriptor");
+  ASTK_CHECK_DESC(d, astk_lstm_stack_desc);
   PrecScope prec_scope(d->precision, d->gemm_operands);
   GemmForwardScope forward_scope;      // split tiles of this op's products have at most two contributors (reproducible forward pass)
   LstmPlan P;
@@ -309,7 +310,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
                            size_t ws_bytes, void* stream, void* recurrence_stream) {
   hipStream_t s = (hipStream_t)stream;
   hipStream_t sr = recurrence_stream ? (hipStream_t)recurrence_stream : s;
-  ASTK_CHECK(d, "lstm_stack_bwd: null descriptor");
+  ASTK_CHECK_DESC(d, astk_lstm_stack_desc);
   PrecScope prec_scope(d->precision, d->gemm_operands);
   LstmPlan P;
   ASTK_TRY(make_plan(d, ws, masks != nullptr, P));

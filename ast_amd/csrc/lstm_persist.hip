@@ -1066,14 +1066,12 @@ bool lstm_persist_applicable(int T, int B, int h, int nl, int nd) {
   if (!(h == 64 || h == 128 || h == 256 || h == 512 || h == 1024)) return false;
   if (B < 1 || T < 1) return false;
   if (lstm_persist_hoisted(h)) {
-    static const bool hoist_off = getenv("ASTK_LSTM_HOIST") && getenv("ASTK_LSTM_HOIST")[0] == '0';
-    if (hoist_off) return false;
+    if (!tune_on(TUNE_LSTM_HOIST)) return false;
   }
   if (lstm_persist_layers_per_launch(B, h, nl, nd) < 1) return false;
   // hand-off buffers are addressed with 32-bit byte offsets
   if ((long)T * B * h * 16 >= (1L << 31) || (long)T * ((B + 15) / 16) * (h / 16) * (h / 16) * 1024 >= (1L << 31)) return false;
-  const char* e = getenv("ASTK_LSTM_PERSIST");
-  if (e && e[0] == '0') return false;
+  if (!tune_on(TUNE_LSTM_PERSIST)) return false;
   return true;
 }
 
@@ -1107,10 +1105,9 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   }
   ProfScope prof(PROF_CELL, s);
   // arithmetic of the recurrences' products: the mode in force for this call (fp16x2: two-term fp16 splits; bf16x3: three-term bf16 splits
-  // where the weight fragments fit the registers, h <= 256; f32, or bf16x3 at h = 512: f32 MFMAs).  ASTK_LSTM_X3=0 keeps f32 MFMAs under bf16x3.
+  // where the weight fragments fit the registers, h <= 256; f32, or bf16x3 at h = 512: f32 MFMAs).  "lstm.x3" 0 keeps f32 MFMAs under bf16x3.
   const int mode = gemm_precision_mode();
-  static const bool x3_off = getenv("ASTK_LSTM_X3") && getenv("ASTK_LSTM_X3")[0] == '0';
-  static const bool x4_off = getenv("ASTK_LSTM_X4") && getenv("ASTK_LSTM_X4")[0] == '0';
+  const bool x3_off = !tune_on(TUNE_LSTM_X3), x4_off = !tune_on(TUNE_LSTM_X4);
   const int xs = mode == 0 ? 2 : (mode == 1 && !x3_off ? (h <= 256 ? 3 : (x4_off ? 0 : 4)) : 0);       // (4: bf16x3 with the weights' lo plane in LDS)
 #define ASTK_LSTM_FWD_(KB_, XS_) hipLaunchKernelGGL((lstm_persist_fwd_g<KB_, XS_>), grid, blk, 0, s, a)
   switch (h) {
@@ -1164,8 +1161,7 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   dim3 grid(h / 16, nbt, ncells), blk(256);
   ProfScope prof(PROF_CELL, s);
   const int mode = gemm_precision_mode();      // (see lstm_persist_fwd_launch)
-  static const bool x3_off = getenv("ASTK_LSTM_X3") && getenv("ASTK_LSTM_X3")[0] == '0';
-  static const bool x4_off = getenv("ASTK_LSTM_X4") && getenv("ASTK_LSTM_X4")[0] == '0';
+  const bool x3_off = !tune_on(TUNE_LSTM_X3), x4_off = !tune_on(TUNE_LSTM_X4);
   const int xs = mode == 0 ? 2 : (mode == 1 && !x3_off ? (h <= 256 ? 3 : (x4_off ? 0 : 4)) : 0);
 #define ASTK_LSTM_BWD_(KB_, XS_) hipLaunchKernelGGL((lstm_persist_bwd_rs<KB_, XS_>), grid, blk, 0, s, a)
   switch (h) {

@@ -268,14 +268,10 @@ __global__ __launch_bounds__(64 * NW) void lstm_cell_bwd_kernel(CellBwdBatch bat
   }
 }
 
-// eight waves share K once a four-wave workgroup would need more than two exposed round trips per wave (ASTK_ROW_LONGK overrides the
+// eight waves share K once a four-wave workgroup would need more than two exposed round trips per wave (astk_set_tuning("row.longk") overrides the
 // threshold, 0 = never: for A/B runs)
 bool long_k(int k) {
-  static int thr = -1;
-  if (thr < 0) {
-    const char* e = getenv("ASTK_ROW_LONGK");
-    thr = e ? atoi(e) : 2048;
-  }
+  const int thr = (int)tune(TUNE_ROW_LONGK);
   return thr > 0 && k >= thr;
 }
 

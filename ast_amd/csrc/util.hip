@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <stdarg.h>
 #include <vector>
+#include <atomic>
+#include <mutex>
 
 namespace astk {
 
@@ -64,11 +66,60 @@ AbortCtl abort_ctl(unsigned* word, unsigned bit) {
   ab.word = word;
   ab.status = persist_status_ptr();
   ab.limit = 1u << 22;
-  const char* e = getenv("ASTK_PERSIST_SPIN_LIMIT");      // test knob: a tiny bound forces the time-out path
-  if (e && e[0]) { const long v = atol(e); if (v > 0) ab.limit = (unsigned)v; }
+  const double lim = tune(TUNE_PERSIST_SPIN_LIMIT);       // test knob ("persist.spin_limit"): a tiny bound forces the time-out path
+  if (lim >= 1.0) ab.limit = (unsigned)lim;
   ab.bit = bit;
   return ab;
 }
+// ---- tuning knobs (astk_set_tuning): name, default
+struct TuneEntry { const char* name; double def; };
+static const TuneEntry g_tune_table[TUNE_COUNT] = {
+    {"gemm.tile", 0},              // force the block tile: 64 | 128 | 256 (0 = chosen per launch)
+    {"gemm.t256_above", 2e10},     // launches of at least this many flops take the 12-wave 256 x 128 kernel
+    {"gemm.grid", -1},             // force the stream-K grid (workgroups; <= 0 = chosen per launch)
+    {"gemm.hybrid", 1},            // data-parallel waves of whole tiles in XCD-local blocks + stream-K remainder (0: all stream-K, rounds 1-4)
+    {"gemm.chunk", 1},             // few tiles / deep K accumulating launches run chunk-major
+    {"gemm.chunk_div", 4},         // ... when tiles * chunk_div <= grid
+    {"gemm.log", 0},               // print every launch's shape and schedule to stderr
+    {"gemm.ticket", 1},            // libastk_test.so only: split tiles handed over by tickets instead of a zeroing launch
+    {"gemm.deterministic", 0},     // process default of the descriptors' `deterministic` field (fixed-order split-tile sums, astk.h)
+    {"conv.direct0", 1},           // layer 0 as a direct convolution (0: im2col + GEMM)
+    {"conv.seq_fwd", 1},           // BatchNorm + ReLU written straight into the LSTM's (T'',B,C*F') layout by the tiled kernel
+    {"conv.seq_bwd", 1},           // the last layer's BatchNorm backward reads that layout itself
+    {"conv.seq_stats_blocks", 1024},
+    {"conv.seq_apply_blocks", 1024},
+    {"dec.persist", 1},            // persistent decoder loops (0: the per-launch loop)
+    {"dec.b6_split", 1},           // K-half items of the d_x0 role (one-layer kernel)
+    {"dec.b6_fused", 1},           // ... with the d_pre role fused into them
+    {"dec.wide", 1},               // decoder_wide.hip's persistent loops at H = A = 1024
+    {"lstm.persist", 1},           // persistent encoder recurrences (0: one fused-cell launch per step)
+    {"lstm.hoist", 1},             // hoisted form of the persistent kernels at h = 1024
+    {"lstm.x3", 1},                // bf16x3 fragments inside the recurrences (0: f32-input MFMAs under the bf16x3 arithmetic)
+    {"lstm.x4", 1},                // ... with the weights' lo plane in LDS at h = 512 / 1024
+    {"lstm.rows32", -1},           // 32 batch rows per recurrence workgroup: 1 always, 0 never, -1 = when it spares launches or an overlap partner exists
+    {"lstm.overlap_chunk", 8},     // time steps per chunk of the layer-0 products that run beside the recurrences (side_stream)
+    {"row.longk", 2048},           // row-panel kernels split K over eight waves from this K on (0 = never)
+    {"persist.spin_limit", 0},     // bound of the persistent kernels' spins in polls (0 = the default, 2^22)
+    {"colreduce.blocks", 256},     // blocks of a column reduction
+};
+static std::atomic<double> g_tune[TUNE_COUNT];
+static std::atomic<int> g_tune_init{0};
+static void tune_init() {
+  if (g_tune_init.load(std::memory_order_acquire)) return;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (g_tune_init.load()) return;
+  for (int i = 0; i < TUNE_COUNT; ++i) g_tune[i].store(g_tune_table[i].def);
+  g_tune_init.store(1, std::memory_order_release);
+}
+double tune(TuneKey k) { tune_init(); return g_tune[k].load(std::memory_order_relaxed); }
+static int tune_find(const char* key) {
+  if (!key) return -1;
+  for (int i = 0; i < TUNE_COUNT; ++i)
+    if (!strcmp(key, g_tune_table[i].name)) return i;
+  return -1;
+}
+
 int device_cu_count() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
@@ -740,7 +791,7 @@ int astk_colsum_add_f32(float* dst, const float* src, long lds, int rows, int co
 
 int astk_gemm_f32_ex(int layout, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                      const float* bias, int mode, int ksplit, int batch, long sA, long sB, long sC, int precision, void* stream) {
-  ASTK_CHECK(precision >= ASTK_PREC_DEFAULT && precision <= ASTK_PREC_F32, "gemm: precision must be one of ASTK_PREC_*");
+  ASTK_CHECK(precision >= ASTK_PREC_DEFAULT && precision <= ASTK_PREC_F32, "gemm: precision must be 0 (default), 1 (fp16x2), 2 (bf16x3) or 3 (f32): the enum of astk.h");
   PrecScope ps(precision, ASTK_OPERANDS_DEFAULT);
   GemmArgs g = gemm_args(M, N, K, mat(A, lda), mat(B, ldb), C, ldc, bias, mode, ksplit);
   g.batch = batch < 1 ? 1 : batch;
@@ -834,3 +885,18 @@ int astk_prof_end(double* res) {
 }
 
 }  // extern "C"
+
+extern "C" int astk_set_tuning(const char* key, double value) {
+  const int i = astk::tune_find(key);
+  if (i < 0) { astk::set_error("set_tuning: unknown key '%s'", key ? key : "(null)"); return -1; }
+  astk::tune_init();
+  astk::g_tune[i].store(value);
+  return 0;
+}
+extern "C" int astk_get_tuning(const char* key, double* value) {
+  const int i = astk::tune_find(key);
+  if (i < 0 || !value) { astk::set_error("get_tuning: unknown key '%s'", key ? key : "(null)"); return -1; }
+  *value = astk::tune((astk::TuneKey)i);
+  return 0;
+}
+extern "C" const char* astk_tuning_key(int index) { return index >= 0 && index < astk::TUNE_COUNT ? astk::g_tune_table[index].name : nullptr; }

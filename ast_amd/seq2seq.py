@@ -64,10 +64,10 @@ def raise_if_aborted(status, where="train step"):
     if mask:
         names = [n for b, n in ((1, "encoder forward"), (2, "encoder backward"), (4, "decoder forward"), (8, "decoder backward"),
                                 (16, "reported by a peer rank of the data-parallel job")) if mask & b]
-        _lib.load().astk_persist_status(None, 1)          # clear the sticky word: the caller may retry (e.g. with ASTK_*_PERSIST=0)
+        _lib.load().astk_persist_status(None, 1)          # clear the sticky word: the caller may retry (e.g. with the *.persist knobs at 0)
         raise _lib.AstkError(f"{where}: persistent kernel(s) timed out waiting for a peer workgroup ({', '.join(names)}); the results "
                              "of this step are invalid.  The whole grid must be resident (one workgroup per CU); set "
-                             "ASTK_LSTM_PERSIST=0 / ASTK_DEC_PERSIST=0 to use the per-launch kernels on a shared device")
+                             "the tuning knobs lstm.persist / dec.persist to 0 (ast_amd._lib.set_tuning) to use the per-launch kernels on a shared device")
 
 
 def draw_flags_and_targets(yh, teach_ratio, random_out, V, randint, rank=None, world=None, gather=None):

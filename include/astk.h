@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ASTK_VERSION 104
+#define ASTK_VERSION 106
 #define ASTK_MAX_CNN_LAYERS 4
 #define ASTK_MAX_RNN_LAYERS 8
 #define ASTK_MAX_ATTN 4
@@ -39,7 +39,7 @@ int astk_version(void);
 const char* astk_last_error(void);
 
 /* Arithmetic of an op's f32-accurate products: field `precision` of the descriptors below, argument of astk_gemm_f32_ex.
- *   ASTK_PREC_DEFAULT  the process-wide default (bf16x3 unless astk_set_gemm_precision / ASTK_GEMM_PREC changed it)
+ *   ASTK_PREC_DEFAULT  the process-wide default (bf16x3 unless astk_set_gemm_precision changed it)
  *   ASTK_PREC_FP16X2   two fp16 terms per operand behind a per-operand power-of-two scale: 22 significant bits, and only for values within
  *                      2^-17 of the operand's maximum (NARROWER than float32: opt-in), three MFMAs per 16 k; encoder recurrences likewise
  *   ASTK_PREC_BF16X3   three bf16 terms per operand (exact representation of every f32 value, f32 exponent range), six MFMAs per 16 k
@@ -75,7 +75,7 @@ int astk_gemm_f32_ex(int layout, int M, int N, int K,
 int astk_set_low_precision_gemms(int mode);
 int astk_get_low_precision_gemms(void);
 /* fp16x2 mode only: launches below `flops` floating-point operations do not repay the absolute-maximum pass the scaled fp16 terms
- * need and run as bf16x3 instead.  Default 3e9 (environment: ASTK_GEMM_X3_BELOW); 0 = fp16 terms always.  Process-wide; returns the
+ * need and run as bf16x3 instead.  Default 3e9; 0 = fp16 terms always.  Process-wide; returns the
  * previous value. */
 double astk_set_gemm_bf16_split_below(double flops);
 /* The process-wide DEFAULT arithmetic (what ASTK_PREC_DEFAULT resolves to), switchable at run time (bench.py times the same step under each):
@@ -83,9 +83,24 @@ double astk_set_gemm_bf16_split_below(double flops);
  *      the encoder's persistent recurrence kernels -- NARROWER than float32, opt-in;
  *   1  bf16x3 (default): three bf16 terms (exact operands, no scales) in the batched GEMMs, exact-f32 MFMAs in the recurrences;
  *   2  f32: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 everywhere (IEEE f32 products, the reference's literal arithmetic).
- * The environment variable ASTK_GEMM_PREC = fp16x2 | bf16x3 | f32 sets the initial mode.  Returns the previous mode (<0: error). */
+ * Returns the previous mode (<0: error). */
 int astk_set_gemm_precision(int mode);
 int astk_get_gemm_precision(void);
+/* Tuning knobs: the ONE documented, process-wide switchboard for A/B measurements and fall-backs (the library reads no environment
+ * variable).  Read at every launch; not meant to be flipped between a forward call and its backward call (the decoder / CNN backward
+ * refuse a workspace whose forward took another kernel path).  Keys (default):
+ *   gemm.tile (0 = per launch; 64 | 128 | 256 forces the block tile)     gemm.t256_above (2e10 flops: the 12-wave 256 x 128 kernel from here on)
+ *   gemm.grid (-1 = per launch)   gemm.hybrid (1)   gemm.chunk (1)   gemm.chunk_div (4)   gemm.log (0: 1 prints every launch to stderr)
+ *   gemm.deterministic (0: process default of the descriptors' `deterministic` field)   gemm.ticket (libastk_test.so only)
+ *   conv.direct0 (1)   conv.seq_fwd (1)   conv.seq_bwd (1)   conv.seq_stats_blocks (1024)   conv.seq_apply_blocks (1024)
+ *   dec.persist (1: 0 = per-launch decoder loop)   dec.b6_split (1)   dec.b6_fused (1)   dec.wide (1)
+ *   lstm.persist (1: 0 = one fused-cell launch per step)   lstm.hoist (1)   lstm.x3 (1)   lstm.x4 (1)
+ *   lstm.rows32 (-1 = when it spares launches or frees CUs for side-stream work; 0 never; 1 always)   lstm.overlap_chunk (8 time steps)
+ *   row.longk (2048)   persist.spin_limit (0 = 2^22 polls)   colreduce.blocks (256)
+ * astk_set_tuning returns 0, or -1 for an unknown key; astk_tuning_key(i) enumerates the keys (NULL behind the last). */
+int astk_set_tuning(const char* key, double value);
+int astk_get_tuning(const char* key, double* value);
+const char* astk_tuning_key(int index);
 #ifdef ASTK_TEST_HOOKS
 /* Test hook (libastk_test.so only): sets the generation counter of the fp16x2 scale slots (tests preset it close to the 32-bit wrap). */
 int astk_debug_set_amax_generation(unsigned gen);
@@ -96,6 +111,10 @@ int astk_debug_set_amax_generation(unsigned gen);
  * re-layout with feature index c*F'+f (quirk Q9).  Layer 0: in_channels 1, kernel (kt,kf), stride (st,sf),
  * pad (pt,0).  Layers >= 1: kernel (kt,1), stride (st,1), pad (pt,0) -- the shipped cnn_config. */
 typedef struct {
+  size_t struct_size;  /* sizeof(astk_cnn_desc) of the header the caller was built against: every entry point refuses a descriptor whose size
+                          differs from its own (the descriptors carry pointers the library writes through -- status_dst here, zero_ptr in the
+                          decoder's -- so a caller built against an older layout must fail loudly, not hand over garbage).  ZERO-INITIALISE the
+                          struct, set struct_size, then the fields you use: every optional field's "off" value is 0 / NULL. */
   int B, T, D;
   int n_layers;
   int C[ASTK_MAX_CNN_LAYERS];
@@ -114,6 +133,9 @@ typedef struct {
   float* status_dst;   /* optional (NULL = none): astk_conv_bn_relu_bwd(_sync) also leaves a copy of the persistent kernels' status word
                           there, written by the op's last kernel -- astk_persist_status_snapshot without a launch of its own (the CNN
                           backward is the train step's last op behind the recurrences).  Ignored by the forward call. */
+  int deterministic;   /* backward call: 1 = every accumulated sum of this op (split tiles of the weight / input gradient products) is formed in a
+                          fixed order -- bit-reproducible from run to run, a few per cent slower; 0 = the process default (astk_set_tuning
+                          "gemm.deterministic", default off: float atomics in arrival order) */
 } astk_cnn_desc;
 
 typedef struct {
@@ -179,6 +201,7 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
  * layer's *output* copy only.  Direction 1 consumes frames in the reference's order 0,T-1,...,1 (quirk Q1)
  * and its outputs are flipped before the concat, so enc_states[b,p,h:2h] is what seq2seq.py:231-242 builds. */
 typedef struct {
+  size_t struct_size;  /* sizeof(astk_lstm_stack_desc), see astk_cnn_desc.struct_size */
   int T, B, in_dim, h, n_layers, n_dirs;
   /* Optional hints that spare the f32-accurate GEMMs their absolute-maximum passes (0 / NULL: every launch measures its operands):
    *   out_bound  an upper bound of |layer output| as the next layer and the weight-gradient products read it: 1 without dropout
@@ -188,6 +211,18 @@ typedef struct {
   const void* x_amax;
   int precision;       /* ASTK_PREC_*: batched products AND the persistent recurrence kernels (0 = process default) */
   int gemm_operands;   /* ASTK_OPERANDS_* (0 = process default) */
+  /* Work BESIDE the recurrences (optional; NULL / 0 = everything in line on `stream`).  The persistent recurrence kernels are latency-bound
+   * and occupy one workgroup per (direction, layer, 16-unit slice, batch tile): 96-192 of the 256 CUs at the shipped shape.  With a
+   * caller-owned ORDINARY second stream in `side_stream` (hipStream_t; no CU mask needed) the layer-0 batched products run on it in time
+   * chunks, each launch capped at `side_wgs` workgroups (0 = the CUs the recurrence grid leaves free), gated by flags in the workspace:
+   * forward, chunk k of the input projection is produced on the side stream while the recurrence consumes chunk k-1 (the cells of layer 0 wait
+   * for the chunk's flag, bounded spins + abort word like every other hand-off); backward, the input / weight gradient of a chunk starts when the
+   * recurrence has passed it.  The capped grids can never keep the recurrence grid from becoming resident.  Both calls join the side stream
+   * before they return, so callers see one-stream semantics.  Results are bit-identical to the in-line schedule in the forward pass and
+   * equal up to the order of float atomics in the backward pass (identical under `deterministic`). */
+  void* side_stream;
+  int side_wgs;
+  int deterministic;   /* backward call: 1 = bias gradients and split tiles summed in a fixed order (see astk_cnn_desc.deterministic); 0 = process default */
 } astk_lstm_stack_desc;
 
 typedef struct {
@@ -239,6 +274,7 @@ int astk_attn_step_bwd(int B, int T, int H, const float* enc, const float* alpha
  * -> logits = Wo ht + bo -> argmax feedback when not teacher-forced (quirk Q4) -> class-weighted softmax-CE
  * with denominator B (quirk Q6), summed over the L-1 steps. */
 typedef struct {
+  size_t struct_size;  /* sizeof(astk_decoder_desc), see astk_cnn_desc.struct_size */
   int B, L, T, H, E, A, V, n_layers;
   /* optional features of the reference's model (rnn_config; zero = the shipped configs).  Any of them set routes the loop through
    * the per-launch kernels (astk_decoder_path returns 0): the persistent loop is built for the shipped model only. */
@@ -261,6 +297,10 @@ typedef struct {
                           launcher does it with the fill launch it has anyway, the other paths with a fill of their own.  Ignored by the forward
                           calls and by ASTK_DEC_BWD_PARAMS. */
   size_t zero_bytes;
+  int side_wgs;        /* ASTK_DEC_BWD_PARAMS only: cap on the workgroups of every batched product of the phase (0 = none).  A caller that runs the
+                          phase on a second stream beside the encoder's backward recurrence passes the CUs that recurrence leaves free, so that
+                          these launches can never keep its grid from becoming resident */
+  int deterministic;   /* backward calls: 1 = weight-gradient split tiles summed in a fixed order (see astk_cnn_desc.deterministic); 0 = process default */
 } astk_decoder_desc;
 
 typedef struct {
@@ -445,7 +485,7 @@ int astk_spin(unsigned usec, unsigned* flag, void* stream);
  *   astk_persist_status_snapshot  enqueues a copy of the word (as a float) to *dst on `stream`: the Python shim places it next to
  *                                 the loss scalar, so the loss read-back of nn.py:189 sees it without an extra synchronisation;
  *   astk_persist_status           synchronises the device, returns the word in *mask_out (may be NULL) and clears it if `reset`.
- * ASTK_PERSIST_SPIN_LIMIT=<polls> (environment, read at every launch) shrinks the spin bound; tests use it to force a time-out. */
+ * astk_set_tuning("persist.spin_limit", polls) shrinks the spin bound; tests use it to force a time-out. */
 int astk_persist_status_snapshot(float* dst, void* stream);
 /* Data parallelism: `summed` = the SUM over all ranks of the words astk_persist_status_snapshot wrote (the Python shim appends the
  * word to the last gradient range, so the gradient all-reduce carries it: ast_amd/dist.py).  Non-zero: some rank's step is garbage --

@@ -36,3 +36,23 @@ def gemm_scheme(request):
     """The whole-model parity tests run once under EVERY arithmetic scheme bench.py times (round-3 review, item 1b): the test sets
     `model.gemm_precision = gemm_scheme`, which goes into the op descriptors' `precision` field (per call, no process-wide state)."""
     return request.param
+
+
+@pytest.fixture
+def tune():
+    """tune(key, value, lib=None): sets one of the library's documented tuning knobs (astk_set_tuning, include/astk.h) for the running
+    test -- on `lib` or on the currently loaded library -- and puts the old value back afterwards.  (Rounds 1-5 used environment
+    variables for this; the product library reads none any more: tests/test_host.py checks.)"""
+    import ctypes as C
+    from ast_amd import _lib
+    saved = []
+
+    def _set(key, value, lib=None):
+        lib = lib or _lib.load()
+        prev = C.c_double()
+        assert lib.astk_get_tuning(key.encode(), C.byref(prev)) == 0, key
+        assert lib.astk_set_tuning(key.encode(), float(value)) == 0, key
+        saved.append((lib, key, prev.value))
+    yield _set
+    for lib, key, value in reversed(saved):
+        lib.astk_set_tuning(key.encode(), value)

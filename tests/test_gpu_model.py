@@ -923,10 +923,10 @@ def test_device_loader_reproduces_the_loader_oracle_with_its_own_draws_injected(
     assert lost > 0
 
 
-def test_persistent_kernel_timeout_raises_instead_of_training_on(monkeypatch):
+def test_persistent_kernel_timeout_raises_instead_of_training_on(tune):
     """Every spin of the persistent encoder / decoder kernels is bounded; a time-out (grid not fully resident) drains the grid and
     sets a sticky status word that rides next to the loss scalar (include/astk.h astk_persist_status_snapshot).  Forced here with
-    ASTK_PERSIST_SPIN_LIMIT=1 (a wait that is not satisfied by its second poll gives up): reading the loss must raise, through
+    the tuning knob persist.spin_limit = 1 (a wait that is not satisfied by its second poll gives up): reading the loss must raise, through
     float(loss) and through NN.train_epoch's one-step-late read-back helper alike, the word must clear, and the next clean step
     must give the oracle's loss again."""
     from oracle import ast_ref as R
@@ -950,7 +950,7 @@ def test_persistent_kernel_timeout_raises_instead_of_training_on(monkeypatch):
             g.cleargrads()
             loss.backward()
         return loss
-    monkeypatch.setenv("ASTK_PERSIST_SPIN_LIMIT", "1")
+    tune("persist.spin_limit", 1)
     loss = step()
     with pytest.raises(_lib.AstkError, match="timed out"):
         float(loss)
@@ -974,7 +974,7 @@ def test_persistent_kernel_timeout_raises_instead_of_training_on(monkeypatch):
     pair = loss.pair.clone()                                                            # what NN.train_epoch keeps for its late read
     with pytest.raises(_lib.AstkError, match="NN.train_epoch"):
         raise_if_aborted(pair.tolist()[1], "NN.train_epoch")
-    monkeypatch.delenv("ASTK_PERSIST_SPIN_LIMIT")
+    tune("persist.spin_limit", 0)
     loss = step()
     assert _rel(float(loss.data), float(rl.data)) < 1e-4
     opt.update()

@@ -564,11 +564,11 @@ def test_decoder_fwd_bwd(lib, B, L, T, H, E, A, V, nl, masks, gemm_split):
                                                     (19, 6, 200, 1024, 128, 1024, 300, 1, True), (4, 12, 40, 1024, 128, 1024, 8004, 1, True),
                                                     (32, 5, 256, 1024, 128, 1024, 1098, 1, False), (32, 4, 263, 1024, 128, 1024, 300, 1, False),
                                                     (1, 7, 7, 1024, 128, 1024, 50, 1, False), (64, 6, 200, 1024, 128, 1024, 300, 1, True), (45, 5, 40, 1024, 128, 1024, 300, 1, False)])
-def test_decoder_per_launch_loop_scored_behind_the_loop(lib, monkeypatch, B, L, T, H, E, A, V, nl, masks, gemm_split):
+def test_decoder_per_launch_loop_scored_behind_the_loop(lib, tune, B, L, T, H, E, A, V, nl, masks, gemm_split):
     """The per-launch loop with the caller's HOST copy of the flags (astk_decoder_desc.use_truth_host): logits inside the loop only for the
     steps whose argmax is fed back, every step scored by one product and one softmax-CE launch behind it; in the backward, dlogits Wo as
     one product in front of the loop and the carry through input feeding from the epilogue of the next step's d_x0 product."""
-    monkeypatch.setenv("ASTK_DEC_PERSIST", "0")
+    tune("dec.persist", 0, lib)
     s = _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=B + L + 1)
     assert not (lib.astk_decoder_path(C.byref(s["d"])) & 1)
     # configs[4]'s width: decoder_wide.hip's persistent loops
@@ -582,24 +582,24 @@ def test_decoder_per_launch_loop_scored_behind_the_loop(lib, monkeypatch, B, L, 
     _decoder_case(lib, s, B, L, T, H, E, A, V, nl, masks)
 
 
-@pytest.mark.parametrize("env", ["ASTK_DEC_B6_FUSED", "ASTK_DEC_B6_SPLIT"])
+@pytest.mark.parametrize("env", ["dec.b6_fused", "dec.b6_split"])
 @pytest.mark.parametrize("B,L,T,H,E,A,V,nl,masks", [(32, 7, 50, 512, 128, 512, 1098, 1, True), (17, 5, 60, 256, 64, 128, 300, 1, False),
                                                     (32, 6, 50, 512, 128, 512, 1098, 3, True)])
-def test_decoder_backward_older_role_layouts(lib, monkeypatch, env, B, L, T, H, E, A, V, nl, masks):
-    """The persistent backward kernel's role layouts of rounds 2-3, kept behind switches for A/B runs: ASTK_DEC_B6_FUSED=0 = a d_x0 role
-    (two K halves per item) handing the carry to the d_pre items; ASTK_DEC_B6_SPLIT=0 (one layer only) = whole d_x0 items inside the kernel.
+def test_decoder_backward_older_role_layouts(lib, tune, env, B, L, T, H, E, A, V, nl, masks):
+    """The persistent backward kernel's role layouts of rounds 2-3, kept behind tuning knobs for A/B runs: dec.b6_fused 0 = a d_x0 role
+    (two K halves per item) handing the carry to the d_pre items; dec.b6_split 0 (one layer only) = whole d_x0 items inside the kernel.
     The default (no d_x0 role, d_pre formed by the d_cvh items) is what every other decoder test runs."""
-    if env == "ASTK_DEC_B6_SPLIT" and nl > 1:
+    if env == "dec.b6_split" and nl > 1:
         pytest.skip("the multi-layer role layout always splits the d_x0 items")
-    monkeypatch.setenv(env, "0")
+    tune(env, 0, lib)
     s = _dec_setup(lib, B, L, T, H, E, A, V, nl, masks, seed=B + L + 2)
     assert lib.astk_decoder_path(C.byref(s["d"])) & 1, "persistent decoder path not taken"
     _decoder_case(lib, s, B, L, T, H, E, A, V, nl, masks)
 
 
-def test_wide_decoder_path_and_bounded_spins(lib, monkeypatch):
+def test_wide_decoder_path_and_bounded_spins(lib, tune):
     """configs[4]'s decoder (H = A = 1024, E = 128, one layer, 32 rows, T'' = 200, V = 8004) reports decoder_wide.hip's persistent loops
-    (astk_decoder_path bit 4), and their spins are bounded like every other persistent kernel's: with ASTK_PERSIST_SPIN_LIMIT = 1 the
+    (astk_decoder_path bit 4), and their spins are bounded like every other persistent kernel's: with the knob persist.spin_limit = 1 the
     launches give up, drain and leave the decoder bits in the library's sticky status word instead of hanging."""
     from ast_amd._lib import DecoderDesc
     assert lib.astk_decoder_path(C.byref(DecoderDesc(32, 40, 200, 1024, 128, 1024, 8004, 1))) == 16
@@ -616,7 +616,7 @@ def test_wide_decoder_path_and_bounded_spins(lib, monkeypatch):
     loss_d, pred_d = torch.zeros(1, device="cuda"), torch.zeros(s["S"], B, dtype=torch.int32, device="cuda")
     mask = C.c_uint(0)
     assert lib.astk_persist_status(C.byref(mask), 1) == 0
-    monkeypatch.setenv("ASTK_PERSIST_SPIN_LIMIT", "1")
+    tune("persist.spin_limit", 1, lib)
     ok(lib, lib.astk_decoder_fwd(C.byref(s["d"]), C.byref(s["dp"]), vp(enc_d), vp(c0_d), vp(h0_d), vp(y_d), vp(fl_d), None, None,
                                  vp(loss_d), vp(pred_d), vp(ws), nbytes, stream()))
     assert lib.astk_persist_status(C.byref(mask), 1) == 0 and mask.value & 4, mask.value           # PERSIST_DEC_FWD
@@ -625,7 +625,7 @@ def test_wide_decoder_path_and_bounded_spins(lib, monkeypatch):
     ok(lib, lib.astk_decoder_bwd(C.byref(s["d"]), C.byref(s["dp"]), C.byref(s["dg"]), vp(enc_d), vp(c0_d), vp(h0_d), vp(y_d), None,
                                  None, vp(d_enc), vp(d_c0), vp(d_h0), vp(ws), nbytes, stream()))
     assert lib.astk_persist_status(C.byref(mask), 1) == 0 and mask.value & 8, mask.value           # PERSIST_DEC_BWD
-    monkeypatch.delenv("ASTK_PERSIST_SPIN_LIMIT")
+    tune("persist.spin_limit", 0, lib)
     ws.check("wide decoder, timed-out launches")
 
 
@@ -1023,7 +1023,7 @@ def test_gemm_heavy_tailed_operands_every_scheme_against_the_exact_f32_kernel(li
         operand puts its largest entry at 2^15, an entry keeps all 22 bits down to 2^-17 of that maximum and 11 bits down to 2^-29
         (gemm.hip); here the MEDIAN entry sits 2^-25 below the maximum.  The error grows to 1e-4 .. 1e-3 of the entry's scale and the
         test pins that bound -- and that the bf16x3 scheme (no scales: bf16 has f32's exponent range), which astk_set_gemm_precision(1)
-        / ASTK_GEMM_PREC=bf16x3 select at run time, is as accurate as the f32 kernel on the same data."""
+        selects at run time, is as accurate as the f32 kernel on the same data."""
     rng = np.random.default_rng(1000 * layout + M)
     def heavy(r, c):
         mag = np.exp(rng.normal(0.0, sigma, size=(r, c)))

@@ -46,8 +46,28 @@ def test_library_exports_every_declared_symbol():
     assert lib.astk_version() >= 100
     # in-kernel instrumentation of the persistent kernels (phase timers, the dawdling slice of the last-arrival regression test) is read
     # from ASTK_PERSIST_DBG by the TEST-HOOK build only: the product library does not even contain the variable's name
-    assert b"ASTK_PERSIST_DBG" not in open(_lib.LIB_PATH, "rb").read()
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"ASTK_PERSIST_DBG" not in blob
     assert b"ASTK_PERSIST_DBG" in open(_lib.TEST_LIB_PATH, "rb").read()
+    # ... and the product library reads NO environment variable at all (round 6: the ~30 getenv knobs of rounds 1-5 are entries of the one
+    # documented switchboard astk_set_tuning): no ASTK_ name of that kind is in the binary, and it does not import getenv
+    import subprocess
+    names = set(re.findall(rb"ASTK_[A-Z][A-Z0-9_]{2,}", blob))
+    assert not names, names
+    nm = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True)
+    if nm.returncode == 0:
+        assert not re.search(r"\bU (secure_)?getenv\b", nm.stdout), "libastk.so imports getenv"
+    # every knob is enumerable and round-trips
+    import ctypes as C
+    keys = []
+    while lib.astk_tuning_key(len(keys)):
+        keys.append(lib.astk_tuning_key(len(keys)).decode())
+    assert {"gemm.hybrid", "dec.persist", "lstm.persist", "persist.spin_limit", "lstm.rows32"} <= set(keys) and len(keys) == len(set(keys))
+    for k in keys:
+        v = C.c_double()
+        assert lib.astk_get_tuning(k.encode(), C.byref(v)) == 0
+        assert _lib.set_tuning(k, v.value) == v.value
+    assert lib.astk_set_tuning(b"no.such.knob", 1.0) != 0 and b"no.such.knob" in lib.astk_last_error()
 
 
 def test_parameter_counts_match_the_reference_model():
