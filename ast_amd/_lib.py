@@ -178,6 +178,7 @@ SIGNATURES = {
     "astk_persist_status": (C.c_int, [C.POINTER(C.c_uint), _I]),
     "astk_device_cu_count": (C.c_int, []),
     "astk_lstm_stack_path": (C.c_int, [C.POINTER(LstmStackDesc)]),
+    "astk_lstm_stack_free_cus": (C.c_int, [C.POINTER(LstmStackDesc)]),
     "astk_decoder_path": (C.c_int, [C.POINTER(DecoderDesc)]),
     "astk_prof_begin": (C.c_int, []),
     "astk_prof_end": (C.c_int, [C.POINTER(C.c_double)]),

@@ -349,11 +349,12 @@ struct GemmForwardScope {
   ~GemmForwardScope();
   int prev;
 };
-// Scoped cap on the co-resident GEMM workgroups per CU for launches made by this thread (0 = none): work that is meant to run
-// BESIDE a persistent recurrence kernel must leave registers free on every CU, or that kernel cannot become resident until the
-// stream-K workgroups (which live for the whole launch) have finished.
+// Scoped cap on the GRID of the GEMM launches made by this thread (workgroups; 0 = none): work that is meant to run BESIDE a persistent
+// recurrence kernel, on a second stream, gets at most the CUs that kernel's grid leaves free -- whichever of the two is dispatched first,
+// the recurrence grid still becomes resident (a workgroup of it needs a CU's whole register file, and stream-K workgroups live for the
+// whole launch).  Capped launches take operand schemes that need no scale slots (the slots' ring is ordered by ONE stream).
 struct GemmWgCap {
-  explicit GemmWgCap(int per_cu);
+  explicit GemmWgCap(int wgs);
   ~GemmWgCap();
   int prev;
 };

@@ -870,7 +870,7 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
   }
   }   // do_chain
   if (!do_params) return 0;
-  GemmWgCap cap(phase == ASTK_DEC_BWD_PARAMS ? 2 : 0);   // on its own stream this phase shares the CUs with the encoder's recurrence kernel
+  GemmWgCap cap(phase == ASTK_DEC_BWD_PARAMS ? d->side_wgs : 0);   // on its own stream this phase shares the CUs with the encoder's recurrence kernel
   // ==== parameter gradients: read only what the chain phase left in the workspace; nothing downstream of the decoder needs them, so a
   // caller may run this phase on a second stream beside the encoder's backward recurrence (ASTK_DEC_BWD_PARAMS)
   if (wide_b)      // the embedding columns of d_x0 (only the embedding scatter reads them): one batched product over all steps

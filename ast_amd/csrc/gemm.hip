@@ -1185,7 +1185,7 @@ static thread_local int tl_forward = 0;
 GemmForwardScope::GemmForwardScope() : prev(tl_forward) { tl_forward = 1; }
 GemmForwardScope::~GemmForwardScope() { tl_forward = prev; }
 static thread_local int tl_wg_cap = 0;
-GemmWgCap::GemmWgCap(int per_cu) : prev(tl_wg_cap) { tl_wg_cap = per_cu; }
+GemmWgCap::GemmWgCap(int wgs) : prev(tl_wg_cap) { tl_wg_cap = wgs > 0 ? std::max(8, wgs / 8 * 8) : 0; }      // (a multiple of the 8 XCDs)
 GemmWgCap::~GemmWgCap() { tl_wg_cap = prev; }
 
 // operand precision of the f32-accurate products.  Process default: bf16x3 (three-term bf16 split: every f32 operand value is represented
@@ -1372,7 +1372,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     if (g2 > tiles) { G = g2; aligned = false; }
   }
   if (force_g > 0) { G = std::min<long>(force_g, grp.iters_total); aligned = false; }
-  if (tl_wg_cap > 0 && G > 256L * tl_wg_cap) { G = 256L * tl_wg_cap; aligned = false; }
+  if (tl_wg_cap > 0 && G > tl_wg_cap) { G = tl_wg_cap; aligned = false; }
   if (aligned && grp.n > 1) {
     // one tile per workgroup needs boundaries on tile boundaries: only true for uniform kt; otherwise fall back to an even split
     bool uniform = true;

@@ -32,6 +32,7 @@ struct PersistCellHost {
 bool lstm_persist_hoisted(int h);
 bool lstm_persist_applicable(int T, int B, int h, int nl, int nd);
 int lstm_persist_layers_per_launch(int B, int h, int nl, int nd);
+int lstm_persist_grid_wgs(int B, int h, int layers, int nd);
 size_t lstm_persist_pr_floats(int B, int h);
 size_t lstm_persist_pd_floats(int T, int B, int h);
 int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters, hipStream_t s);
@@ -138,6 +139,14 @@ extern "C" {
 int astk_lstm_stack_path(const astk_lstm_stack_desc* d) {
   if (!d || d->struct_size != sizeof(astk_lstm_stack_desc)) return 0;
   return lstm_persist_applicable(d->T, d->B, d->h, d->n_layers, d->n_dirs) ? (lstm_persist_hoisted(d->h) ? 2 : 1) : 0;
+}
+
+int astk_lstm_stack_free_cus(const astk_lstm_stack_desc* d) {
+  if (!d || d->struct_size != sizeof(astk_lstm_stack_desc)) return 0;
+  if (!lstm_persist_applicable(d->T, d->B, d->h, d->n_layers, d->n_dirs)) return 0;
+  const int lpl = lstm_persist_layers_per_launch(d->B, d->h, d->n_layers, d->n_dirs);
+  const int wgs = lstm_persist_grid_wgs(d->B, d->h, std::min(lpl, d->n_layers), d->n_dirs);
+  return std::max(0, device_cu_count() - wgs);
 }
 
 size_t astk_lstm_stack_workspace_bytes(const astk_lstm_stack_desc* d) {

@@ -1057,6 +1057,9 @@ int lstm_persist_layers_per_launch(int B, int h, int nl, int nd) {
   return (int)lpl;
 }
 
+// workgroups of one launch over `layers` layers of all directions
+int lstm_persist_grid_wgs(int B, int h, int layers, int nd) { return (h / 16) * ((B + 15) / 16) * nd * layers; }
+
 // Hoisted form (h = 1024): the weight fragments of one product fill a workgroup's registers, so every layer runs as a launch of its
 // own over cells that get their input projection from a batched GEMM in front of it (forward) and leave the gradient for the layer below
 // to a batched GEMM behind it (backward) -- the structure of the per-step path with T launches per layer replaced by one.

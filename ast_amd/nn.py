@@ -167,7 +167,7 @@ class NN:
             avg_loss = total_loss / n_batches
             pbar.set_description("loss={0:0.4f}".format(avg_loss))
             pbar.update(p[2] * self.data_loader.world)
-        # (a stream of its own rather than the legacy default stream: slightly faster, and required by the model's opt-in CU-masked side streams)
+        # (a stream of its own rather than the legacy default stream: slightly faster, and what lets the model's side stream run beside the recurrences)
         if getattr(self, "_compute_stream", None) is None:
             self._compute_stream = torch.cuda.Stream(device=self.model.device)
         torch.cuda.synchronize(self.model.device)

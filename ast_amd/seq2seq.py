@@ -166,34 +166,6 @@ def _vp(t):
 _LAZY_CLEARGRADS = os.environ.get("ASTK_LAZY_CLEARGRADS", "1") != "0"      # (0: cleargrads() always fills at once -- A/B runs)
 
 
-# Raw hipStream_t handles made with hipExtStreamCreateWithCUMask (opt-in overlap, _cu_streams).  torch only BORROWS them
-# (ExternalStream), so nothing ever destroyed them: they were still alive when the HIP runtime's static destructors ran, and five
-# rocprofv3 runs in a row ended with SIGSEGV inside __cxa_finalize after their results were written (round-1 logs ovl2/ovl3/sp/dpt/
-# dpt2).  They are now owned here: destroyed by SpeechEncoderDecoder.close() or, at the latest, by an atexit hook -- Python's
-# atexit runs before the interpreter and the runtime libraries are torn down.
-_MASKED_STREAMS = []
-
-
-def _destroy_masked_streams(handles=None):
-    todo = list(_MASKED_STREAMS) if handles is None else [h for h in handles if h in _MASKED_STREAMS]
-    if not todo:
-        return
-    try:
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        hip = C.CDLL("libamdhip64.so")
-        hip.hipStreamDestroy.argtypes = [C.c_void_p]
-        for h in todo:
-            hip.hipStreamDestroy(C.c_void_p(h))
-            _MASKED_STREAMS.remove(h)
-    except Exception:                                      # interpreter shutdown: nothing useful can be done with an error here
-        pass
-
-
-import atexit  # noqa: E402
-atexit.register(_destroy_masked_streams)
-
-
 class SpeechEncoderDecoder:
     def __init__(self, gpuid, cfg):
         self.gpuid = gpuid
@@ -244,11 +216,13 @@ class SpeechEncoderDecoder:
         self._dec_c = self._dec_h = None
         self.grad_buckets = None        # ast_amd.dist.GradBuckets under data parallelism: ranges are all-reduced as they become final
         self.stat_exchange = None       # ast_amd.dist.StatExchange: BatchNorm statistics over the global batch (train mode only)
-        # Opt-in (ASTK_OVERLAP_PARAM_GRADS=1): decoder parameter gradients on a CU-masked stream beside the encoder's backward
-        # recurrence.  Worth 0.03-0.08 ms per step when it works, but in processes that have created many streams (several models,
-        # other libraries) the masked queues fall into a state that costs 2-4 ms per step -- HIP multiplexes streams onto a few
-        # hardware queues -- and a pairwise concurrency probe does not see it coming.  Off by default for that reason.
-        self.overlap_param_grads = os.environ.get("ASTK_OVERLAP_PARAM_GRADS", "0") == "1"
+        # Work BESIDE the latency-bound encoder recurrences (round 6): an ORDINARY second stream carries (i) the decoder's parameter
+        # gradients beside the encoder's backward recurrence and (ii) -- inside the library, astk_lstm_stack_desc.side_stream -- the
+        # time-chunked layer-0 products beside both recurrences; every launch on it is capped at the CUs the recurrence grid leaves
+        # free, so neither order of dispatch can keep that grid from becoming resident.  (Rounds 1-5 needed CU-masked streams for
+        # this and kept it opt-in: uncapped stream-K grids that got the CUs first blocked the recurrence.)  ASTK_SIDE_STREAM=0: in line.
+        self.side_stream_on = os.environ.get("ASTK_SIDE_STREAM", "1") != "0"
+        self._side = None
         self.mask_pad_id = None
         # Arithmetic of the batched products, per model (-> the descriptors' `precision` / `gemm_operands` fields): None = the library's
         # process-wide default (bf16x3: exact f32 operands on the 16-bit matrix pipe); "bf16x3" | "f32" | "fp16x2" (narrower, opt-in);
@@ -632,71 +606,20 @@ class SpeechEncoderDecoder:
             self._dec_c, self._dec_h = st["c0"].clone(), st["h0"].clone()
 
     # ------------------------------------------------------------------ seq2seq.py:399-473
-    def _cu_streams(self, st):
-        """(recurrence stream masked to the CUs the encoder's persistent kernels occupy, side stream masked to the others), or None.
-        hipExtStreamCreateWithCUMask: bit i = CU i; contiguous ranges confine a launch as expected on MI355X (scratch/cumask_probe.hip)."""
-        if torch.cuda.current_stream(self.device).cuda_stream == 0:
-            # masked streams are created "blocking": they and the legacy default stream wait for each other's work, which serialises
-            # exactly what should overlap.  Callers that want the overlap run the step on a stream of their own (bench.py, NN.train_epoch).
+    def _side_stream(self):
+        """The model's second stream (ordinary, from torch's pool), or None when side-stream work is off or the step runs on the legacy
+        default stream (which synchronises implicitly with every other stream: nothing would overlap)."""
+        if not self.side_stream_on or self.enc_variant is not None:
             return None
-        need = (self.h // 16) * ((st["B"] + 15) // 16) * self.n_dirs * len(self.rnn_enc)      # workgroups of lstm_persist_*: one per CU
-        n_lo = (need + 31) // 32 * 32
-        key = ("cu_streams", n_lo)
-        if key not in self._ws:
-            self._ws[key] = None
-            n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
-            if self.h % 16 == 0 and n_cu == 256 and n_lo + 32 <= n_cu:
-                try:
-                    hip = C.CDLL("libamdhip64.so")
-
-                    def make(lo, hi):
-                        mask = (C.c_uint32 * (n_cu // 32))()
-                        for bit in range(lo, hi):
-                            mask[bit // 32] |= 1 << (bit % 32)
-                        handle = C.c_void_p()
-                        if hip.hipExtStreamCreateWithCUMask(C.byref(handle), len(mask), mask) != 0:
-                            raise RuntimeError("hipExtStreamCreateWithCUMask failed")
-                        return handle
-                    with torch.cuda.device(self.device):
-                        rec, side = make(0, n_lo), make(n_lo, n_cu)
-                    rec_t = torch.cuda.ExternalStream(rec.value, device=self.device)
-                    side_t = torch.cuda.ExternalStream(side.value, device=self.device)
-                    main = torch.cuda.current_stream(self.device)
-                    # HIP multiplexes streams onto a few hardware queues; streams that share one are serialised whatever their events
-                    # say, and then the "overlap" costs a millisecond instead of saving a tenth.  Probe every pair once.
-                    _MASKED_STREAMS.extend([rec.value, side.value])
-                    if all(self._concurrent(a, b) for a, b in ((main, side_t), (main, rec_t), (rec_t, side_t))):
-                        self._ws[key] = (rec, side_t, rec_t)
-                    else:
-                        del rec_t, side_t
-                        _destroy_masked_streams([rec.value, side.value])
-                except (OSError, RuntimeError, AttributeError):
-                    pass                                       # no masked streams on this stack: the phases run in line
-        return self._ws[key]
+        if torch.cuda.current_stream(self.device).cuda_stream == 0:
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def close(self):
-        """Gives back what the model owns outside torch's allocator: the CU-masked streams of the opt-in overlap (the torch wrappers
-        are dropped first, then the handles are destroyed)."""
-        handles = []
-        for key in [k for k in self._ws if isinstance(k, tuple) and k[0] == "cu_streams"]:
-            v = self._ws.pop(key)
-            if v is not None:
-                handles += [v[0].value, v[1].cuda_stream]
-        _destroy_masked_streams(handles)
-
-    def _concurrent(self, a, b):
-        """True if a kernel on stream b runs while stream a is busy (one 300 us spin on a, a trivial kernel on b)."""
-        lib = _lib.load()
-        probe = self._ws.setdefault("probe", torch.zeros(4, device=self.device))
-        check(lib.astk_spin(300, None, C.c_void_p(a.cuda_stream)))
-        ea, eb = torch.cuda.Event(), torch.cuda.Event()
-        ea.record(a)
-        check(lib.astk_scale_f32(_vp(probe), 4, 1.0, C.c_void_p(b.cuda_stream)))
-        eb.record(b)
-        eb.synchronize()
-        overlapped = not ea.query()
-        ea.synchronize()
-        return overlapped
+        """Kept for callers of rounds 2-5 (the CU-masked streams it used to destroy are gone; torch owns the side stream)."""
+        self._side = None
 
     def _upload_flags(self, dst, flags):
         """Host -> device copy of the teacher-forcing flags WITHOUT a host sync: a copy from pageable memory would make the host wait
@@ -796,24 +719,25 @@ class SpeechEncoderDecoder:
             check(lib.astk_decoder_bwd_phase_ex(C.byref(st["dd"]), C.byref(st["dp"]), C.byref(st["dg"]), _vp(st["enc_states"]), _vp(st["c0"]),
                                                 _vp(st["h0"]), _vp(st["y"]), _vp(st["emb_mask"]), _vp(st["rnn_masks"]), _vp(st["out_mask"]),
                                                 _vp(st["d_enc"]), _vp(st["d_c0"]), _vp(st["d_h0"]), _vp(wd), wd.numel(), phase, stream))
-        joined, rec_stream = None, None
-        cu = self._cu_streams(st) if (self.overlap_param_grads and self.enc_variant is None) else None
-        if cu is not None:
-            # The encoder's backward recurrence (1 ms; one workgroup on each of 192 CUs, one wave per SIMD) leaves the device mostly
-            # idle and needs nothing from the decoder's parameter gradients (0.17 ms of GEMMs at full speed).  They run beside it:
-            # the recurrence kernel on a stream masked to the first CUs, the parameter phase on a stream masked to the remaining ones
-            # (on unmasked streams the two slow each other down by as much as the overlap saves: scratch/overlap_probe.py),
-            # ordered after the chain phase by an event and joined before anything reads the gradient arena or reuses the workspace.
-            rec_stream, side = cu[0], cu[1]
+        joined = None
+        side = self._side_stream()
+        free = lib.astk_lstm_stack_free_cus(C.byref(st["ld"])) if side is not None else 0
+        if side is not None and free >= 16:
+            # The encoder's backward recurrence (0.7 ms; one workgroup on each of 96-192 CUs, one wave per SIMD) leaves the rest of the
+            # device idle and needs nothing from the decoder's parameter gradients (0.17 ms of GEMMs at full speed).  They run beside
+            # it on the side stream, every grid capped at the free CUs, ordered after the chain phase by an event and joined before
+            # anything reads the gradient arena or reuses the workspace.
             main = torch.cuda.current_stream(self.device)
             dec_bwd(1, s)                                    # ASTK_DEC_BWD_CHAIN
             fork = torch.cuda.Event()
             fork.record(main)
+            st["dd"].side_wgs = free
             with torch.cuda.stream(side):
                 side.wait_event(fork)
                 dec_bwd(2, C.c_void_p(side.cuda_stream))     # ASTK_DEC_BWD_PARAMS
                 joined = torch.cuda.Event()
                 joined.record(side)
+            st["dd"].side_wgs = 0
         else:
             dec_bwd(0, s)
         # The decoder's gradient range is final here, but its all-reduce is NOT launched yet: an RCCL kernel holds its CUs until every
@@ -827,11 +751,10 @@ class SpeechEncoderDecoder:
             self.enc_variant.backward(st, st["d_enc"], st["d_cT"], st["d_hT"], st["d_xlstm"])
         else:
             wl = self._workspace("lstm", st["ws_lstm"])
-            check(lib.astk_lstm_stack_bwd_on(C.byref(st["ld"]), st["lp"], st["lg"], _vp(st["xlstm"]), _vp(st["enc_masks"]), _vp(st["d_enc"]),
-                                             _vp(st["d_cT"]), _vp(st["d_hT"]), _vp(st["d_xlstm"]), _vp(wl), wl.numel(), s, rec_stream))
+            check(lib.astk_lstm_stack_bwd(C.byref(st["ld"]), st["lp"], st["lg"], _vp(st["xlstm"]), _vp(st["enc_masks"]), _vp(st["d_enc"]),
+                                          _vp(st["d_cT"]), _vp(st["d_hT"]), _vp(st["d_xlstm"]), _vp(wl), wl.numel(), s))
         if joined is not None:
-            # the side stream finished long ago (0.5 ms of work beside a 1 ms kernel); from here on everything is on one stream again,
-            # and the gradient exchange is launched from it
+            # from here on everything is on one stream again, and the gradient exchange is launched from it
             torch.cuda.current_stream(self.device).wait_event(joined)
         if self.grad_buckets is not None:
             self.grad_buckets.launch("dec")

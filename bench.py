@@ -196,7 +196,7 @@ def main():
     base_scheme = args.precision or SCHEME_OF_MODE[lib.astk_get_gemm_precision()]
     compute = torch.cuda.Stream()
     # The step runs on a stream of its own, not on the legacy default stream (measured 0.05 ms per step faster; also what the
-    # opt-in CU-masked side streams of ast_amd/seq2seq.py need, which synchronise implicitly with stream 0).
+    # side stream of ast_amd/seq2seq.py needs: the legacy default stream synchronises implicitly with every other stream).
 
     def model_cfg(name):
         cfg = copy.deepcopy(MODEL_CFG)
@@ -265,14 +265,14 @@ def main():
         def profile(self, nsteps):
             """`nsteps` extra steps with per-kernel HIP-event timing on the launch stream (astk_prof_*): res[] of include/astk.h."""
             m = self.model
-            # per-kernel figures are taken with every kernel alone on the device: with the opt-in side-stream overlap
-            # (decoder parameter gradients on 64 masked CUs beside the encoder recurrence) those GEMMs would be priced as slow ones
-            overlap, m.overlap_param_grads = m.overlap_param_grads, False
+            # per-kernel figures are taken with every kernel alone on the device: with the side-stream work (decoder parameter gradients
+            # and the time-chunked layer-0 products on the CUs the recurrences leave free) those GEMMs would be priced as slow ones
+            overlap, m.side_stream_on = m.side_stream_on, False
             lib.astk_prof_begin()
             for _ in range(nsteps):
                 self.step()
             torch.cuda.synchronize()
-            m.overlap_param_grads = overlap
+            m.side_stream_on = overlap
             res = (C.c_double * 24)()
             lib.astk_prof_end(res)
             return res
@@ -304,7 +304,8 @@ def main():
                                if dpath & 16 else "per-launch loop (fallback)")
         paths["encoder_persistent"], paths["decoder_persistent"] = bool(lib.astk_lstm_stack_path(C.byref(st["ld"]))), bool(dpath & 17)
         paths["cu_count"] = int(lib.astk_device_cu_count())
-        paths["overlap_param_grads"] = bool(model.overlap_param_grads)
+        paths["side_stream"] = bool(model._side_stream() is not None)
+        paths["free_cus_beside_recurrences"] = int(lib.astk_lstm_stack_free_cus(C.byref(st["ld"])))
         return paths
     paths = paths_of(model)
 

@@ -503,6 +503,9 @@ int astk_persist_status_merge(const float* summed, void* stream);
  *                         T'' <= 256 at 32 rows) on decoder_wide.hip's persistent loops, one launch for the forward and one for the backward
  *                         (with bit 2: two of each, over halves of more than 32 rows); bits 8.. = number of decoder layers fused into the persistent kernels */
 int astk_lstm_stack_path(const astk_lstm_stack_desc* d);
+/* CUs the persistent recurrence launches of this shape leave FREE on the current device (0: not the persistent path, or none): what a
+ * caller may pass as `side_wgs` for work it runs on a second stream beside the recurrences (astk_decoder_desc.side_wgs). */
+int astk_lstm_stack_free_cus(const astk_lstm_stack_desc* d);
 int astk_decoder_path(const astk_decoder_desc* d);
 int astk_persist_status(unsigned* mask_out, int reset);
 int astk_device_cu_count(void);

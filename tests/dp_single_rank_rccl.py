@@ -1,5 +1,5 @@
 """Exercises the data-parallel code path with the RCCL backend on ONE GPU (a process group of one rank): bucketed asynchronous
-all-reduces launched from the backward pass, the masked side streams, the non-default compute stream and the optional BatchNorm
+all-reduces launched from the backward pass, the side stream, the non-default compute stream and the optional BatchNorm
 statistics exchange all run against the real backend; with one rank the result must equal the plain step."""
 import copy, os, random, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))   # run as a script from tests/
