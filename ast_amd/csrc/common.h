@@ -262,6 +262,7 @@ struct MatView {
   int tn;
   long sg, st;
   const int* rowidx;
+  long idx_rows;      // indexed rows: rows of the array p the indices point into (0: the indices are a permutation of the operand's own rows)
 };
 static inline MatView mat(const float* p, long ld) { return MatView{p, ld, 0, 0, 0, nullptr}; }
 static inline MatView mat2(const float* p, int tn, long sg, long st) { return MatView{p, st, tn, sg, st, nullptr}; }

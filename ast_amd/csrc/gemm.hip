@@ -1155,7 +1155,7 @@ static int gemm_prepare(int layout, const GemmArgs& g, GemmArgs& a, bool& twolvl
   auto span = [&](const MatView& v, bool kr, int rows) -> long {   // floats from v.p to the end of the last element touched
     const long k4 = (g.K + 3) & ~3L, r4 = (rows + 3) & ~3L;      // padded to the 16-byte granule (leading dimensions are multiples of 4)
     if (kr) return v.tn > 0 ? 0 : (long)(g.K - 1) * v.ld + r4;   // two-level K-major rows use 64-bit offsets
-    if (v.rowidx) return (long)rows * v.ld;                      // indexed rows: a permutation of [0, rows)
+    if (v.rowidx) return (v.idx_rows > 0 ? v.idx_rows : (long)rows) * v.ld;      // indexed rows: a permutation of [0, rows), or any rows of an array of idx_rows rows
     if (v.tn > 0) return (long)((rows - 1) / v.tn) * v.sg + (long)(v.tn - 1) * v.st + k4;
     return (long)(rows - 1) * v.ld + k4;
   };
@@ -1406,6 +1406,17 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
         a.bm = std::max(1, chunk / cols);
       }
     }
+  }
+  // Forward launches outside the hybrid branch (fewer tiles than workgroups, mixed depths in a group, a capped or odd grid): the same
+  // guarantee -- at most TWO contributors per split tile, so that the float atomics commute and the forward pass is bit-reproducible whatever
+  // shapes occur -- by shrinking the grid until every stream-K range is at least as deep as the deepest tile, or to exactly two half-tile
+  // ranges per tile where the depths allow it (round-5 advice: the guarantee used to depend on which shapes happened to come by).
+  if (tl_forward && !aligned && grp.dp_waves == 0) {
+    int max_kt = 0;
+    bool uniform = true;
+    for (int i = 0; i < grp.n; ++i) { max_kt = std::max(max_kt, grp.g[i].kt); uniform = uniform && grp.g[i].kt == grp.g[0].kt; }
+    const long gmax = std::max(1L, grp.iters_total / std::max(1, max_kt));
+    if (G > gmax) G = (uniform && max_kt % (2 * grp.unit) == 0 && G >= 2 * tiles) ? 2 * tiles : gmax;
   }
   // Few tiles, deep K, accumulating output (the weight gradients: TN 512 x 1152 x 38400 is 18 tiles of 2400 k-iterations): chunk-major order,
   // chunk = the divisor of kt nearest to a workgroup's share.  ("gemm.chunk" 0: tile-major always.)

@@ -28,18 +28,59 @@ struct PersistCellHost {
   unsigned long long* amax;
   float* db;
   long dy_sb, dy_st;
+  const unsigned* zx_flags; int zx_s0, zx_cs;
+  unsigned* prog; int prog_cs;
+  float* db_part;
 };
 bool lstm_persist_hoisted(int h);
 bool lstm_persist_applicable(int T, int B, int h, int nl, int nd);
-int lstm_persist_layers_per_launch(int B, int h, int nl, int nd);
-int lstm_persist_grid_wgs(int B, int h, int layers, int nd);
+int lstm_persist_rows(int B, int h, int nl, int nd, bool side);
+int lstm_persist_layers_per_launch(int B, int h, int nl, int nd, int rows);
+int lstm_persist_grid_wgs(int B, int h, int layers, int nd, int rows);
 size_t lstm_persist_pr_floats(int B, int h);
 size_t lstm_persist_pd_floats(int T, int B, int h);
-int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters, hipStream_t s);
+int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters, int rows, hipStream_t s);
 int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters, unsigned amax_gen,
-                            hipStream_t s);
+                            int rows, hipStream_t s);
 
 namespace {
+
+constexpr int SIDE_CHUNKS_MAX = 60;
+
+// ---- work beside the recurrences (astk_lstm_stack_desc.side_stream): the plan of the forward pass.
+// The layer-0 input projection (per direction (T B) x 4h x in, the largest product of the step) is cut along time: steps [0, s0) are
+// multiplied in line, at full width, in front of the recurrence launch; the rest in chunks of `cs` steps on the side stream, every launch
+// capped at `cap` workgroups (the CUs the recurrence grid leaves free), a one-lane kernel behind each chunk raising its flag.  A chunk holds as
+// many 128-row tile rows as give `cap` tiles over all directions, so a chunk launch is ONE WHOLE TILE PER WORKGROUP: plain stores, no split
+// tiles, the same sum order in every run.  s0 is the smallest head for which, by a rate model (a tile pass ~ 0.66 us per 16 k + 15 us; a
+// recurrence step 2.9 / 3.3 us at 16 / 32 rows per workgroup, 3.8 at h = 512), no chunk is late; if the model is wrong the layer-0 cells wait
+// on a flag (bounded like every other hand-off) -- slower, never wrong.  n = 0: everything in line.
+struct SidePlan { int s0, cs, n, cap; };
+SidePlan plan_side_fwd(const astk_lstm_stack_desc* d, int rows, int wgs_first_launch) {
+  SidePlan sp = {d->T, 0, 0, 0};
+  if (!d->side_stream || lstm_persist_hoisted(d->h)) return sp;
+  int cap = device_cu_count() - wgs_first_launch;
+  if (d->side_wgs > 0) cap = std::min(cap, d->side_wgs);
+  cap = cap / 8 * 8;
+  const int tiles_per_row = d->n_dirs * ((4 * d->h + 127) / 128);       // 128 x 128 tiles per 128 rows of all directions
+  const int tile_rows = cap / tiles_per_row;
+  if (cap < 16 || tile_rows < 1) return sp;
+  int cs = (int)tune(TUNE_LSTM_OVERLAP_CHUNK);
+  if (cs <= 0) cs = tile_rows * 128 / d->B;
+  if (cs < 4 || d->T < 3 * cs / 2) return sp;
+  const double t_chunk = ((d->in_dim + 15) / 16) * 0.66 + 15.0;           // one tile pass (every workgroup of a chunk launch does one)
+  const double r_step = (d->h > 256 ? 3.8 : rows == 32 ? 3.3 : 2.9) * 0.9; // (10 % margin)
+  for (int n = std::min(SIDE_CHUNKS_MAX, (d->T - 2) / cs); n >= 1; --n) {
+    const int s0 = d->T - n * cs;
+    bool ok = s0 >= 2;
+    for (int k = 0; k < n && ok; ++k) ok = (k + 1) * t_chunk <= (s0 + (double)k * cs) * r_step;
+    if (ok) { sp.s0 = s0; sp.cs = cs; sp.n = n; sp.cap = cap; return sp; }
+  }
+  return sp;
+}
+__global__ void k_set_flag(unsigned* f) {
+  if (threadIdx.x == 0) __hip_atomic_store(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 struct LstmPlan {
   int T, B, in, h, nl, nd;
@@ -52,6 +93,7 @@ struct LstmPlan {
   float* WlT[2][ASTK_MAX_RNN_LAYERS];  // (h, 4h)
   float* WuT[2][ASTK_MAX_RNN_LAYERS];  // (h, 4h) transposed upward weights of layers >= 1 (persistent backward)
   unsigned* counters;                  // arrival counters of the persistent kernels
+  unsigned* zflags;                    // side-stream chunks: forward [SIDE_CHUNKS_MAX + 2] chunk flags, then 2 progress counters of the backward (one word per 256-byte line)
   float* PR[2][ASTK_MAX_RNN_LAYERS];   // persistent backward (reduce-scatter): partial dh_rec ring of each cell
   float* PD[2][ASTK_MAX_RNN_LAYERS];   // partial dx handed to the layer below (layers >= 1)
   unsigned long long* ax;              // the frames' maximum, folded from desc.x_amax into one line by the forward call (read by both calls)
@@ -89,6 +131,7 @@ int make_plan(const astk_lstm_stack_desc* d, void* ws, bool with_masks, LstmPlan
   P.GATH = c.take<float>(P.nd > 1 ? tb * 4 * P.h : 4);
   P.ax = c.take<unsigned long long>(AMAX_SLOT_WORDS);
   P.counters = c.take<unsigned>(((size_t)2 * P.nd * P.nl * ((P.B + 15) / 16) + 2) * 64);
+  P.zflags = c.take<unsigned>((size_t)(SIDE_CHUNKS_MAX + 2 + 2) * 64);
   {
     const bool pp = lstm_persist_applicable(P.T, P.B, P.h, P.nl, P.nd);
     for (int dd = 0; dd < P.nd; ++dd)
@@ -106,9 +149,11 @@ int make_plan(const astk_lstm_stack_desc* d, void* ws, bool with_masks, LstmPlan
 // quirk Q1: the reverse stack reads frame X[-i] = (T - i) % T at step i -- an involution, so the frame permutation is its own inverse.
 // One launch writes it (perm = inv) and its expansions to (T*B) row indices: rows[i*B+b] = perm[i]*B + b.
 __global__ void k_perm_rows(int* perm, int* inv, int* rows_perm, int* rows_inv, int T, int B, const unsigned long long* fold_src,
-                            unsigned long long* fold_dst) {
+                            unsigned long long* fold_dst, unsigned* zflags, int nzf) {
   // (rides along: the frames' maximum arrives in a STRIDED producer slot -- thousands of blocks wrote it -- and the GEMMs read one line)
   if (fold_src && blockIdx.x == 0 && threadIdx.x < 64) amax_compact(fold_src, fold_dst);
+  // (rides along: the chunk flags of the side-stream plan go down before the side stream is let loose)
+  if (zflags && blockIdx.x == 0 && (int)threadIdx.x < nzf) __hip_atomic_store(zflags + threadIdx.x * 64, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < T) {
     const int f = (T - i) % T;
@@ -144,8 +189,9 @@ int astk_lstm_stack_path(const astk_lstm_stack_desc* d) {
 int astk_lstm_stack_free_cus(const astk_lstm_stack_desc* d) {
   if (!d || d->struct_size != sizeof(astk_lstm_stack_desc)) return 0;
   if (!lstm_persist_applicable(d->T, d->B, d->h, d->n_layers, d->n_dirs)) return 0;
-  const int lpl = lstm_persist_layers_per_launch(d->B, d->h, d->n_layers, d->n_dirs);
-  const int wgs = lstm_persist_grid_wgs(d->B, d->h, std::min(lpl, d->n_layers), d->n_dirs);
+  const int rows = lstm_persist_rows(d->B, d->h, d->n_layers, d->n_dirs, d->side_stream != nullptr);
+  const int lpl = lstm_persist_layers_per_launch(d->B, d->h, d->n_layers, d->n_dirs, rows);
+  const int wgs = lstm_persist_grid_wgs(d->B, d->h, std::min(lpl, d->n_layers), d->n_dirs, rows);
   return std::max(0, device_cu_count() - wgs);
 }
 
@@ -172,11 +218,16 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
   int* rows_inv = (int*)((char*)rows_perm + align_up((size_t)T * B * sizeof(int), 256));
   // a strided producer slot (bit 0 of the handle) is folded into the plan's plain slot; a plain one is used as it is
   const bool x_strided = d->x_amax && (((uintptr_t)d->x_amax) & 1u);
+  const bool persist_path = lstm_persist_applicable(T, B, h, P.nl, P.nd);
+  const int rows_wg = persist_path ? lstm_persist_rows(B, h, P.nl, P.nd, d->side_stream != nullptr) : 16;
+  const int lpl_f = persist_path ? lstm_persist_layers_per_launch(B, h, P.nl, P.nd, rows_wg) : 0;
+  const SidePlan side = persist_path ? plan_side_fwd(d, rows_wg, lstm_persist_grid_wgs(B, h, std::min(lpl_f, P.nl), P.nd, rows_wg)) : SidePlan{T, 0, 0, 0};
+  hipStream_t sside = (hipStream_t)d->side_stream;
   hipLaunchKernelGGL(k_perm_rows, dim3(cdiv(T * B, 256)), dim3(256), 0, s, P.perm, P.inv, rows_perm, rows_inv, T, B,
-                     x_strided ? (const unsigned long long*)d->x_amax : nullptr, P.ax);
+                     x_strided ? (const unsigned long long*)d->x_amax : nullptr, P.ax, side.n > 0 ? P.zflags : nullptr, side.n + 2);
   ASTK_LAUNCH_CHECK();
   const size_t bh = (size_t)B * h;
-  if (lstm_persist_applicable(T, B, h, P.nl, P.nd)) {
+  if (persist_path) {
     // ---- persistent wavefront path: layer-0 upward projection batched over time, everything else in ONE launch
     PersistCellHost cells[16];
     memset(cells, 0, sizeof(cells));
@@ -219,7 +270,38 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
         c.layer = l;
       }
     }
-    ASTK_TRY(gemm_launch_group(GEMM_NT, k9, P.nd, s));
+    if (side.n == 0) {
+      ASTK_TRY(gemm_launch_group(GEMM_NT, k9, P.nd, s));
+    } else {
+      // time-chunked: the head in line, the rest on the side stream beside the recurrence (plan_side_fwd).  Rows are loop-step major in
+      // both directions (direction 1 reads its frames through the permutation table), so a chunk is a row range of both products.
+      auto rows_of = [&](int s_begin, int s_end, GemmArgs* out) {
+        for (int dd = 0; dd < P.nd; ++dd) {
+          GemmArgs g = k9[dd];
+          const size_t r0 = (size_t)s_begin * B;
+          g.M = (s_end - s_begin) * B;
+          if (dd == 0) g.A.p = x + r0 * P.in; else { g.A.rowidx = rows_perm + r0; g.A.idx_rows = (long)T * B; }
+          g.C = P.ZG[dd][0] + r0 * 4 * h;
+          out[dd] = g;
+        }
+      };
+      GemmArgs part[2];
+      ASTK_TRY(stream_order(s, sside));                    // the frames, the index table, the lowered flags
+      rows_of(0, side.s0, part);
+      ASTK_TRY(gemm_launch_group(GEMM_NT, part, P.nd, s));
+      {
+        GemmWgCap cap_scope(side.cap);
+        for (int k = 0; k < side.n; ++k) {
+          rows_of(side.s0 + k * side.cs, std::min(T, side.s0 + (k + 1) * side.cs), part);
+          ASTK_TRY(gemm_launch_group(GEMM_NT, part, P.nd, sside));
+          hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(64), 0, sside, P.zflags + (size_t)k * 64);
+          ASTK_LAUNCH_CHECK();
+        }
+      }
+      for (int dd = 0; dd < P.nd; ++dd) {
+        cells[dd * P.nl].zx_flags = P.zflags; cells[dd * P.nl].zx_s0 = side.s0; cells[dd * P.nl].zx_cs = side.cs;
+      }
+    }
     if (lstm_persist_hoisted(h)) {
       // hoisted form: every layer a launch of its own over "layer-0 like" cells -- the input projection of all time steps comes from a
       // batched product in front of the launch (written into the gates buffer, where the cell replaces it step by step)
@@ -234,19 +316,20 @@ int astk_lstm_stack_fwd(const astk_lstm_stack_desc* d, const astk_lstm_params* p
           grp[dd] = c;
         }
         if (l > 0) ASTK_TRY(gemm_launch_group(GEMM_NT, up, P.nd, s));
-        ASTK_TRY(lstm_persist_fwd_launch(grp, P.nd, 1, T, B, h, H, P.counters, s));
+        ASTK_TRY(lstm_persist_fwd_launch(grp, P.nd, 1, T, B, h, H, P.counters, 16, s));
       }
     } else {
       // one launch per group of layers (normally a single group: the whole stack); a later group finds the outputs of the layer
       // below complete (its sentinel polls succeed at once)
-      const int lpl = lstm_persist_layers_per_launch(B, h, P.nl, P.nd);
+      const int lpl = lpl_f;
       for (int l0 = 0; l0 < P.nl; l0 += lpl) {
         const int ngl = std::min(lpl, P.nl - l0);
         PersistCellHost grp[16];
         for (int dd = 0; dd < P.nd; ++dd)
           for (int l = 0; l < ngl; ++l) grp[dd * ngl + l] = cells[dd * P.nl + l0 + l];
-        ASTK_TRY(lstm_persist_fwd_launch(grp, P.nd * ngl, ngl, T, B, h, H, P.counters, s));
+        ASTK_TRY(lstm_persist_fwd_launch(grp, P.nd * ngl, ngl, T, B, h, H, P.counters, rows_wg, s));
       }
+      if (side.n > 0) ASTK_TRY(stream_order(sside, s));      // join: the caller sees one-stream semantics
     }
     CopySegs cp;   // final states of every cell: one launch
     cp.n = 0;
@@ -375,14 +458,15 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
           if (l < P.nl - 1) { c.d_enc = P.DX[dd]; c.dy_sb = h; c.dy_st = (long)B * h; c.reverse_pos = 0; }
           grp[dd] = c;
         }
-        ASTK_TRY(lstm_persist_bwd_launch(grp, P.nd, 1, T, B, h, H, P.counters, dz_amax_gen, sr));
+        ASTK_TRY(lstm_persist_bwd_launch(grp, P.nd, 1, T, B, h, H, P.counters, dz_amax_gen, 16, sr));
         if (l > 0)
           for (int dd = 0; dd < P.nd; ++dd)
             ASTK_TRY(gemm_launch(GEMM_NN, with_amax_a(gemm_args(T * B, h, 4 * h, mat(P.ZG[dd][l], 4 * h), mat(prm[dd * P.nl + l].Wu, h), P.DX[dd], h), dz_amax[dd * P.nl + l]), sr));
       }
     } else {
       // groups of layers, top group first; the top layer of a lower group reads the partial dx tiles the previous launch left
-      const int lpl = lstm_persist_layers_per_launch(B, h, P.nl, P.nd);
+      const int rows_wg = lstm_persist_rows(B, h, P.nl, P.nd, d->side_stream != nullptr);
+      const int lpl = lstm_persist_layers_per_launch(B, h, P.nl, P.nd, rows_wg);
       int l1 = P.nl;
       while (l1 > 0) {
         // same grouping as the forward pass (groups start at multiples of lpl)
@@ -394,7 +478,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
             grp[dd * ngl + l] = cells[dd * P.nl + l0 + l];
             if (l == ngl - 1 && l1 < P.nl) grp[dd * ngl + l].up_external = 1;
           }
-        ASTK_TRY(lstm_persist_bwd_launch(grp, P.nd * ngl, ngl, T, B, h, H, P.counters, dz_amax_gen, sr));
+        ASTK_TRY(lstm_persist_bwd_launch(grp, P.nd * ngl, ngl, T, B, h, H, P.counters, dz_amax_gen, rows_wg, sr));
         l1 = l0;
       }
     }

@@ -54,6 +54,11 @@ struct PCellF {
   float* enc;           // top layer: enc_states + dir*h ; row stride enc_ldb per batch row, enc_ldt per position
   int reverse_pos;      // top layer of direction 1: position = T-1-t
   int layer;
+  // layer 0 with its input projection produced in time chunks on a side stream (astk_lstm_stack_desc.side_stream): steps [0, zx_s0) are
+  // there when the launch starts; chunk k >= 0 = steps [zx_s0 + k zx_cs, zx_s0 + (k+1) zx_cs) is there when zx_flags[k * CTR_STRIDE] != 0
+  // (one word per chunk on its own line, zeroed before the side stream starts, set by a one-lane kernel behind the chunk's product).  null: all there.
+  const unsigned* zx_flags;
+  int zx_s0, zx_cs;
 };
 struct PFwdArgs {
   PCellF c[16];
@@ -84,6 +89,12 @@ struct PCellB {
   int layer;
   u64* amax;            // 16 sharded words for max |dz| of this cell (the fp16x2 GEMMs' operand scale, gemm_amax_reserve), or null
   float* db;            // (4h) bias gradient, += the column sums of dz over all steps and rows (null: the caller sums dz itself)
+  float* db_part;       // deterministic calls: [workgroup rows][4h] scratch that receives every row's sums instead of the atomics into db (null: atomics)
+  // layer 0 with side-stream consumers of dz (the time-chunked input / weight gradient products): dz goes out written through, and every
+  // workgroup of the cell arrives once on *prog per chunk of prog_cs steps (>= 4) -- chunk k = loop steps [k prog_cs, (k+1) prog_cs) counted from
+  // the END of the sequence, complete when *prog >= (k+1) x workgroups of the cell.  null: dz is read behind the launch only.
+  unsigned* prog;
+  int prog_cs;
 };
 struct PBwdArgs {
   PCellB c[16];
@@ -305,14 +316,18 @@ __device__ __forceinline__ float4 frag_vals(const u32x4& g) {
 // Code shape: everything a wait depends on is UNCONDITIONAL inside the loop (HAS_UP is a template parameter, step 0 is
 // peeled, prefetch indices are clamped instead of guarded): a conditionally issued load becomes a phi of "old registers /
 // load result", and hipcc then copies the result right behind the load, i.e. waits for it at the point of issue.
-template <int KB, bool HAS_UP, int XS>
+// MT = 16-row batch tiles per workgroup (1 or 2).  MT = 2 (round 6): the workgroup's resident weight fragments serve BOTH tiles -- two sets
+// of activation fragments and accumulators against the same B operands -- so a batch of 32 rows takes 96 workgroups instead of 192 (160 CUs
+// free for the time-chunked layer-0 products on the side stream), batch 64 runs as ONE launch and the 6-layer stacks need half the launches.
+// The hand-off protocol is unchanged (every wave polls the fragments of both tiles); the matrix part and the gate epilogue of a step double.
+template <int KB, bool HAS_UP, int XS, int MT>
 __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& c, float* red0, float* red1, u32q* lo_lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int bt = blockIdx.y, j0 = blockIdx.x * 16;
   const int T = a.T, B = a.B, h = a.h, HH = a.H, dbg = PERSIST_DBG(a);
   const AbortCtl ab = a.ab;       // (locals: see the note on the kernel-argument block in lstm_persist_fwd_g)
-  const int m0 = bt * 16;
+  const int m0 = bt * 16 * MT;
   bool dead = false;
 
   auto wl_at = [&](int i, int g) { return *reinterpret_cast<const float4*>(c.Wl + (long)(4 * (j0 + r) + g) * h + 16 * (wave + 4 * i) + 4 * q); };
@@ -371,37 +386,72 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
   }
   const __amdgpu_buffer_rsrc_t r_own = make_rsrc(c.HR);
   const __amdgpu_buffer_rsrc_t r_below = make_rsrc(HAS_UP ? c.xin : c.HR);
-  const int arow = min(m0 + r, B - 1);
-  const int eb = m0 + (tid >> 4), eu = j0 + (tid & 15);      // epilogue ownership: (batch row, unit)
-  const bool evalid = eb < B;
-  const long ebc = evalid ? eb : 0;
+  // layer 0: the input projection of all time steps comes from a batched product; with time-chunked products on a side stream
+  // (astk_lstm_stack_desc.side_stream) the rows of step t exist once the flag of t's chunk is up -- read with sc1 loads behind the flag (the
+  // producing launch ended, i.e. its stores are in memory, before the flag kernel behind it ran)
+  const __amdgpu_buffer_rsrc_t r_zx = make_rsrc(HAS_UP ? (const float*)c.HR : c.zx);
+  const unsigned* const zflags = HAS_UP ? nullptr : c.zx_flags;
+  const int zs0 = c.zx_s0, zcs = max(c.zx_cs, 1);
+  const int eu = j0 + (tid & 15);                            // epilogue ownership: unit eu, batch rows eb[mt]
+  int frag0[MT], eb[MT];
+  long ebc[MT];
+  bool evalid[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int arow = min(m0 + 16 * mt + r, B - 1);
+    frag0[mt] = (arow * h + 4 * q) * 4;   // byte offset of this lane's fragment row at step 0
+    eb[mt] = m0 + 16 * mt + (tid >> 4);
+    evalid[mt] = eb[mt] < B;
+    ebc[mt] = evalid[mt] ? eb[mt] : 0;
+  }
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (HAS_UP) bias4 = *reinterpret_cast<const float4*>(c.bias + 4 * eu);
   const bool use_mask = c.mask != nullptr;
   const float* maskp = use_mask ? c.mask : c.C;   // always a readable (T,B,h) buffer: the mask load is unconditional
-  float c_state = 0.f;
+  float c_state[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) c_state[mt] = 0.f;
   const int step_bytes = B * h * 4;
-  const int frag0 = (arow * h + 4 * q) * 4;   // byte offset of this lane's fragment row at step 0
-  u32x4 gx[KB];
-  float4 ax[KB];
-  Frag axh[X2 ? NPR : 1];
+  u32x4 gx[MT][KB];
+  float4 ax[MT][KB];
+  Frag axh[MT][X2 ? NPR : 1];
   auto take_x = [&]() {
     if constexpr (X2) {
 #pragma unroll
-      for (int p = 0; p < NPR; ++p) axh[p] = split_frag<XS>(ax[2 * p], 2 * p + 1 < KB ? ax[2 * p + 1] : zero4, ACT_SCALE);
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < NPR; ++p) axh[mt][p] = split_frag<XS>(ax[mt][2 * p], 2 * p + 1 < KB ? ax[mt][2 * p + 1] : zero4, ACT_SCALE);
+    }
+  };
+  auto zx_load = [&](long tbs) {      // this thread's four pre-activations of (step, row) tbs: sc1 (see r_zx)
+    return frag_vals(__builtin_amdgcn_raw_buffer_load_b128(r_zx, (int)((tbs * 4 * h + 4 * eu) * 4), 0, 16));
+  };
+  // chunk flag of time step ts (layer 0 with side-stream chunks only): the word to look at, and the wait
+  auto zflag_of = [&](int ts) { return zflags + (ts < zs0 ? 0 : 1 + (ts - zs0) / zcs) * CTR_STRIDE; };
+  auto zflag_wait = [&](const unsigned* fp, unsigned seen) {
+    unsigned spins = 0;
+    while (seen == 0u && !dead) {
+      seen = ld_flag(fp);
+      if (++spins > (ab.limit >> 1)) { abort_raise(ab); dead = true; }
+      else if ((spins & 63u) == 0 && abort_seen(ab)) dead = true;
     }
   };
   // what only later launches read, stored half a step late
-  float4 p_gates = make_float4(0.f, 0.f, 0.f, 0.f);
-  float p_hd = 0.f, p_c = 0.f;
+  float4 p_gates[MT];
+  float p_hd[MT], p_c[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) { p_gates[mt] = make_float4(0.f, 0.f, 0.f, 0.f); p_hd[mt] = 0.f; p_c[mt] = 0.f; }
   auto store_saved = [&](int ts) {
-    if (!evalid) return;
-    const long tbs = (long)ts * B + eb;
-    *reinterpret_cast<float4*>(c.gates + tbs * 4 * h + 4 * eu) = p_gates;
-    c.C[tbs * h + eu] = p_c;
-    if (c.enc) {
-      const int pos = c.reverse_pos ? T - 1 - ts : ts;
-      c.enc[((long)eb * T + pos) * HH + eu] = p_hd;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (!evalid[mt]) continue;
+      const long tbs = (long)ts * B + eb[mt];
+      *reinterpret_cast<float4*>(c.gates + tbs * 4 * h + 4 * eu) = p_gates[mt];
+      c.C[tbs * h + eu] = p_c[mt];
+      if (c.enc) {
+        const int pos = c.reverse_pos ? T - 1 - ts : ts;
+        c.enc[((long)eb[mt] * T + pos) * HH + eu] = p_hd[mt];
+      }
     }
   };
   long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -411,52 +461,80 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
 #define TICK(i, t0) if (timing) { __builtin_amdgcn_sched_barrier(0); const long long now_ = wall_clock64(); tk[i] += now_ - t0; t0 = now_; __builtin_amdgcn_sched_barrier(0); }
 
   // ---- prologue: inputs of step 0; x_0 into registers, x_1 in flight
-  float4 zadd = bias4, zadd_n = bias4;
-  float mk_raw, mk_raw_n;
-  if (!HAS_UP) zadd = *reinterpret_cast<const float4*>(c.zx + ebc * 4 * h + 4 * eu);
-  mk_raw = maskp[ebc * h + eu];
-  if (HAS_UP) {
-    frag_issue<KB>(r_below, frag0, wave, gx);
-    if (!frag_ok<KB>(gx)) frag_wait<KB>(r_below, frag0, wave, gx, dead, ab);
+  float4 zadd[MT], zadd_n[MT];
+  float mk_raw[MT], mk_raw_n[MT];
+  unsigned zf_seen = 1u;            // the flag word of the chunk that holds step t + 2 (asked for a step early; 1 = nothing to wait for)
+  if (!HAS_UP && zflags) {
+    zflag_wait(zflag_of(0), 0u);                                       // the rows of steps 0 and 1 (one chunk, or the in-line part)
+    if (T > 1) zflag_wait(zflag_of(1), 0u);
+    zf_seen = ld_flag(zflag_of(min(2, T - 1)));
+  }
 #pragma unroll
-    for (int i = 0; i < KB; ++i) ax[i] = frag_vals(gx[i]);
-    frag_issue<KB>(r_below, frag0 + min(1, T - 1) * step_bytes, wave, gx);
+  for (int mt = 0; mt < MT; ++mt) {
+    zadd[mt] = bias4; zadd_n[mt] = bias4;
+    if (!HAS_UP) zadd[mt] = zx_load(ebc[mt]);
+    mk_raw[mt] = maskp[ebc[mt] * h + eu];
+  }
+  if (HAS_UP) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) frag_issue<KB>(r_below, frag0[mt], wave, gx[mt]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (!frag_ok<KB>(gx[mt])) frag_wait<KB>(r_below, frag0[mt], wave, gx[mt], dead, ab);
+#pragma unroll
+      for (int i = 0; i < KB; ++i) ax[mt][i] = frag_vals(gx[mt][i]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) frag_issue<KB>(r_below, frag0[mt] + min(1, T - 1) * step_bytes, wave, gx[mt]);
   }
 
   // One step.  FIRST: no recurrent part (h_{-1} = 0).
   auto step = [&](auto first_tag, int t) {
     constexpr bool FIRST = decltype(first_tag)::value;
     long long t0 = timing ? wall_clock64() : 0;
-    f32x4 acc[4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frag = frag0 + t * step_bytes;
-    u32x4 gh[KB];
-    if (!FIRST) frag_issue<KB>(r_own, frag - step_bytes, wave, gh);   // in flight behind the upward MFMAs
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[mt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 gh[MT][KB];
+    if (!FIRST) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) frag_issue<KB>(r_own, frag0[mt] + (t - 1) * step_bytes, wave, gh[mt]);   // in flight behind the upward MFMAs
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (HAS_UP) {
       if constexpr (X2) {
         take_x();       // x_t (taken at W_{t-1}) is split HERE, in front of the wait for h, not between that wait and the recurrent MFMAs
 #pragma unroll
-        for (int p = 0; p < NPR; ++p) {
-          if constexpr (XS == 4) { MFMA32BG4(acc, axh[p], wuh[p], lo_u + p * 4 * 256) } else if constexpr (XS == 3) { MFMA32BG(acc, axh[p], wuh[p]) } else { MFMA32HG(acc, axh[p], wuh[p]) }
-        }
+        for (int p = 0; p < NPR; ++p)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            if constexpr (XS == 4) { MFMA32BG4(acc[mt], axh[mt][p], wuh[p], lo_u + p * 4 * 256) } else if constexpr (XS == 3) { MFMA32BG(acc[mt], axh[mt][p], wuh[p]) } else { MFMA32HG(acc[mt], axh[mt][p], wuh[p]) }
+          }
       } else {
 #pragma unroll
-        for (int i = 0; i < KB; ++i) { MFMA4G(acc, ax[i], wu[i]) }
+        for (int i = 0; i < KB; ++i)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) { MFMA4G(acc[mt], ax[mt][i], wu[i]) }
       }
     }
     const int t1 = min(t + 1, T - 1), t2 = min(t + 2, T - 1);
     if (HAS_UP) {   // x_{t+1}: issued a whole step ago, taken over HERE, while h_{t-1} is still in flight (behind the wait it was 0.27 us of the chain)
-      if (!frag_ok<KB>(gx)) { ++slow_x; frag_wait<KB>(r_below, frag0 + t1 * step_bytes, wave, gx, dead, ab); }
 #pragma unroll
-      for (int i = 0; i < KB; ++i) ax[i] = frag_vals(gx[i]);
+      for (int mt = 0; mt < MT; ++mt) {
+        if (!frag_ok<KB>(gx[mt])) { ++slow_x; frag_wait<KB>(r_below, frag0[mt] + t1 * step_bytes, wave, gx[mt], dead, ab); }
+#pragma unroll
+        for (int i = 0; i < KB; ++i) ax[mt][i] = frag_vals(gx[mt][i]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     TICK(0, t0)
     // ---- W_t
     if (!FIRST) {
-      if (!frag_ok<KB>(gh)) { ++slow_h; frag_wait<KB>(r_own, frag - step_bytes, wave, gh, dead, ab); }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        if (!frag_ok<KB>(gh[mt])) { ++slow_h; frag_wait<KB>(r_own, frag0[mt] + (t - 1) * step_bytes, wave, gh[mt], dead, ab); }
     }
     TICK(1, t0)
     // Everything issued so far has landed (that is what W_t is); saying so explicitly lets the compiler drop its own
@@ -467,26 +545,39 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
     if (!FIRST) {
       if constexpr (X2) {
 #pragma unroll
-        for (int p = 0; p < NPR; ++p) {
-          const Frag ah = split_frag<XS>(frag_vals(gh[2 * p]), 2 * p + 1 < KB ? frag_vals(gh[2 * p + 1 < KB ? 2 * p + 1 : 0]) : zero4, ACT_SCALE);
-          if constexpr (XS == 4) { MFMA32BG4(acc, ah, wlh[p], lo_l + p * 4 * 256) } else if constexpr (XS == 3) { MFMA32BG(acc, ah, wlh[p]) } else { MFMA32HG(acc, ah, wlh[p]) }
-        }
+        for (int p = 0; p < NPR; ++p)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const Frag ah = split_frag<XS>(frag_vals(gh[mt][2 * p]), 2 * p + 1 < KB ? frag_vals(gh[mt][2 * p + 1 < KB ? 2 * p + 1 : 0]) : zero4, ACT_SCALE);
+            if constexpr (XS == 4) { MFMA32BG4(acc[mt], ah, wlh[p], lo_l + p * 4 * 256) } else if constexpr (XS == 3) { MFMA32BG(acc[mt], ah, wlh[p]) } else { MFMA32HG(acc[mt], ah, wlh[p]) }
+          }
       } else {
 #pragma unroll
-        for (int i = 0; i < KB; ++i) {
-          const float4 ah = frag_vals(gh[i]);
-          MFMA4G(acc, ah, wl[i])
-        }
+        for (int i = 0; i < KB; ++i)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const float4 ah = frag_vals(gh[mt][i]);
+            MFMA4G(acc[mt], ah, wl[i])
+          }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- off-path traffic: issued BEHIND the recurrent MFMAs (they run in the matrix pipe meanwhile; in front of them these loads, stores and their
     // address arithmetic were 0.18 us of the chain)
-    if (HAS_UP) frag_issue<KB>(r_below, frag0 + t2 * step_bytes, wave, gx);
-    {
-      const long tbs = (long)t1 * B + ebc;
-      if (!HAS_UP) zadd_n = *reinterpret_cast<const float4*>(c.zx + tbs * 4 * h + 4 * eu);
-      mk_raw_n = maskp[tbs * h + eu];
+    if (HAS_UP) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) frag_issue<KB>(r_below, frag0[mt] + t2 * step_bytes, wave, gx[mt]);
+    }
+    if (!HAS_UP && zflags) {
+      // the rows of step t + 1: their chunk's flag was asked for a step ago (zf_seen); wait only if it was not up then.  Then ask for t + 2's.
+      if (zf_seen == 0u) zflag_wait(zflag_of(t1), 0u);
+      zf_seen = ld_flag(zflag_of(t2));
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const long tbs = (long)t1 * B + ebc[mt];
+      if (!HAS_UP) zadd_n[mt] = zx_load(tbs);
+      mk_raw_n[mt] = maskp[tbs * h + eu];
     }
     if (!FIRST) store_saved(t - 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -494,35 +585,42 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
     // ---- 4-wave K reduction through LDS (double-buffered: one barrier per step)
     float* rd = (t & 1) ? red1 : red0;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(&rd[((wave * 4 + g) * 64 + lane) * 4]) = acc[g];
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(&rd[mt * 4096 + ((wave * 4 + g) * 64 + lane) * 4]) = acc[mt][g];
     TICK(4, t0)
     __syncthreads();
     TICK(5, t0)
     {
       const int row = tid >> 4, col = tid & 15;
       const int src = ((row >> 2) * 16 + col) * 4 + (row & 3);
-      float z[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        z[g] = rd[(0 * 4 + g) * 256 + src] + rd[(1 * 4 + g) * 256 + src] + rd[(2 * 4 + g) * 256 + src] + rd[(3 * 4 + g) * 256 + src];
-      if constexpr (XS == 2) {
+      for (int mt = 0; mt < MT; ++mt) {
+        const float* rm = rd + mt * 4096;
+        float z[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) z[g] *= zscale;      // 1 / (weight scale x activation scale)
+        for (int g = 0; g < 4; ++g)
+          z[g] = rm[(0 * 4 + g) * 256 + src] + rm[(1 * 4 + g) * 256 + src] + rm[(2 * 4 + g) * 256 + src] + rm[(3 * 4 + g) * 256 + src];
+        if constexpr (XS == 2) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) z[g] *= zscale;      // 1 / (weight scale x activation scale)
+        }
+        const float ga = tanh_fast(z[0] + zadd[mt].x), gi = sigm_fast(z[1] + zadd[mt].y), gf = sigm_fast(z[2] + zadd[mt].z), go = sigm_fast(z[3] + zadd[mt].w);
+        c_state[mt] = ga * gi + gf * c_state[mt];
+        const float hh = go * tanh_fast(c_state[mt]);
+        const float hd = use_mask ? hh * mk_raw[mt] : hh;
+        // the hand-off: the values themselves, write-through; nothing to drain or signal
+        if (evalid[mt]) {
+          const long o = ((long)t * B + eb[mt]) * h + eu;
+          st4_sc1(c.HR + o, hh);
+          if (c.HD) st4_sc1(c.HD + o, hd);
+        }
+        p_gates[mt] = make_float4(ga, gi, gf, go);
+        p_hd[mt] = hd; p_c[mt] = c_state[mt];
       }
-      const float ga = tanh_fast(z[0] + zadd.x), gi = sigm_fast(z[1] + zadd.y), gf = sigm_fast(z[2] + zadd.z), go = sigm_fast(z[3] + zadd.w);
-      c_state = ga * gi + gf * c_state;
-      const float hh = go * tanh_fast(c_state);
-      const float hd = use_mask ? hh * mk_raw : hh;
-      // the hand-off: the values themselves, write-through; nothing to drain or signal
-      if (evalid) {
-        const long o = ((long)t * B + eb) * h + eu;
-        st4_sc1(c.HR + o, hh);
-        if (c.HD) st4_sc1(c.HD + o, hd);
-      }
-      p_gates = make_float4(ga, gi, gf, go);
-      p_hd = hd; p_c = c_state;
     }
-    zadd = zadd_n; mk_raw = mk_raw_n;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { zadd[mt] = zadd_n[mt]; mk_raw[mt] = mk_raw_n[mt]; }
     TICK(6, t0)
   };
   step(std::true_type{}, 0);
@@ -534,9 +632,9 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
 #undef TICK
 }
 
-template <int KB, int XS>
+template <int KB, int XS, int MT>
 __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_g(PFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[2][4 * 4 * 256];
+  __shared__ __attribute__((aligned(16))) float red[2][MT * 4 * 4 * 256];
   // (a COPY, not a reference into the kernel-argument block: fields read through a dynamically indexed reference are re-loaded behind
   //  every global store of the step loop -- the stores might alias them -- and each re-load is a scalar-cache round trip on the chain)
   __shared__ __attribute__((aligned(16))) u32q lo_lds[XS == 4 ? LO_LDS_FRAGS * 256 : 1];
@@ -544,11 +642,10 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_g(PFwdArgs a) {
   // a cell multiplies its input itself iff it was given the upward weight: layer 0 -- and, in the hoisted form (h = 1024: the weight
   // fragments of ONE product fill the registers), every layer -- gets the projection of all time steps from a batched GEMM (zx)
   if constexpr (KB <= 8) {
-    if (c.Wu != nullptr) { lstm_fwd_steps<KB, true, XS>(a, c, red[0], red[1], lo_lds); return; }
+    if (c.Wu != nullptr) { lstm_fwd_steps<KB, true, XS, MT>(a, c, red[0], red[1], lo_lds); return; }
   }
-  lstm_fwd_steps<KB, false, XS>(a, c, red[0], red[1], lo_lds);
+  lstm_fwd_steps<KB, false, XS, MT>(a, c, red[0], red[1], lo_lds);
 }
-
 
 // ------------------------------------------------------------------ backward, reduce-scatter hand-off
 // lstm_persist_bwd gathers: every workgroup pulls the whole dz_{t+1} row block of its cell (16 x 4h) and of the layer above
@@ -580,27 +677,30 @@ constexpr bool bwd_sentinel(int KB) { return ASTK_BWD_SENTINEL && KB <= ASTK_BWD
 // row stride those 16 lanes sit on the same four banks (16-way conflicts on every access: 25.8 M SQ_LDS_BANK_CONFLICT cycles per launch
 // against 4.9 M in the forward kernel, round-3 PMC pass); 68 moves consecutive rows four banks on and the accesses are conflict-free.
 constexpr int DZ_LD = 68;
-template <int KB, bool HAS_UP, int XS>
-__device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCellB& c, float (*dzS2)[16 * DZ_LD], int* s_ok1, int& s_ok2, u32q* lo_lds) {
+// MT = 16-row batch tiles per workgroup (see lstm_fwd_steps): the resident weight fragments of both products serve both tiles; the partial
+// tile buffers keep their per-16-row-tile layout (tile index bt16 = blockIdx.y * MT + mt), the counters are per workgroup row (blockIdx.y).
+template <int KB, bool HAS_UP, int XS, int MT>
+__device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCellB& c, float (*dzS2)[MT * 16 * DZ_LD], int* s_ok1, int& s_ok2, u32q* lo_lds) {
   constexpr int NS = 4 * KB;          // slices of a cell = 16x16 output tiles of a product = partial tiles per consumer
   float* const dzS = dzS2[0];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, q = lane >> 4;
-  const int cell = blockIdx.z, bt = blockIdx.y, j = blockIdx.x, j0 = j * 16;
+  const int cell = blockIdx.z, by = blockIdx.y, j = blockIdx.x, j0 = j * 16;
   const int T = a.T, B = a.B, h = a.h, HH = a.H, dbg = PERSIST_DBG(a);
   const AbortCtl ab = a.ab;
   const unsigned amax_gen = a.amax_gen;
-  const int nbt = gridDim.y;
+  const int nby = gridDim.y, nbt = nby * MT;       // workgroup rows; 16-row tiles the partial buffers are laid out for
   const int K = 4 * h;
   constexpr bool has_up = HAS_UP;
   // h = 1024 (KB = 16): one product's weight fragments fill the registers -- the gradient for the layer below is a batched GEMM behind
   // the launch there (hoisted form), and the code of the down product is compiled out
   constexpr bool CAN_DOWN = KB <= 8;
   const bool has_down = CAN_DOWN && c.PD != nullptr;
-  unsigned* ctrA = a.done + (cell * nbt + bt) * CTR_STRIDE;
-  unsigned* ctrB = a.done + ((a.ncells + cell) * nbt + bt) * CTR_STRIDE;
-  const unsigned* upB = has_up ? a.done + ((a.ncells + cell + 1) * nbt + bt) * CTR_STRIDE : nullptr;
-  const int m0 = bt * 16;
+  unsigned* ctrA = a.done + (cell * nby + by) * CTR_STRIDE;
+  unsigned* ctrB = a.done + ((a.ncells + cell) * nby + by) * CTR_STRIDE;
+  const unsigned* upB = has_up ? a.done + ((a.ncells + cell + 1) * nby + by) * CTR_STRIDE : nullptr;
+  const int m0 = by * 16 * MT;
+  (void)HH;
 
   // resident weight fragments: product tile tl = wave*KB + nt covers output units 16 tl .. 16 tl + 15; K = this slice's 64 gate columns
   // (read straight from the (4h, h) parameters: four 4-byte loads per fragment quad, 16 consecutive lanes on 64 consecutive bytes, once per
@@ -657,16 +757,27 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
   const __amdgpu_buffer_rsrc_t r_pr = make_rsrc(c.PR);
   const __amdgpu_buffer_rsrc_t r_pd = make_rsrc(has_down ? c.PD : c.PR);
   const __amdgpu_buffer_rsrc_t r_pu = make_rsrc(has_up ? c.PD_up : c.PR);
+  const __amdgpu_buffer_rsrc_t r_dz = make_rsrc(c.gates_dz);
   const int u = tid >> 4, r = tid & 15;                   // epilogue ownership: (unit, row)
-  const int eu = j0 + u, eb = m0 + r;
-  const bool evalid = eb < B;
-  const long ebc = evalid ? eb : B - 1;
-  float dc_state = 0.f, dhadd = 0.f, dzmax = 0.f;
+  const int eu = j0 + u;
+  int eb[MT];
+  bool evalid[MT];
+  long ebc[MT];
+  float dc_state[MT], dhadd[MT];
+  float4 dbacc[MT];
+  float dzmax = 0.f;
   // bias gradient = column sums of dz over all steps and rows: this thread's (row, unit) element of every step summed in registers, the
   // 16 rows and the batch tiles at the end -- the separate pass over the six cells' dz (157 MB, 32 us per train step) is gone
-  float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c.d_cT) dc_state = c.d_cT[ebc * h + eu];
-  if (c.d_hT) dhadd = c.d_hT[ebc * h + eu];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    eb[mt] = m0 + 16 * mt + r;
+    evalid[mt] = eb[mt] < B;
+    ebc[mt] = evalid[mt] ? eb[mt] : B - 1;
+    dc_state[mt] = 0.f; dhadd[mt] = 0.f;
+    dbacc[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c.d_cT) dc_state[mt] = c.d_cT[ebc[mt] * h + eu];
+    if (c.d_hT) dhadd[mt] = c.d_hT[ebc[mt] * h + eu];
+  }
   const int tile_bytes = 256 * 4;                          // one 16x16 partial tile
   const long cons_stride = (long)NS * tile_bytes;          // bytes between consumers
   // Partials of the layer above: at rest in HBM when they are wanted (that layer runs ahead), i.e. a full memory latency (2.1-2.6 us in
@@ -679,7 +790,7 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
 #define ASTK_BWD_UP_PREFETCH 1
 #endif
   constexpr bool UP_PREFETCH = ASTK_BWD_UP_PREFETCH && SENT && HAS_UP && KB <= 4;      // (32 more live registers do not fit the h = 512 kernel)
-  float pu[NS];
+  float pu[MT][NS];
   bool alive = true;
   if (UP_PREFETCH) {
     if (!c.up_external) {
@@ -688,42 +799,55 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
       alive = s_ok1[0] != 0;
       __syncthreads();
     }
-    const int base = (int)((((long)(T - 1) * nbt + bt) * NS + j) * cons_stride) + tid * 4;
 #pragma unroll
-    for (int p = 0; p < NS; ++p) pu[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pu, base + p * tile_bytes, 0, 16));
+    for (int mt = 0; mt < MT; ++mt) {
+      const int base = (int)((((long)(T - 1) * nbt + by * MT + mt) * NS + j) * cons_stride) + tid * 4;
+#pragma unroll
+      for (int p = 0; p < NS; ++p) pu[mt][p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pu, base + p * tile_bytes, 0, 16));
+    }
   }
   bool pending_b = false;
+  bool pending_prog = false;     // layer 0 with side-stream consumers: a chunk's arrival on the progress counter is due at the next drain point
   bool dead = false;      // this wave gave up waiting (abort / time-out): it runs the remaining steps without waiting, so that barriers still match
-  f32x4 acc2[CAN_DOWN ? KB : 1];
+  f32x4 acc2[MT][CAN_DOWN ? KB : 1];
 #pragma unroll
-  for (int nt = 0; nt < (CAN_DOWN ? KB : 1); ++nt) acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < (CAN_DOWN ? KB : 1); ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto store_down = [&](int ts) {
 #pragma unroll
-    for (int nt = 0; nt < (CAN_DOWN ? KB : 0); ++nt) {
-      const int tl = wave * KB + nt;
-      u32x4 o;
-      o.x = __float_as_uint(acc2[nt][0]); o.y = __float_as_uint(acc2[nt][1]); o.z = __float_as_uint(acc2[nt][2]); o.w = __float_as_uint(acc2[nt][3]);
-      __builtin_amdgcn_raw_buffer_store_b128(o, r_pd, (int)((((long)ts * nbt + bt) * NS + tl) * cons_stride) + j * tile_bytes + (r16 * 16 + 4 * q) * 4, 0, 16);
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < (CAN_DOWN ? KB : 0); ++nt) {
+        const int tl = wave * KB + nt;
+        u32x4 o;
+        o.x = __float_as_uint(acc2[mt][nt][0]); o.y = __float_as_uint(acc2[mt][nt][1]); o.z = __float_as_uint(acc2[mt][nt][2]); o.w = __float_as_uint(acc2[mt][nt][3]);
+        __builtin_amdgcn_raw_buffer_store_b128(o, r_pd, (int)((((long)ts * nbt + by * MT + mt) * NS + tl) * cons_stride) + j * tile_bytes + (r16 * 16 + 4 * q) * 4, 0, 16);
+      }
   };
 
   // Saved forward state and the incoming gradient of a step: from earlier launches, i.e. fetchable at any time.  Fetched ONE STEP EARLY,
   // right behind the step's barrier: at the top of a step the wave's memory queue is still full of the previous step's write-through
   // stores (partials, sentinel resets, dz), and loads issued there -- and the sweep behind them -- wait for the queue, not for data.
-  float4 in_g = make_float4(0.f, 0.f, 0.f, 0.f);
-  float in_cc = 0.f, in_cp = 0.f, in_mk = 1.f, in_dye = 0.f;
+  float4 in_g[MT];
+  float in_cc[MT], in_cp[MT], in_mk[MT], in_dye[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) { in_g[mt] = make_float4(0.f, 0.f, 0.f, 0.f); in_cc[mt] = 0.f; in_cp[mt] = 0.f; in_mk[mt] = 1.f; in_dye[mt] = 0.f; }
   auto fetch_inputs = [&](const int ts) {          // ts >= 0 (callers clamp)
-    const long tbs = (long)ts * B + ebc;
-    in_g = *reinterpret_cast<const float4*>(c.gates_dz + tbs * K + 4 * eu);
-    in_cc = c.C[tbs * h + eu];
-    in_cp = c.C[max(tbs - B, 0L) * h + eu];
-    // (unconditional loads through a selected pointer: a load under `if (c.d_enc)` is a phi of "old value / load result", which hipcc
-    //  resolves by waiting for the load where it is issued -- a full memory latency per step, 1.75 us in the top layer's timers)
-    const float* const mp = c.mask ? c.mask + tbs * h + eu : c.C + tbs * h + eu;
-    const float* const dp = c.d_enc ? c.d_enc + ebc * c.dy_sb + (c.reverse_pos ? T - 1 - ts : ts) * c.dy_st + eu : c.C + tbs * h + eu;
-    const float mv = *mp, dv = *dp;
-    in_mk = c.mask ? mv : 1.f;
-    in_dye = c.d_enc ? dv : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const long tbs = (long)ts * B + ebc[mt];
+      in_g[mt] = *reinterpret_cast<const float4*>(c.gates_dz + tbs * K + 4 * eu);
+      in_cc[mt] = c.C[tbs * h + eu];
+      in_cp[mt] = c.C[max(tbs - B, 0L) * h + eu];
+      // (unconditional loads through a selected pointer: a load under `if (c.d_enc)` is a phi of "old value / load result", which hipcc
+      //  resolves by waiting for the load where it is issued -- a full memory latency per step, 1.75 us in the top layer's timers)
+      const float* const mp = c.mask ? c.mask + tbs * h + eu : c.C + tbs * h + eu;
+      const float* const dp = c.d_enc ? c.d_enc + ebc[mt] * c.dy_sb + (c.reverse_pos ? T - 1 - ts : ts) * c.dy_st + eu : c.C + tbs * h + eu;
+      const float mv = *mp, dv = *dp;
+      in_mk[mt] = c.mask ? mv : 1.f;
+      in_dye[mt] = c.d_enc ? dv : 0.f;
+    }
   };
   if (alive && T > 0) fetch_inputs(T - 1);
   long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -733,11 +857,14 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     long long t0 = timing ? wall_clock64() : 0;
     const int stepno = T - 1 - t;
     float* const dzT = dzS2[stepno & 1];
-    const long tb = (long)t * B + ebc;
     // inputs from earlier launches (fetched a step ago, see fetch_inputs)
-    const float4 g = in_g;
-    const float ccur = in_cc, cp = t > 0 ? in_cp : 0.f, mk = in_mk, dye = in_dye;
-    float v1 = 0.f;
+    float4 g[MT];
+    float ccur[MT], cp[MT], mk[MT], dye[MT], v1[MT], v0[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      g[mt] = in_g[mt]; ccur[mt] = in_cc[mt]; cp[mt] = t > 0 ? in_cp[mt] : 0.f; mk[mt] = in_mk[mt]; dye[mt] = in_dye[mt];
+      v1[mt] = 0.f; v0[mt] = 0.f;
+    }
     unsigned up_seen = 0;
     if (has_up) {                            // partials handed down by the layer above (it runs ahead)
       if (!UP_PREFETCH) {
@@ -746,54 +873,61 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
           __syncthreads();
           if (!s_ok1[0]) break;
         }
-        const int base = (int)((((long)t * nbt + bt) * NS + j) * cons_stride) + tid * 4;
 #pragma unroll
-        for (int p = 0; p < NS; ++p) pu[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pu, base + p * tile_bytes, 0, 16));
+        for (int mt = 0; mt < MT; ++mt) {
+          const int base = (int)((((long)t * nbt + by * MT + mt) * NS + j) * cons_stride) + tid * 4;
+#pragma unroll
+          for (int p = 0; p < NS; ++p) pu[mt][p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pu, base + p * tile_bytes, 0, 16));
+        }
       }
 #pragma unroll
-      for (int p = 0; p < NS; ++p) v1 += pu[p];
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) v1[mt] += pu[mt][p];
       if (UP_PREFETCH && !c.up_external && tid == 0) up_seen = ld_flag(upB);
     }
     TICK(0, t0)
-    float v0 = 0.f;
-    int reset_base = -1;
+    int reset_base[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) reset_base[mt] = -1;
     if (stepno > 0) {                        // partial dh_rec tiles of this cell's step t+1
       const int slot = (t + 1) % PR_RING;
-      const int base = (int)((((long)slot * nbt + bt) * NS + j) * cons_stride) + tid * 4;
+      int base[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) base[mt] = (int)((((long)slot * nbt + by * MT + mt) * NS + j) * cons_stride) + tid * 4;
       if constexpr (SENT) {
-      unsigned pw[NS];
+      unsigned pw[MT][NS];
+      auto sweep = [&]() {
+        unsigned mx = 0;      // (the sentinel is the largest unsigned word: a running maximum and one compare, not a branch per word)
 #pragma unroll
-      for (int p = 0; p < NS; ++p) pw[p] = __builtin_amdgcn_raw_buffer_load_b32(r_pr, base + p * tile_bytes, 0, 16);
-      unsigned mx = 0;      // (the sentinel is the largest unsigned word: a running maximum and one compare, not a branch per word)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int p = 0; p < NS; ++p) mx = max(mx, pw[p]);
-      if (!__all(mx != SENTINEL)) {
+          for (int p = 0; p < NS; ++p) pw[mt][p] = __builtin_amdgcn_raw_buffer_load_b32(r_pr, base[mt] + p * tile_bytes, 0, 16);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int p = 0; p < NS; ++p) mx = max(mx, pw[mt][p]);
+        return __all(mx != SENTINEL);
+      };
+      if (!sweep()) {
         // slow path: poll ONE word per lane (its first missing one) until the wave has them all, then re-read everything; bounded
         unsigned spins = 0;
         while (!dead) {
 #if ASTK_FRAG_WAIT_SWEEP
           if (spins < ASTK_FRAG_WAIT_SWEEP) {      // the first retries are whole sweeps (see frag_wait)
-#pragma unroll
-            for (int p = 0; p < NS; ++p) pw[p] = __builtin_amdgcn_raw_buffer_load_b32(r_pr, base + p * tile_bytes, 0, 16);
-            mx = 0;
-#pragma unroll
-            for (int p = 0; p < NS; ++p) mx = max(mx, pw[p]);
-            if (__all(mx != SENTINEL)) break;
+            if (sweep()) break;
             ++spins;
             continue;
           }
 #endif
-          int moff = base;
+          int moff = base[0];
 #pragma unroll
-          for (int p = NS - 1; p >= 0; --p) moff = pw[p] == SENTINEL ? base + p * tile_bytes : moff;
+          for (int mt = MT - 1; mt >= 0; --mt)
+#pragma unroll
+            for (int p = NS - 1; p >= 0; --p) moff = pw[mt][p] == SENTINEL ? base[mt] + p * tile_bytes : moff;
           const unsigned cw = __builtin_amdgcn_raw_buffer_load_b32(r_pr, moff, 0, 16);
           if (__all(cw != SENTINEL)) {
-#pragma unroll
-            for (int p = 0; p < NS; ++p) pw[p] = __builtin_amdgcn_raw_buffer_load_b32(r_pr, base + p * tile_bytes, 0, 16);
-            mx = 0;
-#pragma unroll
-            for (int p = 0; p < NS; ++p) mx = max(mx, pw[p]);
-            if (__all(mx != SENTINEL)) break;
+            if (sweep()) break;
           }
           if (++spins > (ab.limit >> 1)) { abort_raise(ab); dead = true; }
           else if ((spins & 63u) == 0 && abort_seen(ab)) dead = true;
@@ -801,18 +935,24 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
       }
       TICK(1, t0)
 #pragma unroll
-      for (int p = 0; p < NS; ++p) v0 += __uint_as_float(pw[p]);
-      reset_base = base - tid * 4;      // (the slot's words go back to the sentinel behind this step's barrier and product-1 stores)
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int p = 0; p < NS; ++p) v0[mt] += __uint_as_float(pw[mt][p]);
+        reset_base[mt] = base[mt] - tid * 4;      // (the slot's words go back to the sentinel behind this step's barrier and product-1 stores)
+      }
       } else {
       if (tid == 0) s_ok2 = wait_ge(ctrA, (unsigned)(NS * stepno), ab) ? 1 : 0;
       __syncthreads();
       if (!s_ok2) break;
       TICK(1, t0)
-      float pv[NS];
 #pragma unroll
-      for (int p = 0; p < NS; ++p) pv[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pr, base + p * tile_bytes, 0, 16));
+      for (int mt = 0; mt < MT; ++mt) {
+        float pv[NS];
 #pragma unroll
-      for (int p = 0; p < NS; ++p) v0 += pv[p];
+        for (int p = 0; p < NS; ++p) pv[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pr, base[mt] + p * tile_bytes, 0, 16));
+#pragma unroll
+        for (int p = 0; p < NS; ++p) v0[mt] += pv[p];
+      }
       }
     }
     TICK(2, t0)
@@ -824,15 +964,17 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
 #else
     if constexpr (!SENT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-    float4 dz;
-    {
-      const float dh = v0 + (v1 + dye) * mk + (stepno == 0 ? dhadd : 0.f);
-      const float tc = tanh_fast(ccur);   // the same function the forward kernel used for tanh(c)
-      const float dcv = dh * g.w * (1.f - tc * tc) + dc_state;
-      dz = make_float4(dcv * g.y * (1.f - g.x * g.x), dcv * g.x * g.y * (1.f - g.y), dcv * cp * g.z * (1.f - g.z), dh * tc * g.w * (1.f - g.w));
-      dc_state = dcv * g.z;
-      *reinterpret_cast<float4*>(&dzT[r * DZ_LD + 4 * u]) = dz;
-      dzmax = fmaxf(fmaxf(dzmax, fmaxf(fabsf(dz.x), fabsf(dz.y))), fmaxf(fabsf(dz.z), fabsf(dz.w)));   // (rows past B repeat row B-1)
+    float4 dz[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const float dh = v0[mt] + (v1[mt] + dye[mt]) * mk[mt] + (stepno == 0 ? dhadd[mt] : 0.f);
+      const float tc = tanh_fast(ccur[mt]);   // the same function the forward kernel used for tanh(c)
+      const float dcv = dh * g[mt].w * (1.f - tc * tc) + dc_state[mt];
+      dz[mt] = make_float4(dcv * g[mt].y * (1.f - g[mt].x * g[mt].x), dcv * g[mt].x * g[mt].y * (1.f - g[mt].y), dcv * cp[mt] * g[mt].z * (1.f - g[mt].z),
+                           dh * tc * g[mt].w * (1.f - g[mt].w));
+      dc_state[mt] = dcv * g[mt].z;
+      *reinterpret_cast<float4*>(&dzT[mt * 16 * DZ_LD + r * DZ_LD + 4 * u]) = dz[mt];
+      dzmax = fmaxf(fmaxf(dzmax, fmaxf(fabsf(dz[mt].x), fabsf(dz[mt].y))), fmaxf(fabsf(dz[mt].z), fabsf(dz[mt].w)));   // (rows past B repeat row B-1)
     }
     TICK(3, t0)
     if (UP_PREFETCH && !c.up_external && tid == 0) {
@@ -841,55 +983,81 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     }
     __syncthreads();
     if (pending_b && tid == 0) __hip_atomic_fetch_add(ctrB, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // down-partials of step t+1
+    if (pending_prog) {          // (uniform) dz of the chunk that ended with step t+1: written through a step ago, drained by this step's partial loads
+      if (tid == 0) __hip_atomic_fetch_add(c.prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pending_prog = false;
+    }
     if (UP_PREFETCH) {
       if (!c.up_external && !s_ok1[stepno & 1]) break;
-      const int base = (int)((((long)max(t - 1, 0) * nbt + bt) * NS + j) * cons_stride) + tid * 4;      // (the last step fetches its own again)
 #pragma unroll
-      for (int p = 0; p < NS; ++p) pu[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pu, base + p * tile_bytes, 0, 16));
+      for (int mt = 0; mt < MT; ++mt) {
+        const int base = (int)((((long)max(t - 1, 0) * nbt + by * MT + mt) * NS + j) * cons_stride) + tid * 4;      // (the last step fetches its own again)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) pu[mt][p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pu, base + p * tile_bytes, 0, 16));
+      }
     }
     fetch_inputs(max(t - 1, 0));
-    float4 af[4];
+    float4 af[MT][4];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) af[s4] = *reinterpret_cast<const float4*>(&dzT[r16 * DZ_LD + 16 * s4 + 4 * q]);
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) af[mt][s4] = *reinterpret_cast<const float4*>(&dzT[mt * 16 * DZ_LD + r16 * DZ_LD + 16 * s4 + 4 * q]);
     // X2: dz is unbounded: its scale is taken from this step's tile (every wave holds the whole 16 x 64 tile across its lanes)
-    float pscale = 1.f;       // 1 / (weight scale x dz scale), applied to the partial sums
-    Frag afh[2];
-    if constexpr (XS == 2) {
-      const float m = wave_max_nonneg(amax4f(amax4f(amax4f(amax4f(0.f, af[0]), af[1]), af[2]), af[3]));
-      float ainv;
-      const float ascl = pow2_scale_for(m, ainv);
-      pscale = ainv * winv;
-      afh[0] = split8(af[0], af[1], ascl);
-      afh[1] = split8(af[2], af[3], ascl);
-    } else if constexpr (XS == 3 || XS == 4) {      // bf16 has f32's exponent range: no scale, however small or large dz is
-      afh[0] = split8b(af[0], af[1]);
-      afh[1] = split8b(af[2], af[3]);
+    float pscale[MT];       // 1 / (weight scale x dz scale), applied to the partial sums
+    Frag afh[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      pscale[mt] = 1.f;
+      if constexpr (XS == 2) {
+        const float m = wave_max_nonneg(amax4f(amax4f(amax4f(amax4f(0.f, af[mt][0]), af[mt][1]), af[mt][2]), af[mt][3]));
+        float ainv;
+        const float ascl = pow2_scale_for(m, ainv);
+        pscale[mt] = ainv * winv;
+        afh[mt][0] = split8(af[mt][0], af[mt][1], ascl);
+        afh[mt][1] = split8(af[mt][2], af[mt][3], ascl);
+      } else if constexpr (XS == 3 || XS == 4) {      // bf16 has f32's exponent range: no scale, however small or large dz is
+        afh[mt][0] = split8b(af[mt][0], af[mt][1]);
+        afh[mt][1] = split8b(af[mt][2], af[mt][3]);
+      }
     }
     // ---- product 1: partial dh_rec for every slice of this cell -> write-through stores
     {
       const int slot = t % PR_RING;
 #pragma unroll
       for (int nt = 0; nt < KB; ++nt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (XS == 2) {
-          MFMA32H(acc, afh[0], wlh[nt][0])
-          MFMA32H(acc, afh[1], wlh[nt][1])
-          acc *= pscale;
-        } else if constexpr (XS == 4) {
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (XS == 4) {
           const u32q l0 = lo_l[(nt * 2) * 256], l1 = lo_l[(nt * 2 + 1) * 256];
-          MFMA32B4(acc, afh[0], wlh[nt][0], l0)
-          MFMA32B4(acc, afh[1], wlh[nt][1], l1)
-        } else if constexpr (XS == 3) {
-          MFMA32B(acc, afh[0], wlh[nt][0])
-          MFMA32B(acc, afh[1], wlh[nt][1])
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            MFMA32B4(acc[mt], afh[mt][0], wlh[nt][0], l0)
+            MFMA32B4(acc[mt], afh[mt][1], wlh[nt][1], l1)
+          }
         } else {
 #pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc, af[s4], wl[nt][s4]) }
+          for (int mt = 0; mt < MT; ++mt) {
+            if constexpr (XS == 2) {
+              MFMA32H(acc[mt], afh[mt][0], wlh[nt][0])
+              MFMA32H(acc[mt], afh[mt][1], wlh[nt][1])
+              acc[mt] *= pscale[mt];
+            } else if constexpr (XS == 3) {
+              MFMA32B(acc[mt], afh[mt][0], wlh[nt][0])
+              MFMA32B(acc[mt], afh[mt][1], wlh[nt][1])
+            } else {
+#pragma unroll
+              for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc[mt], af[mt][s4], wl[nt][s4]) }
+            }
+          }
         }
         const int tl = wave * KB + nt;
-        u32x4 o;
-        o.x = __float_as_uint(acc[0]); o.y = __float_as_uint(acc[1]); o.z = __float_as_uint(acc[2]); o.w = __float_as_uint(acc[3]);
-        __builtin_amdgcn_raw_buffer_store_b128(o, r_pr, (int)((((long)slot * nbt + bt) * NS + tl) * cons_stride) + j * tile_bytes + (r16 * 16 + 4 * q) * 4, 0, 16);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          u32x4 o;
+          o.x = __float_as_uint(acc[mt][0]); o.y = __float_as_uint(acc[mt][1]); o.z = __float_as_uint(acc[mt][2]); o.w = __float_as_uint(acc[mt][3]);
+          __builtin_amdgcn_raw_buffer_store_b128(o, r_pr, (int)((((long)slot * nbt + by * MT + mt) * NS + tl) * cons_stride) + j * tile_bytes + (r16 * 16 + 4 * q) * 4, 0, 16);
+        }
       }
     }
     // (ASTK_PERSIST_DBG & 16, the regression test of the last-arrival rule on counter B: slice 0 of every cell with a layer below dawdles for
@@ -903,60 +1071,72 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     // behind the publish, with or without holding its stores back: 0.3-0.4 us per step slower -- the peers see counter A only
     // ~2 us after the atomic either way, so hiding the 0.5 us drain is what pays.)
     constexpr int KB1 = (KB + 1) / 2;     // first half of product 2 hides the drain, second half runs behind the publish
-    if constexpr (CAN_DOWN) if (has_down) {
-#pragma unroll
-      for (int nt = 0; nt < KB1; ++nt) {
-        acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (XS == 2) {
-          MFMA32H(acc2[nt], afh[0], wdh[nt][0])
-          MFMA32H(acc2[nt], afh[1], wdh[nt][1])
-          acc2[nt] *= pscale;
-        } else if constexpr (XS == 4) {
+    auto product2 = [&](const int nt) {
+      if constexpr (CAN_DOWN) {
+        if constexpr (XS == 4) {
           const u32q l0 = lo_d[(nt * 2) * 256], l1 = lo_d[(nt * 2 + 1) * 256];
-          MFMA32B4(acc2[nt], afh[0], wdh[nt][0], l0)
-          MFMA32B4(acc2[nt], afh[1], wdh[nt][1], l1)
-        } else if constexpr (XS == 3) {
-          MFMA32B(acc2[nt], afh[0], wdh[nt][0])
-          MFMA32B(acc2[nt], afh[1], wdh[nt][1])
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            MFMA32B4(acc2[mt][nt], afh[mt][0], wdh[nt][0], l0)
+            MFMA32B4(acc2[mt][nt], afh[mt][1], wdh[nt][1], l1)
+          }
         } else {
 #pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc2[nt], af[s4], wd[nt][s4]) }
+          for (int mt = 0; mt < MT; ++mt) {
+            acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (XS == 2) {
+              MFMA32H(acc2[mt][nt], afh[mt][0], wdh[nt][0])
+              MFMA32H(acc2[mt][nt], afh[mt][1], wdh[nt][1])
+              acc2[mt][nt] *= pscale[mt];
+            } else if constexpr (XS == 3) {
+              MFMA32B(acc2[mt][nt], afh[mt][0], wdh[nt][0])
+              MFMA32B(acc2[mt][nt], afh[mt][1], wdh[nt][1])
+            } else {
+#pragma unroll
+              for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc2[mt][nt], af[mt][s4], wd[nt][s4]) }
+            }
+          }
         }
       }
+    };
+    if constexpr (CAN_DOWN) if (has_down) {
+#pragma unroll
+      for (int nt = 0; nt < KB1; ++nt) product2(nt);
     }
     TICK(4, t0)
     if constexpr (SENT) {
-    if (reset_base >= 0) {   // behind the step's barrier every reader of the slot just consumed is done with it: the sentinel goes back (16 KB in a row)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+    if (reset_base[mt] >= 0) {   // behind the step's barrier every reader of the slot just consumed is done with it: the sentinel goes back (16 KB in a row)
       const u32x4 sent = {SENTINEL, SENTINEL, SENTINEL, SENTINEL};
 #pragma unroll
-      for (int i = 0; i < NS / 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(sent, r_pr, reset_base + (i * 256 + tid) * 16, 0, 16);
+      for (int i = 0; i < NS / 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(sent, r_pr, reset_base[mt] + (i * 256 + tid) * 16, 0, 16);
     }
     } else {
       publish(ctrA);      // drain (product-1 stores only), barrier, one arrival
     }
     TICK(5, t0)
-    if (evalid) *reinterpret_cast<float4*>(c.gates_dz + tb * K + 4 * eu) = dz;   // for the batched products after the launch
-    dbacc.x += dz.x; dbacc.y += dz.y; dbacc.z += dz.z; dbacc.w += dz.w;
-    if constexpr (CAN_DOWN) if (has_down) {
+    // dz for the batched products: behind the launch (plain stores), or -- layer 0 with side-stream consumers -- beside it, chunk by chunk:
+    // written through (sc1), the chunk's arrival on the progress counter follows at the next step's drain point
 #pragma unroll
-      for (int nt = KB1; nt < KB; ++nt) {
-        acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (XS == 2) {
-          MFMA32H(acc2[nt], afh[0], wdh[nt][0])
-          MFMA32H(acc2[nt], afh[1], wdh[nt][1])
-          acc2[nt] *= pscale;
-        } else if constexpr (XS == 4) {
-          const u32q l0 = lo_d[(nt * 2) * 256], l1 = lo_d[(nt * 2 + 1) * 256];
-          MFMA32B4(acc2[nt], afh[0], wdh[nt][0], l0)
-          MFMA32B4(acc2[nt], afh[1], wdh[nt][1], l1)
-        } else if constexpr (XS == 3) {
-          MFMA32B(acc2[nt], afh[0], wdh[nt][0])
-          MFMA32B(acc2[nt], afh[1], wdh[nt][1])
+    for (int mt = 0; mt < MT; ++mt) {
+      if (evalid[mt]) {
+        const long tb = (long)t * B + eb[mt];
+        if (c.prog) {
+          u32x4 o;
+          o.x = __float_as_uint(dz[mt].x); o.y = __float_as_uint(dz[mt].y); o.z = __float_as_uint(dz[mt].z); o.w = __float_as_uint(dz[mt].w);
+          __builtin_amdgcn_raw_buffer_store_b128(o, r_dz, (int)((tb * K + 4 * eu) * 4), 0, 16);
         } else {
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) { MFMA4(acc2[nt], af[s4], wd[nt][s4]) }
+          *reinterpret_cast<float4*>(c.gates_dz + tb * K + 4 * eu) = dz[mt];
         }
       }
+      dbacc[mt].x += dz[mt].x; dbacc[mt].y += dz[mt].y; dbacc[mt].z += dz[mt].z; dbacc[mt].w += dz[mt].w;
+    }
+    if (c.prog && (stepno + 1) % c.prog_cs == 0 && t > 0) pending_prog = true;
+    if constexpr (CAN_DOWN) if (has_down) {
+#pragma unroll
+      for (int nt = KB1; nt < KB; ++nt) product2(nt);
       store_down(t);
       pending_b = true;
     }
@@ -978,20 +1158,34 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     }
     publish(ctrB);
   }
+  if (c.prog) {
+    // the last chunk (and a pending one): every storing wave drains, the workgroup barriers, one lane arrives.  The consumer (a wait kernel
+    // on the side stream) wants `chunks x workgroups of the cell` arrivals for the chunk that ends with step 0: one arrival per workgroup and
+    // chunk, pending or not, so the total is always ceil(T / prog_cs) per workgroup
+    publish(c.prog);
+  }
   if (c.db) {
-    if (!evalid) dbacc = make_float4(0.f, 0.f, 0.f, 0.f);        // (rows past B repeat row B - 1)
+    float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      if (evalid[mt]) { dbs.x += dbacc[mt].x; dbs.y += dbacc[mt].y; dbs.z += dbacc[mt].z; dbs.w += dbacc[mt].w; }        // (rows past B repeat row B - 1)
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) {        // the 16 rows of a unit are 16 consecutive lanes
-      dbacc.x += __shfl_xor(dbacc.x, o); dbacc.y += __shfl_xor(dbacc.y, o);
-      dbacc.z += __shfl_xor(dbacc.z, o); dbacc.w += __shfl_xor(dbacc.w, o);
+      dbs.x += __shfl_xor(dbs.x, o); dbs.y += __shfl_xor(dbs.y, o);
+      dbs.z += __shfl_xor(dbs.z, o); dbs.w += __shfl_xor(dbs.w, o);
     }
-    // One float atomic per column and batch tile into the gradient arena.  With at most TWO contributions per element into a zeroed
-    // buffer (B <= 32) the sum does not depend on their order: bit-reproducible, which the last-arrival regression test relies on.  With
-    // three or more batch tiles (B > 32), or gradients accumulated over several calls, the order of the adds varies from run to run and
-    // the bias gradients are reproducible only to float rounding (like every split tile of the batched products).
+    // One float atomic per column and workgroup row into the gradient arena.  With at most TWO contributions per element into a zeroed
+    // buffer (B <= 32 with 16-row tiles, B <= 64 with 32-row tiles) the sum does not depend on their order: bit-reproducible, which the
+    // last-arrival regression test relies on.  With more workgroup rows, or gradients accumulated over several calls, the order of the adds
+    // varies from run to run and the bias gradients are reproducible only to float rounding (like every split tile of the batched
+    // products) -- unless the call is `deterministic` (db_part below).
     if (r == 0) {
-      atomicAdd(c.db + 4 * eu, dbacc.x); atomicAdd(c.db + 4 * eu + 1, dbacc.y);
-      atomicAdd(c.db + 4 * eu + 2, dbacc.z); atomicAdd(c.db + 4 * eu + 3, dbacc.w);
+      if (c.db_part) {      // deterministic: this workgroup row's sums to a scratch row; the host-side fold adds the rows in order
+        *reinterpret_cast<float4*>(c.db_part + (long)by * 4 * h + 4 * eu) = dbs;
+      } else {
+        atomicAdd(c.db + 4 * eu, dbs.x); atomicAdd(c.db + 4 * eu + 1, dbs.y);
+        atomicAdd(c.db + 4 * eu + 2, dbs.z); atomicAdd(c.db + 4 * eu + 3, dbs.w);
+      }
     }
   }
   if (c.amax) {
@@ -1013,16 +1207,16 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
 #undef TICK
 }
 
-template <int KB, int XS>
+template <int KB, int XS, int MT>
 __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_rs(PBwdArgs a) {
   // (two copies of the dz tile, used alternately: with the sentinel hand-off the step's ONE barrier sits between a tile's writes and its
   //  reads, and only the copy keeps a wave that is a step ahead from writing into what a slower wave still reads; the flags likewise)
-  __shared__ __attribute__((aligned(16))) float dzS2[2][16 * DZ_LD];
+  __shared__ __attribute__((aligned(16))) float dzS2[2][MT * 16 * DZ_LD];
   __shared__ int s_ok1[2], s_ok2;
   __shared__ __attribute__((aligned(16))) u32q lo_lds[XS == 4 ? LO_LDS_FRAGS * 256 : 1];
   const PCellB c = a.c[blockIdx.z];      // a copy (see lstm_persist_fwd_g)
-  if (c.PD_up != nullptr) lstm_bwd_rs_steps<KB, true, XS>(a, c, dzS2, s_ok1, s_ok2, lo_lds);
-  else lstm_bwd_rs_steps<KB, false, XS>(a, c, dzS2, s_ok1, s_ok2, lo_lds);
+  if (c.PD_up != nullptr) lstm_bwd_rs_steps<KB, true, XS, MT>(a, c, dzS2, s_ok1, s_ok2, lo_lds);
+  else lstm_bwd_rs_steps<KB, false, XS, MT>(a, c, dzS2, s_ok1, s_ok2, lo_lds);
 }
 
 }  // namespace
@@ -1039,6 +1233,9 @@ struct PersistCellHost {
   unsigned long long* amax;       // backward: where max |dz| of the cell goes (16 sharded words, gemm_amax_reserve), null: not wanted
   float* db;                      // backward: bias gradient accumulated by the recurrence kernel itself (null: not wanted)
   long dy_sb, dy_st;              // backward: strides of d_enc (see PCellB)
+  const unsigned* zx_flags; int zx_s0, zx_cs;      // forward, layer 0: chunk flags of the input projection (see PCellF)
+  unsigned* prog; int prog_cs;                     // backward, layer 0: progress counter for side-stream consumers of dz (see PCellB)
+  float* db_part;                                  // backward: deterministic bias-gradient scratch (see PCellB)
 };
 
 // Layers per launch.  One workgroup per CU must hold a launch's whole grid; a stack with more (direction, layer) cells than fit is
@@ -1046,8 +1243,23 @@ struct PersistCellHost {
 // groups is lost, everything else stays (BASELINE configs[4]: 6 layers x 2 directions x 32 unit slices x 2 batch tiles = 768
 // workgroups -> 3 launches of 2 layers; batch 64 at the shipped width: 2 launches).  0 = not applicable.
 bool lstm_persist_hoisted(int h);
-int lstm_persist_layers_per_launch(int B, int h, int nl, int nd) {
-  const long per_layer = (long)(h / 16) * ((B + 15) / 16) * nd;
+// Batch rows per workgroup: 16, or 32 (two 16-row tiles against one set of resident weight fragments; h <= 256, where both tiles' fragments
+// fit the registers).  32-row workgroups halve the grid -- batch 64 at the shipped width and the 6-layer stacks run in half the launches,
+// and at batch 32 the stack leaves 160 CUs free instead of 64 -- at ~15 % more time per step (two tiles' MFMAs and epilogues per hand-off).
+// Tuning knob lstm.rows32: 1 = whenever possible, 0 = never, -1 (default) = when it spares launches, or when the caller runs side-stream work
+// beside the recurrences (`side`), which is what the freed CUs are for.
+int lstm_persist_rows(int B, int h, int nl, int nd, bool side) {
+  const int knob = (int)tune(TUNE_LSTM_ROWS32);
+  if (knob == 0 || h > 256 || B <= 16) return 16;
+  if (knob > 0) return 32;
+  const long cus = device_cu_count();
+  const long wg16 = (long)(h / 16) * ((B + 15) / 16) * nd * nl, wg32 = (long)(h / 16) * ((B + 31) / 32) * nd * nl;
+  const long launches16 = (wg16 + cus - 1) / cus, launches32 = (wg32 + cus - 1) / cus;
+  if (launches32 < launches16) return 32;
+  return side ? 32 : 16;
+}
+int lstm_persist_layers_per_launch(int B, int h, int nl, int nd, int rows) {
+  const long per_layer = (long)(h / 16) * ((B + rows - 1) / rows) * nd;
   const long cus = device_cu_count();
   if (per_layer < 1 || per_layer > cus) return 0;
   long lpl = cus / per_layer;
@@ -1058,7 +1270,7 @@ int lstm_persist_layers_per_launch(int B, int h, int nl, int nd) {
 }
 
 // workgroups of one launch over `layers` layers of all directions
-int lstm_persist_grid_wgs(int B, int h, int layers, int nd) { return (h / 16) * ((B + 15) / 16) * nd * layers; }
+int lstm_persist_grid_wgs(int B, int h, int layers, int nd, int rows) { return (h / 16) * ((B + rows - 1) / rows) * nd * layers; }
 
 // Hoisted form (h = 1024): the weight fragments of one product fill a workgroup's registers, so every layer runs as a launch of its
 // own over cells that get their input projection from a batched GEMM in front of it (forward) and leave the gradient for the layer below
@@ -1071,23 +1283,25 @@ bool lstm_persist_applicable(int T, int B, int h, int nl, int nd) {
   if (lstm_persist_hoisted(h)) {
     if (!tune_on(TUNE_LSTM_HOIST)) return false;
   }
-  if (lstm_persist_layers_per_launch(B, h, nl, nd) < 1) return false;
+  if (lstm_persist_layers_per_launch(B, h, nl, nd, lstm_persist_rows(B, h, nl, nd, false)) < 1) return false;
   // hand-off buffers are addressed with 32-bit byte offsets
-  if ((long)T * B * h * 16 >= (1L << 31) || (long)T * ((B + 15) / 16) * (h / 16) * (h / 16) * 1024 >= (1L << 31)) return false;
+  if ((long)T * B * h * 16 >= (1L << 31) || (long)T * (2 * ((B + 31) / 32)) * (h / 16) * (h / 16) * 1024 >= (1L << 31)) return false;
   if (!tune_on(TUNE_LSTM_PERSIST)) return false;
   return true;
 }
 
-int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters,
+int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters, int rows,
                             hipStream_t s) {
   PFwdArgs a;
   memset(&a, 0, sizeof(a));
-  const int nbt = (B + 15) / 16;
+  ASTK_CHECK(rows == 16 || (rows == 32 && h <= 256), "lstm_persist_fwd: %d rows per workgroup at h = %d", rows, h);
+  const int nbt = (B + rows - 1) / rows;      // workgroup rows
   for (int i = 0; i < ncells; ++i) {
     const PersistCellHost& c = cells[i];
     PCellF& d = a.c[i];
     d.Wl = c.Wl; d.Wu = c.Wu; d.bias = c.bias; d.zx = c.zx; d.gates = c.gates; d.C = c.C; d.HR = c.HR; d.HD = c.HD;
     d.xin = c.xin; d.mask = c.mask; d.enc = c.enc; d.reverse_pos = c.reverse_pos; d.layer = c.layer;
+    d.zx_flags = c.zx_flags; d.zx_s0 = c.zx_s0; d.zx_cs = c.zx_cs;
   }
   a.ncells = ncells; a.nl = nl; a.T = T; a.B = B; a.h = h; a.H = H;
   a.dbg = persist_dbg_env();
@@ -1112,14 +1326,16 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   const int mode = gemm_precision_mode();
   const bool x3_off = !tune_on(TUNE_LSTM_X3), x4_off = !tune_on(TUNE_LSTM_X4);
   const int xs = mode == 0 ? 2 : (mode == 1 && !x3_off ? (h <= 256 ? 3 : (x4_off ? 0 : 4)) : 0);       // (4: bf16x3 with the weights' lo plane in LDS)
-#define ASTK_LSTM_FWD_(KB_, XS_) hipLaunchKernelGGL((lstm_persist_fwd_g<KB_, XS_>), grid, blk, 0, s, a)
+#define ASTK_LSTM_FWD_(KB_, XS_, MT_) hipLaunchKernelGGL((lstm_persist_fwd_g<KB_, XS_, MT_>), grid, blk, 0, s, a)
+#define ASTK_LSTM_FWD_XS_(KB_, MT_) { if (xs == 2) ASTK_LSTM_FWD_(KB_, 2, MT_); else if (xs == 3) ASTK_LSTM_FWD_(KB_, 3, MT_); else ASTK_LSTM_FWD_(KB_, 0, MT_); }
   switch (h) {
-    case 64: if (xs == 2) ASTK_LSTM_FWD_(1, 2); else if (xs == 3) ASTK_LSTM_FWD_(1, 3); else ASTK_LSTM_FWD_(1, 0); break;
-    case 128: if (xs == 2) ASTK_LSTM_FWD_(2, 2); else if (xs == 3) ASTK_LSTM_FWD_(2, 3); else ASTK_LSTM_FWD_(2, 0); break;
-    case 256: if (xs == 2) ASTK_LSTM_FWD_(4, 2); else if (xs == 3) ASTK_LSTM_FWD_(4, 3); else ASTK_LSTM_FWD_(4, 0); break;
-    case 512: if (xs == 2) ASTK_LSTM_FWD_(8, 2); else if (xs == 4) ASTK_LSTM_FWD_(8, 4); else ASTK_LSTM_FWD_(8, 0); break;
-    default: if (xs == 2) ASTK_LSTM_FWD_(16, 2); else if (xs == 4) ASTK_LSTM_FWD_(16, 4); else ASTK_LSTM_FWD_(16, 0); break;
+    case 64: if (rows == 32) ASTK_LSTM_FWD_XS_(1, 2) else ASTK_LSTM_FWD_XS_(1, 1) break;
+    case 128: if (rows == 32) ASTK_LSTM_FWD_XS_(2, 2) else ASTK_LSTM_FWD_XS_(2, 1) break;
+    case 256: if (rows == 32) ASTK_LSTM_FWD_XS_(4, 2) else ASTK_LSTM_FWD_XS_(4, 1) break;
+    case 512: if (xs == 2) ASTK_LSTM_FWD_(8, 2, 1); else if (xs == 4) ASTK_LSTM_FWD_(8, 4, 1); else ASTK_LSTM_FWD_(8, 0, 1); break;
+    default: if (xs == 2) ASTK_LSTM_FWD_(16, 2, 1); else if (xs == 4) ASTK_LSTM_FWD_(16, 4, 1); else ASTK_LSTM_FWD_(16, 0, 1); break;
   }
+#undef ASTK_LSTM_FWD_XS_
 #undef ASTK_LSTM_FWD_
   ASTK_LAUNCH_CHECK();
   return 0;
@@ -1127,10 +1343,11 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
 
 size_t lstm_persist_pr_floats(int B, int h);
 int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, int T, int B, int h, int H, unsigned* counters,
-                            unsigned amax_gen, hipStream_t s) {
+                            unsigned amax_gen, int rows, hipStream_t s) {
   PBwdArgs a;
   memset(&a, 0, sizeof(a));
-  const int nbt = (B + 15) / 16;
+  ASTK_CHECK(rows == 16 || (rows == 32 && h <= 256), "lstm_persist_bwd: %d rows per workgroup at h = %d", rows, h);
+  const int nbt = (B + rows - 1) / rows;      // workgroup rows (the counters are per workgroup row)
   for (int i = 0; i < ncells; ++i) {
     const PersistCellHost& c = cells[i];
     PCellB& d = a.c[i];
@@ -1140,6 +1357,9 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
     d.Wu = c.PD ? c.Wu : nullptr; d.PR = c.PR; d.PD = c.PD; d.PD_up = c.PD_up; d.up_external = c.up_external;
     d.amax = (u64*)c.amax;
     d.db = c.db;
+    d.db_part = c.db_part;
+    d.prog = c.prog; d.prog_cs = c.prog_cs > 0 ? c.prog_cs : 1;
+    ASTK_CHECK(!c.prog || c.prog_cs >= 4, "lstm_persist_bwd: progress chunks of %d steps (the arrivals' one-apart invariant needs >= 4)", c.prog_cs);
   }
   a.ncells = ncells; a.nl = nl; a.T = T; a.B = B; a.h = h; a.H = H;
   a.amax_gen = amax_gen;
@@ -1166,21 +1386,24 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   const int mode = gemm_precision_mode();      // (see lstm_persist_fwd_launch)
   const bool x3_off = !tune_on(TUNE_LSTM_X3), x4_off = !tune_on(TUNE_LSTM_X4);
   const int xs = mode == 0 ? 2 : (mode == 1 && !x3_off ? (h <= 256 ? 3 : (x4_off ? 0 : 4)) : 0);
-#define ASTK_LSTM_BWD_(KB_, XS_) hipLaunchKernelGGL((lstm_persist_bwd_rs<KB_, XS_>), grid, blk, 0, s, a)
+#define ASTK_LSTM_BWD_(KB_, XS_, MT_) hipLaunchKernelGGL((lstm_persist_bwd_rs<KB_, XS_, MT_>), grid, blk, 0, s, a)
+#define ASTK_LSTM_BWD_XS_(KB_, MT_) { if (xs == 2) ASTK_LSTM_BWD_(KB_, 2, MT_); else if (xs == 3) ASTK_LSTM_BWD_(KB_, 3, MT_); else ASTK_LSTM_BWD_(KB_, 0, MT_); }
   switch (h) {
-    case 64: if (xs == 2) ASTK_LSTM_BWD_(1, 2); else if (xs == 3) ASTK_LSTM_BWD_(1, 3); else ASTK_LSTM_BWD_(1, 0); break;
-    case 128: if (xs == 2) ASTK_LSTM_BWD_(2, 2); else if (xs == 3) ASTK_LSTM_BWD_(2, 3); else ASTK_LSTM_BWD_(2, 0); break;
-    case 256: if (xs == 2) ASTK_LSTM_BWD_(4, 2); else if (xs == 3) ASTK_LSTM_BWD_(4, 3); else ASTK_LSTM_BWD_(4, 0); break;
-    case 512: if (xs == 2) ASTK_LSTM_BWD_(8, 2); else if (xs == 4) ASTK_LSTM_BWD_(8, 4); else ASTK_LSTM_BWD_(8, 0); break;
-    default: if (xs == 2) ASTK_LSTM_BWD_(16, 2); else if (xs == 4) ASTK_LSTM_BWD_(16, 4); else ASTK_LSTM_BWD_(16, 0); break;
+    case 64: if (rows == 32) ASTK_LSTM_BWD_XS_(1, 2) else ASTK_LSTM_BWD_XS_(1, 1) break;
+    case 128: if (rows == 32) ASTK_LSTM_BWD_XS_(2, 2) else ASTK_LSTM_BWD_XS_(2, 1) break;
+    case 256: if (rows == 32) ASTK_LSTM_BWD_XS_(4, 2) else ASTK_LSTM_BWD_XS_(4, 1) break;
+    case 512: if (xs == 2) ASTK_LSTM_BWD_(8, 2, 1); else if (xs == 4) ASTK_LSTM_BWD_(8, 4, 1); else ASTK_LSTM_BWD_(8, 0, 1); break;
+    default: if (xs == 2) ASTK_LSTM_BWD_(16, 2, 1); else if (xs == 4) ASTK_LSTM_BWD_(16, 4, 1); else ASTK_LSTM_BWD_(16, 0, 1); break;
   }
+#undef ASTK_LSTM_BWD_XS_
 #undef ASTK_LSTM_BWD_
   ASTK_LAUNCH_CHECK();
   return 0;
 }
 
 // bytes of the reduce-scatter partial buffers of one cell (lstm.hip sizes the workspace with these)
-size_t lstm_persist_pr_floats(int B, int h) { return (size_t)PR_RING * ((B + 15) / 16) * (h / 16) * (h / 16) * 256; }
-size_t lstm_persist_pd_floats(int T, int B, int h) { return (size_t)T * ((B + 15) / 16) * (h / 16) * (h / 16) * 256; }
+// (sized for an EVEN number of 16-row tiles: a 32-row workgroup addresses tiles 2 by and 2 by + 1 whether the second one has rows or not)
+size_t lstm_persist_pr_floats(int B, int h) { return (size_t)PR_RING * (2 * ((B + 31) / 32)) * (h / 16) * (h / 16) * 256; }
+size_t lstm_persist_pd_floats(int T, int B, int h) { return (size_t)T * (2 * ((B + 31) / 32)) * (h / 16) * (h / 16) * 256; }
 
 }  // namespace astk

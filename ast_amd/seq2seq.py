@@ -223,6 +223,7 @@ class SpeechEncoderDecoder:
         # this and kept it opt-in: uncapped stream-K grids that got the CUs first blocked the recurrence.)  ASTK_SIDE_STREAM=0: in line.
         self.side_stream_on = os.environ.get("ASTK_SIDE_STREAM", "1") != "0"
         self._side = None
+        self._side_by_main = {}
         self.mask_pad_id = None
         # Arithmetic of the batched products, per model (-> the descriptors' `precision` / `gemm_operands` fields): None = the library's
         # process-wide default (bf16x3: exact f32 operands on the 16-bit matrix pipe); "bf16x3" | "f32" | "fp16x2" (narrower, opt-in);
@@ -573,6 +574,10 @@ class SpeechEncoderDecoder:
                 self.enc_variant.forward(st)
         else:
             wl = self._workspace("lstm", st["ws_lstm"])
+            # work beside the recurrences: the library cuts the layer-0 products into time chunks on this stream (astk.h side_stream), and
+            # sizes its recurrence workgroups (16 / 32 batch rows) by whether it has one -- the backward call sees the same descriptor
+            side = self._side_stream()
+            st["ld"].side_stream = side.cuda_stream if side is not None else None
             check(lib.astk_lstm_stack_fwd(C.byref(st["ld"]), st["lp"], _vp(st["xlstm"]), _vp(st["enc_masks"]), _vp(st["enc_states"]),
                                           _vp(st["cT"]), _vp(st["hT"]), _vp(wl), wl.numel(), s))
         self.enc_states = st["enc_states"]
@@ -607,19 +612,47 @@ class SpeechEncoderDecoder:
 
     # ------------------------------------------------------------------ seq2seq.py:399-473
     def _side_stream(self):
-        """The model's second stream (ordinary, from torch's pool), or None when side-stream work is off or the step runs on the legacy
-        default stream (which synchronises implicitly with every other stream: nothing would overlap)."""
+        """The model's second stream (ordinary, from torch's pool) for the stream the step is running on, or None: side-stream work off, the
+        step on the legacy default stream (which synchronises implicitly with every other stream), or no stream found that really runs
+        CONCURRENTLY with it.  HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and two streams that
+        share one execute in order whatever their events say -- the flag-gated hand-offs between the recurrence kernels and the chunked
+        products beside them need true concurrency (in one queue the consumer would sit in front of its producer until its bounded spin
+        times out), so every candidate is probed once (a 300 us spin on one stream, a trivial kernel on the other)."""
         if not self.side_stream_on or self.enc_variant is not None:
             return None
-        if torch.cuda.current_stream(self.device).cuda_stream == 0:
+        main = torch.cuda.current_stream(self.device)
+        if main.cuda_stream == 0:
             return None
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+        if main.cuda_stream not in self._side_by_main:
+            chosen = None
+            for _ in range(6):
+                cand = torch.cuda.Stream(device=self.device)
+                if self._concurrent(main, cand) and self._concurrent(cand, main):
+                    chosen = cand
+                    break
+            self._side_by_main[main.cuda_stream] = chosen
+        self._side = self._side_by_main[main.cuda_stream]
         return self._side
 
+    def _concurrent(self, a, b):
+        """True if a kernel on stream b runs while stream a is busy (one 300 us spin on a, a trivial kernel on b)."""
+        lib = _lib.load()
+        probe = self._ws.setdefault("probe", torch.zeros(4, device=self.device))
+        torch.cuda.synchronize(self.device)
+        check(lib.astk_spin(300, None, C.c_void_p(a.cuda_stream)))
+        ea, eb = torch.cuda.Event(), torch.cuda.Event()
+        ea.record(a)
+        check(lib.astk_scale_f32(_vp(probe), 4, 1.0, C.c_void_p(b.cuda_stream)))
+        eb.record(b)
+        eb.synchronize()
+        overlapped = not ea.query()
+        ea.synchronize()
+        return overlapped
+
     def close(self):
-        """Kept for callers of rounds 2-5 (the CU-masked streams it used to destroy are gone; torch owns the side stream)."""
+        """Kept for callers of rounds 2-5 (the CU-masked streams it used to destroy are gone; torch owns the side streams)."""
         self._side = None
+        self._side_by_main = {}
 
     def _upload_flags(self, dst, flags):
         """Host -> device copy of the teacher-forcing flags WITHOUT a host sync: a copy from pageable memory would make the host wait

@@ -97,6 +97,62 @@ def cpu_baseline(model_cfg, B, T, D, L, V, budget_s=30.0):
                       "path, per-step Python loop and one BLAS sgemm per Linear like Chainer-on-NumPy (Chainer is not installable offline)"}
 
 
+def bucket_plan(path, B, tokens_per_word, bucket_batch=None, num_b=20, width_b=80, max_sp=1680, max_pred=175, seed="seed-ast-20h"):
+    """The Fisher-20h training set cut the way the reference cuts it: bucket = min(frames // width_b, num_b - 1) (prep_buckets.py:52), every
+    bucket shuffled and sliced into batches (dataloader.py:127-140; the OLD path's per-bucket sizes nmt_run.py:421-426 with `bucket_batch`),
+    every batch padded to its longest utterance (<= max_sp frames, dataloader.py:95-108) and to its longest target
+    [GO] + ids[:max_pred - 2] + [EOS] (dataloader.py:139-147), target length = round(tokens_per_word x words).  Returns one row per bucket:
+    utterances, batch size, batches, the PADDED extent a step of that bucket is timed at (T = the bucket's upper edge, L = the mean batch
+    maximum), real and padded frames."""
+    import math
+    d = json.load(open(path))
+    frames, words = d["frames"]["fisher_train"], d["en_w"]["fisher_train"]
+    rnd = random.Random(seed)
+    buckets = [[] for _ in range(num_b)]
+    for f, wd in zip(frames, words):
+        buckets[min(f // width_b, num_b - 1)].append((min(f, max_sp), min(max_pred, 2 + int(math.ceil(tokens_per_word * wd)))))
+    rows = []
+    for b, bk in enumerate(buckets):
+        if not bk:
+            continue
+        size = B
+        if bucket_batch:
+            size = bucket_batch[0] if b < num_b // 3 else bucket_batch[1] if b < (num_b * 2) // 3 else bucket_batch[2]
+        rnd.shuffle(bk)
+        batches = [bk[i:i + size] for i in range(0, len(bk), size)]
+        Lmean = sum(max(u[1] for u in bt) for bt in batches) / len(batches)
+        Tb = min((b + 1) * width_b, max_sp) if b < num_b - 1 else max_sp
+        rows.append({"bucket": b, "utts": len(bk), "batch": size, "batches": len(batches), "T": Tb, "L": max(3, int(round(Lmean))),
+                     "real_frames": sum(u[0] for u in bk), "rows": sum(len(bt) for bt in batches)})
+    return rows
+
+
+def histogram_leg(w, args, B, T, L, barrier):
+    """One timed train step per bucket (same model, optimizer, scheme and step definition as the headline), weighted by the batches per
+    bucket: what an EPOCH of the reference's es_en_20h training set costs, not one bucket of it."""
+    bb = [int(x) for x in args.bucket_batch.split(",")] if args.bucket_batch else None
+    rows = bucket_plan(args.histogram, B, args.tokens_per_word, bb)
+    total_ms = real = padded = 0.0
+    table = []
+    for r in rows:
+        w.set_batch(r["batch"], r["T"], r["L"], seed=100 + r["bucket"])
+        dt, _ = w.timed(3, args.hist_steps)
+        ms = dt / args.hist_steps * 1e3
+        # (a bucket's last batch is short: priced at its share of a full batch's time -- the latency-bound kernels do not care, so this is
+        #  slightly optimistic, by less than one batch per bucket)
+        full = r["rows"] / r["batch"]
+        total_ms += ms * full
+        real += r["real_frames"]
+        padded += r["rows"] * r["T"]
+        table.append([r["bucket"], r["utts"], r["batch"], r["T"], r["L"], round(ms, 3)])
+    return {"what": "one epoch of the reference's Fisher-20h training set (17 306 utterances; tests/golden/fisher_20h_frames.json) on the model of "
+                    + w.name + ": one timed step per bucket x batches per bucket",
+            "tokens_per_word": args.tokens_per_word, "bucket_batch": bb or B,
+            "columns": ["bucket", "utts", "batch", "T", "L", "ms_per_step"], "buckets": table,
+            "epoch_s": round(total_ms * 1e-3, 3), "frames_per_s_real": round(real / (total_ms * 1e-3), 1),
+            "frames_per_s_padded": round(padded / (total_ms * 1e-3), 1), "real_frames": int(real)}
+
+
 def self_launch_command(gpus, argv, port=None):
     """The command `python bench.py --gpus N` (N > 1, no launcher in the environment) runs as a CHILD process: one rank per GPU under
     torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve), the same arguments."""
@@ -156,6 +212,16 @@ def main():
                     help="arithmetic of the batched products for the headline (default: the library's default, bf16x3 = exact f32 operands "
                          "as three bf16 terms; f32 = f32-input MFMAs; fp16x2 = two scaled fp16 terms, narrower than float32)")
     ap.add_argument("--no-also", action="store_true", help="skip the second workload (the shipped es_en_20h model) of the default cfg1 run")
+    ap.add_argument("--histogram", default=os.path.join(ROOT, "tests", "golden", "fisher_20h_frames.json"),
+                    help="corpus description (per-utterance frame and word counts of the reference's data/fisher/fisher_20h.info, extracted by "
+                         "tests/golden/make_fisher_frames.py): one timed step per bucket of the reference's bucketing rule (prep_buckets.py:52, "
+                         "20 buckets of 80 frames), weighted by the batches per bucket => epoch frames/s on the REAL shape distribution "
+                         "(`epoch` in the JSON line); 'none' skips the leg")
+    ap.add_argument("--hist-steps", type=int, default=8, help="timed steps per bucket of the --histogram leg (after 3 warm-ups)")
+    ap.add_argument("--tokens-per-word", type=float, default=1.3, help="--histogram: BPE-1k tokens per English word (the token counts live in the "
+                    "LDC-licensed text the reference does not ship; the .info file holds word counts)")
+    ap.add_argument("--bucket-batch", default=None, help="--histogram: per-bucket batch sizes 'max,med,min' of the reference's OLD path "
+                    "(nmt_run.py:421-426: first third of the buckets / second third / rest), e.g. 64,48,32; default: --batch everywhere")
     args = ap.parse_args()
     maybe_self_launch(args, sys.argv[1:])
 
@@ -236,6 +302,12 @@ def main():
             self.X, self.y = torch.from_numpy(Xh).cuda(), torch.from_numpy(yh).cuda()
             torch.cuda.synchronize()
 
+        def set_batch(self, Bs, Ts, Ls, seed=20):
+            """Another resident synthetic batch (the --histogram leg: one shape per bucket); the model's buffers are grow-only pools."""
+            Xh, yh = synth_batch(Bs, Ts, D, Ls, self.V, seed + rank)
+            self.X, self.y = torch.from_numpy(Xh).cuda(), torch.from_numpy(yh).cuda()
+            torch.cuda.synchronize()
+
         def step(self):
             with torch.cuda.stream(compute), using_config("train", True):
                 loss = self.model.forward_loss(X=self.X, y=self.y, teach_ratio=TRAIN["teach_ratio"], random_out=0, add_noise=TRAIN["speech_noise"])
@@ -304,7 +376,7 @@ def main():
                                if dpath & 16 else "per-launch loop (fallback)")
         paths["encoder_persistent"], paths["decoder_persistent"] = bool(lib.astk_lstm_stack_path(C.byref(st["ld"]))), bool(dpath & 17)
         paths["cu_count"] = int(lib.astk_device_cu_count())
-        paths["side_stream"] = bool(model._side_stream() is not None)
+        paths["side_stream"] = bool(model._side is not None)
         paths["free_cus_beside_recurrences"] = int(lib.astk_lstm_stack_free_cus(C.byref(st["ld"])))
         return paths
     paths = paths_of(model)
@@ -429,6 +501,12 @@ def main():
             e2["kernels"] = kernel_extras(w2.profile(args.profile_steps), args.profile_steps, w2.model._cur["T2"])
         also.append(e2)
 
+    # ---- the reference's REAL shape distribution (round 6): one timed step per bucket of the Fisher-20h training set
+    epoch = None
+    if args.histogram and args.histogram != "none" and os.path.exists(args.histogram) and world == 1:
+        epoch = histogram_leg(w2 if w2 is not None else w, args, B, T, L, barrier)
+        (w2 if w2 is not None else w).set_batch(B, T, L)
+
     out = {"metric": "speech frames/s (train step)", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": PRECISIONS[base_scheme] + ("" if args.gemm_operands == "f32" else "; single-term fp16 operands in the CNN / encoder-input / decoder-output GEMMs (--gemm-operands fp16)"),
@@ -443,12 +521,29 @@ def main():
                      "buckets": list(model.grad_buckets.ranges), "bucket_launch": "dec+enc behind the encoder recurrence, cnn behind the CNN backward",
                      "NCCL_MAX_NCHANNELS": chan_cap, "recurrence_grid_cus": need}
     out.update({"kernels": extra} if extra else {})
+    if epoch is not None:
+        out["epoch"] = epoch
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            # bounded CPU samples (the NumPy oracle on this box's host cores): ~30 s for the headline's model, ~15 s for the shipped one
+            # bounded CPU samples (the NumPy oracle on this box's host cores): ~20 s each for the headline's model and the shipped one,
+            # both at the GPU's batch
             out["cpu_baseline"] = cpu_baseline(cfg, B, T, D, L, V)
             if also:
-                also[0]["cpu_baseline"] = cpu_baseline(w2.cfg, B, T, D, L, w2.V, budget_s=15.0)
+                also[0]["cpu_baseline"] = cpu_baseline(w2.cfg, B, T, D, L, w2.V, budget_s=25.0)
+        if also:
+            # LAST key of the line (a record that keeps only the line's tail still shows the model north_star's >= 50x target names):
+            # the shipped es_en_20h model, compact
+            e2 = also[0]
+            cb = e2.get("cpu_baseline")
+            out["es_en_20h"] = {"model": "shipped es_en_20h (3 decoder layers), same batch / scheme / step as the headline", "precision": base_scheme,
+                                "ms_per_step": e2["ms_per_step"], "value": e2["value"], "unit": "frames/s",
+                                "decoder_us_per_step": (e2.get("kernels") or {}).get("decoder_us_per_decoder_step"),
+                                "decoder_ms_per_step": (e2.get("kernels") or {}).get("decoder_persistent_ms_per_step"),
+                                "paths": {k: e2["paths"][k] for k in ("encoder_persistent", "decoder_persistent", "side_stream") if k in e2["paths"]},
+                                "cpu_baseline": ({"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                                  "sample": cb["sample"].split(" in ")[0]} if cb else None),
+                                "gpu_over_cpu": round(e2["value"] / cb["value"], 1) if cb else None,
+                                "epoch_frames_per_s_real_shapes": (epoch or {}).get("frames_per_s_real")}
         print(json.dumps(out), flush=True)
     if dp:
         torch.distributed.destroy_process_group()

@@ -316,6 +316,47 @@ def test_cnn_max_pool_fwd_bwd(lib, B, T, D, c0, c1, pool, gemm_split):
                                                    # 4-deep ring of partial tiles comes round twice
                                                    (3, 4, 16, 1024, 2, False), (9, 19, 24, 1024, 3, True), (5, 32, 16, 1024, 2, True)])
 def test_lstm_stack(lib, T, B, in_dim, h, nl, masks, gemm_split):
+    _lstm_stack_case(lib, T, B, in_dim, h, nl, masks)
+
+
+@pytest.mark.parametrize("side", [False, True])
+@pytest.mark.parametrize("T,B,in_dim,h,nl,masks", [(6, 32, 32, 256, 3, True), (23, 33, 16, 64, 3, True), (9, 48, 24, 128, 2, False), (7, 64, 32, 256, 3, True),
+                                                   (5, 17, 16, 256, 1, False), (2, 40, 16, 128, 3, True), (26, 64, 48, 64, 2, False), (12, 200, 16, 64, 3, True)])
+def test_lstm_stack_32_row_workgroups_and_side_stream(lib, tune, T, B, in_dim, h, nl, masks, side, gemm_split):
+    """Round 6.  (a) 32 batch rows per recurrence workgroup (two 16-row tiles against one set of resident weight fragments: lstm.rows32 = 1
+    forces what the library otherwise chooses when it spares launches or frees CUs for side-stream work): full, ragged (33, 17, 40, 48) and
+    many (200) batch tiles, 1-3 layers, masks, every arithmetic scheme.  (b) `side`: the layer-0 input projection in time chunks on a second
+    stream beside the forward recurrence (astk_lstm_stack_desc.side_stream; chunks of 4 steps here so that small T already has several),
+    flag-gated inside the layer-0 cells.  Same float64 reference as test_lstm_stack."""
+    tune("lstm.rows32", 1, lib)
+    if side:
+        tune("lstm.overlap_chunk", 4, lib)
+    _lstm_stack_case(lib, T, B, in_dim, h, nl, masks, side=side)
+
+
+def _concurrent_stream(lib, main):
+    """A second stream that really executes beside `main` (HIP multiplexes streams onto a few hardware queues; two streams that share one run
+    in order, and a flag-gated consumer would then sit in front of its producer): probed like ast_amd/seq2seq.py does."""
+    probe = torch.zeros(4, device="cuda")
+    for _ in range(8):
+        cand = torch.cuda.Stream()
+        good = True
+        for a, b in ((main, cand), (cand, main)):
+            torch.cuda.synchronize()
+            ok(lib, lib.astk_spin(300, None, C.c_void_p(a.cuda_stream)))
+            ea, eb = torch.cuda.Event(), torch.cuda.Event()
+            ea.record(a)
+            ok(lib, lib.astk_scale_f32(vp(probe), 4, 1.0, C.c_void_p(b.cuda_stream)))
+            eb.record(b)
+            eb.synchronize()
+            good = good and not ea.query()
+            ea.synchronize()
+        if good:
+            return cand
+    pytest.skip("no pair of concurrently executing streams on this device")
+
+
+def _lstm_stack_case(lib, T, B, in_dim, h, nl, masks, side=False):
     from ast_amd._lib import LstmGrads, LstmParams, LstmStackDesc
     from oracle.ast_ref_torch import encoder_torch
     rng = np.random.default_rng(T + B)
@@ -340,6 +381,16 @@ def test_lstm_stack(lib, T, B, in_dim, h, nl, masks, gemm_split):
     d = LstmStackDesc(T, B, in_dim, h, nl, 2)
     if h in (64, 128, 256, 512, 1024):
         assert lib.astk_lstm_stack_path(C.byref(d)) == (2 if h == 1024 else 1), "persistent encoder path not taken"
+    main, side_s = None, None
+    if side:                            # the op on a stream of its own + a second one for the chunked products (joined inside the calls)
+        main = torch.cuda.Stream()
+        side_s = _concurrent_stream(lib, main)
+        d.side_stream = side_s.cuda_stream
+        assert lib.astk_lstm_stack_free_cus(C.byref(d)) > 0
+        torch.cuda.synchronize()
+
+    def stream():                       # (shadows the module's helper: the stream this case launches on)
+        return C.c_void_p(main.cuda_stream if main is not None else torch.cuda.current_stream().cuda_stream)
     prm = {k: dev(v) for k, v in P.items()}
     grd = {k: torch.zeros_like(v) for k, v in prm.items()}
     lp, lg = (LstmParams * (2 * nl))(), (LstmGrads * (2 * nl))()
@@ -351,15 +402,19 @@ def test_lstm_stack(lib, T, B, in_dim, h, nl, masks, gemm_split):
     xd, md = dev(x), (dev(mk) if masks else None)
     enc_d = torch.zeros(B, T, 2 * h, device="cuda")
     cT_d, hT_d = torch.zeros(2, nl, B, h, device="cuda"), torch.zeros(2, nl, B, h, device="cuda")
+    torch.cuda.synchronize()
     ok(lib, lib.astk_lstm_stack_fwd(C.byref(d), lp, vp(xd), vp(md), vp(enc_d), vp(cT_d), vp(hT_d), vp(ws), nbytes, stream()))
+    torch.cuda.synchronize()
     ws.check("lstm fwd")
     close(enc_d, enc, msg="enc_states")
     close(cT_d, cT, msg="cT")
     close(hT_d, hT, msg="hT")
     dx = torch.zeros(T, B, in_dim, device="cuda")
     ge_d, gc_d, gh_d = dev(g_enc), dev(g_c), dev(g_h)     # keep alive: the call only enqueues work
+    torch.cuda.synchronize()
     ok(lib, lib.astk_lstm_stack_bwd(C.byref(d), lp, lg, vp(xd), vp(md), vp(ge_d), vp(gc_d), vp(gh_d), vp(dx), vp(ws),
                                     nbytes, stream()))
+    torch.cuda.synchronize()
     ws.check("lstm bwd")
     close(dx, xt.grad, rtol=5e-4, msg="dx")
     for k in P:
