@@ -14,6 +14,7 @@
 //   ZG (T,B,4h) gates -> dz | HR (T,B,h) raw h | CC (T,B,h) cell | HD (T,B,h) dropped output (only with masks)
 #include "common.h"
 #include <algorithm>
+#include <vector>
 
 namespace astk {
 
@@ -58,7 +59,7 @@ constexpr int SIDE_CHUNKS_MAX = 60;
 struct SidePlan { int s0, cs, n, cap; };
 SidePlan plan_side_fwd(const astk_lstm_stack_desc* d, int rows, int wgs_first_launch) {
   SidePlan sp = {d->T, 0, 0, 0};
-  if (!d->side_stream || lstm_persist_hoisted(d->h)) return sp;
+  if (!d->side_stream || lstm_persist_hoisted(d->h) || !tune_on(TUNE_LSTM_SIDE_FWD)) return sp;
   int cap = device_cu_count() - wgs_first_launch;
   if (d->side_wgs > 0) cap = std::min(cap, d->side_wgs);
   cap = cap / 8 * 8;
@@ -80,6 +81,39 @@ SidePlan plan_side_fwd(const astk_lstm_stack_desc* d, int rows, int wgs_first_la
 }
 __global__ void k_set_flag(unsigned* f) {
   if (threadIdx.x == 0) __hip_atomic_store(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ---- the backward pass beside its recurrence.  The layer-0 cells write dz through and arrive on a progress counter per direction once per
+// chunk of `cs` loop steps (lstm_persist_bwd_rs, PCellB::prog); on the side stream a one-wave kernel waits for a chunk's arrivals -- bounded
+// spin with s_sleep; a time-out sets the encoder-backward bit of the sticky status word, so the step is reported, and exits, so nothing
+// hangs -- and the input-gradient products of that chunk follow it in stream order (a kernel boundary behind the wait: their loads see
+// the written-through dz).  Every launch is capped at the CUs the recurrence grid leaves free.
+__global__ void k_wait_progress(const unsigned* p0, const unsigned* p1, unsigned target, AbortCtl ab) {
+  if (threadIdx.x != 0) return;
+  unsigned spins = 0;
+  while (__hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target ||
+         (p1 && __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)) {
+    __builtin_amdgcn_s_sleep(32);
+    if (++spins > ab.limit) { abort_raise(ab); return; }
+    if ((spins & 63u) == 0 && abort_seen(ab)) return;
+  }
+}
+__global__ void k_zero_words(unsigned* p, int n, int stride) {
+  if ((int)threadIdx.x < n) __hip_atomic_store(p + threadIdx.x * stride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+SidePlan plan_side_bwd(const astk_lstm_stack_desc* d, int rows, int lpl, bool want_dx) {
+  SidePlan sp = {d->T, 0, 0, 0};
+  if (!d->side_stream || !want_dx || lstm_persist_hoisted(d->h) || lpl < d->n_layers || low_precision_gemms() || !tune_on(TUNE_LSTM_SIDE_BWD)) return sp;
+  int cap = device_cu_count() - lstm_persist_grid_wgs(d->B, d->h, d->n_layers, d->n_dirs, rows);
+  if (d->side_wgs > 0) cap = std::min(cap, d->side_wgs);
+  cap = cap / 8 * 8;
+  if (cap < 16) return sp;
+  int cs = (int)tune(TUNE_LSTM_OVERLAP_CHUNK);
+  if (cs <= 0) cs = std::max(4, (cap / (2 * ((d->in_dim + 127) / 128))) * 128 / d->B * 2);      // ~2 x cap tiles per direction and chunk
+  cs = std::max(4, cs);
+  const int n = std::min(SIDE_CHUNKS_MAX, (d->T + cs - 1) / cs);
+  if (n < 2) return sp;
+  sp.cs = cs; sp.n = n; sp.cap = cap; sp.s0 = 0;
+  return sp;
 }
 
 struct LstmPlan {
@@ -415,6 +449,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
   const size_t bh = (size_t)B * h;
   const bool persist = lstm_persist_applicable(T, B, h, P.nl, P.nd);
   const bool rs_path = persist;
+  SidePlan bside = {T, 0, 0, 0};
   unsigned long long* dz_amax[16] = {nullptr};
   unsigned dz_amax_gen = 0;
   if (persist) {
@@ -446,6 +481,54 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
     // the recurrence kernel leaves max |dz| of every cell for the batched products behind it (fp16x2 GEMM scales)
     gemm_amax_reserve(P.nd * P.nl, dz_amax, &dz_amax_gen, s);
     for (int i = 0; i < P.nd * P.nl; ++i) cells[i].amax = dz_amax[i];
+    const int rows_b = lstm_persist_rows(B, h, P.nl, P.nd, d->side_stream != nullptr);
+    if (!lstm_persist_hoisted(h)) bside = plan_side_bwd(d, rows_b, lstm_persist_layers_per_launch(B, h, P.nl, P.nd, rows_b), dx != nullptr && sr == s);
+    if (bside.n > 0) {
+      // The input gradient dx (T,B,in) = dz_0 W_u0 of both directions, chunk by chunk behind the recurrence (see k_wait_progress).  Loop step
+      // i of direction 0 is frame i, of direction 1 frame (T - i) % T (quirk Q1): the backward recurrence passes loop steps T-1 .. 0, so
+      // direction 0 delivers the high frames first and direction 1 the low ones.  A product STORES the frames nobody has written yet and
+      // ACCUMULATES into the others (the host keeps the book: no zero fill of the 79 MB, and the sums are the in-line schedule's).
+      hipStream_t sside = (hipStream_t)d->side_stream;
+      unsigned* prog = P.zflags + (size_t)(SIDE_CHUNKS_MAX + 2) * 64;
+      const unsigned wgs_cell = (unsigned)((h / 16) * ((B + rows_b - 1) / rows_b));
+      for (int dd = 0; dd < P.nd; ++dd) { cells[dd * P.nl].prog = prog + dd * 64; cells[dd * P.nl].prog_cs = bside.cs; }
+      hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, s, prog, 3, 64);      // the two counters and the wait kernels' abort word
+      ASTK_LAUNCH_CHECK();
+      ASTK_TRY(stream_order(s, sside));          // everything the products read besides dz (weights, index tables) and the zeroed counters
+      std::vector<char> touched((size_t)T, 0);
+      const AbortCtl wab = abort_ctl(prog + 2 * 64, PERSIST_ENC_BWD);
+      GemmWgCap cap_scope(bside.cap);
+      for (int k = 0; k < bside.n; ++k) {
+        const int i1 = T - k * bside.cs, i0 = std::max(0, i1 - bside.cs);       // loop steps [i0, i1) are final when chunk k has arrived
+        hipLaunchKernelGGL(k_wait_progress, dim3(1), dim3(64), 0, sside, prog, P.nd > 1 ? prog + 64 : nullptr, (unsigned)(k + 1) * wgs_cell, wab);
+        ASTK_LAUNCH_CHECK();
+        for (int dd = 0; dd < P.nd; ++dd) {
+          // frames of this chunk, as maximal runs [f0, f1)
+          int runs[2][2], nruns = 0;
+          if (dd == 0) { runs[0][0] = i0; runs[0][1] = i1; nruns = 1; }
+          else {
+            const int lo = std::max(i0, 1);                                    // loop steps lo .. i1-1 -> frames T-i1+1 .. T-lo
+            if (i1 > lo) { runs[nruns][0] = T - i1 + 1; runs[nruns][1] = T - lo + 1; ++nruns; }
+            if (i0 == 0) { runs[nruns][0] = 0; runs[nruns][1] = 1; ++nruns; }   // loop step 0 = frame 0
+          }
+          for (int r = 0; r < nruns; ++r) {
+            int f = runs[r][0];
+            while (f < runs[r][1]) {               // sub-runs of equal "written yet?" state
+              int g = f;
+              while (g < runs[r][1] && touched[g] == touched[f]) ++g;
+              const astk_lstm_params& p0 = prm[dd * P.nl];
+              const float* dz = P.ZG[dd][0];
+              MatView A = dd == 0 ? mat(dz + (size_t)f * B * 4 * h, 4 * h) : mat_idx(dz, 4 * h, rows_inv + (size_t)f * B);
+              if (dd == 1) A.idx_rows = (long)T * B;
+              ASTK_TRY(gemm_launch(GEMM_NN, gemm_args((g - f) * B, P.in, 4 * h, A, mat(p0.Wu, P.in), dx + (size_t)f * B * P.in, P.in, nullptr,
+                                                      touched[f] ? GEMM_ACCUM : GEMM_STORE), sside));
+              for (int q = f; q < g; ++q) touched[q] = 1;
+              f = g;
+            }
+          }
+        }
+      }
+    }
     ASTK_TRY(stream_order(s, sr));     // the recurrence kernel may live on its own (CU-masked) stream, see astk.h
     if (lstm_persist_hoisted(h)) {
       // hoisted form: layer by layer from the top; a lower layer's incoming gradient is the dense (T,B,h) product dz W_u of the layer
@@ -580,7 +663,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
       // gradient wrt the layer input
       if (l > 0) {
         if (!persist) ASTK_TRY(gemm_launch(GEMM_NN, with_amax_a(gemm_args(rows, h, 4 * h, mat(dz, 4 * h), mat(p.Wu, h), P.DX[dd], h), adz), s));
-      } else if (dx) {
+      } else if (dx && bside.n == 0) {
         // dx (T,B,in) in frame order: direction 0 stores, direction 1 accumulates through the inverse permutation
         MatView A = dd == 0 ? mat(dz, 4 * h) : mat_idx(dz, 4 * h, rows_inv);
         ASTK_TRY(gemm_launch(GEMM_NN, with_amax_b(with_amax_a(lowp(gemm_args(rows, in, 4 * h, A, mat(p.Wu, in), dx, in, nullptr, dd == 0 ? GEMM_STORE : GEMM_ACCUM)), adz), aw0[dd]), s));
@@ -589,6 +672,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
   }
   ASTK_TRY(cb.flush(s));
   if (nwg > 0) ASTK_TRY(gemm_launch_group(GEMM_TN, wg, nwg, s));
+  if (bside.n > 0) ASTK_TRY(stream_order((hipStream_t)d->side_stream, s));      // join: the caller sees one-stream semantics
   return 0;
 }
 

@@ -426,14 +426,29 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
   auto zx_load = [&](long tbs) {      // this thread's four pre-activations of (step, row) tbs: sc1 (see r_zx)
     return frag_vals(__builtin_amdgcn_raw_buffer_load_b128(r_zx, (int)((tbs * 4 * h + 4 * eu) * 4), 0, 16));
   };
-  // chunk flag of time step ts (layer 0 with side-stream chunks only): the word to look at, and the wait
-  auto zflag_of = [&](int ts) { return zflags + (ts < zs0 ? 0 : 1 + (ts - zs0) / zcs) * CTR_STRIDE; };
+  // Chunk flags (layer 0 with side-stream chunks only).  z_next = first step of the next chunk this wave has not entered yet, zfp = that
+  // chunk's flag word (one per 256-byte line; the word behind the last chunk's stays 0 and is never waited for).  The word is LOOKED AT
+  // every step (one uniform load, off the chain), so when the chunk's first rows are wanted the answer is at least a step old; entering a
+  // chunk = (wait for the flag if it was not up yet) + ONE agent-scope acquire: the chunk was written with plain stores by a launch that
+  // ended before the flag kernel ran, so its bytes are in memory, and the acquire keeps this CU from answering the loads below out of lines
+  // it may still hold from an earlier launch (MI355X_MICROARCH.md "Consumer, always").
+  int z_next = zflags ? zs0 : 0x7fffffff;
+  const unsigned* zfp = zflags;
+  unsigned zf_seen = 1u;
   auto zflag_wait = [&](const unsigned* fp, unsigned seen) {
     unsigned spins = 0;
     while (seen == 0u && !dead) {
       seen = ld_flag(fp);
       if (++spins > (ab.limit >> 1)) { abort_raise(ab); dead = true; }
       else if ((spins & 63u) == 0 && abort_seen(ab)) dead = true;
+    }
+  };
+  auto zx_enter = [&](int ts) {              // (uniform) the rows of step ts are about to be loaded
+    while (ts >= z_next) {
+      if (zf_seen == 0u) zflag_wait(zfp, 0u);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      z_next += zcs; zfp += CTR_STRIDE;
+      zf_seen = ld_flag(zfp);
     }
   };
   // what only later launches read, stored half a step late
@@ -463,11 +478,9 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
   // ---- prologue: inputs of step 0; x_0 into registers, x_1 in flight
   float4 zadd[MT], zadd_n[MT];
   float mk_raw[MT], mk_raw_n[MT];
-  unsigned zf_seen = 1u;            // the flag word of the chunk that holds step t + 2 (asked for a step early; 1 = nothing to wait for)
   if (!HAS_UP && zflags) {
-    zflag_wait(zflag_of(0), 0u);                                       // the rows of steps 0 and 1 (one chunk, or the in-line part)
-    if (T > 1) zflag_wait(zflag_of(1), 0u);
-    zf_seen = ld_flag(zflag_of(min(2, T - 1)));
+    zf_seen = ld_flag(zfp);
+    zx_enter(0);
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -569,9 +582,8 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
       for (int mt = 0; mt < MT; ++mt) frag_issue<KB>(r_below, frag0[mt] + t2 * step_bytes, wave, gx[mt]);
     }
     if (!HAS_UP && zflags) {
-      // the rows of step t + 1: their chunk's flag was asked for a step ago (zf_seen); wait only if it was not up then.  Then ask for t + 2's.
-      if (zf_seen == 0u) zflag_wait(zflag_of(t1), 0u);
-      zf_seen = ld_flag(zflag_of(t2));
+      zx_enter(t1);                   // (once per chunk: see zx_enter)
+      zf_seen = ld_flag(zfp);         // the next chunk's flag, looked at every step
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {

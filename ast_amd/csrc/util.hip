@@ -97,7 +97,9 @@ static const TuneEntry g_tune_table[TUNE_COUNT] = {
     {"lstm.x3", 1},                // bf16x3 fragments inside the recurrences (0: f32-input MFMAs under the bf16x3 arithmetic)
     {"lstm.x4", 1},                // ... with the weights' lo plane in LDS at h = 512 / 1024
     {"lstm.rows32", -1},           // 32 batch rows per recurrence workgroup: 1 always, 0 never, -1 = when it spares launches or an overlap partner exists
-    {"lstm.overlap_chunk", 8},     // time steps per chunk of the layer-0 products that run beside the recurrences (side_stream)
+    {"lstm.overlap_chunk", 0},     // time steps per chunk of the layer-0 products that run beside the recurrences (side_stream); 0 = from the free CUs
+    {"lstm.side_fwd", 1},          // side_stream: the layer-0 input projection in chunks beside the forward recurrence
+    {"lstm.side_bwd", 1},          // side_stream: the input gradient in chunks behind the backward recurrence's progress
     {"row.longk", 2048},           // row-panel kernels split K over eight waves from this K on (0 = never)
     {"persist.spin_limit", 0},     // bound of the persistent kernels' spins in polls (0 = the default, 2^22)
     {"colreduce.blocks", 256},     // blocks of a column reduction
