@@ -204,6 +204,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # In a process that also uses PyTorch-ROCm the library must bind to the HIP runtime torch ships (its wheel bundles libamdhip64):
+        # loaded first, libastk.so would pull in /opt/rocm's copy beside it, and kernels launched through one runtime on streams of the
+        # other fail with "no ROCm-capable device" or crash.  (A pure C / ctypes user without torch is unaffected.)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise AstkError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(there is no CPU or PyTorch fallback for the compute path)")

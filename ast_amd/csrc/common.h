@@ -350,6 +350,17 @@ struct GemmForwardScope {
   ~GemmForwardScope();
   int prev;
 };
+// Deterministic mode (descriptor field `deterministic`, or the process default "gemm.deterministic"): every accumulated sum of the calls made
+// by this thread inside the scope is formed in a fixed order -- split tiles of the batched products through the fix-up workspace
+// (gemm.hip, "Deterministic split tiles"), column reductions with one block per column group, the embedding scatter per token, the LSTM
+// bias gradients through a per-workgroup-row scratch; no side-stream work (the fix-up workspace serves one launch at a time).  The
+// backward entry points open one; a soak that compares two passes then sees ANY run-to-run difference as a defect.
+struct DetScope {
+  explicit DetScope(int requested);
+  ~DetScope();
+  int prev;
+};
+bool deterministic_mode();
 // Scoped cap on the GRID of the GEMM launches made by this thread (workgroups; 0 = none): work that is meant to run BESIDE a persistent
 // recurrence kernel, on a second stream, gets at most the CUs that kernel's grid leaves free -- whichever of the two is dispatched first,
 // the recurrence grid still becomes resident (a workgroup of it needs a CU's whole register file, and stream-K workgroups live for the
@@ -609,7 +620,7 @@ static inline dim3 colreduce_grid(int rows, int cols) {
   const int CL = q < COLREDUCE_CL ? q : COLREDUCE_CL, NR = 256 / CL;
   const int gx = (q + CL - 1) / CL;
   const int blocks = (int)tune(TUNE_COLREDUCE_BLOCKS);
-  int gy = blocks / gx;
+  int gy = deterministic_mode() ? 1 : blocks / gx;       // (deterministic: one block per column group sums its rows in order: one add per column)
   const int max_gy = (rows + 16 * NR - 1) / (16 * NR);
   if (gy > max_gy) gy = max_gy;
   if (gy < 1) gy = 1;

@@ -1225,6 +1225,7 @@ int astk_conv_bn_relu_bwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
   hipStream_t s = (hipStream_t)stream;
   ASTK_CHECK_DESC(d, astk_cnn_desc);
   PrecScope prec_scope(d->precision, d->gemm_operands);
+  DetScope det_scope(d->deterministic);
   ASTK_CHECK(world >= 1, "conv_bn_relu_bwd: world %d", world);
   if (world == 1 || d->no_bn) exchange = nullptr;      // (no statistics to exchange without BatchNorm)
   CnnPlan P;

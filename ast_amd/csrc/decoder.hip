@@ -213,6 +213,24 @@ __global__ void k_embed_bwd(float* __restrict__ d_embed, const int32_t* __restri
   }
 }
 
+// deterministic calls: one block per TOKEN adds the rows that embedded it, in row order (no atomics: the table row is the block's own)
+__global__ void k_embed_bwd_det(float* __restrict__ d_embed, const int32_t* __restrict__ tok, const float* __restrict__ dx0,
+                                const float* __restrict__ mask, int SB, int E, int XI, int V) {
+  const int t = blockIdx.x;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float sum = 0.f;
+    bool any = false;
+    for (int r = 0; r < SB; ++r) {
+      if (min(max(tok[r], 0), V - 1) != t) continue;
+      float v = dx0[(long)r * XI + e];
+      if (mask) v *= mask[(long)r * E + e];
+      sum += v;
+      any = true;
+    }
+    if (any) d_embed[(long)t * E + e] += sum;
+  }
+}
+
 // One block per row: log-softmax, weighted NLL / count, first-max argmax, dlogits in place (Chainer-sem A6).
 // Row r is (step r / rows_per_step, batch row r % rows_per_step); its class id is targets[(r % rows_per_step) * t_stride + r / rows_per_step]
 // (one decoder step: rows_per_step = B and `targets` points at the step's column).  argmax_only: feedback tokens of a step whose loss is
@@ -672,6 +690,7 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
   (void)c0; (void)h0; (void)y;
   ASTK_CHECK_DESC(d, astk_decoder_desc);
   PrecScope prec_scope(d->precision, d->gemm_operands);
+  DetScope det_scope(d->deterministic);
   ASTK_CHECK(phase == ASTK_DEC_BWD_ALL || phase == ASTK_DEC_BWD_CHAIN || phase == ASTK_DEC_BWD_PARAMS, "decoder_bwd: bad phase %d", phase);
   {
     SplitPlan sp;
@@ -930,7 +949,8 @@ int astk_decoder_bwd_phase_ex(const astk_decoder_desc* d, const astk_decoder_par
     wbl.n = 0;
     ASTK_TRY(wb.flush(s));
   }
-  hipLaunchKernelGGL(k_embed_bwd, dim3(SB), dim3(128), 0, s, g->d_embed, P.TOK, P.DX0, emb_mask, SB, E, XI, V);
+  if (deterministic_mode()) hipLaunchKernelGGL(k_embed_bwd_det, dim3(V), dim3(128), 0, s, g->d_embed, P.TOK, P.DX0, emb_mask, SB, E, XI, V);
+  else hipLaunchKernelGGL(k_embed_bwd, dim3(SB), dim3(128), 0, s, g->d_embed, P.TOK, P.DX0, emb_mask, SB, E, XI, V);
   ASTK_LAUNCH_CHECK();
   return 0;
 }

@@ -88,6 +88,26 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __host__ __device__ __forceinline__ long wg_first_iter(const GemmGroup& grp, unsigned w, unsigned G) {
   return grp.rem_start + ((grp.iters_total - grp.rem_start) / grp.unit) * (long)w / (long)G * grp.unit;
 }
+// ---- Deterministic split tiles (round 6; template parameter FIX, launches of a `deterministic` call).  A tile whose k range is shared by
+// several workgroups is normally zeroed in front of the launch and accumulated with float atomics by every contributor: the sum then depends
+// on the order the atomics arrive in, which varies from run to run (2-6e-10 of the clip norm) -- harmless for training, but it blinds a
+// soak that compares two passes bit for bit exactly where a hand-off race would show.  FIX kernels: every contributing WAVE stores its 64 x 64
+// accumulator block to a slot of g_fix_part (16-byte write-through stores, lane-major), drains them and draws a ticket on the (tile, wave)
+// counter; the wave that draws the LAST ticket reads all blocks of its sub-tile back in WORKGROUP ORDER (sc1 loads behind the returned
+// ticket: the per-wave form of MI355X_MICROARCH.md's hand-off table), sums them in that fixed order and writes the tile the way `mode` says
+// (plain stores for GEMM_STORE: no zeroing launch; ONE atomic add per element for GEMM_ATOMIC / GEMM_ACCUM).  Nobody waits for anybody (no
+// spin, residency does not matter); the last arriver puts the counter back to zero.  Slot of (workgroup w, tile X) = 2 w + (X holds the START
+// of w's range ? 0 : 1): a stream-K range has at most two split tiles, one at each end.  One launch at a time may use the slots (they are
+// process-wide like the scale ring): deterministic calls run everything on ONE stream.  Measured (round 5, as an always-on experiment): every
+// launch a few per cent slower -- a weight-gradient tile has up to 14 contributors whose blocks the last one reads one after the other --
+// which is why it is a mode, not the default.  Instantiated for the 128 x 128 bf16x3 kernel only; a deterministic call runs all its split
+// launches on it (launches of the f32 scheme fall back to one whole tile per workgroup).
+constexpr int FIX_WGS = 256;                       // launches of up to this many workgroups
+constexpr int FIX_WAVES = 4;
+constexpr int FIX_BLOCK = 64 * 64;                 // floats of one wave's accumulator block
+__device__ float g_fix_part[(size_t)2 * FIX_WGS * FIX_WAVES * FIX_BLOCK];      // 32 MB
+__device__ unsigned g_fix_ctr[2 * FIX_WGS * FIX_WAVES];
+
 // Tile `tile` of a problem (batch-major, then the block order of GemmArgs::bm) -> batch slice and tile coordinates.
 __host__ __device__ __forceinline__ void decode_tile(const GemmArgs& g, long tile, int TLM, int TL, int& zb, int& m0, int& n0) {
   const int tiles_n = (g.N + TL - 1) / TL;
@@ -396,8 +416,9 @@ constexpr int gemm_min_waves(int TL, int PREC, int TLM) { return (PREC != PREC_F
 // TL: tile edge along N (and along M unless TLM says otherwise: the bf16x3 path also runs 256 x 128 tiles -- per k-iteration the split
 // costs vector-ALU issue slots in proportion to TLM + TL while the MFMAs grow with TLM x TL, and only from 256 x 128 on do the MFMAs
 // (1536 cycles per wave and iteration) outlast the split's issue time on the same SIMD).
-template <int TL, bool A_RK, bool B_RK, bool TWOLVL, int PREC, int TLM = TL>
+template <int TL, bool A_RK, bool B_RK, bool TWOLVL, int PREC, int TLM = TL, bool FIX = false>
 __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, TLM)) void gemm_f32_kernel(GemmGroup grp) {
+  static_assert(!FIX || (PREC == PREC_BF16X3 && TL == 128 && TLM == 128), "the deterministic fix-up is instantiated for the 128 x 128 bf16x3 kernel");
   constexpr int LD_KR = ld_kr(TL);
   constexpr int LDA = A_RK ? LD_RK : LD_KR;
   constexpr int LDB = B_RK ? LD_RK : LD_KR;
@@ -518,6 +539,10 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
     //  the kernel-argument block, hipcc re-loads the field behind every global store -- the stores might alias it -- and waits for the
     //  scalar load, 64 times per lane and tile)
     const float* const e_bias = add_bias ? g.bias : nullptr;
+    // FIX: the tile's first iteration in the launch's sequence, -1 for a whole tile (everything else about the split is derived in the
+    // epilogue, behind the k loop)
+    const long fix_gs0 = (FIX && !whole) ? grp.iter_start[prob] + tile * kt_tile : -1;
+    const int g_mode = g.mode, e_kt = g.kt;
     const int e_M = g.M, e_N = g.N, e_ctn = g.c_tn;
     const long e_ldc = g.ldc, e_csg = g.c_sg, e_cst = g.c_st;
     auto epilogue = [&](f32x16 (&acc)[NAM][NA]) {
@@ -537,6 +562,70 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
         }
       }
       const int col0 = n0 + wn * WT + li;
+      int out_mode = mode;
+      if constexpr (FIX) {
+        if (fix_gs0 >= 0) {                     // (uniform) a split tile of a deterministic launch
+          int gl = (int)(fix_gs0 & 0xffffffffL), gh = (int)(fix_gs0 >> 32);
+          asm volatile("" : "+v"(gl), "+v"(gh));          // (opaque: keeps this derivation behind the k loop)
+          const long gs = ((long)__builtin_amdgcn_readfirstlane(gh) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(gl), ge = gs + e_kt;
+          const unsigned Gn = gridDim.x;
+          // the contributors: the workgroups whose ranges meet [gs, ge), found by walking from this workgroup's own range
+          int lo = (int)wgi, hi = (int)wgi, n = 0;
+          while (lo > 0 && wg_first_iter(grp, lo, Gn) > gs) --lo;
+          while (hi + 1 < (int)Gn && wg_first_iter(grp, hi + 1, Gn) < ge) ++hi;
+          for (int w2 = lo; w2 <= hi; ++w2) n += wg_first_iter(grp, w2 + 1, Gn) > wg_first_iter(grp, w2, Gn) ? 1 : 0;
+          if (n > 1) {
+            const long fm = wg_first_iter(grp, wgi, Gn), fl = wg_first_iter(grp, lo, Gn);
+            const int slot = 2 * (int)wgi + ((fm >= gs && fm < ge) ? 0 : 1);
+            const int key = 2 * lo + ((fl >= gs && fl < ge) ? 0 : 1);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g_fix_part, 0, 0x7fffffff, 0x00020000);
+            const int mine = (int)(((size_t)slot * FIX_WAVES + wave) * FIX_BLOCK * 4) + lane * 16;
+#pragma unroll
+            for (int i = 0; i < NAM; ++i)
+#pragma unroll
+              for (int j = 0; j < NA; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  u32x4 o;
+                  o.x = __float_as_uint(acc[i][j][4 * q]); o.y = __float_as_uint(acc[i][j][4 * q + 1]);
+                  o.z = __float_as_uint(acc[i][j][4 * q + 2]); o.w = __float_as_uint(acc[i][j][4 * q + 3]);
+                  __builtin_amdgcn_raw_buffer_store_b128(o, rs, mine + ((i * NA + j) * 4 + q) * 1024, 0, 16);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's block has left for memory ...
+            unsigned ticket = 0;
+            if (lane == 0) ticket = __hip_atomic_fetch_add(&g_fix_ctr[key * FIX_WAVES + wave], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ticket = __builtin_amdgcn_readfirstlane(ticket);       // ... before its ticket is drawn; the loads below depend on the returned value
+            if ((int)ticket != n - 1) return;                      // not the last contributor of this sub-tile: done
+            if (lane == 0) __hip_atomic_store(&g_fix_ctr[key * FIX_WAVES + wave], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < NAM; ++i)
+#pragma unroll
+              for (int j = 0; j < NA; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int w2 = lo; w2 <= hi; ++w2) {                    // every contributor's block, in workgroup order (its own from memory too)
+              const long f2 = wg_first_iter(grp, w2, Gn);
+              if (wg_first_iter(grp, w2 + 1, Gn) <= f2) continue;      // (an empty range contributes nothing)
+              const int slot2 = 2 * w2 + ((f2 >= gs && f2 < ge) ? 0 : 1);
+              const int base = (int)(((size_t)slot2 * FIX_WAVES + wave) * FIX_BLOCK * 4) + lane * 16;
+#pragma unroll
+              for (int i = 0; i < NAM; ++i)
+#pragma unroll
+                for (int j = 0; j < NA; ++j) {
+                  u32x4 t[4];
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + ((i * NA + j) * 4 + q) * 1024, 0, 16);
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) {
+                    acc[i][j][4 * q] += __uint_as_float(t[q].x); acc[i][j][4 * q + 1] += __uint_as_float(t[q].y);
+                    acc[i][j][4 * q + 2] += __uint_as_float(t[q].z); acc[i][j][4 * q + 3] += __uint_as_float(t[q].w);
+                  }
+                }
+            }
+            out_mode = g_mode == GEMM_ACCUM ? GEMM_ATOMIC : g_mode;      // the finished tile goes out the way the caller asked
+          }
+        }
+      }
       // Ticket protocol of a split GEMM_STORE tile.  The element loops below are the two the kernel always had (plain stores / atomic
       // adds), byte for byte: a third copy with written-through stores, or ticket state alive across them, pushed the 168-register kernel's
       // epilogue over its budget -- 100 scratch reloads, each behind an s_waitcnt vmcnt(0) that also drains the epilogue's own stores: the
@@ -584,7 +673,7 @@ __global__ __launch_bounds__(gemm_threads(PREC, TLM), gemm_min_waves(TL, PREC, T
           }
         }
       };
-      if (mode == GEMM_STORE || tick_first) body(std::true_type{});
+      if (out_mode == GEMM_STORE || tick_first) body(std::true_type{});
       else body(std::false_type{});
       if constexpr (ASTK_GEMM_TICKET) {
         int tick_i = tick_idx;
@@ -1184,6 +1273,10 @@ int low_precision_gemms() { return tl_lowp >= 0 ? tl_lowp : g_lowp_mode; }
 static thread_local int tl_forward = 0;
 GemmForwardScope::GemmForwardScope() : prev(tl_forward) { tl_forward = 1; }
 GemmForwardScope::~GemmForwardScope() { tl_forward = prev; }
+static thread_local int tl_det = 0;
+DetScope::DetScope(int requested) : prev(tl_det) { tl_det = (requested != 0 || tune_on(TUNE_GEMM_DETERMINISTIC)) ? 1 : 0; }
+DetScope::~DetScope() { tl_det = prev; }
+bool deterministic_mode() { return tl_det != 0; }
 static thread_local int tl_wg_cap = 0;
 GemmWgCap::GemmWgCap(int wgs) : prev(tl_wg_cap) { tl_wg_cap = wgs > 0 ? std::max(8, wgs / 8 * 8) : 0; }      // (a multiple of the 8 XCDs)
 GemmWgCap::~GemmWgCap() { tl_wg_cap = prev; }
@@ -1298,6 +1391,10 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   // launches capped to share the CUs with a recurrence kernel are the ones a caller puts on a SIDE stream: the scale slots of the
   // fp16x2 scheme are a process-wide ring ordered by one stream, so these launches take the scheme that needs none
   if (prec == PREC_F16X2 && tl_wg_cap > 0) prec = PREC_BF16X3;
+  // deterministic calls: split launches run on the 128 x 128 bf16x3 kernel, the one the fix-up epilogue is instantiated for (fp16x2 asks
+  // for less accuracy than that, so it may have it); the f32 and single-term-fp16 schemes keep their kernels with one whole tile per workgroup
+  const bool det = tl_det != 0;
+  if (det && prec == PREC_F16X2) prec = PREC_BF16X3;
   int TL = 128, TLM = 128;
   for (int pass = 0; pass < 3; ++pass) {
     memset(&grp, 0, sizeof(grp));
@@ -1332,6 +1429,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     const double big_flops = tune(TUNE_GEMM_T256_ABOVE);
     const bool big = prec == PREC_BF16X3 && BK == 16 && tall_ok && flops >= big_flops && !small;
     int want = force_tl == 64 || force_tl == 128 || force_tl == 256 ? force_tl : (small ? 64 : (big ? 256 : 128));
+    if (det && prec == PREC_BF16X3) want = 128;
     if (want == 256 && (prec != PREC_BF16X3 || BK != 16)) want = 128;
     if (want == 64 && prec == PREC_F16) want = 128;        // (the fp16 variant is instantiated for 128-tiles only)
     if (want == 128) break;
@@ -1373,6 +1471,8 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   }
   if (force_g > 0) { G = std::min<long>(force_g, grp.iters_total); aligned = false; }
   if (tl_wg_cap > 0 && G > tl_wg_cap) { G = tl_wg_cap; aligned = false; }
+  if (det && prec != PREC_BF16X3) { G = tiles; aligned = true; }        // no fix-up kernel for these schemes: whole tiles only
+  if (det && !aligned && G > FIX_WGS) G = FIX_WGS;
   if (aligned && grp.n > 1) {
     // one tile per workgroup needs boundaries on tile boundaries: only true for uniform kt; otherwise fall back to an even split
     bool uniform = true;
@@ -1423,7 +1523,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   const bool chunk_on = tune_on(TUNE_GEMM_CHUNK);
   const int chunk_div = (int)tune(TUNE_GEMM_CHUNK_DIV);      // (tuning hook: tiles * div <= G)
   for (int i = 0; i < grp.n; ++i) { grp.g[i].cs = 0; grp.g[i].chunk_iters = 0; }
-  if (chunk_on && grp.n == 1 && !aligned && grp.dp_waves == 0 && grp.g[0].mode != GEMM_STORE && prec != PREC_F32 && tiles * chunk_div <= G && grp.g[0].kt >= 128) {
+  if (chunk_on && !det && grp.n == 1 && !aligned && grp.dp_waves == 0 && grp.g[0].mode != GEMM_STORE && prec != PREC_F32 && tiles * chunk_div <= G && grp.g[0].kt >= 128) {
     GemmArgs& a = grp.g[0];
     const long share = grp.iters_total / G;      // k-iterations per workgroup
     int best = 0;
@@ -1450,7 +1550,8 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   // (Builds with -DASTK_GEMM_TICKET=1: the ticket protocol instead -- kernel: "Split tiles without a zeroing launch", measured, off.)
   const bool ticket_on = ASTK_GEMM_TICKET && tune_on(TUNE_GEMM_TICKET);
   grp.tick = nullptr;
-  bool need_zero = !aligned && any_store && G > 1;
+  const bool fixup = det && !aligned && prec == PREC_BF16X3 && TL == 128 && TLM == 128;
+  bool need_zero = !aligned && any_store && G > 1 && !fixup;
   if (need_zero && ticket_on) {
     long ntiles = 0;
     bool fits = true;
@@ -1527,6 +1628,18 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   } else if (TLM == 256) {
     if constexpr (BK == 16) { ASTK_GEMM_LAUNCH(128, PREC_BF16X3, 256) }      // (three 256-row stages of a 32-deep tile do not fit LDS)
   } else if (TL == 64) { ASTK_GEMM_LAUNCH(64, PREC_BF16X3, 64)
+  } else if (fixup) {
+    switch (layout) {
+      case GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<128, true, true, false, PREC_BF16X3, 128, true>), grid, dim3(gemm_threads(PREC_BF16X3, 128)), 0, s, grp); break;
+      case GEMM_NN:
+        if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<128, true, false, true, PREC_BF16X3, 128, true>), grid, dim3(gemm_threads(PREC_BF16X3, 128)), 0, s, grp);
+        else hipLaunchKernelGGL((gemm_f32_kernel<128, true, false, false, PREC_BF16X3, 128, true>), grid, dim3(gemm_threads(PREC_BF16X3, 128)), 0, s, grp);
+        break;
+      default:
+        if (twolvl) hipLaunchKernelGGL((gemm_f32_kernel<128, false, false, true, PREC_BF16X3, 128, true>), grid, dim3(gemm_threads(PREC_BF16X3, 128)), 0, s, grp);
+        else hipLaunchKernelGGL((gemm_f32_kernel<128, false, false, false, PREC_BF16X3, 128, true>), grid, dim3(gemm_threads(PREC_BF16X3, 128)), 0, s, grp);
+        break;
+    }
   } else { ASTK_GEMM_LAUNCH(128, PREC_BF16X3, 128) }
 #undef ASTK_GEMM_LAUNCH
   ASTK_LAUNCH_CHECK();

@@ -59,7 +59,7 @@ constexpr int SIDE_CHUNKS_MAX = 60;
 struct SidePlan { int s0, cs, n, cap; };
 SidePlan plan_side_fwd(const astk_lstm_stack_desc* d, int rows, int wgs_first_launch) {
   SidePlan sp = {d->T, 0, 0, 0};
-  if (!d->side_stream || lstm_persist_hoisted(d->h) || !tune_on(TUNE_LSTM_SIDE_FWD)) return sp;
+  if (!d->side_stream || lstm_persist_hoisted(d->h) || !tune_on(TUNE_LSTM_SIDE_FWD) || d->deterministic || tune_on(TUNE_GEMM_DETERMINISTIC)) return sp;
   int cap = device_cu_count() - wgs_first_launch;
   if (d->side_wgs > 0) cap = std::min(cap, d->side_wgs);
   cap = cap / 8 * 8;
@@ -97,12 +97,21 @@ __global__ void k_wait_progress(const unsigned* p0, const unsigned* p1, unsigned
     if ((spins & 63u) == 0 && abort_seen(ab)) return;
   }
 }
+// deterministic calls: db[cell][c] += sum over the workgroup rows, in order, of the sums the persistent backward kernel left per row
+struct FoldDbJobs { int n, nby, cols; float* db[16]; const float* part[16]; };
+__global__ void k_fold_db(FoldDbJobs j) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  if (c >= j.cols || q >= j.n) return;
+  float sum = 0.f;
+  for (int by = 0; by < j.nby; ++by) sum += j.part[q][(long)by * j.cols + c];
+  j.db[q][c] += sum;
+}
 __global__ void k_zero_words(unsigned* p, int n, int stride) {
   if ((int)threadIdx.x < n) __hip_atomic_store(p + threadIdx.x * stride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 SidePlan plan_side_bwd(const astk_lstm_stack_desc* d, int rows, int lpl, bool want_dx) {
   SidePlan sp = {d->T, 0, 0, 0};
-  if (!d->side_stream || !want_dx || lstm_persist_hoisted(d->h) || lpl < d->n_layers || low_precision_gemms() || !tune_on(TUNE_LSTM_SIDE_BWD)) return sp;
+  if (!d->side_stream || !want_dx || lstm_persist_hoisted(d->h) || lpl < d->n_layers || low_precision_gemms() || !tune_on(TUNE_LSTM_SIDE_BWD) || deterministic_mode()) return sp;
   int cap = device_cu_count() - lstm_persist_grid_wgs(d->B, d->h, d->n_layers, d->n_dirs, rows);
   if (d->side_wgs > 0) cap = std::min(cap, d->side_wgs);
   cap = cap / 8 * 8;
@@ -127,13 +136,14 @@ struct LstmPlan {
   float* WlT[2][ASTK_MAX_RNN_LAYERS];  // (h, 4h)
   float* WuT[2][ASTK_MAX_RNN_LAYERS];  // (h, 4h) transposed upward weights of layers >= 1 (persistent backward)
   unsigned* counters;                  // arrival counters of the persistent kernels
-  unsigned* zflags;                    // side-stream chunks: forward [SIDE_CHUNKS_MAX + 2] chunk flags, then 2 progress counters of the backward (one word per 256-byte line)
+  unsigned* zflags;                    // side-stream chunks: forward [SIDE_CHUNKS_MAX + 2] chunk flags, then 2 progress counters of the backward and the wait kernels' abort word (one word per 256-byte line)
   float* PR[2][ASTK_MAX_RNN_LAYERS];   // persistent backward (reduce-scatter): partial dh_rec ring of each cell
   float* PD[2][ASTK_MAX_RNN_LAYERS];   // partial dx handed to the layer below (layers >= 1)
   unsigned long long* ax;              // the frames' maximum, folded from desc.x_amax into one line by the forward call (read by both calls)
   float* GATH;                         // (T,B,4h) dz of the reverse stack's layer 0 re-ordered to frame order
   float* DX[2];                        // (T,B,h) gradient wrt a layer's input (layers >= 1)
   float* DC[2][2];                     // dc ping-pong (B,h)
+  float* DBP[2][ASTK_MAX_RNN_LAYERS];  // deterministic calls: [workgroup rows][4h] bias-gradient sums of the persistent backward kernel
   size_t bytes;
 };
 
@@ -162,10 +172,12 @@ int make_plan(const astk_lstm_stack_desc* d, void* ws, bool with_masks, LstmPlan
     P.DC[dd][1] = c.take<float>((size_t)P.B * P.h);
   }
   (void)with_masks;
+  for (int dd = 0; dd < P.nd; ++dd)
+    for (int l = 0; l < P.nl; ++l) P.DBP[dd][l] = c.take<float>((size_t)((P.B + 15) / 16) * 4 * P.h);
   P.GATH = c.take<float>(P.nd > 1 ? tb * 4 * P.h : 4);
   P.ax = c.take<unsigned long long>(AMAX_SLOT_WORDS);
   P.counters = c.take<unsigned>(((size_t)2 * P.nd * P.nl * ((P.B + 15) / 16) + 2) * 64);
-  P.zflags = c.take<unsigned>((size_t)(SIDE_CHUNKS_MAX + 2 + 2) * 64);
+  P.zflags = c.take<unsigned>((size_t)(SIDE_CHUNKS_MAX + 2 + 3) * 64);      // chunk flags (+ 2 zero words), two progress counters, the wait kernels' abort word
   {
     const bool pp = lstm_persist_applicable(P.T, P.B, P.h, P.nl, P.nd);
     for (int dd = 0; dd < P.nd; ++dd)
@@ -438,6 +450,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
   hipStream_t sr = recurrence_stream ? (hipStream_t)recurrence_stream : s;
   ASTK_CHECK_DESC(d, astk_lstm_stack_desc);
   PrecScope prec_scope(d->precision, d->gemm_operands);
+  DetScope det_scope(d->deterministic);
   LstmPlan P;
   ASTK_TRY(make_plan(d, ws, masks != nullptr, P));
   const size_t need = astk_lstm_stack_workspace_bytes(d);
@@ -468,6 +481,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
           c.PD_up = top ? nullptr : P.PD[dd][l + 1];
         }
         c.db = gr[dd * P.nl + l].db;      // the recurrence kernel sums its dz columns itself
+        c.db_part = deterministic_mode() ? P.DBP[dd][l] : nullptr;
         c.gates = P.ZG[dd][l];
         c.C = P.CC[dd][l];
         c.mask = masks ? masks + ((size_t)dd * P.nl + l) * T * bh : nullptr;
@@ -566,6 +580,15 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
       }
     }
     ASTK_TRY(stream_order(sr, s));
+    if (deterministic_mode()) {
+      FoldDbJobs j;
+      j.n = P.nd * P.nl; j.cols = 4 * h;
+      const int rows_d = lstm_persist_hoisted(h) ? 16 : rows_b;
+      j.nby = (B + rows_d - 1) / rows_d;
+      for (int i = 0; i < j.n; ++i) { j.db[i] = cells[i].db; j.part[i] = cells[i].db_part; }
+      hipLaunchKernelGGL(k_fold_db, dim3(cdiv(4 * h, 256), j.n), dim3(256), 0, s, j);
+      ASTK_LAUNCH_CHECK();
+    }
   }
   GemmArgs wg[GEMM_GROUP_MAX];   // weight-gradient products, issued as grouped launches
   int nwg = 0;

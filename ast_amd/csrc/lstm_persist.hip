@@ -1256,10 +1256,12 @@ struct PersistCellHost {
 // workgroups -> 3 launches of 2 layers; batch 64 at the shipped width: 2 launches).  0 = not applicable.
 bool lstm_persist_hoisted(int h);
 // Batch rows per workgroup: 16, or 32 (two 16-row tiles against one set of resident weight fragments; h <= 256, where both tiles' fragments
-// fit the registers).  32-row workgroups halve the grid -- batch 64 at the shipped width and the 6-layer stacks run in half the launches,
-// and at batch 32 the stack leaves 160 CUs free instead of 64 -- at ~15 % more time per step (two tiles' MFMAs and epilogues per hand-off).
-// Tuning knob lstm.rows32: 1 = whenever possible, 0 = never, -1 (default) = when it spares launches, or when the caller runs side-stream work
-// beside the recurrences (`side`), which is what the freed CUs are for.
+// fit the registers).  32-row workgroups halve the grid -- but a step is only ~40 % hand-off latency: the two tiles' splits, MFMAs, LDS
+// reduction and gate epilogue add up, and a step takes 4.4 / 5.3 us (forward / backward) instead of 2.9 / 3.6 (MEASURED, round 6: +50 %, not
+// the +15 % the plan assumed).  So 32 rows pay exactly where they spare LAUNCHES (batch 64 at the shipped width: one launch of 4.4 us steps
+// instead of two of 2.9), not as a way to free CUs at batch 32 (the time-chunked products that would use the 160 free CUs recover 0.14 ms of
+// the 0.6 ms the slower recurrences cost: r6_ab tables in profiles/).
+// Tuning knob lstm.rows32: 1 = whenever possible, 0 = never, -1 (default) = when it spares launches.
 int lstm_persist_rows(int B, int h, int nl, int nd, bool side) {
   const int knob = (int)tune(TUNE_LSTM_ROWS32);
   if (knob == 0 || h > 256 || B <= 16) return 16;
@@ -1267,8 +1269,8 @@ int lstm_persist_rows(int B, int h, int nl, int nd, bool side) {
   const long cus = device_cu_count();
   const long wg16 = (long)(h / 16) * ((B + 15) / 16) * nd * nl, wg32 = (long)(h / 16) * ((B + 31) / 32) * nd * nl;
   const long launches16 = (wg16 + cus - 1) / cus, launches32 = (wg32 + cus - 1) / cus;
-  if (launches32 < launches16) return 32;
-  return side ? 32 : 16;
+  (void)side;
+  return launches32 < launches16 ? 32 : 16;
 }
 int lstm_persist_layers_per_launch(int B, int h, int nl, int nd, int rows) {
   const long per_layer = (long)(h / 16) * ((B + rows - 1) / rows) * nd;

@@ -96,10 +96,11 @@ static const TuneEntry g_tune_table[TUNE_COUNT] = {
     {"lstm.hoist", 1},             // hoisted form of the persistent kernels at h = 1024
     {"lstm.x3", 1},                // bf16x3 fragments inside the recurrences (0: f32-input MFMAs under the bf16x3 arithmetic)
     {"lstm.x4", 1},                // ... with the weights' lo plane in LDS at h = 512 / 1024
-    {"lstm.rows32", -1},           // 32 batch rows per recurrence workgroup: 1 always, 0 never, -1 = when it spares launches or an overlap partner exists
+    {"lstm.rows32", -1},           // 32 batch rows per recurrence workgroup: 1 always, 0 never, -1 = when it spares launches
     {"lstm.overlap_chunk", 0},     // time steps per chunk of the layer-0 products that run beside the recurrences (side_stream); 0 = from the free CUs
     {"lstm.side_fwd", 1},          // side_stream: the layer-0 input projection in chunks beside the forward recurrence
-    {"lstm.side_bwd", 1},          // side_stream: the input gradient in chunks behind the backward recurrence's progress
+    {"lstm.side_bwd", 0},          // side_stream: the input gradient in chunks behind the backward recurrence's progress (off: with 64 free CUs the
+                                   // decoder's parameter gradients already fill them; measured slower at 160, profiles/r6_ab_side.txt)
     {"row.longk", 2048},           // row-panel kernels split K over eight waves from this K on (0 = never)
     {"persist.spin_limit", 0},     // bound of the persistent kernels' spins in polls (0 = the default, 2^22)
     {"colreduce.blocks", 256},     // blocks of a column reduction
@@ -795,6 +796,7 @@ int astk_gemm_f32_ex(int layout, int M, int N, int K, const float* A, long lda, 
                      const float* bias, int mode, int ksplit, int batch, long sA, long sB, long sC, int precision, void* stream) {
   ASTK_CHECK(precision >= ASTK_PREC_DEFAULT && precision <= ASTK_PREC_F32, "gemm: precision must be 0 (default), 1 (fp16x2), 2 (bf16x3) or 3 (f32): the enum of astk.h");
   PrecScope ps(precision, ASTK_OPERANDS_DEFAULT);
+  DetScope ds(0);        // (the process default: astk_set_tuning("gemm.deterministic", 1) makes plain GEMM calls deterministic too)
   GemmArgs g = gemm_args(M, N, K, mat(A, lda), mat(B, ldb), C, ldc, bias, mode, ksplit);
   g.batch = batch < 1 ? 1 : batch;
   g.sA = sA; g.sB = sB; g.sC = sC;

@@ -82,6 +82,8 @@ class NN:
         if prec not in (None, "bf16x3", "f32", "fp16x2"):
             raise ValueError("extras.gemm_precision must be 'bf16x3', 'f32' or 'fp16x2'")
         self.model.gemm_operands, self.model.gemm_precision = ops, prec
+        # extension key: extras.deterministic = true -> every gradient sum in a fixed order (include/astk.h `deterministic`; a few per cent slower)
+        self.model.deterministic = bool(self.cfg.train.get("extras", {}).get("deterministic", False))
         self.init_optimizer(self.cfg.train["optimizer"])
         if self.cfg.train.get("save_optimizer", False) and self.loaded_from and self.model.arena is not None:
             # extension key: checkpoints also carry the Adam moments, so a resumed run continues instead of re-warming them

@@ -230,6 +230,11 @@ class SpeechEncoderDecoder:
         # gemm_operands "fp16" = single-term fp16 operands for the eligible products (BASELINE configs[4]; reduced precision).
         self.gemm_precision = None
         self.gemm_operands = None
+        # Deterministic backward (-> the descriptors' `deterministic` field, astk.h): every accumulated sum of the backward pass in a fixed
+        # order -- split tiles of the batched products through the fix-up workspace instead of float atomics, ordered column / embedding /
+        # bias sums, no side-stream work.  A few per cent slower; two runs over the same batches are then bit-identical in EVERY gradient,
+        # which is what lets a soak see a hand-off race in the backward half of the step (train_cfg.json: extras.deterministic).
+        self.deterministic = False
 
     # ------------------------------------------------------------------ parameters
     def materialize(self, in_dim, values=None, seed=0):
@@ -362,6 +367,7 @@ class SpeechEncoderDecoder:
         prec, ops = _lib.PREC_BY_NAME[self.gemm_precision], _lib.OPERANDS_BY_NAME[self.gemm_operands]
         for k in ("cd", "ld", "dd"):
             st[k].precision, st[k].gemm_operands = prec, ops
+            st[k].deterministic = 1 if self.deterministic else 0
         return st
 
     def _shape_state_cached(self, B, T, D, L):
@@ -617,8 +623,8 @@ class SpeechEncoderDecoder:
         CONCURRENTLY with it.  HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and two streams that
         share one execute in order whatever their events say -- the flag-gated hand-offs between the recurrence kernels and the chunked
         products beside them need true concurrency (in one queue the consumer would sit in front of its producer until its bounded spin
-        times out), so every candidate is probed once (a 300 us spin on one stream, a trivial kernel on the other)."""
-        if not self.side_stream_on or self.enc_variant is not None:
+        times out), so every candidate is probed once (a 3 ms spin on one stream, a trivial kernel on the other)."""
+        if not self.side_stream_on or self.enc_variant is not None or self.deterministic:
             return None
         main = torch.cuda.current_stream(self.device)
         if main.cuda_stream == 0:
@@ -635,11 +641,15 @@ class SpeechEncoderDecoder:
         return self._side
 
     def _concurrent(self, a, b):
-        """True if a kernel on stream b runs while stream a is busy (one 300 us spin on a, a trivial kernel on b)."""
+        """True if a kernel on stream b runs while stream a is busy (one 3 ms spin on a, a trivial kernel on b)."""
         lib = _lib.load()
-        probe = self._ws.setdefault("probe", torch.zeros(4, device=self.device))
+        probe = self._ws.get("probe")
+        if probe is None:
+            probe = self._ws["probe"] = torch.zeros(4, device=self.device)
+            check(lib.astk_spin(10, None, C.c_void_p(a.cuda_stream)))              # (first launches load the code objects: not inside the probe)
+            check(lib.astk_scale_f32(_vp(probe), 4, 1.0, C.c_void_p(a.cuda_stream)))
         torch.cuda.synchronize(self.device)
-        check(lib.astk_spin(300, None, C.c_void_p(a.cuda_stream)))
+        check(lib.astk_spin(3000, None, C.c_void_p(a.cuda_stream)))
         ea, eb = torch.cuda.Event(), torch.cuda.Event()
         ea.record(a)
         check(lib.astk_scale_f32(_vp(probe), 4, 1.0, C.c_void_p(b.cuda_stream)))

@@ -1,5 +1,6 @@
 """bench.py with tuning knobs from ASTK_BENCH_KNOBS="key=value,key=value" (SIDE=0 switches the model's side stream off): same-box A/B runs."""
 import os, sys, runpy
+import torch  # noqa: F401  (first: libastk.so must bind to the HIP runtime torch ships, not load /opt/rocm's beside it)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ast_amd import _lib
 for kv in os.environ.get("ASTK_BENCH_KNOBS", "").split(","):

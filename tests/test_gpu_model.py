@@ -719,6 +719,55 @@ def test_forward_pass_is_bit_reproducible_from_run_to_run():
                 assert torch.equal(got[1], ref[1]), it
 
 
+@pytest.mark.parametrize("model_name,B", [("cfg1", 32), ("es_en_20h", 32), ("cfg1", 64)])
+def test_backward_pass_is_bit_reproducible_in_deterministic_mode(model_name, B):
+    """model.deterministic (-> astk.h `deterministic` of the three descriptors): the whole train step -- forward AND backward -- at BASELINE
+    configs[1]'s shape (and the shipped 3-decoder-layer model, and batch 64), 12 times over two alternating batches at fixed weights: every
+    evaluation of a batch must leave the SAME BITS in every gradient.  Without the mode the backward's weight-gradient products sum their
+    split tiles with float atomics in arrival order (differences of 2-6e-10 of the clip norm from run to run: harmless, but they hide
+    exactly the kind of error a hand-off race in the backward makes -- round 4's was 1e-4 of two tensors once in ~4000 launches); with
+    it the split tiles go through the fix-up workspace (gemm.hip), column / embedding / bias sums are ordered, nothing runs on a side
+    stream.  Also: the deterministic gradients agree with the default mode's to float-atomics accuracy (same sums, other order)."""
+    import bench
+    import copy
+    from ast_amd.seq2seq import using_config
+    cfg = copy.deepcopy(bench.MODEL_CFG)
+    if model_name == "es_en_20h":
+        cfg["rnn_config"]["dec_layers"] = 3
+    V = cfg["rnn_config"]["dec_vocab_size"]
+    T, D, L = 800, 80, 40
+    P, X, y = _make(cfg, B, T, D, L, V)
+    X2 = np.roll(X, 1, axis=0) * 0.9
+    m = _gpu_model(cfg, P, D, V)
+    m.inject["use_truth"] = [1 if (i % 5) else 0 for i in range(L - 1)]
+    m.inject["use_truth"][0] = 1
+    sets = [(torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()), (torch.from_numpy(np.ascontiguousarray(X2, np.float32)).cuda(), torch.from_numpy(y).cuda())]
+    compute = torch.cuda.Stream()
+
+    def evaluate(which):
+        m.rng_seed, m._rng_offset = 777, 0                  # the same dropout masks and speech noise in every evaluation
+        with torch.cuda.stream(compute), using_config("train", True):
+            loss = m.forward_loss(sets[which][0], sets[which][1], 0.8, add_noise=0.25)
+            m.cleargrads()
+            loss.backward()
+            out = (float(loss.data), m.arena.grad.clone())
+        torch.cuda.synchronize()
+        return out
+    m.deterministic = True
+    ref = [evaluate(0), evaluate(1)]
+    assert m._side is None, "deterministic steps must not use the side stream"
+    for it in range(5):
+        for which in (1, 0):
+            loss, grad = evaluate(which)
+            assert loss == ref[which][0], (it, which, loss, ref[which][0])
+            assert torch.equal(grad, ref[which][1]), (it, which, float((grad - ref[which][1]).abs().max()))
+    m.deterministic = False
+    loss, grad = evaluate(0)
+    assert loss == ref[0][0]
+    scale = float(ref[0][1].abs().max())
+    assert float((grad - ref[0][1]).abs().max()) <= 2e-5 * scale
+
+
 @pytest.mark.parametrize("dec_layers", [1, 2])
 def test_deferred_cleargrads_cannot_be_observed(dec_layers):
     """cleargrads() behind a forward_loss defers its zero fill to the backward pass (the decoder backward's first fill launch takes the

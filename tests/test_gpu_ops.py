@@ -327,10 +327,12 @@ def test_lstm_stack_32_row_workgroups_and_side_stream(lib, tune, T, B, in_dim, h
     forces what the library otherwise chooses when it spares launches or frees CUs for side-stream work): full, ragged (33, 17, 40, 48) and
     many (200) batch tiles, 1-3 layers, masks, every arithmetic scheme.  (b) `side`: the layer-0 input projection in time chunks on a second
     stream beside the forward recurrence (astk_lstm_stack_desc.side_stream; chunks of 4 steps here so that small T already has several),
-    flag-gated inside the layer-0 cells.  Same float64 reference as test_lstm_stack."""
+    flag-gated inside the layer-0 cells; and the input gradient in chunks behind the backward recurrence's progress counter (lstm.side_bwd).
+    Same float64 reference as test_lstm_stack."""
     tune("lstm.rows32", 1, lib)
     if side:
         tune("lstm.overlap_chunk", 4, lib)
+        tune("lstm.side_bwd", 1, lib)          # (off by default: measured slower on the train step; the mechanism stays tested)
     _lstm_stack_case(lib, T, B, in_dim, h, nl, masks, side=side)
 
 
@@ -338,12 +340,14 @@ def _concurrent_stream(lib, main):
     """A second stream that really executes beside `main` (HIP multiplexes streams onto a few hardware queues; two streams that share one run
     in order, and a flag-gated consumer would then sit in front of its producer): probed like ast_amd/seq2seq.py does."""
     probe = torch.zeros(4, device="cuda")
+    ok(lib, lib.astk_spin(10, None, C.c_void_p(main.cuda_stream)))            # (first launches load the code objects: not inside the probe)
+    ok(lib, lib.astk_scale_f32(vp(probe), 4, 1.0, C.c_void_p(main.cuda_stream)))
     for _ in range(8):
         cand = torch.cuda.Stream()
         good = True
         for a, b in ((main, cand), (cand, main)):
             torch.cuda.synchronize()
-            ok(lib, lib.astk_spin(300, None, C.c_void_p(a.cuda_stream)))
+            ok(lib, lib.astk_spin(3000, None, C.c_void_p(a.cuda_stream)))
             ea, eb = torch.cuda.Event(), torch.cuda.Event()
             ea.record(a)
             ok(lib, lib.astk_scale_f32(vp(probe), 4, 1.0, C.c_void_p(b.cuda_stream)))
@@ -987,6 +991,41 @@ def test_gemm_split_tiles_of_store_products_overwrite_what_the_buffer_held(lib, 
     tens in the deep ones; the last runs the 12-wave kernel under the default arithmetic) into NaN-poisoned outputs, several launches in
     a row: the split tiles are zeroed in front of the launch, the contributions are atomic adds."""
     _split_tiles_body(lib, M, N, K, 5)
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K,mode", [(512, 1152, 38400, 2), (260, 200, 51200, 1), (4100, 1150, 332, 0), (1100, 3072, 1024, 0), (300, 260, 20000, 0)])
+def test_gemm_deterministic_split_tiles_are_bit_reproducible_and_right(lib, tune, layout, M, N, K, mode):
+    """The fix-up epilogue of deterministic calls (gemm.hip "Deterministic split tiles"; here through the process default gemm.deterministic):
+    every contributor of a split tile leaves its accumulator block in the workspace, the last one sums the blocks in workgroup order and writes
+    the tile.  Weight-gradient shapes (a few tiles, thousands of k-iterations, up to ~14 contributors), hybrid launches (whole-tile waves +
+    stream-K remainder), store / accumulate / atomic output: (a) right against float64, (b) TEN launches give the same bits -- which the
+    default schedule (float atomics in arrival order) does not promise for these shapes, (c) nothing outside N is written."""
+    tune("gemm.deterministic", 1, lib)
+    rng = np.random.default_rng(M + N + K + layout)
+    pad4 = lambda n: (n + 3) // 4 * 4
+    A = (rng.standard_normal((M, K)) * 0.1).astype(np.float32)
+    B = (rng.standard_normal((N, K)) * 0.1).astype(np.float32)
+    ref = (torch.from_numpy(A).double().cuda() @ torch.from_numpy(B).double().cuda().T).cpu().numpy()
+
+    def store(X, transpose):
+        X = X.T if transpose else X
+        P = np.zeros((X.shape[0], pad4(X.shape[1]) + 4), np.float32)
+        P[:, :X.shape[1]] = X
+        return P
+    Ad, Bd = store(A, layout == 2), store(B, layout != 0)
+    a, b = dev(Ad), dev(Bd)
+    ldc = pad4(N) + 4
+    first = None
+    for rep in range(10):
+        c = torch.full((M, ldc), 0.5, device="cuda")
+        ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(a), Ad.shape[1], vp(b), Bd.shape[1], vp(c), ldc, None, mode, 1, 1, 0, 0, 0, stream()))
+        if first is None:
+            first = c.clone()
+            close(c[:, :N], (0.5 if mode != 0 else 0.0) + ref, rtol=3e-5, msg=f"layout {layout} mode {mode}")
+            assert float(c[:, N:].min()) == 0.5 and float(c[:, N:].max()) == 0.5, "wrote outside N"
+        else:
+            assert torch.equal(c, first), (rep, float((c - first).abs().max()))
 
 
 @pytest.mark.parametrize("M,N,K", [(4100, 1150, 332), (300, 260, 20000), (130, 70, 5000), (8200, 1930, 1100)])
