@@ -54,7 +54,7 @@ constexpr int SIDE_CHUNKS_MAX = 60;
 // capped at `cap` workgroups (the CUs the recurrence grid leaves free), a one-lane kernel behind each chunk raising its flag.  A chunk holds as
 // many 128-row tile rows as give `cap` tiles over all directions, so a chunk launch is ONE WHOLE TILE PER WORKGROUP: plain stores, no split
 // tiles, the same sum order in every run.  s0 is the smallest head for which, by a rate model (a tile pass ~ 0.66 us per 16 k + 15 us; a
-// recurrence step 2.9 / 3.3 us at 16 / 32 rows per workgroup, 3.8 at h = 512), no chunk is late; if the model is wrong the layer-0 cells wait
+// recurrence step 2.9 / 4.4 us at 16 / 32 rows per workgroup, 3.8 at h = 512), no chunk is late; if the model is wrong the layer-0 cells wait
 // on a flag (bounded like every other hand-off) -- slower, never wrong.  n = 0: everything in line.
 struct SidePlan { int s0, cs, n, cap; };
 SidePlan plan_side_fwd(const astk_lstm_stack_desc* d, int rows, int wgs_first_launch) {
@@ -70,11 +70,13 @@ SidePlan plan_side_fwd(const astk_lstm_stack_desc* d, int rows, int wgs_first_la
   if (cs <= 0) cs = tile_rows * 128 / d->B;
   if (cs < 4 || d->T < 3 * cs / 2) return sp;
   const double t_chunk = ((d->in_dim + 15) / 16) * 0.66 + 15.0;           // one tile pass (every workgroup of a chunk launch does one)
-  const double r_step = (d->h > 256 ? 3.8 : rows == 32 ? 3.3 : 2.9) * 0.9; // (10 % margin)
+  const double r_step = (d->h > 256 ? 3.8 : rows == 32 ? 4.4 : 2.9) * 0.9; // (10 % margin)
+  // (the side stream starts together with the in-line head, so the chunks have the head's time -- ~190 TFLOP/s on the whole chip -- on top)
+  const double head_step = 0.8 * d->n_dirs * 2.0 * d->B * 4.0 * d->h * d->in_dim / 190e6;
   for (int n = std::min(SIDE_CHUNKS_MAX, (d->T - 2) / cs); n >= 1; --n) {
     const int s0 = d->T - n * cs;
     bool ok = s0 >= 2;
-    for (int k = 0; k < n && ok; ++k) ok = (k + 1) * t_chunk <= (s0 + (double)k * cs) * r_step;
+    for (int k = 0; k < n && ok; ++k) ok = (k + 1) * t_chunk <= s0 * head_step + (s0 + (double)k * cs) * r_step;
     if (ok) { sp.s0 = s0; sp.cs = cs; sp.n = n; sp.cap = cap; return sp; }
   }
   return sp;
