@@ -79,7 +79,7 @@ int device_cu_count();                                 // multiProcessorCount of
 // variables the library read in rounds 1-5; the product library reads NO environment variable).
 enum TuneKey {
   TUNE_GEMM_TILE, TUNE_GEMM_T256_ABOVE, TUNE_GEMM_GRID, TUNE_GEMM_HYBRID, TUNE_GEMM_CHUNK, TUNE_GEMM_CHUNK_DIV, TUNE_GEMM_LOG, TUNE_GEMM_TICKET,
-  TUNE_GEMM_DETERMINISTIC,
+  TUNE_GEMM_DETERMINISTIC, TUNE_GEMM_FORWARD_PAIRS,
   TUNE_CONV_DIRECT0, TUNE_CONV_SEQ_FWD, TUNE_CONV_SEQ_BWD, TUNE_CONV_SEQ_STATS_BLOCKS, TUNE_CONV_SEQ_APPLY_BLOCKS,
   TUNE_DEC_PERSIST, TUNE_DEC_B6_SPLIT, TUNE_DEC_B6_FUSED, TUNE_DEC_WIDE,
   TUNE_LSTM_PERSIST, TUNE_LSTM_HOIST, TUNE_LSTM_X3, TUNE_LSTM_X4, TUNE_LSTM_ROWS32, TUNE_LSTM_OVERLAP_CHUNK, TUNE_LSTM_SIDE_FWD, TUNE_LSTM_SIDE_BWD,

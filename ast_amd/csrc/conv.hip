@@ -1106,7 +1106,10 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
   if (!conv0_direct(d)) ASTK_TRY(fill_zero(P.zero_fwd_from, zero_fwd, s));       // (the direct layer-0 kernel does it on its way in)
   // the backward's region: zeroed by this call's last kernel (train) -- a fill launch less in the backward call
   const bool seq_out_zeroes = train != 0;
-  conv0_path_record(ws, conv0_direct(d), seq_out_zeroes);
+  // (the layer-0 path is recorded now -- the backward must refuse a workspace whose forward took the other path even if this call fails
+  //  half-way --, the "backward region is clean" mark only behind the LAST launch below: a forward call that fails before its last kernel
+  //  was enqueued must not leave a mark that spares the backward its own zero fill; round-5 advice)
+  conv0_path_record(ws, conv0_direct(d), false);
   void* const zb_from = seq_out_zeroes ? (void*)P.stat[0] : nullptr;
   bool c0_stats = false;
   if (conv0_direct(d)) {
@@ -1188,6 +1191,7 @@ int astk_conv_bn_relu_fwd_sync(const astk_cnn_desc* d, const astk_cnn_layer_para
       ASTK_LAUNCH_CHECK();
     }
   }
+  if (seq_out_zeroes) conv0_path_record(ws, conv0_direct(d), true);      // every launch of the call went out: its last kernel zeroes the backward's region
   return 0;
 }
 

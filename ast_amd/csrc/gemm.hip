@@ -1514,7 +1514,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   // guarantee -- at most TWO contributors per split tile, so that the float atomics commute and the forward pass is bit-reproducible whatever
   // shapes occur -- by shrinking the grid until every stream-K range is at least as deep as the deepest tile, or to exactly two half-tile
   // ranges per tile where the depths allow it (round-5 advice: the guarantee used to depend on which shapes happened to come by).
-  if (tl_forward && !aligned && grp.dp_waves == 0) {
+  if (tl_forward && !aligned && grp.dp_waves == 0 && tune_on(TUNE_GEMM_FORWARD_PAIRS)) {
     int max_kt = 0;
     bool uniform = true;
     for (int i = 0; i < grp.n; ++i) { max_kt = std::max(max_kt, grp.g[i].kt); uniform = uniform && grp.g[i].kt == grp.g[0].kt; }

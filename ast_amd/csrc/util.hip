@@ -83,6 +83,7 @@ static const TuneEntry g_tune_table[TUNE_COUNT] = {
     {"gemm.log", 0},               // print every launch's shape and schedule to stderr
     {"gemm.ticket", 1},            // libastk_test.so only: split tiles handed over by tickets instead of a zeroing launch
     {"gemm.deterministic", 0},     // process default of the descriptors' `deterministic` field (fixed-order split-tile sums, astk.h)
+    {"gemm.forward_pairs", 1},     // forward launches outside the hybrid branch: grid shrunk until a split tile has <= 2 contributors
     {"conv.direct0", 1},           // layer 0 as a direct convolution (0: im2col + GEMM)
     {"conv.seq_fwd", 1},           // BatchNorm + ReLU written straight into the LSTM's (T'',B,C*F') layout by the tiled kernel
     {"conv.seq_bwd", 1},           // the last layer's BatchNorm backward reads that layout itself
@@ -831,6 +832,10 @@ int astk_persist_status(unsigned* mask_out, int reset) {
   if (reset && v != 0) {
     hipLaunchKernelGGL(k_status_reset, dim3(1), dim3(1), 0, (hipStream_t)0, st);
     ASTK_LAUNCH_CHECK();
+    // (the clip norm's arrival counter too: a norm launch that died with the aborted step would have left it short, and every later
+    //  norm of the process wrong -- round-5 advice)
+    const unsigned zero = 0;
+    ASTK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sq_ctr), &zero, sizeof(zero)));
     ASTK_HIP(hipDeviceSynchronize());
   }
   return 0;

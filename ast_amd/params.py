@@ -5,6 +5,7 @@ parameter 16-byte aligned, in Chainer's layouts and under Chainer's save_npz nam
 flat buffer makes `cleargrads` a single memset, the WeightDecay -> GradientClipping -> Adam hooks of
 nn.py:81-119 two kernel launches, and the data-parallel gradient exchange a single RCCL all-reduce.
 """
+from collections.abc import Mapping
 import numpy as np
 import torch
 
@@ -112,28 +113,33 @@ def init_values(cfg, in_dim, vocab_size=None, seed=0):
     return out
 
 
-class _FlushingViews(dict):
-    """name -> gradient view; any read performs the arena's deferred zero fill first (ParamArena.flush_zero)."""
+class _FlushingViews(Mapping):
+    """name -> gradient view; ANY read performs the arena's deferred zero fill first (ParamArena.flush_zero).  A Mapping, not a dict
+    subclass (round-5 advice: dict(gviews), {**gviews}, .copy() and CPython's fast iteration paths bypass overridden dict methods and
+    would hand out gradients cleargrads() has cleared): every way in -- [], get, items, values, iteration, dict(...) -- goes through
+    __getitem__ / __iter__ here.  (A view a caller obtained EARLIER and kept is an alias of the arena like any tensor slice; it shows the
+    fill once something has flushed it.)"""
 
     def __init__(self, arena):
-        super().__init__()
         self._arena = arena
+        self._views = {}
+
+    def _put(self, k, v):                 # (construction only)
+        self._views[k] = v
+
+    def raw(self, k):                     # an address, not a read: no flush
+        return self._views[k]
 
     def __getitem__(self, k):
         self._arena.flush_zero()
-        return dict.__getitem__(self, k)
+        return self._views[k]
 
-    def get(self, k, default=None):
+    def __iter__(self):
         self._arena.flush_zero()
-        return dict.get(self, k, default)
+        return iter(self._views)
 
-    def items(self):
-        self._arena.flush_zero()
-        return dict.items(self)
-
-    def values(self):
-        self._arena.flush_zero()
-        return dict.values(self)
+    def __len__(self):
+        return len(self._views)
 
 
 class ParamArena:
@@ -163,7 +169,7 @@ class ParamArena:
         for name, shp in self.shapes.items():
             o, n = self.offsets[name], int(np.prod(shp))
             self.views[name] = self.data[o:o + n].view(shp)
-            dict.__setitem__(self.gviews, name, self._grad[o:o + n].view(shp))
+            self.gviews._put(name, self._grad[o:o + n].view(shp))
 
     @property
     def grad(self):
@@ -192,7 +198,7 @@ class ParamArena:
         return self.views[name].data_ptr()
 
     def g(self, name):
-        return dict.__getitem__(self.gviews, name).data_ptr()       # (an address, not a read: no flush)
+        return self.gviews.raw(name).data_ptr()       # (an address, not a read: no flush)
 
     def load(self, values):
         for name in self.shapes:

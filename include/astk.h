@@ -91,7 +91,7 @@ int astk_get_gemm_precision(void);
  * refuse a workspace whose forward took another kernel path).  Keys (default):
  *   gemm.tile (0 = per launch; 64 | 128 | 256 forces the block tile)     gemm.t256_above (2e10 flops: the 12-wave 256 x 128 kernel from here on)
  *   gemm.grid (-1 = per launch)   gemm.hybrid (1)   gemm.chunk (1)   gemm.chunk_div (4)   gemm.log (0: 1 prints every launch to stderr)
- *   gemm.deterministic (0: process default of the descriptors' `deterministic` field)   gemm.ticket (libastk_test.so only)
+ *   gemm.deterministic (0: process default of the descriptors' `deterministic` field)   gemm.forward_pairs (1)   gemm.ticket (libastk_test.so only)
  *   conv.direct0 (1)   conv.seq_fwd (1)   conv.seq_bwd (1)   conv.seq_stats_blocks (1024)   conv.seq_apply_blocks (1024)
  *   dec.persist (1: 0 = per-launch decoder loop)   dec.b6_split (1)   dec.b6_fused (1)   dec.wide (1)
  *   lstm.persist (1: 0 = one fused-cell launch per step)   lstm.hoist (1)   lstm.x3 (1)   lstm.x4 (1)
@@ -398,7 +398,10 @@ int astk_softmax_ce_fwd(int B, int V, long ld, float* logits_inout, const int32_
                         const float* class_weight, float inv_count, float* loss_rows, int32_t* argmax, void* stream);
 
 /* ---------------------------------------------------------------- optimizer  (nn.py:81-119, Chainer-sem A7/A8)
- * One flat parameter / gradient buffer.  sqnorm[0] = sum (g + l2*p)^2 in float64 (the clip norm of hook order
+ * One flat parameter / gradient buffer.  ONE norm launch at a time per process: astk_grad_sqnorm(_scaled) folds its per-block partial
+ * sums through a process-wide scratch (no zeroing launch in front, a block-order sum whatever order the blocks finish in), so calls must
+ * be ordered on one stream at a time -- which a train step's single optimizer is; astk_persist_status(.., reset = 1) also re-arms it.
+ * sqnorm[0] = sum (g + l2*p)^2 in float64 (the clip norm of hook order
  * WeightDecay -> GradientClipping); the step applies decay, the clip rate min(1, clip/sqrt(sqnorm)) and
  * AMSGrad-Adam with lr_t = alpha*sqrt(1-b2^t)/(1-b1^t) computed by the caller.  Both update kernels leave p (and the moments)
  * untouched while the persistent kernels' sticky status word is non-zero (a kernel of the step timed out: the gradients are
