@@ -82,7 +82,7 @@ enum TuneKey {
   TUNE_GEMM_DETERMINISTIC, TUNE_GEMM_FORWARD_PAIRS,
   TUNE_CONV_DIRECT0, TUNE_CONV_SEQ_FWD, TUNE_CONV_SEQ_BWD, TUNE_CONV_SEQ_STATS_BLOCKS, TUNE_CONV_SEQ_APPLY_BLOCKS,
   TUNE_DEC_PERSIST, TUNE_DEC_B6_SPLIT, TUNE_DEC_B6_FUSED, TUNE_DEC_WIDE,
-  TUNE_LSTM_PERSIST, TUNE_LSTM_HOIST, TUNE_LSTM_X3, TUNE_LSTM_X4, TUNE_LSTM_ROWS32, TUNE_LSTM_OVERLAP_CHUNK, TUNE_LSTM_SIDE_FWD, TUNE_LSTM_SIDE_BWD,
+  TUNE_LSTM_PERSIST, TUNE_LSTM_HOIST, TUNE_LSTM_X3, TUNE_LSTM_X4, TUNE_LSTM_ROWS32, TUNE_LSTM_OVERLAP_CHUNK, TUNE_LSTM_SIDE_FWD, TUNE_LSTM_SIDE_BWD, TUNE_LSTM_DUO_SIDE,
   TUNE_ROW_LONGK, TUNE_PERSIST_SPIN_LIMIT, TUNE_COLREDUCE_BLOCKS,
   TUNE_COUNT
 };

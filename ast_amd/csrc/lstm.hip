@@ -70,7 +70,7 @@ SidePlan plan_side_fwd(const astk_lstm_stack_desc* d, int rows, int wgs_first_la
   if (cs <= 0) cs = tile_rows * 128 / d->B;
   if (cs < 4 || d->T < 3 * cs / 2) return sp;
   const double t_chunk = ((d->in_dim + 15) / 16) * 0.66 + 15.0;           // one tile pass (every workgroup of a chunk launch does one)
-  const double r_step = (d->h > 256 ? 3.8 : rows == 32 ? 4.4 : 2.9) * 0.9; // (10 % margin)
+  const double r_step = (d->h > 256 ? 3.8 : rows == 32 ? 4.4 : rows == 33 ? 3.3 : 2.9) * 0.9; // (10 % margin)
   // (the side stream starts together with the in-line head, so the chunks have the head's time -- ~190 TFLOP/s on the whole chip -- on top)
   const double head_step = 0.8 * d->n_dirs * 2.0 * d->B * 4.0 * d->h * d->in_dim / 190e6;
   for (int n = std::min(SIDE_CHUNKS_MAX, (d->T - 2) / cs); n >= 1; --n) {
@@ -175,10 +175,10 @@ int make_plan(const astk_lstm_stack_desc* d, void* ws, bool with_masks, LstmPlan
   }
   (void)with_masks;
   for (int dd = 0; dd < P.nd; ++dd)
-    for (int l = 0; l < P.nl; ++l) P.DBP[dd][l] = c.take<float>((size_t)((P.B + 15) / 16) * 4 * P.h);
+    for (int l = 0; l < P.nl; ++l) P.DBP[dd][l] = c.take<float>((size_t)(2 * ((P.B + 31) / 32)) * 4 * P.h);
   P.GATH = c.take<float>(P.nd > 1 ? tb * 4 * P.h : 4);
   P.ax = c.take<unsigned long long>(AMAX_SLOT_WORDS);
-  P.counters = c.take<unsigned>(((size_t)2 * P.nd * P.nl * ((P.B + 15) / 16) + 2) * 64);
+  P.counters = c.take<unsigned>(((size_t)2 * P.nd * P.nl * (2 * ((P.B + 31) / 32)) + 2) * 64);      // (an even number of 16-row tiles: the 32-row forms)
   P.zflags = c.take<unsigned>((size_t)(SIDE_CHUNKS_MAX + 2 + 3) * 64);      // chunk flags (+ 2 zero words), two progress counters, the wait kernels' abort word
   {
     const bool pp = lstm_persist_applicable(P.T, P.B, P.h, P.nl, P.nd);
@@ -506,7 +506,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
       // ACCUMULATES into the others (the host keeps the book: no zero fill of the 79 MB, and the sums are the in-line schedule's).
       hipStream_t sside = (hipStream_t)d->side_stream;
       unsigned* prog = P.zflags + (size_t)(SIDE_CHUNKS_MAX + 2) * 64;
-      const unsigned wgs_cell = (unsigned)((h / 16) * ((B + rows_b - 1) / rows_b));
+      const unsigned wgs_cell = (unsigned)((h / 16) * (rows_b == 16 ? (B + 15) / 16 : rows_b == 33 ? 2 * ((B + 31) / 32) : (B + 31) / 32));      // arrivals per chunk: (virtual) workgroups of a cell
       for (int dd = 0; dd < P.nd; ++dd) { cells[dd * P.nl].prog = prog + dd * 64; cells[dd * P.nl].prog_cs = bside.cs; }
       hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, s, prog, 3, 64);      // the two counters and the wait kernels' abort word
       ASTK_LAUNCH_CHECK();
@@ -586,7 +586,7 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
       FoldDbJobs j;
       j.n = P.nd * P.nl; j.cols = 4 * h;
       const int rows_d = lstm_persist_hoisted(h) ? 16 : rows_b;
-      j.nby = (B + rows_d - 1) / rows_d;
+      j.nby = rows_d == 16 ? (B + 15) / 16 : rows_d == 33 ? 2 * ((B + 31) / 32) : (B + 31) / 32;
       for (int i = 0; i < j.n; ++i) { j.db[i] = cells[i].db; j.part[i] = cells[i].db_part; }
       hipLaunchKernelGGL(k_fold_db, dim3(cdiv(4 * h, 256), j.n), dim3(256), 0, s, j);
       ASTK_LAUNCH_CHECK();

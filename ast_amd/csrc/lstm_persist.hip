@@ -126,10 +126,11 @@ __device__ __forceinline__ bool wait_ge(const unsigned* ctr, unsigned target, co
 }
 
 // publish: every storing wave drains its stores, the workgroup barriers, one lane bumps the arrival counter
-__device__ __forceinline__ void publish(unsigned* ctr) {
+// (tid: the caller's thread index inside its -- possibly virtual, see DUO -- workgroup)
+__device__ __forceinline__ void publish(unsigned* ctr, int tid) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Gate activations of the persistent kernels' epilogues (on the recurrence's critical path): v_exp_f32 / v_rcp_f32 based,
@@ -320,11 +321,18 @@ __device__ __forceinline__ float4 frag_vals(const u32x4& g) {
 // of activation fragments and accumulators against the same B operands -- so a batch of 32 rows takes 96 workgroups instead of 192 (160 CUs
 // free for the time-chunked layer-0 products on the side stream), batch 64 runs as ONE launch and the 6-layer stacks need half the launches.
 // The hand-off protocol is unchanged (every wave polls the fragments of both tiles); the matrix part and the gate epilogue of a step double.
-template <int KB, bool HAS_UP, int XS, int MT>
+// DUO (round 6; bf16x3 with the lo plane in LDS, h <= 256): a 512-thread workgroup = TWO virtual 256-thread workgroups of the 16-row form, one per
+// batch tile (virtual workgroup row 2 blockIdx.y + half), two waves per SIMD.  Each half keeps its own weight fragments (hi / mid in 128
+// registers: a wave has 256) and shares the lo plane in LDS (the same weights: both halves write and read identical words); every hand-off,
+// counter and buffer is the 16-row form's, per half; the only coupling is the workgroup barrier.  A step's WORK is ~60 % of its time
+// (MT above): here the two tiles' work runs on the SAME SIMDs from different waves, so one tile's splits and gate epilogue (vector ALU) overlap
+// the other's MFMAs (matrix pipe) and its hand-off wait -- which one wave doing both tiles in turn (MT = 2) cannot.
+template <int KB, bool HAS_UP, int XS, int MT, bool DUO = false>
 __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& c, float* red0, float* red1, u32q* lo_lds) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  static_assert(!DUO || (MT == 1 && XS == 4), "DUO: 16-row halves on the bf16x3 form with the lo plane in LDS");
+  const int tid = DUO ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int bt = blockIdx.y, j0 = blockIdx.x * 16;
+  const int bt = DUO ? (int)(blockIdx.y * 2 + (threadIdx.x >> 8)) : (int)blockIdx.y, j0 = blockIdx.x * 16;
   const int T = a.T, B = a.B, h = a.h, HH = a.H, dbg = PERSIST_DBG(a);
   const AbortCtl ab = a.ab;       // (locals: see the note on the kernel-argument block in lstm_persist_fwd_g)
   const int m0 = bt * 16 * MT;
@@ -644,6 +652,18 @@ __device__ __forceinline__ void lstm_fwd_steps(const PFwdArgs& a, const PCellF& 
 #undef TICK
 }
 
+// the DUO form of the forward kernel (see lstm_fwd_steps): 512 threads, both halves share the lo plane, each has its own reduction buffers
+template <int KB>
+__global__ __launch_bounds__(512, 1) void lstm_persist_fwd_duo(PFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[2][2][4 * 4 * 256];
+  __shared__ __attribute__((aligned(16))) u32q lo_lds[(LO_LDS_FRAGS / 2) * 256];
+  static_assert(2 * ((KB + 1) / 2) * 4 <= LO_LDS_FRAGS / 2, "lo plane of both products in 64 KB");
+  const PCellF c = a.c[blockIdx.z];
+  const int half = threadIdx.x >> 8;
+  if (c.Wu != nullptr) { lstm_fwd_steps<KB, true, 4, 1, true>(a, c, red[half][0], red[half][1], lo_lds); return; }
+  lstm_fwd_steps<KB, false, 4, 1, true>(a, c, red[half][0], red[half][1], lo_lds);
+}
+
 template <int KB, int XS, int MT>
 __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_g(PFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float red[2][MT * 4 * 4 * 256];
@@ -691,17 +711,19 @@ constexpr bool bwd_sentinel(int KB) { return ASTK_BWD_SENTINEL && KB <= ASTK_BWD
 constexpr int DZ_LD = 68;
 // MT = 16-row batch tiles per workgroup (see lstm_fwd_steps): the resident weight fragments of both products serve both tiles; the partial
 // tile buffers keep their per-16-row-tile layout (tile index bt16 = blockIdx.y * MT + mt), the counters are per workgroup row (blockIdx.y).
-template <int KB, bool HAS_UP, int XS, int MT>
+// DUO: see lstm_fwd_steps -- two virtual 16-row workgroups (by = 2 blockIdx.y + half) in one 512-thread workgroup, lo planes shared in LDS.
+template <int KB, bool HAS_UP, int XS, int MT, bool DUO = false>
 __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCellB& c, float (*dzS2)[MT * 16 * DZ_LD], int* s_ok1, int& s_ok2, u32q* lo_lds) {
+  static_assert(!DUO || (MT == 1 && XS == 4), "DUO: 16-row halves on the bf16x3 form with the lo plane in LDS");
   constexpr int NS = 4 * KB;          // slices of a cell = 16x16 output tiles of a product = partial tiles per consumer
   float* const dzS = dzS2[0];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = DUO ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, q = lane >> 4;
-  const int cell = blockIdx.z, by = blockIdx.y, j = blockIdx.x, j0 = j * 16;
+  const int cell = blockIdx.z, by = DUO ? (int)(blockIdx.y * 2 + (threadIdx.x >> 8)) : (int)blockIdx.y, j = blockIdx.x, j0 = j * 16;
   const int T = a.T, B = a.B, h = a.h, HH = a.H, dbg = PERSIST_DBG(a);
   const AbortCtl ab = a.ab;
   const unsigned amax_gen = a.amax_gen;
-  const int nby = gridDim.y, nbt = nby * MT;       // workgroup rows; 16-row tiles the partial buffers are laid out for
+  const int nby = DUO ? (int)gridDim.y * 2 : (int)gridDim.y, nbt = nby * MT;       // (virtual) workgroup rows; 16-row tiles the partial buffers are laid out for
   const int K = 4 * h;
   constexpr bool has_up = HAS_UP;
   // h = 1024 (KB = 16): one product's weight fragments fill the registers -- the gradient for the layer below is a batched GEMM behind
@@ -1126,7 +1148,7 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
       for (int i = 0; i < NS / 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(sent, r_pr, reset_base[mt] + (i * 256 + tid) * 16, 0, 16);
     }
     } else {
-      publish(ctrA);      // drain (product-1 stores only), barrier, one arrival
+      publish(ctrA, tid);      // drain (product-1 stores only), barrier, one arrival
     }
     TICK(5, t0)
     // dz for the batched products: behind the launch (plain stores), or -- layer 0 with side-stream consumers -- beside it, chunk by chunk:
@@ -1168,13 +1190,13 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
       if (tid == 0) (void)wait_ge(ctrB, (unsigned)(NS * (T - 1)), ab);
       __syncthreads();
     }
-    publish(ctrB);
+    publish(ctrB, tid);
   }
   if (c.prog) {
     // the last chunk (and a pending one): every storing wave drains, the workgroup barriers, one lane arrives.  The consumer (a wait kernel
     // on the side stream) wants `chunks x workgroups of the cell` arrivals for the chunk that ends with step 0: one arrival per workgroup and
     // chunk, pending or not, so the total is always ceil(T / prog_cs) per workgroup
-    publish(c.prog);
+    publish(c.prog, tid);
   }
   if (c.db) {
     float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1210,13 +1232,25 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     if (tid == 0) {
       float m = fmaxf(fmaxf(dzS[0], dzS[1]), fmaxf(dzS[2], dzS[3]));
       if (!(m <= 3.0e38f)) m = 3.0e38f;
-      atomicMax(amax_shard(c.amax, blockIdx.x + blockIdx.y * gridDim.x), ((u64)amax_gen << 32) | (u64)__float_as_uint(m));
+      atomicMax(amax_shard(c.amax, blockIdx.x + by * gridDim.x), ((u64)amax_gen << 32) | (u64)__float_as_uint(m));
     }
   }
   if (timing && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0)
     printf("bwd_rs cell %d (layer %d): per-step 10ns: up wait+loads %lld  own wait %lld  own loads+sum %lld  epilogue %lld  barrier+mfma1+stores %lld  publishA %lld  product2+publishB %lld\n",
            cell, c.layer, tk[0] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T, tk[5] / T, tk[6] / T);
 #undef TICK
+}
+
+template <int KB>
+__global__ __launch_bounds__(512, 1) void lstm_persist_bwd_duo(PBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float dzS2[2][2][16 * DZ_LD];
+  __shared__ int s_ok1[2][2], s_ok2[2];
+  __shared__ __attribute__((aligned(16))) u32q lo_lds[(LO_LDS_FRAGS / 2) * 256];
+  static_assert(2 * KB * 2 <= LO_LDS_FRAGS / 2, "lo plane of both products in 64 KB");
+  const PCellB c = a.c[blockIdx.z];
+  const int half = threadIdx.x >> 8;
+  if (c.PD_up != nullptr) lstm_bwd_rs_steps<KB, true, 4, 1, true>(a, c, dzS2[half], s_ok1[half], s_ok2[half], lo_lds);
+  else lstm_bwd_rs_steps<KB, false, 4, 1, true>(a, c, dzS2[half], s_ok1[half], s_ok2[half], lo_lds);
 }
 
 template <int KB, int XS, int MT>
@@ -1255,25 +1289,29 @@ struct PersistCellHost {
 // groups is lost, everything else stays (BASELINE configs[4]: 6 layers x 2 directions x 32 unit slices x 2 batch tiles = 768
 // workgroups -> 3 launches of 2 layers; batch 64 at the shipped width: 2 launches).  0 = not applicable.
 bool lstm_persist_hoisted(int h);
-// Batch rows per workgroup: 16, or 32 (two 16-row tiles against one set of resident weight fragments; h <= 256, where both tiles' fragments
-// fit the registers).  32-row workgroups halve the grid -- but a step is only ~40 % hand-off latency: the two tiles' splits, MFMAs, LDS
-// reduction and gate epilogue add up, and a step takes 4.4 / 5.3 us (forward / backward) instead of 2.9 / 3.6 (MEASURED, round 6: +50 %, not
-// the +15 % the plan assumed).  So 32 rows pay exactly where they spare LAUNCHES (batch 64 at the shipped width: one launch of 4.4 us steps
-// instead of two of 2.9), not as a way to free CUs at batch 32 (the time-chunked products that would use the 160 free CUs recover 0.14 ms of
-// the 0.6 ms the slower recurrences cost: r6_ab tables in profiles/).
-// Tuning knob lstm.rows32: 1 = whenever possible, 0 = never, -1 (default) = when it spares launches.
+// Form of the recurrence workgroups (the `rows` argument of everything below): 16 = one 16-row batch tile per 256-thread workgroup;
+// 33 = DUO: two 16-row tiles per 512-thread workgroup as two virtual workgroups, two waves per SIMD (bf16x3 arithmetic, h <= 256);
+// 32 = MT 2: two tiles per 256-thread workgroup against one set of weight fragments (any arithmetic, h <= 256).  Both 32-row forms halve
+// the grid -- batch 64 at the shipped width runs as ONE launch, a batch of 32 leaves 160 CUs free for side-stream work instead of 64.
+// What they cost (MEASURED, profiles/r6_ab_side.txt): MT 2 does both tiles' splits, MFMAs, LDS reduction and gate epilogue one after the
+// other -- a step is only ~40 % hand-off latency -- 4.4 / 5.3 us per step against 2.9 / 3.6; DUO overlaps one tile's vector-ALU work with the
+// other's MFMAs and hand-off wait.  Knob lstm.rows32: -1 (default) = DUO where available when it spares launches or the caller runs
+// side-stream work, MT 2 when it spares launches and DUO is not available; 0 = always 16; 1 = MT 2 / 2 = DUO whenever possible.
+static bool duo_available(int h) { return h <= 256 && gemm_precision_mode() == 1 && tune_on(TUNE_LSTM_X3) && tune_on(TUNE_LSTM_X4); }
 int lstm_persist_rows(int B, int h, int nl, int nd, bool side) {
   const int knob = (int)tune(TUNE_LSTM_ROWS32);
   if (knob == 0 || h > 256 || B <= 16) return 16;
-  if (knob > 0) return 32;
+  if (knob == 1) return 32;
+  if (knob >= 2) return duo_available(h) ? 33 : 16;
   const long cus = device_cu_count();
   const long wg16 = (long)(h / 16) * ((B + 15) / 16) * nd * nl, wg32 = (long)(h / 16) * ((B + 31) / 32) * nd * nl;
   const long launches16 = (wg16 + cus - 1) / cus, launches32 = (wg32 + cus - 1) / cus;
-  (void)side;
-  return launches32 < launches16 ? 32 : 16;
+  if (launches32 < launches16) return duo_available(h) ? 33 : 32;
+  return side && duo_available(h) && tune_on(TUNE_LSTM_DUO_SIDE) ? 33 : 16;
 }
 int lstm_persist_layers_per_launch(int B, int h, int nl, int nd, int rows) {
-  const long per_layer = (long)(h / 16) * ((B + rows - 1) / rows) * nd;
+  const int rw = rows == 16 ? 16 : 32;
+  const long per_layer = (long)(h / 16) * ((B + rw - 1) / rw) * nd;
   const long cus = device_cu_count();
   if (per_layer < 1 || per_layer > cus) return 0;
   long lpl = cus / per_layer;
@@ -1284,7 +1322,7 @@ int lstm_persist_layers_per_launch(int B, int h, int nl, int nd, int rows) {
 }
 
 // workgroups of one launch over `layers` layers of all directions
-int lstm_persist_grid_wgs(int B, int h, int layers, int nd, int rows) { return (h / 16) * ((B + rows - 1) / rows) * nd * layers; }
+int lstm_persist_grid_wgs(int B, int h, int layers, int nd, int rows) { const int rw = rows == 16 ? 16 : 32; return (h / 16) * ((B + rw - 1) / rw) * nd * layers; }
 
 // Hoisted form (h = 1024): the weight fragments of one product fill a workgroup's registers, so every layer runs as a launch of its
 // own over cells that get their input projection from a batched GEMM in front of it (forward) and leave the gradient for the layer below
@@ -1308,8 +1346,10 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
                             hipStream_t s) {
   PFwdArgs a;
   memset(&a, 0, sizeof(a));
-  ASTK_CHECK(rows == 16 || (rows == 32 && h <= 256), "lstm_persist_fwd: %d rows per workgroup at h = %d", rows, h);
-  const int nbt = (B + rows - 1) / rows;      // workgroup rows
+  ASTK_CHECK(rows == 16 || ((rows == 32 || rows == 33) && h <= 256), "lstm_persist_fwd: form %d at h = %d", rows, h);
+  const bool duo = rows == 33;
+  const int nby = (B + (rows == 16 ? 16 : 32) - 1) / (rows == 16 ? 16 : 32);      // workgroup rows of the grid
+  const int nbt = duo ? 2 * nby : nby;                                            // (virtual) workgroup rows the counters are laid out for
   for (int i = 0; i < ncells; ++i) {
     const PersistCellHost& c = cells[i];
     PCellF& d = a.c[i];
@@ -1321,7 +1361,7 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   a.dbg = persist_dbg_env();
   a.done = counters;
   a.ab = abort_ctl(counters + (size_t)ncells * nbt * 64, PERSIST_ENC_FWD);
-  dim3 grid(h / 16, nbt, ncells), blk(256);
+  dim3 grid(h / 16, nby, ncells), blk(duo ? 512 : 256);
   {
     // hand-off buffers = the saved activations themselves: sentinel-filled before every launch (the counters / abort word ride along, zeroed)
     FillSegs f;
@@ -1340,6 +1380,16 @@ int lstm_persist_fwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   const int mode = gemm_precision_mode();
   const bool x3_off = !tune_on(TUNE_LSTM_X3), x4_off = !tune_on(TUNE_LSTM_X4);
   const int xs = mode == 0 ? 2 : (mode == 1 && !x3_off ? (h <= 256 ? 3 : (x4_off ? 0 : 4)) : 0);       // (4: bf16x3 with the weights' lo plane in LDS)
+  if (duo) {
+    ASTK_CHECK(xs == 3 && !x4_off, "lstm_persist_fwd: the two-waves-per-SIMD form needs the bf16x3 arithmetic");
+    switch (h) {
+      case 64: hipLaunchKernelGGL((lstm_persist_fwd_duo<1>), grid, blk, 0, s, a); break;
+      case 128: hipLaunchKernelGGL((lstm_persist_fwd_duo<2>), grid, blk, 0, s, a); break;
+      default: hipLaunchKernelGGL((lstm_persist_fwd_duo<4>), grid, blk, 0, s, a); break;
+    }
+    ASTK_LAUNCH_CHECK();
+    return 0;
+  }
 #define ASTK_LSTM_FWD_(KB_, XS_, MT_) hipLaunchKernelGGL((lstm_persist_fwd_g<KB_, XS_, MT_>), grid, blk, 0, s, a)
 #define ASTK_LSTM_FWD_XS_(KB_, MT_) { if (xs == 2) ASTK_LSTM_FWD_(KB_, 2, MT_); else if (xs == 3) ASTK_LSTM_FWD_(KB_, 3, MT_); else ASTK_LSTM_FWD_(KB_, 0, MT_); }
   switch (h) {
@@ -1360,8 +1410,10 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
                             unsigned amax_gen, int rows, hipStream_t s) {
   PBwdArgs a;
   memset(&a, 0, sizeof(a));
-  ASTK_CHECK(rows == 16 || (rows == 32 && h <= 256), "lstm_persist_bwd: %d rows per workgroup at h = %d", rows, h);
-  const int nbt = (B + rows - 1) / rows;      // workgroup rows (the counters are per workgroup row)
+  ASTK_CHECK(rows == 16 || ((rows == 32 || rows == 33) && h <= 256), "lstm_persist_bwd: form %d at h = %d", rows, h);
+  const bool duo = rows == 33;
+  const int nby = (B + (rows == 16 ? 16 : 32) - 1) / (rows == 16 ? 16 : 32);      // workgroup rows of the grid
+  const int nbt = duo ? 2 * nby : nby;                                            // (virtual) workgroup rows: the counters are per (virtual) workgroup row
   for (int i = 0; i < ncells; ++i) {
     const PersistCellHost& c = cells[i];
     PCellB& d = a.c[i];
@@ -1395,11 +1447,21 @@ int lstm_persist_bwd_launch(const PersistCellHost* cells, int ncells, int nl, in
   } else {
     ASTK_HIP(hipMemsetAsync(counters, 0, ((size_t)2 * ncells * nbt + 1) * 64 * sizeof(unsigned), s));
   }
-  dim3 grid(h / 16, nbt, ncells), blk(256);
+  dim3 grid(h / 16, nby, ncells), blk(duo ? 512 : 256);
   ProfScope prof(PROF_CELL, s);
   const int mode = gemm_precision_mode();      // (see lstm_persist_fwd_launch)
   const bool x3_off = !tune_on(TUNE_LSTM_X3), x4_off = !tune_on(TUNE_LSTM_X4);
   const int xs = mode == 0 ? 2 : (mode == 1 && !x3_off ? (h <= 256 ? 3 : (x4_off ? 0 : 4)) : 0);
+  if (duo) {
+    ASTK_CHECK(xs == 3 && !x4_off, "lstm_persist_bwd: the two-waves-per-SIMD form needs the bf16x3 arithmetic");
+    switch (h) {
+      case 64: hipLaunchKernelGGL((lstm_persist_bwd_duo<1>), grid, blk, 0, s, a); break;
+      case 128: hipLaunchKernelGGL((lstm_persist_bwd_duo<2>), grid, blk, 0, s, a); break;
+      default: hipLaunchKernelGGL((lstm_persist_bwd_duo<4>), grid, blk, 0, s, a); break;
+    }
+    ASTK_LAUNCH_CHECK();
+    return 0;
+  }
 #define ASTK_LSTM_BWD_(KB_, XS_, MT_) hipLaunchKernelGGL((lstm_persist_bwd_rs<KB_, XS_, MT_>), grid, blk, 0, s, a)
 #define ASTK_LSTM_BWD_XS_(KB_, MT_) { if (xs == 2) ASTK_LSTM_BWD_(KB_, 2, MT_); else if (xs == 3) ASTK_LSTM_BWD_(KB_, 3, MT_); else ASTK_LSTM_BWD_(KB_, 0, MT_); }
   switch (h) {

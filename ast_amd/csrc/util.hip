@@ -100,6 +100,7 @@ static const TuneEntry g_tune_table[TUNE_COUNT] = {
     {"lstm.rows32", -1},           // 32 batch rows per recurrence workgroup: 1 always, 0 never, -1 = when it spares launches
     {"lstm.overlap_chunk", 0},     // time steps per chunk of the layer-0 products that run beside the recurrences (side_stream); 0 = from the free CUs
     {"lstm.side_fwd", 1},          // side_stream: the layer-0 input projection in chunks beside the forward recurrence
+    {"lstm.duo_side", 0},          // side_stream + batch <= 32: take the two-waves-per-SIMD form (96 workgroups, 160 CUs free) instead of 192 workgroups of 16 rows
     {"lstm.side_bwd", 0},          // side_stream: the input gradient in chunks behind the backward recurrence's progress (off: with 64 free CUs the
                                    // decoder's parameter gradients already fill them; measured slower at 160, profiles/r6_ab_side.txt)
     {"row.longk", 2048},           // row-panel kernels split K over eight waves from this K on (0 = never)

@@ -417,7 +417,7 @@ def main():
             nprod, peak, pipe = {"fp16x2": (3, MFMA_16BIT_PEAK_TFLOPS, "fp16 MFMA (v_mfma_f32_32x32x16_f16), 3 per useful 16-k product block (fp16x2 split)"),
                                  "bf16x3": (6, MFMA_16BIT_PEAK_TFLOPS, "bf16 MFMA (v_mfma_f32_32x32x16_bf16), 6 per useful 16-k product block (bf16x3 split)"),
                                  "f32": (1, MFMA_F32_PEAK_TFLOPS, "f32-input MFMA (v_mfma_f32_32x32x2_f32)")}[base_scheme]
-            tj = (profile_json("r5_gemm_traffic.json") or profile_json("r4_gemm_traffic.json") or {}).get(base_scheme) or {}
+            tj = (profile_json("r6_gemm_traffic.json") or profile_json("r5_gemm_traffic.json") or profile_json("r4_gemm_traffic.json") or {}).get(base_scheme) or {}
             # `achieved` / `frac` = ALGORITHMIC flops (2*M*N*K) over the launches' time against the dense peak of the pipe that executes
             # them -- the task's definition; `executed_*` = the same rate times the MFMAs a useful product costs under the scheme (what
             # the matrix pipe really does: 6x under bf16x3), `algorithmic_over_f32_mfma_peak` = the same algorithmic rate against what
@@ -428,7 +428,7 @@ def main():
                     "executed_tflops": round(tfl * nprod, 2), "executed_frac_of_pipe_peak": round(tfl * nprod / peak, 4),
                     "algorithmic_over_f32_mfma_peak": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
                     "traffic": tj.get("hbm_bytes_per_step"),
-                    "traffic_source": ("STATIC FILE, not measured in this run: " + tj.get("source", "profiles/r5_gemm_traffic.json")) if tj else None,
+                    "traffic_source": ("STATIC FILE, not measured in this run: " + tj.get("source", "profiles/r6_gemm_traffic.json")) if tj else None,
                     "mfma_pipe_busy_frac_pmc": tj.get("mfma_pipe_busy_frac"),
                     # logical operand / result bytes (window operands of the conv GEMMs counted at their im2col extent, not at the
                     # smaller extent of the arrays they address); `traffic` is what crosses the L2's memory side, Infinity-Cache hits
@@ -447,7 +447,7 @@ def main():
             # over the launch's duration.  Phase-level (in-kernel stamps, hand-off satisfied -> partial published) is given for
             # reference only: it is an HBM-EQUIVALENT rate of an on-chip pass, not HBM traffic.
             k_fwd_us, k_bwd_us = res[16] / res[17] * 1e3, res[18] / res[19] * 1e3
-            attn_traffic = profile_json("r5_attn_traffic.json") or profile_json("r4_attn_traffic.json") or profile_json("r3_attn_traffic.json") or profile_json("attn_traffic.json")
+            attn_traffic = profile_json("r6_attn_traffic.json") or profile_json("r5_attn_traffic.json") or profile_json("r4_attn_traffic.json") or profile_json("r3_attn_traffic.json") or profile_json("attn_traffic.json")
             ach = S * bytes_scan / ((k_fwd_us + k_bwd_us) / 2 * 1e-6) / 1e9
             scan = {"bound": "latency (priced against the HBM roofline north_star names; slices are LDS-resident, measured HBM traffic < algorithmic bytes)",
                     "kernel": "decoder_persist_fwd / decoder_persist_bwd (all S decoder steps per launch)",

@@ -1,11 +1,11 @@
 #!/bin/bash
-# per-launch table of the train step's batched products: logged shapes (ASTK_GEMM_LOG) matched in order with the kernel trace
+# per-launch table of the train step's batched products: logged shapes (tuning knob gemm.log) matched in order with the kernel trace (side stream off)
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/gemm_step
 rm -rf $OUT && mkdir -p $OUT
-export ASTK_GEMM_LOG=1
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-alt-precisions --no-also ${BENCH_ARGS} > $OUT/run.log 2>&1
+export ASTK_BENCH_KNOBS="gemm.log=1,SIDE=0${EXTRA_KNOBS:+,$EXTRA_KNOBS}"
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 scratch/bench_knobs.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-alt-precisions --no-also --histogram none ${BENCH_ARGS} > $OUT/run.log 2>&1
 python3 - <<'PY'
 import csv, glob, re
 f = sorted(glob.glob('gpurun_out/gemm_step/**/*kernel_trace.csv', recursive=True))[-1]
