@@ -1425,7 +1425,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
     bool small = grp.iters_total < 256L * wgs_per_cu(128) * 10 * (32 / BK) && (tiles < 192 || max_kt <= 12 * (16 / BK > 0 ? 16 / BK : 1));
     // (a capped launch -- work beside a recurrence kernel on a side stream -- is "small" only if its 128-tiles cannot fill the CAPPED grid:
     //  a chunk of the layer-0 projection is 64 tiles for 64 workgroups, one whole tile each; as 64-tiles it ran 240 us instead of 140)
-    if (tl_wg_cap > 0) small = small && tiles < tl_wg_cap;
+    if (tl_wg_cap > 0) small = small && 2 * tiles < tl_wg_cap;
     // 256 x 128 tiles on the 12-wave kernel (round 5): launches of 20 GFLOP and more whose M extents waste at most 10 % more rows than
     // with 128-row tiles -- measured per launch of the train step (scratch/r5_gemm_t256.sh): 3-6 % faster on every launch above 200 us,
     // slower on the small ones (6400 x 512 x 512: 40 -> 58 us)

@@ -119,7 +119,8 @@ SidePlan plan_side_bwd(const astk_lstm_stack_desc* d, int rows, int lpl, bool wa
   cap = cap / 8 * 8;
   if (cap < 16) return sp;
   int cs = (int)tune(TUNE_LSTM_OVERLAP_CHUNK);
-  if (cs <= 0) cs = std::max(4, (cap / (2 * ((d->in_dim + 127) / 128))) * 128 / d->B * 2);      // ~2 x cap tiles per direction and chunk
+  // (as many 128-row tile rows of ONE direction's product as give at most `cap` tiles: one whole tile per workgroup, no split tiles)
+  if (cs <= 0) cs = std::max(4, std::max(1, cap / ((d->in_dim + 127) / 128)) * 128 / d->B);
   cs = std::max(4, cs);
   const int n = std::min(SIDE_CHUNKS_MAX, (d->T + cs - 1) / cs);
   if (n < 2) return sp;

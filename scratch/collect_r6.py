@@ -14,7 +14,7 @@ for f in ("phase_stamps.log", "phase_stamps_es.log"):
     fresh += [l.rstrip("\n") for l in open(f"{P}/{f}") if not l.startswith("{") and ("persist" in l or "bwd_rs" in l or "dec" in l)]
 open("profiles/r6_phase_stamps.txt", "w").write("\n".join(fresh) + "\n")
 out = {}
-for n in ["bench_default", "bench_inline", "bench_deterministic", "bench_bucket_batch", "bench_cfg5", "bench_cfg5_fp16", "bench_cfg5_wide", "bench_b64", "bench_b64_rows16", "bench_t1200", "bench_t1680"]:
+for n in ["bench_default", "bench_inline", "bench_deterministic", "bench_bucket_batch", "bench_cfg5", "bench_cfg5_fp16", "bench_cfg5_wide", "bench_b64", "bench_b64_rows16", "bench_b64_mt2", "bench_duo_inline", "bench_mt2_inline", "bench_duo_side", "bench_t1200", "bench_t1680"]:
     lines = [l for l in open(f"{P}/{n}.log") if l.startswith("{")]
     if lines:
         out[n] = json.loads(lines[-1])

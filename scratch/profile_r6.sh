@@ -40,6 +40,10 @@ python3 bench.py --model cfg5 --steps 20 --warmup 5 --no-cpu-baseline --no-alt-p
 python3 bench.py --model cfg5 --gemm-operands fp16 --steps 20 --warmup 5 --no-cpu-baseline --no-alt-precisions --histogram none > $OUT/bench_cfg5_fp16.log 2>&1
 python3 bench.py --batch 64 --steps 30 --warmup 10 --no-cpu-baseline --no-alt-precisions --no-also --histogram none > $OUT/bench_b64.log 2>&1
 ASTK_BENCH_KNOBS="lstm.rows32=0" python3 scratch/bench_knobs.py --batch 64 --steps 30 --warmup 10 --no-cpu-baseline --no-alt-precisions --no-also --histogram none > $OUT/bench_b64_rows16.log 2>&1
+ASTK_BENCH_KNOBS="lstm.rows32=1" python3 scratch/bench_knobs.py --batch 64 --steps 30 --warmup 10 --no-cpu-baseline --no-alt-precisions --no-also --histogram none > $OUT/bench_b64_mt2.log 2>&1
+ASTK_BENCH_KNOBS="lstm.rows32=2,SIDE=0" python3 scratch/bench_knobs.py --steps 30 --warmup 10 --no-cpu-baseline --no-alt-precisions --no-also --histogram none > $OUT/bench_duo_inline.log 2>&1
+ASTK_BENCH_KNOBS="lstm.rows32=1,SIDE=0" python3 scratch/bench_knobs.py --steps 30 --warmup 10 --no-cpu-baseline --no-alt-precisions --no-also --histogram none > $OUT/bench_mt2_inline.log 2>&1
+ASTK_BENCH_KNOBS="lstm.rows32=2,lstm.side_bwd=1" python3 scratch/bench_knobs.py --steps 30 --warmup 10 --no-cpu-baseline --no-alt-precisions --no-also --histogram none > $OUT/bench_duo_side.log 2>&1
 python3 bench.py --model cfg5 --hidden 2048 --steps 10 --warmup 3 --no-cpu-baseline --no-alt-precisions --histogram none > $OUT/bench_cfg5_wide.log 2>&1
 python3 bench.py --frames 1200 --steps 30 --warmup 10 --no-cpu-baseline --no-alt-precisions --no-also --histogram none > $OUT/bench_t1200.log 2>&1
 python3 bench.py --frames 1680 --steps 30 --warmup 10 --no-cpu-baseline --no-alt-precisions --no-also --histogram none > $OUT/bench_t1680.log 2>&1

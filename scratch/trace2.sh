@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=${1:-r6_trace}
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/trace_tmp
-rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/trace_tmp -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --profile-steps 0 --no-alt-precisions --no-also --histogram none $PROF_ARGS > $GRAFT_REPO_ROOT/gpurun_out/$OUT.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/trace_tmp -- python3 $GRAFT_REPO_ROOT/scratch/bench_knobs.py --steps 4 --warmup 2 --no-cpu-baseline --profile-steps 0 --no-alt-precisions --no-also --histogram none $PROF_ARGS > $GRAFT_REPO_ROOT/gpurun_out/$OUT.log 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 root = os.environ["GRAFT_REPO_ROOT"]

@@ -410,7 +410,7 @@ def _lstm_stack_case(lib, T, B, in_dim, h, nl, masks, side=False):
         main = torch.cuda.Stream()
         side_s = _concurrent_stream(lib, main)
         d.side_stream = side_s.cuda_stream
-        assert lib.astk_lstm_stack_free_cus(C.byref(d)) > 0
+        # (astk_lstm_stack_free_cus may be 0 -- a stack that fills the chip launch by launch: the library then keeps everything in line)
         torch.cuda.synchronize()
 
     def stream():                       # (shadows the module's helper: the stream this case launches on)
