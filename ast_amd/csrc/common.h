@@ -615,12 +615,15 @@ __device__ __forceinline__ void colreduce_block(int rows, int cols, Acc acc, Emi
 // grid for colreduce_block: one block per CU, at least 16 rows per lane.  (Every block ends in same-address double atomics, one per column and
 // statistic: with 512 blocks the layer-0 BatchNorm statistics -- 128 columns, i.e. 256 arrivals per address -- took 29 us for a 39 MB read, with
 // 256 blocks 19; 128 blocks lose on the wide layers.  astk_set_tuning("colreduce.blocks") overrides.)
-static inline dim3 colreduce_grid(int rows, int cols) {
+// float_sums: the blocks publish FLOAT atomics (bias gradients): under a deterministic call one block per column group sums its rows in
+// order -- one add per column.  The BatchNorm statistics' DOUBLE atomics keep their grids: their order changes a float result only when a
+// double sum falls within 2^-29 of a float rounding boundary (the forward pass has used them through every bit-identical soak).
+static inline dim3 colreduce_grid(int rows, int cols, bool float_sums = false) {
   const int q = (cols + 3) / 4;
   const int CL = q < COLREDUCE_CL ? q : COLREDUCE_CL, NR = 256 / CL;
   const int gx = (q + CL - 1) / CL;
   const int blocks = (int)tune(TUNE_COLREDUCE_BLOCKS);
-  int gy = deterministic_mode() ? 1 : blocks / gx;       // (deterministic: one block per column group sums its rows in order: one add per column)
+  int gy = (float_sums && deterministic_mode()) ? 1 : blocks / gx;
   const int max_gy = (rows + 16 * NR - 1) / (16 * NR);
   if (gy > max_gy) gy = max_gy;
   if (gy < 1) gy = 1;

@@ -1196,6 +1196,14 @@ __device__ __forceinline__ void lstm_bwd_rs_steps(const PBwdArgs& a, const PCell
     // the last chunk (and a pending one): every storing wave drains, the workgroup barriers, one lane arrives.  The consumer (a wait kernel
     // on the side stream) wants `chunks x workgroups of the cell` arrivals for the chunk that ends with step 0: one arrival per workgroup and
     // chunk, pending or not, so the total is always ceil(T / prog_cs) per workgroup
+    // (the LAST arrival is the one that needs nothing from the peers -- the same shape as counter B's: a workgroup that finishes early must not
+    //  lift the count to `workgroups x k` while a peer has made k - 1 arrivals and not yet stored the last dz of chunk k - 1; it waits until
+    //  every peer has made all its deferred arrivals.  tests/protocol_model.py: progress_counter_procs finds the stale read without this wait.)
+    const int nchunks = (T + c.prog_cs - 1) / c.prog_cs;
+    if (nchunks > 1) {
+      if (tid == 0) (void)wait_ge(c.prog, (unsigned)(NS * nby * (nchunks - 1)), ab);
+      __syncthreads();
+    }
     publish(c.prog, tid);
   }
   if (c.db) {

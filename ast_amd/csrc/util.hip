@@ -588,7 +588,7 @@ int copy_segments(const CopySegs& c, hipStream_t s) {
 int colsum_add_f32(float* dst, const float* src, long lds, int rows, int cols, hipStream_t s) {
   if (rows <= 0 || cols <= 0) return 0;
   ASTK_CHECK((lds % 4) == 0 && aligned16(src), "colsum: source must be 16-byte aligned with a leading dimension multiple of 4");
-  hipLaunchKernelGGL(k_colsum, colreduce_grid(rows, cols), dim3(256), 0, s, dst, src, lds, rows, cols);
+  hipLaunchKernelGGL(k_colsum, colreduce_grid(rows, cols, true), dim3(256), 0, s, dst, src, lds, rows, cols);
   ASTK_LAUNCH_CHECK();
   return 0;
 }
@@ -610,7 +610,7 @@ int ColsumBatch::add(float* dst, const float* src, long lds, int rows, int cols,
   if (rows <= 0 || cols <= 0) return 0;
   ASTK_CHECK((lds % 4) == 0 && aligned16(src), "colsum: source must be 16-byte aligned with a leading dimension multiple of 4");
   if (j.n == COLSUM_BATCH_MAX) ASTK_TRY(flush(s));
-  const dim3 g = colreduce_grid(rows, cols);
+  const dim3 g = colreduce_grid(rows, cols, true);
   const int i = j.n++;
   j.dst[i] = dst; j.src[i] = src; j.lds[i] = lds; j.rows[i] = rows; j.cols[i] = cols; j.gx[i] = (int)g.x; j.gy[i] = (int)g.y;
   return 0;

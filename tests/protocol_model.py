@@ -455,3 +455,65 @@ def explore_gemm_ticket(nks, launches=2, reset_by="departure", done_before_store
                 raise Violation(f"launch {launch}: deadlock, contributors at steps {pcs} with word {word}")
         visited += len(seen)
     return visited
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# Round 6: work beside the recurrences.
+# (a) Forward: the layer-0 input projection arrives in time chunks from the side stream; chunk k = steps [s0 + k cs, ...) is in memory when
+#     flag[k] is up (a one-lane kernel BEHIND the chunk's product: the kernel boundary is the release).  The layer-0 cells (one process
+#     per workgroup) enter a chunk behind its flag.  flag_first=True models the bug of raising the flag in front of the product.
+def side_chunk_flag_procs(T=6, s0=2, cs=2, nwg=2, flag_first=False):
+    tag = lambda t: ("zx", t)
+    mem = {("ZX", t, w): (tag(t) if t < s0 else STALE) for t in range(T) for w in range(nwg)}
+    nch = (T - s0 + cs - 1) // cs
+    prod = []
+    for k in range(nch):
+        steps = range(s0 + k * cs, min(T, s0 + (k + 1) * cs))
+        wr = [("writes", [("ZX", t, w) for t in steps for w in range(nwg)], None)]      # placeholder, split per step below (tags differ)
+        wr = [("writes", [("ZX", t, w) for w in range(nwg)], tag(t)) for t in steps]
+        prod += ([("add", ("flag", k))] + wr) if flag_first else (wr + [("add", ("flag", k))])
+    procs = [prod]
+    for w in range(nwg):
+        a = []
+        for t in range(T):
+            if t >= s0 and (t - s0) % cs == 0:
+                a.append(("wait", [(("flag", (t - s0) // cs), 1)]))
+            a.append(("read", ("ZX", t, w), tag(t)))
+        procs.append(a)
+    return procs, mem
+
+
+# (b) Backward: every workgroup of a layer-0 cell writes dz through and arrives on the progress counter once per chunk of cs loop steps --
+#     the arrival of a chunk that ends with step s is DEFERRED to the barrier of step s + 1 (its stores have drained by then), the last chunk's
+#     follows the loop.  The workgroups of a cell are coupled by the recurrence itself (step s needs every peer's partials of step s - 1:
+#     counter "A" here).  A consumer (the side stream's wait kernel + the products behind it) takes chunk k when the counter shows
+#     NS (k + 1) arrivals.  last_arrival_fix: the arrival behind the loop first waits for NS (chunks - 1) -- without it an early finisher's
+#     last arrival completes the count for chunk k - 1 while a peer has not stored that chunk's last dz (the round-4 race's shape).
+def progress_counter_procs(NS=2, T=5, cs=2, last_arrival_fix=True):
+    tag = lambda s: ("dz", s)
+    mem = {("DZ", s, j): STALE for s in range(T) for j in range(NS)}
+    nch = (T + cs - 1) // cs
+    procs = []
+    for j in range(NS):
+        a, pending = [], False
+        for s in range(T):
+            if s > 0:
+                a.append(("wait", [("A", NS * s)]))               # the peers' partials of step s - 1
+            if pending:                                            # behind the step's barrier: the deferred arrival of the chunk that ended with s - 1
+                a.append(("add", "P"))
+                pending = False
+            a.append(("add", "A"))                                 # product-1 partials of step s (what the peers' next step waits for)
+            a.append(("write", ("DZ", s, j), tag(s)))              # dz of step s: behind the product-1 stores in program order
+            if (s + 1) % cs == 0 and s < T - 1:
+                pending = True
+        if last_arrival_fix and nch > 1:
+            a.append(("wait", [("P", NS * (nch - 1))]))
+        a.append(("add", "P"))
+        procs.append(a)
+    cons = []
+    for k in range(nch):
+        cons.append(("wait", [("P", NS * (k + 1))]))
+        for s in range(k * cs, min(T, (k + 1) * cs)):
+            cons += [("read", ("DZ", s, j), tag(s)) for j in range(NS)]
+    procs.append(cons)
+    return procs, mem

@@ -9,6 +9,7 @@ when the fix is taken out of it.  DESIGN.md, section "Hand-off protocols", state
 ast_amd/csrc/lstm_persist.hip (lstm_bwd_rs_steps) and ast_amd/csrc/decoder_wide.hip."""
 import pytest
 
+import protocol_model as M
 from protocol_model import Violation, encoder_backward_procs, explore, explore_gemm_ticket, wide_decoder_bwd_procs, wide_decoder_fwd_procs
 
 
@@ -97,3 +98,22 @@ def test_gemm_split_tile_ticket_word(nks):
     if len(nks) >= 3:
         with pytest.raises(Violation, match="deadlock|ticket word"):
             explore_gemm_ticket(nks, reset_by="arrival")
+
+
+def test_side_stream_chunk_flags_and_progress_counter():
+    """Round 6 (work beside the recurrences).  Forward: a chunk flag raised BEHIND the chunk's product lets the layer-0 cells read only finished
+    rows; raised in front of it, some interleaving reads a row of the previous launch.  Backward: with the deferred per-chunk arrivals and the
+    last arrival's wait, `count >= workgroups x (k + 1)` means every workgroup has stored chunk k's dz; WITHOUT that wait an early finisher
+    completes the count for the second-to-last chunk while a peer has not stored its last dz -- the checker finds the stale read (the shape
+    of round 4's counter-B race, caught here before it ever ran)."""
+    procs, mem = M.side_chunk_flag_procs(T=6, s0=2, cs=2, nwg=2)
+    assert M.explore(procs, mem) > 0
+    procs, mem = M.side_chunk_flag_procs(T=6, s0=2, cs=2, nwg=2, flag_first=True)
+    with pytest.raises(M.Violation):
+        M.explore(procs, mem)
+    for T, cs in ((5, 2), (4, 2), (7, 3), (4, 1)):
+        procs, mem = M.progress_counter_procs(NS=2, T=T, cs=cs)
+        assert M.explore(procs, mem) > 0
+    procs, mem = M.progress_counter_procs(NS=2, T=5, cs=2, last_arrival_fix=False)
+    with pytest.raises(M.Violation):
+        M.explore(procs, mem)
