@@ -189,6 +189,7 @@ TEST_HOOK_SIGNATURES = {
     "astk_debug_set_amax_generation": (C.c_int, [C.c_uint]),
     "astk_conv_debug_preact": (C.c_int, [C.POINTER(CnnDesc), _VP, _SZ, _I, _VP, _VP]),
     "astk_conv_debug_kill_units": (C.c_int, [_VP, _I]),
+    "astk_debug_gemm_group": (C.c_int, [_I, _I, c_int_p, c_int_p, c_int_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, _I, _VP]),
 }
 
 _lib = None

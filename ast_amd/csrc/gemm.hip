@@ -1465,6 +1465,9 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   // shapes against 60-93 for one-tile-per-workgroup launches.  Smaller products keep one tile per workgroup unless they have too
   // few tiles to occupy the chip; then their k range is split as well.
   const int force_g = (int)tune(TUNE_GEMM_GRID);   // tuning hook
+  // (forward ops open a GemmForwardScope; "gemm.forward_pairs" 2 applies their two-contributor rule to EVERY launch of the process -- plain
+  //  astk_gemm_f32 calls included: how the tests reach it on the product library with shapes no op produces)
+  const bool forward_rule = tl_forward != 0 || tune(TUNE_GEMM_FORWARD_PAIRS) >= 2;
   long G = tiles;
   bool aligned = true;   // workgroup boundaries fall on tile boundaries
   if (grp.iters_total >= 256L * WGS_PER_CU * 10 * (32 / BK)) { G = 256 * WGS_PER_CU; aligned = false; }
@@ -1497,7 +1500,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
       grp.dp_waves = (int)(tiles / G);
       // (forward launches: one wave fewer -- the remainder then has >= G tiles, every stream-K range >= one tile, <= 2 contributors per split
       //  tile: run-to-run reproducible sums, see GemmForwardScope)
-      if (tl_forward && grp.dp_waves > 0) --grp.dp_waves;
+      if (forward_rule && grp.dp_waves > 0) --grp.dp_waves;
       grp.dp_kt = grp.g[0].kt;
       grp.rem_start = (long)grp.dp_waves * G * grp.dp_kt;
       const int chunk = (int)(G / 8);          // tiles of one XCD and wave
@@ -1514,7 +1517,7 @@ int gemm_launch_group(int layout, const GemmArgs* list, int n, hipStream_t s) {
   // guarantee -- at most TWO contributors per split tile, so that the float atomics commute and the forward pass is bit-reproducible whatever
   // shapes occur -- by shrinking the grid until every stream-K range is at least as deep as the deepest tile, or to exactly two half-tile
   // ranges per tile where the depths allow it (round-5 advice: the guarantee used to depend on which shapes happened to come by).
-  if (tl_forward && !aligned && grp.dp_waves == 0 && tune_on(TUNE_GEMM_FORWARD_PAIRS)) {
+  if (forward_rule && !aligned && grp.dp_waves == 0 && tune_on(TUNE_GEMM_FORWARD_PAIRS)) {
     int max_kt = 0;
     bool uniform = true;
     for (int i = 0; i < grp.n; ++i) { max_kt = std::max(max_kt, grp.g[i].kt); uniform = uniform && grp.g[i].kt == grp.g[0].kt; }
@@ -1738,6 +1741,22 @@ extern "C" int astk_get_gemm_precision(void) {
 }
 #ifdef ASTK_TEST_HOOKS
 extern "C" int astk_debug_set_amax_generation(unsigned gen) { astk::g_amax_counter.store(gen ? gen : 1u); return 0; }
+// libastk_test.so only: ONE grouped launch of n products C_i = A_i B_i (dense row-major operands, leading dimension = inner extent of the
+// layout) the way a forward op issues it -- under GemmForwardScope when `forward` is set -- so that the two-contributor rule can be tested
+// on shapes no op of the step produces (few tiles and deep K, groups of unequal K).
+extern "C" int astk_debug_gemm_group(int layout, int n, const int* M, const int* N, const int* K, const float* const* A, const float* const* B,
+                                     float* const* C, int forward, int precision, void* stream) {
+  using namespace astk;
+  ASTK_CHECK(n >= 1 && n <= GEMM_GROUP_MAX && layout >= GEMM_NT && layout <= GEMM_TN, "debug_gemm_group: bad arguments");
+  PrecScope prec_scope(precision, 0);
+  GemmArgs g[GEMM_GROUP_MAX];
+  for (int i = 0; i < n; ++i) {
+    const long lda = layout == GEMM_TN ? M[i] : K[i], ldb = layout == GEMM_NT ? K[i] : N[i];
+    g[i] = gemm_args(M[i], N[i], K[i], mat(A[i], lda), mat(B[i], ldb), C[i], N[i]);
+  }
+  if (forward) { GemmForwardScope fs; return gemm_launch_group(layout, g, n, (hipStream_t)stream); }
+  return gemm_launch_group(layout, g, n, (hipStream_t)stream);
+}
 #endif
 extern "C" double astk_set_gemm_bf16_split_below(double flops) { return astk::g_small_flops.exchange(flops < 0 ? 0.0 : flops); }
 

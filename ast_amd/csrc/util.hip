@@ -83,7 +83,7 @@ static const TuneEntry g_tune_table[TUNE_COUNT] = {
     {"gemm.log", 0},               // print every launch's shape and schedule to stderr
     {"gemm.ticket", 1},            // libastk_test.so only: split tiles handed over by tickets instead of a zeroing launch
     {"gemm.deterministic", 0},     // process default of the descriptors' `deterministic` field (fixed-order split-tile sums, astk.h)
-    {"gemm.forward_pairs", 1},     // forward launches outside the hybrid branch: grid shrunk until a split tile has <= 2 contributors
+    {"gemm.forward_pairs", 1},     // forward launches outside the hybrid branch: grid shrunk until a split tile has <= 2 contributors (2: the forward rule for EVERY launch)
     {"conv.direct0", 1},           // layer 0 as a direct convolution (0: im2col + GEMM)
     {"conv.seq_fwd", 1},           // BatchNorm + ReLU written straight into the LSTM's (T'',B,C*F') layout by the tiled kernel
     {"conv.seq_bwd", 1},           // the last layer's BatchNorm backward reads that layout itself

@@ -91,7 +91,7 @@ int astk_get_gemm_precision(void);
  * refuse a workspace whose forward took another kernel path).  Keys (default):
  *   gemm.tile (0 = per launch; 64 | 128 | 256 forces the block tile)     gemm.t256_above (2e10 flops: the 12-wave 256 x 128 kernel from here on)
  *   gemm.grid (-1 = per launch)   gemm.hybrid (1)   gemm.chunk (1)   gemm.chunk_div (4)   gemm.log (0: 1 prints every launch to stderr)
- *   gemm.deterministic (0: process default of the descriptors' `deterministic` field)   gemm.forward_pairs (1)   gemm.ticket (libastk_test.so only)
+ *   gemm.deterministic (0: process default of the descriptors' `deterministic` field)   gemm.forward_pairs (1; 2 = the forward ops' two-contributor rule for every launch, plain astk_gemm_f32 calls included)   gemm.ticket (libastk_test.so only)
  *   conv.direct0 (1)   conv.seq_fwd (1)   conv.seq_bwd (1)   conv.seq_stats_blocks (1024)   conv.seq_apply_blocks (1024)
  *   dec.persist (1: 0 = per-launch decoder loop)   dec.b6_split (1)   dec.b6_fused (1)   dec.wide (1)
  *   lstm.persist (1: 0 = one fused-cell launch per step)   lstm.hoist (1)   lstm.x3 (1)   lstm.x4 (1)
@@ -106,6 +106,10 @@ const char* astk_tuning_key(int index);
 #ifdef ASTK_TEST_HOOKS
 /* Test hook (libastk_test.so only): sets the generation counter of the fp16x2 scale slots (tests preset it close to the 32-bit wrap). */
 int astk_debug_set_amax_generation(unsigned gen);
+/* Test hook (libastk_test.so only): ONE grouped launch of n products C_i = op(A_i) op(B_i) (dense row-major operands) the way a forward op
+ * issues it -- under the forward ops' two-contributor rule when `forward` is set -- for shapes no op of the step produces. */
+int astk_debug_gemm_group(int layout, int n, const int* M, const int* N, const int* K, const float* const* A, const float* const* B,
+                          float* const* C, int forward, int precision, void* stream);
 #endif
 
 /* ---------------------------------------------------------------- CNN front-end  (seq2seq.py:158-180)

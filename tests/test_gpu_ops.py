@@ -1059,6 +1059,71 @@ def test_gemm_split_tiles_ticket_protocol_on_the_instrumented_build(M, N, K):
         _split_tiles_body(lib, M, N, K, 20)
 
 
+@pytest.mark.parametrize("layout,shapes", [
+    (0, [(256, 256, 16384)]),                                   # few tiles, deep K: without the rule 256 workgroups share four tiles
+    (2, [(384, 128, 40000)]),
+    (0, [(1248, 512, 512), (1248, 512, 1152), (640, 1024, 3072)]),      # a group of unequal K (not uniform: outside the hybrid branch)
+    (1, [(2000, 640, 256), (700, 384, 2048)]),
+    (0, [(38400, 512, 1152)]),                                  # the hybrid branch itself (the step's layer-1 convolution)
+])
+def test_gemm_forward_launches_have_two_contributors_per_split_tile_on_any_shape(layout, shapes):
+    """GemmForwardScope (common.h) promises the forward ops run-to-run identical sums: every split tile of their launches has at most two
+    contributors (two float atomic adds into a zeroed tile commute).  Round 5 kept the promise only inside the hybrid branch; since round 6
+    the launcher shrinks the grid of every other forward launch until a stream-K range is at least one tile deep.  Shapes no op of the step
+    produces -- few tiles with deep K, grouped products of unequal K -- go through the instrumented build's astk_debug_gemm_group (one
+    grouped launch under the scope): twelve launches must agree BIT FOR BIT, and with float64.  The same launches without the scope are run
+    once for their values (their sums are allowed to vary)."""
+    from ast_amd import _lib as L_
+    torch.manual_seed(11)
+    n = len(shapes)
+    As, Bs, refs = [], [], []
+    for M, N, K in shapes:
+        a = torch.randn((K, M) if layout == 2 else (M, K), device="cuda")
+        b = torch.randn((N, K) if layout == 0 else (K, N), device="cuda")
+        As.append(a); Bs.append(b)
+        ad, bd = a.double(), b.double()
+        refs.append((ad.t() if layout == 2 else ad) @ (bd.t() if layout == 0 else bd))
+    arr = lambda vals: (C.c_int32 * n)(*vals)
+    ptrs = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    with L_.load_test_hooks() as tl:
+        for forward in (1, 0):
+            first = None
+            for rep in range(12 if forward else 1):
+                Cs = [torch.full((M, N), float("nan"), device="cuda") for M, N, K in shapes]
+                ok(tl, tl.astk_debug_gemm_group(layout, n, arr([s[0] for s in shapes]), arr([s[1] for s in shapes]), arr([s[2] for s in shapes]),
+                                                ptrs(As), ptrs(Bs), ptrs(Cs), forward, L_.PREC_BF16X3, stream()))
+                torch.cuda.synchronize()
+                if first is None:
+                    first = [c.clone() for c in Cs]
+                    for c, r, sh in zip(Cs, refs, shapes):
+                        close(c, r, rtol=3e-5, msg=f"layout {layout} {sh} forward {forward}")
+                else:
+                    for c, f, sh in zip(Cs, first, shapes):
+                        assert torch.equal(c, f), (rep, sh, float((c - f).abs().max()))
+
+
+@pytest.mark.parametrize("layout,M,N,K", [(0, 256, 256, 16384), (2, 384, 128, 40000), (1, 1200, 300, 6000), (0, 38400, 512, 1152)])
+def test_gemm_forward_rule_on_the_product_library_is_bit_reproducible(lib, tune, layout, M, N, K):
+    """The same promise on the SHIPPED library (zeroing launch + float atomics instead of the instrumented build's ticket protocol):
+    `gemm.forward_pairs` = 2 puts every launch under the forward ops' rule, so plain astk_gemm_f32 calls reach it.  Twelve launches of a
+    few-tiles / deep-K product (256 workgroups would share its tiles without the rule) agree bit for bit."""
+    tune("gemm.forward_pairs", 2, lib)
+    torch.manual_seed(12)
+    a = torch.randn((K, M) if layout == 2 else (M, K), device="cuda")
+    b = torch.randn((N, K) if layout == 0 else (K, N), device="cuda")
+    ref = (a.double().t() if layout == 2 else a.double()) @ (b.double().t() if layout == 0 else b.double())
+    first = None
+    for rep in range(12):
+        c = torch.full((M, N), float("nan"), device="cuda")
+        ok(lib, lib.astk_gemm_f32(layout, M, N, K, vp(a), a.shape[1], vp(b), b.shape[1], vp(c), N, None, 0, 1, 1, 0, 0, 0, stream()))
+        torch.cuda.synchronize()
+        if first is None:
+            first = c.clone()
+            close(c, ref, rtol=3e-5, msg=f"layout {layout} {M}x{N}x{K}")
+        else:
+            assert torch.equal(c, first), (rep, float((c - first).abs().max()))
+
+
 @pytest.mark.parametrize("layout", [0, 1, 2])
 def test_gemm_twelve_wave_256x128_kernel_on_a_big_ragged_product(lib, layout):
     """Launches of 20 GFLOP and more run 256 x 128 tiles on the 12-wave kernel (8 multiplying + 4 staging waves, round 5) under the default
