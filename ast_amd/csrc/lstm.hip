@@ -122,9 +122,13 @@ SidePlan plan_side_bwd(const astk_lstm_stack_desc* d, int rows, int lpl, bool wa
   // (as many 128-row tile rows of ONE direction's product as give at most `cap` tiles: one whole tile per workgroup, no split tiles)
   if (cs <= 0) cs = std::max(4, std::max(1, cap / ((d->in_dim + 127) / 128)) * 128 / d->B);
   cs = std::max(4, cs);
-  const int n = std::min(SIDE_CHUNKS_MAX, (d->T + cs - 1) / cs);
-  if (n < 2) return sp;
-  sp.cs = cs; sp.n = n; sp.cap = cap; sp.s0 = 0;
+  const int nall = std::min(SIDE_CHUNKS_MAX, (d->T + cs - 1) / cs);
+  if (nall < 2) return sp;
+  // "lstm.side_bwd" = how many chunks (the LAST loop steps, which the backward passes first) go to the side stream; the rest of dx follows in
+  // line, at full width, behind the recurrence.  (< 0: every chunk.)  The side stream is the caller's: what else it has queued there --
+  // the decoder's parameter gradients in the train step -- decides how many chunks finish inside the recurrence's duration.
+  const int want = (int)tune(TUNE_LSTM_SIDE_BWD);
+  sp.cs = cs; sp.n = want < 0 ? nall : std::min(want, nall); sp.cap = cap; sp.s0 = 0;
   return sp;
 }
 
@@ -466,6 +470,35 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
   const bool persist = lstm_persist_applicable(T, B, h, P.nl, P.nd);
   const bool rs_path = persist;
   SidePlan bside = {T, 0, 0, 0};
+  // dx (T,B,in) = dz_0 W_u0 of both directions for the loop steps [i0, i1) (side-stream chunks, and the rest in line).  Loop step i of
+  // direction 0 is frame i, of direction 1 frame (T - i) % T (quirk Q1).  A product STORES the frames nobody has written yet and
+  // ACCUMULATES into the others (the host keeps the book: no zero fill of dx, and the sums are the in-line schedule's).
+  std::vector<char> touched;
+  auto dx_steps = [&](int dd, int i0, int i1, hipStream_t st, const unsigned long long* amax_dz, const unsigned long long* amax_w) -> int {
+    int runs[2][2], nruns = 0;       // frames of these loop steps, as maximal runs [f0, f1)
+    if (dd == 0) { runs[0][0] = i0; runs[0][1] = i1; nruns = 1; }
+    else {
+      const int lo = std::max(i0, 1);                                    // loop steps lo .. i1-1 -> frames T-i1+1 .. T-lo
+      if (i1 > lo) { runs[nruns][0] = T - i1 + 1; runs[nruns][1] = T - lo + 1; ++nruns; }
+      if (i0 == 0) { runs[nruns][0] = 0; runs[nruns][1] = 1; ++nruns; }   // loop step 0 = frame 0
+    }
+    for (int r = 0; r < nruns; ++r) {
+      int f = runs[r][0];
+      while (f < runs[r][1]) {               // sub-runs of equal "written yet?" state
+        int g = f;
+        while (g < runs[r][1] && touched[g] == touched[f]) ++g;
+        const astk_lstm_params& p0 = prm[dd * P.nl];
+        const float* dz = P.ZG[dd][0];
+        MatView A = dd == 0 ? mat(dz + (size_t)f * B * 4 * h, 4 * h) : mat_idx(dz, 4 * h, rows_inv + (size_t)f * B);
+        if (dd == 1) A.idx_rows = (long)T * B;
+        ASTK_TRY(gemm_launch(GEMM_NN, with_amax_b(with_amax_a(gemm_args((g - f) * B, P.in, 4 * h, A, mat(p0.Wu, P.in), dx + (size_t)f * B * P.in, P.in, nullptr,
+                                                                        touched[f] ? GEMM_ACCUM : GEMM_STORE), amax_dz), amax_w), st));
+        for (int q = f; q < g; ++q) touched[q] = 1;
+        f = g;
+      }
+    }
+    return 0;
+  };
   unsigned long long* dz_amax[16] = {nullptr};
   unsigned dz_amax_gen = 0;
   if (persist) {
@@ -512,38 +545,14 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
       hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, s, prog, 3, 64);      // the two counters and the wait kernels' abort word
       ASTK_LAUNCH_CHECK();
       ASTK_TRY(stream_order(s, sside));          // everything the products read besides dz (weights, index tables) and the zeroed counters
-      std::vector<char> touched((size_t)T, 0);
+      touched.assign((size_t)T, 0);
       const AbortCtl wab = abort_ctl(prog + 2 * 64, PERSIST_ENC_BWD);
       GemmWgCap cap_scope(bside.cap);
       for (int k = 0; k < bside.n; ++k) {
         const int i1 = T - k * bside.cs, i0 = std::max(0, i1 - bside.cs);       // loop steps [i0, i1) are final when chunk k has arrived
         hipLaunchKernelGGL(k_wait_progress, dim3(1), dim3(64), 0, sside, prog, P.nd > 1 ? prog + 64 : nullptr, (unsigned)(k + 1) * wgs_cell, wab);
         ASTK_LAUNCH_CHECK();
-        for (int dd = 0; dd < P.nd; ++dd) {
-          // frames of this chunk, as maximal runs [f0, f1)
-          int runs[2][2], nruns = 0;
-          if (dd == 0) { runs[0][0] = i0; runs[0][1] = i1; nruns = 1; }
-          else {
-            const int lo = std::max(i0, 1);                                    // loop steps lo .. i1-1 -> frames T-i1+1 .. T-lo
-            if (i1 > lo) { runs[nruns][0] = T - i1 + 1; runs[nruns][1] = T - lo + 1; ++nruns; }
-            if (i0 == 0) { runs[nruns][0] = 0; runs[nruns][1] = 1; ++nruns; }   // loop step 0 = frame 0
-          }
-          for (int r = 0; r < nruns; ++r) {
-            int f = runs[r][0];
-            while (f < runs[r][1]) {               // sub-runs of equal "written yet?" state
-              int g = f;
-              while (g < runs[r][1] && touched[g] == touched[f]) ++g;
-              const astk_lstm_params& p0 = prm[dd * P.nl];
-              const float* dz = P.ZG[dd][0];
-              MatView A = dd == 0 ? mat(dz + (size_t)f * B * 4 * h, 4 * h) : mat_idx(dz, 4 * h, rows_inv + (size_t)f * B);
-              if (dd == 1) A.idx_rows = (long)T * B;
-              ASTK_TRY(gemm_launch(GEMM_NN, gemm_args((g - f) * B, P.in, 4 * h, A, mat(p0.Wu, P.in), dx + (size_t)f * B * P.in, P.in, nullptr,
-                                                      touched[f] ? GEMM_ACCUM : GEMM_STORE), sside));
-              for (int q = f; q < g; ++q) touched[q] = 1;
-              f = g;
-            }
-          }
-        }
+        for (int dd = 0; dd < P.nd; ++dd) ASTK_TRY(dx_steps(dd, i0, i1, sside, nullptr, nullptr));
       }
     }
     ASTK_TRY(stream_order(s, sr));     // the recurrence kernel may live on its own (CU-masked) stream, see astk.h
@@ -693,6 +702,11 @@ int astk_lstm_stack_bwd_on(const astk_lstm_stack_desc* d, const astk_lstm_params
         // dx (T,B,in) in frame order: direction 0 stores, direction 1 accumulates through the inverse permutation
         MatView A = dd == 0 ? mat(dz, 4 * h) : mat_idx(dz, 4 * h, rows_inv);
         ASTK_TRY(gemm_launch(GEMM_NN, with_amax_b(with_amax_a(lowp(gemm_args(rows, in, 4 * h, A, mat(p.Wu, in), dx, in, nullptr, dd == 0 ? GEMM_STORE : GEMM_ACCUM)), adz), aw0[dd]), s));
+      } else if (dx) {
+        // the loop steps the side stream did not take, at full width; the side chunks were sized to be done by now, and their frames are in `touched`
+        if (dd == 0) ASTK_TRY(stream_order((hipStream_t)d->side_stream, s));
+        const int i1 = T - bside.n * bside.cs;
+        if (i1 > 0) ASTK_TRY(dx_steps(dd, 0, i1, s, adz, aw0[dd]));
       }
     }
   }

@@ -72,41 +72,49 @@ AbortCtl abort_ctl(unsigned* word, unsigned bit) {
   return ab;
 }
 // ---- tuning knobs (astk_set_tuning): name, default
-struct TuneEntry { const char* name; double def; };
-static const TuneEntry g_tune_table[TUNE_COUNT] = {
-    {"gemm.tile", 0},              // force the block tile: 64 | 128 | 256 (0 = chosen per launch)
-    {"gemm.t256_above", 2e10},     // launches of at least this many flops take the 12-wave 256 x 128 kernel
-    {"gemm.grid", -1},             // force the stream-K grid (workgroups; <= 0 = chosen per launch)
-    {"gemm.hybrid", 1},            // data-parallel waves of whole tiles in XCD-local blocks + stream-K remainder (0: all stream-K, rounds 1-4)
-    {"gemm.chunk", 1},             // few tiles / deep K accumulating launches run chunk-major
-    {"gemm.chunk_div", 4},         // ... when tiles * chunk_div <= grid
-    {"gemm.log", 0},               // print every launch's shape and schedule to stderr
-    {"gemm.ticket", 1},            // libastk_test.so only: split tiles handed over by tickets instead of a zeroing launch
-    {"gemm.deterministic", 0},     // process default of the descriptors' `deterministic` field (fixed-order split-tile sums, astk.h)
-    {"gemm.forward_pairs", 1},     // forward launches outside the hybrid branch: grid shrunk until a split tile has <= 2 contributors (2: the forward rule for EVERY launch)
-    {"conv.direct0", 1},           // layer 0 as a direct convolution (0: im2col + GEMM)
-    {"conv.seq_fwd", 1},           // BatchNorm + ReLU written straight into the LSTM's (T'',B,C*F') layout by the tiled kernel
-    {"conv.seq_bwd", 1},           // the last layer's BatchNorm backward reads that layout itself
-    {"conv.seq_stats_blocks", 1024},
-    {"conv.seq_apply_blocks", 1024},
-    {"dec.persist", 1},            // persistent decoder loops (0: the per-launch loop)
-    {"dec.b6_split", 1},           // K-half items of the d_x0 role (one-layer kernel)
-    {"dec.b6_fused", 1},           // ... with the d_pre role fused into them
-    {"dec.wide", 1},               // decoder_wide.hip's persistent loops at H = A = 1024
-    {"lstm.persist", 1},           // persistent encoder recurrences (0: one fused-cell launch per step)
-    {"lstm.hoist", 1},             // hoisted form of the persistent kernels at h = 1024
-    {"lstm.x3", 1},                // bf16x3 fragments inside the recurrences (0: f32-input MFMAs under the bf16x3 arithmetic)
-    {"lstm.x4", 1},                // ... with the weights' lo plane in LDS at h = 512 / 1024
-    {"lstm.rows32", -1},           // 32 batch rows per recurrence workgroup: 1 always, 0 never, -1 = when it spares launches
-    {"lstm.overlap_chunk", 0},     // time steps per chunk of the layer-0 products that run beside the recurrences (side_stream); 0 = from the free CUs
-    {"lstm.side_fwd", 1},          // side_stream: the layer-0 input projection in chunks beside the forward recurrence
-    {"lstm.duo_side", 0},          // side_stream + batch <= 32: take the two-waves-per-SIMD form (96 workgroups, 160 CUs free) instead of 192 workgroups of 16 rows
-    {"lstm.side_bwd", 0},          // side_stream: the input gradient in chunks behind the backward recurrence's progress (off: with 64 free CUs the
-                                   // decoder's parameter gradients already fill them; measured slower at 160, profiles/r6_ab_side.txt)
-    {"row.longk", 2048},           // row-panel kernels split K over eight waves from this K on (0 = never)
-    {"persist.spin_limit", 0},     // bound of the persistent kernels' spins in polls (0 = the default, 2^22)
-    {"colreduce.blocks", 256},     // blocks of a column reduction
+struct TuneEntry { TuneKey key; const char* name; double def; };
+static constexpr TuneEntry g_tune_table[TUNE_COUNT] = {
+    {TUNE_GEMM_TILE, "gemm.tile", 0},              // force the block tile: 64 | 128 | 256 (0 = chosen per launch)
+    {TUNE_GEMM_T256_ABOVE, "gemm.t256_above", 2e10},     // launches of at least this many flops take the 12-wave 256 x 128 kernel
+    {TUNE_GEMM_GRID, "gemm.grid", -1},             // force the stream-K grid (workgroups; <= 0 = chosen per launch)
+    {TUNE_GEMM_HYBRID, "gemm.hybrid", 1},            // data-parallel waves of whole tiles in XCD-local blocks + stream-K remainder (0: all stream-K, rounds 1-4)
+    {TUNE_GEMM_CHUNK, "gemm.chunk", 1},             // few tiles / deep K accumulating launches run chunk-major
+    {TUNE_GEMM_CHUNK_DIV, "gemm.chunk_div", 4},         // ... when tiles * chunk_div <= grid
+    {TUNE_GEMM_LOG, "gemm.log", 0},               // print every launch's shape and schedule to stderr
+    {TUNE_GEMM_TICKET, "gemm.ticket", 1},            // libastk_test.so only: split tiles handed over by tickets instead of a zeroing launch
+    {TUNE_GEMM_DETERMINISTIC, "gemm.deterministic", 0},     // process default of the descriptors' `deterministic` field (fixed-order split-tile sums, astk.h)
+    {TUNE_GEMM_FORWARD_PAIRS, "gemm.forward_pairs", 1},     // forward launches outside the hybrid branch: grid shrunk until a split tile has <= 2 contributors (2: the forward rule for EVERY launch)
+    {TUNE_CONV_DIRECT0, "conv.direct0", 1},           // layer 0 as a direct convolution (0: im2col + GEMM)
+    {TUNE_CONV_SEQ_FWD, "conv.seq_fwd", 1},           // BatchNorm + ReLU written straight into the LSTM's (T'',B,C*F') layout by the tiled kernel
+    {TUNE_CONV_SEQ_BWD, "conv.seq_bwd", 1},           // the last layer's BatchNorm backward reads that layout itself
+    {TUNE_CONV_SEQ_STATS_BLOCKS, "conv.seq_stats_blocks", 1024},
+    {TUNE_CONV_SEQ_APPLY_BLOCKS, "conv.seq_apply_blocks", 1024},
+    {TUNE_DEC_PERSIST, "dec.persist", 1},            // persistent decoder loops (0: the per-launch loop)
+    {TUNE_DEC_B6_SPLIT, "dec.b6_split", 1},           // K-half items of the d_x0 role (one-layer kernel)
+    {TUNE_DEC_B6_FUSED, "dec.b6_fused", 1},           // ... with the d_pre role fused into them
+    {TUNE_DEC_WIDE, "dec.wide", 1},               // decoder_wide.hip's persistent loops at H = A = 1024
+    {TUNE_LSTM_PERSIST, "lstm.persist", 1},           // persistent encoder recurrences (0: one fused-cell launch per step)
+    {TUNE_LSTM_HOIST, "lstm.hoist", 1},             // hoisted form of the persistent kernels at h = 1024
+    {TUNE_LSTM_X3, "lstm.x3", 1},                // bf16x3 fragments inside the recurrences (0: f32-input MFMAs under the bf16x3 arithmetic)
+    {TUNE_LSTM_X4, "lstm.x4", 1},                // ... with the weights' lo plane in LDS at h = 512 / 1024
+    {TUNE_LSTM_ROWS32, "lstm.rows32", -1},           // 32 batch rows per recurrence workgroup: 1 always, 0 never, -1 = when it spares launches
+    {TUNE_LSTM_OVERLAP_CHUNK, "lstm.overlap_chunk", 0},     // time steps per chunk of the layer-0 products that run beside the recurrences (side_stream); 0 = from the free CUs
+    {TUNE_LSTM_SIDE_FWD, "lstm.side_fwd", 1},          // side_stream: the layer-0 input projection in chunks beside the forward recurrence
+    {TUNE_LSTM_SIDE_BWD, "lstm.side_bwd", 0},          // side_stream: this many chunks of the input gradient behind the backward recurrence's progress counter, the
+                                   // rest in line (< 0: every chunk).  Off: measured slower at any count, profiles/r6_ab_side_bwd.txt
+    {TUNE_LSTM_DUO_SIDE, "lstm.duo_side", 0},          // side_stream + batch <= 32: take the two-waves-per-SIMD form (96 workgroups, 160 CUs free) instead of 192 workgroups of 16 rows
+    {TUNE_ROW_LONGK, "row.longk", 2048},           // row-panel kernels split K over eight waves from this K on (0 = never)
+    {TUNE_PERSIST_SPIN_LIMIT, "persist.spin_limit", 0},     // bound of the persistent kernels' spins in polls (0 = the default, 2^22)
+    {TUNE_COLREDUCE_BLOCKS, "colreduce.blocks", 256},     // blocks of a column reduction
 };
+// (the table is indexed by TuneKey: a row out of place would make one knob's NAME set another knob's value -- round 6 shipped
+//  "lstm.side_bwd" and "lstm.duo_side" swapped for a while, found when an A/B of the first showed the second's effect)
+constexpr bool tune_table_in_order() {
+  for (int i = 0; i < TUNE_COUNT; ++i)
+    if (g_tune_table[i].key != i) return false;
+  return true;
+}
+static_assert(tune_table_in_order(), "g_tune_table rows must follow enum TuneKey");
 static std::atomic<double> g_tune[TUNE_COUNT];
 static std::atomic<int> g_tune_init{0};
 static void tune_init() {

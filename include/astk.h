@@ -97,7 +97,7 @@ int astk_get_gemm_precision(void);
  *   lstm.persist (1: 0 = one fused-cell launch per step)   lstm.hoist (1)   lstm.x3 (1)   lstm.x4 (1)
  *   lstm.rows32 (-1 = 32 batch rows per recurrence workgroup when that spares launches; 0 never; 1 = one wave set doing two tiles, 2 = two
  *   wave sets per SIMD, whenever possible)   lstm.duo_side (0)
- *   lstm.overlap_chunk (0 = sized from the free CUs; else time steps per side-stream chunk)   lstm.side_fwd (1)   lstm.side_bwd (0)
+ *   lstm.overlap_chunk (0 = sized from the free CUs; else time steps per side-stream chunk)   lstm.side_fwd (1)   lstm.side_bwd (0 = off; n = chunks of the input gradient on side_stream behind the backward recurrence, the rest in line; < 0 every chunk)
  *   row.longk (2048)   persist.spin_limit (0 = 2^22 polls)   colreduce.blocks (256)
  * astk_set_tuning returns 0, or -1 for an unknown key; astk_tuning_key(i) enumerates the keys (NULL behind the last). */
 int astk_set_tuning(const char* key, double value);

@@ -352,7 +352,7 @@ def test_lstm_stack_32_row_workgroups_and_side_stream(lib, tune, T, B, in_dim, h
     tune("lstm.rows32", form, lib)
     if side:
         tune("lstm.overlap_chunk", 4, lib)
-        tune("lstm.side_bwd", 1, lib)          # (off by default: measured slower on the train step; the mechanism stays tested)
+        tune("lstm.side_bwd", -1 if T % 2 else 2, lib)      # every chunk on the side stream / two chunks there and the rest of dx in line behind the recurrence
     _lstm_stack_case(lib, T, B, in_dim, h, nl, masks, side=side)
 
 
