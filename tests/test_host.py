@@ -68,6 +68,23 @@ def test_library_exports_every_declared_symbol():
         assert lib.astk_get_tuning(k.encode(), C.byref(v)) == 0
         assert _lib.set_tuning(k, v.value) == v.value
     assert lib.astk_set_tuning(b"no.such.knob", 1.0) != 0 and b"no.such.knob" in lib.astk_last_error()
+    # ... every knob is DOCUMENTED in the header, and setting one moves no other (the table's rows carry their key: util.hip's static_assert
+    # keeps a name from landing on another knob's slot, which no outside test can see -- set and get would agree on the wrong slot)
+    hdr = open(os.path.join(ROOT, "include", "astk.h")).read()
+    assert not [k for k in keys if k not in hdr], [k for k in keys if k not in hdr]
+    def read_all():
+        out = {}
+        for q in keys:
+            v = C.c_double()
+            assert lib.astk_get_tuning(q.encode(), C.byref(v)) == 0
+            out[q] = v.value
+        return out
+    before = read_all()
+    for k in ("lstm.side_bwd", "lstm.duo_side", "gemm.forward_pairs"):
+        prev = _lib.set_tuning(k, 7.0)
+        assert read_all() == {**before, k: 7.0}, k
+        _lib.set_tuning(k, prev)
+    assert read_all() == before
 
 
 def test_parameter_counts_match_the_reference_model():
